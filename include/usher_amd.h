@@ -1,0 +1,186 @@
+/*
+ * usher_amd.h -- C ABI of the MI355X placement engine (libusher_amd.so).
+ *
+ * Drop-in boundary for UShER's parsimony-placement hot path.  The reference
+ * has no FFI layer: the seam is the C++ call
+ *     void mapper2_body(mapper2_input&, bool, bool)      src/usher_graph.hpp:103
+ * made N times per sample from three tbb::parallel_for blocks in
+ * usher_common()                                         src/usher_common.cpp:252-273, 389-414, 426-449
+ * (4 more call sites in matUtils / ripples).  This library replaces the whole
+ * per-sample block (usher_common.cpp:342-449) for a BATCH of samples against a
+ * static tree: the caller hands over the tree once (ugp_mat_create), then any
+ * number of query batches (ugp_place_batch & friends).  Plain pointers and
+ * sizes only; no C++ or torch types cross the boundary; nothing is thrown and
+ * the process is never exited (the reference's loaders call exit(1),
+ * mutation_annotated_tree.cpp:473-475, 894-896, 2142-2145).
+ *
+ * Node numbering.  Every node index in this API is the node's position in the
+ * reference's breadth-first expansion (Tree::breadth_first_expansion,
+ * mutation_annotated_tree.cpp:1225-1251) -- the `j` of usher_common.cpp:391-403
+ * and mapper2_input::j (usher_graph.hpp:82).  Tie-breaking among equally
+ * parsimonious nodes (usher_mapper.cpp:483-486) is by larger number of
+ * descendant leaves, then larger j, exactly as the reference.
+ *
+ * Alleles are the reference's one-hot codes A=1 C=2 G=4 T=8, ambiguity codes
+ * are unions, N = 15 (mutation_annotated_tree.cpp:19-74).
+ */
+#ifndef USHER_AMD_H
+#define USHER_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define UGP_OK               0
+#define UGP_ERR_INVALID     -1   /* bad argument / malformed tree or query arrays            */
+#define UGP_ERR_UNSUPPORTED -2   /* input violates a precondition of the device algorithm    */
+#define UGP_ERR_HIP         -3   /* a HIP runtime call failed (no device, out of memory ...)  */
+#define UGP_ERR_NOMEM       -4   /* host allocation failed                                    */
+
+/* Opaque handle: the flattened mutation-annotated tree resident in the HBM of
+ * one device (replaces MAT::Tree* + the BFS vector of usher_common.cpp:342). */
+typedef struct ugp_mat ugp_mat;
+/* Opaque handle: a validated query batch resident in HBM. */
+typedef struct ugp_qset ugp_qset;
+
+/*
+ * The tree, as flat arrays in BFS order (replaces MAT::Node / MAT::Mutation,
+ * mutation_annotated_tree.hpp:45-111).  Children of a node are the nodes that
+ * name it as parent, in increasing index (= the reference's child order).
+ */
+typedef struct ugp_tree_desc {
+    uint64_t n_nodes;
+    const uint32_t *parent;   /* [n_nodes]   parent[0] = UINT32_MAX, parent[j] < j            */
+    const uint64_t *mut_off;  /* [n_nodes+1] CSR offsets into the mutation arrays             */
+    const int32_t *mut_pos;   /* [n_muts]    1-based position; < 0 = masked (hpp:76-78)       */
+    const uint8_t *mut_ref;   /* [n_muts]    one-hot reference base (ignored when masked)     */
+    const uint8_t *mut_par;   /* [n_muts]    parent allele as stored in the MAT (informational:
+                                             the library derives the true parent state itself,
+                                             like usher_mapper.cpp:275-286 does)              */
+    const uint8_t *mut_nuc;   /* [n_muts]    one-hot mutated base                             */
+} ugp_tree_desc;
+
+/*
+ * A batch of query samples: per sample the rows read_vcf() would have put in
+ * Missing_Sample::mutations (mutation_annotated_tree.cpp:2234-2270,
+ * usher_graph.hpp:33-53).  Rows of one sample must be sorted by position with
+ * no duplicates (UGP_ERR_UNSUPPORTED otherwise).
+ */
+typedef struct ugp_queries {
+    uint64_t n_queries;
+    const uint64_t *ent_off;     /* [n_queries+1] CSR offsets                                  */
+    const int32_t *pos;          /* [n_ent] position                                           */
+    const uint8_t *ref;          /* [n_ent] one-hot VCF REF base                               */
+    const uint8_t *nuc;          /* [n_ent] allele mask of the sample at pos (15 when missing) */
+    const uint8_t *is_missing;   /* [n_ent] 1 for N / '.' cells (mutation.is_missing)          */
+} ugp_queries;
+
+/* Per-sample placement summary: the values usher_common.cpp:451-453 prints and
+ * uses -- *best_set_difference, *num_best, *best_j, *has_unique of
+ * mapper2_input (usher_graph.hpp:79-92). */
+typedef struct ugp_result {
+    int32_t best_set_difference;   /* parsimony score of the best placement            */
+    uint32_t num_best;             /* number of equally parsimonious placements        */
+    uint32_t best_j;               /* BFS index of the chosen node                     */
+    uint32_t best_has_unique;      /* 1: place as sibling even if the node is internal */
+} ugp_result;
+
+typedef struct ugp_info {
+    uint64_t n_nodes;
+    uint64_t n_muts;            /* non-masked mutations                                        */
+    uint64_t n_sites;           /* distinct mutated positions (rows of an allele tile)         */
+    uint64_t stream_bytes;      /* device bytes of the DFS record stream read per tree pass    */
+    uint64_t algo_tree_bytes;   /* 4*M + 8*N                                      */
+    uint64_t algo_tile_bytes;   /* per sample, L/2 + 16                           */
+    uint32_t n_chunks;
+    uint32_t max_slots;         /* depth of the per-lane D stack the tree needs                */
+    uint32_t max_position;
+    uint32_t device;
+} ugp_info;
+
+typedef struct ugp_timing {
+    float table_ms;      /* allele-tile build kernels of the last call          */
+    float place_ms;      /* the dominant kernel (ugp_place_kernel) of the last call */
+    float merge_ms;      /* partial-result merge of the last call               */
+    uint32_t place_launches;
+    uint32_t n_tiles;    /* 64-sample tiles in the last call                    */
+    uint32_t n_groups;   /* waves per tile in the last call                     */
+} ugp_timing;
+
+/* Flatten + upload.  device = HIP device ordinal.  Replaces the per-sample
+ * BFS rebuild and 2N vector allocations of usher_common.cpp:342-365. */
+int ugp_mat_create(const ugp_tree_desc *tree, int device, ugp_mat **out);
+void ugp_mat_destroy(ugp_mat *mat);
+int ugp_mat_info(const ugp_mat *mat, ugp_info *out);
+
+/*
+ * Score every node of the tree for every query sample and reduce to the best
+ * placement: passes 1 and 2 of usher_common.cpp:389-449 for each sample (static
+ * tree: the -n / -p semantics).  Host buffers in, host buffer out, synchronous.
+ */
+int ugp_place_batch(ugp_mat *mat, const ugp_queries *q, ugp_result *out /* [n_queries] */);
+
+/*
+ * -p / --write-parsimony-scores-per-node (usher_common.cpp:406-412, 557-578):
+ * out[q * n_nodes + j] = set_difference of placing sample q at BFS node j, +1
+ * when the node is not an eligible placement (usher_mapper.cpp:498-502).
+ */
+int ugp_scores_per_node(ugp_mat *mat, const ugp_queries *q, int32_t *out /* [n_queries * n_nodes] */);
+
+/*
+ * best_j_vec / node_has_unique (usher_graph.hpp:89-90): all equally
+ * parsimonious nodes of each sample, ascending BFS index (the order
+ * usher_common.cpp:588 sorts them into), at most `cap` per sample;
+ * tie_count[q] receives the true count.
+ */
+int ugp_tied_nodes(ugp_mat *mat, const ugp_queries *q, uint32_t cap,
+                   uint32_t *tie_j /* [n_queries * cap] */,
+                   uint8_t *tie_has_unique /* [n_queries * cap] */,
+                   uint32_t *tie_count /* [n_queries] */);
+
+/* Device-resident variant (no PCIe in the timed path): upload once, place many
+ * times.  `stream` is a hipStream_t (NULL = the default stream); d_out is a
+ * device pointer to n_queries ugp_result records.  Asynchronous on `stream`. */
+int ugp_qset_upload(ugp_mat *mat, const ugp_queries *q, ugp_qset **out);
+void ugp_qset_destroy(ugp_qset *qs);
+uint64_t ugp_qset_size(const ugp_qset *qs);
+int ugp_place_device(ugp_mat *mat, ugp_qset *qs, void *d_out, void *stream);
+
+/* Per-kernel durations of the last ugp_place_* call on this handle, measured
+ * with HIP events on the stream the kernels ran on (synchronises that stream). */
+int ugp_get_timing(ugp_mat *mat, ugp_timing *out);
+
+/* Message for the last non-zero return on the calling thread. */
+const char *ugp_last_error(void);
+
+/* ---- test / tuning hooks (not part of the drop-in surface) ---------------- */
+
+/* ugp_mat_create with an explicit chunk size (nodes per DFS chunk), so small
+ * fixtures exercise multi-chunk launches. */
+int ugp_mat_create_chunked(const ugp_tree_desc *tree, int device, uint32_t chunk_nodes, ugp_mat **out);
+
+/* Host-only view of the flattened tree (works without a GPU): the DFS record
+ * stream and tables that ugp_mat_create uploads. */
+typedef struct ugp_flat ugp_flat;
+enum {
+    UGP_FLAT_STREAM = 0,        /* uint32 */
+    UGP_FLAT_PRE_STREAM = 1,    /* uint32 */
+    UGP_FLAT_CHUNK_BODY_OFF = 2,/* uint32 [n_chunks+1] */
+    UGP_FLAT_CHUNK_PRE_OFF = 3, /* uint32 [n_chunks+1] */
+    UGP_FLAT_CHUNK_NODE_OFF = 4,/* uint32 [n_chunks+1] */
+    UGP_FLAT_POS2SITE = 5,      /* int32  [max_pos+1] */
+    UGP_FLAT_SITE_REF = 6,      /* uint8  [n_sites] */
+    UGP_FLAT_RANK2BFS = 7,      /* uint32 [n_nodes] */
+    UGP_FLAT_DFS2BFS = 8,       /* uint32 [n_nodes] */
+    UGP_FLAT_MAX_SLOTS = 9      /* count only */
+};
+int ugp_flat_create(const ugp_tree_desc *tree, uint32_t chunk_nodes, ugp_flat **out);
+void ugp_flat_destroy(ugp_flat *flat);
+int ugp_flat_get(const ugp_flat *flat, int which, const void **ptr, uint64_t *count);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* USHER_AMD_H */

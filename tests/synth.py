@@ -1,0 +1,121 @@
+"""Small seeded random trees / queries for parity tests (test helper).
+
+Trees are emitted directly as the BFS-order flat arrays the oracle and the
+C-ABI take.  The generator deliberately produces the awkward cases: internal
+nodes and leaves without mutations, root mutations, back-mutations and repeated
+positions along a path, masked mutations (position < 0), queries with N cells,
+IUPAC codes (with and without the reference base), rows at positions the tree
+never mutates and rows equal to the reference base.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+ONEHOT = [1, 2, 4, 8]
+
+
+def random_tree(rng: np.random.Generator, n_leaves: int, genome_len: int = 2000, n_sites: int = 120,
+                mut_counts=(0, 0, 1, 1, 1, 2, 3), p_masked: float = 0.0, root_muts: int = 0):
+    ref = rng.choice(ONEHOT, size=genome_len + 1)
+    sites = np.sort(rng.choice(np.arange(1, genome_len + 1), size=min(n_sites, genome_len), replace=False))
+    # random attachment: a leaf gets 2-3 children, an internal node one more
+    children = {0: []}
+    nid = 1
+    n_leaf = 1
+    while n_leaf < n_leaves:
+        v = int(rng.integers(0, nid))
+        k = int(rng.choice([2, 2, 3])) if not children[v] else 1
+        if not children[v]:
+            n_leaf -= 1
+        for _ in range(k):
+            children[v].append(nid)
+            children[nid] = []
+            nid += 1
+            n_leaf += 1
+    # BFS renumbering
+    order = [0]
+    head = 0
+    while head < len(order):
+        order.extend(children[order[head]])
+        head += 1
+    new = {old: j for j, old in enumerate(order)}
+    n = len(order)
+    parent = np.full(n, -1, dtype=np.int64)
+    for old in order:
+        for c in children[old]:
+            parent[new[c]] = new[old]
+    # mutations by walking parents-first with the true state
+    state = [None] * n
+    mut_off = np.zeros(n + 1, dtype=np.int64)
+    pos, rf, par, nuc = [], [], [], []
+    for j in range(n):
+        st = {} if parent[j] < 0 else dict(state[parent[j]])
+        k = root_muts if parent[j] < 0 else int(rng.choice(mut_counts))
+        chosen = np.sort(rng.choice(sites, size=min(k, len(sites)), replace=False)) if k else []
+        muts = []
+        if parent[j] >= 0 and rng.random() < p_masked:
+            muts.append((-1, 0, 0, 0))
+        for p in chosen:
+            p = int(p)
+            cur = st.get(p, int(ref[p]))
+            new_allele = int(rng.choice([a for a in ONEHOT if a != cur]))
+            muts.append((p, int(ref[p]), cur, new_allele))
+            st[p] = new_allele
+        state[j] = st
+        for (p, r, pa, m) in muts:
+            pos.append(p); rf.append(r); par.append(pa); nuc.append(m)
+        mut_off[j + 1] = len(pos)
+    arrays = {
+        "n": n, "parent": parent, "mut_off": mut_off,
+        "mut_pos": np.asarray(pos, dtype=np.int32), "mut_ref": np.asarray(rf, dtype=np.int8),
+        "mut_par": np.asarray(par, dtype=np.int8), "mut_nuc": np.asarray(nuc, dtype=np.int8),
+        "names": ["n%d" % j for j in range(n)],
+    }
+    return arrays, ref, sites, state
+
+
+def random_query(rng: np.random.Generator, arrays, ref, sites, state, genome_len: int,
+                 n_subst=(0, 1, 2, 3), n_ambig=(0, 0, 2, 5, 30), name="Q"):
+    n = arrays["n"]
+    src = int(rng.integers(0, n))
+    geno = {p: a for p, a in state[src].items() if a != int(ref[p])}
+    for _ in range(int(rng.choice(n_subst))):
+        p = int(rng.integers(1, genome_len + 1)) if rng.random() < 0.3 else int(rng.choice(sites))
+        cur = geno.get(p, int(ref[p]))
+        a = int(rng.choice([x for x in ONEHOT if x != cur]))
+        if a == int(ref[p]):
+            geno.pop(p, None)
+        else:
+            geno[p] = a
+    rows = {p: (a, 0) for p, a in geno.items()}
+    for _ in range(int(rng.choice(n_ambig))):
+        p = int(rng.choice(sites)) if rng.random() < 0.8 else int(rng.integers(1, genome_len + 1))
+        kind = rng.random()
+        if kind < 0.4:
+            rows[p] = (15, 1)                       # N / '.'
+        elif kind < 0.95:
+            mask = int(rng.integers(1, 15))
+            if mask & (mask - 1) == 0:
+                mask |= int(rng.choice(ONEHOT))
+            if mask == 15:
+                rows[p] = (15, 1)
+            else:
+                rows[p] = (mask, 0)
+        else:
+            rows[p] = (int(ref[p]), 0)              # explicit row equal to the reference base
+    ps = sorted(rows)
+    return {
+        "name": name,
+        "pos": np.asarray(ps, dtype=np.int32),
+        "ref": np.asarray([int(ref[p]) for p in ps], dtype=np.int8),
+        "nuc": np.asarray([rows[p][0] for p in ps], dtype=np.int8),
+        "is_missing": np.asarray([rows[p][1] for p in ps], dtype=np.int8),
+    }
+
+
+def make_case(seed: int, n_leaves: int, n_queries: int, genome_len: int = 2000, n_sites: int = 120, **kw):
+    rng = np.random.default_rng(seed)
+    qkw = {k: kw.pop(k) for k in ("n_subst", "n_ambig") if k in kw}
+    arrays, ref, sites, state = random_tree(rng, n_leaves, genome_len, n_sites, **kw)
+    queries = [random_query(rng, arrays, ref, sites, state, genome_len, name="Q%d" % i, **qkw) for i in range(n_queries)]
+    return arrays, queries

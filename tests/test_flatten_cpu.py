@@ -1,0 +1,94 @@
+"""CPU checks of the product's host flattening (libusher_amd.so, no GPU): the
+DFS record stream interpreted by tests/stream_interp.py must reproduce the
+oracle for every chunking / grouping, and the C-ABI must export every symbol
+include/usher_amd.h declares."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+from oracle import capi, refio
+from tests import stream_interp, synth
+from usher_amd import FlatTreeView, _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def test_capi_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "usher_amd.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(ugp_[a-z_0-9]+)\s*\(", hdr))
+    assert declared, "no declarations parsed"
+    L = _lib.lib()
+    for name in sorted(declared):
+        assert hasattr(L, name), "libusher_amd.so does not export %s" % name
+    assert declared == set(_lib.SYMBOLS), (declared ^ set(_lib.SYMBOLS))
+
+
+def _check(arrays, samples, chunk_nodes, n_groups, scores=True):
+    flat = FlatTreeView(arrays, chunk_nodes=chunk_nodes)
+    ot = capi.OracleTree(arrays)
+    for s in samples:
+        want = ot.place(s, compute_scores=scores)
+        got = stream_interp.place(flat, s, n_groups=n_groups, want_scores=scores)
+        for k in ("best", "num_best", "best_j", "has_unique"):
+            assert got[k] == want[k], (s["name"], k, got[k], want[k])
+        if scores:
+            assert got["scores"].tolist() == want["scores"].tolist()
+    return flat
+
+
+@pytest.mark.parametrize("chunk_nodes,n_groups", [(0, 1), (16, 1), (16, 7), (5, 1000), (64, 3)])
+def test_stream_matches_oracle_on_global_fixture(chunk_nodes, n_groups):
+    T = refio.load_mutation_annotated_tree(os.path.join(GOLD, "survey_ref", "global", "global_assignments.pb"))
+    samples = [refio.sample_to_arrays(s) for s in refio.read_vcf(T, os.path.join(GOLD, "ref_fixtures", "new_samples.vcf"))]
+    flat = _check(refio.tree_to_bfs_arrays(T), samples, chunk_nodes, n_groups)
+    assert len(flat.dfs2bfs) == 474 and sorted(flat.dfs2bfs.tolist()) == list(range(474))
+
+
+@pytest.mark.parametrize("seed", [21, 22, 23, 24])
+def test_stream_matches_oracle_random(seed):
+    arrays, queries = synth.make_case(seed, n_leaves=150, n_queries=10, n_sites=60, p_masked=0.05 if seed % 2 else 0.0,
+                                      root_muts=seed % 3)
+    _check(arrays, queries, chunk_nodes=11, n_groups=9)
+    _check(arrays, queries, chunk_nodes=0, n_groups=1, scores=False)
+
+
+def test_stream_on_syn_fixture():
+    T = refio.load_mutation_annotated_tree(os.path.join(GOLD, "survey_ref", "syn", "tree.pb"))
+    samples = [refio.sample_to_arrays(s) for s in refio.read_vcf(T, os.path.join(GOLD, "survey_ref", "syn", "query.vcf"))]
+    _check(refio.tree_to_bfs_arrays(T), samples[:8], chunk_nodes=100, n_groups=5)
+
+
+def test_slot_depth_is_logarithmic():
+    # a caterpillar (every internal node has one leaf child and one internal child) is the
+    # worst case for a per-level stack; largest-child-last keeps the slot count tiny
+    n_int = 300
+    parent = [-1]
+    for i in range(n_int):
+        # BFS order: node 2i+1 = leaf child, 2i+2 = internal child of node (2(i-1)+2 or 0)
+        par = 0 if i == 0 else 2 * (i - 1) + 2
+        parent += [par, par]
+    n = len(parent)
+    arrays = {"n": n, "parent": np.array(parent), "mut_off": np.zeros(n + 1, np.int64), "mut_pos": np.zeros(0, np.int32),
+              "mut_ref": np.zeros(0, np.int8), "mut_par": np.zeros(0, np.int8), "mut_nuc": np.zeros(0, np.int8)}
+    flat = FlatTreeView(arrays)
+    assert flat.max_slots <= 2
+    rng = np.random.default_rng(5)
+    arrays2, _ = synth.make_case(3, n_leaves=2000, n_queries=0)
+    assert FlatTreeView(arrays2).max_slots <= int(np.log2(arrays2["n"])) + 2
+
+
+def test_flatten_rejects_bad_trees():
+    from usher_amd import UgpError
+    base = {"n": 2, "parent": np.array([-1, 0]), "mut_off": np.array([0, 0, 1]), "mut_pos": np.array([7], np.int32),
+            "mut_ref": np.array([1], np.int8), "mut_par": np.array([1], np.int8), "mut_nuc": np.array([3], np.int8)}
+    with pytest.raises(UgpError) as e:
+        FlatTreeView(base)            # ambiguous tree allele
+    assert e.value.code == -2
+    bad = dict(base, mut_nuc=np.array([2], np.int8), parent=np.array([-1, 1]))
+    with pytest.raises(UgpError) as e:
+        FlatTreeView(bad)             # parent[j] >= j
+    assert e.value.code == -1

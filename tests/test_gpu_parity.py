@@ -1,0 +1,155 @@
+"""GPU parity tests proper: the HIP path, called through the C ABI
+(libusher_amd.so), against the oracle on the recorded reference fixtures and on
+seeded random trees.  Bit-exact: placement node, score, tie count, sibling flag,
+per-node scores and tie sets."""
+import gzip
+import os
+import tempfile
+
+import numpy as np
+import pytest
+
+from oracle import capi, refio
+from tests import synth
+from usher_amd import Placer, QueryBatch, UgpError
+
+pytestmark = pytest.mark.gpu
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+SURVEY = os.path.join(GOLD, "survey_ref")
+
+
+def _load(pb, vcf):
+    T = refio.load_mutation_annotated_tree(pb)
+    arrays = refio.tree_to_bfs_arrays(T)
+    samples = [refio.sample_to_arrays(s) for s in refio.read_vcf(T, vcf)]
+    return arrays, samples
+
+
+def _read_stats(path):
+    rows = []
+    with open(path) as f:
+        for line in f:
+            w = line.rstrip("\n").split("\t")
+            if len(w) >= 3:
+                rows.append((w[0], int(w[1]), int(w[2])))
+    return rows
+
+
+def _assert_same(res, i, want, name=""):
+    got = (int(res["best_set_difference"][i]), int(res["num_best"][i]), int(res["best_j"][i]), bool(res["best_has_unique"][i]))
+    exp = (want["best"], want["num_best"], want["best_j"], want["has_unique"])
+    assert got == exp, (name, got, exp)
+
+
+@pytest.mark.parametrize("chunk_nodes", [None, 16, 3])
+def test_global_fixture_matches_reference_and_oracle(chunk_nodes):
+    arrays, samples = _load(os.path.join(SURVEY, "global", "global_assignments.pb"), os.path.join(GOLD, "ref_fixtures", "new_samples.vcf"))
+    pl = Placer(arrays, chunk_nodes=chunk_nodes)
+    res = pl.place(QueryBatch(samples))
+    want = _read_stats(os.path.join(SURVEY, "global", "out3", "placement_stats.tsv"))
+    assert [(int(r["best_set_difference"]), int(r["num_best"])) for r in res] == [(w[1], w[2]) for w in want]
+    ot = capi.OracleTree(arrays)
+    for i, s in enumerate(samples):
+        _assert_same(res, i, ot.place(s), s["name"])
+    pl.close()
+
+
+def test_global_fixture_per_node_scores_match_reference():
+    arrays, samples = _load(os.path.join(SURVEY, "global", "global_assignments.pb"), os.path.join(GOLD, "ref_fixtures", "new_samples.vcf"))
+    pl = Placer(arrays, chunk_nodes=32)
+    got = pl.scores_per_node(QueryBatch(samples))
+    rows = {}
+    with gzip.open(os.path.join(SURVEY, "global", "out4", "parsimony-scores.tsv.gz"), "rt") as f:
+        next(f)
+        for line in f:
+            w = line.split("\t")
+            rows.setdefault(w[0], []).append(int(w[2]))
+    for i, s in enumerate(samples):
+        assert got[i].tolist() == rows[s["name"]]
+    ties, ties_hu, tc = pl.tied_nodes(QueryBatch(samples), cap=8)
+    for i in range(len(samples)):
+        assert [arrays["names"][j] for j in ties[i]] == ["node_7", "node_11"]
+    pl.close()
+
+
+def test_syn_fixture_scores_ties_and_stats():
+    arrays, samples = _load(os.path.join(SURVEY, "syn", "tree.pb"), os.path.join(SURVEY, "syn", "query.vcf"))
+    pl = Placer(arrays, chunk_nodes=64)
+    batch = QueryBatch(samples)
+    res = pl.place(batch)
+    want = _read_stats(os.path.join(SURVEY, "syn", "o3", "placement_stats.tsv"))
+    assert [(s["name"], int(r["best_set_difference"]), int(r["num_best"])) for s, r in zip(samples, res)] == want
+    ot = capi.OracleTree(arrays)
+    scores = pl.scores_per_node(batch)
+    ties, ties_hu, tc = pl.tied_nodes(batch, cap=4096)
+    for i, s in enumerate(samples):
+        w = ot.place(s, compute_scores=True)
+        _assert_same(res, i, w, s["name"])
+        assert scores[i].tolist() == w["scores"].tolist()
+        assert int(tc[i]) == w["num_best"]
+        assert ties[i].tolist() == w["ties"].tolist()
+        assert ties_hu[i].tolist() == w["ties_has_unique"].tolist()
+    pl.close()
+
+
+def test_big_fixture_matches_reference():
+    with gzip.open(os.path.join(SURVEY, "big", "tree.pb.gz"), "rb") as f, tempfile.NamedTemporaryFile(suffix=".pb") as tmp:
+        tmp.write(f.read())
+        tmp.flush()
+        arrays, samples = _load(tmp.name, os.path.join(SURVEY, "big", "query.vcf"))
+    pl = Placer(arrays)
+    res = pl.place(QueryBatch(samples))
+    want = _read_stats(os.path.join(SURVEY, "big", "o3", "placement_stats.tsv"))
+    assert [(s["name"], int(r["best_set_difference"]), int(r["num_best"])) for s, r in zip(samples, res)] == want
+    ot = capi.OracleTree(arrays)
+    for i in range(0, 64, 7):
+        _assert_same(res, i, ot.place(samples[i]), samples[i]["name"])
+    pl.close()
+
+
+@pytest.mark.parametrize("seed,n_leaves,n_queries,chunk", [(31, 200, 70, 13), (32, 400, 130, None), (33, 900, 65, 50), (34, 60, 1, 4)])
+def test_random_trees_match_oracle(seed, n_leaves, n_queries, chunk):
+    arrays, queries = synth.make_case(seed, n_leaves=n_leaves, n_queries=n_queries, n_sites=80,
+                                      p_masked=0.05 if seed % 2 else 0.0, root_muts=seed % 3)
+    pl = Placer(arrays, chunk_nodes=chunk)
+    res = pl.place(QueryBatch(queries))
+    ot = capi.OracleTree(arrays)
+    for i, s in enumerate(queries):
+        _assert_same(res, i, ot.place(s), s["name"])
+    scores = pl.scores_per_node(QueryBatch(queries[:5]))
+    for i in range(min(5, len(queries))):
+        assert scores[i].tolist() == ot.place(queries[i], compute_scores=True)["scores"].tolist()
+    pl.close()
+
+
+def test_edge_cases():
+    # single-node tree, empty batch, empty sample, sample with only N rows
+    one = {"n": 1, "parent": np.array([-1]), "mut_off": np.array([0, 0]), "mut_pos": np.zeros(0, np.int32),
+           "mut_ref": np.zeros(0, np.int8), "mut_par": np.zeros(0, np.int8), "mut_nuc": np.zeros(0, np.int8)}
+    empty = {"name": "e", "pos": np.zeros(0, np.int32), "ref": np.zeros(0, np.int8), "nuc": np.zeros(0, np.int8),
+             "is_missing": np.zeros(0, np.int8)}
+    only_n = {"name": "n", "pos": np.array([3, 9], np.int32), "ref": np.array([1, 2], np.int8), "nuc": np.array([15, 15], np.int8),
+              "is_missing": np.array([1, 1], np.int8)}
+    q = {"name": "q", "pos": np.array([5], np.int32), "ref": np.array([1], np.int8), "nuc": np.array([4], np.int8),
+         "is_missing": np.array([0], np.int8)}
+    pl = Placer(one)
+    assert len(pl.place(QueryBatch([]))) == 0
+    res = pl.place(QueryBatch([empty, only_n, q]))
+    ot = capi.OracleTree(one)
+    for i, s in enumerate([empty, only_n, q]):
+        _assert_same(res, i, ot.place(s), s["name"])
+    pl.close()
+    arrays, queries = synth.make_case(40, n_leaves=50, n_queries=3)
+    pl = Placer(arrays)
+    res = pl.place(QueryBatch([empty, only_n] + queries))
+    ot = capi.OracleTree(arrays)
+    for i, s in enumerate([empty, only_n] + queries):
+        _assert_same(res, i, ot.place(s), s["name"])
+    # unsorted / duplicated rows are refused loudly, not mis-scored
+    bad = dict(q, pos=np.array([9, 5], np.int32), ref=np.array([1, 1], np.int8), nuc=np.array([4, 4], np.int8),
+               is_missing=np.array([0, 0], np.int8))
+    with pytest.raises(UgpError) as e:
+        pl.place(QueryBatch([bad]))
+    assert e.value.code == -2
+    pl.close()

@@ -1,0 +1,85 @@
+"""ctypes binding of libusher_amd.so (include/usher_amd.h).  No fallback: if the
+shared library is missing this raises, it never substitutes a CPU path."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libusher_amd.so")
+_lib = None
+
+
+class ugp_tree_desc(C.Structure):
+    _fields_ = [("n_nodes", C.c_uint64), ("parent", C.c_void_p), ("mut_off", C.c_void_p), ("mut_pos", C.c_void_p),
+                ("mut_ref", C.c_void_p), ("mut_par", C.c_void_p), ("mut_nuc", C.c_void_p)]
+
+
+class ugp_queries(C.Structure):
+    _fields_ = [("n_queries", C.c_uint64), ("ent_off", C.c_void_p), ("pos", C.c_void_p), ("ref", C.c_void_p),
+                ("nuc", C.c_void_p), ("is_missing", C.c_void_p)]
+
+
+class ugp_result(C.Structure):
+    _fields_ = [("best_set_difference", C.c_int32), ("num_best", C.c_uint32), ("best_j", C.c_uint32),
+                ("best_has_unique", C.c_uint32)]
+
+
+class ugp_info(C.Structure):
+    _fields_ = [("n_nodes", C.c_uint64), ("n_muts", C.c_uint64), ("n_sites", C.c_uint64), ("stream_bytes", C.c_uint64),
+                ("algo_tree_bytes", C.c_uint64), ("algo_tile_bytes", C.c_uint64), ("n_chunks", C.c_uint32),
+                ("max_slots", C.c_uint32), ("max_position", C.c_uint32), ("device", C.c_uint32)]
+
+
+class ugp_timing(C.Structure):
+    _fields_ = [("table_ms", C.c_float), ("place_ms", C.c_float), ("merge_ms", C.c_float),
+                ("place_launches", C.c_uint32), ("n_tiles", C.c_uint32), ("n_groups", C.c_uint32)]
+
+
+# every symbol include/usher_amd.h declares: name -> (restype, argtypes)
+P = C.c_void_p
+SYMBOLS = {
+    "ugp_mat_create": (C.c_int, [C.POINTER(ugp_tree_desc), C.c_int, C.POINTER(P)]),
+    "ugp_mat_destroy": (None, [P]),
+    "ugp_mat_info": (C.c_int, [P, C.POINTER(ugp_info)]),
+    "ugp_place_batch": (C.c_int, [P, C.POINTER(ugp_queries), P]),
+    "ugp_scores_per_node": (C.c_int, [P, C.POINTER(ugp_queries), P]),
+    "ugp_tied_nodes": (C.c_int, [P, C.POINTER(ugp_queries), C.c_uint32, P, P, P]),
+    "ugp_qset_upload": (C.c_int, [P, C.POINTER(ugp_queries), C.POINTER(P)]),
+    "ugp_qset_destroy": (None, [P]),
+    "ugp_qset_size": (C.c_uint64, [P]),
+    "ugp_place_device": (C.c_int, [P, P, P, P]),
+    "ugp_get_timing": (C.c_int, [P, C.POINTER(ugp_timing)]),
+    "ugp_last_error": (C.c_char_p, []),
+    "ugp_mat_create_chunked": (C.c_int, [C.POINTER(ugp_tree_desc), C.c_int, C.c_uint32, C.POINTER(P)]),
+    "ugp_flat_create": (C.c_int, [C.POINTER(ugp_tree_desc), C.c_uint32, C.POINTER(P)]),
+    "ugp_flat_destroy": (None, [P]),
+    "ugp_flat_get": (C.c_int, [P, C.c_int, C.POINTER(P), C.POINTER(C.c_uint64)]),
+}
+
+
+def build_library(force: bool = False) -> str:
+    """Compile libusher_amd.so in-tree with hipcc for gfx950 (cross-compiles without a GPU)."""
+    csrc = os.path.join(_HERE, "csrc")
+    cmd = ["make", "-s", "-C", csrc]
+    if force:
+        cmd.append("-B")
+    subprocess.check_call(cmd)
+    return LIB_PATH
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                "libusher_amd.so is not built (%s); run `python -c 'import __graft_entry__ as g; g.build()'` "
+                "or `make -C usher_amd/csrc`. There is no CPU fallback." % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib

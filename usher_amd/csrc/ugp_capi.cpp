@@ -1,0 +1,502 @@
+// ugp_capi.cpp -- the extern "C" boundary of libusher_amd.so (include/usher_amd.h).
+// Owns device memory behind opaque handles; never throws across the ABI and
+// never exits the process.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "ugp_flatten.hpp"
+#include "ugp_kernels.hpp"
+#include "usher_amd.h"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string &msg) {
+    g_err = msg;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                         \
+    do {                                                                                      \
+        hipError_t e_ = (expr);                                                               \
+        if (e_ != hipSuccess)                                                                 \
+            return fail(UGP_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));      \
+    } while (0)
+
+template <typename T>
+struct DevBuf {
+    T *p = nullptr;
+    size_t cap = 0;   // elements
+    ~DevBuf() { release(); }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr; cap = 0;
+    }
+    hipError_t reserve(size_t n) {
+        if (n <= cap) return hipSuccess;
+        release();
+        hipError_t e = hipMalloc((void **)&p, std::max<size_t>(n, 1) * sizeof(T));
+        if (e == hipSuccess) cap = n; else p = nullptr;
+        return e;
+    }
+    hipError_t upload(const std::vector<T> &v) {
+        hipError_t e = reserve(v.size());
+        if (e != hipSuccess || v.empty()) return e;
+        return hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice);
+    }
+};
+
+struct EventSet {
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    bool used = false;
+};
+
+constexpr uint32_t kMaxTilesPerLaunch = 4096;   // 262,144 samples per sub-batch
+
+}  // namespace
+
+struct ugp_mat {
+    int device = 0;
+    ugp::FlatMat flat;   // host copy of the small tables (pos2site, site_ref); streams are dropped after upload
+    uint64_t stream_dwords = 0, pre_dwords = 0;
+    DevBuf<uint32_t> d_stream, d_pre, d_chunk_body, d_chunk_pre, d_chunk_node, d_rank2bfs, d_dfs2bfs;
+    DevBuf<int32_t> d_pos2site;
+    DevBuf<uint8_t> d_site_ref;
+    // per-call workspaces (grown on demand)
+    DevBuf<uint32_t> d_table, d_dbottom, d_part_best, d_part_cnt, d_part_key;
+    std::vector<EventSet> events;
+    size_t events_used = 0;
+    ugp_timing last = {};
+    hipStream_t last_stream = nullptr;
+    bool timing_pending = false;
+};
+
+struct ugp_qset {
+    int device = 0;
+    uint64_t n_queries = 0, n_ent = 0;
+    DevBuf<int32_t> d_pos;
+    DevBuf<uint8_t> d_ref, d_nuc, d_missing;
+    DevBuf<uint32_t> d_ent_q;
+    std::vector<uint64_t> ent_off;   // host copy, for sub-batching
+};
+
+namespace {
+
+uint32_t pick_groups(const ugp_mat *m, uint32_t n_tiles) {
+    uint32_t target_waves = 4096;
+    if (const char *e = getenv("UGP_TARGET_WAVES")) target_waves = (uint32_t)std::max(1, atoi(e));
+    uint32_t g = (target_waves + n_tiles - 1) / n_tiles;
+    if (const char *e = getenv("UGP_GROUPS")) g = (uint32_t)std::max(1, atoi(e));
+    g = std::min<uint32_t>(g, m->flat.n_chunks);
+    g = std::max<uint32_t>(g, 1);
+    if (g >= 8) g &= ~7u;   // XCD-aware block mapping wants a multiple of 8
+    return g;
+}
+
+int validate_queries(const ugp_mat *m, const ugp_queries *q, std::vector<uint32_t> &ent_q) {
+    if (!q || (q->n_queries && !q->ent_off)) return fail(UGP_ERR_INVALID, "null query arrays");
+    if (q->n_queries >= (1ull << 31)) return fail(UGP_ERR_UNSUPPORTED, "more than 2^31 queries in one batch");
+    const uint64_t n_ent = q->n_queries ? q->ent_off[q->n_queries] : 0;
+    if (n_ent && (!q->pos || !q->ref || !q->nuc || !q->is_missing)) return fail(UGP_ERR_INVALID, "null query entry arrays");
+    ent_q.resize(n_ent);
+    const auto &f = m->flat;
+    for (uint64_t s = 0; s < q->n_queries; s++) {
+        const uint64_t b = q->ent_off[s], e = q->ent_off[s + 1];
+        if (e < b || e > n_ent) return fail(UGP_ERR_INVALID, "ent_off is not monotone");
+        for (uint64_t i = b; i < e; i++) {
+            ent_q[i] = (uint32_t)s;
+            if (i > b && q->pos[i] <= q->pos[i - 1])
+                return fail(UGP_ERR_UNSUPPORTED, "rows of sample " + std::to_string(s) +
+                                                     " are not sorted by position / contain a duplicate position");
+            const uint8_t r = q->ref[i];
+            if (r != 1 && r != 2 && r != 4 && r != 8)
+                return fail(UGP_ERR_UNSUPPORTED, "VCF REF base of a row is not one of A,C,G,T");
+            if (!q->is_missing[i] && (q->nuc[i] == 0 || q->nuc[i] > 15))
+                return fail(UGP_ERR_INVALID, "allele mask out of range");
+            const int32_t p = q->pos[i];
+            if (p >= 0 && (uint32_t)p <= f.max_pos && f.pos2site[p] >= 0 && f.site_ref[f.pos2site[p]] != r)
+                return fail(UGP_ERR_UNSUPPORTED, "VCF REF differs from the tree's reference base at position " +
+                                                     std::to_string(p));
+        }
+    }
+    return UGP_OK;
+}
+
+int ensure_events(ugp_mat *m, size_t n) {
+    while (m->events.size() < n) {
+        EventSet es;
+        for (int i = 0; i < 4; i++) HIP_TRY(hipEventCreate(&es.ev[i]));
+        m->events.push_back(es);
+    }
+    return UGP_OK;
+}
+
+// mode 0: results to d_out (device ugp_result[n_queries]);
+// mode 1: per-node scores to d_scores (device int32 [n_queries][n_nodes]);
+// mode 2: tied nodes (needs d_best_in) -- see ugp_kernels.hip.
+int run_place(ugp_mat *m, ugp_qset *qs, int mode, ugp_result *d_out, int32_t *d_scores, const int32_t *d_best_in,
+              uint32_t *d_tie_count, uint32_t *d_tie_j, uint8_t *d_tie_hu, uint32_t tie_cap, hipStream_t s) {
+    HIP_TRY(hipSetDevice(m->device));
+    const auto &f = m->flat;
+    const uint64_t Q = qs->n_queries;
+    m->events_used = 0;
+    m->last = {};
+    m->last_stream = s;
+    m->timing_pending = true;
+    if (Q == 0) return UGP_OK;
+    const uint32_t n_sites = (uint32_t)f.n_sites;
+    for (uint64_t q0 = 0; q0 < Q; q0 += (uint64_t)kMaxTilesPerLaunch * 64) {
+        const uint64_t nq = std::min<uint64_t>(Q - q0, (uint64_t)kMaxTilesPerLaunch * 64);
+        const uint32_t n_tiles = (uint32_t)((nq + 63) / 64);
+        const uint32_t G = pick_groups(m, n_tiles);
+        const uint64_t table_dwords = (uint64_t)n_tiles * n_sites * 8;
+        HIP_TRY(m->d_table.reserve(table_dwords));
+        HIP_TRY(m->d_dbottom.reserve((size_t)n_tiles * 64));
+        if (mode == 0) {
+            const size_t np = (size_t)n_tiles * G * 64;
+            HIP_TRY(m->d_part_best.reserve(np));
+            HIP_TRY(m->d_part_cnt.reserve(np));
+            HIP_TRY(m->d_part_key.reserve(np));
+        }
+        if (int rc = ensure_events(m, m->events_used + 1)) return rc;
+        EventSet &es = m->events[m->events_used++];
+        const uint64_t e0 = qs->ent_off[q0], e1 = qs->ent_off[q0 + nq];
+
+        HIP_TRY(hipEventRecord(es.ev[0], s));
+        HIP_TRY(hipMemsetAsync(m->d_dbottom.p, 0, (size_t)n_tiles * 64 * sizeof(uint32_t), s));
+        HIP_TRY(ugp::launch_fill_table(m->d_table.p, m->d_site_ref.p, n_sites, table_dwords, s));
+        HIP_TRY(ugp::launch_scatter(m->d_table.p, m->d_dbottom.p, qs->d_pos.p + e0, qs->d_ref.p + e0,
+                                    qs->d_nuc.p + e0, qs->d_missing.p + e0, qs->d_ent_q.p + e0, m->d_pos2site.p,
+                                    f.max_pos, n_sites, e1 - e0, (uint32_t)q0, s));
+        HIP_TRY(hipEventRecord(es.ev[1], s));
+
+        ugp::PlaceArgs a;
+        memset(&a, 0, sizeof(a));
+        a.stream = m->d_stream.p; a.pre_stream = m->d_pre.p;
+        a.chunk_body_off = m->d_chunk_body.p; a.chunk_pre_off = m->d_chunk_pre.p; a.chunk_node_off = m->d_chunk_node.p;
+        a.table = m->d_table.p; a.dbottom = m->d_dbottom.p;
+        a.n_sites = n_sites; a.n_chunks = f.n_chunks; a.n_groups = G; a.n_tiles = n_tiles; a.n_queries = (uint32_t)nq;
+        a.part_best = m->d_part_best.p; a.part_cnt = m->d_part_cnt.p; a.part_key = m->d_part_key.p;
+        a.dfs2bfs = m->d_dfs2bfs.p; a.n_nodes = f.n_nodes;
+        a.scores = d_scores ? d_scores + q0 * f.n_nodes : nullptr;
+        a.best_in = d_best_in ? d_best_in + q0 : nullptr;
+        a.tie_count = d_tie_count ? d_tie_count + q0 : nullptr;
+        a.tie_j = d_tie_j ? d_tie_j + q0 * tie_cap : nullptr;
+        a.tie_hu = d_tie_hu ? d_tie_hu + q0 * tie_cap : nullptr;
+        a.tie_cap = tie_cap;
+        HIP_TRY(ugp::launch_place(a, mode, f.max_slots, s));
+        HIP_TRY(hipEventRecord(es.ev[2], s));
+        if (mode == 0)
+            HIP_TRY(ugp::launch_merge(m->d_part_best.p, m->d_part_cnt.p, m->d_part_key.p, m->d_rank2bfs.p, G,
+                                      (uint32_t)nq, d_out + q0, s));
+        HIP_TRY(hipEventRecord(es.ev[3], s));
+        es.used = true;
+        m->last.place_launches++;
+        m->last.n_tiles += n_tiles;
+        m->last.n_groups = G;
+    }
+    return UGP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *ugp_last_error(void) { return g_err.c_str(); }
+
+static int mat_create_impl(const ugp_tree_desc *tree, int device, const ugp::Options &opt, ugp_mat **out) {
+    if (!tree || !out) return fail(UGP_ERR_INVALID, "null argument");
+    *out = nullptr;
+    ugp_mat *m = new (std::nothrow) ugp_mat();
+    if (!m) return fail(UGP_ERR_NOMEM, "out of host memory");
+    m->device = device;
+    std::string err;
+    int rc;
+    try {
+        rc = ugp::flatten(*tree, opt, m->flat, err);
+    } catch (const std::bad_alloc &) {
+        delete m;
+        return fail(UGP_ERR_NOMEM, "out of host memory while flattening the tree");
+    }
+    if (rc != UGP_OK) { delete m; return fail(rc, err); }
+    auto bail = [&](hipError_t e, const char *what) {
+        std::string msg = std::string(what) + ": " + hipGetErrorString(e);
+        delete m;
+        return fail(UGP_ERR_HIP, msg);
+    };
+    hipError_t e;
+    if ((e = hipSetDevice(device)) != hipSuccess) return bail(e, "hipSetDevice");
+    auto &f = m->flat;
+    if ((e = m->d_stream.upload(f.stream)) != hipSuccess) return bail(e, "upload stream");
+    if ((e = m->d_pre.upload(f.pre_stream)) != hipSuccess) return bail(e, "upload preambles");
+    if ((e = m->d_chunk_body.upload(f.chunk_body_off)) != hipSuccess) return bail(e, "upload chunk table");
+    if ((e = m->d_chunk_pre.upload(f.chunk_pre_off)) != hipSuccess) return bail(e, "upload chunk table");
+    if ((e = m->d_chunk_node.upload(f.chunk_node_off)) != hipSuccess) return bail(e, "upload chunk table");
+    if ((e = m->d_rank2bfs.upload(f.rank2bfs)) != hipSuccess) return bail(e, "upload rank table");
+    if ((e = m->d_dfs2bfs.upload(f.dfs2bfs)) != hipSuccess) return bail(e, "upload dfs table");
+    if ((e = m->d_pos2site.upload(f.pos2site)) != hipSuccess) return bail(e, "upload site table");
+    if ((e = m->d_site_ref.upload(f.site_ref)) != hipSuccess) return bail(e, "upload site table");
+    m->stream_dwords = f.stream.size();
+    m->pre_dwords = f.pre_stream.size();
+    std::vector<uint32_t>().swap(f.stream);
+    std::vector<uint32_t>().swap(f.pre_stream);
+    std::vector<uint32_t>().swap(f.rank2bfs);
+    std::vector<uint32_t>().swap(f.dfs2bfs);
+    *out = m;
+    return UGP_OK;
+}
+
+int ugp_mat_create(const ugp_tree_desc *tree, int device, ugp_mat **out) {
+    ugp::Options opt;
+    if (const char *e = getenv("UGP_CHUNK_NODES")) opt.chunk_nodes = (uint32_t)std::max(1, atoi(e));
+    return mat_create_impl(tree, device, opt, out);
+}
+
+void ugp_mat_destroy(ugp_mat *m) {
+    if (!m) return;
+    (void)hipSetDevice(m->device);
+    for (auto &es : m->events)
+        for (int i = 0; i < 4; i++)
+            if (es.ev[i]) (void)hipEventDestroy(es.ev[i]);
+    delete m;
+}
+
+int ugp_mat_info(const ugp_mat *m, ugp_info *out) {
+    if (!m || !out) return fail(UGP_ERR_INVALID, "null argument");
+    const auto &f = m->flat;
+    out->n_nodes = f.n_nodes;
+    out->n_muts = f.n_muts;
+    out->n_sites = f.n_sites;
+    out->stream_bytes = m->stream_dwords * 4;
+    out->algo_tree_bytes = 4 * f.n_muts + 8 * f.n_nodes;
+    out->algo_tile_bytes = (uint64_t)f.max_pos / 2 + 16;
+    out->n_chunks = f.n_chunks;
+    out->max_slots = f.max_slots;
+    out->max_position = f.max_pos;
+    out->device = (uint32_t)m->device;
+    return UGP_OK;
+}
+
+int ugp_qset_upload(ugp_mat *m, const ugp_queries *q, ugp_qset **out) {
+    if (!m || !q || !out) return fail(UGP_ERR_INVALID, "null argument");
+    *out = nullptr;
+    std::vector<uint32_t> ent_q;
+    try {
+        if (int rc = validate_queries(m, q, ent_q)) return rc;
+    } catch (const std::bad_alloc &) {
+        return fail(UGP_ERR_NOMEM, "out of host memory");
+    }
+    HIP_TRY(hipSetDevice(m->device));
+    ugp_qset *qs = new (std::nothrow) ugp_qset();
+    if (!qs) return fail(UGP_ERR_NOMEM, "out of host memory");
+    qs->device = m->device;
+    qs->n_queries = q->n_queries;
+    qs->n_ent = ent_q.size();
+    qs->ent_off.assign(q->ent_off, q->ent_off + q->n_queries + 1);
+    if (q->n_queries == 0) qs->ent_off.assign(1, 0);
+    const size_t n = qs->n_ent;
+    hipError_t e = hipSuccess;
+    auto up = [&](auto &buf, const void *src, size_t bytes_per) {
+        if (e != hipSuccess) return;
+        e = buf.reserve(n);
+        if (e == hipSuccess && n) e = hipMemcpy(buf.p, src, n * bytes_per, hipMemcpyHostToDevice);
+    };
+    up(qs->d_pos, q->pos, 4);
+    up(qs->d_ref, q->ref, 1);
+    up(qs->d_nuc, q->nuc, 1);
+    up(qs->d_missing, q->is_missing, 1);
+    up(qs->d_ent_q, ent_q.data(), 4);
+    if (e != hipSuccess) {
+        delete qs;
+        return fail(UGP_ERR_HIP, std::string("query upload: ") + hipGetErrorString(e));
+    }
+    *out = qs;
+    return UGP_OK;
+}
+
+void ugp_qset_destroy(ugp_qset *qs) {
+    if (!qs) return;
+    (void)hipSetDevice(qs->device);
+    delete qs;
+}
+
+uint64_t ugp_qset_size(const ugp_qset *qs) { return qs ? qs->n_queries : 0; }
+
+int ugp_place_device(ugp_mat *m, ugp_qset *qs, void *d_out, void *stream) {
+    if (!m || !qs || (!d_out && qs->n_queries)) return fail(UGP_ERR_INVALID, "null argument");
+    if (qs->device != m->device) return fail(UGP_ERR_INVALID, "query set lives on another device");
+    return run_place(m, qs, 0, (ugp_result *)d_out, nullptr, nullptr, nullptr, nullptr, nullptr, 0,
+                     (hipStream_t)stream);
+}
+
+int ugp_place_batch(ugp_mat *m, const ugp_queries *q, ugp_result *out) {
+    if (!m || !q || (!out && q->n_queries)) return fail(UGP_ERR_INVALID, "null argument");
+    ugp_qset *qs = nullptr;
+    if (int rc = ugp_qset_upload(m, q, &qs)) return rc;
+    DevBuf<ugp_result> d_out;
+    int rc = UGP_OK;
+    hipError_t e = d_out.reserve(q->n_queries);
+    if (e != hipSuccess) rc = fail(UGP_ERR_HIP, std::string("hipMalloc results: ") + hipGetErrorString(e));
+    if (rc == UGP_OK) rc = run_place(m, qs, 0, d_out.p, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr);
+    if (rc == UGP_OK && q->n_queries) {
+        e = hipMemcpy(out, d_out.p, q->n_queries * sizeof(ugp_result), hipMemcpyDeviceToHost);
+        if (e != hipSuccess) rc = fail(UGP_ERR_HIP, std::string("copy results: ") + hipGetErrorString(e));
+    }
+    ugp_qset_destroy(qs);
+    return rc;
+}
+
+int ugp_scores_per_node(ugp_mat *m, const ugp_queries *q, int32_t *out) {
+    if (!m || !q || (!out && q->n_queries)) return fail(UGP_ERR_INVALID, "null argument");
+    ugp_qset *qs = nullptr;
+    if (int rc = ugp_qset_upload(m, q, &qs)) return rc;
+    const size_t total = (size_t)q->n_queries * m->flat.n_nodes;
+    DevBuf<int32_t> d_scores;
+    int rc = UGP_OK;
+    hipError_t e = d_scores.reserve(total);
+    if (e != hipSuccess) rc = fail(UGP_ERR_HIP, std::string("hipMalloc scores: ") + hipGetErrorString(e));
+    if (rc == UGP_OK) rc = run_place(m, qs, 1, nullptr, d_scores.p, nullptr, nullptr, nullptr, nullptr, 0, nullptr);
+    if (rc == UGP_OK && total) {
+        e = hipMemcpy(out, d_scores.p, total * sizeof(int32_t), hipMemcpyDeviceToHost);
+        if (e != hipSuccess) rc = fail(UGP_ERR_HIP, std::string("copy scores: ") + hipGetErrorString(e));
+    }
+    ugp_qset_destroy(qs);
+    return rc;
+}
+
+int ugp_tied_nodes(ugp_mat *m, const ugp_queries *q, uint32_t cap, uint32_t *tie_j, uint8_t *tie_has_unique,
+                   uint32_t *tie_count) {
+    if (!m || !q || !tie_count || (cap && (!tie_j || !tie_has_unique))) return fail(UGP_ERR_INVALID, "null argument");
+    const uint64_t Q = q->n_queries;
+    if (Q == 0) return UGP_OK;
+    ugp_qset *qs = nullptr;
+    if (int rc = ugp_qset_upload(m, q, &qs)) return rc;
+    DevBuf<ugp_result> d_res;
+    DevBuf<int32_t> d_best;
+    DevBuf<uint32_t> d_cnt, d_j;
+    DevBuf<uint8_t> d_hu;
+    int rc = UGP_OK;
+    std::vector<ugp_result> res(Q);
+    std::vector<int32_t> best(Q);
+    const uint64_t padded = ((Q + 63) / 64) * 64;
+    hipError_t e = hipSuccess;
+    auto chk = [&](hipError_t x, const char *what) {
+        if (rc == UGP_OK && x != hipSuccess) rc = fail(UGP_ERR_HIP, std::string(what) + ": " + hipGetErrorString(x));
+    };
+    chk(d_res.reserve(Q), "hipMalloc");
+    chk(d_best.reserve(Q), "hipMalloc");
+    chk(d_cnt.reserve(padded), "hipMalloc");
+    chk(d_j.reserve((size_t)Q * std::max<uint32_t>(cap, 1)), "hipMalloc");
+    chk(d_hu.reserve((size_t)Q * std::max<uint32_t>(cap, 1)), "hipMalloc");
+    if (rc == UGP_OK) rc = run_place(m, qs, 0, d_res.p, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr);
+    if (rc == UGP_OK) {
+        chk(hipMemcpy(res.data(), d_res.p, Q * sizeof(ugp_result), hipMemcpyDeviceToHost), "copy results");
+        for (uint64_t i = 0; i < Q; i++) best[i] = res[i].best_set_difference;
+        chk(hipMemcpy(d_best.p, best.data(), Q * sizeof(int32_t), hipMemcpyHostToDevice), "copy best");
+        chk(hipMemset(d_cnt.p, 0, padded * sizeof(uint32_t)), "memset");
+    }
+    if (rc == UGP_OK) rc = run_place(m, qs, 2, nullptr, nullptr, d_best.p, d_cnt.p, d_j.p, d_hu.p, cap, nullptr);
+    if (rc == UGP_OK) {
+        chk(hipMemcpy(tie_count, d_cnt.p, Q * sizeof(uint32_t), hipMemcpyDeviceToHost), "copy tie counts");
+        if (cap) {
+            chk(hipMemcpy(tie_j, d_j.p, (size_t)Q * cap * sizeof(uint32_t), hipMemcpyDeviceToHost), "copy ties");
+            chk(hipMemcpy(tie_has_unique, d_hu.p, (size_t)Q * cap, hipMemcpyDeviceToHost), "copy ties");
+        }
+    }
+    if (rc == UGP_OK && cap) {
+        // ascending BFS index, the order usher_common.cpp:588 establishes
+        std::vector<std::pair<uint32_t, uint8_t>> tmp;
+        for (uint64_t i = 0; i < Q; i++) {
+            const uint32_t k = std::min<uint32_t>(tie_count[i], cap);
+            tmp.resize(k);
+            for (uint32_t t = 0; t < k; t++) tmp[t] = {tie_j[i * cap + t], tie_has_unique[i * cap + t]};
+            std::sort(tmp.begin(), tmp.end());
+            for (uint32_t t = 0; t < k; t++) { tie_j[i * cap + t] = tmp[t].first; tie_has_unique[i * cap + t] = tmp[t].second; }
+        }
+    }
+    (void)e;
+    ugp_qset_destroy(qs);
+    return rc;
+}
+
+int ugp_get_timing(ugp_mat *m, ugp_timing *out) {
+    if (!m || !out) return fail(UGP_ERR_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(m->device));
+    if (m->timing_pending) {
+        float table = 0, place = 0, merge = 0;
+        for (size_t i = 0; i < m->events_used; i++) {
+            EventSet &es = m->events[i];
+            HIP_TRY(hipEventSynchronize(es.ev[3]));
+            float t;
+            HIP_TRY(hipEventElapsedTime(&t, es.ev[0], es.ev[1])); table += t;
+            HIP_TRY(hipEventElapsedTime(&t, es.ev[1], es.ev[2])); place += t;
+            HIP_TRY(hipEventElapsedTime(&t, es.ev[2], es.ev[3])); merge += t;
+        }
+        m->last.table_ms = table; m->last.place_ms = place; m->last.merge_ms = merge;
+        m->timing_pending = false;
+    }
+    *out = m->last;
+    return UGP_OK;
+}
+
+// Test / tuning hook (not part of the drop-in surface): ugp_mat_create with an
+// explicit chunk size so small fixtures exercise multi-chunk launches.
+int ugp_mat_create_chunked(const ugp_tree_desc *tree, int device, uint32_t chunk_nodes, ugp_mat **out) {
+    ugp::Options opt;
+    opt.chunk_nodes = chunk_nodes;
+    return mat_create_impl(tree, device, opt, out);
+}
+
+// Host-only view of the flattened tree (no device needed) so the CPU test
+// suite can check the record stream, slots, preambles and tables.
+struct ugp_flat { ugp::FlatMat f; };
+
+int ugp_flat_create(const ugp_tree_desc *tree, uint32_t chunk_nodes, ugp_flat **out) {
+    if (!tree || !out) return fail(UGP_ERR_INVALID, "null argument");
+    *out = nullptr;
+    ugp_flat *fl = new (std::nothrow) ugp_flat();
+    if (!fl) return fail(UGP_ERR_NOMEM, "out of host memory");
+    ugp::Options opt;
+    opt.chunk_nodes = chunk_nodes;
+    std::string err;
+    int rc;
+    try {
+        rc = ugp::flatten(*tree, opt, fl->f, err);
+    } catch (const std::bad_alloc &) {
+        delete fl;
+        return fail(UGP_ERR_NOMEM, "out of host memory while flattening the tree");
+    }
+    if (rc != UGP_OK) { delete fl; return fail(rc, err); }
+    *out = fl;
+    return UGP_OK;
+}
+
+void ugp_flat_destroy(ugp_flat *fl) { delete fl; }
+
+int ugp_flat_get(const ugp_flat *fl, int which, const void **ptr, uint64_t *count) {
+    if (!fl || !ptr || !count) return fail(UGP_ERR_INVALID, "null argument");
+    const auto &f = fl->f;
+    switch (which) {
+        case UGP_FLAT_STREAM: *ptr = f.stream.data(); *count = f.stream.size(); break;
+        case UGP_FLAT_PRE_STREAM: *ptr = f.pre_stream.data(); *count = f.pre_stream.size(); break;
+        case UGP_FLAT_CHUNK_BODY_OFF: *ptr = f.chunk_body_off.data(); *count = f.chunk_body_off.size(); break;
+        case UGP_FLAT_CHUNK_PRE_OFF: *ptr = f.chunk_pre_off.data(); *count = f.chunk_pre_off.size(); break;
+        case UGP_FLAT_CHUNK_NODE_OFF: *ptr = f.chunk_node_off.data(); *count = f.chunk_node_off.size(); break;
+        case UGP_FLAT_POS2SITE: *ptr = f.pos2site.data(); *count = f.pos2site.size(); break;
+        case UGP_FLAT_SITE_REF: *ptr = f.site_ref.data(); *count = f.site_ref.size(); break;
+        case UGP_FLAT_RANK2BFS: *ptr = f.rank2bfs.data(); *count = f.rank2bfs.size(); break;
+        case UGP_FLAT_DFS2BFS: *ptr = f.dfs2bfs.data(); *count = f.dfs2bfs.size(); break;
+        case UGP_FLAT_MAX_SLOTS: *ptr = nullptr; *count = f.max_slots; break;
+        default: return fail(UGP_ERR_INVALID, "unknown array id");
+    }
+    return UGP_OK;
+}
+
+}  // extern "C"

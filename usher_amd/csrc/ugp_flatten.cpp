@@ -1,0 +1,236 @@
+// ugp_flatten.cpp -- BFS-ordered tree arrays -> DFS record stream (host, C++).
+//
+// What the reference does per sample (rebuild the BFS vector, allocate 2N
+// vectors, walk parent pointers to the root for every node:
+// usher_common.cpp:342-365, usher_mapper.cpp:275-286) is hoisted here and done
+// once per tree: the true parent state of every mutation, the descendant-leaf
+// counts (Tree::get_num_leaves, mutation_annotated_tree.cpp:866-879), the
+// (n_leaves, j) tie rank (usher_mapper.cpp:483-486) and a traversal order whose
+// running state fits a log2(N)-deep per-lane stack.
+#include "ugp_flatten.hpp"
+
+#include <algorithm>
+#include <cstring>
+#include <numeric>
+
+namespace ugp {
+
+static inline int nuc_index(uint8_t onehot) {
+    switch (onehot) {
+        case 1: return 0;
+        case 2: return 1;
+        case 4: return 2;
+        case 8: return 3;
+        default: return -1;
+    }
+}
+
+int flatten(const ugp_tree_desc &t, const Options &opt, FlatMat &out, std::string &err) {
+    const uint64_t N = t.n_nodes;
+    if (N == 0 || !t.parent || !t.mut_off) { err = "empty tree or null arrays"; return UGP_ERR_INVALID; }
+    if (N >= (1ull << 31)) { err = "more than 2^31 nodes"; return UGP_ERR_UNSUPPORTED; }
+    if (t.parent[0] != UINT32_MAX) { err = "parent[0] must be UINT32_MAX (root first, BFS order)"; return UGP_ERR_INVALID; }
+    const uint64_t M = t.mut_off[N];
+    if (M && (!t.mut_pos || !t.mut_ref || !t.mut_nuc)) { err = "null mutation arrays"; return UGP_ERR_INVALID; }
+
+    // ---- children (BFS order keeps each node's children contiguous & ordered)
+    std::vector<uint32_t> child_off(N + 1, 0);
+    for (uint64_t j = 1; j < N; j++) {
+        if (t.parent[j] >= j) { err = "parent[j] must be < j (BFS order)"; return UGP_ERR_INVALID; }
+        child_off[t.parent[j] + 1]++;
+    }
+    for (uint64_t j = 0; j < N; j++) child_off[j + 1] += child_off[j];
+    std::vector<uint32_t> children(N > 1 ? N - 1 : 0);
+    {
+        std::vector<uint32_t> fill(child_off.begin(), child_off.end() - 1);
+        for (uint64_t j = 1; j < N; j++) children[fill[t.parent[j]]++] = (uint32_t)j;
+    }
+    // ---- subtree sizes and descendant-leaf counts
+    std::vector<uint32_t> sub(N, 1), leaves(N, 0);
+    for (uint64_t j = N; j-- > 0;) {
+        if (child_off[j + 1] == child_off[j]) leaves[j] = 1;
+        if (j > 0) { sub[t.parent[j]] += sub[j]; leaves[t.parent[j]] += leaves[j]; }
+    }
+    // largest subtree last
+    for (uint64_t j = 0; j < N; j++) {
+        uint32_t b = child_off[j], e = child_off[j + 1];
+        if (e - b < 2) continue;
+        uint32_t best = b;
+        for (uint32_t k = b + 1; k < e; k++) if (sub[children[k]] > sub[children[best]]) best = k;
+        uint32_t c = children[best];
+        for (uint32_t k = best; k + 1 < e; k++) children[k] = children[k + 1];
+        children[e - 1] = c;
+    }
+    // ---- tie rank: ascending (n_leaves, j)
+    out.rank2bfs.resize(N);
+    std::iota(out.rank2bfs.begin(), out.rank2bfs.end(), 0u);
+    std::stable_sort(out.rank2bfs.begin(), out.rank2bfs.end(),
+                     [&](uint32_t a, uint32_t b) { return leaves[a] < leaves[b]; });
+    std::vector<uint32_t> rank(N);
+    for (uint64_t r = 0; r < N; r++) rank[out.rank2bfs[r]] = (uint32_t)r;
+
+    // ---- sites
+    int32_t max_pos = 0;
+    for (uint64_t i = 0; i < M; i++) max_pos = std::max(max_pos, t.mut_pos[i]);
+    out.max_pos = (uint32_t)max_pos;
+    out.pos2site.assign((size_t)max_pos + 1, -1);
+    out.site_ref.clear();
+    uint64_t n_real = 0;
+    for (uint64_t i = 0; i < M; i++) {
+        int32_t p = t.mut_pos[i];
+        if (p < 0) continue;
+        n_real++;
+        if (nuc_index(t.mut_nuc[i]) < 0) { err = "tree mutation allele is not one-hot (ambiguous MAT alleles are unsupported)"; return UGP_ERR_UNSUPPORTED; }
+        if (nuc_index(t.mut_ref[i]) < 0) { err = "tree mutation reference base is not one-hot"; return UGP_ERR_UNSUPPORTED; }
+        if (out.pos2site[p] < 0) {
+            out.pos2site[p] = (int32_t)out.site_ref.size();
+            out.site_ref.push_back(t.mut_ref[i]);
+        } else if (out.site_ref[out.pos2site[p]] != t.mut_ref[i]) {
+            err = "tree mutations disagree on the reference base at position " + std::to_string(p);
+            return UGP_ERR_UNSUPPORTED;
+        }
+    }
+    // number sites by position so a tile row index grows with the genome coordinate
+    {
+        std::vector<uint8_t> ref_by_pos;
+        uint32_t s = 0;
+        std::vector<uint8_t> new_ref(out.site_ref.size());
+        for (int32_t p = 0; p <= max_pos; p++) {
+            if (out.pos2site[p] < 0) continue;
+            new_ref[s] = out.site_ref[out.pos2site[p]];
+            out.pos2site[p] = (int32_t)s++;
+        }
+        out.site_ref.swap(new_ref);
+    }
+    out.n_sites = out.site_ref.size();
+    if (out.n_sites > MAX_SITES) { err = "more than 2^22 mutated positions"; return UGP_ERR_UNSUPPORTED; }
+    out.n_nodes = N;
+    out.n_muts = n_real;
+
+    // ---- DFS emission
+    out.stream.clear();
+    out.stream.reserve(2 * N + n_real);
+    out.dfs2bfs.resize(N);
+    std::vector<uint32_t> rec_off(N);        // by BFS index: dword offset of the node's record
+    std::vector<uint8_t> slot(N, 0);         // by BFS index
+    std::vector<uint8_t> cur(out.n_sites);   // running allele index per site
+    for (uint64_t s = 0; s < out.n_sites; s++) cur[s] = (uint8_t)nuc_index(out.site_ref[s]);
+    struct Undo { uint32_t site; uint8_t old; };
+    std::vector<Undo> undo;
+    struct Frame { uint32_t node, next, undo_mark; };
+    std::vector<Frame> stack;
+    uint32_t max_slot_used = 0;
+    uint64_t dfs_idx = 0;
+
+    auto emit = [&](uint32_t j, bool first_child) -> int {
+        const uint64_t b = t.mut_off[j], e = t.mut_off[j + 1];
+        if (e < b || e > M) { err = "mut_off is not monotone"; return UGP_ERR_INVALID; }
+        const uint32_t nch = child_off[j + 1] - child_off[j];
+        uint32_t w0 = 0;
+        const bool root = (j == 0);
+        uint32_t rslot = root ? RS_BOTTOM : (first_child ? RS_REG : slot[t.parent[j]]);
+        uint32_t wslot = WS_NONE;
+        if (nch >= 2) { wslot = slot[j]; max_slot_used = std::max<uint32_t>(max_slot_used, slot[j] + 1u); }
+        if (nch == 0) w0 |= F_LEAF;
+        if (root) w0 |= F_ROOT;
+        rec_off[j] = (uint32_t)out.stream.size();
+        out.stream.push_back(0);
+        out.stream.push_back(rank[j] << 1);
+        uint32_t nwords = 0;
+        bool masked = false;
+        int32_t last_pos = -1;
+        for (uint64_t i = b; i < e; i++) {
+            int32_t p = t.mut_pos[i];
+            if (p < 0) { masked = true; continue; }
+            if (p == last_pos) { err = "node carries two mutations at position " + std::to_string(p); return UGP_ERR_UNSUPPORTED; }
+            last_pos = p;   // (adjacent duplicates; the loader keeps lists sorted)
+            uint32_t site = (uint32_t)out.pos2site[p];
+            uint32_t mi = (uint32_t)nuc_index(t.mut_nuc[i]);
+            uint32_t pi = cur[site];
+            uint32_t ri = (uint32_t)nuc_index(out.site_ref[site]);
+            uint32_t w = site | (mi << 22) | (pi << 24) | (ri << 26);
+            if (masked && !root) w |= M_AFTER_MASK;
+            out.stream.push_back(w);
+            undo.push_back({site, cur[site]});
+            cur[site] = (uint8_t)mi;
+            nwords++;
+        }
+        if (nwords > MAX_NODE_MUTS) { err = "node with more than 65535 mutations"; return UGP_ERR_UNSUPPORTED; }
+        if (masked && !root) w0 |= F_MASKED;   // root: masked mutations are inert (usher_mapper.cpp:266-269, 309-311, 401-403)
+        w0 |= nwords | (rslot << 16) | (wslot << 22);
+        out.stream[rec_off[j]] = w0;
+        out.dfs2bfs[dfs_idx++] = j;
+        return UGP_OK;
+    };
+
+    stack.push_back({0u, 0u, 0u});
+    slot[0] = 0;
+    { int rc = emit(0, false); if (rc) return rc; }
+    while (!stack.empty()) {
+        Frame &f = stack.back();
+        const uint32_t b = child_off[f.node], e = child_off[f.node + 1];
+        if (b + f.next < e) {
+            const uint32_t k = f.next++;
+            const uint32_t c = children[b + k];
+            const bool last = (b + k + 1 == e);
+            uint32_t s = last ? slot[f.node] : slot[f.node] + 1u;
+            if (s >= MAX_SLOTS) { err = "D stack deeper than MAX_SLOTS"; return UGP_ERR_UNSUPPORTED; }
+            slot[c] = (uint8_t)s;
+            const uint32_t mark = (uint32_t)undo.size();
+            int rc = emit(c, k == 0);
+            if (rc) return rc;
+            stack.push_back({c, 0u, mark});
+        } else {
+            // leaving: restore the running state
+            const uint32_t mark = f.undo_mark;
+            while (undo.size() > mark) { cur[undo.back().site] = undo.back().old; undo.pop_back(); }
+            stack.pop_back();
+        }
+    }
+    out.max_slots = std::max<uint32_t>(max_slot_used, 1u);
+
+    // ---- chunks: equal dword budgets, cut at node boundaries
+    uint64_t chunk_nodes = opt.chunk_nodes ? opt.chunk_nodes : std::max<uint64_t>(256, N / 4096);
+    uint64_t want_chunks = std::max<uint64_t>(1, (N + chunk_nodes - 1) / chunk_nodes);
+    const uint64_t total = out.stream.size();
+    out.chunk_body_off.clear(); out.chunk_node_off.clear(); out.chunk_pre_off.clear(); out.pre_stream.clear();
+    {
+        uint64_t next_cut = 0, c = 0;
+        for (uint64_t d = 0; d < N; d++) {
+            uint32_t off = rec_off[out.dfs2bfs[d]];
+            if (off >= next_cut && c < want_chunks) {
+                out.chunk_body_off.push_back(off);
+                out.chunk_node_off.push_back((uint32_t)d);
+                c++;
+                next_cut = total * c / want_chunks;
+                if (next_cut <= off) next_cut = off + 1;
+            }
+        }
+        out.chunk_body_off.push_back((uint32_t)total);
+        out.chunk_node_off.push_back((uint32_t)N);
+    }
+    out.n_chunks = (uint32_t)out.chunk_body_off.size() - 1;
+    // ---- preambles: the root path of each chunk's first node, replayed without scoring
+    std::vector<uint32_t> path;
+    for (uint32_t c = 0; c < out.n_chunks; c++) {
+        out.chunk_pre_off.push_back((uint32_t)out.pre_stream.size());
+        uint32_t a = out.dfs2bfs[out.chunk_node_off[c]];
+        path.clear();
+        for (uint32_t q = a; q != 0;) { q = t.parent[q]; path.push_back(q); }
+        for (size_t i = path.size(); i-- > 0;) {
+            uint32_t q = path[i];
+            uint32_t off = rec_off[q];
+            uint32_t w0 = out.stream[off];
+            uint32_t nwords = w0 & 0xFFFF;
+            uint32_t rs = (q == 0) ? RS_BOTTOM : RS_REG;
+            w0 = (w0 & ~(63u << 16)) | (rs << 16) | F_NOSCORE;
+            out.pre_stream.push_back(w0);
+            out.pre_stream.push_back(out.stream[off + 1]);
+            for (uint32_t k = 0; k < nwords; k++) out.pre_stream.push_back(out.stream[off + 2 + k]);
+        }
+    }
+    out.chunk_pre_off.push_back((uint32_t)out.pre_stream.size());
+    return UGP_OK;
+}
+
+}  // namespace ugp

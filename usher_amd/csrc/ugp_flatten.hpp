@@ -1,0 +1,58 @@
+// ugp_flatten.hpp -- host-side flattening of a mutation-annotated tree into the
+// DFS record stream the HIP kernels walk.  Pure C++ (no HIP), so the CPU test
+// suite can exercise it without a GPU.
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "usher_amd.h"
+
+namespace ugp {
+
+// ---- record stream encoding (shared with ugp_kernels.hip) -----------------
+//
+// One record per node, in the library's own DFS preorder (children reordered
+// so the largest subtree comes last, which bounds the D stack by log2 N):
+//   w0  [15:0]  number of mutation words that follow
+//       [21:16] rslot: slot to read D(parent) from; RS_REG = D of the
+//               previous record (first child), RS_BOTTOM = D_bottom (root)
+//       [27:22] wslot: slot to save D(node) into, WS_NONE = not needed
+//       [28] leaf  [29] noscore (preamble copy)  [30] root  [31] has_masked
+//   w1  tie key: (rank of (n_leaves, bfs_j) among all nodes) << 1
+//   w2.. one word per non-masked mutation:
+//       [21:0]  site index (row of the allele tile)
+//       [23:22] mutated allele index (0..3 = A,C,G,T)
+//       [25:24] true parent-state allele index
+//       [27:26] reference allele index
+//       [31]    after_mask: mutation sits behind the node's first masked
+//               mutation (usher_mapper.cpp:197-200): changes D only
+constexpr uint32_t RS_REG = 63, RS_BOTTOM = 62, WS_NONE = 63;
+constexpr uint32_t F_LEAF = 1u << 28, F_NOSCORE = 1u << 29, F_ROOT = 1u << 30, F_MASKED = 1u << 31;
+constexpr uint32_t M_AFTER_MASK = 1u << 31;
+constexpr uint32_t MAX_SLOTS = 40;        // > log2(2^32) + 1
+constexpr uint32_t MAX_SITES = 1u << 22;
+constexpr uint32_t MAX_NODE_MUTS = 65535;
+
+struct Options {
+    uint32_t chunk_nodes = 0;   // 0 = automatic (about N/4096, at least 256)
+};
+
+struct FlatMat {
+    uint64_t n_nodes = 0, n_muts = 0, n_sites = 0;
+    uint32_t max_pos = 0, max_slots = 0, n_chunks = 0;
+    std::vector<uint32_t> stream;          // node records, DFS order
+    std::vector<uint32_t> pre_stream;      // per-chunk preamble records (root path of the chunk's first node)
+    std::vector<uint32_t> chunk_body_off;  // [n_chunks+1] dword offsets into stream
+    std::vector<uint32_t> chunk_pre_off;   // [n_chunks+1] dword offsets into pre_stream
+    std::vector<uint32_t> chunk_node_off;  // [n_chunks+1] DFS index of the chunk's first node
+    std::vector<int32_t> pos2site;         // [max_pos+1], -1 = position never mutated in the tree
+    std::vector<uint8_t> site_ref;         // [n_sites] one-hot reference base
+    std::vector<uint32_t> rank2bfs;        // [n_nodes] tie rank -> BFS index
+    std::vector<uint32_t> dfs2bfs;         // [n_nodes]
+};
+
+// Returns UGP_OK or a negative UGP_ERR_* with `err` filled.
+int flatten(const ugp_tree_desc &t, const Options &opt, FlatMat &out, std::string &err);
+
+}  // namespace ugp

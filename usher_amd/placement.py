@@ -1,0 +1,191 @@
+"""Python mirror of the placement C ABI (include/usher_amd.h).
+
+Mirrors, for a batch of samples on a static tree, the reference's per-sample
+block usher_common.cpp:342-449 (`mapper2_body` over every BFS node, then the
+tie pass): `Placer.place` returns per sample the reference's
+`best_set_difference`, `num_best`, `best_j` (BFS index) and `has_unique`
+(usher_graph.hpp:79-92).  All compute happens in libusher_amd.so on the GPU.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+
+from . import _lib
+from ._lib import build_library  # noqa: F401
+
+RESULT_DTYPE = np.dtype([("best_set_difference", np.int32), ("num_best", np.uint32), ("best_j", np.uint32),
+                         ("best_has_unique", np.uint32)])
+
+
+class UgpError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__("ugp error %d: %s" % (code, msg))
+        self.code = code
+
+
+def _check(rc: int) -> None:
+    if rc != 0:
+        raise UgpError(rc, (_lib.lib().ugp_last_error() or b"").decode())
+
+
+def _ptr(a: Optional[np.ndarray]):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class _TreeArrays:
+    """Keeps numpy arrays alive and typed for a ugp_tree_desc."""
+
+    def __init__(self, arrays: Dict):
+        n = int(arrays["n"])
+        parent = np.asarray(arrays["parent"]).astype(np.int64)
+        par32 = np.where(parent < 0, 0xFFFFFFFF, parent).astype(np.uint32)
+        self.n = n
+        self.parent = np.ascontiguousarray(par32)
+        self.mut_off = np.ascontiguousarray(arrays["mut_off"], dtype=np.uint64)
+        self.mut_pos = np.ascontiguousarray(arrays["mut_pos"], dtype=np.int32)
+        self.mut_ref = np.ascontiguousarray(arrays["mut_ref"]).astype(np.uint8)
+        self.mut_par = np.ascontiguousarray(arrays["mut_par"]).astype(np.uint8)
+        self.mut_nuc = np.ascontiguousarray(arrays["mut_nuc"]).astype(np.uint8)
+        self.desc = _lib.ugp_tree_desc(n, _ptr(self.parent), _ptr(self.mut_off), _ptr(self.mut_pos),
+                                       _ptr(self.mut_ref), _ptr(self.mut_par), _ptr(self.mut_nuc))
+
+
+class QueryBatch:
+    """CSR batch of query samples (the rows read_vcf() puts in Missing_Sample::mutations)."""
+
+    def __init__(self, samples: Sequence[Dict]):
+        self.names = [s.get("name", "q%d" % i) for i, s in enumerate(samples)]
+        lens = [len(s["pos"]) for s in samples]
+        self.ent_off = np.zeros(len(samples) + 1, dtype=np.uint64)
+        if lens:
+            self.ent_off[1:] = np.cumsum(lens)
+        cat = lambda k, dt: (np.concatenate([np.asarray(s[k]) for s in samples]).astype(dt) if lens and sum(lens)
+                             else np.zeros(0, dt))
+        self.pos = np.ascontiguousarray(cat("pos", np.int32))
+        self.ref = np.ascontiguousarray(cat("ref", np.uint8))
+        self.nuc = np.ascontiguousarray(cat("nuc", np.uint8))
+        self.is_missing = np.ascontiguousarray(cat("is_missing", np.uint8))
+        self.desc = _lib.ugp_queries(len(samples), _ptr(self.ent_off), _ptr(self.pos), _ptr(self.ref), _ptr(self.nuc),
+                                     _ptr(self.is_missing))
+
+    @classmethod
+    def from_csr(cls, ent_off, pos, ref, nuc, is_missing, names=None) -> "QueryBatch":
+        self = cls.__new__(cls)
+        self.ent_off = np.ascontiguousarray(ent_off, dtype=np.uint64)
+        self.pos = np.ascontiguousarray(pos, dtype=np.int32)
+        self.ref = np.ascontiguousarray(ref, dtype=np.uint8)
+        self.nuc = np.ascontiguousarray(nuc, dtype=np.uint8)
+        self.is_missing = np.ascontiguousarray(is_missing, dtype=np.uint8)
+        n = len(self.ent_off) - 1
+        self.names = list(names) if names is not None else ["q%d" % i for i in range(n)]
+        self.desc = _lib.ugp_queries(n, _ptr(self.ent_off), _ptr(self.pos), _ptr(self.ref), _ptr(self.nuc),
+                                     _ptr(self.is_missing))
+        return self
+
+    def __len__(self) -> int:
+        return len(self.ent_off) - 1
+
+    def slice(self, lo: int, hi: int) -> "QueryBatch":
+        e0, e1 = int(self.ent_off[lo]), int(self.ent_off[hi])
+        return QueryBatch.from_csr(self.ent_off[lo:hi + 1] - self.ent_off[lo], self.pos[e0:e1], self.ref[e0:e1],
+                                   self.nuc[e0:e1], self.is_missing[e0:e1], self.names[lo:hi])
+
+
+class FlatTreeView:
+    """Host-only view of the flattened tree (no GPU needed): what ugp_mat_create uploads."""
+
+    IDS = {"stream": (0, np.uint32), "pre_stream": (1, np.uint32), "chunk_body_off": (2, np.uint32),
+           "chunk_pre_off": (3, np.uint32), "chunk_node_off": (4, np.uint32), "pos2site": (5, np.int32),
+           "site_ref": (6, np.uint8), "rank2bfs": (7, np.uint32), "dfs2bfs": (8, np.uint32)}
+
+    def __init__(self, arrays: Dict, chunk_nodes: int = 0):
+        L = _lib.lib()
+        self._t = _TreeArrays(arrays)
+        h = C.c_void_p()
+        _check(L.ugp_flat_create(C.byref(self._t.desc), chunk_nodes, C.byref(h)))
+        try:
+            for name, (which, dt) in self.IDS.items():
+                p = C.c_void_p()
+                n = C.c_uint64()
+                _check(L.ugp_flat_get(h, which, C.byref(p), C.byref(n)))
+                if n.value:
+                    buf = (C.c_char * (n.value * np.dtype(dt).itemsize)).from_address(p.value)
+                    setattr(self, name, np.frombuffer(buf, dtype=dt).copy())
+                else:
+                    setattr(self, name, np.zeros(0, dt))
+            p = C.c_void_p()
+            n = C.c_uint64()
+            _check(L.ugp_flat_get(h, 9, C.byref(p), C.byref(n)))
+            self.max_slots = int(n.value)
+        finally:
+            L.ugp_flat_destroy(h)
+
+
+class Placer:
+    """A flattened MAT resident on one GPU (ugp_mat) plus the batch entry points."""
+
+    def __init__(self, arrays: Dict, device: int = 0, chunk_nodes: Optional[int] = None):
+        L = _lib.lib()
+        self._t = _TreeArrays(arrays)
+        self.n_nodes = self._t.n
+        self._h = C.c_void_p()
+        if chunk_nodes is None:
+            _check(L.ugp_mat_create(C.byref(self._t.desc), device, C.byref(self._h)))
+        else:
+            _check(L.ugp_mat_create_chunked(C.byref(self._t.desc), device, int(chunk_nodes), C.byref(self._h)))
+        self.device = device
+
+    def close(self) -> None:
+        if getattr(self, "_h", None) and self._h.value:
+            _lib.lib().ugp_mat_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def info(self) -> Dict:
+        out = _lib.ugp_info()
+        _check(_lib.lib().ugp_mat_info(self._h, C.byref(out)))
+        return {k: getattr(out, k) for k, _ in out._fields_}
+
+    def place(self, batch: QueryBatch) -> np.ndarray:
+        """ugp_place_batch: structured array (best_set_difference, num_best, best_j, best_has_unique)."""
+        out = np.zeros(len(batch), dtype=RESULT_DTYPE)
+        _check(_lib.lib().ugp_place_batch(self._h, C.byref(batch.desc), _ptr(out)))
+        return out
+
+    def scores_per_node(self, batch: QueryBatch) -> np.ndarray:
+        out = np.zeros((len(batch), self.n_nodes), dtype=np.int32)
+        _check(_lib.lib().ugp_scores_per_node(self._h, C.byref(batch.desc), _ptr(out)))
+        return out
+
+    def tied_nodes(self, batch: QueryBatch, cap: int):
+        tj = np.zeros((len(batch), max(cap, 1)), dtype=np.uint32)
+        th = np.zeros((len(batch), max(cap, 1)), dtype=np.uint8)
+        tc = np.zeros(len(batch), dtype=np.uint32)
+        _check(_lib.lib().ugp_tied_nodes(self._h, C.byref(batch.desc), cap, _ptr(tj), _ptr(th), _ptr(tc)))
+        return [tj[i, :min(int(tc[i]), cap)].copy() for i in range(len(batch))], \
+               [th[i, :min(int(tc[i]), cap)].astype(bool) for i in range(len(batch))], tc
+
+    # ---- device-resident path (bench / multi-GPU) ---------------------------
+    def upload(self, batch: QueryBatch):
+        h = C.c_void_p()
+        _check(_lib.lib().ugp_qset_upload(self._h, C.byref(batch.desc), C.byref(h)))
+        return h
+
+    def free_qset(self, h) -> None:
+        _lib.lib().ugp_qset_destroy(h)
+
+    def place_device(self, qset, d_out_ptr: int, stream: int = 0) -> None:
+        _check(_lib.lib().ugp_place_device(self._h, qset, C.c_void_p(d_out_ptr), C.c_void_p(stream)))
+
+    def timing(self) -> Dict:
+        out = _lib.ugp_timing()
+        _check(_lib.lib().ugp_get_timing(self._h, C.byref(out)))
+        return {k: getattr(out, k) for k, _ in out._fields_}
