@@ -129,9 +129,10 @@ def test_edge_cases():
            "mut_ref": np.zeros(0, np.int8), "mut_par": np.zeros(0, np.int8), "mut_nuc": np.zeros(0, np.int8)}
     empty = {"name": "e", "pos": np.zeros(0, np.int32), "ref": np.zeros(0, np.int8), "nuc": np.zeros(0, np.int8),
              "is_missing": np.zeros(0, np.int8)}
-    only_n = {"name": "n", "pos": np.array([3, 9], np.int32), "ref": np.array([1, 2], np.int8), "nuc": np.array([15, 15], np.int8),
+    # positions beyond the synthetic genome (2000) so REF cannot clash with a tree site
+    only_n = {"name": "n", "pos": np.array([3003, 3009], np.int32), "ref": np.array([1, 2], np.int8), "nuc": np.array([15, 15], np.int8),
               "is_missing": np.array([1, 1], np.int8)}
-    q = {"name": "q", "pos": np.array([5], np.int32), "ref": np.array([1], np.int8), "nuc": np.array([4], np.int8),
+    q = {"name": "q", "pos": np.array([3005], np.int32), "ref": np.array([1], np.int8), "nuc": np.array([4], np.int8),
          "is_missing": np.array([0], np.int8)}
     pl = Placer(one)
     assert len(pl.place(QueryBatch([]))) == 0
@@ -147,7 +148,7 @@ def test_edge_cases():
     for i, s in enumerate([empty, only_n] + queries):
         _assert_same(res, i, ot.place(s), s["name"])
     # unsorted / duplicated rows are refused loudly, not mis-scored
-    bad = dict(q, pos=np.array([9, 5], np.int32), ref=np.array([1, 1], np.int8), nuc=np.array([4, 4], np.int8),
+    bad = dict(q, pos=np.array([3009, 3005], np.int32), ref=np.array([1, 1], np.int8), nuc=np.array([4, 4], np.int8),
                is_missing=np.array([0, 0], np.int8))
     with pytest.raises(UgpError) as e:
         pl.place(QueryBatch([bad]))
