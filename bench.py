@@ -90,13 +90,13 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     place_ms = table_ms = merge_ms = 0.0
-    tiles = groups = 0
+    tiles = groups = packed = 0
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
         tm = pl.timing()   # HIP events recorded by the library on `stream` around each kernel of this step
         place_ms += tm["place_ms"]; table_ms += tm["table_ms"]; merge_ms += tm["merge_ms"]
-        tiles, groups = tm["n_tiles"], tm["n_groups"]
+        tiles, groups, packed = tm["n_tiles"], tm["n_groups"], tm["packed_path"]
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -113,14 +113,15 @@ def main():
         ms_per_step = elapsed * 1e3 / args.steps
         value = world * Q * args.steps / elapsed
         # roofline of the dominant kernel (k_place): algorithmic bytes per launch, SURVEY 8(d):
-        # every 64-sample tile makes one pass over the tree: B_tree + 64 * (L/2 + 16)
-        algo_bytes = tiles * (info["algo_tree_bytes"] + 64 * info["algo_tile_bytes"])
+        # every T-sample tile makes one pass over the tree: B_tree + T * (L/2 + 16); T = 512 on the packed path
+        T = 512 if packed else 64
+        algo_bytes = tiles * (info["algo_tree_bytes"] + T * info["algo_tile_bytes"])
         k_ms = place_ms / args.steps
         achieved = algo_bytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
         node_evals = float(Q) * (info["n_nodes"] + info["n_muts"])
         roofline = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
-                    "kernel": "k_place<0>", "kernel_ms": round(k_ms, 4), "algo_bytes_per_launch": int(algo_bytes),
+                    "kernel": "k_best8" if packed else "k_place<0>", "tile_samples": T, "kernel_ms": round(k_ms, 4), "algo_bytes_per_launch": int(algo_bytes),
                     "node_plus_mut_evals_per_s": round(node_evals / (k_ms * 1e-3), 1) if k_ms > 0 else 0.0,
                     "table_ms": round(table_ms / args.steps, 4), "merge_ms": round(merge_ms / args.steps, 4)}
         # ---- CPU baseline: the literal oracle (port of mapper2_body + driver), node-parallel on the host cores
@@ -149,11 +150,11 @@ def main():
             "metric": "sample placements/sec on 10M-node MAT; bit-exact parsimony score vs reference",
             "value": round(value, 2), "unit": "placements/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "u32 (4-bit allele sets, int32 counters)", "data": "synthetic",
+            "dtype": "u16 packed (4-bit allele sets, 4-bit SWAR node counters, 16-bit D/cost)" if packed else "u32 (4-bit allele sets, int32 counters)", "data": "synthetic",
             "config": {"workload": "synthetic MAT %d nodes / %d mutations / %d variable sites, L=%d; %d queries per GPU per step%s"
                                    % (info["n_nodes"], info["n_muts"], info["n_sites"], args.genome, Q,
                                       " (100-5000 N + 0-30 IUPAC cells each)" if args.ambiguous else ""),
-                       "nodes": int(info["n_nodes"]), "queries_per_gpu": Q, "tile": 64, "tiles": tiles, "waves_per_tile": groups,
+                       "nodes": int(info["n_nodes"]), "queries_per_gpu": Q, "tile": T, "tiles": tiles, "waves_per_tile": groups,
                        "parallelism": "queries sharded x%d, MAT replicated, RCCL all-gather of results" % world,
                        "seed": args.seed, "gen_s": round(t_gen, 2), "flatten_upload_s": round(t_flat, 2)},
             "roofline": roofline, "cpu_baseline": cpu,

@@ -102,11 +102,13 @@ typedef struct ugp_info {
 
 typedef struct ugp_timing {
     float table_ms;      /* allele-tile build kernels of the last call          */
-    float place_ms;      /* the dominant kernel (ugp_place_kernel) of the last call */
-    float merge_ms;      /* partial-result merge of the last call               */
+    float place_ms;      /* the dominant kernel of the last call (k_best8, or k_place on the 32-bit path) */
+    float merge_ms;      /* reduction after it (phase 2: k_gbest/k_select/k_ties/k_final, or k_merge)     */
     uint32_t place_launches;
-    uint32_t n_tiles;    /* 64-sample tiles in the last call                    */
+    uint32_t n_tiles;    /* sample tiles (one tree pass each) in the last call: 512-sample tiles on
+                            the packed path, 64-sample tiles on the 32-bit path */
     uint32_t n_groups;   /* waves per tile in the last call                     */
+    uint32_t packed_path; /* 1: 8-samples-per-lane 16-bit kernel + phase 2; 0: 32-bit kernel */
 } ugp_timing;
 
 /* Flatten + upload.  device = HIP device ordinal.  Replaces the per-sample
@@ -174,7 +176,12 @@ enum {
     UGP_FLAT_SITE_REF = 6,      /* uint8  [n_sites] */
     UGP_FLAT_RANK2BFS = 7,      /* uint32 [n_nodes] */
     UGP_FLAT_DFS2BFS = 8,       /* uint32 [n_nodes] */
-    UGP_FLAT_MAX_SLOTS = 9      /* count only */
+    UGP_FLAT_MAX_SLOTS = 9,     /* count only */
+    UGP_FLAT_STREAM8 = 10,      /* uint32: packed stream walked by the 8-samples-per-lane kernel */
+    UGP_FLAT_PRE8_STREAM = 11,  /* uint32 */
+    UGP_FLAT_CHUNK8_BODY_OFF = 12, /* uint32 [n_chunks+1] */
+    UGP_FLAT_CHUNK8_PRE_OFF = 13,  /* uint32 [n_chunks+1] */
+    UGP_FLAT_MAX_PATH_MUTS = 14 /* count only */
 };
 int ugp_flat_create(const ugp_tree_desc *tree, uint32_t chunk_nodes, ugp_flat **out);
 void ugp_flat_destroy(ugp_flat *flat);

@@ -108,3 +108,146 @@ def place(flat, sample, n_groups=1, want_scores=False):
     if want_scores:
         out["scores"] = scores
     return out
+
+
+# --------------------------------------------------------------------------
+# packed stream ("stream8"): interpreter of k_best8 + phase 2, one sample at a
+# time but with the kernel's 16-bit wrap-around arithmetic and 4-bit counters.
+# --------------------------------------------------------------------------
+H_TAG, H_SKIPD, H_NOSCORE8, H_END, H_FREE, H_CHUNK_END, H_NOP = (
+    1 << 31, 1 << 12, 1 << 13, 1 << 16, 1 << 17, 1 << 18, 1 << 19)
+M_FLUSH, M_END = 1 << 28, 1 << 30
+U16 = 0xFFFF
+
+
+def best8_group(flat, nib, dbot, c0, c1):
+    """Chunk-local minima of one sample for chunks [c0, c1), as k_best8 computes them."""
+    slots = {}
+    lbest = {}
+    best = U16
+    dcur = dpar = 0
+    accP = accC = accN = 0
+    carryD = carryN = carryC = 0
+    flushed = False
+    hdr = 0
+    chunk = c0
+
+    def finish():
+        nonlocal best, dcur, accP, accC, accN, flushed, carryD, carryN, carryC
+        assert accP <= 15 and accC <= 15 and accN <= 15
+        dn = 0
+        if not (hdr & H_SKIPD):
+            dn = (dpar + accP - accC + (carryD if flushed else 0)) & U16
+            dcur = dn
+            wslot = (hdr >> 6) & 63
+            if wslot != WS_NONE:
+                slots[wslot] = dn
+        if not (hdr & H_NOSCORE8):
+            cost = (dpar - accN - (carryN if flushed else 0)) & U16
+            common = (accC + (carryC if flushed else 0) + (1 if hdr & H_FREE else 0)) & U16
+            inelig = U16 if common == 0 else 0
+            best = min(best, cost | inelig)
+        accP = accC = accN = 0
+        flushed = False
+
+    for words, lo, hi in ((flat.pre8_stream, int(flat.chunk8_pre_off[c0]), int(flat.chunk8_pre_off[c0 + 1])),
+                          (flat.stream8, int(flat.chunk8_body_off[c0]), int(flat.chunk8_body_off[c1]))):
+        for i in range(lo, hi):
+            w = int(words[i])
+            if w & H_TAG:
+                if w & H_NOP:
+                    continue
+                if w & H_CHUNK_END:
+                    lbest[chunk] = best
+                    best = U16
+                    chunk += 1
+                    continue
+                hdr = w
+                rslot = w & 63
+                dpar = dcur if rslot == RS_REG else (dbot if rslot == RS_BOTTOM else slots[rslot])
+                if w & H_END:
+                    finish()
+            else:
+                site, mi, pi = w & 0x3FFFFF, (w >> 22) & 3, (w >> 24) & 3
+                x = int(nib[site])
+                c, p = (x >> mi) & 1, (x >> pi) & 1
+                accP += p
+                accC += c
+                accN += c & (1 - p)
+                if w & M_FLUSH:
+                    carryD = ((carryD if flushed else 0) + accP - accC) & U16
+                    carryN = ((carryN if flushed else 0) + accN) & U16
+                    carryC = ((carryC if flushed else 0) + accC) & U16
+                    accP = accC = accN = 0
+                    flushed = True
+                if w & M_END:
+                    finish()
+    assert chunk == c1
+    return lbest
+
+
+def place8(flat, sample, n_groups=1):
+    """Phase 1 (k_best8) + phase 2 (k_gbest, k_select, k_ties with the 32-bit walk, k_final)."""
+    nib, dbot = sample_site_alleles(flat, sample)
+    n_chunks = len(flat.chunk8_body_off) - 1
+    n_groups = max(1, min(n_groups, n_chunks))
+    lbest = {}
+    for g in range(n_groups):
+        c0, c1 = g * n_chunks // n_groups, (g + 1) * n_chunks // n_groups
+        if c0 < c1:
+            lbest.update(best8_group(flat, nib, dbot, c0, c1))
+    assert len(lbest) == n_chunks
+    gbest = min(lbest.values())
+    cnt, key = 0, 0
+    for c in range(n_chunks):
+        if lbest[c] != gbest:
+            continue
+        b, k_cnt, k_key = _ties_chunk(flat, nib, dbot, c, gbest)
+        cnt += k_cnt
+        key = max(key, k_key)
+    return {"best": gbest, "num_best": cnt, "best_j": int(flat.rank2bfs[key >> 1]), "has_unique": bool(key & 1),
+            "candidate_chunks": sum(1 for c in range(n_chunks) if lbest[c] == gbest)}
+
+
+def _ties_chunk(flat, nib, dbot, c, want):
+    """walk<3>: count / key of the eligible nodes of chunk c whose cost equals `want`."""
+    scores = {}
+    slots = {}
+    cnt, key_best = 0, 0
+    dcur = 0
+    for words, lo, hi in ((flat.pre_stream, int(flat.chunk_pre_off[c]), int(flat.chunk_pre_off[c + 1])),
+                          (flat.stream, int(flat.chunk_body_off[c]), int(flat.chunk_body_off[c + 1]))):
+        i = lo
+        while i < hi:
+            w0 = int(words[i]); key = int(words[i + 1]); i += 2
+            nmut = w0 & 0xFFFF
+            rslot, wslot = (w0 >> 16) & 63, (w0 >> 22) & 63
+            dpar = dcur if rslot == RS_REG else (dbot if rslot == RS_BOTTOM else slots[rslot])
+            tsum = neg = common = n_before = 0
+            for _ in range(nmut):
+                w = int(words[i]); i += 1
+                site, mi, pi = w & 0x3FFFFF, (w >> 22) & 3, (w >> 24) & 3
+                x = int(nib[site])
+                cc, pp = (x >> mi) & 1, (x >> pi) & 1
+                d = pp - cc
+                tsum += d
+                if not (w & M_AFTER_MASK):
+                    n_before += 1
+                    common += cc
+                    neg += min(d, 0)
+            dn = dpar + tsum
+            if wslot != WS_NONE:
+                slots[wslot] = dn
+            dcur = dn
+            if not (w0 & F_NOSCORE):
+                if w0 & F_ROOT:
+                    cost, elig, hu = dn, True, 0
+                else:
+                    cost = dpar + neg
+                    masked = bool(w0 & F_MASKED)
+                    elig = common > 0 or (not (w0 & F_LEAF) and not masked and nmut == 0)
+                    hu = 1 if (masked or common != n_before) else 0
+                if elig and cost == want:
+                    cnt += 1
+                    key_best = max(key_best, key | hu)
+    return want, cnt, key_best

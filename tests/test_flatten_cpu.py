@@ -37,6 +37,9 @@ def _check(arrays, samples, chunk_nodes, n_groups, scores=True):
             assert got[k] == want[k], (s["name"], k, got[k], want[k])
         if scores:
             assert got["scores"].tolist() == want["scores"].tolist()
+        got8 = stream_interp.place8(flat, s, n_groups=n_groups)
+        for k in ("best", "num_best", "best_j", "has_unique"):
+            assert got8[k] == want[k], ("packed", s["name"], k, got8[k], want[k])
     return flat
 
 
@@ -92,3 +95,11 @@ def test_flatten_rejects_bad_trees():
     with pytest.raises(UgpError) as e:
         FlatTreeView(bad)             # parent[j] >= j
     assert e.value.code == -1
+
+
+def test_packed_stream_flushes_long_branches():
+    """A node with more than 15 mutations exercises the 4-bit counter spill (M_FLUSH)."""
+    rng = np.random.default_rng(9)
+    arrays, queries = synth.make_case(50, n_leaves=40, n_queries=8, n_sites=200, mut_counts=(0, 1, 17, 33, 40))
+    flat = _check(arrays, queries, chunk_nodes=7, n_groups=4)
+    assert ((flat.stream8 & (1 << 28)) != 0).any() and flat.max_path_muts > 30

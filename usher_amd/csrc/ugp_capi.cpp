@@ -67,10 +67,14 @@ struct ugp_mat {
     ugp::FlatMat flat;   // host copy of the small tables (pos2site, site_ref); streams are dropped after upload
     uint64_t stream_dwords = 0, pre_dwords = 0;
     DevBuf<uint32_t> d_stream, d_pre, d_chunk_body, d_chunk_pre, d_chunk_node, d_rank2bfs, d_dfs2bfs;
+    DevBuf<uint32_t> d_stream8, d_pre8, d_chunk8_body, d_chunk8_pre;
+    uint64_t stream8_dwords = 0;
     DevBuf<int32_t> d_pos2site;
     DevBuf<uint8_t> d_site_ref;
     // per-call workspaces (grown on demand)
     DevBuf<uint32_t> d_table, d_dbottom, d_part_best, d_part_cnt, d_part_key;
+    DevBuf<uint32_t> d_lbest, d_gbest, d_items, d_nitems, d_cnt, d_key, d_active;
+    bool last_used_best8 = false;
     std::vector<EventSet> events;
     size_t events_used = 0;
     ugp_timing last = {};
@@ -81,6 +85,7 @@ struct ugp_mat {
 struct ugp_qset {
     int device = 0;
     uint64_t n_queries = 0, n_ent = 0;
+    uint64_t max_rows = 0;           // largest number of rows of one sample
     DevBuf<int32_t> d_pos;
     DevBuf<uint8_t> d_ref, d_nuc, d_missing;
     DevBuf<uint32_t> d_ent_q;
@@ -89,8 +94,7 @@ struct ugp_qset {
 
 namespace {
 
-uint32_t pick_groups(const ugp_mat *m, uint32_t n_tiles) {
-    uint32_t target_waves = 4096;
+uint32_t pick_groups(const ugp_mat *m, uint32_t n_tiles, uint32_t target_waves = 4096) {
     if (const char *e = getenv("UGP_TARGET_WAVES")) target_waves = (uint32_t)std::max(1, atoi(e));
     uint32_t g = (target_waves + n_tiles - 1) / n_tiles;
     if (const char *e = getenv("UGP_GROUPS")) g = (uint32_t)std::max(1, atoi(e));
@@ -151,15 +155,38 @@ int run_place(ugp_mat *m, ugp_qset *qs, int mode, ugp_result *d_out, int32_t *d_
     m->last_stream = s;
     m->timing_pending = true;
     if (Q == 0) return UGP_OK;
-    const uint32_t n_sites = (uint32_t)f.n_sites;
+    // at least one table row, so that words without a row of their own (headers,
+    // reference-everywhere sites) always have the valid row 0 to fetch
+    const uint32_t n_sites = std::max<uint32_t>((uint32_t)f.n_sites, 1u);
+    const uint32_t active_words = (n_sites + 31) / 32;
     for (uint64_t q0 = 0; q0 < Q; q0 += (uint64_t)kMaxTilesPerLaunch * 64) {
         const uint64_t nq = std::min<uint64_t>(Q - q0, (uint64_t)kMaxTilesPerLaunch * 64);
         const uint32_t n_tiles = (uint32_t)((nq + 63) / 64);
-        const uint32_t G = pick_groups(m, n_tiles);
-        const uint64_t table_dwords = (uint64_t)n_tiles * n_sites * 8;
+        const uint32_t n_tiles512 = (uint32_t)((nq + 511) / 512);
+        // 16-bit packed phase 1 is exact while every D / cost stays below 0xFFFF
+        const bool use8 = (mode == 0) && !getenv("UGP_FORCE_V1") &&
+                          (qs->max_rows + f.max_path_muts + 2 < 0xFFFFull);
+        uint32_t G = pick_groups(m, n_tiles);
+        if (use8) {   // one XCD-load of waves per tile once there are >= 8 tiles (see k_best8)
+            uint32_t waves = 3072;
+            if (const char *e = getenv("UGP_TARGET_WAVES")) waves = (uint32_t)std::max(1, atoi(e));
+            G = std::max<uint32_t>(1, waves / std::min<uint32_t>(n_tiles512, 8));
+            if (const char *e = getenv("UGP_GROUPS")) G = (uint32_t)std::max(1, atoi(e));
+            G = std::min<uint32_t>(G, f.n_chunks);
+        }
+        const uint64_t table_dwords = (uint64_t)n_tiles512 * n_sites * 64;
         HIP_TRY(m->d_table.reserve(table_dwords));
-        HIP_TRY(m->d_dbottom.reserve((size_t)n_tiles * 64));
-        if (mode == 0) {
+        HIP_TRY(m->d_dbottom.reserve((size_t)n_tiles512 * 512));
+        HIP_TRY(m->d_active.reserve((size_t)n_tiles512 * active_words));
+        const uint64_t pairs = (uint64_t)f.n_chunks * n_tiles512 * 8;
+        if (use8) {
+            HIP_TRY(m->d_lbest.reserve((size_t)f.n_chunks * n_tiles512 * 256));
+            HIP_TRY(m->d_gbest.reserve((size_t)n_tiles512 * 256));
+            HIP_TRY(m->d_items.reserve(pairs));
+            HIP_TRY(m->d_nitems.reserve(1));
+            HIP_TRY(m->d_cnt.reserve((size_t)n_tiles512 * 512));
+            HIP_TRY(m->d_key.reserve((size_t)n_tiles512 * 512));
+        } else if (mode == 0) {
             const size_t np = (size_t)n_tiles * G * 64;
             HIP_TRY(m->d_part_best.reserve(np));
             HIP_TRY(m->d_part_cnt.reserve(np));
@@ -170,11 +197,17 @@ int run_place(ugp_mat *m, ugp_qset *qs, int mode, ugp_result *d_out, int32_t *d_
         const uint64_t e0 = qs->ent_off[q0], e1 = qs->ent_off[q0 + nq];
 
         HIP_TRY(hipEventRecord(es.ev[0], s));
-        HIP_TRY(hipMemsetAsync(m->d_dbottom.p, 0, (size_t)n_tiles * 64 * sizeof(uint32_t), s));
+        HIP_TRY(hipMemsetAsync(m->d_dbottom.p, 0, (size_t)n_tiles512 * 512 * sizeof(uint32_t), s));
+        HIP_TRY(hipMemsetAsync(m->d_active.p, 0, (size_t)n_tiles512 * active_words * sizeof(uint32_t), s));
+        if (use8) {
+            HIP_TRY(hipMemsetAsync(m->d_nitems.p, 0, sizeof(uint32_t), s));
+            HIP_TRY(hipMemsetAsync(m->d_cnt.p, 0, (size_t)n_tiles512 * 512 * sizeof(uint32_t), s));
+            HIP_TRY(hipMemsetAsync(m->d_key.p, 0, (size_t)n_tiles512 * 512 * sizeof(uint32_t), s));
+        }
         HIP_TRY(ugp::launch_fill_table(m->d_table.p, m->d_site_ref.p, n_sites, table_dwords, s));
         HIP_TRY(ugp::launch_scatter(m->d_table.p, m->d_dbottom.p, qs->d_pos.p + e0, qs->d_ref.p + e0,
                                     qs->d_nuc.p + e0, qs->d_missing.p + e0, qs->d_ent_q.p + e0, m->d_pos2site.p,
-                                    f.max_pos, n_sites, e1 - e0, (uint32_t)q0, s));
+                                    f.max_pos, n_sites, e1 - e0, (uint32_t)q0, m->d_active.p, active_words, s));
         HIP_TRY(hipEventRecord(es.ev[1], s));
 
         ugp::PlaceArgs a;
@@ -191,15 +224,34 @@ int run_place(ugp_mat *m, ugp_qset *qs, int mode, ugp_result *d_out, int32_t *d_
         a.tie_j = d_tie_j ? d_tie_j + q0 * tie_cap : nullptr;
         a.tie_hu = d_tie_hu ? d_tie_hu + q0 * tie_cap : nullptr;
         a.tie_cap = tie_cap;
-        HIP_TRY(ugp::launch_place(a, mode, f.max_slots, s));
-        HIP_TRY(hipEventRecord(es.ev[2], s));
-        if (mode == 0)
-            HIP_TRY(ugp::launch_merge(m->d_part_best.p, m->d_part_cnt.p, m->d_part_key.p, m->d_rank2bfs.p, G,
-                                      (uint32_t)nq, d_out + q0, s));
+        if (use8) {
+            ugp::Best8Args b;
+            memset(&b, 0, sizeof(b));
+            b.stream8 = m->d_stream8.p; b.pre8 = m->d_pre8.p;
+            b.chunk8_body_off = m->d_chunk8_body.p; b.chunk8_pre_off = m->d_chunk8_pre.p;
+            b.table = m->d_table.p; b.dbottom = m->d_dbottom.p;
+            b.n_sites = n_sites; b.n_chunks = f.n_chunks; b.n_groups = G; b.n_tiles = n_tiles512;
+            b.lbest = m->d_lbest.p;
+            b.max_slots = f.max_slots;
+            b.active = m->d_active.p; b.active_words = active_words;
+            HIP_TRY(ugp::launch_best8(b, f.max_slots, s));
+            HIP_TRY(hipEventRecord(es.ev[2], s));
+            HIP_TRY(ugp::launch_phase2(a, m->d_lbest.p, m->d_gbest.p, n_tiles512, m->d_items.p, m->d_nitems.p,
+                                       (uint32_t)std::min<uint64_t>(pairs, 0xFFFFFFFFull), m->d_cnt.p, m->d_key.p,
+                                       m->d_rank2bfs.p, d_out + q0, f.max_slots, s));
+        } else {
+            HIP_TRY(ugp::launch_place(a, mode, f.max_slots, s));
+            HIP_TRY(hipEventRecord(es.ev[2], s));
+            if (mode == 0)
+                HIP_TRY(ugp::launch_merge(m->d_part_best.p, m->d_part_cnt.p, m->d_part_key.p, m->d_rank2bfs.p, G,
+                                          (uint32_t)nq, d_out + q0, s));
+        }
         HIP_TRY(hipEventRecord(es.ev[3], s));
+        m->last_used_best8 = use8;
+        m->last.packed_path = use8 ? 1u : 0u;
         es.used = true;
         m->last.place_launches++;
-        m->last.n_tiles += n_tiles;
+        m->last.n_tiles += use8 ? n_tiles512 : n_tiles;
         m->last.n_groups = G;
     }
     return UGP_OK;
@@ -242,7 +294,18 @@ static int mat_create_impl(const ugp_tree_desc *tree, int device, const ugp::Opt
     if ((e = m->d_rank2bfs.upload(f.rank2bfs)) != hipSuccess) return bail(e, "upload rank table");
     if ((e = m->d_dfs2bfs.upload(f.dfs2bfs)) != hipSuccess) return bail(e, "upload dfs table");
     if ((e = m->d_pos2site.upload(f.pos2site)) != hipSuccess) return bail(e, "upload site table");
-    if ((e = m->d_site_ref.upload(f.site_ref)) != hipSuccess) return bail(e, "upload site table");
+    {
+        std::vector<uint8_t> sr(f.site_ref);
+        if (sr.empty()) sr.push_back(1);   // a tree without mutations still gets one (unused) table row
+        if ((e = m->d_site_ref.upload(sr)) != hipSuccess) return bail(e, "upload site table");
+    }
+    if ((e = m->d_stream8.upload(f.stream8)) != hipSuccess) return bail(e, "upload packed stream");
+    if ((e = m->d_pre8.upload(f.pre8_stream)) != hipSuccess) return bail(e, "upload packed preambles");
+    if ((e = m->d_chunk8_body.upload(f.chunk8_body_off)) != hipSuccess) return bail(e, "upload chunk table");
+    if ((e = m->d_chunk8_pre.upload(f.chunk8_pre_off)) != hipSuccess) return bail(e, "upload chunk table");
+    m->stream8_dwords = f.stream8.size();
+    std::vector<uint32_t>().swap(f.stream8);
+    std::vector<uint32_t>().swap(f.pre8_stream);
     m->stream_dwords = f.stream.size();
     m->pre_dwords = f.pre_stream.size();
     std::vector<uint32_t>().swap(f.stream);
@@ -274,7 +337,7 @@ int ugp_mat_info(const ugp_mat *m, ugp_info *out) {
     out->n_nodes = f.n_nodes;
     out->n_muts = f.n_muts;
     out->n_sites = f.n_sites;
-    out->stream_bytes = m->stream_dwords * 4;
+    out->stream_bytes = m->stream8_dwords * 4;
     out->algo_tree_bytes = 4 * f.n_muts + 8 * f.n_nodes;
     out->algo_tile_bytes = (uint64_t)f.max_pos / 2 + 16;
     out->n_chunks = f.n_chunks;
@@ -301,6 +364,7 @@ int ugp_qset_upload(ugp_mat *m, const ugp_queries *q, ugp_qset **out) {
     qs->n_ent = ent_q.size();
     qs->ent_off.assign(q->ent_off, q->ent_off + q->n_queries + 1);
     if (q->n_queries == 0) qs->ent_off.assign(1, 0);
+    for (uint64_t i = 0; i < q->n_queries; i++) qs->max_rows = std::max(qs->max_rows, q->ent_off[i + 1] - q->ent_off[i]);
     const size_t n = qs->n_ent;
     hipError_t e = hipSuccess;
     auto up = [&](auto &buf, const void *src, size_t bytes_per) {
@@ -494,6 +558,11 @@ int ugp_flat_get(const ugp_flat *fl, int which, const void **ptr, uint64_t *coun
         case UGP_FLAT_RANK2BFS: *ptr = f.rank2bfs.data(); *count = f.rank2bfs.size(); break;
         case UGP_FLAT_DFS2BFS: *ptr = f.dfs2bfs.data(); *count = f.dfs2bfs.size(); break;
         case UGP_FLAT_MAX_SLOTS: *ptr = nullptr; *count = f.max_slots; break;
+        case UGP_FLAT_STREAM8: *ptr = f.stream8.data(); *count = f.stream8.size(); break;
+        case UGP_FLAT_PRE8_STREAM: *ptr = f.pre8_stream.data(); *count = f.pre8_stream.size(); break;
+        case UGP_FLAT_CHUNK8_BODY_OFF: *ptr = f.chunk8_body_off.data(); *count = f.chunk8_body_off.size(); break;
+        case UGP_FLAT_CHUNK8_PRE_OFF: *ptr = f.chunk8_pre_off.data(); *count = f.chunk8_pre_off.size(); break;
+        case UGP_FLAT_MAX_PATH_MUTS: *ptr = nullptr; *count = f.max_path_muts; break;
         default: return fail(UGP_ERR_INVALID, "unknown array id");
     }
     return UGP_OK;

@@ -112,6 +112,7 @@ int flatten(const ugp_tree_desc &t, const Options &opt, FlatMat &out, std::strin
     out.stream.reserve(2 * N + n_real);
     out.dfs2bfs.resize(N);
     std::vector<uint32_t> rec_off(N);        // by BFS index: dword offset of the node's record
+    std::vector<uint8_t> node_masked(N, 0);  // by BFS index: carries a masked mutation (non-root)
     std::vector<uint8_t> slot(N, 0);         // by BFS index
     std::vector<uint8_t> cur(out.n_sites);   // running allele index per site
     for (uint64_t s = 0; s < out.n_sites; s++) cur[s] = (uint8_t)nuc_index(out.site_ref[s]);
@@ -156,6 +157,7 @@ int flatten(const ugp_tree_desc &t, const Options &opt, FlatMat &out, std::strin
             nwords++;
         }
         if (nwords > MAX_NODE_MUTS) { err = "node with more than 65535 mutations"; return UGP_ERR_UNSUPPORTED; }
+        if (masked && !root) node_masked[j] = 1;
         if (masked && !root) w0 |= F_MASKED;   // root: masked mutations are inert (usher_mapper.cpp:266-269, 309-311, 401-403)
         w0 |= nwords | (rslot << 16) | (wslot << 22);
         out.stream[rec_off[j]] = w0;
@@ -230,6 +232,70 @@ int flatten(const ugp_tree_desc &t, const Options &opt, FlatMat &out, std::strin
         }
     }
     out.chunk_pre_off.push_back((uint32_t)out.pre_stream.size());
+
+    // ---- packed stream (stream8) on the effective tree -----------------------
+    // dropped[j]: leaf whose record has no mutation words (never eligible, no descendants)
+    std::vector<uint8_t> dropped(N, 0);
+    for (uint64_t j = 1; j < N; j++)
+        if (child_off[j + 1] == child_off[j] && (out.stream[rec_off[j]] & 0xFFFFu) == 0) dropped[j] = 1;
+    std::vector<uint32_t> eff_children(N, 0);
+    std::vector<uint8_t> first_eff(N, 0);     // j is the first effective child of its parent
+    for (uint64_t d = 0; d < N; d++) {        // DFS order: children of a node appear in emission order
+        uint32_t j = out.dfs2bfs[d];
+        if (j == 0 || dropped[j]) continue;
+        if (eff_children[t.parent[j]]++ == 0) first_eff[j] = 1;
+    }
+    // mutation count on the root path (bound for the 16-bit counters)
+    {
+        std::vector<uint32_t> path(N, 0);
+        uint32_t mx = 0;
+        for (uint64_t j = 0; j < N; j++) {   // BFS order: parents first
+            uint32_t own = out.stream[rec_off[j]] & 0xFFFFu;
+            path[j] = (j ? path[t.parent[j]] : 0) + own;
+            mx = std::max(mx, path[j]);
+        }
+        out.max_path_muts = mx;
+    }
+    auto emit8 = [&](std::vector<uint32_t> &dst, uint32_t j, bool preamble) {
+        const uint32_t off = rec_off[j];
+        const uint32_t w0 = out.stream[off];
+        const uint32_t nwords = w0 & 0xFFFFu;
+        const bool root = (j == 0);
+        const uint32_t nch = child_off[j + 1] - child_off[j];
+        uint32_t rslot = root ? RS_BOTTOM : ((preamble || first_eff[j]) ? RS_REG : slot[t.parent[j]]);
+        uint32_t wslot = (eff_children[j] >= 2) ? slot[j] : WS_NONE;
+        uint32_t h = H_TAG | rslot | (wslot << 6);
+        if (eff_children[j] == 0 && !root) h |= H_SKIPD;
+        if (preamble || root || node_masked[j]) h |= H_NOSCORE;
+        if (nwords == 0) h |= H_END;
+        if (!root && nch > 0 && nwords == 0 && !node_masked[j]) h |= H_FREE;
+        dst.push_back(h);
+        for (uint32_t k = 0; k < nwords; k++) {
+            uint32_t w = out.stream[off + 2 + k] & 0x0FFFFFFFu;   // site, mutated / parent-state / reference allele
+            if (k + 1 == nwords) w |= M_END;
+            else if ((k + 1) % 15 == 0) w |= M_FLUSH;
+            dst.push_back(w);
+        }
+        // the root scores through a pseudo-node right behind its D record: cost = D(parent) = D(root)
+        if (root && !preamble) dst.push_back(H_TAG | RS_REG | (WS_NONE << 6) | H_SKIPD | H_FREE | H_END);
+    };
+    out.stream8.clear(); out.pre8_stream.clear(); out.chunk8_body_off.clear(); out.chunk8_pre_off.clear();
+    out.stream8.reserve(N + n_real + out.n_chunks);
+    for (uint32_t c = 0; c < out.n_chunks; c++) {
+        out.chunk8_body_off.push_back((uint32_t)out.stream8.size());
+        for (uint32_t d = out.chunk_node_off[c]; d < out.chunk_node_off[c + 1]; d++) {
+            uint32_t j = out.dfs2bfs[d];
+            if (!dropped[j]) emit8(out.stream8, j, false);
+        }
+        out.stream8.push_back(H_TAG | H_CHUNK_END);
+        out.chunk8_pre_off.push_back((uint32_t)out.pre8_stream.size());
+        uint32_t a = out.dfs2bfs[out.chunk_node_off[c]];
+        path.clear();
+        for (uint32_t q = a; q != 0;) { q = t.parent[q]; path.push_back(q); }
+        for (size_t i = path.size(); i-- > 0;) emit8(out.pre8_stream, path[i], true);
+    }
+    out.chunk8_body_off.push_back((uint32_t)out.stream8.size());
+    out.chunk8_pre_off.push_back((uint32_t)out.pre8_stream.size());
     return UGP_OK;
 }
 

@@ -31,6 +31,31 @@ constexpr uint32_t RS_REG = 63, RS_BOTTOM = 62, WS_NONE = 63;
 constexpr uint32_t F_LEAF = 1u << 28, F_NOSCORE = 1u << 29, F_ROOT = 1u << 30, F_MASKED = 1u << 31;
 constexpr uint32_t M_AFTER_MASK = 1u << 31;
 constexpr uint32_t MAX_SLOTS = 40;        // > log2(2^32) + 1
+
+// ---- packed stream ("stream8") walked by k_best8: 8 samples per lane -------
+//
+// One 32-bit word per event.  Leaves without mutation words never influence a
+// result (not eligible, no descendants) and are dropped.
+//   HDR word (bit 31 set), opens a node:
+//       [5:0] rslot  [11:6] wslot   (same meaning as above, on the effective tree)
+//       H_SKIPD   D(node) is not needed (no effective children)
+//       H_NOSCORE not a candidate here: preamble copy, node carrying a masked
+//                 mutation (never eligible), or the root's D record (see below)
+//       H_FREE    every sample is eligible (internal node without mutations)
+//       H_END     node has no mutation words: finish it now
+//       H_CHUNK_END (alone) closes a chunk: publish the chunk-local minimum and reset
+//       H_NOP     padding
+//     The root is emitted as two records: its D record (rslot = RS_BOTTOM,
+//     H_NOSCORE) followed by a scoring pseudo-node (RS_REG, H_SKIPD | H_FREE |
+//     H_END) whose cost is D(parent) = D(root): cost(root) = D(root), always
+//     eligible (usher_mapper.cpp:454).
+//   MUT word (bit 31 clear):
+//       [21:0] site  [23:22] mutated allele  [25:24] parent-state allele  [27:26] reference allele
+//       M_FLUSH  15 mutations accumulated in the 4-bit counters: spill them
+//       M_END    last mutation word of the node
+constexpr uint32_t H_TAG = 1u << 31, H_SKIPD = 1u << 12, H_NOSCORE = 1u << 13, H_END = 1u << 16,
+                   H_FREE = 1u << 17, H_CHUNK_END = 1u << 18, H_NOP = 1u << 19;
+constexpr uint32_t M_FLUSH = 1u << 28, M_END = 1u << 30;
 constexpr uint32_t MAX_SITES = 1u << 22;
 constexpr uint32_t MAX_NODE_MUTS = 65535;
 
@@ -50,6 +75,10 @@ struct FlatMat {
     std::vector<uint8_t> site_ref;         // [n_sites] one-hot reference base
     std::vector<uint32_t> rank2bfs;        // [n_nodes] tie rank -> BFS index
     std::vector<uint32_t> dfs2bfs;         // [n_nodes]
+    // packed stream for k_best8 (same chunk cut points, by DFS node index)
+    std::vector<uint32_t> stream8, pre8_stream;
+    std::vector<uint32_t> chunk8_body_off, chunk8_pre_off;   // [n_chunks+1]
+    uint32_t max_path_muts = 0;            // max over nodes of the mutation count on the root path
 };
 
 // Returns UGP_OK or a negative UGP_ERR_* with `err` filled.

@@ -8,34 +8,62 @@
 // plus the eligibility predicate, and per sample the reduction
 //     (min cost, #ties, argmax (n_leaves, bfs_j) among ties).
 //
-// Mapping to the hardware.  Lanes = samples: one 64-lane wavefront owns a
-// "tile" of 64 query samples and walks a contiguous range of the tree's DFS
-// record stream.  The stream is wave-uniform: 64 dwords at a time are loaded
-// coalesced into one VGPR and handed to the scalar unit with v_readlane, so
-// all control flow (record decode, slot numbers, loop counts) runs on SGPRs.
-// The only per-lane memory traffic is one coalesced 32-byte row of the tile's
-// 4-bit allele table per tree mutation (8 lanes share a dword) and the D stack
-// in LDS (one 256-byte row per saved ancestor; depth <= log2 N by
-// construction, see ugp_flatten.cpp).  Integer work only; no MFMA.
+// Mapping to the hardware.  Lanes = samples: a 64-lane wavefront owns a tile of
+// query samples and walks a contiguous range of the tree's DFS record stream.
+// The stream is wave-uniform: 64 dwords at a time are loaded coalesced into one
+// VGPR and handed to the scalar unit with v_readlane, so record decode, slot
+// numbers and loop control run on SGPRs.  Per-lane memory traffic is one
+// coalesced row of the tile's 4-bit allele table per tree mutation and the D
+// stack in LDS (depth <= log2 N by construction, see ugp_flatten.cpp).
+// Integer work only; no MFMA.
+//
+//   k_best8   phase 1, the dominant kernel: 8 samples per lane (512 per wave),
+//             nibble-parallel membership tests on the lane's table dword, 4-bit
+//             SWAR accumulators per node, packed 16-bit D / cost / running
+//             minimum, software-pipelined row prefetch.  Produces the minimum
+//             cost per (chunk, sample).
+//   k_gbest / k_select / k_ties / k_final   phase 2: global minimum per sample,
+//             then only the (chunk, 64-sample tile) pairs that attain it are
+//             re-walked (one sample per lane, 32-bit) to count ties and pick the
+//             reference's winner.
+//   k_place   one sample per lane, 32-bit: per-node scores (-p), tie lists, and
+//             the general fallback when 16-bit counters could overflow.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+
+#include <type_traits>
 
 #include "ugp_kernels.hpp"
 
 namespace ugp {
 
+typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ uint32_t pk_add(uint32_t a, uint32_t b) {
+    return __builtin_bit_cast(uint32_t, __builtin_bit_cast(us2, a) + __builtin_bit_cast(us2, b));
+}
+__device__ __forceinline__ uint32_t pk_sub(uint32_t a, uint32_t b) {
+    return __builtin_bit_cast(uint32_t, __builtin_bit_cast(us2, a) - __builtin_bit_cast(us2, b));
+}
+__device__ __forceinline__ uint32_t pk_min(uint32_t a, uint32_t b) {
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(us2, a), __builtin_bit_cast(us2, b)));
+}
+__device__ __forceinline__ uint32_t rdlane(uint32_t v, uint32_t l) {
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)l);
+}
+
 // ----------------------------------------------------------- allele tiles
 
-// table[tile][site][8 dwords]: 64 nibbles, nibble l = allele set of sample
-// (tile*64 + l) at that site.  Initialised to the reference base everywhere
-// (a sample without a VCF row at a position carries the reference allele,
-// usher_mapper.cpp:244, 301, 425).
+// table[tile512][site][64 dwords]: one 256-byte row per (512-sample tile, site);
+// dword l, nibble j = allele set of sample tile*512 + 8*l + j at that site.
+// Initialised to the reference base everywhere (a sample without a VCF row at a
+// position carries the reference allele, usher_mapper.cpp:244, 301, 425).
 __global__ void k_fill_table(uint32_t *__restrict__ table, const uint8_t *__restrict__ site_ref,
                              uint32_t n_sites, uint64_t total_dwords) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     for (; i < total_dwords; i += stride) {
-        uint32_t site = (uint32_t)((i >> 3) % n_sites);
+        uint32_t site = (uint32_t)((i >> 6) % n_sites);
         table[i] = (uint32_t)site_ref[site] * 0x11111111u;
     }
 }
@@ -47,7 +75,8 @@ __global__ void k_scatter_entries(uint32_t *__restrict__ table, uint32_t *__rest
                                   const int32_t *__restrict__ pos, const uint8_t *__restrict__ ref,
                                   const uint8_t *__restrict__ nuc, const uint8_t *__restrict__ is_missing,
                                   const uint32_t *__restrict__ ent_q, const int32_t *__restrict__ pos2site,
-                                  uint32_t max_pos, uint32_t n_sites, uint64_t n_ent, uint32_t q_base) {
+                                  uint32_t max_pos, uint32_t n_sites, uint64_t n_ent, uint32_t q_base,
+                                  uint32_t *__restrict__ active, uint32_t active_words) {
     uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= n_ent) return;
     const uint32_t q = ent_q[e] - q_base;   // sample index within this launch's tiles
@@ -59,13 +88,17 @@ __global__ void k_scatter_entries(uint32_t *__restrict__ table, uint32_t *__rest
     if (p < 0 || (uint32_t)p > max_pos) return;
     const int32_t site = pos2site[p];
     if (site < 0) return;
-    const uint32_t tile = q >> 6, lane = q & 63;
-    uint32_t *w = table + ((uint64_t)tile * n_sites + (uint32_t)site) * 8 + (lane >> 3);
-    const uint32_t sh = (lane & 7) * 4;
+    const uint32_t tile = q >> 9, within = q & 511;
+    uint32_t *w = table + ((uint64_t)tile * n_sites + (uint32_t)site) * 64 + (within >> 3);
+    const uint32_t sh = (within & 7) * 4;
     atomicXor(w, ((r ^ a) & 15u) << sh);   // nibble was r (k_fill_table); rows are unique per (sample, position)
+    // the row of (tile, site) is no longer "reference everywhere"
+    if (r != a) atomicOr(&active[(uint64_t)tile * active_words + ((uint32_t)site >> 5)], 1u << ((uint32_t)site & 31u));
 }
 
-// ------------------------------------------------------------ stream reader
+// ====================================================================
+// One sample per lane, 32-bit walk (scores, tie lists, phase 2, fallback)
+// ====================================================================
 
 struct Reader {
     const uint32_t *p;
@@ -82,51 +115,26 @@ struct Reader {
             base += 64; cur = 0;
             buf = (base + lane < end) ? p[base + lane] : 0u;
         }
-        uint32_t w = (uint32_t)__builtin_amdgcn_readlane((int)buf, (int)cur);
+        uint32_t w = rdlane(buf, cur);
         cur++;
         return w;
     }
 };
 
-// -------------------------------------------------------------- the kernel
+struct WalkOut { uint32_t best, cnt, key; };
 
-template <int MODE>   // 0: best placement  1: per-node scores  2: collect tied nodes
-__global__ void __launch_bounds__(64) k_place(PlaceArgs a) {
-    extern __shared__ __attribute__((aligned(16))) uint32_t slots[];   // [max_slots][64]
-    const uint32_t lane = threadIdx.x;
-    uint32_t tile, g;
-    {
-        const uint32_t b = blockIdx.x, G = a.n_groups;
-        if ((G & 7u) == 0) {
-            const uint32_t xcd = b & 7u, r = b >> 3, Gx = G >> 3;
-            tile = r / Gx;
-            g = (r % Gx) * 8 + xcd;
-        } else {
-            tile = b / G;
-            g = b % G;
-        }
-    }
-    const uint32_t c0 = (uint32_t)(((uint64_t)g * a.n_chunks) / a.n_groups);
-    const uint32_t c1 = (uint32_t)(((uint64_t)(g + 1) * a.n_chunks) / a.n_groups);
-    if (c0 >= c1) {
-        if (MODE == 0) {
-            const uint64_t o = ((uint64_t)tile * a.n_groups + g) * 64 + lane;
-            a.part_best[o] = 0x7fffffffu; a.part_cnt[o] = 0; a.part_key[o] = 0;
-        }
-        return;
-    }
-    const uint32_t *tab = a.table + (uint64_t)tile * a.n_sites * 8 + (lane >> 3);
+// MODE 0: full reduction (min, count, key)   MODE 1: per-node scores
+// MODE 2: append tied nodes to lists         MODE 3: count / key of nodes with cost == want
+template <int MODE>
+__device__ __forceinline__ WalkOut walk(const PlaceArgs &a, uint32_t *slots, uint32_t tile, uint32_t c0, uint32_t c1,
+                                        uint32_t lane, uint32_t want_best) {
+    const uint32_t *tab = a.table + (uint64_t)(tile >> 3) * a.n_sites * 64 + (tile & 7u) * 8 + (lane >> 3);
     const uint32_t sh = (lane & 7u) * 4u;
     const uint32_t q = tile * 64 + lane;
     const uint32_t dbot = a.dbottom[q];
-
-    uint32_t best = 0x7fffffffu, cnt = 0, bkey = 0;
-    uint32_t want_best = 0;
-    if (MODE == 2) want_best = (q < a.n_queries) ? (uint32_t)a.best_in[q] : 0xffffffffu;
+    WalkOut o; o.best = 0x7fffffffu; o.cnt = 0; o.key = 0;
     uint32_t dcur = 0;
-    uint32_t node_idx = a.chunk_node_off[c0];   // DFS index of the next body record (MODE 1)
-    (void)node_idx;
-
+    uint32_t node_idx = a.chunk_node_off[c0];   // DFS index of the next body record
     for (int phase = 0; phase < 2; phase++) {
         Reader rd;
         if (phase == 0) rd.init(a.pre_stream, a.chunk_pre_off[c0], a.chunk_pre_off[c0 + 1], lane);
@@ -145,7 +153,7 @@ __global__ void __launch_bounds__(64) k_place(PlaceArgs a) {
             for (uint32_t m = 0; m < nmut; m++) {
                 const uint32_t w = rd.next(lane);
                 const uint32_t site = w & 0x3FFFFFu, mi = (w >> 22) & 3u, pi = (w >> 24) & 3u;
-                const uint32_t x = tab[(uint64_t)site * 8];
+                const uint32_t x = tab[(uint64_t)site * 64];
                 const uint32_t nib = (x >> sh) & 15u;
                 const int c = (int)((nib >> mi) & 1u), p = (int)((nib >> pi) & 1u);
                 const int d = p - c;
@@ -174,14 +182,13 @@ __global__ void __launch_bounds__(64) k_place(PlaceArgs a) {
                 if (MODE == 0) {
                     const uint32_t k = key | hu;
                     if (elig) {
-                        if (cost < best) { best = cost; cnt = 1; bkey = k; }
-                        else if (cost == best) { cnt++; bkey = max(bkey, k); }
+                        if (cost < o.best) { o.best = cost; o.cnt = 1; o.key = k; }
+                        else if (cost == o.best) { o.cnt++; o.key = max(o.key, k); }
                     }
                 } else if (MODE == 1) {
                     const uint32_t bfs = a.dfs2bfs[node_idx];
                     if (q < a.n_queries) a.scores[(uint64_t)q * a.n_nodes + bfs] = (int32_t)(cost + (elig ? 0u : 1u));
-                    node_idx++;
-                } else {
+                } else if (MODE == 2) {
                     const uint32_t bfs = a.dfs2bfs[node_idx];
                     if (elig && cost == want_best) {
                         const uint32_t i = atomicAdd(&a.tie_count[q], 1u);
@@ -190,15 +197,44 @@ __global__ void __launch_bounds__(64) k_place(PlaceArgs a) {
                             a.tie_hu[(uint64_t)q * a.tie_cap + i] = (uint8_t)hu;
                         }
                     }
-                    node_idx++;
+                } else {
+                    if (elig && cost == want_best) { o.cnt++; o.key = max(o.key, key | hu); }
                 }
+                node_idx++;
             }
         }
     }
-    if (MODE == 0) {
-        const uint64_t o = ((uint64_t)tile * a.n_groups + g) * 64 + lane;
-        a.part_best[o] = best; a.part_cnt[o] = cnt; a.part_key[o] = bkey;
+    return o;
+}
+
+template <int MODE>   // 0, 1, 2 (see walk)
+__global__ void __launch_bounds__(64) k_place(PlaceArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t slots[];   // [max_slots][64]
+    const uint32_t lane = threadIdx.x;
+    uint32_t tile, g;
+    {
+        const uint32_t b = blockIdx.x, G = a.n_groups;
+        if ((G & 7u) == 0) {
+            const uint32_t xcd = b & 7u, r = b >> 3, Gx = G >> 3;
+            tile = r / Gx;
+            g = (r % Gx) * 8 + xcd;
+        } else {
+            tile = b / G;
+            g = b % G;
+        }
     }
+    const uint32_t c0 = (uint32_t)(((uint64_t)g * a.n_chunks) / a.n_groups);
+    const uint32_t c1 = (uint32_t)(((uint64_t)(g + 1) * a.n_chunks) / a.n_groups);
+    const uint64_t o = ((uint64_t)tile * a.n_groups + g) * 64 + lane;
+    if (c0 >= c1) {
+        if (MODE == 0) { a.part_best[o] = 0x7fffffffu; a.part_cnt[o] = 0; a.part_key[o] = 0; }
+        return;
+    }
+    const uint32_t q = tile * 64 + lane;
+    uint32_t want_best = 0;
+    if (MODE == 2) want_best = (q < a.n_queries) ? (uint32_t)a.best_in[q] : 0xffffffffu;
+    WalkOut r = walk<MODE>(a, slots, tile, c0, c1, lane, want_best);
+    if (MODE == 0) { a.part_best[o] = r.best; a.part_cnt[o] = r.cnt; a.part_key[o] = r.key; }
 }
 
 // Merge the per-group partial reductions of each sample (usher_mapper.cpp:
@@ -226,13 +262,293 @@ __global__ void k_merge(const uint32_t *__restrict__ part_best, const uint32_t *
     out[q] = r;
 }
 
+// ====================================================================
+// Phase 1: 8 samples per lane, packed 16-bit, minimum only
+// ====================================================================
+//
+// Lane l of the wave that owns 512-sample tile T holds samples T*512 + 8*l + j,
+// j = 0..7 = nibble j of the lane's dword x of a table row.  For a mutation
+// with allele indices (mut, prev):
+//     C = (x >> mut)  & 0x11111111      bit 4j: mut  in S_j
+//     P = (x >> prev) & 0x11111111      bit 4j: prev in S_j
+// and per node three 4-bit-per-sample accumulators  accP += P, accC += C,
+// accN += C & ~P  (flushed every 15 mutations).  At the end of a node they are
+// widened to the packed layout {sample j | sample j+4 << 16}, j = 0..3:
+//     e(acc, j) = (acc >> 4j) & 0x000F000F
+//     D(n)  = D(par) + e(accP) - e(accC)
+//     cost  = D(par) - e(accN)          ineligible samples (common == 0) -> 0xFFFF
+//     best  = min(best, cost)           v_pk_min_u16
+// 16-bit counters are safe because the host only takes this path when
+// max_rows(sample) + max_root_path_mutations(tree) < 0xFFFF.
+
+struct Pk4 { uint32_t v[4]; };
+
+__device__ __forceinline__ uint32_t ex4(uint32_t acc, int j) { return (acc >> (4 * j)) & 0x000F000Fu; }
+
+__global__ void __launch_bounds__(64) k_best8(Best8Args a) {
+    extern __shared__ __attribute__((aligned(16))) uint4 slots8[];   // [max_slots][64] x 16 B saved-D slots
+    const uint32_t lane = threadIdx.x;
+    // Work unit u = (tile, group).  Units are dealt to the 8 XCDs in contiguous
+    // runs (block b is observed to land on XCD b % 8), so one XCD walks few tiles
+    // at a time and their non-reference table rows stay resident in its 4 MiB L2.
+    // Placement affects speed only.
+    uint32_t tile, g;
+    {
+        const uint32_t U = a.n_tiles * a.n_groups, U8 = (U + 7u) >> 3;
+        const uint32_t u = (blockIdx.x & 7u) * U8 + (blockIdx.x >> 3);
+        if (u >= U) return;
+        tile = u / a.n_groups;
+        g = u % a.n_groups;
+    }
+    const uint32_t c0 = (uint32_t)(((uint64_t)g * a.n_chunks) / a.n_groups);
+    const uint32_t c1 = (uint32_t)(((uint64_t)(g + 1) * a.n_chunks) / a.n_groups);
+    if (c0 >= c1) return;
+    const uint32_t *tab = a.table + (uint64_t)tile * a.n_sites * 64 + lane;   // lane's dword of row 0
+    Pk4 dbot;
+    {
+        const uint32_t *db = a.dbottom + (uint64_t)tile * 512 + lane * 8;
+#pragma unroll
+        for (int j = 0; j < 4; j++) dbot.v[j] = (db[j] & 0xFFFFu) | (db[j + 4] << 16);
+    }
+    Pk4 best, dcur, dpar, carryD, carryN, carryC;
+#pragma unroll
+    for (int j = 0; j < 4; j++) { best.v[j] = 0xFFFFFFFFu; dcur.v[j] = 0; dpar.v[j] = 0; carryD.v[j] = 0; carryN.v[j] = 0; carryC.v[j] = 0; }
+    uint32_t accP = 0, accC = 0, accN = 0;
+    uint32_t hdr = 0;          // uniform: header of the open node
+    bool flushed = false;      // uniform
+    uint32_t chunk = c0;       // uniform: chunk whose body is being walked
+    const uint32_t NOPW = H_TAG | H_NOP;
+
+    // One stream word.  x = the lane's dword of the word's table row (unused for headers).
+    auto step = [&](uint32_t w, uint32_t x) {
+        if (w & H_TAG) {
+            if (w & (H_NOP | H_CHUNK_END)) {
+                if (w & H_CHUNK_END) {
+                    uint4 *dst = (uint4 *)(a.lbest + (((uint64_t)chunk * a.n_tiles + tile) * 64 + lane) * 4);
+                    *dst = make_uint4(best.v[0], best.v[1], best.v[2], best.v[3]);
+#pragma unroll
+                    for (int j = 0; j < 4; j++) best.v[j] = 0xFFFFFFFFu;
+                    chunk++;
+                }
+                return;
+            }
+            hdr = w;
+            const uint32_t rslot = w & 63u;
+            if (rslot == RS_REG) {
+#pragma unroll
+                for (int j = 0; j < 4; j++) dpar.v[j] = dcur.v[j];
+            } else if (rslot == RS_BOTTOM) {
+#pragma unroll
+                for (int j = 0; j < 4; j++) dpar.v[j] = dbot.v[j];
+            } else {
+                const uint4 t = slots8[rslot * 64 + lane];
+                dpar.v[0] = t.x; dpar.v[1] = t.y; dpar.v[2] = t.z; dpar.v[3] = t.w;
+            }
+            if (!(w & H_END)) return;
+        } else {
+            const uint32_t mi = (w >> 22) & 3u, pi = (w >> 24) & 3u;
+            const uint32_t C = (x >> mi) & 0x11111111u, P = (x >> pi) & 0x11111111u;
+            accP += P; accC += C; accN += C & ~P;
+            if (w & M_FLUSH) {   // 15 mutations in the 4-bit counters: spill to the packed carries (rare)
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const uint32_t eP = ex4(accP, j), eC = ex4(accC, j), eN = ex4(accN, j);
+                    carryD.v[j] = pk_sub(pk_add(carryD.v[j], eP), eC);   // carries are zero outside a long node
+                    carryN.v[j] = pk_add(carryN.v[j], eN);
+                    carryC.v[j] = pk_add(carryC.v[j], eC);
+                }
+                accP = accC = accN = 0;
+                flushed = true;
+            }
+            if (!(w & M_END)) return;
+        }
+        // ---- end of the open node
+        if (flushed) {   // node with more than 15 mutations (rare): fold the carries in first
+            if (!(hdr & H_SKIPD)) {
+#pragma unroll
+                for (int j = 0; j < 4; j++) dcur.v[j] = pk_add(pk_sub(pk_add(dpar.v[j], ex4(accP, j)), ex4(accC, j)), carryD.v[j]);
+                const uint32_t wslot = (hdr >> 6) & 63u;
+                if (wslot != WS_NONE) slots8[wslot * 64 + lane] = make_uint4(dcur.v[0], dcur.v[1], dcur.v[2], dcur.v[3]);
+            }
+            if (!(hdr & H_NOSCORE)) {
+                const uint32_t freec = (hdr & H_FREE) ? 0x00010001u : 0u;
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const uint32_t cost = pk_sub(pk_sub(dpar.v[j], ex4(accN, j)), carryN.v[j]);
+                    const uint32_t common = pk_add(pk_add(ex4(accC, j), carryC.v[j]), freec);
+                    const uint32_t inelig = pk_sub(pk_min(common, 0x00010001u), 0x00010001u);
+                    best.v[j] = pk_min(best.v[j], cost | inelig);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; j++) { carryD.v[j] = 0; carryN.v[j] = 0; carryC.v[j] = 0; }
+            flushed = false;
+        } else {
+            if (!(hdr & H_SKIPD)) {
+#pragma unroll
+                for (int j = 0; j < 4; j++) dcur.v[j] = pk_sub(pk_add(dpar.v[j], ex4(accP, j)), ex4(accC, j));
+                const uint32_t wslot = (hdr >> 6) & 63u;
+                if (wslot != WS_NONE) slots8[wslot * 64 + lane] = make_uint4(dcur.v[0], dcur.v[1], dcur.v[2], dcur.v[3]);
+            }
+            if (!(hdr & H_NOSCORE)) {
+                const uint32_t freec = (hdr & H_FREE) ? 0x00010001u : 0u;
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const uint32_t cost = pk_sub(dpar.v[j], ex4(accN, j));
+                    const uint32_t common = pk_add(ex4(accC, j), freec);
+                    const uint32_t inelig = pk_sub(pk_min(common, 0x00010001u), 0x00010001u);   // 0xFFFF where no mutation is shared
+                    best.v[j] = pk_min(best.v[j], cost | inelig);
+                }
+            }
+        }
+        accP = accC = accN = 0;
+    };
+
+    // Software pipeline over groups of 8 words, four stages deep:
+    //   group g+3  stream words being fetched (8 lanes x 4 B)
+    //   group g+2  "is this (tile, site) row non-reference?" bits being fetched (8-lane gather, 3 KB bitmap)
+    //   group g+1  table rows in flight, one per word, into X[0..7]; a word whose row is
+    //              reference-everywhere fetches the (hot) row 0 instead and uses a constant
+    //   group g    evaluated
+    // Every load is unconditional and in a fixed order, which keeps the compiler's vmcnt
+    // bookkeeping exact (s_waitcnt vmcnt(N) with the younger loads still in flight).
+    const uint32_t *abm = a.active + (uint64_t)tile * a.active_words;
+    for (int phase = 0; phase < 2; phase++) {
+        const uint32_t *sp = phase == 0 ? a.pre8 : a.stream8;
+        const uint32_t begin = phase == 0 ? a.chunk8_pre_off[c0] : a.chunk8_body_off[c0];
+        const uint32_t end = phase == 0 ? a.chunk8_pre_off[c0 + 1] : a.chunk8_body_off[c1];
+        if (begin >= end) continue;
+        const uint32_t n = end - begin;
+        sp += begin;
+        const uint32_t l8 = lane & 7u;
+        auto load_words = [&](uint32_t off) -> uint32_t {   // words off .. off+7 in lanes 0..7 (replicated x8)
+            const uint32_t i = off + l8;
+            const uint32_t v = sp[i < n ? i : n - 1];
+            return i < n ? v : NOPW;
+        };
+        auto load_bits = [&](uint32_t wv) -> uint32_t {     // per lane: bitmap dword of its word's site
+            const uint32_t site = (wv & H_TAG) ? 0u : (wv & 0x3FFFFFu);
+            return abm[site >> 5];
+        };
+        auto active_mask = [&](uint32_t wv, uint32_t bits) -> uint32_t {   // bit k: word k needs its real row
+            const bool act = !(wv & H_TAG) && ((bits >> (wv & 31u)) & 1u);
+            return (uint32_t)__builtin_amdgcn_ballot_w64(act) & 0xFFu;
+        };
+        uint32_t w0 = load_words(0), w1 = load_words(8), w2 = load_words(16);
+        uint32_t m0 = active_mask(w0, load_bits(w0));
+        uint32_t m1 = active_mask(w1, load_bits(w1));
+        uint32_t X[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const uint32_t w = rdlane(w0, k);
+            X[k] = tab[(uint64_t)(((m0 >> k) & 1u) ? (w & 0x3FFFFFu) : 0u) * 64];
+        }
+        for (uint32_t off = 0; off < n; off += 8) {
+            const uint32_t w3 = load_words(off + 24);
+            const uint32_t b2 = load_bits(w2);
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const uint32_t w = rdlane(w0, k);
+                const uint32_t ref_row = 0x11111111u << ((w >> 26) & 3u);   // every sample carries the reference base
+                step(w, ((m0 >> k) & 1u) ? X[k] : ref_row);
+                const uint32_t wn = rdlane(w1, k);
+                X[k] = tab[(uint64_t)(((m1 >> k) & 1u) ? (wn & 0x3FFFFFu) : 0u) * 64];
+            }
+            m0 = m1;
+            m1 = active_mask(w2, b2);
+            w0 = w1; w1 = w2; w2 = w3;
+        }
+    }
+}
+
+// Global minimum per sample over the chunk-local minima.
+__global__ void k_gbest(const uint32_t *__restrict__ lbest, uint32_t n_chunks, uint32_t n_tiles,
+                        uint32_t *__restrict__ gbest /* [n_tiles][64][4] packed */) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;   // dword index within one chunk's record
+    const uint32_t per_chunk = n_tiles * 256;
+    if (i >= per_chunk) return;
+    uint32_t m = 0xFFFFFFFFu;
+    for (uint32_t c = 0; c < n_chunks; c++) m = pk_min(m, lbest[(uint64_t)c * per_chunk + i]);
+    gbest[i] = m;
+}
+
+__device__ __forceinline__ uint32_t pk_lookup(const uint32_t *packed, uint32_t tile512, uint32_t within) {
+    // sample `within` (0..511) of a tile: lane = within >> 3, nibble j = within & 7 ->
+    // dword (j & 3), half (j >> 2)
+    const uint32_t l = within >> 3, j = within & 7u;
+    const uint32_t w = packed[((uint64_t)tile512 * 64 + l) * 4 + (j & 3u)];
+    return (j >> 2) ? (w >> 16) : (w & 0xFFFFu);
+}
+
+// One thread per (chunk, 64-sample tile): does any of its samples attain its
+// global minimum in this chunk?  If so the pair becomes a phase-2 work item.
+__global__ void k_select(const uint32_t *__restrict__ lbest, const uint32_t *__restrict__ gbest, uint32_t n_chunks,
+                         uint32_t n_tiles, uint32_t n_queries, uint32_t *__restrict__ items,
+                         uint32_t *__restrict__ n_items, uint32_t cap) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t n_t64 = n_tiles * 8;
+    if (i >= (uint64_t)n_chunks * n_t64) return;
+    const uint32_t c = (uint32_t)(i / n_t64), t64 = (uint32_t)(i % n_t64);
+    if ((uint64_t)t64 * 64 >= n_queries) return;
+    // the 64 samples of t64 are lanes (t64&7)*8 .. +8 of tile t64>>3: 32 consecutive dwords
+    const uint64_t off = ((uint64_t)(t64 >> 3) * 64 + (t64 & 7u) * 8) * 4;
+    const uint32_t *lb = lbest + (uint64_t)c * n_tiles * 256 + off;
+    const uint32_t *gb = gbest + off;
+    bool hit = false;
+    for (uint32_t k = 0; k < 32; k++) {
+        const uint32_t x = lb[k] ^ gb[k];
+        const uint32_t q0 = t64 * 64 + (k >> 2) * 8 + (k & 3u);   // low half: nibble (k&3); high half: +4
+        if ((x & 0xFFFFu) == 0 && q0 < n_queries) hit = true;
+        if ((x >> 16) == 0 && q0 + 4 < n_queries) hit = true;
+    }
+    if (hit) {
+        const uint32_t idx = atomicAdd(n_items, 1u);
+        if (idx < cap) items[idx] = c * n_t64 + t64;
+    }
+}
+
+// Phase 2: re-walk only the selected (chunk, 64-sample tile) pairs, one sample
+// per lane, counting the nodes that attain the sample's global minimum and
+// keeping the reference's winner among them (usher_mapper.cpp:476-497).
+__global__ void __launch_bounds__(64) k_ties(PlaceArgs a, const uint32_t *__restrict__ gbest,
+                                             const uint32_t *__restrict__ items, const uint32_t *__restrict__ n_items,
+                                             uint32_t cap, uint32_t n_t64 /* 8 * n_tiles512, as k_select encodes */,
+                                             uint32_t *__restrict__ cnt_out, uint32_t *__restrict__ key_out) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t slots[];
+    const uint32_t lane = threadIdx.x;
+    const uint32_t n = min(*n_items, cap);
+    for (uint32_t it = blockIdx.x; it < n; it += gridDim.x) {
+        const uint32_t item = items[it];
+        const uint32_t c = item / n_t64, t64 = item % n_t64;
+        const uint32_t q = t64 * 64 + lane;
+        const uint32_t want = (q < a.n_queries) ? pk_lookup(gbest, q >> 9, q & 511u) : 0xFFFFFFFFu;
+        WalkOut r = walk<3>(a, slots, t64, c, c + 1, lane, want);
+        if (r.cnt) {
+            atomicAdd(&cnt_out[q], r.cnt);
+            atomicMax(&key_out[q], r.key);
+        }
+    }
+}
+
+__global__ void k_final(const uint32_t *__restrict__ gbest, const uint32_t *__restrict__ cnt, const uint32_t *__restrict__ key,
+                        const uint32_t *__restrict__ rank2bfs, uint32_t n_queries, ugp_result *__restrict__ out) {
+    const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= n_queries) return;
+    ugp_result r;
+    r.best_set_difference = (int32_t)pk_lookup(gbest, q >> 9, q & 511u);
+    r.num_best = cnt[q];
+    r.best_j = rank2bfs[key[q] >> 1];
+    r.best_has_unique = key[q] & 1u;
+    out[q] = r;
+}
+
 // ---------------------------------------------------------------- launchers
 
 hipError_t launch_fill_table(uint32_t *table, const uint8_t *site_ref, uint32_t n_sites, uint64_t total_dwords,
                              hipStream_t s) {
     if (total_dwords == 0) return hipSuccess;
     uint64_t blocks = (total_dwords + 255) / 256;
-    if (blocks > 8192) blocks = 8192;
+    if (blocks > 16384) blocks = 16384;
     hipLaunchKernelGGL(k_fill_table, dim3((uint32_t)blocks), dim3(256), 0, s, table, site_ref, n_sites, total_dwords);
     return hipGetLastError();
 }
@@ -240,11 +556,11 @@ hipError_t launch_fill_table(uint32_t *table, const uint8_t *site_ref, uint32_t 
 hipError_t launch_scatter(uint32_t *table, uint32_t *dbottom, const int32_t *pos, const uint8_t *ref,
                           const uint8_t *nuc, const uint8_t *is_missing, const uint32_t *ent_q,
                           const int32_t *pos2site, uint32_t max_pos, uint32_t n_sites, uint64_t n_ent, uint32_t q_base,
-                          hipStream_t s) {
+                          uint32_t *active, uint32_t active_words, hipStream_t s) {
     if (n_ent == 0) return hipSuccess;
     uint64_t blocks = (n_ent + 255) / 256;
     hipLaunchKernelGGL(k_scatter_entries, dim3((uint32_t)blocks), dim3(256), 0, s, table, dbottom, pos, ref, nuc,
-                       is_missing, ent_q, pos2site, max_pos, n_sites, n_ent, q_base);
+                       is_missing, ent_q, pos2site, max_pos, n_sites, n_ent, q_base, active, active_words);
     return hipGetLastError();
 }
 
@@ -263,6 +579,31 @@ hipError_t launch_merge(const uint32_t *part_best, const uint32_t *part_cnt, con
     if (n_queries == 0) return hipSuccess;
     hipLaunchKernelGGL(k_merge, dim3((n_queries + 255) / 256), dim3(256), 0, s, part_best, part_cnt, part_key,
                        rank2bfs, n_groups, n_queries, out);
+    return hipGetLastError();
+}
+
+hipError_t launch_best8(const Best8Args &a, uint32_t max_slots, hipStream_t s) {
+    const uint32_t blocks = ((a.n_tiles * a.n_groups + 7u) / 8u) * 8u;
+    const size_t lds = (size_t)max_slots * 64 * 16;
+    hipLaunchKernelGGL(k_best8, dim3(blocks), dim3(64), lds, s, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_phase2(const PlaceArgs &a, const uint32_t *lbest, uint32_t *gbest, uint32_t n_tiles512,
+                         uint32_t *items, uint32_t *n_items, uint32_t cap, uint32_t *cnt, uint32_t *key,
+                         const uint32_t *rank2bfs, ugp_result *out, uint32_t max_slots, hipStream_t s) {
+    const uint32_t per_chunk = n_tiles512 * 256;
+    hipLaunchKernelGGL(k_gbest, dim3((per_chunk + 255) / 256), dim3(256), 0, s, lbest, a.n_chunks, n_tiles512, gbest);
+    const uint64_t pairs = (uint64_t)a.n_chunks * n_tiles512 * 8;
+    hipLaunchKernelGGL(k_select, dim3((uint32_t)((pairs + 255) / 256)), dim3(256), 0, s, lbest, gbest, a.n_chunks,
+                       n_tiles512, a.n_queries, items, n_items, cap);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    const size_t lds = (size_t)max_slots * 64 * sizeof(uint32_t);
+    uint32_t blocks = 256 * 16;
+    if ((uint64_t)blocks > pairs) blocks = (uint32_t)pairs;
+    hipLaunchKernelGGL(k_ties, dim3(blocks), dim3(64), lds, s, a, gbest, items, n_items, cap, n_tiles512 * 8, cnt, key);
+    hipLaunchKernelGGL(k_final, dim3((a.n_queries + 255) / 256), dim3(256), 0, s, gbest, cnt, key, rank2bfs, a.n_queries, out);
     return hipGetLastError();
 }
 

@@ -11,8 +11,8 @@ namespace ugp {
 struct PlaceArgs {
     const uint32_t *stream, *pre_stream;
     const uint32_t *chunk_body_off, *chunk_pre_off, *chunk_node_off;
-    const uint32_t *table;     // [n_tiles][n_sites][8]
-    const uint32_t *dbottom;   // [n_tiles*64]
+    const uint32_t *table;     // [ceil(n_tiles/8)][n_sites][64]  (512-sample tile layout)
+    const uint32_t *dbottom;   // [ceil(n_tiles/8)*512]
     uint32_t n_sites, n_chunks, n_groups, n_tiles, n_queries;
     // MODE 0
     uint32_t *part_best, *part_cnt, *part_key;   // [n_tiles][n_groups][64]
@@ -27,12 +27,30 @@ struct PlaceArgs {
     uint32_t tie_cap;
 };
 
+struct Best8Args {
+    const uint32_t *stream8, *pre8;
+    const uint32_t *chunk8_body_off, *chunk8_pre_off;   // [n_chunks+1]
+    const uint32_t *table;     // [n_tiles][n_sites][64]
+    const uint32_t *dbottom;   // [n_tiles*512]
+    uint32_t n_sites, n_chunks, n_groups, n_tiles;   // n_tiles = 512-sample tiles
+    uint32_t max_slots;
+    const uint32_t *active;    // [n_tiles][active_words] bit per site: some sample of the tile is not reference there
+    uint32_t active_words;
+    uint32_t *lbest;           // [n_chunks][n_tiles][64][4] packed u16 pairs
+};
+
+hipError_t launch_best8(const Best8Args &a, uint32_t max_slots, hipStream_t s);
+// a.n_tiles = number of 64-sample tiles; lbest/gbest in the packed 512-tile layout
+hipError_t launch_phase2(const PlaceArgs &a, const uint32_t *lbest, uint32_t *gbest, uint32_t n_tiles512,
+                         uint32_t *items, uint32_t *n_items, uint32_t cap, uint32_t *cnt, uint32_t *key,
+                         const uint32_t *rank2bfs, ugp_result *out, uint32_t max_slots, hipStream_t s);
+
 hipError_t launch_fill_table(uint32_t *table, const uint8_t *site_ref, uint32_t n_sites, uint64_t total_dwords,
                              hipStream_t s);
 hipError_t launch_scatter(uint32_t *table, uint32_t *dbottom, const int32_t *pos, const uint8_t *ref,
                           const uint8_t *nuc, const uint8_t *is_missing, const uint32_t *ent_q,
                           const int32_t *pos2site, uint32_t max_pos, uint32_t n_sites, uint64_t n_ent, uint32_t q_base,
-                          hipStream_t s);
+                          uint32_t *active, uint32_t active_words, hipStream_t s);
 hipError_t launch_place(const PlaceArgs &a, int mode, uint32_t max_slots, hipStream_t s);
 hipError_t launch_merge(const uint32_t *part_best, const uint32_t *part_cnt, const uint32_t *part_key,
                         const uint32_t *rank2bfs, uint32_t n_groups, uint32_t n_queries, ugp_result *out,

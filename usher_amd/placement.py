@@ -99,7 +99,9 @@ class FlatTreeView:
 
     IDS = {"stream": (0, np.uint32), "pre_stream": (1, np.uint32), "chunk_body_off": (2, np.uint32),
            "chunk_pre_off": (3, np.uint32), "chunk_node_off": (4, np.uint32), "pos2site": (5, np.int32),
-           "site_ref": (6, np.uint8), "rank2bfs": (7, np.uint32), "dfs2bfs": (8, np.uint32)}
+           "site_ref": (6, np.uint8), "rank2bfs": (7, np.uint32), "dfs2bfs": (8, np.uint32),
+           "stream8": (10, np.uint32), "pre8_stream": (11, np.uint32), "chunk8_body_off": (12, np.uint32),
+           "chunk8_pre_off": (13, np.uint32)}
 
     def __init__(self, arrays: Dict, chunk_nodes: int = 0):
         L = _lib.lib()
@@ -120,6 +122,8 @@ class FlatTreeView:
             n = C.c_uint64()
             _check(L.ugp_flat_get(h, 9, C.byref(p), C.byref(n)))
             self.max_slots = int(n.value)
+            _check(L.ugp_flat_get(h, 14, C.byref(p), C.byref(n)))
+            self.max_path_muts = int(n.value)
         finally:
             L.ugp_flat_destroy(h)
 
