@@ -145,7 +145,7 @@ def best8_group(flat, nib, dbot, c0, c1):
         if not (hdr & H_NOSCORE8):
             cost = (dpar - accN - (carryN if flushed else 0)) & U16
             common = (accC + (carryC if flushed else 0) + (1 if hdr & H_FREE else 0)) & U16
-            inelig = U16 if common == 0 else 0
+            inelig = 0x8000 if common == 0 else 0   # bit 15 = ineligible flag; valid costs stay below 0x8000
             best = min(best, cost | inelig)
         accP = accC = accN = 0
         flushed = False

@@ -163,9 +163,9 @@ int run_place(ugp_mat *m, ugp_qset *qs, int mode, ugp_result *d_out, int32_t *d_
         const uint64_t nq = std::min<uint64_t>(Q - q0, (uint64_t)kMaxTilesPerLaunch * 64);
         const uint32_t n_tiles = (uint32_t)((nq + 63) / 64);
         const uint32_t n_tiles512 = (uint32_t)((nq + 511) / 512);
-        // 16-bit packed phase 1 is exact while every D / cost stays below 0xFFFF
+        // 16-bit packed phase 1 is exact while every D / cost stays below 0x8000 (bit 15 is the ineligible flag)
         const bool use8 = (mode == 0) && !getenv("UGP_FORCE_V1") &&
-                          (qs->max_rows + f.max_path_muts + 2 < 0xFFFFull);
+                          (qs->max_rows + f.max_path_muts + 2 < 0x7FFFull);
         uint32_t G = pick_groups(m, n_tiles);
         if (use8) {   // one XCD-load of waves per tile once there are >= 8 tiles (see k_best8)
             uint32_t waves = 3072;

@@ -296,6 +296,35 @@ int flatten(const ugp_tree_desc &t, const Options &opt, FlatMat &out, std::strin
     }
     out.chunk8_body_off.push_back((uint32_t)out.stream8.size());
     out.chunk8_pre_off.push_back((uint32_t)out.pre8_stream.size());
+
+    // Renumber the packed stream's slots by access frequency, hottest first: the
+    // kernel keeps the first few in LDS and the cold remainder in a global scratch
+    // (slot use is bell-shaped over the index, a handful of slots take ~95 %).
+    {
+        uint64_t freq[64] = {0};
+        for (uint32_t w : out.stream8) {
+            if (!(w & H_TAG) || (w & (H_CHUNK_END | H_NOP))) continue;
+            uint32_t rs = w & 63u, ws = (w >> 6) & 63u;
+            if (rs < RS_BOTTOM) freq[rs]++;
+            if (ws != WS_NONE) freq[ws]++;
+        }
+        uint32_t order[64], remap[64];
+        for (uint32_t i = 0; i < 64; i++) order[i] = i;
+        std::stable_sort(order, order + out.max_slots, [&](uint32_t a, uint32_t b) { return freq[a] > freq[b]; });
+        for (uint32_t i = 0; i < 64; i++) remap[i] = i;
+        for (uint32_t i = 0; i < out.max_slots; i++) remap[order[i]] = i;
+        auto fix = [&](std::vector<uint32_t> &v) {
+            for (uint32_t &w : v) {
+                if (!(w & H_TAG) || (w & (H_CHUNK_END | H_NOP))) continue;
+                uint32_t rs = w & 63u, ws = (w >> 6) & 63u;
+                if (rs < RS_BOTTOM) rs = remap[rs];
+                if (ws != WS_NONE) ws = remap[ws];
+                w = (w & ~0xFFFu) | rs | (ws << 6);
+            }
+        };
+        fix(out.stream8);
+        fix(out.pre8_stream);
+    }
     return UGP_OK;
 }
 

@@ -38,6 +38,7 @@
 namespace ugp {
 
 typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ uint32_t pk_add(uint32_t a, uint32_t b) {
     return __builtin_bit_cast(uint32_t, __builtin_bit_cast(us2, a) + __builtin_bit_cast(us2, b));
@@ -286,8 +287,13 @@ struct Pk4 { uint32_t v[4]; };
 __device__ __forceinline__ uint32_t ex4(uint32_t acc, int j) { return (acc >> (4 * j)) & 0x000F000Fu; }
 
 __global__ void __launch_bounds__(64) k_best8(Best8Args a) {
-    extern __shared__ __attribute__((aligned(16))) uint4 slots8[];   // [max_slots][64] x 16 B saved-D slots
+    extern __shared__ __attribute__((aligned(16))) u32x4 slots8[];   // [lds_slots][64] x 16 B: the hot saved-D slots
     const uint32_t lane = threadIdx.x;
+    // (All slots stay in LDS: spilling the rarely used ones to global memory would put stores into
+    // the loop, and on gfx9 stores share vmcnt with loads out of order, which makes hipcc wait
+    // vmcnt(0) before every table-row use and destroys the prefetch pipeline.)
+    auto slot_load = [&](uint32_t sl) -> u32x4 { return slots8[sl * 64 + lane]; };
+    auto slot_store = [&](uint32_t sl, u32x4 v) { slots8[sl * 64 + lane] = v; };
     // Work unit u = (tile, group).  Units are dealt to the 8 XCDs in contiguous
     // runs (block b is observed to land on XCD b % 8), so one XCD walks few tiles
     // at a time and their non-reference table rows stay resident in its 4 MiB L2.
@@ -303,7 +309,10 @@ __global__ void __launch_bounds__(64) k_best8(Best8Args a) {
     const uint32_t c0 = (uint32_t)(((uint64_t)g * a.n_chunks) / a.n_groups);
     const uint32_t c1 = (uint32_t)(((uint64_t)(g + 1) * a.n_chunks) / a.n_groups);
     if (c0 >= c1) return;
-    const uint32_t *tab = a.table + (uint64_t)tile * a.n_sites * 64 + lane;   // lane's dword of row 0
+    // table rows through a buffer resource: address = tile base + 4*lane (VGPR) + 256*site (SGPR soffset)
+    const __amdgpu_buffer_rsrc_t trsrc = __builtin_amdgcn_make_buffer_rsrc(
+        (void *)(a.table + (uint64_t)tile * a.n_sites * 64), 0, (int)(a.n_sites * 256u), 0x00020000);
+    const uint32_t lane4 = lane * 4u;
     Pk4 dbot;
     {
         const uint32_t *db = a.dbottom + (uint64_t)tile * 512 + lane * 8;
@@ -341,7 +350,7 @@ __global__ void __launch_bounds__(64) k_best8(Best8Args a) {
 #pragma unroll
                 for (int j = 0; j < 4; j++) dpar.v[j] = dbot.v[j];
             } else {
-                const uint4 t = slots8[rslot * 64 + lane];
+                const u32x4 t = slot_load(rslot);
                 dpar.v[0] = t.x; dpar.v[1] = t.y; dpar.v[2] = t.z; dpar.v[3] = t.w;
             }
             if (!(w & H_END)) return;
@@ -363,21 +372,24 @@ __global__ void __launch_bounds__(64) k_best8(Best8Args a) {
             if (!(w & M_END)) return;
         }
         // ---- end of the open node
-        if (flushed) {   // node with more than 15 mutations (rare): fold the carries in first
+        // A sample is ineligible here when it shares no mutation with the branch (common == 0,
+        // usher_mapper.cpp:454-455) unless the node is "free": z has bit 4j set for such samples
+        // and is turned into a 0x8000 penalty on the 16-bit cost (valid costs stay below 0x8000).
+        if (flushed) {   // node with more than 15 mutations (rare): fold the carries in
             if (!(hdr & H_SKIPD)) {
 #pragma unroll
                 for (int j = 0; j < 4; j++) dcur.v[j] = pk_add(pk_sub(pk_add(dpar.v[j], ex4(accP, j)), ex4(accC, j)), carryD.v[j]);
                 const uint32_t wslot = (hdr >> 6) & 63u;
-                if (wslot != WS_NONE) slots8[wslot * 64 + lane] = make_uint4(dcur.v[0], dcur.v[1], dcur.v[2], dcur.v[3]);
+                if (wslot != WS_NONE) slot_store(wslot, u32x4{dcur.v[0], dcur.v[1], dcur.v[2], dcur.v[3]});
             }
             if (!(hdr & H_NOSCORE)) {
-                const uint32_t freec = (hdr & H_FREE) ? 0x00010001u : 0u;
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
                     const uint32_t cost = pk_sub(pk_sub(dpar.v[j], ex4(accN, j)), carryN.v[j]);
-                    const uint32_t common = pk_add(pk_add(ex4(accC, j), carryC.v[j]), freec);
-                    const uint32_t inelig = pk_sub(pk_min(common, 0x00010001u), 0x00010001u);
-                    best.v[j] = pk_min(best.v[j], cost | inelig);
+                    const uint32_t common = pk_add(ex4(accC, j), carryC.v[j]);
+                    uint32_t pen = 0;
+                    if (!(hdr & H_FREE)) pen = (((common & 0xFFFFu) ? 0u : 0x8000u) | ((common >> 16) ? 0u : 0x80000000u));
+                    best.v[j] = pk_min(best.v[j], cost | pen);
                 }
             }
 #pragma unroll
@@ -388,16 +400,17 @@ __global__ void __launch_bounds__(64) k_best8(Best8Args a) {
 #pragma unroll
                 for (int j = 0; j < 4; j++) dcur.v[j] = pk_sub(pk_add(dpar.v[j], ex4(accP, j)), ex4(accC, j));
                 const uint32_t wslot = (hdr >> 6) & 63u;
-                if (wslot != WS_NONE) slots8[wslot * 64 + lane] = make_uint4(dcur.v[0], dcur.v[1], dcur.v[2], dcur.v[3]);
+                if (wslot != WS_NONE) slot_store(wslot, u32x4{dcur.v[0], dcur.v[1], dcur.v[2], dcur.v[3]});
             }
             if (!(hdr & H_NOSCORE)) {
-                const uint32_t freec = (hdr & H_FREE) ? 0x00010001u : 0u;
+                uint32_t z = accC | (accC >> 1);
+                z |= z >> 2;
+                z = ~z & ((hdr & H_FREE) ? 0u : 0x11111111u);   // bit 4j: sample j shares no mutation with this branch
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
                     const uint32_t cost = pk_sub(dpar.v[j], ex4(accN, j));
-                    const uint32_t common = pk_add(ex4(accC, j), freec);
-                    const uint32_t inelig = pk_sub(pk_min(common, 0x00010001u), 0x00010001u);   // 0xFFFF where no mutation is shared
-                    best.v[j] = pk_min(best.v[j], cost | inelig);
+                    const uint32_t pen = (j == 3 ? (z << 3) : (z << (15 - 4 * j))) & 0x80008000u;
+                    best.v[j] = pk_min(best.v[j], cost | pen);
                 }
             }
         }
@@ -441,7 +454,7 @@ __global__ void __launch_bounds__(64) k_best8(Best8Args a) {
 #pragma unroll
         for (int k = 0; k < 8; k++) {
             const uint32_t w = rdlane(w0, k);
-            X[k] = tab[(uint64_t)(((m0 >> k) & 1u) ? (w & 0x3FFFFFu) : 0u) * 64];
+            X[k] = __builtin_amdgcn_raw_buffer_load_b32(trsrc, lane4, (((m0 >> k) & 1u) ? (w & 0x3FFFFFu) : 0u) << 8, 0);
         }
         for (uint32_t off = 0; off < n; off += 8) {
             const uint32_t w3 = load_words(off + 24);
@@ -452,7 +465,7 @@ __global__ void __launch_bounds__(64) k_best8(Best8Args a) {
                 const uint32_t ref_row = 0x11111111u << ((w >> 26) & 3u);   // every sample carries the reference base
                 step(w, ((m0 >> k) & 1u) ? X[k] : ref_row);
                 const uint32_t wn = rdlane(w1, k);
-                X[k] = tab[(uint64_t)(((m1 >> k) & 1u) ? (wn & 0x3FFFFFu) : 0u) * 64];
+                X[k] = __builtin_amdgcn_raw_buffer_load_b32(trsrc, lane4, (((m1 >> k) & 1u) ? (wn & 0x3FFFFFu) : 0u) << 8, 0);
             }
             m0 = m1;
             m1 = active_mask(w2, b2);
