@@ -154,3 +154,30 @@ def test_edge_cases():
         pl.place(QueryBatch([bad]))
     assert e.value.code == -2
     pl.close()
+
+
+def test_usher_cli_on_gpu_matches_reference(tmp_path):
+    """bin/usher-amd (C++ host + HIP backend through the C ABI) end to end on the in-tree fixture:
+    default add-mode, -n and -p outputs identical to the recorded reference outputs."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "usher_amd", "bin", "usher-amd")
+    pb = os.path.join(SURVEY, "global", "global_assignments.pb")
+    vcf = os.path.join(GOLD, "ref_fixtures", "new_samples.vcf")
+
+    def read(p):
+        with (gzip.open(p, "rt") if p.endswith(".gz") else open(p)) as f:
+            return f.read()
+
+    for flags, sub, files in ((["-u"], "out2", ["placement_stats.tsv", "mutation-paths.txt", "uncondensed-final-tree.nh"]),
+                              (["-n"], "out3", ["placement_stats.tsv", "final-tree.nh"]),
+                              (["-p"], "out4", ["parsimony-scores.tsv", "current-tree.nh"])):
+        d = tmp_path / sub
+        d.mkdir()
+        r = subprocess.run([exe, "-i", pb, "-v", vcf, "-d", str(d)] + flags, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        for name in files:
+            want = os.path.join(SURVEY, "global", sub, name)
+            if not os.path.exists(want):
+                want += ".gz"
+            assert read(str(d / name)) == read(want), (flags, name)

@@ -1,0 +1,113 @@
+"""The usher-compatible front end (C++ host: loaders, VCF ingest, tree update,
+output files) against the recorded reference outputs.  CPU only: the oracle is
+plugged in as the placement backend (tests/host_harness.py)."""
+import gzip
+import os
+import shutil
+
+import pytest
+
+from oracle import refio
+from tests.host_harness import run_usher
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+SURVEY = os.path.join(GOLD, "survey_ref")
+FIX = os.path.join(GOLD, "ref_fixtures")
+
+
+def _read(path):
+    opener = gzip.open if path.endswith(".gz") else open
+    with opener(path, "rt") as f:
+        return f.read()
+
+
+def _pb_semantic(path):
+    with (gzip.open if path.endswith(".gz") else open)(path, "rb") as f:
+        newick, muts, cond, meta = refio.parse_parsimony_pb(f.read())
+    return newick, muts, sorted((k, tuple(v)) for k, v in cond), meta
+
+
+@pytest.fixture(scope="module")
+def global_pb(tmp_path_factory):
+    d = tmp_path_factory.mktemp("build")
+    vcf = str(d / "global_samples.vcf")
+    with gzip.open(os.path.join(FIX, "global_samples.vcf.gz"), "rb") as f, open(vcf, "wb") as o:
+        shutil.copyfileobj(f, o)
+    pb = str(d / "g.pb")
+    rc = run_usher(["-t", os.path.join(FIX, "global_phylo.nh"), "-v", vcf, "-o", pb, "-d", str(d)])
+    assert rc == 0
+    return pb, str(d)
+
+
+def test_build_mat_from_newick_and_vcf(global_pb):
+    """usher -t global_phylo.nh -v global_samples.vcf -o g.pb  (Fitch-Sankoff + condensing + pb writer)."""
+    pb, d = global_pb
+    assert _pb_semantic(pb) == _pb_semantic(os.path.join(SURVEY, "global", "global_assignments.pb"))
+    assert _read(os.path.join(d, "final-tree.nh")) == _read(os.path.join(SURVEY, "global", "build-final-tree.nh"))
+    # and the writer is byte-compatible with the reference's serialisation up to condensed-node order
+    assert os.path.getsize(pb) == os.path.getsize(os.path.join(SURVEY, "global", "global_assignments.pb"))
+
+
+def test_default_add_mode_matches_reference(global_pb, tmp_path):
+    """usher -i g.pb -v new_samples.vcf -u : 1 2 / 1 1 / 0 1 / 1 1 / 0 1, sequential insertion."""
+    pb, _ = global_pb
+    rc = run_usher(["-i", pb, "-v", os.path.join(FIX, "new_samples.vcf"), "-u", "-d", str(tmp_path)])
+    assert rc == 0
+    for name in ("placement_stats.tsv", "mutation-paths.txt", "uncondensed-final-tree.nh"):
+        assert _read(str(tmp_path / name)) == _read(os.path.join(SURVEY, "global", "out2", name)), name
+
+
+def test_no_add_mode_matches_reference(global_pb, tmp_path):
+    pb, _ = global_pb
+    rc = run_usher(["-i", pb, "-v", os.path.join(FIX, "new_samples.vcf"), "-n", "-d", str(tmp_path)])
+    assert rc == 0
+    assert _read(str(tmp_path / "placement_stats.tsv")) == _read(os.path.join(SURVEY, "global", "out3", "placement_stats.tsv"))
+    assert _read(str(tmp_path / "final-tree.nh")) == _read(os.path.join(SURVEY, "global", "out3", "final-tree.nh"))
+
+
+def test_per_node_scores_file_matches_reference(global_pb, tmp_path):
+    pb, _ = global_pb
+    rc = run_usher(["-i", pb, "-v", os.path.join(FIX, "new_samples.vcf"), "-p", "-d", str(tmp_path)])
+    assert rc == 0
+    assert _read(str(tmp_path / "parsimony-scores.tsv")) == _read(os.path.join(SURVEY, "global", "out4", "parsimony-scores.tsv.gz"))
+    assert _read(str(tmp_path / "current-tree.nh")) == _read(os.path.join(SURVEY, "global", "out4", "current-tree.nh"))
+
+
+def test_baseline_config0_tree_plus_new_samples(tmp_path):
+    """BASELINE config 0, literally: usher -t test/global_phylo.nh -v test/new_samples.vcf."""
+    rc = run_usher(["-t", os.path.join(FIX, "global_phylo.nh"), "-v", os.path.join(FIX, "new_samples.vcf"), "-d", str(tmp_path)])
+    assert rc == 0
+    for name in ("placement_stats.tsv", "mutation-paths.txt", "final-tree.nh"):
+        assert _read(str(tmp_path / name)) == _read(os.path.join(SURVEY, "global", "out8", name)), name
+
+
+def test_branchlen2_known_answer(tmp_path):
+    pb = str(tmp_path / "t.pb")
+    rc = run_usher(["-t", os.path.join(FIX, "testBranchLen2.nwk"), "-v", os.path.join(FIX, "testBranchLen2.vcf"), "-o", pb, "-l", "-d", str(tmp_path)])
+    assert rc == 0
+    assert _read(str(tmp_path / "final-tree.nh")) == _read(os.path.join(SURVEY, "branchlen2", "final-tree.nh"))
+    assert open(pb, "rb").read() == open(os.path.join(SURVEY, "branchlen2", "tbl2.pb"), "rb").read()
+
+
+def test_syn_no_add_stats_with_imputed_mutations(tmp_path):
+    rc = run_usher(["-i", os.path.join(SURVEY, "syn", "tree.pb"), "-v", os.path.join(SURVEY, "syn", "query.vcf"), "-n", "-d", str(tmp_path)])
+    assert rc == 0
+    assert _read(str(tmp_path / "placement_stats.tsv")) == _read(os.path.join(SURVEY, "syn", "o3", "placement_stats.tsv"))
+
+
+def test_pb_round_trip_and_gz(tmp_path):
+    src = os.path.join(SURVEY, "syn", "tree.pb")
+    out = str(tmp_path / "o.pb.gz")
+    rc = run_usher(["-i", src, "-v", os.path.join(SURVEY, "syn", "query.vcf"), "-n", "-o", out, "-d", str(tmp_path)])
+    assert rc == 0
+    a, b = _pb_semantic(src), _pb_semantic(out)
+    assert a[0] == b[0] and a[1] == b[1]
+
+
+def test_cli_flag_surface(tmp_path):
+    assert run_usher(["--version"]) == 0
+    assert run_usher(["--help"]) == 0
+    assert run_usher(["-i", "x.pb"]) == 1                       # --vcf is required
+    assert run_usher(["-v", "x.vcf"]) == 1                      # no tree / MAT
+    assert run_usher(["-i", os.path.join(SURVEY, "syn", "tree.pb"), "-v", os.path.join(SURVEY, "syn", "query.vcf"), "-r", "-d", str(tmp_path)]) == 1
+    assert run_usher(["-i", os.path.join(SURVEY, "syn", "tree.pb"), "-v", os.path.join(SURVEY, "syn", "query.vcf"), "-p", "-M", "2", "-d", str(tmp_path)]) == 1

@@ -1,0 +1,152 @@
+// cli.cpp -- command line of the usher-compatible front end: the 22 flags of the
+// reference's src/usher.cpp:47-86 (+ --version / --help), tree / MAT / VCF
+// loading (usher.cpp:132-173) and the call into the driver (usher.cpp:175-178).
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "driver.hpp"
+
+#define UH_VERSION "0.7.0-amd"
+
+namespace uh {
+
+static const char *kHelp =
+    "Options:\n"
+    "  -v [ --vcf ] arg                          Input VCF file (in uncompressed or gzip-compressed .gz format) [REQUIRED]\n"
+    "  -t [ --tree ] arg                         Input tree file\n"
+    "  -d [ --outdir ] arg (=.)                  Output directory to dump output and log files [DEFAULT uses current directory]\n"
+    "  -i [ --load-mutation-annotated-tree ] arg Load mutation-annotated tree object\n"
+    "  -o [ --save-mutation-annotated-tree ] arg Save output mutation-annotated tree object to the specified filename\n"
+    "  -s [ --sort-before-placement-1 ]          Sort new samples based on computed parsimony score and then number of optimal placements before the actual placement [EXPERIMENTAL].\n"
+    "  -S [ --sort-before-placement-2 ]          Sort new samples based on the number of optimal placements and then the parsimony score before the actual placement [EXPERIMENTAL].\n"
+    "  -A [ --sort-before-placement-3 ]          Sort new samples based on the number of ambiguous bases [EXPERIMENTAL].\n"
+    "  -r [ --reverse-sort ]                     Reverse the sorting order of sorting options [EXPERIMENTAL]\n"
+    "  -c [ --collapse-tree ]                    Collapse internal nodes of the input tree with no mutations and condense identical sequences (not supported by this build)\n"
+    "  -C [ --collapse-output-tree ]             Collapse internal nodes of the output tree with no mutations (not supported by this build)\n"
+    "  -e [ --max-uncertainty-per-sample ] arg (=1000000) Maximum number of equally parsimonious placements allowed per sample beyond which the sample is ignored\n"
+    "  -E [ --max-parsimony-per-sample ] arg (=1000000)   Maximum parsimony score of the most parsimonious placement(s) allowed per sample beyond which the sample is ignored\n"
+    "  -u [ --write-uncondensed-final-tree ]     Write the final tree in uncondensed format and save to file uncondensed-final-tree.nh in outdir\n"
+    "  -k [ --write-subtrees-size ] arg (=0)     Write minimum set of subtrees covering the newly added samples (not supported by this build)\n"
+    "  -K [ --write-single-subtree ] arg (=0)    Similar to write-subtrees-size but produces a single subtree (not supported by this build)\n"
+    "  -p [ --write-parsimony-scores-per-node ]  Write the parsimony scores for adding new samples at each existing node in the tree without modifying the tree in a file names parsimony-scores.tsv in outdir\n"
+    "  -M [ --multiple-placements ] arg (=1)     Create a new tree up to this limit for each possibility of parsimony-optimal placement (only 1 supported by this build)\n"
+    "  -l [ --retain-input-branch-lengths ]      Retain the branch lengths from the input tree in out newick files instead of using number of mutations for the branch lengths.\n"
+    "  -n [ --no-add ]                           Do not add new samples to the tree\n"
+    "  -D [ --detailed-clades ]                  In clades.txt, write a histogram of annotated clades and counts across all equally parsimonious placements\n"
+    "  -T [ --threads ] arg                      Number of host threads (the node x sample search runs on the GPU)\n"
+    "  --device arg (=0)                         HIP device ordinal\n"
+    "  --version                                 Print version number\n"
+    "  -h [ --help ]                             Print help messages\n";
+
+// Returns 0 to continue, 1 = exit with error, 2 = exit(0) (help / version).
+static int parse(int argc, char **argv, Options &o) {
+    struct Spec { char s; const char *l; int kind; };   // kind 0 flag, 1 string/number value
+    static const Spec specs[] = {
+        {'v', "vcf", 1}, {'t', "tree", 1}, {'d', "outdir", 1}, {'i', "load-mutation-annotated-tree", 1},
+        {'o', "save-mutation-annotated-tree", 1}, {'s', "sort-before-placement-1", 0}, {'S', "sort-before-placement-2", 0},
+        {'A', "sort-before-placement-3", 0}, {'r', "reverse-sort", 0}, {'c', "collapse-tree", 0}, {'C', "collapse-output-tree", 0},
+        {'e', "max-uncertainty-per-sample", 1}, {'E', "max-parsimony-per-sample", 1}, {'u', "write-uncondensed-final-tree", 0},
+        {'k', "write-subtrees-size", 1}, {'K', "write-single-subtree", 1}, {'p', "write-parsimony-scores-per-node", 0},
+        {'M', "multiple-placements", 1}, {'l', "retain-input-branch-lengths", 0}, {'n', "no-add", 0}, {'D', "detailed-clades", 0},
+        {'T', "threads", 1}, {0, "device", 1}, {0, "version", 0}, {'h', "help", 0}};
+    bool version = false, help = false, bad = false;
+    auto apply = [&](const Spec &sp, const char *val) {
+        const std::string l = sp.l;
+        auto num = [&](const char *v) { return strtoull(v, nullptr, 10); };
+        if (l == "vcf") o.vcf = val; else if (l == "tree") o.tree = val; else if (l == "outdir") o.outdir = val;
+        else if (l == "load-mutation-annotated-tree") o.load_mat = val; else if (l == "save-mutation-annotated-tree") o.save_mat = val;
+        else if (l == "sort-before-placement-1") o.sort1 = true; else if (l == "sort-before-placement-2") o.sort2 = true;
+        else if (l == "sort-before-placement-3") o.sort3 = true; else if (l == "reverse-sort") o.reverse_sort = true;
+        else if (l == "collapse-tree") o.collapse_tree = true; else if (l == "collapse-output-tree") o.collapse_output_tree = true;
+        else if (l == "max-uncertainty-per-sample") o.max_uncertainty = (uint32_t)num(val);
+        else if (l == "max-parsimony-per-sample") o.max_parsimony = (uint32_t)num(val);
+        else if (l == "write-uncondensed-final-tree") o.write_uncondensed = true;
+        else if (l == "write-subtrees-size") o.subtrees_size = num(val); else if (l == "write-single-subtree") o.subtrees_single = num(val);
+        else if (l == "write-parsimony-scores-per-node") o.print_scores = true; else if (l == "multiple-placements") o.max_trees = (uint32_t)num(val);
+        else if (l == "retain-input-branch-lengths") o.retain_branch_len = true; else if (l == "no-add") o.no_add = true;
+        else if (l == "detailed-clades") o.detailed_clades = true; else if (l == "threads") o.threads = (uint32_t)num(val);
+        else if (l == "device") o.device = (int)num(val); else if (l == "version") version = true; else if (l == "help") help = true;
+    };
+    for (int i = 1; i < argc && !bad; i++) {
+        const std::string a = argv[i];
+        const Spec *sp = nullptr;
+        const char *val = nullptr;
+        std::string inline_val;
+        if (a.size() > 2 && a[0] == '-' && a[1] == '-') {
+            std::string name = a.substr(2);
+            size_t eq = name.find('=');
+            if (eq != std::string::npos) { inline_val = name.substr(eq + 1); name = name.substr(0, eq); val = inline_val.c_str(); }
+            for (const Spec &s : specs) if (name == s.l) sp = &s;
+        } else if (a.size() >= 2 && a[0] == '-') {
+            for (const Spec &s : specs) if (s.s && a[1] == s.s) sp = &s;
+            if (sp && a.size() > 2) {
+                if (sp->kind == 1) { inline_val = a.substr(2); val = inline_val.c_str(); }
+                else {   // stuck switches, e.g. -un
+                    for (size_t k = 1; k < a.size(); k++) {
+                        const Spec *f = nullptr;
+                        for (const Spec &s : specs) if (s.s && a[k] == s.s && s.kind == 0) f = &s;
+                        if (!f) { bad = true; break; }
+                        apply(*f, nullptr);
+                    }
+                    continue;
+                }
+            }
+        }
+        if (!sp) { bad = true; break; }
+        if (sp->kind == 1 && !val) {
+            if (i + 1 >= argc) { bad = true; break; }
+            val = argv[++i];
+        }
+        apply(*sp, val);
+    }
+    if (version) { printf("UShER (v%s)\n", UH_VERSION); if (o.vcf.empty() || bad || help) return 2; }
+    if (help || bad || o.vcf.empty()) {   // usher.cpp:92-107
+        if (!version) { fprintf(stderr, "UShER (v%s)\n", UH_VERSION); fprintf(stderr, "%s\n", kHelp); }
+        return (help || version) ? 2 : 1;
+    }
+    return 0;
+}
+
+int usher_main(int argc, char **argv, const Backend &be) {
+    Options opt;
+    int pr = parse(argc, argv, opt);
+    if (pr == 2) return 0;
+    if (pr == 1) return 1;
+    Tree T;
+    std::vector<MissingSample> missing;
+    std::string err;
+    if (!opt.tree.empty()) {                                                    // usher.cpp:132-149
+        fprintf(stderr, "Loading input tree.\n");
+        FILE *f = fopen(opt.tree.c_str(), "r");
+        if (!f) { fprintf(stderr, "ERROR: Could not open the tree file: %s!\n", opt.tree.c_str()); return 1; }
+        std::string nwk;
+        int c;
+        while ((c = fgetc(f)) != EOF && c != '\n') nwk += (char)c;
+        fclose(f);
+        if (!tree_from_newick(nwk, T, err)) { fprintf(stderr, "ERROR: %s!\n", err.c_str()); return 1; }
+        if (!T.root) { fprintf(stderr, "ERROR: Empty tree.\n"); return 1; }
+        fprintf(stderr, "Loading VCF file.\nComputing parsimonious assignments for input variants.\n");
+        if (!read_vcf_build(T, opt.vcf, missing, err)) { fprintf(stderr, "%s\n", err.c_str()); return 1; }
+    } else if (!opt.load_mat.empty()) {                                         // usher.cpp:151-170
+        fprintf(stderr, "Loading existing mutation-annotated tree object from file %s\n", opt.load_mat.c_str());
+        if (!load_mat(opt.load_mat, T, err)) { fprintf(stderr, "%s\n", err.c_str()); return 1; }
+        if (!T.root) { fprintf(stderr, "ERROR: Empty tree.\n"); return 1; }
+        fprintf(stderr, "Loading VCF file\n");
+        if (!read_vcf_missing(T, opt.vcf, missing, err)) { fprintf(stderr, "%s\n", err.c_str()); return 1; }
+    } else {
+        fprintf(stderr, "Error! No input tree or assignment file provided!\n");
+        return 1;
+    }
+    return run_usher(opt, T, missing, be);
+}
+
+}  // namespace uh
+
+// C entry for tests: the same front end with a caller-supplied placement backend.
+extern "C" int uh_usher_main(int argc, char **argv, const uh::Backend *be) {
+    if (!be || !be->place) { fprintf(stderr, "ERROR: no placement backend\n"); return 1; }
+    return uh::usher_main(argc, argv, *be);
+}

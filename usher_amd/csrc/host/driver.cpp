@@ -1,0 +1,492 @@
+// driver.cpp -- usher-compatible placement driver.  Written from scratch; the
+// behaviour (messages, file formats, ordering rules) follows the reference's
+// src/usher_common.cpp, cited inline.
+#include "driver.hpp"
+
+#include <sys/stat.h>
+#include <sys/time.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <numeric>
+#include <unordered_map>
+
+namespace uh {
+
+namespace {
+
+struct Timer {   // usher_graph.hpp:15-31
+    timeval t0;
+    void start() { gettimeofday(&t0, nullptr); }
+    long stop() const {
+        timeval t1;
+        gettimeofday(&t1, nullptr);
+        return (long)((t1.tv_sec - t0.tv_sec) * 1000 + (t1.tv_usec - t0.tv_usec) / 1000.0 + 0.5);
+    }
+};
+
+// Flat BFS arrays of the current tree: the ugp_tree_desc the backend takes.
+struct FlatTree {
+    std::vector<Node *> bfs;
+    std::vector<uint32_t> parent;
+    std::vector<uint64_t> mut_off;
+    std::vector<int32_t> pos;
+    std::vector<uint8_t> ref, par, nuc;
+    ugp_tree_desc desc{};
+    void build(const Tree &T) {
+        bfs = T.bfs();
+        std::unordered_map<const Node *, uint32_t> idx;
+        idx.reserve(bfs.size() * 2);
+        for (uint32_t j = 0; j < bfs.size(); j++) idx[bfs[j]] = j;
+        parent.assign(bfs.size(), UINT32_MAX);
+        mut_off.assign(bfs.size() + 1, 0);
+        pos.clear(); ref.clear(); par.clear(); nuc.clear();
+        for (uint32_t j = 0; j < bfs.size(); j++) {
+            if (bfs[j]->parent) parent[j] = idx[bfs[j]->parent];
+            for (const Mutation &m : bfs[j]->mutations) {
+                pos.push_back(m.position); ref.push_back((uint8_t)m.ref_nuc);
+                par.push_back((uint8_t)m.par_nuc); nuc.push_back((uint8_t)m.mut_nuc);
+            }
+            mut_off[j + 1] = pos.size();
+        }
+        desc.n_nodes = bfs.size(); desc.parent = parent.data(); desc.mut_off = mut_off.data();
+        desc.mut_pos = pos.data(); desc.mut_ref = ref.data(); desc.mut_par = par.data(); desc.mut_nuc = nuc.data();
+    }
+};
+
+struct FlatQueries {
+    std::vector<uint64_t> ent_off{0};
+    std::vector<int32_t> pos;
+    std::vector<uint8_t> ref, nuc, miss;
+    ugp_queries desc{};
+    void add(const std::vector<Mutation> &muts) {
+        for (const Mutation &m : muts) {
+            pos.push_back(m.position); ref.push_back((uint8_t)m.ref_nuc);
+            nuc.push_back((uint8_t)m.mut_nuc); miss.push_back(m.is_missing ? 1 : 0);
+        }
+        ent_off.push_back(pos.size());
+    }
+    void finish() {
+        desc.n_queries = ent_off.size() - 1; desc.ent_off = ent_off.data(); desc.pos = pos.data();
+        desc.ref = ref.data(); desc.nuc = nuc.data(); desc.is_missing = miss.data();
+    }
+};
+
+bool by_pos(const Mutation &a, const Mutation &b) { return a.position < b.position; }
+
+}  // namespace
+
+// ---------------------------------------------------------------------------
+// mapper2_body(inp, true, true) for ONE node: used for the winning node only
+// (what pass 2 does, usher_common.cpp:426-449) and for the optimal rows of -p.
+// ---------------------------------------------------------------------------
+void node_vecs(const Node *node, const std::vector<Mutation> &sample, NodeVecs &out) {
+    out.excess.clear(); out.imputed.clear(); out.set_difference = 0; out.has_unique = false;
+    std::vector<Mutation> anc;                 // ancestral_mutations (usher_mapper.cpp:178-179)
+    auto anc_has = [&](int32_t p) { for (const Mutation &m : anc) if (m.position == p) return true; return false; };
+    if (!node->is_root()) {                    // branch loop, :190-264
+        size_t start = 0;
+        for (const Mutation &m1 : node->mutations) {
+            if (m1.masked()) { out.has_unique = true; break; }                 // :197-200
+            bool found = false, found_pos = false;
+            for (size_t k = start; k < sample.size(); k++) {
+                const Mutation &m2 = sample[k];
+                start = k;
+                if (m1.position == m2.position) {
+                    found_pos = true;
+                    if (m2.is_missing) found = true;                           // :209-211
+                    else if (m2.mut_nuc & m1.mut_nuc) {                        // :214-235
+                        Mutation m = m1; m.is_missing = false;
+                        anc.push_back(m); out.excess.push_back(m);
+                        found = true;
+                        break;
+                    }
+                }
+                if (m1.position < m2.position) break;
+            }
+            if (!found) {
+                if (!found_pos && m1.mut_nuc == m1.ref_nuc) {                  // :244-259
+                    Mutation m = m1; m.is_missing = false;
+                    anc.push_back(m); out.excess.push_back(m);
+                } else out.has_unique = true;
+            }
+        }
+    } else {
+        for (const Mutation &m : node->mutations) anc.push_back(m);            // :266-269
+    }
+    for (const Node *a = node->parent; a; a = a->parent)                       // :275-286
+        for (const Mutation &m : a->mutations)
+            if (!m.masked() && !anc_has(m.position)) anc.push_back(m);
+    std::sort(anc.begin(), anc.end(), by_pos);                                 // :289
+    for (const Mutation &m1 : sample) {                                        // :292-388
+        if (m1.is_missing) continue;
+        bool found_pos = false, found = false;
+        const bool has_ref = (m1.mut_nuc & m1.ref_nuc) != 0;
+        int8_t anc_nuc = m1.ref_nuc;
+        for (const Mutation &m2 : anc) {
+            if (m2.masked()) continue;
+            if (m1.position == m2.position) {
+                found_pos = true; anc_nuc = m2.mut_nuc;
+                if (m1.mut_nuc & anc_nuc) found = true;
+                break;
+            }
+        }
+        const bool ambiguous = (m1.mut_nuc & (m1.mut_nuc - 1)) != 0;
+        Mutation m = m1; m.is_missing = false; m.par_nuc = anc_nuc;
+        if (found) {
+            if (ambiguous) { m.mut_nuc = anc_nuc; out.imputed.push_back(m); }              // :322-335
+        } else if (!found_pos && has_ref) {
+            if (ambiguous) { m.mut_nuc = m1.ref_nuc; out.imputed.push_back(m); }           // :341-351
+        } else {                                                                             // :356-387
+            if (has_ref) m.mut_nuc = m1.ref_nuc;
+            else { m.mut_nuc = 0; for (int b = 0; b < 4; b++) if (m1.mut_nuc & (1 << b)) { m.mut_nuc = (int8_t)(1 << b); break; } }
+            if (ambiguous) out.imputed.push_back(m);
+            if (m.mut_nuc != m.par_nuc) { out.excess.push_back(m); out.set_difference++; }
+        }
+    }
+    for (const Mutation &m1 : anc) {                                           // back-mutations, :393-445
+        if (m1.masked()) continue;   // masked root entries: ref == par == 0, never counted (:428-436)
+        bool found = false, found_pos = false;
+        for (const Mutation &m2 : sample) {
+            if (m1.position == m2.position) {
+                found_pos = true;
+                if (m2.is_missing) { found = true; break; }
+                if (m2.mut_nuc & m1.mut_nuc) found = true;
+            }
+        }
+        if (found || found_pos) continue;
+        if (m1.mut_nuc == m1.ref_nuc) continue;
+        Mutation m = m1; m.par_nuc = m1.mut_nuc; m.mut_nuc = m1.ref_nuc; m.is_missing = false;
+        out.excess.push_back(m);
+        out.set_difference++;
+    }
+}
+
+// ---------------------------------------------------------------------------
+
+static bool write_text(const std::string &path, const std::string &text) {
+    FILE *f = fopen(path.c_str(), "w");
+    if (!f) return false;
+    fwrite(text.data(), 1, text.size(), f);
+    fclose(f);
+    return true;
+}
+
+// Insert `sample` next to / below `best` (usher_common.cpp:652-765).
+static void insert_sample(Tree &T, Node *best, bool as_sibling, const std::string &sample, const std::vector<Mutation> &excess) {
+    auto matches = [](const Mutation &a, const Mutation &b) { return a.position == b.position && a.mut_nuc == b.mut_nuc; };
+    if (as_sibling) {                                                           // :654-729
+        const std::string nid = T.new_internal_node_id();
+        Node *mid = T.create_node(nid, best->parent);
+        Node *leaf = T.create_node(sample, mid);
+        T.reattach(best, mid);                                                  // move_node(best, nid): children = [sample, best]
+        const std::vector<Mutation> branch = best->mutations;
+        best->mutations.clear();
+        std::vector<Mutation> common, l1, l2;
+        for (const Mutation &m1 : branch) {                                     // :677-694
+            bool found = false;
+            if (!m1.masked()) for (const Mutation &m2 : excess) if (matches(m1, m2)) { found = true; break; }
+            if (!found) l1.push_back(m1);
+        }
+        for (const Mutation &m1 : excess) {                                     // :696-715
+            bool found = false;
+            if (!m1.masked()) for (const Mutation &m2 : branch) if (matches(m1, m2)) { found = true; break; }
+            (found ? common : l2).push_back(m1);
+        }
+        for (const Mutation &m : common) mid->add_mutation(m);
+        for (const Mutation &m : l1) best->add_mutation(m);
+        for (const Mutation &m : l2) leaf->add_mutation(m);
+    } else {                                                                    // :731-764
+        Node *leaf = T.create_node(sample, best);
+        for (const Mutation &m1 : excess) {
+            bool found = false;
+            if (!m1.masked()) for (const Mutation &m2 : best->mutations) if (matches(m1, m2)) { found = true; break; }
+            if (!found) leaf->add_mutation(m1);
+        }
+    }
+}
+
+int run_usher(const Options &opt, Tree &T, std::vector<MissingSample> &missing, const Backend &be) {
+    // ---- option validation, usher_common.cpp:14-77
+    if (opt.subtrees_size == 1) { fprintf(stderr, "ERROR: print-subtrees-size should be larger than 1\n"); return 1; }
+    if ((int)opt.sort1 + (int)opt.sort2 + (int)opt.sort3 > 1) {
+        fprintf(stderr, "ERROR: Can't use two or more of sort-before-placement-1, sort-before-placement-2 and sort-before-placement-3 simultaneously. Please specify only one.\n");
+        return 1;
+    }
+    if (opt.sort1 || opt.sort2 || opt.sort3) {
+        fprintf(stderr, "WARNING: Using experimental option %s\n", opt.sort1 ? "--sort-before-placement-1 (-s)" : opt.sort2 ? "--sort-before-placement-2 (-S)" : "--sort-before-placement-3 (-A)");
+    } else if (opt.reverse_sort) {
+        fprintf(stderr, "ERROR: Can't use reverse-sort without sorting options (sort-before-placement-1 or sort-before-placement-2 or sort-before-placement-3)\n");
+        return 1;
+    }
+    if (opt.print_scores) {
+        if (opt.max_trees > 1) { fprintf(stderr, "ERROR: cannot use --multiple-placements (-M) and --print_parsimony_scores (-p) options simulaneously.\n"); return 1; }
+        if (opt.sort1 || opt.sort2 || opt.sort3 || opt.collapse_tree || opt.collapse_output_tree || opt.write_uncondensed || opt.subtrees_size > 0 || !opt.save_mat.empty())
+            fprintf(stderr, "WARNING: --print-parsimony-scores-per-node is set. Will terminate without modifying the original tree.\n");
+    }
+    if (opt.max_trees == 0) { fprintf(stderr, "ERROR: Number of trees specified by --multiple-placements (-M) should be >= 1\n"); return 1; }
+    if (opt.no_add && (opt.subtrees_size > 0 || opt.subtrees_single)) { fprintf(stderr, "ERROR: Sorry, cannot output subtrees when -n/--no-add is specified.\n"); return 1; }
+    // features of the reference front end that this build does not provide yet
+    if (opt.max_trees > 1) { fprintf(stderr, "ERROR: --multiple-placements > 1 is not supported by this build.\n"); return 1; }
+    if (opt.collapse_tree || opt.collapse_output_tree) { fprintf(stderr, "ERROR: --collapse-tree / --collapse-output-tree are not supported by this build.\n"); return 1; }
+    if (opt.subtrees_size > 0 || opt.subtrees_single > 0) { fprintf(stderr, "ERROR: --write-subtrees-size / --write-single-subtree are not supported by this build.\n"); return 1; }
+
+    if (opt.retain_branch_len) fprintf(stderr, "Output newick files will retain branch lengths from the input tree (unspecified at branches modified during the placement).\n\n");
+    else fprintf(stderr, "Output newick files will have branch lengths equal to the number of mutations of that branch.\n\n");
+
+    std::string outdir = opt.outdir;
+    struct stat sb;
+    if (stat(outdir.c_str(), &sb) != 0) {
+        fprintf(stderr, "Creating output directory.\n\n");
+        if (mkdir(outdir.c_str(), 0777) != 0) { fprintf(stderr, "ERROR: cannot create %s\n", outdir.c_str()); return 1; }
+    }
+    Timer timer;
+    fprintf(stderr, "Found %zu missing samples.\n\n", missing.size());
+    std::vector<std::string> low_confidence;
+    auto be_fail = [&](const char *what) {
+        fprintf(stderr, "ERROR: %s failed: %s\n", what, be.last_error ? be.last_error(be.ctx) : "?");
+        return 1;
+    };
+
+    if (opt.sort3) {                                                            // :150-159
+        std::stable_sort(missing.begin(), missing.end(), [](const MissingSample &a, const MissingSample &b) { return a.num_ambiguous < b.num_ambiguous; });
+        if (opt.reverse_sort) std::reverse(missing.begin(), missing.end());
+    }
+
+    uint64_t tree_version = 1;
+    FlatTree flat;
+    if (!missing.empty()) {
+        std::vector<size_t> indexes(missing.size());
+        std::iota(indexes.begin(), indexes.end(), 0);
+        // The reference sorts sample rows only in the -s/-S pre-pass (:203); its scans need sorted
+        // rows to mean what they say, VCF rows are sorted by position, and the backend requires it.
+        for (auto &ms : missing) std::stable_sort(ms.mutations.begin(), ms.mutations.end(), by_pos);
+
+        const bool static_tree = opt.print_scores || opt.no_add;
+        std::vector<ugp_result> batch_res;
+        std::vector<int32_t> batch_scores;
+        FlatQueries allq;
+        for (auto &ms : missing) allq.add(ms.mutations);
+        allq.finish();
+
+        if (opt.print_scores) {                                                 // :176-185
+            timer.start();
+            const std::string fn = outdir + "/current-tree.nh";
+            fprintf(stderr, "Writing current tree with internal nodes labelled to file %s \n", fn.c_str());
+            write_text(fn, newick(T, T.root, true, true) + "\n");
+            fprintf(stderr, "Completed in %ld msec \n\n", timer.stop());
+        } else if ((opt.sort1 || opt.sort2) && missing.size() > 1) {            // :187-301
+            timer.start();
+            fprintf(stderr, "Computing parsimony scores and number of parsimony-optimal placements for new samples and using them to sort the samples.\n");
+            flat.build(T);
+            std::vector<ugp_result> r(missing.size());
+            if (be.place(be.ctx, &flat.desc, tree_version, &allq.desc, r.data()) != 0) return be_fail("placement");
+            auto key1 = [&](size_t i) { return std::make_pair((int64_t)r[i].best_set_difference, (int64_t)r[i].num_best); };
+            auto key2 = [&](size_t i) { return std::make_pair((int64_t)r[i].num_best, (int64_t)r[i].best_set_difference); };
+            if (opt.sort1) std::stable_sort(indexes.begin(), indexes.end(), [&](size_t a, size_t b) { return key1(a) < key1(b); });
+            else std::stable_sort(indexes.begin(), indexes.end(), [&](size_t a, size_t b) { return key2(a) < key2(b); });
+            if (opt.reverse_sort) std::reverse(indexes.begin(), indexes.end());
+            fprintf(stderr, "Completed in %ld msec \n\n", timer.stop());
+        }
+        if (!opt.print_scores) fprintf(stderr, "Adding missing samples to the tree.\n");
+
+        if (static_tree) {   // the tree never changes: one batch call serves every sample
+            flat.build(T);
+            batch_res.resize(missing.size());
+            if (be.place(be.ctx, &flat.desc, tree_version, &allq.desc, batch_res.data()) != 0) return be_fail("placement");
+            if (opt.print_scores) {
+                batch_scores.resize(missing.size() * flat.bfs.size());
+                if (be.scores(be.ctx, &flat.desc, tree_version, &allq.desc, batch_scores.data()) != 0) return be_fail("per-node scoring");
+            }
+        }
+
+        FILE *stats = fopen((outdir + "/placement_stats.tsv").c_str(), "w");
+        if (!stats) { fprintf(stderr, "ERROR: cannot write to %s\n", outdir.c_str()); return 1; }
+        FILE *scores_file = nullptr;
+        for (size_t ii = 0; ii < indexes.size(); ii++) {                        // :310
+            timer.start();
+            const size_t s = indexes[ii];
+            MissingSample &ms = missing[s];
+            if (T.get_node(ms.name)) { fprintf(stderr, "WARNING: Sample %s already in the tree! Ignoring.\n\n", ms.name.c_str()); continue; }
+            if (!static_tree) flat.build(T);                                    // :342 (the reference also re-expands per sample)
+            const size_t total_nodes = flat.bfs.size();
+            if (opt.print_scores && s == 0) {                                   // :331-340
+                const std::string fn = outdir + "/parsimony-scores.tsv";
+                fprintf(stderr, "\nNow computing branch parsimony scores for adding the missing samples at each of the %zu nodes in the existing tree without modifying the tree.\n", total_nodes);
+                fprintf(stderr, "The branch parsimony scores will be written to file %s\n\n", fn.c_str());
+                scores_file = fopen(fn.c_str(), "w");
+                if (scores_file) fprintf(scores_file, "#Sample\tTree node\tParsimony score\tOptimal (y/n)\tParsimony-increasing mutations (for optimal nodes)\n");
+            }
+            ugp_result r;
+            if (static_tree) r = batch_res[s];
+            else {
+                FlatQueries q1;
+                q1.add(ms.mutations);
+                q1.finish();
+                if (be.place(be.ctx, &flat.desc, tree_version, &q1.desc, &r) != 0) { fclose(stats); return be_fail("placement"); }
+            }
+            const int best = r.best_set_difference;
+            const size_t num_best = r.num_best;
+            Node *best_node = flat.bfs[r.best_j];
+            const bool best_has_unique = r.best_has_unique != 0;
+
+            if (!opt.print_scores) {                                            // :451-469
+                fprintf(stderr, "Current tree size (#nodes): %zu\tSample name: %s\tParsimony score: %d\tNumber of parsimony-optimal placements: %zu\n", total_nodes, ms.name.c_str(), best, num_best);
+                fprintf(stats, "%s\t%d\t%zu\t", ms.name.c_str(), best, num_best);
+                if (num_best > 1) {
+                    low_confidence.push_back(ms.name);
+                    if (num_best > opt.max_uncertainty) fprintf(stderr, "WARNING: Number of parsimony-optimal placements exceeds maximum allowed value (%u). Ignoring sample %s.\n", opt.max_uncertainty, ms.name.c_str());
+                    else if ((uint32_t)best <= opt.max_parsimony) fprintf(stderr, "WARNING: Multiple parsimony-optimal placements found. Placement done without high confidence.\n");
+                }
+                if ((uint32_t)best > opt.max_parsimony) fprintf(stderr, "WARNING: Parsimony score of the most parsimonious placement exceeds the maximum allowed value (%u). Ignoring sample %s.\n", opt.max_parsimony, ms.name.c_str());
+            } else {
+                fprintf(stderr, "Missing sample: %s\t Best parsimony score: %d\tNumber of parsimony-optimal placements: %zu\n", ms.name.c_str(), best, num_best);
+            }
+
+            NodeVecs vec;
+            if (opt.print_scores) {                                             // :557-578
+                const int32_t *sc = batch_scores.data() + s * total_nodes;
+                for (size_t k = 0; k < total_nodes && scores_file; k++) {
+                    const bool optimal = sc[k] == best;
+                    fprintf(scores_file, "%s\t%s\t%d\t\t%c\t", ms.name.c_str(), flat.bfs[k]->id.c_str(), sc[k], optimal ? 'y' : 'n');
+                    if (optimal) {
+                        if (sc[k] == 0) fprintf(scores_file, "*");
+                        node_vecs(flat.bfs[k], ms.mutations, vec);
+                        for (int i = 0; i < sc[k] && (size_t)i < vec.excess.size(); i++)   // first `score` entries of the excess vector (:565-572)
+                            fprintf(scores_file, "%s%s", vec.excess[i].str().c_str(), i + 1 < sc[k] ? "," : "");
+                    } else fprintf(scores_file, "N/A");
+                    fprintf(scores_file, "\n");
+                }
+            } else if (num_best <= opt.max_uncertainty && (uint32_t)best <= opt.max_parsimony) {   // :583
+                const size_t n_ann = T.num_annotations();
+                if (n_ann > 0) {                                                // clade assignment, :601-619
+                    FlatQueries q1;
+                    q1.add(ms.mutations);
+                    q1.finish();
+                    const uint32_t cap = (uint32_t)std::min<size_t>(num_best, 1u << 20);
+                    std::vector<uint32_t> tj(cap), tc(1);
+                    std::vector<uint8_t> th(cap);
+                    if (be.ties(be.ctx, &flat.desc, tree_version, &q1.desc, cap, tj.data(), th.data(), tc.data()) != 0) { fclose(stats); return be_fail("tie listing"); }
+                    const size_t nt = std::min<size_t>(tc[0], cap);
+                    ms.clade_assignments.assign(n_ann, {});
+                    ms.best_clade_assignment.assign(n_ann, "");
+                    for (size_t c = 0; c < n_ann; c++) {
+                        for (size_t k = 0; k < nt; k++) {
+                            Node *nd = flat.bfs[tj[k]];
+                            const bool include_self = !nd->is_leaf() && !th[k];
+                            std::string ca = T.clade_assignment(nd, c, include_self);
+                            if (nd == best_node) ms.best_clade_assignment[c] = ca;
+                            ms.clade_assignments[c].push_back(std::move(ca));
+                        }
+                        std::sort(ms.clade_assignments[c].begin(), ms.clade_assignments[c].end());
+                    }
+                }
+                node_vecs(best_node, ms.mutations, vec);                        // pass 2 for the winner, :426-449
+                if (!opt.no_add) {
+                    insert_sample(T, best_node, best_node->is_leaf() || best_has_unique, ms.name, vec.excess);
+                    tree_version++;
+                }
+                if (!vec.imputed.empty()) {                                     // :767-781
+                    fprintf(stderr, "Imputed mutations:\t");
+                    for (size_t i = 0; i < vec.imputed.size(); i++) {
+                        const char *sep = i + 1 < vec.imputed.size() ? ";" : "";
+                        fprintf(stderr, "%i:%c%s", vec.imputed[i].position, nuc_char(vec.imputed[i].mut_nuc), sep);
+                        fprintf(stats, "%i:%c%s", vec.imputed[i].position, nuc_char(vec.imputed[i].mut_nuc), sep);
+                    }
+                    fprintf(stderr, "\n");
+                }
+            }
+            fputc('\n', stats);
+            fprintf(stderr, "Completed in %ld msec \n\n", timer.stop());
+        }
+        fclose(stats);
+        if (scores_file) fclose(scores_file);
+    }
+    if (opt.print_scores) return 0;                                             // :800-805
+
+    // ---- outputs, usher_common.cpp:828-1044
+    timer.start();
+    if (opt.write_uncondensed) {
+        const std::string fn = outdir + "/uncondensed-final-tree.nh";
+        fprintf(stderr, "Writing uncondensed final tree to file %s \n", fn.c_str());
+        fprintf(stderr, "The parsimony score for this tree is: %zu \n", T.parsimony_score());
+        write_text(fn, newick(T, T.root, true, true, true));
+    } else {
+        const std::string fn = outdir + "/final-tree.nh";
+        fprintf(stderr, "Writing final tree to file %s \n", fn.c_str());
+        fprintf(stderr, "The parsimony score for this tree is: %zu \n", T.parsimony_score());
+        write_text(fn, newick(T, T.root, true, true));
+    }
+    fprintf(stderr, "Completed in %ld msec \n\n", timer.stop());
+
+    if (!missing.empty()) {
+        timer.start();
+        const std::string fn = outdir + "/mutation-paths.txt";                  // get_sample_mutation_paths, mutation_annotated_tree.cpp:1991-2050
+        fprintf(stderr, "Writing mutation paths to file %s \n", fn.c_str());
+        std::string text;
+        for (auto &ms : missing) {
+            Node *n = T.get_node(ms.name);
+            if (!n) continue;
+            std::vector<std::string> parts;
+            for (Node *a : T.rsearch(n, true)) {
+                if (a->mutations.empty()) continue;
+                std::string p = a->id + ":";
+                for (size_t k = 0; k < a->mutations.size(); k++) p += a->mutations[k].str() + (k + 1 < a->mutations.size() ? "," : " ");
+                parts.push_back(std::move(p));
+            }
+            text += ms.name + "\t";
+            for (size_t i = parts.size(); i-- > 0;) text += parts[i];
+            text += "\n";
+        }
+        write_text(fn, text);
+        fprintf(stderr, "Completed in %ld msec \n\n", timer.stop());
+
+        const size_t n_ann = T.num_annotations();
+        if (n_ann > 0) {                                                        // clades.txt, :909-970
+            timer.start();
+            const std::string cf = outdir + "/clades.txt";
+            fprintf(stderr, "Writing clade annotations to file %s \n", cf.c_str());
+            std::string ctext;
+            for (auto &ms : missing) {
+                if (ms.best_clade_assignment.empty()) continue;
+                ctext += ms.name + "\t";
+                for (size_t k = 0; k < n_ann; k++) {
+                    ctext += ms.best_clade_assignment[k];
+                    if (opt.detailed_clades) {
+                        ctext += "*|";
+                        std::string cur; int cnt = 0;
+                        const auto &all = ms.clade_assignments[k];
+                        std::vector<std::string> segs;
+                        for (const std::string &c : all) {
+                            if (c == cur) cnt++;
+                            else { if (cnt > 0) segs.push_back(cur + "(" + std::to_string(cnt) + "/" + std::to_string(all.size()) + ")"); cur = c; cnt = 1; }
+                        }
+                        for (auto &sg : segs) ctext += sg + ",";
+                        if (cnt > 0) ctext += cur + "(" + std::to_string(cnt) + "/" + std::to_string(all.size()) + ")";
+                    }
+                    if (k + 1 < n_ann) ctext += "\t";
+                }
+                ctext += "\n";
+            }
+            write_text(cf, ctext);
+            fprintf(stderr, "Completed in %ld msec \n\n", timer.stop());
+        }
+    }
+    if (!low_confidence.empty()) {                                              // :1016-1021
+        fprintf(stderr, "WARNING: Following samples had multiple possibilities of parsimony-optimal placements:\n");
+        for (auto &l : low_confidence) fprintf(stderr, "%s\n", l.c_str());
+    }
+    if (!opt.save_mat.empty()) {                                                // :1024-1044
+        timer.start();
+        fprintf(stderr, "Saving mutation-annotated tree object to file (after condensing identical sequences) %s\n", opt.save_mat.c_str());
+        if (!T.condensed_nodes.empty()) T.uncondense_leaves();
+        T.condense_leaves();
+        std::string err;
+        if (!save_mat(T, opt.save_mat, err)) { fprintf(stderr, "ERROR: %s\n", err.c_str()); return 1; }
+        fprintf(stderr, "Completed in %ld msec \n\n", timer.stop());
+    }
+    return 0;
+}
+
+}  // namespace uh

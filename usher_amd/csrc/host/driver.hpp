@@ -1,0 +1,52 @@
+// driver.hpp -- the usher-compatible placement driver (host side of the drop-in):
+// option validation, per-sample bookkeeping, tree update and every output file
+// of the reference's usher_common() (src/usher_common.cpp:7-1073), with the
+// node x sample search delegated to a placement backend (the GPU library).
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "mat.hpp"
+#include "usher_amd.h"
+
+namespace uh {
+
+struct Options {   // the 22 flags of src/usher.cpp:47-86
+    std::string vcf, tree, outdir = ".", load_mat, save_mat;
+    bool sort1 = false, sort2 = false, sort3 = false, reverse_sort = false;
+    bool collapse_tree = false, collapse_output_tree = false;
+    uint32_t max_uncertainty = 1000000, max_parsimony = 1000000;
+    bool write_uncondensed = false;
+    size_t subtrees_size = 0, subtrees_single = 0;
+    bool print_scores = false;
+    uint32_t max_trees = 1;
+    bool retain_branch_len = false, no_add = false, detailed_clades = false;
+    uint32_t threads = 0;
+    int device = 0;   // extension: HIP device ordinal (--device)
+};
+
+// The search block of usher_common.cpp:342-449 for a batch of samples on a
+// static tree.  Signatures mirror include/usher_amd.h; `ctx` is backend state.
+struct Backend {
+    void *ctx = nullptr;
+    int (*place)(void *ctx, const ugp_tree_desc *, uint64_t tree_version, const ugp_queries *, ugp_result *) = nullptr;
+    int (*scores)(void *ctx, const ugp_tree_desc *, uint64_t tree_version, const ugp_queries *, int32_t *) = nullptr;
+    int (*ties)(void *ctx, const ugp_tree_desc *, uint64_t tree_version, const ugp_queries *, uint32_t cap, uint32_t *,
+                uint8_t *, uint32_t *) = nullptr;
+    const char *(*last_error)(void *ctx) = nullptr;
+};
+
+// Returns the process exit code (usher_common.cpp:6).
+int run_usher(const Options &opt, Tree &T, std::vector<MissingSample> &missing, const Backend &be);
+
+// mapper2_body(inp, true, true) for one node (usher_mapper.cpp:167-504): the
+// excess / imputed mutation vectors, score and has_unique the placement needs.
+struct NodeVecs {
+    std::vector<Mutation> excess, imputed;
+    int set_difference = 0;
+    bool has_unique = false;
+};
+void node_vecs(const Node *n, const std::vector<Mutation> &sample, NodeVecs &out);
+
+}  // namespace uh

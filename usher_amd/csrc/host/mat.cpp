@@ -1,0 +1,720 @@
+// mat.cpp -- host-side MAT model, newick / parsimony.proto / VCF readers and
+// writers.  Written from scratch; each function cites the reference behaviour
+// it reproduces (src/mutation_annotated_tree.cpp unless noted).
+#include "mat.hpp"
+
+#include <zlib.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <sstream>
+
+namespace uh {
+
+// ------------------------------------------------------------- nucleotides
+
+int8_t nuc_id(char c) {   // :19-74
+    switch (c) {
+        case 'a': case 'A': return 1;
+        case 'c': case 'C': return 2;
+        case 'g': case 'G': return 4;
+        case 't': case 'T': return 8;
+        case 'R': return 5;
+        case 'Y': return 10;
+        case 'S': return 6;
+        case 'W': return 9;
+        case 'K': return 12;
+        case 'M': return 3;
+        case 'B': return 14;
+        case 'D': return 13;
+        case 'H': return 11;
+        default: return 15;   // 'V' included: the reference's case falls through to N (:65-70)
+    }
+}
+
+char nuc_char(int8_t id) {   // :88-139
+    static const char *t = "NACMGRSVTWYHKDBN";
+    return (id >= 1 && id <= 14) ? t[id] : 'N';
+}
+
+int8_t nuc_index(int8_t id) {   // :142-162
+    switch (id) { case 1: return 0; case 2: return 1; case 4: return 2; case 8: return 3; default: return -1; }
+}
+
+std::string Mutation::str() const {   // hpp:79-85
+    if (masked()) return "MASKED";
+    return std::string(1, nuc_char(par_nuc)) + std::to_string(position) + std::string(1, nuc_char(mut_nuc));
+}
+
+// -------------------------------------------------------------------- node
+
+bool Node::add_mutation(const Mutation &mut) {   // :720-752
+    auto it = std::lower_bound(mutations.begin(), mutations.end(), mut,
+                               [](const Mutation &a, const Mutation &b) { return a.position < b.position; });
+    if (it != mutations.end() && it->position == mut.position) {
+        if (it->par_nuc != mut.mut_nuc) {
+            it->mut_nuc = mut.mut_nuc;           // update to the new allele
+        } else {
+            if (it->mut_nuc != mut.par_nuc) return false;   // "consecutive mutations at same position disagree"
+            const int32_t p = it->position;       // reversal: drop every mutation at this position
+            mutations.erase(std::remove_if(mutations.begin(), mutations.end(),
+                                           [p](const Mutation &m) { return m.position == p; }),
+                            mutations.end());
+        }
+    } else {
+        mutations.insert(it, mut);
+    }
+    return true;
+}
+
+// -------------------------------------------------------------------- tree
+
+Tree::~Tree() {
+    for (auto &kv : all_nodes) delete kv.second;
+}
+
+uint32_t Tree::chrom_id(const std::string &c) {
+    for (uint32_t i = 0; i < chroms.size(); i++) if (chroms[i] == c) return i;
+    chroms.push_back(c);
+    return (uint32_t)chroms.size() - 1;
+}
+
+Node *Tree::get_node(const std::string &id) const {
+    auto it = all_nodes.find(id);
+    return it == all_nodes.end() ? nullptr : it->second;
+}
+
+Node *Tree::create_node(const std::string &id, Node *parent, float branch_length) {   // :881-910
+    if (parent && all_nodes.count(id)) return nullptr;   // "already in the tree"
+    Node *n = new Node();
+    n->id = id;
+    n->parent = parent;
+    n->branch_length = branch_length;
+    n->level = parent ? parent->level + 1 : 1;
+    if (!parent) {
+        for (auto &kv : all_nodes) delete kv.second;
+        all_nodes.clear();
+        root = n;
+    } else {
+        n->clade_annotations.assign(num_annotations(), "");
+        parent->children.push_back(n);
+    }
+    all_nodes[id] = n;
+    return n;
+}
+
+std::vector<Node *> Tree::bfs() const {
+    std::vector<Node *> out;
+    if (!root) return out;
+    out.reserve(all_nodes.size());
+    out.push_back(root);
+    for (size_t h = 0; h < out.size(); h++)
+        for (Node *c : out[h]->children) out.push_back(c);
+    return out;
+}
+
+std::vector<Node *> Tree::dfs(Node *from) const {
+    std::vector<Node *> out;
+    Node *start = from ? from : root;
+    if (!start) return out;
+    std::vector<Node *> st{start};
+    while (!st.empty()) {
+        Node *n = st.back();
+        st.pop_back();
+        out.push_back(n);
+        for (size_t i = n->children.size(); i-- > 0;) st.push_back(n->children[i]);
+    }
+    return out;
+}
+
+std::vector<Node *> Tree::rsearch(Node *n, bool include_self) const {
+    std::vector<Node *> out;
+    if (!n) return out;
+    if (include_self) out.push_back(n);
+    for (Node *p = n->parent; p; p = p->parent) out.push_back(p);
+    return out;
+}
+
+std::string Tree::clade_assignment(Node *n, size_t clade, bool include_self) const {
+    for (Node *a : rsearch(n, include_self))
+        if (a->clade_annotations.size() > clade && !a->clade_annotations[clade].empty()) return a->clade_annotations[clade];
+    return "UNDEFINED";
+}
+
+size_t Tree::parsimony_score() const {
+    size_t s = 0;
+    for (auto &kv : all_nodes) s += kv.second->mutations.size();
+    return s;
+}
+
+void Tree::fix_levels(Node *from) {
+    std::vector<Node *> st{from};
+    while (!st.empty()) {
+        Node *n = st.back();
+        st.pop_back();
+        n->level = n->parent ? n->parent->level + 1 : 1;
+        for (Node *c : n->children) st.push_back(c);
+    }
+}
+
+// move_node() for the case usher's placement uses: the destination was just
+// created and has one mutation-free child, so no "same mutations" merge can
+// trigger (:1150-1158): unlink from the old parent, append below dst.
+void Tree::reattach(Node *src, Node *dst) {
+    Node *old = src->parent;
+    old->children.erase(std::find(old->children.begin(), old->children.end(), src));
+    src->parent = dst;
+    src->branch_length = -1.0f;
+    dst->children.push_back(src);
+    fix_levels(src);
+}
+
+void Tree::remove_leaf(Node *n) {
+    Node *p = n->parent;
+    if (p) p->children.erase(std::find(p->children.begin(), p->children.end(), n));
+    all_nodes.erase(n->id);
+    delete n;
+}
+
+void Tree::condense_leaves() {   // :1287-1332
+    if (!condensed_nodes.empty()) uncondense_leaves();
+    std::vector<std::string> leaf_ids;
+    for (Node *n : bfs()) if (n->is_leaf()) leaf_ids.push_back(n->id);
+    for (const std::string &lid : leaf_ids) {
+        Node *l1 = get_node(lid);
+        if (!l1 || !l1->mutations.empty() || !l1->parent) continue;
+        std::vector<Node *> poly;
+        for (Node *l2 : l1->parent->children)
+            if (l2->is_leaf() && l2->mutations.empty()) poly.push_back(l2);
+        if (poly.size() > 1) {
+            std::string name = "node_" + std::to_string(1 + condensed_nodes.size()) + "_condensed_" +
+                               std::to_string(poly.size()) + "_leaves";
+            create_node(name, l1->parent, l1->branch_length);
+            std::vector<std::string> ids;
+            for (Node *p : poly) ids.push_back(p->id);
+            for (Node *p : poly) remove_leaf(p);
+            condensed_nodes[name] = ids;
+        }
+    }
+}
+
+void Tree::uncondense_leaves() {   // :1334-1382
+    for (auto &cn : condensed_nodes) {
+        Node *n = get_node(cn.first);
+        if (!n) continue;
+        Node *par = n->parent ? n->parent : n;
+        const size_t k = cn.second.size();
+        if (k > 1 && !n->mutations.empty()) {
+            all_nodes.erase(n->id);
+            n->id = new_internal_node_id();
+            all_nodes[n->id] = n;
+            for (size_t s = 0; s < k; s++) {
+                Node *c = new Node();
+                c->id = cn.second[s]; c->parent = n; c->branch_length = -1.0f; c->level = n->level + 1;
+                c->clade_annotations.assign(num_annotations(), "");
+                all_nodes[c->id] = c;
+                n->children.push_back(c);
+            }
+        } else if (k > 1) {
+            all_nodes.erase(n->id);
+            n->id = cn.second[0];
+            all_nodes[n->id] = n;
+            for (size_t s = 1; s < k; s++) {
+                Node *c = new Node();
+                c->id = cn.second[s]; c->parent = par; c->branch_length = n->branch_length; c->level = par->level + 1;
+                c->clade_annotations.assign(num_annotations(), "");
+                all_nodes[c->id] = c;
+                par->children.push_back(c);
+            }
+        } else if (k == 1) {
+            all_nodes.erase(n->id);
+            n->id = cn.second[0];
+            all_nodes[n->id] = n;
+        }
+    }
+    condensed_nodes.clear();
+    condensed_leaves.clear();
+}
+
+// ------------------------------------------------------------------ newick
+
+static void split(const std::string &s, char delim, std::vector<std::string> &out) {   // string_split, :383-398
+    size_t start = 0, end;
+    while ((end = s.find(delim, start)) != std::string::npos) {
+        out.push_back(s.substr(start, end - start));
+        start = end + 1;
+    }
+    if (start < s.size()) out.push_back(s.substr(start));
+}
+
+bool tree_from_newick(const std::string &nwk, Tree &T, std::string &err) {   // :415-508
+    std::vector<std::string> parts;
+    split(nwk, ',', parts);
+    struct Item { std::string leaf; size_t open = 0, close = 0; };
+    std::vector<Item> items;
+    std::vector<std::vector<float>> blen(128);
+    size_t level = 0;
+    auto to_len = [](const std::string &b) { return b.empty() ? -1.0f : std::stof(b); };
+    for (const std::string &s : parts) {
+        Item it;
+        bool stop = false, branch_start = false;
+        std::string branch;
+        for (char c : s) {
+            if (c == ':') { stop = true; branch.clear(); branch_start = true; }
+            else if (c == '(') { it.open++; level++; if (blen.size() <= level) blen.resize(level * 2); }
+            else if (c == ')') {
+                stop = true; it.close++;
+                blen[level].push_back(to_len(branch));
+                if (level == 0) { err = "incorrect Newick format"; return false; }
+                level--; branch_start = false;
+            } else if (!stop) { it.leaf += c; branch_start = false; }
+            else if (branch_start && (isdigit((unsigned char)c) || c == '.' || c == 'e' || c == 'E' || c == '-' || c == '+')) branch += c;
+        }
+        blen[level].push_back(to_len(branch));
+        items.push_back(std::move(it));
+    }
+    if (level != 0) { err = "incorrect Newick format"; return false; }
+    std::vector<size_t> head(blen.size(), 0);
+    std::vector<Node *> stack;
+    for (Item &it : items) {
+        for (size_t j = 0; j < it.open; j++) {
+            Node *n = T.create_node(T.new_internal_node_id(), stack.empty() ? nullptr : stack.back(), blen[level][head[level]++]);
+            if (!n) { err = "duplicate node identifier in Newick"; return false; }
+            level++;
+            stack.push_back(n);
+        }
+        if (stack.empty()) { err = "incorrect Newick format"; return false; }
+        if (!T.create_node(it.leaf, stack.back(), blen[level][head[level]++])) { err = "Error: " + it.leaf + " already in the tree!"; return false; }
+        for (size_t j = 0; j < it.close; j++) { stack.pop_back(); level--; }
+    }
+    return true;
+}
+
+static void put_len(std::string &out, float v) {   // operator<<(float): %g
+    char buf[32];
+    snprintf(buf, sizeof buf, "%g", v);
+    out += buf;
+}
+
+std::string newick(const Tree &T, Node *from, bool internal_ids, bool branch_len, bool uncondense) {   // :215-346
+    std::string out;
+    Node *start = from ? from : T.root;
+    if (!start) return ";";
+    std::unordered_map<std::string, const std::vector<std::string> *> cmap;
+    if (uncondense) for (auto &cn : T.condensed_nodes) cmap[cn.first] = &cn.second;
+    const size_t level_offset = start->level - 1;
+    size_t curr_level = 0;
+    bool prev_open = true;
+    std::vector<std::pair<std::string, float>> stack;
+    auto leaf_text = [&](Node *n, bool comma) {
+        if (comma) out += ',';
+        auto it = cmap.find(n->id);
+        if (uncondense && it != cmap.end()) {
+            for (size_t i = 0; i < it->second->size(); i++) { if (i) out += ','; out += (*it->second)[i]; }
+        } else out += n->id;
+        if (branch_len) { out += ':'; put_len(out, (float)n->mutations.size()); }
+    };
+    auto close_one = [&]() {
+        out += ')';
+        if (internal_ids) out += stack.back().first;
+        if (branch_len && stack.back().second >= 0) { out += ':'; put_len(out, stack.back().second); }
+        stack.pop_back();
+    };
+    for (Node *n : T.dfs(start)) {
+        const size_t level = n->level - level_offset;
+        const float bl = (float)n->mutations.size();   // the ":230 band-aid": branch length = #mutations
+        if (curr_level < level) {
+            if (!prev_open) out += ',';
+            size_t l = level - 1;
+            if (curr_level > 1) l = level - curr_level;
+            for (size_t i = 0; i < l; i++) { out += '('; prev_open = true; }
+            if (n->is_leaf()) { leaf_text(n, false); prev_open = false; }
+            else stack.emplace_back(n->id, bl);
+        } else if (curr_level > level) {
+            prev_open = false;
+            for (size_t i = level; i < curr_level; i++) close_one();
+            if (n->is_leaf()) leaf_text(n, true);
+            else stack.emplace_back(n->id, bl);
+        } else {
+            prev_open = false;
+            if (n->is_leaf()) leaf_text(n, true);
+            else stack.emplace_back(n->id, bl);
+        }
+        curr_level = level;
+    }
+    while (!stack.empty()) close_one();
+    out += ';';
+    return out;
+}
+
+// ---------------------------------------------------------- parsimony.proto
+
+namespace {
+
+bool read_file(const std::string &path, std::string &buf, std::string &err) {
+    if (path.find(".gz") != std::string::npos) {   // :530 / :2086
+        gzFile f = gzopen(path.c_str(), "rb");
+        if (!f) { err = "Could not open " + path; return false; }
+        char tmp[1 << 16];
+        int n;
+        while ((n = gzread(f, tmp, sizeof tmp)) > 0) buf.append(tmp, (size_t)n);
+        gzclose(f);
+        return n == 0;
+    }
+    std::ifstream in(path, std::ios::binary);
+    if (!in) { err = "Could not open " + path; return false; }
+    std::stringstream ss;
+    ss << in.rdbuf();
+    buf = ss.str();
+    return true;
+}
+
+struct Rd {
+    const uint8_t *p, *e;
+    bool ok = true;
+    uint64_t varint() {
+        uint64_t v = 0; int sh = 0;
+        while (p < e) { uint8_t b = *p++; v |= (uint64_t)(b & 0x7F) << sh; if (!(b & 0x80)) return v; sh += 7; if (sh > 63) break; }
+        ok = false; return 0;
+    }
+    bool field(uint32_t &fno, uint32_t &wt, uint64_t &val, Rd &sub) {
+        if (p >= e || !ok) return false;
+        uint64_t key = varint();
+        fno = (uint32_t)(key >> 3); wt = (uint32_t)(key & 7);
+        if (wt == 0) val = varint();
+        else if (wt == 2) { uint64_t n = varint(); if ((uint64_t)(e - p) < n) { ok = false; return false; } sub.p = p; sub.e = p + n; sub.ok = true; p += n; }
+        else if (wt == 1) { if (e - p < 8) { ok = false; return false; } p += 8; }
+        else if (wt == 5) { if (e - p < 4) { ok = false; return false; } p += 4; }
+        else { ok = false; return false; }
+        return ok;
+    }
+};
+
+void put_varint(std::string &o, uint64_t v) {
+    while (v >= 0x80) { o += (char)((v & 0x7F) | 0x80); v >>= 7; }
+    o += (char)v;
+}
+void put_tag(std::string &o, uint32_t fno, uint32_t wt) { put_varint(o, ((uint64_t)fno << 3) | wt); }
+void put_bytes(std::string &o, uint32_t fno, const std::string &b) { put_tag(o, fno, 2); put_varint(o, b.size()); o += b; }
+void put_int32(std::string &o, uint32_t fno, int32_t v) {   // proto3: zero is omitted, negatives are sign-extended to 64 bits
+    if (v == 0) return;
+    put_tag(o, fno, 0);
+    put_varint(o, (uint64_t)(int64_t)v);
+}
+
+}  // namespace
+
+bool load_mat(const std::string &path, Tree &T, std::string &err) {   // :522-612
+    std::string buf;
+    if (!read_file(path, buf, err)) { err = "ERROR: Could not load the mutation-annotated tree object from file: " + path + "!"; return false; }
+    Rd top{(const uint8_t *)buf.data(), (const uint8_t *)buf.data() + buf.size()};
+    std::string nwk;
+    struct PMut { int32_t pos = 0, ref = 0, par = 0; std::vector<int32_t> nuc; std::string chrom; };
+    std::vector<std::vector<PMut>> node_muts;
+    std::vector<std::pair<std::string, std::vector<std::string>>> cond;
+    std::vector<std::vector<std::string>> meta;
+    uint32_t fno, wt; uint64_t val; Rd sub{nullptr, nullptr};
+    while (top.field(fno, wt, val, sub)) {
+        if (fno == 1 && wt == 2) nwk.assign((const char *)sub.p, sub.e - sub.p);
+        else if (fno == 2 && wt == 2) {
+            node_muts.emplace_back();
+            uint32_t f2, w2; uint64_t v2; Rd s2{nullptr, nullptr};
+            while (sub.field(f2, w2, v2, s2)) {
+                if (f2 != 1 || w2 != 2) continue;
+                PMut m;
+                uint32_t f3, w3; uint64_t v3; Rd s3{nullptr, nullptr};
+                while (s2.field(f3, w3, v3, s3)) {
+                    if (f3 == 1 && w3 == 0) m.pos = (int32_t)(int64_t)v3;
+                    else if (f3 == 2 && w3 == 0) m.ref = (int32_t)(int64_t)v3;
+                    else if (f3 == 3 && w3 == 0) m.par = (int32_t)(int64_t)v3;
+                    else if (f3 == 4 && w3 == 0) m.nuc.push_back((int32_t)(int64_t)v3);
+                    else if (f3 == 4 && w3 == 2) { while (s3.p < s3.e && s3.ok) m.nuc.push_back((int32_t)(int64_t)s3.varint()); }
+                    else if (f3 == 5 && w3 == 2) m.chrom.assign((const char *)s3.p, s3.e - s3.p);
+                }
+                if (!s2.ok) { err = "malformed protobuf (mut)"; return false; }
+                node_muts.back().push_back(std::move(m));
+            }
+            if (!sub.ok) { err = "malformed protobuf (mutation_list)"; return false; }
+        } else if (fno == 3 && wt == 2) {
+            cond.emplace_back();
+            uint32_t f2, w2; uint64_t v2; Rd s2{nullptr, nullptr};
+            while (sub.field(f2, w2, v2, s2)) {
+                if (f2 == 1 && w2 == 2) cond.back().first.assign((const char *)s2.p, s2.e - s2.p);
+                else if (f2 == 2 && w2 == 2) cond.back().second.emplace_back((const char *)s2.p, s2.e - s2.p);
+            }
+        } else if (fno == 4 && wt == 2) {
+            meta.emplace_back();
+            uint32_t f2, w2; uint64_t v2; Rd s2{nullptr, nullptr};
+            while (sub.field(f2, w2, v2, s2))
+                if (f2 == 1 && w2 == 2) meta.back().emplace_back((const char *)s2.p, s2.e - s2.p);
+        }
+    }
+    if (!top.ok) { err = "malformed protobuf"; return false; }
+    if (!tree_from_newick(nwk, T, err)) return false;
+    auto order = T.dfs();
+    if (node_muts.size() < order.size()) { err = "protobuf has fewer mutation lists than tree nodes"; return false; }
+    const bool hasmeta = !meta.empty();
+    if (!hasmeta) fprintf(stderr, "WARNING: This pb does not include any metadata. Filling in default values\n");
+    if (hasmeta && meta.size() < order.size()) { err = "protobuf has fewer metadata entries than tree nodes"; return false; }
+    for (size_t i = 0; i < order.size(); i++) {
+        Node *n = order[i];
+        if (hasmeta) n->clade_annotations = meta[i];
+        for (const PMut &pm : node_muts[i]) {
+            Mutation m;
+            m.chrom = T.chrom_id(pm.chrom);
+            m.position = pm.pos;
+            if (pm.pos >= 0) {
+                m.ref_nuc = (int8_t)(1 << pm.ref);
+                m.par_nuc = (int8_t)(1 << pm.par);
+                int8_t nuc = 0;
+                for (int32_t b : pm.nuc) nuc = (int8_t)(nuc + (1 << b));   // get_nuc_id(vector), :77-85
+                m.mut_nuc = nuc;
+                if (m.mut_nuc != m.par_nuc && !n->add_mutation(m)) { err = "add_mutation: mutations at the same position disagree"; return false; }
+            } else {
+                m.ref_nuc = m.par_nuc = m.mut_nuc = 0;
+                n->add_mutation(m);   // note: two masked entries cancel through the reversal rule, as in the reference
+            }
+        }
+    }
+    for (auto &c : cond) {
+        for (auto &l : c.second) T.condensed_leaves.insert(l);
+        T.condensed_nodes.emplace(c.first, c.second);
+    }
+    return true;
+}
+
+bool save_mat(Tree &T, const std::string &path, std::string &err) {   // :614-681
+    std::string out;
+    put_bytes(out, 1, newick(T, T.root, false, true));
+    auto order = T.dfs();
+    for (Node *n : order) {
+        std::string ml;
+        for (const Mutation &m : n->mutations) {
+            std::string mm;
+            put_int32(mm, 1, m.position);
+            if (m.masked()) {
+                put_int32(mm, 2, -1);
+                put_int32(mm, 3, -1);
+            } else {
+                put_int32(mm, 2, nuc_index(m.ref_nuc));
+                put_int32(mm, 3, nuc_index(m.par_nuc));
+                std::string packed;
+                for (int b = 0; b < 4; b++) if (m.mut_nuc & (1 << b)) put_varint(packed, (uint64_t)b);
+                if (!packed.empty()) put_bytes(mm, 4, packed);
+            }
+            if (!T.chroms[m.chrom].empty()) put_bytes(mm, 5, T.chroms[m.chrom]);
+            put_bytes(ml, 1, mm);
+        }
+        put_bytes(out, 2, ml);
+    }
+    for (auto &cn : T.condensed_nodes) {
+        std::string c;
+        if (!cn.first.empty()) put_bytes(c, 1, cn.first);
+        for (auto &l : cn.second) put_bytes(c, 2, l);
+        put_bytes(out, 3, c);
+    }
+    for (Node *n : order) {
+        std::string md;
+        for (auto &a : n->clade_annotations) put_bytes(md, 1, a);
+        put_bytes(out, 4, md);
+    }
+    if (path.find(".gz") != std::string::npos) {
+        gzFile f = gzopen(path.c_str(), "wb");
+        if (!f) { err = "Could not write " + path; return false; }
+        bool ok = gzwrite(f, out.data(), (unsigned)out.size()) == (int)out.size();
+        gzclose(f);
+        if (!ok) err = "short write to " + path;
+        return ok;
+    }
+    std::ofstream o(path, std::ios::binary);
+    if (!o) { err = "Could not write " + path; return false; }
+    o.write(out.data(), (std::streamsize)out.size());
+    return (bool)o;
+}
+
+// --------------------------------------------------------------------- VCF
+
+static void split_ws(const std::string &s, std::vector<std::string> &w) {
+    size_t i = 0, n = s.size();
+    while (i < n) {
+        while (i < n && isspace((unsigned char)s[i])) i++;
+        size_t j = i;
+        while (j < n && !isspace((unsigned char)s[j])) j++;
+        if (j > i) w.push_back(s.substr(i, j - i));
+        i = j;
+    }
+}
+
+static bool read_lines(const std::string &path, std::vector<std::string> &lines, std::string &err) {
+    std::string buf;
+    if (!read_file(path, buf, err)) { err = "ERROR: Could not open the VCF file: " + path + "!"; return false; }
+    size_t s = 0;
+    while (s < buf.size()) {
+        size_t e = buf.find('\n', s);
+        if (e == std::string::npos) e = buf.size();
+        lines.push_back(buf.substr(s, e - s));
+        s = e + 1;
+    }
+    return true;
+}
+
+bool read_vcf_missing(Tree &T, const std::string &path, std::vector<MissingSample> &out, std::string &err) {   // :2180-2277
+    std::vector<std::string> lines;
+    if (!read_lines(path, lines, err)) return false;
+    bool header_found = false;
+    size_t n_ids = 0;
+    std::vector<size_t> missing_idx;
+    for (const std::string &s : lines) {
+        std::vector<std::string> words;
+        split_ws(s, words);
+        if (!header_found && words.size() > 1) {
+            if (words[1] == "POS") {
+                for (size_t j = 9; j < words.size(); j++) {
+                    n_ids++;
+                    if (!T.get_node(words[j]) && !T.condensed_leaves.count(words[j])) {
+                        MissingSample ms; ms.name = words[j];
+                        out.push_back(std::move(ms));
+                        missing_idx.push_back(j);
+                    } else {
+                        fprintf(stderr, "WARNING: Ignoring sample %s as it is already in the tree.\n", words[j].c_str());
+                    }
+                }
+                header_found = true;
+            }
+        } else if (header_found) {
+            if (words.empty()) continue;
+            if (words.size() != 9 + n_ids) {
+                err = "ERROR! Incorrect VCF format. Expected " + std::to_string(9 + n_ids) + " columns but got " + std::to_string(words.size()) + ".";
+                return false;
+            }
+            std::vector<std::string> alleles;
+            split(words[4], ',', alleles);
+            const int32_t pos = (int32_t)strtol(words[1].c_str(), nullptr, 10);
+            const int8_t ref = nuc_id(words[3][0]);
+            const uint32_t chrom = T.chrom_id(words[0]);
+            for (size_t k = 0; k < missing_idx.size(); k++) {
+                const std::string &cell = words[missing_idx[k]];
+                Mutation m;
+                m.chrom = chrom; m.position = pos; m.ref_nuc = ref; m.par_nuc = ref;
+                if (isdigit((unsigned char)cell[0])) {
+                    const long allele_id = strtol(cell.c_str(), nullptr, 10);   // std::stoi: leading digits
+                    if (allele_id <= 0) continue;
+                    if ((size_t)allele_id > alleles.size()) { err = "ERROR! VCF genotype refers to a missing ALT allele."; return false; }
+                    const std::string &allele = alleles[allele_id - 1];
+                    if (allele[0] == 'N') { m.is_missing = true; m.mut_nuc = 15; }
+                    else { m.mut_nuc = nuc_id(allele[0]); m.is_missing = (m.mut_nuc == 15); }
+                } else {
+                    m.is_missing = true; m.mut_nuc = 15;
+                }
+                if (m.mut_nuc & (m.mut_nuc - 1)) out[k].num_ambiguous++;
+                out[k].mutations.push_back(m);
+            }
+        }
+    }
+    return true;
+}
+
+// Fitch-Sankoff for one site: mapper_body::operator(), usher_mapper.cpp:6-161.
+static void fitch_site(const std::vector<Node *> &bfs, const std::vector<uint32_t> &parent_idx, const std::vector<uint8_t> &is_leaf,
+                       int8_t ref_nuc, const std::vector<std::pair<uint32_t, int8_t>> &variants, uint32_t chrom, int32_t pos) {
+    const size_t n = bfs.size();
+    const int big = (int)n;
+    std::vector<int> sc(n * 4, 0);
+    std::vector<int8_t> st(n, 0);
+    const int8_t ref_id = nuc_index(ref_nuc);
+    for (size_t j = 0; j < n; j++)
+        if (is_leaf[j]) for (int b = 0; b < 4; b++) if (b != ref_id) sc[j * 4 + b] = big;
+    for (auto &v : variants)
+        for (int b = 0; b < 4; b++) sc[(size_t)v.first * 4 + b] = ((1 << b) & v.second) ? 0 : big;
+    for (size_t j = n; j-- > 1;) {   // forward pass: children feed parents (reverse BFS order)
+        const size_t p = parent_idx[j];
+        for (int b = 0; b < 4; b++) {
+            int mn = big + 1;
+            for (int k = 0; k < 4; k++) { int c = sc[j * 4 + k] + (k == b ? 0 : 1); if (c < mn) mn = c; }
+            sc[p * 4 + b] += mn;
+        }
+    }
+    for (size_t j = 0; j < n; j++) {   // backward pass: prefer the parent's state on ties (:129-141)
+        const int8_t par_state = j ? st[parent_idx[j]] : ref_id;
+        int8_t state = par_state;
+        int mn = sc[j * 4 + par_state];
+        for (int b = 0; b < 4; b++) if (sc[j * 4 + b] < mn) { mn = sc[j * 4 + b]; state = (int8_t)b; }
+        if (state != par_state && sc[j * 4 + par_state] == mn) state = par_state;
+        st[j] = state;
+        if (state != par_state) {
+            Mutation m;
+            m.chrom = chrom; m.position = pos; m.ref_nuc = ref_nuc;
+            m.par_nuc = (int8_t)(1 << par_state); m.mut_nuc = (int8_t)(1 << state);
+            bfs[j]->add_mutation(m);
+        }
+    }
+}
+
+bool read_vcf_build(Tree &T, const std::string &path, std::vector<MissingSample> &out, std::string &err) {   // :2052-2179
+    std::vector<std::string> lines;
+    if (!read_lines(path, lines, err)) return false;
+    auto bfs = T.bfs();
+    std::unordered_map<std::string, uint32_t> idx;
+    std::vector<uint32_t> parent_idx(bfs.size(), 0);
+    std::vector<uint8_t> is_leaf(bfs.size(), 0);
+    for (uint32_t j = 0; j < bfs.size(); j++) idx[bfs[j]->id] = j;
+    for (uint32_t j = 0; j < bfs.size(); j++) {
+        if (bfs[j]->parent) parent_idx[j] = idx[bfs[j]->parent->id];
+        is_leaf[j] = bfs[j]->is_leaf();
+    }
+    bool header_found = false;
+    std::vector<std::string> ids;
+    std::vector<int64_t> col_node;      // per VCF column: BFS index, or -1 - (index into out)
+    for (const std::string &s : lines) {
+        std::vector<std::string> words;
+        split_ws(s, words);
+        if (!header_found && words.size() > 1) {
+            if (words[1] == "POS") {
+                for (size_t j = 9; j < words.size(); j++) {
+                    ids.push_back(words[j]);
+                    auto it = idx.find(words[j]);
+                    if (it == idx.end()) {
+                        MissingSample ms; ms.name = words[j];
+                        col_node.push_back(-1 - (int64_t)out.size());
+                        out.push_back(std::move(ms));
+                    } else col_node.push_back(it->second);
+                }
+                header_found = true;
+            }
+        } else if (header_found) {
+            if (words.empty()) continue;
+            if (words.size() != 9 + ids.size()) { err = "ERROR! Incorrect VCF format."; return false; }
+            std::vector<std::string> alleles;
+            split(words[4], ',', alleles);
+            const int32_t pos = (int32_t)strtol(words[1].c_str(), nullptr, 10);
+            const int8_t ref = nuc_id(words[3][0]);
+            if (nuc_index(ref) < 0) { err = "ERROR! VCF REF base is not one of A,C,G,T."; return false; }
+            const uint32_t chrom = T.chrom_id(words[0]);
+            fprintf(stderr, "At variant site %i\n", pos);
+            std::vector<std::pair<uint32_t, int8_t>> variants;
+            for (size_t j = 9; j < words.size(); j++) {
+                int8_t nuc;
+                if (isdigit((unsigned char)words[j][0])) {
+                    const long a = strtol(words[j].c_str(), nullptr, 10);
+                    if (a <= 0) continue;
+                    if ((size_t)a > alleles.size()) { err = "ERROR! VCF genotype refers to a missing ALT allele."; return false; }
+                    nuc = nuc_id(alleles[a - 1][0]);
+                } else nuc = 15;
+                const int64_t c = col_node[j - 9];
+                if (c >= 0) variants.emplace_back((uint32_t)c, nuc);
+                else {   // sample to be placed later: keep its row (usher_mapper.cpp:65-82)
+                    Mutation m;
+                    m.chrom = chrom; m.position = pos; m.ref_nuc = ref; m.par_nuc = ref;
+                    if (nuc == 15) { m.is_missing = true; m.mut_nuc = 15; } else m.mut_nuc = nuc;
+                    out[(size_t)(-1 - c)].mutations.push_back(m);
+                }
+            }
+            fitch_site(bfs, parent_idx, is_leaf, ref, variants, chrom, pos);
+        }
+    }
+    return true;
+}
+
+}  // namespace uh

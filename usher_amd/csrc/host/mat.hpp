@@ -1,0 +1,96 @@
+// mat.hpp -- host-side mutation-annotated tree (MAT) model, readers and writers
+// for the usher-compatible front end.  Written from scratch; behaviour follows
+// the reference's src/mutation_annotated_tree.{hpp,cpp} (cited per function).
+#pragma once
+#include <cstdint>
+#include <string>
+#include <unordered_map>
+#include <unordered_set>
+#include <vector>
+
+namespace uh {
+
+// one-hot allele codes A=1 C=2 G=4 T=8, IUPAC = unions, N = 15
+int8_t nuc_id(char c);        // mutation_annotated_tree.cpp:19-74 (incl. the 'V' -> N fall-through)
+char nuc_char(int8_t id);     // :88-139
+int8_t nuc_index(int8_t id);  // :142-162  (A,C,G,T -> 0..3, else -1)
+
+struct Mutation {             // mutation_annotated_tree.hpp:45-86
+    int32_t position = 0;     // < 0 = masked
+    int8_t ref_nuc = 0, par_nuc = 0, mut_nuc = 0;
+    bool is_missing = false;
+    uint32_t chrom = 0;       // index into Tree::chroms
+    bool masked() const { return position < 0; }
+    std::string str() const;  // "A123G" / "MASKED"
+};
+
+struct Node {                 // mutation_annotated_tree.hpp:88-111
+    std::string id;
+    Node *parent = nullptr;
+    std::vector<Node *> children;
+    std::vector<Mutation> mutations;      // sorted by position
+    std::vector<std::string> clade_annotations;
+    float branch_length = -1.0f;
+    size_t level = 1;
+    bool is_leaf() const { return children.empty(); }
+    bool is_root() const { return parent == nullptr; }
+    // :720-752.  Returns false on the reference's "called out of order" error.
+    bool add_mutation(const Mutation &m);
+};
+
+struct Tree {                 // mutation_annotated_tree.hpp:113-161
+    Node *root = nullptr;
+    std::unordered_map<std::string, Node *> all_nodes;
+    size_t curr_internal_node = 0;
+    // name -> condensed leaf ids.  (The reference keeps a tbb::concurrent_unordered_map here, whose
+    // iteration order is unspecified; a std::unordered_map fed in the same sequence is used instead.)
+    std::unordered_map<std::string, std::vector<std::string>> condensed_nodes;
+    std::unordered_set<std::string> condensed_leaves;
+    std::vector<std::string> chroms{""};
+
+    Tree() = default;
+    Tree(const Tree &) = delete;
+    Tree &operator=(const Tree &) = delete;
+    ~Tree();
+
+    std::string new_internal_node_id() { return "node_" + std::to_string(++curr_internal_node); }
+    uint32_t chrom_id(const std::string &c);
+    Node *get_node(const std::string &id) const;
+    size_t num_annotations() const { return root ? root->clade_annotations.size() : 0; }
+    Node *create_node(const std::string &id, Node *parent, float branch_length = -1.0f);   // :881-910
+    std::vector<Node *> bfs() const;   // :1225-1251
+    std::vector<Node *> dfs(Node *from = nullptr) const;   // :1253-1273
+    std::vector<Node *> rsearch(Node *n, bool include_self) const;   // :931-948
+    std::string clade_assignment(Node *n, size_t clade, bool include_self) const;   // :950-958
+    size_t parsimony_score() const;   // :1275-1285
+    // move `src` (a child elsewhere) below `dst` as its last child; plain case of :1135-1158
+    void reattach(Node *src, Node *dst);
+    void remove_leaf(Node *n);   // the part of remove_node() condense_leaves needs (:960-1049, move_level=false)
+    void condense_leaves();      // :1287-1332
+    void uncondense_leaves();    // :1334-1382
+    void fix_levels(Node *from);
+};
+
+// newick --------------------------------------------------------------------
+bool tree_from_newick(const std::string &nwk, Tree &out, std::string &err);   // :415-508
+std::string newick(const Tree &t, Node *from, bool internal_ids, bool branch_len, bool uncondense = false);   // :215-346
+
+// parsimony.proto -------------------------------------------------------------
+bool load_mat(const std::string &path, Tree &out, std::string &err);   // :522-612 (.gz via zlib)
+bool save_mat(Tree &t, const std::string &path, std::string &err);     // :614-681
+
+// VCF ---------------------------------------------------------------------------
+struct MissingSample {           // usher_graph.hpp:33-53
+    std::string name;
+    std::vector<Mutation> mutations;
+    size_t num_ambiguous = 0;
+    std::vector<std::string> best_clade_assignment;
+    std::vector<std::vector<std::string>> clade_assignments;
+};
+// existing-MAT branch of read_vcf, :2180-2277
+bool read_vcf_missing(Tree &t, const std::string &path, std::vector<MissingSample> &out, std::string &err);
+// new-MAT branch, :2052-2179: Fitch-Sankoff per site (mapper_body, usher_mapper.cpp:6-161) on the host,
+// sites in file order (deterministic)
+bool read_vcf_build(Tree &t, const std::string &path, std::vector<MissingSample> &out, std::string &err);
+
+}  // namespace uh
