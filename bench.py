@@ -119,8 +119,24 @@ def main():
         k_ms = place_ms / args.steps
         achieved = algo_bytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
         node_evals = float(Q) * (info["n_nodes"] + info["n_muts"])
+        # HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC pass of this same
+        # workload (tools/profile_round.sh -> profiles/rNN_pmc_summary.json; FETCH_SIZE doubled as the
+        # gfx950 note in MI355X_MICROARCH.md prescribes); null when the workload differs.
+        traffic = None
+        try:
+            import glob
+            for fn in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.json")), reverse=True):
+                with open(fn) as f:
+                    ps = json.load(f)
+                cfg = ps.get("bench", {}).get("config", {})
+                k = ps.get("kernels", {}).get("ugp::k_best8" if packed else "ugp::k_place<0>", {})
+                if cfg.get("nodes") == int(info["n_nodes"]) and cfg.get("queries_per_gpu") == Q and "hbm_read_bytes_per_dispatch_corrected" in k:
+                    traffic = int(k["hbm_read_bytes_per_dispatch_corrected"] + k.get("hbm_write_bytes_per_dispatch", 0))
+                    break
+        except Exception:
+            traffic = None
         roofline = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                    "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                     "kernel": "k_best8" if packed else "k_place<0>", "tile_samples": T, "kernel_ms": round(k_ms, 4), "algo_bytes_per_launch": int(algo_bytes),
                     "node_plus_mut_evals_per_s": round(node_evals / (k_ms * 1e-3), 1) if k_ms > 0 else 0.0,
                     "table_ms": round(table_ms / args.steps, 4), "merge_ms": round(merge_ms / args.steps, 4)}
