@@ -41,6 +41,7 @@ def main():
     ap.add_argument("--ambiguous", action="store_true", help="BASELINE config 5: 100-5000 N cells + 0-30 IUPAC cells per query")
     ap.add_argument("--cpu-queries", type=int, default=-1, help="queries timed on the CPU oracle (0 = skip; default: sized for ~10-30 s)")
     ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--sort-by-source", action="store_true", help="experiment: order the queries by their generator source node")
     args = ap.parse_args()
 
     import torch
@@ -71,6 +72,16 @@ def main():
     info = pl.info()
     kw = dict(n_lo=100, n_hi=5000, iupac_hi=30) if args.ambiguous else {}
     q = st.queries(args.queries, seed=args.seed * 1000 + 17 + rank, **kw)
+    if args.sort_by_source:
+        from usher_amd import FlatTreeView
+        d2b = FlatTreeView(st.arrays).dfs2bfs
+        dfs_rank = np.empty(len(d2b), np.int64); dfs_rank[d2b] = np.arange(len(d2b))
+        order = np.argsort(dfs_rank[q["source"]], kind="stable")
+        lens = np.diff(q["ent_off"].astype(np.int64))
+        starts = q["ent_off"].astype(np.int64)[:-1]
+        idx = np.concatenate([np.arange(starts[i], starts[i] + lens[i]) for i in order]) if len(order) else np.zeros(0, np.int64)
+        new_off = np.zeros(len(order) + 1, np.uint64); new_off[1:] = np.cumsum(lens[order])
+        q = {"ent_off": new_off, "pos": q["pos"][idx], "ref": q["ref"][idx], "nuc": q["nuc"][idx], "is_missing": q["is_missing"][idx], "source": q["source"][order]}
     batch = QueryBatch.from_csr(q["ent_off"], q["pos"], q["ref"], q["nuc"], q["is_missing"])
     qset = pl.upload(batch)
     Q = len(batch)
@@ -90,13 +101,14 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     place_ms = table_ms = merge_ms = 0.0
-    tiles = groups = packed = 0
+    tiles = groups = packed = skipped = wtotal = nskips = 0
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
         tm = pl.timing()   # HIP events recorded by the library on `stream` around each kernel of this step
         place_ms += tm["place_ms"]; table_ms += tm["table_ms"]; merge_ms += tm["merge_ms"]
         tiles, groups, packed = tm["n_tiles"], tm["n_groups"], tm["packed_path"]
+        skipped, wtotal, nskips = tm["words_skipped"], tm["words_total"], tm["reserved"]
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -139,7 +151,8 @@ def main():
                     "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                     "kernel": "k_best8" if packed else "k_place<0>", "tile_samples": T, "kernel_ms": round(k_ms, 4), "algo_bytes_per_launch": int(algo_bytes),
                     "node_plus_mut_evals_per_s": round(node_evals / (k_ms * 1e-3), 1) if k_ms > 0 else 0.0,
-                    "table_ms": round(table_ms / args.steps, 4), "merge_ms": round(merge_ms / args.steps, 4)}
+                    "table_ms": round(table_ms / args.steps, 4), "merge_ms": round(merge_ms / args.steps, 4),
+                    "pruned_frac": round(skipped / wtotal, 4) if wtotal else 0.0, "prune_skips": nskips}
         # ---- CPU baseline: the literal oracle (port of mapper2_body + driver), node-parallel on the host cores
         cpu = None
         n_cpu = args.cpu_queries

@@ -109,6 +109,9 @@ typedef struct ugp_timing {
                             the packed path, 64-sample tiles on the 32-bit path */
     uint32_t n_groups;   /* waves per tile in the last call                     */
     uint32_t packed_path; /* 1: 8-samples-per-lane 16-bit kernel + phase 2; 0: 32-bit kernel */
+    uint32_t reserved;
+    uint64_t words_total;   /* packed path: stream words x tiles the dominant kernel had to cover      */
+    uint64_t words_skipped; /* ... of which exact lower-bound pruning skipped (0 with UGP_NO_PRUNE)    */
 } ugp_timing;
 
 /* Flatten + upload.  device = HIP device ordinal.  Replaces the per-sample

@@ -114,14 +114,16 @@ def place(flat, sample, n_groups=1, want_scores=False):
 # packed stream ("stream8"): interpreter of k_best8 + phase 2, one sample at a
 # time but with the kernel's 16-bit wrap-around arithmetic and 4-bit counters.
 # --------------------------------------------------------------------------
-H_TAG, H_SKIPD, H_NOSCORE8, H_END, H_FREE, H_CHUNK_END, H_NOP = (
-    1 << 31, 1 << 12, 1 << 13, 1 << 16, 1 << 17, 1 << 18, 1 << 19)
+H_TAG, H_SKIPD, H_NOSCORE8, H_END, H_FREE, H_CHUNK_END, H_NOP, H_INFO = (
+    1 << 31, 1 << 12, 1 << 13, 1 << 16, 1 << 17, 1 << 18, 1 << 19, 1 << 30)
 M_FLUSH, M_END = 1 << 28, 1 << 30
 U16 = 0xFFFF
 
 
-def best8_group(flat, nib, dbot, c0, c1):
-    """Chunk-local minima of one sample for chunks [c0, c1), as k_best8 computes them."""
+def best8_group(flat, nib, dbot, c0, c1, ub=None, stats=None):
+    """Chunk-local minima of one sample for chunks [c0, c1), as k_best8 computes them.
+    ub: None = no pruning; otherwise a one-element list holding an upper bound of the sample's best
+    score, used (and tightened at chunk ends) exactly like the kernel's shared bound."""
     slots = {}
     lbest = {}
     best = U16
@@ -150,15 +152,25 @@ def best8_group(flat, nib, dbot, c0, c1):
         accP = accC = accN = 0
         flushed = False
 
-    for words, lo, hi in ((flat.pre8_stream, int(flat.chunk8_pre_off[c0]), int(flat.chunk8_pre_off[c0 + 1])),
-                          (flat.stream8, int(flat.chunk8_body_off[c0]), int(flat.chunk8_body_off[c1]))):
-        for i in range(lo, hi):
+    info = None
+    for phase, (words, lo, hi) in enumerate(((flat.pre8_stream, int(flat.chunk8_pre_off[c0]), int(flat.chunk8_pre_off[c0 + 1])),
+                                             (flat.stream8, int(flat.chunk8_body_off[c0]), int(flat.chunk8_body_off[c1])))):
+        i = lo - 1
+        while i + 1 < hi:
+            i += 1
             w = int(words[i])
+            ended = False
             if w & H_TAG:
                 if w & H_NOP:
                     continue
+                if w & H_INFO:
+                    if ub is not None and phase == 1:
+                        info = w
+                    continue
                 if w & H_CHUNK_END:
                     lbest[chunk] = best
+                    if ub is not None:
+                        ub[0] = min(ub[0], best)
                     best = U16
                     chunk += 1
                     continue
@@ -167,6 +179,7 @@ def best8_group(flat, nib, dbot, c0, c1):
                 dpar = dcur if rslot == RS_REG else (dbot if rslot == RS_BOTTOM else slots[rslot])
                 if w & H_END:
                     finish()
+                    ended = True
             else:
                 site, mi, pi = w & 0x3FFFFF, (w >> 22) & 3, (w >> 24) & 3
                 x = int(nib[site])
@@ -182,20 +195,37 @@ def best8_group(flat, nib, dbot, c0, c1):
                     flushed = True
                 if w & M_END:
                     finish()
+                    ended = True
+            if ended and info is not None:
+                hs, jump = (info >> 22) & 0xFF, info & 0x3FFFFF
+                info = None
+                if dcur >= ub[0] + 1 + hs:          # D(node) - hsub > upper bound: no descendant can tie or win
+                    target = i + 1 + jump
+                    if stats is not None:
+                        stats["skipped"] = stats.get("skipped", 0) + min(target, hi) - (i + 1)
+                    while chunk < c1 and target > int(flat.chunk8_body_off[chunk + 1]) - 1:
+                        lbest[chunk] = best
+                        ub[0] = min(ub[0], best)
+                        best = U16
+                        chunk += 1
+                    i = target - 1
     assert chunk == c1
     return lbest
 
 
-def place8(flat, sample, n_groups=1):
-    """Phase 1 (k_best8) + phase 2 (k_gbest, k_select, k_ties with the 32-bit walk, k_final)."""
+def place8(flat, sample, n_groups=1, prune_ub=None, stats=None):
+    """Phase 1 (k_best8) + phase 2 (k_gbest, k_select, k_ties with the 32-bit walk, k_final).
+    prune_ub: None = no pruning; an int = initial upper bound shared by the groups (0x7F7F = the
+    kernel's start value; the true best = the tightest legal bound)."""
     nib, dbot = sample_site_alleles(flat, sample)
     n_chunks = len(flat.chunk8_body_off) - 1
     n_groups = max(1, min(n_groups, n_chunks))
     lbest = {}
+    ub = None if prune_ub is None else [int(prune_ub)]
     for g in range(n_groups):
         c0, c1 = g * n_chunks // n_groups, (g + 1) * n_chunks // n_groups
         if c0 < c1:
-            lbest.update(best8_group(flat, nib, dbot, c0, c1))
+            lbest.update(best8_group(flat, nib, dbot, c0, c1, ub, stats))
     assert len(lbest) == n_chunks
     gbest = min(lbest.values())
     cnt, key = 0, 0

@@ -37,9 +37,10 @@ def _check(arrays, samples, chunk_nodes, n_groups, scores=True):
             assert got[k] == want[k], (s["name"], k, got[k], want[k])
         if scores:
             assert got["scores"].tolist() == want["scores"].tolist()
-        got8 = stream_interp.place8(flat, s, n_groups=n_groups)
-        for k in ("best", "num_best", "best_j", "has_unique"):
-            assert got8[k] == want[k], ("packed", s["name"], k, got8[k], want[k])
+        for ub in (None, 0x7F7F, want["best"]):   # no pruning / the kernel's start bound / the tightest legal bound
+            got8 = stream_interp.place8(flat, s, n_groups=n_groups, prune_ub=ub)
+            for k in ("best", "num_best", "best_j", "has_unique"):
+                assert got8[k] == want[k], ("packed", ub, s["name"], k, got8[k], want[k])
     return flat
 
 
@@ -103,3 +104,22 @@ def test_packed_stream_flushes_long_branches():
     arrays, queries = synth.make_case(50, n_leaves=40, n_queries=8, n_sites=200, mut_counts=(0, 1, 17, 33, 40))
     flat = _check(arrays, queries, chunk_nodes=7, n_groups=4)
     assert ((flat.stream8 & (1 << 28)) != 0).any() and flat.max_path_muts > 30
+
+
+def test_pruning_records_skip_far_subtrees_exactly():
+    """Trees large enough to carry pruning records (subtrees >= 256 stream words): with a tight
+    upper bound most of the stream is skipped and the result does not change."""
+    arrays, queries = synth.make_case(61, n_leaves=3000, n_queries=6, n_sites=400, n_ambig=(0, 0, 2))
+    flat = FlatTreeView(arrays, chunk_nodes=700)
+    assert ((flat.stream8 >> 30) == 3).sum() > 5            # H_TAG | H_INFO words exist
+    ot = capi.OracleTree(arrays)
+    skipped = 0
+    for s in queries:
+        want = ot.place(s)
+        for ub in (0x7F7F, want["best"]):
+            st = {}
+            got = stream_interp.place8(flat, s, n_groups=3, prune_ub=ub, stats=st)
+            for k in ("best", "num_best", "best_j", "has_unique"):
+                assert got[k] == want[k], (ub, k)
+            skipped += st.get("skipped", 0)
+    assert skipped > len(flat.stream8)                      # pruning really happened

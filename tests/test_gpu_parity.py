@@ -181,3 +181,23 @@ def test_usher_cli_on_gpu_matches_reference(tmp_path):
             if not os.path.exists(want):
                 want += ".gz"
             assert read(str(d / name)) == read(want), (flags, name)
+
+
+def test_locality_sort_and_pruning_paths_are_exact(monkeypatch):
+    """Force the speed-only machinery (coarse-MAT locality sort, pruning records, work queues) onto a
+    mid-size tree and a multi-tile batch; results must not change, with every switch combination."""
+    arrays, queries = synth.make_case(71, n_leaves=6000, n_queries=1300, n_sites=500, n_ambig=(0, 0, 2, 5))
+    ot = capi.OracleTree(arrays)
+    want = [ot.place(s, want_ties=False) for s in queries]
+    batch = QueryBatch(queries)
+    for env in ({"UGP_COARSE_MIN_NODES": "0"}, {"UGP_COARSE_MIN_NODES": "0", "UGP_UNIT_CHUNKS": "1"},
+                {"UGP_NO_SORT": "1"}, {"UGP_NO_PRUNE": "1"}, {"UGP_FORCE_V1": "1"}):
+        for k in ("UGP_COARSE_MIN_NODES", "UGP_UNIT_CHUNKS", "UGP_NO_SORT", "UGP_NO_PRUNE", "UGP_FORCE_V1"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        pl = Placer(arrays, chunk_nodes=300)
+        res = pl.place(batch)
+        for i, w in enumerate(want):
+            _assert_same(res, i, w, "%s #%d" % (env, i))
+        pl.close()

@@ -34,7 +34,8 @@ class ugp_info(C.Structure):
 
 class ugp_timing(C.Structure):
     _fields_ = [("table_ms", C.c_float), ("place_ms", C.c_float), ("merge_ms", C.c_float),
-                ("place_launches", C.c_uint32), ("n_tiles", C.c_uint32), ("n_groups", C.c_uint32), ("packed_path", C.c_uint32)]
+                ("place_launches", C.c_uint32), ("n_tiles", C.c_uint32), ("n_groups", C.c_uint32), ("packed_path", C.c_uint32),
+                ("reserved", C.c_uint32), ("words_total", C.c_uint64), ("words_skipped", C.c_uint64)]
 
 
 # every symbol include/usher_amd.h declares: name -> (restype, argtypes)

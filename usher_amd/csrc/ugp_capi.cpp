@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <new>
@@ -73,7 +74,14 @@ struct ugp_mat {
     DevBuf<uint8_t> d_site_ref;
     // per-call workspaces (grown on demand)
     DevBuf<uint32_t> d_table, d_dbottom, d_part_best, d_part_cnt, d_part_key;
-    DevBuf<uint32_t> d_lbest, d_gbest, d_items, d_nitems, d_cnt, d_key, d_active;
+    DevBuf<uint32_t> d_lbest, d_gbest, d_items, d_nitems, d_cnt, d_key, d_active, d_ub, d_queue;
+    DevBuf<uint64_t> d_stats;
+    uint64_t last_words_total = 0;
+    // locality sort (speed only): a coarse MAT of the top of the tree and the map coarse BFS index -> DFS rank in the full tree
+    ugp_mat *coarse = nullptr;
+    DevBuf<uint32_t> d_coarse2dfs, d_keys, d_keys2, d_idx, d_order, d_slot;
+    DevBuf<ugp_result> d_coarse_res;
+    DevBuf<uint8_t> d_sort_tmp;
     bool last_used_best8 = false;
     std::vector<EventSet> events;
     size_t events_used = 0;
@@ -159,20 +167,29 @@ int run_place(ugp_mat *m, ugp_qset *qs, int mode, ugp_result *d_out, int32_t *d_
     // reference-everywhere sites) always have the valid row 0 to fetch
     const uint32_t n_sites = std::max<uint32_t>((uint32_t)f.n_sites, 1u);
     const uint32_t active_words = (n_sites + 31) / 32;
+    // Locality sort: place every sample on the coarse top-of-the-tree MAT first; samples are then
+    // assigned to 512-sample tiles in the DFS order of that coarse placement (k_sort_keys).
+    const bool packed_ok = (mode == 0) && !getenv("UGP_FORCE_V1") && (qs->max_rows + f.max_path_muts + 2 < 0x7FFFull);
+    const bool sorted = packed_ok && m->coarse && Q > 512 && !getenv("UGP_NO_SORT") && !getenv("UGP_NO_PRUNE");
+    if (sorted) {
+        HIP_TRY(m->d_coarse_res.reserve(Q));
+        if (int rc = run_place(m->coarse, qs, 0, m->d_coarse_res.p, nullptr, nullptr, nullptr, nullptr, nullptr, 0, s)) return rc;
+        HIP_TRY(hipSetDevice(m->device));
+    }
     for (uint64_t q0 = 0; q0 < Q; q0 += (uint64_t)kMaxTilesPerLaunch * 64) {
         const uint64_t nq = std::min<uint64_t>(Q - q0, (uint64_t)kMaxTilesPerLaunch * 64);
         const uint32_t n_tiles = (uint32_t)((nq + 63) / 64);
         const uint32_t n_tiles512 = (uint32_t)((nq + 511) / 512);
         // 16-bit packed phase 1 is exact while every D / cost stays below 0x8000 (bit 15 is the ineligible flag)
-        const bool use8 = (mode == 0) && !getenv("UGP_FORCE_V1") &&
-                          (qs->max_rows + f.max_path_muts + 2 < 0x7FFFull);
+        const bool use8 = packed_ok;
         uint32_t G = pick_groups(m, n_tiles);
-        if (use8) {   // one XCD-load of waves per tile once there are >= 8 tiles (see k_best8)
-            uint32_t waves = 3072;
-            if (const char *e = getenv("UGP_TARGET_WAVES")) waves = (uint32_t)std::max(1, atoi(e));
-            G = std::max<uint32_t>(1, waves / std::min<uint32_t>(n_tiles512, 8));
-            if (const char *e = getenv("UGP_GROUPS")) G = (uint32_t)std::max(1, atoi(e));
-            G = std::min<uint32_t>(G, f.n_chunks);
+        if (use8) {   // work units of a few chunks each, pulled from per-XCD queues by persistent waves (see k_best8)
+            uint32_t unit_chunks = 4;
+            if (const char *e = getenv("UGP_UNIT_CHUNKS")) unit_chunks = (uint32_t)std::max(1, atoi(e));
+            G = std::max<uint32_t>(1, (f.n_chunks + unit_chunks - 1) / unit_chunks);
+            // a small batch still has to fill the chip: at least ~4096 units in total
+            while (G < f.n_chunks && (uint64_t)G * n_tiles512 < 4096) G = std::min<uint32_t>(f.n_chunks, G * 2);
+            if (const char *e = getenv("UGP_GROUPS")) G = std::min<uint32_t>(f.n_chunks, (uint32_t)std::max(1, atoi(e)));
         }
         const uint64_t table_dwords = (uint64_t)n_tiles512 * n_sites * 64;
         HIP_TRY(m->d_table.reserve(table_dwords));
@@ -182,6 +199,8 @@ int run_place(ugp_mat *m, ugp_qset *qs, int mode, ugp_result *d_out, int32_t *d_
         if (use8) {
             HIP_TRY(m->d_lbest.reserve((size_t)f.n_chunks * n_tiles512 * 256));
             HIP_TRY(m->d_gbest.reserve((size_t)n_tiles512 * 256));
+            HIP_TRY(m->d_ub.reserve((size_t)n_tiles512 * 256));
+            HIP_TRY(m->d_queue.reserve(8));
             HIP_TRY(m->d_items.reserve(pairs));
             HIP_TRY(m->d_nitems.reserve(1));
             HIP_TRY(m->d_cnt.reserve((size_t)n_tiles512 * 512));
@@ -197,17 +216,31 @@ int run_place(ugp_mat *m, ugp_qset *qs, int mode, ugp_result *d_out, int32_t *d_
         const uint64_t e0 = qs->ent_off[q0], e1 = qs->ent_off[q0 + nq];
 
         HIP_TRY(hipEventRecord(es.ev[0], s));
+        const uint32_t *slot_of = nullptr, *order = nullptr;
+        if (sorted) {
+            HIP_TRY(m->d_keys.reserve(nq)); HIP_TRY(m->d_keys2.reserve(nq)); HIP_TRY(m->d_idx.reserve(nq));
+            HIP_TRY(m->d_order.reserve(nq)); HIP_TRY(m->d_slot.reserve(nq));
+            size_t tmp_bytes = 0;
+            HIP_TRY(ugp::launch_locality_sort(nullptr, nullptr, (uint32_t)nq, m->d_keys.p, m->d_keys2.p, m->d_idx.p, m->d_order.p,
+                                              m->d_slot.p, nullptr, &tmp_bytes, s));
+            HIP_TRY(m->d_sort_tmp.reserve(tmp_bytes));
+            HIP_TRY(ugp::launch_locality_sort(m->d_coarse_res.p + q0, m->d_coarse2dfs.p, (uint32_t)nq, m->d_keys.p, m->d_keys2.p,
+                                              m->d_idx.p, m->d_order.p, m->d_slot.p, m->d_sort_tmp.p, &tmp_bytes, s));
+            slot_of = m->d_slot.p; order = m->d_order.p;
+        }
         HIP_TRY(hipMemsetAsync(m->d_dbottom.p, 0, (size_t)n_tiles512 * 512 * sizeof(uint32_t), s));
         HIP_TRY(hipMemsetAsync(m->d_active.p, 0, (size_t)n_tiles512 * active_words * sizeof(uint32_t), s));
         if (use8) {
             HIP_TRY(hipMemsetAsync(m->d_nitems.p, 0, sizeof(uint32_t), s));
+            HIP_TRY(hipMemsetAsync(m->d_queue.p, 0, 8 * sizeof(uint32_t), s));
+            HIP_TRY(hipMemsetAsync(m->d_ub.p, 0x7F, (size_t)n_tiles512 * 256 * sizeof(uint32_t), s));   // 0x7F7F: above every valid cost
             HIP_TRY(hipMemsetAsync(m->d_cnt.p, 0, (size_t)n_tiles512 * 512 * sizeof(uint32_t), s));
             HIP_TRY(hipMemsetAsync(m->d_key.p, 0, (size_t)n_tiles512 * 512 * sizeof(uint32_t), s));
         }
         HIP_TRY(ugp::launch_fill_table(m->d_table.p, m->d_site_ref.p, n_sites, table_dwords, s));
         HIP_TRY(ugp::launch_scatter(m->d_table.p, m->d_dbottom.p, qs->d_pos.p + e0, qs->d_ref.p + e0,
                                     qs->d_nuc.p + e0, qs->d_missing.p + e0, qs->d_ent_q.p + e0, m->d_pos2site.p,
-                                    f.max_pos, n_sites, e1 - e0, (uint32_t)q0, m->d_active.p, active_words, s));
+                                    f.max_pos, n_sites, e1 - e0, (uint32_t)q0, m->d_active.p, active_words, slot_of, s));
         HIP_TRY(hipEventRecord(es.ev[1], s));
 
         ugp::PlaceArgs a;
@@ -232,13 +265,19 @@ int run_place(ugp_mat *m, ugp_qset *qs, int mode, ugp_result *d_out, int32_t *d_
             b.table = m->d_table.p; b.dbottom = m->d_dbottom.p;
             b.n_sites = n_sites; b.n_chunks = f.n_chunks; b.n_groups = G; b.n_tiles = n_tiles512;
             b.lbest = m->d_lbest.p;
+            b.queue = m->d_queue.p;
+            b.ub = getenv("UGP_NO_PRUNE") ? nullptr : m->d_ub.p;
+            HIP_TRY(m->d_stats.reserve(32));
+            if (q0 == 0) { HIP_TRY(hipMemsetAsync(m->d_stats.p, 0, 32 * sizeof(uint64_t), s)); m->last_words_total = 0; }
+            b.stats = getenv("UGP_STATS") ? m->d_stats.p : nullptr;   // the counters are two contended atomics per skip: debug only
+            m->last_words_total += (uint64_t)n_tiles512 * m->stream8_dwords;
             b.max_slots = f.max_slots;
             b.active = m->d_active.p; b.active_words = active_words;
             HIP_TRY(ugp::launch_best8(b, f.max_slots, s));
             HIP_TRY(hipEventRecord(es.ev[2], s));
             HIP_TRY(ugp::launch_phase2(a, m->d_lbest.p, m->d_gbest.p, n_tiles512, m->d_items.p, m->d_nitems.p,
                                        (uint32_t)std::min<uint64_t>(pairs, 0xFFFFFFFFull), m->d_cnt.p, m->d_key.p,
-                                       m->d_rank2bfs.p, d_out + q0, f.max_slots, s));
+                                       m->d_rank2bfs.p, d_out + q0, order, f.max_slots, s));
         } else {
             HIP_TRY(ugp::launch_place(a, mode, f.max_slots, s));
             HIP_TRY(hipEventRecord(es.ev[2], s));
@@ -263,7 +302,46 @@ extern "C" {
 
 const char *ugp_last_error(void) { return g_err.c_str(); }
 
-static int mat_create_impl(const ugp_tree_desc *tree, int device, const ugp::Options &opt, ugp_mat **out) {
+static int mat_create_impl(const ugp_tree_desc *tree, int device, const ugp::Options &opt, ugp_mat **out, bool with_coarse = true);
+
+// The top of the tree (nodes with the largest subtrees, about N/128 of them) as a MAT of its own.
+static int build_coarse(const ugp_tree_desc *t, int device, const std::vector<uint32_t> &dfs2bfs, ugp_mat *m) {
+    const uint64_t N = t->n_nodes;
+    uint64_t min_nodes = 1u << 18;   // below this a tree pass is too short for the sort to pay off
+    if (const char *e = getenv("UGP_COARSE_MIN_NODES")) min_nodes = (uint64_t)atoll(e);   // tests lower it
+    if (N < min_nodes || N < 64 || getenv("UGP_NO_SORT")) return UGP_OK;
+    std::vector<uint32_t> sub(N, 1);
+    for (uint64_t j = N; j-- > 1;) sub[t->parent[j]] += sub[j];
+    const uint64_t target = std::min<uint64_t>(N / 2, std::max<uint64_t>(N / 128, std::min<uint64_t>(4096, N / 4)));
+    std::vector<uint32_t> sorted_sub(sub);
+    std::nth_element(sorted_sub.begin(), sorted_sub.begin() + (N - target), sorted_sub.end());
+    const uint32_t S = std::max<uint32_t>(2, sorted_sub[N - target]);
+    std::vector<uint32_t> newid(N, UINT32_MAX), keep;
+    for (uint64_t j = 0; j < N; j++) if (sub[j] >= S || j == 0) { newid[j] = (uint32_t)keep.size(); keep.push_back((uint32_t)j); }
+    std::vector<uint32_t> parent(keep.size());
+    std::vector<uint64_t> mut_off(keep.size() + 1, 0);
+    std::vector<int32_t> pos; std::vector<uint8_t> ref, par, nuc;
+    for (size_t k = 0; k < keep.size(); k++) {
+        const uint32_t j = keep[k];
+        parent[k] = j ? newid[t->parent[j]] : UINT32_MAX;
+        for (uint64_t i = t->mut_off[j]; i < t->mut_off[j + 1]; i++) {
+            pos.push_back(t->mut_pos[i]); ref.push_back(t->mut_ref[i]);
+            par.push_back(t->mut_par ? t->mut_par[i] : 0); nuc.push_back(t->mut_nuc[i]);
+        }
+        mut_off[k + 1] = pos.size();
+    }
+    ugp_tree_desc d{keep.size(), parent.data(), mut_off.data(), pos.data(), ref.data(), par.data(), nuc.data()};
+    ugp::Options copt;
+    int rc = mat_create_impl(&d, device, copt, &m->coarse, false);
+    if (rc != UGP_OK) return rc;
+    std::vector<uint32_t> dfs_rank(N), c2d(keep.size());
+    for (uint64_t r = 0; r < N; r++) dfs_rank[dfs2bfs[r]] = (uint32_t)r;
+    for (size_t k = 0; k < keep.size(); k++) c2d[k] = dfs_rank[keep[k]];
+    if (m->d_coarse2dfs.upload(c2d) != hipSuccess) return fail(UGP_ERR_HIP, "upload coarse table");
+    return UGP_OK;
+}
+
+static int mat_create_impl(const ugp_tree_desc *tree, int device, const ugp::Options &opt, ugp_mat **out, bool with_coarse) {
     if (!tree || !out) return fail(UGP_ERR_INVALID, "null argument");
     *out = nullptr;
     ugp_mat *m = new (std::nothrow) ugp_mat();
@@ -306,6 +384,9 @@ static int mat_create_impl(const ugp_tree_desc *tree, int device, const ugp::Opt
     m->stream8_dwords = f.stream8.size();
     std::vector<uint32_t>().swap(f.stream8);
     std::vector<uint32_t>().swap(f.pre8_stream);
+    if (with_coarse) {
+        if (int rc = build_coarse(tree, device, f.dfs2bfs, m)) { delete m; return rc; }
+    }
     m->stream_dwords = f.stream.size();
     m->pre_dwords = f.pre_stream.size();
     std::vector<uint32_t>().swap(f.stream);
@@ -328,6 +409,7 @@ void ugp_mat_destroy(ugp_mat *m) {
     for (auto &es : m->events)
         for (int i = 0; i < 4; i++)
             if (es.ev[i]) (void)hipEventDestroy(es.ev[i]);
+    if (m->coarse) ugp_mat_destroy(m->coarse);
     delete m;
 }
 
@@ -504,6 +586,20 @@ int ugp_get_timing(ugp_mat *m, ugp_timing *out) {
             HIP_TRY(hipEventElapsedTime(&t, es.ev[2], es.ev[3])); merge += t;
         }
         m->last.table_ms = table; m->last.place_ms = place; m->last.merge_ms = merge;
+        m->last.words_total = m->last_words_total;
+        m->last.words_skipped = 0;
+        if (m->last_used_best8 && m->d_stats.p) {
+            uint64_t v[32] = {0};
+            HIP_TRY(hipMemcpy(v, m->d_stats.p, sizeof v, hipMemcpyDeviceToHost));
+            m->last.words_skipped = v[0];
+            m->last.reserved = (uint32_t)std::min<uint64_t>(v[1], 0xFFFFFFFFull);   // pipeline (re)starts
+            if (getenv("UGP_STATS")) {
+                fprintf(stderr, "[ugp stats] restarts=%llu restart_cycles=%llu wave_cycles=%llu max_wave=%llu hist:", (unsigned long long)v[1],
+                        (unsigned long long)v[2], (unsigned long long)v[3], (unsigned long long)v[4]);
+                for (int i = 0; i < 16; i++) fprintf(stderr, " %llu", (unsigned long long)v[5 + i]);
+                fprintf(stderr, "\n");
+            }
+        }
         m->timing_pending = false;
     }
     *out = m->last;

@@ -279,14 +279,44 @@ int flatten(const ugp_tree_desc &t, const Options &opt, FlatMat &out, std::strin
         // the root scores through a pseudo-node right behind its D record: cost = D(parent) = D(root)
         if (root && !preamble) dst.push_back(H_TAG | RS_REG | (WS_NONE << 6) | H_SKIPD | H_FREE | H_END);
     };
+    // pruning records: hsub[j] = max mutation words on a path j -> descendant (excluding j's own),
+    // subw[j] = stream words of j's descendants (approximate: without the records themselves)
+    std::vector<uint32_t> hsub(N, 0), subw(N, 0), dfsidx(N, 0);
+    for (uint64_t d = 0; d < N; d++) dfsidx[out.dfs2bfs[d]] = (uint32_t)d;
+    for (uint64_t j = N; j-- > 1;) {
+        const uint32_t nw = out.stream[rec_off[j]] & 0xFFFFu;
+        const uint32_t p = t.parent[j];
+        hsub[p] = std::max(hsub[p], nw + hsub[j]);
+        subw[p] += subw[j] + (dropped[j] ? 0u : 1u + nw);
+    }
+    struct OpenBig { uint32_t info_pos, own_end, dfs_end; };
+    std::vector<OpenBig> open_big;
+    auto close_big = [&](uint32_t next_dfs) {   // patch the records of subtrees that end before DFS node next_dfs
+        while (!open_big.empty() && open_big.back().dfs_end <= next_dfs) {
+            const OpenBig &b = open_big.back();
+            const uint64_t jump = out.stream8.size() - b.own_end;
+            const uint32_t hs = (out.stream8[b.info_pos] >> 22) & 0xFFu;
+            out.stream8[b.info_pos] = (jump < (1u << 22) && jump > 0) ? (H_TAG | H_INFO | (hs << 22) | (uint32_t)jump) : (H_TAG | H_NOP);
+            open_big.pop_back();
+        }
+    };
     out.stream8.clear(); out.pre8_stream.clear(); out.chunk8_body_off.clear(); out.chunk8_pre_off.clear();
     out.stream8.reserve(N + n_real + out.n_chunks);
     for (uint32_t c = 0; c < out.n_chunks; c++) {
         out.chunk8_body_off.push_back((uint32_t)out.stream8.size());
         for (uint32_t d = out.chunk_node_off[c]; d < out.chunk_node_off[c + 1]; d++) {
             uint32_t j = out.dfs2bfs[d];
-            if (!dropped[j]) emit8(out.stream8, j, false);
+            close_big(d);
+            if (dropped[j]) continue;
+            const bool big = j != 0 && subw[j] >= PRUNE_MIN_WORDS && hsub[j] <= 255;
+            if (big) {
+                open_big.push_back({(uint32_t)out.stream8.size(), 0u, d + sub[j]});
+                out.stream8.push_back(H_TAG | H_INFO | (hsub[j] << 22));   // jump patched when the subtree closes
+            }
+            emit8(out.stream8, j, false);
+            if (big) open_big.back().own_end = (uint32_t)out.stream8.size();
         }
+        close_big(out.chunk_node_off[c + 1]);
         out.stream8.push_back(H_TAG | H_CHUNK_END);
         out.chunk8_pre_off.push_back((uint32_t)out.pre8_stream.size());
         uint32_t a = out.dfs2bfs[out.chunk_node_off[c]];
@@ -303,7 +333,7 @@ int flatten(const ugp_tree_desc &t, const Options &opt, FlatMat &out, std::strin
     {
         uint64_t freq[64] = {0};
         for (uint32_t w : out.stream8) {
-            if (!(w & H_TAG) || (w & (H_CHUNK_END | H_NOP))) continue;
+            if (!(w & H_TAG) || (w & (H_CHUNK_END | H_NOP | H_INFO))) continue;
             uint32_t rs = w & 63u, ws = (w >> 6) & 63u;
             if (rs < RS_BOTTOM) freq[rs]++;
             if (ws != WS_NONE) freq[ws]++;
@@ -315,7 +345,7 @@ int flatten(const ugp_tree_desc &t, const Options &opt, FlatMat &out, std::strin
         for (uint32_t i = 0; i < out.max_slots; i++) remap[order[i]] = i;
         auto fix = [&](std::vector<uint32_t> &v) {
             for (uint32_t &w : v) {
-                if (!(w & H_TAG) || (w & (H_CHUNK_END | H_NOP))) continue;
+                if (!(w & H_TAG) || (w & (H_CHUNK_END | H_NOP | H_INFO))) continue;
                 uint32_t rs = w & 63u, ws = (w >> 6) & 63u;
                 if (rs < RS_BOTTOM) rs = remap[rs];
                 if (ws != WS_NONE) ws = remap[ws];

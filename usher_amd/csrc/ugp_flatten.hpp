@@ -45,6 +45,11 @@ constexpr uint32_t MAX_SLOTS = 40;        // > log2(2^32) + 1
 //       H_END     node has no mutation words: finish it now
 //       H_CHUNK_END (alone) closes a chunk: publish the chunk-local minimum and reset
 //       H_NOP     padding
+//       H_INFO    (alone, in front of the header of a node with a large subtree) pruning record:
+//                 [21:0] jump = stream words occupied by the node's descendants,
+//                 [29:22] hsub = largest number of mutation words on any path node -> descendant;
+//                 every descendant d has cost(d) >= D(node) - hsub (each mutation lowers D by at most 1),
+//                 so the subtree can be skipped when D(node,s) - hsub > upper bound of best(s) for all s
 //     The root is emitted as two records: its D record (rslot = RS_BOTTOM,
 //     H_NOSCORE) followed by a scoring pseudo-node (RS_REG, H_SKIPD | H_FREE |
 //     H_END) whose cost is D(parent) = D(root): cost(root) = D(root), always
@@ -54,7 +59,8 @@ constexpr uint32_t MAX_SLOTS = 40;        // > log2(2^32) + 1
 //       M_FLUSH  15 mutations accumulated in the 4-bit counters: spill them
 //       M_END    last mutation word of the node
 constexpr uint32_t H_TAG = 1u << 31, H_SKIPD = 1u << 12, H_NOSCORE = 1u << 13, H_END = 1u << 16,
-                   H_FREE = 1u << 17, H_CHUNK_END = 1u << 18, H_NOP = 1u << 19;
+                   H_FREE = 1u << 17, H_CHUNK_END = 1u << 18, H_NOP = 1u << 19, H_INFO = 1u << 30;
+constexpr uint32_t PRUNE_MIN_WORDS = 48;    // only subtrees at least this long carry a pruning record
 constexpr uint32_t M_FLUSH = 1u << 28, M_END = 1u << 30;
 constexpr uint32_t MAX_SITES = 1u << 22;
 constexpr uint32_t MAX_NODE_MUTS = 65535;

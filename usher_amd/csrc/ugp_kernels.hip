@@ -29,8 +29,10 @@
 //   k_place   one sample per lane, 32-bit: per-node scores (-p), tie lists, and
 //             the general fallback when 16-bit counters could overflow.
 #include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
 #include <stdint.h>
 
+#include <algorithm>
 #include <type_traits>
 
 #include "ugp_kernels.hpp"
@@ -77,10 +79,12 @@ __global__ void k_scatter_entries(uint32_t *__restrict__ table, uint32_t *__rest
                                   const uint8_t *__restrict__ nuc, const uint8_t *__restrict__ is_missing,
                                   const uint32_t *__restrict__ ent_q, const int32_t *__restrict__ pos2site,
                                   uint32_t max_pos, uint32_t n_sites, uint64_t n_ent, uint32_t q_base,
-                                  uint32_t *__restrict__ active, uint32_t active_words) {
+                                  uint32_t *__restrict__ active, uint32_t active_words,
+                                  const uint32_t *__restrict__ slot_of) {
     uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= n_ent) return;
-    const uint32_t q = ent_q[e] - q_base;   // sample index within this launch's tiles
+    uint32_t q = ent_q[e] - q_base;         // sample index within this launch
+    if (slot_of) q = slot_of[q];            // ... and its place in the locality-sorted tiles
     const int32_t p = pos[e];
     const uint32_t r = ref[e];
     const uint32_t miss = is_missing[e];
@@ -294,21 +298,36 @@ __global__ void __launch_bounds__(64) k_best8(Best8Args a) {
     // vmcnt(0) before every table-row use and destroys the prefetch pipeline.)
     auto slot_load = [&](uint32_t sl) -> u32x4 { return slots8[sl * 64 + lane]; };
     auto slot_store = [&](uint32_t sl, u32x4 v) { slots8[sl * 64 + lane] = v; };
-    // Work unit u = (tile, group).  Units are dealt to the 8 XCDs in contiguous
-    // runs (block b is observed to land on XCD b % 8), so one XCD walks few tiles
-    // at a time and their non-reference table rows stay resident in its 4 MiB L2.
-    // Placement affects speed only.
-    uint32_t tile, g;
+    // Persistent wave: work units u = (tile, chunk range) are pulled from 8 queues, one per XCD.
+    // Queue x owns a contiguous run of tiles, so an XCD walks few tiles at a time and their
+    // non-reference table rows stay resident in its 4 MiB L2 (block b is observed to land on XCD
+    // b % 8; placement affects speed only).  A wave whose queue is empty steals from the others.
+    // Static one-block-per-unit launches lose ~40 % here: with pruning the unit durations differ
+    // by >10x and the in-order, round-robin-per-XCD workgroup dispatcher stalls behind the slow XCD.
+    const uint32_t home = blockIdx.x & 7u;
+    uint32_t drained = 0;   // bit x: queue x is known to be empty
+    for (;;) {
+    uint32_t tile = 0, g = 0;
     {
-        const uint32_t U = a.n_tiles * a.n_groups, U8 = (U + 7u) >> 3;
-        const uint32_t u = (blockIdx.x & 7u) * U8 + (blockIdx.x >> 3);
-        if (u >= U) return;
-        tile = u / a.n_groups;
-        g = u % a.n_groups;
+        bool got = false;
+        for (uint32_t t = 0; t < 8 && !got; t++) {
+            const uint32_t x = (home + t) & 7u;
+            if (drained & (1u << x)) continue;
+            const uint32_t tlo = x * a.n_tiles / 8u, thi = (x + 1u) * a.n_tiles / 8u;
+            const uint32_t ux = (thi - tlo) * a.n_groups;
+            uint32_t v = 0xFFFFFFFFu;
+            if (ux) {
+                if (lane == 0) v = atomicAdd(&a.queue[x], 1u);
+                v = (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
+            }
+            if (v < ux) { tile = tlo + v / a.n_groups; g = v % a.n_groups; got = true; }
+            else drained |= 1u << x;
+        }
+        if (!got) return;
     }
     const uint32_t c0 = (uint32_t)(((uint64_t)g * a.n_chunks) / a.n_groups);
     const uint32_t c1 = (uint32_t)(((uint64_t)(g + 1) * a.n_chunks) / a.n_groups);
-    if (c0 >= c1) return;
+    if (c0 >= c1) continue;
     // table rows through a buffer resource: address = tile base + 4*lane (VGPR) + 256*site (SGPR soffset)
     const __amdgpu_buffer_rsrc_t trsrc = __builtin_amdgcn_make_buffer_rsrc(
         (void *)(a.table + (uint64_t)tile * a.n_sites * 64), 0, (int)(a.n_sites * 256u), 0x00020000);
@@ -327,18 +346,43 @@ __global__ void __launch_bounds__(64) k_best8(Best8Args a) {
     bool flushed = false;      // uniform
     uint32_t chunk = c0;       // uniform: chunk whose body is being walked
     const uint32_t NOPW = H_TAG | H_NOP;
+    // pruning: ub1 = (upper bound of best(s)) + 1 per sample, refreshed from / published to a.ub at chunk ends
+    bool prune = false;        // uniform; only while walking the body (phase 1)
+    bool have_info = false;    // uniform
+    uint32_t info = 0;         // uniform: pending pruning record
+    uint32_t skip_to = 0;      // uniform: restart request (0 = none)
+    Pk4 ub1;
+#pragma unroll
+    for (int j = 0; j < 4; j++) ub1.v[j] = 0x80008000u;
+    uint32_t *ubp = a.ub ? a.ub + ((uint64_t)tile * 64 + lane) * 4 : nullptr;
+    auto exchange_ub = [&]() {   // ub = min(ub, what other waves found, this chunk's minimum); racy but every value is a real cost
+        if (!ubp) return;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            uint32_t u = __hip_atomic_load(ubp + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            u = pk_min(pk_min(u, best.v[j]), pk_sub(ub1.v[j], 0x00010001u));
+            __hip_atomic_store(ubp + j, u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            ub1.v[j] = pk_add(u, 0x00010001u);
+        }
+    };
+    auto chunk_end = [&]() {     // publish the chunk-local minimum, start the next chunk
+        uint4 *dst = (uint4 *)(a.lbest + (((uint64_t)chunk * a.n_tiles + tile) * 64 + lane) * 4);
+        *dst = make_uint4(best.v[0], best.v[1], best.v[2], best.v[3]);
+        exchange_ub();
+#pragma unroll
+        for (int j = 0; j < 4; j++) best.v[j] = 0xFFFFFFFFu;
+        chunk++;
+    };
 
     // One stream word.  x = the lane's dword of the word's table row (unused for headers).
-    auto step = [&](uint32_t w, uint32_t x) {
+    // `pos` = index of the word inside the wave's range.  A step may ask the pipeline to restart at
+    // another position through skip_to (chunk end: publish results outside the load pipeline; pruning:
+    // jump over a subtree).
+    auto step = [&](uint32_t w, uint32_t x, uint32_t pos) {
         if (w & H_TAG) {
-            if (w & (H_NOP | H_CHUNK_END)) {
-                if (w & H_CHUNK_END) {
-                    uint4 *dst = (uint4 *)(a.lbest + (((uint64_t)chunk * a.n_tiles + tile) * 64 + lane) * 4);
-                    *dst = make_uint4(best.v[0], best.v[1], best.v[2], best.v[3]);
-#pragma unroll
-                    for (int j = 0; j < 4; j++) best.v[j] = 0xFFFFFFFFu;
-                    chunk++;
-                }
+            if (w & (H_NOP | H_CHUNK_END | H_INFO)) {
+                if (w & H_CHUNK_END) skip_to = pos + 1;          // handled by the restart code below
+                else if ((w & H_INFO) && prune) { info = w; have_info = true; }
                 return;
             }
             hdr = w;
@@ -415,6 +459,17 @@ __global__ void __launch_bounds__(64) k_best8(Best8Args a) {
             }
         }
         accP = accC = accN = 0;
+        if (have_info) {   // this node carries a pruning record: can its whole subtree be skipped?
+            have_info = false;
+            const uint32_t hs = ((info >> 22) & 0xFFu) * 0x00010001u;
+            uint32_t bad = 0;   // non-zero where D(node,s) - hsub <= upper bound of best(s)
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const uint32_t t1 = pk_add(ub1.v[j], hs);
+                bad |= pk_min(dcur.v[j], t1) ^ t1;
+            }
+            if (__builtin_amdgcn_ballot_w64(bad != 0) == 0) skip_to = pos + 1 + (info & 0x3FFFFFu);
+        }
     };
 
     // Software pipeline over groups of 8 words, four stages deep:
@@ -426,6 +481,8 @@ __global__ void __launch_bounds__(64) k_best8(Best8Args a) {
     // Every load is unconditional and in a fixed order, which keeps the compiler's vmcnt
     // bookkeeping exact (s_waitcnt vmcnt(N) with the younger loads still in flight).
     const uint32_t *abm = a.active + (uint64_t)tile * a.active_words;
+    const uint64_t t_wave0 = a.stats ? __builtin_amdgcn_s_memtime() : 0;
+    uint64_t t_restart = 0, n_restart = 0;
     for (int phase = 0; phase < 2; phase++) {
         const uint32_t *sp = phase == 0 ? a.pre8 : a.stream8;
         const uint32_t begin = phase == 0 ? a.chunk8_pre_off[c0] : a.chunk8_body_off[c0];
@@ -447,31 +504,59 @@ __global__ void __launch_bounds__(64) k_best8(Best8Args a) {
             const bool act = !(wv & H_TAG) && ((bits >> (wv & 31u)) & 1u);
             return (uint32_t)__builtin_amdgcn_ballot_w64(act) & 0xFFu;
         };
-        uint32_t w0 = load_words(0), w1 = load_words(8), w2 = load_words(16);
-        uint32_t m0 = active_mask(w0, load_bits(w0));
-        uint32_t m1 = active_mask(w1, load_bits(w1));
-        uint32_t X[8];
+        prune = (phase == 1) && ubp != nullptr;
+        if (prune) {   // start from what earlier waves of this tile already know
 #pragma unroll
-        for (int k = 0; k < 8; k++) {
-            const uint32_t w = rdlane(w0, k);
-            X[k] = __builtin_amdgcn_raw_buffer_load_b32(trsrc, lane4, (((m0 >> k) & 1u) ? (w & 0x3FFFFFu) : 0u) << 8, 0);
+            for (int j = 0; j < 4; j++)
+                ub1.v[j] = pk_add(__hip_atomic_load(ubp + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), 0x00010001u);
         }
-        for (uint32_t off = 0; off < n; off += 8) {
-            const uint32_t w3 = load_words(off + 24);
-            const uint32_t b2 = load_bits(w2);
+        uint32_t off = 0;
+        while (off < n) {
+            // (re)fill the pipeline at `off`
+            const uint64_t t_r0 = a.stats ? __builtin_amdgcn_s_memtime() : 0;
+            uint32_t w0 = load_words(off), w1 = load_words(off + 8), w2 = load_words(off + 16);
+            uint32_t m0 = active_mask(w0, load_bits(w0));
+            uint32_t m1 = active_mask(w1, load_bits(w1));
+            uint32_t X[8];
 #pragma unroll
             for (int k = 0; k < 8; k++) {
                 const uint32_t w = rdlane(w0, k);
-                const uint32_t ref_row = 0x11111111u << ((w >> 26) & 3u);   // every sample carries the reference base
-                step(w, ((m0 >> k) & 1u) ? X[k] : ref_row);
-                const uint32_t wn = rdlane(w1, k);
-                X[k] = __builtin_amdgcn_raw_buffer_load_b32(trsrc, lane4, (((m1 >> k) & 1u) ? (wn & 0x3FFFFFu) : 0u) << 8, 0);
+                X[k] = __builtin_amdgcn_raw_buffer_load_b32(trsrc, lane4, (((m0 >> k) & 1u) ? (w & 0x3FFFFFu) : 0u) << 8, 0);
             }
-            m0 = m1;
-            m1 = active_mask(w2, b2);
-            w0 = w1; w1 = w2; w2 = w3;
+            skip_to = 0;
+            if (a.stats) { t_restart += __builtin_amdgcn_s_memtime() - t_r0 + (X[0] & 0u); n_restart++; }
+            for (; off < n; off += 8) {
+                const uint32_t w3 = load_words(off + 24);
+                const uint32_t b2 = load_bits(w2);
+#pragma unroll
+                for (int k = 0; k < 8; k++) {
+                    const uint32_t w = rdlane(w0, k);
+                    const uint32_t ref_row = 0x11111111u << ((w >> 26) & 3u);   // every sample carries the reference base
+                    if (!skip_to) step(w, ((m0 >> k) & 1u) ? X[k] : ref_row, off + k);   // words after a restart request are dead
+                    const uint32_t wn = rdlane(w1, k);
+                    X[k] = __builtin_amdgcn_raw_buffer_load_b32(trsrc, lane4, (((m1 >> k) & 1u) ? (wn & 0x3FFFFFu) : 0u) << 8, 0);
+                }
+                if (skip_to) break;
+                m0 = m1;
+                m1 = active_mask(w2, b2);
+                w0 = w1; w1 = w2; w2 = w3;
+            }
+            if (!skip_to) break;   // walked to the end of the range
+            // restart request: close every chunk whose end marker lies before the new position
+            while (chunk < c1 && skip_to > a.chunk8_body_off[chunk + 1] - 1u - begin) chunk_end();
+            off = skip_to;
         }
     }
+    if (a.stats && lane == 0) {   // debug accounting, one update per wave
+        const unsigned long long tw = __builtin_amdgcn_s_memtime() - t_wave0;
+        unsigned long long *st = (unsigned long long *)a.stats;
+        atomicAdd(st + 1, (unsigned long long)n_restart);
+        atomicAdd(st + 2, (unsigned long long)t_restart);
+        atomicAdd(st + 3, tw);
+        atomicMax(st + 4, tw);
+        atomicAdd(st + 5 + min(tw >> 22, 15ull), 1ull);   // histogram of unit durations, 4.2M-cycle bins
+    }
+    }   // next work unit
 }
 
 // Global minimum per sample over the chunk-local minima.
@@ -544,7 +629,8 @@ __global__ void __launch_bounds__(64) k_ties(PlaceArgs a, const uint32_t *__rest
 }
 
 __global__ void k_final(const uint32_t *__restrict__ gbest, const uint32_t *__restrict__ cnt, const uint32_t *__restrict__ key,
-                        const uint32_t *__restrict__ rank2bfs, uint32_t n_queries, ugp_result *__restrict__ out) {
+                        const uint32_t *__restrict__ rank2bfs, uint32_t n_queries, ugp_result *__restrict__ out,
+                        const uint32_t *__restrict__ order /* slot -> sample, or nullptr */) {
     const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
     if (q >= n_queries) return;
     ugp_result r;
@@ -552,10 +638,38 @@ __global__ void k_final(const uint32_t *__restrict__ gbest, const uint32_t *__re
     r.num_best = cnt[q];
     r.best_j = rank2bfs[key[q] >> 1];
     r.best_has_unique = key[q] & 1u;
-    out[q] = r;
+    out[order ? order[q] : q] = r;
+}
+
+// Locality sort of the samples (speed only): key = DFS rank of the sample's best node in a coarse
+// top-of-the-tree MAT.  Samples that land in the same region of the tree share tiles, so the
+// lower-bound pruning of k_best8 can skip the rest of the tree for the whole tile.
+__global__ void k_sort_keys(const ugp_result *__restrict__ coarse_res, const uint32_t *__restrict__ coarse2dfs, uint32_t n,
+                            uint32_t *__restrict__ keys, uint32_t *__restrict__ idx) {
+    const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= n) return;
+    keys[q] = coarse2dfs[coarse_res[q].best_j];
+    idx[q] = q;
+}
+__global__ void k_invert(const uint32_t *__restrict__ order, uint32_t n, uint32_t *__restrict__ slot_of) {
+    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s < n) slot_of[order[s]] = s;
 }
 
 // ---------------------------------------------------------------- launchers
+
+hipError_t launch_locality_sort(const ugp_result *coarse_res, const uint32_t *coarse2dfs, uint32_t n, uint32_t *keys,
+                                uint32_t *keys_sorted, uint32_t *idx, uint32_t *order, uint32_t *slot_of, void *temp,
+                                size_t *temp_bytes, hipStream_t s) {
+    if (!temp) {   // size query
+        return hipcub::DeviceRadixSort::SortPairs(nullptr, *temp_bytes, keys, keys_sorted, idx, order, (int)n, 0, 32, s);
+    }
+    hipLaunchKernelGGL(k_sort_keys, dim3((n + 255) / 256), dim3(256), 0, s, coarse_res, coarse2dfs, n, keys, idx);
+    hipError_t e = hipcub::DeviceRadixSort::SortPairs(temp, *temp_bytes, keys, keys_sorted, idx, order, (int)n, 0, 32, s);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_invert, dim3((n + 255) / 256), dim3(256), 0, s, order, n, slot_of);
+    return hipGetLastError();
+}
 
 hipError_t launch_fill_table(uint32_t *table, const uint8_t *site_ref, uint32_t n_sites, uint64_t total_dwords,
                              hipStream_t s) {
@@ -569,11 +683,11 @@ hipError_t launch_fill_table(uint32_t *table, const uint8_t *site_ref, uint32_t 
 hipError_t launch_scatter(uint32_t *table, uint32_t *dbottom, const int32_t *pos, const uint8_t *ref,
                           const uint8_t *nuc, const uint8_t *is_missing, const uint32_t *ent_q,
                           const int32_t *pos2site, uint32_t max_pos, uint32_t n_sites, uint64_t n_ent, uint32_t q_base,
-                          uint32_t *active, uint32_t active_words, hipStream_t s) {
+                          uint32_t *active, uint32_t active_words, const uint32_t *slot_of, hipStream_t s) {
     if (n_ent == 0) return hipSuccess;
     uint64_t blocks = (n_ent + 255) / 256;
     hipLaunchKernelGGL(k_scatter_entries, dim3((uint32_t)blocks), dim3(256), 0, s, table, dbottom, pos, ref, nuc,
-                       is_missing, ent_q, pos2site, max_pos, n_sites, n_ent, q_base, active, active_words);
+                       is_missing, ent_q, pos2site, max_pos, n_sites, n_ent, q_base, active, active_words, slot_of);
     return hipGetLastError();
 }
 
@@ -596,15 +710,29 @@ hipError_t launch_merge(const uint32_t *part_best, const uint32_t *part_cnt, con
 }
 
 hipError_t launch_best8(const Best8Args &a, uint32_t max_slots, hipStream_t s) {
-    const uint32_t blocks = ((a.n_tiles * a.n_groups + 7u) / 8u) * 8u;
     const size_t lds = (size_t)max_slots * 64 * 16;
-    hipLaunchKernelGGL(k_best8, dim3(blocks), dim3(64), lds, s, a);
+    // persistent grid: as many one-wave blocks as the device keeps resident, never more than there are units
+    static int per_cu = 0, n_cu = 0;
+    static size_t lds_of = ~(size_t)0;
+    if (lds_of != lds) {
+        int dev = 0;
+        hipError_t e = hipGetDevice(&dev);
+        if (e == hipSuccess) e = hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
+        if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_best8, 64, lds);
+        if (e != hipSuccess) return e;
+        lds_of = lds;
+    }
+    uint64_t blocks = (uint64_t)std::max(per_cu, 1) * std::max(n_cu, 1);
+    const uint64_t units = (uint64_t)a.n_tiles * a.n_groups;
+    if (blocks > units) blocks = units;
+    blocks = ((blocks + 7) / 8) * 8;
+    hipLaunchKernelGGL(k_best8, dim3((uint32_t)blocks), dim3(64), lds, s, a);
     return hipGetLastError();
 }
 
 hipError_t launch_phase2(const PlaceArgs &a, const uint32_t *lbest, uint32_t *gbest, uint32_t n_tiles512,
                          uint32_t *items, uint32_t *n_items, uint32_t cap, uint32_t *cnt, uint32_t *key,
-                         const uint32_t *rank2bfs, ugp_result *out, uint32_t max_slots, hipStream_t s) {
+                         const uint32_t *rank2bfs, ugp_result *out, const uint32_t *order, uint32_t max_slots, hipStream_t s) {
     const uint32_t per_chunk = n_tiles512 * 256;
     hipLaunchKernelGGL(k_gbest, dim3((per_chunk + 255) / 256), dim3(256), 0, s, lbest, a.n_chunks, n_tiles512, gbest);
     const uint64_t pairs = (uint64_t)a.n_chunks * n_tiles512 * 8;
@@ -616,7 +744,7 @@ hipError_t launch_phase2(const PlaceArgs &a, const uint32_t *lbest, uint32_t *gb
     uint32_t blocks = 256 * 16;
     if ((uint64_t)blocks > pairs) blocks = (uint32_t)pairs;
     hipLaunchKernelGGL(k_ties, dim3(blocks), dim3(64), lds, s, a, gbest, items, n_items, cap, n_tiles512 * 8, cnt, key);
-    hipLaunchKernelGGL(k_final, dim3((a.n_queries + 255) / 256), dim3(256), 0, s, gbest, cnt, key, rank2bfs, a.n_queries, out);
+    hipLaunchKernelGGL(k_final, dim3((a.n_queries + 255) / 256), dim3(256), 0, s, gbest, cnt, key, rank2bfs, a.n_queries, out, order);
     return hipGetLastError();
 }
 

@@ -37,20 +37,27 @@ struct Best8Args {
     const uint32_t *active;    // [n_tiles][active_words] bit per site: some sample of the tile is not reference there
     uint32_t active_words;
     uint32_t *lbest;           // [n_chunks][n_tiles][64][4] packed u16 pairs
+    uint32_t *queue;           // [8] work-queue heads, one per XCD, zeroed before the launch
+    uint64_t *stats;           // optional: [0] += stream words skipped by pruning (debug / bench)
+    uint32_t *ub;              // [n_tiles][64][4] packed upper bounds of best(s) shared by the waves of a tile; nullptr = no pruning
 };
 
 hipError_t launch_best8(const Best8Args &a, uint32_t max_slots, hipStream_t s);
 // a.n_tiles = number of 64-sample tiles; lbest/gbest in the packed 512-tile layout
 hipError_t launch_phase2(const PlaceArgs &a, const uint32_t *lbest, uint32_t *gbest, uint32_t n_tiles512,
                          uint32_t *items, uint32_t *n_items, uint32_t cap, uint32_t *cnt, uint32_t *key,
-                         const uint32_t *rank2bfs, ugp_result *out, uint32_t max_slots, hipStream_t s);
+                         const uint32_t *rank2bfs, ugp_result *out, const uint32_t *order, uint32_t max_slots, hipStream_t s);
 
 hipError_t launch_fill_table(uint32_t *table, const uint8_t *site_ref, uint32_t n_sites, uint64_t total_dwords,
                              hipStream_t s);
 hipError_t launch_scatter(uint32_t *table, uint32_t *dbottom, const int32_t *pos, const uint8_t *ref,
                           const uint8_t *nuc, const uint8_t *is_missing, const uint32_t *ent_q,
                           const int32_t *pos2site, uint32_t max_pos, uint32_t n_sites, uint64_t n_ent, uint32_t q_base,
-                          uint32_t *active, uint32_t active_words, hipStream_t s);
+                          uint32_t *active, uint32_t active_words, const uint32_t *slot_of, hipStream_t s);
+// locality sort (see k_sort_keys); temp == nullptr: only *temp_bytes is filled
+hipError_t launch_locality_sort(const ugp_result *coarse_res, const uint32_t *coarse2dfs, uint32_t n, uint32_t *keys,
+                                uint32_t *keys_sorted, uint32_t *idx, uint32_t *order, uint32_t *slot_of, void *temp,
+                                size_t *temp_bytes, hipStream_t s);
 hipError_t launch_place(const PlaceArgs &a, int mode, uint32_t max_slots, hipStream_t s);
 hipError_t launch_merge(const uint32_t *part_best, const uint32_t *part_cnt, const uint32_t *part_key,
                         const uint32_t *rank2bfs, uint32_t n_groups, uint32_t n_queries, ugp_result *out,
