@@ -41,7 +41,7 @@ def main():
     ap.add_argument("--ambiguous", action="store_true", help="BASELINE config 5: 100-5000 N cells + 0-30 IUPAC cells per query")
     ap.add_argument("--cpu-queries", type=int, default=-1, help="queries timed on the CPU oracle (0 = skip; default: sized for ~10-30 s)")
     ap.add_argument("--seed", type=int, default=1)
-    ap.add_argument("--sort-by-source", action="store_true", help="experiment: order the queries by their generator source node")
+    ap.add_argument("--sort-by-source", action="store_true", help="experiment: hand the queries over already ordered by their generator source node")
     args = ap.parse_args()
 
     import torch

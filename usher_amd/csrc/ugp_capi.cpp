@@ -304,7 +304,7 @@ const char *ugp_last_error(void) { return g_err.c_str(); }
 
 static int mat_create_impl(const ugp_tree_desc *tree, int device, const ugp::Options &opt, ugp_mat **out, bool with_coarse = true);
 
-// The top of the tree (nodes with the largest subtrees, about N/128 of them) as a MAT of its own.
+// The top of the tree (the nodes with the largest subtrees: N/2048 of them, at least 4096) as a MAT of its own.
 static int build_coarse(const ugp_tree_desc *t, int device, const std::vector<uint32_t> &dfs2bfs, ugp_mat *m) {
     const uint64_t N = t->n_nodes;
     uint64_t min_nodes = 1u << 18;   // below this a tree pass is too short for the sort to pay off
@@ -312,7 +312,9 @@ static int build_coarse(const ugp_tree_desc *t, int device, const std::vector<ui
     if (N < min_nodes || N < 64 || getenv("UGP_NO_SORT")) return UGP_OK;
     std::vector<uint32_t> sub(N, 1);
     for (uint64_t j = N; j-- > 1;) sub[t->parent[j]] += sub[j];
-    const uint64_t target = std::min<uint64_t>(N / 2, std::max<uint64_t>(N / 128, std::min<uint64_t>(4096, N / 4)));
+    uint64_t div = 2048;
+    if (const char *e = getenv("UGP_COARSE_DIV")) div = (uint64_t)std::max(2, atoi(e));
+    const uint64_t target = std::min<uint64_t>(N / 2, std::max<uint64_t>(N / div, std::min<uint64_t>(4096, N / 4)));
     std::vector<uint32_t> sorted_sub(sub);
     std::nth_element(sorted_sub.begin(), sorted_sub.begin() + (N - target), sorted_sub.end());
     const uint32_t S = std::max<uint32_t>(2, sorted_sub[N - target]);
@@ -400,6 +402,7 @@ static int mat_create_impl(const ugp_tree_desc *tree, int device, const ugp::Opt
 int ugp_mat_create(const ugp_tree_desc *tree, int device, ugp_mat **out) {
     ugp::Options opt;
     if (const char *e = getenv("UGP_CHUNK_NODES")) opt.chunk_nodes = (uint32_t)std::max(1, atoi(e));
+    if (const char *e = getenv("UGP_PRUNE_MIN_WORDS")) opt.prune_min_words = (uint32_t)std::max(1, atoi(e));
     return mat_create_impl(tree, device, opt, out);
 }
 

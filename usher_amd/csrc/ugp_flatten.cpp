@@ -308,7 +308,7 @@ int flatten(const ugp_tree_desc &t, const Options &opt, FlatMat &out, std::strin
             uint32_t j = out.dfs2bfs[d];
             close_big(d);
             if (dropped[j]) continue;
-            const bool big = j != 0 && subw[j] >= PRUNE_MIN_WORDS && hsub[j] <= 255;
+            const bool big = j != 0 && subw[j] >= opt.prune_min_words && hsub[j] <= 255;
             if (big) {
                 open_big.push_back({(uint32_t)out.stream8.size(), 0u, d + sub[j]});
                 out.stream8.push_back(H_TAG | H_INFO | (hsub[j] << 22));   // jump patched when the subtree closes

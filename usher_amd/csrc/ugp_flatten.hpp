@@ -60,13 +60,14 @@ constexpr uint32_t MAX_SLOTS = 40;        // > log2(2^32) + 1
 //       M_END    last mutation word of the node
 constexpr uint32_t H_TAG = 1u << 31, H_SKIPD = 1u << 12, H_NOSCORE = 1u << 13, H_END = 1u << 16,
                    H_FREE = 1u << 17, H_CHUNK_END = 1u << 18, H_NOP = 1u << 19, H_INFO = 1u << 30;
-constexpr uint32_t PRUNE_MIN_WORDS = 48;    // only subtrees at least this long carry a pruning record
+constexpr uint32_t PRUNE_MIN_WORDS = 8;     // only subtrees at least this long carry a pruning record
 constexpr uint32_t M_FLUSH = 1u << 28, M_END = 1u << 30;
 constexpr uint32_t MAX_SITES = 1u << 22;
 constexpr uint32_t MAX_NODE_MUTS = 65535;
 
 struct Options {
     uint32_t chunk_nodes = 0;   // 0 = automatic (about N/4096, at least 256)
+    uint32_t prune_min_words = PRUNE_MIN_WORDS;   // subtrees at least this long (stream words) carry a pruning record
 };
 
 struct FlatMat {
