@@ -201,3 +201,38 @@ def test_locality_sort_and_pruning_paths_are_exact(monkeypatch):
         for i, w in enumerate(want):
             _assert_same(res, i, w, "%s #%d" % (env, i))
         pl.close()
+
+
+def test_full_size_properties_1m_nodes(monkeypatch):
+    """Size-independent properties on a 1M-node synthetic MAT (too large for the oracle to sweep):
+    the packed/pruned/sorted path, the plain 32-bit path and a permuted batch must agree sample by
+    sample; a query equal to a tree node's genotype scores 0; and a sample of queries is checked
+    against the oracle."""
+    from usher_amd import synth as gsynth
+    for k in ("UGP_FORCE_V1", "UGP_NO_SORT", "UGP_NO_PRUNE"):
+        monkeypatch.delenv(k, raising=False)
+    st = gsynth.SynthTree(1_000_000, n_sites=8000, seed=5)
+    q = st.queries(3000, seed=9, max_subst=3, n_lo=0, n_hi=40, iupac_hi=4)
+    q0 = st.queries(600, seed=10, max_subst=0)            # exact genotypes of tree nodes
+    batch = QueryBatch.from_csr(q["ent_off"], q["pos"], q["ref"], q["nuc"], q["is_missing"])
+    batch0 = QueryBatch.from_csr(q0["ent_off"], q0["pos"], q0["ref"], q0["nuc"], q0["is_missing"])
+    pl = Placer(st.arrays)
+    assert pl.info()["n_nodes"] == 1_000_000
+    fast = pl.place(batch)
+    again = pl.place(batch)
+    assert (fast.view(np.int32) == again.view(np.int32)).all()                      # idempotent
+    perm = np.random.default_rng(3).permutation(len(batch))
+    samples = [gsynth.csr_sample(q, int(i)) for i in perm]
+    shuffled = pl.place(QueryBatch(samples))
+    assert (shuffled.view(np.int32).reshape(-1, 4) == fast.view(np.int32).reshape(-1, 4)[perm]).all()   # order-independent
+    z = pl.place(batch0)
+    assert (z["best_set_difference"] == 0).all() and (z["num_best"] >= 1).all()     # self-placement costs nothing
+    monkeypatch.setenv("UGP_FORCE_V1", "1")
+    slow = pl.place(batch)                                                          # 32-bit, one sample per lane, no pruning
+    monkeypatch.delenv("UGP_FORCE_V1")
+    assert (slow.view(np.int32) == fast.view(np.int32)).all()
+    ot = capi.OracleTree(st.arrays)
+    for i in range(0, 3000, 500):
+        w = ot.place_mt(gsynth.csr_sample(q, i), 8)
+        assert (w["best"], w["num_best"], w["best_j"]) == (int(fast["best_set_difference"][i]), int(fast["num_best"][i]), int(fast["best_j"][i]))
+    pl.close()
