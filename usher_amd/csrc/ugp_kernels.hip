@@ -559,14 +559,25 @@ __global__ void __launch_bounds__(64) k_best8(Best8Args a) {
     }   // next work unit
 }
 
-// Global minimum per sample over the chunk-local minima.
+// Global minimum per sample over the chunk-local minima: the chunk axis is cut into gridDim.y
+// slices (partial minima in `part`), then k_gbest2 folds the slices.
 __global__ void k_gbest(const uint32_t *__restrict__ lbest, uint32_t n_chunks, uint32_t n_tiles,
-                        uint32_t *__restrict__ gbest /* [n_tiles][64][4] packed */) {
+                        uint32_t *__restrict__ part /* [gridDim.y][n_tiles*256] */) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;   // dword index within one chunk's record
     const uint32_t per_chunk = n_tiles * 256;
     if (i >= per_chunk) return;
+    const uint32_t c0 = (uint32_t)((uint64_t)blockIdx.y * n_chunks / gridDim.y);
+    const uint32_t c1 = (uint32_t)((uint64_t)(blockIdx.y + 1) * n_chunks / gridDim.y);
     uint32_t m = 0xFFFFFFFFu;
-    for (uint32_t c = 0; c < n_chunks; c++) m = pk_min(m, lbest[(uint64_t)c * per_chunk + i]);
+    for (uint32_t c = c0; c < c1; c++) m = pk_min(m, lbest[(uint64_t)c * per_chunk + i]);
+    part[(uint64_t)blockIdx.y * per_chunk + i] = m;
+}
+__global__ void k_gbest2(const uint32_t *__restrict__ part, uint32_t n_slices, uint32_t per_chunk,
+                         uint32_t *__restrict__ gbest /* [n_tiles][64][4] packed */) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= per_chunk) return;
+    uint32_t m = 0xFFFFFFFFu;
+    for (uint32_t k = 0; k < n_slices; k++) m = pk_min(m, part[(uint64_t)k * per_chunk + i]);
     gbest[i] = m;
 }
 
@@ -730,18 +741,20 @@ hipError_t launch_best8(const Best8Args &a, uint32_t max_slots, hipStream_t s) {
     return hipGetLastError();
 }
 
-hipError_t launch_phase2(const PlaceArgs &a, const uint32_t *lbest, uint32_t *gbest, uint32_t n_tiles512,
+hipError_t launch_phase2(const PlaceArgs &a, const uint32_t *lbest, uint32_t *gbest_part, uint32_t *gbest, uint32_t n_tiles512,
                          uint32_t *items, uint32_t *n_items, uint32_t cap, uint32_t *cnt, uint32_t *key,
                          const uint32_t *rank2bfs, ugp_result *out, const uint32_t *order, uint32_t max_slots, hipStream_t s) {
     const uint32_t per_chunk = n_tiles512 * 256;
-    hipLaunchKernelGGL(k_gbest, dim3((per_chunk + 255) / 256), dim3(256), 0, s, lbest, a.n_chunks, n_tiles512, gbest);
+    const uint32_t slices = std::min<uint32_t>(GBEST_SLICES, a.n_chunks);
+    hipLaunchKernelGGL(k_gbest, dim3((per_chunk + 255) / 256, slices), dim3(256), 0, s, lbest, a.n_chunks, n_tiles512, gbest_part);
+    hipLaunchKernelGGL(k_gbest2, dim3((per_chunk + 255) / 256), dim3(256), 0, s, gbest_part, slices, per_chunk, gbest);
     const uint64_t pairs = (uint64_t)a.n_chunks * n_tiles512 * 8;
     hipLaunchKernelGGL(k_select, dim3((uint32_t)((pairs + 255) / 256)), dim3(256), 0, s, lbest, gbest, a.n_chunks,
                        n_tiles512, a.n_queries, items, n_items, cap);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     const size_t lds = (size_t)max_slots * 64 * sizeof(uint32_t);
-    uint32_t blocks = 256 * 16;
+    uint32_t blocks = 256 * 32;   // latency-bound walk: as many waves as a CU holds (3.3 KB of LDS each)
     if ((uint64_t)blocks > pairs) blocks = (uint32_t)pairs;
     hipLaunchKernelGGL(k_ties, dim3(blocks), dim3(64), lds, s, a, gbest, items, n_items, cap, n_tiles512 * 8, cnt, key);
     hipLaunchKernelGGL(k_final, dim3((a.n_queries + 255) / 256), dim3(256), 0, s, gbest, cnt, key, rank2bfs, a.n_queries, out, order);
