@@ -290,6 +290,7 @@ struct Pk4 { uint32_t v[4]; };
 
 __device__ __forceinline__ uint32_t ex4(uint32_t acc, int j) { return (acc >> (4 * j)) & 0x000F000Fu; }
 
+template <bool STATS>   // STATS: per-unit cycle accounting for tuning (UGP_STATS); off in production, it costs SGPRs
 __global__ void __launch_bounds__(64) k_best8(Best8Args a) {
     extern __shared__ __attribute__((aligned(16))) u32x4 slots8[];   // [lds_slots][64] x 16 B: the hot saved-D slots
     const uint32_t lane = threadIdx.x;
@@ -481,7 +482,7 @@ __global__ void __launch_bounds__(64) k_best8(Best8Args a) {
     // Every load is unconditional and in a fixed order, which keeps the compiler's vmcnt
     // bookkeeping exact (s_waitcnt vmcnt(N) with the younger loads still in flight).
     const uint32_t *abm = a.active + (uint64_t)tile * a.active_words;
-    const uint64_t t_wave0 = a.stats ? __builtin_amdgcn_s_memtime() : 0;
+    const uint64_t t_wave0 = STATS ? __builtin_amdgcn_s_memtime() : 0;
     uint64_t t_restart = 0, n_restart = 0;
     for (int phase = 0; phase < 2; phase++) {
         const uint32_t *sp = phase == 0 ? a.pre8 : a.stream8;
@@ -513,7 +514,7 @@ __global__ void __launch_bounds__(64) k_best8(Best8Args a) {
         uint32_t off = 0;
         while (off < n) {
             // (re)fill the pipeline at `off`
-            const uint64_t t_r0 = a.stats ? __builtin_amdgcn_s_memtime() : 0;
+            const uint64_t t_r0 = STATS ? __builtin_amdgcn_s_memtime() : 0;
             uint32_t w0 = load_words(off), w1 = load_words(off + 8), w2 = load_words(off + 16);
             uint32_t m0 = active_mask(w0, load_bits(w0));
             uint32_t m1 = active_mask(w1, load_bits(w1));
@@ -524,7 +525,7 @@ __global__ void __launch_bounds__(64) k_best8(Best8Args a) {
                 X[k] = __builtin_amdgcn_raw_buffer_load_b32(trsrc, lane4, (((m0 >> k) & 1u) ? (w & 0x3FFFFFu) : 0u) << 8, 0);
             }
             skip_to = 0;
-            if (a.stats) { t_restart += __builtin_amdgcn_s_memtime() - t_r0 + (X[0] & 0u); n_restart++; }
+            if (STATS) { t_restart += __builtin_amdgcn_s_memtime() - t_r0 + (X[0] & 0u); n_restart++; }
             for (; off < n; off += 8) {
                 const uint32_t w3 = load_words(off + 24);
                 const uint32_t b2 = load_bits(w2);
@@ -547,7 +548,7 @@ __global__ void __launch_bounds__(64) k_best8(Best8Args a) {
             off = skip_to;
         }
     }
-    if (a.stats && lane == 0) {   // debug accounting, one update per wave
+    if (STATS && lane == 0) {   // debug accounting, one update per unit
         const unsigned long long tw = __builtin_amdgcn_s_memtime() - t_wave0;
         unsigned long long *st = (unsigned long long *)a.stats;
         atomicAdd(st + 1, (unsigned long long)n_restart);
@@ -729,7 +730,7 @@ hipError_t launch_best8(const Best8Args &a, uint32_t max_slots, hipStream_t s) {
         int dev = 0;
         hipError_t e = hipGetDevice(&dev);
         if (e == hipSuccess) e = hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
-        if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_best8, 64, lds);
+        if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_best8<false>, 64, lds);
         if (e != hipSuccess) return e;
         lds_of = lds;
     }
@@ -737,7 +738,8 @@ hipError_t launch_best8(const Best8Args &a, uint32_t max_slots, hipStream_t s) {
     const uint64_t units = (uint64_t)a.n_tiles * a.n_groups;
     if (blocks > units) blocks = units;
     blocks = ((blocks + 7) / 8) * 8;
-    hipLaunchKernelGGL(k_best8, dim3((uint32_t)blocks), dim3(64), lds, s, a);
+    if (a.stats) hipLaunchKernelGGL(k_best8<true>, dim3((uint32_t)blocks), dim3(64), lds, s, a);
+    else hipLaunchKernelGGL(k_best8<false>, dim3((uint32_t)blocks), dim3(64), lds, s, a);
     return hipGetLastError();
 }
 
