@@ -141,7 +141,8 @@ def main():
                 with open(fn) as f:
                     ps = json.load(f)
                 cfg = ps.get("bench", {}).get("config", {})
-                k = ps.get("kernels", {}).get("ugp::k_best8" if packed else "ugp::k_place<0>", {})
+                want = "ugp::k_best8" if packed else "ugp::k_place<0>"
+                k = next((v for n, v in ps.get("kernels", {}).items() if n.startswith(want)), {})
                 if cfg.get("nodes") == int(info["n_nodes"]) and cfg.get("queries_per_gpu") == Q and "hbm_read_bytes_per_dispatch_corrected" in k:
                     traffic = int(k["hbm_read_bytes_per_dispatch_corrected"] + k.get("hbm_write_bytes_per_dispatch", 0))
                     break

@@ -111,3 +111,43 @@ def test_cli_flag_surface(tmp_path):
     assert run_usher(["-v", "x.vcf"]) == 1                      # no tree / MAT
     assert run_usher(["-i", os.path.join(SURVEY, "syn", "tree.pb"), "-v", os.path.join(SURVEY, "syn", "query.vcf"), "-r", "-d", str(tmp_path)]) == 1
     assert run_usher(["-i", os.path.join(SURVEY, "syn", "tree.pb"), "-v", os.path.join(SURVEY, "syn", "query.vcf"), "-p", "-M", "2", "-d", str(tmp_path)]) == 1
+
+
+def test_vcf_cell_quirks_match_the_reference_reader(tmp_path):
+    """read_vcf quirks (SURVEY 7 'quirk fidelity'): 'V' falls through to N, lower case only for
+    acgtn, ALT uses its first character, GT cells go through stoi ('1:x' -> 1, '0/1' -> 0), '.'
+    is missing.  The C++ reader must produce exactly what the python restatement of
+    mutation_annotated_tree.cpp:2180-2277 produces: compare the -n placement statistics."""
+    import numpy as np
+    from oracle import capi
+    pb = os.path.join(SURVEY, "syn", "tree.pb")
+    T = refio.load_mutation_annotated_tree(pb)
+    ref_at = {}
+    for n in T.depth_first_expansion():
+        for m in n.mutations:
+            if m.position >= 0:
+                ref_at[m.position] = refio.get_nuc(m.ref_nuc)
+    sites = sorted(ref_at)[:60]
+    alts = ["V", "a", "c", "g", "t", "n", "r", "ACGT", "N", "R", "Y", "K", "TTT", "H", "."]
+    cells = ["0", "1", "1:x", "0/1", "1/1", ".", "2", "2:0", "1|0", "x"]
+    rng = np.random.default_rng(4)
+    names = ["E%d" % i for i in range(12)]
+    vcf = str(tmp_path / "edge.vcf")
+    with open(vcf, "w") as f:
+        f.write("##fileformat=VCFv4.2\n#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\t" + "\t".join(names) + "\n")
+        for p in sites:
+            a1, a2 = rng.choice(alts, 2, replace=False)
+            row = [str(rng.choice(cells)) for _ in names]
+            f.write("chr\t%d\t.\t%s\t%s,%s\t.\t.\t.\tGT\t%s\n" % (p, ref_at[p], a1, a2, "\t".join(row)))
+    rc = run_usher(["-i", pb, "-v", vcf, "-n", "-d", str(tmp_path)])
+    assert rc == 0
+    got = _read(str(tmp_path / "placement_stats.tsv")).splitlines()
+    samples = refio.read_vcf(T, vcf)
+    ot = capi.OracleTree(refio.tree_to_bfs_arrays(T))
+    assert len(got) == len(samples) == len(names)
+    for line, s in zip(got, samples):
+        sa = refio.sample_to_arrays(s)
+        r = ot.place(sa)
+        v = ot.node_vecs(sa, r["best_j"])
+        imputed = ";".join("%d:%s" % (p, refio.get_nuc(m)) for (p, _, _, m) in v["imputed"])
+        assert line == "%s\t%d\t%d\t%s" % (s.name, r["best"], r["num_best"], imputed)

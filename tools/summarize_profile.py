@@ -30,7 +30,7 @@ for sub in ("fetch", "write", "tcc", "sq"):
     agg = collections.defaultdict(lambda: collections.defaultdict(float))
     disp = collections.defaultdict(set)
     for r in csv.DictReader(open(files[0])):
-        k = r["Kernel_Name"].split("(")[0]
+        k = r["Kernel_Name"].split("(")[0].replace("void ", "")
         agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
         disp[k].add(r["Dispatch_Id"])
     for k in agg:

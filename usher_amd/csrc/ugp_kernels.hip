@@ -287,6 +287,10 @@ __global__ void k_merge(const uint32_t *__restrict__ part_best, const uint32_t *
 // max_rows(sample) + max_root_path_mutations(tree) < 0xFFFF.
 
 struct Pk4 { uint32_t v[4]; };
+#ifndef UGP_GRP
+#define UGP_GRP 8
+#endif
+constexpr uint32_t GRP = UGP_GRP;   // stream words per pipeline group (= unroll factor of the walk)
 
 __device__ __forceinline__ uint32_t ex4(uint32_t acc, int j) { return (acc >> (4 * j)) & 0x000F000Fu; }
 
@@ -491,7 +495,7 @@ __global__ void __launch_bounds__(64) k_best8(Best8Args a) {
         if (begin >= end) continue;
         const uint32_t n = end - begin;
         sp += begin;
-        const uint32_t l8 = lane & 7u;
+        const uint32_t l8 = lane & (GRP - 1u);
         auto load_words = [&](uint32_t off) -> uint32_t {   // words off .. off+7 in lanes 0..7 (replicated x8)
             const uint32_t i = off + l8;
             const uint32_t v = sp[i < n ? i : n - 1];
@@ -503,7 +507,7 @@ __global__ void __launch_bounds__(64) k_best8(Best8Args a) {
         };
         auto active_mask = [&](uint32_t wv, uint32_t bits) -> uint32_t {   // bit k: word k needs its real row
             const bool act = !(wv & H_TAG) && ((bits >> (wv & 31u)) & 1u);
-            return (uint32_t)__builtin_amdgcn_ballot_w64(act) & 0xFFu;
+            return (uint32_t)__builtin_amdgcn_ballot_w64(act) & ((1u << GRP) - 1u);
         };
         prune = (phase == 1) && ubp != nullptr;
         if (prune) {   // start from what earlier waves of this tile already know
@@ -515,22 +519,22 @@ __global__ void __launch_bounds__(64) k_best8(Best8Args a) {
         while (off < n) {
             // (re)fill the pipeline at `off`
             const uint64_t t_r0 = STATS ? __builtin_amdgcn_s_memtime() : 0;
-            uint32_t w0 = load_words(off), w1 = load_words(off + 8), w2 = load_words(off + 16);
+            uint32_t w0 = load_words(off), w1 = load_words(off + GRP), w2 = load_words(off + 2 * GRP);
             uint32_t m0 = active_mask(w0, load_bits(w0));
             uint32_t m1 = active_mask(w1, load_bits(w1));
-            uint32_t X[8];
+            uint32_t X[GRP];
 #pragma unroll
-            for (int k = 0; k < 8; k++) {
+            for (int k = 0; k < (int)GRP; k++) {
                 const uint32_t w = rdlane(w0, k);
                 X[k] = __builtin_amdgcn_raw_buffer_load_b32(trsrc, lane4, (((m0 >> k) & 1u) ? (w & 0x3FFFFFu) : 0u) << 8, 0);
             }
             skip_to = 0;
             if (STATS) { t_restart += __builtin_amdgcn_s_memtime() - t_r0 + (X[0] & 0u); n_restart++; }
-            for (; off < n; off += 8) {
-                const uint32_t w3 = load_words(off + 24);
+            for (; off < n; off += GRP) {
+                const uint32_t w3 = load_words(off + 3 * GRP);
                 const uint32_t b2 = load_bits(w2);
 #pragma unroll
-                for (int k = 0; k < 8; k++) {
+                for (int k = 0; k < (int)GRP; k++) {
                     const uint32_t w = rdlane(w0, k);
                     const uint32_t ref_row = 0x11111111u << ((w >> 26) & 3u);   // every sample carries the reference base
                     if (!skip_to) step(w, ((m0 >> k) & 1u) ? X[k] : ref_row, off + k);   // words after a restart request are dead
