@@ -236,3 +236,24 @@ def test_full_size_properties_1m_nodes(monkeypatch):
         w = ot.place_mt(gsynth.csr_sample(q, i), 8)
         assert (w["best"], w["num_best"], w["best_j"]) == (int(fast["best_set_difference"][i]), int(fast["num_best"][i]), int(fast["best_j"][i]))
     pl.close()
+
+
+def test_sub_batching_and_tiny_batches():
+    """More than 262,144 samples in one call (the library splits into sub-batches) and batches smaller
+    than one tile give the same per-sample answers."""
+    arrays, queries = synth.make_case(81, n_leaves=120, n_queries=40, n_sites=50)
+    ot = capi.OracleTree(arrays)
+    want = [ot.place(s, want_ties=False) for s in queries]
+    pl = Placer(arrays, chunk_nodes=20)
+    for n in (1, 2, 63, 65):
+        res = pl.place(QueryBatch([queries[i % 40] for i in range(n)]))
+        for i in range(n):
+            _assert_same(res, i, want[i % 40], "n=%d" % n)
+    reps = 262144 // 40 + 30                       # 40 * reps > 262,144: two launch sequences
+    big = QueryBatch(queries * reps)
+    assert len(big) > 262144
+    res = pl.place(big)
+    w = np.array([[x["best"], x["num_best"], x["best_j"], int(x["has_unique"])] for x in want], dtype=np.int64)
+    got = res.view(np.int32).reshape(-1, 4).astype(np.int64)
+    assert (got == np.tile(w, (reps, 1))).all()
+    pl.close()
