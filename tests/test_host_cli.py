@@ -151,3 +151,91 @@ def test_vcf_cell_quirks_match_the_reference_reader(tmp_path):
         v = ot.node_vecs(sa, r["best_j"])
         imputed = ";".join("%d:%s" % (p, refio.get_nuc(m)) for (p, _, _, m) in v["imputed"])
         assert line == "%s\t%d\t%d\t%s" % (s.name, r["best"], r["num_best"], imputed)
+
+
+def _evolve_vcf(rng, n_leaves, n_sites, n_new, path_tree, path_old, path_new):
+    """A random binary tree with genotypes evolved along it (existing samples) and new samples
+    derived from random leaves (a few substitutions, some N and IUPAC cells)."""
+    import numpy as np
+    nuc = "ACGT"
+    ref = rng.integers(0, 4, n_sites)
+    pos = np.sort(rng.choice(np.arange(1, 30000), n_sites, replace=False))
+    nodes = [("S%d" % i, None, ref.copy()) for i in range(1)]
+    # grow by splitting a random leaf
+    leaves = [{"name": None, "g": ref.copy(), "nwk": None}]
+    tree = {"children": [], "g": ref.copy()}
+    tips = [tree]
+    while len(tips) < n_leaves:
+        t = tips.pop(int(rng.integers(0, len(tips))))
+        for _ in range(2):
+            g = t["g"].copy()
+            for s in rng.choice(n_sites, int(rng.integers(0, 3)), replace=False):
+                g[s] = rng.integers(0, 4)
+            c = {"children": [], "g": g}
+            t["children"].append(c)
+            tips.append(c)
+    for i, t in enumerate(tips):
+        t["name"] = "S%d" % i
+
+    def nwk(t):
+        return t["name"] if not t["children"] else "(" + ",".join(nwk(c) for c in t["children"]) + ")"
+    with open(path_tree, "w") as f:
+        f.write(nwk(tree) + ";\n")
+
+    def write(path, names, G, codes=None):
+        with open(path, "w") as f:
+            f.write("##fileformat=VCFv4.2\n#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\t" + "\t".join(names) + "\n")
+            for s in range(n_sites):
+                alts = [a for a in range(4) if a != ref[s]]
+                cells = []
+                for k in range(len(names)):
+                    c = codes[k][s] if codes is not None and codes[k][s] is not None else None
+                    if c == "N":
+                        cells.append(".")
+                    elif c is not None:
+                        cells.append(c)
+                    else:
+                        cells.append("0" if G[k][s] == ref[s] else str(alts.index(G[k][s]) + 1))
+                f.write("chr\t%d\t%s%d\t%s\t%s\t.\t.\t.\tGT\t%s\n" % (pos[s], nuc[ref[s]], pos[s], nuc[ref[s]],
+                                                                     ",".join(nuc[a] for a in alts), "\t".join(cells)))
+    write(path_old, [t["name"] for t in tips], [t["g"] for t in tips])
+    new_g, new_codes = [], []
+    for k in range(n_new):
+        g = tips[int(rng.integers(0, len(tips)))]["g"].copy()
+        for s in rng.choice(n_sites, int(rng.integers(0, 3)), replace=False):
+            g[s] = rng.integers(0, 4)
+        codes = [None] * n_sites
+        for s in rng.choice(n_sites, int(rng.integers(0, 4)), replace=False):
+            codes[s] = "N"
+        new_g.append(g)
+        new_codes.append(codes)
+    write(path_new, ["NEW%d" % k for k in range(n_new)], new_g, new_codes)
+
+
+@pytest.mark.parametrize("seed,n_leaves,n_new", [(1, 60, 80), (2, 150, 120), (3, 30, 200)])
+def test_batched_add_mode_equals_per_sample_research(tmp_path, monkeypatch, seed, n_leaves, n_new):
+    """Add-mode places the remaining samples in batches and reuses an answer only while it is provably
+    unchanged by the insertions made since; with USHER_AMD_MAX_TOUCHED=0 every sample is searched again on
+    the updated tree, which is the reference's loop (usher_common.cpp:310-449).  Both must write the same files."""
+    import numpy as np
+    from tests.host_harness import OracleBackend
+    rng = np.random.default_rng(seed)
+    nh, old, new = str(tmp_path / "t.nh"), str(tmp_path / "old.vcf"), str(tmp_path / "new.vcf")
+    _evolve_vcf(rng, n_leaves, 90, n_new, nh, old, new)
+    pb = str(tmp_path / "base.pb")
+    assert run_usher(["-t", nh, "-v", old, "-o", pb, "-d", str(tmp_path)]) == 0
+    outs, calls = {}, {}
+    for mode, env in (("research", "0"), ("batched", None)):
+        if env is None:
+            monkeypatch.delenv("USHER_AMD_MAX_TOUCHED", raising=False)
+        else:
+            monkeypatch.setenv("USHER_AMD_MAX_TOUCHED", env)
+        d = tmp_path / mode
+        d.mkdir()
+        be = OracleBackend()
+        assert run_usher(["-i", pb, "-v", new, "-u", "-o", str(d / "out.pb"), "-d", str(d)], backend=be) == 0
+        outs[mode] = {n: _read(str(d / n)) for n in ("placement_stats.tsv", "mutation-paths.txt", "uncondensed-final-tree.nh")}
+        outs[mode]["pb"] = _pb_semantic(str(d / "out.pb"))
+        calls[mode] = be.calls
+    assert outs["batched"] == outs["research"]
+    assert calls["batched"] < calls["research"]

@@ -82,12 +82,14 @@ bool by_pos(const Mutation &a, const Mutation &b) { return a.position < b.positi
 // (what pass 2 does, usher_common.cpp:426-449) and for the optimal rows of -p.
 // ---------------------------------------------------------------------------
 void node_vecs(const Node *node, const std::vector<Mutation> &sample, NodeVecs &out) {
-    out.excess.clear(); out.imputed.clear(); out.set_difference = 0; out.has_unique = false;
+    out.excess.clear(); out.imputed.clear(); out.set_difference = 0; out.has_unique = false; out.eligible = false;
+    int node_num_mut = 0, num_common = 0;      // :184-185
     std::vector<Mutation> anc;                 // ancestral_mutations (usher_mapper.cpp:178-179)
     auto anc_has = [&](int32_t p) { for (const Mutation &m : anc) if (m.position == p) return true; return false; };
     if (!node->is_root()) {                    // branch loop, :190-264
         size_t start = 0;
         for (const Mutation &m1 : node->mutations) {
+            node_num_mut++;
             if (m1.masked()) { out.has_unique = true; break; }                 // :197-200
             bool found = false, found_pos = false;
             for (size_t k = start; k < sample.size(); k++) {
@@ -95,11 +97,11 @@ void node_vecs(const Node *node, const std::vector<Mutation> &sample, NodeVecs &
                 start = k;
                 if (m1.position == m2.position) {
                     found_pos = true;
-                    if (m2.is_missing) found = true;                           // :209-211
+                    if (m2.is_missing) { found = true; num_common++; }        // :209-211
                     else if (m2.mut_nuc & m1.mut_nuc) {                        // :214-235
                         Mutation m = m1; m.is_missing = false;
                         anc.push_back(m); out.excess.push_back(m);
-                        found = true;
+                        found = true; num_common++;
                         break;
                     }
                 }
@@ -109,6 +111,7 @@ void node_vecs(const Node *node, const std::vector<Mutation> &sample, NodeVecs &
                 if (!found_pos && m1.mut_nuc == m1.ref_nuc) {                  // :244-259
                     Mutation m = m1; m.is_missing = false;
                     anc.push_back(m); out.excess.push_back(m);
+                    num_common++;
                 } else out.has_unique = true;
             }
         }
@@ -161,6 +164,9 @@ void node_vecs(const Node *node, const std::vector<Mutation> &sample, NodeVecs &
         out.excess.push_back(m);
         out.set_difference++;
     }
+    const bool leaf = node->is_leaf();                                          // :454-455
+    out.eligible = node->is_root() || (out.has_unique && !leaf && num_common > 0 && node_num_mut != num_common) ||
+                   (leaf && num_common > 0) || (!out.has_unique && !leaf && node_num_mut == num_common);
 }
 
 // ---------------------------------------------------------------------------
@@ -174,7 +180,8 @@ static bool write_text(const std::string &path, const std::string &text) {
 }
 
 // Insert `sample` next to / below `best` (usher_common.cpp:652-765).
-static void insert_sample(Tree &T, Node *best, bool as_sibling, const std::string &sample, const std::vector<Mutation> &excess) {
+static void insert_sample(Tree &T, Node *best, bool as_sibling, const std::string &sample, const std::vector<Mutation> &excess,
+                          std::vector<Node *> &touched /* nodes created or whose branch changed */) {
     auto matches = [](const Mutation &a, const Mutation &b) { return a.position == b.position && a.mut_nuc == b.mut_nuc; };
     if (as_sibling) {                                                           // :654-729
         const std::string nid = T.new_internal_node_id();
@@ -197,6 +204,7 @@ static void insert_sample(Tree &T, Node *best, bool as_sibling, const std::strin
         for (const Mutation &m : common) mid->add_mutation(m);
         for (const Mutation &m : l1) best->add_mutation(m);
         for (const Mutation &m : l2) leaf->add_mutation(m);
+        touched.push_back(mid); touched.push_back(leaf); touched.push_back(best);
     } else {                                                                    // :731-764
         Node *leaf = T.create_node(sample, best);
         for (const Mutation &m1 : excess) {
@@ -204,6 +212,7 @@ static void insert_sample(Tree &T, Node *best, bool as_sibling, const std::strin
             if (!m1.masked()) for (const Mutation &m2 : best->mutations) if (matches(m1, m2)) { found = true; break; }
             if (!found) leaf->add_mutation(m1);
         }
+        touched.push_back(leaf);
     }
 }
 
@@ -301,6 +310,21 @@ int run_usher(const Options &opt, Tree &T, std::vector<MissingSample> &missing, 
             }
         }
 
+        // Add-mode: the reference re-searches the whole tree for every sample because the previous
+        // insertion changed it (usher_common.cpp:342).  Here all remaining samples are placed in one
+        // batch on the tree as it is; a batched answer stays exact after later insertions as long as
+        // (a) it had a unique optimum (tie-breaks read n_leaves / BFS order, which insertions change),
+        // (b) its node was not rewritten, and (c) no node created or rewritten since then scores as
+        // well or better for this sample (every other node keeps its cost and eligibility: the
+        // mutations on its root path are unchanged).  Otherwise the tree is flattened and placed again.
+        std::vector<ugp_result> spec_res;
+        size_t spec_base = 0, spec_len = 0, spec_next = 64;   // batch length adapts to how long answers survive
+        bool have_spec = false;
+        uint64_t flat_version = tree_version;
+        std::vector<Node *> touched;
+        size_t max_touched = 192;
+        if (const char *e = getenv("USHER_AMD_MAX_TOUCHED")) max_touched = (size_t)atoll(e);
+        NodeVecs probe;
         FILE *stats = fopen((outdir + "/placement_stats.tsv").c_str(), "w");
         if (!stats) { fprintf(stderr, "ERROR: cannot write to %s\n", outdir.c_str()); return 1; }
         FILE *scores_file = nullptr;
@@ -309,8 +333,7 @@ int run_usher(const Options &opt, Tree &T, std::vector<MissingSample> &missing, 
             const size_t s = indexes[ii];
             MissingSample &ms = missing[s];
             if (T.get_node(ms.name)) { fprintf(stderr, "WARNING: Sample %s already in the tree! Ignoring.\n\n", ms.name.c_str()); continue; }
-            if (!static_tree) flat.build(T);                                    // :342 (the reference also re-expands per sample)
-            const size_t total_nodes = flat.bfs.size();
+            const size_t total_nodes = T.all_nodes.size();                      // == bfs.size() of the current tree (:343)
             if (opt.print_scores && s == 0) {                                   // :331-340
                 const std::string fn = outdir + "/parsimony-scores.tsv";
                 fprintf(stderr, "\nNow computing branch parsimony scores for adding the missing samples at each of the %zu nodes in the existing tree without modifying the tree.\n", total_nodes);
@@ -321,10 +344,34 @@ int run_usher(const Options &opt, Tree &T, std::vector<MissingSample> &missing, 
             ugp_result r;
             if (static_tree) r = batch_res[s];
             else {
-                FlatQueries q1;
-                q1.add(ms.mutations);
-                q1.finish();
-                if (be.place(be.ctx, &flat.desc, tree_version, &q1.desc, &r) != 0) { fclose(stats); return be_fail("placement"); }
+                bool redo = !have_spec || ii >= spec_base + spec_len || touched.size() > max_touched;
+                if (!redo) {
+                    r = spec_res[ii - spec_base];
+                    if (!touched.empty()) {
+                        Node *bn = flat.bfs[r.best_j];
+                        if (r.num_best > 1) redo = true;
+                        for (size_t k = 0; k < touched.size() && !redo; k++) {
+                            if (touched[k] == bn) { redo = true; break; }
+                            node_vecs(touched[k], ms.mutations, probe);
+                            if (probe.eligible && probe.set_difference <= r.best_set_difference) redo = true;
+                        }
+                    }
+                }
+                if (redo) {
+                    flat.build(T);
+                    flat_version = tree_version;
+                    if (have_spec) spec_next = std::max<size_t>(2 * (ii - spec_base), 1);
+                    spec_len = std::min(spec_next, indexes.size() - ii);
+                    FlatQueries rest;
+                    for (size_t k = ii; k < ii + spec_len; k++) rest.add(missing[indexes[k]].mutations);
+                    rest.finish();
+                    spec_res.assign(spec_len, ugp_result{});
+                    if (be.place(be.ctx, &flat.desc, flat_version, &rest.desc, spec_res.data()) != 0) { fclose(stats); return be_fail("placement"); }
+                    spec_base = ii;
+                    have_spec = true;
+                    touched.clear();
+                    r = spec_res[0];
+                }
             }
             const int best = r.best_set_difference;
             const size_t num_best = r.num_best;
@@ -367,8 +414,13 @@ int run_usher(const Options &opt, Tree &T, std::vector<MissingSample> &missing, 
                     const uint32_t cap = (uint32_t)std::min<size_t>(num_best, 1u << 20);
                     std::vector<uint32_t> tj(cap), tc(1);
                     std::vector<uint8_t> th(cap);
-                    if (be.ties(be.ctx, &flat.desc, tree_version, &q1.desc, cap, tj.data(), th.data(), tc.data()) != 0) { fclose(stats); return be_fail("tie listing"); }
-                    const size_t nt = std::min<size_t>(tc[0], cap);
+                    size_t nt = 1;
+                    if (num_best > 1) {   // (a batched answer with ties is never reused, so `flat` is current here)
+                        if (be.ties(be.ctx, &flat.desc, static_tree ? tree_version : flat_version, &q1.desc, cap, tj.data(), th.data(), tc.data()) != 0) { fclose(stats); return be_fail("tie listing"); }
+                        nt = std::min<size_t>(tc[0], cap);
+                    } else {
+                        tj[0] = r.best_j; th[0] = (uint8_t)best_has_unique;
+                    }
                     ms.clade_assignments.assign(n_ann, {});
                     ms.best_clade_assignment.assign(n_ann, "");
                     for (size_t c = 0; c < n_ann; c++) {
@@ -384,7 +436,7 @@ int run_usher(const Options &opt, Tree &T, std::vector<MissingSample> &missing, 
                 }
                 node_vecs(best_node, ms.mutations, vec);                        // pass 2 for the winner, :426-449
                 if (!opt.no_add) {
-                    insert_sample(T, best_node, best_node->is_leaf() || best_has_unique, ms.name, vec.excess);
+                    insert_sample(T, best_node, best_node->is_leaf() || best_has_unique, ms.name, vec.excess, touched);
                     tree_version++;
                 }
                 if (!vec.imputed.empty()) {                                     // :767-781

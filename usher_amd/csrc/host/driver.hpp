@@ -46,6 +46,7 @@ struct NodeVecs {
     std::vector<Mutation> excess, imputed;
     int set_difference = 0;
     bool has_unique = false;
+    bool eligible = false;   // the placement predicate of usher_mapper.cpp:454-455
 };
 void node_vecs(const Node *n, const std::vector<Mutation> &sample, NodeVecs &out);
 
