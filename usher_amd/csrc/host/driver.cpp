@@ -304,11 +304,22 @@ int run_usher(const Options &opt, Tree &T, std::vector<MissingSample> &missing, 
             flat.build(T);
             batch_res.resize(missing.size());
             if (be.place(be.ctx, &flat.desc, tree_version, &allq.desc, batch_res.data()) != 0) return be_fail("placement");
-            if (opt.print_scores) {
-                batch_scores.resize(missing.size() * flat.bfs.size());
-                if (be.scores(be.ctx, &flat.desc, tree_version, &allq.desc, batch_scores.data()) != 0) return be_fail("per-node scoring");
-            }
         }
+        // -p: the samples x nodes score matrix is produced in slabs of at most ~1 GiB
+        size_t slab_base = 0, slab_len = 0;
+        auto scores_row = [&](size_t s) -> const int32_t * {
+            const size_t n = flat.bfs.size();
+            if (s >= slab_base + slab_len || s < slab_base) {
+                slab_base = s;
+                slab_len = std::min(missing.size() - s, std::max<size_t>(1, ((size_t)1 << 28) / std::max<size_t>(n, 1)));
+                FlatQueries part;
+                for (size_t k = s; k < s + slab_len; k++) part.add(missing[k].mutations);
+                part.finish();
+                batch_scores.resize(slab_len * n);
+                if (be.scores(be.ctx, &flat.desc, tree_version, &part.desc, batch_scores.data()) != 0) return nullptr;
+            }
+            return batch_scores.data() + (s - slab_base) * n;
+        };
 
         // Add-mode: the reference re-searches the whole tree for every sample because the previous
         // insertion changed it (usher_common.cpp:342).  Here all remaining samples are placed in one
@@ -393,7 +404,8 @@ int run_usher(const Options &opt, Tree &T, std::vector<MissingSample> &missing, 
 
             NodeVecs vec;
             if (opt.print_scores) {                                             // :557-578
-                const int32_t *sc = batch_scores.data() + s * total_nodes;
+                const int32_t *sc = scores_row(s);
+                if (!sc) { fclose(stats); return be_fail("per-node scoring"); }
                 for (size_t k = 0; k < total_nodes && scores_file; k++) {
                     const bool optimal = sc[k] == best;
                     fprintf(scores_file, "%s\t%s\t%d\t\t%c\t", ms.name.c_str(), flat.bfs[k]->id.c_str(), sc[k], optimal ? 'y' : 'n');
