@@ -160,6 +160,30 @@ int ugp_get_timing(ugp_mat *mat, ugp_timing *out);
 /* Message for the last non-zero return on the calling thread. */
 const char *ugp_last_error(void);
 
+/* ---- MAT construction: Fitch-Sankoff over a batch of VCF sites ---------------
+ * Replaces mapper_body::operator() (src/usher_mapper.cpp:6-161), which the VCF
+ * reader runs once per site (src/mutation_annotated_tree.cpp:2108-2179) when a
+ * MAT is built from a newick tree (`usher -t`).  All sites are assigned in one
+ * call; the caller adds the returned mutations to its nodes (Node::add_mutation).
+ * Cells of samples that are not in the tree never reach this call (the reader
+ * keeps them as the samples' own mutation lists, usher_mapper.cpp:65-82). */
+typedef struct ugp_sites {
+    uint64_t n_sites;
+    const uint8_t *ref;        /* [n_sites] one-hot reference allele (1,2,4,8) */
+    const uint64_t *var_off;   /* [n_sites + 1] CSR into var_* */
+    const uint32_t *var_node;  /* breadth-first index of the node the VCF column names (leaf or internal) */
+    const uint8_t *var_nuc;    /* its allele mask 1..15 (15 = missing); cells equal to REF are simply absent */
+} ugp_sites;
+typedef struct ugp_fitch ugp_fitch;   /* result handle (host memory) */
+
+/* `parent` is the breadth-first parent array of ugp_tree_desc (root first, parent[0] = UINT32_MAX).
+ * The result lists every (site, node) whose assigned state differs from its parent's
+ * (the root's parent state is REF), ordered by site, then node index. */
+int ugp_fitch_sankoff(int device, uint64_t n_nodes, const uint32_t *parent, const ugp_sites *sites, ugp_fitch **out);
+uint64_t ugp_fitch_count(const ugp_fitch *f);
+int ugp_fitch_get(const ugp_fitch *f, uint32_t *site, uint32_t *node, uint8_t *par_nuc /* one-hot */, uint8_t *mut_nuc /* one-hot */);
+void ugp_fitch_destroy(ugp_fitch *f);
+
 /* ---- test / tuning hooks (not part of the drop-in surface) ---------------- */
 
 /* ugp_mat_create with an explicit chunk size (nodes per DFS chunk), so small

@@ -20,10 +20,13 @@ SCORES_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(_lib.ugp_tree_desc), C.c_
 TIES_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(_lib.ugp_tree_desc), C.c_uint64, C.POINTER(_lib.ugp_queries), C.c_uint32,
                       C.c_void_p, C.c_void_p, C.c_void_p)
 ERR_FN = C.CFUNCTYPE(C.c_char_p, C.c_void_p)
+FITCH_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_uint64, C.c_void_p, C.POINTER(_lib.ugp_sites), C.POINTER(C.c_uint64))
+FITCH_GET_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p)
 
 
 class Backend(C.Structure):
-    _fields_ = [("ctx", C.c_void_p), ("place", PLACE_FN), ("scores", SCORES_FN), ("ties", TIES_FN), ("last_error", ERR_FN)]
+    _fields_ = [("ctx", C.c_void_p), ("place", PLACE_FN), ("scores", SCORES_FN), ("ties", TIES_FN), ("last_error", ERR_FN),
+                ("fitch", FITCH_FN), ("fitch_get", FITCH_GET_FN)]
 
 
 def _arr(ptr, n, dt):
@@ -100,7 +103,37 @@ class OracleBackend:
             C.memmove(tc, a_c.ctypes.data, a_c.nbytes)
             return 0
 
-        self._cbs = (PLACE_FN(place), SCORES_FN(scores), TIES_FN(ties), ERR_FN(lambda ctx: b"oracle backend"))
+        def fitch(ctx, n_nodes, parent, sites, n_out):
+            # oracle restatement of mapper_body, one site at a time
+            st = sites.contents
+            par = _arr(parent, int(n_nodes), np.uint32).astype(np.int64)
+            par[par == 0xFFFFFFFF] = -1
+            ns = int(st.n_sites)
+            ref = _arr(st.ref, ns, np.uint8)
+            off = _arr(st.var_off, ns + 1, np.uint64).astype(np.int64) if ns else np.zeros(1, np.int64)
+            vn = _arr(st.var_node, int(off[-1]), np.uint32).astype(np.int64)
+            vc = _arr(st.var_nuc, int(off[-1]), np.uint8).astype(np.int8)
+            rows = []
+            for s in range(ns):
+                _, mpar, mnuc = capi.fitch_site(par, int(ref[s]), vn[off[s]:off[s + 1]], vc[off[s]:off[s + 1]])
+                for j in np.flatnonzero(mnuc):
+                    rows.append((s, int(j), int(mpar[j]), int(mnuc[j])))
+            self._fitch = rows
+            n_out[0] = len(rows)
+            return 0
+
+        def fitch_get(ctx, site, node, mpar, mnuc):
+            rows = self._fitch
+            for ptr, col, dt in ((site, 0, np.uint32), (node, 1, np.uint32), (mpar, 2, np.uint8), (mnuc, 3, np.uint8)):
+                a = np.array([r[col] for r in rows], dt)
+                if len(a):
+                    C.memmove(ptr, a.ctypes.data, a.nbytes)
+            self._fitch = []
+            return 0
+
+        self._fitch = []
+        self._cbs = (PLACE_FN(place), SCORES_FN(scores), TIES_FN(ties), ERR_FN(lambda ctx: b"oracle backend"),
+                     FITCH_FN(fitch), FITCH_GET_FN(fitch_get))
         self.struct = Backend(None, *self._cbs)
 
 

@@ -183,6 +183,32 @@ def test_usher_cli_on_gpu_matches_reference(tmp_path):
             assert read(str(d / name)) == read(want), (flags, name)
 
 
+def test_usher_cli_builds_mat_on_gpu(tmp_path):
+    """usher-amd -t global_phylo.nh -v global_samples.vcf -o g.pb: the Fitch-Sankoff assignment runs in
+    ugp_fitch_sankoff; the written MAT and tree equal the reference's (and testBranchLen2's known answer)."""
+    import shutil
+    import subprocess
+    from oracle import refio
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "usher_amd", "bin", "usher-amd")
+    fix = os.path.join(GOLD, "ref_fixtures")
+    vcf = str(tmp_path / "global_samples.vcf")
+    with gzip.open(os.path.join(fix, "global_samples.vcf.gz"), "rb") as f, open(vcf, "wb") as o:
+        shutil.copyfileobj(f, o)
+    pb = str(tmp_path / "g.pb")
+    r = subprocess.run([exe, "-t", os.path.join(fix, "global_phylo.nh"), "-v", vcf, "-o", pb, "-d", str(tmp_path)],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+
+    def sem(path):
+        with open(path, "rb") as f:
+            newick, muts, cond, meta = refio.parse_parsimony_pb(f.read())
+        return newick, muts, sorted((k, tuple(v)) for k, v in cond), meta
+    assert sem(pb) == sem(os.path.join(SURVEY, "global", "global_assignments.pb"))
+    with open(str(tmp_path / "final-tree.nh")) as f, open(os.path.join(SURVEY, "global", "build-final-tree.nh")) as g:
+        assert f.read() == g.read()
+
+
 def test_locality_sort_and_pruning_paths_are_exact(monkeypatch):
     """Force the speed-only machinery (coarse-MAT locality sort, pruning records, work queues) onto a
     mid-size tree and a multi-tile batch; results must not change, with every switch combination."""

@@ -38,6 +38,11 @@ class ugp_timing(C.Structure):
                 ("reserved", C.c_uint32), ("words_total", C.c_uint64), ("words_skipped", C.c_uint64)]
 
 
+class ugp_sites(C.Structure):
+    _fields_ = [("n_sites", C.c_uint64), ("ref", C.c_void_p), ("var_off", C.c_void_p), ("var_node", C.c_void_p),
+                ("var_nuc", C.c_void_p)]
+
+
 # every symbol include/usher_amd.h declares: name -> (restype, argtypes)
 P = C.c_void_p
 SYMBOLS = {
@@ -53,6 +58,10 @@ SYMBOLS = {
     "ugp_place_device": (C.c_int, [P, P, P, P]),
     "ugp_get_timing": (C.c_int, [P, C.POINTER(ugp_timing)]),
     "ugp_last_error": (C.c_char_p, []),
+    "ugp_fitch_sankoff": (C.c_int, [C.c_int, C.c_uint64, P, C.POINTER(ugp_sites), C.POINTER(P)]),
+    "ugp_fitch_count": (C.c_uint64, [P]),
+    "ugp_fitch_get": (C.c_int, [P, P, P, P, P]),
+    "ugp_fitch_destroy": (None, [P]),
     "ugp_mat_create_chunked": (C.c_int, [C.POINTER(ugp_tree_desc), C.c_int, C.c_uint32, C.POINTER(P)]),
     "ugp_flat_create": (C.c_int, [C.POINTER(ugp_tree_desc), C.c_uint32, C.POINTER(P)]),
     "ugp_flat_destroy": (None, [P]),

@@ -110,6 +110,20 @@ static int parse(int argc, char **argv, Options &o) {
     return 0;
 }
 
+static bool assign_via_backend(void *ctx, const SiteBatch &in, SiteMutations &out, std::string &err) {
+    const Backend &be = *(const Backend *)ctx;
+    if (!be.fitch || !be.fitch_get) { err = "ERROR: the placement backend has no Fitch-Sankoff entry point."; return false; }
+    ugp_sites sites{};
+    sites.n_sites = in.ref.size(); sites.ref = in.ref.data(); sites.var_off = in.var_off.data();
+    sites.var_node = in.var_node.data(); sites.var_nuc = in.var_nuc.data();
+    uint64_t n = 0;
+    auto why = [&]() { return std::string(be.last_error ? be.last_error(be.ctx) : "?"); };
+    if (be.fitch(be.ctx, in.parent.size(), in.parent.data(), &sites, &n) != 0) { err = "ERROR: Fitch-Sankoff backend failed: " + why(); return false; }
+    out.site.resize(n); out.node.resize(n); out.par_nuc.resize(n); out.mut_nuc.resize(n);
+    if (be.fitch_get(be.ctx, out.site.data(), out.node.data(), out.par_nuc.data(), out.mut_nuc.data()) != 0) { err = "ERROR: Fitch-Sankoff backend failed: " + why(); return false; }
+    return true;
+}
+
 int usher_main(int argc, char **argv, const Backend &be) {
     Options opt;
     int pr = parse(argc, argv, opt);
@@ -129,7 +143,7 @@ int usher_main(int argc, char **argv, const Backend &be) {
         if (!tree_from_newick(nwk, T, err)) { fprintf(stderr, "ERROR: %s!\n", err.c_str()); return 1; }
         if (!T.root) { fprintf(stderr, "ERROR: Empty tree.\n"); return 1; }
         fprintf(stderr, "Loading VCF file.\nComputing parsimonious assignments for input variants.\n");
-        if (!read_vcf_build(T, opt.vcf, missing, err)) { fprintf(stderr, "%s\n", err.c_str()); return 1; }
+        if (!read_vcf_build(T, opt.vcf, missing, err, assign_via_backend, (void *)&be)) { fprintf(stderr, "%s\n", err.c_str()); return 1; }
     } else if (!opt.load_mat.empty()) {                                         // usher.cpp:151-170
         fprintf(stderr, "Loading existing mutation-annotated tree object from file %s\n", opt.load_mat.c_str());
         if (!load_mat(opt.load_mat, T, err)) { fprintf(stderr, "%s\n", err.c_str()); return 1; }

@@ -35,6 +35,10 @@ struct Backend {
     int (*ties)(void *ctx, const ugp_tree_desc *, uint64_t tree_version, const ugp_queries *, uint32_t cap, uint32_t *,
                 uint8_t *, uint32_t *) = nullptr;
     const char *(*last_error)(void *ctx) = nullptr;
+    // mapper_body (usher_mapper.cpp:6-161) for all VCF sites of a `-t` build: ugp_fitch_sankoff.
+    // `fitch` computes and keeps the result in the backend, `fitch_get` copies it out and releases it.
+    int (*fitch)(void *ctx, uint64_t n_nodes, const uint32_t *parent, const ugp_sites *sites, uint64_t *n_out) = nullptr;
+    int (*fitch_get)(void *ctx, uint32_t *site, uint32_t *node, uint8_t *par_nuc, uint8_t *mut_nuc) = nullptr;
 };
 
 // Returns the process exit code (usher_common.cpp:6).

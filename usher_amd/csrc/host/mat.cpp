@@ -616,54 +616,18 @@ bool read_vcf_missing(Tree &T, const std::string &path, std::vector<MissingSampl
     return true;
 }
 
-// Fitch-Sankoff for one site: mapper_body::operator(), usher_mapper.cpp:6-161.
-static void fitch_site(const std::vector<Node *> &bfs, const std::vector<uint32_t> &parent_idx, const std::vector<uint8_t> &is_leaf,
-                       int8_t ref_nuc, const std::vector<std::pair<uint32_t, int8_t>> &variants, uint32_t chrom, int32_t pos) {
-    const size_t n = bfs.size();
-    const int big = (int)n;
-    std::vector<int> sc(n * 4, 0);
-    std::vector<int8_t> st(n, 0);
-    const int8_t ref_id = nuc_index(ref_nuc);
-    for (size_t j = 0; j < n; j++)
-        if (is_leaf[j]) for (int b = 0; b < 4; b++) if (b != ref_id) sc[j * 4 + b] = big;
-    for (auto &v : variants)
-        for (int b = 0; b < 4; b++) sc[(size_t)v.first * 4 + b] = ((1 << b) & v.second) ? 0 : big;
-    for (size_t j = n; j-- > 1;) {   // forward pass: children feed parents (reverse BFS order)
-        const size_t p = parent_idx[j];
-        for (int b = 0; b < 4; b++) {
-            int mn = big + 1;
-            for (int k = 0; k < 4; k++) { int c = sc[j * 4 + k] + (k == b ? 0 : 1); if (c < mn) mn = c; }
-            sc[p * 4 + b] += mn;
-        }
-    }
-    for (size_t j = 0; j < n; j++) {   // backward pass: prefer the parent's state on ties (:129-141)
-        const int8_t par_state = j ? st[parent_idx[j]] : ref_id;
-        int8_t state = par_state;
-        int mn = sc[j * 4 + par_state];
-        for (int b = 0; b < 4; b++) if (sc[j * 4 + b] < mn) { mn = sc[j * 4 + b]; state = (int8_t)b; }
-        if (state != par_state && sc[j * 4 + par_state] == mn) state = par_state;
-        st[j] = state;
-        if (state != par_state) {
-            Mutation m;
-            m.chrom = chrom; m.position = pos; m.ref_nuc = ref_nuc;
-            m.par_nuc = (int8_t)(1 << par_state); m.mut_nuc = (int8_t)(1 << state);
-            bfs[j]->add_mutation(m);
-        }
-    }
-}
-
-bool read_vcf_build(Tree &T, const std::string &path, std::vector<MissingSample> &out, std::string &err) {   // :2052-2179
+bool read_vcf_build(Tree &T, const std::string &path, std::vector<MissingSample> &out, std::string &err, AssignFn assign, void *ctx) {   // :2052-2179
     std::vector<std::string> lines;
     if (!read_lines(path, lines, err)) return false;
     auto bfs = T.bfs();
     std::unordered_map<std::string, uint32_t> idx;
-    std::vector<uint32_t> parent_idx(bfs.size(), 0);
-    std::vector<uint8_t> is_leaf(bfs.size(), 0);
+    SiteBatch batch;
+    batch.parent.assign(bfs.size(), UINT32_MAX);
     for (uint32_t j = 0; j < bfs.size(); j++) idx[bfs[j]->id] = j;
-    for (uint32_t j = 0; j < bfs.size(); j++) {
-        if (bfs[j]->parent) parent_idx[j] = idx[bfs[j]->parent->id];
-        is_leaf[j] = bfs[j]->is_leaf();
-    }
+    for (uint32_t j = 0; j < bfs.size(); j++)
+        if (bfs[j]->parent) batch.parent[j] = idx[bfs[j]->parent->id];
+    std::vector<int32_t> site_pos;
+    std::vector<uint32_t> site_chrom;
     bool header_found = false;
     std::vector<std::string> ids;
     std::vector<int64_t> col_node;      // per VCF column: BFS index, or -1 - (index into out)
@@ -693,7 +657,6 @@ bool read_vcf_build(Tree &T, const std::string &path, std::vector<MissingSample>
             if (nuc_index(ref) < 0) { err = "ERROR! VCF REF base is not one of A,C,G,T."; return false; }
             const uint32_t chrom = T.chrom_id(words[0]);
             fprintf(stderr, "At variant site %i\n", pos);
-            std::vector<std::pair<uint32_t, int8_t>> variants;
             for (size_t j = 9; j < words.size(); j++) {
                 int8_t nuc;
                 if (isdigit((unsigned char)words[j][0])) {
@@ -703,7 +666,7 @@ bool read_vcf_build(Tree &T, const std::string &path, std::vector<MissingSample>
                     nuc = nuc_id(alleles[a - 1][0]);
                 } else nuc = 15;
                 const int64_t c = col_node[j - 9];
-                if (c >= 0) variants.emplace_back((uint32_t)c, nuc);
+                if (c >= 0) { batch.var_node.push_back((uint32_t)c); batch.var_nuc.push_back((uint8_t)nuc); }
                 else {   // sample to be placed later: keep its row (usher_mapper.cpp:65-82)
                     Mutation m;
                     m.chrom = chrom; m.position = pos; m.ref_nuc = ref; m.par_nuc = ref;
@@ -711,8 +674,21 @@ bool read_vcf_build(Tree &T, const std::string &path, std::vector<MissingSample>
                     out[(size_t)(-1 - c)].mutations.push_back(m);
                 }
             }
-            fitch_site(bfs, parent_idx, is_leaf, ref, variants, chrom, pos);
+            batch.ref.push_back((uint8_t)ref);
+            batch.var_off.push_back(batch.var_node.size());
+            site_pos.push_back(pos);
+            site_chrom.push_back(chrom);
         }
+    }
+    if (!assign) { err = "ERROR: no Fitch-Sankoff backend (the GPU library is required to build a MAT from a tree)."; return false; }
+    SiteMutations muts;
+    if (!assign(ctx, batch, muts, err)) return false;
+    for (size_t i = 0; i < muts.site.size(); i++) {                             // usher_mapper.cpp:143-156
+        if (muts.site[i] >= site_pos.size() || muts.node[i] >= bfs.size()) { err = "ERROR: Fitch-Sankoff backend returned an out-of-range index."; return false; }
+        Mutation m;
+        m.chrom = site_chrom[muts.site[i]]; m.position = site_pos[muts.site[i]]; m.ref_nuc = (int8_t)batch.ref[muts.site[i]];
+        m.par_nuc = (int8_t)muts.par_nuc[i]; m.mut_nuc = (int8_t)muts.mut_nuc[i];
+        bfs[muts.node[i]]->add_mutation(m);
     }
     return true;
 }

@@ -89,8 +89,18 @@ struct MissingSample {           // usher_graph.hpp:33-53
 };
 // existing-MAT branch of read_vcf, :2180-2277
 bool read_vcf_missing(Tree &t, const std::string &path, std::vector<MissingSample> &out, std::string &err);
-// new-MAT branch, :2052-2179: Fitch-Sankoff per site (mapper_body, usher_mapper.cpp:6-161) on the host,
-// sites in file order (deterministic)
-bool read_vcf_build(Tree &t, const std::string &path, std::vector<MissingSample> &out, std::string &err);
+// new-MAT branch, :2052-2179.  The Fitch-Sankoff assignment of every site (mapper_body,
+// usher_mapper.cpp:6-161) is delegated to `assign` (the GPU library's ugp_fitch_sankoff); the
+// resulting mutations are added in file order of the sites, nodes in breadth-first order (deterministic).
+struct SiteBatch {               // what ugp_sites carries, owned
+    std::vector<uint32_t> parent;            // breadth-first parent indices, root = UINT32_MAX
+    std::vector<uint8_t> ref;
+    std::vector<uint64_t> var_off{0};
+    std::vector<uint32_t> var_node;
+    std::vector<uint8_t> var_nuc;
+};
+struct SiteMutations { std::vector<uint32_t> site, node; std::vector<uint8_t> par_nuc, mut_nuc; };
+typedef bool (*AssignFn)(void *ctx, const SiteBatch &in, SiteMutations &out, std::string &err);
+bool read_vcf_build(Tree &t, const std::string &path, std::vector<MissingSample> &out, std::string &err, AssignFn assign, void *ctx);
 
 }  // namespace uh

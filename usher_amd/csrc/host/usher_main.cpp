@@ -12,6 +12,7 @@ namespace {
 
 struct GpuCtx {
     ugp_mat *mat = nullptr;
+    ugp_fitch *fitch = nullptr;
     uint64_t version = 0;
     int device = 0;
 };
@@ -40,6 +41,20 @@ int gpu_ties(void *ctx, const ugp_tree_desc *t, uint64_t v, const ugp_queries *q
     return ugp_tied_nodes(c->mat, q, cap, tj, th, tc);
 }
 const char *gpu_err(void *) { return ugp_last_error(); }
+int gpu_fitch(void *ctx, uint64_t n_nodes, const uint32_t *parent, const ugp_sites *sites, uint64_t *n_out) {
+    GpuCtx *c = (GpuCtx *)ctx;
+    if (c->fitch) { ugp_fitch_destroy(c->fitch); c->fitch = nullptr; }
+    if (int rc = ugp_fitch_sankoff(c->device, n_nodes, parent, sites, &c->fitch)) return rc;
+    *n_out = ugp_fitch_count(c->fitch);
+    return UGP_OK;
+}
+int gpu_fitch_get(void *ctx, uint32_t *site, uint32_t *node, uint8_t *par_nuc, uint8_t *mut_nuc) {
+    GpuCtx *c = (GpuCtx *)ctx;
+    int rc = ugp_fitch_get(c->fitch, site, node, par_nuc, mut_nuc);
+    ugp_fitch_destroy(c->fitch);
+    c->fitch = nullptr;
+    return rc;
+}
 
 }  // namespace
 
@@ -48,7 +63,9 @@ int main(int argc, char **argv) {
     for (int i = 1; i + 1 < argc; i++) if (std::string(argv[i]) == "--device") ctx.device = atoi(argv[i + 1]);
     uh::Backend be;
     be.ctx = &ctx; be.place = gpu_place; be.scores = gpu_scores; be.ties = gpu_ties; be.last_error = gpu_err;
+    be.fitch = gpu_fitch; be.fitch_get = gpu_fitch_get;
     int rc = uh::usher_main(argc, argv, be);
     if (ctx.mat) ugp_mat_destroy(ctx.mat);
+    if (ctx.fitch) ugp_fitch_destroy(ctx.fitch);
     return rc;
 }

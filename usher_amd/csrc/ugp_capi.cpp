@@ -31,6 +31,14 @@ int fail(int code, const std::string &msg) {
             return fail(UGP_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));      \
     } while (0)
 
+}  // namespace
+
+namespace ugp {
+int set_error(int code, const std::string &msg) { return fail(code, msg); }   // for the other translation units
+}
+
+namespace {
+
 template <typename T>
 struct DevBuf {
     T *p = nullptr;
