@@ -116,9 +116,14 @@ def test_gpu_fitch_sankoff_equals_oracle(kind, n, n_sites, seed, monkeypatch):
     parent = random_bfs_tree(rng, n, kind)
     ref, off, nodes, nucs = random_sites(rng, parent, n_sites, p_var=0.1 if n > 1000 else 0.3)
     want = oracle_mutations(parent, ref, off, nodes, nucs)
-    for budget in (None, str(n * 4 * 3)):   # one pass, and several passes of 24 sites
+    # one pass; several passes of 24 sites; and the exact listing pass used when the first buffer is too small
+    for budget, cap in ((None, None), (str(n * 4 * 3), None), (None, "3")):
+        monkeypatch.delenv("UGP_FITCH_BYTES", raising=False)
+        monkeypatch.delenv("UGP_FITCH_EMIT_CAP", raising=False)
         if budget:
             monkeypatch.setenv("UGP_FITCH_BYTES", budget)
+        if cap:
+            monkeypatch.setenv("UGP_FITCH_EMIT_CAP", cap)
         site, node, mpar, mnuc = fitch_sankoff(parent, ref, off, nodes, nucs)
         got = list(zip(site.tolist(), node.tolist(), mpar.tolist(), mnuc.tolist()))
         assert got == want

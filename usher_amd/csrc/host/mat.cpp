@@ -628,6 +628,7 @@ bool read_vcf_build(Tree &T, const std::string &path, std::vector<MissingSample>
         if (bfs[j]->parent) batch.parent[j] = idx[bfs[j]->parent->id];
     std::vector<int32_t> site_pos;
     std::vector<uint32_t> site_chrom;
+    std::vector<std::pair<uint32_t, uint8_t>> line_cells;
     bool header_found = false;
     std::vector<std::string> ids;
     std::vector<int64_t> col_node;      // per VCF column: BFS index, or -1 - (index into out)
@@ -657,6 +658,7 @@ bool read_vcf_build(Tree &T, const std::string &path, std::vector<MissingSample>
             if (nuc_index(ref) < 0) { err = "ERROR! VCF REF base is not one of A,C,G,T."; return false; }
             const uint32_t chrom = T.chrom_id(words[0]);
             fprintf(stderr, "At variant site %i\n", pos);
+            line_cells.clear();
             for (size_t j = 9; j < words.size(); j++) {
                 int8_t nuc;
                 if (isdigit((unsigned char)words[j][0])) {
@@ -666,13 +668,20 @@ bool read_vcf_build(Tree &T, const std::string &path, std::vector<MissingSample>
                     nuc = nuc_id(alleles[a - 1][0]);
                 } else nuc = 15;
                 const int64_t c = col_node[j - 9];
-                if (c >= 0) { batch.var_node.push_back((uint32_t)c); batch.var_nuc.push_back((uint8_t)nuc); }
+                if (c >= 0) line_cells.emplace_back((uint32_t)c, (uint8_t)nuc);
                 else {   // sample to be placed later: keep its row (usher_mapper.cpp:65-82)
                     Mutation m;
                     m.chrom = chrom; m.position = pos; m.ref_nuc = ref; m.par_nuc = ref;
                     if (nuc == 15) { m.is_missing = true; m.mut_nuc = 15; } else m.mut_nuc = nuc;
                     out[(size_t)(-1 - c)].mutations.push_back(m);
                 }
+            }
+            // cells in ascending node order (what the backend's fast path wants); a node named by several
+            // columns keeps the cell of the last one, as the in-order loop of usher_mapper.cpp:47-62 does
+            std::stable_sort(line_cells.begin(), line_cells.end(), [](const auto &a, const auto &b) { return a.first < b.first; });
+            for (size_t k = 0; k < line_cells.size(); k++) {
+                if (k + 1 < line_cells.size() && line_cells[k + 1].first == line_cells[k].first) continue;
+                batch.var_node.push_back(line_cells[k].first); batch.var_nuc.push_back(line_cells[k].second);
             }
             batch.ref.push_back((uint8_t)ref);
             batch.var_off.push_back(batch.var_node.size());

@@ -25,12 +25,13 @@
 #include <hipcub/hipcub.hpp>
 
 #include <algorithm>
+#include <chrono>
+#include <cstdio>
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
-#include <unordered_map>
 #include <vector>
 
 #include "usher_amd.h"
@@ -53,115 +54,216 @@ __device__ __forceinline__ uint32_t nib_lowbit(uint32_t f) {   // lowest set bit
     return f & ~up;
 }
 
+// Work items are (node, 64-word tile) pairs in node-major order, so consecutive items of a wave
+// walk contiguous memory.  FS_NB items per wave amortise the wave launch and put FS_NB independent
+// loads in flight.
+constexpr int FS_NB = 8;
+
 // leaves start as {REF}, internal nodes as "any base"
-__global__ void k_fs_init(uint32_t *__restrict__ F, const uint32_t *__restrict__ refw, const uint32_t *__restrict__ n_children,
-                          uint64_t n_nodes, uint32_t W) {
-    const uint64_t total = n_nodes * W;
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (uint64_t)gridDim.x * blockDim.x) {
-        const uint64_t n = i / W;
-        const uint32_t w = (uint32_t)(i - n * W);
-        F[i] = n_children[n] ? 0xFFFFFFFFu : refw[w];
+__global__ __launch_bounds__(256) void k_fs_init(uint32_t *__restrict__ F, const uint32_t *__restrict__ refw,
+                                                 const uint32_t *__restrict__ n_children, uint32_t n_nodes, uint32_t W, uint32_t gy) {
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const uint64_t total = (uint64_t)n_nodes * gy;
+    uint64_t T = ((uint64_t)blockIdx.x * 4 + wave) * FS_NB;
+    if (T >= total) return;
+    uint32_t n = (uint32_t)(T / gy), wt = (uint32_t)(T % gy);
+#pragma unroll
+    for (int u = 0; u < FS_NB; u++) {
+        const uint32_t w = wt * 64 + lane;
+        if (T + u < total && w < W) F[(uint64_t)n * W + w] = n_children[n] ? 0xFFFFFFFFu : refw[w];
+        if (++wt == gy) { wt = 0; n++; }
     }
 }
 
-// genotype cells of tree nodes: replace the initial nibble by the allele mask (:47-62)
+// genotype cells of tree nodes: replace the initial nibble by the allele mask (:47-62).
+// Cells are grouped by site; v_off[s] is the first cell of site s of this pass.
 __global__ void k_fs_scatter(uint32_t *__restrict__ F, const uint32_t *__restrict__ refw, const uint32_t *__restrict__ n_children,
-                             const uint32_t *__restrict__ v_site, const uint32_t *__restrict__ v_node,
+                             const uint64_t *__restrict__ v_off, uint32_t n_sites, const uint32_t *__restrict__ v_node,
                              const uint8_t *__restrict__ v_nuc, uint64_t n_var, uint32_t W) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_var) return;
-    const uint32_t s = v_site[i], n = v_node[i];
+    uint32_t lo = 0, hi = n_sites;   // last s with v_off[s] <= i
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (v_off[mid] <= i) lo = mid; else hi = mid;
+    }
+    const uint32_t s = lo, n = v_node[i];
     const uint32_t w = s >> 3, sh = (s & 7) * 4;
     const uint32_t old = n_children[n] ? 0xFu : ((refw[w] >> sh) & 0xFu);
     const uint32_t x = (old ^ (v_nuc[i] & 0xFu)) << sh;
     if (x) atomicXor(&F[(uint64_t)n * W + w], x);
 }
 
-// forward pass for the internal nodes of one level (:86-111)
+// forward pass for the internal nodes of one level (:86-111).  A wave takes FS_FN (node, tile) items; the
+// node's own row and its first two child rows of every item are requested before any is used.
+constexpr int FS_FN = 4;
+
 __global__ __launch_bounds__(256) void k_fs_forward(uint32_t *__restrict__ F, const uint32_t *__restrict__ nodes, uint32_t n_level,
                                                     const uint32_t *__restrict__ first_child,
-                                                    const uint32_t *__restrict__ n_children, uint32_t W) {
-    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const uint32_t idx = blockIdx.x * 4 + wave;
-    const uint32_t w = blockIdx.y * 64 + lane;
-    if (idx >= n_level || w >= W) return;
-    const uint32_t p = __builtin_amdgcn_readfirstlane(nodes[idx]);
-    const uint32_t c0 = __builtin_amdgcn_readfirstlane(first_child[p]);
-    const uint32_t nc = __builtin_amdgcn_readfirstlane(n_children[p]);
-    const int K = 32 - __builtin_clz(nc);   // planes needed to count to nc
-    uint32_t plane[FS_PLANES];
+                                                    const uint32_t *__restrict__ n_children, uint32_t W, uint32_t gy) {
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const uint64_t total = (uint64_t)n_level * gy;
+    const uint64_t T = ((uint64_t)blockIdx.x * 4 + wave) * FS_FN;
+    if (T >= total) return;
+    uint32_t idx = (uint32_t)(T / gy), wt = (uint32_t)(T % gy);
+    uint32_t own[FS_FN], ch0[FS_FN], ch1[FS_FN], pp[FS_FN], cc0[FS_FN], ncs[FS_FN], ww[FS_FN];
+    bool ok[FS_FN];
 #pragma unroll
-    for (int k = 0; k < FS_PLANES; k++) plane[k] = 0;
-    const uint32_t *row = F + (uint64_t)c0 * W + w;
-    uint32_t nxt = *row;
-    for (uint32_t c = 0; c < nc; c++) {
-        const uint32_t x = nxt;
-        if (c + 1 < nc) nxt = row[(uint64_t)(c + 1) * W];
-        uint32_t carry = ~x;   // +1 for every (site, base) with base not in F_c
-#pragma unroll
-        for (int k = 0; k < FS_PLANES; k++) {
-            if (k >= K) break;
-            const uint32_t t = plane[k] & carry;
-            plane[k] ^= carry;
-            carry = t;
+    for (int u = 0; u < FS_FN; u++) {
+        const uint32_t w = wt * 64 + lane;
+        ok[u] = T + u < total;
+        ww[u] = w;
+        pp[u] = 0; cc0[u] = 0; ncs[u] = 0; own[u] = 0; ch0[u] = 0xFFFFFFFFu; ch1[u] = 0xFFFFFFFFu;
+        if (ok[u]) {
+            const uint32_t p = nodes[idx];
+            pp[u] = p; cc0[u] = first_child[p]; ncs[u] = n_children[p];
+            if (w < W) {
+                own[u] = F[(uint64_t)p * W + w];
+                ch0[u] = F[(uint64_t)cc0[u] * W + w];
+                if (ncs[u] > 1) ch1[u] = F[(uint64_t)(cc0[u] + 1) * W + w];
+            }
         }
+        if (++wt == gy) { wt = 0; idx++; }
     }
-    uint32_t cand = F[(uint64_t)p * W + w];   // allowed bases (all four, or the node's own genotype mask)
 #pragma unroll
-    for (int k = FS_PLANES - 1; k >= 0; k--) {
-        if (k >= K) continue;
-        const uint32_t z = cand & ~plane[k];   // candidates whose counter has a 0 here
-        const uint32_t m = nib_any(z);
-        cand = (z & m) | (cand & ~m);
+    for (int u = 0; u < FS_FN; u++) {
+        if (!ok[u] || ww[u] >= W) continue;
+        const uint32_t nc = ncs[u];
+        const int K = 32 - __builtin_clz(nc);   // planes needed to count to nc
+        uint32_t plane[FS_PLANES];
+#pragma unroll
+        for (int k = 0; k < FS_PLANES; k++) plane[k] = 0;
+        // +1 for every (site, base) with base not in F_c; the first two children by hand, the rest rippled
+        plane[0] = ~ch0[u];
+        if (nc > 1) {
+            const uint32_t c = ~ch1[u];
+            plane[1] = plane[0] & c;
+            plane[0] ^= c;
+        }
+        if (nc > 2) {
+            const uint32_t *row = F + (uint64_t)cc0[u] * W + ww[u];
+            uint32_t nxt = row[(uint64_t)2 * W];
+            for (uint32_t c = 2; c < nc; c++) {
+                const uint32_t x = nxt;
+                if (c + 1 < nc) nxt = row[(uint64_t)(c + 1) * W];
+                uint32_t carry = ~x;
+#pragma unroll
+                for (int k = 0; k < FS_PLANES; k++) {
+                    if (k >= K) break;
+                    const uint32_t t = plane[k] & carry;
+                    plane[k] ^= carry;
+                    carry = t;
+                }
+            }
+        }
+        uint32_t cand = own[u];   // allowed bases (all four, or the node's own genotype mask)
+#pragma unroll
+        for (int k = FS_PLANES - 1; k >= 0; k--) {
+            if (k >= K) continue;
+            const uint32_t z = cand & ~plane[k];   // candidates whose counter has a 0 here
+            const uint32_t m = nib_any(z);
+            cand = (z & m) | (cand & ~m);
+        }
+        F[(uint64_t)pp[u] * W + ww[u]] = cand;
     }
-    F[(uint64_t)p * W + w] = cand;
 }
 
-// backward pass for all nodes of one level (:114-141); states replace F in place.
-__global__ __launch_bounds__(256) void k_fs_backward(uint32_t *__restrict__ F, const uint32_t *__restrict__ refw,
-                                                     const uint32_t *__restrict__ parent, uint32_t lvl_begin, uint32_t lvl_end,
-                                                     uint32_t W, unsigned long long *__restrict__ n_mut) {
-    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const uint32_t n = lvl_begin + blockIdx.x * 4 + wave;
-    const uint32_t w = blockIdx.y * 64 + lane;
-    uint32_t changed = 0;
-    if (n < lvl_end && w < W) {
-        const uint32_t par = __builtin_amdgcn_readfirstlane(parent[n]);
-        const uint32_t sp = par == 0xFFFFFFFFu ? refw[w] : F[(uint64_t)par * W + w];
-        const uint32_t f = F[(uint64_t)n * W + w];
-        const uint32_t keep = nib_any(f & sp);
-        const uint32_t s = (sp & keep) | (nib_lowbit(f) & ~keep);
-        F[(uint64_t)n * W + w] = s;
-        changed = __builtin_popcount(nib_any(s ^ sp) & 0x11111111u);
-    }
-    // one atomic per wave
-    for (int o = 32; o; o >>= 1) changed += __shfl_down(changed, o, 64);
-    if (lane == 0 && changed) atomicAdd(n_mut, (unsigned long long)changed);
-}
+// Listed changes go to FS_SEG independent segments of the output buffer (cursor + base per segment):
+// atomics on a single address run at ~90 per microsecond on this part, which would otherwise bound the pass.
+constexpr uint32_t FS_SEG = 2048;
 
-// list the (site, node) pairs whose state differs from the parent's (:143-156)
-__global__ __launch_bounds__(256) void k_fs_emit(const uint32_t *__restrict__ F, const uint32_t *__restrict__ refw,
-                                                 const uint32_t *__restrict__ parent, uint32_t n_nodes, uint32_t W, uint32_t site_base,
-                                                 unsigned long long *__restrict__ cursor, uint64_t *__restrict__ out_key,
-                                                 uint8_t *__restrict__ out_val) {
-    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const uint32_t n = blockIdx.x * 4 + wave;
-    const uint32_t w = blockIdx.y * 64 + lane;
-    if (n >= n_nodes || w >= W) return;
-    const uint32_t par = __builtin_amdgcn_readfirstlane(parent[n]);
-    const uint32_t sp = par == 0xFFFFFFFFu ? refw[w] : F[(uint64_t)par * W + w];
-    const uint32_t s = F[(uint64_t)n * W + w];
-    uint32_t d = nib_any(s ^ sp) & 0x11111111u;
-    if (!d) return;
+__device__ __forceinline__ void fs_emit(uint32_t d, uint32_t s, uint32_t sp, uint32_t n, uint32_t site0,
+                                        unsigned long long *__restrict__ cursor, unsigned long long cap,
+                                        uint64_t *__restrict__ out_key, uint8_t *__restrict__ out_val) {
     const unsigned long long at = atomicAdd(cursor, (unsigned long long)__builtin_popcount(d));
     uint32_t k = 0;
     while (d) {
         const uint32_t sh = __builtin_ctz(d);
         d &= d - 1;
-        const uint32_t site = site_base + w * 8 + (sh >> 2);
-        out_key[at + k] = ((uint64_t)site << 32) | n;
-        out_val[at + k] = (uint8_t)((((sp >> sh) & 0xFu) << 4) | ((s >> sh) & 0xFu));
+        if (at + k < cap) {
+            out_key[at + k] = ((uint64_t)(site0 + (sh >> 2)) << 32) | n;
+            out_val[at + k] = (uint8_t)((((sp >> sh) & 0xFu) << 4) | ((s >> sh) & 0xFu));
+        }
         k++;
+    }
+}
+
+// backward pass for all nodes of one level (:114-141); states replace F in place (only internal
+// nodes are read again, so leaves are not stored) and state changes are listed as they are found
+// (:143-156) in segment (wave index mod FS_SEG).  cursor[seg * 8] ends as the number of changes of
+// the segment; entries beyond `seg_cap` are dropped and the caller falls back to k_fs_emit.
+__global__ __launch_bounds__(256) void k_fs_backward(uint32_t *__restrict__ F, const uint32_t *__restrict__ refw,
+                                                     const uint32_t *__restrict__ parent, const uint32_t *__restrict__ n_children,
+                                                     uint32_t lvl_begin, uint32_t lvl_end, uint32_t W, uint32_t gy, uint32_t site_base,
+                                                     unsigned long long *__restrict__ cursor, unsigned long long seg_cap,
+                                                     uint64_t *__restrict__ out_key, uint8_t *__restrict__ out_val) {
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const uint32_t seg = (blockIdx.x * 4 + wave) & (FS_SEG - 1);
+    cursor += seg * 8;
+    out_key += seg * seg_cap;
+    out_val += seg * seg_cap;
+    const uint64_t total = (uint64_t)(lvl_end - lvl_begin) * gy;
+    const uint64_t T = ((uint64_t)blockIdx.x * 4 + wave) * FS_NB;
+    if (T >= total) return;
+    uint32_t n = lvl_begin + (uint32_t)(T / gy), wt = (uint32_t)(T % gy);
+    uint32_t f[FS_NB], sp[FS_NB], nn[FS_NB], ww[FS_NB];
+    bool ok[FS_NB];
+#pragma unroll
+    for (int u = 0; u < FS_NB; u++) {
+        const uint32_t w = wt * 64 + lane;
+        ok[u] = T + u < total && w < W;
+        nn[u] = n; ww[u] = w;
+        f[u] = 0; sp[u] = 0;
+        if (ok[u]) {
+            const uint32_t par = parent[n];
+            sp[u] = par == 0xFFFFFFFFu ? refw[w] : F[(uint64_t)par * W + w];
+            f[u] = F[(uint64_t)n * W + w];
+        }
+        if (++wt == gy) { wt = 0; n++; }
+    }
+#pragma unroll
+    for (int u = 0; u < FS_NB; u++) {
+        if (!ok[u]) continue;
+        const uint32_t keep = nib_any(f[u] & sp[u]);
+        const uint32_t s = (sp[u] & keep) | (nib_lowbit(f[u]) & ~keep);
+        if (n_children[nn[u]]) F[(uint64_t)nn[u] * W + ww[u]] = s;
+        const uint32_t d = nib_any(s ^ sp[u]) & 0x11111111u;
+        if (d) fs_emit(d, s, sp[u], nn[u], site_base + ww[u] * 8, cursor, seg_cap, out_key, out_val);
+    }
+}
+
+// fallback listing pass when the buffer given to k_fs_backward was too small.  Internal rows hold
+// states, leaf rows still hold their sets, so a leaf's state is derived again.
+__global__ __launch_bounds__(256) void k_fs_emit(const uint32_t *__restrict__ F, const uint32_t *__restrict__ refw,
+                                                 const uint32_t *__restrict__ parent, const uint32_t *__restrict__ n_children,
+                                                 uint32_t n_nodes, uint32_t W, uint32_t gy, uint32_t site_base,
+                                                 unsigned long long *__restrict__ cursor, unsigned long long cap,
+                                                 uint64_t *__restrict__ out_key, uint8_t *__restrict__ out_val) {
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const uint64_t T = (uint64_t)blockIdx.x * 4 + wave;
+    const uint32_t n = (uint32_t)(T / gy);
+    const uint32_t w = (uint32_t)(T % gy) * 64 + lane;
+    if (n >= n_nodes || w >= W) return;
+    const uint32_t par = parent[n];
+    const uint32_t sp = par == 0xFFFFFFFFu ? refw[w] : F[(uint64_t)par * W + w];
+    uint32_t s = F[(uint64_t)n * W + w];
+    if (!n_children[n]) {
+        const uint32_t keep = nib_any(s & sp);
+        s = (sp & keep) | (nib_lowbit(s) & ~keep);
+    }
+    const uint32_t d = nib_any(s ^ sp) & 0x11111111u;
+    if (d) fs_emit(d, s, sp, n, site_base + w * 8, cursor, cap, out_key, out_val);
+}
+
+// gather the segments into one dense list
+__global__ void k_fs_compact(const uint64_t *__restrict__ seg_key, const uint8_t *__restrict__ seg_val,
+                             const unsigned long long *__restrict__ seg_begin, unsigned long long seg_cap,
+                             uint64_t *__restrict__ out_key, uint8_t *__restrict__ out_val) {
+    const uint32_t seg = blockIdx.x;
+    const unsigned long long b = seg_begin[seg], e = seg_begin[seg + 1];
+    for (unsigned long long i = threadIdx.x; i < e - b; i += blockDim.x) {
+        out_key[b + i] = seg_key[seg * seg_cap + i];
+        out_val[b + i] = seg_val[seg * seg_cap + i];
     }
 }
 
@@ -205,6 +307,14 @@ extern "C" int ugp_fitch_sankoff(int device, uint64_t n_nodes, const uint32_t *p
     if (n_var && (!sites->var_node || !sites->var_nuc)) return ugp::set_error(UGP_ERR_INVALID, "null variant arrays");
     // topology: breadth-first order means parent[] is non-decreasing and children are contiguous
     if (parent[0] != 0xFFFFFFFFu) return ugp::set_error(UGP_ERR_INVALID, "parent[0] must be the root (UINT32_MAX)");
+    auto t_last = std::chrono::steady_clock::now();
+    auto lap = [&]() {
+        auto now = std::chrono::steady_clock::now();
+        double ms = std::chrono::duration<double, std::milli>(now - t_last).count();
+        t_last = now;
+        return ms;
+    };
+    double t_topo = 0, t_alloc = 0, t_prep = 0, t_kern = 0, t_out = 0;
     const uint32_t N = (uint32_t)n_nodes;
     std::vector<uint32_t> first_child(N, 0), n_children(N, 0), level(N, 0);
     for (uint32_t j = 1; j < N; j++) {
@@ -240,6 +350,7 @@ extern "C" int ugp_fitch_sankoff(int device, uint64_t n_nodes, const uint32_t *p
     struct Guard { ugp_fitch *r; ~Guard() { delete r; } } guard{res};
     if (S == 0) { guard.r = nullptr; *out = res; return UGP_OK; }
 
+    t_topo = lap();
     FS_TRY(hipSetDevice(device));
     hipStream_t stream = nullptr;
     Dev<uint32_t> d_parent, d_first, d_nchild, d_inodes;
@@ -248,102 +359,152 @@ extern "C" int ugp_fitch_sankoff(int device, uint64_t n_nodes, const uint32_t *p
     FS_TRY(d_nchild.upload(n_children.data(), N));
     FS_TRY(d_inodes.upload(inodes.data(), inodes.size()));
 
-    // sites per pass: F takes N * W * 4 bytes; use up to half of the free HBM (UGP_FITCH_BYTES overrides)
+    // sites per pass: F takes N * W * 4 bytes.  Passes of up to 4 GiB (or half of the free HBM if that is
+    // less; UGP_FITCH_BYTES overrides): larger buffers only add allocation time, the kernels are
+    // already at full width with 512-site rows.
     size_t free_b = 0, total_b = 0;
     FS_TRY(hipMemGetInfo(&free_b, &total_b));
-    uint64_t budget = free_b / 2;
+    uint64_t budget = std::min<uint64_t>(free_b / 2, 4ull << 30);
     if (const char *e = getenv("UGP_FITCH_BYTES")) budget = strtoull(e, nullptr, 10);
     uint64_t W_max = std::max<uint64_t>(budget / ((uint64_t)N * 4), 1);
     if (W_max >= 64) W_max &= ~63ull;   // whole 512-site wave rows
     const uint64_t W_all = (S + 7) / 8;
     const uint32_t W_pass = (uint32_t)std::min<uint64_t>(W_max, W_all);
-    Dev<uint32_t> d_F, d_refw, d_vsite, d_vnode;
-    Dev<uint8_t> d_vnuc, d_oval, d_oval2;
-    Dev<uint64_t> d_okey, d_okey2;
-    Dev<unsigned long long> d_cnt;
-    Dev<uint8_t> d_tmp;
+    Dev<uint32_t> d_F, d_refw, d_vnode;
+    Dev<uint8_t> d_vnuc, d_oval, d_oval2, d_tmp;
+    Dev<uint64_t> d_okey, d_okey2, d_voff;
+    Dev<unsigned long long> d_cnt, d_segb;
     FS_TRY(d_F.alloc((size_t)N * W_pass));
     FS_TRY(d_refw.alloc(W_pass));
-    FS_TRY(d_cnt.alloc(2));
-    std::vector<uint32_t> refw(W_pass), vsite, vnode;
+    FS_TRY(d_cnt.alloc((size_t)FS_SEG * 8 + 8));
+    FS_TRY(d_segb.alloc(FS_SEG + 1));
+    std::vector<uint32_t> refw(W_pass), vnode;
     std::vector<uint8_t> vnuc;
-    std::vector<uint64_t> h_key;
+    std::vector<uint64_t> voff, h_key;
     std::vector<uint8_t> h_val;
+    std::vector<unsigned long long> h_cnt((size_t)FS_SEG * 8), h_segb(FS_SEG + 1);
+    std::vector<uint32_t> seen_site;   // (slow path) last site, 1-based, a node had a cell at -- and where
+    std::vector<uint64_t> seen_at;
+    t_alloc = lap();
 
     for (uint64_t w0 = 0; w0 < W_all; w0 += W_pass) {
         const uint32_t W = (uint32_t)std::min<uint64_t>(W_pass, W_all - w0);
         const uint64_t s0 = w0 * 8, s1 = std::min<uint64_t>(S, s0 + (uint64_t)W * 8);
+        const uint32_t n_s = (uint32_t)(s1 - s0);
         std::fill(refw.begin(), refw.end(), 0x11111111u);
         for (uint64_t s = s0; s < s1; s++) {
             const uint32_t sh = (uint32_t)((s - s0) & 7) * 4;
             uint32_t &x = refw[(s - s0) >> 3];
             x = (x & ~(0xFu << sh)) | ((uint32_t)sites->ref[s] << sh);
         }
-        // genotype cells of this pass; a node named twice at one site keeps the last cell (:47-62 runs in order)
-        vsite.clear(); vnode.clear(); vnuc.clear();
-        std::unordered_map<uint32_t, size_t> seen;
-        for (uint64_t s = s0; s < s1; s++) {
-            seen.clear();
-            for (uint64_t v = sites->var_off[s]; v < sites->var_off[s + 1]; v++) {
-                auto it = seen.find(sites->var_node[v]);
-                if (it != seen.end()) { vnuc[it->second] = sites->var_nuc[v]; continue; }
-                seen.emplace(sites->var_node[v], vsite.size());
-                vsite.push_back((uint32_t)(s - s0)); vnode.push_back(sites->var_node[v]); vnuc.push_back(sites->var_nuc[v]);
+        // Genotype cells of this pass.  A node named twice at one site keeps the last cell (:47-62 runs in
+        // order).  Cells whose node indices ascend within every site cannot repeat a node and are uploaded as
+        // they are; otherwise they are filtered through a last-seen table first.
+        const uint64_t v0 = sites->var_off[s0], v1 = sites->var_off[s1];
+        bool ascending = true;
+        for (uint64_t s = s0; s < s1 && ascending; s++)
+            for (uint64_t v = sites->var_off[s] + 1; v < sites->var_off[s + 1]; v++)
+                if (sites->var_node[v] <= sites->var_node[v - 1]) { ascending = false; break; }
+        const uint32_t *cell_node = sites->var_node + v0;
+        const uint8_t *cell_nuc = sites->var_nuc + v0;
+        uint64_t n_cells = v1 - v0;
+        voff.resize(n_s + 1);
+        if (ascending) {
+            for (uint32_t k = 0; k <= n_s; k++) voff[k] = sites->var_off[s0 + k] - v0;
+        } else {
+            if (seen_site.empty()) { seen_site.assign(N, 0); seen_at.assign(N, 0); }
+            vnode.clear(); vnuc.clear();
+            for (uint64_t s = s0; s < s1; s++) {
+                voff[s - s0] = vnode.size();
+                for (uint64_t v = sites->var_off[s]; v < sites->var_off[s + 1]; v++) {
+                    const uint32_t nd = sites->var_node[v];
+                    if (seen_site[nd] == (uint32_t)(s + 1)) { vnuc[seen_at[nd]] = sites->var_nuc[v]; continue; }
+                    seen_site[nd] = (uint32_t)(s + 1);
+                    seen_at[nd] = vnode.size();
+                    vnode.push_back(nd); vnuc.push_back(sites->var_nuc[v]);
+                }
             }
+            voff[n_s] = vnode.size();
+            cell_node = vnode.data(); cell_nuc = vnuc.data(); n_cells = vnode.size();
         }
         FS_TRY(hipMemcpy(d_refw.p, refw.data(), (size_t)W * 4, hipMemcpyHostToDevice));
-        FS_TRY(d_vsite.upload(vsite.data(), vsite.size()));
-        FS_TRY(d_vnode.upload(vnode.data(), vnode.size()));
-        FS_TRY(d_vnuc.upload(vnuc.data(), vnuc.size()));
-        FS_TRY(hipMemsetAsync(d_cnt.p, 0, 2 * sizeof(unsigned long long), stream));
+        FS_TRY(d_voff.upload(voff.data(), voff.size()));
+        FS_TRY(d_vnode.upload(cell_node, n_cells));
+        FS_TRY(d_vnuc.upload(cell_nuc, n_cells));
+        FS_TRY(hipMemsetAsync(d_cnt.p, 0, ((size_t)FS_SEG * 8 + 8) * sizeof(unsigned long long), stream));
+        // room for the listed changes: without cells on internal nodes a site has at most (cells + 1) of
+        // them, and usually far fewer; anything beyond the guess is handled by the exact pass below
+        unsigned long long seg_cap = (n_cells + n_s) / FS_SEG * 3 / 2 + 256;
+        if (const char *e = getenv("UGP_FITCH_EMIT_CAP")) seg_cap = strtoull(e, nullptr, 10);
+        FS_TRY(d_okey.alloc(seg_cap * FS_SEG));
+        FS_TRY(d_oval.alloc(seg_cap * FS_SEG));
+        t_prep += lap();
 
-        const uint64_t cells = (uint64_t)N * W;
-        hipLaunchKernelGGL(k_fs_init, dim3((unsigned)std::min<uint64_t>((cells + 255) / 256, 1u << 20)), dim3(256), 0, stream, d_F.p,
-                           d_refw.p, d_nchild.p, (uint64_t)N, W);
-        if (!vsite.empty())
-            hipLaunchKernelGGL(k_fs_scatter, dim3((unsigned)((vsite.size() + 255) / 256)), dim3(256), 0, stream, d_F.p, d_refw.p,
-                               d_nchild.p, d_vsite.p, d_vnode.p, d_vnuc.p, (uint64_t)vsite.size(), W);
-        const unsigned gy = (W + 63) / 64;
+        const uint32_t gy = (W + 63) / 64;
+        auto blocks = [&](uint64_t items, int per_wave) { return dim3((unsigned)((items + 4ull * per_wave - 1) / (4ull * per_wave))); };
+        hipLaunchKernelGGL(k_fs_init, blocks((uint64_t)N * gy, FS_NB), dim3(256), 0, stream, d_F.p, d_refw.p, d_nchild.p, N, W, gy);
+        if (n_cells)
+            hipLaunchKernelGGL(k_fs_scatter, dim3((unsigned)((n_cells + 255) / 256)), dim3(256), 0, stream, d_F.p, d_refw.p, d_nchild.p,
+                               d_voff.p, n_s, d_vnode.p, d_vnuc.p, n_cells, W);
         for (uint32_t L = n_levels; L-- > 0;) {
             const uint32_t cnt = ilvl_off[L + 1] - ilvl_off[L];
             if (cnt)
-                hipLaunchKernelGGL(k_fs_forward, dim3((cnt + 3) / 4, gy), dim3(256), 0, stream, d_F.p, d_inodes.p + ilvl_off[L], cnt,
-                                   d_first.p, d_nchild.p, W);
+                hipLaunchKernelGGL(k_fs_forward, blocks((uint64_t)cnt * gy, FS_FN), dim3(256), 0, stream, d_F.p, d_inodes.p + ilvl_off[L], cnt,
+                                   d_first.p, d_nchild.p, W, gy);
         }
         for (uint32_t L = 0; L < n_levels; L++) {
             const uint32_t cnt = lvl_off[L + 1] - lvl_off[L];
-            hipLaunchKernelGGL(k_fs_backward, dim3((cnt + 3) / 4, gy), dim3(256), 0, stream, d_F.p, d_refw.p, d_parent.p, lvl_off[L],
-                               lvl_off[L + 1], W, d_cnt.p);
+            hipLaunchKernelGGL(k_fs_backward, blocks((uint64_t)cnt * gy, FS_NB), dim3(256), 0, stream, d_F.p, d_refw.p, d_parent.p,
+                               d_nchild.p, lvl_off[L], lvl_off[L + 1], W, gy, (uint32_t)s0, d_cnt.p, seg_cap, d_okey.p, d_oval.p);
         }
         FS_TRY(hipGetLastError());
-        unsigned long long n_mut = 0;
-        FS_TRY(hipMemcpyAsync(&n_mut, d_cnt.p, sizeof(n_mut), hipMemcpyDeviceToHost, stream));
+        FS_TRY(hipMemcpyAsync(h_cnt.data(), d_cnt.p, h_cnt.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
         FS_TRY(hipStreamSynchronize(stream));
+        unsigned long long n_mut = 0;
+        bool overflow = false;
+        for (uint32_t g = 0; g < FS_SEG; g++) {
+            h_segb[g] = n_mut;
+            n_mut += h_cnt[(size_t)g * 8];
+            overflow = overflow || h_cnt[(size_t)g * 8] > seg_cap;
+        }
+        h_segb[FS_SEG] = n_mut;
+        t_kern += lap();
         if (n_mut == 0) continue;
-        FS_TRY(d_okey.alloc(n_mut));
         FS_TRY(d_okey2.alloc(n_mut));
-        FS_TRY(d_oval.alloc(n_mut));
         FS_TRY(d_oval2.alloc(n_mut));
-        hipLaunchKernelGGL(k_fs_emit, dim3((N + 3) / 4, gy), dim3(256), 0, stream, d_F.p, d_refw.p, d_parent.p, N, W, (uint32_t)s0,
-                           d_cnt.p + 1, d_okey.p, d_oval.p);
+        if (overflow) {   // the guess was too small for some segment: list again, exactly
+            hipLaunchKernelGGL(k_fs_emit, blocks((uint64_t)N * gy, 1), dim3(256), 0, stream, d_F.p, d_refw.p, d_parent.p, d_nchild.p, N, W,
+                               gy, (uint32_t)s0, d_cnt.p + (size_t)FS_SEG * 8, n_mut, d_okey2.p, d_oval2.p);
+        } else {
+            FS_TRY(hipMemcpyAsync(d_segb.p, h_segb.data(), h_segb.size() * sizeof(unsigned long long), hipMemcpyHostToDevice, stream));
+            hipLaunchKernelGGL(k_fs_compact, dim3(FS_SEG), dim3(256), 0, stream, d_okey.p, d_oval.p, d_segb.p, seg_cap, d_okey2.p, d_oval2.p);
+        }
         FS_TRY(hipGetLastError());
+        FS_TRY(d_okey.alloc(n_mut));
+        FS_TRY(d_oval.alloc(n_mut));
         // deterministic order: by site, then breadth-first node index
         size_t tmp_bytes = 0;
-        FS_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, d_okey.p, d_okey2.p, d_oval.p, d_oval2.p, (int64_t)n_mut, 0, 64, stream));
+        FS_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, d_okey2.p, d_okey.p, d_oval2.p, d_oval.p, (int64_t)n_mut, 0, 64, stream));
         FS_TRY(d_tmp.alloc(tmp_bytes));
-        FS_TRY(hipcub::DeviceRadixSort::SortPairs(d_tmp.p, tmp_bytes, d_okey.p, d_okey2.p, d_oval.p, d_oval2.p, (int64_t)n_mut, 0, 64, stream));
+        FS_TRY(hipcub::DeviceRadixSort::SortPairs(d_tmp.p, tmp_bytes, d_okey2.p, d_okey.p, d_oval2.p, d_oval.p, (int64_t)n_mut, 0, 64, stream));
         h_key.resize(n_mut);
         h_val.resize(n_mut);
-        FS_TRY(hipMemcpyAsync(h_key.data(), d_okey2.p, n_mut * sizeof(uint64_t), hipMemcpyDeviceToHost, stream));
-        FS_TRY(hipMemcpyAsync(h_val.data(), d_oval2.p, n_mut, hipMemcpyDeviceToHost, stream));
+        FS_TRY(hipMemcpyAsync(h_key.data(), d_okey.p, n_mut * sizeof(uint64_t), hipMemcpyDeviceToHost, stream));
+        FS_TRY(hipMemcpyAsync(h_val.data(), d_oval.p, n_mut, hipMemcpyDeviceToHost, stream));
         FS_TRY(hipStreamSynchronize(stream));
+        const size_t base = res->site.size();
+        res->site.resize(base + n_mut); res->node.resize(base + n_mut); res->par.resize(base + n_mut); res->nuc.resize(base + n_mut);
         for (unsigned long long i = 0; i < n_mut; i++) {
-            res->site.push_back((uint32_t)(h_key[i] >> 32));
-            res->node.push_back((uint32_t)h_key[i]);
-            res->par.push_back(h_val[i] >> 4);
-            res->nuc.push_back(h_val[i] & 0xF);
+            res->site[base + i] = (uint32_t)(h_key[i] >> 32);
+            res->node[base + i] = (uint32_t)h_key[i];
+            res->par[base + i] = h_val[i] >> 4;
+            res->nuc[base + i] = h_val[i] & 0xF;
         }
+        t_out += lap();
     }
+    if (getenv("UGP_FITCH_VERBOSE"))
+        fprintf(stderr, "[ugp_fitch] topology %.1f ms, alloc %.1f ms, per-pass prep %.1f ms, kernels %.1f ms, sort+download %.1f ms\n",
+                t_topo, t_alloc, t_prep, t_kern, t_out);
     guard.r = nullptr;
     *out = res;
     return UGP_OK;
