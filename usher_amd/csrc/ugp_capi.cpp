@@ -192,7 +192,7 @@ int run_place(ugp_mat *m, ugp_qset *qs, int mode, ugp_result *d_out, int32_t *d_
         const bool use8 = packed_ok;
         uint32_t G = pick_groups(m, n_tiles);
         if (use8) {   // work units of a few chunks each, pulled from per-XCD queues by persistent waves (see k_best8)
-            uint32_t unit_chunks = 4;
+            uint32_t unit_chunks = 2;
             if (const char *e = getenv("UGP_UNIT_CHUNKS")) unit_chunks = (uint32_t)std::max(1, atoi(e));
             G = std::max<uint32_t>(1, (f.n_chunks + unit_chunks - 1) / unit_chunks);
             // a small batch still has to fill the chip: at least ~4096 units in total
@@ -242,7 +242,10 @@ int run_place(ugp_mat *m, ugp_qset *qs, int mode, ugp_result *d_out, int32_t *d_
         if (use8) {
             HIP_TRY(hipMemsetAsync(m->d_nitems.p, 0, sizeof(uint32_t), s));
             HIP_TRY(hipMemsetAsync(m->d_queue.p, 0, 8 * sizeof(uint32_t), s));
-            HIP_TRY(hipMemsetAsync(m->d_ub.p, 0x7F, (size_t)n_tiles512 * 256 * sizeof(uint32_t), s));   // 0x7F7F: above every valid cost
+            if (sorted && !getenv("UGP_NO_SEED"))   // start from the coarse pass's best costs (real costs of real nodes)
+                HIP_TRY(ugp::launch_seed_ub(m->d_coarse_res.p + q0, order, (uint32_t)nq, n_tiles512, m->d_ub.p, s));
+            else
+                HIP_TRY(hipMemsetAsync(m->d_ub.p, 0x7F, (size_t)n_tiles512 * 256 * sizeof(uint32_t), s));   // 0x7F7F: above every valid cost
             HIP_TRY(hipMemsetAsync(m->d_cnt.p, 0, (size_t)n_tiles512 * 512 * sizeof(uint32_t), s));
             HIP_TRY(hipMemsetAsync(m->d_key.p, 0, (size_t)n_tiles512 * 512 * sizeof(uint32_t), s));
         }

@@ -356,6 +356,7 @@ __global__ void __launch_bounds__(64) k_best8(Best8Args a) {
     bool have_info = false;    // uniform
     uint32_t info = 0;         // uniform: pending pruning record
     uint32_t skip_to = 0;      // uniform: restart request (0 = none)
+    uint64_t n_skipped = 0;    // uniform (STATS): words jumped over
     Pk4 ub1;
 #pragma unroll
     for (int j = 0; j < 4; j++) ub1.v[j] = 0x80008000u;
@@ -473,7 +474,10 @@ __global__ void __launch_bounds__(64) k_best8(Best8Args a) {
                 const uint32_t t1 = pk_add(ub1.v[j], hs);
                 bad |= pk_min(dcur.v[j], t1) ^ t1;
             }
-            if (__builtin_amdgcn_ballot_w64(bad != 0) == 0) skip_to = pos + 1 + (info & 0x3FFFFFu);
+            if (__builtin_amdgcn_ballot_w64(bad != 0) == 0) {
+                skip_to = pos + 1 + (info & 0x3FFFFFu);
+                if (STATS) n_skipped += info & 0x3FFFFFu;
+            }
         }
     };
 
@@ -555,6 +559,7 @@ __global__ void __launch_bounds__(64) k_best8(Best8Args a) {
     if (STATS && lane == 0) {   // debug accounting, one update per unit
         const unsigned long long tw = __builtin_amdgcn_s_memtime() - t_wave0;
         unsigned long long *st = (unsigned long long *)a.stats;
+        atomicAdd(st + 0, (unsigned long long)n_skipped);
         atomicAdd(st + 1, (unsigned long long)n_restart);
         atomicAdd(st + 2, (unsigned long long)t_restart);
         atomicAdd(st + 3, tw);
@@ -672,7 +677,31 @@ __global__ void k_invert(const uint32_t *__restrict__ order, uint32_t n, uint32_
     if (s < n) slot_of[order[s]] = s;
 }
 
+// Seed the per-sample upper bounds of k_best8 with the samples' best cost in the coarse MAT.  The coarse
+// MAT is the top of the tree with every kept node's own mutations, so a node that is eligible there is
+// eligible in the full tree with the same cost (a kept node that is a leaf only in the coarse tree is
+// eligible there iff common > 0, which makes an internal node eligible too): the value is a real cost.
+__global__ void k_seed_ub(const ugp_result *__restrict__ coarse_res, const uint32_t *__restrict__ order, uint32_t n_queries,
+                          uint32_t n_words, uint32_t *__restrict__ ub) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;   // word (tile*64 + lane)*4 + jj holds samples jj and jj+4 of the lane
+    if (i >= n_words) return;
+    const uint32_t slot = (i >> 2) * 8 + (i & 3u);
+    auto val = [&](uint32_t q) -> uint32_t {
+        if (q >= n_queries) return 0x7F7Fu;
+        const int32_t b = coarse_res[order[q]].best_set_difference;
+        return b < 0 || b > 0x7F7F ? 0x7F7Fu : (uint32_t)b;
+    };
+    ub[i] = val(slot) | (val(slot + 4) << 16);
+}
+
 // ---------------------------------------------------------------- launchers
+
+hipError_t launch_seed_ub(const ugp_result *coarse_res, const uint32_t *order, uint32_t n_queries, uint32_t n_tiles512, uint32_t *ub,
+                          hipStream_t s) {
+    const uint32_t n_words = n_tiles512 * 256;
+    hipLaunchKernelGGL(k_seed_ub, dim3((n_words + 255) / 256), dim3(256), 0, s, coarse_res, order, n_queries, n_words, ub);
+    return hipGetLastError();
+}
 
 hipError_t launch_locality_sort(const ugp_result *coarse_res, const uint32_t *coarse2dfs, uint32_t n, uint32_t *keys,
                                 uint32_t *keys_sorted, uint32_t *idx, uint32_t *order, uint32_t *slot_of, void *temp,

@@ -57,6 +57,8 @@ hipError_t launch_scatter(uint32_t *table, uint32_t *dbottom, const int32_t *pos
                           const int32_t *pos2site, uint32_t max_pos, uint32_t n_sites, uint64_t n_ent, uint32_t q_base,
                           uint32_t *active, uint32_t active_words, const uint32_t *slot_of, hipStream_t s);
 // locality sort (see k_sort_keys); temp == nullptr: only *temp_bytes is filled
+hipError_t launch_seed_ub(const ugp_result *coarse_res, const uint32_t *order, uint32_t n_queries, uint32_t n_tiles512, uint32_t *ub,
+                          hipStream_t s);
 hipError_t launch_locality_sort(const ugp_result *coarse_res, const uint32_t *coarse2dfs, uint32_t n, uint32_t *keys,
                                 uint32_t *keys_sorted, uint32_t *idx, uint32_t *order, uint32_t *slot_of, void *temp,
                                 size_t *temp_bytes, hipStream_t s);
