@@ -767,7 +767,9 @@ hipError_t launch_best8(const Best8Args &a, uint32_t max_slots, hipStream_t s) {
         if (e != hipSuccess) return e;
         lds_of = lds;
     }
-    uint64_t blocks = (uint64_t)std::max(per_cu, 1) * std::max(n_cu, 1);
+    int waves_cu = std::max(per_cu, 1);
+    if (const char *e = getenv("UGP_WAVES_PER_CU")) waves_cu = std::max(1, std::min(waves_cu, atoi(e)));   // tuning
+    uint64_t blocks = (uint64_t)waves_cu * std::max(n_cu, 1);
     const uint64_t units = (uint64_t)a.n_tiles * a.n_groups;
     if (blocks > units) blocks = units;
     blocks = ((blocks + 7) / 8) * 8;
