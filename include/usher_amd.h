@@ -208,7 +208,9 @@ enum {
     UGP_FLAT_PRE8_STREAM = 11,  /* uint32 */
     UGP_FLAT_CHUNK8_BODY_OFF = 12, /* uint32 [n_chunks+1] */
     UGP_FLAT_CHUNK8_PRE_OFF = 13,  /* uint32 [n_chunks+1] */
-    UGP_FLAT_MAX_PATH_MUTS = 14 /* count only */
+    UGP_FLAT_MAX_PATH_MUTS = 14, /* count only */
+    UGP_FLAT_STREAM_T = 15,     /* uint32: tie stream walked by phase 2 (chunk bodies + pruning pseudo-records) */
+    UGP_FLAT_CHUNK_T_OFF = 16   /* uint32 [n_chunks+1] */
 };
 int ugp_flat_create(const ugp_tree_desc *tree, uint32_t chunk_nodes, ugp_flat **out);
 void ugp_flat_destroy(ugp_flat *flat);

@@ -245,12 +245,16 @@ def _ties_chunk(flat, nib, dbot, c, want):
     slots = {}
     cnt, key_best = 0, 0
     dcur = 0
+    info = None
     for words, lo, hi in ((flat.pre_stream, int(flat.chunk_pre_off[c]), int(flat.chunk_pre_off[c + 1])),
-                          (flat.stream, int(flat.chunk_body_off[c]), int(flat.chunk_body_off[c + 1]))):
+                          (flat.stream_t, int(flat.chunk_t_off[c]), int(flat.chunk_t_off[c + 1]))):
         i = lo
         while i < hi:
             w0 = int(words[i]); key = int(words[i + 1]); i += 2
             nmut = w0 & 0xFFFF
+            if nmut == 0xFFFF:          # pruning pseudo-record of the tie stream (walk_ties)
+                info = key
+                continue
             rslot, wslot = (w0 >> 16) & 63, (w0 >> 22) & 63
             dpar = dcur if rslot == RS_REG else (dbot if rslot == RS_BOTTOM else slots[rslot])
             tsum = neg = common = n_before = 0
@@ -280,4 +284,10 @@ def _ties_chunk(flat, nib, dbot, c, want):
                 if elig and cost == want:
                     cnt += 1
                     key_best = max(key_best, key | hu)
+            if info is not None:
+                hs, jump = info >> 24, info & 0xFFFFFF
+                info = None
+                if not dn <= want + hs:     # D - hsub > want: no descendant can tie
+                    i += jump
+                    assert i <= hi
     return want, cnt, key_best

@@ -76,7 +76,7 @@ struct ugp_mat {
     ugp::FlatMat flat;   // host copy of the small tables (pos2site, site_ref); streams are dropped after upload
     uint64_t stream_dwords = 0, pre_dwords = 0;
     DevBuf<uint32_t> d_stream, d_pre, d_chunk_body, d_chunk_pre, d_chunk_node, d_rank2bfs, d_dfs2bfs;
-    DevBuf<uint32_t> d_stream8, d_pre8, d_chunk8_body, d_chunk8_pre;
+    DevBuf<uint32_t> d_stream8, d_pre8, d_chunk8_body, d_chunk8_pre, d_stream_t, d_chunk_t;
     uint64_t stream8_dwords = 0;
     DevBuf<int32_t> d_pos2site;
     DevBuf<uint8_t> d_site_ref;
@@ -259,6 +259,7 @@ int run_place(ugp_mat *m, ugp_qset *qs, int mode, ugp_result *d_out, int32_t *d_
         memset(&a, 0, sizeof(a));
         a.stream = m->d_stream.p; a.pre_stream = m->d_pre.p;
         a.chunk_body_off = m->d_chunk_body.p; a.chunk_pre_off = m->d_chunk_pre.p; a.chunk_node_off = m->d_chunk_node.p;
+        a.stream_t = m->d_stream_t.p; a.chunk_t_off = m->d_chunk_t.p;
         a.table = m->d_table.p; a.dbottom = m->d_dbottom.p;
         a.n_sites = n_sites; a.n_chunks = f.n_chunks; a.n_groups = G; a.n_tiles = n_tiles; a.n_queries = (uint32_t)nq;
         a.part_best = m->d_part_best.p; a.part_cnt = m->d_part_cnt.p; a.part_key = m->d_part_key.p;
@@ -395,6 +396,9 @@ static int mat_create_impl(const ugp_tree_desc *tree, int device, const ugp::Opt
     if ((e = m->d_pre8.upload(f.pre8_stream)) != hipSuccess) return bail(e, "upload packed preambles");
     if ((e = m->d_chunk8_body.upload(f.chunk8_body_off)) != hipSuccess) return bail(e, "upload chunk table");
     if ((e = m->d_chunk8_pre.upload(f.chunk8_pre_off)) != hipSuccess) return bail(e, "upload chunk table");
+    if ((e = m->d_stream_t.upload(f.stream_t)) != hipSuccess) return bail(e, "upload tie stream");
+    if ((e = m->d_chunk_t.upload(f.chunk_t_off)) != hipSuccess) return bail(e, "upload chunk table");
+    std::vector<uint32_t>().swap(f.stream_t);
     m->stream8_dwords = f.stream8.size();
     std::vector<uint32_t>().swap(f.stream8);
     std::vector<uint32_t>().swap(f.pre8_stream);
@@ -673,6 +677,8 @@ int ugp_flat_get(const ugp_flat *fl, int which, const void **ptr, uint64_t *coun
         case UGP_FLAT_PRE8_STREAM: *ptr = f.pre8_stream.data(); *count = f.pre8_stream.size(); break;
         case UGP_FLAT_CHUNK8_BODY_OFF: *ptr = f.chunk8_body_off.data(); *count = f.chunk8_body_off.size(); break;
         case UGP_FLAT_CHUNK8_PRE_OFF: *ptr = f.chunk8_pre_off.data(); *count = f.chunk8_pre_off.size(); break;
+        case UGP_FLAT_STREAM_T: *ptr = f.stream_t.data(); *count = f.stream_t.size(); break;
+        case UGP_FLAT_CHUNK_T_OFF: *ptr = f.chunk_t_off.data(); *count = f.chunk_t_off.size(); break;
         case UGP_FLAT_MAX_PATH_MUTS: *ptr = nullptr; *count = f.max_path_muts; break;
         default: return fail(UGP_ERR_INVALID, "unknown array id");
     }

@@ -156,7 +156,7 @@ int flatten(const ugp_tree_desc &t, const Options &opt, FlatMat &out, std::strin
             cur[site] = (uint8_t)mi;
             nwords++;
         }
-        if (nwords > MAX_NODE_MUTS) { err = "node with more than 65535 mutations"; return UGP_ERR_UNSUPPORTED; }
+        if (nwords > MAX_NODE_MUTS) { err = "node with more than 65534 mutations"; return UGP_ERR_UNSUPPORTED; }
         if (masked && !root) node_masked[j] = 1;
         if (masked && !root) w0 |= F_MASKED;   // root: masked mutations are inert (usher_mapper.cpp:266-269, 309-311, 401-403)
         w0 |= nwords | (rslot << 16) | (wslot << 22);
@@ -326,6 +326,44 @@ int flatten(const ugp_tree_desc &t, const Options &opt, FlatMat &out, std::strin
     }
     out.chunk8_body_off.push_back((uint32_t)out.stream8.size());
     out.chunk8_pre_off.push_back((uint32_t)out.pre8_stream.size());
+
+    // ---- tie stream (phase 2 walks it one chunk at a time)
+    {
+        out.stream_t.clear(); out.chunk_t_off.clear();
+        out.stream_t.reserve(out.stream.size());
+        std::vector<uint32_t> subd(N, 0);   // dwords of the kept records of j's descendants
+        for (uint64_t j = N; j-- > 1;)
+            subd[t.parent[j]] += subd[j] + (dropped[j] ? 0u : 2u + (out.stream[rec_off[j]] & 0xFFFFu));
+        struct Open { uint32_t info_pos, own_end, dfs_end; };
+        std::vector<Open> open;
+        auto close = [&](uint32_t next_dfs) {
+            while (!open.empty() && open.back().dfs_end <= next_dfs) {
+                const Open &b = open.back();
+                const uint64_t jump = out.stream_t.size() - b.own_end;
+                out.stream_t[b.info_pos + 1] = (out.stream_t[b.info_pos + 1] & 0xFF000000u) | (uint32_t)std::min<uint64_t>(jump, 0xFFFFFFu);
+                open.pop_back();
+            }
+        };
+        for (uint32_t c = 0; c < out.n_chunks; c++) {
+            out.chunk_t_off.push_back((uint32_t)out.stream_t.size());
+            for (uint32_t d = out.chunk_node_off[c]; d < out.chunk_node_off[c + 1]; d++) {
+                const uint32_t j = out.dfs2bfs[d];
+                close(d);
+                if (dropped[j]) continue;
+                const uint32_t off = rec_off[j];
+                const uint32_t nwords = out.stream[off] & 0xFFFFu;
+                if (j != 0 && subd[j] >= T_PRUNE_MIN_DWORDS && hsub[j] <= 255) {
+                    open.push_back({(uint32_t)out.stream_t.size(), 0u, d + sub[j]});
+                    out.stream_t.push_back(T_INFO_MARK);
+                    out.stream_t.push_back(hsub[j] << 24);
+                    open.back().own_end = (uint32_t)out.stream_t.size() + 2u + nwords;
+                }
+                for (uint32_t k = 0; k < 2u + nwords; k++) out.stream_t.push_back(out.stream[off + k]);
+            }
+            close(UINT32_MAX);   // a jump never leaves its chunk
+        }
+        out.chunk_t_off.push_back((uint32_t)out.stream_t.size());
+    }
 
     // Renumber the packed stream's slots by access frequency, hottest first: the
     // kernel keeps the first few in LDS and the cold remainder in a global scratch

@@ -32,6 +32,9 @@ constexpr uint32_t F_LEAF = 1u << 28, F_NOSCORE = 1u << 29, F_ROOT = 1u << 30, F
 constexpr uint32_t M_AFTER_MASK = 1u << 31;
 constexpr uint32_t MAX_SLOTS = 40;        // > log2(2^32) + 1
 
+constexpr uint32_t T_INFO_MARK = 0xFFFFu;   // tie stream: mutation-count field of a pruning pseudo-record
+constexpr uint32_t T_PRUNE_MIN_DWORDS = 24;  // subtrees shorter than this are not worth a record
+
 // ---- packed stream ("stream8") walked by k_best8: 8 samples per lane -------
 //
 // One 32-bit word per event.  Leaves without mutation words never influence a
@@ -63,7 +66,7 @@ constexpr uint32_t H_TAG = 1u << 31, H_SKIPD = 1u << 12, H_NOSCORE = 1u << 13, H
 constexpr uint32_t PRUNE_MIN_WORDS = 8;     // only subtrees at least this long carry a pruning record
 constexpr uint32_t M_FLUSH = 1u << 28, M_END = 1u << 30;
 constexpr uint32_t MAX_SITES = 1u << 22;
-constexpr uint32_t MAX_NODE_MUTS = 65535;
+constexpr uint32_t MAX_NODE_MUTS = 65534;   // 0xFFFF marks a pruning pseudo-record of the tie stream
 
 struct Options {
     uint32_t chunk_nodes = 0;   // 0 = automatic (about N/4096, at least 256)
@@ -85,6 +88,11 @@ struct FlatMat {
     // packed stream for k_best8 (same chunk cut points, by DFS node index)
     std::vector<uint32_t> stream8, pre8_stream;
     std::vector<uint32_t> chunk8_body_off, chunk8_pre_off;   // [n_chunks+1]
+    // Tie stream (phase 2): the chunk bodies of `stream` without the leaves that can never be eligible and
+    // with pruning pseudo-records {w0 = T_INFO_MARK, w1 = hsub << 24 | jump}: the node that follows may be
+    // skipped together with its descendants (`jump` dwords behind its own record, inside the chunk)
+    // when D(node) - hsub exceeds the wanted score of every sample that still looks for ties here.
+    std::vector<uint32_t> stream_t, chunk_t_off;             // chunk_t_off: [n_chunks+1]
     uint32_t max_path_muts = 0;            // max over nodes of the mutation count on the root path
 };
 

@@ -128,6 +128,88 @@ struct Reader {
 
 struct WalkOut { uint32_t best, cnt, key; };
 
+// Phase-2 walk of one chunk of the tie stream: count / key of the eligible nodes whose cost equals the
+// lane's wanted score.  Only lanes with `relevant` set look for ties in this chunk (the chunk minimum of
+// phase 1 equals their global minimum); a subtree is jumped over when D(node) - hsub > want for all of
+// them, since cost(d) >= D(node) - hsub for every descendant d.
+__device__ __forceinline__ WalkOut walk_ties(const PlaceArgs &a, uint32_t *slots, uint32_t tile, uint32_t c, uint32_t lane,
+                                             uint32_t want, bool relevant) {
+    const uint32_t *tab = a.table + (uint64_t)(tile >> 3) * a.n_sites * 64 + (tile & 7u) * 8 + (lane >> 3);
+    const uint32_t sh = (lane & 7u) * 4u;
+    const uint32_t dbot = a.dbottom[tile * 64 + lane];
+    WalkOut o; o.best = 0; o.cnt = 0; o.key = 0;
+    uint32_t dcur = 0;
+    for (int phase = 0; phase < 2; phase++) {
+        const uint32_t *p = phase == 0 ? a.pre_stream : a.stream_t;
+        uint32_t pos = phase == 0 ? a.chunk_pre_off[c] : a.chunk_t_off[c];          // uniform
+        const uint32_t end = phase == 0 ? a.chunk_pre_off[c + 1] : a.chunk_t_off[c + 1];
+        uint32_t base = pos;
+        uint32_t buf = (base + lane < end) ? p[base + lane] : 0u;
+        auto next = [&]() -> uint32_t {
+            if (pos - base >= 64u) { base = pos; buf = (base + lane < end) ? p[base + lane] : 0u; }
+            const uint32_t w = rdlane(buf, pos - base);
+            pos++;
+            return w;
+        };
+        bool have_info = false;
+        uint32_t info = 0;
+        while (pos < end) {
+            const uint32_t w0 = next();
+            const uint32_t key = next();
+            const uint32_t nmut = w0 & 0xFFFFu;
+            if (nmut == T_INFO_MARK) { have_info = true; info = key; continue; }
+            const uint32_t rslot = (w0 >> 16) & 63u, wslot = (w0 >> 22) & 63u;
+            uint32_t dpar;
+            if (rslot == RS_REG) dpar = dcur;
+            else if (rslot == RS_BOTTOM) dpar = dbot;
+            else dpar = slots[rslot * 64 + lane];
+            int tsum = 0, neg = 0;
+            uint32_t common = 0, n_before = 0;
+            for (uint32_t m = 0; m < nmut; m++) {
+                const uint32_t w = next();
+                const uint32_t site = w & 0x3FFFFFu, mi = (w >> 22) & 3u, pi = (w >> 24) & 3u;
+                const uint32_t x = tab[(uint64_t)site * 64];
+                const uint32_t nib = (x >> sh) & 15u;
+                const int cc = (int)((nib >> mi) & 1u), pp = (int)((nib >> pi) & 1u);
+                const int d = pp - cc;
+                tsum += d;
+                if (!(w & M_AFTER_MASK)) {
+                    n_before++;
+                    common += (uint32_t)cc;
+                    neg += min(d, 0);
+                }
+            }
+            const uint32_t dn = dpar + (uint32_t)tsum;
+            if (wslot != WS_NONE) slots[wslot * 64 + lane] = dn;
+            dcur = dn;
+            if (!(w0 & F_NOSCORE)) {
+                uint32_t cost, hu;
+                bool elig;
+                if (w0 & F_ROOT) {
+                    cost = dn; elig = true; hu = 0;
+                } else {
+                    cost = dpar + (uint32_t)neg;
+                    const bool masked = (w0 & F_MASKED) != 0;
+                    const bool free_internal = !(w0 & F_LEAF) && !masked && nmut == 0;
+                    elig = (common > 0) || free_internal;
+                    hu = (masked || common != n_before) ? 1u : 0u;
+                }
+                if (relevant && elig && cost == want) { o.cnt++; o.key = max(o.key, key | hu); }
+            }
+            if (have_info) {
+                have_info = false;
+                const uint32_t hs = info >> 24;
+                const bool near = relevant && dn <= want + hs;   // D - hsub <= want: a descendant may still tie
+                if (__builtin_amdgcn_ballot_w64(near) == 0) {
+                    pos += info & 0xFFFFFFu;
+                    if (pos - base >= 64u && pos < end) { base = pos; buf = (base + lane < end) ? p[base + lane] : 0u; }
+                }
+            }
+        }
+    }
+    return o;
+}
+
 // MODE 0: full reduction (min, count, key)   MODE 1: per-node scores
 // MODE 2: append tied nodes to lists         MODE 3: count / key of nodes with cost == want
 template <int MODE>
@@ -629,7 +711,7 @@ __global__ void k_select(const uint32_t *__restrict__ lbest, const uint32_t *__r
 // Phase 2: re-walk only the selected (chunk, 64-sample tile) pairs, one sample
 // per lane, counting the nodes that attain the sample's global minimum and
 // keeping the reference's winner among them (usher_mapper.cpp:476-497).
-__global__ void __launch_bounds__(64) k_ties(PlaceArgs a, const uint32_t *__restrict__ gbest,
+__global__ void __launch_bounds__(64) k_ties(PlaceArgs a, const uint32_t *__restrict__ lbest, const uint32_t *__restrict__ gbest,
                                              const uint32_t *__restrict__ items, const uint32_t *__restrict__ n_items,
                                              uint32_t cap, uint32_t n_t64 /* 8 * n_tiles512, as k_select encodes */,
                                              uint32_t *__restrict__ cnt_out, uint32_t *__restrict__ key_out) {
@@ -641,7 +723,8 @@ __global__ void __launch_bounds__(64) k_ties(PlaceArgs a, const uint32_t *__rest
         const uint32_t c = item / n_t64, t64 = item % n_t64;
         const uint32_t q = t64 * 64 + lane;
         const uint32_t want = (q < a.n_queries) ? pk_lookup(gbest, q >> 9, q & 511u) : 0xFFFFFFFFu;
-        WalkOut r = walk<3>(a, slots, t64, c, c + 1, lane, want);
+        const bool relevant = q < a.n_queries && pk_lookup(lbest + (uint64_t)c * (n_t64 / 8u) * 256u, q >> 9, q & 511u) == want;
+        WalkOut r = walk_ties(a, slots, t64, c, lane, want, relevant);
         if (r.cnt) {
             atomicAdd(&cnt_out[q], r.cnt);
             atomicMax(&key_out[q], r.key);
@@ -793,7 +876,7 @@ hipError_t launch_phase2(const PlaceArgs &a, const uint32_t *lbest, uint32_t *gb
     const size_t lds = (size_t)max_slots * 64 * sizeof(uint32_t);
     uint32_t blocks = 256 * 32;   // latency-bound walk: as many waves as a CU holds (3.3 KB of LDS each)
     if ((uint64_t)blocks > pairs) blocks = (uint32_t)pairs;
-    hipLaunchKernelGGL(k_ties, dim3(blocks), dim3(64), lds, s, a, gbest, items, n_items, cap, n_tiles512 * 8, cnt, key);
+    hipLaunchKernelGGL(k_ties, dim3(blocks), dim3(64), lds, s, a, lbest, gbest, items, n_items, cap, n_tiles512 * 8, cnt, key);
     hipLaunchKernelGGL(k_final, dim3((a.n_queries + 255) / 256), dim3(256), 0, s, gbest, cnt, key, rank2bfs, a.n_queries, out, order);
     return hipGetLastError();
 }

@@ -11,6 +11,7 @@ namespace ugp {
 struct PlaceArgs {
     const uint32_t *stream, *pre_stream;
     const uint32_t *chunk_body_off, *chunk_pre_off, *chunk_node_off;
+    const uint32_t *stream_t, *chunk_t_off;   // tie stream (phase 2)
     const uint32_t *table;     // [ceil(n_tiles/8)][n_sites][64]  (512-sample tile layout)
     const uint32_t *dbottom;   // [ceil(n_tiles/8)*512]
     uint32_t n_sites, n_chunks, n_groups, n_tiles, n_queries;
