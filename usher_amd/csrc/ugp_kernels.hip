@@ -602,12 +602,13 @@ __global__ void __launch_bounds__(64) k_best8(Best8Args a) {
                 ub1.v[j] = pk_add(__hip_atomic_load(ubp + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), 0x00010001u);
         }
         uint32_t off = 0;
+        bool cautious = false;   // uniform: the last run was cut short by a jump inside its first group
         while (off < n) {
             // (re)fill the pipeline at `off`
             const uint64_t t_r0 = STATS ? __builtin_amdgcn_s_memtime() : 0;
             uint32_t w0 = load_words(off), w1 = load_words(off + GRP), w2 = load_words(off + 2 * GRP);
             uint32_t m0 = active_mask(w0, load_bits(w0));
-            uint32_t m1 = active_mask(w1, load_bits(w1));
+            uint32_t m1 = 0;
             uint32_t X[GRP];
 #pragma unroll
             for (int k = 0; k < (int)GRP; k++) {
@@ -616,6 +617,34 @@ __global__ void __launch_bounds__(64) k_best8(Best8Args a) {
             }
             skip_to = 0;
             if (STATS) { t_restart += __builtin_amdgcn_s_memtime() - t_r0 + (X[0] & 0u); n_restart++; }
+            bool first = true;   // uniform: still inside the first group of this run
+            if (cautious) {
+                // Sparse regime (runs of a few words between jumps): evaluate the first group before
+                // anything is requested for the second one, so a jump does not leave eight dead row loads
+                // ahead of the next refill in the in-order return queue.
+#pragma unroll
+                for (int k = 0; k < (int)GRP; k++) {
+                    const uint32_t w = rdlane(w0, k);
+                    const uint32_t ref_row = 0x11111111u << ((w >> 26) & 3u);
+                    if (!skip_to) step(w, ((m0 >> k) & 1u) ? X[k] : ref_row, off + k);
+                }
+                if (!skip_to) {   // the run goes on: bring the pipeline to its steady state one group further
+                    m1 = active_mask(w1, load_bits(w1));
+#pragma unroll
+                    for (int k = 0; k < (int)GRP; k++) {
+                        const uint32_t wn = rdlane(w1, k);
+                        X[k] = __builtin_amdgcn_raw_buffer_load_b32(trsrc, lane4, (((m1 >> k) & 1u) ? (wn & 0x3FFFFFu) : 0u) << 8, 0);
+                    }
+                    m0 = m1;
+                    w0 = w1; w1 = w2; w2 = load_words(off + 3 * GRP);
+                    m1 = active_mask(w1, load_bits(w1));
+                    off += GRP;
+                    first = false;
+                }
+            } else {
+                m1 = active_mask(w1, load_bits(w1));
+            }
+            if (!skip_to)
             for (; off < n; off += GRP) {
                 const uint32_t w3 = load_words(off + 3 * GRP);
                 const uint32_t b2 = load_bits(w2);
@@ -631,8 +660,10 @@ __global__ void __launch_bounds__(64) k_best8(Best8Args a) {
                 m0 = m1;
                 m1 = active_mask(w2, b2);
                 w0 = w1; w1 = w2; w2 = w3;
+                first = false;
             }
             if (!skip_to) break;   // walked to the end of the range
+            cautious = first;
             // restart request: close every chunk whose end marker lies before the new position
             while (chunk < c1 && skip_to > a.chunk8_body_off[chunk + 1] - 1u - begin) chunk_end();
             off = skip_to;
