@@ -119,3 +119,64 @@ def make_case(seed: int, n_leaves: int, n_queries: int, genome_len: int = 2000, 
     arrays, ref, sites, state = random_tree(rng, n_leaves, genome_len, n_sites, **kw)
     queries = [random_query(rng, arrays, ref, sites, state, genome_len, name="Q%d" % i, **qkw) for i in range(n_queries)]
     return arrays, queries
+
+
+def caterpillar_case(seed: int, depth: int, muts_per_node: int, n_queries: int, genome_len: int = 29000, n_sites: int = 3000):
+    """A maximally deep tree: a chain of `depth` internal nodes, each with one leaf child and the next
+    chain node (BFS order: chain node 2k-1, leaf 2k at level k).  Root paths carry depth*muts_per_node
+    mutations, so D values, the hsub bound and the 16-bit packed counters are all pushed to their limits."""
+    rng = np.random.default_rng(seed)
+    ref = rng.choice(ONEHOT, size=genome_len + 1)
+    sites = np.sort(rng.choice(np.arange(1, genome_len + 1), size=n_sites, replace=False))
+    n = 2 * depth + 1
+    parent = np.full(n, -1, dtype=np.int64)
+    for k in range(1, depth + 1):
+        parent[2 * k - 1] = 0 if k == 1 else 2 * k - 3
+        parent[2 * k] = 0 if k == 1 else 2 * k - 3
+    chain = {}                       # running genotype of the chain
+    chain_muts = []                  # per level: list of (pos, new_allele)
+    recs = [[] for _ in range(n)]
+    for k in range(1, depth + 1):
+        c, l = 2 * k - 1, 2 * k
+        # the leaf hangs off chain node k-1: its mutations see the state before level k's chain mutations
+        for p in np.sort(rng.choice(sites, size=1, replace=False)):
+            p = int(p)
+            cur = chain.get(p, int(ref[p]))
+            recs[l].append((p, int(ref[p]), cur, int(rng.choice([a for a in ONEHOT if a != cur]))))
+        lvl = []
+        for p in np.sort(rng.choice(sites, size=muts_per_node, replace=False)):
+            p = int(p)
+            cur = chain.get(p, int(ref[p]))
+            a = int(rng.choice([x for x in ONEHOT if x != cur]))
+            recs[c].append((p, int(ref[p]), cur, a))
+            chain[p] = a
+            lvl.append((p, a))
+        chain_muts.append(lvl)
+    mut_off = np.zeros(n + 1, dtype=np.int64)
+    pos, rf, par, nuc = [], [], [], []
+    for j in range(n):
+        for (p, r, pa, m) in recs[j]:
+            pos.append(p); rf.append(r); par.append(pa); nuc.append(m)
+        mut_off[j + 1] = len(pos)
+    arrays = {"n": n, "parent": parent, "mut_off": mut_off, "mut_pos": np.asarray(pos, dtype=np.int32),
+              "mut_ref": np.asarray(rf, dtype=np.int8), "mut_par": np.asarray(par, dtype=np.int8),
+              "mut_nuc": np.asarray(nuc, dtype=np.int8), "names": ["n%d" % j for j in range(n)]}
+    queries = []
+    for i in range(n_queries):
+        k = int(rng.integers(1, depth + 1))
+        geno = {}
+        for lvl in chain_muts[:k]:
+            for p, a in lvl:
+                geno[p] = a
+        for _ in range(int(rng.integers(0, 3))):
+            p = int(rng.choice(sites))
+            geno[p] = int(rng.choice([x for x in ONEHOT if x != geno.get(p, int(ref[p]))]))
+        rows = {p: (a, 0) for p, a in geno.items() if a != int(ref[p])}
+        for _ in range(int(rng.integers(0, 4))):
+            rows[int(rng.choice(sites))] = (15, 1)
+        ps = sorted(rows)
+        queries.append({"name": "Q%d" % i, "pos": np.asarray(ps, dtype=np.int32),
+                        "ref": np.asarray([int(ref[p]) for p in ps], dtype=np.int8),
+                        "nuc": np.asarray([rows[p][0] for p in ps], dtype=np.int8),
+                        "is_missing": np.asarray([rows[p][1] for p in ps], dtype=np.int8)})
+    return arrays, queries

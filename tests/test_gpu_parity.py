@@ -283,3 +283,34 @@ def test_sub_batching_and_tiny_batches():
     got = res.view(np.int32).reshape(-1, 4).astype(np.int64)
     assert (got == np.tile(w, (reps, 1))).all()
     pl.close()
+
+
+def test_deep_caterpillar_tree_packed_and_fallback_paths():
+    """Maximally deep trees.  (a) 700 levels x 2 mutations: root paths of 1,400 mutations -- D in the
+    thousands, hsub beyond its 8-bit field near the top (no pruning record there), deep preambles; still
+    inside the 16-bit packed path.  (b) 400 levels x 85 mutations: 34,000 mutations on a root path exceed
+    what the packed counters can hold, so the library must take the 32-bit kernel.  Checked against the
+    closed-form restatement (the literal oracle is quadratic in the path length) and, for (a), two samples
+    against the literal oracle as well."""
+    from oracle.closed_form import ClosedFormTree
+    arrays, queries = synth.caterpillar_case(11, depth=700, muts_per_node=2, n_queries=70)
+    cf = ClosedFormTree(arrays)
+    for chunk_nodes in (None, 37):
+        pl = Placer(arrays, chunk_nodes=chunk_nodes)
+        res = pl.place(QueryBatch(queries))
+        assert pl.timing()["packed_path"] == 1
+        for i, s in enumerate(queries):
+            _assert_same(res, i, cf.place(s), "caterpillar #%d" % i)
+        pl.close()
+    ot = capi.OracleTree(arrays)
+    for i in (0, 1):
+        _assert_same(res, i, ot.place(queries[i], want_ties=False), "caterpillar literal #%d" % i)
+
+    arrays, queries = synth.caterpillar_case(12, depth=400, muts_per_node=85, n_queries=12)
+    cf = ClosedFormTree(arrays)
+    pl = Placer(arrays, chunk_nodes=50)
+    res = pl.place(QueryBatch(queries))
+    assert pl.timing()["packed_path"] == 0          # 16-bit counters would overflow: 32-bit kernel
+    for i, s in enumerate(queries):
+        _assert_same(res, i, cf.place(s), "very deep #%d" % i)
+    pl.close()
