@@ -212,11 +212,14 @@ def _evolve_vcf(rng, n_leaves, n_sites, n_new, path_tree, path_old, path_new):
     write(path_new, ["NEW%d" % k for k in range(n_new)], new_g, new_codes)
 
 
-@pytest.mark.parametrize("seed,n_leaves,n_new", [(1, 60, 80), (2, 150, 120), (3, 30, 200)])
-def test_batched_add_mode_equals_per_sample_research(tmp_path, monkeypatch, seed, n_leaves, n_new):
-    """Add-mode places the remaining samples in batches and reuses an answer only while it is provably
-    unchanged by the insertions made since; with USHER_AMD_MAX_TOUCHED=0 every sample is searched again on
-    the updated tree, which is the reference's loop (usher_common.cpp:310-449).  Both must write the same files."""
+@pytest.mark.parametrize("seed,n_leaves,n_new,max_touched", [(1, 60, 80, None), (2, 150, 120, None), (3, 30, 200, None),
+                                                             (4, 80, 400, None), (5, 10, 150, "12"), (6, 200, 250, "40")])
+def test_batched_add_mode_equals_per_sample_research(tmp_path, monkeypatch, seed, n_leaves, n_new, max_touched):
+    """Add-mode places the remaining samples in batches on the tree as it was and re-derives each answer on
+    the tree as it is now: untouched optimal nodes keep their cost, nodes created or rewritten since are
+    evaluated on the host, and the winner is chosen with today's leaf counts and breadth-first order.  With
+    USHER_AMD_MAX_TOUCHED=0 every sample is searched again on the updated tree, which is the reference's
+    loop (usher_common.cpp:310-449).  Both must write the same files."""
     import numpy as np
     from tests.host_harness import OracleBackend
     rng = np.random.default_rng(seed)
@@ -225,7 +228,7 @@ def test_batched_add_mode_equals_per_sample_research(tmp_path, monkeypatch, seed
     pb = str(tmp_path / "base.pb")
     assert run_usher(["-t", nh, "-v", old, "-o", pb, "-d", str(tmp_path)]) == 0
     outs, calls = {}, {}
-    for mode, env in (("research", "0"), ("batched", None)):
+    for mode, env in (("research", "0"), ("batched", max_touched)):
         if env is None:
             monkeypatch.delenv("USHER_AMD_MAX_TOUCHED", raising=False)
         else:

@@ -10,7 +10,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <numeric>
+#include <climits>
 #include <unordered_map>
+#include <unordered_set>
 
 namespace uh {
 
@@ -34,9 +36,11 @@ struct FlatTree {
     std::vector<int32_t> pos;
     std::vector<uint8_t> ref, par, nuc;
     ugp_tree_desc desc{};
+    std::unordered_map<const Node *, uint32_t> idx;   // node -> breadth-first index at build time
+    std::vector<uint32_t> leaves;                     // leaves below each node at build time (Tree::get_num_leaves)
     void build(const Tree &T) {
         bfs = T.bfs();
-        std::unordered_map<const Node *, uint32_t> idx;
+        idx.clear();
         idx.reserve(bfs.size() * 2);
         for (uint32_t j = 0; j < bfs.size(); j++) idx[bfs[j]] = j;
         parent.assign(bfs.size(), UINT32_MAX);
@@ -50,10 +54,29 @@ struct FlatTree {
             }
             mut_off[j + 1] = pos.size();
         }
+        leaves.assign(bfs.size(), 0);
+        for (uint32_t j = (uint32_t)bfs.size(); j-- > 0;) {
+            if (bfs[j]->is_leaf()) leaves[j] = 1;
+            if (j) leaves[parent[j]] += leaves[j];
+        }
         desc.n_nodes = bfs.size(); desc.parent = parent.data(); desc.mut_off = mut_off.data();
         desc.mut_pos = pos.data(); desc.mut_ref = ref.data(); desc.mut_par = par.data(); desc.mut_nuc = nuc.data();
     }
 };
+
+// Does `a` come before `b` in the breadth-first expansion of the tree as it is now
+// (mutation_annotated_tree.cpp:1225-1251)?  Levels first; within a level the order of the parents, then
+// the position among the parent's children.
+bool bfs_before(const Node *a, const Node *b) {
+    if (a == b) return false;
+    if (a->level != b->level) return a->level < b->level;
+    while (a->parent != b->parent) { a = a->parent; b = b->parent; }
+    for (const Node *c : a->parent->children) {
+        if (c == a) return true;
+        if (c == b) return false;
+    }
+    return false;
+}
 
 struct FlatQueries {
     std::vector<uint64_t> ent_off{0};
@@ -322,20 +345,36 @@ int run_usher(const Options &opt, Tree &T, std::vector<MissingSample> &missing, 
         };
 
         // Add-mode: the reference re-searches the whole tree for every sample because the previous
-        // insertion changed it (usher_common.cpp:342).  Here all remaining samples are placed in one
-        // batch on the tree as it is; a batched answer stays exact after later insertions as long as
-        // (a) it had a unique optimum (tie-breaks read n_leaves / BFS order, which insertions change),
-        // (b) its node was not rewritten, and (c) no node created or rewritten since then scores as
-        // well or better for this sample (every other node keeps its cost and eligibility: the
-        // mutations on its root path are unchanged).  Otherwise the tree is flattened and placed again.
+        // insertion changed it (usher_common.cpp:342).  Here the next samples are placed in one batch on the
+        // tree as it is (`flat`), together with their tie lists, and each answer is re-derived on the tree as
+        // it has become: an insertion leaves the root-path mutation set of every other node unchanged, so
+        // only the nodes created or rewritten since (`touched`) can have a different cost, eligibility or
+        // has_unique; they are evaluated on the host with the literal per-node routine and merged with the
+        // untouched part of the batched tie set, and the winner is picked with the current leaf counts and
+        // breadth-first order.  The tree is flattened and placed again only when `touched` grows past
+        // max_touched, when a tie list was too long to keep, or when every batched optimum was rewritten
+        // and no touched node is at least as good.
         std::vector<ugp_result> spec_res;
         size_t spec_base = 0, spec_len = 0, spec_next = 64;   // batch length adapts to how long answers survive
         bool have_spec = false;
         uint64_t flat_version = tree_version;
         std::vector<Node *> touched;
+        std::unordered_set<const Node *> touched_set;
+        std::unordered_map<const Node *, size_t> added_leaves;   // leaves gained below a node since `flat` was built
+        std::vector<std::vector<std::pair<uint32_t, uint8_t>>> spec_ties;   // per batched sample with 1 < num_best <= kTieCap
+        const uint32_t kTieCap = 256;
         size_t max_touched = 192;
         if (const char *e = getenv("USHER_AMD_MAX_TOUCHED")) max_touched = (size_t)atoll(e);
         NodeVecs probe;
+        auto leaves_now = [&](const Node *n) -> size_t {
+            size_t v = 0;
+            auto it = flat.idx.find(n);
+            if (it != flat.idx.end()) v = flat.leaves[it->second];
+            auto a = added_leaves.find(n);
+            return a == added_leaves.end() ? v : v + a->second;
+        };
+        struct Tie { Node *n; bool hu; };
+        std::vector<Tie> tie_now;   // the tie set of the current sample on the tree as it is now (when it had to be rebuilt)
         FILE *stats = fopen((outdir + "/placement_stats.tsv").c_str(), "w");
         if (!stats) { fprintf(stderr, "ERROR: cannot write to %s\n", outdir.c_str()); return 1; }
         FILE *scores_file = nullptr;
@@ -353,18 +392,58 @@ int run_usher(const Options &opt, Tree &T, std::vector<MissingSample> &missing, 
                 if (scores_file) fprintf(scores_file, "#Sample\tTree node\tParsimony score\tOptimal (y/n)\tParsimony-increasing mutations (for optimal nodes)\n");
             }
             ugp_result r;
+            bool patched = false, patched_hu = false;
+            int patched_best = 0;
+            Node *patched_node = nullptr;
             if (static_tree) r = batch_res[s];
             else {
                 bool redo = !have_spec || ii >= spec_base + spec_len || touched.size() > max_touched;
+                tie_now.clear();
+                patched = false;
                 if (!redo) {
                     r = spec_res[ii - spec_base];
                     if (!touched.empty()) {
-                        Node *bn = flat.bfs[r.best_j];
-                        if (r.num_best > 1) redo = true;
-                        for (size_t k = 0; k < touched.size() && !redo; k++) {
-                            if (touched[k] == bn) { redo = true; break; }
-                            node_vecs(touched[k], ms.mutations, probe);
-                            if (probe.eligible && probe.set_difference <= r.best_set_difference) redo = true;
+                        // Rebuild the answer on the current tree from the batched one: the nodes that were
+                        // optimal then and have not been touched keep their cost; touched and new nodes are
+                        // evaluated here; the winner follows the reference's rule (more leaves, then the later
+                        // breadth-first index, usher_mapper.cpp:476-497) with today's leaf counts and order.
+                        const auto &bt = spec_ties[ii - spec_base];
+                        if (r.num_best > 1 && bt.empty()) redo = true;   // tie list not kept (too long)
+                        int base_best = r.best_set_difference;
+                        if (!redo) {
+                            if (r.num_best == 1) {
+                                Node *bn = flat.bfs[r.best_j];
+                                if (!touched_set.count(bn)) tie_now.push_back({bn, r.best_has_unique != 0});
+                            } else {
+                                for (const auto &e : bt)
+                                    if (!touched_set.count(flat.bfs[e.first])) tie_now.push_back({flat.bfs[e.first], e.second != 0});
+                            }
+                            int m_best = INT32_MAX;
+                            std::vector<Tie> m_ties;
+                            for (Node *tn : touched) {
+                                node_vecs(tn, ms.mutations, probe);
+                                if (!probe.eligible) continue;
+                                if (probe.set_difference < m_best) { m_best = probe.set_difference; m_ties.clear(); }
+                                if (probe.set_difference == m_best) m_ties.push_back({tn, probe.has_unique});
+                            }
+                            if (tie_now.empty()) {
+                                // every node that was optimal has been rewritten: the untouched nodes are only known
+                                // to cost more than base_best, which decides the matter only if a touched node does not
+                                if (m_best <= base_best) tie_now = m_ties; else redo = true;
+                            } else if (m_best < base_best) tie_now = m_ties;
+                            else if (m_best == base_best) tie_now.insert(tie_now.end(), m_ties.begin(), m_ties.end());
+                            if (!redo) {
+                                const Tie *w = &tie_now[0];
+                                size_t w_leaves = leaves_now(w->n);
+                                for (size_t k = 1; k < tie_now.size(); k++) {
+                                    const size_t l = leaves_now(tie_now[k].n);
+                                    if (l > w_leaves || (l == w_leaves && bfs_before(w->n, tie_now[k].n))) { w = &tie_now[k]; w_leaves = l; }
+                                }
+                                patched = true;
+                                patched_best = std::min(base_best, m_best);
+                                patched_node = w->n;
+                                patched_hu = w->hu;
+                            }
                         }
                     }
                 }
@@ -378,16 +457,36 @@ int run_usher(const Options &opt, Tree &T, std::vector<MissingSample> &missing, 
                     rest.finish();
                     spec_res.assign(spec_len, ugp_result{});
                     if (be.place(be.ctx, &flat.desc, flat_version, &rest.desc, spec_res.data()) != 0) { fclose(stats); return be_fail("placement"); }
+                    // tie lists of the batch (needed to re-derive a tied answer after later insertions)
+                    spec_ties.assign(spec_len, {});
+                    if (!opt.no_add && be.ties) {
+                        FlatQueries tq;
+                        std::vector<size_t> who;
+                        for (size_t k = 1; k < spec_len; k++)   // (sample 0 is consumed right away, on the fresh tree)
+                            if (spec_res[k].num_best > 1 && spec_res[k].num_best <= kTieCap) { who.push_back(k); tq.add(missing[indexes[ii + k]].mutations); }
+                        if (!who.empty()) {
+                            tq.finish();
+                            std::vector<uint32_t> tj(who.size() * (size_t)kTieCap), tc(who.size());
+                            std::vector<uint8_t> th(who.size() * (size_t)kTieCap);
+                            if (be.ties(be.ctx, &flat.desc, flat_version, &tq.desc, kTieCap, tj.data(), th.data(), tc.data()) != 0) { fclose(stats); return be_fail("tie listing"); }
+                            for (size_t w = 0; w < who.size(); w++) {
+                                if (tc[w] != spec_res[who[w]].num_best) continue;   // (cannot happen; without a full list the sample is searched again)
+                                for (uint32_t k = 0; k < tc[w]; k++) spec_ties[who[w]].push_back({tj[w * kTieCap + k], th[w * kTieCap + k]});
+                            }
+                        }
+                    }
                     spec_base = ii;
                     have_spec = true;
                     touched.clear();
+                    touched_set.clear();
+                    added_leaves.clear();
                     r = spec_res[0];
                 }
             }
-            const int best = r.best_set_difference;
-            const size_t num_best = r.num_best;
-            Node *best_node = flat.bfs[r.best_j];
-            const bool best_has_unique = r.best_has_unique != 0;
+            const int best = patched ? patched_best : r.best_set_difference;
+            const size_t num_best = patched ? tie_now.size() : r.num_best;
+            Node *best_node = patched ? patched_node : flat.bfs[r.best_j];
+            const bool best_has_unique = patched ? patched_hu : r.best_has_unique != 0;
 
             if (!opt.print_scores) {                                            // :451-469
                 fprintf(stderr, "Current tree size (#nodes): %zu\tSample name: %s\tParsimony score: %d\tNumber of parsimony-optimal placements: %zu\n", total_nodes, ms.name.c_str(), best, num_best);
@@ -427,18 +526,20 @@ int run_usher(const Options &opt, Tree &T, std::vector<MissingSample> &missing, 
                     std::vector<uint32_t> tj(cap), tc(1);
                     std::vector<uint8_t> th(cap);
                     size_t nt = 1;
-                    if (num_best > 1) {   // (a batched answer with ties is never reused, so `flat` is current here)
+                    std::vector<Tie> tl;
+                    if (patched) tl = tie_now;   // rebuilt on the current tree above
+                    else if (num_best > 1) {      // `flat` is current here
                         if (be.ties(be.ctx, &flat.desc, static_tree ? tree_version : flat_version, &q1.desc, cap, tj.data(), th.data(), tc.data()) != 0) { fclose(stats); return be_fail("tie listing"); }
                         nt = std::min<size_t>(tc[0], cap);
-                    } else {
-                        tj[0] = r.best_j; th[0] = (uint8_t)best_has_unique;
-                    }
+                        for (size_t k = 0; k < nt; k++) tl.push_back({flat.bfs[tj[k]], th[k] != 0});
+                    } else tl.push_back({best_node, best_has_unique});
+                    nt = tl.size();
                     ms.clade_assignments.assign(n_ann, {});
                     ms.best_clade_assignment.assign(n_ann, "");
                     for (size_t c = 0; c < n_ann; c++) {
                         for (size_t k = 0; k < nt; k++) {
-                            Node *nd = flat.bfs[tj[k]];
-                            const bool include_self = !nd->is_leaf() && !th[k];
+                            Node *nd = tl[k].n;
+                            const bool include_self = !nd->is_leaf() && !tl[k].hu;
                             std::string ca = T.clade_assignment(nd, c, include_self);
                             if (nd == best_node) ms.best_clade_assignment[c] = ca;
                             ms.clade_assignments[c].push_back(std::move(ca));
@@ -448,8 +549,24 @@ int run_usher(const Options &opt, Tree &T, std::vector<MissingSample> &missing, 
                 }
                 node_vecs(best_node, ms.mutations, vec);                        // pass 2 for the winner, :426-449
                 if (!opt.no_add) {
+                    const size_t t0 = touched.size();
+                    const size_t best_leaves = leaves_now(best_node);
                     insert_sample(T, best_node, best_node->is_leaf() || best_has_unique, ms.name, vec.excess, touched);
                     tree_version++;
+                    if (!static_tree) {   // bookkeeping for re-deriving later batched answers on the changed tree
+                        Node *leaf = nullptr;
+                        size_t keep = t0;   // `touched` lists every node once
+                        for (size_t k = t0; k < touched.size(); k++) {
+                            if (touched[k]->is_leaf() && touched[k] != best_node) leaf = touched[k];
+                            if (touched_set.insert(touched[k]).second) touched[keep++] = touched[k];
+                        }
+                        touched.resize(keep);
+                        if (leaf) {
+                            if (leaf->parent != best_node) added_leaves[leaf->parent] = best_leaves;   // the new internal node starts with best_node's leaves
+                            added_leaves[leaf] = 1;
+                            for (const Node *a = leaf->parent; a; a = a->parent) added_leaves[a] += 1;
+                        }
+                    }
                 }
                 if (!vec.imputed.empty()) {                                     // :767-781
                     fprintf(stderr, "Imputed mutations:\t");
