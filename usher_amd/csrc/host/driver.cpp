@@ -10,7 +10,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <numeric>
+#include <chrono>
 #include <climits>
+#include <cmath>
 #include <unordered_map>
 #include <unordered_set>
 
@@ -363,8 +365,12 @@ int run_usher(const Options &opt, Tree &T, std::vector<MissingSample> &missing, 
         std::unordered_map<const Node *, size_t> added_leaves;   // leaves gained below a node since `flat` was built
         std::vector<std::vector<std::pair<uint32_t, uint8_t>>> spec_ties;   // per batched sample with 1 < num_best <= kTieCap
         const uint32_t kTieCap = 256;
-        size_t max_touched = 192;
-        if (const char *e = getenv("USHER_AMD_MAX_TOUCHED")) max_touched = (size_t)atoll(e);
+        // |touched| at which the tree is flattened again.  Re-deriving an answer costs ~10 us per touched node,
+        // a flatten + batch placement costs t_redo and is amortised over ~|touched|/3 insertions, so the
+        // total is least near sqrt(3 t_redo / 10 us): ~20 for a 1k-node tree, ~900 for a 10M-node one.
+        size_t max_touched = 64;
+        const bool fixed_cap = getenv("USHER_AMD_MAX_TOUCHED") != nullptr;
+        if (fixed_cap) max_touched = (size_t)atoll(getenv("USHER_AMD_MAX_TOUCHED"));
         NodeVecs probe;
         auto leaves_now = [&](const Node *n) -> size_t {
             size_t v = 0;
@@ -397,10 +403,56 @@ int run_usher(const Options &opt, Tree &T, std::vector<MissingSample> &missing, 
             Node *patched_node = nullptr;
             if (static_tree) r = batch_res[s];
             else {
-                bool redo = !have_spec || ii >= spec_base + spec_len || touched.size() > max_touched;
-                tie_now.clear();
-                patched = false;
-                if (!redo) {
+                // need_flat: flatten the current tree again; need_batch: place the next batch of samples (on the
+                // tree as flattened last -- not necessarily the current one)
+                bool need_flat = !have_spec || touched.size() > max_touched;
+                bool need_batch = need_flat || ii >= spec_base + spec_len;
+                for (int attempt = 0; attempt < 2; attempt++) {
+                    if (need_batch) {
+                        const auto t_redo0 = std::chrono::steady_clock::now();
+                        if (need_flat) {
+                            flat.build(T);
+                            flat_version = tree_version;
+                            touched.clear();
+                            touched_set.clear();
+                            added_leaves.clear();
+                        }
+                        if (have_spec) spec_next = (attempt == 0 && ii >= spec_base + spec_len) ? std::min<size_t>(2 * spec_len, 4096)   // consumed whole: grow
+                                                                                                  : std::max<size_t>(spec_len / 2, 16);      // cut short: shrink
+                        spec_len = std::min(spec_next, indexes.size() - ii);
+                        FlatQueries rest;
+                        for (size_t k = ii; k < ii + spec_len; k++) rest.add(missing[indexes[k]].mutations);
+                        rest.finish();
+                        spec_res.assign(spec_len, ugp_result{});
+                        if (be.place(be.ctx, &flat.desc, flat_version, &rest.desc, spec_res.data()) != 0) { fclose(stats); return be_fail("placement"); }
+                        // tie lists of the batch (needed to re-derive a tied answer after later insertions)
+                        spec_ties.assign(spec_len, {});
+                        if (!opt.no_add && be.ties) {
+                            FlatQueries tq;
+                            std::vector<size_t> who;
+                            for (size_t k = touched.empty() ? 1 : 0; k < spec_len; k++)   // (on a fresh tree sample 0 is consumed as it is)
+                                if (spec_res[k].num_best > 1 && spec_res[k].num_best <= kTieCap) { who.push_back(k); tq.add(missing[indexes[ii + k]].mutations); }
+                            if (!who.empty()) {
+                                tq.finish();
+                                std::vector<uint32_t> tj(who.size() * (size_t)kTieCap), tc(who.size());
+                                std::vector<uint8_t> th(who.size() * (size_t)kTieCap);
+                                if (be.ties(be.ctx, &flat.desc, flat_version, &tq.desc, kTieCap, tj.data(), th.data(), tc.data()) != 0) { fclose(stats); return be_fail("tie listing"); }
+                                for (size_t w = 0; w < who.size(); w++) {
+                                    if (tc[w] != spec_res[who[w]].num_best) continue;   // (cannot happen; without a full list the sample is searched again)
+                                    for (uint32_t k = 0; k < tc[w]; k++) spec_ties[who[w]].push_back({tj[w * kTieCap + k], th[w * kTieCap + k]});
+                                }
+                            }
+                        }
+                        if (!fixed_cap && need_flat) {
+                            const double t_redo = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_redo0).count();
+                            max_touched = (size_t)std::min(4096.0, std::max(16.0, std::sqrt(3.0 * t_redo / 1e-5)));
+                        }
+                        spec_base = ii;
+                        have_spec = true;
+                    }
+                    bool redo = false;
+                    tie_now.clear();
+                    patched = false;
                     r = spec_res[ii - spec_base];
                     if (!touched.empty()) {
                         // Rebuild the answer on the current tree from the batched one: the nodes that were
@@ -446,41 +498,8 @@ int run_usher(const Options &opt, Tree &T, std::vector<MissingSample> &missing, 
                             }
                         }
                     }
-                }
-                if (redo) {
-                    flat.build(T);
-                    flat_version = tree_version;
-                    if (have_spec) spec_next = std::max<size_t>(2 * (ii - spec_base), 1);
-                    spec_len = std::min(spec_next, indexes.size() - ii);
-                    FlatQueries rest;
-                    for (size_t k = ii; k < ii + spec_len; k++) rest.add(missing[indexes[k]].mutations);
-                    rest.finish();
-                    spec_res.assign(spec_len, ugp_result{});
-                    if (be.place(be.ctx, &flat.desc, flat_version, &rest.desc, spec_res.data()) != 0) { fclose(stats); return be_fail("placement"); }
-                    // tie lists of the batch (needed to re-derive a tied answer after later insertions)
-                    spec_ties.assign(spec_len, {});
-                    if (!opt.no_add && be.ties) {
-                        FlatQueries tq;
-                        std::vector<size_t> who;
-                        for (size_t k = 1; k < spec_len; k++)   // (sample 0 is consumed right away, on the fresh tree)
-                            if (spec_res[k].num_best > 1 && spec_res[k].num_best <= kTieCap) { who.push_back(k); tq.add(missing[indexes[ii + k]].mutations); }
-                        if (!who.empty()) {
-                            tq.finish();
-                            std::vector<uint32_t> tj(who.size() * (size_t)kTieCap), tc(who.size());
-                            std::vector<uint8_t> th(who.size() * (size_t)kTieCap);
-                            if (be.ties(be.ctx, &flat.desc, flat_version, &tq.desc, kTieCap, tj.data(), th.data(), tc.data()) != 0) { fclose(stats); return be_fail("tie listing"); }
-                            for (size_t w = 0; w < who.size(); w++) {
-                                if (tc[w] != spec_res[who[w]].num_best) continue;   // (cannot happen; without a full list the sample is searched again)
-                                for (uint32_t k = 0; k < tc[w]; k++) spec_ties[who[w]].push_back({tj[w * kTieCap + k], th[w * kTieCap + k]});
-                            }
-                        }
-                    }
-                    spec_base = ii;
-                    have_spec = true;
-                    touched.clear();
-                    touched_set.clear();
-                    added_leaves.clear();
-                    r = spec_res[0];
+                    if (!redo) break;
+                    need_flat = need_batch = true;   // this answer cannot be re-derived: search the current tree
                 }
             }
             const int best = patched ? patched_best : r.best_set_difference;
