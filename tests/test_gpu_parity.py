@@ -314,3 +314,31 @@ def test_deep_caterpillar_tree_packed_and_fallback_paths():
     for i, s in enumerate(queries):
         _assert_same(res, i, cf.place(s), "very deep #%d" % i)
     pl.close()
+
+
+def test_usher_cli_add_mode_batched_equals_research_on_gpu(tmp_path):
+    """bin/usher-amd, default (sequential add) mode on a 3,000-node tree built by the GPU Fitch-Sankoff path:
+    the batched scheme (answers re-derived on the changing tree) and a full search per
+    sample (USHER_AMD_MAX_TOUCHED=0, the reference's loop) must write identical files."""
+    import subprocess
+    import numpy as np
+    from tests.test_host_cli import _evolve_vcf
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "usher_amd", "bin", "usher-amd")
+    nh, old, new = str(tmp_path / "t.nh"), str(tmp_path / "old.vcf"), str(tmp_path / "new.vcf")
+    _evolve_vcf(np.random.default_rng(21), 1500, 200, 350, nh, old, new)
+    pb = str(tmp_path / "base.pb")
+    r = subprocess.run([exe, "-t", nh, "-v", old, "-o", pb, "-d", str(tmp_path)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    outs = {}
+    for mode, env in (("research", {"USHER_AMD_MAX_TOUCHED": "0"}), ("batched", {})):
+        d = tmp_path / mode
+        d.mkdir()
+        e = dict(os.environ)
+        e.pop("USHER_AMD_MAX_TOUCHED", None)
+        e.update(env)
+        r = subprocess.run([exe, "-i", pb, "-v", new, "-u", "-d", str(d)], capture_output=True, text=True, timeout=900, env=e)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs[mode] = {n: open(str(d / n)).read() for n in ("placement_stats.tsv", "mutation-paths.txt", "uncondensed-final-tree.nh")}
+    assert outs["batched"] == outs["research"]
+    assert sum(1 for l in outs["batched"]["placement_stats.tsv"].splitlines() if l.split("\t")[2] != "1") > 20   # ties were exercised
