@@ -82,7 +82,7 @@ struct ugp_mat {
     DevBuf<uint8_t> d_site_ref;
     // per-call workspaces (grown on demand)
     DevBuf<uint32_t> d_table, d_dbottom, d_part_best, d_part_cnt, d_part_key;
-    DevBuf<uint32_t> d_lbest, d_gbest, d_gbest_part, d_items, d_nitems, d_cnt, d_key, d_active, d_ub, d_queue;
+    DevBuf<uint32_t> d_lbest, d_gbest, d_gbest_part, d_items, d_nitems, d_cnt, d_key, d_active, d_ub, d_queue, d_gstart, d_hlen;
     DevBuf<uint64_t> d_stats;
     uint64_t last_words_total = 0;
     // locality sort (speed only): a coarse MAT of the top of the tree and the map coarse BFS index -> DFS rank in the full tree
@@ -192,7 +192,7 @@ int run_place(ugp_mat *m, ugp_qset *qs, int mode, ugp_result *d_out, int32_t *d_
         const bool use8 = packed_ok;
         uint32_t G = pick_groups(m, n_tiles);
         if (use8) {   // work units of a few chunks each, pulled from per-XCD queues by persistent waves (see k_best8)
-            uint32_t unit_chunks = 2;
+            uint32_t unit_chunks = 4;
             if (const char *e = getenv("UGP_UNIT_CHUNKS")) unit_chunks = (uint32_t)std::max(1, atoi(e));
             G = std::max<uint32_t>(1, (f.n_chunks + unit_chunks - 1) / unit_chunks);
             // a small batch still has to fill the chip: at least ~4096 units in total
@@ -280,6 +280,15 @@ int run_place(ugp_mat *m, ugp_qset *qs, int mode, ugp_result *d_out, int32_t *d_
             b.lbest = m->d_lbest.p;
             b.queue = m->d_queue.p;
             b.ub = getenv("UGP_NO_PRUNE") ? nullptr : m->d_ub.p;
+            if (sorted && !getenv("UGP_NO_LPT")) {   // hand out every tile's own region first (scheduling only)
+                HIP_TRY(m->d_gstart.reserve(n_tiles512)); HIP_TRY(m->d_hlen.reserve(n_tiles512));
+                HIP_TRY(ugp::launch_tile_ranges(m->d_keys2.p, (uint32_t)nq, n_tiles512, m->d_chunk_node.p, f.n_chunks,
+                                                std::max<uint32_t>(1, (f.n_chunks + G - 1) / G), m->d_gstart.p, m->d_hlen.p, s));
+                b.tile_hstart = m->d_gstart.p; b.tile_hlen = m->d_hlen.p;
+            }
+            b.unit_chunks = std::max<uint32_t>(1, (f.n_chunks + G - 1) / G);
+            b.heavy_chunks = 4;
+            if (const char *e = getenv("UGP_HEAVY_CHUNKS")) b.heavy_chunks = (uint32_t)std::max(1, atoi(e));
             HIP_TRY(m->d_stats.reserve(32));
             if (q0 == 0) { HIP_TRY(hipMemsetAsync(m->d_stats.p, 0, 32 * sizeof(uint64_t), s)); m->last_words_total = 0; }
             b.stats = getenv("UGP_STATS") ? m->d_stats.p : nullptr;   // the counters are two contended atomics per skip: debug only

@@ -394,26 +394,52 @@ __global__ void __launch_bounds__(64) k_best8(Best8Args a) {
     const uint32_t home = blockIdx.x & 7u;
     uint32_t drained = 0;   // bit x: queue x is known to be empty
     for (;;) {
-    uint32_t tile = 0, g = 0;
+    uint32_t tile = 0, c0 = 0, c1 = 0;   // the unit: chunks [c0, c1) of the stream for one tile
     {
+        // Units of a tile.  Its own region H = [h0, h0 + hl) (the chunks its samples sit in, from the
+        // locality sort; hl = 0 without it) cannot be pruned and is dense work: a.heavy_chunks chunks per unit, and
+        // the queue hands out every tile's H first (longest first).  The rest of the ring, A = [h0 + hl,
+        // n_chunks) and B = [0, h0), is mostly jumped over: a.unit_chunks chunks per unit, which amortises
+        // the preamble replay.
+        const uint32_t U = a.unit_chunks;
         bool got = false;
         for (uint32_t t = 0; t < 8 && !got; t++) {
             const uint32_t x = (home + t) & 7u;
             if (drained & (1u << x)) continue;
             const uint32_t tlo = x * a.n_tiles / 8u, thi = (x + 1u) * a.n_tiles / 8u;
-            const uint32_t ux = (thi - tlo) * a.n_groups;
+            const uint32_t HU = a.heavy_chunks;
+            uint32_t heavy = 0, light = 0;
+            for (uint32_t tt = tlo; tt < thi; tt++) {
+                const uint32_t h0 = a.tile_hstart ? a.tile_hstart[tt] : 0u, hl = a.tile_hstart ? a.tile_hlen[tt] : 0u;
+                heavy += (hl + HU - 1u) / HU;
+                light += (a.n_chunks - h0 - hl + U - 1u) / U + (h0 + U - 1u) / U;
+            }
+            const uint32_t ux = heavy + light;
             uint32_t v = 0xFFFFFFFFu;
             if (ux) {
                 if (lane == 0) v = atomicAdd(&a.queue[x], 1u);
                 v = (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
             }
-            if (v < ux) { tile = tlo + v / a.n_groups; g = v % a.n_groups; got = true; }
-            else drained |= 1u << x;
+            if (v >= ux) { drained |= 1u << x; continue; }
+            got = true;
+            if (v < heavy) {
+                uint32_t tt = tlo, r = v;
+                while (r >= (a.tile_hlen[tt] + HU - 1u) / HU) { r -= (a.tile_hlen[tt] + HU - 1u) / HU; tt++; }
+                tile = tt; c0 = a.tile_hstart[tt] + r * HU; c1 = min(c0 + HU, a.tile_hstart[tt] + a.tile_hlen[tt]);
+            } else {
+                uint32_t tt = tlo, r = v - heavy;
+                for (;; tt++) {
+                    const uint32_t h0 = a.tile_hstart ? a.tile_hstart[tt] : 0u, hl = a.tile_hstart ? a.tile_hlen[tt] : 0u;
+                    const uint32_t nA = (a.n_chunks - h0 - hl + U - 1u) / U, nB = (h0 + U - 1u) / U;
+                    if (r < nA) { c0 = h0 + hl + r * U; c1 = min(c0 + U, a.n_chunks); break; }
+                    if (r < nA + nB) { c0 = (r - nA) * U; c1 = min(c0 + U, h0); break; }
+                    r -= nA + nB;
+                }
+                tile = tt;
+            }
         }
         if (!got) return;
     }
-    const uint32_t c0 = (uint32_t)(((uint64_t)g * a.n_chunks) / a.n_groups);
-    const uint32_t c1 = (uint32_t)(((uint64_t)(g + 1) * a.n_chunks) / a.n_groups);
     if (c0 >= c1) continue;
     // table rows through a buffer resource: address = tile base + 4*lane (VGPR) + 256*site (SGPR soffset)
     const __amdgpu_buffer_rsrc_t trsrc = __builtin_amdgcn_make_buffer_rsrc(
@@ -808,7 +834,38 @@ __global__ void k_seed_ub(const ugp_result *__restrict__ coarse_res, const uint3
     ub[i] = val(slot) | (val(slot + 4) << 16);
 }
 
+// Where in the chunk order do a tile's own samples sit?  keys_sorted[q] = DFS rank of the coarse best node of
+// the q-th sample in tile order; the region runs from the first sample's chunk to a few chunks past the
+// last one's (the coarse node's own subtree).  Scheduling hint only.
+__global__ void k_tile_ranges(const uint32_t *__restrict__ keys_sorted, uint32_t n_queries, uint32_t n_tiles,
+                              const uint32_t *__restrict__ chunk_node_off, uint32_t n_chunks, uint32_t align,
+                              uint32_t *__restrict__ hstart, uint32_t *__restrict__ hlen) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_tiles) return;
+    const uint32_t q0 = t * 512u, q1 = min(n_queries, q0 + 512u) - 1u;
+    if (q0 >= n_queries) { hstart[t] = 0; hlen[t] = 0; return; }
+    auto chunk_of = [&](uint32_t d) {   // last c with chunk_node_off[c] <= d
+        uint32_t lo = 0, hi = n_chunks;
+        while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (chunk_node_off[mid] <= d) lo = mid; else hi = mid; }
+        return lo;
+    };
+    const uint32_t c_first = chunk_of(keys_sorted[q0]);
+    const uint32_t c_last = min(n_chunks - 1u, chunk_of(keys_sorted[q1]) + 3u);
+    // snapped to the unit grid, so the units of all tiles cover the same chunk ranges
+    const uint32_t h0 = c_first / align * align;
+    const uint32_t h1 = min(n_chunks, (c_last / align + 1u) * align);
+    hstart[t] = h0;
+    hlen[t] = h1 - h0;
+}
+
 // ---------------------------------------------------------------- launchers
+
+hipError_t launch_tile_ranges(const uint32_t *keys_sorted, uint32_t n_queries, uint32_t n_tiles512, const uint32_t *chunk_node_off,
+                              uint32_t n_chunks, uint32_t align, uint32_t *hstart, uint32_t *hlen, hipStream_t s) {
+    hipLaunchKernelGGL(k_tile_ranges, dim3((n_tiles512 + 63) / 64), dim3(64), 0, s, keys_sorted, n_queries, n_tiles512, chunk_node_off,
+                       n_chunks, align, hstart, hlen);
+    return hipGetLastError();
+}
 
 hipError_t launch_seed_ub(const ugp_result *coarse_res, const uint32_t *order, uint32_t n_queries, uint32_t n_tiles512, uint32_t *ub,
                           hipStream_t s) {

@@ -39,6 +39,9 @@ struct Best8Args {
     uint32_t active_words;
     uint32_t *lbest;           // [n_chunks][n_tiles][64][4] packed u16 pairs
     uint32_t *queue;           // [8] work-queue heads, one per XCD, zeroed before the launch
+    const uint32_t *tile_hstart, *tile_hlen;   // [n_tiles] or null: per tile, the first chunk of the region its own samples
+                                               // sit in and that region's length in chunks (scheduled first)
+    uint32_t unit_chunks, heavy_chunks;        // chunks per unit outside / inside that region
     uint64_t *stats;           // optional: [0] += stream words skipped by pruning (debug / bench)
     uint32_t *ub;              // [n_tiles][64][4] packed upper bounds of best(s) shared by the waves of a tile; nullptr = no pruning
 };
@@ -58,6 +61,8 @@ hipError_t launch_scatter(uint32_t *table, uint32_t *dbottom, const int32_t *pos
                           const int32_t *pos2site, uint32_t max_pos, uint32_t n_sites, uint64_t n_ent, uint32_t q_base,
                           uint32_t *active, uint32_t active_words, const uint32_t *slot_of, hipStream_t s);
 // locality sort (see k_sort_keys); temp == nullptr: only *temp_bytes is filled
+hipError_t launch_tile_ranges(const uint32_t *keys_sorted, uint32_t n_queries, uint32_t n_tiles512, const uint32_t *chunk_node_off,
+                              uint32_t n_chunks, uint32_t align, uint32_t *hstart, uint32_t *hlen, hipStream_t s);
 hipError_t launch_seed_ub(const ugp_result *coarse_res, const uint32_t *order, uint32_t n_queries, uint32_t n_tiles512, uint32_t *ub,
                           hipStream_t s);
 hipError_t launch_locality_sort(const ugp_result *coarse_res, const uint32_t *coarse2dfs, uint32_t n, uint32_t *keys,
