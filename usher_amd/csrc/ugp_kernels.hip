@@ -468,9 +468,13 @@ __global__ void __launch_bounds__(64) k_best8(Best8Args a) {
     Pk4 ub1;
 #pragma unroll
     for (int j = 0; j < 4; j++) ub1.v[j] = 0x80008000u;
-    uint32_t *ubp = a.ub ? a.ub + ((uint64_t)tile * 64 + lane) * 4 : nullptr;
+    // (the tests below use the kernel argument, not the per-lane pointer: a condition derived from `lane`
+    // is formally divergent, and one such flag turned the whole walk's control flow -- jump target, open
+    // header, position -- into vector registers with exec-mask branches)
+    const bool can_prune = a.ub != nullptr;   // uniform
+    uint32_t *ubp = a.ub + ((uint64_t)tile * 64 + lane) * 4;
     auto exchange_ub = [&]() {   // ub = min(ub, what other waves found, this chunk's minimum); racy but every value is a real cost
-        if (!ubp) return;
+        if (!can_prune) return;
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             uint32_t u = __hip_atomic_load(ubp + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -621,7 +625,7 @@ __global__ void __launch_bounds__(64) k_best8(Best8Args a) {
             const bool act = !(wv & H_TAG) && ((bits >> (wv & 31u)) & 1u);
             return (uint32_t)__builtin_amdgcn_ballot_w64(act) & ((1u << GRP) - 1u);
         };
-        prune = (phase == 1) && ubp != nullptr;
+        prune = (phase == 1) && can_prune;
         if (prune) {   // start from what earlier waves of this tile already know
 #pragma unroll
             for (int j = 0; j < 4; j++)
