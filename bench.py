@@ -153,7 +153,9 @@ def main():
                     "kernel": "k_best8" if packed else "k_place<0>", "tile_samples": T, "kernel_ms": round(k_ms, 4), "algo_bytes_per_launch": int(algo_bytes),
                     "node_plus_mut_evals_per_s": round(node_evals / (k_ms * 1e-3), 1) if k_ms > 0 else 0.0,
                     "table_ms": round(table_ms / args.steps, 4), "merge_ms": round(merge_ms / args.steps, 4),
-                    "pruned_frac": round(skipped / wtotal, 4) if wtotal else 0.0, "prune_skips": nskips}
+                    # the two pruning counters exist only in the instrumented kernel variant (UGP_STATS=1)
+                    "pruned_frac": (round(skipped / wtotal, 4) if wtotal else 0.0) if os.environ.get("UGP_STATS") else None,
+                    "prune_skips": nskips if os.environ.get("UGP_STATS") else None}
         # ---- CPU baseline: the literal oracle (port of mapper2_body + driver), node-parallel on the host cores
         cpu = None
         n_cpu = args.cpu_queries
