@@ -10,6 +10,9 @@
 #include "ugp_flatten.hpp"
 
 #include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <numeric>
 
@@ -33,6 +36,14 @@ int flatten(const ugp_tree_desc &t, const Options &opt, FlatMat &out, std::strin
     const uint64_t M = t.mut_off[N];
     if (M && (!t.mut_pos || !t.mut_ref || !t.mut_nuc)) { err = "null mutation arrays"; return UGP_ERR_INVALID; }
 
+    const bool verbose = getenv("UGP_FLATTEN_VERBOSE") != nullptr;
+    auto t_prev = std::chrono::steady_clock::now();
+    auto flat_lap = [&](const char *what) {
+        if (!verbose) return;
+        auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[ugp flatten] %-28s %8.1f ms\n", what, std::chrono::duration<double, std::milli>(now - t_prev).count());
+        t_prev = now;
+    };
     // ---- children (BFS order keeps each node's children contiguous & ordered)
     std::vector<uint32_t> child_off(N + 1, 0);
     for (uint64_t j = 1; j < N; j++) {
@@ -45,6 +56,7 @@ int flatten(const ugp_tree_desc &t, const Options &opt, FlatMat &out, std::strin
         std::vector<uint32_t> fill(child_off.begin(), child_off.end() - 1);
         for (uint64_t j = 1; j < N; j++) children[fill[t.parent[j]]++] = (uint32_t)j;
     }
+    flat_lap("children");
     // ---- subtree sizes and descendant-leaf counts
     std::vector<uint32_t> sub(N, 1), leaves(N, 0);
     for (uint64_t j = N; j-- > 0;) {
@@ -61,14 +73,29 @@ int flatten(const ugp_tree_desc &t, const Options &opt, FlatMat &out, std::strin
         for (uint32_t k = best; k + 1 < e; k++) children[k] = children[k + 1];
         children[e - 1] = c;
     }
+    flat_lap("subtree sizes");
     // ---- tie rank: ascending (n_leaves, j)
+    // (stable LSD radix sort of j by leaves[j], 11 bits per pass; as many passes as the largest count needs)
     out.rank2bfs.resize(N);
     std::iota(out.rank2bfs.begin(), out.rank2bfs.end(), 0u);
-    std::stable_sort(out.rank2bfs.begin(), out.rank2bfs.end(),
-                     [&](uint32_t a, uint32_t b) { return leaves[a] < leaves[b]; });
+    {
+        std::vector<uint32_t> tmp(N);
+        const uint32_t max_leaves = leaves[0];
+        for (uint32_t shift = 0; shift < 32 && (max_leaves >> shift) != 0; shift += 11) {
+            uint64_t count[2049] = {0};
+            for (uint64_t i = 0; i < N; i++) count[((leaves[out.rank2bfs[i]] >> shift) & 2047u) + 1]++;
+            for (int b = 0; b < 2048; b++) count[b + 1] += count[b];
+            for (uint64_t i = 0; i < N; i++) {
+                const uint32_t j = out.rank2bfs[i];
+                tmp[count[(leaves[j] >> shift) & 2047u]++] = j;
+            }
+            out.rank2bfs.swap(tmp);
+        }
+    }
     std::vector<uint32_t> rank(N);
     for (uint64_t r = 0; r < N; r++) rank[out.rank2bfs[r]] = (uint32_t)r;
 
+    flat_lap("tie rank");
     // ---- sites
     int32_t max_pos = 0;
     for (uint64_t i = 0; i < M; i++) max_pos = std::max(max_pos, t.mut_pos[i]);
@@ -107,6 +134,7 @@ int flatten(const ugp_tree_desc &t, const Options &opt, FlatMat &out, std::strin
     out.n_nodes = N;
     out.n_muts = n_real;
 
+    flat_lap("sites");
     // ---- DFS emission
     out.stream.clear();
     out.stream.reserve(2 * N + n_real);
@@ -191,6 +219,7 @@ int flatten(const ugp_tree_desc &t, const Options &opt, FlatMat &out, std::strin
     }
     out.max_slots = std::max<uint32_t>(max_slot_used, 1u);
 
+    flat_lap("DFS emission");
     // ---- chunks: equal dword budgets, cut at node boundaries
     uint64_t chunk_nodes = opt.chunk_nodes ? opt.chunk_nodes : std::max<uint64_t>(256, N / 4096);
     uint64_t want_chunks = std::max<uint64_t>(1, (N + chunk_nodes - 1) / chunk_nodes);
@@ -212,6 +241,7 @@ int flatten(const ugp_tree_desc &t, const Options &opt, FlatMat &out, std::strin
         out.chunk_node_off.push_back((uint32_t)N);
     }
     out.n_chunks = (uint32_t)out.chunk_body_off.size() - 1;
+    flat_lap("chunks");
     // ---- preambles: the root path of each chunk's first node, replayed without scoring
     std::vector<uint32_t> path;
     for (uint32_t c = 0; c < out.n_chunks; c++) {
@@ -233,6 +263,7 @@ int flatten(const ugp_tree_desc &t, const Options &opt, FlatMat &out, std::strin
     }
     out.chunk_pre_off.push_back((uint32_t)out.pre_stream.size());
 
+    flat_lap("preambles");
     // ---- packed stream (stream8) on the effective tree -----------------------
     // dropped[j]: leaf whose record has no mutation words (never eligible, no descendants)
     std::vector<uint8_t> dropped(N, 0);
@@ -241,10 +272,16 @@ int flatten(const ugp_tree_desc &t, const Options &opt, FlatMat &out, std::strin
     std::vector<uint32_t> eff_children(N, 0);
     std::vector<uint8_t> first_eff(N, 0);     // j is the first effective child of its parent
     for (uint64_t d = 0; d < N; d++) {        // DFS order: children of a node appear in emission order
+        if (d + 24 < N) {   // nodes are visited in DFS order but stored by BFS index: fetch ahead
+            const uint32_t jn = out.dfs2bfs[d + 24];
+            __builtin_prefetch(&dropped[jn]); __builtin_prefetch(&t.parent[jn]); __builtin_prefetch(&first_eff[jn]);
+        }
+        if (d + 12 < N) __builtin_prefetch(&eff_children[t.parent[out.dfs2bfs[d + 12]]]);
         uint32_t j = out.dfs2bfs[d];
         if (j == 0 || dropped[j]) continue;
         if (eff_children[t.parent[j]]++ == 0) first_eff[j] = 1;
     }
+    flat_lap("  eff children");
     // mutation count on the root path (bound for the 16-bit counters)
     {
         std::vector<uint32_t> path(N, 0);
@@ -256,6 +293,7 @@ int flatten(const ugp_tree_desc &t, const Options &opt, FlatMat &out, std::strin
         }
         out.max_path_muts = mx;
     }
+    flat_lap("  path muts");
     auto emit8 = [&](std::vector<uint32_t> &dst, uint32_t j, bool preamble) {
         const uint32_t off = rec_off[j];
         const uint32_t w0 = out.stream[off];
@@ -289,6 +327,7 @@ int flatten(const ugp_tree_desc &t, const Options &opt, FlatMat &out, std::strin
         hsub[p] = std::max(hsub[p], nw + hsub[j]);
         subw[p] += subw[j] + (dropped[j] ? 0u : 1u + nw);
     }
+    flat_lap("  hsub/subw");
     struct OpenBig { uint32_t info_pos, own_end, dfs_end; };
     std::vector<OpenBig> open_big;
     auto close_big = [&](uint32_t next_dfs) {   // patch the records of subtrees that end before DFS node next_dfs
@@ -305,6 +344,14 @@ int flatten(const ugp_tree_desc &t, const Options &opt, FlatMat &out, std::strin
     for (uint32_t c = 0; c < out.n_chunks; c++) {
         out.chunk8_body_off.push_back((uint32_t)out.stream8.size());
         for (uint32_t d = out.chunk_node_off[c]; d < out.chunk_node_off[c + 1]; d++) {
+            if ((uint64_t)d + 24 < N) {
+                const uint32_t jn = out.dfs2bfs[d + 24];
+                __builtin_prefetch(&dropped[jn]); __builtin_prefetch(&subw[jn]); __builtin_prefetch(&hsub[jn]); __builtin_prefetch(&sub[jn]);
+                __builtin_prefetch(&rec_off[jn]); __builtin_prefetch(&child_off[jn]); __builtin_prefetch(&first_eff[jn]);
+                __builtin_prefetch(&slot[jn]); __builtin_prefetch(&eff_children[jn]); __builtin_prefetch(&node_masked[jn]);
+                __builtin_prefetch(&t.parent[jn]);
+            }
+            if ((uint64_t)d + 12 < N) __builtin_prefetch(&slot[t.parent[out.dfs2bfs[d + 12]]]);
             uint32_t j = out.dfs2bfs[d];
             close_big(d);
             if (dropped[j]) continue;
@@ -327,6 +374,7 @@ int flatten(const ugp_tree_desc &t, const Options &opt, FlatMat &out, std::strin
     out.chunk8_body_off.push_back((uint32_t)out.stream8.size());
     out.chunk8_pre_off.push_back((uint32_t)out.pre8_stream.size());
 
+    flat_lap("packed stream");
     // ---- tie stream (phase 2 walks it one chunk at a time)
     {
         out.stream_t.clear(); out.chunk_t_off.clear();
@@ -347,6 +395,11 @@ int flatten(const ugp_tree_desc &t, const Options &opt, FlatMat &out, std::strin
         for (uint32_t c = 0; c < out.n_chunks; c++) {
             out.chunk_t_off.push_back((uint32_t)out.stream_t.size());
             for (uint32_t d = out.chunk_node_off[c]; d < out.chunk_node_off[c + 1]; d++) {
+                if ((uint64_t)d + 24 < N) {
+                    const uint32_t jn = out.dfs2bfs[d + 24];
+                    __builtin_prefetch(&dropped[jn]); __builtin_prefetch(&rec_off[jn]); __builtin_prefetch(&subd[jn]);
+                    __builtin_prefetch(&hsub[jn]); __builtin_prefetch(&sub[jn]);
+                }
                 const uint32_t j = out.dfs2bfs[d];
                 close(d);
                 if (dropped[j]) continue;
@@ -365,6 +418,7 @@ int flatten(const ugp_tree_desc &t, const Options &opt, FlatMat &out, std::strin
         out.chunk_t_off.push_back((uint32_t)out.stream_t.size());
     }
 
+    flat_lap("tie stream");
     // Renumber the packed stream's slots by access frequency, hottest first: the
     // kernel keeps the first few in LDS and the cold remainder in a global scratch
     // (slot use is bell-shaped over the index, a handful of slots take ~95 %).
@@ -393,6 +447,7 @@ int flatten(const ugp_tree_desc &t, const Options &opt, FlatMat &out, std::strin
         fix(out.stream8);
         fix(out.pre8_stream);
     }
+    flat_lap("slot renumbering");
     return UGP_OK;
 }
 
