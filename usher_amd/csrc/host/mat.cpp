@@ -87,7 +87,20 @@ Node *Tree::get_node(const std::string &id) const {
 }
 
 Node *Tree::create_node(const std::string &id, Node *parent, float branch_length) {   // :881-910
-    if (parent && all_nodes.count(id)) return nullptr;   // "already in the tree"
+    if (parent) {
+        auto ins = all_nodes.emplace(id, nullptr);
+        if (!ins.second) return nullptr;   // "already in the tree"
+        Node *n = new Node();
+        n->id = id;
+        n->parent = parent;
+        n->branch_length = branch_length;
+        n->level = parent->level + 1;
+        const size_t na = num_annotations();
+        if (na) n->clade_annotations.assign(na, "");
+        parent->children.push_back(n);
+        ins.first->second = n;
+        return n;
+    }
     Node *n = new Node();
     n->id = id;
     n->parent = parent;
@@ -276,6 +289,7 @@ bool tree_from_newick(const std::string &nwk, Tree &T, std::string &err) {   // 
         items.push_back(std::move(it));
     }
     if (level != 0) { err = "incorrect Newick format"; return false; }
+    T.all_nodes.reserve(items.size() * 2 + 16);
     std::vector<size_t> head(blen.size(), 0);
     std::vector<Node *> stack;
     for (Item &it : items) {
@@ -411,65 +425,64 @@ bool load_mat(const std::string &path, Tree &T, std::string &err) {   // :522-61
     if (!read_file(path, buf, err)) { err = "ERROR: Could not load the mutation-annotated tree object from file: " + path + "!"; return false; }
     Rd top{(const uint8_t *)buf.data(), (const uint8_t *)buf.data() + buf.size()};
     std::string nwk;
-    struct PMut { int32_t pos = 0, ref = 0, par = 0; std::vector<int32_t> nuc; std::string chrom; };
-    std::vector<std::vector<PMut>> node_muts;
+    // First pass: the newick string, and where each node's mutation list / metadata entry sits in the buffer
+    // (they are decoded straight into the nodes once the tree exists; no intermediate copies).
+    std::vector<Rd> mut_lists, meta_lists;
     std::vector<std::pair<std::string, std::vector<std::string>>> cond;
-    std::vector<std::vector<std::string>> meta;
     uint32_t fno, wt; uint64_t val; Rd sub{nullptr, nullptr};
     while (top.field(fno, wt, val, sub)) {
         if (fno == 1 && wt == 2) nwk.assign((const char *)sub.p, sub.e - sub.p);
-        else if (fno == 2 && wt == 2) {
-            node_muts.emplace_back();
-            uint32_t f2, w2; uint64_t v2; Rd s2{nullptr, nullptr};
-            while (sub.field(f2, w2, v2, s2)) {
-                if (f2 != 1 || w2 != 2) continue;
-                PMut m;
-                uint32_t f3, w3; uint64_t v3; Rd s3{nullptr, nullptr};
-                while (s2.field(f3, w3, v3, s3)) {
-                    if (f3 == 1 && w3 == 0) m.pos = (int32_t)(int64_t)v3;
-                    else if (f3 == 2 && w3 == 0) m.ref = (int32_t)(int64_t)v3;
-                    else if (f3 == 3 && w3 == 0) m.par = (int32_t)(int64_t)v3;
-                    else if (f3 == 4 && w3 == 0) m.nuc.push_back((int32_t)(int64_t)v3);
-                    else if (f3 == 4 && w3 == 2) { while (s3.p < s3.e && s3.ok) m.nuc.push_back((int32_t)(int64_t)s3.varint()); }
-                    else if (f3 == 5 && w3 == 2) m.chrom.assign((const char *)s3.p, s3.e - s3.p);
-                }
-                if (!s2.ok) { err = "malformed protobuf (mut)"; return false; }
-                node_muts.back().push_back(std::move(m));
-            }
-            if (!sub.ok) { err = "malformed protobuf (mutation_list)"; return false; }
-        } else if (fno == 3 && wt == 2) {
+        else if (fno == 2 && wt == 2) mut_lists.push_back(sub);
+        else if (fno == 3 && wt == 2) {
             cond.emplace_back();
             uint32_t f2, w2; uint64_t v2; Rd s2{nullptr, nullptr};
             while (sub.field(f2, w2, v2, s2)) {
                 if (f2 == 1 && w2 == 2) cond.back().first.assign((const char *)s2.p, s2.e - s2.p);
                 else if (f2 == 2 && w2 == 2) cond.back().second.emplace_back((const char *)s2.p, s2.e - s2.p);
             }
-        } else if (fno == 4 && wt == 2) {
-            meta.emplace_back();
-            uint32_t f2, w2; uint64_t v2; Rd s2{nullptr, nullptr};
-            while (sub.field(f2, w2, v2, s2))
-                if (f2 == 1 && w2 == 2) meta.back().emplace_back((const char *)s2.p, s2.e - s2.p);
-        }
+        } else if (fno == 4 && wt == 2) meta_lists.push_back(sub);
     }
     if (!top.ok) { err = "malformed protobuf"; return false; }
     if (!tree_from_newick(nwk, T, err)) return false;
     auto order = T.dfs();
-    if (node_muts.size() < order.size()) { err = "protobuf has fewer mutation lists than tree nodes"; return false; }
-    const bool hasmeta = !meta.empty();
+    if (mut_lists.size() < order.size()) { err = "protobuf has fewer mutation lists than tree nodes"; return false; }
+    const bool hasmeta = !meta_lists.empty();
     if (!hasmeta) fprintf(stderr, "WARNING: This pb does not include any metadata. Filling in default values\n");
-    if (hasmeta && meta.size() < order.size()) { err = "protobuf has fewer metadata entries than tree nodes"; return false; }
+    if (hasmeta && meta_lists.size() < order.size()) { err = "protobuf has fewer metadata entries than tree nodes"; return false; }
+    std::string chrom, last_chrom;
+    uint32_t last_chrom_id = T.chrom_id("");
     for (size_t i = 0; i < order.size(); i++) {
         Node *n = order[i];
-        if (hasmeta) n->clade_annotations = meta[i];
-        for (const PMut &pm : node_muts[i]) {
+        if (hasmeta) {
+            Rd ml = meta_lists[i];
+            uint32_t f2, w2; uint64_t v2; Rd s2{nullptr, nullptr};
+            while (ml.field(f2, w2, v2, s2))
+                if (f2 == 1 && w2 == 2) n->clade_annotations.emplace_back((const char *)s2.p, s2.e - s2.p);
+        }
+        Rd list = mut_lists[i];
+        uint32_t f2, w2; uint64_t v2; Rd s2{nullptr, nullptr};
+        while (list.field(f2, w2, v2, s2)) {
+            if (f2 != 1 || w2 != 2) continue;
+            int32_t pos = 0, ref = 0, par = 0;
+            int8_t nuc = 0;                                     // get_nuc_id(vector), :77-85
+            chrom.clear();
+            uint32_t f3, w3; uint64_t v3; Rd s3{nullptr, nullptr};
+            while (s2.field(f3, w3, v3, s3)) {
+                if (f3 == 1 && w3 == 0) pos = (int32_t)(int64_t)v3;
+                else if (f3 == 2 && w3 == 0) ref = (int32_t)(int64_t)v3;
+                else if (f3 == 3 && w3 == 0) par = (int32_t)(int64_t)v3;
+                else if (f3 == 4 && w3 == 0) nuc = (int8_t)(nuc + (1 << (int32_t)(int64_t)v3));
+                else if (f3 == 4 && w3 == 2) { while (s3.p < s3.e && s3.ok) nuc = (int8_t)(nuc + (1 << (int32_t)(int64_t)s3.varint())); }
+                else if (f3 == 5 && w3 == 2) chrom.assign((const char *)s3.p, s3.e - s3.p);
+            }
+            if (!s2.ok) { err = "malformed protobuf (mut)"; return false; }
+            if (chrom != last_chrom) { last_chrom = chrom; last_chrom_id = T.chrom_id(chrom); }
             Mutation m;
-            m.chrom = T.chrom_id(pm.chrom);
-            m.position = pm.pos;
-            if (pm.pos >= 0) {
-                m.ref_nuc = (int8_t)(1 << pm.ref);
-                m.par_nuc = (int8_t)(1 << pm.par);
-                int8_t nuc = 0;
-                for (int32_t b : pm.nuc) nuc = (int8_t)(nuc + (1 << b));   // get_nuc_id(vector), :77-85
+            m.chrom = last_chrom_id;
+            m.position = pos;
+            if (pos >= 0) {
+                m.ref_nuc = (int8_t)(1 << ref);
+                m.par_nuc = (int8_t)(1 << par);
                 m.mut_nuc = nuc;
                 if (m.mut_nuc != m.par_nuc && !n->add_mutation(m)) { err = "add_mutation: mutations at the same position disagree"; return false; }
             } else {
@@ -477,6 +490,7 @@ bool load_mat(const std::string &path, Tree &T, std::string &err) {   // :522-61
                 n->add_mutation(m);   // note: two masked entries cancel through the reversal rule, as in the reference
             }
         }
+        if (!list.ok) { err = "malformed protobuf (mutation_list)"; return false; }
     }
     for (auto &c : cond) {
         for (auto &l : c.second) T.condensed_leaves.insert(l);
