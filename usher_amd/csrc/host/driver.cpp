@@ -38,18 +38,19 @@ struct FlatTree {
     std::vector<int32_t> pos;
     std::vector<uint8_t> ref, par, nuc;
     ugp_tree_desc desc{};
-    std::unordered_map<const Node *, uint32_t> idx;   // node -> breadth-first index at build time
+    uint32_t epoch = 0;                               // nodes stamped with this epoch carry their index here (Node::flat_index)
     std::vector<uint32_t> leaves;                     // leaves below each node at build time (Tree::get_num_leaves)
+    bool has(const Node *n) const { return n->flat_epoch == epoch; }
     void build(const Tree &T) {
+        static uint32_t next_epoch = 0;
+        epoch = ++next_epoch;
         bfs = T.bfs();
-        idx.clear();
-        idx.reserve(bfs.size() * 2);
-        for (uint32_t j = 0; j < bfs.size(); j++) idx[bfs[j]] = j;
+        for (uint32_t j = 0; j < bfs.size(); j++) { bfs[j]->flat_index = j; bfs[j]->flat_epoch = epoch; }
         parent.assign(bfs.size(), UINT32_MAX);
         mut_off.assign(bfs.size() + 1, 0);
         pos.clear(); ref.clear(); par.clear(); nuc.clear();
         for (uint32_t j = 0; j < bfs.size(); j++) {
-            if (bfs[j]->parent) parent[j] = idx[bfs[j]->parent];
+            if (bfs[j]->parent) parent[j] = bfs[j]->parent->flat_index;
             for (const Mutation &m : bfs[j]->mutations) {
                 pos.push_back(m.position); ref.push_back((uint8_t)m.ref_nuc);
                 par.push_back((uint8_t)m.par_nuc); nuc.push_back((uint8_t)m.mut_nuc);
@@ -374,8 +375,7 @@ int run_usher(const Options &opt, Tree &T, std::vector<MissingSample> &missing, 
         NodeVecs probe;
         auto leaves_now = [&](const Node *n) -> size_t {
             size_t v = 0;
-            auto it = flat.idx.find(n);
-            if (it != flat.idx.end()) v = flat.leaves[it->second];
+            if (flat.has(n)) v = flat.leaves[n->flat_index];
             auto a = added_leaves.find(n);
             return a == added_leaves.end() ? v : v + a->second;
         };

@@ -32,6 +32,9 @@ struct Node {                 // mutation_annotated_tree.hpp:88-111
     std::vector<std::string> clade_annotations;
     float branch_length = -1.0f;
     size_t level = 1;
+    // scratch for the placement driver: breadth-first index in its last flattening of the tree (valid
+    // while flat_epoch equals the flattening's epoch) -- avoids a 10M-entry hash map per flattening
+    mutable uint32_t flat_index = 0, flat_epoch = 0;
     bool is_leaf() const { return children.empty(); }
     bool is_root() const { return parent == nullptr; }
     // :720-752.  Returns false on the reference's "called out of order" error.
