@@ -120,6 +120,15 @@ def main():
         elapsed = float(tt.item())
 
     res = out.cpu().numpy()
+    host_path = None
+    if rank == 0 and world == 1:
+        pl.place(batch)   # warm
+        t0 = time.perf_counter()
+        for _ in range(2):
+            hres = pl.place(batch)
+        dt = (time.perf_counter() - t0) / 2
+        host_path = {"placements_per_s": round(Q / dt, 2), "ms_per_batch": round(dt * 1e3, 3),
+                     "identical_to_device_path": bool((np.stack([hres[k] for k in ("best_set_difference", "num_best", "best_j", "best_has_unique")], 1).astype(np.int64) == res.astype(np.int64)).all())}
     result = None
     if rank == 0:
         ms_per_step = elapsed * 1e3 / args.steps
@@ -190,6 +199,9 @@ def main():
                        "parallelism": "queries sharded x%d, MAT replicated, RCCL all-gather of results" % world,
                        "seed": args.seed, "gen_s": round(t_gen, 2), "flatten_upload_s": round(t_flat, 2)},
             "roofline": roofline, "cpu_baseline": cpu,
+            # the same batch through the host-buffer entry point (ugp_place_batch: query upload over PCIe, tile
+            # build, kernels, result download), outside the timed region; never `value`
+            "host_buffer_path": host_path,
         }
     pl.free_qset(qset)
     pl.close()
