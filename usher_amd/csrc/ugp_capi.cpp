@@ -184,15 +184,19 @@ int run_place(ugp_mat *m, ugp_qset *qs, int mode, ugp_result *d_out, int32_t *d_
         if (int rc = run_place(m->coarse, qs, 0, m->d_coarse_res.p, nullptr, nullptr, nullptr, nullptr, nullptr, 0, s)) return rc;
         HIP_TRY(hipSetDevice(m->device));
     }
-    for (uint64_t q0 = 0; q0 < Q; q0 += (uint64_t)kMaxTilesPerLaunch * 64) {
-        const uint64_t nq = std::min<uint64_t>(Q - q0, (uint64_t)kMaxTilesPerLaunch * 64);
+    // samples per sub-batch: at most 262,144, and few enough that the per-(chunk, sample) minima of phase 1
+    // (2 bytes each) stay below 8 GiB
+    uint64_t sub_tiles = kMaxTilesPerLaunch;
+    if (m->flat.n_chunks) sub_tiles = std::min<uint64_t>(sub_tiles, std::max<uint64_t>(8, ((8ull << 30) / ((uint64_t)m->flat.n_chunks * 128)) & ~7ull));
+    for (uint64_t q0 = 0; q0 < Q; q0 += sub_tiles * 64) {
+        const uint64_t nq = std::min<uint64_t>(Q - q0, sub_tiles * 64);
         const uint32_t n_tiles = (uint32_t)((nq + 63) / 64);
         const uint32_t n_tiles512 = (uint32_t)((nq + 511) / 512);
         // 16-bit packed phase 1 is exact while every D / cost stays below 0x8000 (bit 15 is the ineligible flag)
         const bool use8 = packed_ok;
         uint32_t G = pick_groups(m, n_tiles);
         if (use8) {   // work units of a few chunks each, pulled from per-XCD queues by persistent waves (see k_best8)
-            uint32_t unit_chunks = 4;
+            uint32_t unit_chunks = 16;
             if (const char *e = getenv("UGP_UNIT_CHUNKS")) unit_chunks = (uint32_t)std::max(1, atoi(e));
             G = std::max<uint32_t>(1, (f.n_chunks + unit_chunks - 1) / unit_chunks);
             // a small batch still has to fill the chip: at least ~4096 units in total
@@ -287,7 +291,9 @@ int run_place(ugp_mat *m, ugp_qset *qs, int mode, ugp_result *d_out, int32_t *d_
                 b.tile_hstart = m->d_gstart.p; b.tile_hlen = m->d_hlen.p;
             }
             b.unit_chunks = std::max<uint32_t>(1, (f.n_chunks + G - 1) / G);
-            b.heavy_chunks = 4;
+            b.ub_every = 128;
+            if (const char *e = getenv("UGP_UB_EVERY")) b.ub_every = (uint32_t)std::max(1, atoi(e));
+            b.heavy_chunks = 32;
             if (const char *e = getenv("UGP_HEAVY_CHUNKS")) b.heavy_chunks = (uint32_t)std::max(1, atoi(e));
             HIP_TRY(m->d_stats.reserve(32));
             if (q0 == 0) { HIP_TRY(hipMemsetAsync(m->d_stats.p, 0, 32 * sizeof(uint64_t), s)); m->last_words_total = 0; }

@@ -221,7 +221,9 @@ int flatten(const ugp_tree_desc &t, const Options &opt, FlatMat &out, std::strin
 
     flat_lap("DFS emission");
     // ---- chunks: equal dword budgets, cut at node boundaries
-    uint64_t chunk_nodes = opt.chunk_nodes ? opt.chunk_nodes : std::max<uint64_t>(256, N / 4096);
+    // ~300 nodes per chunk on a 10M-node tree: chunks are the granule of the phase-1 minima (short phase-2
+    // re-walks) and of the work units (16 / 32 chunks each outside / inside a tile's own region)
+    uint64_t chunk_nodes = opt.chunk_nodes ? opt.chunk_nodes : std::max<uint64_t>(128, N / 32768);
     uint64_t want_chunks = std::max<uint64_t>(1, (N + chunk_nodes - 1) / chunk_nodes);
     const uint64_t total = out.stream.size();
     out.chunk_body_off.clear(); out.chunk_node_off.clear(); out.chunk_pre_off.clear(); out.pre_stream.clear();

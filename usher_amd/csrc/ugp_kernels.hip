@@ -393,6 +393,14 @@ __global__ void __launch_bounds__(64) k_best8(Best8Args a) {
     // by >10x and the in-order, round-robin-per-XCD workgroup dispatcher stalls behind the slow XCD.
     const uint32_t home = blockIdx.x & 7u;
     uint32_t drained = 0;   // bit x: queue x is known to be empty
+    // Upper bounds (+1) of the tile this wave worked on last, kept across units: the shared copy is read and
+    // written with agent-scope accesses that leave the XCD, ~40 us of wave time per exchange, so it is
+    // consulted when the wave moves to another tile and every a.ub_every chunk ends, not at every chunk end.
+    Pk4 ub1;
+#pragma unroll
+    for (int j = 0; j < 4; j++) ub1.v[j] = 0x80008000u;
+    uint32_t ub_tile = 0xFFFFFFFFu;   // uniform: tile whose bounds are in ub1
+    uint32_t ub_age = 0;              // uniform: chunk ends since the last exchange
     for (;;) {
     uint32_t tile = 0, c0 = 0, c1 = 0;   // the unit: chunks [c0, c1) of the stream for one tile
     {
@@ -465,9 +473,6 @@ __global__ void __launch_bounds__(64) k_best8(Best8Args a) {
     uint32_t info = 0;         // uniform: pending pruning record
     uint32_t skip_to = 0;      // uniform: restart request (0 = none)
     uint64_t n_skipped = 0;    // uniform (STATS): words jumped over
-    Pk4 ub1;
-#pragma unroll
-    for (int j = 0; j < 4; j++) ub1.v[j] = 0x80008000u;
     // (the tests below use the kernel argument, not the per-lane pointer: a condition derived from `lane`
     // is formally divergent, and one such flag turned the whole walk's control flow -- jump target, open
     // header, position -- into vector registers with exec-mask branches)
@@ -486,7 +491,14 @@ __global__ void __launch_bounds__(64) k_best8(Best8Args a) {
     auto chunk_end = [&]() {     // publish the chunk-local minimum, start the next chunk
         uint4 *dst = (uint4 *)(a.lbest + (((uint64_t)chunk * a.n_tiles + tile) * 64 + lane) * 4);
         *dst = make_uint4(best.v[0], best.v[1], best.v[2], best.v[3]);
-        exchange_ub();
+        if (can_prune) {
+            if (++ub_age >= a.ub_every) { exchange_ub(); ub_age = 0; }
+            else {
+#pragma unroll
+                for (int j = 0; j < 4; j++)   // what this wave found itself ("no candidate" is 0xFFFF: take the minimum before the +1)
+                    ub1.v[j] = pk_add(pk_min(pk_sub(ub1.v[j], 0x00010001u), best.v[j]), 0x00010001u);
+            }
+        }
 #pragma unroll
         for (int j = 0; j < 4; j++) best.v[j] = 0xFFFFFFFFu;
         chunk++;
@@ -626,10 +638,12 @@ __global__ void __launch_bounds__(64) k_best8(Best8Args a) {
             return (uint32_t)__builtin_amdgcn_ballot_w64(act) & ((1u << GRP) - 1u);
         };
         prune = (phase == 1) && can_prune;
-        if (prune) {   // start from what earlier waves of this tile already know
+        if (prune && ub_tile != tile) {   // start from what earlier waves of this tile already know
 #pragma unroll
             for (int j = 0; j < 4; j++)
                 ub1.v[j] = pk_add(__hip_atomic_load(ubp + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), 0x00010001u);
+            ub_tile = tile;
+            ub_age = 0;
         }
         uint32_t off = 0;
         bool cautious = false;   // uniform: the last run was cut short by a jump inside its first group
