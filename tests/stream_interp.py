@@ -161,11 +161,11 @@ def best8_group(flat, nib, dbot, c0, c1, ub=None, stats=None):
             w = int(words[i])
             ended = False
             if w & H_TAG:
-                if w & H_NOP:
-                    continue
-                if w & H_INFO:
+                if w & H_INFO:          # first: the jump length of a pruning record overlaps the other flag bits
                     if ub is not None and phase == 1:
                         info = w
+                    continue
+                if w & H_NOP:
                     continue
                 if w & H_CHUNK_END:
                     lbest[chunk] = best

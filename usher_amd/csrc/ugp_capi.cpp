@@ -82,6 +82,7 @@ struct ugp_mat {
     DevBuf<uint8_t> d_site_ref;
     // per-call workspaces (grown on demand)
     DevBuf<uint32_t> d_table, d_dbottom, d_part_best, d_part_cnt, d_part_key;
+    DevBuf<uint8_t> d_lflag;
     DevBuf<uint32_t> d_lbest, d_gbest, d_gbest_part, d_items, d_nitems, d_cnt, d_key, d_active, d_ub, d_queue, d_gstart, d_hlen;
     DevBuf<uint64_t> d_stats;
     uint64_t last_words_total = 0;
@@ -210,6 +211,7 @@ int run_place(ugp_mat *m, ugp_qset *qs, int mode, ugp_result *d_out, int32_t *d_
         const uint64_t pairs = (uint64_t)f.n_chunks * n_tiles512 * 8;
         if (use8) {
             HIP_TRY(m->d_lbest.reserve((size_t)f.n_chunks * n_tiles512 * 256));
+            HIP_TRY(m->d_lflag.reserve((size_t)f.n_chunks * n_tiles512));
             HIP_TRY(m->d_gbest.reserve((size_t)n_tiles512 * 256));
             HIP_TRY(m->d_gbest_part.reserve((size_t)ugp::GBEST_SLICES * n_tiles512 * 256));
             HIP_TRY(m->d_ub.reserve((size_t)n_tiles512 * 256));
@@ -282,6 +284,8 @@ int run_place(ugp_mat *m, ugp_qset *qs, int mode, ugp_result *d_out, int32_t *d_
             b.table = m->d_table.p; b.dbottom = m->d_dbottom.p;
             b.n_sites = n_sites; b.n_chunks = f.n_chunks; b.n_groups = G; b.n_tiles = n_tiles512;
             b.lbest = m->d_lbest.p;
+            b.lflag = m->d_lflag.p;
+            HIP_TRY(hipMemsetAsync(m->d_lflag.p, 0, (size_t)f.n_chunks * n_tiles512, s));
             b.queue = m->d_queue.p;
             b.ub = getenv("UGP_NO_PRUNE") ? nullptr : m->d_ub.p;
             if (sorted && !getenv("UGP_NO_LPT")) {   // hand out every tile's own region first (scheduling only)
@@ -303,7 +307,7 @@ int run_place(ugp_mat *m, ugp_qset *qs, int mode, ugp_result *d_out, int32_t *d_
             b.active = m->d_active.p; b.active_words = active_words;
             HIP_TRY(ugp::launch_best8(b, f.max_slots, s));
             HIP_TRY(hipEventRecord(es.ev[2], s));
-            HIP_TRY(ugp::launch_phase2(a, m->d_lbest.p, m->d_gbest_part.p, m->d_gbest.p, n_tiles512, m->d_items.p, m->d_nitems.p,
+            HIP_TRY(ugp::launch_phase2(a, m->d_lbest.p, m->d_lflag.p, m->d_gbest_part.p, m->d_gbest.p, n_tiles512, m->d_items.p, m->d_nitems.p,
                                        (uint32_t)std::min<uint64_t>(pairs, 0xFFFFFFFFull), m->d_cnt.p, m->d_key.p,
                                        m->d_rank2bfs.p, d_out + q0, order, f.max_slots, s));
         } else {

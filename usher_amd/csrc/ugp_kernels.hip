@@ -488,9 +488,22 @@ __global__ void __launch_bounds__(64) k_best8(Best8Args a) {
             ub1.v[j] = pk_add(u, 0x00010001u);
         }
     };
+    // A chunk's minima matter only if some sample's minimum is within its upper bound (the global minimum
+    // never exceeds the bound): only then are they stored, and lflag[chunk][tile] tells phase 2 that the
+    // record exists.  Most chunks are far from the tile's samples and end without a store.
+    auto chunk_has_candidate = [&]() -> bool {
+        if (!can_prune) return true;
+        uint32_t t = 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) t |= pk_min(best.v[j], ub1.v[j]) ^ ub1.v[j];   // non-zero where best < ub + 1
+        return __builtin_amdgcn_ballot_w64(t != 0) != 0;
+    };
     auto chunk_end = [&]() {     // publish the chunk-local minimum, start the next chunk
-        uint4 *dst = (uint4 *)(a.lbest + (((uint64_t)chunk * a.n_tiles + tile) * 64 + lane) * 4);
-        *dst = make_uint4(best.v[0], best.v[1], best.v[2], best.v[3]);
+        if (chunk_has_candidate()) {
+            uint4 *dst = (uint4 *)(a.lbest + (((uint64_t)chunk * a.n_tiles + tile) * 64 + lane) * 4);
+            *dst = make_uint4(best.v[0], best.v[1], best.v[2], best.v[3]);
+            if (lane == 0) a.lflag[(uint64_t)chunk * a.n_tiles + tile] = 1;
+        }
         if (can_prune) {
             if (++ub_age >= a.ub_every) { exchange_ub(); ub_age = 0; }
             else {
@@ -511,8 +524,19 @@ __global__ void __launch_bounds__(64) k_best8(Best8Args a) {
     auto step = [&](uint32_t w, uint32_t x, uint32_t pos) {
         if (w & H_TAG) {
             if (w & (H_NOP | H_CHUNK_END | H_INFO)) {
-                if (w & H_CHUNK_END) skip_to = pos + 1;          // handled by the restart code below
-                else if ((w & H_INFO) && prune) { info = w; have_info = true; }
+                // (H_INFO first: the jump length of a pruning record overlaps the other flag bits)
+                if (w & H_INFO) { if (prune) { info = w; have_info = true; } }
+                else if (w & H_CHUNK_END) {
+                    // a chunk with a candidate (or a due exchange of bounds) is closed by the restart code, which may
+                    // store; any other chunk just ends here, inside the pipeline
+                    if (chunk_has_candidate() || ub_age + 1 >= a.ub_every) skip_to = pos + 1;
+                    else {
+                        ub_age++;
+#pragma unroll
+                        for (int j = 0; j < 4; j++) best.v[j] = 0xFFFFFFFFu;
+                        chunk++;
+                    }
+                }
                 return;
             }
             hdr = w;
@@ -728,7 +752,7 @@ __global__ void __launch_bounds__(64) k_best8(Best8Args a) {
 
 // Global minimum per sample over the chunk-local minima: the chunk axis is cut into gridDim.y
 // slices (partial minima in `part`), then k_gbest2 folds the slices.
-__global__ void k_gbest(const uint32_t *__restrict__ lbest, uint32_t n_chunks, uint32_t n_tiles,
+__global__ void k_gbest(const uint32_t *__restrict__ lbest, const uint8_t *__restrict__ lflag, uint32_t n_chunks, uint32_t n_tiles,
                         uint32_t *__restrict__ part /* [gridDim.y][n_tiles*256] */) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;   // dword index within one chunk's record
     const uint32_t per_chunk = n_tiles * 256;
@@ -736,7 +760,9 @@ __global__ void k_gbest(const uint32_t *__restrict__ lbest, uint32_t n_chunks, u
     const uint32_t c0 = (uint32_t)((uint64_t)blockIdx.y * n_chunks / gridDim.y);
     const uint32_t c1 = (uint32_t)((uint64_t)(blockIdx.y + 1) * n_chunks / gridDim.y);
     uint32_t m = 0xFFFFFFFFu;
-    for (uint32_t c = c0; c < c1; c++) m = pk_min(m, lbest[(uint64_t)c * per_chunk + i]);
+    const uint32_t tile = i >> 8;
+    for (uint32_t c = c0; c < c1; c++)
+        if (lflag[(uint64_t)c * n_tiles + tile]) m = pk_min(m, lbest[(uint64_t)c * per_chunk + i]);   // records without a flag were never written
     part[(uint64_t)blockIdx.y * per_chunk + i] = m;
 }
 __global__ void k_gbest2(const uint32_t *__restrict__ part, uint32_t n_slices, uint32_t per_chunk,
@@ -758,7 +784,7 @@ __device__ __forceinline__ uint32_t pk_lookup(const uint32_t *packed, uint32_t t
 
 // One thread per (chunk, 64-sample tile): does any of its samples attain its
 // global minimum in this chunk?  If so the pair becomes a phase-2 work item.
-__global__ void k_select(const uint32_t *__restrict__ lbest, const uint32_t *__restrict__ gbest, uint32_t n_chunks,
+__global__ void k_select(const uint32_t *__restrict__ lbest, const uint8_t *__restrict__ lflag, const uint32_t *__restrict__ gbest, uint32_t n_chunks,
                          uint32_t n_tiles, uint32_t n_queries, uint32_t *__restrict__ items,
                          uint32_t *__restrict__ n_items, uint32_t cap) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -766,6 +792,7 @@ __global__ void k_select(const uint32_t *__restrict__ lbest, const uint32_t *__r
     if (i >= (uint64_t)n_chunks * n_t64) return;
     const uint32_t c = (uint32_t)(i / n_t64), t64 = (uint32_t)(i % n_t64);
     if ((uint64_t)t64 * 64 >= n_queries) return;
+    if (!lflag[(uint64_t)c * n_tiles + (t64 >> 3)]) return;
     // the 64 samples of t64 are lanes (t64&7)*8 .. +8 of tile t64>>3: 32 consecutive dwords
     const uint64_t off = ((uint64_t)(t64 >> 3) * 64 + (t64 & 7u) * 8) * 4;
     const uint32_t *lb = lbest + (uint64_t)c * n_tiles * 256 + off;
@@ -967,15 +994,15 @@ hipError_t launch_best8(const Best8Args &a, uint32_t max_slots, hipStream_t s) {
     return hipGetLastError();
 }
 
-hipError_t launch_phase2(const PlaceArgs &a, const uint32_t *lbest, uint32_t *gbest_part, uint32_t *gbest, uint32_t n_tiles512,
+hipError_t launch_phase2(const PlaceArgs &a, const uint32_t *lbest, const uint8_t *lflag, uint32_t *gbest_part, uint32_t *gbest, uint32_t n_tiles512,
                          uint32_t *items, uint32_t *n_items, uint32_t cap, uint32_t *cnt, uint32_t *key,
                          const uint32_t *rank2bfs, ugp_result *out, const uint32_t *order, uint32_t max_slots, hipStream_t s) {
     const uint32_t per_chunk = n_tiles512 * 256;
     const uint32_t slices = std::min<uint32_t>(GBEST_SLICES, a.n_chunks);
-    hipLaunchKernelGGL(k_gbest, dim3((per_chunk + 255) / 256, slices), dim3(256), 0, s, lbest, a.n_chunks, n_tiles512, gbest_part);
+    hipLaunchKernelGGL(k_gbest, dim3((per_chunk + 255) / 256, slices), dim3(256), 0, s, lbest, lflag, a.n_chunks, n_tiles512, gbest_part);
     hipLaunchKernelGGL(k_gbest2, dim3((per_chunk + 255) / 256), dim3(256), 0, s, gbest_part, slices, per_chunk, gbest);
     const uint64_t pairs = (uint64_t)a.n_chunks * n_tiles512 * 8;
-    hipLaunchKernelGGL(k_select, dim3((uint32_t)((pairs + 255) / 256)), dim3(256), 0, s, lbest, gbest, a.n_chunks,
+    hipLaunchKernelGGL(k_select, dim3((uint32_t)((pairs + 255) / 256)), dim3(256), 0, s, lbest, lflag, gbest, a.n_chunks,
                        n_tiles512, a.n_queries, items, n_items, cap);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
