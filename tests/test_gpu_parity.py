@@ -342,3 +342,34 @@ def test_usher_cli_add_mode_batched_equals_research_on_gpu(tmp_path):
         outs[mode] = {n: open(str(d / n)).read() for n in ("placement_stats.tsv", "mutation-paths.txt", "uncondensed-final-tree.nh")}
     assert outs["batched"] == outs["research"]
     assert sum(1 for l in outs["batched"]["placement_stats.tsv"].splitlines() if l.split("\t")[2] != "1") > 20   # ties were exercised
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_randomised_trees_and_scheduling_knobs(seed, monkeypatch):
+    """Differential fuzz: random trees (masked mutations, long branches, root mutations), multi-tile batches
+    with N / IUPAC cells, and random values of every speed-only knob (chunk size, unit sizes, bound-exchange
+    period, locality sort, longest-first scheduling); results must equal the oracle's sample by sample."""
+    rng = np.random.default_rng(1000 + seed)
+    n_leaves = int(rng.integers(150, 2500))
+    arrays, queries = synth.make_case(2000 + seed, n_leaves=n_leaves, n_queries=int(rng.integers(530, 1100)),
+                                      n_sites=int(rng.integers(60, 400)), p_masked=float(rng.choice([0.0, 0.02])),
+                                      root_muts=int(rng.integers(0, 3)), mut_counts=(0, 0, 1, 1, 1, 2, 3, int(rng.choice([3, 18]))),
+                                      n_ambig=(0, 0, 2, 5, 30))
+    ot = capi.OracleTree(arrays)
+    want = [ot.place(s, want_ties=False) for s in queries]
+    knobs = {"UGP_COARSE_MIN_NODES": "0", "UGP_UNIT_CHUNKS": str(int(rng.integers(1, 9))), "UGP_HEAVY_CHUNKS": str(int(rng.integers(1, 9))),
+             "UGP_UB_EVERY": str(int(rng.choice([1, 2, 7, 1000]))), "UGP_PRUNE_MIN_WORDS": str(int(rng.choice([2, 8, 40])))}
+    if rng.random() < 0.3:
+        knobs["UGP_NO_LPT"] = "1"
+    if rng.random() < 0.2:
+        knobs["UGP_NO_SEED"] = "1"
+    for k in ("UGP_COARSE_MIN_NODES", "UGP_UNIT_CHUNKS", "UGP_HEAVY_CHUNKS", "UGP_UB_EVERY", "UGP_PRUNE_MIN_WORDS", "UGP_NO_LPT", "UGP_NO_SEED",
+              "UGP_NO_SORT", "UGP_NO_PRUNE", "UGP_FORCE_V1"):
+        monkeypatch.delenv(k, raising=False)
+    for k, v in knobs.items():
+        monkeypatch.setenv(k, v)
+    pl = Placer(arrays, chunk_nodes=int(rng.integers(3, 80)))
+    res = pl.place(QueryBatch(queries))
+    for i, w in enumerate(want):
+        _assert_same(res, i, w, "%s #%d" % (knobs, i))
+    pl.close()
