@@ -403,6 +403,7 @@ __global__ void __launch_bounds__(64) k_best8(Best8Args a) {
     uint32_t ub_age = 0;              // uniform: chunk ends since the last exchange
     for (;;) {
     uint32_t tile = 0, c0 = 0, c1 = 0;   // the unit: chunks [c0, c1) of the stream for one tile
+    bool unit_heavy = false;             // (STATS) the unit lies in the tile's own region
     {
         // Units of a tile.  Its own region H = [h0, h0 + hl) (the chunks its samples sit in, from the
         // locality sort; hl = 0 without it) cannot be pruned and is dense work: a.heavy_chunks chunks per unit, and
@@ -430,6 +431,7 @@ __global__ void __launch_bounds__(64) k_best8(Best8Args a) {
             }
             if (v >= ux) { drained |= 1u << x; continue; }
             got = true;
+            unit_heavy = v < heavy;
             if (v < heavy) {
                 uint32_t tt = tlo, r = v;
                 while (r >= (a.tile_hlen[tt] + HU - 1u) / HU) { r -= (a.tile_hlen[tt] + HU - 1u) / HU; tt++; }
@@ -744,6 +746,8 @@ __global__ void __launch_bounds__(64) k_best8(Best8Args a) {
         atomicAdd(st + 1, (unsigned long long)n_restart);
         atomicAdd(st + 2, (unsigned long long)t_restart);
         atomicAdd(st + 3, tw);
+        atomicAdd(st + (unit_heavy ? 27 : 28), tw);   // wave cycles inside / outside the tiles' own regions
+        atomicAdd(st + (unit_heavy ? 29 : 30), 1ull);
         atomicMax(st + 4, tw);
         atomicAdd(st + 5 + min(tw >> 22, 15ull), 1ull);   // histogram of unit durations, 4.2M-cycle bins
     }
