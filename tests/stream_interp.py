@@ -114,6 +114,7 @@ def place(flat, sample, n_groups=1, want_scores=False):
 # packed stream ("stream8"): interpreter of k_best8 + phase 2, one sample at a
 # time but with the kernel's 16-bit wrap-around arithmetic and 4-bit counters.
 # --------------------------------------------------------------------------
+H_SIB = 1 << 21
 H_TAG, H_SKIPD, H_NOSCORE8, H_END, H_FREE, H_CHUNK_END, H_NOP, H_INFO = (
     1 << 31, 1 << 12, 1 << 13, 1 << 16, 1 << 17, 1 << 18, 1 << 19, 1 << 30)
 M_FLUSH, M_END = 1 << 28, 1 << 30
@@ -153,6 +154,7 @@ def best8_group(flat, nib, dbot, c0, c1, ub=None, stats=None):
         flushed = False
 
     info = None
+    sinfo = None
     for phase, (words, lo, hi) in enumerate(((flat.pre8_stream, int(flat.chunk8_pre_off[c0]), int(flat.chunk8_pre_off[c0 + 1])),
                                              (flat.stream8, int(flat.chunk8_body_off[c0]), int(flat.chunk8_body_off[c1])))):
         i = lo - 1
@@ -163,7 +165,10 @@ def best8_group(flat, nib, dbot, c0, c1, ub=None, stats=None):
             if w & H_TAG:
                 if w & H_INFO:          # first: the jump length of a pruning record overlaps the other flag bits
                     if ub is not None and phase == 1:
-                        info = w
+                        if w & H_SIB:
+                            sinfo = w
+                        else:
+                            info = w
                     continue
                 if w & H_NOP:
                     continue
@@ -177,6 +182,22 @@ def best8_group(flat, nib, dbot, c0, c1, ub=None, stats=None):
                 hdr = w
                 rslot = w & 63
                 dpar = dcur if rslot == RS_REG else (dbot if rslot == RS_BOTTOM else slots[rslot])
+                if sinfo is not None:   # sibling record: skip this child and the non-last siblings after it?
+                    hs, jump = (sinfo >> 22) & 0xFF, sinfo & 0x1FFFFF
+                    sinfo = None
+                    if dpar >= ub[0] + 1 + hs:
+                        target = i + jump
+                        info = None
+                        if stats is not None:
+                            stats["skipped"] = stats.get("skipped", 0) + min(target, hi) - i
+                            stats["sibling_jumps"] = stats.get("sibling_jumps", 0) + 1
+                        while chunk < c1 and target > int(flat.chunk8_body_off[chunk + 1]) - 1:
+                            lbest[chunk] = best
+                            ub[0] = min(ub[0], best)
+                            best = U16
+                            chunk += 1
+                        i = target - 1
+                        continue
                 if w & H_END:
                     finish()
                     ended = True
@@ -197,7 +218,7 @@ def best8_group(flat, nib, dbot, c0, c1, ub=None, stats=None):
                     finish()
                     ended = True
             if ended and info is not None:
-                hs, jump = (info >> 22) & 0xFF, info & 0x3FFFFF
+                hs, jump = (info >> 22) & 0xFF, info & 0x1FFFFF
                 info = None
                 if dcur >= ub[0] + 1 + hs:          # D(node) - hsub > upper bound: no descendant can tie or win
                     target = i + 1 + jump

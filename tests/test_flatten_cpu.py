@@ -123,3 +123,24 @@ def test_pruning_records_skip_far_subtrees_exactly():
                 assert got[k] == want[k], (ub, k)
             skipped += st.get("skipped", 0)
     assert skipped > len(flat.stream8)                      # pruning really happened
+
+
+def test_sibling_records_skip_runs_of_siblings_exactly():
+    """Sibling records (H_INFO | H_SIB): one jump over a child and all later non-last siblings when
+    D(parent) minus the largest downward mutation count among them exceeds the bound.  Present in the
+    stream, used by the model, and the results do not change."""
+    arrays, queries = synth.make_case(63, n_leaves=5000, n_queries=6, n_sites=300, n_ambig=(0, 0, 2))
+    flat = FlatTreeView(arrays, chunk_nodes=900)
+    is_sib = ((flat.stream8 >> 30) == 3) & ((flat.stream8 & (1 << 21)) != 0)
+    assert is_sib.sum() > 20
+    ot = capi.OracleTree(arrays)
+    jumps = 0
+    for s in queries:
+        want = ot.place(s)
+        for ub in (0x7F7F, want["best"] + 2, want["best"]):
+            st = {}
+            got = stream_interp.place8(flat, s, n_groups=4, prune_ub=ub, stats=st)
+            for k in ("best", "num_best", "best_j", "has_unique"):
+                assert got[k] == want[k], (ub, k)
+            jumps += st.get("sibling_jumps", 0)
+    assert jumps > 10

@@ -635,6 +635,7 @@ int ugp_get_timing(ugp_mat *m, ugp_timing *out) {
                 fprintf(stderr, "[ugp stats] restarts=%llu restart_cycles=%llu wave_cycles=%llu max_wave=%llu hist:", (unsigned long long)v[1],
                         (unsigned long long)v[2], (unsigned long long)v[3], (unsigned long long)v[4]);
                 for (int i = 0; i < 16; i++) fprintf(stderr, " %llu", (unsigned long long)v[5 + i]);
+                fprintf(stderr, "\n[ugp stats] jumps decided by the first node after a restart=%llu", (unsigned long long)v[26]);
                 fprintf(stderr, "\n[ugp stats] own-region units=%llu cycles=%llu   other units=%llu cycles=%llu\n", (unsigned long long)v[29],
                         (unsigned long long)v[27], (unsigned long long)v[30], (unsigned long long)v[28]);
             }

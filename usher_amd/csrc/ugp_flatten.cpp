@@ -10,6 +10,7 @@
 #include "ugp_flatten.hpp"
 
 #include <algorithm>
+#include <unordered_map>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -63,7 +64,16 @@ int flatten(const ugp_tree_desc &t, const Options &opt, FlatMat &out, std::strin
         if (child_off[j + 1] == child_off[j]) leaves[j] = 1;
         if (j > 0) { sub[t.parent[j]] += sub[j]; leaves[t.parent[j]] += leaves[j]; }
     }
-    // largest subtree last
+    // hdown[j] = own mutation words of j + the largest number of mutation words on a path j -> descendant:
+    // no node of j's subtree (j included) costs less than D(parent(j)) - hdown[j]
+    std::vector<uint32_t> hdown(N, 0);
+    for (uint64_t j = N; j-- > 0;) {
+        uint32_t nw = 0;
+        for (uint64_t i = t.mut_off[j]; i < t.mut_off[j + 1] && i < M; i++) nw += t.mut_pos[i] >= 0;
+        hdown[j] += nw;
+        if (j > 0) hdown[t.parent[j]] = std::max(hdown[t.parent[j]], hdown[j]);   // (the parent's own words are added when it is visited)
+    }
+    // largest subtree last; the others by descending hdown (the sibling pruning records rely on it)
     for (uint64_t j = 0; j < N; j++) {
         uint32_t b = child_off[j], e = child_off[j + 1];
         if (e - b < 2) continue;
@@ -72,6 +82,7 @@ int flatten(const ugp_tree_desc &t, const Options &opt, FlatMat &out, std::strin
         uint32_t c = children[best];
         for (uint32_t k = best; k + 1 < e; k++) children[k] = children[k + 1];
         children[e - 1] = c;
+        if (e - b > 2) std::stable_sort(children.begin() + b, children.begin() + e - 1, [&](uint32_t x, uint32_t y) { return hdown[x] > hdown[y]; });
     }
     flat_lap("subtree sizes");
     // ---- tie rank: ascending (n_leaves, j)
@@ -330,6 +341,30 @@ int flatten(const ugp_tree_desc &t, const Options &opt, FlatMat &out, std::strin
         subw[p] += subw[j] + (dropped[j] ? 0u : 1u + nw);
     }
     flat_lap("  hsub/subw");
+    // sibling records.  last_eff[p] = p's last effective child; for a non-last effective child j:
+    // suffix_h[j] = max hdown over j and the non-last effective siblings after it, big_after[j] = how many of
+    // those later siblings carry a pruning record of their own (a jump that the sibling record can save)
+    std::vector<uint32_t> last_eff(N, UINT32_MAX), suffix_h(N, 0), big_after(N, 0), sib_slot(N, UINT32_MAX);
+    for (uint64_t p = 0; p < N; p++) {
+        const uint32_t b = child_off[p], e = child_off[p + 1];
+        uint32_t last = UINT32_MAX;
+        for (uint32_t k = e; k-- > b;) if (!dropped[children[k]]) { last = children[k]; break; }
+        last_eff[p] = last;
+        uint32_t run_h = 0, run_big = 0;
+        for (uint32_t k = e; k-- > b;) {
+            const uint32_t c = children[k];
+            if (dropped[c] || c == last) continue;
+            big_after[c] = run_big;
+            run_h = std::max(run_h, hdown[c]);
+            suffix_h[c] = run_h;
+            if (subw[c] >= opt.prune_min_words && hsub[c] <= 255) run_big++;
+        }
+    }
+    std::vector<std::vector<uint32_t>> sib_open;   // per open parent: positions of its unpatched sibling records
+    std::vector<uint32_t> free_sib;
+    std::unordered_map<uint32_t, uint32_t> sib_hdr_pos;   // record position -> position of the header it precedes
+    uint32_t sib_pending_hdr = UINT32_MAX;
+    const bool preamble_only = false;
     struct OpenBig { uint32_t info_pos, own_end, dfs_end; };
     std::vector<OpenBig> open_big;
     auto close_big = [&](uint32_t next_dfs) {   // patch the records of subtrees that end before DFS node next_dfs
@@ -337,7 +372,7 @@ int flatten(const ugp_tree_desc &t, const Options &opt, FlatMat &out, std::strin
             const OpenBig &b = open_big.back();
             const uint64_t jump = out.stream8.size() - b.own_end;
             const uint32_t hs = (out.stream8[b.info_pos] >> 22) & 0xFFu;
-            out.stream8[b.info_pos] = (jump < (1u << 22) && jump > 0) ? (H_TAG | H_INFO | (hs << 22) | (uint32_t)jump) : (H_TAG | H_NOP);
+            out.stream8[b.info_pos] = (jump <= INFO_JUMP_MASK && jump > 0) ? (H_TAG | H_INFO | (hs << 22) | (uint32_t)jump) : (H_TAG | H_NOP);
             open_big.pop_back();
         }
     };
@@ -357,11 +392,37 @@ int flatten(const ugp_tree_desc &t, const Options &opt, FlatMat &out, std::strin
             uint32_t j = out.dfs2bfs[d];
             close_big(d);
             if (dropped[j]) continue;
+            // sibling record: j is a non-last effective child and at least one more non-last sibling with a
+            // pruning record of its own follows (otherwise there is no jump to save)
+            if (j != 0) {
+                const uint32_t p = t.parent[j];
+                if (last_eff[p] == j) {   // p's last child starts here: the pending sibling records of p jump to this word
+                  if (sib_slot[p] != UINT32_MAX) {
+                    for (uint32_t pos8 : sib_open[sib_slot[p]]) {
+                        const uint64_t jump = out.stream8.size() - sib_hdr_pos[pos8];
+                        uint32_t &w = out.stream8[pos8];
+                        w = (jump <= INFO_JUMP_MASK && jump > 0) ? (w | (uint32_t)jump) : (H_TAG | H_NOP);
+                    }
+                    sib_open[sib_slot[p]].clear();
+                    free_sib.push_back(sib_slot[p]);
+                    sib_slot[p] = UINT32_MAX;
+                  }
+                } else if (big_after[j] >= 1 && suffix_h[j] <= 255 && !preamble_only) {
+                    if (sib_slot[p] == UINT32_MAX) {
+                        if (free_sib.empty()) { free_sib.push_back((uint32_t)sib_open.size()); sib_open.emplace_back(); }
+                        sib_slot[p] = free_sib.back(); free_sib.pop_back();
+                    }
+                    sib_open[sib_slot[p]].push_back((uint32_t)out.stream8.size());
+                    sib_pending_hdr = (uint32_t)out.stream8.size();
+                    out.stream8.push_back(H_TAG | H_INFO | H_SIB | (suffix_h[j] << 22));   // jump patched when the last child starts
+                }
+            }
             const bool big = j != 0 && subw[j] >= opt.prune_min_words && hsub[j] <= 255;
             if (big) {
                 open_big.push_back({(uint32_t)out.stream8.size(), 0u, d + sub[j]});
                 out.stream8.push_back(H_TAG | H_INFO | (hsub[j] << 22));   // jump patched when the subtree closes
             }
+            if (sib_pending_hdr != UINT32_MAX) { sib_hdr_pos[sib_pending_hdr] = (uint32_t)out.stream8.size(); sib_pending_hdr = UINT32_MAX; }
             emit8(out.stream8, j, false);
             if (big) open_big.back().own_end = (uint32_t)out.stream8.size();
         }

@@ -49,10 +49,17 @@ constexpr uint32_t T_PRUNE_MIN_DWORDS = 24;  // subtrees shorter than this are n
 //       H_CHUNK_END (alone) closes a chunk: publish the chunk-local minimum and reset
 //       H_NOP     padding
 //       H_INFO    (alone, in front of the header of a node with a large subtree) pruning record:
-//                 [21:0] jump = stream words occupied by the node's descendants,
+//                 [20:0] jump = stream words occupied by the node's descendants,
 //                 [29:22] hsub = largest number of mutation words on any path node -> descendant;
 //                 every descendant d has cost(d) >= D(node) - hsub (each mutation lowers D by at most 1),
 //                 so the subtree can be skipped when D(node,s) - hsub > upper bound of best(s) for all s
+//       H_INFO | H_SIB (alone, in front of a non-last child c_i of a node p, before c_i's own H_INFO):
+//                 sibling record: [20:0] jump = stream words from c_i's header to the start of p's last child,
+//                 [29:22] hs = max over the remaining non-last children c_j (j >= i) of (mutation words of c_j +
+//                 hsub(c_j)); every node d of those subtrees has cost(d) >= D(p) - hs, so when
+//                 D(p,s) - hs > upper bound of best(s) for all s they are all skipped with one jump.  The
+//                 non-last children are emitted in descending order of that quantity, so hs only shrinks.
+//                 (Both kinds of record keep their jump in 21 bits.)
 //     The root is emitted as two records: its D record (rslot = RS_BOTTOM,
 //     H_NOSCORE) followed by a scoring pseudo-node (RS_REG, H_SKIPD | H_FREE |
 //     H_END) whose cost is D(parent) = D(root): cost(root) = D(root), always
@@ -62,8 +69,10 @@ constexpr uint32_t T_PRUNE_MIN_DWORDS = 24;  // subtrees shorter than this are n
 //       M_FLUSH  15 mutations accumulated in the 4-bit counters: spill them
 //       M_END    last mutation word of the node
 constexpr uint32_t H_TAG = 1u << 31, H_SKIPD = 1u << 12, H_NOSCORE = 1u << 13, H_END = 1u << 16,
-                   H_FREE = 1u << 17, H_CHUNK_END = 1u << 18, H_NOP = 1u << 19, H_INFO = 1u << 30;
-constexpr uint32_t PRUNE_MIN_WORDS = 8;     // only subtrees at least this long carry a pruning record
+                   H_FREE = 1u << 17, H_CHUNK_END = 1u << 18, H_NOP = 1u << 19, H_INFO = 1u << 30,
+                   H_SIB = 1u << 21;   // with H_INFO: sibling record
+constexpr uint32_t INFO_JUMP_MASK = (1u << 21) - 1u;
+constexpr uint32_t PRUNE_MIN_WORDS = 6;     // only subtrees at least this long carry a pruning record
 constexpr uint32_t M_FLUSH = 1u << 28, M_END = 1u << 30;
 constexpr uint32_t MAX_SITES = 1u << 22;
 constexpr uint32_t MAX_NODE_MUTS = 65534;   // 0xFFFF marks a pruning pseudo-record of the tie stream

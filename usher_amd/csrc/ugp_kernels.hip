@@ -472,9 +472,13 @@ __global__ void __launch_bounds__(64) k_best8(Best8Args a) {
     // pruning: ub1 = (upper bound of best(s)) + 1 per sample, refreshed from / published to a.ub at chunk ends
     bool prune = false;        // uniform; only while walking the body (phase 1)
     bool have_info = false;    // uniform
+    bool have_sinfo = false;   // uniform: a sibling record waits for the next header
+    uint32_t sinfo = 0;        // uniform
     uint32_t info = 0;         // uniform: pending pruning record
     uint32_t skip_to = 0;      // uniform: restart request (0 = none)
     uint64_t n_skipped = 0;    // uniform (STATS): words jumped over
+    uint32_t run_nodes = 0;    // uniform (STATS): nodes completed since the last restart
+    uint64_t n_first_skip = 0; // uniform (STATS): jumps decided by the first node after a restart
     // (the tests below use the kernel argument, not the per-lane pointer: a condition derived from `lane`
     // is formally divergent, and one such flag turned the whole walk's control flow -- jump target, open
     // header, position -- into vector registers with exec-mask branches)
@@ -527,7 +531,12 @@ __global__ void __launch_bounds__(64) k_best8(Best8Args a) {
         if (w & H_TAG) {
             if (w & (H_NOP | H_CHUNK_END | H_INFO)) {
                 // (H_INFO first: the jump length of a pruning record overlaps the other flag bits)
-                if (w & H_INFO) { if (prune) { info = w; have_info = true; } }
+                if (w & H_INFO) {
+                    if (prune) {
+                        if (w & H_SIB) { sinfo = w; have_sinfo = true; }   // about the node that follows and its later siblings
+                        else { info = w; have_info = true; }               // about the node that follows and its descendants
+                    }
+                }
                 else if (w & H_CHUNK_END) {
                     // a chunk with a candidate (or a due exchange of bounds) is closed by the restart code, which may
                     // store; any other chunk just ends here, inside the pipeline
@@ -552,6 +561,22 @@ __global__ void __launch_bounds__(64) k_best8(Best8Args a) {
             } else {
                 const u32x4 t = slot_load(rslot);
                 dpar.v[0] = t.x; dpar.v[1] = t.y; dpar.v[2] = t.z; dpar.v[3] = t.w;
+            }
+            if (have_sinfo) {   // sibling record: can this child and the non-last siblings after it all be skipped?
+                have_sinfo = false;
+                const uint32_t hs = ((sinfo >> 22) & 0xFFu) * 0x00010001u;
+                uint32_t bad = 0;   // non-zero where D(parent,s) - hs <= upper bound of best(s)
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const uint32_t t1 = pk_add(ub1.v[j], hs);
+                    bad |= pk_min(dpar.v[j], t1) ^ t1;
+                }
+                if (__builtin_amdgcn_ballot_w64(bad != 0) == 0) {
+                    skip_to = pos + (sinfo & INFO_JUMP_MASK);   // the start of the parent's last child
+                    have_info = false;
+                    if (STATS) n_skipped += sinfo & INFO_JUMP_MASK;
+                    return;
+                }
             }
             if (!(w & H_END)) return;
         } else {
@@ -625,10 +650,11 @@ __global__ void __launch_bounds__(64) k_best8(Best8Args a) {
                 bad |= pk_min(dcur.v[j], t1) ^ t1;
             }
             if (__builtin_amdgcn_ballot_w64(bad != 0) == 0) {
-                skip_to = pos + 1 + (info & 0x3FFFFFu);
-                if (STATS) n_skipped += info & 0x3FFFFFu;
+                skip_to = pos + 1 + (info & INFO_JUMP_MASK);
+                if (STATS) { n_skipped += info & 0x3FFFFFu; if (run_nodes == 0) n_first_skip++; }
             }
         }
+        if (STATS) run_nodes++;
     };
 
     // Software pipeline over groups of 8 words, four stages deep:
@@ -686,7 +712,7 @@ __global__ void __launch_bounds__(64) k_best8(Best8Args a) {
                 X[k] = __builtin_amdgcn_raw_buffer_load_b32(trsrc, lane4, (((m0 >> k) & 1u) ? (w & 0x3FFFFFu) : 0u) << 8, 0);
             }
             skip_to = 0;
-            if (STATS) { t_restart += __builtin_amdgcn_s_memtime() - t_r0 + (X[0] & 0u); n_restart++; }
+            if (STATS) { t_restart += __builtin_amdgcn_s_memtime() - t_r0 + (X[0] & 0u); n_restart++; run_nodes = 0; }
             bool first = true;   // uniform: still inside the first group of this run
             if (cautious) {
                 // Sparse regime (runs of a few words between jumps): evaluate the first group before
@@ -743,6 +769,7 @@ __global__ void __launch_bounds__(64) k_best8(Best8Args a) {
         const unsigned long long tw = __builtin_amdgcn_s_memtime() - t_wave0;
         unsigned long long *st = (unsigned long long *)a.stats;
         atomicAdd(st + 0, (unsigned long long)n_skipped);
+        atomicAdd(st + 26, (unsigned long long)n_first_skip);
         atomicAdd(st + 1, (unsigned long long)n_restart);
         atomicAdd(st + 2, (unsigned long long)t_restart);
         atomicAdd(st + 3, tw);
