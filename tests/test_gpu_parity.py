@@ -358,13 +358,14 @@ def test_randomised_trees_and_scheduling_knobs(seed, monkeypatch):
     ot = capi.OracleTree(arrays)
     want = [ot.place(s, want_ties=False) for s in queries]
     knobs = {"UGP_COARSE_MIN_NODES": "0", "UGP_UNIT_CHUNKS": str(int(rng.integers(1, 9))), "UGP_HEAVY_CHUNKS": str(int(rng.integers(1, 9))),
+             "UGP_LDS_SLOTS": str(int(rng.integers(1, 10))),   # few LDS slots: the others go through the global scratch
              "UGP_UB_EVERY": str(int(rng.choice([1, 2, 7, 1000]))), "UGP_PRUNE_MIN_WORDS": str(int(rng.choice([2, 8, 40])))}
     if rng.random() < 0.3:
         knobs["UGP_NO_LPT"] = "1"
     if rng.random() < 0.2:
         knobs["UGP_NO_SEED"] = "1"
     for k in ("UGP_COARSE_MIN_NODES", "UGP_UNIT_CHUNKS", "UGP_HEAVY_CHUNKS", "UGP_UB_EVERY", "UGP_PRUNE_MIN_WORDS", "UGP_NO_LPT", "UGP_NO_SEED",
-              "UGP_NO_SORT", "UGP_NO_PRUNE", "UGP_FORCE_V1"):
+              "UGP_NO_SORT", "UGP_NO_PRUNE", "UGP_FORCE_V1", "UGP_LDS_SLOTS"):
         monkeypatch.delenv(k, raising=False)
     for k, v in knobs.items():
         monkeypatch.setenv(k, v)

@@ -83,7 +83,7 @@ struct ugp_mat {
     // per-call workspaces (grown on demand)
     DevBuf<uint32_t> d_table, d_dbottom, d_part_best, d_part_cnt, d_part_key;
     DevBuf<uint8_t> d_lflag;
-    DevBuf<uint32_t> d_lbest, d_gbest, d_gbest_part, d_items, d_nitems, d_cnt, d_key, d_active, d_ub, d_queue, d_gstart, d_hlen;
+    DevBuf<uint32_t> d_lbest, d_gbest, d_gbest_part, d_items, d_nitems, d_cnt, d_key, d_active, d_ub, d_queue, d_gstart, d_hlen, d_cold;
     DevBuf<uint64_t> d_stats;
     uint64_t last_words_total = 0;
     // locality sort (speed only): a coarse MAT of the top of the tree and the map coarse BFS index -> DFS rank in the full tree
@@ -304,6 +304,16 @@ int run_place(ugp_mat *m, ugp_qset *qs, int mode, ugp_result *d_out, int32_t *d_
             b.stats = getenv("UGP_STATS") ? m->d_stats.p : nullptr;   // the counters are two contended atomics per skip: debug only
             m->last_words_total += (uint64_t)n_tiles512 * m->stream8_dwords;
             b.max_slots = f.max_slots;
+            // LDS holds the hot slots only (the kernel's registers allow 6 waves per SIMD, 13 KB of LDS per wave
+            // would stop at 3); the colder ones, touched once per ~1,300 words, go to a small global scratch
+            b.lds_slots = std::min<uint32_t>(f.max_slots, 8);
+            if (const char *e = getenv("UGP_LDS_SLOTS")) b.lds_slots = std::min<uint32_t>(f.max_slots, (uint32_t)std::max(1, atoi(e)));
+            {
+                int n_cu = 0;
+                HIP_TRY(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, m->device));
+                HIP_TRY(m->d_cold.reserve((size_t)std::max(n_cu, 1) * 32 * std::max<uint32_t>(f.max_slots - b.lds_slots, 1) * 256));
+                b.cold = m->d_cold.p;
+            }
             b.active = m->d_active.p; b.active_words = active_words;
             HIP_TRY(ugp::launch_best8(b, f.max_slots, s));
             HIP_TRY(hipEventRecord(es.ev[2], s));

@@ -527,7 +527,15 @@ __global__ void __launch_bounds__(64) k_best8(Best8Args a) {
     // `pos` = index of the word inside the wave's range.  A step may ask the pipeline to restart at
     // another position through skip_to (chunk end: publish results outside the load pipeline; pruning:
     // jump over a subtree).
-    auto step = [&](uint32_t w, uint32_t x, uint32_t pos) {
+    // Saved-D slots beyond a.lds_slots live in a small global scratch (one access per ~1,300 words at 10M
+    // nodes; 8 KB of LDS per wave instead of 13 lets 20 waves share a CU).  The pipelined copies of `step`
+    // (SLOW = false) do not touch it -- a store there would share vmcnt with the row loads and force
+    // vmcnt(0) waits: a node that reads or writes a cold slot asks for a restart at its header, and the
+    // restart code walks that one node with the SLOW copy, which accesses the scratch directly.
+    uint32_t *coldp = a.cold + ((uint64_t)blockIdx.x * (a.max_slots > a.lds_slots ? a.max_slots - a.lds_slots : 0u) * 64 + lane) * 4;
+    bool replay = false;       // uniform: restart at skip_to - 1 and walk one node with the SLOW copy
+    auto step = [&](uint32_t w, uint32_t x, uint32_t pos, auto slow_tag) {
+        constexpr bool SLOW = decltype(slow_tag)::value;
         if (w & H_TAG) {
             if (w & (H_NOP | H_CHUNK_END | H_INFO)) {
                 // (H_INFO first: the jump length of a pruning record overlaps the other flag bits)
@@ -550,14 +558,24 @@ __global__ void __launch_bounds__(64) k_best8(Best8Args a) {
                 }
                 return;
             }
-            hdr = w;
             const uint32_t rslot = w & 63u;
+            if (!SLOW) {
+                const uint32_t ws = (w >> 6) & 63u;
+                if ((rslot < RS_BOTTOM && rslot >= a.lds_slots) || (ws != WS_NONE && ws >= a.lds_slots)) {
+                    replay = true; skip_to = pos + 1;   // (nothing of this node has been touched yet)
+                    return;
+                }
+            }
+            hdr = w;
             if (rslot == RS_REG) {
 #pragma unroll
                 for (int j = 0; j < 4; j++) dpar.v[j] = dcur.v[j];
             } else if (rslot == RS_BOTTOM) {
 #pragma unroll
                 for (int j = 0; j < 4; j++) dpar.v[j] = dbot.v[j];
+            } else if (SLOW && rslot >= a.lds_slots) {
+                const u32x4 t = *(const u32x4 *)(coldp + (uint64_t)(rslot - a.lds_slots) * 256);
+                dpar.v[0] = t.x; dpar.v[1] = t.y; dpar.v[2] = t.z; dpar.v[3] = t.w;
             } else {
                 const u32x4 t = slot_load(rslot);
                 dpar.v[0] = t.x; dpar.v[1] = t.y; dpar.v[2] = t.z; dpar.v[3] = t.w;
@@ -605,7 +623,11 @@ __global__ void __launch_bounds__(64) k_best8(Best8Args a) {
 #pragma unroll
                 for (int j = 0; j < 4; j++) dcur.v[j] = pk_add(pk_sub(pk_add(dpar.v[j], ex4(accP, j)), ex4(accC, j)), carryD.v[j]);
                 const uint32_t wslot = (hdr >> 6) & 63u;
-                if (wslot != WS_NONE) slot_store(wslot, u32x4{dcur.v[0], dcur.v[1], dcur.v[2], dcur.v[3]});
+                if (wslot != WS_NONE) {
+                    if (SLOW && wslot >= a.lds_slots)
+                        *(u32x4 *)(coldp + (uint64_t)(wslot - a.lds_slots) * 256) = u32x4{dcur.v[0], dcur.v[1], dcur.v[2], dcur.v[3]};
+                    else slot_store(wslot, u32x4{dcur.v[0], dcur.v[1], dcur.v[2], dcur.v[3]});
+                }
             }
             if (!(hdr & H_NOSCORE)) {
 #pragma unroll
@@ -625,7 +647,11 @@ __global__ void __launch_bounds__(64) k_best8(Best8Args a) {
 #pragma unroll
                 for (int j = 0; j < 4; j++) dcur.v[j] = pk_sub(pk_add(dpar.v[j], ex4(accP, j)), ex4(accC, j));
                 const uint32_t wslot = (hdr >> 6) & 63u;
-                if (wslot != WS_NONE) slot_store(wslot, u32x4{dcur.v[0], dcur.v[1], dcur.v[2], dcur.v[3]});
+                if (wslot != WS_NONE) {
+                    if (SLOW && wslot >= a.lds_slots)
+                        *(u32x4 *)(coldp + (uint64_t)(wslot - a.lds_slots) * 256) = u32x4{dcur.v[0], dcur.v[1], dcur.v[2], dcur.v[3]};
+                    else slot_store(wslot, u32x4{dcur.v[0], dcur.v[1], dcur.v[2], dcur.v[3]});
+                }
             }
             if (!(hdr & H_NOSCORE)) {
                 uint32_t z = accC | (accC >> 1);
@@ -722,7 +748,7 @@ __global__ void __launch_bounds__(64) k_best8(Best8Args a) {
                 for (int k = 0; k < (int)GRP; k++) {
                     const uint32_t w = rdlane(w0, k);
                     const uint32_t ref_row = 0x11111111u << ((w >> 26) & 3u);
-                    if (!skip_to) step(w, ((m0 >> k) & 1u) ? X[k] : ref_row, off + k);
+                    if (!skip_to) step(w, ((m0 >> k) & 1u) ? X[k] : ref_row, off + k, std::false_type{});
                 }
                 if (!skip_to) {   // the run goes on: bring the pipeline to its steady state one group further
                     m1 = active_mask(w1, load_bits(w1));
@@ -748,7 +774,7 @@ __global__ void __launch_bounds__(64) k_best8(Best8Args a) {
                 for (int k = 0; k < (int)GRP; k++) {
                     const uint32_t w = rdlane(w0, k);
                     const uint32_t ref_row = 0x11111111u << ((w >> 26) & 3u);   // every sample carries the reference base
-                    if (!skip_to) step(w, ((m0 >> k) & 1u) ? X[k] : ref_row, off + k);   // words after a restart request are dead
+                    if (!skip_to) step(w, ((m0 >> k) & 1u) ? X[k] : ref_row, off + k, std::false_type{});   // words after a restart request are dead
                     const uint32_t wn = rdlane(w1, k);
                     X[k] = __builtin_amdgcn_raw_buffer_load_b32(trsrc, lane4, (((m1 >> k) & 1u) ? (wn & 0x3FFFFFu) : 0u) << 8, 0);
                 }
@@ -760,6 +786,22 @@ __global__ void __launch_bounds__(64) k_best8(Best8Args a) {
             }
             if (!skip_to) break;   // walked to the end of the range
             cautious = first;
+            if (replay) {
+                // the node whose header sits at skip_to - 1 uses a cold slot: walk it here, word by word
+                replay = false;
+                uint32_t p = skip_to - 1u;
+                skip_to = 0;
+                for (;;) {
+                    const uint32_t w = (uint32_t)__builtin_amdgcn_readfirstlane((int)sp[p]);
+                    uint32_t x = 0;
+                    if (!(w & H_TAG)) x = __builtin_amdgcn_raw_buffer_load_b32(trsrc, lane4, (w & 0x3FFFFFu) << 8, 0);
+                    step(w, x, p, std::true_type{});
+                    p++;
+                    if (skip_to || ((w & H_TAG) ? (w & H_END) != 0 : (w & M_END) != 0)) break;
+                }
+                __builtin_amdgcn_s_waitcnt(0);   // (a cold slot written here may be read by the very next node)
+                if (!skip_to) { off = p; continue; }
+            }
             // restart request: close every chunk whose end marker lies before the new position
             while (chunk < c1 && skip_to > a.chunk8_body_off[chunk + 1] - 1u - begin) chunk_end();
             off = skip_to;
@@ -1002,7 +1044,7 @@ hipError_t launch_merge(const uint32_t *part_best, const uint32_t *part_cnt, con
 }
 
 hipError_t launch_best8(const Best8Args &a, uint32_t max_slots, hipStream_t s) {
-    const size_t lds = (size_t)max_slots * 64 * 16;
+    const size_t lds = (size_t)a.lds_slots * 64 * 16;
     // persistent grid: as many one-wave blocks as the device keeps resident, never more than there are units
     static int per_cu = 0, n_cu = 0;
     static size_t lds_of = ~(size_t)0;

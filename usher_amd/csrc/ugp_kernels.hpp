@@ -35,6 +35,8 @@ struct Best8Args {
     const uint32_t *dbottom;   // [n_tiles*512]
     uint32_t n_sites, n_chunks, n_groups, n_tiles;   // n_tiles = 512-sample tiles
     uint32_t max_slots;
+    uint32_t lds_slots;        // saved-D slots kept in LDS (1 KB each per wave); the colder ones live in `cold`
+    uint32_t *cold;            // [resident waves][max_slots - lds_slots][64][4]
     const uint32_t *active;    // [n_tiles][active_words] bit per site: some sample of the tile is not reference there
     uint32_t active_words;
     uint32_t *lbest;           // [n_chunks][n_tiles][64][4] packed u16 pairs; a record exists only where lflag is set
