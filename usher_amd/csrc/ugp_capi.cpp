@@ -197,7 +197,7 @@ int run_place(ugp_mat *m, ugp_qset *qs, int mode, ugp_result *d_out, int32_t *d_
         const bool use8 = packed_ok;
         uint32_t G = pick_groups(m, n_tiles);
         if (use8) {   // work units of a few chunks each, pulled from per-XCD queues by persistent waves (see k_best8)
-            uint32_t unit_chunks = 16;
+            uint32_t unit_chunks = 8;
             if (const char *e = getenv("UGP_UNIT_CHUNKS")) unit_chunks = (uint32_t)std::max(1, atoi(e));
             G = std::max<uint32_t>(1, (f.n_chunks + unit_chunks - 1) / unit_chunks);
             // a small batch still has to fill the chip: at least ~4096 units in total
@@ -297,7 +297,7 @@ int run_place(ugp_mat *m, ugp_qset *qs, int mode, ugp_result *d_out, int32_t *d_
             b.unit_chunks = std::max<uint32_t>(1, (f.n_chunks + G - 1) / G);
             b.ub_every = 128;
             if (const char *e = getenv("UGP_UB_EVERY")) b.ub_every = (uint32_t)std::max(1, atoi(e));
-            b.heavy_chunks = 32;
+            b.heavy_chunks = 16;
             if (const char *e = getenv("UGP_HEAVY_CHUNKS")) b.heavy_chunks = (uint32_t)std::max(1, atoi(e));
             HIP_TRY(m->d_stats.reserve(32));
             if (q0 == 0) { HIP_TRY(hipMemsetAsync(m->d_stats.p, 0, 32 * sizeof(uint64_t), s)); m->last_words_total = 0; }
@@ -306,7 +306,7 @@ int run_place(ugp_mat *m, ugp_qset *qs, int mode, ugp_result *d_out, int32_t *d_
             b.max_slots = f.max_slots;
             // LDS holds the hot slots only (the kernel's registers allow 6 waves per SIMD, 13 KB of LDS per wave
             // would stop at 3); the colder ones, touched once per ~1,300 words, go to a small global scratch
-            b.lds_slots = std::min<uint32_t>(f.max_slots, 8);
+            b.lds_slots = std::min<uint32_t>(f.max_slots, 7);
             if (const char *e = getenv("UGP_LDS_SLOTS")) b.lds_slots = std::min<uint32_t>(f.max_slots, (uint32_t)std::max(1, atoi(e)));
             {
                 int n_cu = 0;
@@ -354,7 +354,7 @@ static int build_coarse(const ugp_tree_desc *t, int device, const std::vector<ui
     if (N < min_nodes || N < 64 || getenv("UGP_NO_SORT")) return UGP_OK;
     std::vector<uint32_t> sub(N, 1);
     for (uint64_t j = N; j-- > 1;) sub[t->parent[j]] += sub[j];
-    uint64_t div = 2048;
+    uint64_t div = 1024;
     if (const char *e = getenv("UGP_COARSE_DIV")) div = (uint64_t)std::max(2, atoi(e));
     const uint64_t target = std::min<uint64_t>(N / 2, std::max<uint64_t>(N / div, std::min<uint64_t>(4096, N / 4)));
     std::vector<uint32_t> sorted_sub(sub);
