@@ -448,6 +448,7 @@ int ugp_mat_create(const ugp_tree_desc *tree, int device, ugp_mat **out) {
     ugp::Options opt;
     if (const char *e = getenv("UGP_CHUNK_NODES")) opt.chunk_nodes = (uint32_t)std::max(1, atoi(e));
     if (const char *e = getenv("UGP_PRUNE_MIN_WORDS")) opt.prune_min_words = (uint32_t)std::max(1, atoi(e));
+    if (getenv("UGP_NO_SIB")) opt.sibling_records = false;
     return mat_create_impl(tree, device, opt, out);
 }
 

@@ -364,7 +364,7 @@ int flatten(const ugp_tree_desc &t, const Options &opt, FlatMat &out, std::strin
     std::vector<uint32_t> free_sib;
     std::unordered_map<uint32_t, uint32_t> sib_hdr_pos;   // record position -> position of the header it precedes
     uint32_t sib_pending_hdr = UINT32_MAX;
-    const bool preamble_only = false;
+    const bool preamble_only = !opt.sibling_records;   // (no sibling records at all)
     struct OpenBig { uint32_t info_pos, own_end, dfs_end; };
     std::vector<OpenBig> open_big;
     auto close_big = [&](uint32_t next_dfs) {   // patch the records of subtrees that end before DFS node next_dfs

@@ -78,8 +78,9 @@ constexpr uint32_t MAX_SITES = 1u << 22;
 constexpr uint32_t MAX_NODE_MUTS = 65534;   // 0xFFFF marks a pruning pseudo-record of the tie stream
 
 struct Options {
-    uint32_t chunk_nodes = 0;   // 0 = automatic (about N/4096, at least 256)
+    uint32_t chunk_nodes = 0;   // 0 = automatic (about N/32768, at least 128)
     uint32_t prune_min_words = PRUNE_MIN_WORDS;   // subtrees at least this long (stream words) carry a pruning record
+    bool sibling_records = true;   // emit H_INFO | H_SIB records
 };
 
 struct FlatMat {
