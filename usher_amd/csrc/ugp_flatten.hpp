@@ -72,7 +72,7 @@ constexpr uint32_t H_TAG = 1u << 31, H_SKIPD = 1u << 12, H_NOSCORE = 1u << 13, H
                    H_FREE = 1u << 17, H_CHUNK_END = 1u << 18, H_NOP = 1u << 19, H_INFO = 1u << 30,
                    H_SIB = 1u << 21;   // with H_INFO: sibling record
 constexpr uint32_t INFO_JUMP_MASK = (1u << 21) - 1u;
-constexpr uint32_t PRUNE_MIN_WORDS = 6;     // only subtrees at least this long carry a pruning record
+constexpr uint32_t PRUNE_MIN_WORDS = 4;     // only subtrees at least this long carry a pruning record
 constexpr uint32_t M_FLUSH = 1u << 28, M_END = 1u << 30;
 constexpr uint32_t MAX_SITES = 1u << 22;
 constexpr uint32_t MAX_NODE_MUTS = 65534;   // 0xFFFF marks a pruning pseudo-record of the tie stream

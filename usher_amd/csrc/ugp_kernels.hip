@@ -476,6 +476,8 @@ __global__ void __launch_bounds__(64) k_best8(Best8Args a) {
     uint32_t sinfo = 0;        // uniform
     uint32_t info = 0;         // uniform: pending pruning record
     uint32_t skip_to = 0;      // uniform: restart request (0 = none)
+    uint32_t cend = 0xFFFFFFFFu;   // uniform: position of the open chunk's end marker (phase 1)
+    bool cend_stale = false;       // uniform: `chunk` advanced inside the pipeline since cend was loaded
     uint64_t n_skipped = 0;    // uniform (STATS): words jumped over
     uint32_t run_nodes = 0;    // uniform (STATS): nodes completed since the last restart
     uint64_t n_first_skip = 0; // uniform (STATS): jumps decided by the first node after a restart
@@ -554,6 +556,7 @@ __global__ void __launch_bounds__(64) k_best8(Best8Args a) {
 #pragma unroll
                         for (int j = 0; j < 4; j++) best.v[j] = 0xFFFFFFFFu;
                         chunk++;
+                        cend_stale = true;
                     }
                 }
                 return;
@@ -716,6 +719,8 @@ __global__ void __launch_bounds__(64) k_best8(Best8Args a) {
             return (uint32_t)__builtin_amdgcn_ballot_w64(act) & ((1u << GRP) - 1u);
         };
         prune = (phase == 1) && can_prune;
+        cend = phase == 1 ? (uint32_t)__builtin_amdgcn_readfirstlane((int)(a.chunk8_body_off[c0 + 1] - 1u - begin)) : 0xFFFFFFFFu;
+        cend_stale = false;
         if (prune && ub_tile != tile) {   // start from what earlier waves of this tile already know
 #pragma unroll
             for (int j = 0; j < 4; j++)
@@ -803,7 +808,16 @@ __global__ void __launch_bounds__(64) k_best8(Best8Args a) {
                 if (!skip_to) { off = p; continue; }
             }
             // restart request: close every chunk whose end marker lies before the new position
-            while (chunk < c1 && skip_to > a.chunk8_body_off[chunk + 1] - 1u - begin) chunk_end();
+            // (the end-marker position of the open chunk is kept in a register: loading it here put a memory round
+            // trip, behind every load still in flight, in front of each refill)
+            if (cend_stale) {
+                cend_stale = false;
+                cend = chunk < c1 ? (uint32_t)__builtin_amdgcn_readfirstlane((int)(a.chunk8_body_off[chunk + 1] - 1u - begin)) : 0xFFFFFFFFu;
+            }
+            while (chunk < c1 && skip_to > cend) {
+                chunk_end();
+                cend = chunk < c1 ? (uint32_t)__builtin_amdgcn_readfirstlane((int)(a.chunk8_body_off[chunk + 1] - 1u - begin)) : 0xFFFFFFFFu;
+            }
             off = skip_to;
         }
     }
