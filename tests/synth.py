@@ -180,3 +180,42 @@ def caterpillar_case(seed: int, depth: int, muts_per_node: int, n_queries: int, 
                         "nuc": np.asarray([rows[p][0] for p in ps], dtype=np.int8),
                         "is_missing": np.asarray([rows[p][1] for p in ps], dtype=np.int8)})
     return arrays, queries
+
+
+def polytomy_case(seed: int, fanouts=(40, 60, 25), n_queries: int = 600, genome_len: int = 5000, n_sites: int = 400):
+    """A bushy tree: every internal node of level L has fanouts[L] children (huge polytomies, as in trees of
+    densely sampled outbreaks), 0-2 mutations per branch, many leaves identical to their parent."""
+    rng = np.random.default_rng(seed)
+    ref = rng.choice(ONEHOT, size=genome_len + 1)
+    sites = np.sort(rng.choice(np.arange(1, genome_len + 1), size=n_sites, replace=False))
+    parent = [-1]
+    level = [0]
+    frontier = [0]
+    for L, k in enumerate(fanouts):   # BFS construction: children of a node are contiguous, parents non-decreasing
+        nxt = []
+        for p in frontier:
+            kk = k if L == 0 else int(rng.integers(1, k + 1))
+            for _ in range(kk):
+                parent.append(p); level.append(L + 1); nxt.append(len(parent) - 1)
+        frontier = nxt
+    n = len(parent)
+    parent = np.asarray(parent, dtype=np.int64)
+    state = [None] * n
+    mut_off = np.zeros(n + 1, dtype=np.int64)
+    pos, rf, par, nuc = [], [], [], []
+    for j in range(n):
+        st = {} if parent[j] < 0 else dict(state[parent[j]])
+        k = 0 if parent[j] < 0 else int(rng.choice([0, 0, 0, 1, 1, 2]))
+        for p in (np.sort(rng.choice(sites, size=k, replace=False)) if k else []):
+            p = int(p)
+            cur = st.get(p, int(ref[p]))
+            a = int(rng.choice([x for x in ONEHOT if x != cur]))
+            pos.append(p); rf.append(int(ref[p])); par.append(cur); nuc.append(a)
+            st[p] = a
+        state[j] = st
+        mut_off[j + 1] = len(pos)
+    arrays = {"n": n, "parent": parent, "mut_off": mut_off, "mut_pos": np.asarray(pos, dtype=np.int32),
+              "mut_ref": np.asarray(rf, dtype=np.int8), "mut_par": np.asarray(par, dtype=np.int8),
+              "mut_nuc": np.asarray(nuc, dtype=np.int8), "names": ["n%d" % j for j in range(n)]}
+    queries = [random_query(rng, arrays, ref, sites, state, genome_len, name="Q%d" % i, n_ambig=(0, 0, 1, 3)) for i in range(n_queries)]
+    return arrays, queries

@@ -374,3 +374,20 @@ def test_randomised_trees_and_scheduling_knobs(seed, monkeypatch):
     for i, w in enumerate(want):
         _assert_same(res, i, w, "%s #%d" % (knobs, i))
     pl.close()
+
+
+def test_huge_polytomies(monkeypatch):
+    """Nodes with tens to thousands of children (root with 2,500), most leaves identical to their parent: the
+    sibling records, the child ordering they rely on and the slot numbering are exercised at their extremes."""
+    for k in ("UGP_COARSE_MIN_NODES",):
+        monkeypatch.setenv(k, "0")
+    for fan, nq in (((2500, 6, 4), 700), ((30, 50, 20), 900)):
+        arrays, queries = synth.polytomy_case(31 + len(fan) + fan[0], fanouts=fan, n_queries=nq)
+        ot = capi.OracleTree(arrays)
+        want = [ot.place(s, want_ties=False) for s in queries]
+        for chunk_nodes in (None, 11):
+            pl = Placer(arrays, chunk_nodes=chunk_nodes)
+            res = pl.place(QueryBatch(queries))
+            for i, w in enumerate(want):
+                _assert_same(res, i, w, "polytomy %s #%d" % (fan, i))
+            pl.close()
