@@ -874,26 +874,30 @@ __device__ __forceinline__ uint32_t pk_lookup(const uint32_t *packed, uint32_t t
 __global__ void k_select(const uint32_t *__restrict__ lbest, const uint8_t *__restrict__ lflag, const uint32_t *__restrict__ gbest, uint32_t n_chunks,
                          uint32_t n_tiles, uint32_t n_queries, uint32_t *__restrict__ items,
                          uint32_t *__restrict__ n_items, uint32_t cap) {
+    // one thread per (chunk, 512-sample tile): most pairs have no record and leave after one byte
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (uint64_t)n_chunks * n_tiles) return;
+    if (!lflag[i]) return;
+    const uint32_t c = (uint32_t)(i / n_tiles), tile = (uint32_t)(i % n_tiles);
     const uint32_t n_t64 = n_tiles * 8;
-    if (i >= (uint64_t)n_chunks * n_t64) return;
-    const uint32_t c = (uint32_t)(i / n_t64), t64 = (uint32_t)(i % n_t64);
-    if ((uint64_t)t64 * 64 >= n_queries) return;
-    if (!lflag[(uint64_t)c * n_tiles + (t64 >> 3)]) return;
-    // the 64 samples of t64 are lanes (t64&7)*8 .. +8 of tile t64>>3: 32 consecutive dwords
-    const uint64_t off = ((uint64_t)(t64 >> 3) * 64 + (t64 & 7u) * 8) * 4;
-    const uint32_t *lb = lbest + (uint64_t)c * n_tiles * 256 + off;
-    const uint32_t *gb = gbest + off;
-    bool hit = false;
-    for (uint32_t k = 0; k < 32; k++) {
-        const uint32_t x = lb[k] ^ gb[k];
-        const uint32_t q0 = t64 * 64 + (k >> 2) * 8 + (k & 3u);   // low half: nibble (k&3); high half: +4
-        if ((x & 0xFFFFu) == 0 && q0 < n_queries) hit = true;
-        if ((x >> 16) == 0 && q0 + 4 < n_queries) hit = true;
-    }
-    if (hit) {
-        const uint32_t idx = atomicAdd(n_items, 1u);
-        if (idx < cap) items[idx] = c * n_t64 + t64;
+    for (uint32_t t8 = 0; t8 < 8; t8++) {
+        const uint32_t t64 = tile * 8 + t8;
+        if ((uint64_t)t64 * 64 >= n_queries) break;
+        // the 64 samples of t64 are lanes (t64&7)*8 .. +8 of tile t64>>3: 32 consecutive dwords
+        const uint64_t off = ((uint64_t)tile * 64 + t8 * 8) * 4;
+        const uint32_t *lb = lbest + (uint64_t)c * n_tiles * 256 + off;
+        const uint32_t *gb = gbest + off;
+        bool hit = false;
+        for (uint32_t k = 0; k < 32; k++) {
+            const uint32_t x = lb[k] ^ gb[k];
+            const uint32_t q0 = t64 * 64 + (k >> 2) * 8 + (k & 3u);   // low half: nibble (k&3); high half: +4
+            if ((x & 0xFFFFu) == 0 && q0 < n_queries) hit = true;
+            if ((x >> 16) == 0 && q0 + 4 < n_queries) hit = true;
+        }
+        if (hit) {
+            const uint32_t idx = atomicAdd(n_items, 1u);
+            if (idx < cap) items[idx] = c * n_t64 + t64;
+        }
     }
 }
 
@@ -1089,7 +1093,7 @@ hipError_t launch_phase2(const PlaceArgs &a, const uint32_t *lbest, const uint8_
     hipLaunchKernelGGL(k_gbest, dim3((per_chunk + 255) / 256, slices), dim3(256), 0, s, lbest, lflag, a.n_chunks, n_tiles512, gbest_part);
     hipLaunchKernelGGL(k_gbest2, dim3((per_chunk + 255) / 256), dim3(256), 0, s, gbest_part, slices, per_chunk, gbest);
     const uint64_t pairs = (uint64_t)a.n_chunks * n_tiles512 * 8;
-    hipLaunchKernelGGL(k_select, dim3((uint32_t)((pairs + 255) / 256)), dim3(256), 0, s, lbest, lflag, gbest, a.n_chunks,
+    hipLaunchKernelGGL(k_select, dim3((uint32_t)((pairs / 8 + 255) / 256)), dim3(256), 0, s, lbest, lflag, gbest, a.n_chunks,
                        n_tiles512, a.n_queries, items, n_items, cap);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
