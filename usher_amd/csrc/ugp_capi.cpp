@@ -376,6 +376,8 @@ static int build_coarse(const ugp_tree_desc *t, int device, const std::vector<ui
     }
     ugp_tree_desc d{keep.size(), parent.data(), mut_off.data(), pos.data(), ref.data(), par.data(), nuc.data()};
     ugp::Options copt;
+    copt.chunk_nodes = 128;
+    if (const char *e = getenv("UGP_COARSE_CHUNK_NODES")) copt.chunk_nodes = (uint32_t)std::max(1, atoi(e));
     int rc = mat_create_impl(&d, device, copt, &m->coarse, false);
     if (rc != UGP_OK) return rc;
     std::vector<uint32_t> dfs_rank(N), c2d(keep.size());
