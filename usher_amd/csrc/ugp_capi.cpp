@@ -83,7 +83,7 @@ struct ugp_mat {
     // per-call workspaces (grown on demand)
     DevBuf<uint32_t> d_table, d_dbottom, d_part_best, d_part_cnt, d_part_key;
     DevBuf<uint8_t> d_lflag;
-    DevBuf<uint32_t> d_lbest, d_gbest, d_gbest_part, d_items, d_nitems, d_cnt, d_key, d_active, d_ub, d_queue, d_gstart, d_hlen, d_cold;
+    DevBuf<uint32_t> d_lbest, d_gbest, d_gbest_part, d_items, d_nitems, d_cnt, d_key, d_active, d_ub, d_queue, d_gstart, d_hlen, d_cold, d_list, d_list_n;
     DevBuf<uint64_t> d_stats;
     uint64_t last_words_total = 0;
     // locality sort (speed only): a coarse MAT of the top of the tree and the map coarse BFS index -> DFS rank in the full tree
@@ -212,6 +212,8 @@ int run_place(ugp_mat *m, ugp_qset *qs, int mode, ugp_result *d_out, int32_t *d_
         if (use8) {
             HIP_TRY(m->d_lbest.reserve((size_t)f.n_chunks * n_tiles512 * 256));
             HIP_TRY(m->d_lflag.reserve((size_t)f.n_chunks * n_tiles512));
+            HIP_TRY(m->d_list.reserve((size_t)f.n_chunks * n_tiles512));
+            HIP_TRY(m->d_list_n.reserve(n_tiles512));
             HIP_TRY(m->d_gbest.reserve((size_t)n_tiles512 * 256));
             HIP_TRY(m->d_gbest_part.reserve((size_t)ugp::GBEST_SLICES * n_tiles512 * 256));
             HIP_TRY(m->d_ub.reserve((size_t)n_tiles512 * 256));
@@ -317,7 +319,7 @@ int run_place(ugp_mat *m, ugp_qset *qs, int mode, ugp_result *d_out, int32_t *d_
             b.active = m->d_active.p; b.active_words = active_words;
             HIP_TRY(ugp::launch_best8(b, f.max_slots, s));
             HIP_TRY(hipEventRecord(es.ev[2], s));
-            HIP_TRY(ugp::launch_phase2(a, m->d_lbest.p, m->d_lflag.p, m->d_gbest_part.p, m->d_gbest.p, n_tiles512, m->d_items.p, m->d_nitems.p,
+            HIP_TRY(ugp::launch_phase2(a, m->d_lbest.p, m->d_lflag.p, m->d_list.p, m->d_list_n.p, m->d_gbest_part.p, m->d_gbest.p, n_tiles512, m->d_items.p, m->d_nitems.p,
                                        (uint32_t)std::min<uint64_t>(pairs, 0xFFFFFFFFull), m->d_cnt.p, m->d_key.p,
                                        m->d_rank2bfs.p, d_out + q0, order, f.max_slots, s));
         } else {

@@ -837,19 +837,31 @@ __global__ void __launch_bounds__(64) k_best8(Best8Args a) {
     }   // next work unit
 }
 
-// Global minimum per sample over the chunk-local minima: the chunk axis is cut into gridDim.y
-// slices (partial minima in `part`), then k_gbest2 folds the slices.
-__global__ void k_gbest(const uint32_t *__restrict__ lbest, const uint8_t *__restrict__ lflag, uint32_t n_chunks, uint32_t n_tiles,
-                        uint32_t *__restrict__ part /* [gridDim.y][n_tiles*256] */) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;   // dword index within one chunk's record
+// The chunks of each tile that left a record in phase 1 (about 4 % of them), as a list: block = one tile.
+__global__ void k_list_records(const uint8_t *__restrict__ lflag, uint32_t n_chunks, uint32_t n_tiles, uint32_t *__restrict__ list /* [n_tiles][n_chunks] */,
+                               uint32_t *__restrict__ list_n /* [n_tiles] */) {
+    __shared__ uint32_t n;
+    const uint32_t tile = blockIdx.x;
+    if (threadIdx.x == 0) n = 0;
+    __syncthreads();
+    for (uint32_t c = threadIdx.x; c < n_chunks; c += blockDim.x)
+        if (lflag[(uint64_t)c * n_tiles + tile]) list[(uint64_t)tile * n_chunks + atomicAdd(&n, 1u)] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) list_n[tile] = n;
+}
+
+// Global minimum per sample over the chunk-local minima that were recorded: the list of a tile is cut into
+// gridDim.y slices (partial minima in `part`), then k_gbest2 folds the slices.  Block = (tile, slice), thread =
+// one dword of the tile's 1 KB record.
+__global__ void k_gbest(const uint32_t *__restrict__ lbest, const uint32_t *__restrict__ list, const uint32_t *__restrict__ list_n,
+                        uint32_t n_chunks, uint32_t n_tiles, uint32_t *__restrict__ part /* [gridDim.y][n_tiles*256] */) {
+    const uint32_t tile = blockIdx.x, i = tile * 256 + threadIdx.x;
     const uint32_t per_chunk = n_tiles * 256;
-    if (i >= per_chunk) return;
-    const uint32_t c0 = (uint32_t)((uint64_t)blockIdx.y * n_chunks / gridDim.y);
-    const uint32_t c1 = (uint32_t)((uint64_t)(blockIdx.y + 1) * n_chunks / gridDim.y);
+    const uint32_t n = list_n[tile];
+    const uint32_t e0 = (uint32_t)((uint64_t)blockIdx.y * n / gridDim.y), e1 = (uint32_t)((uint64_t)(blockIdx.y + 1) * n / gridDim.y);
+    const uint32_t *l = list + (uint64_t)tile * n_chunks;
     uint32_t m = 0xFFFFFFFFu;
-    const uint32_t tile = i >> 8;
-    for (uint32_t c = c0; c < c1; c++)
-        if (lflag[(uint64_t)c * n_tiles + tile]) m = pk_min(m, lbest[(uint64_t)c * per_chunk + i]);   // records without a flag were never written
+    for (uint32_t e = e0; e < e1; e++) m = pk_min(m, lbest[(uint64_t)l[e] * per_chunk + i]);
     part[(uint64_t)blockIdx.y * per_chunk + i] = m;
 }
 __global__ void k_gbest2(const uint32_t *__restrict__ part, uint32_t n_slices, uint32_t per_chunk,
@@ -871,18 +883,17 @@ __device__ __forceinline__ uint32_t pk_lookup(const uint32_t *packed, uint32_t t
 
 // One thread per (chunk, 64-sample tile): does any of its samples attain its
 // global minimum in this chunk?  If so the pair becomes a phase-2 work item.
-__global__ void k_select(const uint32_t *__restrict__ lbest, const uint8_t *__restrict__ lflag, const uint32_t *__restrict__ gbest, uint32_t n_chunks,
-                         uint32_t n_tiles, uint32_t n_queries, uint32_t *__restrict__ items,
-                         uint32_t *__restrict__ n_items, uint32_t cap) {
-    // one thread per (chunk, 512-sample tile): most pairs have no record and leave after one byte
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (uint64_t)n_chunks * n_tiles) return;
-    if (!lflag[i]) return;
-    const uint32_t c = (uint32_t)(i / n_tiles), tile = (uint32_t)(i % n_tiles);
-    const uint32_t n_t64 = n_tiles * 8;
-    for (uint32_t t8 = 0; t8 < 8; t8++) {
+__global__ void k_select(const uint32_t *__restrict__ lbest, const uint32_t *__restrict__ list, const uint32_t *__restrict__ list_n,
+                         const uint32_t *__restrict__ gbest, uint32_t n_chunks, uint32_t n_tiles, uint32_t n_queries,
+                         uint32_t *__restrict__ items, uint32_t *__restrict__ n_items, uint32_t cap) {
+    // block = one tile; threads stride over (recorded chunk, 64-sample sub-tile) pairs
+    const uint32_t tile = blockIdx.x;
+    const uint32_t n = list_n[tile], n_t64 = n_tiles * 8;
+    const uint32_t *l = list + (uint64_t)tile * n_chunks;
+    for (uint32_t p = threadIdx.x; p < n * 8u; p += blockDim.x) {
+        const uint32_t c = l[p >> 3], t8 = p & 7u;
         const uint32_t t64 = tile * 8 + t8;
-        if ((uint64_t)t64 * 64 >= n_queries) break;
+        if ((uint64_t)t64 * 64 >= n_queries) continue;
         // the 64 samples of t64 are lanes (t64&7)*8 .. +8 of tile t64>>3: 32 consecutive dwords
         const uint64_t off = ((uint64_t)tile * 64 + t8 * 8) * 4;
         const uint32_t *lb = lbest + (uint64_t)c * n_tiles * 256 + off;
@@ -1085,16 +1096,18 @@ hipError_t launch_best8(const Best8Args &a, uint32_t max_slots, hipStream_t s) {
     return hipGetLastError();
 }
 
-hipError_t launch_phase2(const PlaceArgs &a, const uint32_t *lbest, const uint8_t *lflag, uint32_t *gbest_part, uint32_t *gbest, uint32_t n_tiles512,
+hipError_t launch_phase2(const PlaceArgs &a, const uint32_t *lbest, const uint8_t *lflag, uint32_t *list, uint32_t *list_n, uint32_t *gbest_part,
+                         uint32_t *gbest, uint32_t n_tiles512,
                          uint32_t *items, uint32_t *n_items, uint32_t cap, uint32_t *cnt, uint32_t *key,
                          const uint32_t *rank2bfs, ugp_result *out, const uint32_t *order, uint32_t max_slots, hipStream_t s) {
     const uint32_t per_chunk = n_tiles512 * 256;
     const uint32_t slices = std::min<uint32_t>(GBEST_SLICES, a.n_chunks);
-    hipLaunchKernelGGL(k_gbest, dim3((per_chunk + 255) / 256, slices), dim3(256), 0, s, lbest, lflag, a.n_chunks, n_tiles512, gbest_part);
+    hipLaunchKernelGGL(k_list_records, dim3(n_tiles512), dim3(256), 0, s, lflag, a.n_chunks, n_tiles512, list, list_n);
+    hipLaunchKernelGGL(k_gbest, dim3(n_tiles512, slices), dim3(256), 0, s, lbest, list, list_n, a.n_chunks, n_tiles512, gbest_part);
     hipLaunchKernelGGL(k_gbest2, dim3((per_chunk + 255) / 256), dim3(256), 0, s, gbest_part, slices, per_chunk, gbest);
     const uint64_t pairs = (uint64_t)a.n_chunks * n_tiles512 * 8;
-    hipLaunchKernelGGL(k_select, dim3((uint32_t)((pairs / 8 + 255) / 256)), dim3(256), 0, s, lbest, lflag, gbest, a.n_chunks,
-                       n_tiles512, a.n_queries, items, n_items, cap);
+    hipLaunchKernelGGL(k_select, dim3(n_tiles512), dim3(256), 0, s, lbest, list, list_n, gbest, a.n_chunks, n_tiles512, a.n_queries, items,
+                       n_items, cap);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     const size_t lds = (size_t)max_slots * 64 * sizeof(uint32_t);

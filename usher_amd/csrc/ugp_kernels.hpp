@@ -54,7 +54,8 @@ hipError_t launch_best8(const Best8Args &a, uint32_t max_slots, hipStream_t s);
 // a.n_tiles = number of 64-sample tiles; lbest/gbest in the packed 512-tile layout
 constexpr uint32_t GBEST_SLICES = 64;   // chunk-axis slices of the global-minimum reduction
 // gbest_part: [GBEST_SLICES][n_tiles512*256] scratch
-hipError_t launch_phase2(const PlaceArgs &a, const uint32_t *lbest, const uint8_t *lflag, uint32_t *gbest_part, uint32_t *gbest, uint32_t n_tiles512,
+hipError_t launch_phase2(const PlaceArgs &a, const uint32_t *lbest, const uint8_t *lflag, uint32_t *list, uint32_t *list_n, uint32_t *gbest_part,
+                         uint32_t *gbest, uint32_t n_tiles512,
                          uint32_t *items, uint32_t *n_items, uint32_t cap, uint32_t *cnt, uint32_t *key,
                          const uint32_t *rank2bfs, ugp_result *out, const uint32_t *order, uint32_t max_slots, hipStream_t s);
 
