@@ -112,6 +112,8 @@ typedef struct ugp_timing {
     uint32_t reserved;
     uint64_t words_total;   /* packed path: stream words x tiles the dominant kernel had to cover      */
     uint64_t words_skipped; /* ... of which exact lower-bound pruning skipped (0 with UGP_NO_PRUNE)    */
+    float coarse_ms;     /* locality pre-pass of the last call (placement on the coarse top-of-tree MAT), 0 when not run */
+    float reserved2;
 } ugp_timing;
 
 /* Flatten + upload.  device = HIP device ordinal.  Replaces the per-sample

@@ -35,6 +35,13 @@ def lib():
         L.orc_place_sample.argtypes = [P, C.c_int64, P, P, P, P, C.c_int, P, P, P, P, P, P, C.c_int64, P]
         L.orc_place_sample_mt.restype = C.c_int
         L.orc_place_sample_mt.argtypes = [P, C.c_int64, P, P, P, P, C.c_int, P, P, P]
+        L.orc_cf_create.restype = P
+        L.orc_cf_create.argtypes = [P]
+        L.orc_cf_destroy.argtypes = [P]
+        L.orc_cf_place_batch.restype = C.c_int
+        L.orc_cf_place_batch.argtypes = [P, C.c_int64, P, P, P, P, P, C.c_int, P, P, P, P, P, P, C.c_int64]
+        L.orc_cf_scores.restype = C.c_int
+        L.orc_cf_scores.argtypes = [P, C.c_int64, P, P, P, P, P]
         L.orc_node_vecs.restype = C.c_int
         L.orc_node_vecs.argtypes = [P, C.c_int64, P, P, P, P, C.c_int64, C.c_int64] + [P] * 12
         L.orc_fitch_site.restype = C.c_int
@@ -128,6 +135,66 @@ class OracleTree:
 
         return {"excess": pack(ex, nex[0]), "imputed": pack(im, nim[0]), "set_difference": int(sd[0]),
                 "has_unique": bool(hu[0])}
+
+
+class ClosedFormC:
+    """The closed form of mapper2_body (oracle/closed_form.py) as an O(N + M) C sweep per sample, sample-parallel:
+    the checker for EVERY sample of a full-size batch.  Built on an OracleTree (shares its arrays)."""
+
+    def __init__(self, ot: OracleTree):
+        self.ot = ot
+        self.h = lib().orc_cf_create(ot.h)
+        if not self.h:
+            raise ValueError("orc_cf_create failed (tree alleles must be one-hot)")
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().orc_cf_destroy(self.h)
+            self.h = None
+
+    def place_csr(self, ent_off, pos, ref, nuc, is_missing, nthreads: int = 0, tie_cap: int = 0):
+        """Structured result per sample: best, num_best, best_j, has_unique (+ ties lists when tie_cap > 0)."""
+        ent_off = np.ascontiguousarray(ent_off, dtype=np.int64)
+        pos = np.ascontiguousarray(pos, dtype=np.int32)
+        ref = np.ascontiguousarray(ref).astype(np.int8)
+        nuc = np.ascontiguousarray(nuc).astype(np.int8)
+        mis = np.ascontiguousarray(is_missing).astype(np.int8)
+        n = len(ent_off) - 1
+        best = np.zeros(n, np.int32)
+        nb = np.zeros(n, np.int64)
+        bj = np.zeros(n, np.int64)
+        hu = np.zeros(n, np.int8)
+        ties = np.zeros((n, tie_cap), np.int64) if tie_cap else None
+        thu = np.zeros((n, tie_cap), np.int8) if tie_cap else None
+        rc = lib().orc_cf_place_batch(self.h, n, _p(ent_off), _p(pos), _p(ref), _p(nuc), _p(mis), int(nthreads or os.cpu_count() or 1),
+                                      _p(best), _p(nb), _p(bj), _p(hu), _p(ties), _p(thu), tie_cap)
+        if rc != 0:
+            raise ValueError("orc_cf_place_batch: sample rows must be sorted by position without duplicates")
+        out = {"best": best, "num_best": nb, "best_j": bj, "has_unique": hu.astype(bool)}
+        if tie_cap:
+            out["ties"] = [ties[i, :min(int(nb[i]), tie_cap)].copy() for i in range(n)]
+            out["ties_has_unique"] = [thu[i, :min(int(nb[i]), tie_cap)].astype(bool) for i in range(n)]
+        return out
+
+    def place(self, sample: dict, tie_cap: int = 0):
+        off = np.array([0, len(sample["pos"])], np.int64)
+        r = self.place_csr(off, sample["pos"], sample["ref"], sample["nuc"], sample["is_missing"], 1, tie_cap)
+        out = {"best": int(r["best"][0]), "num_best": int(r["num_best"][0]), "best_j": int(r["best_j"][0]), "has_unique": bool(r["has_unique"][0])}
+        if tie_cap:
+            out["ties"] = r["ties"][0]
+            out["ties_has_unique"] = r["ties_has_unique"][0]
+        return out
+
+    def scores(self, sample: dict) -> np.ndarray:
+        pos = np.ascontiguousarray(sample["pos"], dtype=np.int32)
+        ref = np.ascontiguousarray(sample["ref"]).astype(np.int8)
+        nuc = np.ascontiguousarray(sample["nuc"]).astype(np.int8)
+        mis = np.ascontiguousarray(sample["is_missing"]).astype(np.int8)
+        out = np.zeros(self.ot.n, np.int32)
+        rc = lib().orc_cf_scores(self.h, len(pos), _p(pos), _p(ref), _p(nuc), _p(mis), _p(out))
+        if rc != 0:
+            raise ValueError("orc_cf_scores failed")
+        return out
 
 
 def fitch_site(parent: np.ndarray, ref_nuc: int, var_node: np.ndarray, var_nuc: np.ndarray):

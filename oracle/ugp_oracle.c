@@ -467,52 +467,127 @@ int orc_node_vecs(const orc_tree *t, int64_t n_ent, const int32_t *pos, const in
 
 /* ------------------------------------------------- threaded CPU baseline */
 
+/*
+ * Persistent worker pool (the reference keeps its TBB workers alive across
+ * samples, usher.cpp:117; tbb::parallel_for hands out node ranges dynamically,
+ * usher_common.cpp:389).  Workers sleep on a condition variable between
+ * samples; within a sample they pull fixed-size node ranges from an atomic
+ * counter, so deep (expensive) regions of the BFS order do not end up on one
+ * thread.  Test infrastructure: only the timed CPU baseline uses it.
+ */
+#define ORC_GRAIN 2048
+
 typedef struct {
     const orc_tree *t; const orc_mut *sm; int64_t n_sm;
-    int64_t lo, hi; int init_best;
+    int init_best;
     orc_shared sh;
 } orc_job;
 
-static void *orc_worker(void *p) {
-    orc_job *jb = (orc_job *)p;
+typedef struct orc_pool {
+    int nthreads;                 /* workers, not counting the caller */
+    pthread_t *th;
+    pthread_mutex_t mu;
+    pthread_cond_t cv_go, cv_done;
+    uint64_t epoch;               /* bumped per sample */
+    int running, stop;
+    orc_job *jobs;                /* [nthreads + 1], slot nthreads = the caller */
+    int64_t next;                 /* next unclaimed node (atomic) */
+    int64_t n;
+} orc_pool;
+
+static void orc_run_ranges(orc_pool *pl, orc_job *jb) {
     mvec anc = {0, 0, 0};
-    for (int64_t k = jb->lo; k < jb->hi; k++)
-        orc_mapper2(jb->t, k, jb->sm, jb->n_sm, &jb->sh, 0, 0, NULL, NULL, NULL, &anc, NULL);
+    for (;;) {
+        int64_t lo = __atomic_fetch_add(&pl->next, ORC_GRAIN, __ATOMIC_RELAXED);
+        if (lo >= pl->n) break;
+        int64_t hi = lo + ORC_GRAIN < pl->n ? lo + ORC_GRAIN : pl->n;
+        for (int64_t k = lo; k < hi; k++)
+            orc_mapper2(jb->t, k, jb->sm, jb->n_sm, &jb->sh, 0, 0, NULL, NULL, NULL, &anc, NULL);
+    }
     free(anc.v);
-    return NULL;
+}
+
+typedef struct { orc_pool *pl; int idx; } orc_warg;
+
+static void *orc_pool_worker(void *p) {
+    orc_warg *wa = (orc_warg *)p;
+    orc_pool *pl = wa->pl; int idx = wa->idx;
+    free(wa);
+    uint64_t seen = 0;
+    for (;;) {
+        pthread_mutex_lock(&pl->mu);
+        while (!pl->stop && pl->epoch == seen) pthread_cond_wait(&pl->cv_go, &pl->mu);
+        if (pl->stop) { pthread_mutex_unlock(&pl->mu); return NULL; }
+        seen = pl->epoch;
+        pthread_mutex_unlock(&pl->mu);
+        orc_run_ranges(pl, &pl->jobs[idx]);
+        pthread_mutex_lock(&pl->mu);
+        if (--pl->running == 0) pthread_cond_signal(&pl->cv_done);
+        pthread_mutex_unlock(&pl->mu);
+    }
+}
+
+orc_pool *orc_pool_create(int nthreads) {
+    if (nthreads < 1) nthreads = 1;
+    orc_pool *pl = (orc_pool *)calloc(1, sizeof(orc_pool));
+    pl->nthreads = nthreads - 1;
+    pl->jobs = (orc_job *)calloc((size_t)nthreads, sizeof(orc_job));
+    pl->th = (pthread_t *)calloc((size_t)nthreads, sizeof(pthread_t));
+    pthread_mutex_init(&pl->mu, NULL);
+    pthread_cond_init(&pl->cv_go, NULL);
+    pthread_cond_init(&pl->cv_done, NULL);
+    for (int i = 0; i < pl->nthreads; i++) {
+        orc_warg *wa = (orc_warg *)malloc(sizeof(orc_warg));
+        wa->pl = pl; wa->idx = i;
+        pthread_create(&pl->th[i], NULL, orc_pool_worker, wa);
+    }
+    return pl;
+}
+
+void orc_pool_destroy(orc_pool *pl) {
+    if (!pl) return;
+    pthread_mutex_lock(&pl->mu);
+    pl->stop = 1;
+    pthread_cond_broadcast(&pl->cv_go);
+    pthread_mutex_unlock(&pl->mu);
+    for (int i = 0; i < pl->nthreads; i++) pthread_join(pl->th[i], NULL);
+    pthread_mutex_destroy(&pl->mu); pthread_cond_destroy(&pl->cv_go); pthread_cond_destroy(&pl->cv_done);
+    free(pl->th); free(pl->jobs); free(pl);
 }
 
 /*
- * Node-parallel pass 1 (usher_common.cpp:389-414) with nthreads workers, one
- * sample at a time as the reference's file-scope locks force
- * (usher_mapper.cpp:3-4).  Each worker owns a contiguous node range and a
- * private copy of the shared state; the copies are merged with the same
- * (score, num_leaves, j) rule, which is order-independent.  Used only as the
- * timed CPU baseline; returns the same (best, num_best, best_j).
+ * Node-parallel pass 1 (usher_common.cpp:389-414) on the pool, one sample at a
+ * time as the reference's file-scope locks force (usher_mapper.cpp:3-4).  Each
+ * worker keeps a private copy of the shared state; the copies are merged with
+ * the same (score, num_leaves, j) rule, which is order-independent.  Used only
+ * as the timed CPU baseline; returns the same (best, num_best, best_j).
  */
-int orc_place_sample_mt(const orc_tree *t, int64_t n_ent, const int32_t *pos, const int8_t *ref,
-                        const int8_t *nuc, const int8_t *is_missing, int nthreads,
-                        int32_t *out_best, int64_t *out_num_best, int64_t *out_best_j) {
-    if (nthreads < 1) nthreads = 1;
+int orc_place_sample_pool(orc_pool *pl, const orc_tree *t, int64_t n_ent, const int32_t *pos, const int8_t *ref,
+                          const int8_t *nuc, const int8_t *is_missing,
+                          int32_t *out_best, int64_t *out_num_best, int64_t *out_best_j) {
     orc_mut *sm = make_sample(n_ent, pos, ref, nuc, is_missing);
     int64_t root_muts = t->mut_off[1] - t->mut_off[0];
     int init_best = (int)(n_ent + root_muts + 1);
-    orc_job *jobs = (orc_job *)calloc((size_t)nthreads, sizeof(orc_job));
-    pthread_t *th = (pthread_t *)malloc(sizeof(pthread_t) * (size_t)nthreads);
     int8_t *nhu = (int8_t *)calloc((size_t)t->n, 1);
-    for (int i = 0; i < nthreads; i++) {
-        jobs[i].t = t; jobs[i].sm = sm; jobs[i].n_sm = n_ent;
-        jobs[i].lo = t->n * i / nthreads; jobs[i].hi = t->n * (i + 1) / nthreads;
-        jobs[i].sh.best_set_difference = init_best;
-        jobs[i].sh.node_has_unique = nhu;   /* disjoint indices per worker */
-        jobs[i].sh.num_best = 0;
-        if (nthreads == 1) orc_worker(&jobs[i]);
-        else pthread_create(&th[i], NULL, orc_worker, &jobs[i]);
+    const int nj = pl->nthreads + 1;
+    for (int i = 0; i < nj; i++) {
+        memset(&pl->jobs[i], 0, sizeof(orc_job));
+        pl->jobs[i].t = t; pl->jobs[i].sm = sm; pl->jobs[i].n_sm = n_ent;
+        pl->jobs[i].sh.best_set_difference = init_best;
+        pl->jobs[i].sh.node_has_unique = nhu;   /* disjoint indices per worker */
+        pl->jobs[i].sh.num_best = 0;
     }
+    pthread_mutex_lock(&pl->mu);
+    pl->n = t->n; pl->next = 0; pl->running = pl->nthreads; pl->epoch++;
+    pthread_cond_broadcast(&pl->cv_go);
+    pthread_mutex_unlock(&pl->mu);
+    orc_run_ranges(pl, &pl->jobs[pl->nthreads]);   /* the caller works too */
+    pthread_mutex_lock(&pl->mu);
+    while (pl->running > 0) pthread_cond_wait(&pl->cv_done, &pl->mu);
+    pthread_mutex_unlock(&pl->mu);
     int best = init_best; int64_t nb = 0, bj = 0, bl = -1;
-    for (int i = 0; i < nthreads; i++) {
-        if (nthreads > 1) pthread_join(th[i], NULL);
-        orc_shared *s = &jobs[i].sh;
+    for (int i = 0; i < nj; i++) {
+        orc_shared *s = &pl->jobs[i].sh;
         if (s->num_best == 0) { free(s->best_j_vec); continue; }
         if (s->best_set_difference < best) {
             best = s->best_set_difference; nb = s->num_best; bj = s->best_j; bl = s->best_node_num_leaves;
@@ -525,8 +600,217 @@ int orc_place_sample_mt(const orc_tree *t, int64_t n_ent, const int32_t *pos, co
         free(s->best_j_vec);
     }
     *out_best = best; *out_num_best = nb; *out_best_j = bj;
-    free(nhu); free(th); free(jobs); free(sm);
+    free(nhu); free(sm);
     return 0;
+}
+
+/* Convenience form kept for the tests: a pool per (process, thread count), created on first use. */
+int orc_place_sample_mt(const orc_tree *t, int64_t n_ent, const int32_t *pos, const int8_t *ref,
+                        const int8_t *nuc, const int8_t *is_missing, int nthreads,
+                        int32_t *out_best, int64_t *out_num_best, int64_t *out_best_j) {
+    static orc_pool *pool = NULL;
+    static pthread_mutex_t mu = PTHREAD_MUTEX_INITIALIZER;
+    if (nthreads < 1) nthreads = 1;
+    pthread_mutex_lock(&mu);   /* one sample at a time (usher_mapper.cpp:3-4) */
+    if (!pool || pool->nthreads + 1 != nthreads) { orc_pool_destroy(pool); pool = orc_pool_create(nthreads); }
+    int rc = orc_place_sample_pool(pool, t, n_ent, pos, ref, nuc, is_missing, out_best, out_num_best, out_best_j);
+    pthread_mutex_unlock(&mu);
+    return rc;
+}
+
+/* -------------------------------------------- closed form, at full size */
+
+/*
+ * The closed form of mapper2_body (oracle/closed_form.py is the
+ * readable statement, checked against the literal restatement above on every
+ * small test tree) as one O(N + M) sweep per sample in BFS order, so that the
+ * parity tests can check EVERY sample of a 10M-node batch and not only the
+ * handful the literal O(N * depth) routine finishes in seconds:
+ *     D(n)    = D(parent) + sum_m ([prev(m) in S] - [mut(m) in S])      (non-masked m)
+ *     cost(n) = D(parent) + sum_{m before the first masked one} min(delta, 0);  cost(root) = D(root)
+ *     common  = #{m before the first masked one : mut(m) in S}
+ *     eligible = root | common > 0 | (internal & no mutations)          usher_mapper.cpp:454-455
+ *     has_unique = masked | common != num_mut                           usher_mapper.cpp:197-264
+ *     winner = argmax (num_leaves, j) among the eligible minima         usher_mapper.cpp:476-497
+ * prev(m) = the true parent state at m's position (usher_mapper.cpp:275-286
+ * ignores the stored par_nuc as well), derived once per tree by a DFS.
+ * Preconditions as in closed_form.py: sample rows sorted, no duplicate
+ * positions; tree alleles one-hot.  Returns NULL when the tree violates them.
+ */
+typedef struct orc_cf {
+    const orc_tree *t;
+    int8_t *prev;        /* [M] true parent-state allele of every mutation (0 for masked) */
+    int32_t max_pos;
+    int8_t *ref_at;      /* [max_pos + 1] reference base at positions the tree mutates, else 0 */
+} orc_cf;
+
+void orc_cf_destroy(orc_cf *c) { if (!c) return; free(c->prev); free(c->ref_at); free(c); }
+
+orc_cf *orc_cf_create(const orc_tree *t) {
+    orc_cf *c = (orc_cf *)calloc(1, sizeof(orc_cf));
+    c->t = t;
+    const int64_t M = t->mut_off[t->n];
+    c->prev = (int8_t *)calloc((size_t)(M > 0 ? M : 1), 1);
+    int32_t mp = 0;
+    for (int64_t i = 0; i < M; i++) if (t->muts[i].position > mp) mp = t->muts[i].position;
+    c->max_pos = mp;
+    c->ref_at = (int8_t *)calloc((size_t)mp + 1, 1);
+    int8_t *state = (int8_t *)calloc((size_t)mp + 1, 1);   /* 0 = reference */
+    for (int64_t i = 0; i < M; i++) {
+        const orc_mut *m = &t->muts[i];
+        if (m->position < 0) continue;
+        if (m->mut_nuc <= 0 || (m->mut_nuc & (m->mut_nuc - 1)) || m->mut_nuc > 8) { free(state); orc_cf_destroy(c); return NULL; }
+        if (c->ref_at[m->position] == 0) c->ref_at[m->position] = m->ref_nuc;
+    }
+    /* iterative DFS with an undo log */
+    typedef struct { int32_t pos; int8_t old; } undo_t;
+    undo_t *undo = (undo_t *)malloc(sizeof(undo_t) * (size_t)(M > 0 ? M : 1));
+    int64_t n_undo = 0;
+    int64_t *stk_node = (int64_t *)malloc(sizeof(int64_t) * (size_t)t->n);
+    int64_t *stk_next = (int64_t *)malloc(sizeof(int64_t) * (size_t)t->n);
+    int64_t *stk_mark = (int64_t *)malloc(sizeof(int64_t) * (size_t)t->n);
+    int64_t sp = 0;
+    stk_node[0] = 0; stk_next[0] = t->child_off[0]; stk_mark[0] = 0; sp = 1;
+    for (int64_t i = t->mut_off[0]; i < t->mut_off[1]; i++) {
+        const orc_mut *m = &t->muts[i];
+        if (m->position < 0) continue;
+        c->prev[i] = state[m->position] ? state[m->position] : c->ref_at[m->position];
+        undo[n_undo].pos = m->position; undo[n_undo].old = state[m->position]; n_undo++;
+        state[m->position] = m->mut_nuc;
+    }
+    while (sp > 0) {
+        const int64_t j = stk_node[sp - 1];
+        if (stk_next[sp - 1] < t->child_off[j + 1]) {
+            const int64_t ch = t->children[stk_next[sp - 1]++];
+            stk_node[sp] = ch; stk_next[sp] = t->child_off[ch]; stk_mark[sp] = n_undo; sp++;
+            for (int64_t i = t->mut_off[ch]; i < t->mut_off[ch + 1]; i++) {
+                const orc_mut *m = &t->muts[i];
+                if (m->position < 0) continue;
+                c->prev[i] = state[m->position] ? state[m->position] : c->ref_at[m->position];
+                undo[n_undo].pos = m->position; undo[n_undo].old = state[m->position]; n_undo++;
+                state[m->position] = m->mut_nuc;
+            }
+        } else {
+            while (n_undo > stk_mark[sp - 1]) { n_undo--; state[undo[n_undo].pos] = undo[n_undo].old; }
+            sp--;
+        }
+    }
+    free(undo); free(stk_node); free(stk_next); free(stk_mark); free(state);
+    return c;
+}
+
+/* One sample.  S = scratch [max_pos + 1], all zero on entry and on return (0 = "no row": reference base).
+ * D = scratch int32 [n].  ties (optional): ascending BFS indices of the optimal nodes, at most cap. */
+static int orc_cf_place_one(const orc_cf *c, int64_t n_ent, const int32_t *pos, const int8_t *ref, const int8_t *nuc,
+                            const int8_t *is_missing, uint8_t *S, int32_t *D, int32_t *scores,
+                            int32_t *out_best, int64_t *out_num_best, int64_t *out_best_j, int8_t *out_hu,
+                            int64_t *ties, int8_t *ties_hu, int64_t cap) {
+    const orc_tree *t = c->t;
+    int32_t dbot = 0;
+    for (int64_t i = 0; i < n_ent; i++) {
+        if (i > 0 && pos[i] <= pos[i - 1]) return -1;
+        const uint8_t a = is_missing[i] ? 15 : (uint8_t)nuc[i];
+        if (!is_missing[i] && (a & (uint8_t)ref[i]) == 0) dbot++;
+        if (pos[i] >= 0 && pos[i] <= c->max_pos) S[pos[i]] = a;
+    }
+    int32_t best = 0x7fffffff; int64_t nb = 0, bj = 0, bl = -1; int8_t bhu = 0;
+    int64_t n_t = 0;
+    for (int64_t j = 0; j < t->n; j++) {
+        const int32_t dpar = j ? D[t->parent[j]] : dbot;
+        int32_t tsum = 0, neg = 0, common = 0, num_mut = 0; int masked = 0;
+        for (int64_t i = t->mut_off[j]; i < t->mut_off[j + 1]; i++) {
+            const orc_mut *m = &t->muts[i];
+            if (m->position < 0) { if (!masked) num_mut++; masked = 1; continue; }
+            const uint8_t s = S[m->position] ? S[m->position] : (uint8_t)c->ref_at[m->position];
+            const int cc = (s & (uint8_t)m->mut_nuc) != 0, pp = (s & (uint8_t)c->prev[i]) != 0;
+            const int d = pp - cc;
+            tsum += d;
+            if (!masked) { num_mut++; common += cc; if (d < 0) neg += d; }
+        }
+        D[j] = dpar + tsum;
+        int32_t cost; int elig, hu;
+        if (j == 0) { cost = D[0]; elig = 1; hu = 0; }
+        else {
+            const int leaf = is_leaf(t, j);
+            cost = dpar + neg;
+            elig = common > 0 || (!leaf && num_mut == 0);
+            hu = masked || common != num_mut;
+        }
+        if (scores) scores[j] = cost + (elig ? 0 : 1);
+        if (!elig) continue;
+        if (cost < best) {
+            best = cost; nb = 1; bj = j; bl = t->num_leaves[j]; bhu = (int8_t)hu;
+            if (ties && cap > 0) { ties[0] = j; if (ties_hu) ties_hu[0] = (int8_t)hu; }
+            n_t = 1;
+        }
+        else if (cost == best) {
+            if (ties && n_t < cap) { ties[n_t] = j; if (ties_hu) ties_hu[n_t] = (int8_t)hu; }
+            n_t++; nb++;
+            if (t->num_leaves[j] > bl || (t->num_leaves[j] == bl && j > bj)) { bj = j; bl = t->num_leaves[j]; bhu = (int8_t)hu; }
+        }
+    }
+    for (int64_t i = 0; i < n_ent; i++) if (pos[i] >= 0 && pos[i] <= c->max_pos) S[pos[i]] = 0;
+    *out_best = best; *out_num_best = nb; *out_best_j = bj; *out_hu = bhu;
+    return 0;
+}
+
+typedef struct {
+    const orc_cf *c; int64_t n_q; const int64_t *ent_off; const int32_t *pos; const int8_t *ref, *nuc, *mis;
+    int32_t *best; int64_t *num_best, *best_j; int8_t *hu;
+    int64_t *ties; int8_t *ties_hu; int64_t cap;
+    int64_t *next; int rc;
+} orc_cf_job;
+
+static void *orc_cf_worker(void *p) {
+    orc_cf_job *jb = (orc_cf_job *)p;
+    uint8_t *S = (uint8_t *)calloc((size_t)jb->c->max_pos + 1, 1);
+    int32_t *D = (int32_t *)malloc(sizeof(int32_t) * (size_t)jb->c->t->n);
+    for (;;) {
+        const int64_t q = __atomic_fetch_add(jb->next, 1, __ATOMIC_RELAXED);
+        if (q >= jb->n_q) break;
+        const int64_t b = jb->ent_off[q], e = jb->ent_off[q + 1];
+        if (orc_cf_place_one(jb->c, e - b, jb->pos + b, jb->ref + b, jb->nuc + b, jb->mis + b, S, D, NULL,
+                             &jb->best[q], &jb->num_best[q], &jb->best_j[q], &jb->hu[q],
+                             jb->ties ? jb->ties + q * jb->cap : NULL, jb->ties_hu ? jb->ties_hu + q * jb->cap : NULL, jb->cap) != 0) {
+            jb->rc = -1;
+            memset(S, 0, (size_t)jb->c->max_pos + 1);
+        }
+    }
+    free(S); free(D);
+    return NULL;
+}
+
+/* A CSR batch of samples, sample-parallel over nthreads (each thread owns an S and a D array). */
+int orc_cf_place_batch(const orc_cf *c, int64_t n_q, const int64_t *ent_off, const int32_t *pos, const int8_t *ref,
+                       const int8_t *nuc, const int8_t *is_missing, int nthreads,
+                       int32_t *best, int64_t *num_best, int64_t *best_j, int8_t *hu,
+                       int64_t *ties, int8_t *ties_hu, int64_t cap) {
+    if (nthreads < 1) nthreads = 1;
+    if (nthreads > n_q) nthreads = (int)(n_q > 0 ? n_q : 1);
+    int64_t next = 0;
+    orc_cf_job *jobs = (orc_cf_job *)calloc((size_t)nthreads, sizeof(orc_cf_job));
+    pthread_t *th = (pthread_t *)malloc(sizeof(pthread_t) * (size_t)nthreads);
+    for (int i = 0; i < nthreads; i++) {
+        orc_cf_job jb = {c, n_q, ent_off, pos, ref, nuc, is_missing, best, num_best, best_j, hu, ties, ties_hu, cap, &next, 0};
+        jobs[i] = jb;
+        if (i + 1 < nthreads) pthread_create(&th[i], NULL, orc_cf_worker, &jobs[i]);
+    }
+    orc_cf_worker(&jobs[nthreads - 1]);
+    int rc = jobs[nthreads - 1].rc;
+    for (int i = 0; i + 1 < nthreads; i++) { pthread_join(th[i], NULL); if (jobs[i].rc) rc = jobs[i].rc; }
+    free(th); free(jobs);
+    return rc;
+}
+
+/* Per-node scores of one sample (the -p column: cost, +1 when not eligible). */
+int orc_cf_scores(const orc_cf *c, int64_t n_ent, const int32_t *pos, const int8_t *ref, const int8_t *nuc,
+                  const int8_t *is_missing, int32_t *scores) {
+    uint8_t *S = (uint8_t *)calloc((size_t)c->max_pos + 1, 1);
+    int32_t *D = (int32_t *)malloc(sizeof(int32_t) * (size_t)c->t->n);
+    int32_t b; int64_t nb, bj; int8_t hu;
+    int rc = orc_cf_place_one(c, n_ent, pos, ref, nuc, is_missing, S, D, scores, &b, &nb, &bj, &hu, NULL, NULL, 0);
+    free(S); free(D);
+    return rc;
 }
 
 /* --------------------------------------------------------- Fitch-Sankoff */

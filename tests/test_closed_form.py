@@ -67,3 +67,30 @@ def test_closed_form_tiny_trees():
     three = {"n": 3, "parent": np.array([-1, 0, 0]), "mut_off": np.array([0, 0, 1, 1]), "mut_pos": np.array([5], np.int32),
              "mut_ref": np.array([1], np.int8), "mut_par": np.array([1], np.int8), "mut_nuc": np.array([4], np.int8), "names": list("rab")}
     _check(three, [empty, q])
+
+
+@pytest.mark.parametrize("seed", [3, 4, 5])
+def test_c_closed_form_and_pool_equal_literal_oracle(seed):
+    """oracle/ugp_oracle.c's O(N+M) closed-form sweep (the full-size checker) and the pooled node-parallel
+    literal routine (the timed CPU baseline) against the literal single-thread oracle: placements, tie
+    lists, per-node scores."""
+    from oracle import capi
+    arrays, queries = synth.make_case(500 + seed, n_leaves=400, n_queries=50, n_sites=90, p_masked=0.04 if seed % 2 else 0.0,
+                                      root_muts=seed % 3, n_ambig=(0, 0, 2, 5, 30))
+    ot = capi.OracleTree(arrays)
+    cf = capi.ClosedFormC(ot)
+    lens = [len(s["pos"]) for s in queries]
+    off = np.zeros(len(queries) + 1, np.int64)
+    off[1:] = np.cumsum(lens)
+    cat = lambda k, dt: np.concatenate([np.asarray(s[k]) for s in queries]).astype(dt)
+    batch = cf.place_csr(off, cat("pos", np.int32), cat("ref", np.int8), cat("nuc", np.int8), cat("is_missing", np.int8), nthreads=3, tie_cap=4096)
+    for i, s in enumerate(queries):
+        w = ot.place(s, compute_scores=True)
+        assert (int(batch["best"][i]), int(batch["num_best"][i]), int(batch["best_j"][i]), bool(batch["has_unique"][i])) == \
+               (w["best"], w["num_best"], w["best_j"], w["has_unique"])
+        assert batch["ties"][i].tolist() == w["ties"].tolist()
+        assert batch["ties_has_unique"][i].tolist() == w["ties_has_unique"].tolist()
+        assert cf.scores(s).tolist() == w["scores"].tolist()
+        for threads in (1, 5):
+            m = ot.place_mt(s, threads)
+            assert (m["best"], m["num_best"], m["best_j"]) == (w["best"], w["num_best"], w["best_j"])

@@ -391,3 +391,150 @@ def test_huge_polytomies(monkeypatch):
             for i, w in enumerate(want):
                 _assert_same(res, i, w, "polytomy %s #%d" % (fan, i))
             pl.close()
+
+
+# ---------------------------------------------------------------------------
+# BASELINE.json configurations at their stated sizes
+# ---------------------------------------------------------------------------
+
+def _csr_batch(q):
+    return QueryBatch.from_csr(q["ent_off"], q["pos"], q["ref"], q["nuc"], q["is_missing"])
+
+
+def _rows(res):
+    return np.stack([res["best_set_difference"].astype(np.int64), res["num_best"].astype(np.int64), res["best_j"].astype(np.int64),
+                     res["best_has_unique"].astype(np.int64)], 1)
+
+
+def _cf_rows(r):
+    return np.stack([r["best"].astype(np.int64), r["num_best"].astype(np.int64), r["best_j"].astype(np.int64), r["has_unique"].astype(np.int64)], 1)
+
+
+@pytest.mark.parametrize("coarse", [False, True])
+def test_config2_100k_nodes_1k_queries_every_sample_vs_oracle(coarse, monkeypatch):
+    """BASELINE config 2: 100k-node synthetic MAT, 1,024 SARS-CoV-2-length queries; every sample against the
+    literal oracle (node-parallel pool) and the closed form, with the default knobs (no coarse pass at this
+    size) and with the locality sort / seeded bounds forced on."""
+    from usher_amd import synth as gsynth
+    for k in ("UGP_FORCE_V1", "UGP_NO_SORT", "UGP_NO_PRUNE", "UGP_COARSE_MIN_NODES"):
+        monkeypatch.delenv(k, raising=False)
+    if coarse:
+        monkeypatch.setenv("UGP_COARSE_MIN_NODES", "0")
+    st = gsynth.SynthTree(100_000, n_sites=1500, seed=2)
+    q = st.queries(1024, seed=77)
+    pl = Placer(st.arrays)
+    assert pl.info()["n_nodes"] == 100_000
+    res = pl.place(_csr_batch(q))
+    assert pl.timing()["packed_path"] == 1
+    ot = capi.OracleTree(st.arrays)
+    cf = capi.ClosedFormC(ot).place_csr(q["ent_off"], q["pos"], q["ref"], q["nuc"], q["is_missing"])
+    assert (_rows(res) == _cf_rows(cf)).all()
+    threads = os.cpu_count() or 1
+    for i in range(1024):
+        w = ot.place_mt(gsynth.csr_sample(q, i), threads)
+        assert (w["best"], w["num_best"], w["best_j"]) == (int(res["best_set_difference"][i]), int(res["num_best"][i]), int(res["best_j"][i])), i
+    pl.close()
+
+
+def test_config3_10m_nodes_10k_queries(monkeypatch):
+    """BASELINE config 3 at the size of the 10M-node substitute (the public SARS-CoV-2 MAT is not in the image):
+    10,000 queries; the packed / pruned / sorted path, the plain 32-bit kernel and a permuted batch agree sample
+    by sample; 2,048 samples against the closed form; 32 against the literal oracle."""
+    from usher_amd import synth as gsynth
+    for k in ("UGP_FORCE_V1", "UGP_NO_SORT", "UGP_NO_PRUNE", "UGP_COARSE_MIN_NODES"):
+        monkeypatch.delenv(k, raising=False)
+    st = gsynth.SynthTree(10_000_000, n_sites=25000, seed=1)
+    q = st.queries(10_000, seed=4242)
+    batch = _csr_batch(q)
+    pl = Placer(st.arrays)
+    assert pl.info()["n_nodes"] == 10_000_000
+    fast = pl.place(batch)
+    assert pl.timing()["packed_path"] == 1
+    perm = np.random.default_rng(8).permutation(len(batch))
+    shuffled = pl.place(QueryBatch([gsynth.csr_sample(q, int(i)) for i in perm]))
+    assert (_rows(shuffled) == _rows(fast)[perm]).all()
+    monkeypatch.setenv("UGP_FORCE_V1", "1")
+    slow = pl.place(batch)
+    assert pl.timing()["packed_path"] == 0
+    monkeypatch.delenv("UGP_FORCE_V1")
+    assert (_rows(slow) == _rows(fast)).all()
+    pl.close()
+    ot = capi.OracleTree(st.arrays)
+    n_cf = 2048
+    e1 = int(q["ent_off"][n_cf])
+    cf = capi.ClosedFormC(ot).place_csr(q["ent_off"][:n_cf + 1], q["pos"][:e1], q["ref"][:e1], q["nuc"][:e1], q["is_missing"][:e1])
+    assert (_rows(fast)[:n_cf] == _cf_rows(cf)).all()
+    threads = os.cpu_count() or 1
+    for i in range(5000, 5032):
+        w = ot.place_mt(gsynth.csr_sample(q, i), threads)
+        assert (w["best"], w["num_best"], w["best_j"]) == (int(fast["best_set_difference"][i]), int(fast["num_best"][i]), int(fast["best_j"][i])), i
+
+
+def test_config5_high_ambiguity_results_and_tie_lists(monkeypatch):
+    """BASELINE config 5 on one device: 100-5,000 N cells + 0-30 IUPAC cells per query on a 1M-node MAT;
+    placements AND the lists of equally parsimonious nodes (ugp_tied_nodes) against the closed form for every
+    sample, a handful against the literal oracle."""
+    from usher_amd import synth as gsynth
+    for k in ("UGP_FORCE_V1", "UGP_NO_SORT", "UGP_NO_PRUNE", "UGP_COARSE_MIN_NODES"):
+        monkeypatch.delenv(k, raising=False)
+    st = gsynth.SynthTree(1_000_000, n_sites=8000, seed=6)
+    q = st.queries(1536, seed=55, max_subst=3, n_lo=100, n_hi=5000, iupac_hi=30)
+    assert int(np.diff(q["ent_off"].astype(np.int64)).max()) > 3000
+    batch = _csr_batch(q)
+    pl = Placer(st.arrays)
+    res = pl.place(batch)
+    assert pl.timing()["packed_path"] == 1
+    cap = 64
+    ties, ties_hu, tc = pl.tied_nodes(batch, cap)
+    pl.close()
+    ot = capi.OracleTree(st.arrays)
+    cf = capi.ClosedFormC(ot).place_csr(q["ent_off"], q["pos"], q["ref"], q["nuc"], q["is_missing"], tie_cap=cap)
+    assert (_rows(res) == _cf_rows(cf)).all()
+    assert (tc.astype(np.int64) == cf["num_best"]).all()
+    assert int((cf["num_best"] > 1).sum()) > 50            # ties are common with this much ambiguity
+    for i in range(len(batch)):
+        if cf["num_best"][i] <= cap:
+            assert ties[i].tolist() == cf["ties"][i].tolist(), i
+            assert ties_hu[i].tolist() == cf["ties_has_unique"][i].tolist(), i
+    for i in range(0, 1536, 256):
+        w = ot.place(gsynth.csr_sample(q, i), tie_cap=cap)
+        _assert_same(res, i, w, "literal #%d" % i)
+        if w["num_best"] <= cap:
+            assert ties[i].tolist() == w["ties"].tolist()
+
+
+@pytest.mark.parametrize("coarse", [False, True])
+def test_sixteen_bit_boundary_of_the_packed_path(coarse, monkeypatch):
+    """Costs right below the largest value the packed 16-bit path admits (the shared upper bounds start at
+    0x7F7F) and right above it (the library must fall back to the 32-bit kernel): samples with ~32,600
+    mismatching rows at positions the tree never mutates, next to ordinary samples in the same tiles."""
+    for k in ("UGP_FORCE_V1", "UGP_NO_SORT", "UGP_NO_PRUNE", "UGP_COARSE_MIN_NODES", "UGP_NO_SEED"):
+        monkeypatch.delenv(k, raising=False)
+    if coarse:
+        monkeypatch.setenv("UGP_COARSE_MIN_NODES", "0")
+    arrays, queries = synth.make_case(91, n_leaves=700, n_queries=600, n_sites=100)
+    ot = capi.OracleTree(arrays)
+    cfc = capi.ClosedFormC(ot)
+    from usher_amd import FlatTreeView
+    path = FlatTreeView(arrays).max_path_muts
+
+    def fat(base, n_rows, name):
+        keep = base["pos"] <= 2000                                        # the test genome has 2,000 bases
+        k = int(keep.sum())
+        n_extra = n_rows - k
+        extra = np.arange(3001, 3001 + n_extra, dtype=np.int32)
+        return {"name": name, "pos": np.concatenate([base["pos"][keep], extra]),
+                "ref": np.concatenate([base["ref"][keep], np.full(n_extra, 1, np.int8)]),
+                "nuc": np.concatenate([base["nuc"][keep], np.full(n_extra, 4, np.int8)]),
+                "is_missing": np.concatenate([base["is_missing"][keep], np.zeros(n_extra, np.int8)])}
+
+    for max_rows, want_packed in ((0x7F7F - 3 - path, 1), (0x7F7F - 2 - path, 0), (0x7FFE, 0)):
+        big = [fat(queries[i], max_rows - 2 * i, "F%d" % i) for i in (0, 1, 2)]
+        qs = queries[:300] + big[:1] + queries[300:] + big[1:]
+        assert (max(len(s["pos"]) for s in qs) + path + 2 < 0x7F7F) == bool(want_packed)
+        pl = Placer(arrays, chunk_nodes=40)
+        res = pl.place(QueryBatch(qs))
+        assert pl.timing()["packed_path"] == want_packed
+        for i, s in enumerate(qs):
+            _assert_same(res, i, cfc.place(s), "%s rows %d" % (s["name"], max_rows))
+        pl.close()

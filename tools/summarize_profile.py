@@ -16,14 +16,14 @@ os.makedirs(prof, exist_ok=True)
 stats = glob.glob(os.path.join(go, tag + "_stats", "*kernel_stats.csv"))
 if stats:
     shutil.copy(stats[0], os.path.join(prof, tag + "_kernel_stats.csv"))
-summary = {"tag": tag, "command": "python3 bench.py --queries 16384 --steps 3 --warmup 1 --cpu-queries 0", "kernels": {}}
+summary = {"tag": tag, "command": "python3 bench.py --queries 16384 --steps 3 --warmup 1 --cpu-queries 0" + (" " + sys.argv[2] if len(sys.argv) > 2 else ""), "kernels": {}}
 log = os.path.join(go, tag + "_stats.log")
 if os.path.exists(log):
     with open(log) as f:
         lines = [l for l in f if l.startswith("{")]
     if lines:
         summary["bench"] = json.loads(lines[-1])
-for sub in ("fetch", "write", "tcc", "sq"):
+for sub in ("fetch", "write", "tcc", "sq", "sq2"):
     files = glob.glob(os.path.join(go, "%s_%s" % (tag, sub), "*counter_collection.csv"))
     if not files:
         continue
@@ -73,6 +73,17 @@ for k, e in summary["kernels"].items():
         e["hbm_write_bytes_per_dispatch"] = e["WRITE_SIZE_per_dispatch"] * 1024
     if "TCC_HIT_sum_per_dispatch" in e:
         e["l2_hit_rate"] = e["TCC_HIT_sum_per_dispatch"] / (e["TCC_HIT_sum_per_dispatch"] + e["TCC_MISS_sum_per_dispatch"])
+    # Instruction issue (the bound that applies to k_best8).  A wave64 VALU instruction occupies its SIMD-32 for 2
+    # cycles (MI355X_MICROARCH.md "Wave scheduling"): chip capacity = 256 CU x 4 SIMD x f x t / 2; the scalar unit
+    # is one per CU: 256 x f x t issue slots.  f = 2.4 GHz nominal.
+    if "avg_duration_ns_full_dispatch" in e:
+        t = e["avg_duration_ns_full_dispatch"] * 1e-9
+        if "SQ_INSTS_VALU_per_dispatch" in e:
+            e["valu_issue_frac"] = e["SQ_INSTS_VALU_per_dispatch"] / (256 * 4 * 2.4e9 * t / 2)
+        if "SQ_INSTS_SALU_per_dispatch" in e:
+            e["salu_issue_frac"] = (e["SQ_INSTS_SALU_per_dispatch"] + e.get("SQ_INSTS_SMEM_per_dispatch", 0.0)) / (256 * 2.4e9 * t)
+    if "SQ_INST_CYCLES_SALU_per_dispatch" in e and e.get("SQ_BUSY_CU_CYCLES_per_dispatch"):
+        e["salu_busy_frac_measured"] = e["SQ_INST_CYCLES_SALU_per_dispatch"] / e["SQ_BUSY_CU_CYCLES_per_dispatch"]
 with open(os.path.join(prof, tag + "_pmc_summary.json"), "w") as f:
     json.dump(summary, f, indent=1, sort_keys=True)
 print(json.dumps({k: {c: round(v, 3) for c, v in e.items()} for k, e in summary["kernels"].items() if "best8" in k}, indent=1))

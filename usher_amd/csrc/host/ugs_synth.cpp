@@ -7,6 +7,15 @@
 // bases.  Queries copy the genotype of a uniformly random node, add 0..3
 // substitutions and optionally N runs and IUPAC cells (BASELINE config 5).
 // Output is in the reference's BFS node order, the layout ugp_tree_desc takes.
+//
+// shape 1 ("sars2") imitates the public SARS-CoV-2 tree instead (BASELINE configs 3-5; the real
+// public-latest.all.masked.pb.gz is not in the image): three new nodes in four attach as a SIBLING of a
+// random existing node (7 times in 10 one of the newest fifth: the epidemic grows from its recent lineages) --
+// preferential attachment by child count, which grows polytomies of hundreds to thousands of children -- and
+// one in four below it; the tree stays shallow (depth in the tens, a ladder-like backbone); internal branches carry about one mutation, more than half of the leaves are
+// identical to their parent (at most one such leaf per parent: identical samples are condensed), and the
+// mutated site is drawn with a quadratic skew so that a few sites are hit thousands of times (homoplasy).
+// "recent" queries copy one of the last 10 % of the nodes created and add a few private mutations.
 #include <algorithm>
 #include <cstdint>
 #include <cstring>
@@ -45,6 +54,7 @@ struct ugs_tree {
     std::vector<uint8_t> mut_ref, mut_par, mut_nuc;
     std::vector<uint8_t> ref;         // [genome_len+1] allele index
     std::vector<uint32_t> sites;      // sorted variable positions
+    std::vector<uint32_t> recent;     // BFS ids of the last 10 % of the nodes created (shape 1)
 };
 
 struct ugs_queries {
@@ -56,7 +66,12 @@ struct ugs_queries {
 
 extern "C" {
 
+ugs_tree *ugs_tree_create2(uint64_t target_nodes, uint32_t genome_len, uint32_t n_sites, uint64_t seed, uint32_t shape);
 ugs_tree *ugs_tree_create(uint64_t target_nodes, uint32_t genome_len, uint32_t n_sites, uint64_t seed) {
+    return ugs_tree_create2(target_nodes, genome_len, n_sites, seed, 0);
+}
+
+ugs_tree *ugs_tree_create2(uint64_t target_nodes, uint32_t genome_len, uint32_t n_sites, uint64_t seed, uint32_t shape) {
     if (target_nodes < 1 || genome_len < 1 || n_sites < 1 || n_sites > genome_len || target_nodes >= (1ull << 31)) return nullptr;
     ugs_tree *t = new (std::nothrow) ugs_tree();
     if (!t) return nullptr;
@@ -76,10 +91,22 @@ ugs_tree *ugs_tree_create(uint64_t target_nodes, uint32_t genome_len, uint32_t n
     std::vector<uint32_t> nchild;
     par.reserve(target_nodes + 4); nchild.reserve(target_nodes + 4);
     par.push_back(UINT32_MAX); nchild.push_back(0);
-    while (par.size() < target_nodes) {
-        uint32_t v = (uint32_t)rng.below(par.size());
-        uint32_t k = nchild[v] ? 1u : (rng.below(3) < 2 ? 2u : 3u);
-        for (uint32_t i = 0; i < k; i++) { par.push_back(v); nchild.push_back(0); nchild[v]++; }
+    if (shape == 0) {
+        while (par.size() < target_nodes) {
+            uint32_t v = (uint32_t)rng.below(par.size());
+            uint32_t k = nchild[v] ? 1u : (rng.below(3) < 2 ? 2u : 3u);
+            for (uint32_t i = 0; i < k; i++) { par.push_back(v); nchild.push_back(0); nchild[v]++; }
+        }
+    } else {
+        while (par.size() < target_nodes) {
+            // the epidemic grows from its recent lineages: 7 times in 10 the anchor is one of the newest 20 % of the nodes
+            const uint64_t sz = par.size(), win = std::max<uint64_t>(1, sz / 5);
+            uint32_t v = rng.below(10) < 7 ? (uint32_t)(sz - 1 - rng.below(win)) : (uint32_t)rng.below(sz);
+            uint32_t p = (v != 0 && rng.below(4) != 0) ? par[v] : v;   // sibling of v (3 in 4) or child of v
+            // a leaf that gets its first child would become a one-child internal node: give it two
+            const uint32_t k = nchild[p] ? 1u : 2u;
+            for (uint32_t i = 0; i < k && par.size() < target_nodes + 1; i++) { par.push_back(p); nchild.push_back(0); nchild[p]++; }
+        }
     }
     const uint64_t N = par.size();
     std::vector<uint32_t> coff(N + 1, 0), kids(N > 1 ? N - 1 : 0);
@@ -97,6 +124,7 @@ ugs_tree *ugs_tree_create(uint64_t target_nodes, uint32_t genome_len, uint32_t n
     for (uint64_t j = 0; j < N; j++) newid[order[j]] = (uint32_t)j;
     t->parent.resize(N);
     for (uint64_t j = 0; j < N; j++) t->parent[newid[j]] = (par[j] == UINT32_MAX) ? UINT32_MAX : newid[par[j]];
+    if (shape != 0) for (uint64_t j = N - std::max<uint64_t>(1, N / 10); j < N; j++) t->recent.push_back(newid[j]);
     // children CSR in BFS ids (contiguous by construction)
     std::vector<uint32_t> first(N + 1, 0);
     for (uint64_t j = 1; j < N; j++) first[t->parent[j] + 1]++;
@@ -111,13 +139,28 @@ ugs_tree *ugs_tree_create(uint64_t target_nodes, uint32_t genome_len, uint32_t n
     struct Frame { uint32_t node, next, mark; };
     std::vector<Frame> st;
     const uint32_t counts[7] = {0, 0, 1, 1, 1, 2, 3};
+    std::vector<uint8_t> has_twin;   // shape 1: the node already has a leaf child identical to it
+    if (shape != 0) has_twin.assign(N, 0);
     auto mutate = [&](uint32_t node) {
         if (node == 0) return;
         uint32_t k = counts[rng.below(7)];
+        if (shape != 0) {
+            const bool leaf = first[node + 1] == first[node];
+            const uint64_t u = rng.below(100);
+            if (leaf) {
+                k = u < 58 ? 0u : (u < 88 ? 1u : (u < 97 ? 2u : 3u));
+                if (k == 0) { if (has_twin[t->parent[node]]) k = 1; else has_twin[t->parent[node]] = 1; }
+            } else k = u < 6 ? 0u : (u < 76 ? 1u : (u < 94 ? 2u : 3u));
+        }
         uint32_t chosen[3];
         for (uint32_t i = 0; i < k; i++) {
             for (;;) {
                 uint32_t s = (uint32_t)rng.below(n_sites);
+                if (shape != 0) {   // quadratic skew over a fixed pseudo-random order of the sites
+                    const uint64_t a = rng.below(1u << 20), b = rng.below(1u << 20);
+                    const uint64_t r = (a * b * (uint64_t)n_sites) >> 40;
+                    s = (uint32_t)((r * 2654435761ull) % n_sites);
+                }
                 bool dup = false;
                 for (uint32_t q = 0; q < i; q++) dup |= (chosen[q] == s);
                 if (!dup) { chosen[i] = s; break; }
@@ -178,8 +221,41 @@ const uint8_t *ugs_tree_mut_par(const ugs_tree *t) { return t->mut_par.data(); }
 const uint8_t *ugs_tree_mut_nuc(const ugs_tree *t) { return t->mut_nuc.data(); }
 
 // n_lo..n_hi: number of N cells per query (as 1..8 contiguous runs); iupac_hi: 0..iupac_hi ambiguity cells.
+ugs_queries *ugs_queries_create2(const ugs_tree *t, uint64_t n_queries, uint64_t seed, uint32_t max_subst,
+                                 uint32_t n_lo, uint32_t n_hi, uint32_t iupac_hi, uint32_t recent);
 ugs_queries *ugs_queries_create(const ugs_tree *t, uint64_t n_queries, uint64_t seed, uint32_t max_subst,
                                 uint32_t n_lo, uint32_t n_hi, uint32_t iupac_hi) {
+    return ugs_queries_create2(t, n_queries, seed, max_subst, n_lo, n_hi, iupac_hi, 0);
+}
+
+// Adopt existing tree arrays (another process generated them with the same seed / genome_len / n_sites): only
+// the reference genome and the site list, the first draws of the generator, are regenerated.
+ugs_tree *ugs_tree_adopt(uint64_t n_nodes, const uint32_t *parent, const uint64_t *mut_off, const int32_t *mut_pos, const uint8_t *mut_ref,
+                         const uint8_t *mut_par, const uint8_t *mut_nuc, uint32_t genome_len, uint32_t n_sites, uint64_t seed, uint32_t shape) {
+    ugs_tree *t = new (std::nothrow) ugs_tree();
+    if (!t) return nullptr;
+    Rng rng(seed);
+    t->genome_len = genome_len;
+    t->ref.resize(genome_len + 1);
+    for (auto &r : t->ref) r = (uint8_t)rng.below(4);
+    std::vector<uint32_t> all(genome_len);
+    for (uint32_t i = 0; i < genome_len; i++) all[i] = i + 1;
+    for (uint32_t i = 0; i < n_sites; i++) std::swap(all[i], all[i + rng.below(genome_len - i)]);
+    t->sites.assign(all.begin(), all.begin() + n_sites);
+    std::sort(t->sites.begin(), t->sites.end());
+    const uint64_t M = mut_off[n_nodes];
+    t->parent.assign(parent, parent + n_nodes);
+    t->mut_off.assign(mut_off, mut_off + n_nodes + 1);
+    t->mut_pos.assign(mut_pos, mut_pos + M); t->mut_ref.assign(mut_ref, mut_ref + M);
+    t->mut_par.assign(mut_par, mut_par + M); t->mut_nuc.assign(mut_nuc, mut_nuc + M);
+    if (shape != 0) {   // "recent" is not recoverable from the arrays: the deepest tenth of the BFS order stands in
+        for (uint64_t j = n_nodes - std::max<uint64_t>(1, n_nodes / 10); j < n_nodes; j++) t->recent.push_back((uint32_t)j);
+    }
+    return t;
+}
+
+ugs_queries *ugs_queries_create2(const ugs_tree *t, uint64_t n_queries, uint64_t seed, uint32_t max_subst,
+                                 uint32_t n_lo, uint32_t n_hi, uint32_t iupac_hi, uint32_t recent) {
     ugs_queries *q = new (std::nothrow) ugs_queries();
     if (!q) return nullptr;
     Rng rng(seed ^ 0x5eed5eed5eedull);
@@ -193,6 +269,7 @@ ugs_queries *ugs_queries_create(const ugs_tree *t, uint64_t n_queries, uint64_t 
         for (const Row &r : rows) row_of_pos[r.pos] = -1;
         rows.clear();
         uint32_t node = (uint32_t)rng.below(N);
+        if (recent && !t->recent.empty()) node = t->recent[rng.below(t->recent.size())];
         q->source_node.push_back(node);
         // genotype of `node`: most recent mutation per position on the root path
         for (uint32_t v = node; v != UINT32_MAX; v = t->parent[v]) {

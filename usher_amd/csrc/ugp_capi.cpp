@@ -92,7 +92,13 @@ struct ugp_mat {
     DevBuf<ugp_result> d_coarse_res;
     DevBuf<uint8_t> d_sort_tmp;
     bool last_used_best8 = false;
+    ugp_qset *own_qs = nullptr;          // reusable query set / result buffer of the host-buffer entry points
+    DevBuf<ugp_result> d_own_out;
+    size_t occ_lds = ~(size_t)0;   // k_best8 occupancy cache: LDS bytes it was queried for
+    int occ_per_cu = 0, n_cu = 0;
     std::vector<EventSet> events;
+    hipEvent_t ev_coarse[2] = {nullptr, nullptr};
+    bool coarse_timed = false;
     size_t events_used = 0;
     ugp_timing last = {};
     hipStream_t last_stream = nullptr;
@@ -106,6 +112,8 @@ struct ugp_qset {
     DevBuf<int32_t> d_pos;
     DevBuf<uint8_t> d_ref, d_nuc, d_missing;
     DevBuf<uint32_t> d_ent_q;
+    DevBuf<uint64_t> d_ent_off;
+    DevBuf<unsigned long long> d_err;
     std::vector<uint64_t> ent_off;   // host copy, for sub-batching
 };
 
@@ -121,32 +129,19 @@ uint32_t pick_groups(const ugp_mat *m, uint32_t n_tiles, uint32_t target_waves =
     return g;
 }
 
-int validate_queries(const ugp_mat *m, const ugp_queries *q, std::vector<uint32_t> &ent_q) {
+// Host part of the query checks: the CSR offsets.  The per-row checks run on the device (k_rows_prepare).
+int validate_offsets(const ugp_queries *q, uint64_t &n_ent, uint64_t &max_rows) {
     if (!q || (q->n_queries && !q->ent_off)) return fail(UGP_ERR_INVALID, "null query arrays");
     if (q->n_queries >= (1ull << 31)) return fail(UGP_ERR_UNSUPPORTED, "more than 2^31 queries in one batch");
-    const uint64_t n_ent = q->n_queries ? q->ent_off[q->n_queries] : 0;
+    n_ent = q->n_queries ? q->ent_off[q->n_queries] : 0;
     if (n_ent && (!q->pos || !q->ref || !q->nuc || !q->is_missing)) return fail(UGP_ERR_INVALID, "null query entry arrays");
-    ent_q.resize(n_ent);
-    const auto &f = m->flat;
+    max_rows = 0;
     for (uint64_t s = 0; s < q->n_queries; s++) {
         const uint64_t b = q->ent_off[s], e = q->ent_off[s + 1];
         if (e < b || e > n_ent) return fail(UGP_ERR_INVALID, "ent_off is not monotone");
-        for (uint64_t i = b; i < e; i++) {
-            ent_q[i] = (uint32_t)s;
-            if (i > b && q->pos[i] <= q->pos[i - 1])
-                return fail(UGP_ERR_UNSUPPORTED, "rows of sample " + std::to_string(s) +
-                                                     " are not sorted by position / contain a duplicate position");
-            const uint8_t r = q->ref[i];
-            if (r != 1 && r != 2 && r != 4 && r != 8)
-                return fail(UGP_ERR_UNSUPPORTED, "VCF REF base of a row is not one of A,C,G,T");
-            if (!q->is_missing[i] && (q->nuc[i] == 0 || q->nuc[i] > 15))
-                return fail(UGP_ERR_INVALID, "allele mask out of range");
-            const int32_t p = q->pos[i];
-            if (p >= 0 && (uint32_t)p <= f.max_pos && f.pos2site[p] >= 0 && f.site_ref[f.pos2site[p]] != r)
-                return fail(UGP_ERR_UNSUPPORTED, "VCF REF differs from the tree's reference base at position " +
-                                                     std::to_string(p));
-        }
+        max_rows = std::max(max_rows, e - b);
     }
+    if (q->n_queries && q->ent_off[0] != 0) return fail(UGP_ERR_INVALID, "ent_off[0] must be 0");
     return UGP_OK;
 }
 
@@ -178,12 +173,20 @@ int run_place(ugp_mat *m, ugp_qset *qs, int mode, ugp_result *d_out, int32_t *d_
     const uint32_t active_words = (n_sites + 31) / 32;
     // Locality sort: place every sample on the coarse top-of-the-tree MAT first; samples are then
     // assigned to 512-sample tiles in the DFS order of that coarse placement (k_sort_keys).
-    const bool packed_ok = (mode == 0) && !getenv("UGP_FORCE_V1") && (qs->max_rows + f.max_path_muts + 2 < 0x7FFFull);
+    // (16-bit phase 1: every D / cost must stay below 0x7F7F, the value the shared upper bounds start from;
+    // a tree with a masked mutation behind an ordinary one on the same node -- never produced by the reference's
+    // sorted Node::add_mutation, mutation_annotated_tree.cpp:720-752 -- needs the order-aware 32-bit walk)
+    const bool packed_ok = (mode == 0) && !getenv("UGP_FORCE_V1") && !f.mask_not_first && (qs->max_rows + f.max_path_muts + 2 < 0x7F7Full);
     const bool sorted = packed_ok && m->coarse && Q > 512 && !getenv("UGP_NO_SORT") && !getenv("UGP_NO_PRUNE");
+    m->coarse_timed = false;
     if (sorted) {
         HIP_TRY(m->d_coarse_res.reserve(Q));
+        if (!m->ev_coarse[0]) { HIP_TRY(hipEventCreate(&m->ev_coarse[0])); HIP_TRY(hipEventCreate(&m->ev_coarse[1])); }
+        HIP_TRY(hipEventRecord(m->ev_coarse[0], s));
         if (int rc = run_place(m->coarse, qs, 0, m->d_coarse_res.p, nullptr, nullptr, nullptr, nullptr, nullptr, 0, s)) return rc;
         HIP_TRY(hipSetDevice(m->device));
+        HIP_TRY(hipEventRecord(m->ev_coarse[1], s));
+        m->coarse_timed = true;
     }
     // samples per sub-batch: at most 262,144, and few enough that the per-(chunk, sample) minima of phase 1
     // (2 bytes each) stay below 8 GiB
@@ -310,14 +313,23 @@ int run_place(ugp_mat *m, ugp_qset *qs, int mode, ugp_result *d_out, int32_t *d_
             // would stop at 3); the colder ones, touched once per ~1,300 words, go to a small global scratch
             b.lds_slots = std::min<uint32_t>(f.max_slots, 7);
             if (const char *e = getenv("UGP_LDS_SLOTS")) b.lds_slots = std::min<uint32_t>(f.max_slots, (uint32_t)std::max(1, atoi(e)));
-            {
-                int n_cu = 0;
-                HIP_TRY(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, m->device));
-                HIP_TRY(m->d_cold.reserve((size_t)std::max(n_cu, 1) * 32 * std::max<uint32_t>(f.max_slots - b.lds_slots, 1) * 256));
-                b.cold = m->d_cold.p;
+            // persistent grid: as many one-wave blocks as the device keeps resident (cached per handle and LDS
+            // size), never more than there are units; the cold-slot scratch is sized for exactly that grid
+            const size_t lds_bytes = (size_t)b.lds_slots * 64 * 16;
+            if (m->occ_lds != lds_bytes) {
+                HIP_TRY(hipDeviceGetAttribute(&m->n_cu, hipDeviceAttributeMultiprocessorCount, m->device));
+                HIP_TRY(ugp::best8_occupancy(lds_bytes, &m->occ_per_cu));
+                m->occ_lds = lds_bytes;
             }
+            int waves_cu = std::max(m->occ_per_cu, 1);
+            if (const char *e = getenv("UGP_WAVES_PER_CU")) waves_cu = std::max(1, std::min(waves_cu, atoi(e)));   // tuning
+            uint64_t blocks = (uint64_t)waves_cu * std::max(m->n_cu, 1);
+            blocks = std::min<uint64_t>(blocks, (uint64_t)n_tiles512 * G);
+            blocks = ((blocks + 7) / 8) * 8;
+            HIP_TRY(m->d_cold.reserve((size_t)blocks * std::max<uint32_t>(f.max_slots - b.lds_slots, 1) * 256));
+            b.cold = m->d_cold.p;
             b.active = m->d_active.p; b.active_words = active_words;
-            HIP_TRY(ugp::launch_best8(b, f.max_slots, s));
+            HIP_TRY(ugp::launch_best8(b, (uint32_t)blocks, s));
             HIP_TRY(hipEventRecord(es.ev[2], s));
             HIP_TRY(ugp::launch_phase2(a, m->d_lbest.p, m->d_lflag.p, m->d_list.p, m->d_list_n.p, m->d_gbest_part.p, m->d_gbest.p, n_tiles512, m->d_items.p, m->d_nitems.p,
                                        (uint32_t)std::min<uint64_t>(pairs, 0xFFFFFFFFull), m->d_cnt.p, m->d_key.p,
@@ -462,7 +474,9 @@ void ugp_mat_destroy(ugp_mat *m) {
     for (auto &es : m->events)
         for (int i = 0; i < 4; i++)
             if (es.ev[i]) (void)hipEventDestroy(es.ev[i]);
+    for (int i = 0; i < 2; i++) if (m->ev_coarse[i]) (void)hipEventDestroy(m->ev_coarse[i]);
     if (m->coarse) ugp_mat_destroy(m->coarse);
+    delete m->own_qs;
     delete m;
 }
 
@@ -482,40 +496,58 @@ int ugp_mat_info(const ugp_mat *m, ugp_info *out) {
     return UGP_OK;
 }
 
-int ugp_qset_upload(ugp_mat *m, const ugp_queries *q, ugp_qset **out) {
-    if (!m || !q || !out) return fail(UGP_ERR_INVALID, "null argument");
-    *out = nullptr;
-    std::vector<uint32_t> ent_q;
+// Upload the rows of a batch into `qs` (buffers grow on demand and are reused) and check them on the device.
+static int qset_fill(ugp_mat *m, const ugp_queries *q, ugp_qset *qs) {
+    uint64_t n_ent = 0, max_rows = 0;
+    if (int rc = validate_offsets(q, n_ent, max_rows)) return rc;
+    HIP_TRY(hipSetDevice(m->device));
+    qs->device = m->device;
+    qs->n_queries = q->n_queries;
+    qs->n_ent = n_ent;
+    qs->max_rows = max_rows;
     try {
-        if (int rc = validate_queries(m, q, ent_q)) return rc;
+        if (q->n_queries) qs->ent_off.assign(q->ent_off, q->ent_off + q->n_queries + 1);
+        else qs->ent_off.assign(1, 0);
     } catch (const std::bad_alloc &) {
         return fail(UGP_ERR_NOMEM, "out of host memory");
     }
-    HIP_TRY(hipSetDevice(m->device));
+    if (n_ent == 0) return UGP_OK;
+    const auto &f = m->flat;
+    HIP_TRY(qs->d_pos.reserve(n_ent)); HIP_TRY(qs->d_ref.reserve(n_ent)); HIP_TRY(qs->d_nuc.reserve(n_ent));
+    HIP_TRY(qs->d_missing.reserve(n_ent)); HIP_TRY(qs->d_ent_q.reserve(n_ent));
+    HIP_TRY(qs->d_ent_off.reserve(q->n_queries + 1)); HIP_TRY(qs->d_err.reserve(1));
+    hipStream_t s = nullptr;
+    HIP_TRY(hipMemcpyAsync(qs->d_pos.p, q->pos, n_ent * 4, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(qs->d_ref.p, q->ref, n_ent, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(qs->d_nuc.p, q->nuc, n_ent, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(qs->d_missing.p, q->is_missing, n_ent, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(qs->d_ent_off.p, q->ent_off, (q->n_queries + 1) * 8, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemsetAsync(qs->d_err.p, 0xFF, sizeof(unsigned long long), s));
+    HIP_TRY(ugp::launch_rows_prepare(qs->d_ent_off.p, (uint32_t)q->n_queries, n_ent, qs->d_pos.p, qs->d_ref.p, qs->d_nuc.p, qs->d_missing.p,
+                                     m->d_pos2site.p, m->d_site_ref.p, f.max_pos, (uint32_t)f.n_sites, qs->d_ent_q.p, qs->d_err.p, s));
+    unsigned long long err = ~0ull;
+    HIP_TRY(hipMemcpy(&err, qs->d_err.p, sizeof err, hipMemcpyDeviceToHost));
+    if (err != ~0ull) {
+        const uint64_t row = err >> 3;
+        const uint64_t smp = (uint64_t)(std::upper_bound(qs->ent_off.begin(), qs->ent_off.end(), row) - qs->ent_off.begin()) - 1;
+        switch ((int)(err & 7)) {
+            case ugp::ROWS_UNSORTED:
+                return fail(UGP_ERR_UNSUPPORTED, "rows of sample " + std::to_string(smp) + " are not sorted by position / contain a duplicate position");
+            case ugp::ROWS_BAD_REF: return fail(UGP_ERR_UNSUPPORTED, "VCF REF base of a row is not one of A,C,G,T");
+            case ugp::ROWS_BAD_MASK: return fail(UGP_ERR_INVALID, "allele mask out of range");
+            default:
+                return fail(UGP_ERR_UNSUPPORTED, "VCF REF differs from the tree's reference base at position " + std::to_string(q->pos[row]));
+        }
+    }
+    return UGP_OK;
+}
+
+int ugp_qset_upload(ugp_mat *m, const ugp_queries *q, ugp_qset **out) {
+    if (!m || !q || !out) return fail(UGP_ERR_INVALID, "null argument");
+    *out = nullptr;
     ugp_qset *qs = new (std::nothrow) ugp_qset();
     if (!qs) return fail(UGP_ERR_NOMEM, "out of host memory");
-    qs->device = m->device;
-    qs->n_queries = q->n_queries;
-    qs->n_ent = ent_q.size();
-    qs->ent_off.assign(q->ent_off, q->ent_off + q->n_queries + 1);
-    if (q->n_queries == 0) qs->ent_off.assign(1, 0);
-    for (uint64_t i = 0; i < q->n_queries; i++) qs->max_rows = std::max(qs->max_rows, q->ent_off[i + 1] - q->ent_off[i]);
-    const size_t n = qs->n_ent;
-    hipError_t e = hipSuccess;
-    auto up = [&](auto &buf, const void *src, size_t bytes_per) {
-        if (e != hipSuccess) return;
-        e = buf.reserve(n);
-        if (e == hipSuccess && n) e = hipMemcpy(buf.p, src, n * bytes_per, hipMemcpyHostToDevice);
-    };
-    up(qs->d_pos, q->pos, 4);
-    up(qs->d_ref, q->ref, 1);
-    up(qs->d_nuc, q->nuc, 1);
-    up(qs->d_missing, q->is_missing, 1);
-    up(qs->d_ent_q, ent_q.data(), 4);
-    if (e != hipSuccess) {
-        delete qs;
-        return fail(UGP_ERR_HIP, std::string("query upload: ") + hipGetErrorString(e));
-    }
+    if (int rc = qset_fill(m, q, qs)) { (void)hipSetDevice(m->device); delete qs; return rc; }
     *out = qs;
     return UGP_OK;
 }
@@ -537,19 +569,14 @@ int ugp_place_device(ugp_mat *m, ugp_qset *qs, void *d_out, void *stream) {
 
 int ugp_place_batch(ugp_mat *m, const ugp_queries *q, ugp_result *out) {
     if (!m || !q || (!out && q->n_queries)) return fail(UGP_ERR_INVALID, "null argument");
-    ugp_qset *qs = nullptr;
-    if (int rc = ugp_qset_upload(m, q, &qs)) return rc;
-    DevBuf<ugp_result> d_out;
-    int rc = UGP_OK;
-    hipError_t e = d_out.reserve(q->n_queries);
-    if (e != hipSuccess) rc = fail(UGP_ERR_HIP, std::string("hipMalloc results: ") + hipGetErrorString(e));
-    if (rc == UGP_OK) rc = run_place(m, qs, 0, d_out.p, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr);
-    if (rc == UGP_OK && q->n_queries) {
-        e = hipMemcpy(out, d_out.p, q->n_queries * sizeof(ugp_result), hipMemcpyDeviceToHost);
-        if (e != hipSuccess) rc = fail(UGP_ERR_HIP, std::string("copy results: ") + hipGetErrorString(e));
-    }
-    ugp_qset_destroy(qs);
-    return rc;
+    // the handle's own query set and result buffer are reused from call to call (no hipMalloc in the steady state)
+    if (!m->own_qs) { m->own_qs = new (std::nothrow) ugp_qset(); if (!m->own_qs) return fail(UGP_ERR_NOMEM, "out of host memory"); }
+    ugp_qset *qs = m->own_qs;
+    if (int rc = qset_fill(m, q, qs)) return rc;
+    HIP_TRY(m->d_own_out.reserve(q->n_queries));
+    if (int rc = run_place(m, qs, 0, m->d_own_out.p, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr)) return rc;
+    if (q->n_queries) HIP_TRY(hipMemcpy(out, m->d_own_out.p, q->n_queries * sizeof(ugp_result), hipMemcpyDeviceToHost));
+    return UGP_OK;
 }
 
 int ugp_scores_per_node(ugp_mat *m, const ugp_queries *q, int32_t *out) {
@@ -582,8 +609,6 @@ int ugp_tied_nodes(ugp_mat *m, const ugp_queries *q, uint32_t cap, uint32_t *tie
     DevBuf<uint32_t> d_cnt, d_j;
     DevBuf<uint8_t> d_hu;
     int rc = UGP_OK;
-    std::vector<ugp_result> res(Q);
-    std::vector<int32_t> best(Q);
     const uint64_t padded = ((Q + 63) / 64) * 64;
     hipError_t e = hipSuccess;
     auto chk = [&](hipError_t x, const char *what) {
@@ -595,11 +620,9 @@ int ugp_tied_nodes(ugp_mat *m, const ugp_queries *q, uint32_t cap, uint32_t *tie
     chk(d_j.reserve((size_t)Q * std::max<uint32_t>(cap, 1)), "hipMalloc");
     chk(d_hu.reserve((size_t)Q * std::max<uint32_t>(cap, 1)), "hipMalloc");
     if (rc == UGP_OK) rc = run_place(m, qs, 0, d_res.p, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr);
-    if (rc == UGP_OK) {
-        chk(hipMemcpy(res.data(), d_res.p, Q * sizeof(ugp_result), hipMemcpyDeviceToHost), "copy results");
-        for (uint64_t i = 0; i < Q; i++) best[i] = res[i].best_set_difference;
-        chk(hipMemcpy(d_best.p, best.data(), Q * sizeof(int32_t), hipMemcpyHostToDevice), "copy best");
-        chk(hipMemset(d_cnt.p, 0, padded * sizeof(uint32_t)), "memset");
+    if (rc == UGP_OK) {   // the wanted scores stay on the device
+        chk(ugp::launch_extract_best(d_res.p, (uint32_t)Q, d_best.p, nullptr), "extract best");
+        chk(hipMemsetAsync(d_cnt.p, 0, padded * sizeof(uint32_t), nullptr), "memset");
     }
     if (rc == UGP_OK) rc = run_place(m, qs, 2, nullptr, nullptr, d_best.p, d_cnt.p, d_j.p, d_hu.p, cap, nullptr);
     if (rc == UGP_OK) {
@@ -639,6 +662,8 @@ int ugp_get_timing(ugp_mat *m, ugp_timing *out) {
             HIP_TRY(hipEventElapsedTime(&t, es.ev[2], es.ev[3])); merge += t;
         }
         m->last.table_ms = table; m->last.place_ms = place; m->last.merge_ms = merge;
+        m->last.coarse_ms = 0;
+        if (m->coarse_timed) { HIP_TRY(hipEventSynchronize(m->ev_coarse[1])); HIP_TRY(hipEventElapsedTime(&m->last.coarse_ms, m->ev_coarse[0], m->ev_coarse[1])); }
         m->last.words_total = m->last_words_total;
         m->last.words_skipped = 0;
         if (m->last_used_best8 && m->d_stats.p) {

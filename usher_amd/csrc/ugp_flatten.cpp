@@ -148,6 +148,7 @@ int flatten(const ugp_tree_desc &t, const Options &opt, FlatMat &out, std::strin
     flat_lap("sites");
     // ---- DFS emission
     out.stream.clear();
+    out.mask_not_first = false;
     out.stream.reserve(2 * N + n_real);
     out.dfs2bfs.resize(N);
     std::vector<uint32_t> rec_off(N);        // by BFS index: dword offset of the node's record
@@ -181,7 +182,7 @@ int flatten(const ugp_tree_desc &t, const Options &opt, FlatMat &out, std::strin
         int32_t last_pos = -1;
         for (uint64_t i = b; i < e; i++) {
             int32_t p = t.mut_pos[i];
-            if (p < 0) { masked = true; continue; }
+            if (p < 0) { if (nwords > 0 && !root) out.mask_not_first = true; masked = true; continue; }
             if (p == last_pos) { err = "node carries two mutations at position " + std::to_string(p); return UGP_ERR_UNSUPPORTED; }
             last_pos = p;   // (adjacent duplicates; the loader keeps lists sorted)
             uint32_t site = (uint32_t)out.pos2site[p];

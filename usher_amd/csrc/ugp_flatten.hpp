@@ -104,6 +104,8 @@ struct FlatMat {
     // when D(node) - hsub exceeds the wanted score of every sample that still looks for ties here.
     std::vector<uint32_t> stream_t, chunk_t_off;             // chunk_t_off: [n_chunks+1]
     uint32_t max_path_muts = 0;            // max over nodes of the mutation count on the root path
+    bool mask_not_first = false;           // some non-root node lists a masked mutation behind an ordinary one: only the
+                                           // 32-bit walk (M_AFTER_MASK) scores such a node the way usher_mapper.cpp:190-270 does
 };
 
 // Returns UGP_OK or a negative UGP_ERR_* with `err` filled.

@@ -101,6 +101,43 @@ __global__ void k_scatter_entries(uint32_t *__restrict__ table, uint32_t *__rest
     if (r != a) atomicOr(&active[(uint64_t)tile * active_words + ((uint32_t)site >> 5)], 1u << ((uint32_t)site & 31u));
 }
 
+// Query rows on arrival (one thread per VCF row): the sample each row belongs to (binary search in the CSR
+// offsets) and the checks that validate_queries() used to run on the host -- rows of a sample sorted by
+// position without duplicates, REF one of A,C,G,T, allele mask in range, REF equal to the tree's reference
+// base at tree sites.  The first offending row (smallest row index, then smallest kind) is left in *err as
+// (row << 3) | kind; ~0 = clean.
+__global__ void k_rows_prepare(const uint64_t *__restrict__ ent_off, uint32_t n_queries, uint64_t n_ent,
+                               const int32_t *__restrict__ pos, const uint8_t *__restrict__ ref, const uint8_t *__restrict__ nuc,
+                               const uint8_t *__restrict__ is_missing, const int32_t *__restrict__ pos2site,
+                               const uint8_t *__restrict__ site_ref, uint32_t max_pos, uint32_t n_sites,
+                               uint32_t *__restrict__ ent_q, unsigned long long *__restrict__ err) {
+    const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n_ent) return;
+    uint32_t lo = 0, hi = n_queries;   // last q with ent_off[q] <= e
+    while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (ent_off[mid] <= e) lo = mid; else hi = mid; }
+    ent_q[e] = lo;
+    uint32_t kind = 0;
+    const int32_t p = pos[e];
+    const uint32_t r = ref[e];
+    if (e > ent_off[lo] && p <= pos[e - 1]) kind = ROWS_UNSORTED;
+    else if (r != 1 && r != 2 && r != 4 && r != 8) kind = ROWS_BAD_REF;
+    else if (!is_missing[e] && (nuc[e] == 0 || nuc[e] > 15)) kind = ROWS_BAD_MASK;
+    else if (p >= 0 && (uint32_t)p <= max_pos && n_sites) {
+        const int32_t site = pos2site[p];
+        if (site >= 0 && site_ref[site] != r) kind = ROWS_REF_MISMATCH;
+    }
+    if (kind) atomicMin(err, (unsigned long long)((e << 3) | kind));
+}
+
+hipError_t launch_rows_prepare(const uint64_t *ent_off, uint32_t n_queries, uint64_t n_ent, const int32_t *pos, const uint8_t *ref,
+                               const uint8_t *nuc, const uint8_t *is_missing, const int32_t *pos2site, const uint8_t *site_ref,
+                               uint32_t max_pos, uint32_t n_sites, uint32_t *ent_q, unsigned long long *err, hipStream_t s) {
+    if (n_ent == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_rows_prepare, dim3((uint32_t)((n_ent + 255) / 256)), dim3(256), 0, s, ent_off, n_queries, n_ent, pos, ref, nuc,
+                       is_missing, pos2site, site_ref, max_pos, n_sites, ent_q, err);
+    return hipGetLastError();
+}
+
 // ====================================================================
 // One sample per lane, 32-bit walk (scores, tie lists, phase 2, fallback)
 // ====================================================================
@@ -366,7 +403,8 @@ __global__ void k_merge(const uint32_t *__restrict__ part_best, const uint32_t *
 //     cost  = D(par) - e(accN)          ineligible samples (common == 0) -> 0xFFFF
 //     best  = min(best, cost)           v_pk_min_u16
 // 16-bit counters are safe because the host only takes this path when
-// max_rows(sample) + max_root_path_mutations(tree) < 0xFFFF.
+// max_rows(sample) + max_root_path_mutations(tree) + 2 < 0x7F7F: every D / cost then stays below the
+// 0x7F7F the shared upper bounds start from (bit 15 is the ineligible flag).
 
 struct Pk4 { uint32_t v[4]; };
 #ifndef UGP_GRP
@@ -1005,7 +1043,18 @@ __global__ void k_tile_ranges(const uint32_t *__restrict__ keys_sorted, uint32_t
     hlen[t] = h1 - h0;
 }
 
+__global__ void k_extract_best(const ugp_result *__restrict__ res, uint32_t n, int32_t *__restrict__ best) {
+    const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q < n) best[q] = res[q].best_set_difference;
+}
+
 // ---------------------------------------------------------------- launchers
+
+hipError_t launch_extract_best(const ugp_result *res, uint32_t n, int32_t *best, hipStream_t s) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_extract_best, dim3((n + 255) / 256), dim3(256), 0, s, res, n, best);
+    return hipGetLastError();
+}
 
 hipError_t launch_tile_ranges(const uint32_t *keys_sorted, uint32_t n_queries, uint32_t n_tiles512, const uint32_t *chunk_node_off,
                               uint32_t n_chunks, uint32_t align, uint32_t *hstart, uint32_t *hlen, hipStream_t s) {
@@ -1072,27 +1121,16 @@ hipError_t launch_merge(const uint32_t *part_best, const uint32_t *part_cnt, con
     return hipGetLastError();
 }
 
-hipError_t launch_best8(const Best8Args &a, uint32_t max_slots, hipStream_t s) {
+// Resident one-wave blocks of k_best8 per CU for a given dynamic LDS size, on the current device.
+hipError_t best8_occupancy(size_t lds_bytes, int *per_cu) {
+    return hipOccupancyMaxActiveBlocksPerMultiprocessor(per_cu, k_best8<false>, 64, lds_bytes);
+}
+
+// Persistent grid of `blocks` one-wave workgroups (the caller sizes a.cold for exactly that many).
+hipError_t launch_best8(const Best8Args &a, uint32_t blocks, hipStream_t s) {
     const size_t lds = (size_t)a.lds_slots * 64 * 16;
-    // persistent grid: as many one-wave blocks as the device keeps resident, never more than there are units
-    static int per_cu = 0, n_cu = 0;
-    static size_t lds_of = ~(size_t)0;
-    if (lds_of != lds) {
-        int dev = 0;
-        hipError_t e = hipGetDevice(&dev);
-        if (e == hipSuccess) e = hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
-        if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_best8<false>, 64, lds);
-        if (e != hipSuccess) return e;
-        lds_of = lds;
-    }
-    int waves_cu = std::max(per_cu, 1);
-    if (const char *e = getenv("UGP_WAVES_PER_CU")) waves_cu = std::max(1, std::min(waves_cu, atoi(e)));   // tuning
-    uint64_t blocks = (uint64_t)waves_cu * std::max(n_cu, 1);
-    const uint64_t units = (uint64_t)a.n_tiles * a.n_groups;
-    if (blocks > units) blocks = units;
-    blocks = ((blocks + 7) / 8) * 8;
-    if (a.stats) hipLaunchKernelGGL(k_best8<true>, dim3((uint32_t)blocks), dim3(64), lds, s, a);
-    else hipLaunchKernelGGL(k_best8<false>, dim3((uint32_t)blocks), dim3(64), lds, s, a);
+    if (a.stats) hipLaunchKernelGGL(k_best8<true>, dim3(blocks), dim3(64), lds, s, a);
+    else hipLaunchKernelGGL(k_best8<false>, dim3(blocks), dim3(64), lds, s, a);
     return hipGetLastError();
 }
 

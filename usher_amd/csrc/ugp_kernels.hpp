@@ -50,7 +50,8 @@ struct Best8Args {
     uint32_t *ub;              // [n_tiles][64][4] packed upper bounds of best(s) shared by the waves of a tile; nullptr = no pruning
 };
 
-hipError_t launch_best8(const Best8Args &a, uint32_t max_slots, hipStream_t s);
+hipError_t best8_occupancy(size_t lds_bytes, int *per_cu);
+hipError_t launch_best8(const Best8Args &a, uint32_t blocks, hipStream_t s);
 // a.n_tiles = number of 64-sample tiles; lbest/gbest in the packed 512-tile layout
 constexpr uint32_t GBEST_SLICES = 64;   // chunk-axis slices of the global-minimum reduction
 // gbest_part: [GBEST_SLICES][n_tiles512*256] scratch
@@ -59,6 +60,11 @@ hipError_t launch_phase2(const PlaceArgs &a, const uint32_t *lbest, const uint8_
                          uint32_t *items, uint32_t *n_items, uint32_t cap, uint32_t *cnt, uint32_t *key,
                          const uint32_t *rank2bfs, ugp_result *out, const uint32_t *order, uint32_t max_slots, hipStream_t s);
 
+// row checks of k_rows_prepare: *err = (row << 3) | kind of the first offending row, ~0 when clean
+enum { ROWS_UNSORTED = 1, ROWS_BAD_REF = 2, ROWS_BAD_MASK = 3, ROWS_REF_MISMATCH = 4 };
+hipError_t launch_rows_prepare(const uint64_t *ent_off, uint32_t n_queries, uint64_t n_ent, const int32_t *pos, const uint8_t *ref,
+                               const uint8_t *nuc, const uint8_t *is_missing, const int32_t *pos2site, const uint8_t *site_ref,
+                               uint32_t max_pos, uint32_t n_sites, uint32_t *ent_q, unsigned long long *err, hipStream_t s);
 hipError_t launch_fill_table(uint32_t *table, const uint8_t *site_ref, uint32_t n_sites, uint64_t total_dwords,
                              hipStream_t s);
 hipError_t launch_scatter(uint32_t *table, uint32_t *dbottom, const int32_t *pos, const uint8_t *ref,
@@ -73,6 +79,7 @@ hipError_t launch_seed_ub(const ugp_result *coarse_res, const uint32_t *order, u
 hipError_t launch_locality_sort(const ugp_result *coarse_res, const uint32_t *coarse2dfs, uint32_t n, uint32_t *keys,
                                 uint32_t *keys_sorted, uint32_t *idx, uint32_t *order, uint32_t *slot_of, void *temp,
                                 size_t *temp_bytes, hipStream_t s);
+hipError_t launch_extract_best(const ugp_result *res, uint32_t n, int32_t *best, hipStream_t s);
 hipError_t launch_place(const PlaceArgs &a, int mode, uint32_t max_slots, hipStream_t s);
 hipError_t launch_merge(const uint32_t *part_best, const uint32_t *part_cnt, const uint32_t *part_key,
                         const uint32_t *rank2bfs, uint32_t n_groups, uint32_t n_queries, ugp_result *out,

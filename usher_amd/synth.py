@@ -19,8 +19,10 @@ def _L():
             raise RuntimeError("libugp_synth.so is not built; run `make -C usher_amd/csrc`")
         L = C.CDLL(_PATH)
         P = C.c_void_p
-        L.ugs_tree_create.restype = P
-        L.ugs_tree_create.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint64]
+        L.ugs_tree_create2.restype = P
+        L.ugs_tree_create2.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint32]
+        L.ugs_tree_adopt.restype = P
+        L.ugs_tree_adopt.argtypes = [C.c_uint64, P, P, P, P, P, P, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint32]
         L.ugs_tree_destroy.argtypes = [P]
         for n in ("nodes", "muts"):
             getattr(L, "ugs_tree_" + n).restype = C.c_uint64
@@ -28,8 +30,8 @@ def _L():
         for n in ("parent", "mut_off", "mut_pos", "mut_ref", "mut_par", "mut_nuc"):
             getattr(L, "ugs_tree_" + n).restype = P
             getattr(L, "ugs_tree_" + n).argtypes = [P]
-        L.ugs_queries_create.restype = P
-        L.ugs_queries_create.argtypes = [P, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]
+        L.ugs_queries_create2.restype = P
+        L.ugs_queries_create2.argtypes = [P, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]
         L.ugs_queries_destroy.argtypes = [P]
         for n in ("count", "entries"):
             getattr(L, "ugs_queries_" + n).restype = C.c_uint64
@@ -48,12 +50,34 @@ def _arr(ptr, n, dt):
     return np.frombuffer(buf, dtype=dt).copy()
 
 
+SHAPES = {"random": 0, "sars2": 1}
+
+
 class SynthTree:
-    def __init__(self, target_nodes: int, genome_len: int = 29903, n_sites: int = 1500, seed: int = 1):
+    def __init__(self, target_nodes: int, genome_len: int = 29903, n_sites: int = 1500, seed: int = 1, shape: str = "random"):
         L = _L()
-        self._h = L.ugs_tree_create(target_nodes, genome_len, n_sites, seed)
+        self._h = L.ugs_tree_create2(target_nodes, genome_len, n_sites, seed, SHAPES[shape])
         if not self._h:
             raise ValueError("ugs_tree_create failed")
+        self._load(genome_len)
+
+    @classmethod
+    def from_arrays(cls, arrays: dict, genome_len: int = 29903, n_sites: int = 1500, seed: int = 1, shape: str = "random") -> "SynthTree":
+        """Adopt tree arrays another process generated with the same (seed, genome_len, n_sites): keeps the query generator usable."""
+        L = _L()
+        self = cls.__new__(cls)
+        par = np.asarray(arrays["parent"]).astype(np.int64)
+        par32 = np.ascontiguousarray(np.where(par < 0, 0xFFFFFFFF, par).astype(np.uint32))
+        keep = [par32, np.ascontiguousarray(arrays["mut_off"], dtype=np.uint64), np.ascontiguousarray(arrays["mut_pos"], dtype=np.int32)] + \
+               [np.ascontiguousarray(arrays[k]).astype(np.uint8) for k in ("mut_ref", "mut_par", "mut_nuc")]
+        self._h = L.ugs_tree_adopt(len(par32), *[a.ctypes.data_as(C.c_void_p) for a in keep], genome_len, n_sites, seed, SHAPES[shape])
+        if not self._h:
+            raise MemoryError("ugs_tree_adopt failed")
+        self._load(genome_len)
+        return self
+
+    def _load(self, genome_len: int):
+        L = _L()
         n, m = L.ugs_tree_nodes(self._h), L.ugs_tree_muts(self._h)
         par = _arr(L.ugs_tree_parent(self._h), n, np.uint32).astype(np.int64)
         par[par == 0xFFFFFFFF] = -1
@@ -64,10 +88,10 @@ class SynthTree:
         }
         self.genome_len = genome_len
 
-    def queries(self, n_queries: int, seed: int = 1, max_subst: int = 3, n_lo: int = 0, n_hi: int = 0, iupac_hi: int = 0):
+    def queries(self, n_queries: int, seed: int = 1, max_subst: int = 3, n_lo: int = 0, n_hi: int = 0, iupac_hi: int = 0, recent: bool = False):
         """CSR query arrays: (ent_off, pos, ref, nuc, is_missing, source_node)."""
         L = _L()
-        q = L.ugs_queries_create(self._h, n_queries, seed, max_subst, n_lo, n_hi, iupac_hi)
+        q = L.ugs_queries_create2(self._h, n_queries, seed, max_subst, n_lo, n_hi, iupac_hi, 1 if recent else 0)
         if not q:
             raise MemoryError("ugs_queries_create failed")
         try:
