@@ -119,6 +119,9 @@ typedef struct ugp_timing {
 /* Flatten + upload.  device = HIP device ordinal.  Replaces the per-sample
  * BFS rebuild and 2N vector allocations of usher_common.cpp:342-365. */
 int ugp_mat_create(const ugp_tree_desc *tree, int device, ugp_mat **out);
+/* Same tree on several devices of one node (flattened once, uploaded n times): the replicated read-only MAT of
+ * the multi-GPU path -- query samples shard across the handles, one host thread per handle. */
+int ugp_mat_create_multi(const ugp_tree_desc *tree, const int *devices, int n_devices, ugp_mat **out /* [n_devices] */);
 void ugp_mat_destroy(ugp_mat *mat);
 int ugp_mat_info(const ugp_mat *mat, ugp_info *out);
 

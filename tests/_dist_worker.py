@@ -1,0 +1,37 @@
+"""Worker of tests/test_multi_gpu.py: one rank per GPU (torchrun), queries sharded through
+usher_amd.dist.place_sharded with the RCCL all-gather, checked on every rank against the closed form."""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    import torch
+    import torch.distributed as dist
+    from oracle import capi
+    from usher_amd import Placer, QueryBatch, synth
+    from usher_amd.dist import place_sharded
+    local = int(os.environ["LOCAL_RANK"])
+    torch.cuda.set_device(local)
+    dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    st = synth.SynthTree(300_000, n_sites=4000, seed=12)
+    q = st.queries(5001, seed=99, n_lo=0, n_hi=30, iupac_hi=3)      # odd count: shards differ in size
+    batch = QueryBatch.from_csr(q["ent_off"], q["pos"], q["ref"], q["nuc"], q["is_missing"])
+    pl = Placer(st.arrays, device=local)
+    res = place_sharded(pl.place, batch, device="cuda")
+    pl.close()
+    cf = capi.ClosedFormC(capi.OracleTree(st.arrays)).place_csr(q["ent_off"], q["pos"], q["ref"], q["nuc"], q["is_missing"])
+    ok = (res["best_set_difference"].astype(np.int64) == cf["best"]).all() and (res["num_best"].astype(np.int64) == cf["num_best"]).all() \
+        and (res["best_j"].astype(np.int64) == cf["best_j"]).all() and (res["best_has_unique"].astype(bool) == cf["has_unique"]).all()
+    dist.barrier()
+    dist.destroy_process_group()
+    print("rank %d %s" % (int(os.environ["RANK"]), "OK" if ok else "MISMATCH"))
+    sys.exit(0 if ok else 1)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,67 @@
+"""Multi-GPU paths on real devices (skipped on a one-GPU box; the CPU suite covers the sharding logic with gloo,
+tests/test_dist_cpu.py): one process per GPU with the RCCL all-gather, the in-process MultiPlacer, and the
+front end's --devices list.  `--devices 0` on one device must equal the default run."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+EXE = os.path.join(ROOT, "usher_amd", "bin", "usher-amd")
+
+
+def _n_devices():
+    import torch
+    return torch.cuda.device_count()
+
+
+def test_place_sharded_on_two_devices_rccl():
+    if _n_devices() < 2:
+        pytest.skip("needs two GPUs")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29731", os.path.join(ROOT, "tests", "_dist_worker.py")], capture_output=True, text=True, timeout=1200, env=env)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
+    assert "rank 0 OK" in r.stdout and "rank 1 OK" in r.stdout
+
+
+def test_multiplacer_matches_single_device():
+    from oracle import capi
+    from usher_amd import MultiPlacer, Placer, QueryBatch, synth
+    st = synth.SynthTree(300_000, n_sites=4000, seed=12)
+    q = st.queries(3001, seed=5)
+    batch = QueryBatch.from_csr(q["ent_off"], q["pos"], q["ref"], q["nuc"], q["is_missing"])
+    devs = list(range(min(_n_devices(), 4)))
+    mp = MultiPlacer(st.arrays, devs + ([0] if len(devs) == 1 else []))   # on one GPU: two handles on device 0
+    multi = mp.place(batch)
+    mp.close()
+    pl = Placer(st.arrays)
+    single = pl.place(batch)
+    pl.close()
+    assert (multi.view(np.int32) == single.view(np.int32)).all()
+    cf = capi.ClosedFormC(capi.OracleTree(st.arrays)).place_csr(q["ent_off"], q["pos"], q["ref"], q["nuc"], q["is_missing"])
+    assert (multi["best_set_difference"].astype(np.int64) == cf["best"]).all() and (multi["best_j"].astype(np.int64) == cf["best_j"]).all()
+
+
+@pytest.mark.parametrize("flags", [["-n"], ["-u"], ["-p"]])
+def test_cli_devices_list_equals_default(flags, tmp_path):
+    """`--devices 0` (and `--devices 0,1,...` when the box has them) writes the same files as the default run."""
+    pb = os.path.join(GOLD, "survey_ref", "syn", "tree.pb")
+    vcf = os.path.join(GOLD, "survey_ref", "syn", "query.vcf")
+    # "0,0": two replicas on one device, so the sharding threads run on a one-GPU box too
+    lists = ["0", "0,0"] + (["0-%d" % (min(_n_devices(), 8) - 1)] if _n_devices() > 1 else [])
+    outs = []
+    for k, dev in enumerate([None] + lists):
+        d = tmp_path / ("o%d" % k)
+        d.mkdir()
+        cmd = [EXE, "-i", pb, "-v", vcf, "-d", str(d)] + flags + (["--devices", dev] if dev else [])
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=dict(os.environ, USHER_AMD_SHARD_MIN="7"))
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append({n: open(str(d / n)).read() for n in sorted(os.listdir(str(d)))})
+    for o in outs[1:]:
+        assert o == outs[0]

@@ -38,6 +38,7 @@ static const char *kHelp =
     "  -D [ --detailed-clades ]                  In clades.txt, write a histogram of annotated clades and counts across all equally parsimonious placements\n"
     "  -T [ --threads ] arg                      Number of host threads (the node x sample search runs on the GPU)\n"
     "  --device arg (=0)                         HIP device ordinal\n"
+    "  --devices arg                             HIP devices to shard the samples across, e.g. 0-7 or 0,2,3 (the tree is replicated)\n"
     "  --version                                 Print version number\n"
     "  -h [ --help ]                             Print help messages\n";
 
@@ -51,7 +52,7 @@ static int parse(int argc, char **argv, Options &o) {
         {'e', "max-uncertainty-per-sample", 1}, {'E', "max-parsimony-per-sample", 1}, {'u', "write-uncondensed-final-tree", 0},
         {'k', "write-subtrees-size", 1}, {'K', "write-single-subtree", 1}, {'p', "write-parsimony-scores-per-node", 0},
         {'M', "multiple-placements", 1}, {'l', "retain-input-branch-lengths", 0}, {'n', "no-add", 0}, {'D', "detailed-clades", 0},
-        {'T', "threads", 1}, {0, "device", 1}, {0, "version", 0}, {'h', "help", 0}};
+        {'T', "threads", 1}, {0, "device", 1}, {0, "devices", 1}, {0, "version", 0}, {'h', "help", 0}};
     bool version = false, help = false, bad = false;
     auto apply = [&](const Spec &sp, const char *val) {
         const std::string l = sp.l;
@@ -68,7 +69,7 @@ static int parse(int argc, char **argv, Options &o) {
         else if (l == "write-parsimony-scores-per-node") o.print_scores = true; else if (l == "multiple-placements") o.max_trees = (uint32_t)num(val);
         else if (l == "retain-input-branch-lengths") o.retain_branch_len = true; else if (l == "no-add") o.no_add = true;
         else if (l == "detailed-clades") o.detailed_clades = true; else if (l == "threads") o.threads = (uint32_t)num(val);
-        else if (l == "device") o.device = (int)num(val); else if (l == "version") version = true; else if (l == "help") help = true;
+        else if (l == "device") o.device = (int)num(val); else if (l == "devices") o.devices = val; else if (l == "version") version = true; else if (l == "help") help = true;
     };
     for (int i = 1; i < argc && !bad; i++) {
         const std::string a = argv[i];

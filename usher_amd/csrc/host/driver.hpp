@@ -24,6 +24,7 @@ struct Options {   // the 22 flags of src/usher.cpp:47-86
     bool retain_branch_len = false, no_add = false, detailed_clades = false;
     uint32_t threads = 0;
     int device = 0;   // extension: HIP device ordinal (--device)
+    std::string devices;   // extension: device list to shard the samples across (--devices 0-7); parsed by the backend
 };
 
 // The search block of usher_common.cpp:342-449 for a batch of samples on a

@@ -73,7 +73,7 @@ constexpr uint32_t kMaxTilesPerLaunch = 4096;   // 262,144 samples per sub-batch
 
 struct ugp_mat {
     int device = 0;
-    ugp::FlatMat flat;   // host copy of the small tables (pos2site, site_ref); streams are dropped after upload
+    ugp::FlatMat flat;   // the scalars of the flattening only (counts, depths); the arrays live on the device
     uint64_t stream_dwords = 0, pre_dwords = 0;
     DevBuf<uint32_t> d_stream, d_pre, d_chunk_body, d_chunk_pre, d_chunk_node, d_rank2bfs, d_dfs2bfs;
     DevBuf<uint32_t> d_stream8, d_pre8, d_chunk8_body, d_chunk8_pre, d_stream_t, d_chunk_t;
@@ -358,10 +358,20 @@ extern "C" {
 
 const char *ugp_last_error(void) { return g_err.c_str(); }
 
-static int mat_create_impl(const ugp_tree_desc *tree, int device, const ugp::Options &opt, ugp_mat **out, bool with_coarse = true);
+// Host side of a handle: the flattened tree plus, for trees large enough to profit from the locality sort, the
+// flattened coarse MAT (the top of the tree) and the map coarse BFS index -> DFS rank in the full tree.  Built
+// once per tree whatever the number of devices it is uploaded to.
+struct HostFlat {
+    ugp::FlatMat f;
+    std::vector<uint32_t> coarse2dfs;
+    HostFlat *coarse = nullptr;
+    ~HostFlat() { delete coarse; }
+};
 
-// The top of the tree (the nodes with the largest subtrees: N/2048 of them, at least 4096) as a MAT of its own.
-static int build_coarse(const ugp_tree_desc *t, int device, const std::vector<uint32_t> &dfs2bfs, ugp_mat *m) {
+static int host_flatten(const ugp_tree_desc *tree, const ugp::Options &opt, bool with_coarse, HostFlat &hf);
+
+// The top of the tree (the nodes with the largest subtrees: N/1024 of them, at least 4096) as a MAT of its own.
+static int build_coarse(const ugp_tree_desc *t, HostFlat &hf) {
     const uint64_t N = t->n_nodes;
     uint64_t min_nodes = 1u << 18;   // below this a tree pass is too short for the sort to pay off
     if (const char *e = getenv("UGP_COARSE_MIN_NODES")) min_nodes = (uint64_t)atoll(e);   // tests lower it
@@ -392,38 +402,50 @@ static int build_coarse(const ugp_tree_desc *t, int device, const std::vector<ui
     ugp::Options copt;
     copt.chunk_nodes = 128;
     if (const char *e = getenv("UGP_COARSE_CHUNK_NODES")) copt.chunk_nodes = (uint32_t)std::max(1, atoi(e));
-    int rc = mat_create_impl(&d, device, copt, &m->coarse, false);
-    if (rc != UGP_OK) return rc;
-    std::vector<uint32_t> dfs_rank(N), c2d(keep.size());
-    for (uint64_t r = 0; r < N; r++) dfs_rank[dfs2bfs[r]] = (uint32_t)r;
-    for (size_t k = 0; k < keep.size(); k++) c2d[k] = dfs_rank[keep[k]];
-    if (m->d_coarse2dfs.upload(c2d) != hipSuccess) return fail(UGP_ERR_HIP, "upload coarse table");
+    hf.coarse = new HostFlat();
+    if (int rc = host_flatten(&d, copt, false, *hf.coarse)) return rc;
+    std::vector<uint32_t> dfs_rank(N);
+    hf.coarse2dfs.resize(keep.size());
+    for (uint64_t r = 0; r < N; r++) dfs_rank[hf.f.dfs2bfs[r]] = (uint32_t)r;
+    for (size_t k = 0; k < keep.size(); k++) hf.coarse2dfs[k] = dfs_rank[keep[k]];
     return UGP_OK;
 }
 
-static int mat_create_impl(const ugp_tree_desc *tree, int device, const ugp::Options &opt, ugp_mat **out, bool with_coarse) {
-    if (!tree || !out) return fail(UGP_ERR_INVALID, "null argument");
+static int host_flatten(const ugp_tree_desc *tree, const ugp::Options &opt, bool with_coarse, HostFlat &hf) {
+    std::string err;
+    int rc;
+    try {
+        rc = ugp::flatten(*tree, opt, hf.f, err);
+        if (rc == UGP_OK && with_coarse) {
+            rc = build_coarse(tree, hf);
+            if (rc != UGP_OK) return rc;   // (message already set)
+        }
+    } catch (const std::bad_alloc &) {
+        return fail(UGP_ERR_NOMEM, "out of host memory while flattening the tree");
+    }
+    if (rc != UGP_OK) return fail(rc, err);
+    return UGP_OK;
+}
+
+// Upload a flattened tree to one device.  The handle keeps the scalars of the flattening only.
+static int upload_flat(const HostFlat &hf, int device, ugp_mat **out) {
     *out = nullptr;
     ugp_mat *m = new (std::nothrow) ugp_mat();
     if (!m) return fail(UGP_ERR_NOMEM, "out of host memory");
     m->device = device;
-    std::string err;
-    int rc;
-    try {
-        rc = ugp::flatten(*tree, opt, m->flat, err);
-    } catch (const std::bad_alloc &) {
-        delete m;
-        return fail(UGP_ERR_NOMEM, "out of host memory while flattening the tree");
-    }
-    if (rc != UGP_OK) { delete m; return fail(rc, err); }
     auto bail = [&](hipError_t e, const char *what) {
         std::string msg = std::string(what) + ": " + hipGetErrorString(e);
-        delete m;
+        ugp_mat_destroy(m);
         return fail(UGP_ERR_HIP, msg);
     };
     hipError_t e;
     if ((e = hipSetDevice(device)) != hipSuccess) return bail(e, "hipSetDevice");
-    auto &f = m->flat;
+    const auto &f = hf.f;
+    {   // scalars
+        auto &g = m->flat;
+        g.n_nodes = f.n_nodes; g.n_muts = f.n_muts; g.n_sites = f.n_sites; g.max_pos = f.max_pos; g.max_slots = f.max_slots;
+        g.n_chunks = f.n_chunks; g.max_path_muts = f.max_path_muts; g.mask_not_first = f.mask_not_first;
+    }
     if ((e = m->d_stream.upload(f.stream)) != hipSuccess) return bail(e, "upload stream");
     if ((e = m->d_pre.upload(f.pre_stream)) != hipSuccess) return bail(e, "upload preambles");
     if ((e = m->d_chunk_body.upload(f.chunk_body_off)) != hipSuccess) return bail(e, "upload chunk table");
@@ -443,29 +465,52 @@ static int mat_create_impl(const ugp_tree_desc *tree, int device, const ugp::Opt
     if ((e = m->d_chunk8_pre.upload(f.chunk8_pre_off)) != hipSuccess) return bail(e, "upload chunk table");
     if ((e = m->d_stream_t.upload(f.stream_t)) != hipSuccess) return bail(e, "upload tie stream");
     if ((e = m->d_chunk_t.upload(f.chunk_t_off)) != hipSuccess) return bail(e, "upload chunk table");
-    std::vector<uint32_t>().swap(f.stream_t);
     m->stream8_dwords = f.stream8.size();
-    std::vector<uint32_t>().swap(f.stream8);
-    std::vector<uint32_t>().swap(f.pre8_stream);
-    if (with_coarse) {
-        if (int rc = build_coarse(tree, device, f.dfs2bfs, m)) { delete m; return rc; }
-    }
     m->stream_dwords = f.stream.size();
     m->pre_dwords = f.pre_stream.size();
-    std::vector<uint32_t>().swap(f.stream);
-    std::vector<uint32_t>().swap(f.pre_stream);
-    std::vector<uint32_t>().swap(f.rank2bfs);
-    std::vector<uint32_t>().swap(f.dfs2bfs);
+    if (hf.coarse) {
+        if (int rc = upload_flat(*hf.coarse, device, &m->coarse)) { ugp_mat_destroy(m); return rc; }
+        if ((e = m->d_coarse2dfs.upload(hf.coarse2dfs)) != hipSuccess) return bail(e, "upload coarse table");
+    }
     *out = m;
     return UGP_OK;
 }
 
-int ugp_mat_create(const ugp_tree_desc *tree, int device, ugp_mat **out) {
+static ugp::Options default_options() {
     ugp::Options opt;
     if (const char *e = getenv("UGP_CHUNK_NODES")) opt.chunk_nodes = (uint32_t)std::max(1, atoi(e));
     if (const char *e = getenv("UGP_PRUNE_MIN_WORDS")) opt.prune_min_words = (uint32_t)std::max(1, atoi(e));
     if (getenv("UGP_NO_SIB")) opt.sibling_records = false;
-    return mat_create_impl(tree, device, opt, out);
+    return opt;
+}
+
+static int mat_create_impl(const ugp_tree_desc *tree, int device, const ugp::Options &opt, ugp_mat **out) {
+    if (!tree || !out) return fail(UGP_ERR_INVALID, "null argument");
+    *out = nullptr;
+    HostFlat hf;
+    if (int rc = host_flatten(tree, opt, true, hf)) return rc;
+    return upload_flat(hf, device, out);
+}
+
+// One flattening, n devices: the replicated read-only MAT of the multi-GPU path.  out[i] lives on
+// devices[i]; on failure nothing is left allocated.
+int ugp_mat_create_multi(const ugp_tree_desc *tree, const int *devices, int n_devices, ugp_mat **out) {
+    if (!tree || !devices || !out || n_devices < 1) return fail(UGP_ERR_INVALID, "null argument");
+    for (int i = 0; i < n_devices; i++) out[i] = nullptr;
+    HostFlat hf;
+    if (int rc = host_flatten(tree, default_options(), true, hf)) return rc;
+    for (int i = 0; i < n_devices; i++) {
+        if (int rc = upload_flat(hf, devices[i], &out[i])) {
+            const std::string msg = g_err;
+            for (int k = 0; k < i; k++) { ugp_mat_destroy(out[k]); out[k] = nullptr; }
+            return fail(rc, msg);
+        }
+    }
+    return UGP_OK;
+}
+
+int ugp_mat_create(const ugp_tree_desc *tree, int device, ugp_mat **out) {
+    return mat_create_impl(tree, device, default_options(), out);
 }
 
 void ugp_mat_destroy(ugp_mat *m) {

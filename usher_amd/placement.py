@@ -193,3 +193,62 @@ class Placer:
         out = _lib.ugp_timing()
         _check(_lib.lib().ugp_get_timing(self._h, C.byref(out)))
         return {k: getattr(out, k) for k, _ in out._fields_}
+
+
+class MultiPlacer:
+    """The same tree on several devices of one node (ugp_mat_create_multi: flattened once, uploaded n times).
+    `place` shards a batch into contiguous blocks, one per device, each placed by its own host thread (ctypes
+    releases the GIL for the duration of the call); the gather is a host-memory write.  This is the in-process
+    form of the multi-GPU path (the reference simply loops over samples, usher_common.cpp:310); usher_amd.dist is
+    the one-process-per-GPU form with an RCCL all-gather."""
+
+    def __init__(self, arrays: Dict, devices: Sequence[int]):
+        L = _lib.lib()
+        self._t = _TreeArrays(arrays)
+        self.n_nodes = self._t.n
+        self.devices = list(devices)
+        n = len(self.devices)
+        devs = (C.c_int * n)(*self.devices)
+        hs = (C.c_void_p * n)()
+        _check(L.ugp_mat_create_multi(C.byref(self._t.desc), devs, n, hs))
+        self._hs = [C.c_void_p(h) for h in hs]
+
+    def close(self) -> None:
+        for h in getattr(self, "_hs", []):
+            if h.value:
+                _lib.lib().ugp_mat_destroy(h)
+        self._hs = []
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def place(self, batch: QueryBatch) -> np.ndarray:
+        import threading
+        from .dist import shard_bounds
+        n = len(self._hs)
+        out = np.zeros(len(batch), dtype=RESULT_DTYPE)
+        errs: List[Optional[BaseException]] = [None] * n
+
+        def work(d: int):
+            try:
+                lo, hi = shard_bounds(len(batch), n, d)
+                if hi > lo:
+                    part = batch.slice(lo, hi)
+                    res = np.zeros(hi - lo, dtype=RESULT_DTYPE)
+                    _check(_lib.lib().ugp_place_batch(self._hs[d], C.byref(part.desc), _ptr(res)))
+                    out[lo:hi] = res
+            except BaseException as e:   # noqa: BLE001 -- re-raised on the calling thread
+                errs[d] = e
+
+        ts = [threading.Thread(target=work, args=(d,)) for d in range(n)]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join()
+        for e in errs:
+            if e is not None:
+                raise e
+        return out
