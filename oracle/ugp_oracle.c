@@ -493,6 +493,8 @@ typedef struct orc_pool {
     orc_job *jobs;                /* [nthreads + 1], slot nthreads = the caller */
     int64_t next;                 /* next unclaimed node (atomic) */
     int64_t n;
+    int shared_best;              /* smallest best_set_difference any worker has found (atomic): the reference's
+                                     workers all read ONE *input.best_set_difference (usher_mapper.cpp:457-461) */
 } orc_pool;
 
 static void orc_run_ranges(orc_pool *pl, orc_job *jb) {
@@ -501,8 +503,18 @@ static void orc_run_ranges(orc_pool *pl, orc_job *jb) {
         int64_t lo = __atomic_fetch_add(&pl->next, ORC_GRAIN, __ATOMIC_RELAXED);
         if (lo >= pl->n) break;
         int64_t hi = lo + ORC_GRAIN < pl->n ? lo + ORC_GRAIN : pl->n;
+        /* adopt a strictly better score another worker has found: this worker's own ties are then obsolete
+         * (the early return of usher_mapper.cpp:383-385 only ever drops nodes that are strictly worse) */
+        int g = __atomic_load_n(&pl->shared_best, __ATOMIC_RELAXED);
+        if (g < jb->sh.best_set_difference) {
+            jb->sh.best_set_difference = g; jb->sh.num_best = 0; jb->sh.best_j_vec_n = 0;
+            jb->sh.best_node_num_leaves = -1; jb->sh.best_j = -1;   /* no winner of its own at this score yet */
+        }
         for (int64_t k = lo; k < hi; k++)
             orc_mapper2(jb->t, k, jb->sm, jb->n_sm, &jb->sh, 0, 0, NULL, NULL, NULL, &anc, NULL);
+        g = __atomic_load_n(&pl->shared_best, __ATOMIC_RELAXED);
+        while (jb->sh.best_set_difference < g &&
+               !__atomic_compare_exchange_n(&pl->shared_best, &g, jb->sh.best_set_difference, 0, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {}
     }
     free(anc.v);
 }
@@ -578,7 +590,7 @@ int orc_place_sample_pool(orc_pool *pl, const orc_tree *t, int64_t n_ent, const 
         pl->jobs[i].sh.num_best = 0;
     }
     pthread_mutex_lock(&pl->mu);
-    pl->n = t->n; pl->next = 0; pl->running = pl->nthreads; pl->epoch++;
+    pl->n = t->n; pl->next = 0; pl->running = pl->nthreads; pl->shared_best = init_best; pl->epoch++;
     pthread_cond_broadcast(&pl->cv_go);
     pthread_mutex_unlock(&pl->mu);
     orc_run_ranges(pl, &pl->jobs[pl->nthreads]);   /* the caller works too */
@@ -799,6 +811,16 @@ int orc_cf_place_batch(const orc_cf *c, int64_t n_q, const int64_t *ent_off, con
     int rc = jobs[nthreads - 1].rc;
     for (int i = 0; i + 1 < nthreads; i++) { pthread_join(th[i], NULL); if (jobs[i].rc) rc = jobs[i].rc; }
     free(th); free(jobs);
+    return rc;
+}
+
+/* D(n, s) of every node for one sample (tuning / analysis aid for the pruning bounds). */
+int orc_cf_D(const orc_cf *c, int64_t n_ent, const int32_t *pos, const int8_t *ref, const int8_t *nuc,
+             const int8_t *is_missing, int32_t *D) {
+    uint8_t *S = (uint8_t *)calloc((size_t)c->max_pos + 1, 1);
+    int32_t b; int64_t nb, bj; int8_t hu;
+    int rc = orc_cf_place_one(c, n_ent, pos, ref, nuc, is_missing, S, D, NULL, &b, &nb, &bj, &hu, NULL, NULL, 0);
+    free(S);
     return rc;
 }
 

@@ -423,7 +423,7 @@ def test_config2_100k_nodes_1k_queries_every_sample_vs_oracle(coarse, monkeypatc
     st = gsynth.SynthTree(100_000, n_sites=1500, seed=2)
     q = st.queries(1024, seed=77)
     pl = Placer(st.arrays)
-    assert pl.info()["n_nodes"] == 100_000
+    assert pl.info()["n_nodes"] >= 100_000
     res = pl.place(_csr_batch(q))
     assert pl.timing()["packed_path"] == 1
     ot = capi.OracleTree(st.arrays)
