@@ -114,9 +114,10 @@ def place(flat, sample, n_groups=1, want_scores=False):
 # packed stream ("stream8"): interpreter of k_best8 + phase 2, one sample at a
 # time but with the kernel's 16-bit wrap-around arithmetic and 4-bit counters.
 # --------------------------------------------------------------------------
-H_SIB = 1 << 21
-H_TAG, H_SKIPD, H_NOSCORE8, H_END, H_FREE, H_CHUNK_END, H_NOP, H_INFO = (
-    1 << 31, 1 << 12, 1 << 13, 1 << 16, 1 << 17, 1 << 18, 1 << 19, 1 << 30)
+# layout of ugp_flatten.hpp (final encoding)
+H_TAG, H_INFO, H_RARE, H_SIB = 1 << 31, 1 << 30, 1 << 29, 1 << 21
+H_REG, H_STORE, H_NOSCORE8, H_END, H_FREE, H_SKIPD, H_BOTTOM, H_SLOW, H_CHUNK_END, H_NOP = (1 << k for k in range(10))
+H_RSLOT_SHIFT, H_WSLOT_SHIFT, INFO_HS_SHIFT = 10, 20, 22
 M_FLUSH, M_END = 1 << 28, 1 << 30
 U16 = 0xFFFF
 
@@ -138,13 +139,11 @@ def best8_group(flat, nib, dbot, c0, c1, ub=None, stats=None):
     def finish():
         nonlocal best, dcur, accP, accC, accN, flushed, carryD, carryN, carryC
         assert accP <= 15 and accC <= 15 and accN <= 15
-        dn = 0
-        if not (hdr & H_SKIPD):
-            dn = (dpar + accP - accC + (carryD if flushed else 0)) & U16
-            dcur = dn
-            wslot = (hdr >> 6) & 63
-            if wslot != WS_NONE:
-                slots[wslot] = dn
+        # (the kernel computes D(node) for H_SKIPD nodes too; nothing reads it)
+        dn = (dpar + accP - accC + (carryD if flushed else 0)) & U16
+        dcur = dn
+        if hdr & H_STORE:
+            slots[(hdr >> H_WSLOT_SHIFT) & 63] = dn
         if not (hdr & H_NOSCORE8):
             cost = (dpar - accN - (carryN if flushed else 0)) & U16
             common = (accC + (carryC if flushed else 0) + (1 if hdr & H_FREE else 0)) & U16
@@ -163,6 +162,10 @@ def best8_group(flat, nib, dbot, c0, c1, ub=None, stats=None):
             w = int(words[i])
             ended = False
             if w & H_TAG:
+                if w & (H_INFO | H_CHUNK_END | H_NOP) or (w & H_SLOW):
+                    assert w & H_RARE   # everything off the fast path carries the one bit the kernel tests first
+                else:
+                    assert not (w & H_RARE) and not (w & H_BOTTOM)
                 if w & H_INFO:          # first: the jump length of a pruning record overlaps the other flag bits
                     if ub is not None and phase == 1:
                         if w & H_SIB:
@@ -180,10 +183,15 @@ def best8_group(flat, nib, dbot, c0, c1, ub=None, stats=None):
                     chunk += 1
                     continue
                 hdr = w
-                rslot = w & 63
-                dpar = dcur if rslot == RS_REG else (dbot if rslot == RS_BOTTOM else slots[rslot])
+                if w & H_SLOW:          # cold slot (beyond the LDS-resident ones) or the root
+                    rs, ws = (w >> H_RSLOT_SHIFT) & 63, (w >> H_WSLOT_SHIFT) & 63
+                    assert (w & H_BOTTOM) or (not (w & H_REG) and rs >= flat.lds_slots) or ((w & H_STORE) and ws >= flat.lds_slots)
+                else:
+                    assert (w & H_REG) or ((w >> H_RSLOT_SHIFT) & 63) < flat.lds_slots
+                    assert not (w & H_STORE) or ((w >> H_WSLOT_SHIFT) & 63) < flat.lds_slots
+                dpar = dcur if w & H_REG else (dbot if w & H_BOTTOM else slots[(w >> H_RSLOT_SHIFT) & 63])
                 if sinfo is not None:   # sibling record: skip this child and the non-last siblings after it?
-                    hs, jump = (sinfo >> 22) & 0xFF, sinfo & 0x1FFFFF
+                    hs, jump = (sinfo >> INFO_HS_SHIFT) & 0x7F, sinfo & 0x1FFFFF
                     sinfo = None
                     if dpar >= ub[0] + 1 + hs:
                         target = i + jump
@@ -218,7 +226,7 @@ def best8_group(flat, nib, dbot, c0, c1, ub=None, stats=None):
                     finish()
                     ended = True
             if ended and info is not None:
-                hs, jump = (info >> 22) & 0xFF, info & 0x1FFFFF
+                hs, jump = (info >> INFO_HS_SHIFT) & 0x7F, info & 0x1FFFFF
                 info = None
                 if dcur >= ub[0] + 1 + hs:          # D(node) - hsub > upper bound: no descendant can tie or win
                     target = i + 1 + jump

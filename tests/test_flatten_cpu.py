@@ -103,7 +103,7 @@ def test_packed_stream_flushes_long_branches():
     rng = np.random.default_rng(9)
     arrays, queries = synth.make_case(50, n_leaves=40, n_queries=8, n_sites=200, mut_counts=(0, 1, 17, 33, 40))
     flat = _check(arrays, queries, chunk_nodes=7, n_groups=4)
-    assert ((flat.stream8 & (1 << 28)) != 0).any() and flat.max_path_muts > 30
+    assert (((flat.stream8 >> 31) == 0) & ((flat.stream8 & (1 << 28)) != 0)).any() and flat.max_path_muts > 30
 
 
 def test_pruning_records_skip_far_subtrees_exactly():

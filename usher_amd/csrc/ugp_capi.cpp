@@ -207,7 +207,7 @@ int run_place(ugp_mat *m, ugp_qset *qs, int mode, ugp_result *d_out, int32_t *d_
             while (G < f.n_chunks && (uint64_t)G * n_tiles512 < 4096) G = std::min<uint32_t>(f.n_chunks, G * 2);
             if (const char *e = getenv("UGP_GROUPS")) G = std::min<uint32_t>(f.n_chunks, (uint32_t)std::max(1, atoi(e)));
         }
-        const uint64_t table_dwords = (uint64_t)n_tiles512 * n_sites * 64;
+        const uint64_t table_dwords = (uint64_t)n_tiles512 * (n_sites + ugp::TABLE_CONST_ROWS) * 64;
         HIP_TRY(m->d_table.reserve(table_dwords));
         HIP_TRY(m->d_dbottom.reserve((size_t)n_tiles512 * 512));
         HIP_TRY(m->d_active.reserve((size_t)n_tiles512 * active_words));
@@ -311,8 +311,7 @@ int run_place(ugp_mat *m, ugp_qset *qs, int mode, ugp_result *d_out, int32_t *d_
             b.max_slots = f.max_slots;
             // LDS holds the hot slots only (the kernel's registers allow 6 waves per SIMD, 13 KB of LDS per wave
             // would stop at 3); the colder ones, touched once per ~1,300 words, go to a small global scratch
-            b.lds_slots = std::min<uint32_t>(f.max_slots, 7);
-            if (const char *e = getenv("UGP_LDS_SLOTS")) b.lds_slots = std::min<uint32_t>(f.max_slots, (uint32_t)std::max(1, atoi(e)));
+            b.lds_slots = f.lds_slots;   // fixed when the tree was flattened (headers touching colder slots are flagged there)
             // persistent grid: as many one-wave blocks as the device keeps resident (cached per handle and LDS
             // size), never more than there are units; the cold-slot scratch is sized for exactly that grid
             const size_t lds_bytes = (size_t)b.lds_slots * 64 * 16;
@@ -401,6 +400,7 @@ static int build_coarse(const ugp_tree_desc *t, HostFlat &hf) {
     ugp_tree_desc d{keep.size(), parent.data(), mut_off.data(), pos.data(), ref.data(), par.data(), nuc.data()};
     ugp::Options copt;
     copt.chunk_nodes = 128;
+    if (const char *e = getenv("UGP_LDS_SLOTS")) copt.lds_slots = (uint32_t)std::max(1, std::min(60, atoi(e)));
     if (const char *e = getenv("UGP_COARSE_CHUNK_NODES")) copt.chunk_nodes = (uint32_t)std::max(1, atoi(e));
     hf.coarse = new HostFlat();
     if (int rc = host_flatten(&d, copt, false, *hf.coarse)) return rc;
@@ -444,7 +444,7 @@ static int upload_flat(const HostFlat &hf, int device, ugp_mat **out) {
     {   // scalars
         auto &g = m->flat;
         g.n_nodes = f.n_nodes; g.n_muts = f.n_muts; g.n_sites = f.n_sites; g.max_pos = f.max_pos; g.max_slots = f.max_slots;
-        g.n_chunks = f.n_chunks; g.max_path_muts = f.max_path_muts; g.mask_not_first = f.mask_not_first;
+        g.n_chunks = f.n_chunks; g.max_path_muts = f.max_path_muts; g.mask_not_first = f.mask_not_first; g.lds_slots = f.lds_slots;
     }
     if ((e = m->d_stream.upload(f.stream)) != hipSuccess) return bail(e, "upload stream");
     if ((e = m->d_pre.upload(f.pre_stream)) != hipSuccess) return bail(e, "upload preambles");
@@ -481,6 +481,7 @@ static ugp::Options default_options() {
     if (const char *e = getenv("UGP_CHUNK_NODES")) opt.chunk_nodes = (uint32_t)std::max(1, atoi(e));
     if (const char *e = getenv("UGP_PRUNE_MIN_WORDS")) opt.prune_min_words = (uint32_t)std::max(1, atoi(e));
     if (getenv("UGP_NO_SIB")) opt.sibling_records = false;
+    if (const char *e = getenv("UGP_LDS_SLOTS")) opt.lds_slots = (uint32_t)std::max(1, std::min(60, atoi(e)));
     return opt;
 }
 
@@ -734,7 +735,7 @@ int ugp_get_timing(ugp_mat *m, ugp_timing *out) {
 // Test / tuning hook (not part of the drop-in surface): ugp_mat_create with an
 // explicit chunk size so small fixtures exercise multi-chunk launches.
 int ugp_mat_create_chunked(const ugp_tree_desc *tree, int device, uint32_t chunk_nodes, ugp_mat **out) {
-    ugp::Options opt;
+    ugp::Options opt = default_options();
     opt.chunk_nodes = chunk_nodes;
     return mat_create_impl(tree, device, opt, out);
 }
@@ -748,7 +749,7 @@ int ugp_flat_create(const ugp_tree_desc *tree, uint32_t chunk_nodes, ugp_flat **
     *out = nullptr;
     ugp_flat *fl = new (std::nothrow) ugp_flat();
     if (!fl) return fail(UGP_ERR_NOMEM, "out of host memory");
-    ugp::Options opt;
+    ugp::Options opt = default_options();
     opt.chunk_nodes = chunk_nodes;
     std::string err;
     int rc;
@@ -786,6 +787,7 @@ int ugp_flat_get(const ugp_flat *fl, int which, const void **ptr, uint64_t *coun
         case UGP_FLAT_STREAM_T: *ptr = f.stream_t.data(); *count = f.stream_t.size(); break;
         case UGP_FLAT_CHUNK_T_OFF: *ptr = f.chunk_t_off.data(); *count = f.chunk_t_off.size(); break;
         case UGP_FLAT_MAX_PATH_MUTS: *ptr = nullptr; *count = f.max_path_muts; break;
+        case UGP_FLAT_LDS_SLOTS: *ptr = nullptr; *count = f.lds_slots; break;
         default: return fail(UGP_ERR_INVALID, "unknown array id");
     }
     return UGP_OK;

@@ -19,6 +19,15 @@
 
 namespace ugp {
 
+// Intermediate encoding of the packed stream while it is being emitted (slot numbers are renumbered by use
+// afterwards, and only then can a header be told apart as fast-path or H_SLOW): rslot [5:0], wslot [11:6],
+// flags below; pruning records {E_INFO, hs [29:22], jump [20:0]}.  finalize8() converts to the layout of
+// ugp_flatten.hpp.
+namespace {
+constexpr uint32_t E_SKIPD = 1u << 12, E_NOSCORE = 1u << 13, E_END = 1u << 16, E_FREE = 1u << 17, E_CHUNK_END = 1u << 18,
+                   E_NOP = 1u << 19, E_SIB = 1u << 21, E_INFO = 1u << 30;
+}
+
 static inline int nuc_index(uint8_t onehot) {
     switch (onehot) {
         case 1: return 0;
@@ -317,10 +326,10 @@ int flatten(const ugp_tree_desc &t, const Options &opt, FlatMat &out, std::strin
         uint32_t rslot = root ? RS_BOTTOM : ((preamble || first_eff[j]) ? RS_REG : slot[t.parent[j]]);
         uint32_t wslot = (eff_children[j] >= 2) ? slot[j] : WS_NONE;
         uint32_t h = H_TAG | rslot | (wslot << 6);
-        if (eff_children[j] == 0 && !root) h |= H_SKIPD;
-        if (preamble || root || node_masked[j]) h |= H_NOSCORE;
-        if (nwords == 0) h |= H_END;
-        if (!root && nch > 0 && nwords == 0 && !node_masked[j]) h |= H_FREE;
+        if (eff_children[j] == 0 && !root) h |= E_SKIPD;
+        if (preamble || root || node_masked[j]) h |= E_NOSCORE;
+        if (nwords == 0) h |= E_END;
+        if (!root && nch > 0 && nwords == 0 && !node_masked[j]) h |= E_FREE;
         dst.push_back(h);
         for (uint32_t k = 0; k < nwords; k++) {
             uint32_t w = out.stream[off + 2 + k] & 0x0FFFFFFFu;   // site, mutated / parent-state / reference allele
@@ -329,7 +338,7 @@ int flatten(const ugp_tree_desc &t, const Options &opt, FlatMat &out, std::strin
             dst.push_back(w);
         }
         // the root scores through a pseudo-node right behind its D record: cost = D(parent) = D(root)
-        if (root && !preamble) dst.push_back(H_TAG | RS_REG | (WS_NONE << 6) | H_SKIPD | H_FREE | H_END);
+        if (root && !preamble) dst.push_back(H_TAG | RS_REG | (WS_NONE << 6) | E_SKIPD | E_FREE | E_END);
     };
     // pruning records: hsub[j] = max mutation words on a path j -> descendant (excluding j's own),
     // subw[j] = stream words of j's descendants (approximate: without the records themselves)
@@ -358,7 +367,7 @@ int flatten(const ugp_tree_desc &t, const Options &opt, FlatMat &out, std::strin
             big_after[c] = run_big;
             run_h = std::max(run_h, hdown[c]);
             suffix_h[c] = run_h;
-            if (subw[c] >= opt.prune_min_words && hsub[c] <= 255) run_big++;
+            if (subw[c] >= opt.prune_min_words && hsub[c] <= INFO_HS_MAX) run_big++;
         }
     }
     std::vector<std::vector<uint32_t>> sib_open;   // per open parent: positions of its unpatched sibling records
@@ -373,7 +382,7 @@ int flatten(const ugp_tree_desc &t, const Options &opt, FlatMat &out, std::strin
             const OpenBig &b = open_big.back();
             const uint64_t jump = out.stream8.size() - b.own_end;
             const uint32_t hs = (out.stream8[b.info_pos] >> 22) & 0xFFu;
-            out.stream8[b.info_pos] = (jump <= INFO_JUMP_MASK && jump > 0) ? (H_TAG | H_INFO | (hs << 22) | (uint32_t)jump) : (H_TAG | H_NOP);
+            out.stream8[b.info_pos] = (jump <= INFO_JUMP_MASK && jump > 0) ? (H_TAG | E_INFO | (hs << 22) | (uint32_t)jump) : (H_TAG | E_NOP);
             open_big.pop_back();
         }
     };
@@ -402,33 +411,33 @@ int flatten(const ugp_tree_desc &t, const Options &opt, FlatMat &out, std::strin
                     for (uint32_t pos8 : sib_open[sib_slot[p]]) {
                         const uint64_t jump = out.stream8.size() - sib_hdr_pos[pos8];
                         uint32_t &w = out.stream8[pos8];
-                        w = (jump <= INFO_JUMP_MASK && jump > 0) ? (w | (uint32_t)jump) : (H_TAG | H_NOP);
+                        w = (jump <= INFO_JUMP_MASK && jump > 0) ? (w | (uint32_t)jump) : (H_TAG | E_NOP);
                     }
                     sib_open[sib_slot[p]].clear();
                     free_sib.push_back(sib_slot[p]);
                     sib_slot[p] = UINT32_MAX;
                   }
-                } else if (big_after[j] >= 1 && suffix_h[j] <= 255 && !preamble_only) {
+                } else if (big_after[j] >= 1 && suffix_h[j] <= INFO_HS_MAX && !preamble_only) {
                     if (sib_slot[p] == UINT32_MAX) {
                         if (free_sib.empty()) { free_sib.push_back((uint32_t)sib_open.size()); sib_open.emplace_back(); }
                         sib_slot[p] = free_sib.back(); free_sib.pop_back();
                     }
                     sib_open[sib_slot[p]].push_back((uint32_t)out.stream8.size());
                     sib_pending_hdr = (uint32_t)out.stream8.size();
-                    out.stream8.push_back(H_TAG | H_INFO | H_SIB | (suffix_h[j] << 22));   // jump patched when the last child starts
+                    out.stream8.push_back(H_TAG | E_INFO | E_SIB | (suffix_h[j] << 22));   // jump patched when the last child starts
                 }
             }
-            const bool big = j != 0 && subw[j] >= opt.prune_min_words && hsub[j] <= 255;
+            const bool big = j != 0 && subw[j] >= opt.prune_min_words && hsub[j] <= INFO_HS_MAX;
             if (big) {
                 open_big.push_back({(uint32_t)out.stream8.size(), 0u, d + sub[j]});
-                out.stream8.push_back(H_TAG | H_INFO | (hsub[j] << 22));   // jump patched when the subtree closes
+                out.stream8.push_back(H_TAG | E_INFO | (hsub[j] << 22));   // jump patched when the subtree closes
             }
             if (sib_pending_hdr != UINT32_MAX) { sib_hdr_pos[sib_pending_hdr] = (uint32_t)out.stream8.size(); sib_pending_hdr = UINT32_MAX; }
             emit8(out.stream8, j, false);
             if (big) open_big.back().own_end = (uint32_t)out.stream8.size();
         }
         close_big(out.chunk_node_off[c + 1]);
-        out.stream8.push_back(H_TAG | H_CHUNK_END);
+        out.stream8.push_back(H_TAG | E_CHUNK_END);
         out.chunk8_pre_off.push_back((uint32_t)out.pre8_stream.size());
         uint32_t a = out.dfs2bfs[out.chunk_node_off[c]];
         path.clear();
@@ -485,11 +494,13 @@ int flatten(const ugp_tree_desc &t, const Options &opt, FlatMat &out, std::strin
     flat_lap("tie stream");
     // Renumber the packed stream's slots by access frequency, hottest first: the
     // kernel keeps the first few in LDS and the cold remainder in a global scratch
-    // (slot use is bell-shaped over the index, a handful of slots take ~95 %).
+    // (slot use is bell-shaped over the index, a handful of slots take ~95 %).  Then
+    // convert every header to its final layout (ugp_flatten.hpp): only now is it known
+    // which headers touch a cold slot and have to leave the fast path (H_SLOW).
     {
         uint64_t freq[64] = {0};
         for (uint32_t w : out.stream8) {
-            if (!(w & H_TAG) || (w & (H_CHUNK_END | H_NOP | H_INFO))) continue;
+            if (!(w & H_TAG) || (w & (E_CHUNK_END | E_NOP | E_INFO))) continue;
             uint32_t rs = w & 63u, ws = (w >> 6) & 63u;
             if (rs < RS_BOTTOM) freq[rs]++;
             if (ws != WS_NONE) freq[ws]++;
@@ -499,17 +510,34 @@ int flatten(const ugp_tree_desc &t, const Options &opt, FlatMat &out, std::strin
         std::stable_sort(order, order + out.max_slots, [&](uint32_t a, uint32_t b) { return freq[a] > freq[b]; });
         for (uint32_t i = 0; i < 64; i++) remap[i] = i;
         for (uint32_t i = 0; i < out.max_slots; i++) remap[order[i]] = i;
-        auto fix = [&](std::vector<uint32_t> &v) {
+        out.lds_slots = std::max<uint32_t>(1, std::min<uint32_t>(opt.lds_slots, out.max_slots));
+        const uint32_t hot = out.lds_slots;
+        auto finalize8 = [&](std::vector<uint32_t> &v) {
             for (uint32_t &w : v) {
-                if (!(w & H_TAG) || (w & (H_CHUNK_END | H_NOP | H_INFO))) continue;
+                if (!(w & H_TAG)) continue;
+                if (w & E_INFO) {   // (first: the jump length overlaps the other intermediate flag bits)
+                    w = H_TAG | H_INFO | H_RARE | (w & E_SIB ? H_SIB : 0u) | (((w >> 22) & 0x7Fu) << INFO_HS_SHIFT) | (w & INFO_JUMP_MASK);
+                    continue;
+                }
+                if (w & E_CHUNK_END) { w = H_TAG | H_RARE | H_CHUNK_END; continue; }
+                if (w & E_NOP) { w = H_TAG | H_RARE | H_NOP; continue; }
                 uint32_t rs = w & 63u, ws = (w >> 6) & 63u;
-                if (rs < RS_BOTTOM) rs = remap[rs];
-                if (ws != WS_NONE) ws = remap[ws];
-                w = (w & ~0xFFFu) | rs | (ws << 6);
+                uint32_t h = H_TAG;
+                bool slow = false;
+                if (rs == RS_REG) h |= H_REG;
+                else if (rs == RS_BOTTOM) { h |= H_BOTTOM; slow = true; }
+                else { rs = remap[rs]; h |= rs << H_RSLOT_SHIFT; slow |= rs >= hot; }
+                if (ws != WS_NONE) { ws = remap[ws]; h |= H_STORE | (ws << H_WSLOT_SHIFT); slow |= ws >= hot; }
+                if (w & E_SKIPD) h |= H_SKIPD;
+                if (w & E_NOSCORE) h |= H_NOSCORE;
+                if (w & E_END) h |= H_END;
+                if (w & E_FREE) h |= H_FREE;
+                if (slow) h |= H_SLOW | H_RARE;
+                w = h;
             }
         };
-        fix(out.stream8);
-        fix(out.pre8_stream);
+        finalize8(out.stream8);
+        finalize8(out.pre8_stream);
     }
     flat_lap("slot renumbering");
     return UGP_OK;

@@ -38,41 +38,52 @@ constexpr uint32_t T_PRUNE_MIN_DWORDS = 24;  // subtrees shorter than this are n
 // ---- packed stream ("stream8") walked by k_best8: 8 samples per lane -------
 //
 // One 32-bit word per event.  Leaves without mutation words never influence a
-// result (not eligible, no descendants) and are dropped.
+// result (not eligible, no descendants) and are dropped.  The layout is chosen
+// so that the walk needs almost no scalar-ALU work per word (k_best8 is bound
+// by the one scalar unit of a CU, not by its four vector units): every flag
+// the fast path branches on is one bit (s_bitcmp), slot numbers sit where a
+// vector AND yields the LDS byte address, and everything that needs more
+// decoding is flagged H_RARE and handled outside the pipelined loop.
 //   HDR word (bit 31 set), opens a node:
-//       [5:0] rslot  [11:6] wslot   (same meaning as above, on the effective tree)
-//       H_SKIPD   D(node) is not needed (no effective children)
+//       H_REG     D(parent) is the D of the previous node (first effective child, preamble copies)
+//       [15:10]   rslot: saved-D slot holding D(parent) when !H_REG  ((w & 0xFC00) = byte offset of the slot row in LDS)
+//       H_STORE   D(node) is saved for later children, into
+//       [25:20]   wslot  (((w >> 10) & 0xFC00) = byte offset)
 //       H_NOSCORE not a candidate here: preamble copy, node carrying a masked
 //                 mutation (never eligible), or the root's D record (see below)
-//       H_FREE    every sample is eligible (internal node without mutations)
 //       H_END     node has no mutation words: finish it now
-//       H_CHUNK_END (alone) closes a chunk: publish the chunk-local minimum and reset
-//       H_NOP     padding
-//       H_INFO    (alone, in front of the header of a node with a large subtree) pruning record:
+//       H_FREE    every sample is eligible (internal node without mutations)
+//       H_SKIPD   D(node) is not needed (no effective children); informational -- computing it anyway is harmless
+//       H_RARE    the word leaves the fast path: a pruning record, a chunk end, padding, or a header that
+//                 needs the general code (H_SLOW: one of its slots is not among the LDS-resident ones, or
+//                 H_BOTTOM: the root, whose D(parent) is D_bottom)
+//       H_CHUNK_END (with H_RARE) closes a chunk: publish the chunk-local minimum and reset
+//       H_NOP     (with H_RARE) padding
+//       H_INFO    (with H_RARE, in front of the header of a node with a large subtree) pruning record:
 //                 [20:0] jump = stream words occupied by the node's descendants,
-//                 [29:22] hsub = largest number of mutation words on any path node -> descendant;
+//                 [28:22] hsub = largest number of mutation words on any path node -> descendant;
 //                 every descendant d has cost(d) >= D(node) - hsub (each mutation lowers D by at most 1),
 //                 so the subtree can be skipped when D(node,s) - hsub > upper bound of best(s) for all s
-//       H_INFO | H_SIB (alone, in front of a non-last child c_i of a node p, before c_i's own H_INFO):
+//       H_INFO | H_SIB (in front of a non-last child c_i of a node p, before c_i's own H_INFO):
 //                 sibling record: [20:0] jump = stream words from c_i's header to the start of p's last child,
-//                 [29:22] hs = max over the remaining non-last children c_j (j >= i) of (mutation words of c_j +
+//                 [28:22] hs = max over the remaining non-last children c_j (j >= i) of (mutation words of c_j +
 //                 hsub(c_j)); every node d of those subtrees has cost(d) >= D(p) - hs, so when
 //                 D(p,s) - hs > upper bound of best(s) for all s they are all skipped with one jump.  The
 //                 non-last children are emitted in descending order of that quantity, so hs only shrinks.
-//                 (Both kinds of record keep their jump in 21 bits.)
-//     The root is emitted as two records: its D record (rslot = RS_BOTTOM,
-//     H_NOSCORE) followed by a scoring pseudo-node (RS_REG, H_SKIPD | H_FREE |
-//     H_END) whose cost is D(parent) = D(root): cost(root) = D(root), always
-//     eligible (usher_mapper.cpp:454).
+//     The root is emitted as two records: its D record (H_BOTTOM, H_NOSCORE) followed by a scoring
+//     pseudo-node (H_REG | H_SKIPD | H_FREE | H_END) whose cost is D(parent) = D(root): cost(root) = D(root),
+//     always eligible (usher_mapper.cpp:454).
 //   MUT word (bit 31 clear):
 //       [21:0] site  [23:22] mutated allele  [25:24] parent-state allele  [27:26] reference allele
 //       M_FLUSH  15 mutations accumulated in the 4-bit counters: spill them
 //       M_END    last mutation word of the node
-constexpr uint32_t H_TAG = 1u << 31, H_SKIPD = 1u << 12, H_NOSCORE = 1u << 13, H_END = 1u << 16,
-                   H_FREE = 1u << 17, H_CHUNK_END = 1u << 18, H_NOP = 1u << 19, H_INFO = 1u << 30,
-                   H_SIB = 1u << 21;   // with H_INFO: sibling record
-constexpr uint32_t INFO_JUMP_MASK = (1u << 21) - 1u;
+constexpr uint32_t H_TAG = 1u << 31, H_INFO = 1u << 30, H_RARE = 1u << 29, H_SIB = 1u << 21;
+constexpr uint32_t H_REG = 1u << 0, H_STORE = 1u << 1, H_NOSCORE = 1u << 2, H_END = 1u << 3, H_FREE = 1u << 4,
+                   H_SKIPD = 1u << 5, H_BOTTOM = 1u << 6, H_SLOW = 1u << 7, H_CHUNK_END = 1u << 8, H_NOP = 1u << 9;
+constexpr uint32_t H_RSLOT_SHIFT = 10, H_WSLOT_SHIFT = 20;
+constexpr uint32_t INFO_JUMP_MASK = (1u << 21) - 1u, INFO_HS_SHIFT = 22, INFO_HS_MAX = 127;
 constexpr uint32_t PRUNE_MIN_WORDS = 4;     // only subtrees at least this long carry a pruning record
+constexpr uint32_t LDS_SLOTS = 7;           // saved-D slots k_best8 keeps in LDS (1 KB each per wave); the colder ones live in a global scratch
 constexpr uint32_t M_FLUSH = 1u << 28, M_END = 1u << 30;
 constexpr uint32_t MAX_SITES = 1u << 22;
 constexpr uint32_t MAX_NODE_MUTS = 65534;   // 0xFFFF marks a pruning pseudo-record of the tie stream
@@ -81,6 +92,7 @@ struct Options {
     uint32_t chunk_nodes = 0;   // 0 = automatic (about N/32768, at least 128)
     uint32_t prune_min_words = PRUNE_MIN_WORDS;   // subtrees at least this long (stream words) carry a pruning record
     bool sibling_records = true;   // emit H_INFO | H_SIB records
+    uint32_t lds_slots = LDS_SLOTS; // headers whose (renumbered) slots are >= this are flagged H_SLOW
 };
 
 struct FlatMat {
@@ -104,6 +116,7 @@ struct FlatMat {
     // when D(node) - hsub exceeds the wanted score of every sample that still looks for ties here.
     std::vector<uint32_t> stream_t, chunk_t_off;             // chunk_t_off: [n_chunks+1]
     uint32_t max_path_muts = 0;            // max over nodes of the mutation count on the root path
+    uint32_t lds_slots = 0;                // the Options value the packed stream was encoded for (<= max_slots)
     bool mask_not_first = false;           // some non-root node lists a masked mutation behind an ordinary one: only the
                                            // 32-bit walk (M_AFTER_MASK) scores such a node the way usher_mapper.cpp:190-270 does
 };

@@ -57,17 +57,19 @@ __device__ __forceinline__ uint32_t rdlane(uint32_t v, uint32_t l) {
 
 // ----------------------------------------------------------- allele tiles
 
-// table[tile512][site][64 dwords]: one 256-byte row per (512-sample tile, site);
+// table[tile512][4 + site][64 dwords]: one 256-byte row per (512-sample tile, site), behind 4 constant rows;
 // dword l, nibble j = allele set of sample tile*512 + 8*l + j at that site.
 // Initialised to the reference base everywhere (a sample without a VCF row at a
 // position carries the reference allele, usher_mapper.cpp:244, 301, 425).
+// Rows 0..3 of every tile are constants ("every sample carries A / C / G / T"): k_best8 fetches the constant
+// row of a site's reference base instead of the site's own row wherever no sample of the tile differs from it.
 __global__ void k_fill_table(uint32_t *__restrict__ table, const uint8_t *__restrict__ site_ref,
-                             uint32_t n_sites, uint64_t total_dwords) {
+                             uint32_t n_rows, uint64_t total_dwords) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     for (; i < total_dwords; i += stride) {
-        uint32_t site = (uint32_t)((i >> 6) % n_sites);
-        table[i] = (uint32_t)site_ref[site] * 0x11111111u;
+        const uint32_t row = (uint32_t)((i >> 6) % n_rows);
+        table[i] = row < TABLE_CONST_ROWS ? (0x11111111u << row) : (uint32_t)site_ref[row - TABLE_CONST_ROWS] * 0x11111111u;
     }
 }
 
@@ -94,7 +96,7 @@ __global__ void k_scatter_entries(uint32_t *__restrict__ table, uint32_t *__rest
     const int32_t site = pos2site[p];
     if (site < 0) return;
     const uint32_t tile = q >> 9, within = q & 511;
-    uint32_t *w = table + ((uint64_t)tile * n_sites + (uint32_t)site) * 64 + (within >> 3);
+    uint32_t *w = table + ((uint64_t)tile * (n_sites + TABLE_CONST_ROWS) + TABLE_CONST_ROWS + (uint32_t)site) * 64 + (within >> 3);
     const uint32_t sh = (within & 7) * 4;
     atomicXor(w, ((r ^ a) & 15u) << sh);   // nibble was r (k_fill_table); rows are unique per (sample, position)
     // the row of (tile, site) is no longer "reference everywhere"
@@ -171,7 +173,7 @@ struct WalkOut { uint32_t best, cnt, key; };
 // them, since cost(d) >= D(node) - hsub for every descendant d.
 __device__ __forceinline__ WalkOut walk_ties(const PlaceArgs &a, uint32_t *slots, uint32_t tile, uint32_t c, uint32_t lane,
                                              uint32_t want, bool relevant) {
-    const uint32_t *tab = a.table + (uint64_t)(tile >> 3) * a.n_sites * 64 + (tile & 7u) * 8 + (lane >> 3);
+    const uint32_t *tab = a.table + ((uint64_t)(tile >> 3) * (a.n_sites + TABLE_CONST_ROWS) + TABLE_CONST_ROWS) * 64 + (tile & 7u) * 8 + (lane >> 3);
     const uint32_t sh = (lane & 7u) * 4u;
     const uint32_t dbot = a.dbottom[tile * 64 + lane];
     WalkOut o; o.best = 0; o.cnt = 0; o.key = 0;
@@ -252,7 +254,7 @@ __device__ __forceinline__ WalkOut walk_ties(const PlaceArgs &a, uint32_t *slots
 template <int MODE>
 __device__ __forceinline__ WalkOut walk(const PlaceArgs &a, uint32_t *slots, uint32_t tile, uint32_t c0, uint32_t c1,
                                         uint32_t lane, uint32_t want_best) {
-    const uint32_t *tab = a.table + (uint64_t)(tile >> 3) * a.n_sites * 64 + (tile & 7u) * 8 + (lane >> 3);
+    const uint32_t *tab = a.table + ((uint64_t)(tile >> 3) * (a.n_sites + TABLE_CONST_ROWS) + TABLE_CONST_ROWS) * 64 + (tile & 7u) * 8 + (lane >> 3);
     const uint32_t sh = (lane & 7u) * 4u;
     const uint32_t q = tile * 64 + lane;
     const uint32_t dbot = a.dbottom[q];
@@ -400,29 +402,37 @@ __global__ void k_merge(const uint32_t *__restrict__ part_best, const uint32_t *
 // widened to the packed layout {sample j | sample j+4 << 16}, j = 0..3:
 //     e(acc, j) = (acc >> 4j) & 0x000F000F
 //     D(n)  = D(par) + e(accP) - e(accC)
-//     cost  = D(par) - e(accN)          ineligible samples (common == 0) -> 0xFFFF
+//     cost  = D(par) - e(accN)          ineligible samples (common == 0) -> bit 15 set
 //     best  = min(best, cost)           v_pk_min_u16
 // 16-bit counters are safe because the host only takes this path when
 // max_rows(sample) + max_root_path_mutations(tree) + 2 < 0x7F7F: every D / cost then stays below the
 // 0x7F7F the shared upper bounds start from (bit 15 is the ineligible flag).
+//
+// Instruction mix.  The walk is wave-uniform, and a compiler puts every uniform computation on the
+// scalar ALU -- of which a CU has ONE, shared by its four SIMDs.  The first version of this kernel
+// issued 1.2 scalar instructions per vector instruction and was bound by that unit (68 % busy,
+// profiles/r02a) with the vector ALUs 25 % busy.  Here the decoding of the stream words is done by
+// the vector units instead, eight words at a time, one word per lane (`decode`): row offset with
+// the "row is reference-everywhere for this tile" substitution folded in, shift amounts, LDS byte
+// offsets of the slots; a word then costs one v_readlane per field it actually uses, its flag
+// tests are single-bit scalar compares, and everything unusual (pruning records, chunk ends, headers
+// touching a cold slot) is one H_RARE bit away from the fast path.
 
 struct Pk4 { uint32_t v[4]; };
 #ifndef UGP_GRP
 #define UGP_GRP 8
 #endif
 constexpr uint32_t GRP = UGP_GRP;   // stream words per pipeline group (= unroll factor of the walk)
+constexpr uint32_t CONST_ROWS = TABLE_CONST_ROWS;  // rows 0..3 of every tile's table: all samples carry A / C / G / T
 
 __device__ __forceinline__ uint32_t ex4(uint32_t acc, int j) { return (acc >> (4 * j)) & 0x000F000Fu; }
 
-template <bool STATS>   // STATS: per-unit cycle accounting for tuning (UGP_STATS); off in production, it costs SGPRs
+template <bool STATS>   // STATS: per-unit accounting for tuning (UGP_STATS); off in production, it costs SGPRs
 __global__ void __launch_bounds__(64) k_best8(Best8Args a) {
     extern __shared__ __attribute__((aligned(16))) u32x4 slots8[];   // [lds_slots][64] x 16 B: the hot saved-D slots
     const uint32_t lane = threadIdx.x;
-    // (All slots stay in LDS: spilling the rarely used ones to global memory would put stores into
-    // the loop, and on gfx9 stores share vmcnt with loads out of order, which makes hipcc wait
-    // vmcnt(0) before every table-row use and destroys the prefetch pipeline.)
-    auto slot_load = [&](uint32_t sl) -> u32x4 { return slots8[sl * 64 + lane]; };
-    auto slot_store = [&](uint32_t sl, u32x4 v) { slots8[sl * 64 + lane] = v; };
+    const uint32_t lane16 = lane * 16u;
+    auto lds_at = [&](uint32_t byte_off) -> u32x4 * { return (u32x4 *)((char *)slots8 + byte_off); };
     // Persistent wave: work units u = (tile, chunk range) are pulled from 8 queues, one per XCD.
     // Queue x owns a contiguous run of tiles, so an XCD walks few tiles at a time and their
     // non-reference table rows stay resident in its 4 MiB L2 (block b is observed to land on XCD
@@ -489,9 +499,11 @@ __global__ void __launch_bounds__(64) k_best8(Best8Args a) {
         if (!got) return;
     }
     if (c0 >= c1) continue;
-    // table rows through a buffer resource: address = tile base + 4*lane (VGPR) + 256*site (SGPR soffset)
+    // table rows through a buffer resource: address = tile base + 4*lane (VGPR) + 256*row (SGPR soffset);
+    // rows 0..3 are the constant rows, site s is row s + 4
+    const uint32_t n_rows = a.n_sites + CONST_ROWS;
     const __amdgpu_buffer_rsrc_t trsrc = __builtin_amdgcn_make_buffer_rsrc(
-        (void *)(a.table + (uint64_t)tile * a.n_sites * 64), 0, (int)(a.n_sites * 256u), 0x00020000);
+        (void *)(a.table + (uint64_t)tile * n_rows * 64), 0, (int)(n_rows * 256u), 0x00020000);
     const uint32_t lane4 = lane * 4u;
     Pk4 dbot;
     {
@@ -504,9 +516,10 @@ __global__ void __launch_bounds__(64) k_best8(Best8Args a) {
     for (int j = 0; j < 4; j++) { best.v[j] = 0xFFFFFFFFu; dcur.v[j] = 0; dpar.v[j] = 0; carryD.v[j] = 0; carryN.v[j] = 0; carryC.v[j] = 0; }
     uint32_t accP = 0, accC = 0, accN = 0;
     uint32_t hdr = 0;          // uniform: header of the open node
+    uint32_t hdr_wa = 0;       // uniform: LDS byte offset of its write slot
     bool flushed = false;      // uniform
     uint32_t chunk = c0;       // uniform: chunk whose body is being walked
-    const uint32_t NOPW = H_TAG | H_NOP;
+    const uint32_t NOPW = H_TAG | H_RARE | H_NOP;
     // pruning: ub1 = (upper bound of best(s)) + 1 per sample, refreshed from / published to a.ub at chunk ends
     bool prune = false;        // uniform; only while walking the body (phase 1)
     bool have_info = false;    // uniform
@@ -562,114 +575,35 @@ __global__ void __launch_bounds__(64) k_best8(Best8Args a) {
         for (int j = 0; j < 4; j++) best.v[j] = 0xFFFFFFFFu;
         chunk++;
     };
-
-    // One stream word.  x = the lane's dword of the word's table row (unused for headers).
-    // `pos` = index of the word inside the wave's range.  A step may ask the pipeline to restart at
-    // another position through skip_to (chunk end: publish results outside the load pipeline; pruning:
-    // jump over a subtree).
-    // Saved-D slots beyond a.lds_slots live in a small global scratch (one access per ~1,300 words at 10M
-    // nodes; 8 KB of LDS per wave instead of 13 lets 20 waves share a CU).  The pipelined copies of `step`
-    // (SLOW = false) do not touch it -- a store there would share vmcnt with the row loads and force
-    // vmcnt(0) waits: a node that reads or writes a cold slot asks for a restart at its header, and the
-    // restart code walks that one node with the SLOW copy, which accesses the scratch directly.
-    uint32_t *coldp = a.cold + ((uint64_t)blockIdx.x * (a.max_slots > a.lds_slots ? a.max_slots - a.lds_slots : 0u) * 64 + lane) * 4;
-    bool replay = false;       // uniform: restart at skip_to - 1 and walk one node with the SLOW copy
-    auto step = [&](uint32_t w, uint32_t x, uint32_t pos, auto slow_tag) {
-        constexpr bool SLOW = decltype(slow_tag)::value;
-        if (w & H_TAG) {
-            if (w & (H_NOP | H_CHUNK_END | H_INFO)) {
-                // (H_INFO first: the jump length of a pruning record overlaps the other flag bits)
-                if (w & H_INFO) {
-                    if (prune) {
-                        if (w & H_SIB) { sinfo = w; have_sinfo = true; }   // about the node that follows and its later siblings
-                        else { info = w; have_info = true; }               // about the node that follows and its descendants
-                    }
-                }
-                else if (w & H_CHUNK_END) {
-                    // a chunk with a candidate (or a due exchange of bounds) is closed by the restart code, which may
-                    // store; any other chunk just ends here, inside the pipeline
-                    if (chunk_has_candidate() || ub_age + 1 >= a.ub_every) skip_to = pos + 1;
-                    else {
-                        ub_age++;
+    // "can everything below / beside this node be skipped?": true when D - hs > upper bound of best(s) for all 512 samples
+    auto all_far = [&](const Pk4 &d, uint32_t rec) -> bool {
+        const uint32_t hs = ((rec >> INFO_HS_SHIFT) & 0x7Fu) * 0x00010001u;
+        uint32_t near = 0;   // non-zero where D(s) - hs <= upper bound of best(s)
 #pragma unroll
-                        for (int j = 0; j < 4; j++) best.v[j] = 0xFFFFFFFFu;
-                        chunk++;
-                        cend_stale = true;
-                    }
-                }
-                return;
-            }
-            const uint32_t rslot = w & 63u;
-            if (!SLOW) {
-                const uint32_t ws = (w >> 6) & 63u;
-                if ((rslot < RS_BOTTOM && rslot >= a.lds_slots) || (ws != WS_NONE && ws >= a.lds_slots)) {
-                    replay = true; skip_to = pos + 1;   // (nothing of this node has been touched yet)
-                    return;
-                }
-            }
-            hdr = w;
-            if (rslot == RS_REG) {
-#pragma unroll
-                for (int j = 0; j < 4; j++) dpar.v[j] = dcur.v[j];
-            } else if (rslot == RS_BOTTOM) {
-#pragma unroll
-                for (int j = 0; j < 4; j++) dpar.v[j] = dbot.v[j];
-            } else if (SLOW && rslot >= a.lds_slots) {
-                const u32x4 t = *(const u32x4 *)(coldp + (uint64_t)(rslot - a.lds_slots) * 256);
-                dpar.v[0] = t.x; dpar.v[1] = t.y; dpar.v[2] = t.z; dpar.v[3] = t.w;
-            } else {
-                const u32x4 t = slot_load(rslot);
-                dpar.v[0] = t.x; dpar.v[1] = t.y; dpar.v[2] = t.z; dpar.v[3] = t.w;
-            }
-            if (have_sinfo) {   // sibling record: can this child and the non-last siblings after it all be skipped?
-                have_sinfo = false;
-                const uint32_t hs = ((sinfo >> 22) & 0xFFu) * 0x00010001u;
-                uint32_t bad = 0;   // non-zero where D(parent,s) - hs <= upper bound of best(s)
-#pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    const uint32_t t1 = pk_add(ub1.v[j], hs);
-                    bad |= pk_min(dpar.v[j], t1) ^ t1;
-                }
-                if (__builtin_amdgcn_ballot_w64(bad != 0) == 0) {
-                    skip_to = pos + (sinfo & INFO_JUMP_MASK);   // the start of the parent's last child
-                    have_info = false;
-                    if (STATS) n_skipped += sinfo & INFO_JUMP_MASK;
-                    return;
-                }
-            }
-            if (!(w & H_END)) return;
-        } else {
-            const uint32_t mi = (w >> 22) & 3u, pi = (w >> 24) & 3u;
-            const uint32_t C = (x >> mi) & 0x11111111u, P = (x >> pi) & 0x11111111u;
-            accP += P; accC += C; accN += C & ~P;
-            if (w & M_FLUSH) {   // 15 mutations in the 4-bit counters: spill to the packed carries (rare)
-#pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    const uint32_t eP = ex4(accP, j), eC = ex4(accC, j), eN = ex4(accN, j);
-                    carryD.v[j] = pk_sub(pk_add(carryD.v[j], eP), eC);   // carries are zero outside a long node
-                    carryN.v[j] = pk_add(carryN.v[j], eN);
-                    carryC.v[j] = pk_add(carryC.v[j], eC);
-                }
-                accP = accC = accN = 0;
-                flushed = true;
-            }
-            if (!(w & M_END)) return;
+        for (int j = 0; j < 4; j++) {
+            const uint32_t t1 = pk_add(ub1.v[j], hs);
+            near |= pk_min(d.v[j], t1) ^ t1;
         }
-        // ---- end of the open node
+        return __builtin_amdgcn_ballot_w64(near != 0) == 0;
+    };
+
+    // Saved-D slots beyond a.lds_slots live in a small global scratch (one access per ~1,300 words at 10M
+    // nodes; 7 KB of LDS per wave lets 20 waves share a CU).  The pipelined loop never touches it -- a store
+    // there would share vmcnt with the row loads and force vmcnt(0) waits: a header that reads or writes a cold
+    // slot (or the root, whose parent value is D_bottom) carries H_SLOW | H_RARE, asks for a restart at its
+    // own position, and the restart code walks that one node with `slow_node`, the general form of the step.
+    uint32_t *coldp = a.cold + ((uint64_t)blockIdx.x * (a.max_slots > a.lds_slots ? a.max_slots - a.lds_slots : 0u) * 64 + lane) * 4;
+    bool replay = false;       // uniform: restart at skip_to - 1 and walk one node with slow_node
+
+    // ---- end of the open node (shared by the fast and the slow step); wa = LDS byte offset of the write slot,
+    // or 0xFFFFFFFF with `cold_ws` >= 0 for a cold one
+    auto node_end = [&](uint32_t pos, int cold_ws) -> bool {   // true: a pruning jump was requested (skip_to)
         // A sample is ineligible here when it shares no mutation with the branch (common == 0,
         // usher_mapper.cpp:454-455) unless the node is "free": z has bit 4j set for such samples
         // and is turned into a 0x8000 penalty on the 16-bit cost (valid costs stay below 0x8000).
         if (flushed) {   // node with more than 15 mutations (rare): fold the carries in
-            if (!(hdr & H_SKIPD)) {
 #pragma unroll
-                for (int j = 0; j < 4; j++) dcur.v[j] = pk_add(pk_sub(pk_add(dpar.v[j], ex4(accP, j)), ex4(accC, j)), carryD.v[j]);
-                const uint32_t wslot = (hdr >> 6) & 63u;
-                if (wslot != WS_NONE) {
-                    if (SLOW && wslot >= a.lds_slots)
-                        *(u32x4 *)(coldp + (uint64_t)(wslot - a.lds_slots) * 256) = u32x4{dcur.v[0], dcur.v[1], dcur.v[2], dcur.v[3]};
-                    else slot_store(wslot, u32x4{dcur.v[0], dcur.v[1], dcur.v[2], dcur.v[3]});
-                }
-            }
+            for (int j = 0; j < 4; j++) dcur.v[j] = pk_add(pk_sub(pk_add(dpar.v[j], ex4(accP, j)), ex4(accC, j)), carryD.v[j]);
             if (!(hdr & H_NOSCORE)) {
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
@@ -684,16 +618,9 @@ __global__ void __launch_bounds__(64) k_best8(Best8Args a) {
             for (int j = 0; j < 4; j++) { carryD.v[j] = 0; carryN.v[j] = 0; carryC.v[j] = 0; }
             flushed = false;
         } else {
-            if (!(hdr & H_SKIPD)) {
+            // (D(node) is computed even where no child will read it: cheaper than testing for it)
 #pragma unroll
-                for (int j = 0; j < 4; j++) dcur.v[j] = pk_sub(pk_add(dpar.v[j], ex4(accP, j)), ex4(accC, j));
-                const uint32_t wslot = (hdr >> 6) & 63u;
-                if (wslot != WS_NONE) {
-                    if (SLOW && wslot >= a.lds_slots)
-                        *(u32x4 *)(coldp + (uint64_t)(wslot - a.lds_slots) * 256) = u32x4{dcur.v[0], dcur.v[1], dcur.v[2], dcur.v[3]};
-                    else slot_store(wslot, u32x4{dcur.v[0], dcur.v[1], dcur.v[2], dcur.v[3]});
-                }
-            }
+            for (int j = 0; j < 4; j++) dcur.v[j] = pk_sub(pk_add(dpar.v[j], ex4(accP, j)), ex4(accC, j));
             if (!(hdr & H_NOSCORE)) {
                 uint32_t z = accC | (accC >> 1);
                 z |= z >> 2;
@@ -706,37 +633,118 @@ __global__ void __launch_bounds__(64) k_best8(Best8Args a) {
                 }
             }
         }
+        if (hdr & H_STORE) {
+            const u32x4 v = u32x4{dcur.v[0], dcur.v[1], dcur.v[2], dcur.v[3]};
+            if (cold_ws >= 0) *(u32x4 *)(coldp + (uint64_t)cold_ws * 256) = v;
+            else *lds_at(hdr_wa | lane16) = v;
+        }
         accP = accC = accN = 0;
+        if (STATS) run_nodes++;
         if (have_info) {   // this node carries a pruning record: can its whole subtree be skipped?
             have_info = false;
-            const uint32_t hs = ((info >> 22) & 0xFFu) * 0x00010001u;
-            uint32_t bad = 0;   // non-zero where D(node,s) - hsub <= upper bound of best(s)
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const uint32_t t1 = pk_add(ub1.v[j], hs);
-                bad |= pk_min(dcur.v[j], t1) ^ t1;
-            }
-            if (__builtin_amdgcn_ballot_w64(bad != 0) == 0) {
+            if (all_far(dcur, info)) {
                 skip_to = pos + 1 + (info & INFO_JUMP_MASK);
-                if (STATS) { n_skipped += info & 0x3FFFFFu; if (run_nodes == 0) n_first_skip++; }
+                if (STATS) { n_skipped += info & INFO_JUMP_MASK; if (run_nodes == 1) n_first_skip++; }
+                return true;
             }
         }
-        if (STATS) run_nodes++;
+        return false;
+    };
+    auto flush_acc = [&]() {   // 15 mutations in the 4-bit counters: spill to the packed carries (rare)
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const uint32_t eP = ex4(accP, j), eC = ex4(accC, j), eN = ex4(accN, j);
+            carryD.v[j] = pk_sub(pk_add(carryD.v[j], eP), eC);   // carries are zero outside a long node
+            carryN.v[j] = pk_add(carryN.v[j], eN);
+            carryC.v[j] = pk_add(carryC.v[j], eC);
+        }
+        accP = accC = accN = 0;
+        flushed = true;
+    };
+    // sibling record waiting at a header: can this child and the non-last siblings after it all be skipped?
+    auto sibling_test = [&](uint32_t pos) -> bool {
+        have_sinfo = false;
+        if (!all_far(dpar, sinfo)) return false;
+        skip_to = pos + (sinfo & INFO_JUMP_MASK);   // the start of the parent's last child
+        have_info = false;
+        if (STATS) n_skipped += sinfo & INFO_JUMP_MASK;
+        return true;
+    };
+    // words that leave the fast path (H_RARE); true: the pipeline has to restart at skip_to
+    auto rare_word = [&](uint32_t w, uint32_t pos) -> bool {
+        if (w & H_INFO) {
+            if (prune) {
+                if (w & H_SIB) { sinfo = w; have_sinfo = true; }   // about the node that follows and its later siblings
+                else { info = w; have_info = true; }               // about the node that follows and its descendants
+            }
+            return false;
+        }
+        if (w & H_CHUNK_END) {
+            // a chunk with a candidate (or a due exchange of bounds) is closed by the restart code, which may
+            // store; any other chunk just ends here, inside the pipeline
+            if (chunk_has_candidate() || ub_age + 1 >= a.ub_every) { skip_to = pos + 1; return true; }
+            ub_age++;
+#pragma unroll
+            for (int j = 0; j < 4; j++) best.v[j] = 0xFFFFFFFFu;
+            chunk++;
+            cend_stale = true;
+            return false;
+        }
+        if (w & H_NOP) return false;
+        replay = true; skip_to = pos + 1;   // slow header (nothing of this node has been touched yet)
+        return true;
+    };
+
+    // The general step, one node at a time, outside the pipeline (restart path): any slot, D_bottom, word by word.
+    // `p` = position of the node's header; returns the position behind the node (or wherever a jump leads via skip_to).
+    const uint32_t *sp = nullptr;   // uniform: stream being walked (preambles or bodies), rebased to the unit
+    auto slow_node = [&](uint32_t p) -> uint32_t {
+        const uint32_t w = (uint32_t)__builtin_amdgcn_readfirstlane((int)sp[p]);
+        hdr = w;
+        const uint32_t rs = (w >> H_RSLOT_SHIFT) & 63u, ws = (w >> H_WSLOT_SHIFT) & 63u;
+        if (w & H_REG) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) dpar.v[j] = dcur.v[j];
+        } else if (w & H_BOTTOM) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) dpar.v[j] = dbot.v[j];
+        } else {
+            const u32x4 t = rs >= a.lds_slots ? *(const u32x4 *)(coldp + (uint64_t)(rs - a.lds_slots) * 256) : *lds_at(rs * 1024u + lane16);
+            dpar.v[0] = t.x; dpar.v[1] = t.y; dpar.v[2] = t.z; dpar.v[3] = t.w;
+        }
+        hdr_wa = ws * 1024u;
+        const int cold_ws = ((w & H_STORE) && ws >= a.lds_slots) ? (int)(ws - a.lds_slots) : -1;
+        if (have_sinfo && sibling_test(p)) return p + 1;
+        p++;
+        if (!(w & H_END)) {
+            for (;;) {
+                const uint32_t m = (uint32_t)__builtin_amdgcn_readfirstlane((int)sp[p]);
+                const uint32_t x = __builtin_amdgcn_raw_buffer_load_b32(trsrc, lane4, ((m & 0x3FFFFFu) + CONST_ROWS) << 8, 0);
+                const uint32_t mi = (m >> 22) & 3u, pi = (m >> 24) & 3u;
+                const uint32_t C = (x >> mi) & 0x11111111u, P = (x >> pi) & 0x11111111u;
+                accP += P; accC += C; accN += C & ~P;
+                p++;
+                if (m & M_END) break;
+                if (m & M_FLUSH) flush_acc();
+            }
+        }
+        node_end(p - 1, cold_ws);
+        return p;
     };
 
     // Software pipeline over groups of 8 words, four stages deep:
     //   group g+3  stream words being fetched (8 lanes x 4 B)
     //   group g+2  "is this (tile, site) row non-reference?" bits being fetched (8-lane gather, 3 KB bitmap)
     //   group g+1  table rows in flight, one per word, into X[0..7]; a word whose row is
-    //              reference-everywhere fetches the (hot) row 0 instead and uses a constant
+    //              reference-everywhere for the tile fetches the constant row of its reference base instead
     //   group g    evaluated
-    // Every load is unconditional and in a fixed order, which keeps the compiler's vmcnt
-    // bookkeeping exact (s_waitcnt vmcnt(N) with the younger loads still in flight).
+    // Every load is in a fixed order, which keeps the compiler's vmcnt bookkeeping exact
+    // (s_waitcnt vmcnt(N) with the younger loads still in flight).
     const uint32_t *abm = a.active + (uint64_t)tile * a.active_words;
     const uint64_t t_wave0 = STATS ? __builtin_amdgcn_s_memtime() : 0;
     uint64_t t_restart = 0, n_restart = 0;
     for (int phase = 0; phase < 2; phase++) {
-        const uint32_t *sp = phase == 0 ? a.pre8 : a.stream8;
+        sp = phase == 0 ? a.pre8 : a.stream8;
         const uint32_t begin = phase == 0 ? a.chunk8_pre_off[c0] : a.chunk8_body_off[c0];
         const uint32_t end = phase == 0 ? a.chunk8_pre_off[c0 + 1] : a.chunk8_body_off[c1];
         if (begin >= end) continue;
@@ -752,9 +760,17 @@ __global__ void __launch_bounds__(64) k_best8(Best8Args a) {
             const uint32_t site = (wv & H_TAG) ? 0u : (wv & 0x3FFFFFu);
             return abm[site >> 5];
         };
-        auto active_mask = [&](uint32_t wv, uint32_t bits) -> uint32_t {   // bit k: word k needs its real row
-            const bool act = !(wv & H_TAG) && ((bits >> (wv & 31u)) & 1u);
-            return (uint32_t)__builtin_amdgcn_ballot_w64(act) & ((1u << GRP) - 1u);
+        // Per-lane decoding of a group (lane k of every 8 holds word k):
+        //   off  byte offset of the word's table row: the site's own row if some sample of the tile is
+        //        non-reference there, else the constant row of the site's reference base (headers: row 0)
+        //   fa   mutation word: shift of the mutated allele      header: LDS byte offset of the read slot
+        //   fb   mutation word: shift of the parent-state allele header: LDS byte offset of the write slot
+        auto decode = [&](uint32_t wv, uint32_t bits, uint32_t &off, uint32_t &fa, uint32_t &fb) {
+            const bool is_hdr = (wv & H_TAG) != 0;
+            const bool act = !is_hdr && ((bits >> (wv & 31u)) & 1u);
+            off = (act ? (wv & 0x3FFFFFu) + CONST_ROWS : (is_hdr ? 0u : (wv >> 26) & 3u)) << 8;
+            fa = is_hdr ? (wv & (63u << H_RSLOT_SHIFT)) : ((wv >> 22) & 3u);
+            fb = is_hdr ? ((wv >> (H_WSLOT_SHIFT - 10)) & (63u << 10)) : ((wv >> 24) & 3u);
         };
         prune = (phase == 1) && can_prune;
         cend = phase == 1 ? (uint32_t)__builtin_amdgcn_readfirstlane((int)(a.chunk8_body_off[c0 + 1] - 1u - begin)) : 0xFFFFFFFFu;
@@ -766,84 +782,95 @@ __global__ void __launch_bounds__(64) k_best8(Best8Args a) {
             ub_tile = tile;
             ub_age = 0;
         }
+        // One stream word of the group being evaluated: w0/fa0/fb0 = the group's words and decoded fields,
+        // x = the lane's dword of the word's table row.  Returns true when the pipeline has to restart at
+        // skip_to (chunk end that stores, pruning jump, slow header).
+        auto step = [&](uint32_t w0v, uint32_t fa0, uint32_t fb0, int k, uint32_t x, uint32_t pos) -> bool {
+            const uint32_t w = rdlane(w0v, k);
+            if (w & H_TAG) {
+                if (w & H_RARE) return rare_word(w, pos);
+                hdr = w;
+                hdr_wa = rdlane(fb0, k);
+                if (w & H_REG) {
+#pragma unroll
+                    for (int j = 0; j < 4; j++) dpar.v[j] = dcur.v[j];
+                } else {
+                    const u32x4 t = *lds_at(rdlane(fa0, k) | lane16);
+                    dpar.v[0] = t.x; dpar.v[1] = t.y; dpar.v[2] = t.z; dpar.v[3] = t.w;
+                }
+                if (have_sinfo && sibling_test(pos)) return true;
+                if (!(w & H_END)) return false;
+            } else {
+                const uint32_t mi = rdlane(fa0, k), pi = rdlane(fb0, k);
+                const uint32_t C = (x >> mi) & 0x11111111u, P = (x >> pi) & 0x11111111u;
+                accP += P; accC += C; accN += C & ~P;
+                if (!(w & M_END)) {
+                    if (w & M_FLUSH) flush_acc();
+                    return false;
+                }
+            }
+            return node_end(pos, -1);
+        };
         uint32_t off = 0;
         bool cautious = false;   // uniform: the last run was cut short by a jump inside its first group
         while (off < n) {
             // (re)fill the pipeline at `off`
             const uint64_t t_r0 = STATS ? __builtin_amdgcn_s_memtime() : 0;
             uint32_t w0 = load_words(off), w1 = load_words(off + GRP), w2 = load_words(off + 2 * GRP);
-            uint32_t m0 = active_mask(w0, load_bits(w0));
-            uint32_t m1 = 0;
+            uint32_t o0, fa0, fb0, o1, fa1, fb1;
+            decode(w0, load_bits(w0), o0, fa0, fb0);
+            uint32_t b1 = load_bits(w1);
             uint32_t X[GRP];
 #pragma unroll
-            for (int k = 0; k < (int)GRP; k++) {
-                const uint32_t w = rdlane(w0, k);
-                X[k] = __builtin_amdgcn_raw_buffer_load_b32(trsrc, lane4, (((m0 >> k) & 1u) ? (w & 0x3FFFFFu) : 0u) << 8, 0);
-            }
+            for (int k = 0; k < (int)GRP; k++) X[k] = __builtin_amdgcn_raw_buffer_load_b32(trsrc, lane4, rdlane(o0, k), 0);
             skip_to = 0;
             if (STATS) { t_restart += __builtin_amdgcn_s_memtime() - t_r0 + (X[0] & 0u); n_restart++; run_nodes = 0; }
             bool first = true;   // uniform: still inside the first group of this run
+            bool hit = false;    // uniform: a step asked for a restart
             if (cautious) {
                 // Sparse regime (runs of a few words between jumps): evaluate the first group before
                 // anything is requested for the second one, so a jump does not leave eight dead row loads
                 // ahead of the next refill in the in-order return queue.
 #pragma unroll
                 for (int k = 0; k < (int)GRP; k++) {
-                    const uint32_t w = rdlane(w0, k);
-                    const uint32_t ref_row = 0x11111111u << ((w >> 26) & 3u);
-                    if (!skip_to) step(w, ((m0 >> k) & 1u) ? X[k] : ref_row, off + k, std::false_type{});
+                    if (step(w0, fa0, fb0, k, X[k], off + k)) { hit = true; break; }
                 }
-                if (!skip_to) {   // the run goes on: bring the pipeline to its steady state one group further
-                    m1 = active_mask(w1, load_bits(w1));
+                if (!hit) {   // the run goes on: bring the pipeline to its steady state one group further
+                    decode(w1, b1, o1, fa1, fb1);
 #pragma unroll
-                    for (int k = 0; k < (int)GRP; k++) {
-                        const uint32_t wn = rdlane(w1, k);
-                        X[k] = __builtin_amdgcn_raw_buffer_load_b32(trsrc, lane4, (((m1 >> k) & 1u) ? (wn & 0x3FFFFFu) : 0u) << 8, 0);
-                    }
-                    m0 = m1;
-                    w0 = w1; w1 = w2; w2 = load_words(off + 3 * GRP);
-                    m1 = active_mask(w1, load_bits(w1));
+                    for (int k = 0; k < (int)GRP; k++) X[k] = __builtin_amdgcn_raw_buffer_load_b32(trsrc, lane4, rdlane(o1, k), 0);
+                    w0 = w1; fa0 = fa1; fb0 = fb1;
+                    w1 = w2; w2 = load_words(off + 3 * GRP);
+                    b1 = load_bits(w1);
                     off += GRP;
                     first = false;
                 }
-            } else {
-                m1 = active_mask(w1, load_bits(w1));
             }
-            if (!skip_to)
+            if (!hit)
             for (; off < n; off += GRP) {
                 const uint32_t w3 = load_words(off + 3 * GRP);
                 const uint32_t b2 = load_bits(w2);
+                decode(w1, b1, o1, fa1, fb1);
 #pragma unroll
                 for (int k = 0; k < (int)GRP; k++) {
-                    const uint32_t w = rdlane(w0, k);
-                    const uint32_t ref_row = 0x11111111u << ((w >> 26) & 3u);   // every sample carries the reference base
-                    if (!skip_to) step(w, ((m0 >> k) & 1u) ? X[k] : ref_row, off + k, std::false_type{});   // words after a restart request are dead
-                    const uint32_t wn = rdlane(w1, k);
-                    X[k] = __builtin_amdgcn_raw_buffer_load_b32(trsrc, lane4, (((m1 >> k) & 1u) ? (wn & 0x3FFFFFu) : 0u) << 8, 0);
+                    if (step(w0, fa0, fb0, k, X[k], off + k)) { hit = true; break; }
+                    X[k] = __builtin_amdgcn_raw_buffer_load_b32(trsrc, lane4, rdlane(o1, k), 0);
                 }
-                if (skip_to) break;
-                m0 = m1;
-                m1 = active_mask(w2, b2);
-                w0 = w1; w1 = w2; w2 = w3;
+                if (hit) break;
+                w0 = w1; fa0 = fa1; fb0 = fb1;
+                w1 = w2; w2 = w3; b1 = b2;
                 first = false;
             }
-            if (!skip_to) break;   // walked to the end of the range
+            if (!hit) break;   // walked to the end of the range
             cautious = first;
             if (replay) {
-                // the node whose header sits at skip_to - 1 uses a cold slot: walk it here, word by word
+                // the node whose header sits at skip_to - 1 needs the general step
                 replay = false;
-                uint32_t p = skip_to - 1u;
+                const uint32_t p = skip_to - 1u;
                 skip_to = 0;
-                for (;;) {
-                    const uint32_t w = (uint32_t)__builtin_amdgcn_readfirstlane((int)sp[p]);
-                    uint32_t x = 0;
-                    if (!(w & H_TAG)) x = __builtin_amdgcn_raw_buffer_load_b32(trsrc, lane4, (w & 0x3FFFFFu) << 8, 0);
-                    step(w, x, p, std::true_type{});
-                    p++;
-                    if (skip_to || ((w & H_TAG) ? (w & H_END) != 0 : (w & M_END) != 0)) break;
-                }
+                const uint32_t q = slow_node(p);
                 __builtin_amdgcn_s_waitcnt(0);   // (a cold slot written here may be read by the very next node)
-                if (!skip_to) { off = p; continue; }
+                if (!skip_to) { off = q; continue; }
             }
             // restart request: close every chunk whose end marker lies before the new position
             // (the end-marker position of the open chunk is kept in a register: loading it here put a memory round
@@ -1088,7 +1115,7 @@ hipError_t launch_fill_table(uint32_t *table, const uint8_t *site_ref, uint32_t 
     if (total_dwords == 0) return hipSuccess;
     uint64_t blocks = (total_dwords + 255) / 256;
     if (blocks > 16384) blocks = 16384;
-    hipLaunchKernelGGL(k_fill_table, dim3((uint32_t)blocks), dim3(256), 0, s, table, site_ref, n_sites, total_dwords);
+    hipLaunchKernelGGL(k_fill_table, dim3((uint32_t)blocks), dim3(256), 0, s, table, site_ref, n_sites + TABLE_CONST_ROWS, total_dwords);
     return hipGetLastError();
 }
 

@@ -8,11 +8,13 @@
 
 namespace ugp {
 
+constexpr uint32_t TABLE_CONST_ROWS = 4;   // rows 0..3 of every tile of the allele table: all samples carry A / C / G / T
+
 struct PlaceArgs {
     const uint32_t *stream, *pre_stream;
     const uint32_t *chunk_body_off, *chunk_pre_off, *chunk_node_off;
     const uint32_t *stream_t, *chunk_t_off;   // tie stream (phase 2)
-    const uint32_t *table;     // [ceil(n_tiles/8)][n_sites][64]  (512-sample tile layout)
+    const uint32_t *table;     // [ceil(n_tiles/8)][4 + n_sites][64]  (512-sample tile layout behind 4 constant rows)
     const uint32_t *dbottom;   // [ceil(n_tiles/8)*512]
     uint32_t n_sites, n_chunks, n_groups, n_tiles, n_queries;
     // MODE 0
@@ -31,7 +33,7 @@ struct PlaceArgs {
 struct Best8Args {
     const uint32_t *stream8, *pre8;
     const uint32_t *chunk8_body_off, *chunk8_pre_off;   // [n_chunks+1]
-    const uint32_t *table;     // [n_tiles][n_sites][64]
+    const uint32_t *table;     // [n_tiles][4 + n_sites][64]
     const uint32_t *dbottom;   // [n_tiles*512]
     uint32_t n_sites, n_chunks, n_groups, n_tiles;   // n_tiles = 512-sample tiles
     uint32_t max_slots;

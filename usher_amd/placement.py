@@ -124,6 +124,8 @@ class FlatTreeView:
             self.max_slots = int(n.value)
             _check(L.ugp_flat_get(h, 14, C.byref(p), C.byref(n)))
             self.max_path_muts = int(n.value)
+            _check(L.ugp_flat_get(h, 17, C.byref(p), C.byref(n)))
+            self.lds_slots = int(n.value)
         finally:
             L.ugp_flat_destroy(h)
 
