@@ -122,10 +122,56 @@ M_FLUSH, M_END = 1 << 28, 1 << 30
 U16 = 0xFFFF
 
 
-def best8_group(flat, nib, dbot, c0, c1, ub=None, stats=None):
+SUM_FORCED, SUM_W_SHIFT, SUM_POS_MASK = 1 << 28, 22, (1 << 22) - 1
+
+
+def summary_ranges(flat, nib, c0, slots, dcur, ub, stats=None):
+    """The summary pass of k_best8 for the run of chunks starting at c0 (one sample): the ranges of the body
+    (relative positions, adjacent ones merged) whose top-level subtree survives both bounds."""
+    g = c0 // flat.super_chunks
+    words = flat.sum8
+    i, hi_ = int(flat.sum8_off[g]), int(flat.sum8_off[g + 1])
+    ranges = []
+    while i < hi_:
+        a, b, h = int(words[i]), int(words[i + 1]), int(words[i + 2])
+        i += 3
+        assert (a & (H_TAG | H_INFO | H_RARE)) == (H_TAG | H_INFO | H_RARE) and (b & (H_TAG | H_INFO | H_RARE)) == (H_TAG | H_INFO)
+        assert (h & H_TAG) and not (h & (H_INFO | H_NOP | H_CHUNK_END | H_STORE))
+        forced = bool(b & SUM_FORCED) or bool(h & H_RARE)
+        accP = accC = 0
+        if not (h & H_END):
+            while True:
+                w = int(words[i]); i += 1
+                assert not (w & H_TAG)
+                x = int(nib[w & 0x3FFFFF])
+                accP += (x >> ((w >> 24) & 3)) & 1
+                accC += (x >> ((w >> 22) & 3)) & 1
+                if w & M_END:
+                    break
+        keep = forced
+        if not forced:
+            spar = dcur if h & H_REG else slots[(h >> H_RSLOT_SHIFT) & 63]
+            dn = (spar + accP - accC) & U16
+            hs, wn = (a >> INFO_HS_SHIFT) & 0x7F, (b >> SUM_W_SHIFT) & 63
+            keep = not (dn >= ub[0] + 1 + hs and spar >= ub[0] + 1 + wn)
+        lo, hi = a & SUM_POS_MASK, b & SUM_POS_MASK
+        assert lo < hi
+        if keep:
+            if ranges and ranges[-1][1] == lo:
+                ranges[-1][1] = hi
+            else:
+                assert not ranges or ranges[-1][1] < lo
+                ranges.append([lo, hi])
+        elif stats is not None:
+            stats["summary_skipped"] = stats.get("summary_skipped", 0) + hi - lo
+    return ranges
+
+
+def best8_group(flat, nib, dbot, c0, c1, ub=None, stats=None, use_summary=True):
     """Chunk-local minima of one sample for chunks [c0, c1), as k_best8 computes them.
     ub: None = no pruning; otherwise a one-element list holding an upper bound of the sample's best
-    score, used (and tightened at chunk ends) exactly like the kernel's shared bound."""
+    score, used (and tightened at chunk ends) exactly like the kernel's shared bound.  When the unit
+    coincides with a summary (and pruning is on) the body is walked range by range, as the kernel does."""
     slots = {}
     lbest = {}
     best = U16
@@ -154,9 +200,21 @@ def best8_group(flat, nib, dbot, c0, c1, ub=None, stats=None):
 
     info = None
     sinfo = None
-    for phase, (words, lo, hi) in enumerate(((flat.pre8_stream, int(flat.chunk8_pre_off[c0]), int(flat.chunk8_pre_off[c0 + 1])),
-                                             (flat.stream8, int(flat.chunk8_body_off[c0]), int(flat.chunk8_body_off[c1])))):
+    n_chunks = len(flat.chunk8_body_off) - 1
+    sc = getattr(flat, "super_chunks", 0)
+    summarise = (use_summary and ub is not None and sc and c0 % sc == 0 and c1 == min(c0 + sc, n_chunks))
+    body0 = int(flat.chunk8_body_off[c0])
+    segments = [(0, flat.pre8_stream, int(flat.chunk8_pre_off[c0]), int(flat.chunk8_pre_off[c0 + 1]))]
+    for phase, words, lo, hi in segments:   # (the body segments are appended once the preamble has been replayed)
         i = lo - 1
+        if phase == 1:
+            # close the chunks that lie wholly in front of this range (the kernel's next_range)
+            while chunk < c1 and lo > int(flat.chunk8_body_off[chunk + 1]) - 1:
+                lbest[chunk] = best
+                if ub is not None:
+                    ub[0] = min(ub[0], best)
+                best = U16
+                chunk += 1
         while i + 1 < hi:
             i += 1
             w = int(words[i])
@@ -238,6 +296,14 @@ def best8_group(flat, nib, dbot, c0, c1, ub=None, stats=None):
                         best = U16
                         chunk += 1
                     i = target - 1
+        if phase == 0:
+            body_end = int(flat.chunk8_body_off[c1])
+            if summarise:
+                for r0, r1 in summary_ranges(flat, nib, c0, slots, dcur, ub, stats):
+                    segments.append((1, flat.stream8, body0 + r0, min(body0 + r1, body_end)))
+                segments.append((1, flat.stream8, body_end, body_end))   # closes the remaining chunks
+            else:
+                segments.append((1, flat.stream8, body0, body_end))
     assert chunk == c1
     return lbest
 

@@ -144,3 +144,36 @@ def test_sibling_records_skip_runs_of_siblings_exactly():
                 assert got[k] == want[k], (ub, k)
             jumps += st.get("sibling_jumps", 0)
     assert jumps > 10
+
+
+@pytest.mark.parametrize("seed,chunk_nodes", [(71, 9), (72, 25), (73, 4)])
+def test_summaries_of_top_level_subtrees_are_exact(seed, chunk_nodes, monkeypatch):
+    """Summary streams (ugp_flatten.cpp): work units that coincide with a run of super_chunks chunks evaluate the
+    run's top-level subtrees first and walk only the survivors.  With units of exactly that size the model takes
+    the summary path for every unit; results must equal the oracle's with loose and with tight bounds, some
+    subtrees must really be skipped by it, and the summary path must agree with the plain walk chunk by chunk."""
+    monkeypatch.setenv("UGP_LDS_SLOTS", "3")          # cold slots: some summary entries are forced survivors
+    arrays, queries = synth.make_case(seed, n_leaves=2500, n_queries=8, n_sites=300, n_ambig=(0, 0, 2), p_masked=0.02,
+                                      mut_counts=(0, 0, 1, 1, 1, 2, 3, 17))
+    flat = FlatTreeView(arrays, chunk_nodes=chunk_nodes)
+    assert flat.super_chunks == 8 and len(flat.sum8_off) == (len(flat.chunk8_body_off) - 1 + 7) // 8 + 1
+    n_chunks = len(flat.chunk8_body_off) - 1
+    n_units = (n_chunks + 7) // 8
+    ot = capi.OracleTree(arrays)
+    skipped = 0
+    for s in queries:
+        want = ot.place(s)
+        nib, dbot = stream_interp.sample_site_alleles(flat, s)
+        for ub0 in (0x7F7F, want["best"] + 1, want["best"]):
+            st = {}
+            lb_sum, lb_plain = {}, {}
+            ub_a, ub_b = [ub0], [ub0]
+            for u in range(n_units):
+                c0, c1 = 8 * u, min(8 * u + 8, n_chunks)
+                lb_sum.update(stream_interp.best8_group(flat, nib, dbot, c0, c1, ub_a, st))
+                lb_plain.update(stream_interp.best8_group(flat, nib, dbot, c0, c1, ub_b, None, use_summary=False))
+            assert min(lb_sum.values()) == want["best"] == min(lb_plain.values())
+            # wherever a chunk holds the optimum both walks must have found it there (phase 2 re-walks those chunks)
+            assert [c for c in range(n_chunks) if lb_sum[c] == want["best"]] == [c for c in range(n_chunks) if lb_plain[c] == want["best"]]
+            skipped += st.get("summary_skipped", 0)
+    assert skipped > len(flat.stream8)

@@ -76,7 +76,7 @@ struct ugp_mat {
     ugp::FlatMat flat;   // the scalars of the flattening only (counts, depths); the arrays live on the device
     uint64_t stream_dwords = 0, pre_dwords = 0;
     DevBuf<uint32_t> d_stream, d_pre, d_chunk_body, d_chunk_pre, d_chunk_node, d_rank2bfs, d_dfs2bfs;
-    DevBuf<uint32_t> d_stream8, d_pre8, d_chunk8_body, d_chunk8_pre, d_stream_t, d_chunk_t;
+    DevBuf<uint32_t> d_stream8, d_pre8, d_chunk8_body, d_chunk8_pre, d_stream_t, d_chunk_t, d_sum8, d_sum8_off;
     uint64_t stream8_dwords = 0;
     DevBuf<int32_t> d_pos2site;
     DevBuf<uint8_t> d_site_ref;
@@ -300,6 +300,9 @@ int run_place(ugp_mat *m, ugp_qset *qs, int mode, ugp_result *d_out, int32_t *d_
                 b.tile_hstart = m->d_gstart.p; b.tile_hlen = m->d_hlen.p;
             }
             b.unit_chunks = std::max<uint32_t>(1, (f.n_chunks + G - 1) / G);
+            // light units that coincide with the summaries of the flattening evaluate those first (k_best8)
+            if (b.unit_chunks == f.super_chunks && !getenv("UGP_NO_SUMMARY")) { b.sum8 = m->d_sum8.p; b.sum8_off = m->d_sum8_off.p; }
+            b.super_chunks = std::max<uint32_t>(1, f.super_chunks);
             b.ub_every = 128;
             if (const char *e = getenv("UGP_UB_EVERY")) b.ub_every = (uint32_t)std::max(1, atoi(e));
             b.heavy_chunks = 16;
@@ -444,7 +447,7 @@ static int upload_flat(const HostFlat &hf, int device, ugp_mat **out) {
     {   // scalars
         auto &g = m->flat;
         g.n_nodes = f.n_nodes; g.n_muts = f.n_muts; g.n_sites = f.n_sites; g.max_pos = f.max_pos; g.max_slots = f.max_slots;
-        g.n_chunks = f.n_chunks; g.max_path_muts = f.max_path_muts; g.mask_not_first = f.mask_not_first; g.lds_slots = f.lds_slots;
+        g.n_chunks = f.n_chunks; g.max_path_muts = f.max_path_muts; g.mask_not_first = f.mask_not_first; g.lds_slots = f.lds_slots; g.super_chunks = f.super_chunks;
     }
     if ((e = m->d_stream.upload(f.stream)) != hipSuccess) return bail(e, "upload stream");
     if ((e = m->d_pre.upload(f.pre_stream)) != hipSuccess) return bail(e, "upload preambles");
@@ -463,6 +466,8 @@ static int upload_flat(const HostFlat &hf, int device, ugp_mat **out) {
     if ((e = m->d_pre8.upload(f.pre8_stream)) != hipSuccess) return bail(e, "upload packed preambles");
     if ((e = m->d_chunk8_body.upload(f.chunk8_body_off)) != hipSuccess) return bail(e, "upload chunk table");
     if ((e = m->d_chunk8_pre.upload(f.chunk8_pre_off)) != hipSuccess) return bail(e, "upload chunk table");
+    if ((e = m->d_sum8.upload(f.sum8)) != hipSuccess) return bail(e, "upload summaries");
+    if ((e = m->d_sum8_off.upload(f.sum8_off)) != hipSuccess) return bail(e, "upload summaries");
     if ((e = m->d_stream_t.upload(f.stream_t)) != hipSuccess) return bail(e, "upload tie stream");
     if ((e = m->d_chunk_t.upload(f.chunk_t_off)) != hipSuccess) return bail(e, "upload chunk table");
     m->stream8_dwords = f.stream8.size();
@@ -482,6 +487,7 @@ static ugp::Options default_options() {
     if (const char *e = getenv("UGP_PRUNE_MIN_WORDS")) opt.prune_min_words = (uint32_t)std::max(1, atoi(e));
     if (getenv("UGP_NO_SIB")) opt.sibling_records = false;
     if (const char *e = getenv("UGP_LDS_SLOTS")) opt.lds_slots = (uint32_t)std::max(1, std::min(60, atoi(e)));
+    if (const char *e = getenv("UGP_UNIT_CHUNKS")) opt.super_chunks = (uint32_t)std::max(1, atoi(e));   // summaries follow the light units
     return opt;
 }
 
@@ -788,6 +794,9 @@ int ugp_flat_get(const ugp_flat *fl, int which, const void **ptr, uint64_t *coun
         case UGP_FLAT_CHUNK_T_OFF: *ptr = f.chunk_t_off.data(); *count = f.chunk_t_off.size(); break;
         case UGP_FLAT_MAX_PATH_MUTS: *ptr = nullptr; *count = f.max_path_muts; break;
         case UGP_FLAT_LDS_SLOTS: *ptr = nullptr; *count = f.lds_slots; break;
+        case UGP_FLAT_SUM8: *ptr = f.sum8.data(); *count = f.sum8.size(); break;
+        case UGP_FLAT_SUM8_OFF: *ptr = f.sum8_off.data(); *count = f.sum8_off.size(); break;
+        case UGP_FLAT_SUPER_CHUNKS: *ptr = nullptr; *count = f.super_chunks; break;
         default: return fail(UGP_ERR_INVALID, "unknown array id");
     }
     return UGP_OK;

@@ -388,6 +388,8 @@ int flatten(const ugp_tree_desc &t, const Options &opt, FlatMat &out, std::strin
     };
     out.stream8.clear(); out.pre8_stream.clear(); out.chunk8_body_off.clear(); out.chunk8_pre_off.clear();
     out.stream8.reserve(N + n_real + out.n_chunks);
+    // by DFS index: stream position when the node is reached, of its first word behind a sibling record, of its header
+    std::vector<uint32_t> pos8_at(N + 1, 0), pos8_start(N, 0), pos8_hdr(N, 0);
     for (uint32_t c = 0; c < out.n_chunks; c++) {
         out.chunk8_body_off.push_back((uint32_t)out.stream8.size());
         for (uint32_t d = out.chunk_node_off[c]; d < out.chunk_node_off[c + 1]; d++) {
@@ -401,6 +403,7 @@ int flatten(const ugp_tree_desc &t, const Options &opt, FlatMat &out, std::strin
             if ((uint64_t)d + 12 < N) __builtin_prefetch(&slot[t.parent[out.dfs2bfs[d + 12]]]);
             uint32_t j = out.dfs2bfs[d];
             close_big(d);
+            pos8_at[d] = (uint32_t)out.stream8.size();
             if (dropped[j]) continue;
             // sibling record: j is a non-last effective child and at least one more non-last sibling with a
             // pruning record of its own follows (otherwise there is no jump to save)
@@ -428,11 +431,13 @@ int flatten(const ugp_tree_desc &t, const Options &opt, FlatMat &out, std::strin
                 }
             }
             const bool big = j != 0 && subw[j] >= opt.prune_min_words && hsub[j] <= INFO_HS_MAX;
+            pos8_start[d] = (uint32_t)out.stream8.size();   // (behind the sibling record, if any)
             if (big) {
                 open_big.push_back({(uint32_t)out.stream8.size(), 0u, d + sub[j]});
                 out.stream8.push_back(H_TAG | E_INFO | (hsub[j] << 22));   // jump patched when the subtree closes
             }
             if (sib_pending_hdr != UINT32_MAX) { sib_hdr_pos[sib_pending_hdr] = (uint32_t)out.stream8.size(); sib_pending_hdr = UINT32_MAX; }
+            pos8_hdr[d] = (uint32_t)out.stream8.size();
             emit8(out.stream8, j, false);
             if (big) open_big.back().own_end = (uint32_t)out.stream8.size();
         }
@@ -446,6 +451,7 @@ int flatten(const ugp_tree_desc &t, const Options &opt, FlatMat &out, std::strin
     }
     out.chunk8_body_off.push_back((uint32_t)out.stream8.size());
     out.chunk8_pre_off.push_back((uint32_t)out.pre8_stream.size());
+    pos8_at[N] = (uint32_t)out.stream8.size();
 
     flat_lap("packed stream");
     // ---- tie stream (phase 2 walks it one chunk at a time)
@@ -538,6 +544,44 @@ int flatten(const ugp_tree_desc &t, const Options &opt, FlatMat &out, std::strin
         };
         finalize8(out.stream8);
         finalize8(out.pre8_stream);
+    }
+    // ---- summaries: the top-level subtrees of every run of super_chunks chunks, as one dense stream ----------
+    // Seen from the first node f of such a run, every later node of the run lies in the subtree of f, of a later
+    // sibling of f, or of a later sibling of one of f's ancestors: the "top-level" nodes, whose parents are on the
+    // root path of f (their D is in the slots once the preamble has been replayed).  A wave far from the tile's
+    // samples used to reach them one by one -- evaluate, find the subtree prunable, jump, refill the pipeline:
+    // three dependent memory round trips per node, which is what bound the kernel.  The summary lists them
+    // back to back ({SUM_A, SUM_B, header copy, mutation words} each) so they are evaluated in the pipelined
+    // loop without a single restart; only the survivors' subtrees are walked in the main stream afterwards.
+    {
+        out.super_chunks = std::max<uint32_t>(1, opt.super_chunks);
+        const uint32_t SC = out.super_chunks;
+        out.sum8.clear(); out.sum8_off.clear();
+        for (uint32_t c0 = 0; c0 < out.n_chunks; c0 += SC) {
+            const uint32_t c1 = std::min<uint32_t>(out.n_chunks, c0 + SC);
+            out.sum8_off.push_back((uint32_t)out.sum8.size());
+            const uint32_t base = out.chunk8_body_off[c0], body_end = out.chunk8_body_off[c1];
+            const uint32_t d_end = out.chunk_node_off[c1];
+            for (uint32_t d = out.chunk_node_off[c0]; d < d_end;) {
+                const uint32_t j = out.dfs2bfs[d];
+                const uint32_t d_next = (uint32_t)std::min<uint64_t>((uint64_t)d + sub[j], d_end);
+                if (!dropped[j]) {
+                    const uint32_t hpos = pos8_hdr[d];
+                    uint32_t h = out.stream8[hpos] & ~H_STORE;
+                    const uint32_t nw = out.stream[rec_off[j]] & 0xFFFFu;
+                    // the end of the subtree inside this run (a subtree that reaches beyond it ends with the run)
+                    const uint32_t end_pos = ((uint64_t)d + sub[j] >= d_end ? body_end : pos8_at[d_next]) - base;
+                    const bool forced = hsub[j] > INFO_HS_MAX || nw >= 15 || nw > SUM_W_MAX;   // (no test: always walked)
+                    if (forced) h |= H_END;
+                    out.sum8.push_back(SUM_A | (std::min<uint32_t>(hsub[j], INFO_HS_MAX) << INFO_HS_SHIFT) | (pos8_start[d] - base));
+                    out.sum8.push_back(SUM_B | (forced ? SUM_FORCED : 0u) | (std::min<uint32_t>(nw, SUM_W_MAX) << SUM_W_SHIFT) | end_pos);
+                    out.sum8.push_back(h);
+                    if (!forced) for (uint32_t k = 0; k < nw; k++) out.sum8.push_back(out.stream8[hpos + 1 + k]);
+                }
+                d = d_next;
+            }
+        }
+        out.sum8_off.push_back((uint32_t)out.sum8.size());
     }
     flat_lap("slot renumbering");
     return UGP_OK;

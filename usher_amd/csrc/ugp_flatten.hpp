@@ -82,6 +82,15 @@ constexpr uint32_t H_REG = 1u << 0, H_STORE = 1u << 1, H_NOSCORE = 1u << 2, H_EN
                    H_SKIPD = 1u << 5, H_BOTTOM = 1u << 6, H_SLOW = 1u << 7, H_CHUNK_END = 1u << 8, H_NOP = 1u << 9;
 constexpr uint32_t H_RSLOT_SHIFT = 10, H_WSLOT_SHIFT = 20;
 constexpr uint32_t INFO_JUMP_MASK = (1u << 21) - 1u, INFO_HS_SHIFT = 22, INFO_HS_MAX = 127;
+// summary stream ("sum8", see ugp_flatten.cpp): per top-level subtree of a run of super_chunks chunks
+//   SUM_A  [28:22] hsub of the node (capped)   [21:0] position of the node's first word (pruning record or header,
+//          behind a sibling record) in the packed stream, relative to the run's first body word
+//   SUM_B  SUM_FORCED: no test, the subtree is always walked   [27:22] mutation words of the node   [21:0] position
+//          behind the subtree (relative, capped at the end of the run)
+//   a copy of the node's header without H_STORE (H_END when forced), then its mutation words (unless forced)
+constexpr uint32_t SUM_A = H_TAG | H_INFO | H_RARE, SUM_B = H_TAG | H_INFO, SUM_FORCED = 1u << 28;   // (B: H_INFO without H_RARE)
+constexpr uint32_t SUM_W_SHIFT = 22, SUM_W_MAX = 63, SUM_POS_MASK = (1u << 22) - 1u;
+constexpr uint32_t SUPER_CHUNKS = 8;        // chunks per summary (= the light work units of k_best8)
 constexpr uint32_t PRUNE_MIN_WORDS = 4;     // only subtrees at least this long carry a pruning record
 constexpr uint32_t LDS_SLOTS = 7;           // saved-D slots k_best8 keeps in LDS (1 KB each per wave); the colder ones live in a global scratch
 constexpr uint32_t M_FLUSH = 1u << 28, M_END = 1u << 30;
@@ -93,6 +102,7 @@ struct Options {
     uint32_t prune_min_words = PRUNE_MIN_WORDS;   // subtrees at least this long (stream words) carry a pruning record
     bool sibling_records = true;   // emit H_INFO | H_SIB records
     uint32_t lds_slots = LDS_SLOTS; // headers whose (renumbered) slots are >= this are flagged H_SLOW
+    uint32_t super_chunks = SUPER_CHUNKS;   // chunks per summary
 };
 
 struct FlatMat {
@@ -110,6 +120,8 @@ struct FlatMat {
     // packed stream for k_best8 (same chunk cut points, by DFS node index)
     std::vector<uint32_t> stream8, pre8_stream;
     std::vector<uint32_t> chunk8_body_off, chunk8_pre_off;   // [n_chunks+1]
+    std::vector<uint32_t> sum8, sum8_off;  // summaries: words, [ceil(n_chunks / super_chunks) + 1] offsets
+    uint32_t super_chunks = 0;
     // Tie stream (phase 2): the chunk bodies of `stream` without the leaves that can never be eligible and
     // with pruning pseudo-records {w0 = T_INFO_MARK, w1 = hsub << 24 | jump}: the node that follows may be
     // skipped together with its descendants (`jump` dwords behind its own record, inside the chunk)

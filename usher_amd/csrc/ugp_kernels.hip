@@ -743,18 +743,27 @@ __global__ void __launch_bounds__(64) k_best8(Best8Args a) {
     const uint32_t *abm = a.active + (uint64_t)tile * a.active_words;
     const uint64_t t_wave0 = STATS ? __builtin_amdgcn_s_memtime() : 0;
     uint64_t t_restart = 0, n_restart = 0;
-    for (int phase = 0; phase < 2; phase++) {
-        sp = phase == 0 ? a.pre8 : a.stream8;
-        const uint32_t begin = phase == 0 ? a.chunk8_pre_off[c0] : a.chunk8_body_off[c0];
-        const uint32_t end = phase == 0 ? a.chunk8_pre_off[c0 + 1] : a.chunk8_body_off[c1];
+    // Light units that coincide with a summary (a run of a.super_chunks chunks, see ugp_flatten.cpp) first evaluate
+    // the summary -- the top-level subtrees of the run, densely -- and walk only the survivors in the main stream.
+    // sv_lo / sv_hi: lane i = range i of the main stream still to be walked (relative positions), adjacent ranges merged.
+    const bool summarise = can_prune && !unit_heavy && a.sum8 != nullptr && c0 % a.super_chunks == 0 &&
+                           c1 == min(c0 + a.super_chunks, a.n_chunks);
+    uint32_t sv_lo = 0, sv_hi = 0;   // per lane
+    uint32_t n_sv = 0;               // uniform
+    for (int phase = 0; phase < 3; phase++) {
+        if (phase == 1 && !summarise) continue;
+        sp = phase == 0 ? a.pre8 : (phase == 1 ? a.sum8 : a.stream8);
+        const uint32_t begin = phase == 0 ? a.chunk8_pre_off[c0] : (phase == 1 ? a.sum8_off[c0 / a.super_chunks] : a.chunk8_body_off[c0]);
+        const uint32_t end = phase == 0 ? a.chunk8_pre_off[c0 + 1] : (phase == 1 ? a.sum8_off[c0 / a.super_chunks + 1] : a.chunk8_body_off[c1]);
         if (begin >= end) continue;
         const uint32_t n = end - begin;
         sp += begin;
         const uint32_t l8 = lane & (GRP - 1u);
+        uint32_t lim = n;   // uniform: end of the range being walked (words behind it read as padding)
         auto load_words = [&](uint32_t off) -> uint32_t {   // words off .. off+7 in lanes 0..7 (replicated x8)
             const uint32_t i = off + l8;
-            const uint32_t v = sp[i < n ? i : n - 1];
-            return i < n ? v : NOPW;
+            const uint32_t v = sp[i < lim ? i : lim - 1];
+            return i < lim ? v : NOPW;
         };
         auto load_bits = [&](uint32_t wv) -> uint32_t {     // per lane: bitmap dword of its word's site
             const uint32_t site = (wv & H_TAG) ? 0u : (wv & 0x3FFFFFu);
@@ -772,8 +781,8 @@ __global__ void __launch_bounds__(64) k_best8(Best8Args a) {
             fa = is_hdr ? (wv & (63u << H_RSLOT_SHIFT)) : ((wv >> 22) & 3u);
             fb = is_hdr ? ((wv >> (H_WSLOT_SHIFT - 10)) & (63u << 10)) : ((wv >> 24) & 3u);
         };
-        prune = (phase == 1) && can_prune;
-        cend = phase == 1 ? (uint32_t)__builtin_amdgcn_readfirstlane((int)(a.chunk8_body_off[c0 + 1] - 1u - begin)) : 0xFFFFFFFFu;
+        prune = (phase >= 1) && can_prune;
+        cend = phase == 2 ? (uint32_t)__builtin_amdgcn_readfirstlane((int)(a.chunk8_body_off[c0 + 1] - 1u - begin)) : 0xFFFFFFFFu;
         cend_stale = false;
         if (prune && ub_tile != tile) {   // start from what earlier waves of this tile already know
 #pragma unroll
@@ -811,9 +820,111 @@ __global__ void __launch_bounds__(64) k_best8(Best8Args a) {
             }
             return node_end(pos, -1);
         };
+        if (phase == 1) {
+            // ---- summary pass: no restarts, no stores, no scoring; dcur and the slots are left as the preamble set them
+            uint32_t sA = 0, sB = 0;     // uniform: the open entry's records
+            bool forced = false;         // uniform: the open entry is walked whatever its bounds say
+            Pk4 spar;                    // D(parent) of the open entry
+#pragma unroll
+            for (int j = 0; j < 4; j++) spar.v[j] = 0;
+            auto sum_step = [&](uint32_t w0v, uint32_t fa0, uint32_t fb0, int k, uint32_t x) {
+                const uint32_t w = rdlane(w0v, k);
+                if (w & H_TAG) {
+                    if (w & H_INFO) {                            // SUM_A carries H_RARE, SUM_B does not
+                        if (w & H_RARE) sA = w; else sB = w;
+                        return;
+                    }
+                    if (w & H_NOP) return;                       // padding behind the last entry
+                    forced = (sB & SUM_FORCED) || (w & H_RARE);  // H_RARE on a header: a cold slot or the root
+                    if (!forced) {
+                        if (w & H_REG) {
+#pragma unroll
+                            for (int j = 0; j < 4; j++) spar.v[j] = dcur.v[j];
+                        } else {
+                            const u32x4 t = *lds_at(rdlane(fa0, k) | lane16);
+                            spar.v[0] = t.x; spar.v[1] = t.y; spar.v[2] = t.z; spar.v[3] = t.w;
+                        }
+                    }
+                    if (!(w & H_END)) return;
+                } else {
+                    const uint32_t mi = rdlane(fa0, k), pi = rdlane(fb0, k);
+                    const uint32_t C = (x >> mi) & 0x11111111u, P = (x >> pi) & 0x11111111u;
+                    accP += P; accC += C;
+                    if (!(w & M_END)) return;
+                }
+                // end of the entry: the node costs at least D(parent) - (its words), its descendants at least
+                // D(node) - hsub; if both exceed the upper bound of every sample nothing of this subtree is needed
+                bool keep = forced;
+                if (!forced) {
+                    const uint32_t hs = ((sA >> INFO_HS_SHIFT) & 0x7Fu) * 0x00010001u, ws = ((sB >> SUM_W_SHIFT) & 63u) * 0x00010001u;
+                    uint32_t near = 0;
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        const uint32_t dn = pk_sub(pk_add(spar.v[j], ex4(accP, j)), ex4(accC, j));
+                        const uint32_t t1 = pk_add(ub1.v[j], hs), t2 = pk_add(ub1.v[j], ws);
+                        near |= (pk_min(dn, t1) ^ t1) | (pk_min(spar.v[j], t2) ^ t2);
+                    }
+                    keep = __builtin_amdgcn_ballot_w64(near != 0) != 0;
+                }
+                accP = accC = 0;
+                if (keep) {
+                    const uint32_t lo = sA & SUM_POS_MASK, hi = sB & SUM_POS_MASK;
+                    if (n_sv > 0 && rdlane(sv_hi, (n_sv - 1u) & 63u) == lo) {          // adjacent to the last range: extend it
+                        sv_hi = lane == ((n_sv - 1u) & 63u) ? hi : sv_hi;
+                    } else if (n_sv < 64u) {
+                        sv_lo = lane == n_sv ? lo : sv_lo;
+                        sv_hi = lane == n_sv ? hi : sv_hi;
+                        n_sv++;
+                    } else {                                                            // list full: everything from here on is walked
+                        sv_hi = lane == 63u ? SUM_POS_MASK : sv_hi;
+                    }
+                } else if (STATS) n_skipped += (sB & SUM_POS_MASK) - (sA & SUM_POS_MASK);
+            };
+            uint32_t w0 = load_words(0), w1 = load_words(GRP), w2 = load_words(2 * GRP);
+            uint32_t o0, fa0, fb0, o1, fa1, fb1;
+            decode(w0, load_bits(w0), o0, fa0, fb0);
+            uint32_t b1 = load_bits(w1);
+            uint32_t X[GRP];
+#pragma unroll
+            for (int k = 0; k < (int)GRP; k++) X[k] = __builtin_amdgcn_raw_buffer_load_b32(trsrc, lane4, rdlane(o0, k), 0);
+            for (uint32_t off = 0; off < n; off += GRP) {
+                const uint32_t w3 = load_words(off + 3 * GRP);
+                const uint32_t b2 = load_bits(w2);
+                decode(w1, b1, o1, fa1, fb1);
+#pragma unroll
+                for (int k = 0; k < (int)GRP; k++) {
+                    sum_step(w0, fa0, fb0, k, X[k]);
+                    X[k] = __builtin_amdgcn_raw_buffer_load_b32(trsrc, lane4, rdlane(o1, k), 0);
+                }
+                w0 = w1; fa0 = fa1; fb0 = fb1;
+                w1 = w2; w2 = w3; b1 = b2;
+            }
+            continue;
+        }
+        // body ranges to walk: everything, or the survivors of the summary
         uint32_t off = 0;
+        uint32_t sv_next = 0;        // uniform: next survivor range
+        const bool ranged = phase == 2 && summarise;
+        auto next_range = [&]() -> bool {   // position the walk at the next survivor range, closing the chunks in between
+            const bool more = sv_next < n_sv;
+            const uint32_t lo = more ? rdlane(sv_lo, sv_next & 63u) : n;
+            lim = more ? min(rdlane(sv_hi, sv_next & 63u), n) : n;
+            sv_next++;
+            if (cend_stale) {
+                cend_stale = false;
+                cend = chunk < c1 ? (uint32_t)__builtin_amdgcn_readfirstlane((int)(a.chunk8_body_off[chunk + 1] - 1u - begin)) : 0xFFFFFFFFu;
+            }
+            while (chunk < c1 && lo > cend) {
+                chunk_end();
+                cend = chunk < c1 ? (uint32_t)__builtin_amdgcn_readfirstlane((int)(a.chunk8_body_off[chunk + 1] - 1u - begin)) : 0xFFFFFFFFu;
+            }
+            off = lo;
+            return more;
+        };
+        if (ranged && !next_range()) continue;
         bool cautious = false;   // uniform: the last run was cut short by a jump inside its first group
-        while (off < n) {
+        for (;;) {
+        while (off < lim) {
             // (re)fill the pipeline at `off`
             const uint64_t t_r0 = STATS ? __builtin_amdgcn_s_memtime() : 0;
             uint32_t w0 = load_words(off), w1 = load_words(off + GRP), w2 = load_words(off + 2 * GRP);
@@ -847,7 +958,7 @@ __global__ void __launch_bounds__(64) k_best8(Best8Args a) {
                 }
             }
             if (!hit)
-            for (; off < n; off += GRP) {
+            for (; off < lim; off += GRP) {
                 const uint32_t w3 = load_words(off + 3 * GRP);
                 const uint32_t b2 = load_bits(w2);
                 decode(w1, b1, o1, fa1, fb1);
@@ -885,6 +996,9 @@ __global__ void __launch_bounds__(64) k_best8(Best8Args a) {
             }
             off = skip_to;
         }
+        if (!ranged || !next_range()) break;
+        cautious = false;
+        }   // next survivor range
     }
     if (STATS && lane == 0) {   // debug accounting, one update per unit
         const unsigned long long tw = __builtin_amdgcn_s_memtime() - t_wave0;

@@ -33,6 +33,8 @@ struct PlaceArgs {
 struct Best8Args {
     const uint32_t *stream8, *pre8;
     const uint32_t *chunk8_body_off, *chunk8_pre_off;   // [n_chunks+1]
+    const uint32_t *sum8, *sum8_off;   // summaries of the runs of super_chunks chunks (nullptr: not used)
+    uint32_t super_chunks;
     const uint32_t *table;     // [n_tiles][4 + n_sites][64]
     const uint32_t *dbottom;   // [n_tiles*512]
     uint32_t n_sites, n_chunks, n_groups, n_tiles;   // n_tiles = 512-sample tiles
