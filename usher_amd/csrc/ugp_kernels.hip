@@ -417,6 +417,14 @@ __global__ void k_merge(const uint32_t *__restrict__ part_best, const uint32_t *
 // offsets of the slots; a word then costs one v_readlane per field it actually uses, its flag
 // tests are single-bit scalar compares, and everything unusual (pruning records, chunk ends, headers
 // touching a cold slot) is one H_RARE bit away from the fast path.
+//
+// Instruction costs (tools/micro/issue_rate.hip, measured on MI355X): a plain 32-bit VALU instruction
+// occupies its SIMD for 2 cycles, v_pk_*_u16 and v_readlane_b32 for 4; the scalar unit retires one
+// instruction per cycle per CU -- so a scalar instruction and a 4-cycle vector instruction cost the CU the
+// same, on different pipes.  Hence: the packed 16-bit pairs are added and subtracted with PLAIN 32-bit
+// instructions wherever no carry or borrow can cross the halves (every D and cost is a count in
+// [0, 0x7F7F), see `padd` / `psub`), v_pk_min_u16 is kept for the minima only, the far tests use a biased
+// subtraction instead of packed minima, and field extraction is split between the two pipes.
 
 struct Pk4 { uint32_t v[4]; };
 #ifndef UGP_GRP
@@ -426,6 +434,10 @@ constexpr uint32_t GRP = UGP_GRP;   // stream words per pipeline group (= unroll
 constexpr uint32_t CONST_ROWS = TABLE_CONST_ROWS;  // rows 0..3 of every tile's table: all samples carry A / C / G / T
 
 __device__ __forceinline__ uint32_t ex4(uint32_t acc, int j) { return (acc >> (4 * j)) & 0x000F000Fu; }
+// Packed pairs with plain 32-bit arithmetic: exact as long as both halves of the true result lie in [0, 0xFFFF]
+// (no carry out of / borrow into the low half).  Used for D(par) + e - e' and D(par) - e, whose results are counts.
+__device__ __forceinline__ uint32_t padd(uint32_t a, uint32_t b) { return a + b; }
+__device__ __forceinline__ uint32_t psub(uint32_t a, uint32_t b) { return a - b; }
 
 template <bool STATS>   // STATS: per-unit accounting for tuning (UGP_STATS); off in production, it costs SGPRs
 __global__ void __launch_bounds__(64) k_best8(Best8Args a) {
@@ -516,7 +528,6 @@ __global__ void __launch_bounds__(64) k_best8(Best8Args a) {
     for (int j = 0; j < 4; j++) { best.v[j] = 0xFFFFFFFFu; dcur.v[j] = 0; dpar.v[j] = 0; carryD.v[j] = 0; carryN.v[j] = 0; carryC.v[j] = 0; }
     uint32_t accP = 0, accC = 0, accN = 0;
     uint32_t hdr = 0;          // uniform: header of the open node
-    uint32_t hdr_wa = 0;       // uniform: LDS byte offset of its write slot
     bool flushed = false;      // uniform
     uint32_t chunk = c0;       // uniform: chunk whose body is being walked
     const uint32_t NOPW = H_TAG | H_RARE | H_NOP;
@@ -576,15 +587,14 @@ __global__ void __launch_bounds__(64) k_best8(Best8Args a) {
         chunk++;
     };
     // "can everything below / beside this node be skipped?": true when D - hs > upper bound of best(s) for all 512 samples
+    // (per half: 0x8000 + D - hs - (ub + 1) keeps bit 15 exactly when D - hs > ub; D < 0x7F7F, ub + 1 + hs <= 0x7FFF,
+    // so no half borrows from its neighbour and plain 32-bit arithmetic is exact)
     auto all_far = [&](const Pk4 &d, uint32_t rec) -> bool {
-        const uint32_t hs = ((rec >> INFO_HS_SHIFT) & 0x7Fu) * 0x00010001u;
-        uint32_t near = 0;   // non-zero where D(s) - hs <= upper bound of best(s)
+        const uint32_t K = 0x80008000u - ((rec >> INFO_HS_SHIFT) & 0x7Fu) * 0x00010001u;
+        uint32_t r = 0xFFFFFFFFu;
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const uint32_t t1 = pk_add(ub1.v[j], hs);
-            near |= pk_min(d.v[j], t1) ^ t1;
-        }
-        return __builtin_amdgcn_ballot_w64(near != 0) == 0;
+        for (int j = 0; j < 4; j++) r &= psub(padd(d.v[j], K), ub1.v[j]);
+        return __builtin_amdgcn_ballot_w64((r & 0x80008000u) != 0x80008000u) == 0;
     };
 
     // Saved-D slots beyond a.lds_slots live in a small global scratch (one access per ~1,300 words at 10M
@@ -618,16 +628,17 @@ __global__ void __launch_bounds__(64) k_best8(Best8Args a) {
             for (int j = 0; j < 4; j++) { carryD.v[j] = 0; carryN.v[j] = 0; carryC.v[j] = 0; }
             flushed = false;
         } else {
-            // (D(node) is computed even where no child will read it: cheaper than testing for it)
+            if (!(hdr & H_SKIPD)) {
 #pragma unroll
-            for (int j = 0; j < 4; j++) dcur.v[j] = pk_sub(pk_add(dpar.v[j], ex4(accP, j)), ex4(accC, j));
+                for (int j = 0; j < 4; j++) dcur.v[j] = psub(padd(dpar.v[j], ex4(accP, j)), ex4(accC, j));
+            }
             if (!(hdr & H_NOSCORE)) {
                 uint32_t z = accC | (accC >> 1);
                 z |= z >> 2;
                 z = ~z & ((hdr & H_FREE) ? 0u : 0x11111111u);   // bit 4j: sample j shares no mutation with this branch
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
-                    const uint32_t cost = pk_sub(dpar.v[j], ex4(accN, j));
+                    const uint32_t cost = psub(dpar.v[j], ex4(accN, j));
                     const uint32_t pen = (j == 3 ? (z << 3) : (z << (15 - 4 * j))) & 0x80008000u;
                     best.v[j] = pk_min(best.v[j], cost | pen);
                 }
@@ -636,7 +647,7 @@ __global__ void __launch_bounds__(64) k_best8(Best8Args a) {
         if (hdr & H_STORE) {
             const u32x4 v = u32x4{dcur.v[0], dcur.v[1], dcur.v[2], dcur.v[3]};
             if (cold_ws >= 0) *(u32x4 *)(coldp + (uint64_t)cold_ws * 256) = v;
-            else *lds_at(hdr_wa | lane16) = v;
+            else *lds_at(((hdr >> (H_WSLOT_SHIFT - 10)) & (63u << 10)) | lane16) = v;
         }
         accP = accC = accN = 0;
         if (STATS) run_nodes++;
@@ -712,7 +723,6 @@ __global__ void __launch_bounds__(64) k_best8(Best8Args a) {
             const u32x4 t = rs >= a.lds_slots ? *(const u32x4 *)(coldp + (uint64_t)(rs - a.lds_slots) * 256) : *lds_at(rs * 1024u + lane16);
             dpar.v[0] = t.x; dpar.v[1] = t.y; dpar.v[2] = t.z; dpar.v[3] = t.w;
         }
-        hdr_wa = ws * 1024u;
         const int cold_ws = ((w & H_STORE) && ws >= a.lds_slots) ? (int)(ws - a.lds_slots) : -1;
         if (have_sinfo && sibling_test(p)) return p + 1;
         p++;
@@ -769,17 +779,13 @@ __global__ void __launch_bounds__(64) k_best8(Best8Args a) {
             const uint32_t site = (wv & H_TAG) ? 0u : (wv & 0x3FFFFFu);
             return abm[site >> 5];
         };
-        // Per-lane decoding of a group (lane k of every 8 holds word k):
-        //   off  byte offset of the word's table row: the site's own row if some sample of the tile is
-        //        non-reference there, else the constant row of the site's reference base (headers: row 0)
-        //   fa   mutation word: shift of the mutated allele      header: LDS byte offset of the read slot
-        //   fb   mutation word: shift of the parent-state allele header: LDS byte offset of the write slot
-        auto decode = [&](uint32_t wv, uint32_t bits, uint32_t &off, uint32_t &fa, uint32_t &fb) {
+        // Per-lane decoding of a group (lane k of every 8 holds word k): byte offset of the word's table row -- the
+        // site's own row if some sample of the tile is non-reference there, else the constant row of the site's
+        // reference base (headers: row 0).  The other fields of a word are extracted on the scalar side.
+        auto decode = [&](uint32_t wv, uint32_t bits) -> uint32_t {
             const bool is_hdr = (wv & H_TAG) != 0;
             const bool act = !is_hdr && ((bits >> (wv & 31u)) & 1u);
-            off = (act ? (wv & 0x3FFFFFu) + CONST_ROWS : (is_hdr ? 0u : (wv >> 26) & 3u)) << 8;
-            fa = is_hdr ? (wv & (63u << H_RSLOT_SHIFT)) : ((wv >> 22) & 3u);
-            fb = is_hdr ? ((wv >> (H_WSLOT_SHIFT - 10)) & (63u << 10)) : ((wv >> 24) & 3u);
+            return (act ? (wv & 0x3FFFFFu) + CONST_ROWS : (is_hdr ? 0u : (wv >> 26) & 3u)) << 8;
         };
         prune = (phase >= 1) && can_prune;
         cend = phase == 2 ? (uint32_t)__builtin_amdgcn_readfirstlane((int)(a.chunk8_body_off[c0 + 1] - 1u - begin)) : 0xFFFFFFFFu;
@@ -791,26 +797,25 @@ __global__ void __launch_bounds__(64) k_best8(Best8Args a) {
             ub_tile = tile;
             ub_age = 0;
         }
-        // One stream word of the group being evaluated: w0/fa0/fb0 = the group's words and decoded fields,
+        // One stream word of the group being evaluated: w0v = the group's words (lane k = word k),
         // x = the lane's dword of the word's table row.  Returns true when the pipeline has to restart at
         // skip_to (chunk end that stores, pruning jump, slow header).
-        auto step = [&](uint32_t w0v, uint32_t fa0, uint32_t fb0, int k, uint32_t x, uint32_t pos) -> bool {
+        auto step = [&](uint32_t w0v, int k, uint32_t x, uint32_t pos) -> bool {
             const uint32_t w = rdlane(w0v, k);
             if (w & H_TAG) {
                 if (w & H_RARE) return rare_word(w, pos);
                 hdr = w;
-                hdr_wa = rdlane(fb0, k);
                 if (w & H_REG) {
 #pragma unroll
                     for (int j = 0; j < 4; j++) dpar.v[j] = dcur.v[j];
                 } else {
-                    const u32x4 t = *lds_at(rdlane(fa0, k) | lane16);
+                    const u32x4 t = *lds_at((w & (63u << H_RSLOT_SHIFT)) | lane16);
                     dpar.v[0] = t.x; dpar.v[1] = t.y; dpar.v[2] = t.z; dpar.v[3] = t.w;
                 }
                 if (have_sinfo && sibling_test(pos)) return true;
                 if (!(w & H_END)) return false;
             } else {
-                const uint32_t mi = rdlane(fa0, k), pi = rdlane(fb0, k);
+                const uint32_t mi = (w >> 22) & 3u, pi = (w >> 24) & 3u;
                 const uint32_t C = (x >> mi) & 0x11111111u, P = (x >> pi) & 0x11111111u;
                 accP += P; accC += C; accN += C & ~P;
                 if (!(w & M_END)) {
@@ -827,7 +832,7 @@ __global__ void __launch_bounds__(64) k_best8(Best8Args a) {
             Pk4 spar;                    // D(parent) of the open entry
 #pragma unroll
             for (int j = 0; j < 4; j++) spar.v[j] = 0;
-            auto sum_step = [&](uint32_t w0v, uint32_t fa0, uint32_t fb0, int k, uint32_t x) {
+            auto sum_step = [&](uint32_t w0v, int k, uint32_t x) {
                 const uint32_t w = rdlane(w0v, k);
                 if (w & H_TAG) {
                     if (w & H_INFO) {                            // SUM_A carries H_RARE, SUM_B does not
@@ -841,13 +846,13 @@ __global__ void __launch_bounds__(64) k_best8(Best8Args a) {
 #pragma unroll
                             for (int j = 0; j < 4; j++) spar.v[j] = dcur.v[j];
                         } else {
-                            const u32x4 t = *lds_at(rdlane(fa0, k) | lane16);
+                            const u32x4 t = *lds_at((w & (63u << H_RSLOT_SHIFT)) | lane16);
                             spar.v[0] = t.x; spar.v[1] = t.y; spar.v[2] = t.z; spar.v[3] = t.w;
                         }
                     }
                     if (!(w & H_END)) return;
                 } else {
-                    const uint32_t mi = rdlane(fa0, k), pi = rdlane(fb0, k);
+                    const uint32_t mi = (w >> 22) & 3u, pi = (w >> 24) & 3u;
                     const uint32_t C = (x >> mi) & 0x11111111u, P = (x >> pi) & 0x11111111u;
                     accP += P; accC += C;
                     if (!(w & M_END)) return;
@@ -856,15 +861,15 @@ __global__ void __launch_bounds__(64) k_best8(Best8Args a) {
                 // D(node) - hsub; if both exceed the upper bound of every sample nothing of this subtree is needed
                 bool keep = forced;
                 if (!forced) {
-                    const uint32_t hs = ((sA >> INFO_HS_SHIFT) & 0x7Fu) * 0x00010001u, ws = ((sB >> SUM_W_SHIFT) & 63u) * 0x00010001u;
-                    uint32_t near = 0;
+                    const uint32_t K1 = 0x80008000u - ((sA >> INFO_HS_SHIFT) & 0x7Fu) * 0x00010001u;
+                    const uint32_t K2 = 0x80008000u - ((sB >> SUM_W_SHIFT) & 63u) * 0x00010001u;
+                    uint32_t r = 0xFFFFFFFFu;
 #pragma unroll
                     for (int j = 0; j < 4; j++) {
-                        const uint32_t dn = pk_sub(pk_add(spar.v[j], ex4(accP, j)), ex4(accC, j));
-                        const uint32_t t1 = pk_add(ub1.v[j], hs), t2 = pk_add(ub1.v[j], ws);
-                        near |= (pk_min(dn, t1) ^ t1) | (pk_min(spar.v[j], t2) ^ t2);
+                        const uint32_t dn = psub(padd(spar.v[j], ex4(accP, j)), ex4(accC, j));
+                        r &= psub(padd(dn, K1), ub1.v[j]) & psub(padd(spar.v[j], K2), ub1.v[j]);
                     }
-                    keep = __builtin_amdgcn_ballot_w64(near != 0) != 0;
+                    keep = __builtin_amdgcn_ballot_w64((r & 0x80008000u) != 0x80008000u) != 0;
                 }
                 accP = accC = 0;
                 if (keep) {
@@ -881,8 +886,7 @@ __global__ void __launch_bounds__(64) k_best8(Best8Args a) {
                 } else if (STATS) n_skipped += (sB & SUM_POS_MASK) - (sA & SUM_POS_MASK);
             };
             uint32_t w0 = load_words(0), w1 = load_words(GRP), w2 = load_words(2 * GRP);
-            uint32_t o0, fa0, fb0, o1, fa1, fb1;
-            decode(w0, load_bits(w0), o0, fa0, fb0);
+            const uint32_t o0 = decode(w0, load_bits(w0));
             uint32_t b1 = load_bits(w1);
             uint32_t X[GRP];
 #pragma unroll
@@ -890,14 +894,13 @@ __global__ void __launch_bounds__(64) k_best8(Best8Args a) {
             for (uint32_t off = 0; off < n; off += GRP) {
                 const uint32_t w3 = load_words(off + 3 * GRP);
                 const uint32_t b2 = load_bits(w2);
-                decode(w1, b1, o1, fa1, fb1);
+                const uint32_t o1 = decode(w1, b1);
 #pragma unroll
                 for (int k = 0; k < (int)GRP; k++) {
-                    sum_step(w0, fa0, fb0, k, X[k]);
+                    sum_step(w0, k, X[k]);
                     X[k] = __builtin_amdgcn_raw_buffer_load_b32(trsrc, lane4, rdlane(o1, k), 0);
                 }
-                w0 = w1; fa0 = fa1; fb0 = fb1;
-                w1 = w2; w2 = w3; b1 = b2;
+                w0 = w1; w1 = w2; w2 = w3; b1 = b2;
             }
             continue;
         }
@@ -928,8 +931,7 @@ __global__ void __launch_bounds__(64) k_best8(Best8Args a) {
             // (re)fill the pipeline at `off`
             const uint64_t t_r0 = STATS ? __builtin_amdgcn_s_memtime() : 0;
             uint32_t w0 = load_words(off), w1 = load_words(off + GRP), w2 = load_words(off + 2 * GRP);
-            uint32_t o0, fa0, fb0, o1, fa1, fb1;
-            decode(w0, load_bits(w0), o0, fa0, fb0);
+            const uint32_t o0 = decode(w0, load_bits(w0));
             uint32_t b1 = load_bits(w1);
             uint32_t X[GRP];
 #pragma unroll
@@ -944,13 +946,13 @@ __global__ void __launch_bounds__(64) k_best8(Best8Args a) {
                 // ahead of the next refill in the in-order return queue.
 #pragma unroll
                 for (int k = 0; k < (int)GRP; k++) {
-                    if (step(w0, fa0, fb0, k, X[k], off + k)) { hit = true; break; }
+                    if (step(w0, k, X[k], off + k)) { hit = true; break; }
                 }
                 if (!hit) {   // the run goes on: bring the pipeline to its steady state one group further
-                    decode(w1, b1, o1, fa1, fb1);
+                    const uint32_t o1 = decode(w1, b1);
 #pragma unroll
                     for (int k = 0; k < (int)GRP; k++) X[k] = __builtin_amdgcn_raw_buffer_load_b32(trsrc, lane4, rdlane(o1, k), 0);
-                    w0 = w1; fa0 = fa1; fb0 = fb1;
+                    w0 = w1;
                     w1 = w2; w2 = load_words(off + 3 * GRP);
                     b1 = load_bits(w1);
                     off += GRP;
@@ -961,15 +963,14 @@ __global__ void __launch_bounds__(64) k_best8(Best8Args a) {
             for (; off < lim; off += GRP) {
                 const uint32_t w3 = load_words(off + 3 * GRP);
                 const uint32_t b2 = load_bits(w2);
-                decode(w1, b1, o1, fa1, fb1);
+                const uint32_t o1 = decode(w1, b1);
 #pragma unroll
                 for (int k = 0; k < (int)GRP; k++) {
-                    if (step(w0, fa0, fb0, k, X[k], off + k)) { hit = true; break; }
+                    if (step(w0, k, X[k], off + k)) { hit = true; break; }
                     X[k] = __builtin_amdgcn_raw_buffer_load_b32(trsrc, lane4, rdlane(o1, k), 0);
                 }
                 if (hit) break;
-                w0 = w1; fa0 = fa1; fb0 = fb1;
-                w1 = w2; w2 = w3; b1 = b2;
+                w0 = w1; w1 = w2; w2 = w3; b1 = b2;
                 first = false;
             }
             if (!hit) break;   // walked to the end of the range
