@@ -81,9 +81,8 @@ struct ugp_mat {
     DevBuf<int32_t> d_pos2site;
     DevBuf<uint8_t> d_site_ref;
     // per-call workspaces (grown on demand)
-    DevBuf<uint32_t> d_table, d_dbottom, d_part_best, d_part_cnt, d_part_key;
-    DevBuf<uint8_t> d_lflag;
-    DevBuf<uint32_t> d_lbest, d_gbest, d_gbest_part, d_items, d_nitems, d_cnt, d_key, d_active, d_ub, d_queue, d_gstart, d_hlen, d_cold, d_list, d_list_n;
+    DevBuf<uint32_t> d_table, d_zero, d_part_best, d_part_cnt, d_part_key;
+    DevBuf<uint32_t> d_lbest, d_gbest, d_gbest_part, d_items, d_ub, d_gstart, d_hlen, d_cold, d_list;
     DevBuf<uint64_t> d_stats;
     uint64_t last_words_total = 0;
     // locality sort (speed only): a coarse MAT of the top of the tree and the map coarse BFS index -> DFS rank in the full tree
@@ -158,7 +157,7 @@ int ensure_events(ugp_mat *m, size_t n) {
 // mode 1: per-node scores to d_scores (device int32 [n_queries][n_nodes]);
 // mode 2: tied nodes (needs d_best_in) -- see ugp_kernels.hip.
 int run_place(ugp_mat *m, ugp_qset *qs, int mode, ugp_result *d_out, int32_t *d_scores, const int32_t *d_best_in,
-              uint32_t *d_tie_count, uint32_t *d_tie_j, uint8_t *d_tie_hu, uint32_t tie_cap, hipStream_t s) {
+              uint32_t *d_tie_count, uint32_t *d_tie_j, uint8_t *d_tie_hu, uint32_t tie_cap, hipStream_t s, bool coarse_only = false) {
     HIP_TRY(hipSetDevice(m->device));
     const auto &f = m->flat;
     const uint64_t Q = qs->n_queries;
@@ -183,7 +182,8 @@ int run_place(ugp_mat *m, ugp_qset *qs, int mode, ugp_result *d_out, int32_t *d_
         HIP_TRY(m->d_coarse_res.reserve(Q));
         if (!m->ev_coarse[0]) { HIP_TRY(hipEventCreate(&m->ev_coarse[0])); HIP_TRY(hipEventCreate(&m->ev_coarse[1])); }
         HIP_TRY(hipEventRecord(m->ev_coarse[0], s));
-        if (int rc = run_place(m->coarse, qs, 0, m->d_coarse_res.p, nullptr, nullptr, nullptr, nullptr, nullptr, 0, s)) return rc;
+        // (locality pre-pass: minimum and the chunk that attains it are all the sort needs -- no phase 2)
+        if (int rc = run_place(m->coarse, qs, 0, m->d_coarse_res.p, nullptr, nullptr, nullptr, nullptr, nullptr, 0, s, true)) return rc;
         HIP_TRY(hipSetDevice(m->device));
         HIP_TRY(hipEventRecord(m->ev_coarse[1], s));
         m->coarse_timed = true;
@@ -209,22 +209,25 @@ int run_place(ugp_mat *m, ugp_qset *qs, int mode, ugp_result *d_out, int32_t *d_
         }
         const uint64_t table_dwords = (uint64_t)n_tiles512 * (n_sites + ugp::TABLE_CONST_ROWS) * 64;
         HIP_TRY(m->d_table.reserve(table_dwords));
-        HIP_TRY(m->d_dbottom.reserve((size_t)n_tiles512 * 512));
-        HIP_TRY(m->d_active.reserve((size_t)n_tiles512 * active_words));
         const uint64_t pairs = (uint64_t)f.n_chunks * n_tiles512 * 8;
+        // every small buffer that has to start from zero lives in ONE allocation cleared by one memset:
+        // D(bottom) counters, active-row bitmap, work-queue heads, record lists' lengths, phase-2 item count, tie counts / keys
+        const size_t z_dbottom = 0, z_active = z_dbottom + (size_t)n_tiles512 * 512, z_queue = z_active + (size_t)n_tiles512 * active_words,
+                     z_list_n = z_queue + 8, z_nitems = z_list_n + n_tiles512, z_cnt = z_nitems + 8, z_key = z_cnt + (size_t)n_tiles512 * 512,
+                     z_end = z_key + (size_t)n_tiles512 * 512;
+        HIP_TRY(m->d_zero.reserve(z_end));
+        uint32_t *const d_dbottom = m->d_zero.p + z_dbottom, *const d_active = m->d_zero.p + z_active, *const d_queue = m->d_zero.p + z_queue,
+                 *const d_list_n = m->d_zero.p + z_list_n, *const d_nitems = m->d_zero.p + z_nitems, *const d_cnt = m->d_zero.p + z_cnt,
+                 *const d_key = m->d_zero.p + z_key;
         if (use8) {
             HIP_TRY(m->d_lbest.reserve((size_t)f.n_chunks * n_tiles512 * 256));
-            HIP_TRY(m->d_lflag.reserve((size_t)f.n_chunks * n_tiles512));
             HIP_TRY(m->d_list.reserve((size_t)f.n_chunks * n_tiles512));
-            HIP_TRY(m->d_list_n.reserve(n_tiles512));
-            HIP_TRY(m->d_gbest.reserve((size_t)n_tiles512 * 256));
-            HIP_TRY(m->d_gbest_part.reserve((size_t)ugp::GBEST_SLICES * n_tiles512 * 256));
             HIP_TRY(m->d_ub.reserve((size_t)n_tiles512 * 256));
-            HIP_TRY(m->d_queue.reserve(8));
-            HIP_TRY(m->d_items.reserve(pairs));
-            HIP_TRY(m->d_nitems.reserve(1));
-            HIP_TRY(m->d_cnt.reserve((size_t)n_tiles512 * 512));
-            HIP_TRY(m->d_key.reserve((size_t)n_tiles512 * 512));
+            if (!coarse_only) {
+                HIP_TRY(m->d_gbest.reserve((size_t)n_tiles512 * 256));
+                HIP_TRY(m->d_gbest_part.reserve((size_t)ugp::GBEST_SLICES * n_tiles512 * 256));
+                HIP_TRY(m->d_items.reserve(pairs));
+            }
         } else if (mode == 0) {
             const size_t np = (size_t)n_tiles * G * 64;
             HIP_TRY(m->d_part_best.reserve(np));
@@ -248,22 +251,17 @@ int run_place(ugp_mat *m, ugp_qset *qs, int mode, ugp_result *d_out, int32_t *d_
                                               m->d_idx.p, m->d_order.p, m->d_slot.p, m->d_sort_tmp.p, &tmp_bytes, s));
             slot_of = m->d_slot.p; order = m->d_order.p;
         }
-        HIP_TRY(hipMemsetAsync(m->d_dbottom.p, 0, (size_t)n_tiles512 * 512 * sizeof(uint32_t), s));
-        HIP_TRY(hipMemsetAsync(m->d_active.p, 0, (size_t)n_tiles512 * active_words * sizeof(uint32_t), s));
+        HIP_TRY(hipMemsetAsync(m->d_zero.p, 0, z_end * sizeof(uint32_t), s));
         if (use8) {
-            HIP_TRY(hipMemsetAsync(m->d_nitems.p, 0, sizeof(uint32_t), s));
-            HIP_TRY(hipMemsetAsync(m->d_queue.p, 0, 8 * sizeof(uint32_t), s));
             if (sorted && !getenv("UGP_NO_SEED"))   // start from the coarse pass's best costs (real costs of real nodes)
                 HIP_TRY(ugp::launch_seed_ub(m->d_coarse_res.p + q0, order, (uint32_t)nq, n_tiles512, m->d_ub.p, s));
             else
                 HIP_TRY(hipMemsetAsync(m->d_ub.p, 0x7F, (size_t)n_tiles512 * 256 * sizeof(uint32_t), s));   // 0x7F7F: above every valid cost
-            HIP_TRY(hipMemsetAsync(m->d_cnt.p, 0, (size_t)n_tiles512 * 512 * sizeof(uint32_t), s));
-            HIP_TRY(hipMemsetAsync(m->d_key.p, 0, (size_t)n_tiles512 * 512 * sizeof(uint32_t), s));
         }
         HIP_TRY(ugp::launch_fill_table(m->d_table.p, m->d_site_ref.p, n_sites, table_dwords, s));
-        HIP_TRY(ugp::launch_scatter(m->d_table.p, m->d_dbottom.p, qs->d_pos.p + e0, qs->d_ref.p + e0,
+        HIP_TRY(ugp::launch_scatter(m->d_table.p, d_dbottom, qs->d_pos.p + e0, qs->d_ref.p + e0,
                                     qs->d_nuc.p + e0, qs->d_missing.p + e0, qs->d_ent_q.p + e0, m->d_pos2site.p,
-                                    f.max_pos, n_sites, e1 - e0, (uint32_t)q0, m->d_active.p, active_words, slot_of, s));
+                                    f.max_pos, n_sites, e1 - e0, (uint32_t)q0, d_active, active_words, slot_of, s));
         HIP_TRY(hipEventRecord(es.ev[1], s));
 
         ugp::PlaceArgs a;
@@ -271,7 +269,7 @@ int run_place(ugp_mat *m, ugp_qset *qs, int mode, ugp_result *d_out, int32_t *d_
         a.stream = m->d_stream.p; a.pre_stream = m->d_pre.p;
         a.chunk_body_off = m->d_chunk_body.p; a.chunk_pre_off = m->d_chunk_pre.p; a.chunk_node_off = m->d_chunk_node.p;
         a.stream_t = m->d_stream_t.p; a.chunk_t_off = m->d_chunk_t.p;
-        a.table = m->d_table.p; a.dbottom = m->d_dbottom.p;
+        a.table = m->d_table.p; a.dbottom = d_dbottom;
         a.n_sites = n_sites; a.n_chunks = f.n_chunks; a.n_groups = G; a.n_tiles = n_tiles; a.n_queries = (uint32_t)nq;
         a.part_best = m->d_part_best.p; a.part_cnt = m->d_part_cnt.p; a.part_key = m->d_part_key.p;
         a.dfs2bfs = m->d_dfs2bfs.p; a.n_nodes = f.n_nodes;
@@ -286,12 +284,11 @@ int run_place(ugp_mat *m, ugp_qset *qs, int mode, ugp_result *d_out, int32_t *d_
             memset(&b, 0, sizeof(b));
             b.stream8 = m->d_stream8.p; b.pre8 = m->d_pre8.p;
             b.chunk8_body_off = m->d_chunk8_body.p; b.chunk8_pre_off = m->d_chunk8_pre.p;
-            b.table = m->d_table.p; b.dbottom = m->d_dbottom.p;
+            b.table = m->d_table.p; b.dbottom = d_dbottom;
             b.n_sites = n_sites; b.n_chunks = f.n_chunks; b.n_groups = G; b.n_tiles = n_tiles512;
             b.lbest = m->d_lbest.p;
-            b.lflag = m->d_lflag.p;
-            HIP_TRY(hipMemsetAsync(m->d_lflag.p, 0, (size_t)f.n_chunks * n_tiles512, s));
-            b.queue = m->d_queue.p;
+            b.list = m->d_list.p; b.list_n = d_list_n;
+            b.queue = d_queue;
             b.ub = getenv("UGP_NO_PRUNE") ? nullptr : m->d_ub.p;
             if (sorted && !getenv("UGP_NO_LPT")) {   // hand out every tile's own region first (scheduling only)
                 HIP_TRY(m->d_gstart.reserve(n_tiles512)); HIP_TRY(m->d_hlen.reserve(n_tiles512));
@@ -332,12 +329,16 @@ int run_place(ugp_mat *m, ugp_qset *qs, int mode, ugp_result *d_out, int32_t *d_
             blocks = ((blocks + 7) / 8) * 8;
             HIP_TRY(m->d_cold.reserve((size_t)blocks * std::max<uint32_t>(f.max_slots - b.lds_slots, 1) * 256));
             b.cold = m->d_cold.p;
-            b.active = m->d_active.p; b.active_words = active_words;
+            b.active = d_active; b.active_words = active_words;
             HIP_TRY(ugp::launch_best8(b, (uint32_t)blocks, s));
             HIP_TRY(hipEventRecord(es.ev[2], s));
-            HIP_TRY(ugp::launch_phase2(a, m->d_lbest.p, m->d_lflag.p, m->d_list.p, m->d_list_n.p, m->d_gbest_part.p, m->d_gbest.p, n_tiles512, m->d_items.p, m->d_nitems.p,
-                                       (uint32_t)std::min<uint64_t>(pairs, 0xFFFFFFFFull), m->d_cnt.p, m->d_key.p,
-                                       m->d_rank2bfs.p, d_out + q0, order, f.max_slots, s));
+            if (coarse_only)
+                HIP_TRY(ugp::launch_coarse_result(m->d_lbest.p, m->d_list.p, d_list_n, f.n_chunks, n_tiles512, (uint32_t)nq, m->d_chunk_node.p,
+                                                  m->d_dfs2bfs.p, d_out + q0, s));
+            else
+                HIP_TRY(ugp::launch_phase2(a, m->d_lbest.p, m->d_list.p, d_list_n, m->d_gbest_part.p, m->d_gbest.p, n_tiles512, m->d_items.p, d_nitems,
+                                           (uint32_t)std::min<uint64_t>(pairs, 0xFFFFFFFFull), d_cnt, d_key,
+                                           m->d_rank2bfs.p, d_out + q0, order, f.max_slots, s));
         } else {
             HIP_TRY(ugp::launch_place(a, mode, f.max_slots, s));
             HIP_TRY(hipEventRecord(es.ev[2], s));

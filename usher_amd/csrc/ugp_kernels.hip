@@ -559,8 +559,8 @@ __global__ void __launch_bounds__(64) k_best8(Best8Args a) {
         }
     };
     // A chunk's minima matter only if some sample's minimum is within its upper bound (the global minimum
-    // never exceeds the bound): only then are they stored, and lflag[chunk][tile] tells phase 2 that the
-    // record exists.  Most chunks are far from the tile's samples and end without a store.
+    // never exceeds the bound): only then are they stored, and the chunk is appended to the tile's list of records
+    // for phase 2.  Most chunks are far from the tile's samples and end without a store.
     auto chunk_has_candidate = [&]() -> bool {
         if (!can_prune) return true;
         uint32_t t = 0;
@@ -572,7 +572,7 @@ __global__ void __launch_bounds__(64) k_best8(Best8Args a) {
         if (chunk_has_candidate()) {
             uint4 *dst = (uint4 *)(a.lbest + (((uint64_t)chunk * a.n_tiles + tile) * 64 + lane) * 4);
             *dst = make_uint4(best.v[0], best.v[1], best.v[2], best.v[3]);
-            if (lane == 0) a.lflag[(uint64_t)chunk * a.n_tiles + tile] = 1;
+            if (lane == 0) a.list[(uint64_t)tile * a.n_chunks + atomicAdd(&a.list_n[tile], 1u)] = chunk;   // (order is irrelevant to phase 2)
         }
         if (can_prune) {
             if (++ub_age >= a.ub_every) { exchange_ub(); ub_age = 0; }
@@ -1017,17 +1017,29 @@ __global__ void __launch_bounds__(64) k_best8(Best8Args a) {
     }   // next work unit
 }
 
-// The chunks of each tile that left a record in phase 1 (about 4 % of them), as a list: block = one tile.
-__global__ void k_list_records(const uint8_t *__restrict__ lflag, uint32_t n_chunks, uint32_t n_tiles, uint32_t *__restrict__ list /* [n_tiles][n_chunks] */,
-                               uint32_t *__restrict__ list_n /* [n_tiles] */) {
-    __shared__ uint32_t n;
-    const uint32_t tile = blockIdx.x;
-    if (threadIdx.x == 0) n = 0;
-    __syncthreads();
-    for (uint32_t c = threadIdx.x; c < n_chunks; c += blockDim.x)
-        if (lflag[(uint64_t)c * n_tiles + tile]) list[(uint64_t)tile * n_chunks + atomicAdd(&n, 1u)] = c;
-    __syncthreads();
-    if (threadIdx.x == 0) list_n[tile] = n;
+// Locality pre-pass only (the coarse MAT): per sample the minimum over the recorded chunks and the chunk that
+// attains it (the smallest such chunk); the "node" reported is that chunk's first node -- all the sort needs.
+// Block = one 512-sample tile, thread = one dword of its 1 KB records (two samples).
+__global__ void k_coarse_result(const uint32_t *__restrict__ lbest, const uint32_t *__restrict__ list, const uint32_t *__restrict__ list_n,
+                                uint32_t n_chunks, uint32_t n_tiles, uint32_t n_queries, const uint32_t *__restrict__ chunk_node_off,
+                                const uint32_t *__restrict__ dfs2bfs, ugp_result *__restrict__ out) {
+    const uint32_t tile = blockIdx.x, i = tile * 256 + threadIdx.x;
+    const uint32_t per_chunk = n_tiles * 256;
+    const uint32_t n = list_n[tile];
+    const uint32_t *l = list + (uint64_t)tile * n_chunks;
+    uint32_t mlo = 0xFFFFu, mhi = 0xFFFFu, clo = 0, chi = 0;
+    for (uint32_t e = 0; e < n; e++) {
+        const uint32_t c = l[e];
+        const uint32_t v = lbest[(uint64_t)c * per_chunk + i];
+        const uint32_t lo = v & 0xFFFFu, hi = v >> 16;
+        if (lo < mlo || (lo == mlo && c < clo)) { mlo = lo; clo = c; }
+        if (hi < mhi || (hi == mhi && c < chi)) { mhi = hi; chi = c; }
+    }
+    // dword (lane l, j): samples 8l + j and 8l + j + 4 of the tile
+    const uint32_t l64 = threadIdx.x >> 2, j = threadIdx.x & 3u;
+    const uint32_t q0 = tile * 512 + l64 * 8 + j;
+    if (q0 < n_queries) out[q0] = ugp_result{(int32_t)mlo, 1u, dfs2bfs[chunk_node_off[clo]], 0u};
+    if (q0 + 4 < n_queries) out[q0 + 4] = ugp_result{(int32_t)mhi, 1u, dfs2bfs[chunk_node_off[chi]], 0u};
 }
 
 // Global minimum per sample over the chunk-local minima that were recorded: the list of a tile is cut into
@@ -1276,13 +1288,19 @@ hipError_t launch_best8(const Best8Args &a, uint32_t blocks, hipStream_t s) {
     return hipGetLastError();
 }
 
-hipError_t launch_phase2(const PlaceArgs &a, const uint32_t *lbest, const uint8_t *lflag, uint32_t *list, uint32_t *list_n, uint32_t *gbest_part,
+hipError_t launch_coarse_result(const uint32_t *lbest, const uint32_t *list, const uint32_t *list_n, uint32_t n_chunks, uint32_t n_tiles512,
+                                uint32_t n_queries, const uint32_t *chunk_node_off, const uint32_t *dfs2bfs, ugp_result *out, hipStream_t s) {
+    hipLaunchKernelGGL(k_coarse_result, dim3(n_tiles512), dim3(256), 0, s, lbest, list, list_n, n_chunks, n_tiles512, n_queries, chunk_node_off,
+                       dfs2bfs, out);
+    return hipGetLastError();
+}
+
+hipError_t launch_phase2(const PlaceArgs &a, const uint32_t *lbest, const uint32_t *list, const uint32_t *list_n, uint32_t *gbest_part,
                          uint32_t *gbest, uint32_t n_tiles512,
                          uint32_t *items, uint32_t *n_items, uint32_t cap, uint32_t *cnt, uint32_t *key,
                          const uint32_t *rank2bfs, ugp_result *out, const uint32_t *order, uint32_t max_slots, hipStream_t s) {
     const uint32_t per_chunk = n_tiles512 * 256;
     const uint32_t slices = std::min<uint32_t>(GBEST_SLICES, a.n_chunks);
-    hipLaunchKernelGGL(k_list_records, dim3(n_tiles512), dim3(256), 0, s, lflag, a.n_chunks, n_tiles512, list, list_n);
     hipLaunchKernelGGL(k_gbest, dim3(n_tiles512, slices), dim3(256), 0, s, lbest, list, list_n, a.n_chunks, n_tiles512, gbest_part);
     hipLaunchKernelGGL(k_gbest2, dim3((per_chunk + 255) / 256), dim3(256), 0, s, gbest_part, slices, per_chunk, gbest);
     const uint64_t pairs = (uint64_t)a.n_chunks * n_tiles512 * 8;

@@ -43,8 +43,8 @@ struct Best8Args {
     uint32_t *cold;            // [resident waves][max_slots - lds_slots][64][4]
     const uint32_t *active;    // [n_tiles][active_words] bit per site: some sample of the tile is not reference there
     uint32_t active_words;
-    uint32_t *lbest;           // [n_chunks][n_tiles][64][4] packed u16 pairs; a record exists only where lflag is set
-    uint8_t *lflag;            // [n_chunks][n_tiles], zeroed before the launch
+    uint32_t *lbest;           // [n_chunks][n_tiles][64][4] packed u16 pairs; a record exists only for the chunks in `list`
+    uint32_t *list, *list_n;   // [n_tiles][n_chunks] chunks of each tile that left a record, [n_tiles] their number (zeroed before the launch)
     uint32_t *queue;           // [8] work-queue heads, one per XCD, zeroed before the launch
     const uint32_t *tile_hstart, *tile_hlen;   // [n_tiles] or null: per tile, the first chunk of the region its own samples
                                                // sit in and that region's length in chunks (scheduled first)
@@ -59,7 +59,9 @@ hipError_t launch_best8(const Best8Args &a, uint32_t blocks, hipStream_t s);
 // a.n_tiles = number of 64-sample tiles; lbest/gbest in the packed 512-tile layout
 constexpr uint32_t GBEST_SLICES = 64;   // chunk-axis slices of the global-minimum reduction
 // gbest_part: [GBEST_SLICES][n_tiles512*256] scratch
-hipError_t launch_phase2(const PlaceArgs &a, const uint32_t *lbest, const uint8_t *lflag, uint32_t *list, uint32_t *list_n, uint32_t *gbest_part,
+hipError_t launch_coarse_result(const uint32_t *lbest, const uint32_t *list, const uint32_t *list_n, uint32_t n_chunks, uint32_t n_tiles512,
+                                uint32_t n_queries, const uint32_t *chunk_node_off, const uint32_t *dfs2bfs, ugp_result *out, hipStream_t s);
+hipError_t launch_phase2(const PlaceArgs &a, const uint32_t *lbest, const uint32_t *list, const uint32_t *list_n, uint32_t *gbest_part,
                          uint32_t *gbest, uint32_t n_tiles512,
                          uint32_t *items, uint32_t *n_items, uint32_t cap, uint32_t *cnt, uint32_t *key,
                          const uint32_t *rank2bfs, ugp_result *out, const uint32_t *order, uint32_t max_slots, hipStream_t s);
