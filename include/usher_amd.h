@@ -150,6 +150,36 @@ int ugp_tied_nodes(ugp_mat *mat, const ugp_queries *q, uint32_t cap,
                    uint8_t *tie_has_unique /* [n_queries * cap] */,
                    uint32_t *tie_count /* [n_queries] */);
 
+/* ---- the other callers of mapper2_body ------------------------------------------------------------------
+ * matUtils uncertainty (uncertainty.cpp:212-235: every node but the sample's own, depth-first indices), annotate
+ * (annotate.cpp:615-638: depth-first indices), merge (merge.cpp:253-280: the breadth-first expansion of a subtree, cut
+ * max_levels below its root) and ripples (ripples/main.cpp:343-377: nodes with enough descendants, a per-node
+ * distance, per-node scores) run the same search over THEIR node vector: the index j they hand to mapper2_body --
+ * which also breaks ties, usher_mapper.cpp:483-486 -- is a position in that vector.  These entry points take the
+ * vector as an order (breadth-first or the reference's depth-first expansion, mutation_annotated_tree.cpp:1253-1273)
+ * plus a mask; every node index going in or out is a position in the chosen order.  (A breadth-first expansion of a
+ * subtree lists its nodes in the same relative order as the whole tree's, so merge's sub-BFS is order BFS + mask.)
+ * They run the general one-sample-per-lane kernel (no pruning): exact for any combination of options. */
+#define UGP_ORDER_BFS 0u
+#define UGP_ORDER_DFS 1u
+typedef struct ugp_place_opts {
+    uint32_t order;              /* UGP_ORDER_BFS / UGP_ORDER_DFS: meaning of every node index of this call             */
+    const uint8_t *node_mask;    /* [n_nodes] or NULL: 0 = the node is not scored (shared by all samples of the call)   */
+    const uint32_t *skip_node;   /* [n_queries] or NULL: one node left out for that sample, UINT32_MAX = none           */
+    const uint32_t *distance;    /* [n_nodes] or NULL: mapper2_input::distance; among equal scores the smaller wins     */
+    int32_t *scores;             /* [n_queries * n_nodes] or NULL: per-node scores as compute_parsimony_scores = true
+                                    reports them (+1 when not eligible); nodes that were not scored read 0             */
+} ugp_place_opts;
+/* If no admitted node is eligible the result is {INT32_MAX, 0, UINT32_MAX, 0} (the reference's callers would be left
+ * with their initial values). */
+int ugp_place_batch_ex(ugp_mat *mat, const ugp_queries *q, const ugp_place_opts *opts, ugp_result *out /* [n_queries] */);
+int ugp_tied_nodes_ex(ugp_mat *mat, const ugp_queries *q, const ugp_place_opts *opts, uint32_t cap, uint32_t *tie_j,
+                      uint8_t *tie_has_unique, uint32_t *tie_count);
+/* bfs_of[k] = breadth-first index of the node at position k of `order` (how a caller maps its own node vector). */
+int ugp_node_order(ugp_mat *mat, uint32_t order, uint32_t *bfs_of /* [n_nodes] */);
+/* mask_out[k] = 1 for the nodes of the subtree of root_j that lie at most max_levels below it (merge.cpp:253-256). */
+int ugp_subtree_mask(ugp_mat *mat, uint32_t order, uint32_t root_j, uint32_t max_levels, uint8_t *mask_out /* [n_nodes] */);
+
 /* Device-resident variant (no PCIe in the timed path): upload once, place many
  * times.  `stream` is a hipStream_t (NULL = the default stream); d_out is a
  * device pointer to n_queries ugp_result records.  Asynchronous on `stream`. */

@@ -35,6 +35,8 @@ def lib():
         L.orc_place_sample.argtypes = [P, C.c_int64, P, P, P, P, C.c_int, P, P, P, P, P, P, C.c_int64, P]
         L.orc_place_sample_mt.restype = C.c_int
         L.orc_place_sample_mt.argtypes = [P, C.c_int64, P, P, P, P, C.c_int, P, P, P]
+        L.orc_place_sample_list.restype = C.c_int
+        L.orc_place_sample_list.argtypes = [P, C.c_int64, P, P, P, P, C.c_int64, P, P, P, C.c_int, C.c_int32, C.c_int64, P, P, P, P, P, P, C.c_int64, P]
         L.orc_cf_create.restype = P
         L.orc_cf_create.argtypes = [P]
         L.orc_cf_destroy.argtypes = [P]
@@ -100,6 +102,28 @@ class OracleTree:
             "best": int(best[0]), "num_best": int(nb[0]), "best_j": int(bj[0]), "has_unique": bool(hu[0]),
             "scores": scores, "ties": ties[:k].copy(), "ties_has_unique": thu[:k].astype(bool),
         }
+
+    def place_list(self, sample: dict, nodes, jidx=None, distance=None, compute_scores: bool = False, init_best: int = 10 ** 9,
+                   init_best_distance: int = 10 ** 9, tie_cap: int = 1 << 16):
+        """mapper2_body over a caller-supplied node vector (the matUtils / ripples call sites): `nodes` = BFS indices,
+        jidx = the index j handed to mapper2_body for each (default: the position), distance per entry."""
+        pos = np.ascontiguousarray(sample["pos"], dtype=np.int32)
+        ref = np.ascontiguousarray(sample["ref"], dtype=np.int8)
+        nuc = np.ascontiguousarray(sample["nuc"], dtype=np.int8)
+        mis = np.ascontiguousarray(sample["is_missing"], dtype=np.int8)
+        nodes = np.ascontiguousarray(nodes, dtype=np.int64)
+        jidx = None if jidx is None else np.ascontiguousarray(jidx, dtype=np.int64)
+        distance = None if distance is None else np.ascontiguousarray(distance, dtype=np.int64)
+        best = np.zeros(1, np.int32); nb = np.zeros(1, np.int64); bj = np.zeros(1, np.int64); hu = np.zeros(1, np.int8)
+        scores = np.zeros(len(nodes), np.int32) if compute_scores else None
+        ties = np.zeros(tie_cap, np.int64); thu = np.zeros(tie_cap, np.int8)
+        rc = lib().orc_place_sample_list(self.h, len(pos), _p(pos), _p(ref), _p(nuc), _p(mis), len(nodes), _p(nodes), _p(jidx), _p(distance),
+                                         int(compute_scores), int(init_best), int(init_best_distance), _p(best), _p(nb), _p(bj), _p(hu),
+                                         _p(scores), _p(ties), tie_cap, _p(thu))
+        assert rc == 0
+        k = min(int(nb[0]), tie_cap)
+        return {"best": int(best[0]), "num_best": int(nb[0]), "best_j": int(bj[0]), "has_unique": bool(hu[0]), "scores": scores,
+                "ties": ties[:k].copy(), "ties_has_unique": thu[:k].astype(bool)}
 
     def place_mt(self, sample: dict, nthreads: int):
         pos = np.ascontiguousarray(sample["pos"], dtype=np.int32)

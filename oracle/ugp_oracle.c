@@ -143,6 +143,12 @@ typedef struct {
     int8_t *node_has_unique;      /* (*input.node_has_unique)[] */
     int64_t *best_j_vec;          /* *input.best_j_vec          */
     int64_t best_j_vec_n, best_j_vec_cap;
+    /* the other callers of mapper2_body (matUtils uncertainty / annotate / merge, ripples) pass their own
+     * index j -- position in THEIR node vector, DFS or a sub-BFS -- and ripples a per-node distance
+     * (mapper2_input::j, ::distance, usher_graph.hpp:82-85).  jidx < 0: j is the BFS index itself, distance 0. */
+    int64_t jidx;                 /* input.j of the node being scored      */
+    int64_t distance;             /* input.distance                        */
+    int64_t best_distance;        /* *input.best_distance                  */
 } orc_shared;
 
 static void bjv_push(orc_shared *s, int64_t j) {
@@ -328,28 +334,32 @@ static void orc_mapper2(const orc_tree *t, int64_t j, const orc_mut *sm, int64_t
          (leaf && (num_common_mut > 0)) ||
          (!has_unique && !leaf && (node_num_mut == num_common_mut)))) {          /* :454-455 */
         if (set_difference > sh->best_set_difference) return;                   /* :457-461 */
+        const int64_t jj = sh->jidx >= 0 ? sh->jidx : j;                        /* input.j */
         int64_t num_leaves = t->num_leaves[j];                                  /* :464 */
         if (set_difference < sh->best_set_difference) {                         /* :465-475 */
             sh->best_set_difference = set_difference;
             sh->best_node_num_leaves = num_leaves;
-            sh->best_j = j;
+            sh->best_j = jj;
             sh->num_best = 1;
             sh->best_has_unique = has_unique;
-            sh->node_has_unique[j] = (int8_t)has_unique;
+            sh->best_distance = sh->distance;
+            sh->node_has_unique[jj] = (int8_t)has_unique;
             sh->best_j_vec_n = 0;
-            bjv_push(sh, j);
+            bjv_push(sh, jj);
         } else if (set_difference == sh->best_set_difference) {                 /* :476-497 */
-            /* distance == best_distance always in usher (usher_graph.hpp:97-100) */
-            if ((num_leaves > sh->best_node_num_leaves) ||
-                ((num_leaves == sh->best_node_num_leaves) && (sh->best_j < j))) {
+            if (((sh->distance == sh->best_distance) &&
+                 ((num_leaves > sh->best_node_num_leaves) ||
+                  ((num_leaves == sh->best_node_num_leaves) && (sh->best_j < jj)))) ||
+                (sh->distance < sh->best_distance)) {
                 sh->best_set_difference = set_difference;
                 sh->best_node_num_leaves = num_leaves;
-                sh->best_j = j;
+                sh->best_j = jj;
                 sh->best_has_unique = has_unique;
+                sh->best_distance = sh->distance;
             }
             sh->num_best += 1;
-            sh->node_has_unique[j] = (int8_t)has_unique;
-            bjv_push(sh, j);
+            sh->node_has_unique[jj] = (int8_t)has_unique;
+            bjv_push(sh, jj);
         }
     } else if (compute_parsimony_scores) {
         *set_difference_out = set_difference + 1;                               /* :498-503 */
@@ -390,6 +400,7 @@ int orc_place_sample(const orc_tree *t, int64_t n_ent, const int32_t *pos, const
                      int64_t *best_j_vec, int64_t cap, int8_t *tied_has_unique) {
     orc_mut *sm = make_sample(n_ent, pos, ref, nuc, is_missing);
     orc_shared sh; memset(&sh, 0, sizeof(sh));
+    sh.jidx = -1;
     sh.node_has_unique = (int8_t *)calloc((size_t)t->n, 1);                   /* :379 */
     int64_t root_muts = t->mut_off[1] - t->mut_off[0];
     sh.best_set_difference = (int)(n_ent + root_muts + 1);                    /* :374 */
@@ -434,6 +445,57 @@ int orc_place_sample(const orc_tree *t, int64_t n_ent, const int32_t *pos, const
 }
 
 /*
+ * The search as the OTHER callers of mapper2_body run it: over a caller-supplied node vector `nodes[0..n_list)`
+ * (BFS indices of this tree) whose POSITION k is the index j handed to mapper2_body -- a depth-first expansion
+ * with one node left out (matUtils uncertainty.cpp:212-235, the node itself; annotate.cpp:615-638), a
+ * breadth-first expansion of a subtree cut at max_levels (merge.cpp:253-280), all nodes with enough
+ * descendants and a per-node distance (ripples/main.cpp:343-377).  compute_scores: mapper2_body(inp, true)
+ * as ripples calls it (one pass, scores[k] filled, no second pass); otherwise pass 1 only, as uncertainty /
+ * annotate / merge call it (mapper2_body(inp, false); the early return of :383-385 only ever drops nodes that
+ * are strictly worse than the best so far, so num_best / best_j_vec are those of a full scan).
+ * init_best: the caller's initial *best_set_difference (1e9 in annotate / ripples, |S| + |root muts| + 1 in
+ * uncertainty / merge).  The initial best_j_vec = {0}, num_best = 1 of every caller is reproduced.
+ * Outputs: best, num_best, best_j (the entry's j), has_unique, the tied j ascending.  jidx[] must stay below t->n + n_list.
+ */
+int orc_place_sample_list(const orc_tree *t, int64_t n_ent, const int32_t *pos, const int8_t *ref,
+                          const int8_t *nuc, const int8_t *is_missing,
+                          int64_t n_list, const int64_t *nodes, const int64_t *jidx /* index j per entry; NULL: its position */,
+                          const int64_t *distance /* may be NULL */, int compute_scores, int32_t init_best, int64_t init_best_distance,
+                          int32_t *out_best, int64_t *out_num_best, int64_t *out_best_j, int8_t *out_has_unique,
+                          int32_t *scores /* [n_list] or NULL */, int64_t *best_j_vec, int64_t cap, int8_t *tied_has_unique) {
+    orc_mut *sm = make_sample(n_ent, pos, ref, nuc, is_missing);
+    orc_shared sh; memset(&sh, 0, sizeof(sh));
+    sh.node_has_unique = (int8_t *)calloc((size_t)t->n + (size_t)n_list + 1, 1);
+    sh.best_set_difference = init_best;
+    sh.best_j = 0; sh.num_best = 1; sh.best_has_unique = 0; sh.best_node_num_leaves = 0;
+    sh.best_distance = init_best_distance;
+    bjv_push(&sh, 0);
+    mvec anc = {0, 0, 0}, ex = {0, 0, 0}, im = {0, 0, 0};
+    for (int64_t k = 0; k < n_list; k++) {
+        int sd = 0;
+        ex.n = 0; im.n = 0;
+        sh.jidx = jidx ? jidx[k] : k;
+        sh.distance = distance ? distance[k] : 0;
+        orc_mapper2(t, nodes[k], sm, n_ent, &sh, compute_scores, 1, &sd, &ex, &im, &anc, NULL);
+        if (compute_scores && scores) scores[k] = sd;
+    }
+    *out_best = sh.best_set_difference;
+    *out_num_best = sh.num_best;
+    *out_best_j = sh.best_j;
+    *out_has_unique = (int8_t)sh.best_has_unique;
+    if (best_j_vec) {
+        qsort(sh.best_j_vec, (size_t)sh.best_j_vec_n, sizeof(int64_t), cmp_i64);
+        for (int64_t i = 0; i < sh.best_j_vec_n && i < cap; i++) {
+            best_j_vec[i] = sh.best_j_vec[i];
+            if (tied_has_unique) tied_has_unique[i] = sh.node_has_unique[sh.best_j_vec[i]];
+        }
+    }
+    free(sh.node_has_unique); free(sh.best_j_vec);
+    free(anc.v); free(ex.v); free(im.v); free(sm);
+    return 0;
+}
+
+/*
  * Excess / imputed mutation vectors for placing the sample at node j:
  * mapper2_body(inp, false, true) as run by pass 2 (usher_common.cpp:426-449)
  * with best_set_difference large enough never to return early.  Arrays are
@@ -447,6 +509,7 @@ int orc_node_vecs(const orc_tree *t, int64_t n_ent, const int32_t *pos, const in
                   int32_t *set_difference, int8_t *has_unique) {
     orc_mut *sm = make_sample(n_ent, pos, ref, nuc, is_missing);
     orc_shared sh; memset(&sh, 0, sizeof(sh));
+    sh.jidx = -1;
     sh.node_has_unique = (int8_t *)calloc((size_t)t->n, 1);
     sh.best_set_difference = 0x3fffffff;
     mvec anc = {0, 0, 0}, ex = {0, 0, 0}, im = {0, 0, 0};
@@ -584,6 +647,7 @@ int orc_place_sample_pool(orc_pool *pl, const orc_tree *t, int64_t n_ent, const 
     const int nj = pl->nthreads + 1;
     for (int i = 0; i < nj; i++) {
         memset(&pl->jobs[i], 0, sizeof(orc_job));
+        pl->jobs[i].sh.jidx = -1;
         pl->jobs[i].t = t; pl->jobs[i].sm = sm; pl->jobs[i].n_sm = n_ent;
         pl->jobs[i].sh.best_set_difference = init_best;
         pl->jobs[i].sh.node_has_unique = nhu;   /* disjoint indices per worker */

@@ -1,0 +1,111 @@
+"""The other callers of mapper2_body -- matUtils uncertainty / annotate / merge and ripples -- through the extended C ABI
+(ugp_place_batch_ex, ugp_tied_nodes_ex, ugp_node_order, ugp_subtree_mask) against the oracle's restatement of how each
+of them drives the routine (orc_place_sample_list): their own node vector and index j, a node left out, a level-capped
+subtree, a per-node distance, per-node scores."""
+import numpy as np
+import pytest
+
+from oracle import capi
+from tests import synth
+from usher_amd import Placer, QueryBatch
+
+pytestmark = pytest.mark.gpu
+
+
+def _node_sample(arrays, ref_at, j, name):
+    """The mutation set of node j as those callers build it: most recent mutation per position on root -> j
+    (uncertainty.cpp:143-166), here sorted by position (the ABI's precondition)."""
+    rows = {}
+    a = j
+    while a >= 0:
+        for i in range(int(arrays["mut_off"][a]), int(arrays["mut_off"][a + 1])):
+            p = int(arrays["mut_pos"][i])
+            if p >= 0 and p not in rows:
+                rows[p] = (int(arrays["mut_ref"][i]), int(arrays["mut_nuc"][i]))
+        a = int(arrays["parent"][a])
+    ps = sorted(rows)
+    return {"name": name, "pos": np.asarray(ps, np.int32), "ref": np.asarray([rows[p][0] for p in ps], np.int8),
+            "nuc": np.asarray([rows[p][1] for p in ps], np.int8), "is_missing": np.zeros(len(ps), np.int8)}
+
+
+def _same(res, i, w):
+    assert (int(res["best_set_difference"][i]), int(res["num_best"][i]), int(res["best_j"][i]), bool(res["best_has_unique"][i])) == \
+           (w["best"], w["num_best"], w["best_j"], w["has_unique"]), (i, res[i], w)
+
+
+@pytest.mark.parametrize("seed", [1, 2])
+def test_uncertainty_style_depth_first_indices_and_self_exclusion(seed):
+    """matUtils uncertainty (uncertainty.cpp:132-255): the sample is a tree node's own mutation set, every node but that
+    node is scored, indices are positions in the depth-first expansion; equally parsimonious placements are listed."""
+    arrays, _ = synth.make_case(300 + seed, n_leaves=500, n_queries=1, n_sites=90, p_masked=0.02 if seed == 2 else 0.0)
+    n = arrays["n"]
+    pl = Placer(arrays, chunk_nodes=40)
+    dfs = pl.node_order("dfs").astype(np.int64)              # dfs position -> BFS index
+    assert sorted(dfs.tolist()) == list(range(n)) and dfs[0] == 0
+    pos_of = np.empty(n, np.int64); pos_of[dfs] = np.arange(n)
+    rng = np.random.default_rng(seed)
+    leaves = np.setdiff1d(np.arange(n), arrays["parent"][1:])
+    picks = rng.choice(leaves, 70, replace=False)
+    samples = [_node_sample(arrays, None, int(j), "n%d" % j) for j in picks]
+    batch = QueryBatch(samples)
+    skip = pos_of[picks].astype(np.uint32)
+    res = pl.place_ex(batch, order="dfs", skip_node=skip)
+    ties, ties_hu, tc = pl.tied_nodes_ex(batch, 512, order="dfs", skip_node=skip)
+    ot = capi.OracleTree(arrays)
+    root_muts = int(arrays["mut_off"][1])
+    for i, s in enumerate(samples):
+        keep = dfs != picks[i]
+        w = ot.place_list(s, dfs[keep], jidx=np.arange(n)[keep], init_best=len(s["pos"]) + root_muts + 1)
+        _same(res, i, w)
+        assert int(tc[i]) == w["num_best"] and ties[i].tolist() == w["ties"].tolist() and ties_hu[i].tolist() == w["ties_has_unique"].tolist()
+    pl.close()
+
+
+def test_ripples_style_mask_distance_and_scores():
+    """ripples (ripples/main.cpp:333-377): nodes with fewer descendant leaves than a threshold are not scored, every
+    scored node reports its parsimony score, a per-node distance breaks ties before the leaf count."""
+    arrays, queries = synth.make_case(411, n_leaves=600, n_queries=40, n_sites=100, n_ambig=(0, 0, 2))
+    n = arrays["n"]
+    ot = capi.OracleTree(arrays)
+    leaves_below = np.array([ot.num_leaves(j) for j in range(n)])
+    mask = (leaves_below >= 3).astype(np.uint8)
+    mask[0] = 1
+    rng = np.random.default_rng(5)
+    pl = Placer(arrays, chunk_nodes=64)
+    batch = QueryBatch(queries)
+    nodes = np.flatnonzero(mask)
+    for dist in (None, rng.integers(0, 3, n).astype(np.uint32)):
+        res, scores = pl.place_ex(batch, order="bfs", node_mask=mask, distance=dist, want_scores=True)
+        for i, s in enumerate(queries):
+            w = ot.place_list(s, nodes, jidx=nodes, distance=None if dist is None else dist[nodes], compute_scores=True)
+            _same(res, i, w)
+            assert scores[i][nodes].tolist() == w["scores"].tolist()
+            assert not scores[i][mask == 0].any()
+    pl.close()
+
+
+def test_merge_style_level_capped_subtree():
+    """matUtils merge (merge.cpp:236-280): the search runs over the breadth-first expansion of the subtree of a
+    consistent node, cut max_levels below it; the whole tree's breadth-first order restricted to that subtree lists
+    the nodes in the same relative order, so positions translate by ranking."""
+    arrays, queries = synth.make_case(512, n_leaves=700, n_queries=30, n_sites=100)
+    n = arrays["n"]
+    pl = Placer(arrays, chunk_nodes=50)
+    ot = capi.OracleTree(arrays)
+    internal = np.unique(arrays["parent"][1:])
+    rng = np.random.default_rng(2)
+    for root in (0, int(rng.choice(internal[internal > 0])), int(rng.choice(internal[internal > 0]))):
+        for max_levels in (2, 5, 1000):
+            mask = pl.subtree_mask(root, max_levels)
+            nodes = np.flatnonzero(mask)
+            assert nodes[0] == root
+            res = pl.place_ex(QueryBatch(queries), order="bfs", node_mask=mask)
+            for i, s in enumerate(queries):
+                # (merge starts from |S| + |root-of-subtree mutations| + 1, merge.cpp:245, and keeps (that, 1, 0) when no admitted
+                # node is at least as good; the library reports the search itself -- a caller compares with its own bound)
+                w = ot.place_list(s, nodes, jidx=nodes)
+                if int(res["num_best"][i]) == 0:             # nothing eligible in the admitted set
+                    assert w["best"] == 10 ** 9 and int(res["best_set_difference"][i]) == 2 ** 31 - 1
+                else:
+                    _same(res, i, w)
+    pl.close()

@@ -38,6 +38,10 @@ class ugp_timing(C.Structure):
                 ("reserved", C.c_uint32), ("words_total", C.c_uint64), ("words_skipped", C.c_uint64), ("coarse_ms", C.c_float), ("reserved2", C.c_float)]
 
 
+class ugp_place_opts(C.Structure):
+    _fields_ = [("order", C.c_uint32), ("node_mask", C.c_void_p), ("skip_node", C.c_void_p), ("distance", C.c_void_p), ("scores", C.c_void_p)]
+
+
 class ugp_sites(C.Structure):
     _fields_ = [("n_sites", C.c_uint64), ("ref", C.c_void_p), ("var_off", C.c_void_p), ("var_node", C.c_void_p),
                 ("var_nuc", C.c_void_p)]
@@ -53,6 +57,10 @@ SYMBOLS = {
     "ugp_place_batch": (C.c_int, [P, C.POINTER(ugp_queries), P]),
     "ugp_scores_per_node": (C.c_int, [P, C.POINTER(ugp_queries), P]),
     "ugp_tied_nodes": (C.c_int, [P, C.POINTER(ugp_queries), C.c_uint32, P, P, P]),
+    "ugp_place_batch_ex": (C.c_int, [P, C.POINTER(ugp_queries), C.POINTER(ugp_place_opts), P]),
+    "ugp_tied_nodes_ex": (C.c_int, [P, C.POINTER(ugp_queries), C.POINTER(ugp_place_opts), C.c_uint32, P, P, P]),
+    "ugp_node_order": (C.c_int, [P, C.c_uint32, P]),
+    "ugp_subtree_mask": (C.c_int, [P, C.c_uint32, C.c_uint32, C.c_uint32, P]),
     "ugp_qset_upload": (C.c_int, [P, C.POINTER(ugp_queries), C.POINTER(P)]),
     "ugp_qset_destroy": (None, [P]),
     "ugp_qset_size": (C.c_uint64, [P]),

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <climits>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -91,6 +92,10 @@ struct ugp_mat {
     DevBuf<ugp_result> d_coarse_res;
     DevBuf<uint8_t> d_sort_tmp;
     bool last_used_best8 = false;
+    // extended searches (ugp_place_batch_ex): host copy of the topology, the reference's depth-first order and its tie rank
+    std::vector<uint32_t> h_parent, h_dfs2bfs, h_bfs2dfs;
+    DevBuf<uint32_t> d_dfs_rank, d_dfs_rank2out, d_bfs2dfs;
+    bool dfs_rank_ready = false;
     ugp_qset *own_qs = nullptr;          // reusable query set / result buffer of the host-buffer entry points
     DevBuf<ugp_result> d_own_out;
     size_t occ_lds = ~(size_t)0;   // k_best8 occupancy cache: LDS bytes it was queried for
@@ -153,11 +158,18 @@ int ensure_events(ugp_mat *m, size_t n) {
     return UGP_OK;
 }
 
+// Device-side options of an extended search (the other callers of mapper2_body); null members = not used.
+struct ExDev {
+    const uint8_t *mask = nullptr; const uint32_t *skip = nullptr, *alt_rank = nullptr, *out_index = nullptr, *rank2out = nullptr;
+    int32_t *scores = nullptr;
+};
+
 // mode 0: results to d_out (device ugp_result[n_queries]);
 // mode 1: per-node scores to d_scores (device int32 [n_queries][n_nodes]);
 // mode 2: tied nodes (needs d_best_in) -- see ugp_kernels.hip.
 int run_place(ugp_mat *m, ugp_qset *qs, int mode, ugp_result *d_out, int32_t *d_scores, const int32_t *d_best_in,
-              uint32_t *d_tie_count, uint32_t *d_tie_j, uint8_t *d_tie_hu, uint32_t tie_cap, hipStream_t s, bool coarse_only = false) {
+              uint32_t *d_tie_count, uint32_t *d_tie_j, uint8_t *d_tie_hu, uint32_t tie_cap, hipStream_t s, bool coarse_only = false,
+              const ExDev *ex = nullptr) {
     HIP_TRY(hipSetDevice(m->device));
     const auto &f = m->flat;
     const uint64_t Q = qs->n_queries;
@@ -175,7 +187,7 @@ int run_place(ugp_mat *m, ugp_qset *qs, int mode, ugp_result *d_out, int32_t *d_
     // (16-bit phase 1: every D / cost must stay below 0x7F7F, the value the shared upper bounds start from;
     // a tree with a masked mutation behind an ordinary one on the same node -- never produced by the reference's
     // sorted Node::add_mutation, mutation_annotated_tree.cpp:720-752 -- needs the order-aware 32-bit walk)
-    const bool packed_ok = (mode == 0) && !getenv("UGP_FORCE_V1") && !f.mask_not_first && (qs->max_rows + f.max_path_muts + 2 < 0x7F7Full);
+    const bool packed_ok = (mode == 0) && !ex && !getenv("UGP_FORCE_V1") && !f.mask_not_first && (qs->max_rows + f.max_path_muts + 2 < 0x7F7Full);
     const bool sorted = packed_ok && m->coarse && Q > 512 && !getenv("UGP_NO_SORT") && !getenv("UGP_NO_PRUNE");
     m->coarse_timed = false;
     if (sorted) {
@@ -280,6 +292,10 @@ int run_place(ugp_mat *m, ugp_qset *qs, int mode, ugp_result *d_out, int32_t *d_
         a.tie_j = d_tie_j ? d_tie_j + q0 * tie_cap : nullptr;
         a.tie_hu = d_tie_hu ? d_tie_hu + q0 * tie_cap : nullptr;
         a.tie_cap = tie_cap;
+        if (ex) {
+            a.node_mask = ex->mask; a.skip = ex->skip ? ex->skip + q0 : nullptr; a.alt_rank = ex->alt_rank; a.out_index = ex->out_index;
+            if (mode == 0) a.scores = ex->scores ? ex->scores + q0 * f.n_nodes : nullptr;
+        }
         if (use8) {
             ugp::Best8Args b;
             memset(&b, 0, sizeof(b));
@@ -341,10 +357,10 @@ int run_place(ugp_mat *m, ugp_qset *qs, int mode, ugp_result *d_out, int32_t *d_
                                            (uint32_t)std::min<uint64_t>(pairs, 0xFFFFFFFFull), d_cnt, d_key,
                                            m->d_rank2bfs.p, d_out + q0, order, f.max_slots, s));
         } else {
-            HIP_TRY(ugp::launch_place(a, mode, f.max_slots, s));
+            HIP_TRY(ugp::launch_place(a, ex ? mode + 4 : mode, f.max_slots, s));
             HIP_TRY(hipEventRecord(es.ev[2], s));
             if (mode == 0)
-                HIP_TRY(ugp::launch_merge(m->d_part_best.p, m->d_part_cnt.p, m->d_part_key.p, m->d_rank2bfs.p, G,
+                HIP_TRY(ugp::launch_merge(m->d_part_best.p, m->d_part_cnt.p, m->d_part_key.p, (ex && ex->rank2out) ? ex->rank2out : m->d_rank2bfs.p, G,
                                           (uint32_t)nq, d_out + q0, s));
         }
         HIP_TRY(hipEventRecord(es.ev[3], s));
@@ -369,6 +385,7 @@ const char *ugp_last_error(void) { return g_err.c_str(); }
 // once per tree whatever the number of devices it is uploaded to.
 struct HostFlat {
     ugp::FlatMat f;
+    std::vector<uint32_t> parent;   // copy of the caller's BFS parent array (extended searches need the topology)
     std::vector<uint32_t> coarse2dfs;
     HostFlat *coarse = nullptr;
     ~HostFlat() { delete coarse; }
@@ -423,6 +440,7 @@ static int host_flatten(const ugp_tree_desc *tree, const ugp::Options &opt, bool
     int rc;
     try {
         rc = ugp::flatten(*tree, opt, hf.f, err);
+        if (rc == UGP_OK && with_coarse) hf.parent.assign(tree->parent, tree->parent + tree->n_nodes);   // (the full tree only)
         if (rc == UGP_OK && with_coarse) {
             rc = build_coarse(tree, hf);
             if (rc != UGP_OK) return rc;   // (message already set)
@@ -477,6 +495,7 @@ static int upload_flat(const HostFlat &hf, int device, ugp_mat **out) {
     m->stream8_dwords = f.stream8.size();
     m->stream_dwords = f.stream.size();
     m->pre_dwords = f.pre_stream.size();
+    m->h_parent = hf.parent;
     if (hf.coarse) {
         if (int rc = upload_flat(*hf.coarse, device, &m->coarse)) { ugp_mat_destroy(m); return rc; }
         if ((e = m->d_coarse2dfs.upload(hf.coarse2dfs)) != hipSuccess) return bail(e, "upload coarse table");
@@ -700,6 +719,208 @@ int ugp_tied_nodes(ugp_mat *m, const ugp_queries *q, uint32_t cap, uint32_t *tie
         }
     }
     (void)e;
+    ugp_qset_destroy(qs);
+    return rc;
+}
+
+// ---- extended searches: the other callers of mapper2_body --------------------------------------------------
+
+// The reference's depth-first expansion (mutation_annotated_tree.cpp:1253-1273: preorder, children in stored order).
+static void ensure_dfs_order(ugp_mat *m) {
+    if (!m->h_dfs2bfs.empty()) return;
+    const uint64_t N = m->flat.n_nodes;
+    const auto &par = m->h_parent;
+    std::vector<uint32_t> first(N + 1, 0);
+    for (uint64_t j = 1; j < N; j++) first[par[j] + 1]++;
+    for (uint64_t j = 0; j < N; j++) first[j + 1] += first[j];   // BFS order: the children of j are 1 + first[j] .. 1 + first[j+1]
+    m->h_dfs2bfs.resize(N); m->h_bfs2dfs.resize(N);
+    std::vector<std::pair<uint32_t, uint32_t>> st;   // (node, next child offset)
+    st.push_back({0u, 0u});
+    uint64_t d = 0;
+    m->h_dfs2bfs[d] = 0; m->h_bfs2dfs[0] = 0; d++;
+    while (!st.empty()) {
+        auto &fr = st.back();
+        const uint32_t b = 1 + first[fr.first], e = 1 + first[fr.first + 1];
+        if (b + fr.second < e) {
+            const uint32_t c = b + fr.second++;
+            m->h_dfs2bfs[d] = c; m->h_bfs2dfs[c] = (uint32_t)d; d++;
+            st.push_back({c, 0u});
+        } else st.pop_back();
+    }
+}
+
+int ugp_node_order(ugp_mat *m, uint32_t order, uint32_t *bfs_of) {
+    if (!m || !bfs_of) return fail(UGP_ERR_INVALID, "null argument");
+    const uint64_t N = m->flat.n_nodes;
+    if (order == UGP_ORDER_BFS) { for (uint64_t j = 0; j < N; j++) bfs_of[j] = (uint32_t)j; return UGP_OK; }
+    if (order != UGP_ORDER_DFS) return fail(UGP_ERR_INVALID, "unknown node order");
+    try { ensure_dfs_order(m); } catch (const std::bad_alloc &) { return fail(UGP_ERR_NOMEM, "out of host memory"); }
+    memcpy(bfs_of, m->h_dfs2bfs.data(), N * sizeof(uint32_t));
+    return UGP_OK;
+}
+
+int ugp_subtree_mask(ugp_mat *m, uint32_t order, uint32_t root_j, uint32_t max_levels, uint8_t *mask_out) {
+    if (!m || !mask_out) return fail(UGP_ERR_INVALID, "null argument");
+    const uint64_t N = m->flat.n_nodes;
+    if (root_j >= N || order > UGP_ORDER_DFS) return fail(UGP_ERR_INVALID, "node index / order out of range");
+    try {
+        if (order == UGP_ORDER_DFS) ensure_dfs_order(m);
+        const uint32_t root = order == UGP_ORDER_DFS ? m->h_dfs2bfs[root_j] : root_j;
+        // depth below `root` in BFS order (parents first); UINT32_MAX = outside the subtree
+        std::vector<uint32_t> depth(N, UINT32_MAX);
+        depth[root] = 0;
+        for (uint64_t j = (uint64_t)root + 1; j < N; j++) {
+            const uint32_t dp = depth[m->h_parent[j]];
+            if (dp != UINT32_MAX) depth[j] = dp + 1;
+        }
+        for (uint64_t j = 0; j < N; j++) {
+            const uint64_t o = order == UGP_ORDER_DFS ? m->h_bfs2dfs[j] : j;
+            mask_out[o] = depth[j] != UINT32_MAX && depth[j] <= max_levels;   // merge.cpp:254: level - level(root) > max_levels is skipped
+        }
+    } catch (const std::bad_alloc &) { return fail(UGP_ERR_NOMEM, "out of host memory"); }
+    return UGP_OK;
+}
+
+namespace {
+// Everything an extended call needs on the device, converted from the caller's node order to BFS indexing.
+struct ExHost {
+    DevBuf<uint8_t> d_mask;
+    DevBuf<uint32_t> d_skip, d_rank, d_rank2out, d_out_index;
+    DevBuf<int32_t> d_scores;
+    ExDev dev;
+};
+
+int prepare_ex(ugp_mat *m, const ugp_queries *q, const ugp_place_opts *o, ExHost &x, bool want_scores) {
+    const uint64_t N = m->flat.n_nodes, Q = q->n_queries;
+    if (o->order > UGP_ORDER_DFS) return fail(UGP_ERR_INVALID, "unknown node order");
+    if (m->h_parent.size() != N) return fail(UGP_ERR_INVALID, "this handle has no host topology (created from a coarse tree?)");
+    const bool dfs = o->order == UGP_ORDER_DFS;
+    HIP_TRY(hipSetDevice(m->device));
+    try {
+        if (dfs) ensure_dfs_order(m);
+        auto to_bfs = [&](uint64_t k) -> uint32_t { return dfs ? m->h_dfs2bfs[k] : (uint32_t)k; };
+        if (o->node_mask) {
+            std::vector<uint8_t> mk(N);
+            for (uint64_t k = 0; k < N; k++) mk[to_bfs(k)] = o->node_mask[k] ? 1 : 0;
+            HIP_TRY(x.d_mask.upload(mk));
+            x.dev.mask = x.d_mask.p;
+        }
+        if (o->skip_node) {
+            std::vector<uint32_t> sk(Q);
+            for (uint64_t i = 0; i < Q; i++) {
+                if (o->skip_node[i] != UINT32_MAX && o->skip_node[i] >= N) return fail(UGP_ERR_INVALID, "skip_node out of range");
+                sk[i] = o->skip_node[i] == UINT32_MAX ? UINT32_MAX : to_bfs(o->skip_node[i]);
+            }
+            HIP_TRY(x.d_skip.upload(sk));
+            x.dev.skip = x.d_skip.p;
+        }
+        if (dfs || o->distance) {
+            // tie rank of usher_mapper.cpp:483-486 in the caller's terms: smaller distance, then more descendant leaves,
+            // then the larger index j of the caller's node vector; rank = position in ascending order of "how good"
+            const bool cached = dfs && !o->distance && m->dfs_rank_ready;
+            if (!cached) {
+                std::vector<uint32_t> leaves(N, 0), nch(N, 0);
+                for (uint64_t j = 1; j < N; j++) nch[m->h_parent[j]]++;
+                for (uint64_t j = N; j-- > 0;) { if (!nch[j]) leaves[j] = 1; if (j) leaves[m->h_parent[j]] += leaves[j]; }
+                std::vector<uint32_t> idx(N);   // caller indices, to be sorted worst -> best
+                for (uint64_t k = 0; k < N; k++) idx[k] = (uint32_t)k;
+                const uint32_t *dist = o->distance;
+                std::sort(idx.begin(), idx.end(), [&](uint32_t a, uint32_t b) {
+                    if (dist && dist[a] != dist[b]) return dist[a] > dist[b];
+                    const uint32_t la = leaves[to_bfs(a)], lb = leaves[to_bfs(b)];
+                    if (la != lb) return la < lb;
+                    return a < b;
+                });
+                std::vector<uint32_t> rank(N);
+                for (uint64_t r = 0; r < N; r++) rank[to_bfs(idx[r])] = (uint32_t)r;
+                DevBuf<uint32_t> &dr = (dfs && !dist) ? m->d_dfs_rank : x.d_rank, &d2o = (dfs && !dist) ? m->d_dfs_rank2out : x.d_rank2out;
+                HIP_TRY(dr.upload(rank));
+                HIP_TRY(d2o.upload(idx));   // rank -> caller index
+                if (dfs && !dist) m->dfs_rank_ready = true;
+            }
+            const bool use_cache = dfs && !o->distance;
+            x.dev.alt_rank = use_cache ? m->d_dfs_rank.p : x.d_rank.p;
+            x.dev.rank2out = use_cache ? m->d_dfs_rank2out.p : x.d_rank2out.p;
+        }
+        if (dfs) {
+            if (!m->d_bfs2dfs.p) HIP_TRY(m->d_bfs2dfs.upload(m->h_bfs2dfs));
+            x.dev.out_index = m->d_bfs2dfs.p;
+        }
+    } catch (const std::bad_alloc &) { return fail(UGP_ERR_NOMEM, "out of host memory"); }
+    if (want_scores && o->scores && Q) {
+        HIP_TRY(x.d_scores.reserve((size_t)Q * N));
+        HIP_TRY(hipMemset(x.d_scores.p, 0, (size_t)Q * N * sizeof(int32_t)));
+        x.dev.scores = x.d_scores.p;
+    }
+    return UGP_OK;
+}
+}  // namespace
+
+int ugp_place_batch_ex(ugp_mat *m, const ugp_queries *q, const ugp_place_opts *opts, ugp_result *out) {
+    if (!m || !q || !opts || (!out && q->n_queries)) return fail(UGP_ERR_INVALID, "null argument");
+    if (q->n_queries == 0) return UGP_OK;
+    ugp_qset *qs = nullptr;
+    if (int rc = ugp_qset_upload(m, q, &qs)) return rc;
+    ExHost x;
+    DevBuf<ugp_result> d_out;
+    int rc = prepare_ex(m, q, opts, x, true);
+    if (rc == UGP_OK && d_out.reserve(q->n_queries) != hipSuccess) rc = fail(UGP_ERR_HIP, "hipMalloc results");
+    if (rc == UGP_OK) rc = run_place(m, qs, 0, d_out.p, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, false, &x.dev);
+    if (rc == UGP_OK && hipMemcpy(out, d_out.p, q->n_queries * sizeof(ugp_result), hipMemcpyDeviceToHost) != hipSuccess)
+        rc = fail(UGP_ERR_HIP, "copy results");
+    if (rc == UGP_OK && opts->scores &&
+        hipMemcpy(opts->scores, x.d_scores.p, (size_t)q->n_queries * m->flat.n_nodes * sizeof(int32_t), hipMemcpyDeviceToHost) != hipSuccess)
+        rc = fail(UGP_ERR_HIP, "copy scores");
+    if (rc == UGP_OK) {   // no candidate was eligible: the reference's callers would be left with their initial values
+        for (uint64_t i = 0; i < q->n_queries; i++)
+            if (out[i].num_best == 0) { out[i].best_set_difference = INT32_MAX; out[i].best_j = UINT32_MAX; out[i].best_has_unique = 0; }
+    }
+    ugp_qset_destroy(qs);
+    return rc;
+}
+
+int ugp_tied_nodes_ex(ugp_mat *m, const ugp_queries *q, const ugp_place_opts *opts, uint32_t cap, uint32_t *tie_j, uint8_t *tie_has_unique,
+                      uint32_t *tie_count) {
+    if (!m || !q || !opts || !tie_count || (cap && (!tie_j || !tie_has_unique))) return fail(UGP_ERR_INVALID, "null argument");
+    const uint64_t Q = q->n_queries;
+    if (Q == 0) return UGP_OK;
+    ugp_qset *qs = nullptr;
+    if (int rc = ugp_qset_upload(m, q, &qs)) return rc;
+    ExHost x;
+    DevBuf<ugp_result> d_res;
+    DevBuf<int32_t> d_best;
+    DevBuf<uint32_t> d_cnt, d_j;
+    DevBuf<uint8_t> d_hu;
+    const uint64_t padded = ((Q + 63) / 64) * 64;
+    int rc = prepare_ex(m, q, opts, x, false);
+    auto chk = [&](hipError_t e, const char *what) {
+        if (rc == UGP_OK && e != hipSuccess) rc = fail(UGP_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e));
+    };
+    chk(d_res.reserve(Q), "hipMalloc"); chk(d_best.reserve(Q), "hipMalloc"); chk(d_cnt.reserve(padded), "hipMalloc");
+    chk(d_j.reserve((size_t)Q * std::max<uint32_t>(cap, 1)), "hipMalloc"); chk(d_hu.reserve((size_t)Q * std::max<uint32_t>(cap, 1)), "hipMalloc");
+    if (rc == UGP_OK) rc = run_place(m, qs, 0, d_res.p, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, false, &x.dev);
+    if (rc == UGP_OK) {
+        chk(ugp::launch_extract_best(d_res.p, (uint32_t)Q, d_best.p, nullptr), "extract best");
+        chk(hipMemsetAsync(d_cnt.p, 0, padded * sizeof(uint32_t), nullptr), "memset");
+    }
+    if (rc == UGP_OK) rc = run_place(m, qs, 2, nullptr, nullptr, d_best.p, d_cnt.p, d_j.p, d_hu.p, cap, nullptr, false, &x.dev);
+    if (rc == UGP_OK) {
+        chk(hipMemcpy(tie_count, d_cnt.p, Q * sizeof(uint32_t), hipMemcpyDeviceToHost), "copy tie counts");
+        if (cap) {
+            chk(hipMemcpy(tie_j, d_j.p, (size_t)Q * cap * sizeof(uint32_t), hipMemcpyDeviceToHost), "copy ties");
+            chk(hipMemcpy(tie_has_unique, d_hu.p, (size_t)Q * cap, hipMemcpyDeviceToHost), "copy ties");
+        }
+    }
+    if (rc == UGP_OK && cap) {   // ascending index of the caller's node vector
+        std::vector<std::pair<uint32_t, uint8_t>> tmp;
+        for (uint64_t i = 0; i < Q; i++) {
+            const uint32_t k = std::min<uint32_t>(tie_count[i], cap);
+            tmp.resize(k);
+            for (uint32_t t = 0; t < k; t++) tmp[t] = {tie_j[i * cap + t], tie_has_unique[i * cap + t]};
+            std::sort(tmp.begin(), tmp.end());
+            for (uint32_t t = 0; t < k; t++) { tie_j[i * cap + t] = tmp[t].first; tie_has_unique[i * cap + t] = tmp[t].second; }
+        }
+    }
     ugp_qset_destroy(qs);
     return rc;
 }

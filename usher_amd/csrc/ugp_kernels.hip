@@ -251,7 +251,9 @@ __device__ __forceinline__ WalkOut walk_ties(const PlaceArgs &a, uint32_t *slots
 
 // MODE 0: full reduction (min, count, key)   MODE 1: per-node scores
 // MODE 2: append tied nodes to lists         MODE 3: count / key of nodes with cost == want
-template <int MODE>
+// EX: the extended search of the other mapper2_body callers -- a node counts only if the shared mask admits it and it
+// is not the sample's excluded node; ties are ranked by a.alt_rank; indices are reported through a.out_index.
+template <int MODE, bool EX>
 __device__ __forceinline__ WalkOut walk(const PlaceArgs &a, uint32_t *slots, uint32_t tile, uint32_t c0, uint32_t c1,
                                         uint32_t lane, uint32_t want_best) {
     const uint32_t *tab = a.table + ((uint64_t)(tile >> 3) * (a.n_sites + TABLE_CONST_ROWS) + TABLE_CONST_ROWS) * 64 + (tile & 7u) * 8 + (lane >> 3);
@@ -261,6 +263,7 @@ __device__ __forceinline__ WalkOut walk(const PlaceArgs &a, uint32_t *slots, uin
     WalkOut o; o.best = 0x7fffffffu; o.cnt = 0; o.key = 0;
     uint32_t dcur = 0;
     uint32_t node_idx = a.chunk_node_off[c0];   // DFS index of the next body record
+    const uint32_t skip_bfs = (EX && a.skip && q < a.n_queries) ? a.skip[q] : 0xFFFFFFFFu;
     for (int phase = 0; phase < 2; phase++) {
         Reader rd;
         if (phase == 0) rd.init(a.pre_stream, a.chunk_pre_off[c0], a.chunk_pre_off[c0 + 1], lane);
@@ -305,21 +308,28 @@ __device__ __forceinline__ WalkOut walk(const PlaceArgs &a, uint32_t *slots, uin
                     elig = (common > 0) || free_internal;
                     hu = (masked || common != n_before) ? 1u : 0u;
                 }
+                uint32_t bfs = 0, rkey = key;
+                bool cand = true;
+                if (EX || MODE == 1 || MODE == 2) bfs = a.dfs2bfs[node_idx];
+                if (EX) {
+                    cand = (!a.node_mask || a.node_mask[bfs]) && bfs != skip_bfs;
+                    if (a.alt_rank) rkey = a.alt_rank[bfs] << 1;
+                }
+                const uint32_t oidx = (EX && a.out_index) ? a.out_index[bfs] : bfs;
                 if (MODE == 0) {
-                    const uint32_t k = key | hu;
-                    if (elig) {
+                    const uint32_t k = rkey | hu;
+                    if (elig && cand) {
                         if (cost < o.best) { o.best = cost; o.cnt = 1; o.key = k; }
                         else if (cost == o.best) { o.cnt++; o.key = max(o.key, k); }
                     }
+                    if (EX && a.scores && cand && q < a.n_queries) a.scores[(uint64_t)q * a.n_nodes + oidx] = (int32_t)(cost + (elig ? 0u : 1u));
                 } else if (MODE == 1) {
-                    const uint32_t bfs = a.dfs2bfs[node_idx];
                     if (q < a.n_queries) a.scores[(uint64_t)q * a.n_nodes + bfs] = (int32_t)(cost + (elig ? 0u : 1u));
                 } else if (MODE == 2) {
-                    const uint32_t bfs = a.dfs2bfs[node_idx];
-                    if (elig && cost == want_best) {
+                    if (elig && cand && cost == want_best) {
                         const uint32_t i = atomicAdd(&a.tie_count[q], 1u);
                         if (i < a.tie_cap) {
-                            a.tie_j[(uint64_t)q * a.tie_cap + i] = bfs;
+                            a.tie_j[(uint64_t)q * a.tie_cap + i] = oidx;
                             a.tie_hu[(uint64_t)q * a.tie_cap + i] = (uint8_t)hu;
                         }
                     }
@@ -333,7 +343,7 @@ __device__ __forceinline__ WalkOut walk(const PlaceArgs &a, uint32_t *slots, uin
     return o;
 }
 
-template <int MODE>   // 0, 1, 2 (see walk)
+template <int MODE, bool EX>   // MODE 0, 1, 2 (see walk)
 __global__ void __launch_bounds__(64) k_place(PlaceArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint32_t slots[];   // [max_slots][64]
     const uint32_t lane = threadIdx.x;
@@ -359,7 +369,7 @@ __global__ void __launch_bounds__(64) k_place(PlaceArgs a) {
     const uint32_t q = tile * 64 + lane;
     uint32_t want_best = 0;
     if (MODE == 2) want_best = (q < a.n_queries) ? (uint32_t)a.best_in[q] : 0xffffffffu;
-    WalkOut r = walk<MODE>(a, slots, tile, c0, c1, lane, want_best);
+    WalkOut r = walk<MODE, EX>(a, slots, tile, c0, c1, lane, want_best);
     if (MODE == 0) { a.part_best[o] = r.best; a.part_cnt[o] = r.cnt; a.part_key[o] = r.key; }
 }
 
@@ -1260,9 +1270,11 @@ hipError_t launch_scatter(uint32_t *table, uint32_t *dbottom, const int32_t *pos
 hipError_t launch_place(const PlaceArgs &a, int mode, uint32_t max_slots, hipStream_t s) {
     const uint32_t blocks = a.n_tiles * a.n_groups;
     const size_t lds = (size_t)max_slots * 64 * sizeof(uint32_t);
-    if (mode == 0) hipLaunchKernelGGL(k_place<0>, dim3(blocks), dim3(64), lds, s, a);
-    else if (mode == 1) hipLaunchKernelGGL(k_place<1>, dim3(blocks), dim3(64), lds, s, a);
-    else hipLaunchKernelGGL(k_place<2>, dim3(blocks), dim3(64), lds, s, a);
+    if (mode == 0) hipLaunchKernelGGL((k_place<0, false>), dim3(blocks), dim3(64), lds, s, a);
+    else if (mode == 1) hipLaunchKernelGGL((k_place<1, false>), dim3(blocks), dim3(64), lds, s, a);
+    else if (mode == 2) hipLaunchKernelGGL((k_place<2, false>), dim3(blocks), dim3(64), lds, s, a);
+    else if (mode == 4) hipLaunchKernelGGL((k_place<0, true>), dim3(blocks), dim3(64), lds, s, a);
+    else hipLaunchKernelGGL((k_place<2, true>), dim3(blocks), dim3(64), lds, s, a);
     return hipGetLastError();
 }
 

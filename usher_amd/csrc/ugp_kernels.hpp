@@ -28,6 +28,11 @@ struct PlaceArgs {
     uint32_t *tie_j;           // [n_queries][tie_cap]
     uint8_t *tie_hu;
     uint32_t tie_cap;
+    // extended search (ugp_place_batch_ex / ugp_tied_nodes_ex: the other callers of mapper2_body), all optional
+    const uint8_t *node_mask;    // [n_nodes] by BFS index: 0 = not a candidate
+    const uint32_t *skip;        // [n_queries] BFS index of one node excluded for that sample (UINT32_MAX = none)
+    const uint32_t *alt_rank;    // [n_nodes] by BFS index: tie rank replacing the stream's (n_leaves, bfs_j) rank
+    const uint32_t *out_index;   // [n_nodes] BFS index -> index reported to the caller (its node order)
 };
 
 struct Best8Args {
@@ -86,7 +91,7 @@ hipError_t launch_locality_sort(const ugp_result *coarse_res, const uint32_t *co
                                 uint32_t *keys_sorted, uint32_t *idx, uint32_t *order, uint32_t *slot_of, void *temp,
                                 size_t *temp_bytes, hipStream_t s);
 hipError_t launch_extract_best(const ugp_result *res, uint32_t n, int32_t *best, hipStream_t s);
-hipError_t launch_place(const PlaceArgs &a, int mode, uint32_t max_slots, hipStream_t s);
+hipError_t launch_place(const PlaceArgs &a, int mode, uint32_t max_slots, hipStream_t s);   // mode 0/1/2, +4: extended (a.node_mask etc.)
 hipError_t launch_merge(const uint32_t *part_best, const uint32_t *part_cnt, const uint32_t *part_key,
                         const uint32_t *rank2bfs, uint32_t n_groups, uint32_t n_queries, ugp_result *out,
                         hipStream_t s);

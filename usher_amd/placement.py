@@ -182,6 +182,44 @@ class Placer:
         return [tj[i, :min(int(tc[i]), cap)].copy() for i in range(len(batch))], \
                [th[i, :min(int(tc[i]), cap)].astype(bool) for i in range(len(batch))], tc
 
+    # ---- the other callers of mapper2_body (matUtils uncertainty / annotate / merge, ripples) -------------
+    def _opts(self, batch, order, node_mask, skip_node, distance, scores):
+        keep = [None if a is None else np.ascontiguousarray(a, dtype=dt) for a, dt in
+                ((node_mask, np.uint8), (skip_node, np.uint32), (distance, np.uint32))]
+        if keep[0] is not None and len(keep[0]) != self.n_nodes or keep[2] is not None and len(keep[2]) != self.n_nodes:
+            raise ValueError("node_mask / distance need one entry per node")
+        if keep[1] is not None and len(keep[1]) != len(batch):
+            raise ValueError("skip_node needs one entry per sample")
+        o = _lib.ugp_place_opts({"bfs": 0, "dfs": 1}[order], _ptr(keep[0]), _ptr(keep[1]), _ptr(keep[2]), _ptr(scores))
+        return o, keep
+
+    def place_ex(self, batch: QueryBatch, order: str = "bfs", node_mask=None, skip_node=None, distance=None, want_scores: bool = False):
+        """ugp_place_batch_ex: every node index (mask, skip_node, best_j, score columns) is a position in `order`."""
+        out = np.zeros(len(batch), dtype=RESULT_DTYPE)
+        scores = np.zeros((len(batch), self.n_nodes), dtype=np.int32) if want_scores else None
+        o, keep = self._opts(batch, order, node_mask, skip_node, distance, scores)
+        _check(_lib.lib().ugp_place_batch_ex(self._h, C.byref(batch.desc), C.byref(o), _ptr(out)))
+        return (out, scores) if want_scores else out
+
+    def tied_nodes_ex(self, batch: QueryBatch, cap: int, order: str = "bfs", node_mask=None, skip_node=None, distance=None):
+        tj = np.zeros((len(batch), max(cap, 1)), dtype=np.uint32)
+        th = np.zeros((len(batch), max(cap, 1)), dtype=np.uint8)
+        tc = np.zeros(len(batch), dtype=np.uint32)
+        o, keep = self._opts(batch, order, node_mask, skip_node, distance, None)
+        _check(_lib.lib().ugp_tied_nodes_ex(self._h, C.byref(batch.desc), C.byref(o), cap, _ptr(tj), _ptr(th), _ptr(tc)))
+        return [tj[i, :min(int(tc[i]), cap)].copy() for i in range(len(batch))], \
+               [th[i, :min(int(tc[i]), cap)].astype(bool) for i in range(len(batch))], tc
+
+    def node_order(self, order: str) -> np.ndarray:
+        out = np.zeros(self.n_nodes, dtype=np.uint32)
+        _check(_lib.lib().ugp_node_order(self._h, {"bfs": 0, "dfs": 1}[order], _ptr(out)))
+        return out
+
+    def subtree_mask(self, root_j: int, max_levels: int, order: str = "bfs") -> np.ndarray:
+        out = np.zeros(self.n_nodes, dtype=np.uint8)
+        _check(_lib.lib().ugp_subtree_mask(self._h, {"bfs": 0, "dfs": 1}[order], int(root_j), int(max_levels), _ptr(out)))
+        return out
+
     # ---- device-resident path (bench / multi-GPU) ---------------------------
     def upload(self, batch: QueryBatch):
         h = C.c_void_p()
