@@ -37,6 +37,8 @@ def lib():
         L.orc_place_sample_mt.argtypes = [P, C.c_int64, P, P, P, P, C.c_int, P, P, P]
         L.orc_place_sample_list.restype = C.c_int
         L.orc_place_sample_list.argtypes = [P, C.c_int64, P, P, P, P, C.c_int64, P, P, P, C.c_int, C.c_int32, C.c_int64, P, P, P, P, P, P, C.c_int64, P]
+        L.orc_node_has_unique_prefix.restype = C.c_int
+        L.orc_node_has_unique_prefix.argtypes = [P, C.c_int64, P, P, P, P, C.c_int64, P]
         L.orc_cf_create.restype = P
         L.orc_cf_create.argtypes = [P]
         L.orc_cf_destroy.argtypes = [P]
@@ -124,6 +126,15 @@ class OracleTree:
         k = min(int(nb[0]), tie_cap)
         return {"best": int(best[0]), "num_best": int(nb[0]), "best_j": int(bj[0]), "has_unique": bool(hu[0]), "scores": scores,
                 "ties": ties[:k].copy(), "ties_has_unique": thu[:k].astype(bool)}
+
+    def node_has_unique_prefix(self, sample: dict, k: int) -> np.ndarray:
+        pos = np.ascontiguousarray(sample["pos"], dtype=np.int32)
+        ref = np.ascontiguousarray(sample["ref"], dtype=np.int8)
+        nuc = np.ascontiguousarray(sample["nuc"], dtype=np.int8)
+        mis = np.ascontiguousarray(sample["is_missing"], dtype=np.int8)
+        out = np.zeros(max(k, 1), np.int8)
+        assert lib().orc_node_has_unique_prefix(self.h, len(pos), _p(pos), _p(ref), _p(nuc), _p(mis), k, _p(out)) == 0
+        return out[:k].astype(bool)
 
     def place_mt(self, sample: dict, nthreads: int):
         pos = np.ascontiguousarray(sample["pos"], dtype=np.int32)

@@ -445,6 +445,33 @@ int orc_place_sample(const orc_tree *t, int64_t n_ent, const int32_t *pos, const
 }
 
 /*
+ * (*input.node_has_unique)[0 .. k) after the two passes of usher_common.cpp:389-449 run in breadth-first order on one
+ * thread: what --multiple-placements reads when it indexes the per-node flags with its loop counter (:647).  An entry
+ * is the node's has_unique if the node matched or beat the running optimum when it was visited, or is optimal; else 0.
+ */
+int orc_node_has_unique_prefix(const orc_tree *t, int64_t n_ent, const int32_t *pos, const int8_t *ref,
+                               const int8_t *nuc, const int8_t *is_missing, int64_t k, int8_t *out) {
+    orc_mut *sm = make_sample(n_ent, pos, ref, nuc, is_missing);
+    orc_shared sh; memset(&sh, 0, sizeof(sh));
+    sh.jidx = -1;
+    sh.node_has_unique = (int8_t *)calloc((size_t)t->n, 1);
+    sh.best_set_difference = (int)(n_ent + (t->mut_off[1] - t->mut_off[0]) + 1);
+    sh.best_j = 0; sh.num_best = 1;
+    bjv_push(&sh, 0);
+    mvec anc = {0, 0, 0}, ex = {0, 0, 0}, im = {0, 0, 0};
+    for (int64_t j = 0; j < t->n; j++) orc_mapper2(t, j, sm, n_ent, &sh, 0, 0, NULL, &ex, &im, &anc, NULL);
+    sh.best_set_difference += 1;
+    int64_t ntmp = sh.best_j_vec_n;
+    int64_t *tmp = (int64_t *)malloc(sizeof(int64_t) * (ntmp > 0 ? ntmp : 1));
+    memcpy(tmp, sh.best_j_vec, sizeof(int64_t) * ntmp);
+    sh.num_best = 0; sh.best_j_vec_n = 0;
+    for (int64_t l = 0; l < ntmp; l++) { ex.n = 0; im.n = 0; orc_mapper2(t, tmp[l], sm, n_ent, &sh, 0, 1, NULL, &ex, &im, &anc, NULL); }
+    for (int64_t j = 0; j < k && j < t->n; j++) out[j] = sh.node_has_unique[j];
+    free(tmp); free(sh.node_has_unique); free(sh.best_j_vec); free(anc.v); free(ex.v); free(im.v); free(sm);
+    return 0;
+}
+
+/*
  * The search as the OTHER callers of mapper2_body run it: over a caller-supplied node vector `nodes[0..n_list)`
  * (BFS indices of this tree) whose POSITION k is the index j handed to mapper2_body -- a depth-first expansion
  * with one node left out (matUtils uncertainty.cpp:212-235, the node itself; annotate.cpp:615-638), a

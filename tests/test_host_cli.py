@@ -242,3 +242,110 @@ def test_batched_add_mode_equals_per_sample_research(tmp_path, monkeypatch, seed
         calls[mode] = be.calls
     assert outs["batched"] == outs["research"]
     assert calls["batched"] < calls["research"]
+
+
+@pytest.mark.parametrize("seed,max_trees", [(5, 4), (6, 2), (7, 6)])
+def test_multiple_placements_equal_the_restated_driver_loop(seed, max_trees, tmp_path):
+    """--multiple-placements (usher_common.cpp:584-649): trees are copied through the newick round trip, later trees are
+    searched again for every sample, tied nodes are taken in breadth-first order, the flag that decides sibling vs
+    child placement is read from the per-node vector with the loop counter (:647).  No recorded reference output
+    exists for this mode; the C++ front end (oracle backend) is compared with tests/usher_model.py, a python
+    restatement of that loop on the oracle's own tree model."""
+    import numpy as np
+    from tests import host_harness, usher_model
+    rng = np.random.default_rng(seed)
+    nh, old, new = str(tmp_path / "t.nh"), str(tmp_path / "old.vcf"), str(tmp_path / "new.vcf")
+    _evolve_vcf(rng, 60, 40, 14, nh, old, new)
+    pb = str(tmp_path / "base.pb")
+    assert host_harness.run_usher(["-t", nh, "-v", old, "-o", pb, "-d", str(tmp_path)]) == 0
+    d = tmp_path / "multi"
+    d.mkdir()
+    assert host_harness.run_usher(["-i", pb, "-v", new, "-M", str(max_trees), "-d", str(d)]) == 0
+    T = refio.load_mutation_annotated_tree(pb)
+    want = usher_model.run(T, refio.read_vcf(T, new), max_trees=max_trees)
+    got = {n: open(str(d / n)).read() for n in sorted(os.listdir(str(d)))}
+    assert sorted(got) == sorted(want)
+    for name in want:
+        assert got[name] == want[name], name
+    assert len([n for n in want if n.startswith("final-tree")]) > 1          # several trees were really produced
+
+
+@pytest.mark.parametrize("seed", [11, 12, 13])
+def test_collapse_input_and_output_trees(seed, tmp_path):
+    """--collapse-tree (usher_common.cpp:120-148: collapse_tree + condense_leaves before placing, condensed-tree.nh) and
+    --collapse-output-tree (:808-822) against the python restatement of move_node / remove_node / collapse_tree."""
+    import numpy as np
+    from tests import host_harness, usher_model
+    rng = np.random.default_rng(seed)
+    nh, old, new = str(tmp_path / "t.nh"), str(tmp_path / "old.vcf"), str(tmp_path / "new.vcf")
+    _evolve_vcf(rng, 150, 30, 25, nh, old, new)      # few sites: many mutation-free branches and identical leaves
+    pb = str(tmp_path / "base.pb")
+    assert host_harness.run_usher(["-t", nh, "-v", old, "-o", pb, "-d", str(tmp_path)]) == 0
+    for flags in (["-c"], ["-C"], ["-c", "-C"]):
+        d = tmp_path / ("o" + "".join(f.strip("-") for f in flags))
+        d.mkdir()
+        assert host_harness.run_usher(["-i", pb, "-v", new, "-d", str(d)] + flags) == 0
+        T = refio.load_mutation_annotated_tree(pb)
+        missing = refio.read_vcf(T, new)
+        want = {}
+        if "-c" in flags:
+            usher_model.collapse_tree(T)
+            usher_model.condense_leaves(T)
+            want["condensed-tree.nh"] = refio.get_newick_string(T, T.root, True, True) + "\n"
+        out = usher_model.run(T, missing)
+        if "-C" in flags:
+            usher_model.collapse_tree(T)
+            out["final-tree.nh"] = refio.get_newick_string(T, T.root, True, True)
+            out["mutation-paths.txt"] = usher_model._paths(T, [m.name for m in missing])
+        want.update(out)
+        got = {n: open(str(d / n)).read() for n in sorted(os.listdir(str(d)))}
+        assert sorted(got) == sorted(want), flags
+        for name in want:
+            assert got[name] == want[name], (flags, name)
+
+
+def _newick_leaves(text):
+    import re
+    return [t for t in re.split(r"[(),;]", re.sub(r":[-+0-9.eE]+", "", text)) if t and not re.fullmatch(r"node_\d+", t)]
+
+
+def test_subtrees_around_new_samples(tmp_path):
+    """--write-single-subtree / --write-subtrees-size (usher_common.cpp:973-1012): the leaf choice draws from the C
+    library's rand() exactly as the reference does; get_subtree, rotate_for_display and the three files per subtree
+    are checked against the python restatement.  (-k sorts candidate leaves by distance with std::sort, whose order
+    among equal distances is unspecified, so for -k the chosen leaf sets are taken from the files and everything
+    derived from them is recomputed; sizes and the coverage of the new samples are checked directly.)"""
+    import numpy as np
+    from tests import host_harness, usher_model
+    rng = np.random.default_rng(21)
+    nh, old, new = str(tmp_path / "t.nh"), str(tmp_path / "old.vcf"), str(tmp_path / "new.vcf")
+    _evolve_vcf(rng, 120, 60, 9, nh, old, new)
+    pb = str(tmp_path / "base.pb")
+    assert host_harness.run_usher(["-t", nh, "-v", old, "-o", pb, "-d", str(tmp_path)]) == 0
+    d = tmp_path / "sub"
+    d.mkdir()
+    libc = usher_model._LibcRand()
+    libc.srand(1)            # the state a fresh process starts with (the front end runs inside this process here)
+    assert host_harness.run_usher(["-i", pb, "-v", new, "-d", str(d), "-K", "7", "-k", "4"]) == 0
+    T = refio.load_mutation_annotated_tree(pb)
+    missing = refio.read_vcf(T, new)
+    usher_model.run(T, missing)
+    names = [m.name for m in missing]
+    usher_model.uncondense_leaves(T)
+    got = {n: open(str(d / n)).read() for n in sorted(os.listdir(str(d)))}
+    libc.srand(1)
+    want = usher_model.single_subtree(T, names, 7, libc)
+    for name in want:
+        assert got[name] == want[name], name
+    # -k 4: every placed sample appears in one of the subtree files the loop produced, each with at most 4 leaves
+    subs = sorted(n for n in got if n.startswith("subtree-") and n.endswith(".nh"))
+    assert subs
+    shown = set()
+    for f in subs:
+        leaves = _newick_leaves(got[f])
+        assert 2 <= len(leaves) <= 4
+        shown.update(leaves)
+        files = usher_model._subtree_files(T, usher_model.get_subtree(T, leaves), f[:-3])
+        for name, text in files.items():
+            assert got[name] == text, name
+    assert all(n in shown for n in names if T.get_node(n) is not None)

@@ -24,15 +24,15 @@ static const char *kHelp =
     "  -S [ --sort-before-placement-2 ]          Sort new samples based on the number of optimal placements and then the parsimony score before the actual placement [EXPERIMENTAL].\n"
     "  -A [ --sort-before-placement-3 ]          Sort new samples based on the number of ambiguous bases [EXPERIMENTAL].\n"
     "  -r [ --reverse-sort ]                     Reverse the sorting order of sorting options [EXPERIMENTAL]\n"
-    "  -c [ --collapse-tree ]                    Collapse internal nodes of the input tree with no mutations and condense identical sequences (not supported by this build)\n"
-    "  -C [ --collapse-output-tree ]             Collapse internal nodes of the output tree with no mutations (not supported by this build)\n"
+    "  -c [ --collapse-tree ]                    Collapse internal nodes of the input tree with no mutations and condense identical sequences in polytomies into a single node and the save the tree to file condensed-tree.nh in outdir\n"
+    "  -C [ --collapse-output-tree ]             Collapse internal nodes of the output tree with no mutations before the saving the tree to file final-tree.nh in outdir\n"
     "  -e [ --max-uncertainty-per-sample ] arg (=1000000) Maximum number of equally parsimonious placements allowed per sample beyond which the sample is ignored\n"
     "  -E [ --max-parsimony-per-sample ] arg (=1000000)   Maximum parsimony score of the most parsimonious placement(s) allowed per sample beyond which the sample is ignored\n"
     "  -u [ --write-uncondensed-final-tree ]     Write the final tree in uncondensed format and save to file uncondensed-final-tree.nh in outdir\n"
-    "  -k [ --write-subtrees-size ] arg (=0)     Write minimum set of subtrees covering the newly added samples (not supported by this build)\n"
-    "  -K [ --write-single-subtree ] arg (=0)    Similar to write-subtrees-size but produces a single subtree (not supported by this build)\n"
+    "  -k [ --write-subtrees-size ] arg (=0)     Write minimum set of subtrees covering the newly added samples of size equal to this value\n"
+    "  -K [ --write-single-subtree ] arg (=0)    Similar to write-subtrees-size but produces a single subtree with all newly added samples along with random samples up to the value specified by this argument\n"
     "  -p [ --write-parsimony-scores-per-node ]  Write the parsimony scores for adding new samples at each existing node in the tree without modifying the tree in a file names parsimony-scores.tsv in outdir\n"
-    "  -M [ --multiple-placements ] arg (=1)     Create a new tree up to this limit for each possibility of parsimony-optimal placement (only 1 supported by this build)\n"
+    "  -M [ --multiple-placements ] arg (=1)     Create a new tree up to this limit for each possibility of parsimony-optimal placement\n"
     "  -l [ --retain-input-branch-lengths ]      Retain the branch lengths from the input tree in out newick files instead of using number of mutations for the branch lengths.\n"
     "  -n [ --no-add ]                           Do not add new samples to the tree\n"
     "  -D [ --detailed-clades ]                  In clades.txt, write a histogram of annotated clades and counts across all equally parsimonious placements\n"

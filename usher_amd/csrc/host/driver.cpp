@@ -9,7 +9,9 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
+#include <memory>
 #include <numeric>
+#include <random>
 #include <chrono>
 #include <climits>
 #include <cmath>
@@ -242,6 +244,368 @@ static void insert_sample(Tree &T, Node *best, bool as_sibling, const std::strin
     }
 }
 
+// ---------------------------------------------------------------------------
+// -K / -k: subtrees around the newly placed samples (get_random_single_subtree / get_random_sample_subtrees,
+// mutation_annotated_tree.cpp:1693-1990).  The reference draws with std::rand() (default seed for -K, srand(0)
+// for -k) and std::shuffle(std::default_random_engine{}); the same calls are made here, in the same order.
+// ---------------------------------------------------------------------------
+static void write_subtree_files(Tree &T, Tree &sub, const std::string &stem, const char *what, int number) {
+    sub.rotate_for_display();
+    const std::string nh = stem + ".nh";
+    if (number < 0) fprintf(stderr, "%s %s.\n", what, nh.c_str());
+    else fprintf(stderr, "Writing subtree %d to file %s.\n", number, nh.c_str());
+    write_text(nh, newick(sub, sub.root, true, true));
+    const std::string mf = stem + "-mutations.txt";
+    if (number < 0) fprintf(stderr, "Writing list of mutations at the nodes of the single subtree to file %s\n", mf.c_str());
+    else fprintf(stderr, "Writing list of mutations at the nodes of subtree %d to file %s\n", number, mf.c_str());
+    std::string text;
+    for (Node *n : sub.dfs()) {
+        text += n->id + ": ";
+        for (size_t i = 0; i < n->mutations.size(); i++) text += n->mutations[i].str() + (i + 1 < n->mutations.size() ? "," : "");
+        text += "\n";
+    }
+    write_text(mf, text);
+    std::string expanded;
+    for (Node *l : sub.leaves()) {
+        auto it = T.condensed_nodes.find(l->id);
+        if (it == T.condensed_nodes.end()) continue;
+        expanded += l->id + ": ";
+        for (const std::string &c : it->second) expanded += c + " ";
+        expanded += "\n";
+    }
+    if (!expanded.empty()) {
+        const std::string ef = stem + "-expanded.txt";
+        if (number < 0) fprintf(stderr, "Subtree has condensed nodes.\nExpanding the condensed nodes for the single subtree in file %s\n", ef.c_str());
+        else fprintf(stderr, "Subtree %d has condensed nodes.\nExpanding the condensed nodes for subtree %d in file %s\n", number, number, ef.c_str());
+        write_text(ef, expanded);
+    }
+}
+
+static void write_single_subtree(Tree &T, const std::vector<MissingSample> &missing, const std::string &outdir, size_t subtree_size,
+                                 size_t tree_idx, bool use_tree_idx) {   // :1693-1786
+    const std::string pre = use_tree_idx ? "/tree-" + std::to_string(tree_idx) + "-" : "/";
+    std::unordered_set<Node *> keep;
+    std::vector<Node *> order;   // (insertion order; the reference's std::set<Node*> order does not influence the result)
+    auto add = [&](Node *n) { if (n && keep.insert(n).second) order.push_back(n); };
+    for (const auto &ms : missing) add(T.get_node(ms.name));
+    const std::vector<Node *> all = T.leaves();
+    for (size_t i = 0; i < all.size(); i++) {
+        add(all[(size_t)std::rand() % all.size()]);
+        if (keep.size() >= subtree_size + missing.size()) break;
+    }
+    std::vector<std::string> ids;
+    for (Node *n : order) ids.push_back(n->id);
+    Tree sub;
+    std::string err;
+    if (!get_subtree(T, ids, sub, err)) { fprintf(stderr, "ERROR: %s\n", err.c_str()); return; }
+    char what[160];
+    snprintf(what, sizeof what, "Writing single subtree with %zu randomly added leaves to file", subtree_size);
+    write_subtree_files(T, sub, outdir + pre + "single-subtree", what, -1);
+}
+
+static void write_sample_subtrees(Tree &T, const std::vector<MissingSample> &missing, const std::string &outdir, size_t subtree_size,
+                                  size_t tree_idx, bool use_tree_idx) {   // :1788-1989
+    fprintf(stderr, "Computing subtrees for %ld samples. \n\n", (long)missing.size());
+    const std::string pre = use_tree_idx ? "/tree-" + std::to_string(tree_idx) + "-" : "/";
+    const size_t random_size = subtree_size / 5, nearest_size = subtree_size - random_size;
+    std::srand(0);
+    {   // (the reference draws a set of random leaves here that it never uses; the draws advance the generator all the same)
+        const std::vector<Node *> all = T.leaves();
+        std::unordered_set<Node *> seen;
+        for (size_t i = 0; i < all.size(); i++) {
+            seen.insert(all[(size_t)std::rand() % all.size()]);
+            if (seen.size() >= subtree_size) break;
+        }
+    }
+    std::vector<bool> displayed(missing.size(), false);
+    for (size_t i = 0; i < missing.size(); i++) if (!T.get_node(missing[i].name)) displayed[i] = true;
+    int num_subtrees = 0;
+    for (size_t i = 0; i < missing.size(); i++) {
+        if (displayed[i]) continue;
+        Node *last_anc = T.get_node(missing[i].name);
+        std::vector<std::string> keep;
+        for (Node *anc : T.rsearch(last_anc, true)) {
+            const size_t nl = T.num_leaves(anc);
+            if (nl < subtree_size) { last_anc = anc; continue; }
+            if (nl > subtree_size) {
+                for (Node *l : T.leaves(last_anc)) keep.push_back(l->id);
+                struct NodeDist { Node *node; uint32_t num_mut; };
+                std::vector<NodeDist> dist;
+                for (Node *l : T.leaves(anc)) {
+                    if (T.is_ancestor(last_anc, l)) continue;
+                    uint32_t d = 0;
+                    for (Node *a : T.rsearch(l, true)) { if (a == anc) break; d += (uint32_t)a->mutations.size(); }
+                    dist.push_back({l, d});
+                }
+                std::sort(dist.begin(), dist.end(), [](const NodeDist &a, const NodeDist &b) { return a.num_mut < b.num_mut; });
+                for (const NodeDist &n : dist) { if (keep.size() >= nearest_size) break; keep.push_back(n.node->id); }
+                if (nearest_size < subtree_size && nearest_size < dist.size()) {
+                    std::vector<NodeDist> rest(dist.begin() + nearest_size, dist.end());
+                    std::shuffle(rest.begin(), rest.end(), std::default_random_engine{});
+                    for (const NodeDist &n : rest) { if (keep.size() == subtree_size) break; keep.push_back(n.node->id); }
+                }
+            } else {
+                for (Node *l : T.leaves(anc)) { if (keep.size() == subtree_size) break; keep.push_back(l->id); }
+            }
+            Tree sub;
+            std::string err;
+            if (!get_subtree(T, keep, sub, err)) { fprintf(stderr, "ERROR: %s\n", err.c_str()); return; }
+            for (size_t j = i + 1; j < missing.size(); j++) if (!displayed[j] && sub.get_node(missing[j].name)) displayed[j] = true;
+            ++num_subtrees;
+            write_subtree_files(T, sub, outdir + pre + "subtree-" + std::to_string(num_subtrees), "", num_subtrees);
+            break;
+        }
+    }
+}
+
+// Every output of usher_common.cpp:808-1044 for the final tree(s); with several trees (--multiple-placements) the
+// file names carry the tree number (:836-838, :859-861, :893-895, :918-919) and only the first tree is saved (:1027-1034).
+static int write_outputs(const Options &opt, std::vector<Tree *> &trees, std::vector<MissingSample> &missing,
+                         const std::vector<std::string> &low_confidence) {
+    Timer timer;
+    const std::string &outdir = opt.outdir;
+    const size_t num_trees = trees.size();
+    auto numbered = [&](const std::string &stem, const std::string &ext, size_t t, bool dash) {
+        return num_trees > 1 ? outdir + "/" + stem + (dash ? "-" : "") + std::to_string(t + 1) + ext : outdir + "/" + stem + ext;
+    };
+    if (opt.collapse_output_tree) {                                             // :808-822
+        for (size_t t = 0; t < num_trees; t++) {
+            timer.start();
+            if (num_trees > 1) fprintf(stderr, "Collapsing output tree %zu.\n", t + 1);
+            else fprintf(stderr, "Collapsing output tree.\n");
+            trees[t]->collapse_tree();
+            fprintf(stderr, "Completed in %ld msec \n\n", timer.stop());
+        }
+    }
+    for (size_t t = 0; t < num_trees; t++) {                                    // :828-881
+        Tree &T = *trees[t];
+        timer.start();
+        if (opt.write_uncondensed) {
+            const std::string fn = numbered("uncondensed-final-tree", ".nh", t, true);
+            if (num_trees > 1) fprintf(stderr, "Writing uncondensed final tree %zu to file %s \n", t + 1, fn.c_str());
+            else fprintf(stderr, "Writing uncondensed final tree to file %s \n", fn.c_str());
+            fprintf(stderr, "The parsimony score for this tree is: %zu \n", T.parsimony_score());
+            write_text(fn, newick(T, T.root, true, true, true));
+        } else {
+            const std::string fn = numbered("final-tree", ".nh", t, true);
+            if (num_trees > 1) fprintf(stderr, "Writing final tree %zu to file %s \n", t + 1, fn.c_str());
+            else fprintf(stderr, "Writing final tree to file %s \n", fn.c_str());
+            fprintf(stderr, "The parsimony score for this tree is: %zu \n", T.parsimony_score());
+            write_text(fn, newick(T, T.root, true, true));
+        }
+        fprintf(stderr, "Completed in %ld msec \n\n", timer.stop());
+    }
+    if (!missing.empty()) {
+        for (size_t t = 0; t < num_trees; t++) {                                // :883-907
+            Tree &T = *trees[t];
+            timer.start();
+            const std::string fn = numbered("mutation-paths", ".txt", t, true);   // get_sample_mutation_paths, mutation_annotated_tree.cpp:1991-2050
+            if (num_trees > 1) fprintf(stderr, "Writing mutation paths for tree %zu to file %s \n", t + 1, fn.c_str());
+            else fprintf(stderr, "Writing mutation paths to file %s \n", fn.c_str());
+            std::string text;
+            for (auto &ms : missing) {
+                Node *n = T.get_node(ms.name);
+                if (!n) continue;
+                std::vector<std::string> parts;
+                for (Node *a : T.rsearch(n, true)) {
+                    if (a->mutations.empty()) continue;
+                    std::string p = a->id + ":";
+                    for (size_t k = 0; k < a->mutations.size(); k++) p += a->mutations[k].str() + (k + 1 < a->mutations.size() ? "," : " ");
+                    parts.push_back(std::move(p));
+                }
+                text += ms.name + "\t";
+                for (size_t i = parts.size(); i-- > 0;) text += parts[i];
+                text += "\n";
+            }
+            write_text(fn, text);
+            fprintf(stderr, "Completed in %ld msec \n\n", timer.stop());
+        }
+        for (size_t t = 0; t < num_trees; t++) {                                // clades.txt, :909-970
+            Tree &T = *trees[t];
+            const size_t n_ann = T.num_annotations();
+            if (n_ann == 0) continue;
+            timer.start();
+            const std::string cf = numbered("clades", ".txt", t, false);
+            if (num_trees > 1) fprintf(stderr, "Writing clade annotations for tree %zu to file %s \n", t + 1, cf.c_str());
+            else fprintf(stderr, "Writing clade annotations to file %s \n", cf.c_str());
+            std::string ctext;
+            for (auto &ms : missing) {
+                if (ms.best_clade_assignment.empty()) continue;
+                ctext += ms.name + "\t";
+                for (size_t k = 0; k < n_ann; k++) {
+                    ctext += ms.best_clade_assignment[k];
+                    if (opt.max_trees == 1 && opt.detailed_clades) {
+                        ctext += "*|";
+                        std::string cur; int cnt = 0;
+                        const auto &all = ms.clade_assignments[k];
+                        std::vector<std::string> segs;
+                        for (const std::string &c : all) {
+                            if (c == cur) cnt++;
+                            else { if (cnt > 0) segs.push_back(cur + "(" + std::to_string(cnt) + "/" + std::to_string(all.size()) + ")"); cur = c; cnt = 1; }
+                        }
+                        for (auto &sg : segs) ctext += sg + ",";
+                        if (cnt > 0) ctext += cur + "(" + std::to_string(cnt) + "/" + std::to_string(all.size()) + ")";
+                    }
+                    if (k + 1 < n_ann) ctext += "\t";
+                }
+                ctext += "\n";
+            }
+            write_text(cf, ctext);
+            fprintf(stderr, "Completed in %ld msec \n\n", timer.stop());
+        }
+    }
+    if (opt.subtrees_single > 1 && !missing.empty()) {                          // :973-990
+        fprintf(stderr, "Computing the single subtree for added samples with %zu random leaves. \n\n", opt.subtrees_single);
+        timer.start();
+        for (size_t t = 0; t < num_trees; t++) {
+            trees[t]->uncondense_leaves();
+            write_single_subtree(*trees[t], missing, outdir, opt.subtrees_single, t, num_trees > 1);
+        }
+        fprintf(stderr, "Completed in %ld msec \n\n", timer.stop());
+    }
+    if (opt.subtrees_size > 1 && !missing.empty()) {                            // :992-1012
+        fprintf(stderr, "Computing subtrees for added samples. \n\n");
+        timer.start();
+        for (size_t t = 0; t < num_trees; t++) {
+            trees[t]->uncondense_leaves();
+            write_sample_subtrees(*trees[t], missing, outdir, opt.subtrees_size, t, num_trees > 1);
+        }
+        fprintf(stderr, "Completed in %ld msec \n\n", timer.stop());
+    }
+    if (!low_confidence.empty()) {                                              // :1016-1021
+        fprintf(stderr, "WARNING: Following samples had multiple possibilities of parsimony-optimal placements:\n");
+        for (auto &l : low_confidence) fprintf(stderr, "%s\n", l.c_str());
+    }
+    if (!opt.save_mat.empty()) {                                                // :1024-1044
+        timer.start();
+        fprintf(stderr, "Saving mutation-annotated tree object to file (after condensing identical sequences) %s\n", opt.save_mat.c_str());
+        if (num_trees > 1) fprintf(stderr, "WARNING: --multiple-placements option was used but only the first mutation-annotated tree object will be saved to file.\n");
+        Tree &T = *trees[0];
+        if (!T.condensed_nodes.empty()) T.uncondense_leaves();
+        T.condense_leaves();
+        std::string err;
+        if (!save_mat(T, opt.save_mat, err)) { fprintf(stderr, "ERROR: %s\n", err.c_str()); return 1; }
+        fprintf(stderr, "Completed in %ld msec \n\n", timer.stop());
+    }
+    return 0;
+}
+
+// ---------------------------------------------------------------------------
+// --multiple-placements > 1 (usher_common.cpp:310-792 with max_trees > 1): every tree alive at the start of a
+// sample's turn is searched; the sample goes to the first optimal node on that tree and, while the tree budget
+// lasts, to each further optimal node on a copy of the tree as it was before the insertion (get_tree_copy).
+// Every (sample, tree) pair is a search on a different tree, so this path flattens per search, as the reference
+// re-expands per search; clade assignments are not produced in this mode (:598).
+// ---------------------------------------------------------------------------
+static int run_multi(const Options &opt, Tree &T0, std::vector<MissingSample> &missing, const std::vector<size_t> &indexes,
+                     const Backend &be, uint64_t &tree_version) {
+    Timer timer;
+    std::vector<std::unique_ptr<Tree>> owned;
+    std::vector<Tree *> trees{&T0};
+    std::vector<std::string> low_confidence;   // (only filled when max_trees == 1, :457-459)
+    auto be_fail = [&](const char *what) {
+        fprintf(stderr, "ERROR: %s failed: %s\n", what, be.last_error ? be.last_error(be.ctx) : "?");
+        return 1;
+    };
+    FILE *stats = fopen((opt.outdir + "/placement_stats.tsv").c_str(), "w");
+    if (!stats) { fprintf(stderr, "ERROR: cannot write to %s\n", opt.outdir.c_str()); return 1; }
+    FlatTree flat;
+    for (size_t ii = 0; ii < indexes.size(); ii++) {
+        MissingSample &ms = missing[indexes[ii]];
+        const size_t num_trees = trees.size();
+        for (size_t t_idx = 0; t_idx < num_trees; t_idx++) {
+            timer.start();
+            Tree *T = trees[t_idx];
+            if (num_trees > 1) fprintf(stderr, "==Tree %zu=== \n", t_idx + 1);
+            if (T->get_node(ms.name)) { fprintf(stderr, "WARNING: Sample %s already in the tree! Ignoring.\n\n", ms.name.c_str()); continue; }
+            flat.build(*T);
+            const size_t total_nodes = flat.bfs.size();
+            FlatQueries q1;
+            q1.add(ms.mutations);
+            q1.finish();
+            ugp_result r{};
+            if (be.place(be.ctx, &flat.desc, ++tree_version, &q1.desc, &r) != 0) { fclose(stats); return be_fail("placement"); }
+            int best = r.best_set_difference;
+            size_t num_best = r.num_best;
+            std::vector<uint32_t> tj(std::max<size_t>(1, std::min<size_t>(num_best, (size_t)1 << 20))), tc(1, 0);
+            std::vector<uint8_t> th(tj.size());
+            if (num_best > 1) {   // best_j_vec, ascending (:588), with node_has_unique of each
+                if (be.ties(be.ctx, &flat.desc, tree_version, &q1.desc, (uint32_t)tj.size(), tj.data(), th.data(), tc.data()) != 0) { fclose(stats); return be_fail("tie listing"); }
+            } else { tj[0] = r.best_j; th[0] = (uint8_t)r.best_has_unique; }
+            fprintf(stderr, "Current tree size (#nodes): %zu\tSample name: %s\tParsimony score: %d\tNumber of parsimony-optimal placements: %zu\n", total_nodes, ms.name.c_str(), best, num_best);
+            fprintf(stats, "%s\t%d\t%zu\t", ms.name.c_str(), best, num_best);
+            if (num_best > 1) {
+                if (num_best > opt.max_uncertainty) fprintf(stderr, "WARNING: Number of parsimony-optimal placements exceeds maximum allowed value (%u). Ignoring sample %s.\n", opt.max_uncertainty, ms.name.c_str());
+                else if ((uint32_t)best <= opt.max_parsimony) fprintf(stderr, "WARNING: Multiple parsimony-optimal placements found. Placement done without high confidence.\n");
+            }
+            if ((uint32_t)best > opt.max_parsimony) fprintf(stderr, "WARNING: Parsimony score of the most parsimonious placement exceeds the maximum allowed value (%u). Ignoring sample %s.\n", opt.max_parsimony, ms.name.c_str());
+            // a copy of the tree as it is now, for the 2nd, 3rd ... placement (:548-555)
+            std::unique_ptr<Tree> curr_tree;
+            if (num_best > 1 && num_trees < opt.max_trees) {
+                curr_tree.reset(new Tree());
+                std::string err;
+                if (!copy_tree(*T, *curr_tree, err)) { fprintf(stderr, "ERROR: %s\n", err.c_str()); fclose(stats); return 1; }
+            }
+            if (num_best <= opt.max_uncertainty && (uint32_t)best <= opt.max_parsimony) {   // :583
+                if (num_best > 1 && trees.size() <= opt.max_trees && num_best + trees.size() > opt.max_trees) {   // :592-597
+                    if (num_best + trees.size() > (size_t)opt.max_trees + 1)
+                        fprintf(stderr, "%zu parsimony-optimal placements found but total trees has already exceed the max possible value (%i)!\n", num_best, (int)opt.max_trees);
+                    num_best = 1 + opt.max_trees - trees.size();
+                }
+                // node_has_unique[k] for k < num_best (:647 indexes the per-NODE flags with the loop counter): the flag
+                // of breadth-first node k if that node ever matched or beat the running optimum of the in-order scan
+                // (pass 1, :465-497) or is itself optimal (pass 2), else false (:379)
+                std::vector<uint8_t> quirk(num_best, 0);
+                if (num_best > 1) {
+                    int run = (int)(ms.mutations.size() + T->root->mutations.size() + 1);   // :374
+                    NodeVecs nv;
+                    for (size_t k = 0; k < num_best && k < total_nodes; k++) {
+                        node_vecs(flat.bfs[k], ms.mutations, nv);
+                        if (nv.eligible && nv.set_difference <= run) { quirk[k] = nv.has_unique ? 1 : 0; run = std::min(run, nv.set_difference); }
+                    }
+                }
+                std::vector<Node *> bfs = flat.bfs;
+                for (size_t k = 0; k < num_best; k++) {
+                    Node *best_node = flat.bfs[r.best_j];
+                    bool best_has_unique = r.best_has_unique != 0;
+                    if (num_best > 1) {
+                        if (k == 0) fprintf(stderr, "Creating %zu additional tree(s) for %zu parsimony-optimal placements.\n", num_best - 1, num_best);
+                        if (k > 0) {
+                            owned.emplace_back(new Tree());
+                            std::string err;
+                            if (!copy_tree(*curr_tree, *owned.back(), err)) { fprintf(stderr, "ERROR: %s\n", err.c_str()); fclose(stats); return 1; }
+                            trees.push_back(owned.back().get());
+                            T = trees.back();
+                            bfs = T->bfs();
+                        }
+                        best_node = bfs[tj[k]];
+                        best_has_unique = quirk[k] != 0;
+                    }
+                    NodeVecs vec;
+                    node_vecs(best_node, ms.mutations, vec);
+                    if (!opt.no_add && !T->get_node(ms.name)) {
+                        std::vector<Node *> touched;
+                        insert_sample(*T, best_node, best_node->is_leaf() || best_has_unique, ms.name, vec.excess, touched);
+                    }
+                    if (!vec.imputed.empty()) {                                 // :767-781
+                        fprintf(stderr, "Imputed mutations:\t");
+                        for (size_t i = 0; i < vec.imputed.size(); i++) {
+                            const char *sep = i + 1 < vec.imputed.size() ? ";" : "";
+                            fprintf(stderr, "%i:%c%s", vec.imputed[i].position, nuc_char(vec.imputed[i].mut_nuc), sep);
+                            fprintf(stats, "%i:%c%s", vec.imputed[i].position, nuc_char(vec.imputed[i].mut_nuc), sep);
+                        }
+                        fprintf(stderr, "\n");
+                    }
+                }
+            }
+            fputc('\n', stats);
+            fprintf(stderr, "Completed in %ld msec \n\n", timer.stop());
+        }
+    }
+    fclose(stats);
+    return write_outputs(opt, trees, missing, low_confidence);
+}
+
 int run_usher(const Options &opt, Tree &T, std::vector<MissingSample> &missing, const Backend &be) {
     // ---- option validation, usher_common.cpp:14-77
     if (opt.subtrees_size == 1) { fprintf(stderr, "ERROR: print-subtrees-size should be larger than 1\n"); return 1; }
@@ -262,10 +626,6 @@ int run_usher(const Options &opt, Tree &T, std::vector<MissingSample> &missing, 
     }
     if (opt.max_trees == 0) { fprintf(stderr, "ERROR: Number of trees specified by --multiple-placements (-M) should be >= 1\n"); return 1; }
     if (opt.no_add && (opt.subtrees_size > 0 || opt.subtrees_single)) { fprintf(stderr, "ERROR: Sorry, cannot output subtrees when -n/--no-add is specified.\n"); return 1; }
-    // features of the reference front end that this build does not provide yet
-    if (opt.max_trees > 1) { fprintf(stderr, "ERROR: --multiple-placements > 1 is not supported by this build.\n"); return 1; }
-    if (opt.collapse_tree || opt.collapse_output_tree) { fprintf(stderr, "ERROR: --collapse-tree / --collapse-output-tree are not supported by this build.\n"); return 1; }
-    if (opt.subtrees_size > 0 || opt.subtrees_single > 0) { fprintf(stderr, "ERROR: --write-subtrees-size / --write-single-subtree are not supported by this build.\n"); return 1; }
 
     if (opt.retain_branch_len) fprintf(stderr, "Output newick files will retain branch lengths from the input tree (unspecified at branches modified during the placement).\n\n");
     else fprintf(stderr, "Output newick files will have branch lengths equal to the number of mutations of that branch.\n\n");
@@ -277,6 +637,18 @@ int run_usher(const Options &opt, Tree &T, std::vector<MissingSample> &missing, 
         if (mkdir(outdir.c_str(), 0777) != 0) { fprintf(stderr, "ERROR: cannot create %s\n", outdir.c_str()); return 1; }
     }
     Timer timer;
+    if (opt.collapse_tree) {                                                    // :120-148
+        timer.start();
+        fprintf(stderr, "Collapsing input tree.\n");
+        T.collapse_tree();
+        fprintf(stderr, "Completed in %ld msec \n\n", timer.stop());
+        fprintf(stderr, "Condensing identical sequences. \n");
+        T.condense_leaves();
+        const std::string fn = outdir + "/condensed-tree.nh";
+        fprintf(stderr, "Writing condensed input tree to file %s\n", fn.c_str());
+        write_text(fn, newick(T, T.root, true, true) + "\n");
+        fprintf(stderr, "Completed in %ld msec \n\n", timer.stop());
+    }
     fprintf(stderr, "Found %zu missing samples.\n\n", missing.size());
     std::vector<std::string> low_confidence;
     auto be_fail = [&](const char *what) {
@@ -325,6 +697,7 @@ int run_usher(const Options &opt, Tree &T, std::vector<MissingSample> &missing, 
             fprintf(stderr, "Completed in %ld msec \n\n", timer.stop());
         }
         if (!opt.print_scores) fprintf(stderr, "Adding missing samples to the tree.\n");
+        if (opt.max_trees > 1) return run_multi(opt, T, missing, indexes, be, tree_version);
 
         if (static_tree) {   // the tree never changes: one batch call serves every sample
             flat.build(T);
@@ -604,89 +977,8 @@ int run_usher(const Options &opt, Tree &T, std::vector<MissingSample> &missing, 
         if (scores_file) fclose(scores_file);
     }
     if (opt.print_scores) return 0;                                             // :800-805
-
-    // ---- outputs, usher_common.cpp:828-1044
-    timer.start();
-    if (opt.write_uncondensed) {
-        const std::string fn = outdir + "/uncondensed-final-tree.nh";
-        fprintf(stderr, "Writing uncondensed final tree to file %s \n", fn.c_str());
-        fprintf(stderr, "The parsimony score for this tree is: %zu \n", T.parsimony_score());
-        write_text(fn, newick(T, T.root, true, true, true));
-    } else {
-        const std::string fn = outdir + "/final-tree.nh";
-        fprintf(stderr, "Writing final tree to file %s \n", fn.c_str());
-        fprintf(stderr, "The parsimony score for this tree is: %zu \n", T.parsimony_score());
-        write_text(fn, newick(T, T.root, true, true));
-    }
-    fprintf(stderr, "Completed in %ld msec \n\n", timer.stop());
-
-    if (!missing.empty()) {
-        timer.start();
-        const std::string fn = outdir + "/mutation-paths.txt";                  // get_sample_mutation_paths, mutation_annotated_tree.cpp:1991-2050
-        fprintf(stderr, "Writing mutation paths to file %s \n", fn.c_str());
-        std::string text;
-        for (auto &ms : missing) {
-            Node *n = T.get_node(ms.name);
-            if (!n) continue;
-            std::vector<std::string> parts;
-            for (Node *a : T.rsearch(n, true)) {
-                if (a->mutations.empty()) continue;
-                std::string p = a->id + ":";
-                for (size_t k = 0; k < a->mutations.size(); k++) p += a->mutations[k].str() + (k + 1 < a->mutations.size() ? "," : " ");
-                parts.push_back(std::move(p));
-            }
-            text += ms.name + "\t";
-            for (size_t i = parts.size(); i-- > 0;) text += parts[i];
-            text += "\n";
-        }
-        write_text(fn, text);
-        fprintf(stderr, "Completed in %ld msec \n\n", timer.stop());
-
-        const size_t n_ann = T.num_annotations();
-        if (n_ann > 0) {                                                        // clades.txt, :909-970
-            timer.start();
-            const std::string cf = outdir + "/clades.txt";
-            fprintf(stderr, "Writing clade annotations to file %s \n", cf.c_str());
-            std::string ctext;
-            for (auto &ms : missing) {
-                if (ms.best_clade_assignment.empty()) continue;
-                ctext += ms.name + "\t";
-                for (size_t k = 0; k < n_ann; k++) {
-                    ctext += ms.best_clade_assignment[k];
-                    if (opt.detailed_clades) {
-                        ctext += "*|";
-                        std::string cur; int cnt = 0;
-                        const auto &all = ms.clade_assignments[k];
-                        std::vector<std::string> segs;
-                        for (const std::string &c : all) {
-                            if (c == cur) cnt++;
-                            else { if (cnt > 0) segs.push_back(cur + "(" + std::to_string(cnt) + "/" + std::to_string(all.size()) + ")"); cur = c; cnt = 1; }
-                        }
-                        for (auto &sg : segs) ctext += sg + ",";
-                        if (cnt > 0) ctext += cur + "(" + std::to_string(cnt) + "/" + std::to_string(all.size()) + ")";
-                    }
-                    if (k + 1 < n_ann) ctext += "\t";
-                }
-                ctext += "\n";
-            }
-            write_text(cf, ctext);
-            fprintf(stderr, "Completed in %ld msec \n\n", timer.stop());
-        }
-    }
-    if (!low_confidence.empty()) {                                              // :1016-1021
-        fprintf(stderr, "WARNING: Following samples had multiple possibilities of parsimony-optimal placements:\n");
-        for (auto &l : low_confidence) fprintf(stderr, "%s\n", l.c_str());
-    }
-    if (!opt.save_mat.empty()) {                                                // :1024-1044
-        timer.start();
-        fprintf(stderr, "Saving mutation-annotated tree object to file (after condensing identical sequences) %s\n", opt.save_mat.c_str());
-        if (!T.condensed_nodes.empty()) T.uncondense_leaves();
-        T.condense_leaves();
-        std::string err;
-        if (!save_mat(T, opt.save_mat, err)) { fprintf(stderr, "ERROR: %s\n", err.c_str()); return 1; }
-        fprintf(stderr, "Completed in %ld msec \n\n", timer.stop());
-    }
-    return 0;
+    std::vector<Tree *> trees{&T};
+    return write_outputs(opt, trees, missing, low_confidence);
 }
 
 }  // namespace uh

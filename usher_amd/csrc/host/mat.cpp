@@ -191,6 +191,183 @@ void Tree::remove_leaf(Node *n) {
     delete n;
 }
 
+std::vector<Node *> Tree::leaves(Node *from) const {   // get_leaves, :818-840
+    std::vector<Node *> out, q;
+    Node *start = from ? from : root;
+    if (!start) return out;
+    q.push_back(start);
+    for (size_t h = 0; h < q.size(); h++) {
+        if (q[h]->children.empty()) out.push_back(q[h]);
+        for (Node *c : q[h]->children) q.push_back(c);
+    }
+    return out;
+}
+
+bool Tree::is_ancestor(const Node *anc, const Node *n) const {   // :920-929 (proper ancestor)
+    for (const Node *p = n->parent; p; p = p->parent) if (p == anc) return true;
+    return false;
+}
+
+size_t Tree::num_leaves(Node *n) const { return leaves(n).size(); }
+
+// remove_node_helper, :960-1049.  Deletes `source` with its descendants; a parent left without children goes too,
+// and with move_level a parent left with ONE child is spliced out (the child inherits its mutations / annotations).
+void Tree::remove_node(Node *source, bool move_level) {
+    Node *par = source->parent;
+    if (par) {
+        par->children.erase(std::find(par->children.begin(), par->children.end(), source));
+        if (par->children.empty()) {
+            if (par != root) remove_node(par, move_level);      // (the reference exits on an emptied tree)
+        } else if (move_level && par->children.size() == 1) {
+            Node *child = par->children[0];
+            if (par->parent) {
+                for (size_t k = 0; k < par->clade_annotations.size() && k < child->clade_annotations.size(); k++)
+                    if (child->clade_annotations[k].empty()) child->clade_annotations[k] = par->clade_annotations[k];
+                child->parent = par->parent;
+                child->branch_length += par->branch_length;
+                const std::vector<Mutation> own = child->mutations;
+                child->mutations.clear();
+                for (const Mutation &m : par->mutations) child->add_mutation(m);
+                for (const Mutation &m : own) child->add_mutation(m);
+                par->parent->children.push_back(child);
+                par->parent->children.erase(std::find(par->parent->children.begin(), par->parent->children.end(), par));
+                fix_levels(child);
+                all_nodes.erase(par->id);
+                delete par;
+            }
+        }
+    }
+    std::vector<Node *> q{source};
+    for (size_t h = 0; h < q.size(); h++) for (Node *c : q[h]->children) q.push_back(c);
+    for (Node *n : q) { all_nodes.erase(n->id); delete n; }
+}
+
+static bool same_mutations(const std::vector<Mutation> &a, const std::vector<Mutation> &b) {   // Mutation::operator==, hpp:56-62
+    if (a.size() != b.size()) return false;
+    for (size_t i = 0; i < a.size(); i++)
+        if (a[i].position != b[i].position || a[i].is_missing != b[i].is_missing || a[i].chrom != b[i].chrom ||
+            a[i].par_nuc != b[i].par_nuc || a[i].mut_nuc != b[i].mut_nuc) return false;
+    return true;
+}
+
+// move_node, :1135-1223.  (Mutation lists are kept sorted by add_mutation, so find_child_with_muts' sorting is a no-op.)
+void Tree::move_node(Node *source, Node *destination, bool move_level) {
+    Node *curr_parent = source->parent;
+    if (curr_parent == destination) return;   // (the reference exits with an error)
+    auto link = [](Node *parent, Node *child) { child->parent = parent; child->branch_length = -1.0f; parent->children.push_back(child); };
+    auto unlink = [&](Node *parent, Node *child) {   // remove_child, :1118-1131
+        parent->children.erase(std::find(parent->children.begin(), parent->children.end(), child));
+        if (parent->children.empty()) remove_node(parent, move_level);
+    };
+    Node *existing = nullptr;                      // a child of destination with the same (non-empty) mutations
+    for (Node *c : destination->children) if (same_mutations(c->mutations, source->mutations)) { existing = c; break; }
+    if (existing == curr_parent || source->mutations.empty()) existing = nullptr;
+    std::vector<Node *> relevel;
+    if (!existing) {
+        link(destination, source);
+        unlink(curr_parent, source);
+        relevel.push_back(source);
+    } else if (existing->is_leaf()) {
+        if (source->is_leaf()) {                   // two leaves: a new internal node carries the shared mutations
+            Node *mid = create_node(new_internal_node_id(), destination, -1.0f);
+            for (const Mutation &m : source->mutations) mid->add_mutation(m);
+            source->mutations.clear();
+            existing->mutations.clear();
+            link(mid, source);
+            link(mid, existing);
+            unlink(destination, existing);
+            unlink(curr_parent, source);
+            relevel.push_back(mid);
+        } else {                                   // the existing leaf moves into source
+            existing->mutations.clear();
+            link(source, existing);
+            link(destination, source);
+            unlink(destination, existing);
+            unlink(curr_parent, source);
+            relevel.push_back(source);
+        }
+    } else if (source->is_leaf()) {                // source moves into the existing internal node
+        source->mutations.clear();
+        link(existing, source);
+        unlink(curr_parent, source);
+        relevel.push_back(source);
+    } else {                                       // both internal: source's children move into the existing node (recursively)
+        const std::vector<Node *> kids = source->children;
+        for (Node *k : kids) move_node(k, existing, move_level);
+    }
+    for (Node *n : relevel) fix_levels(n);
+}
+
+static void collapse_r(Tree *T, Node *node) {   // collapse_tree_r, :1384-1420
+    if (node->children.empty()) return;
+    const std::vector<Node *> kids = node->children;
+    for (Node *c : kids) collapse_r(T, c);
+    Node *parent = node->parent;
+    if (!parent) return;
+    if (node->mutations.empty()) {
+        const std::vector<Node *> now = node->children;
+        for (Node *c : now) T->move_node(c, parent, false);
+    } else if (node->children.size() == 1) {
+        Node *child = node->children.front();
+        for (const Mutation &m : child->mutations) node->add_mutation(m);
+        child->mutations = node->mutations;
+        T->move_node(child, parent, false);
+    }
+}
+
+void Tree::collapse_tree() { if (root) collapse_r(this, root); }
+
+void Tree::rotate_for_display() {   // :1426-1453
+    const std::vector<Node *> order = dfs();
+    std::unordered_map<Node *, int> nd;
+    for (size_t i = order.size(); i-- > 0;) {
+        int d = 1;
+        for (Node *c : order[i]->children) d += nd[c];
+        nd[order[i]] = d;
+    }
+    // (tbb::parallel_sort is not stable; children with equal counts keep their order here)
+    for (Node *n : order) std::stable_sort(n->children.begin(), n->children.end(), [&](Node *a, Node *b) { return nd[a] > nd[b]; });
+}
+
+bool get_subtree(const Tree &src, const std::vector<std::string> &samples, Tree &dst, std::string &err) {   // :1575-1681
+    std::unordered_set<const Node *> keep;
+    std::vector<std::unordered_set<const Node *>> anc(samples.size());
+    for (size_t k = 0; k < samples.size(); k++) {
+        Node *n = src.get_node(samples[k]);
+        if (!n) { err = "get_subtree: sample " + samples[k] + " is not in the tree"; return false; }
+        keep.insert(n);
+        for (Node *a : src.rsearch(n, true)) anc[k].insert(a);
+    }
+    for (size_t i = 0; i < samples.size(); i++)
+        for (size_t j = i + 1; j < samples.size(); j++)
+            for (Node *a : src.rsearch(src.get_node(samples[i]), true))
+                if (anc[j].count(a)) { keep.insert(a); break; }
+    const size_t n_ann = src.num_annotations();
+    std::vector<Node *> last;   // stack of subtree nodes (source nodes) on the current path
+    for (Node *n : src.dfs()) {
+        if (!keep.count(n)) continue;
+        while (!last.empty() && !src.is_ancestor(last.back(), n)) last.pop_back();
+        Node *sp = last.empty() ? nullptr : last.back();
+        Node *nn = dst.create_node(n->id, sp ? dst.get_node(sp->id) : nullptr, -1.0f);
+        if (!nn) { err = "get_subtree: duplicate node " + n->id; return false; }
+        nn->clade_annotations.assign(n_ann, "");
+        std::vector<Node *> path = src.rsearch(n, true);           // n .. root
+        std::reverse(path.begin(), path.end());                     // root .. n
+        if (sp) path.erase(path.begin(), std::find(path.begin(), path.end(), sp) + 1);
+        for (Node *c : path) {
+            // (the root of the subtree takes only its own annotations, :1640-1644; inner nodes inherit along the collapsed path)
+            if (sp || c == n)
+                for (size_t k = 0; k < n_ann && k < c->clade_annotations.size(); k++)
+                    if (!c->clade_annotations[k].empty()) nn->clade_annotations[k] = c->clade_annotations[k];
+            for (const Mutation &m : c->mutations) nn->add_mutation(m);
+        }
+        last.push_back(n);
+    }
+    dst.curr_internal_node = src.curr_internal_node;
+    dst.chroms = src.chroms;
+    return true;
+}
+
 void Tree::condense_leaves() {   // :1287-1332
     if (!condensed_nodes.empty()) uncondense_leaves();
     std::vector<std::string> leaf_ids;
@@ -208,13 +385,16 @@ void Tree::condense_leaves() {   // :1287-1332
             std::vector<std::string> ids;
             for (Node *p : poly) ids.push_back(p->id);
             for (Node *p : poly) remove_leaf(p);
-            condensed_nodes[name] = ids;
+            add_condensed(name, ids);
         }
     }
 }
 
 void Tree::uncondense_leaves() {   // :1334-1382
-    for (auto &cn : condensed_nodes) {
+    for (const std::string &cname : condensed_order) {
+        auto cit = condensed_nodes.find(cname);
+        if (cit == condensed_nodes.end()) continue;
+        auto &cn = *cit;
         Node *n = get_node(cn.first);
         if (!n) continue;
         Node *par = n->parent ? n->parent : n;
@@ -248,7 +428,26 @@ void Tree::uncondense_leaves() {   // :1334-1382
         }
     }
     condensed_nodes.clear();
+    condensed_order.clear();
     condensed_leaves.clear();
+}
+
+bool copy_tree(const Tree &src, Tree &dst, std::string &err) {   // get_tree_copy, :1493-1549
+    if (!src.root) { err = "empty tree"; return false; }
+    if (!tree_from_newick(newick(src, src.root, true, true), dst, err)) return false;
+    const std::vector<Node *> d1 = src.dfs(), d2 = dst.dfs();
+    if (d1.size() != d2.size()) { err = "tree copy: node count changed in the newick round trip"; return false; }
+    dst.chroms = src.chroms;
+    for (size_t k = 0; k < d1.size(); k++) {
+        d2[k]->clade_annotations = d1[k]->clade_annotations;
+        for (const Mutation &m : d1[k]->mutations) d2[k]->add_mutation(m);
+    }
+    for (const std::string &cname : src.condensed_order) {
+        const auto &ids = src.condensed_nodes.at(cname);
+        dst.add_condensed(cname, ids);
+        for (const std::string &l : ids) dst.condensed_leaves.insert(l);
+    }
+    return true;
 }
 
 // ------------------------------------------------------------------ newick
@@ -494,7 +693,7 @@ bool load_mat(const std::string &path, Tree &T, std::string &err) {   // :522-61
     }
     for (auto &c : cond) {
         for (auto &l : c.second) T.condensed_leaves.insert(l);
-        T.condensed_nodes.emplace(c.first, c.second);
+        T.add_condensed(c.first, c.second);
     }
     return true;
 }
@@ -523,7 +722,10 @@ bool save_mat(Tree &T, const std::string &path, std::string &err) {   // :614-68
         }
         put_bytes(out, 2, ml);
     }
-    for (auto &cn : T.condensed_nodes) {
+    for (const std::string &cname : T.condensed_order) {
+        auto cit = T.condensed_nodes.find(cname);
+        if (cit == T.condensed_nodes.end()) continue;
+        auto &cn = *cit;
         std::string c;
         if (!cn.first.empty()) put_bytes(c, 1, cn.first);
         for (auto &l : cn.second) put_bytes(c, 2, l);

@@ -48,6 +48,10 @@ struct Tree {                 // mutation_annotated_tree.hpp:113-161
     // name -> condensed leaf ids.  (The reference keeps a tbb::concurrent_unordered_map here, whose
     // iteration order is unspecified; a std::unordered_map fed in the same sequence is used instead.)
     std::unordered_map<std::string, std::vector<std::string>> condensed_nodes;
+    std::vector<std::string> condensed_order;   // keys of condensed_nodes in the order they were entered (iteration order below)
+    void add_condensed(const std::string &name, const std::vector<std::string> &ids) {
+        if (condensed_nodes.emplace(name, ids).second) condensed_order.push_back(name);
+    }
     std::unordered_set<std::string> condensed_leaves;
     std::vector<std::string> chroms{""};
 
@@ -69,10 +73,25 @@ struct Tree {                 // mutation_annotated_tree.hpp:113-161
     // move `src` (a child elsewhere) below `dst` as its last child; plain case of :1135-1158
     void reattach(Node *src, Node *dst);
     void remove_leaf(Node *n);   // the part of remove_node() condense_leaves needs (:960-1049, move_level=false)
+    void remove_node(Node *n, bool move_level);                // :960-1049 (the node and its descendants)
+    void move_node(Node *src, Node *dst, bool move_level = true);   // :1135-1223, incl. the "same mutations" merges
+    void collapse_tree();                                      // :1384-1424
+    std::vector<Node *> leaves(Node *from = nullptr) const;    // get_leaves, :818-840 (breadth-first)
+    bool is_ancestor(const Node *anc, const Node *n) const;    // :920-929
+    size_t num_leaves(Node *n) const;                          // get_num_leaves, :866-879
+    void rotate_for_display();                                 // :1426-1453 (children by descending subtree size)
     void condense_leaves();      // :1287-1332
     void uncondense_leaves();    // :1334-1382
     void fix_levels(Node *from);
 };
+
+// get_tree_copy(), :1493-1549: a newick round trip (internal nodes are re-numbered node_1.. in '(' order, :484),
+// then clade annotations, mutations and the condensed-node table are copied node by node in depth-first order.
+bool copy_tree(const Tree &src, Tree &dst, std::string &err);
+
+// get_subtree(), :1575-1681: the subtree induced by `samples` (their leaves, every pairwise most recent common
+// ancestor, mutations merged along the collapsed paths); internal node names are kept.
+bool get_subtree(const Tree &src, const std::vector<std::string> &samples, Tree &dst, std::string &err);
 
 // newick --------------------------------------------------------------------
 bool tree_from_newick(const std::string &nwk, Tree &out, std::string &err);   // :415-508
