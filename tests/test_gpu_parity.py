@@ -538,3 +538,22 @@ def test_sixteen_bit_boundary_of_the_packed_path(coarse, monkeypatch):
         for i, s in enumerate(qs):
             _assert_same(res, i, cfc.place(s), "%s rows %d" % (s["name"], max_rows))
         pl.close()
+
+
+def test_usher_cli_multiple_placements_on_gpu(tmp_path):
+    """bin/usher-amd -M 4 on the recorded synthetic fixture (50 samples, many with several optimal nodes): every file
+    equals what the python restatement of the reference's multi-tree loop produces with the oracle doing the searches."""
+    import subprocess
+    from tests import usher_model
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "usher_amd", "bin", "usher-amd")
+    pb, vcf = os.path.join(SURVEY, "syn", "tree.pb"), os.path.join(SURVEY, "syn", "query.vcf")
+    r = subprocess.run([exe, "-i", pb, "-v", vcf, "-M", "4", "-d", str(tmp_path)], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    T = refio.load_mutation_annotated_tree(pb)
+    want = usher_model.run(T, refio.read_vcf(T, vcf), max_trees=4)
+    got = {n: open(str(tmp_path / n)).read() for n in sorted(os.listdir(str(tmp_path)))}
+    assert sorted(got) == sorted(want)
+    for name in want:
+        assert got[name] == want[name], name
+    assert "final-tree-4.nh" in got

@@ -349,3 +349,63 @@ def test_subtrees_around_new_samples(tmp_path):
         for name, text in files.items():
             assert got[name] == text, name
     assert all(n in shown for n in names if T.get_node(n) is not None)
+
+
+@pytest.mark.parametrize("seed", [31, 32])
+def test_out_of_order_and_duplicated_rows_follow_the_reference_scans(seed, tmp_path):
+    """VCF rows that are not sorted by position, or repeat a position: the reference's scans are order-dependent there
+    (usher_mapper.cpp:204-242, 393-445).  Such samples are searched on the host with the literal routine instead of
+    being sorted first; -n, -p and the default add mode must equal the oracle's literal answers on the rows as given."""
+    import numpy as np
+    from tests import host_harness, usher_model
+    rng = np.random.default_rng(seed)
+    nh, old, new = str(tmp_path / "t.nh"), str(tmp_path / "old.vcf"), str(tmp_path / "new.vcf")
+    _evolve_vcf(rng, 90, 50, 12, nh, old, new)
+    pb = str(tmp_path / "base.pb")
+    assert host_harness.run_usher(["-t", nh, "-v", old, "-o", pb, "-d", str(tmp_path)]) == 0
+    # shuffle the VCF's data lines and repeat some of them with another allele
+    lines = open(new).read().splitlines()
+    head = [l for l in lines if l.startswith("#")]
+    body = [l for l in lines if not l.startswith("#")]
+    dup = []
+    for l in body[::3]:
+        w = l.split("\t")
+        w[4] = "ACGT".replace(w[3], "")[int(rng.integers(0, 3))]
+        w[9:] = [c if c in ("0", ".") else "1" for c in w[9:]]
+        dup.append("\t".join(w))
+    body = body + dup
+    rng.shuffle(body)
+    odd_vcf = str(tmp_path / "odd.vcf")
+    open(odd_vcf, "w").write("\n".join(head + body) + "\n")
+    T = refio.load_mutation_annotated_tree(pb)
+    missing = refio.read_vcf(T, odd_vcf)
+    assert any(any(b.position <= a.position for a, b in zip(m.mutations, m.mutations[1:])) for m in missing)
+    arrays = refio.tree_to_bfs_arrays(T)
+    from oracle import capi
+    ot = capi.OracleTree(arrays)
+    # -n
+    d = tmp_path / "n"; d.mkdir()
+    assert host_harness.run_usher(["-i", pb, "-v", odd_vcf, "-n", "-d", str(d)]) == 0
+    want = ""
+    for m in missing:
+        r = ot.place(refio.sample_to_arrays(m))
+        nv = ot.node_vecs(refio.sample_to_arrays(m), r["best_j"])
+        want += "%s\t%d\t%d\t%s\n" % (m.name, r["best"], r["num_best"], ";".join("%d:%s" % (p, refio.get_nuc(mu)) for (p, rf, pa, mu) in nv["imputed"]))
+    assert open(str(d / "placement_stats.tsv")).read() == want
+    # -p: score column of every (sample, node)
+    d = tmp_path / "p"; d.mkdir()
+    assert host_harness.run_usher(["-i", pb, "-v", odd_vcf, "-p", "-d", str(d)]) == 0
+    rows = [l.split("\t") for l in open(str(d / "parsimony-scores.tsv")).read().splitlines()[1:]]
+    k = 0
+    for m in missing:
+        sc = ot.place(refio.sample_to_arrays(m), compute_scores=True)["scores"]
+        for j in range(arrays["n"]):
+            assert rows[k][0] == m.name and rows[k][1] == arrays["names"][j] and int(rows[k][2]) == int(sc[j]), (m.name, j)
+            k += 1
+    # default add mode against the restated loop (searches on the rows as given)
+    d = tmp_path / "a"; d.mkdir()
+    assert host_harness.run_usher(["-i", pb, "-v", odd_vcf, "-d", str(d)]) == 0
+    T2 = refio.load_mutation_annotated_tree(pb)
+    want = usher_model.run(T2, refio.read_vcf(T2, odd_vcf))
+    for name in want:
+        assert open(str(d / name)).read() == want[name], name

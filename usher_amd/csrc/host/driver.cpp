@@ -42,7 +42,7 @@ struct FlatTree {
     ugp_tree_desc desc{};
     uint32_t epoch = 0;                               // nodes stamped with this epoch carry their index here (Node::flat_index)
     std::vector<uint32_t> leaves;                     // leaves below each node at build time (Tree::get_num_leaves)
-    bool has(const Node *n) const { return n->flat_epoch == epoch; }
+    bool has(const Node *n) const { return epoch != 0 && n->flat_epoch == epoch; }   // (epoch 0: never built)
     void build(const Tree &T) {
         static uint32_t next_epoch = 0;
         epoch = ++next_epoch;
@@ -198,6 +198,71 @@ void node_vecs(const Node *node, const std::vector<Mutation> &sample, NodeVecs &
 }
 
 // ---------------------------------------------------------------------------
+
+// ---------------------------------------------------------------------------
+// The search of usher_common.cpp:389-449 for ONE sample on the host, with the literal routine above at every node.
+// For inputs outside the preconditions of the device algorithm (rows of a sample not strictly increasing by position:
+// the reference's scans then depend on the row order, usher_mapper.cpp:204-242, 393-445; tree alleles that are not
+// one base): such samples never reach the backend, their answers come from here -- slow (N literal evaluations)
+// but the reference's own answer.
+// ---------------------------------------------------------------------------
+struct HostSearch {
+    int best = 0;
+    size_t num_best = 0;
+    Node *best_node = nullptr;
+    bool best_has_unique = false;
+    std::vector<std::pair<Node *, bool>> ties;   // breadth-first order
+    std::vector<int32_t> scores;                 // (want_scores) breadth-first order, +1 where not eligible
+};
+
+static void host_search(const std::vector<Node *> &bfs, const std::vector<Mutation> &sample, bool want_scores, HostSearch &out) {
+    const size_t n = bfs.size();
+    std::unordered_map<const Node *, size_t> idx;
+    idx.reserve(n * 2);
+    for (size_t j = 0; j < n; j++) idx[bfs[j]] = j;
+    std::vector<uint32_t> leaves(n, 0);
+    for (size_t j = n; j-- > 0;) {
+        if (bfs[j]->is_leaf()) leaves[j] = 1;
+        if (bfs[j]->parent) leaves[idx[bfs[j]->parent]] += leaves[j];
+    }
+    out = HostSearch();
+    out.best = INT32_MAX;
+    if (want_scores) out.scores.assign(n, 0);
+    size_t best_j = 0;
+    NodeVecs nv;
+    for (size_t j = 0; j < n; j++) {
+        node_vecs(bfs[j], sample, nv);
+        if (want_scores) out.scores[j] = nv.set_difference + (nv.eligible ? 0 : 1);
+        if (!nv.eligible || nv.set_difference > out.best) continue;
+        if (nv.set_difference < out.best) {
+            out.best = nv.set_difference; out.ties.clear(); out.num_best = 0;
+            out.best_node = bfs[j]; out.best_has_unique = nv.has_unique; best_j = j;
+        } else if (leaves[j] > leaves[best_j] || (leaves[j] == leaves[best_j] && j > best_j)) {   // usher_mapper.cpp:483-486
+            out.best_node = bfs[j]; out.best_has_unique = nv.has_unique; best_j = j;
+        }
+        out.num_best++;
+        out.ties.push_back({bfs[j], nv.has_unique});
+    }
+}
+
+static bool rows_in_order(const std::vector<Mutation> &rows) {
+    for (size_t i = 1; i < rows.size(); i++) if (rows[i].position <= rows[i - 1].position) return false;
+    return true;
+}
+// Rows the backend accepts in place of an out-of-order sample (its answer for them is never used).
+static std::vector<Mutation> ordered_rows(const std::vector<Mutation> &rows) {
+    std::vector<Mutation> v(rows);
+    std::stable_sort(v.begin(), v.end(), by_pos);
+    v.erase(std::unique(v.begin(), v.end(), [](const Mutation &a, const Mutation &b) { return a.position == b.position; }), v.end());
+    return v;
+}
+static bool tree_alleles_are_bases(const Tree &T) {
+    auto one = [](int8_t a) { return a == 1 || a == 2 || a == 4 || a == 8; };
+    for (const auto &kv : T.all_nodes)
+        for (const Mutation &m : kv.second->mutations)
+            if (!m.masked() && (!one(m.mut_nuc) || !one(m.ref_nuc))) return false;
+    return true;
+}
 
 static bool write_text(const std::string &path, const std::string &text) {
     FILE *f = fopen(path.c_str(), "w");
@@ -666,15 +731,24 @@ int run_usher(const Options &opt, Tree &T, std::vector<MissingSample> &missing, 
     if (!missing.empty()) {
         std::vector<size_t> indexes(missing.size());
         std::iota(indexes.begin(), indexes.end(), 0);
-        // The reference sorts sample rows only in the -s/-S pre-pass (:203); its scans need sorted
-        // rows to mean what they say, VCF rows are sorted by position, and the backend requires it.
-        for (auto &ms : missing) std::stable_sort(ms.mutations.begin(), ms.mutations.end(), by_pos);
+        // The reference sorts sample rows only in the -s/-S pre-pass (:203).  Samples whose rows are not strictly
+        // increasing by position (and every sample, if the tree stores alleles that are not one base) are searched on
+        // the host with the literal routine -- `odd`; the backend gets an ordered stand-in whose answer is ignored.
+        if ((opt.sort1 || opt.sort2) && missing.size() > 1 && !opt.print_scores)
+            for (auto &ms : missing) std::sort(ms.mutations.begin(), ms.mutations.end(), by_pos);   // :203
+        const bool host_all = !tree_alleles_are_bases(T);
+        std::vector<uint8_t> odd(missing.size(), 0);
+        size_t n_odd = 0;
+        for (size_t i = 0; i < missing.size(); i++) { odd[i] = host_all || !rows_in_order(missing[i].mutations); n_odd += odd[i]; }
+        if (n_odd) fprintf(stderr, "NOTE: %zu sample(s) outside the preconditions of the GPU search (rows out of order / duplicated, or ambiguous tree alleles) are searched on the host.\n\n", n_odd);
+        auto rows_of = [&](size_t i) -> std::vector<Mutation> { return odd[i] ? ordered_rows(missing[i].mutations) : missing[i].mutations; };
+        HostSearch hs;
 
         const bool static_tree = opt.print_scores || opt.no_add;
         std::vector<ugp_result> batch_res;
         std::vector<int32_t> batch_scores;
         FlatQueries allq;
-        for (auto &ms : missing) allq.add(ms.mutations);
+        for (size_t i = 0; i < missing.size(); i++) allq.add(rows_of(i));
         allq.finish();
 
         if (opt.print_scores) {                                                 // :176-185
@@ -688,7 +762,11 @@ int run_usher(const Options &opt, Tree &T, std::vector<MissingSample> &missing, 
             fprintf(stderr, "Computing parsimony scores and number of parsimony-optimal placements for new samples and using them to sort the samples.\n");
             flat.build(T);
             std::vector<ugp_result> r(missing.size());
-            if (be.place(be.ctx, &flat.desc, tree_version, &allq.desc, r.data()) != 0) return be_fail("placement");
+            if (!host_all && be.place(be.ctx, &flat.desc, tree_version, &allq.desc, r.data()) != 0) return be_fail("placement");
+            for (size_t i = 0; i < missing.size(); i++) if (odd[i]) {
+                host_search(flat.bfs, missing[i].mutations, false, hs);
+                r[i].best_set_difference = hs.best; r[i].num_best = (uint32_t)hs.num_best;
+            }
             auto key1 = [&](size_t i) { return std::make_pair((int64_t)r[i].best_set_difference, (int64_t)r[i].num_best); };
             auto key2 = [&](size_t i) { return std::make_pair((int64_t)r[i].num_best, (int64_t)r[i].best_set_difference); };
             if (opt.sort1) std::stable_sort(indexes.begin(), indexes.end(), [&](size_t a, size_t b) { return key1(a) < key1(b); });
@@ -702,17 +780,24 @@ int run_usher(const Options &opt, Tree &T, std::vector<MissingSample> &missing, 
         if (static_tree) {   // the tree never changes: one batch call serves every sample
             flat.build(T);
             batch_res.resize(missing.size());
-            if (be.place(be.ctx, &flat.desc, tree_version, &allq.desc, batch_res.data()) != 0) return be_fail("placement");
+            if (!host_all && be.place(be.ctx, &flat.desc, tree_version, &allq.desc, batch_res.data()) != 0) return be_fail("placement");
         }
         // -p: the samples x nodes score matrix is produced in slabs of at most ~1 GiB
         size_t slab_base = 0, slab_len = 0;
+        std::vector<int32_t> host_scores;
         auto scores_row = [&](size_t s) -> const int32_t * {
             const size_t n = flat.bfs.size();
+            if (odd[s]) {
+                HostSearch h;
+                host_search(flat.bfs, missing[s].mutations, true, h);
+                host_scores.swap(h.scores);
+                return host_scores.data();
+            }
             if (s >= slab_base + slab_len || s < slab_base) {
                 slab_base = s;
                 slab_len = std::min(missing.size() - s, std::max<size_t>(1, ((size_t)1 << 28) / std::max<size_t>(n, 1)));
                 FlatQueries part;
-                for (size_t k = s; k < s + slab_len; k++) part.add(missing[k].mutations);
+                for (size_t k = s; k < s + slab_len; k++) part.add(rows_of(k));
                 part.finish();
                 batch_scores.resize(slab_len * n);
                 if (be.scores(be.ctx, &flat.desc, tree_version, &part.desc, batch_scores.data()) != 0) return nullptr;
@@ -774,7 +859,14 @@ int run_usher(const Options &opt, Tree &T, std::vector<MissingSample> &missing, 
             bool patched = false, patched_hu = false;
             int patched_best = 0;
             Node *patched_node = nullptr;
-            if (static_tree) r = batch_res[s];
+            if (odd[s]) {   // searched here, on the tree as it is now
+                if (static_tree) host_search(flat.bfs, ms.mutations, false, hs);
+                else host_search(T.bfs(), ms.mutations, false, hs);
+                tie_now.clear();
+                for (auto &t : hs.ties) tie_now.push_back({t.first, t.second});
+                patched = true; patched_best = hs.best; patched_node = hs.best_node; patched_hu = hs.best_has_unique;
+                r = ugp_result{};
+            } else if (static_tree) r = batch_res[s];
             else {
                 // need_flat: flatten the current tree again; need_batch: place the next batch of samples (on the
                 // tree as flattened last -- not necessarily the current one)
@@ -794,7 +886,7 @@ int run_usher(const Options &opt, Tree &T, std::vector<MissingSample> &missing, 
                                                                                                   : std::max<size_t>(spec_len / 2, 16);      // cut short: shrink
                         spec_len = std::min(spec_next, indexes.size() - ii);
                         FlatQueries rest;
-                        for (size_t k = ii; k < ii + spec_len; k++) rest.add(missing[indexes[k]].mutations);
+                        for (size_t k = ii; k < ii + spec_len; k++) rest.add(rows_of(indexes[k]));
                         rest.finish();
                         spec_res.assign(spec_len, ugp_result{});
                         if (be.place(be.ctx, &flat.desc, flat_version, &rest.desc, spec_res.data()) != 0) { fclose(stats); return be_fail("placement"); }
@@ -804,7 +896,7 @@ int run_usher(const Options &opt, Tree &T, std::vector<MissingSample> &missing, 
                             FlatQueries tq;
                             std::vector<size_t> who;
                             for (size_t k = touched.empty() ? 1 : 0; k < spec_len; k++)   // (on a fresh tree sample 0 is consumed as it is)
-                                if (spec_res[k].num_best > 1 && spec_res[k].num_best <= kTieCap) { who.push_back(k); tq.add(missing[indexes[ii + k]].mutations); }
+                                if (!odd[indexes[ii + k]] && spec_res[k].num_best > 1 && spec_res[k].num_best <= kTieCap) { who.push_back(k); tq.add(missing[indexes[ii + k]].mutations); }
                             if (!who.empty()) {
                                 tq.finish();
                                 std::vector<uint32_t> tj(who.size() * (size_t)kTieCap), tc(who.size());
