@@ -131,7 +131,10 @@ def main():
     t_few_b, o_fb, _ = run(d + "/few.vcf", {}, [])
     t_few_r, o_fr, _ = run(d + "/few.vcf", {"USHER_AMD_MAX_TOUCHED": "0"}, [])
     same = all(open(os.path.join(o_fb, n)).read() == open(os.path.join(o_fr, n)).read() for n in ("placement_stats.tsv", "final-tree.nh"))
-    t_all, o_all, err = run(d + "/new.vcf", {}, [])
+    t_all, o_all, err = run(d + "/new.vcf", {"USHER_AMD_PROFILE": "1", "UGP_FLATTEN_VERBOSE": os.environ.get("UGP_FLATTEN_VERBOSE", "")}, [])
+    for line in err.splitlines():
+        if line.startswith("[usher-amd profile]") or line.startswith("[ugp flatten]"):
+            sys.stderr.write(line + "\n")
     ties = sum(1 for l in open(os.path.join(o_all, "placement_stats.tsv")) if l.split("\t")[2] != "1")
     print(json.dumps({"metric": "sequential sample insertions/sec (default usher mode, bin/usher-amd)", "nodes": int(st.arrays["n"]),
                       "samples": a.samples, "value": round(a.samples / max(t_all - t_load, 1e-9), 2), "unit": "samples/s",

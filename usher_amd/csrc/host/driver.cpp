@@ -245,6 +245,88 @@ static void host_search(const std::vector<Node *> &bfs, const std::vector<Mutati
     }
 }
 
+// ---------------------------------------------------------------------------
+// Closed-form evaluation of ONE node for a sample whose rows are in order (the same formulas the
+// device kernels evaluate, proven equal to the literal routine in tests/test_closed_form.py): used by the add mode to
+// re-derive batched answers on the nodes touched since the batch was placed -- a few thousand (sample, node) pairs
+// per insertion, for which the literal routine's list scans (~1 us each) were the second largest cost.
+//   D(parent) = D(bottom) + sum over positions where the parent's state differs from the reference of
+//               ([state not in S] - [ref not in S]);   cost = D(parent) + sum over own mutations of min(delta, 0)
+// The parent's state is cached per touched node; an insertion never changes the state at an existing node
+// (usher_common.cpp:652-765 only splits one branch in two), so the cache stays valid until the node is touched again.
+// ---------------------------------------------------------------------------
+struct TouchedInfo {
+    struct PathEnt { int32_t pos; uint8_t allele, ref; };
+    struct Own { int32_t pos; uint8_t mut, prev, ref; };
+    std::vector<PathEnt> path;   // positions where the parent's state is not the reference base
+    std::vector<Own> own;        // the node's mutations in front of its first masked one
+    bool masked = false;
+};
+
+struct DenseSample {             // S(p) of one sample as an array over positions: 0 = no row (reference base)
+    std::vector<uint8_t> s;
+    int dbot = 0;
+    void set(const std::vector<Mutation> &rows) {
+        dbot = 0;
+        for (const Mutation &m : rows) {
+            if (m.position < 0) continue;
+            if ((size_t)m.position >= s.size()) s.resize((size_t)m.position * 2 + 1024, 0);
+            const uint8_t a = m.is_missing ? 15 : (uint8_t)m.mut_nuc;
+            s[m.position] = a;
+            if (!m.is_missing && (a & (uint8_t)m.ref_nuc) == 0) dbot++;
+        }
+    }
+    void clear(const std::vector<Mutation> &rows) { for (const Mutation &m : rows) if (m.position >= 0) s[m.position] = 0; }
+    uint8_t at(int32_t p, uint8_t ref) const { return ((size_t)p < s.size() && s[p]) ? s[p] : ref; }
+};
+
+struct TouchedCache {
+    std::unordered_map<const Node *, TouchedInfo> info;
+    std::vector<uint32_t> mark;      // per position: stamp of the walk that set `state`
+    std::vector<uint8_t> state;
+    uint32_t stamp = 0;
+    void build(const Node *x) {
+        TouchedInfo &ti = info[x];
+        ti.path.clear(); ti.own.clear(); ti.masked = false;
+        if (++stamp == 0) { std::fill(mark.begin(), mark.end(), 0u); stamp = 1; }
+        auto touch = [&](int32_t p) { if ((size_t)p >= mark.size()) { mark.resize((size_t)p * 2 + 1024, 0); state.resize(mark.size(), 0); } };
+        for (const Node *a = x->parent; a; a = a->parent)
+            for (const Mutation &m : a->mutations) {
+                if (m.masked()) continue;
+                touch(m.position);
+                if (mark[m.position] == stamp) continue;          // a more recent mutation at this position was seen below
+                mark[m.position] = stamp; state[m.position] = (uint8_t)m.mut_nuc;
+                if (m.mut_nuc != m.ref_nuc) ti.path.push_back({m.position, (uint8_t)m.mut_nuc, (uint8_t)m.ref_nuc});
+            }
+        for (const Mutation &m : x->mutations) {
+            if (m.masked()) { ti.masked = true; break; }
+            touch(m.position);
+            const uint8_t prev = mark[m.position] == stamp ? state[m.position] : (uint8_t)m.ref_nuc;
+            ti.own.push_back({m.position, (uint8_t)m.mut_nuc, prev, (uint8_t)m.ref_nuc});
+        }
+    }
+    // (eligible, cost, has_unique) of usher_mapper.cpp:454-455 / :172-445 for node x (not the root)
+    void eval(const Node *x, const DenseSample &S, bool &eligible, int &cost, bool &has_unique) const {
+        const TouchedInfo &ti = info.at(x);
+        int D = S.dbot;
+        for (const auto &e : ti.path) {
+            const uint8_t sp = S.at(e.pos, e.ref);
+            D += ((sp & e.allele) == 0) - ((sp & e.ref) == 0);
+        }
+        int neg = 0, common = 0;
+        const int num_mut = (int)ti.own.size() + (ti.masked ? 1 : 0);
+        for (const auto &o : ti.own) {
+            const uint8_t sp = S.at(o.pos, o.ref);
+            const int c = (sp & o.mut) != 0, pr = (sp & o.prev) != 0;
+            common += c;
+            if (pr - c < 0) neg += pr - c;
+        }
+        cost = D + neg;
+        eligible = common > 0 || (!x->is_leaf() && num_mut == 0);
+        has_unique = ti.masked || common != num_mut;
+    }
+};
+
 static bool rows_in_order(const std::vector<Mutation> &rows) {
     for (size_t i = 1; i < rows.size(); i++) if (rows[i].position <= rows[i - 1].position) return false;
     return true;
@@ -815,6 +897,9 @@ int run_usher(const Options &opt, Tree &T, std::vector<MissingSample> &missing, 
         // breadth-first order.  The tree is flattened and placed again only when `touched` grows past
         // max_touched, when a tie list was too long to keep, or when every batched optimum was rewritten
         // and no touched node is at least as good.
+        // USHER_AMD_PROFILE=1: where the add mode spends its time (printed once at the end)
+        struct Prof { double build = 0, place = 0, ties = 0, touched = 0; size_t flats = 0, batches = 0, evals = 0; } prof;
+        auto now_s = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
         std::vector<ugp_result> spec_res;
         size_t spec_base = 0, spec_len = 0, spec_next = 64;   // batch length adapts to how long answers survive
         bool have_spec = false;
@@ -824,13 +909,17 @@ int run_usher(const Options &opt, Tree &T, std::vector<MissingSample> &missing, 
         std::unordered_map<const Node *, size_t> added_leaves;   // leaves gained below a node since `flat` was built
         std::vector<std::vector<std::pair<uint32_t, uint8_t>>> spec_ties;   // per batched sample with 1 < num_best <= kTieCap
         const uint32_t kTieCap = 256;
-        // |touched| at which the tree is flattened again.  Re-deriving an answer costs ~10 us per touched node,
-        // a flatten + batch placement costs t_redo and is amortised over ~|touched|/3 insertions, so the
-        // total is least near sqrt(3 t_redo / 10 us): ~20 for a 1k-node tree, ~900 for a 10M-node one.
+        // |touched| at which the tree is flattened again.  Re-deriving an answer costs c ~ 0.15 us per touched node
+        // (closed form; ~1 us with the literal routine), a flatten + batch placement costs t_redo and is amortised
+        // over ~|touched|/3 insertions, so the total is least near sqrt(3 t_redo / c): ~150 for a 1k-node tree,
+        // ~8,000 for a 10M-node one (t_redo ~ 3 s).
         size_t max_touched = 64;
         const bool fixed_cap = getenv("USHER_AMD_MAX_TOUCHED") != nullptr;
         if (fixed_cap) max_touched = (size_t)atoll(getenv("USHER_AMD_MAX_TOUCHED"));
         NodeVecs probe;
+        TouchedCache tcache;
+        DenseSample dense;
+        const bool literal_touched = getenv("USHER_AMD_LITERAL_TOUCHED") != nullptr;   // cross-check switch: literal routine instead of the closed form
         auto leaves_now = [&](const Node *n) -> size_t {
             size_t v = 0;
             if (flat.has(n)) v = flat.leaves[n->flat_index];
@@ -876,10 +965,13 @@ int run_usher(const Options &opt, Tree &T, std::vector<MissingSample> &missing, 
                     if (need_batch) {
                         const auto t_redo0 = std::chrono::steady_clock::now();
                         if (need_flat) {
+                            const double tb = now_s();
                             flat.build(T);
+                            prof.build += now_s() - tb; prof.flats++;
                             flat_version = tree_version;
                             touched.clear();
                             touched_set.clear();
+                            tcache.info.clear();
                             added_leaves.clear();
                         }
                         if (have_spec) spec_next = (attempt == 0 && ii >= spec_base + spec_len) ? std::min<size_t>(2 * spec_len, 4096)   // consumed whole: grow
@@ -889,7 +981,9 @@ int run_usher(const Options &opt, Tree &T, std::vector<MissingSample> &missing, 
                         for (size_t k = ii; k < ii + spec_len; k++) rest.add(rows_of(indexes[k]));
                         rest.finish();
                         spec_res.assign(spec_len, ugp_result{});
+                        const double tp = now_s();
                         if (be.place(be.ctx, &flat.desc, flat_version, &rest.desc, spec_res.data()) != 0) { fclose(stats); return be_fail("placement"); }
+                        prof.place += now_s() - tp; prof.batches++;
                         // tie lists of the batch (needed to re-derive a tied answer after later insertions)
                         spec_ties.assign(spec_len, {});
                         if (!opt.no_add && be.ties) {
@@ -901,7 +995,9 @@ int run_usher(const Options &opt, Tree &T, std::vector<MissingSample> &missing, 
                                 tq.finish();
                                 std::vector<uint32_t> tj(who.size() * (size_t)kTieCap), tc(who.size());
                                 std::vector<uint8_t> th(who.size() * (size_t)kTieCap);
+                                const double tt = now_s();
                                 if (be.ties(be.ctx, &flat.desc, flat_version, &tq.desc, kTieCap, tj.data(), th.data(), tc.data()) != 0) { fclose(stats); return be_fail("tie listing"); }
+                                prof.ties += now_s() - tt;
                                 for (size_t w = 0; w < who.size(); w++) {
                                     if (tc[w] != spec_res[who[w]].num_best) continue;   // (cannot happen; without a full list the sample is searched again)
                                     for (uint32_t k = 0; k < tc[w]; k++) spec_ties[who[w]].push_back({tj[w * kTieCap + k], th[w * kTieCap + k]});
@@ -910,7 +1006,7 @@ int run_usher(const Options &opt, Tree &T, std::vector<MissingSample> &missing, 
                         }
                         if (!fixed_cap && need_flat) {
                             const double t_redo = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_redo0).count();
-                            max_touched = (size_t)std::min(4096.0, std::max(16.0, std::sqrt(3.0 * t_redo / 1e-5)));
+                            max_touched = (size_t)std::min(65536.0, std::max(16.0, std::sqrt(3.0 * t_redo / (literal_touched ? 1e-6 : 1.5e-7))));
                         }
                         spec_base = ii;
                         have_spec = true;
@@ -937,12 +1033,19 @@ int run_usher(const Options &opt, Tree &T, std::vector<MissingSample> &missing, 
                             }
                             int m_best = INT32_MAX;
                             std::vector<Tie> m_ties;
+                            const double te = now_s();
+                            prof.evals += touched.size();
+                            if (!literal_touched) dense.set(ms.mutations);
                             for (Node *tn : touched) {
-                                node_vecs(tn, ms.mutations, probe);
-                                if (!probe.eligible) continue;
-                                if (probe.set_difference < m_best) { m_best = probe.set_difference; m_ties.clear(); }
-                                if (probe.set_difference == m_best) m_ties.push_back({tn, probe.has_unique});
+                                bool el, hu; int cost;
+                                if (literal_touched || tn->is_root()) { node_vecs(tn, ms.mutations, probe); el = probe.eligible; hu = probe.has_unique; cost = probe.set_difference; }
+                                else tcache.eval(tn, dense, el, cost, hu);
+                                if (!el) continue;
+                                if (cost < m_best) { m_best = cost; m_ties.clear(); }
+                                if (cost == m_best) m_ties.push_back({tn, hu});
                             }
+                            if (!literal_touched) dense.clear(ms.mutations);
+                            prof.touched += now_s() - te;
                             if (tie_now.empty()) {
                                 // every node that was optimal has been rewritten: the untouched nodes are only known
                                 // to cost more than base_best, which decides the matter only if a touched node does not
@@ -1042,6 +1145,7 @@ int run_usher(const Options &opt, Tree &T, std::vector<MissingSample> &missing, 
                         size_t keep = t0;   // `touched` lists every node once
                         for (size_t k = t0; k < touched.size(); k++) {
                             if (touched[k]->is_leaf() && touched[k] != best_node) leaf = touched[k];
+                            if (!touched[k]->is_root()) tcache.build(touched[k]);   // (again if it was touched before: its branch changed)
                             if (touched_set.insert(touched[k]).second) touched[keep++] = touched[k];
                         }
                         touched.resize(keep);
@@ -1067,6 +1171,10 @@ int run_usher(const Options &opt, Tree &T, std::vector<MissingSample> &missing, 
         }
         fclose(stats);
         if (scores_file) fclose(scores_file);
+        if (getenv("USHER_AMD_PROFILE"))
+            fprintf(stderr, "[usher-amd profile] tree -> arrays %.3f s (%zu times), batched placement %.3f s (%zu batches), tie lists %.3f s, "
+                            "touched-node evaluation %.3f s (%zu node evaluations)\n", prof.build, prof.flats, prof.place, prof.batches, prof.ties,
+                    prof.touched, prof.evals);
     }
     if (opt.print_scores) return 0;                                             // :800-805
     std::vector<Tree *> trees{&T};
