@@ -909,10 +909,10 @@ int run_usher(const Options &opt, Tree &T, std::vector<MissingSample> &missing, 
         std::unordered_map<const Node *, size_t> added_leaves;   // leaves gained below a node since `flat` was built
         std::vector<std::vector<std::pair<uint32_t, uint8_t>>> spec_ties;   // per batched sample with 1 < num_best <= kTieCap
         const uint32_t kTieCap = 256;
-        // |touched| at which the tree is flattened again.  Re-deriving an answer costs c ~ 0.15 us per touched node
+        // |touched| at which the tree is flattened again.  Re-deriving an answer costs c ~ 0.05 us per touched node
         // (closed form; ~1 us with the literal routine), a flatten + batch placement costs t_redo and is amortised
-        // over ~|touched|/3 insertions, so the total is least near sqrt(3 t_redo / c): ~150 for a 1k-node tree,
-        // ~8,000 for a 10M-node one (t_redo ~ 3 s).
+        // over ~|touched|/3 insertions, so the total is least near sqrt(3 t_redo / c): ~250 for a 1k-node tree,
+        // ~14,000 for a 10M-node one (t_redo ~ 3 s).
         size_t max_touched = 64;
         const bool fixed_cap = getenv("USHER_AMD_MAX_TOUCHED") != nullptr;
         if (fixed_cap) max_touched = (size_t)atoll(getenv("USHER_AMD_MAX_TOUCHED"));
@@ -1006,7 +1006,7 @@ int run_usher(const Options &opt, Tree &T, std::vector<MissingSample> &missing, 
                         }
                         if (!fixed_cap && need_flat) {
                             const double t_redo = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_redo0).count();
-                            max_touched = (size_t)std::min(65536.0, std::max(16.0, std::sqrt(3.0 * t_redo / (literal_touched ? 1e-6 : 1.5e-7))));
+                            max_touched = (size_t)std::min(65536.0, std::max(16.0, std::sqrt(3.0 * t_redo / (literal_touched ? 1e-6 : 5e-8))));
                         }
                         spec_base = ii;
                         have_spec = true;
