@@ -83,24 +83,40 @@ __global__ void k_scatter_entries(uint32_t *__restrict__ table, uint32_t *__rest
                                   uint32_t max_pos, uint32_t n_sites, uint64_t n_ent, uint32_t q_base,
                                   uint32_t *__restrict__ active, uint32_t active_words,
                                   const uint32_t *__restrict__ slot_of) {
-    uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= n_ent) return;
-    uint32_t q = ent_q[e] - q_base;         // sample index within this launch
-    if (slot_of) q = slot_of[q];            // ... and its place in the locality-sorted tiles
-    const int32_t p = pos[e];
-    const uint32_t r = ref[e];
-    const uint32_t miss = is_missing[e];
-    const uint32_t a = miss ? 15u : (uint32_t)nuc[e];
-    if (!miss && (a & r) == 0) atomicAdd(&dbottom[q], 1u);
-    if (p < 0 || (uint32_t)p > max_pos) return;
+    const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool valid = e < n_ent;
+    uint32_t q = 0, r = 0, a = 0, miss = 1;
+    int32_t p = -1;
+    if (valid) {
+        q = ent_q[e] - q_base;                  // sample index within this launch
+        if (slot_of) q = slot_of[q];            // ... and its place in the locality-sorted tiles
+        p = pos[e];
+        r = ref[e];
+        miss = is_missing[e];
+        a = miss ? 15u : (uint32_t)nuc[e];
+    }
+    // D_bottom.  The rows of a sample are consecutive, so a wave usually serves one sample: one atomic per wave
+    // instead of one per row (same-address atomics of a wave are executed one after another).
+    const bool mism = valid && !miss && (a & r) == 0;
+    const unsigned long long mm = __builtin_amdgcn_ballot_w64(mism);
+    const uint32_t q0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)q);
+    if (__builtin_amdgcn_ballot_w64(valid && q != q0) == 0) {
+        if (mm && (threadIdx.x & 63u) == (uint32_t)__builtin_ctzll(mm)) atomicAdd(&dbottom[q0], (uint32_t)__builtin_popcountll(mm));
+    } else if (mism) atomicAdd(&dbottom[q], 1u);
+    if (!valid || p < 0 || (uint32_t)p > max_pos) return;
     const int32_t site = pos2site[p];
     if (site < 0) return;
     const uint32_t tile = q >> 9, within = q & 511;
     uint32_t *w = table + ((uint64_t)tile * (n_sites + TABLE_CONST_ROWS) + TABLE_CONST_ROWS + (uint32_t)site) * 64 + (within >> 3);
     const uint32_t sh = (within & 7) * 4;
     atomicXor(w, ((r ^ a) & 15u) << sh);   // nibble was r (k_fill_table); rows are unique per (sample, position)
-    // the row of (tile, site) is no longer "reference everywhere"
-    if (r != a) atomicOr(&active[(uint64_t)tile * active_words + ((uint32_t)site >> 5)], 1u << ((uint32_t)site & 31u));
+    // the row of (tile, site) is no longer "reference everywhere" (look before setting: after the first few samples of a
+    // tile most bits are set, and a run of N cells hits the same word with every lane)
+    if (r != a) {
+        uint32_t *aw = &active[(uint64_t)tile * active_words + ((uint32_t)site >> 5)];
+        const uint32_t bit = 1u << ((uint32_t)site & 31u);
+        if (!(__hip_atomic_load(aw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & bit)) atomicOr(aw, bit);
+    }
 }
 
 // Query rows on arrival (one thread per VCF row): the sample each row belongs to (binary search in the CSR
