@@ -258,6 +258,8 @@ def main():
                     # the kernel is bound by instruction issue, not HBM: fractions of the chip's VALU / scalar issue slots
                     # over the kernel's duration, from the same stored profile
                     "valu_issue_frac": prof.get("valu_issue_frac"), "salu_issue_frac": prof.get("salu_issue_frac"),
+                    "valu_active_frac_measured": prof.get("valu_active_frac_measured"), "salu_busy_frac_measured": prof.get("salu_busy_frac_measured"),
+                    "wave_wait_frac": prof.get("wave_wait_frac"),
                     "kernel": "k_best8" if packed else "k_place<0>", "tile_samples": T, "kernel_ms": round(k_ms, 4), "algo_bytes_per_launch": int(algo_bytes),
                     "node_plus_mut_evals_decided_per_s": round(node_evals / (k_ms * 1e-3), 1) if k_ms > 0 else 0.0,
                     "coarse_ms": round(coarse_ms / args.steps, 4), "table_ms": round(table_ms / args.steps, 4), "merge_ms": round(merge_ms / args.steps, 4),

@@ -84,6 +84,13 @@ for k, e in summary["kernels"].items():
             e["salu_issue_frac"] = (e["SQ_INSTS_SALU_per_dispatch"] + e.get("SQ_INSTS_SMEM_per_dispatch", 0.0)) / (256 * 2.4e9 * t)
     if "SQ_INST_CYCLES_SALU_per_dispatch" in e and e.get("SQ_BUSY_CU_CYCLES_per_dispatch"):
         e["salu_busy_frac_measured"] = e["SQ_INST_CYCLES_SALU_per_dispatch"] / e["SQ_BUSY_CU_CYCLES_per_dispatch"]
+    # SQ_ACTIVE_INST_VALU counts quad-cycles in which a wave has a vector instruction in flight: x4 / (SIMD-cycles of the
+    # dispatch) = how busy the vector pipes were by the SQ's own account (tools/micro/issue_rate.hip: plain 32-bit VALU
+    # issues every 2 cycles per SIMD, v_pk_*_u16 and v_readlane every 4)
+    if "SQ_ACTIVE_INST_VALU_per_dispatch" in e and "avg_duration_ns_full_dispatch" in e:
+        e["valu_active_frac_measured"] = e["SQ_ACTIVE_INST_VALU_per_dispatch"] * 4 / (256 * 4 * 2.4e9 * e["avg_duration_ns_full_dispatch"] * 1e-9)
+    if "SQ_WAIT_ANY_per_dispatch" in e and e.get("SQ_WAVE_CYCLES_per_dispatch"):
+        e["wave_wait_frac"] = e["SQ_WAIT_ANY_per_dispatch"] / e["SQ_WAVE_CYCLES_per_dispatch"]
 with open(os.path.join(prof, tag + "_pmc_summary.json"), "w") as f:
     json.dump(summary, f, indent=1, sort_keys=True)
 print(json.dumps({k: {c: round(v, 3) for c, v in e.items()} for k, e in summary["kernels"].items() if "best8" in k}, indent=1))

@@ -86,6 +86,8 @@ struct ugp_mat {
     DevBuf<uint32_t> d_lbest, d_gbest, d_gbest_part, d_items, d_ub, d_gstart, d_hlen, d_cold, d_list;
     DevBuf<uint64_t> d_stats;
     uint64_t last_words_total = 0;
+    const uint32_t *last_list_n = nullptr;   // (UGP_STATS) record counts of the last packed launch, per 512-sample tile
+    uint32_t last_list_tiles = 0;
     // locality sort (speed only): a coarse MAT of the top of the tree and the map coarse BFS index -> DFS rank in the full tree
     ugp_mat *coarse = nullptr;
     DevBuf<uint32_t> d_coarse2dfs, d_keys, d_keys2, d_idx, d_order, d_slot;
@@ -305,6 +307,7 @@ int run_place(ugp_mat *m, ugp_qset *qs, int mode, ugp_result *d_out, int32_t *d_
             b.n_sites = n_sites; b.n_chunks = f.n_chunks; b.n_groups = G; b.n_tiles = n_tiles512;
             b.lbest = m->d_lbest.p;
             b.list = m->d_list.p; b.list_n = d_list_n;
+            m->last_list_n = d_list_n; m->last_list_tiles = n_tiles512;
             b.queue = d_queue;
             b.ub = getenv("UGP_NO_PRUNE") ? nullptr : m->d_ub.p;
             if (sorted && !getenv("UGP_NO_LPT")) {   // hand out every tile's own region first (scheduling only)
@@ -955,6 +958,14 @@ int ugp_get_timing(ugp_mat *m, ugp_timing *out) {
                 fprintf(stderr, "\n[ugp stats] jumps decided by the first node after a restart=%llu", (unsigned long long)v[26]);
                 fprintf(stderr, "\n[ugp stats] own-region units=%llu cycles=%llu   other units=%llu cycles=%llu\n", (unsigned long long)v[29],
                         (unsigned long long)v[27], (unsigned long long)v[30], (unsigned long long)v[28]);
+                if (m->last_list_n && m->last_list_tiles) {
+                    std::vector<uint32_t> ln(m->last_list_tiles);
+                    HIP_TRY(hipMemcpy(ln.data(), m->last_list_n, ln.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+                    uint64_t rec = 0;
+                    for (uint32_t x : ln) rec += x;
+                    fprintf(stderr, "[ugp stats] chunk records stored by phase 1: %llu of %llu (chunk, tile) pairs = %.1f MB\n", (unsigned long long)rec,
+                            (unsigned long long)m->flat.n_chunks * m->last_list_tiles, rec * 1024.0 / 1e6);
+                }
             }
         }
         m->timing_pending = false;
