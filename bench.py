@@ -21,6 +21,7 @@ Rank 0 prints ONE JSON line.
 """
 import argparse
 import glob
+import re
 import json
 import os
 import subprocess
@@ -105,7 +106,10 @@ def stored_profile(info, Q, packed):
     """HBM traffic and instruction-issue counters of the dominant kernel from the newest committed rocprofv3 PMC
     summary of this same workload (tools/profile_round.sh -> profiles/rNN_pmc_summary.json); None when absent."""
     try:
-        for fn in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.json")), reverse=True):
+        def round_key(fn):   # rNN_ (a round's final profile) outranks its lettered intermediates rNNa_, rNNb_, ...
+            m = re.match(r"r(\d+)([a-z]*)_", os.path.basename(fn))
+            return (int(m.group(1)), m.group(2) == "", m.group(2)) if m else (-1, False, "")
+        for fn in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.json")), key=round_key, reverse=True):
             with open(fn) as f:
                 ps = json.load(f)
             cfg = ps.get("bench", {}).get("config", {})

@@ -503,6 +503,40 @@ def test_config5_high_ambiguity_results_and_tie_lists(monkeypatch):
             assert ties[i].tolist() == w["ties"].tolist()
 
 
+def test_sars2_shape_10m_nodes_full_size(monkeypatch):
+    """The SARS-CoV-2-shaped generator of `bench.py --shape sars2` (polytomies, recent-biased attachment, skewed
+    site spectrum, queries next to recent leaves) at the headline size: packed path == 32-bit kernel == permuted
+    batch for every sample, 1,536 samples against the closed form, 16 against the literal oracle."""
+    from usher_amd import synth as gsynth
+    for k in ("UGP_FORCE_V1", "UGP_NO_SORT", "UGP_NO_PRUNE", "UGP_COARSE_MIN_NODES"):
+        monkeypatch.delenv(k, raising=False)
+    st = gsynth.SynthTree(10_000_000, n_sites=25000, seed=3, shape="sars2")
+    q = st.queries(8192, seed=99, recent=True)
+    batch = _csr_batch(q)
+    pl = Placer(st.arrays)
+    assert pl.info()["n_nodes"] >= 9_000_000
+    fast = pl.place(batch)
+    assert pl.timing()["packed_path"] == 1
+    perm = np.random.default_rng(9).permutation(len(batch))
+    shuffled = pl.place(QueryBatch([gsynth.csr_sample(q, int(i)) for i in perm]))
+    assert (_rows(shuffled) == _rows(fast)[perm]).all()
+    monkeypatch.setenv("UGP_FORCE_V1", "1")
+    slow = pl.place(batch)
+    assert pl.timing()["packed_path"] == 0
+    monkeypatch.delenv("UGP_FORCE_V1")
+    assert (_rows(slow) == _rows(fast)).all()
+    pl.close()
+    ot = capi.OracleTree(st.arrays)
+    n_cf = 1536
+    e1 = int(q["ent_off"][n_cf])
+    cf = capi.ClosedFormC(ot).place_csr(q["ent_off"][:n_cf + 1], q["pos"][:e1], q["ref"][:e1], q["nuc"][:e1], q["is_missing"][:e1])
+    assert (_rows(fast)[:n_cf] == _cf_rows(cf)).all()
+    threads = os.cpu_count() or 1
+    for i in range(4000, 4016):
+        w = ot.place_mt(gsynth.csr_sample(q, i), threads)
+        assert (w["best"], w["num_best"], w["best_j"]) == (int(fast["best_set_difference"][i]), int(fast["num_best"][i]), int(fast["best_j"][i])), i
+
+
 @pytest.mark.parametrize("coarse", [False, True])
 def test_sixteen_bit_boundary_of_the_packed_path(coarse, monkeypatch):
     """Costs right below the largest value the packed 16-bit path admits (the shared upper bounds start at
