@@ -177,3 +177,66 @@ def test_summaries_of_top_level_subtrees_are_exact(seed, chunk_nodes, monkeypatc
             assert [c for c in range(n_chunks) if lb_sum[c] == want["best"]] == [c for c in range(n_chunks) if lb_plain[c] == want["best"]]
             skipped += st.get("summary_skipped", 0)
     assert skipped > len(flat.stream8)
+
+
+def _flat_arrays(arrays, **kw):
+    v = FlatTreeView(arrays, **kw)
+    out = {}
+    for name in dir(v):
+        a = getattr(v, name)
+        if not name.startswith("_") and isinstance(a, (np.ndarray, int, bool)):
+            out[name] = np.array(a)
+    return out
+
+
+@pytest.mark.parametrize("kind", ["random", "masked", "caterpillar", "polytomy", "synth200k", "not_bfs"])
+def test_flattening_does_not_depend_on_the_thread_count(kind, monkeypatch):
+    """The flattening runs on host threads (level passes, DFS segments, chunks); every stream must be bit-identical
+    whatever the number of threads, including more threads than work."""
+    from usher_amd import synth as gsynth
+    kw = {"chunk_nodes": 24}
+    if kind == "random":
+        arrays, _ = synth.make_case(5, n_leaves=900, n_queries=1, n_sites=150)
+    elif kind == "masked":
+        arrays, _ = synth.make_case(41, n_leaves=400, n_queries=1, n_sites=60, p_masked=0.15, root_muts=3)
+    elif kind == "caterpillar":
+        arrays, _ = synth.caterpillar_case(3, depth=600, muts_per_node=2, n_queries=1)
+    elif kind == "polytomy":
+        arrays, _ = synth.polytomy_case(4, n_queries=1)
+    elif kind == "synth200k":
+        arrays, kw = gsynth.SynthTree(200_000, n_sites=3000, seed=9, shape="sars2").arrays, {}
+    else:   # parents before children but not a breadth-first order: the serial fallback of the level passes
+        arrays, _ = synth.make_case(6, n_leaves=300, n_queries=1, n_sites=80)
+        par = np.asarray(arrays["parent"]).astype(np.int64)
+        n = len(par)
+        order = [0]
+        kids = [[] for _ in range(n)]
+        for j in range(1, n):
+            kids[par[j]].append(j)
+        stack, order = [0], []
+        while stack:                       # preorder: every parent still precedes its children
+            v = stack.pop()
+            order.append(v)
+            stack.extend(reversed(kids[v]))
+        new = np.empty(n, np.int64)
+        new[order] = np.arange(n)
+        off = np.asarray(arrays["mut_off"]).astype(np.int64)
+        cnt = np.diff(off)[order]
+        noff = np.concatenate([[0], np.cumsum(cnt)])
+        take = np.concatenate([np.arange(off[v], off[v + 1]) for v in order]) if off[-1] else np.zeros(0, np.int64)
+        arrays = dict(arrays)
+        arrays["parent"] = np.array([-1 if par[v] < 0 else new[par[v]] for v in order], dtype=np.asarray(arrays["parent"]).dtype)
+        arrays["mut_off"] = noff.astype(np.asarray(arrays["mut_off"]).dtype)
+        for k in ("mut_pos", "mut_ref", "mut_par", "mut_nuc"):
+            if k in arrays:
+                arrays[k] = np.asarray(arrays[k])[take]
+    monkeypatch.setenv("UGP_FLATTEN_THREADS", "1")
+    ref = _flat_arrays(arrays, **kw)
+    if kind != "synth200k":
+        monkeypatch.setenv("UGP_FLATTEN_GRAIN", "1")   # split even the smallest passes
+    for threads in ("2", "5", "64"):
+        monkeypatch.setenv("UGP_FLATTEN_THREADS", threads)
+        got = _flat_arrays(arrays, **kw)
+        assert set(got) == set(ref)
+        for k in ref:
+            assert got[k].shape == ref[k].shape and (got[k] == ref[k]).all(), (k, threads)

@@ -56,7 +56,8 @@ struct DevBuf {
         if (e == hipSuccess) cap = n; else p = nullptr;
         return e;
     }
-    hipError_t upload(const std::vector<T> &v) {
+    template <class V>
+    hipError_t upload(const V &v) {
         hipError_t e = reserve(v.size());
         if (e != hipSuccess || v.empty()) return e;
         return hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice);

@@ -3,7 +3,10 @@
 // suite can exercise it without a GPU.
 #pragma once
 #include <cstdint>
+#include <memory>
+#include <new>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "usher_amd.h"
@@ -103,30 +106,42 @@ struct Options {
     bool sibling_records = true;   // emit H_INFO | H_SIB records
     uint32_t lds_slots = LDS_SLOTS; // headers whose (renumbered) slots are >= this are flagged H_SLOW
     uint32_t super_chunks = SUPER_CHUNKS;   // chunks per summary
+    uint32_t threads = 0;       // host threads (0 = UGP_FLATTEN_THREADS, else min(32, hardware threads)); the output does not depend on it
 };
+
+// Vector whose resize() leaves new elements uninitialised: the big streams are sized first and then written in
+// full by the flattening threads, so their pages are first touched in parallel instead of being zeroed by one thread.
+template <class T>
+struct DefaultInit : std::allocator<T> {
+    template <class U> struct rebind { using other = DefaultInit<U>; };
+    using std::allocator<T>::allocator;
+    template <class U> void construct(U *p) noexcept { ::new (static_cast<void *>(p)) U; }
+    template <class U, class... A> void construct(U *p, A &&...a) { ::new (static_cast<void *>(p)) U(std::forward<A>(a)...); }
+};
+template <class T> using UVec = std::vector<T, DefaultInit<T>>;
 
 struct FlatMat {
     uint64_t n_nodes = 0, n_muts = 0, n_sites = 0;
     uint32_t max_pos = 0, max_slots = 0, n_chunks = 0;
-    std::vector<uint32_t> stream;          // node records, DFS order
-    std::vector<uint32_t> pre_stream;      // per-chunk preamble records (root path of the chunk's first node)
+    UVec<uint32_t> stream;          // node records, DFS order
+    UVec<uint32_t> pre_stream;      // per-chunk preamble records (root path of the chunk's first node)
     std::vector<uint32_t> chunk_body_off;  // [n_chunks+1] dword offsets into stream
     std::vector<uint32_t> chunk_pre_off;   // [n_chunks+1] dword offsets into pre_stream
     std::vector<uint32_t> chunk_node_off;  // [n_chunks+1] DFS index of the chunk's first node
     std::vector<int32_t> pos2site;         // [max_pos+1], -1 = position never mutated in the tree
     std::vector<uint8_t> site_ref;         // [n_sites] one-hot reference base
-    std::vector<uint32_t> rank2bfs;        // [n_nodes] tie rank -> BFS index
-    std::vector<uint32_t> dfs2bfs;         // [n_nodes]
+    UVec<uint32_t> rank2bfs;        // [n_nodes] tie rank -> BFS index
+    UVec<uint32_t> dfs2bfs;         // [n_nodes]
     // packed stream for k_best8 (same chunk cut points, by DFS node index)
-    std::vector<uint32_t> stream8, pre8_stream;
+    UVec<uint32_t> stream8, pre8_stream;
     std::vector<uint32_t> chunk8_body_off, chunk8_pre_off;   // [n_chunks+1]
-    std::vector<uint32_t> sum8, sum8_off;  // summaries: words, [ceil(n_chunks / super_chunks) + 1] offsets
+    UVec<uint32_t> sum8, sum8_off;  // summaries: words, [ceil(n_chunks / super_chunks) + 1] offsets
     uint32_t super_chunks = 0;
     // Tie stream (phase 2): the chunk bodies of `stream` without the leaves that can never be eligible and
     // with pruning pseudo-records {w0 = T_INFO_MARK, w1 = hsub << 24 | jump}: the node that follows may be
     // skipped together with its descendants (`jump` dwords behind its own record, inside the chunk)
     // when D(node) - hsub exceeds the wanted score of every sample that still looks for ties here.
-    std::vector<uint32_t> stream_t, chunk_t_off;             // chunk_t_off: [n_chunks+1]
+    UVec<uint32_t> stream_t, chunk_t_off;             // chunk_t_off: [n_chunks+1]
     uint32_t max_path_muts = 0;            // max over nodes of the mutation count on the root path
     uint32_t lds_slots = 0;                // the Options value the packed stream was encoded for (<= max_slots)
     bool mask_not_first = false;           // some non-root node lists a masked mutation behind an ordinary one: only the
