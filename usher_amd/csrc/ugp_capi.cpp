@@ -5,6 +5,7 @@
 
 #include <algorithm>
 #include <climits>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -398,27 +399,51 @@ struct HostFlat {
 static int host_flatten(const ugp_tree_desc *tree, const ugp::Options &opt, bool with_coarse, HostFlat &hf);
 
 // The top of the tree (the nodes with the largest subtrees: N/1024 of them, at least 4096) as a MAT of its own.
-static int build_coarse(const ugp_tree_desc *t, HostFlat &hf) {
+// `ex` = subtree sizes and DFS positions from the flattening of the full tree.
+static int build_coarse(const ugp_tree_desc *t, const ugp::Options &opt, const ugp::FlatExtras &ex, HostFlat &hf) {
     const uint64_t N = t->n_nodes;
     uint64_t min_nodes = 1u << 18;   // below this a tree pass is too short for the sort to pay off
     if (const char *e = getenv("UGP_COARSE_MIN_NODES")) min_nodes = (uint64_t)atoll(e);   // tests lower it
     if (N < min_nodes || N < 64 || getenv("UGP_NO_SORT")) return UGP_OK;
-    std::vector<uint32_t> sub(N, 1);
-    for (uint64_t j = N; j-- > 1;) sub[t->parent[j]] += sub[j];
+    const uint32_t *sub = ex.sub.data();
     uint64_t div = 1024;
     if (const char *e = getenv("UGP_COARSE_DIV")) div = (uint64_t)std::max(2, atoi(e));
     const uint64_t target = std::min<uint64_t>(N / 2, std::max<uint64_t>(N / div, std::min<uint64_t>(4096, N / 4)));
-    std::vector<uint32_t> sorted_sub(sub);
-    std::nth_element(sorted_sub.begin(), sorted_sub.begin() + (N - target), sorted_sub.end());
-    const uint32_t S = std::max<uint32_t>(2, sorted_sub[N - target]);
-    std::vector<uint32_t> newid(N, UINT32_MAX), keep;
-    for (uint64_t j = 0; j < N; j++) if (sub[j] >= S || j == 0) { newid[j] = (uint32_t)keep.size(); keep.push_back((uint32_t)j); }
+    // S = the (N - target)-th smallest subtree size (0-based): histogram of the sizes below 2^16 on the host threads,
+    // a selection over a copy only when the threshold lies beyond it
+    uint32_t S = 0;
+    {
+        constexpr uint32_t CAP = 1u << 16;
+        const ugp::Par par = ugp::flatten_par(opt);
+        std::vector<uint64_t> hist((size_t)par.T * (CAP + 1), 0);
+        par.run(N, [&](uint64_t b, uint64_t e, unsigned tid) {
+            uint64_t *h = &hist[(size_t)tid * (CAP + 1)];
+            for (uint64_t j = b; j < e; j++) h[std::min<uint32_t>(sub[j], CAP)]++;
+        }, 1u << 16);
+        uint64_t below = 0;   // nodes with a size < v
+        uint32_t v = 0;
+        for (; v < CAP; v++) {
+            uint64_t c = 0;
+            for (unsigned th = 0; th < par.T; th++) c += hist[(size_t)th * (CAP + 1) + v];
+            if (below + c > N - target) break;
+            below += c;
+        }
+        if (v < CAP) S = v;
+        else {
+            std::vector<uint32_t> sorted_sub(sub, sub + N);
+            std::nth_element(sorted_sub.begin(), sorted_sub.begin() + (N - target), sorted_sub.end());
+            S = sorted_sub[N - target];
+        }
+        S = std::max<uint32_t>(2, S);
+    }
+    std::vector<uint32_t> keep;   // ascending BFS index; the parent of a kept node is kept (its subtree is larger)
+    for (uint64_t j = 0; j < N; j++) if (sub[j] >= S || j == 0) keep.push_back((uint32_t)j);
     std::vector<uint32_t> parent(keep.size());
     std::vector<uint64_t> mut_off(keep.size() + 1, 0);
     std::vector<int32_t> pos; std::vector<uint8_t> ref, par, nuc;
     for (size_t k = 0; k < keep.size(); k++) {
         const uint32_t j = keep[k];
-        parent[k] = j ? newid[t->parent[j]] : UINT32_MAX;
+        parent[k] = j ? (uint32_t)(std::lower_bound(keep.begin(), keep.begin() + k, t->parent[j]) - keep.begin()) : UINT32_MAX;
         for (uint64_t i = t->mut_off[j]; i < t->mut_off[j + 1]; i++) {
             pos.push_back(t->mut_pos[i]); ref.push_back(t->mut_ref[i]);
             par.push_back(t->mut_par ? t->mut_par[i] : 0); nuc.push_back(t->mut_nuc[i]);
@@ -432,10 +457,8 @@ static int build_coarse(const ugp_tree_desc *t, HostFlat &hf) {
     if (const char *e = getenv("UGP_COARSE_CHUNK_NODES")) copt.chunk_nodes = (uint32_t)std::max(1, atoi(e));
     hf.coarse = new HostFlat();
     if (int rc = host_flatten(&d, copt, false, *hf.coarse)) return rc;
-    std::vector<uint32_t> dfs_rank(N);
     hf.coarse2dfs.resize(keep.size());
-    for (uint64_t r = 0; r < N; r++) dfs_rank[hf.f.dfs2bfs[r]] = (uint32_t)r;
-    for (size_t k = 0; k < keep.size(); k++) hf.coarse2dfs[k] = dfs_rank[keep[k]];
+    for (size_t k = 0; k < keep.size(); k++) hf.coarse2dfs[k] = ex.dfsidx[keep[k]];
     return UGP_OK;
 }
 
@@ -443,10 +466,11 @@ static int host_flatten(const ugp_tree_desc *tree, const ugp::Options &opt, bool
     std::string err;
     int rc;
     try {
-        rc = ugp::flatten(*tree, opt, hf.f, err);
+        ugp::FlatExtras ex;
+        rc = ugp::flatten(*tree, opt, hf.f, err, with_coarse ? &ex : nullptr);
         if (rc == UGP_OK && with_coarse) hf.parent.assign(tree->parent, tree->parent + tree->n_nodes);   // (the full tree only)
         if (rc == UGP_OK && with_coarse) {
-            rc = build_coarse(tree, hf);
+            rc = build_coarse(tree, opt, ex, hf);
             if (rc != UGP_OK) return rc;   // (message already set)
         }
     } catch (const std::bad_alloc &) {
@@ -522,8 +546,15 @@ static int mat_create_impl(const ugp_tree_desc *tree, int device, const ugp::Opt
     if (!tree || !out) return fail(UGP_ERR_INVALID, "null argument");
     *out = nullptr;
     HostFlat hf;
+    const bool verbose = getenv("UGP_FLATTEN_VERBOSE") != nullptr;
+    const auto t0 = std::chrono::steady_clock::now();
     if (int rc = host_flatten(tree, opt, true, hf)) return rc;
-    return upload_flat(hf, device, out);
+    const auto t1 = std::chrono::steady_clock::now();
+    const int rc = upload_flat(hf, device, out);
+    if (verbose)
+        fprintf(stderr, "[ugp mat_create] flatten + coarse MAT %.1f ms, upload %.1f ms\n", std::chrono::duration<double, std::milli>(t1 - t0).count(),
+                std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t1).count());
+    return rc;
 }
 
 // One flattening, n devices: the replicated read-only MAT of the multi-GPU path.  out[i] lives on

@@ -48,31 +48,6 @@ inline int nuc_index(uint8_t onehot) {
     }
 }
 
-// Contiguous ranges of [0, n) on up to T host threads; fn(begin, end, thread index).
-struct Par {
-    unsigned T;
-    uint64_t grain = 0;   // != 0: items per thread below which a pass stays on one thread (UGP_FLATTEN_GRAIN; the tests set 1)
-    template <class F>
-    void run(uint64_t n, F fn, uint64_t min_per_thread = 8192) const {
-        if (grain) min_per_thread = grain;
-        const unsigned t = (unsigned)std::min<uint64_t>(T, std::max<uint64_t>(1, n / std::max<uint64_t>(1, min_per_thread)));
-        if (t <= 1) { fn((uint64_t)0, n, 0u); return; }
-        std::vector<std::thread> th;
-        th.reserve(t - 1);
-        for (unsigned i = 1; i < t; i++) th.emplace_back([&fn, n, t, i] { fn(n * i / t, n * (i + 1) / t, i); });
-        fn((uint64_t)0, n / t, 0u);
-        for (auto &x : th) x.join();
-    }
-    // a[i] <- sum of a[0..i) ; returns the total
-    uint64_t exclusive_scan(uint32_t *a, uint64_t n) const {
-        std::vector<uint64_t> part(T + 1, 0);
-        run(n, [&](uint64_t b, uint64_t e, unsigned tid) { uint64_t s = 0; for (uint64_t i = b; i < e; i++) s += a[i]; part[tid + 1] = s; }, 1u << 16);
-        for (unsigned i = 0; i < T; i++) part[i + 1] += part[i];
-        run(n, [&](uint64_t b, uint64_t e, unsigned tid) { uint64_t s = part[tid]; for (uint64_t i = b; i < e; i++) { const uint32_t v = a[i]; a[i] = (uint32_t)s; s += v; } }, 1u << 16);
-        return part[T];
-    }
-};
-
 // Scratch array without initialisation: every element is written by the (parallel) pass that produces it before it is
 // read, so the pages are first touched by the threads that fill them.
 template <class V>
@@ -103,7 +78,29 @@ struct FirstError {
 };
 }  // namespace
 
-int flatten(const ugp_tree_desc &t, const Options &opt, FlatMat &out, std::string &err) {
+uint64_t Par::exclusive_scan(uint32_t *a, uint64_t n) const {
+    std::vector<uint64_t> part(T + 1, 0);
+    run(n, [&](uint64_t b, uint64_t e, unsigned tid) { uint64_t s = 0; for (uint64_t i = b; i < e; i++) s += a[i]; part[tid + 1] = s; }, 1u << 16);
+    for (unsigned i = 0; i < T; i++) part[i + 1] += part[i];
+    run(n, [&](uint64_t b, uint64_t e, unsigned tid) { uint64_t s = part[tid]; for (uint64_t i = b; i < e; i++) { const uint32_t v = a[i]; a[i] = (uint32_t)s; s += v; } }, 1u << 16);
+    return part[T];
+}
+
+unsigned flatten_threads(const Options &opt) {
+    unsigned n = opt.threads;
+    if (!n) {
+        if (const char *e = getenv("UGP_FLATTEN_THREADS")) n = (unsigned)std::max(1, atoi(e));
+        else n = std::min(32u, std::max(1u, std::thread::hardware_concurrency()));
+    }
+    return std::min(n, 256u);
+}
+
+Par flatten_par(const Options &opt) {
+    const char *g = getenv("UGP_FLATTEN_GRAIN");
+    return Par{flatten_threads(opt), g ? (uint64_t)std::max(1, atoi(g)) : 0u};
+}
+
+int flatten(const ugp_tree_desc &t, const Options &opt, FlatMat &out, std::string &err, FlatExtras *extras) {
     const uint64_t N = t.n_nodes;
     if (N == 0 || !t.parent || !t.mut_off) { err = "empty tree or null arrays"; return UGP_ERR_INVALID; }
     if (N >= (1ull << 31)) { err = "more than 2^31 nodes"; return UGP_ERR_UNSUPPORTED; }
@@ -111,12 +108,7 @@ int flatten(const ugp_tree_desc &t, const Options &opt, FlatMat &out, std::strin
     const uint64_t M = t.mut_off[N];
     if (M && (!t.mut_pos || !t.mut_ref || !t.mut_nuc)) { err = "null mutation arrays"; return UGP_ERR_INVALID; }
 
-    unsigned n_threads = opt.threads;
-    if (!n_threads) {
-        if (const char *e = getenv("UGP_FLATTEN_THREADS")) n_threads = (unsigned)std::max(1, atoi(e));
-        else n_threads = std::min(32u, std::max(1u, std::thread::hardware_concurrency()));
-    }
-    const Par par{std::min(n_threads, 256u), getenv("UGP_FLATTEN_GRAIN") ? (uint64_t)std::max(1, atoi(getenv("UGP_FLATTEN_GRAIN"))) : 0u};
+    const Par par = flatten_par(opt);
     const unsigned T = par.T;
     FirstError ferr;
     auto failed = [&]() -> int { err = ferr.msg; return ferr.code; };
@@ -203,7 +195,8 @@ int flatten(const ugp_tree_desc &t, const Options &opt, FlatMat &out, std::strin
     // hsub[j] = largest number of mutation words on a path j -> descendant, without j's own (hdown = nw + hsub: no
     // node of j's subtree, j included, costs less than D(parent(j)) - hdown[j]); subw / subd = packed-stream words /
     // tie-stream dwords of j's descendants (without pruning records)
-    Buf<uint32_t> sub(N), leaves(N), hsub(N), subw(N), subd(N);
+    UVec<uint32_t> sub(N);
+    Buf<uint32_t> leaves(N), hsub(N), subw(N), subd(N);
     bottom_up([&](uint64_t p, unsigned) {
         uint32_t s = 1, lv = 0, h = 0, w = 0, d = 0;
         for (uint32_t k = child_off[p]; k < child_off[p + 1]; k++) {
@@ -315,7 +308,8 @@ int flatten(const ugp_tree_desc &t, const Options &opt, FlatMat &out, std::strin
     // ---- DFS positions, saved-D slots, effective children (one top-down pass) -------------------------------------------
     // slot[c] = slot[p] for p's last child, slot[p] + 1 for the others: the number of non-last-child edges on the root
     // path, <= log2 N because the largest subtree goes last
-    Buf<uint32_t> dfsidx(N), pathm(N), eff_children(N), last_eff(N), suffix_h(N), big_after(N);   // (suffix_h / big_after: non-last effective children only)
+    UVec<uint32_t> dfsidx(N);
+    Buf<uint32_t> pathm(N), eff_children(N), last_eff(N), suffix_h(N), big_after(N);   // (suffix_h / big_after: non-last effective children only)
     Buf<uint8_t> slot(N), first_child(N), first_eff(N);
     slot[0] = 0; first_child[0] = 0; first_eff[0] = 0;
     struct alignas(64) Maxima { uint32_t path = 0, slot = 0; };   // one cache line per thread
@@ -731,6 +725,7 @@ int flatten(const ugp_tree_desc &t, const Options &opt, FlatMat &out, std::strin
         par.run(n_units, [&](uint64_t b, uint64_t e, unsigned) { for (uint64_t u = b; u < e; u++) walk_unit((uint32_t)u, out.sum8.data() + out.sum8_off[u]); }, 16);
     }
     flat_lap("summaries");
+    if (extras) { extras->sub.swap(sub); extras->dfsidx.swap(dfsidx); }
     return UGP_OK;
 }
 

@@ -5,7 +5,9 @@
 #include <cstdint>
 #include <memory>
 #include <new>
+#include <algorithm>
 #include <string>
+#include <thread>
 #include <utility>
 #include <vector>
 
@@ -148,7 +150,36 @@ struct FlatMat {
                                            // 32-bit walk (M_AFTER_MASK) scores such a node the way usher_mapper.cpp:190-270 does
 };
 
+// By-products of the flattening that the caller may want (both by BFS index): subtree sizes, DFS position.
+struct FlatExtras {
+    UVec<uint32_t> sub, dfsidx;
+};
+
 // Returns UGP_OK or a negative UGP_ERR_* with `err` filled.
-int flatten(const ugp_tree_desc &t, const Options &opt, FlatMat &out, std::string &err);
+int flatten(const ugp_tree_desc &t, const Options &opt, FlatMat &out, std::string &err, FlatExtras *extras = nullptr);
+
+// Contiguous ranges of [0, n) on up to T host threads; fn(begin, end, thread index).  A pass with fewer than
+// min_per_thread items per thread uses fewer threads (one: it runs inline).
+struct Par {
+    unsigned T;
+    uint64_t grain = 0;   // != 0: overrides min_per_thread (UGP_FLATTEN_GRAIN; the tests set 1 to split even tiny passes)
+    template <class F>
+    void run(uint64_t n, F fn, uint64_t min_per_thread = 8192) const;
+    uint64_t exclusive_scan(uint32_t *a, uint64_t n) const;   // a[i] <- sum of a[0..i); returns the total
+};
+unsigned flatten_threads(const Options &opt);   // Options.threads, else UGP_FLATTEN_THREADS, else min(32, hardware threads)
+Par flatten_par(const Options &opt);
+
+template <class F>
+void Par::run(uint64_t n, F fn, uint64_t min_per_thread) const {
+    if (grain) min_per_thread = grain;
+    const unsigned t = (unsigned)std::min<uint64_t>(T, std::max<uint64_t>(1, n / std::max<uint64_t>(1, min_per_thread)));
+    if (t <= 1) { fn((uint64_t)0, n, 0u); return; }
+    std::vector<std::thread> th;
+    th.reserve(t - 1);
+    for (unsigned i = 1; i < t; i++) th.emplace_back([&fn, n, t, i] { fn(n * i / t, n * (i + 1) / t, i); });
+    fn((uint64_t)0, n / t, 0u);
+    for (auto &x : th) x.join();
+}
 
 }  // namespace ugp
