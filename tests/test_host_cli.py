@@ -228,6 +228,9 @@ def test_batched_add_mode_equals_per_sample_research(tmp_path, monkeypatch, seed
     pb = str(tmp_path / "base.pb")
     assert run_usher(["-t", nh, "-v", old, "-o", pb, "-d", str(tmp_path)]) == 0
     outs, calls = {}, {}
+    if seed % 2 == 0:   # split even these small trees' O(N) passes (tree -> arrays) across host threads
+        monkeypatch.setenv("USHER_AMD_GRAIN", "1")
+        monkeypatch.setenv("USHER_AMD_THREADS", "5")
     for mode, env in (("research", "0"), ("batched", max_touched)):
         if env is None:
             monkeypatch.delenv("USHER_AMD_MAX_TOUCHED", raising=False)

@@ -1,6 +1,7 @@
 // cli.cpp -- command line of the usher-compatible front end: the 22 flags of the
 // reference's src/usher.cpp:47-86 (+ --version / --help), tree / MAT / VCF
 // loading (usher.cpp:132-173) and the call into the driver (usher.cpp:175-178).
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -147,15 +148,23 @@ int usher_main(int argc, char **argv, const Backend &be) {
         if (!read_vcf_build(T, opt.vcf, missing, err, assign_via_backend, (void *)&be)) { fprintf(stderr, "%s\n", err.c_str()); return 1; }
     } else if (!opt.load_mat.empty()) {                                         // usher.cpp:151-170
         fprintf(stderr, "Loading existing mutation-annotated tree object from file %s\n", opt.load_mat.c_str());
+        const auto t0 = std::chrono::steady_clock::now();
         if (!load_mat(opt.load_mat, T, err)) { fprintf(stderr, "%s\n", err.c_str()); return 1; }
         if (!T.root) { fprintf(stderr, "ERROR: Empty tree.\n"); return 1; }
+        const auto t1 = std::chrono::steady_clock::now();
         fprintf(stderr, "Loading VCF file\n");
         if (!read_vcf_missing(T, opt.vcf, missing, err)) { fprintf(stderr, "%s\n", err.c_str()); return 1; }
+        if (getenv("USHER_AMD_PROFILE"))
+            fprintf(stderr, "[usher-amd profile] load MAT %.3f s, read VCF %.3f s\n", std::chrono::duration<double>(t1 - t0).count(),
+                    std::chrono::duration<double>(std::chrono::steady_clock::now() - t1).count());
     } else {
         fprintf(stderr, "Error! No input tree or assignment file provided!\n");
         return 1;
     }
-    return run_usher(opt, T, missing, be);
+    const auto t2 = std::chrono::steady_clock::now();
+    const int rc = run_usher(opt, T, missing, be);
+    if (getenv("USHER_AMD_PROFILE")) fprintf(stderr, "[usher-amd profile] run_usher (placement loop + output files) %.3f s\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - t2).count());
+    return rc;
 }
 
 }  // namespace uh

@@ -2,6 +2,7 @@
 // behaviour (messages, file formats, ordering rules) follows the reference's
 // src/usher_common.cpp, cited inline.
 #include "driver.hpp"
+#include "par.hpp"
 
 #include <sys/stat.h>
 #include <sys/time.h>
@@ -43,28 +44,64 @@ struct FlatTree {
     uint32_t epoch = 0;                               // nodes stamped with this epoch carry their index here (Node::flat_index)
     std::vector<uint32_t> leaves;                     // leaves below each node at build time (Tree::get_num_leaves)
     bool has(const Node *n) const { return epoch != 0 && n->flat_epoch == epoch; }   // (epoch 0: never built)
+    // Tree -> breadth-first arrays, on the host threads: the expansion level by level (the next level is the
+    // concatenation of the children lists of this one: sizes, prefix sum, copy), then per-node fills.
     void build(const Tree &T) {
         static uint32_t next_epoch = 0;
         epoch = ++next_epoch;
-        bfs = T.bfs();
-        for (uint32_t j = 0; j < bfs.size(); j++) { bfs[j]->flat_index = j; bfs[j]->flat_epoch = epoch; }
-        parent.assign(bfs.size(), UINT32_MAX);
-        mut_off.assign(bfs.size() + 1, 0);
-        pos.clear(); ref.clear(); par.clear(); nuc.clear();
-        for (uint32_t j = 0; j < bfs.size(); j++) {
-            if (bfs[j]->parent) parent[j] = bfs[j]->parent->flat_index;
-            for (const Mutation &m : bfs[j]->mutations) {
-                pos.push_back(m.position); ref.push_back((uint8_t)m.ref_nuc);
-                par.push_back((uint8_t)m.par_nuc); nuc.push_back((uint8_t)m.mut_nuc);
+        const size_t N = T.all_nodes.size();
+        bfs.clear();
+        if (!T.root) { parent.clear(); mut_off.assign(1, 0); leaves.clear(); desc = ugp_tree_desc{}; return; }
+        bfs.resize(N);
+        bfs[0] = T.root;
+        std::vector<uint64_t> level_off{0, 1};   // nodes of level l: [level_off[l], level_off[l + 1])
+        std::vector<uint64_t> cnt;
+        for (size_t lo = 0, hi = 1; lo < hi;) {
+            cnt.resize(hi - lo);
+            parallel_for(hi - lo, [&](uint64_t b, uint64_t e, unsigned) { for (uint64_t i = b; i < e; i++) cnt[i] = bfs[lo + i]->children.size(); }, 2048);
+            const uint64_t total = exclusive_scan(cnt.data(), hi - lo);
+            if (hi + total > bfs.size()) bfs.resize(hi + total);   // (all_nodes out of step with the tree: never expected)
+            parallel_for(hi - lo, [&](uint64_t b, uint64_t e, unsigned) {
+                for (uint64_t i = b; i < e; i++) {
+                    Node **dst = &bfs[hi + cnt[i]];
+                    for (Node *c : bfs[lo + i]->children) *dst++ = c;
+                }
+            }, 2048);
+            lo = hi; hi += total;
+            if (total) level_off.push_back(hi);
+        }
+        bfs.resize(level_off.back());
+        const size_t n = bfs.size();
+        parent.resize(n); leaves.resize(n);
+        mut_off.resize(n + 1);
+        parallel_for(n, [&](uint64_t b, uint64_t e, unsigned) {
+            for (uint64_t j = b; j < e; j++) { bfs[j]->flat_index = (uint32_t)j; bfs[j]->flat_epoch = epoch; mut_off[j] = bfs[j]->mutations.size(); }
+        });
+        mut_off[n] = 0;
+        const uint64_t M = exclusive_scan(mut_off.data(), n + 1);
+        pos.resize(M); ref.resize(M); par.resize(M); nuc.resize(M);
+        parallel_for(n, [&](uint64_t b, uint64_t e, unsigned) {
+            for (uint64_t j = b; j < e; j++) {
+                parent[j] = bfs[j]->parent ? bfs[j]->parent->flat_index : UINT32_MAX;
+                uint64_t k = mut_off[j];
+                for (const Mutation &m : bfs[j]->mutations) {
+                    pos[k] = m.position; ref[k] = (uint8_t)m.ref_nuc; par[k] = (uint8_t)m.par_nuc; nuc[k] = (uint8_t)m.mut_nuc;
+                    k++;
+                }
             }
-            mut_off[j + 1] = pos.size();
+        });
+        // leaves below each node: the levels bottom-up, every node summing over its children
+        for (size_t l = level_off.size() - 1; l-- > 0;) {
+            const uint64_t b0 = level_off[l];
+            parallel_for(level_off[l + 1] - b0, [&](uint64_t b, uint64_t e, unsigned) {
+                for (uint64_t j = b0 + b; j < b0 + e; j++) {
+                    uint32_t v = 0;
+                    for (const Node *c : bfs[j]->children) v += leaves[c->flat_index];
+                    leaves[j] = bfs[j]->children.empty() ? 1u : v;
+                }
+            }, 2048);
         }
-        leaves.assign(bfs.size(), 0);
-        for (uint32_t j = (uint32_t)bfs.size(); j-- > 0;) {
-            if (bfs[j]->is_leaf()) leaves[j] = 1;
-            if (j) leaves[parent[j]] += leaves[j];
-        }
-        desc.n_nodes = bfs.size(); desc.parent = parent.data(); desc.mut_off = mut_off.data();
+        desc.n_nodes = n; desc.parent = parent.data(); desc.mut_off = mut_off.data();
         desc.mut_pos = pos.data(); desc.mut_ref = ref.data(); desc.mut_par = par.data(); desc.mut_nuc = nuc.data();
     }
 };
@@ -1178,7 +1215,10 @@ int run_usher(const Options &opt, Tree &T, std::vector<MissingSample> &missing, 
     }
     if (opt.print_scores) return 0;                                             // :800-805
     std::vector<Tree *> trees{&T};
-    return write_outputs(opt, trees, missing, low_confidence);
+    const auto t_out = std::chrono::steady_clock::now();
+    const int rc = write_outputs(opt, trees, missing, low_confidence);
+    if (getenv("USHER_AMD_PROFILE")) fprintf(stderr, "[usher-amd profile] output files %.3f s\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - t_out).count());
+    return rc;
 }
 
 }  // namespace uh
