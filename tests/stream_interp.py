@@ -30,6 +30,11 @@ def sample_site_alleles(flat, sample):
     return nib, dbot
 
 
+def variant_rows(sample):
+    """V of the second pruning bound: rows whose allele set is neither missing nor just the reference base."""
+    return sum(1 for r, a, mis in zip(sample["ref"], sample["nuc"], sample["is_missing"]) if not mis and int(a) != int(r))
+
+
 def run_group(flat, nib, dbot, c0, c1, want_scores=None):
     """One wave's work: preamble of chunk c0, bodies of chunks [c0, c1)."""
     slots = {}
@@ -118,6 +123,16 @@ def place(flat, sample, n_groups=1, want_scores=False):
 H_TAG, H_INFO, H_RARE, H_SIB = 1 << 31, 1 << 30, 1 << 29, 1 << 21
 H_REG, H_STORE, H_NOSCORE8, H_END, H_FREE, H_SKIPD, H_BOTTOM, H_SLOW, H_CHUNK_END, H_NOP = (1 << k for k in range(10))
 H_RSLOT_SHIFT, H_WSLOT_SHIFT, INFO_HS_SHIFT = 10, 20, 22
+INFO_HR_SHIFT, INFO_HR_NONE, INFO_JUMP_MASK, PRE_HS_NONE = 18, 7, (1 << 18) - 1, 127
+
+
+def far(d, rec, ub, vrow, pre=False):
+    """The kernel's all_far for one sample: D - hs > ub, or D - (V + hr) > ub (second bound, when the record has hr).
+    pre: a preamble record, whose hs field may say "not available"."""
+    hs, hr = (rec >> INFO_HS_SHIFT) & 0x7F, (rec >> INFO_HR_SHIFT) & 7
+    if not (pre and hs == PRE_HS_NONE) and d >= ub + 1 + hs:
+        return True
+    return vrow is not None and hr != INFO_HR_NONE and d - hr >= min(ub + 1 + vrow, 0x7F80)
 M_FLUSH, M_END = 1 << 28, 1 << 30
 U16 = 0xFFFF
 
@@ -167,7 +182,7 @@ def summary_ranges(flat, nib, c0, slots, dcur, ub, stats=None):
     return ranges
 
 
-def best8_group(flat, nib, dbot, c0, c1, ub=None, stats=None, use_summary=True):
+def best8_group(flat, nib, dbot, c0, c1, ub=None, stats=None, use_summary=True, vrow=None, use_pre_records=True):
     """Chunk-local minima of one sample for chunks [c0, c1), as k_best8 computes them.
     ub: None = no pruning; otherwise a one-element list holding an upper bound of the sample's best
     score, used (and tightened at chunk ends) exactly like the kernel's shared bound.  When the unit
@@ -200,6 +215,7 @@ def best8_group(flat, nib, dbot, c0, c1, ub=None, stats=None, use_summary=True):
 
     info = None
     sinfo = None
+    body_start = 0
     n_chunks = len(flat.chunk8_body_off) - 1
     sc = getattr(flat, "super_chunks", 0)
     summarise = (use_summary and ub is not None and sc and c0 % sc == 0 and c1 == min(c0 + sc, n_chunks))
@@ -230,6 +246,9 @@ def best8_group(flat, nib, dbot, c0, c1, ub=None, stats=None, use_summary=True):
                             sinfo = w
                         else:
                             info = w
+                    elif ub is not None and phase == 0 and use_pre_records:
+                        assert not (w & H_SIB)
+                        info = w
                     continue
                 if w & H_NOP:
                     continue
@@ -249,9 +268,9 @@ def best8_group(flat, nib, dbot, c0, c1, ub=None, stats=None, use_summary=True):
                     assert not (w & H_STORE) or ((w >> H_WSLOT_SHIFT) & 63) < flat.lds_slots
                 dpar = dcur if w & H_REG else (dbot if w & H_BOTTOM else slots[(w >> H_RSLOT_SHIFT) & 63])
                 if sinfo is not None:   # sibling record: skip this child and the non-last siblings after it?
-                    hs, jump = (sinfo >> INFO_HS_SHIFT) & 0x7F, sinfo & 0x1FFFFF
+                    rec, jump = sinfo, sinfo & INFO_JUMP_MASK
                     sinfo = None
-                    if dpar >= ub[0] + 1 + hs:
+                    if far(dpar, rec, ub[0], vrow):
                         target = i + jump
                         info = None
                         if stats is not None:
@@ -283,10 +302,18 @@ def best8_group(flat, nib, dbot, c0, c1, ub=None, stats=None, use_summary=True):
                 if w & M_END:
                     finish()
                     ended = True
-            if ended and info is not None:
-                hs, jump = (info >> INFO_HS_SHIFT) & 0x7F, info & 0x1FFFFF
+            if ended and info is not None and phase == 0:
+                # preamble record of a path node: nothing of its subtree is needed -> stop the replay, start the body behind it
+                rec, info = info, None
+                if far(dcur, rec, ub[0], vrow, pre=True):
+                    body_start = rec & INFO_JUMP_MASK
+                    if stats is not None:
+                        stats["pre_skipped"] = stats.get("pre_skipped", 0) + min(body_start, int(flat.chunk8_body_off[c1]) - body0)
+                    break
+            elif ended and info is not None:
+                rec, jump = info, info & INFO_JUMP_MASK
                 info = None
-                if dcur >= ub[0] + 1 + hs:          # D(node) - hsub > upper bound: no descendant can tie or win
+                if far(dcur, rec, ub[0], vrow):     # D(node) - bound > upper bound: no descendant can tie or win
                     target = i + 1 + jump
                     if stats is not None:
                         stats["skipped"] = stats.get("skipped", 0) + min(target, hi) - (i + 1)
@@ -298,7 +325,10 @@ def best8_group(flat, nib, dbot, c0, c1, ub=None, stats=None, use_summary=True):
                     i = target - 1
         if phase == 0:
             body_end = int(flat.chunk8_body_off[c1])
-            if summarise:
+            info = None
+            if body_start:
+                segments.append((1, flat.stream8, min(body0 + body_start, body_end), body_end))
+            elif summarise:
                 for r0, r1 in summary_ranges(flat, nib, c0, slots, dcur, ub, stats):
                     segments.append((1, flat.stream8, body0 + r0, min(body0 + r1, body_end)))
                 segments.append((1, flat.stream8, body_end, body_end))   # closes the remaining chunks
@@ -320,7 +350,7 @@ def place8(flat, sample, n_groups=1, prune_ub=None, stats=None):
     for g in range(n_groups):
         c0, c1 = g * n_chunks // n_groups, (g + 1) * n_chunks // n_groups
         if c0 < c1:
-            lbest.update(best8_group(flat, nib, dbot, c0, c1, ub, stats))
+            lbest.update(best8_group(flat, nib, dbot, c0, c1, ub, stats, vrow=variant_rows(sample)))
     assert len(lbest) == n_chunks
     gbest = min(lbest.values())
     cnt, key = 0, 0

@@ -170,8 +170,8 @@ def test_summaries_of_top_level_subtrees_are_exact(seed, chunk_nodes, monkeypatc
             ub_a, ub_b = [ub0], [ub0]
             for u in range(n_units):
                 c0, c1 = 8 * u, min(8 * u + 8, n_chunks)
-                lb_sum.update(stream_interp.best8_group(flat, nib, dbot, c0, c1, ub_a, st))
-                lb_plain.update(stream_interp.best8_group(flat, nib, dbot, c0, c1, ub_b, None, use_summary=False))
+                lb_sum.update(stream_interp.best8_group(flat, nib, dbot, c0, c1, ub_a, st, vrow=stream_interp.variant_rows(s), use_pre_records=False))
+                lb_plain.update(stream_interp.best8_group(flat, nib, dbot, c0, c1, ub_b, None, use_summary=False, vrow=stream_interp.variant_rows(s)))
             assert min(lb_sum.values()) == want["best"] == min(lb_plain.values())
             # wherever a chunk holds the optimum both walks must have found it there (phase 2 re-walks those chunks)
             assert [c for c in range(n_chunks) if lb_sum[c] == want["best"]] == [c for c in range(n_chunks) if lb_plain[c] == want["best"]]
@@ -240,3 +240,39 @@ def test_flattening_does_not_depend_on_the_thread_count(kind, monkeypatch):
         assert set(got) == set(ref)
         for k in ref:
             assert got[k].shape == ref[k].shape and (got[k] == ref[k]).all(), (k, threads)
+
+
+@pytest.mark.parametrize("seed,chunk_nodes", [(81, 9), (82, 30), (83, 64)])
+def test_preamble_records_skip_far_units_exactly(seed, chunk_nodes, monkeypatch):
+    """Every path node of a chunk's preamble carries a pruning record (hsub, reversions below, where the body goes on
+    behind its subtree).  With them, and with the second bound D - (V_s + hrev), a unit far from the sample ends its
+    replay a few nodes below the point where its root path leaves the sample's and skips most of its body; the chunk
+    minima that matter must be unchanged, for loose and tight upper bounds, units of 1, 3 and 8 chunks."""
+    monkeypatch.setenv("UGP_LDS_SLOTS", "3")
+    arrays, queries = synth.make_case(seed, n_leaves=2500, n_queries=8, n_sites=300, n_ambig=(0, 0, 2), p_masked=0.02,
+                                      mut_counts=(0, 0, 1, 1, 1, 2, 3, 17))
+    flat = FlatTreeView(arrays, chunk_nodes=chunk_nodes)
+    n_chunks = len(flat.chunk8_body_off) - 1
+    ot = capi.OracleTree(arrays)
+    pre_skipped = body = 0
+    for s in queries:
+        want = ot.place(s)
+        nib, dbot = stream_interp.sample_site_alleles(flat, s)
+        v = stream_interp.variant_rows(s)
+        for ub0 in (0x7F7F, want["best"] + 2, want["best"]):
+            for unit in (1, 3, 8):
+                st = {}
+                lb_pre, lb_plain = {}, {}
+                ub_a, ub_b = [ub0], [ub0]
+                for c0 in range(0, n_chunks, unit):
+                    c1 = min(c0 + unit, n_chunks)
+                    lb_pre.update(stream_interp.best8_group(flat, nib, dbot, c0, c1, ub_a, st, use_summary=False, vrow=v))
+                    lb_plain.update(stream_interp.best8_group(flat, nib, dbot, c0, c1, ub_b, None, use_summary=False, vrow=None, use_pre_records=False))
+                assert min(lb_pre.values()) == want["best"] == min(lb_plain.values())
+                assert [c for c in range(n_chunks) if lb_pre[c] == want["best"]] == [c for c in range(n_chunks) if lb_plain[c] == want["best"]]
+                if ub0 == want["best"]:
+                    pre_skipped += st.get("pre_skipped", 0)
+                    body += len(flat.stream8)
+        res = stream_interp.place8(flat, s, n_groups=max(1, n_chunks // 4), prune_ub=want["best"] + 1)
+        assert (res["best"], res["num_best"], res["best_j"]) == (want["best"], want["num_best"], want["best_j"])
+    assert pre_skipped > 0.25 * body   # a large part of the tree is ruled out during the replays (5,000 nodes: units are coarse)

@@ -129,11 +129,11 @@ elig[:, 0] = True
 best = np.where(elig, cost, 1 << 20).min(axis=1)
 print("tile", TILE, "best scores: min %d median %d max %d; V: median %d max %d; D tables %.1f s" % (best.min(), np.median(best), best.max(), np.median(V), V.max(), time.time() - t0))
 
-def walk(bound_fn, name):
-    # pruned_at[n]: record and all samples far
+def walk(bound_fn, name, slack=0):
+    # pruned_at[n]: record and all samples far (upper bounds = best + slack: seeds that are not exact)
     far = np.ones(n, bool)
     for k in range(512):
-        far &= (D[k].astype(np.int64) - bound_fn(k)) > best[k]
+        far &= (D[k].astype(np.int64) - bound_fn(k)) > best[k] + slack
     pruned_at = far & has_rec
     blocked = np.zeros(n, bool)
     for li in range(1, len(starts) - 1):
@@ -142,9 +142,14 @@ def walk(bound_fn, name):
     visited = ~blocked
     jumps = int((pruned_at & visited).sum())
     words = int((1 + nw)[visited].sum())
-    print("%-34s visited nodes %9d (%.2f %%)  words %9d  jumps %8d" % (name, int(visited.sum()), 100.0 * visited.sum() / n, words, jumps))
-    return visited
+    print("%-34s slack %d: visited nodes %9d (%.2f %%)  words %9d  jumps %8d" % (name, slack, int(visited.sum()), 100.0 * visited.sum() / n, words, jumps))
+    return visited, pruned_at
 
-va = walk(lambda k: hsub, "A: D - hsub")
-vb = walk(lambda k: np.minimum(hsub, V[k] + hrev), "B: D - min(hsub, V_s + hrev)")
-vc = walk(lambda k: np.minimum(hsub, np.minimum(V[k], 0 * hsub + V[k]) + hrev) * 0 + np.minimum(hsub, hrev + V[k]), "B again (check)")
+for slack in (0, 2, 4, 8):
+    va, pa = walk(lambda k: hsub, "A: D - hsub", slack)
+    vb, pb = walk(lambda k: np.minimum(hsub, V[k] + hrev), "B: D - min(hsub, V_s + hrev)", slack)
+    if slack == 0:
+        # where do the extra jumps of B sit?
+        extra = pb & vb & ~pa
+        print("   B-only jumps: %d; their hsub: median %d, min %d; subtree nodes below them: median %d" % (int(extra.sum()), np.median(hsub[extra]), hsub[extra].min(), np.median(sub[extra])))
+        print("   own region estimate: nodes with some sample at distance <= best+2:", int(((D.astype(np.int32) <= (best[:, None] + 2)).any(axis=0)).sum()))

@@ -92,8 +92,10 @@ struct ugp_mat {
     uint32_t last_list_tiles = 0;
     // locality sort (speed only): a coarse MAT of the top of the tree and the map coarse BFS index -> DFS rank in the full tree
     ugp_mat *coarse = nullptr;
+    DevBuf<uint32_t> d_coarse2bfs, d_child_begin, d_rec_off, d_parent, d_refined;   // seed descent (k_descend)
     DevBuf<uint32_t> d_coarse2dfs, d_keys, d_keys2, d_idx, d_order, d_slot;
-    DevBuf<ugp_result> d_coarse_res;
+    DevBuf<ugp_result> d_coarse_res, d_prev_res;
+    bool prev_valid = false;
     DevBuf<uint8_t> d_sort_tmp;
     bool last_used_best8 = false;
     // extended searches (ugp_place_batch_ex): host copy of the topology, the reference's depth-first order and its tie rank
@@ -231,11 +233,11 @@ int run_place(ugp_mat *m, ugp_qset *qs, int mode, ugp_result *d_out, int32_t *d_
         // D(bottom) counters, active-row bitmap, work-queue heads, record lists' lengths, phase-2 item count, tie counts / keys
         const size_t z_dbottom = 0, z_active = z_dbottom + (size_t)n_tiles512 * 512, z_queue = z_active + (size_t)n_tiles512 * active_words,
                      z_list_n = z_queue + 8, z_nitems = z_list_n + n_tiles512, z_cnt = z_nitems + 8, z_key = z_cnt + (size_t)n_tiles512 * 512,
-                     z_end = z_key + (size_t)n_tiles512 * 512;
+                     z_vrows = z_key + (size_t)n_tiles512 * 512, z_end = z_vrows + (size_t)n_tiles512 * 512;
         HIP_TRY(m->d_zero.reserve(z_end));
         uint32_t *const d_dbottom = m->d_zero.p + z_dbottom, *const d_active = m->d_zero.p + z_active, *const d_queue = m->d_zero.p + z_queue,
                  *const d_list_n = m->d_zero.p + z_list_n, *const d_nitems = m->d_zero.p + z_nitems, *const d_cnt = m->d_zero.p + z_cnt,
-                 *const d_key = m->d_zero.p + z_key;
+                 *const d_key = m->d_zero.p + z_key, *const d_vrows = m->d_zero.p + z_vrows;
         if (use8) {
             HIP_TRY(m->d_lbest.reserve((size_t)f.n_chunks * n_tiles512 * 256));
             HIP_TRY(m->d_list.reserve((size_t)f.n_chunks * n_tiles512));
@@ -269,16 +271,70 @@ int run_place(ugp_mat *m, ugp_qset *qs, int mode, ugp_result *d_out, int32_t *d_
             slot_of = m->d_slot.p; order = m->d_order.p;
         }
         HIP_TRY(hipMemsetAsync(m->d_zero.p, 0, z_end * sizeof(uint32_t), s));
-        if (use8) {
-            if (sorted && !getenv("UGP_NO_SEED"))   // start from the coarse pass's best costs (real costs of real nodes)
-                HIP_TRY(ugp::launch_seed_ub(m->d_coarse_res.p + q0, order, (uint32_t)nq, n_tiles512, m->d_ub.p, s));
-            else
-                HIP_TRY(hipMemsetAsync(m->d_ub.p, 0x7F, (size_t)n_tiles512 * 256 * sizeof(uint32_t), s));   // 0x7F7F: above every valid cost
-        }
         HIP_TRY(ugp::launch_fill_table(m->d_table.p, m->d_site_ref.p, n_sites, table_dwords, s));
         HIP_TRY(ugp::launch_scatter(m->d_table.p, d_dbottom, qs->d_pos.p + e0, qs->d_ref.p + e0,
                                     qs->d_nuc.p + e0, qs->d_missing.p + e0, qs->d_ent_q.p + e0, m->d_pos2site.p,
-                                    f.max_pos, n_sites, e1 - e0, (uint32_t)q0, d_active, active_words, slot_of, s));
+                                    f.max_pos, n_sites, e1 - e0, (uint32_t)q0, d_active, active_words, slot_of, use8 ? d_vrows : nullptr, s));
+        if (use8) {   // upper bounds of best(s) the pruning starts from
+            if (sorted && getenv("UGP_SEED_PREV") && m->d_prev_res.cap >= Q && m->prev_valid)   // (experiment: bounds = the previous call's exact answers)
+                HIP_TRY(ugp::launch_seed_ub(m->d_prev_res.p + q0, order, (uint32_t)nq, n_tiles512, m->d_ub.p, nullptr, s));
+            else if (sorted && !getenv("UGP_NO_SEED")) {
+                // the coarse pass's best costs (real costs of real nodes), tightened by a greedy descent from the coarse best node
+                // through the full tree (k_descend; it reads the sample's alleles from the tiles just built)
+                const uint32_t *refined = nullptr;
+                if (m->d_child_begin.p && !getenv("UGP_NO_DESCENT")) {
+                    HIP_TRY(m->d_refined.reserve(nq));
+                    HIP_TRY(ugp::launch_descend(m->d_coarse_res.p + q0, order, (uint32_t)nq, m->d_coarse2bfs.p, m->d_child_begin.p, m->d_rec_off.p,
+                                                m->d_parent.p, m->d_stream.p, m->d_table.p, n_sites, m->d_refined.p, s));
+                    refined = m->d_refined.p;
+                    if (getenv("UGP_STATS") && getenv("UGP_SEED_CHECK") && m->prev_valid && m->d_prev_res.cap >= Q) {   // debug: seeds against the previous call's answers
+                        std::vector<uint32_t> ref(nq), ord(nq);
+                        std::vector<ugp_result> prev(nq), coarse(nq);
+                        HIP_TRY(hipStreamSynchronize(s));
+                        HIP_TRY(hipMemcpy(ref.data(), m->d_refined.p, nq * 4, hipMemcpyDeviceToHost));
+                        HIP_TRY(hipMemcpy(ord.data(), order, nq * 4, hipMemcpyDeviceToHost));
+                        HIP_TRY(hipMemcpy(prev.data(), m->d_prev_res.p + q0, nq * sizeof(ugp_result), hipMemcpyDeviceToHost));
+                        HIP_TRY(hipMemcpy(coarse.data(), m->d_coarse_res.p + q0, nq * sizeof(ugp_result), hipMemcpyDeviceToHost));
+                        uint64_t hist_r[18] = {0}, hist_c[18] = {0}, miss_anc = 0, miss_other = 0, miss_depth = 0;
+                        std::vector<uint32_t> c2b(m->coarse ? m->coarse->flat.n_nodes : 0);
+                        if (!c2b.empty()) HIP_TRY(hipMemcpy(c2b.data(), m->d_coarse2bfs.p, c2b.size() * 4, hipMemcpyDeviceToHost));
+                        for (uint64_t k = 0; k < nq; k++) {
+                            const int exact = prev[ord[k]].best_set_difference;
+                            hist_r[std::min(17, std::max(0, (int)ref[k] - exact))]++;
+                            hist_c[std::min(17, std::max(0, coarse[ord[k]].best_set_difference - exact))]++;
+                            if ((int)ref[k] > exact && !c2b.empty() && coarse[ord[k]].best_j < c2b.size()) {   // is the coarse best node an ancestor of the true one?
+                                const uint32_t j0 = c2b[coarse[ord[k]].best_j];
+                                uint32_t x = prev[ord[k]].best_j, depth = 0;
+                                while (x != UINT32_MAX && x != j0 && x != 0) { x = m->h_parent[x]; depth++; }
+                                if (x == j0) { miss_anc++; miss_depth += depth; } else {
+                                    miss_other++;
+                                    if (miss_other <= 12) {   // a few examples: depths of j0, the true best and their lowest common ancestor
+                                        auto depth_of = [&](uint32_t v) { uint32_t d = 0; while (v != 0 && v != UINT32_MAX) { v = m->h_parent[v]; d++; } return d; };
+                                        uint32_t a = j0, b = prev[ord[k]].best_j;
+                                        uint32_t da = depth_of(a), db = depth_of(b);
+                                        const uint32_t da0 = da, db0 = db;
+                                        while (da > db) { a = m->h_parent[a]; da--; }
+                                        while (db > da) { b = m->h_parent[b]; db--; }
+                                        while (a != b) { a = m->h_parent[a]; b = m->h_parent[b]; da--; }
+                                        fprintf(stderr, "[ugp stats]   sample %llu: coarse cost %d at depth %u, exact %d (x%u) at depth %u, common ancestor at depth %u, descent %u\n",
+                                                (unsigned long long)ord[k], coarse[ord[k]].best_set_difference, da0, exact, prev[ord[k]].num_best, db0, da, ref[k]);
+                                    }
+                                }
+                            }
+                        }
+                        fprintf(stderr, "[ugp stats] loose seeds: coarse best is an ancestor of the true best for %llu (mean distance %.1f), is not for %llu\n",
+                                (unsigned long long)miss_anc, miss_anc ? (double)miss_depth / miss_anc : 0.0, (unsigned long long)miss_other);
+                        fprintf(stderr, "[ugp stats] seed - exact best, descent:");
+                        for (int i = 0; i < 18; i++) fprintf(stderr, " %llu", (unsigned long long)hist_r[i]);
+                        fprintf(stderr, "\n[ugp stats] seed - exact best, coarse: ");
+                        for (int i = 0; i < 18; i++) fprintf(stderr, " %llu", (unsigned long long)hist_c[i]);
+                        fprintf(stderr, "\n");
+                    }
+                }
+                HIP_TRY(ugp::launch_seed_ub(m->d_coarse_res.p + q0, order, (uint32_t)nq, n_tiles512, m->d_ub.p, refined, s));
+            } else
+                HIP_TRY(hipMemsetAsync(m->d_ub.p, 0x7F, (size_t)n_tiles512 * 256 * sizeof(uint32_t), s));   // 0x7F7F: above every valid cost
+        }
         HIP_TRY(hipEventRecord(es.ev[1], s));
 
         ugp::PlaceArgs a;
@@ -305,7 +361,7 @@ int run_place(ugp_mat *m, ugp_qset *qs, int mode, ugp_result *d_out, int32_t *d_
             memset(&b, 0, sizeof(b));
             b.stream8 = m->d_stream8.p; b.pre8 = m->d_pre8.p;
             b.chunk8_body_off = m->d_chunk8_body.p; b.chunk8_pre_off = m->d_chunk8_pre.p;
-            b.table = m->d_table.p; b.dbottom = d_dbottom;
+            b.table = m->d_table.p; b.dbottom = d_dbottom; b.vrows = getenv("UGP_NO_BOUND2") ? nullptr : d_vrows;
             b.n_sites = n_sites; b.n_chunks = f.n_chunks; b.n_groups = G; b.n_tiles = n_tiles512;
             b.lbest = m->d_lbest.p;
             b.list = m->d_list.p; b.list_n = d_list_n;
@@ -368,6 +424,11 @@ int run_place(ugp_mat *m, ugp_qset *qs, int mode, ugp_result *d_out, int32_t *d_
                 HIP_TRY(ugp::launch_merge(m->d_part_best.p, m->d_part_cnt.p, m->d_part_key.p, (ex && ex->rank2out) ? ex->rank2out : m->d_rank2bfs.p, G,
                                           (uint32_t)nq, d_out + q0, s));
         }
+        if ((getenv("UGP_SEED_PREV") || getenv("UGP_SEED_CHECK")) && use8 && !coarse_only && mode == 0) {
+            HIP_TRY(m->d_prev_res.reserve(Q));
+            HIP_TRY(hipMemcpyAsync(m->d_prev_res.p + q0, d_out + q0, nq * sizeof(ugp_result), hipMemcpyDeviceToDevice, s));
+            m->prev_valid = true;
+        }
         HIP_TRY(hipEventRecord(es.ev[3], s));
         m->last_used_best8 = use8;
         m->last.packed_path = use8 ? 1u : 0u;
@@ -391,7 +452,8 @@ const char *ugp_last_error(void) { return g_err.c_str(); }
 struct HostFlat {
     ugp::FlatMat f;
     std::vector<uint32_t> parent;   // copy of the caller's BFS parent array (extended searches need the topology)
-    std::vector<uint32_t> coarse2dfs;
+    std::vector<uint32_t> coarse2dfs, coarse2bfs;
+    ugp::UVec<uint32_t> child_begin, rec_off;   // full tree, for the seed descent (empty: input not in breadth-first order)
     HostFlat *coarse = nullptr;
     ~HostFlat() { delete coarse; }
 };
@@ -400,7 +462,7 @@ static int host_flatten(const ugp_tree_desc *tree, const ugp::Options &opt, bool
 
 // The top of the tree (the nodes with the largest subtrees: N/1024 of them, at least 4096) as a MAT of its own.
 // `ex` = subtree sizes and DFS positions from the flattening of the full tree.
-static int build_coarse(const ugp_tree_desc *t, const ugp::Options &opt, const ugp::FlatExtras &ex, HostFlat &hf) {
+static int build_coarse(const ugp_tree_desc *t, const ugp::Options &opt, ugp::FlatExtras &ex, HostFlat &hf) {
     const uint64_t N = t->n_nodes;
     uint64_t min_nodes = 1u << 18;   // below this a tree pass is too short for the sort to pay off
     if (const char *e = getenv("UGP_COARSE_MIN_NODES")) min_nodes = (uint64_t)atoll(e);   // tests lower it
@@ -459,6 +521,7 @@ static int build_coarse(const ugp_tree_desc *t, const ugp::Options &opt, const u
     if (int rc = host_flatten(&d, copt, false, *hf.coarse)) return rc;
     hf.coarse2dfs.resize(keep.size());
     for (size_t k = 0; k < keep.size(); k++) hf.coarse2dfs[k] = ex.dfsidx[keep[k]];
+    hf.coarse2bfs = keep;
     return UGP_OK;
 }
 
@@ -472,6 +535,7 @@ static int host_flatten(const ugp_tree_desc *tree, const ugp::Options &opt, bool
         if (rc == UGP_OK && with_coarse) {
             rc = build_coarse(tree, opt, ex, hf);
             if (rc != UGP_OK) return rc;   // (message already set)
+            if (hf.coarse) { hf.child_begin.swap(ex.child_begin); hf.rec_off.swap(ex.rec_off); }
         }
     } catch (const std::bad_alloc &) {
         return fail(UGP_ERR_NOMEM, "out of host memory while flattening the tree");
@@ -527,6 +591,12 @@ static int upload_flat(const HostFlat &hf, int device, ugp_mat **out) {
     if (hf.coarse) {
         if (int rc = upload_flat(*hf.coarse, device, &m->coarse)) { ugp_mat_destroy(m); return rc; }
         if ((e = m->d_coarse2dfs.upload(hf.coarse2dfs)) != hipSuccess) return bail(e, "upload coarse table");
+        if (!hf.child_begin.empty() && !getenv("UGP_NO_DESCENT")) {
+            if ((e = m->d_coarse2bfs.upload(hf.coarse2bfs)) != hipSuccess) return bail(e, "upload coarse table");
+            if ((e = m->d_child_begin.upload(hf.child_begin)) != hipSuccess) return bail(e, "upload children table");
+            if ((e = m->d_rec_off.upload(hf.rec_off)) != hipSuccess) return bail(e, "upload record offsets");
+            if ((e = m->d_parent.upload(hf.parent)) != hipSuccess) return bail(e, "upload parent table");
+        }
     }
     *out = m;
     return UGP_OK;

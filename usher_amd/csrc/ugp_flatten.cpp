@@ -32,8 +32,8 @@ namespace ugp {
 
 // Intermediate encoding of the packed stream while it is being emitted (slot numbers are renumbered by use
 // afterwards, and only then can a header be told apart as fast-path or H_SLOW): rslot [5:0], wslot [11:6],
-// flags below; pruning records {E_INFO, hs [29:22], jump [20:0]}.  finalize8() converts to the layout of
-// ugp_flatten.hpp.
+// flags below; pruning records {E_INFO, hs [29:22], E_SIB, hr [20:18], jump [17:0]}.  finalize8() converts to the
+// layout of ugp_flatten.hpp.
 namespace {
 constexpr uint32_t E_SKIPD = 1u << 12, E_NOSCORE = 1u << 13, E_END = 1u << 16, E_FREE = 1u << 17, E_CHUNK_END = 1u << 18,
                    E_NOP = 1u << 19, E_SIB = 1u << 21, E_INFO = 1u << 30;
@@ -182,12 +182,14 @@ int flatten(const ugp_tree_desc &t, const Options &opt, FlatMat &out, std::strin
 
     // ---- own mutation words, never-eligible leaves --------------------------------------------------------------
     Buf<uint32_t> nw(N);            // non-masked mutations of the node
+    Buf<uint8_t> rev(N);            // ... of which back to the reference base (saturating at 255)
     Buf<uint8_t> dropped(N);        // leaf without mutation words: never eligible, no descendants (packed / tie streams skip it)
     par.run(N, [&](uint64_t b, uint64_t e, unsigned) {
         for (uint64_t j = b; j < e; j++) {
-            uint32_t c = 0;
-            for (uint64_t i = t.mut_off[j]; i < t.mut_off[j + 1] && i < M; i++) c += t.mut_pos[i] >= 0;
+            uint32_t c = 0, r = 0;
+            for (uint64_t i = t.mut_off[j]; i < t.mut_off[j + 1] && i < M; i++) { c += t.mut_pos[i] >= 0; r += t.mut_pos[i] >= 0 && t.mut_nuc[i] == t.mut_ref[i]; }
             nw[j] = c;
+            rev[j] = (uint8_t)std::min<uint32_t>(r, 255);
             dropped[j] = j != 0 && child_off[j + 1] == child_off[j] && c == 0;
         }
     });
@@ -197,16 +199,19 @@ int flatten(const ugp_tree_desc &t, const Options &opt, FlatMat &out, std::strin
     // tie-stream dwords of j's descendants (without pruning records)
     UVec<uint32_t> sub(N);
     Buf<uint32_t> leaves(N), hsub(N), subw(N), subd(N);
+    Buf<uint8_t> hrev(N);   // largest number of reversions on a path j -> descendant, without j's own (saturating at 255)
     bottom_up([&](uint64_t p, unsigned) {
-        uint32_t s = 1, lv = 0, h = 0, w = 0, d = 0;
+        uint32_t s = 1, lv = 0, h = 0, w = 0, d = 0, hr = 0;
         for (uint32_t k = child_off[p]; k < child_off[p + 1]; k++) {
             const uint32_t c = children[k];
             s += sub[c]; lv += leaves[c];
             h = std::max(h, nw[c] + hsub[c]);
+            hr = std::max<uint32_t>(hr, (uint32_t)rev[c] + hrev[c]);
             w += subw[c] + (dropped[c] ? 0u : 1u + nw[c]);
             d += subd[c] + (dropped[c] ? 0u : 2u + nw[c]);
         }
         sub[p] = s; leaves[p] = (child_off[p + 1] == child_off[p]) ? 1u : lv; hsub[p] = h; subw[p] = w; subd[p] = d;
+        hrev[p] = (uint8_t)std::min<uint32_t>(hr, 255);
     });
     // largest subtree last; the others by descending hdown (the sibling pruning records rely on it)
     par.run(N, [&](uint64_t b0, uint64_t e0, unsigned) {
@@ -310,7 +315,7 @@ int flatten(const ugp_tree_desc &t, const Options &opt, FlatMat &out, std::strin
     // path, <= log2 N because the largest subtree goes last
     UVec<uint32_t> dfsidx(N);
     Buf<uint32_t> pathm(N), eff_children(N), last_eff(N), suffix_h(N), big_after(N);   // (suffix_h / big_after: non-last effective children only)
-    Buf<uint8_t> slot(N), first_child(N), first_eff(N);
+    Buf<uint8_t> slot(N), first_child(N), first_eff(N), suffix_hr(N);   // (suffix_hr: like suffix_h, over reversions)
     slot[0] = 0; first_child[0] = 0; first_eff[0] = 0;
     struct alignas(64) Maxima { uint32_t path = 0, slot = 0; };   // one cache line per thread
     std::vector<Maxima> mx(T);
@@ -336,13 +341,15 @@ int flatten(const ugp_tree_desc &t, const Options &opt, FlatMat &out, std::strin
         last_eff[p] = last;
         // sibling records: for a non-last effective child c, suffix_h[c] = max hdown over c and the non-last effective
         // siblings after it, big_after[c] = how many of those later siblings carry a pruning record of their own
-        uint32_t run_h = 0, run_big = 0;
+        uint32_t run_h = 0, run_big = 0, run_hr = 0;
         for (uint32_t k = e; k-- > b;) {
             const uint32_t c = children[k];
             if (dropped[c] || c == last) continue;
             big_after[c] = run_big;
             run_h = std::max(run_h, nw[c] + hsub[c]);
             suffix_h[c] = run_h;
+            run_hr = std::max<uint32_t>(run_hr, (uint32_t)rev[c] + hrev[c]);
+            suffix_hr[c] = (uint8_t)std::min<uint32_t>(run_hr, 255);
             if (subw[c] >= opt.prune_min_words && hsub[c] <= INFO_HS_MAX) run_big++;
         }
     });
@@ -486,23 +493,22 @@ int flatten(const ugp_tree_desc &t, const Options &opt, FlatMat &out, std::strin
         if (root && !preamble) dst[n++] = H_TAG | RS_REG | (WS_NONE << 6) | E_SKIPD | E_FREE | E_END;
         return n;
     };
-    out.chunk_pre_off.assign(NC + 1, 0); out.chunk8_pre_off.assign(NC + 1, 0);
+    out.chunk_pre_off.assign(NC + 1, 0);
     par.run(NC, [&](uint64_t b, uint64_t e, unsigned) {
         for (uint64_t c = b; c < e; c++) {
-            uint32_t l32 = 0, l8 = 0;
-            for (uint32_t q = d2b[cno[c]]; q != 0;) { q = t.parent[q]; l32 += 2u + nw[q]; l8 += 1u + nw[q]; }
-            out.chunk_pre_off[c] = l32; out.chunk8_pre_off[c] = l8;
+            uint32_t l32 = 0;
+            for (uint32_t q = d2b[cno[c]]; q != 0;) { q = t.parent[q]; l32 += 2u + nw[q]; }
+            out.chunk_pre_off[c] = l32;
         }
     }, 64);
     out.pre_stream.resize(par.exclusive_scan(out.chunk_pre_off.data(), NC));
-    out.pre8_stream.resize(par.exclusive_scan(out.chunk8_pre_off.data(), NC));
-    out.chunk_pre_off[NC] = (uint32_t)out.pre_stream.size(); out.chunk8_pre_off[NC] = (uint32_t)out.pre8_stream.size();
+    out.chunk_pre_off[NC] = (uint32_t)out.pre_stream.size();
     par.run(NC, [&](uint64_t b, uint64_t e, unsigned) {
         std::vector<uint32_t> path;
         for (uint64_t c = b; c < e; c++) {
             path.clear();
             for (uint32_t q = d2b[cno[c]]; q != 0;) { q = t.parent[q]; path.push_back(q); }
-            uint32_t *p32 = out.pre_stream.data() + out.chunk_pre_off[c], *p8 = out.pre8_stream.data() + out.chunk8_pre_off[c];
+            uint32_t *p32 = out.pre_stream.data() + out.chunk_pre_off[c];
             for (size_t i = path.size(); i-- > 0;) {
                 const uint32_t q = path[i];
                 const uint32_t *rec = &out.stream[rec_off_d[dfsidx[q]]];
@@ -510,7 +516,6 @@ int flatten(const ugp_tree_desc &t, const Options &opt, FlatMat &out, std::strin
                 *p32++ = (rec[0] & ~(63u << 16)) | ((q == 0 ? RS_BOTTOM : RS_REG) << 16) | F_NOSCORE;
                 *p32++ = rec[1];
                 for (uint32_t k = 0; k < nwords; k++) *p32++ = rec[2 + k];
-                p8 += emit8(p8, q, true);
             }
         }
     }, 64);
@@ -564,19 +569,54 @@ int flatten(const ugp_tree_desc &t, const Options &opt, FlatMat &out, std::strin
                 if (dropped[j]) continue;
                 if (has_sib(j)) {   // jump: from this node's header to the first word of the parent's last effective child
                     const uint64_t jump = (uint64_t)pos8_at[dfsidx[last_eff[t.parent[j]]]] - pos8_hdr[d];
-                    s8[pos8_at[d]] = (jump <= INFO_JUMP_MASK && jump > 0) ? (H_TAG | E_INFO | E_SIB | (suffix_h[j] << 22) | (uint32_t)jump) : (H_TAG | E_NOP);
+                    const uint32_t hr = std::min<uint32_t>(suffix_hr[j], INFO_HR_NONE);
+                    s8[pos8_at[d]] = (jump <= INFO_JUMP_MASK && jump > 0) ? (H_TAG | E_INFO | E_SIB | (suffix_h[j] << 22) | (hr << INFO_HR_SHIFT) | (uint32_t)jump) : (H_TAG | E_NOP);
                 }
                 if (is_big(j)) {    // jump: the words of the descendants (a subtree that ends with a chunk lands on its chunk-end word)
                     const uint64_t d_end = (uint64_t)d + sub[j];
                     const uint64_t own_end = (uint64_t)pos8_hdr[d] + 1u + nw[j];
                     const uint64_t jump = (uint64_t)pos8_at[d_end] - (chunk_start[d_end] ? 1u : 0u) - own_end;
-                    s8[pos8_start[d]] = (jump <= INFO_JUMP_MASK && jump > 0) ? (H_TAG | E_INFO | (hsub[j] << 22) | (uint32_t)jump) : (H_TAG | E_NOP);
+                    const uint32_t hr = std::min<uint32_t>(hrev[j], INFO_HR_NONE);
+                    s8[pos8_start[d]] = (jump <= INFO_JUMP_MASK && jump > 0) ? (H_TAG | E_INFO | (hsub[j] << 22) | (hr << INFO_HR_SHIFT) | (uint32_t)jump) : (H_TAG | E_NOP);
                 }
                 emit8(s8 + pos8_hdr[d], j, false);
             }
             s8[out.chunk8_body_off[c + 1] - 1] = H_TAG | E_CHUNK_END;
         }
     }, 16);
+    // Packed preambles, with a pruning record in front of every path node below the root: {E_INFO, hs, hr, jump} with
+    // jump = where the body goes on behind the node's subtree, relative to the chunk's first body word (capped: "beyond
+    // any unit").  A unit far from the tile's samples is usually inside a subtree that the second bound already rules out
+    // a few nodes below the point where its root path leaves the samples' paths: the replay stops there and the body
+    // starts behind that subtree -- most of the time behind the whole unit.  hs = PRE_HS_NONE: hsub does not fit the field.
+    auto pre_rec = [&](uint32_t q) -> bool { return q != 0 && (hsub[q] < PRE_HS_NONE || hrev[q] < INFO_HR_NONE); };
+    out.chunk8_pre_off.assign(NC + 1, 0);
+    par.run(NC, [&](uint64_t b, uint64_t e, unsigned) {
+        for (uint64_t c = b; c < e; c++) {
+            uint32_t l8 = 0;
+            for (uint32_t q = d2b[cno[c]]; q != 0;) { q = t.parent[q]; l8 += 1u + nw[q] + (pre_rec(q) ? 1u : 0u); }
+            out.chunk8_pre_off[c] = l8;
+        }
+    }, 64);
+    out.pre8_stream.resize(par.exclusive_scan(out.chunk8_pre_off.data(), NC));
+    out.chunk8_pre_off[NC] = (uint32_t)out.pre8_stream.size();
+    par.run(NC, [&](uint64_t b, uint64_t e, unsigned) {
+        std::vector<uint32_t> path;
+        for (uint64_t c = b; c < e; c++) {
+            path.clear();
+            for (uint32_t q = d2b[cno[c]]; q != 0;) { q = t.parent[q]; path.push_back(q); }
+            uint32_t *p8 = out.pre8_stream.data() + out.chunk8_pre_off[c];
+            for (size_t i = path.size(); i-- > 0;) {
+                const uint32_t q = path[i];
+                if (pre_rec(q)) {
+                    const uint64_t rel = (uint64_t)pos8_at[(uint64_t)dfsidx[q] + sub[q]] - out.chunk8_body_off[c];
+                    *p8++ = H_TAG | E_INFO | (std::min<uint32_t>(hsub[q], PRE_HS_NONE) << 22) | (std::min<uint32_t>(hrev[q], INFO_HR_NONE) << INFO_HR_SHIFT) |
+                            (uint32_t)std::min<uint64_t>(rel, INFO_JUMP_MASK);
+                }
+                p8 += emit8(p8, q, true);
+            }
+        }
+    }, 64);
     flat_lap("packed stream");
 
     // ---- tie stream (phase 2 walks it one chunk at a time) ---------------------------------------------------------------------
@@ -655,7 +695,7 @@ int flatten(const ugp_tree_desc &t, const Options &opt, FlatMat &out, std::strin
                     uint32_t &w = v[i];
                     if (!(w & H_TAG)) continue;
                     if (w & E_INFO) {   // (first: the jump length overlaps the other intermediate flag bits)
-                        w = H_TAG | H_INFO | H_RARE | (w & E_SIB ? H_SIB : 0u) | (((w >> 22) & 0x7Fu) << INFO_HS_SHIFT) | (w & INFO_JUMP_MASK);
+                        w = H_TAG | H_INFO | H_RARE | (w & E_SIB ? H_SIB : 0u) | (((w >> 22) & 0x7Fu) << INFO_HS_SHIFT) | (w & ((7u << INFO_HR_SHIFT) | INFO_JUMP_MASK));
                         continue;
                     }
                     if (w & E_CHUNK_END) { w = H_TAG | H_RARE | H_CHUNK_END; continue; }
@@ -725,7 +765,17 @@ int flatten(const ugp_tree_desc &t, const Options &opt, FlatMat &out, std::strin
         par.run(n_units, [&](uint64_t b, uint64_t e, unsigned) { for (uint64_t u = b; u < e; u++) walk_unit((uint32_t)u, out.sum8.data() + out.sum8_off[u]); }, 16);
     }
     flat_lap("summaries");
-    if (extras) { extras->sub.swap(sub); extras->dfsidx.swap(dfsidx); }
+    if (extras) {
+        extras->child_begin.clear(); extras->rec_off.clear();
+        if (bfs_levels) {
+            extras->child_begin.resize(N + 1); extras->rec_off.resize(N);
+            par.run(N, [&](uint64_t b, uint64_t e, unsigned) {
+                for (uint64_t j = b; j < e; j++) { extras->child_begin[j] = child_off[j]; extras->rec_off[j] = rec_off_d[dfsidx[j]]; }
+            });
+            extras->child_begin[N] = child_off[N];
+        }
+        extras->sub.swap(sub); extras->dfsidx.swap(dfsidx);
+    }
     return UGP_OK;
 }
 

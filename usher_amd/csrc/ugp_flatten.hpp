@@ -65,16 +65,26 @@ constexpr uint32_t T_PRUNE_MIN_DWORDS = 24;  // subtrees shorter than this are n
 //       H_CHUNK_END (with H_RARE) closes a chunk: publish the chunk-local minimum and reset
 //       H_NOP     (with H_RARE) padding
 //       H_INFO    (with H_RARE, in front of the header of a node with a large subtree) pruning record:
-//                 [20:0] jump = stream words occupied by the node's descendants,
-//                 [28:22] hsub = largest number of mutation words on any path node -> descendant;
-//                 every descendant d has cost(d) >= D(node) - hsub (each mutation lowers D by at most 1),
-//                 so the subtree can be skipped when D(node,s) - hsub > upper bound of best(s) for all s
+//                 [17:0] jump = stream words occupied by the node's descendants,
+//                 [28:22] hsub = largest number of mutation words on any path node -> descendant,
+//                 [20:18] hrev = largest number of mutations BACK TO THE REFERENCE BASE on any such path
+//                 (INFO_HR_NONE = 7: more than 6, the second bound below is not available).
+//                 Two lower bounds hold for every descendant d and sample s:
+//                   cost(d,s) >= D(node,s) - hsub          each mutation lowers D by at most 1
+//                   cost(d,s) >= D(node,s) - (V_s + hrev)  V_s = rows of s with an allele set other than {reference}:
+//                     along a path a site lowers D at most once more often than it raises it, and only a site whose
+//                     state at `node` lies outside the sample's set can do that -- a site where the sample has such
+//                     a row (at most V_s of them) or a site that the path turns back to the reference base
+//                 so the subtree is skipped when D(node,s) - min(hsub, V_s + hrev) > upper bound of best(s) for
+//                 all s.  Near the top of the tree hsub is large (the deepest path below) and the second bound
+//                 decides; deep down hsub is small and the first one does.
 //       H_INFO | H_SIB (in front of a non-last child c_i of a node p, before c_i's own H_INFO):
-//                 sibling record: [20:0] jump = stream words from c_i's header to the start of p's last child,
+//                 sibling record: [17:0] jump = stream words from c_i's header to the start of p's last child,
 //                 [28:22] hs = max over the remaining non-last children c_j (j >= i) of (mutation words of c_j +
-//                 hsub(c_j)); every node d of those subtrees has cost(d) >= D(p) - hs, so when
-//                 D(p,s) - hs > upper bound of best(s) for all s they are all skipped with one jump.  The
-//                 non-last children are emitted in descending order of that quantity, so hs only shrinks.
+//                 hsub(c_j)), [20:18] hr = the same maximum over (reversions of c_j + hrev(c_j)); every node d of
+//                 those subtrees has cost(d) >= D(p) - min(hs, V_s + hr), so when that exceeds the upper bound of
+//                 best(s) for all s they are all skipped with one jump.  The non-last children are emitted in
+//                 descending order of hs, so hs only shrinks.
 //     The root is emitted as two records: its D record (H_BOTTOM, H_NOSCORE) followed by a scoring
 //     pseudo-node (H_REG | H_SKIPD | H_FREE | H_END) whose cost is D(parent) = D(root): cost(root) = D(root),
 //     always eligible (usher_mapper.cpp:454).
@@ -86,7 +96,13 @@ constexpr uint32_t H_TAG = 1u << 31, H_INFO = 1u << 30, H_RARE = 1u << 29, H_SIB
 constexpr uint32_t H_REG = 1u << 0, H_STORE = 1u << 1, H_NOSCORE = 1u << 2, H_END = 1u << 3, H_FREE = 1u << 4,
                    H_SKIPD = 1u << 5, H_BOTTOM = 1u << 6, H_SLOW = 1u << 7, H_CHUNK_END = 1u << 8, H_NOP = 1u << 9;
 constexpr uint32_t H_RSLOT_SHIFT = 10, H_WSLOT_SHIFT = 20;
-constexpr uint32_t INFO_JUMP_MASK = (1u << 21) - 1u, INFO_HS_SHIFT = 22, INFO_HS_MAX = 127;
+constexpr uint32_t INFO_JUMP_MASK = (1u << 18) - 1u, INFO_HS_SHIFT = 22, INFO_HS_MAX = 127;
+constexpr uint32_t INFO_HR_SHIFT = 18, INFO_HR_NONE = 7;   // hrev field; 7 = not available (more than 6 reversions on some path)
+// Preamble copies (pre8) carry a pruning record too, in front of every path node below the root: same hs / hr fields
+// (hs = PRE_HS_NONE: hsub too large for the field, first bound not available), and [17:0] = the position, relative to
+// the chunk's first body word, where the body goes on behind that node's subtree (INFO_JUMP_MASK = beyond any unit).
+// When the record's test holds during the replay, the rest of the preamble and the body up to that position are skipped.
+constexpr uint32_t PRE_HS_NONE = 127;
 // summary stream ("sum8", see ugp_flatten.cpp): per top-level subtree of a run of super_chunks chunks
 //   SUM_A  [28:22] hsub of the node (capped)   [21:0] position of the node's first word (pruning record or header,
 //          behind a sibling record) in the packed stream, relative to the run's first body word
@@ -153,6 +169,9 @@ struct FlatMat {
 // By-products of the flattening that the caller may want (both by BFS index): subtree sizes, DFS position.
 struct FlatExtras {
     UVec<uint32_t> sub, dfsidx;
+    // only when the input is a breadth-first expansion (parent[] ascending), else empty: the children of node j are the
+    // nodes child_begin[j] + 1 .. child_begin[j + 1]; rec_off[j] = dword offset of j's record in FlatMat::stream
+    UVec<uint32_t> child_begin, rec_off;
 };
 
 // Returns UGP_OK or a negative UGP_ERR_* with `err` filled.

@@ -82,7 +82,7 @@ __global__ void k_scatter_entries(uint32_t *__restrict__ table, uint32_t *__rest
                                   const uint32_t *__restrict__ ent_q, const int32_t *__restrict__ pos2site,
                                   uint32_t max_pos, uint32_t n_sites, uint64_t n_ent, uint32_t q_base,
                                   uint32_t *__restrict__ active, uint32_t active_words,
-                                  const uint32_t *__restrict__ slot_of) {
+                                  const uint32_t *__restrict__ slot_of, uint32_t *__restrict__ vrows) {
     const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const bool valid = e < n_ent;
     uint32_t q = 0, r = 0, a = 0, miss = 1;
@@ -103,6 +103,15 @@ __global__ void k_scatter_entries(uint32_t *__restrict__ table, uint32_t *__rest
     if (__builtin_amdgcn_ballot_w64(valid && q != q0) == 0) {
         if (mm && (threadIdx.x & 63u) == (uint32_t)__builtin_ctzll(mm)) atomicAdd(&dbottom[q0], (uint32_t)__builtin_popcountll(mm));
     } else if (mism) atomicAdd(&dbottom[q], 1u);
+    // V = #{rows whose allele set is neither missing nor just the reference base}: the sites at which the sample can
+    // gain from a mutation away from the reference (second pruning bound of k_best8, ugp_flatten.hpp)
+    if (vrows) {
+        const bool var = valid && !miss && a != r;
+        const unsigned long long vm = __builtin_amdgcn_ballot_w64(var);
+        if (__builtin_amdgcn_ballot_w64(valid && q != q0) == 0) {
+            if (vm && (threadIdx.x & 63u) == (uint32_t)__builtin_ctzll(vm)) atomicAdd(&vrows[q0], (uint32_t)__builtin_popcountll(vm));
+        } else if (var) atomicAdd(&vrows[q], 1u);
+    }
     if (!valid || p < 0 || (uint32_t)p > max_pos) return;
     const int32_t site = pos2site[p];
     if (site < 0) return;
@@ -482,9 +491,9 @@ __global__ void __launch_bounds__(64) k_best8(Best8Args a) {
     // Upper bounds (+1) of the tile this wave worked on last, kept across units: the shared copy is read and
     // written with agent-scope accesses that leave the XCD, ~40 us of wave time per exchange, so it is
     // consulted when the wave moves to another tile and every a.ub_every chunk ends, not at every chunk end.
-    Pk4 ub1;
+    Pk4 ub1, ubv1;   // ubv1 = min(ub1 + V, 0x7F80) per sample, V = the sample's variant rows (second pruning bound)
 #pragma unroll
-    for (int j = 0; j < 4; j++) ub1.v[j] = 0x80008000u;
+    for (int j = 0; j < 4; j++) { ub1.v[j] = 0x80008000u; ubv1.v[j] = 0x7F807F80u; }
     uint32_t ub_tile = 0xFFFFFFFFu;   // uniform: tile whose bounds are in ub1
     uint32_t ub_age = 0;              // uniform: chunk ends since the last exchange
     for (;;) {
@@ -549,6 +558,18 @@ __global__ void __launch_bounds__(64) k_best8(Best8Args a) {
 #pragma unroll
         for (int j = 0; j < 4; j++) dbot.v[j] = (db[j] & 0xFFFFu) | (db[j + 4] << 16);
     }
+    // ubv1 follows ub1 (chunk ends, exchanges: outside the pipelined loop).  V is read again each time rather than held in
+    // four more registers -- they would cost the fifth wave per SIMD.  (ub1 <= 0x8000 and V < 0x7F7F per half: the sum
+    // stays below 0x10000; the cap keeps the far test free of borrows.)
+    const uint32_t *vr = a.vrows + (uint64_t)tile * 512 + lane * 8;
+    auto refresh_ubv = [&]() {
+        if (!a.vrows) return;   // (UGP_NO_BOUND2: ubv1 stays at the cap, the second test never holds)
+        const uint4 lo = *(const uint4 *)vr, hi = *(const uint4 *)(vr + 4);
+        ubv1.v[0] = pk_min(padd(ub1.v[0], (lo.x & 0xFFFFu) | (hi.x << 16)), 0x7F807F80u);
+        ubv1.v[1] = pk_min(padd(ub1.v[1], (lo.y & 0xFFFFu) | (hi.y << 16)), 0x7F807F80u);
+        ubv1.v[2] = pk_min(padd(ub1.v[2], (lo.z & 0xFFFFu) | (hi.z << 16)), 0x7F807F80u);
+        ubv1.v[3] = pk_min(padd(ub1.v[3], (lo.w & 0xFFFFu) | (hi.w << 16)), 0x7F807F80u);
+    };
     Pk4 best, dcur, dpar, carryD, carryN, carryC;
 #pragma unroll
     for (int j = 0; j < 4; j++) { best.v[j] = 0xFFFFFFFFu; dcur.v[j] = 0; dpar.v[j] = 0; carryD.v[j] = 0; carryN.v[j] = 0; carryC.v[j] = 0; }
@@ -559,6 +580,8 @@ __global__ void __launch_bounds__(64) k_best8(Best8Args a) {
     const uint32_t NOPW = H_TAG | H_RARE | H_NOP;
     // pruning: ub1 = (upper bound of best(s)) + 1 per sample, refreshed from / published to a.ub at chunk ends
     bool prune = false;        // uniform; only while walking the body (phase 1)
+    bool pre_prune = false;    // uniform: replaying the preamble with its pruning records (one per path node)
+    uint32_t body_start = 0;   // uniform: where the body walk begins (behind the subtree of a path node found far)
     bool have_info = false;    // uniform
     bool have_sinfo = false;   // uniform: a sibling record waits for the next header
     uint32_t sinfo = 0;        // uniform
@@ -583,6 +606,7 @@ __global__ void __launch_bounds__(64) k_best8(Best8Args a) {
             __hip_atomic_store(ubp + j, u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             ub1.v[j] = pk_add(u, 0x00010001u);
         }
+        refresh_ubv();
     };
     // A chunk's minima matter only if some sample's minimum is within its upper bound (the global minimum
     // never exceeds the bound): only then are they stored, and the chunk is appended to the tile's list of records
@@ -606,20 +630,36 @@ __global__ void __launch_bounds__(64) k_best8(Best8Args a) {
 #pragma unroll
                 for (int j = 0; j < 4; j++)   // what this wave found itself ("no candidate" is 0xFFFF: take the minimum before the +1)
                     ub1.v[j] = pk_add(pk_min(pk_sub(ub1.v[j], 0x00010001u), best.v[j]), 0x00010001u);
+                refresh_ubv();
             }
         }
 #pragma unroll
         for (int j = 0; j < 4; j++) best.v[j] = 0xFFFFFFFFu;
         chunk++;
     };
-    // "can everything below / beside this node be skipped?": true when D - hs > upper bound of best(s) for all 512 samples
-    // (per half: 0x8000 + D - hs - (ub + 1) keeps bit 15 exactly when D - hs > ub; D < 0x7F7F, ub + 1 + hs <= 0x7FFF,
-    // so no half borrows from its neighbour and plain 32-bit arithmetic is exact)
+    // "can everything below / beside this node be skipped?": true when, for all 512 samples,
+    //     D - hs > ub   or   D - (V + hr) > ub            (ub = upper bound of best(s); the two lower bounds of ugp_flatten.hpp)
+    // Per half: 0x8000 + D - hs - (ub + 1) keeps bit 15 exactly when D - hs > ub; D < 0x7F7F, ub + 1 + hs <= 0x7FFF, and
+    // in the second test min(ub + 1 + V, 0x7F80) + hr <= 0x7F86, so no half borrows from its neighbour and plain 32-bit
+    // arithmetic is exact (a capped sum only makes the test fail).
     auto all_far = [&](const Pk4 &d, uint32_t rec) -> bool {
-        const uint32_t K = 0x80008000u - ((rec >> INFO_HS_SHIFT) & 0x7Fu) * 0x00010001u;
+        const uint32_t hs = (rec >> INFO_HS_SHIFT) & 0x7Fu;
+        const uint32_t K = 0x80008000u - hs * 0x00010001u;
+        const uint32_t hr = (rec >> INFO_HR_SHIFT) & 7u;
         uint32_t r = 0xFFFFFFFFu;
+        if (pre_prune && hs == PRE_HS_NONE) {   // preamble record whose hsub does not fit: the second bound only
+            if (hr == INFO_HR_NONE) return false;
+            const uint32_t K2 = 0x80008000u - hr * 0x00010001u;
 #pragma unroll
-        for (int j = 0; j < 4; j++) r &= psub(padd(d.v[j], K), ub1.v[j]);
+            for (int j = 0; j < 4; j++) r &= psub(padd(d.v[j], K2), ubv1.v[j]);
+        } else if (hr != INFO_HR_NONE) {
+            const uint32_t K2 = 0x80008000u - hr * 0x00010001u;
+#pragma unroll
+            for (int j = 0; j < 4; j++) r &= psub(padd(d.v[j], K), ub1.v[j]) | psub(padd(d.v[j], K2), ubv1.v[j]);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; j++) r &= psub(padd(d.v[j], K), ub1.v[j]);
+        }
         return __builtin_amdgcn_ballot_w64((r & 0x80008000u) != 0x80008000u) == 0;
     };
 
@@ -680,6 +720,12 @@ __global__ void __launch_bounds__(64) k_best8(Best8Args a) {
         if (have_info) {   // this node carries a pruning record: can its whole subtree be skipped?
             have_info = false;
             if (all_far(dcur, info)) {
+                if (pre_prune) {   // a path node: nothing of its subtree is needed -- end the replay, start the body behind it
+                    body_start = info & INFO_JUMP_MASK;
+                    skip_to = 0x7FFFFFFFu;
+                    if (STATS) n_skipped += body_start;
+                    return true;
+                }
                 skip_to = pos + 1 + (info & INFO_JUMP_MASK);
                 if (STATS) { n_skipped += info & INFO_JUMP_MASK; if (run_nodes == 1) n_first_skip++; }
                 return true;
@@ -710,7 +756,7 @@ __global__ void __launch_bounds__(64) k_best8(Best8Args a) {
     // words that leave the fast path (H_RARE); true: the pipeline has to restart at skip_to
     auto rare_word = [&](uint32_t w, uint32_t pos) -> bool {
         if (w & H_INFO) {
-            if (prune) {
+            if (prune || pre_prune) {
                 if (w & H_SIB) { sinfo = w; have_sinfo = true; }   // about the node that follows and its later siblings
                 else { info = w; have_info = true; }               // about the node that follows and its descendants
             }
@@ -786,8 +832,9 @@ __global__ void __launch_bounds__(64) k_best8(Best8Args a) {
                            c1 == min(c0 + a.super_chunks, a.n_chunks);
     uint32_t sv_lo = 0, sv_hi = 0;   // per lane
     uint32_t n_sv = 0;               // uniform
+    body_start = 0;
     for (int phase = 0; phase < 3; phase++) {
-        if (phase == 1 && !summarise) continue;
+        if (phase == 1 && (!summarise || body_start)) continue;
         sp = phase == 0 ? a.pre8 : (phase == 1 ? a.sum8 : a.stream8);
         const uint32_t begin = phase == 0 ? a.chunk8_pre_off[c0] : (phase == 1 ? a.sum8_off[c0 / a.super_chunks] : a.chunk8_body_off[c0]);
         const uint32_t end = phase == 0 ? a.chunk8_pre_off[c0 + 1] : (phase == 1 ? a.sum8_off[c0 / a.super_chunks + 1] : a.chunk8_body_off[c1]);
@@ -814,15 +861,18 @@ __global__ void __launch_bounds__(64) k_best8(Best8Args a) {
             return (act ? (wv & 0x3FFFFFu) + CONST_ROWS : (is_hdr ? 0u : (wv >> 26) & 3u)) << 8;
         };
         prune = (phase >= 1) && can_prune;
+        pre_prune = phase == 0 && can_prune && !unit_heavy;
+        have_info = false;
         cend = phase == 2 ? (uint32_t)__builtin_amdgcn_readfirstlane((int)(a.chunk8_body_off[c0 + 1] - 1u - begin)) : 0xFFFFFFFFu;
         cend_stale = false;
-        if (prune && ub_tile != tile) {   // start from what earlier waves of this tile already know
+        if ((prune || pre_prune) && ub_tile != tile) {   // start from what earlier waves of this tile already know
 #pragma unroll
             for (int j = 0; j < 4; j++)
                 ub1.v[j] = pk_add(__hip_atomic_load(ubp + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), 0x00010001u);
             ub_tile = tile;
             ub_age = 0;
         }
+        if (prune || pre_prune) refresh_ubv();   // (V belongs to the unit's tile)
         // One stream word of the group being evaluated: w0v = the group's words (lane k = word k),
         // x = the lane's dword of the word's table row.  Returns true when the pipeline has to restart at
         // skip_to (chunk end that stores, pruning jump, slow header).
@@ -933,7 +983,7 @@ __global__ void __launch_bounds__(64) k_best8(Best8Args a) {
         // body ranges to walk: everything, or the survivors of the summary
         uint32_t off = 0;
         uint32_t sv_next = 0;        // uniform: next survivor range
-        const bool ranged = phase == 2 && summarise;
+        const bool ranged = phase == 2 && summarise && !body_start;
         auto next_range = [&]() -> bool {   // position the walk at the next survivor range, closing the chunks in between
             const bool more = sv_next < n_sv;
             const uint32_t lo = more ? rdlane(sv_lo, sv_next & 63u) : n;
@@ -951,6 +1001,13 @@ __global__ void __launch_bounds__(64) k_best8(Best8Args a) {
             return more;
         };
         if (ranged && !next_range()) continue;
+        if (phase == 2 && body_start) {   // the replay ended at a path node whose subtree is not needed: close the chunks in front of its end
+            off = min(body_start, n);
+            while (chunk < c1 && off > cend) {
+                chunk_end();
+                cend = chunk < c1 ? (uint32_t)__builtin_amdgcn_readfirstlane((int)(a.chunk8_body_off[chunk + 1] - 1u - begin)) : 0xFFFFFFFFu;
+            }
+        }
         bool cautious = false;   // uniform: the last run was cut short by a jump inside its first group
         for (;;) {
         while (off < lim) {
@@ -1187,16 +1244,122 @@ __global__ void k_invert(const uint32_t *__restrict__ order, uint32_t n, uint32_
 // eligible in the full tree with the same cost (a kept node that is a leaf only in the coarse tree is
 // eligible there iff common > 0, which makes an internal node eligible too): the value is a real cost.
 __global__ void k_seed_ub(const ugp_result *__restrict__ coarse_res, const uint32_t *__restrict__ order, uint32_t n_queries,
-                          uint32_t n_words, uint32_t *__restrict__ ub) {
+                          uint32_t n_words, uint32_t *__restrict__ ub, const uint32_t *__restrict__ refined) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;   // word (tile*64 + lane)*4 + jj holds samples jj and jj+4 of the lane
     if (i >= n_words) return;
     const uint32_t slot = (i >> 2) * 8 + (i & 3u);
     auto val = [&](uint32_t q) -> uint32_t {
         if (q >= n_queries) return 0x7F7Fu;
         const int32_t b = coarse_res[order[q]].best_set_difference;
-        return b < 0 || b > 0x7F7F ? 0x7F7Fu : (uint32_t)b;
+        const uint32_t v = b < 0 || b > 0x7F7F ? 0x7F7Fu : (uint32_t)b;
+        return refined ? min(v, refined[q]) : v;   // (the descent below: also the cost of a real eligible node)
     };
     ub[i] = val(slot) | (val(slot + 4) << 16);
+}
+
+// Tighter seeds: a best-first descent from the sample's best node in the coarse MAT.  The coarse MAT ends ~1,000 nodes above
+// the leaves, so its best cost still counts every mutation the sample shares with the rest of its lineage (8 on average, up
+// to 20, at 10M nodes); with bounds that loose the second pruning bound and the preamble records of k_best8 decide late
+// (seeded with the exact answers the kernel is 40 % faster).  One wave per sample: a small frontier of (node, D) pairs lives
+// in LDS; the entry with the smallest D is expanded -- the lanes evaluate its children (64 per round) in the full tree:
+// D(child), cost(child), eligibility, exactly as the walk kernels do -- the smallest eligible cost seen is kept, and every
+// internal child whose D does not exceed its parent's joins the frontier.  Along the sample's own lineage D never grows
+// (every mutation there is one the sample has), siblings that merely tie (no mutations) are dead ends one level further
+// down, so the frontier stays tiny.  Every value recorded is the cost of a real eligible node: the result is a valid upper
+// bound of best(s) whatever the search misses; it only has to be good, not exact.
+// The search starts at the coarse best node AND at its nearest ancestors: in a tree with much homoplasy the coarse winner is
+// now and then (4 % of the benchmark's samples) a sibling branch that happens to share one mutation with the sample, one or
+// two levels below the point where the sample's own lineage leaves the coarse MAT.
+// Needs the children of a node to be contiguous in BFS index (child_begin[j] + 1 .. child_begin[j + 1]).
+constexpr uint32_t DESC_FRONTIER = 32, DESC_MAX_EXPANSIONS = 96, DESC_UP = 3;
+__global__ void __launch_bounds__(256) k_descend(const ugp_result *__restrict__ coarse_res, const uint32_t *__restrict__ order, uint32_t n_queries,
+                          const uint32_t *__restrict__ coarse2bfs, const uint32_t *__restrict__ child_begin, const uint32_t *__restrict__ rec_off,
+                          const uint32_t *__restrict__ parent, const uint32_t *__restrict__ stream, const uint32_t *__restrict__ table, uint32_t n_sites,
+                          uint32_t *__restrict__ refined) {
+    __shared__ uint32_t f_node[4][DESC_FRONTIER];
+    __shared__ int f_d[4][DESC_FRONTIER];
+    const uint32_t wv = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const uint32_t slot = blockIdx.x * 4u + wv;
+    if (slot >= n_queries) return;
+    const ugp_result r = coarse_res[order ? order[slot] : slot];
+    if (r.best_j == 0xFFFFFFFFu || r.best_set_difference < 0 || r.best_set_difference > 0x7F7F) { if (lane == 0) refined[slot] = 0x7F7Fu; return; }
+    const uint32_t *trow = table + ((uint64_t)(slot >> 9) * (n_sites + TABLE_CONST_ROWS) + TABLE_CONST_ROWS) * 64 + ((slot & 511u) >> 3);
+    const uint32_t sh = (slot & 7u) * 4u;
+    // one node for one sample: sum of delta over all words, sum of min(delta, 0) and shared mutations before the first masked one
+    auto eval = [&](uint32_t j, int &dsum, int &neg, uint32_t &common, uint32_t &w0) {
+        const uint32_t *rec = stream + rec_off[j];
+        w0 = rec[0];
+        const uint32_t nw = w0 & 0xFFFFu;
+        dsum = 0; neg = 0; common = 0;
+        for (uint32_t k = 0; k < nw; k++) {
+            const uint32_t w = rec[2 + k];
+            const uint32_t S = (trow[(uint64_t)(w & 0x3FFFFFu) * 64] >> sh) & 15u;
+            const int c = (int)((S >> ((w >> 22) & 3u)) & 1u), p = (int)((S >> ((w >> 24) & 3u)) & 1u);
+            const int d = p - c;
+            dsum += d;
+            if (!(w & M_AFTER_MASK)) { neg += min(d, 0); common += (uint32_t)c; }
+        }
+    };
+    int best = r.best_set_difference;
+    uint32_t n_f = 0;   // uniform: frontier entries
+    uint32_t start[DESC_UP + 1];   // uniform: the start nodes (an ancestor's expansion must not enter the next one again)
+#pragma unroll
+    for (uint32_t i = 0; i <= DESC_UP; i++) start[i] = 0xFFFFFFFFu;
+    {
+        uint32_t node = coarse2bfs[r.best_j];
+        start[0] = node;
+        int dsum, neg; uint32_t common, w0;
+        eval(node, dsum, neg, common, w0);
+        // cost(node) = D(parent) + neg = best  ->  D(parent) = best - neg, D(node) = D(parent) + dsum;  the root's cost is its D
+        int D = (w0 & F_ROOT) ? best : best - neg + dsum;
+        if (lane == 0) { f_node[wv][0] = node; f_d[wv][0] = D; }
+        n_f = 1;
+        for (uint32_t up = 0; up < DESC_UP && node != 0; up++) {   // D(ancestor) = D(child) - (sum of the child's deltas)
+            D -= dsum;
+            node = parent[node];
+            start[up + 1] = node;
+            if (lane == 0) { f_node[wv][n_f] = node; f_d[wv][n_f] = D; }
+            n_f++;
+            eval(node, dsum, neg, common, w0);
+        }
+    }
+    for (uint32_t it = 0; it < DESC_MAX_EXPANSIONS && n_f; it++) {
+        // pop the entry with the smallest D
+        unsigned long long kk = lane < n_f ? (((unsigned long long)(uint32_t)f_d[wv][lane] << 32) | lane) : ~0ull;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { const unsigned long long other = __shfl_xor(kk, o); kk = other < kk ? other : kk; }
+        const uint32_t e = (uint32_t)kk & 63u;
+        const uint32_t node = f_node[wv][e];
+        const int D = f_d[wv][e];
+        n_f--;
+        if (lane == 0 && e != n_f) { f_node[wv][e] = f_node[wv][n_f]; f_d[wv][e] = f_d[wv][n_f]; }
+        const uint32_t cb = child_begin[node] + 1u, ce = child_begin[node + 1] + 1u;   // children: BFS indices [cb, ce)
+        for (uint32_t c0 = cb; c0 < ce; c0 += 64) {
+            const uint32_t c = c0 + lane;
+            int cost = 0x7FFFFFFF, dc = 0;
+            bool push = false;
+            if (c < ce) {
+                int dsum, neg; uint32_t common, w0;
+                eval(c, dsum, neg, common, w0);
+                const bool leaf = (w0 & F_LEAF) != 0, masked = (w0 & F_MASKED) != 0;
+                if (!masked && (common > 0 || (!leaf && (w0 & 0xFFFFu) == 0))) cost = D + neg;
+                dc = D + dsum;
+                push = !leaf && dc <= D;
+#pragma unroll
+                for (uint32_t i = 0; i < DESC_UP; i++) push = push && c != start[i];   // (already in the frontier)
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) cost = min(cost, __shfl_xor(cost, o));
+            best = min(best, cost);
+            const unsigned long long pm = __builtin_amdgcn_ballot_w64(push);
+            if (push) {
+                const uint32_t at = n_f + (uint32_t)__builtin_popcountll(pm & ((1ull << lane) - 1ull));
+                if (at < DESC_FRONTIER) { f_node[wv][at] = c; f_d[wv][at] = dc; }
+            }
+            n_f = min(n_f + (uint32_t)__builtin_popcountll(pm), DESC_FRONTIER);
+        }
+    }
+    if (lane == 0) refined[slot] = (uint32_t)max(0, min(best, 0x7F7F));
 }
 
 // Where in the chunk order do a tile's own samples sit?  keys_sorted[q] = DFS rank of the coarse best node of
@@ -1244,9 +1407,18 @@ hipError_t launch_tile_ranges(const uint32_t *keys_sorted, uint32_t n_queries, u
 }
 
 hipError_t launch_seed_ub(const ugp_result *coarse_res, const uint32_t *order, uint32_t n_queries, uint32_t n_tiles512, uint32_t *ub,
-                          hipStream_t s) {
+                          const uint32_t *refined, hipStream_t s) {
     const uint32_t n_words = n_tiles512 * 256;
-    hipLaunchKernelGGL(k_seed_ub, dim3((n_words + 255) / 256), dim3(256), 0, s, coarse_res, order, n_queries, n_words, ub);
+    hipLaunchKernelGGL(k_seed_ub, dim3((n_words + 255) / 256), dim3(256), 0, s, coarse_res, order, n_queries, n_words, ub, refined);
+    return hipGetLastError();
+}
+
+hipError_t launch_descend(const ugp_result *coarse_res, const uint32_t *order, uint32_t n_queries, const uint32_t *coarse2bfs,
+                          const uint32_t *child_begin, const uint32_t *rec_off, const uint32_t *parent, const uint32_t *stream, const uint32_t *table,
+                          uint32_t n_sites, uint32_t *refined, hipStream_t s) {
+    if (!n_queries) return hipSuccess;
+    hipLaunchKernelGGL(k_descend, dim3((n_queries + 3) / 4), dim3(256), 0, s, coarse_res, order, n_queries, coarse2bfs, child_begin, rec_off, parent,
+                       stream, table, n_sites, refined);
     return hipGetLastError();
 }
 
@@ -1275,11 +1447,11 @@ hipError_t launch_fill_table(uint32_t *table, const uint8_t *site_ref, uint32_t 
 hipError_t launch_scatter(uint32_t *table, uint32_t *dbottom, const int32_t *pos, const uint8_t *ref,
                           const uint8_t *nuc, const uint8_t *is_missing, const uint32_t *ent_q,
                           const int32_t *pos2site, uint32_t max_pos, uint32_t n_sites, uint64_t n_ent, uint32_t q_base,
-                          uint32_t *active, uint32_t active_words, const uint32_t *slot_of, hipStream_t s) {
+                          uint32_t *active, uint32_t active_words, const uint32_t *slot_of, uint32_t *vrows, hipStream_t s) {
     if (n_ent == 0) return hipSuccess;
     uint64_t blocks = (n_ent + 255) / 256;
     hipLaunchKernelGGL(k_scatter_entries, dim3((uint32_t)blocks), dim3(256), 0, s, table, dbottom, pos, ref, nuc,
-                       is_missing, ent_q, pos2site, max_pos, n_sites, n_ent, q_base, active, active_words, slot_of);
+                       is_missing, ent_q, pos2site, max_pos, n_sites, n_ent, q_base, active, active_words, slot_of, vrows);
     return hipGetLastError();
 }
 

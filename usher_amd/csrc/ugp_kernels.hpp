@@ -42,6 +42,7 @@ struct Best8Args {
     uint32_t super_chunks;
     const uint32_t *table;     // [n_tiles][4 + n_sites][64]
     const uint32_t *dbottom;   // [n_tiles*512]
+    const uint32_t *vrows;     // [n_tiles*512] rows per sample whose allele set is neither missing nor just the reference base
     uint32_t n_sites, n_chunks, n_groups, n_tiles;   // n_tiles = 512-sample tiles
     uint32_t max_slots;
     uint32_t lds_slots;        // saved-D slots kept in LDS (1 KB each per wave); the colder ones live in `cold`
@@ -81,12 +82,16 @@ hipError_t launch_fill_table(uint32_t *table, const uint8_t *site_ref, uint32_t 
 hipError_t launch_scatter(uint32_t *table, uint32_t *dbottom, const int32_t *pos, const uint8_t *ref,
                           const uint8_t *nuc, const uint8_t *is_missing, const uint32_t *ent_q,
                           const int32_t *pos2site, uint32_t max_pos, uint32_t n_sites, uint64_t n_ent, uint32_t q_base,
-                          uint32_t *active, uint32_t active_words, const uint32_t *slot_of, hipStream_t s);
+                          uint32_t *active, uint32_t active_words, const uint32_t *slot_of, uint32_t *vrows /* or null */, hipStream_t s);
 // locality sort (see k_sort_keys); temp == nullptr: only *temp_bytes is filled
 hipError_t launch_tile_ranges(const uint32_t *keys_sorted, uint32_t n_queries, uint32_t n_tiles512, const uint32_t *chunk_node_off,
                               uint32_t n_chunks, uint32_t align, uint32_t *hstart, uint32_t *hlen, hipStream_t s);
+// greedy descent from the coarse best node: refined[slot] = smallest cost of an eligible node met (a valid upper bound of best(s))
+hipError_t launch_descend(const ugp_result *coarse_res, const uint32_t *order, uint32_t n_queries, const uint32_t *coarse2bfs,
+                          const uint32_t *child_begin, const uint32_t *rec_off, const uint32_t *parent, const uint32_t *stream, const uint32_t *table,
+                          uint32_t n_sites, uint32_t *refined, hipStream_t s);
 hipError_t launch_seed_ub(const ugp_result *coarse_res, const uint32_t *order, uint32_t n_queries, uint32_t n_tiles512, uint32_t *ub,
-                          hipStream_t s);
+                          const uint32_t *refined /* [n_queries] by sorted slot, or null */, hipStream_t s);
 hipError_t launch_locality_sort(const ugp_result *coarse_res, const uint32_t *coarse2dfs, uint32_t n, uint32_t *keys,
                                 uint32_t *keys_sorted, uint32_t *idx, uint32_t *order, uint32_t *slot_of, void *temp,
                                 size_t *temp_bytes, hipStream_t s);
