@@ -219,7 +219,7 @@ int run_place(ugp_mat *m, ugp_qset *qs, int mode, ugp_result *d_out, int32_t *d_
         const bool use8 = packed_ok;
         uint32_t G = pick_groups(m, n_tiles);
         if (use8) {   // work units of a few chunks each, pulled from per-XCD queues by persistent waves (see k_best8)
-            uint32_t unit_chunks = 8;
+            uint32_t unit_chunks = 16;   // (most far units end in their preamble: the replay is the cost to amortise)
             if (const char *e = getenv("UGP_UNIT_CHUNKS")) unit_chunks = (uint32_t)std::max(1, atoi(e));
             G = std::max<uint32_t>(1, (f.n_chunks + unit_chunks - 1) / unit_chunks);
             // a small batch still has to fill the chip: at least ~4096 units in total
@@ -384,8 +384,8 @@ int run_place(ugp_mat *m, ugp_qset *qs, int mode, ugp_result *d_out, int32_t *d_
             if (const char *e = getenv("UGP_UB_EVERY")) b.ub_every = (uint32_t)std::max(1, atoi(e));
             b.heavy_chunks = 16;
             if (const char *e = getenv("UGP_HEAVY_CHUNKS")) b.heavy_chunks = (uint32_t)std::max(1, atoi(e));
-            HIP_TRY(m->d_stats.reserve(32));
-            if (q0 == 0) { HIP_TRY(hipMemsetAsync(m->d_stats.p, 0, 32 * sizeof(uint64_t), s)); m->last_words_total = 0; }
+            HIP_TRY(m->d_stats.reserve(48));
+            if (q0 == 0) { HIP_TRY(hipMemsetAsync(m->d_stats.p, 0, 48 * sizeof(uint64_t), s)); m->last_words_total = 0; }
             b.stats = getenv("UGP_STATS") ? m->d_stats.p : nullptr;   // the counters are two contended atomics per skip: debug only
             m->last_words_total += (uint64_t)n_tiles512 * m->stream8_dwords;
             b.max_slots = f.max_slots;
@@ -1049,7 +1049,7 @@ int ugp_get_timing(ugp_mat *m, ugp_timing *out) {
         m->last.words_total = m->last_words_total;
         m->last.words_skipped = 0;
         if (m->last_used_best8 && m->d_stats.p) {
-            uint64_t v[32] = {0};
+            uint64_t v[48] = {0};
             HIP_TRY(hipMemcpy(v, m->d_stats.p, sizeof v, hipMemcpyDeviceToHost));
             m->last.words_skipped = v[0];
             m->last.reserved = (uint32_t)std::min<uint64_t>(v[1], 0xFFFFFFFFull);   // pipeline (re)starts
@@ -1060,6 +1060,9 @@ int ugp_get_timing(ugp_mat *m, ugp_timing *out) {
                 fprintf(stderr, "\n[ugp stats] jumps decided by the first node after a restart=%llu", (unsigned long long)v[26]);
                 fprintf(stderr, "\n[ugp stats] own-region units=%llu cycles=%llu   other units=%llu cycles=%llu\n", (unsigned long long)v[29],
                         (unsigned long long)v[27], (unsigned long long)v[30], (unsigned long long)v[28]);
+                fprintf(stderr, "[ugp stats] other units by what the preamble records decided: whole unit skipped %llu (cycles %llu), body entered late %llu (cycles %llu), "
+                                "nothing %llu (cycles %llu); preamble words replayed %llu\n", (unsigned long long)v[32], (unsigned long long)v[33],
+                        (unsigned long long)v[34], (unsigned long long)v[35], (unsigned long long)v[36], (unsigned long long)v[37], (unsigned long long)v[38]);
                 if (m->last_list_n && m->last_list_tiles) {
                     std::vector<uint32_t> ln(m->last_list_tiles);
                     HIP_TRY(hipMemcpy(ln.data(), m->last_list_n, ln.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));

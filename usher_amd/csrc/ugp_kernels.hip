@@ -637,6 +637,22 @@ __global__ void __launch_bounds__(64) k_best8(Best8Args a) {
         for (int j = 0; j < 4; j++) best.v[j] = 0xFFFFFFFFu;
         chunk++;
     };
+    // The chunks that lie wholly in front of relative position `to` (none of them walked, so none holds a candidate) are
+    // closed in one step: their end markers are looked up by the lanes in parallel instead of one dependent load per chunk.
+    // `body0` = stream position of the unit's first body word.  Returns the end-marker position of the chunk left open.
+    auto close_empty_chunks = [&](uint32_t to, uint32_t body0) -> uint32_t {
+        for (;;) {
+            const uint32_t left = c1 - chunk;   // uniform
+            if (!left) return 0xFFFFFFFFu;
+            const uint32_t mark = lane < left ? a.chunk8_body_off[chunk + 1u + lane] - 1u - body0 : 0xFFFFFFFFu;   // end marker of chunk + lane
+            const uint32_t k = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(lane < left && to > mark));
+            if (k) {
+                chunk += k;
+                if (can_prune) { ub_age += k; if (ub_age >= a.ub_every) { exchange_ub(); ub_age = 0; } }
+            }
+            if (k < (left < 64u ? left : 64u)) return rdlane(mark, k);
+        }
+    };
     // "can everything below / beside this node be skipped?": true when, for all 512 samples,
     //     D - hs > ub   or   D - (V + hr) > ub            (ub = upper bound of best(s); the two lower bounds of ugp_flatten.hpp)
     // Per half: 0x8000 + D - hs - (ub + 1) keeps bit 15 exactly when D - hs > ub; D < 0x7F7F, ub + 1 + hs <= 0x7FFF, and
@@ -1003,10 +1019,7 @@ __global__ void __launch_bounds__(64) k_best8(Best8Args a) {
         if (ranged && !next_range()) continue;
         if (phase == 2 && body_start) {   // the replay ended at a path node whose subtree is not needed: close the chunks in front of its end
             off = min(body_start, n);
-            while (chunk < c1 && off > cend) {
-                chunk_end();
-                cend = chunk < c1 ? (uint32_t)__builtin_amdgcn_readfirstlane((int)(a.chunk8_body_off[chunk + 1] - 1u - begin)) : 0xFFFFFFFFu;
-            }
+            cend = close_empty_chunks(off, begin);   // (nothing has been walked yet: no chunk in front of `off` holds a candidate)
         }
         bool cautious = false;   // uniform: the last run was cut short by a jump inside its first group
         for (;;) {
@@ -1074,9 +1087,9 @@ __global__ void __launch_bounds__(64) k_best8(Best8Args a) {
                 cend_stale = false;
                 cend = chunk < c1 ? (uint32_t)__builtin_amdgcn_readfirstlane((int)(a.chunk8_body_off[chunk + 1] - 1u - begin)) : 0xFFFFFFFFu;
             }
-            while (chunk < c1 && skip_to > cend) {
+            if (chunk < c1 && skip_to > cend) {   // the open chunk ends (it may hold a candidate); those behind it, up to the new position, are empty
                 chunk_end();
-                cend = chunk < c1 ? (uint32_t)__builtin_amdgcn_readfirstlane((int)(a.chunk8_body_off[chunk + 1] - 1u - begin)) : 0xFFFFFFFFu;
+                cend = close_empty_chunks(skip_to, begin);
             }
             off = skip_to;
         }
@@ -1094,6 +1107,12 @@ __global__ void __launch_bounds__(64) k_best8(Best8Args a) {
         atomicAdd(st + 3, tw);
         atomicAdd(st + (unit_heavy ? 27 : 28), tw);   // wave cycles inside / outside the tiles' own regions
         atomicAdd(st + (unit_heavy ? 29 : 30), 1ull);
+        if (!unit_heavy) {   // what the preamble records decided for this unit
+            const uint32_t body_words = a.chunk8_body_off[c1] - a.chunk8_body_off[c0];
+            const int cls = body_start >= body_words ? 0 : (body_start ? 1 : 2);
+            atomicAdd(st + 32 + 2 * cls, 1ull);
+            atomicAdd(st + 33 + 2 * cls, tw);
+        }
         atomicMax(st + 4, tw);
         atomicAdd(st + 5 + min(tw >> 22, 15ull), 1ull);   // histogram of unit durations, 4.2M-cycle bins
     }
