@@ -92,7 +92,7 @@ struct ugp_mat {
     uint32_t last_list_tiles = 0;
     // locality sort (speed only): a coarse MAT of the top of the tree and the map coarse BFS index -> DFS rank in the full tree
     ugp_mat *coarse = nullptr;
-    DevBuf<uint32_t> d_coarse2bfs, d_child_begin, d_rec_off, d_parent, d_refined;   // seed descent (k_descend)
+    DevBuf<uint32_t> d_coarse2bfs, d_node_pair, d_parent, d_refined;   // seed descent (k_descend)
     DevBuf<uint32_t> d_coarse2dfs, d_keys, d_keys2, d_idx, d_order, d_slot;
     DevBuf<ugp_result> d_coarse_res, d_prev_res;
     bool prev_valid = false;
@@ -282,9 +282,9 @@ int run_place(ugp_mat *m, ugp_qset *qs, int mode, ugp_result *d_out, int32_t *d_
                 // the coarse pass's best costs (real costs of real nodes), tightened by a greedy descent from the coarse best node
                 // through the full tree (k_descend; it reads the sample's alleles from the tiles just built)
                 const uint32_t *refined = nullptr;
-                if (m->d_child_begin.p && !getenv("UGP_NO_DESCENT")) {
+                if (m->d_node_pair.p && !getenv("UGP_NO_DESCENT")) {
                     HIP_TRY(m->d_refined.reserve(nq));
-                    HIP_TRY(ugp::launch_descend(m->d_coarse_res.p + q0, order, (uint32_t)nq, m->d_coarse2bfs.p, m->d_child_begin.p, m->d_rec_off.p,
+                    HIP_TRY(ugp::launch_descend(m->d_coarse_res.p + q0, order, (uint32_t)nq, m->d_coarse2bfs.p, m->d_node_pair.p,
                                                 m->d_parent.p, m->d_stream.p, m->d_table.p, n_sites, m->d_refined.p, s));
                     refined = m->d_refined.p;
                     if (getenv("UGP_STATS") && getenv("UGP_SEED_CHECK") && m->prev_valid && m->d_prev_res.cap >= Q) {   // debug: seeds against the previous call's answers
@@ -453,7 +453,7 @@ struct HostFlat {
     ugp::FlatMat f;
     std::vector<uint32_t> parent;   // copy of the caller's BFS parent array (extended searches need the topology)
     std::vector<uint32_t> coarse2dfs, coarse2bfs;
-    ugp::UVec<uint32_t> child_begin, rec_off;   // full tree, for the seed descent (empty: input not in breadth-first order)
+    ugp::UVec<uint32_t> node_pair;   // full tree, for the seed descent (empty: input not in breadth-first order)
     HostFlat *coarse = nullptr;
     ~HostFlat() { delete coarse; }
 };
@@ -535,7 +535,7 @@ static int host_flatten(const ugp_tree_desc *tree, const ugp::Options &opt, bool
         if (rc == UGP_OK && with_coarse) {
             rc = build_coarse(tree, opt, ex, hf);
             if (rc != UGP_OK) return rc;   // (message already set)
-            if (hf.coarse) { hf.child_begin.swap(ex.child_begin); hf.rec_off.swap(ex.rec_off); }
+            if (hf.coarse) hf.node_pair.swap(ex.node_pair);
         }
     } catch (const std::bad_alloc &) {
         return fail(UGP_ERR_NOMEM, "out of host memory while flattening the tree");
@@ -591,10 +591,9 @@ static int upload_flat(const HostFlat &hf, int device, ugp_mat **out) {
     if (hf.coarse) {
         if (int rc = upload_flat(*hf.coarse, device, &m->coarse)) { ugp_mat_destroy(m); return rc; }
         if ((e = m->d_coarse2dfs.upload(hf.coarse2dfs)) != hipSuccess) return bail(e, "upload coarse table");
-        if (!hf.child_begin.empty() && !getenv("UGP_NO_DESCENT")) {
+        if (!hf.node_pair.empty() && !getenv("UGP_NO_DESCENT")) {
             if ((e = m->d_coarse2bfs.upload(hf.coarse2bfs)) != hipSuccess) return bail(e, "upload coarse table");
-            if ((e = m->d_child_begin.upload(hf.child_begin)) != hipSuccess) return bail(e, "upload children table");
-            if ((e = m->d_rec_off.upload(hf.rec_off)) != hipSuccess) return bail(e, "upload record offsets");
+            if ((e = m->d_node_pair.upload(hf.node_pair)) != hipSuccess) return bail(e, "upload node table");
             if ((e = m->d_parent.upload(hf.parent)) != hipSuccess) return bail(e, "upload parent table");
         }
     }

@@ -367,7 +367,8 @@ int flatten(const ugp_tree_desc &t, const Options &opt, FlatMat &out, std::strin
     const uint64_t total = par.exclusive_scan(rec_off_d.data(), N);
     if (total >= (1ull << 32)) { err = "tree too large: the record stream exceeds 2^32 dwords"; return UGP_ERR_UNSUPPORTED; }
     rec_off_d[N] = (uint32_t)total;
-    out.stream.resize(total);
+    out.stream.resize(total + 4);   // (4 dwords of padding behind chunk_body_off[n_chunks]: k_descend fetches a record's first words before it knows its length)
+    for (uint64_t i = total; i < total + 4; i++) out.stream[i] = 0;
     Buf<uint8_t> node_masked(N);   // by BFS index: carries a masked mutation (non-root)
     std::atomic<bool> mask_not_first{false};
     par.run(N, [&](uint64_t d0, uint64_t d1, unsigned) {
@@ -766,13 +767,13 @@ int flatten(const ugp_tree_desc &t, const Options &opt, FlatMat &out, std::strin
     }
     flat_lap("summaries");
     if (extras) {
-        extras->child_begin.clear(); extras->rec_off.clear();
+        extras->node_pair.clear();
         if (bfs_levels) {
-            extras->child_begin.resize(N + 1); extras->rec_off.resize(N);
+            extras->node_pair.resize(2 * (N + 1));
             par.run(N, [&](uint64_t b, uint64_t e, unsigned) {
-                for (uint64_t j = b; j < e; j++) { extras->child_begin[j] = child_off[j]; extras->rec_off[j] = rec_off_d[dfsidx[j]]; }
+                for (uint64_t j = b; j < e; j++) { extras->node_pair[2 * j] = child_off[j]; extras->node_pair[2 * j + 1] = rec_off_d[dfsidx[j]]; }
             });
-            extras->child_begin[N] = child_off[N];
+            extras->node_pair[2 * N] = child_off[N]; extras->node_pair[2 * N + 1] = 0;
         }
         extras->sub.swap(sub); extras->dfsidx.swap(dfsidx);
     }

@@ -169,9 +169,10 @@ struct FlatMat {
 // By-products of the flattening that the caller may want (both by BFS index): subtree sizes, DFS position.
 struct FlatExtras {
     UVec<uint32_t> sub, dfsidx;
-    // only when the input is a breadth-first expansion (parent[] ascending), else empty: the children of node j are the
-    // nodes child_begin[j] + 1 .. child_begin[j + 1]; rec_off[j] = dword offset of j's record in FlatMat::stream
-    UVec<uint32_t> child_begin, rec_off;
+    // only when the input is a breadth-first expansion (parent[] ascending), else empty: node_pair[2j] = child_begin[j]
+    // (the children of node j are the nodes child_begin[j] + 1 .. child_begin[j + 1]), node_pair[2j + 1] = dword offset of
+    // j's record in FlatMat::stream; n_nodes + 1 pairs
+    UVec<uint32_t> node_pair;
 };
 
 // Returns UGP_OK or a negative UGP_ERR_* with `err` filled.

@@ -1290,12 +1290,16 @@ __global__ void k_seed_ub(const ugp_result *__restrict__ coarse_res, const uint3
 // now and then (4 % of the benchmark's samples) a sibling branch that happens to share one mutation with the sample, one or
 // two levels below the point where the sample's own lineage leaves the coarse MAT.
 // Needs the children of a node to be contiguous in BFS index (child_begin[j] + 1 .. child_begin[j + 1]).
-constexpr uint32_t DESC_FRONTIER = 32, DESC_MAX_EXPANSIONS = 96, DESC_UP = 3;
+constexpr uint32_t DESC_FRONTIER = 32, DESC_MAX_EXPANSIONS = 96, DESC_UP = 2;
+// node_pair[j] = {child_begin[j], rec_off[j]} (one 8-byte load per node; entry N closes the last child range).
+// The search is a chain of dependent loads (children range -> record -> table rows), a few per expansion: the frontier
+// keeps each entry's children range so that an expansion starts with the children's pairs, a record's first words are
+// fetched together before its length is known (the stream is padded), and the rows of a node's mutations are in flight together.
 __global__ void __launch_bounds__(256) k_descend(const ugp_result *__restrict__ coarse_res, const uint32_t *__restrict__ order, uint32_t n_queries,
-                          const uint32_t *__restrict__ coarse2bfs, const uint32_t *__restrict__ child_begin, const uint32_t *__restrict__ rec_off,
+                          const uint32_t *__restrict__ coarse2bfs, const uint2 *__restrict__ node_pair,
                           const uint32_t *__restrict__ parent, const uint32_t *__restrict__ stream, const uint32_t *__restrict__ table, uint32_t n_sites,
                           uint32_t *__restrict__ refined) {
-    __shared__ uint32_t f_node[4][DESC_FRONTIER];
+    __shared__ uint32_t f_node[4][DESC_FRONTIER], f_cb[4][DESC_FRONTIER], f_ce[4][DESC_FRONTIER];
     __shared__ int f_d[4][DESC_FRONTIER];
     const uint32_t wv = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     const uint32_t slot = blockIdx.x * 4u + wv;
@@ -1305,18 +1309,24 @@ __global__ void __launch_bounds__(256) k_descend(const ugp_result *__restrict__ 
     const uint32_t *trow = table + ((uint64_t)(slot >> 9) * (n_sites + TABLE_CONST_ROWS) + TABLE_CONST_ROWS) * 64 + ((slot & 511u) >> 3);
     const uint32_t sh = (slot & 7u) * 4u;
     // one node for one sample: sum of delta over all words, sum of min(delta, 0) and shared mutations before the first masked one
-    auto eval = [&](uint32_t j, int &dsum, int &neg, uint32_t &common, uint32_t &w0) {
-        const uint32_t *rec = stream + rec_off[j];
+    auto eval = [&](uint32_t rec_at, int &dsum, int &neg, uint32_t &common, uint32_t &w0) {
+        const uint32_t *rec = stream + rec_at;
         w0 = rec[0];
+        const uint32_t m0 = rec[2], m1 = rec[3];   // (fetched with w0; real only if the record is that long)
         const uint32_t nw = w0 & 0xFFFFu;
         dsum = 0; neg = 0; common = 0;
-        for (uint32_t k = 0; k < nw; k++) {
-            const uint32_t w = rec[2 + k];
-            const uint32_t S = (trow[(uint64_t)(w & 0x3FFFFFu) * 64] >> sh) & 15u;
+        auto one = [&](uint32_t w, uint32_t S) {
             const int c = (int)((S >> ((w >> 22) & 3u)) & 1u), p = (int)((S >> ((w >> 24) & 3u)) & 1u);
             const int d = p - c;
             dsum += d;
             if (!(w & M_AFTER_MASK)) { neg += min(d, 0); common += (uint32_t)c; }
+        };
+        if (nw >= 1) {
+            const uint32_t r0 = trow[(uint64_t)(m0 & 0x3FFFFFu) * 64];
+            const uint32_t r1 = nw >= 2 ? trow[(uint64_t)(m1 & 0x3FFFFFu) * 64] : 0u;
+            one(m0, (r0 >> sh) & 15u);
+            if (nw >= 2) one(m1, (r1 >> sh) & 15u);
+            for (uint32_t k = 2; k < nw; k++) { const uint32_t w = rec[2 + k]; one(w, (trow[(uint64_t)(w & 0x3FFFFFu) * 64] >> sh) & 15u); }
         }
     };
     int best = r.best_set_difference;
@@ -1327,19 +1337,23 @@ __global__ void __launch_bounds__(256) k_descend(const ugp_result *__restrict__ 
     {
         uint32_t node = coarse2bfs[r.best_j];
         start[0] = node;
+        uint2 pr = node_pair[node];
+        uint32_t ce = node_pair[node + 1].x;
         int dsum, neg; uint32_t common, w0;
-        eval(node, dsum, neg, common, w0);
+        eval(pr.y, dsum, neg, common, w0);
         // cost(node) = D(parent) + neg = best  ->  D(parent) = best - neg, D(node) = D(parent) + dsum;  the root's cost is its D
         int D = (w0 & F_ROOT) ? best : best - neg + dsum;
-        if (lane == 0) { f_node[wv][0] = node; f_d[wv][0] = D; }
+        if (lane == 0) { f_node[wv][0] = node; f_d[wv][0] = D; f_cb[wv][0] = pr.x + 1u; f_ce[wv][0] = ce + 1u; }
         n_f = 1;
         for (uint32_t up = 0; up < DESC_UP && node != 0; up++) {   // D(ancestor) = D(child) - (sum of the child's deltas)
             D -= dsum;
             node = parent[node];
             start[up + 1] = node;
-            if (lane == 0) { f_node[wv][n_f] = node; f_d[wv][n_f] = D; }
+            pr = node_pair[node];
+            ce = node_pair[node + 1].x;
+            if (lane == 0) { f_node[wv][n_f] = node; f_d[wv][n_f] = D; f_cb[wv][n_f] = pr.x + 1u; f_ce[wv][n_f] = ce + 1u; }
             n_f++;
-            eval(node, dsum, neg, common, w0);
+            eval(pr.y, dsum, neg, common, w0);
         }
     }
     for (uint32_t it = 0; it < DESC_MAX_EXPANSIONS && n_f; it++) {
@@ -1348,22 +1362,27 @@ __global__ void __launch_bounds__(256) k_descend(const ugp_result *__restrict__ 
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) { const unsigned long long other = __shfl_xor(kk, o); kk = other < kk ? other : kk; }
         const uint32_t e = (uint32_t)kk & 63u;
-        const uint32_t node = f_node[wv][e];
         const int D = f_d[wv][e];
+        const uint32_t cb = f_cb[wv][e], ce = f_ce[wv][e];   // children: BFS indices [cb, ce)
         n_f--;
-        if (lane == 0 && e != n_f) { f_node[wv][e] = f_node[wv][n_f]; f_d[wv][e] = f_d[wv][n_f]; }
-        const uint32_t cb = child_begin[node] + 1u, ce = child_begin[node + 1] + 1u;   // children: BFS indices [cb, ce)
+        if (lane == 0 && e != n_f) { f_node[wv][e] = f_node[wv][n_f]; f_d[wv][e] = f_d[wv][n_f]; f_cb[wv][e] = f_cb[wv][n_f]; f_ce[wv][e] = f_ce[wv][n_f]; }
         for (uint32_t c0 = cb; c0 < ce; c0 += 64) {
             const uint32_t c = c0 + lane;
             int cost = 0x7FFFFFFF, dc = 0;
             bool push = false;
+            uint32_t ccb = 0, cce = 0;
             if (c < ce) {
+                const uint2 pr = node_pair[c];
+                cce = node_pair[c + 1].x + 1u;
+                ccb = pr.x + 1u;
                 int dsum, neg; uint32_t common, w0;
-                eval(c, dsum, neg, common, w0);
+                eval(pr.y, dsum, neg, common, w0);
                 const bool leaf = (w0 & F_LEAF) != 0, masked = (w0 & F_MASKED) != 0;
                 if (!masked && (common > 0 || (!leaf && (w0 & 0xFFFFu) == 0))) cost = D + neg;
                 dc = D + dsum;
-                push = !leaf && dc <= D;
+                // follow a child whose D does not grow -- or grows by one while it shares a mutation with the sample (the sample's
+                // lineage passing a node of which it lacks one mutation; a sibling branch shares one only by homoplasy)
+                push = !leaf && (dc <= D || (common > 0 && dc <= D + 1));
 #pragma unroll
                 for (uint32_t i = 0; i < DESC_UP; i++) push = push && c != start[i];   // (already in the frontier)
             }
@@ -1373,7 +1392,7 @@ __global__ void __launch_bounds__(256) k_descend(const ugp_result *__restrict__ 
             const unsigned long long pm = __builtin_amdgcn_ballot_w64(push);
             if (push) {
                 const uint32_t at = n_f + (uint32_t)__builtin_popcountll(pm & ((1ull << lane) - 1ull));
-                if (at < DESC_FRONTIER) { f_node[wv][at] = c; f_d[wv][at] = dc; }
+                if (at < DESC_FRONTIER) { f_node[wv][at] = c; f_d[wv][at] = dc; f_cb[wv][at] = ccb; f_ce[wv][at] = cce; }
             }
             n_f = min(n_f + (uint32_t)__builtin_popcountll(pm), DESC_FRONTIER);
         }
@@ -1433,10 +1452,10 @@ hipError_t launch_seed_ub(const ugp_result *coarse_res, const uint32_t *order, u
 }
 
 hipError_t launch_descend(const ugp_result *coarse_res, const uint32_t *order, uint32_t n_queries, const uint32_t *coarse2bfs,
-                          const uint32_t *child_begin, const uint32_t *rec_off, const uint32_t *parent, const uint32_t *stream, const uint32_t *table,
+                          const uint32_t *node_pair, const uint32_t *parent, const uint32_t *stream, const uint32_t *table,
                           uint32_t n_sites, uint32_t *refined, hipStream_t s) {
     if (!n_queries) return hipSuccess;
-    hipLaunchKernelGGL(k_descend, dim3((n_queries + 3) / 4), dim3(256), 0, s, coarse_res, order, n_queries, coarse2bfs, child_begin, rec_off, parent,
+    hipLaunchKernelGGL(k_descend, dim3((n_queries + 3) / 4), dim3(256), 0, s, coarse_res, order, n_queries, coarse2bfs, (const uint2 *)node_pair, parent,
                        stream, table, n_sites, refined);
     return hipGetLastError();
 }
