@@ -607,6 +607,7 @@ static ugp::Options default_options() {
     if (const char *e = getenv("UGP_PRUNE_MIN_WORDS")) opt.prune_min_words = (uint32_t)std::max(1, atoi(e));
     if (getenv("UGP_NO_SIB")) opt.sibling_records = false;
     if (const char *e = getenv("UGP_LDS_SLOTS")) opt.lds_slots = (uint32_t)std::max(1, std::min(60, atoi(e)));
+    if (const char *e = getenv("UGP_PRE_WEIGHT")) opt.pre_weight = (uint32_t)std::max(0, atoi(e));
     if (const char *e = getenv("UGP_UNIT_CHUNKS")) opt.super_chunks = (uint32_t)std::max(1, atoi(e));   // summaries follow the light units
     return opt;
 }

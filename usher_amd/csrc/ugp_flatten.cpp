@@ -683,6 +683,19 @@ int flatten(const ugp_tree_desc &t, const Options &opt, FlatMat &out, std::strin
         }, 1u << 16);
         uint64_t freq[64] = {0};
         for (unsigned th = 0; th < T; th++) for (int i = 0; i < 64; i++) freq[i] += freq_t[(size_t)th * 64 + i];
+        // The preambles count too: every work unit replays one, and with most of the body pruned away the replays are a
+        // large share of all slot accesses -- all of them to the slots of the top of the tree.  opt.pre_weight replays per
+        // body pass (the body is mostly skipped, a unit's replay is not).
+        if (opt.pre_weight) {
+            uint64_t fp[64] = {0};
+            for (uint32_t w : out.pre8_stream) {
+                if (!(w & H_TAG) || (w & (E_CHUNK_END | E_NOP | E_INFO))) continue;
+                const uint32_t rs = w & 63u, ws = (w >> 6) & 63u;
+                if (rs < RS_BOTTOM) fp[rs]++;
+                if (ws != WS_NONE) fp[ws]++;
+            }
+            for (int i = 0; i < 64; i++) freq[i] += fp[i] * opt.pre_weight;
+        }
         uint32_t order[64], remap[64];
         for (uint32_t i = 0; i < 64; i++) order[i] = i;
         std::stable_sort(order, order + out.max_slots, [&](uint32_t a, uint32_t b) { return freq[a] > freq[b]; });

@@ -124,6 +124,7 @@ struct Options {
     bool sibling_records = true;   // emit H_INFO | H_SIB records
     uint32_t lds_slots = LDS_SLOTS; // headers whose (renumbered) slots are >= this are flagged H_SLOW
     uint32_t super_chunks = SUPER_CHUNKS;   // chunks per summary
+    uint32_t pre_weight = 0;    // weight of the preambles' slot accesses when the hot (LDS) slots are chosen
     uint32_t threads = 0;       // host threads (0 = UGP_FLATTEN_THREADS, else min(32, hardware threads)); the output does not depend on it
 };
 

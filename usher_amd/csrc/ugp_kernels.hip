@@ -196,9 +196,15 @@ struct WalkOut { uint32_t best, cnt, key; };
 // lane's wanted score.  Only lanes with `relevant` set look for ties in this chunk (the chunk minimum of
 // phase 1 equals their global minimum); a subtree is jumped over when D(node) - hsub > want for all of
 // them, since cost(d) >= D(node) - hsub for every descendant d.
-__device__ __forceinline__ WalkOut walk_ties(const PlaceArgs &a, uint32_t *slots, uint32_t tile, uint32_t c, uint32_t lane,
+// Rows through LDS: the stream is read 64 words at a time (one per lane), and together with such a window every lane
+// fetches the tile's 32-byte piece of the table row its word names (a header or key word names none, or a harmless one)
+// into `rowbuf`; the mutation words of the window are then served from LDS.  One exposed memory latency per 64 words
+// instead of one per mutation: this walk is a chain of dependent loads (k_ties 0.43 -> 0.28 ms at 16,384 samples).
+// (Fetching the next window ahead into registers was tried: slower -- the walk jumps, and the registers cost occupancy.)
+__device__ __forceinline__ WalkOut walk_ties(const PlaceArgs &a, uint32_t *slots, uint32_t *rowbuf, uint32_t tile, uint32_t c, uint32_t lane,
                                              uint32_t want, bool relevant) {
-    const uint32_t *tab = a.table + ((uint64_t)(tile >> 3) * (a.n_sites + TABLE_CONST_ROWS) + TABLE_CONST_ROWS) * 64 + (tile & 7u) * 8 + (lane >> 3);
+    const uint32_t *tab8 = a.table + ((uint64_t)(tile >> 3) * (a.n_sites + TABLE_CONST_ROWS) + TABLE_CONST_ROWS) * 64 + (tile & 7u) * 8;   // + 64 * site: 8 dwords
+    const uint32_t col = lane >> 3;
     const uint32_t sh = (lane & 7u) * 4u;
     const uint32_t dbot = a.dbottom[tile * 64 + lane];
     WalkOut o; o.best = 0; o.cnt = 0; o.key = 0;
@@ -208,9 +214,22 @@ __device__ __forceinline__ WalkOut walk_ties(const PlaceArgs &a, uint32_t *slots
         uint32_t pos = phase == 0 ? a.chunk_pre_off[c] : a.chunk_t_off[c];          // uniform
         const uint32_t end = phase == 0 ? a.chunk_pre_off[c + 1] : a.chunk_t_off[c + 1];
         uint32_t base = pos;
-        uint32_t buf = (base + lane < end) ? p[base + lane] : 0u;
+        uint32_t buf = 0;
+        auto window = [&]() {   // words base .. base + 63 and the rows they name
+            buf = (base + lane < end) ? p[base + lane] : 0u;
+            const uint32_t site = buf & 0x3FFFFFu;
+            __syncthreads();   // (one wave per block: orders the previous window's LDS reads before these writes)
+            if (base + lane < end && site < a.n_sites) {
+                const uint4 *src = (const uint4 *)(tab8 + (uint64_t)site * 64);
+                const uint4 lo = src[0], hi = src[1];
+                uint4 *dst = (uint4 *)(rowbuf + lane * 8u);
+                dst[0] = lo; dst[1] = hi;
+            }
+            __syncthreads();
+        };
+        window();
         auto next = [&]() -> uint32_t {
-            if (pos - base >= 64u) { base = pos; buf = (base + lane < end) ? p[base + lane] : 0u; }
+            if (pos - base >= 64u) { base = pos; window(); }
             const uint32_t w = rdlane(buf, pos - base);
             pos++;
             return w;
@@ -231,8 +250,8 @@ __device__ __forceinline__ WalkOut walk_ties(const PlaceArgs &a, uint32_t *slots
             uint32_t common = 0, n_before = 0;
             for (uint32_t m = 0; m < nmut; m++) {
                 const uint32_t w = next();
-                const uint32_t site = w & 0x3FFFFFu, mi = (w >> 22) & 3u, pi = (w >> 24) & 3u;
-                const uint32_t x = tab[(uint64_t)site * 64];
+                const uint32_t mi = (w >> 22) & 3u, pi = (w >> 24) & 3u;
+                const uint32_t x = rowbuf[(pos - 1u - base) * 8u + col];
                 const uint32_t nib = (x >> sh) & 15u;
                 const int cc = (int)((nib >> mi) & 1u), pp = (int)((nib >> pi) & 1u);
                 const int d = pp - cc;
@@ -266,7 +285,7 @@ __device__ __forceinline__ WalkOut walk_ties(const PlaceArgs &a, uint32_t *slots
                 const bool near = relevant && dn <= want + hs;   // D - hsub <= want: a descendant may still tie
                 if (__builtin_amdgcn_ballot_w64(near) == 0) {
                     pos += info & 0xFFFFFFu;
-                    if (pos - base >= 64u && pos < end) { base = pos; buf = (base + lane < end) ? p[base + lane] : 0u; }
+                    if (pos - base >= 64u && pos < end) { base = pos; window(); }
                 }
             }
         }
@@ -1214,6 +1233,7 @@ __global__ void __launch_bounds__(64) k_ties(PlaceArgs a, const uint32_t *__rest
                                              uint32_t cap, uint32_t n_t64 /* 8 * n_tiles512, as k_select encodes */,
                                              uint32_t *__restrict__ cnt_out, uint32_t *__restrict__ key_out) {
     extern __shared__ __attribute__((aligned(16))) uint32_t slots[];
+    __shared__ __attribute__((aligned(16))) uint32_t rowbuf[64 * 8];
     const uint32_t lane = threadIdx.x;
     const uint32_t n = min(*n_items, cap);
     for (uint32_t it = blockIdx.x; it < n; it += gridDim.x) {
@@ -1222,7 +1242,7 @@ __global__ void __launch_bounds__(64) k_ties(PlaceArgs a, const uint32_t *__rest
         const uint32_t q = t64 * 64 + lane;
         const uint32_t want = (q < a.n_queries) ? pk_lookup(gbest, q >> 9, q & 511u) : 0xFFFFFFFFu;
         const bool relevant = q < a.n_queries && pk_lookup(lbest + (uint64_t)c * (n_t64 / 8u) * 256u, q >> 9, q & 511u) == want;
-        WalkOut r = walk_ties(a, slots, t64, c, lane, want, relevant);
+        WalkOut r = walk_ties(a, slots, rowbuf, t64, c, lane, want, relevant);
         if (r.cnt) {
             atomicAdd(&cnt_out[q], r.cnt);
             atomicMax(&key_out[q], r.key);
