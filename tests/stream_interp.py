@@ -138,9 +138,10 @@ U16 = 0xFFFF
 
 
 SUM_FORCED, SUM_W_SHIFT, SUM_POS_MASK = 1 << 28, 22, (1 << 22) - 1
+SUM_A_POS_MASK, SUM_HR_SHIFT = (1 << 19) - 1, 19
 
 
-def summary_ranges(flat, nib, c0, slots, dcur, ub, stats=None):
+def summary_ranges(flat, nib, c0, slots, dcur, ub, stats=None, vrow=None, body_start=0):
     """The summary pass of k_best8 for the run of chunks starting at c0 (one sample): the ranges of the body
     (relative positions, adjacent ones merged) whose top-level subtree survives both bounds."""
     g = c0 // flat.super_chunks
@@ -163,14 +164,17 @@ def summary_ranges(flat, nib, c0, slots, dcur, ub, stats=None):
                 accC += (x >> ((w >> 22) & 3)) & 1
                 if w & M_END:
                     break
-        keep = forced
-        if not forced:
+        lo, hi = a & SUM_A_POS_MASK, b & SUM_POS_MASK
+        assert lo < hi
+        dead = hi <= body_start          # inside the subtree the preamble replay ruled out (its parent's slot may not exist)
+        assert dead or lo >= body_start
+        keep = forced and not dead
+        if not forced and not dead:
             spar = dcur if h & H_REG else slots[(h >> H_RSLOT_SHIFT) & 63]
             dn = (spar + accP - accC) & U16
-            hs, wn = (a >> INFO_HS_SHIFT) & 0x7F, (b >> SUM_W_SHIFT) & 63
-            keep = not (dn >= ub[0] + 1 + hs and spar >= ub[0] + 1 + wn)
-        lo, hi = a & SUM_POS_MASK, b & SUM_POS_MASK
-        assert lo < hi
+            hs, wn, hr = (a >> INFO_HS_SHIFT) & 0x7F, (b >> SUM_W_SHIFT) & 63, (a >> SUM_HR_SHIFT) & 7
+            far_below = dn >= ub[0] + 1 + hs or (vrow is not None and hr != INFO_HR_NONE and dn - hr >= min(ub[0] + 1 + vrow, 0x7F80))
+            keep = not (far_below and spar >= ub[0] + 1 + wn)
         if keep:
             if ranges and ranges[-1][1] == lo:
                 ranges[-1][1] = hi
@@ -326,14 +330,12 @@ def best8_group(flat, nib, dbot, c0, c1, ub=None, stats=None, use_summary=True, 
         if phase == 0:
             body_end = int(flat.chunk8_body_off[c1])
             info = None
-            if body_start:
-                segments.append((1, flat.stream8, min(body0 + body_start, body_end), body_end))
-            elif summarise:
-                for r0, r1 in summary_ranges(flat, nib, c0, slots, dcur, ub, stats):
+            if summarise and body_start < body_end - body0:
+                for r0, r1 in summary_ranges(flat, nib, c0, slots, dcur, ub, stats, vrow, body_start):
                     segments.append((1, flat.stream8, body0 + r0, min(body0 + r1, body_end)))
                 segments.append((1, flat.stream8, body_end, body_end))   # closes the remaining chunks
             else:
-                segments.append((1, flat.stream8, body0, body_end))
+                segments.append((1, flat.stream8, min(body0 + body_start, body_end), body_end))
     assert chunk == c1
     return lbest
 

@@ -156,9 +156,10 @@ def test_summaries_of_top_level_subtrees_are_exact(seed, chunk_nodes, monkeypatc
     arrays, queries = synth.make_case(seed, n_leaves=2500, n_queries=8, n_sites=300, n_ambig=(0, 0, 2), p_masked=0.02,
                                       mut_counts=(0, 0, 1, 1, 1, 2, 3, 17))
     flat = FlatTreeView(arrays, chunk_nodes=chunk_nodes)
-    assert flat.super_chunks == 8 and len(flat.sum8_off) == (len(flat.chunk8_body_off) - 1 + 7) // 8 + 1
+    SC = flat.super_chunks
+    assert SC == 16 and len(flat.sum8_off) == (len(flat.chunk8_body_off) - 1 + SC - 1) // SC + 1
     n_chunks = len(flat.chunk8_body_off) - 1
-    n_units = (n_chunks + 7) // 8
+    n_units = (n_chunks + SC - 1) // SC
     ot = capi.OracleTree(arrays)
     skipped = 0
     for s in queries:
@@ -169,7 +170,7 @@ def test_summaries_of_top_level_subtrees_are_exact(seed, chunk_nodes, monkeypatc
             lb_sum, lb_plain = {}, {}
             ub_a, ub_b = [ub0], [ub0]
             for u in range(n_units):
-                c0, c1 = 8 * u, min(8 * u + 8, n_chunks)
+                c0, c1 = SC * u, min(SC * u + SC, n_chunks)
                 lb_sum.update(stream_interp.best8_group(flat, nib, dbot, c0, c1, ub_a, st, vrow=stream_interp.variant_rows(s), use_pre_records=False))
                 lb_plain.update(stream_interp.best8_group(flat, nib, dbot, c0, c1, ub_b, None, use_summary=False, vrow=stream_interp.variant_rows(s)))
             assert min(lb_sum.values()) == want["best"] == min(lb_plain.values())
@@ -260,13 +261,13 @@ def test_preamble_records_skip_far_units_exactly(seed, chunk_nodes, monkeypatch)
         nib, dbot = stream_interp.sample_site_alleles(flat, s)
         v = stream_interp.variant_rows(s)
         for ub0 in (0x7F7F, want["best"] + 2, want["best"]):
-            for unit in (1, 3, 8):
+            for unit in (1, 3, 8, flat.super_chunks):   # (units of super_chunks chunks also run the summary pass behind the cut replay)
                 st = {}
                 lb_pre, lb_plain = {}, {}
                 ub_a, ub_b = [ub0], [ub0]
                 for c0 in range(0, n_chunks, unit):
                     c1 = min(c0 + unit, n_chunks)
-                    lb_pre.update(stream_interp.best8_group(flat, nib, dbot, c0, c1, ub_a, st, use_summary=False, vrow=v))
+                    lb_pre.update(stream_interp.best8_group(flat, nib, dbot, c0, c1, ub_a, st, use_summary=(unit == flat.super_chunks), vrow=v))
                     lb_plain.update(stream_interp.best8_group(flat, nib, dbot, c0, c1, ub_b, None, use_summary=False, vrow=None, use_pre_records=False))
                 assert min(lb_pre.values()) == want["best"] == min(lb_plain.values())
                 assert [c for c in range(n_chunks) if lb_pre[c] == want["best"]] == [c for c in range(n_chunks) if lb_plain[c] == want["best"]]

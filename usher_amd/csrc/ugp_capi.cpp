@@ -378,10 +378,11 @@ int run_place(ugp_mat *m, ugp_qset *qs, int mode, ugp_result *d_out, int32_t *d_
             // light units that coincide with the summaries of the flattening evaluate those first (k_best8)
             // (measured on the random-attachment benchmark tree: 9 % fewer pipeline restarts, no net gain; kept behind a
             // switch for polytomy-dominated trees, where a unit holds hundreds of top-level subtrees)
-            if (b.unit_chunks == f.super_chunks && getenv("UGP_SUMMARY")) { b.sum8 = m->d_sum8.p; b.sum8_off = m->d_sum8_off.p; }
+            if (f.super_chunks && b.unit_chunks == f.super_chunks && getenv("UGP_SUMMARY")) { b.sum8 = m->d_sum8.p; b.sum8_off = m->d_sum8_off.p; }
             b.super_chunks = std::max<uint32_t>(1, f.super_chunks);
             b.ub_every = 128;
             if (const char *e = getenv("UGP_UB_EVERY")) b.ub_every = (uint32_t)std::max(1, atoi(e));
+            b.refill_all_rows = getenv("UGP_REFILL_ALL") ? 1u : 0u;
             b.heavy_chunks = 16;
             if (const char *e = getenv("UGP_HEAVY_CHUNKS")) b.heavy_chunks = (uint32_t)std::max(1, atoi(e));
             HIP_TRY(m->d_stats.reserve(48));
@@ -514,7 +515,7 @@ static int build_coarse(const ugp_tree_desc *t, const ugp::Options &opt, ugp::Fl
     }
     ugp_tree_desc d{keep.size(), parent.data(), mut_off.data(), pos.data(), ref.data(), par.data(), nuc.data()};
     ugp::Options copt;
-    copt.chunk_nodes = 128;
+    copt.chunk_nodes = 256;   // (the coarse pass is bound by row fetches and by the replay in front of every chunk: long chunks)
     if (const char *e = getenv("UGP_LDS_SLOTS")) copt.lds_slots = (uint32_t)std::max(1, std::min(60, atoi(e)));
     if (const char *e = getenv("UGP_COARSE_CHUNK_NODES")) copt.chunk_nodes = (uint32_t)std::max(1, atoi(e));
     hf.coarse = new HostFlat();
@@ -1061,8 +1062,9 @@ int ugp_get_timing(ugp_mat *m, ugp_timing *out) {
                 fprintf(stderr, "\n[ugp stats] own-region units=%llu cycles=%llu   other units=%llu cycles=%llu\n", (unsigned long long)v[29],
                         (unsigned long long)v[27], (unsigned long long)v[30], (unsigned long long)v[28]);
                 fprintf(stderr, "[ugp stats] other units by what the preamble records decided: whole unit skipped %llu (cycles %llu), body entered late %llu (cycles %llu), "
-                                "nothing %llu (cycles %llu); preamble words replayed %llu\n", (unsigned long long)v[32], (unsigned long long)v[33],
-                        (unsigned long long)v[34], (unsigned long long)v[35], (unsigned long long)v[36], (unsigned long long)v[37], (unsigned long long)v[38]);
+                                "nothing %llu (cycles %llu)\n[ugp stats] units skipped whole: cycles pulling %llu, replaying the preamble %llu, closing %llu\n", (unsigned long long)v[32], (unsigned long long)v[33],
+                        (unsigned long long)v[34], (unsigned long long)v[35], (unsigned long long)v[36], (unsigned long long)v[37], (unsigned long long)v[38],
+                        (unsigned long long)v[39], (unsigned long long)v[40]);
                 if (m->last_list_n && m->last_list_tiles) {
                     std::vector<uint32_t> ln(m->last_list_tiles);
                     HIP_TRY(hipMemcpy(ln.data(), m->last_list_n, ln.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));

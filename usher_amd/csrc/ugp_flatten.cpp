@@ -762,7 +762,8 @@ int flatten(const ugp_tree_desc &t, const Options &opt, FlatMat &out, std::strin
                     if (dst) {
                         uint32_t h = out.stream8[hpos] & ~H_STORE;
                         if (forced) h |= H_END;
-                        dst[n] = SUM_A | (std::min<uint32_t>(hsub[j], INFO_HS_MAX) << INFO_HS_SHIFT) | (pos8_start[d] - base);
+                        dst[n] = SUM_A | (std::min<uint32_t>(hsub[j], INFO_HS_MAX) << INFO_HS_SHIFT) | (std::min<uint32_t>(hrev[j], INFO_HR_NONE) << SUM_HR_SHIFT) |
+                                 (pos8_start[d] - base);
                         dst[n + 1] = SUM_B | (forced ? SUM_FORCED : 0u) | (std::min<uint32_t>(nw[j], SUM_W_MAX) << SUM_W_SHIFT) | end_pos;
                         dst[n + 2] = h;
                         if (!forced) for (uint32_t k = 0; k < nw[j]; k++) dst[n + 3 + k] = out.stream8[hpos + 1 + k];
@@ -773,10 +774,16 @@ int flatten(const ugp_tree_desc &t, const Options &opt, FlatMat &out, std::strin
             }
             return n;
         };
-        par.run(n_units, [&](uint64_t b, uint64_t e, unsigned) { for (uint64_t u = b; u < e; u++) out.sum8_off[u] = walk_unit((uint32_t)u, nullptr); }, 16);
-        out.sum8.resize(par.exclusive_scan(out.sum8_off.data(), n_units));
-        out.sum8_off[n_units] = (uint32_t)out.sum8.size();
-        par.run(n_units, [&](uint64_t b, uint64_t e, unsigned) { for (uint64_t u = b; u < e; u++) walk_unit((uint32_t)u, out.sum8.data() + out.sum8_off[u]); }, 16);
+        bool fits = true;   // every position of a run has to fit SUM_A's field
+        for (uint32_t u = 0; u < n_units; u++)
+            fits = fits && out.chunk8_body_off[std::min<uint32_t>(NC, (u + 1) * SC)] - out.chunk8_body_off[u * SC] <= SUM_A_POS_MASK;
+        if (!fits) { out.super_chunks = 0; out.sum8.clear(); out.sum8_off.assign(1, 0); }
+        else {
+            par.run(n_units, [&](uint64_t b, uint64_t e, unsigned) { for (uint64_t u = b; u < e; u++) out.sum8_off[u] = walk_unit((uint32_t)u, nullptr); }, 16);
+            out.sum8.resize(par.exclusive_scan(out.sum8_off.data(), n_units));
+            out.sum8_off[n_units] = (uint32_t)out.sum8.size();
+            par.run(n_units, [&](uint64_t b, uint64_t e, unsigned) { for (uint64_t u = b; u < e; u++) walk_unit((uint32_t)u, out.sum8.data() + out.sum8_off[u]); }, 16);
+        }
     }
     flat_lap("summaries");
     if (extras) {

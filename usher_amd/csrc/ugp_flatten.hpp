@@ -104,14 +104,15 @@ constexpr uint32_t INFO_HR_SHIFT = 18, INFO_HR_NONE = 7;   // hrev field; 7 = no
 // When the record's test holds during the replay, the rest of the preamble and the body up to that position are skipped.
 constexpr uint32_t PRE_HS_NONE = 127;
 // summary stream ("sum8", see ugp_flatten.cpp): per top-level subtree of a run of super_chunks chunks
-//   SUM_A  [28:22] hsub of the node (capped)   [21:0] position of the node's first word (pruning record or header,
+//   SUM_A  [28:22] hsub of the node (capped)   [21:19] hrev (INFO_HR_NONE: not available)   [18:0] position of the node's first word (pruning record or header,
 //          behind a sibling record) in the packed stream, relative to the run's first body word
 //   SUM_B  SUM_FORCED: no test, the subtree is always walked   [27:22] mutation words of the node   [21:0] position
 //          behind the subtree (relative, capped at the end of the run)
 //   a copy of the node's header without H_STORE (H_END when forced), then its mutation words (unless forced)
 constexpr uint32_t SUM_A = H_TAG | H_INFO | H_RARE, SUM_B = H_TAG | H_INFO, SUM_FORCED = 1u << 28;   // (B: H_INFO without H_RARE)
 constexpr uint32_t SUM_W_SHIFT = 22, SUM_W_MAX = 63, SUM_POS_MASK = (1u << 22) - 1u;
-constexpr uint32_t SUPER_CHUNKS = 8;        // chunks per summary (= the light work units of k_best8)
+constexpr uint32_t SUM_A_POS_MASK = (1u << 19) - 1u, SUM_HR_SHIFT = 19;   // (a run longer than 2^19 words: no summaries at all, super_chunks = 0)
+constexpr uint32_t SUPER_CHUNKS = 16;       // chunks per summary (= the light work units of k_best8)
 constexpr uint32_t PRUNE_MIN_WORDS = 4;     // only subtrees at least this long carry a pruning record
 constexpr uint32_t LDS_SLOTS = 7;           // saved-D slots k_best8 keeps in LDS (1 KB each per wave); the colder ones live in a global scratch
 constexpr uint32_t M_FLUSH = 1u << 28, M_END = 1u << 30;

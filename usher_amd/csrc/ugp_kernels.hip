@@ -516,6 +516,7 @@ __global__ void __launch_bounds__(64) k_best8(Best8Args a) {
     uint32_t ub_tile = 0xFFFFFFFFu;   // uniform: tile whose bounds are in ub1
     uint32_t ub_age = 0;              // uniform: chunk ends since the last exchange
     for (;;) {
+    const uint64_t t_pull0 = STATS ? __builtin_amdgcn_s_memtime() : 0;
     uint32_t tile = 0, c0 = 0, c1 = 0;   // the unit: chunks [c0, c1) of the stream for one tile
     bool unit_heavy = false;             // (STATS) the unit lies in the tile's own region
     {
@@ -868,8 +869,10 @@ __global__ void __launch_bounds__(64) k_best8(Best8Args a) {
     uint32_t sv_lo = 0, sv_hi = 0;   // per lane
     uint32_t n_sv = 0;               // uniform
     body_start = 0;
+    uint64_t t_pre_end = 0;
     for (int phase = 0; phase < 3; phase++) {
-        if (phase == 1 && (!summarise || body_start)) continue;
+        if (STATS && phase == 1) t_pre_end = __builtin_amdgcn_s_memtime();
+        if (phase == 1 && (!summarise || body_start >= a.chunk8_body_off[c1] - a.chunk8_body_off[c0])) continue;   // (nothing left to summarise)
         sp = phase == 0 ? a.pre8 : (phase == 1 ? a.sum8 : a.stream8);
         const uint32_t begin = phase == 0 ? a.chunk8_pre_off[c0] : (phase == 1 ? a.sum8_off[c0 / a.super_chunks] : a.chunk8_body_off[c0]);
         const uint32_t end = phase == 0 ? a.chunk8_pre_off[c0 + 1] : (phase == 1 ? a.sum8_off[c0 / a.super_chunks + 1] : a.chunk8_body_off[c1]);
@@ -970,21 +973,35 @@ __global__ void __launch_bounds__(64) k_best8(Best8Args a) {
                 }
                 // end of the entry: the node costs at least D(parent) - (its words), its descendants at least
                 // D(node) - hsub; if both exceed the upper bound of every sample nothing of this subtree is needed
-                bool keep = forced;
-                if (!forced) {
+                // (descendants: either lower bound of ugp_flatten.hpp; the node itself: each of its words lowers its cost by at most 1)
+                // An entry that ends at or before body_start lies inside the subtree the preamble replay ruled out: dropped
+                // whatever it says (its parent's slot was not even written).
+                const bool dead = (sB & SUM_POS_MASK) <= body_start;
+                bool keep = forced && !dead;
+                if (!forced && !dead) {
                     const uint32_t K1 = 0x80008000u - ((sA >> INFO_HS_SHIFT) & 0x7Fu) * 0x00010001u;
                     const uint32_t K2 = 0x80008000u - ((sB >> SUM_W_SHIFT) & 63u) * 0x00010001u;
+                    const uint32_t hr = (sA >> SUM_HR_SHIFT) & 7u;
                     uint32_t r = 0xFFFFFFFFu;
+                    if (hr != INFO_HR_NONE) {
+                        const uint32_t K3 = 0x80008000u - hr * 0x00010001u;
 #pragma unroll
-                    for (int j = 0; j < 4; j++) {
-                        const uint32_t dn = psub(padd(spar.v[j], ex4(accP, j)), ex4(accC, j));
-                        r &= psub(padd(dn, K1), ub1.v[j]) & psub(padd(spar.v[j], K2), ub1.v[j]);
+                        for (int j = 0; j < 4; j++) {
+                            const uint32_t dn = psub(padd(spar.v[j], ex4(accP, j)), ex4(accC, j));
+                            r &= (psub(padd(dn, K1), ub1.v[j]) | psub(padd(dn, K3), ubv1.v[j])) & psub(padd(spar.v[j], K2), ub1.v[j]);
+                        }
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 4; j++) {
+                            const uint32_t dn = psub(padd(spar.v[j], ex4(accP, j)), ex4(accC, j));
+                            r &= psub(padd(dn, K1), ub1.v[j]) & psub(padd(spar.v[j], K2), ub1.v[j]);
+                        }
                     }
                     keep = __builtin_amdgcn_ballot_w64((r & 0x80008000u) != 0x80008000u) != 0;
                 }
                 accP = accC = 0;
                 if (keep) {
-                    const uint32_t lo = sA & SUM_POS_MASK, hi = sB & SUM_POS_MASK;
+                    const uint32_t lo = sA & SUM_A_POS_MASK, hi = sB & SUM_POS_MASK;
                     if (n_sv > 0 && rdlane(sv_hi, (n_sv - 1u) & 63u) == lo) {          // adjacent to the last range: extend it
                         sv_hi = lane == ((n_sv - 1u) & 63u) ? hi : sv_hi;
                     } else if (n_sv < 64u) {
@@ -994,10 +1011,10 @@ __global__ void __launch_bounds__(64) k_best8(Best8Args a) {
                     } else {                                                            // list full: everything from here on is walked
                         sv_hi = lane == 63u ? SUM_POS_MASK : sv_hi;
                     }
-                } else if (STATS) n_skipped += (sB & SUM_POS_MASK) - (sA & SUM_POS_MASK);
+                } else if (STATS) n_skipped += (sB & SUM_POS_MASK) - (sA & SUM_A_POS_MASK);
             };
             uint32_t w0 = load_words(0), w1 = load_words(GRP), w2 = load_words(2 * GRP);
-            const uint32_t o0 = decode(w0, load_bits(w0));
+            const uint32_t o0 = a.refill_all_rows ? decode(w0, 0xFFFFFFFFu) : decode(w0, load_bits(w0));   // (experiment: no bitmap round trip in front of the first rows)
             uint32_t b1 = load_bits(w1);
             uint32_t X[GRP];
 #pragma unroll
@@ -1018,7 +1035,7 @@ __global__ void __launch_bounds__(64) k_best8(Best8Args a) {
         // body ranges to walk: everything, or the survivors of the summary
         uint32_t off = 0;
         uint32_t sv_next = 0;        // uniform: next survivor range
-        const bool ranged = phase == 2 && summarise && !body_start;
+        const bool ranged = phase == 2 && summarise;
         auto next_range = [&]() -> bool {   // position the walk at the next survivor range, closing the chunks in between
             const bool more = sv_next < n_sv;
             const uint32_t lo = more ? rdlane(sv_lo, sv_next & 63u) : n;
@@ -1036,7 +1053,7 @@ __global__ void __launch_bounds__(64) k_best8(Best8Args a) {
             return more;
         };
         if (ranged && !next_range()) continue;
-        if (phase == 2 && body_start) {   // the replay ended at a path node whose subtree is not needed: close the chunks in front of its end
+        if (phase == 2 && body_start && !ranged) {   // the replay ended at a path node whose subtree is not needed: close the chunks in front of its end
             off = min(body_start, n);
             cend = close_empty_chunks(off, begin);   // (nothing has been walked yet: no chunk in front of `off` holds a candidate)
         }
@@ -1046,7 +1063,7 @@ __global__ void __launch_bounds__(64) k_best8(Best8Args a) {
             // (re)fill the pipeline at `off`
             const uint64_t t_r0 = STATS ? __builtin_amdgcn_s_memtime() : 0;
             uint32_t w0 = load_words(off), w1 = load_words(off + GRP), w2 = load_words(off + 2 * GRP);
-            const uint32_t o0 = decode(w0, load_bits(w0));
+            const uint32_t o0 = a.refill_all_rows ? decode(w0, 0xFFFFFFFFu) : decode(w0, load_bits(w0));   // (experiment: no bitmap round trip in front of the first rows)
             uint32_t b1 = load_bits(w1);
             uint32_t X[GRP];
 #pragma unroll
@@ -1131,6 +1148,11 @@ __global__ void __launch_bounds__(64) k_best8(Best8Args a) {
             const int cls = body_start >= body_words ? 0 : (body_start ? 1 : 2);
             atomicAdd(st + 32 + 2 * cls, 1ull);
             atomicAdd(st + 33 + 2 * cls, tw);
+            if (cls == 0) {   // a unit that ended in its preamble: where did its time go?
+                atomicAdd(st + 38, (unsigned long long)(t_wave0 - t_pull0));      // pulling the unit
+                atomicAdd(st + 39, (unsigned long long)(t_pre_end - t_wave0));    // replaying the preamble
+                atomicAdd(st + 40, (unsigned long long)(t_wave0 + tw - t_pre_end));   // closing the chunks
+            }
         }
         atomicMax(st + 4, tw);
         atomicAdd(st + 5 + min(tw >> 22, 15ull), 1ull);   // histogram of unit durations, 4.2M-cycle bins

@@ -55,6 +55,7 @@ struct Best8Args {
     const uint32_t *tile_hstart, *tile_hlen;   // [n_tiles] or null: per tile, the first chunk of the region its own samples
                                                // sit in and that region's length in chunks (scheduled first)
     uint32_t ub_every;         // exchange the shared upper bounds at every ub_every-th chunk end
+    uint32_t refill_all_rows;  // experiment (UGP_REFILL_ALL): a refill fetches the real row of every word of its first group
     uint32_t unit_chunks, heavy_chunks;        // chunks per unit outside / inside that region
     uint64_t *stats;           // optional: [0] += stream words skipped by pruning (debug / bench)
     uint32_t *ub;              // [n_tiles][64][4] packed upper bounds of best(s) shared by the waves of a tile; nullptr = no pruning
