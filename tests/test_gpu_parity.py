@@ -344,7 +344,7 @@ def test_usher_cli_add_mode_batched_equals_research_on_gpu(tmp_path):
     assert sum(1 for l in outs["batched"]["placement_stats.tsv"].splitlines() if l.split("\t")[2] != "1") > 20   # ties were exercised
 
 
-@pytest.mark.parametrize("seed", range(6))
+@pytest.mark.parametrize("seed", range(10))
 def test_randomised_trees_and_scheduling_knobs(seed, monkeypatch):
     """Differential fuzz: random trees (masked mutations, long branches, root mutations), multi-tile batches
     with N / IUPAC cells, and random values of every speed-only knob (chunk size, unit sizes, bound-exchange
@@ -364,8 +364,18 @@ def test_randomised_trees_and_scheduling_knobs(seed, monkeypatch):
         knobs["UGP_NO_LPT"] = "1"
     if rng.random() < 0.2:
         knobs["UGP_NO_SEED"] = "1"
+    if rng.random() < 0.3:
+        knobs["UGP_NO_DESCENT"] = "1"        # seeds from the coarse pass only
+    if rng.random() < 0.3:
+        knobs["UGP_NO_BOUND2"] = "1"         # first lower bound only
+    if rng.random() < 0.5:
+        knobs["UGP_UNIT_CHUNKS"] = "16"      # units that coincide with the summaries ...
+        if rng.random() < 0.7:
+            knobs["UGP_SUMMARY"] = "1"       # ... and use them
+    if rng.random() < 0.3:
+        knobs["UGP_PRE_WEIGHT"] = "50"
     for k in ("UGP_COARSE_MIN_NODES", "UGP_UNIT_CHUNKS", "UGP_HEAVY_CHUNKS", "UGP_UB_EVERY", "UGP_PRUNE_MIN_WORDS", "UGP_NO_LPT", "UGP_NO_SEED",
-              "UGP_NO_SORT", "UGP_NO_PRUNE", "UGP_FORCE_V1", "UGP_LDS_SLOTS"):
+              "UGP_NO_SORT", "UGP_NO_PRUNE", "UGP_FORCE_V1", "UGP_LDS_SLOTS", "UGP_NO_DESCENT", "UGP_NO_BOUND2", "UGP_SUMMARY", "UGP_PRE_WEIGHT"):
         monkeypatch.delenv(k, raising=False)
     for k, v in knobs.items():
         monkeypatch.setenv(k, v)

@@ -13,7 +13,7 @@ from tests import synth  # noqa: E402
 from usher_amd import Placer, QueryBatch  # noqa: E402
 
 KNOBS = ("UGP_COARSE_MIN_NODES", "UGP_UNIT_CHUNKS", "UGP_HEAVY_CHUNKS", "UGP_UB_EVERY", "UGP_PRUNE_MIN_WORDS", "UGP_NO_LPT", "UGP_NO_SEED",
-         "UGP_LDS_SLOTS", "UGP_NO_SIB", "UGP_NO_SORT")
+         "UGP_LDS_SLOTS", "UGP_NO_SIB", "UGP_NO_SORT", "UGP_NO_DESCENT", "UGP_NO_BOUND2", "UGP_SUMMARY", "UGP_PRE_WEIGHT")
 
 
 def main():
@@ -38,7 +38,10 @@ def main():
         knobs = {"UGP_COARSE_MIN_NODES": "0", "UGP_UNIT_CHUNKS": str(int(rng.integers(1, 12))), "UGP_HEAVY_CHUNKS": str(int(rng.integers(1, 12))),
                  "UGP_UB_EVERY": str(int(rng.choice([1, 2, 7, 1000]))), "UGP_PRUNE_MIN_WORDS": str(int(rng.choice([1, 2, 4, 8, 40]))),
                  "UGP_LDS_SLOTS": str(int(rng.integers(1, 12)))}
-        for k, p in (("UGP_NO_LPT", 0.3), ("UGP_NO_SEED", 0.2), ("UGP_NO_SIB", 0.2), ("UGP_NO_SORT", 0.1)):
+        if rng.random() < 0.4:
+            knobs["UGP_UNIT_CHUNKS"] = "16"   # units that coincide with the summaries
+        for k, p in (("UGP_NO_LPT", 0.3), ("UGP_NO_SEED", 0.2), ("UGP_NO_SIB", 0.2), ("UGP_NO_SORT", 0.1), ("UGP_NO_DESCENT", 0.3), ("UGP_NO_BOUND2", 0.2),
+                     ("UGP_SUMMARY", 0.4), ("UGP_PRE_WEIGHT", 0.2)):
             if rng.random() < p:
                 knobs[k] = "1"
         os.environ.update(knobs)
