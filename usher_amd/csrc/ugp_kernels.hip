@@ -1337,17 +1337,21 @@ constexpr uint32_t DESC_FRONTIER = 32, DESC_MAX_EXPANSIONS = 96, DESC_UP = 2;
 // The search is a chain of dependent loads (children range -> record -> table rows), a few per expansion: the frontier
 // keeps each entry's children range so that an expansion starts with the children's pairs, a record's first words are
 // fetched together before its length is known (the stream is padded), and the rows of a node's mutations are in flight together.
+// A sample is served by 16 lanes (nodes rarely have more children than that at once; more take further rounds), four
+// samples per wave: a quarter of the waves, all of them resident at once, for the same chain per sample.
 __global__ void __launch_bounds__(256) k_descend(const ugp_result *__restrict__ coarse_res, const uint32_t *__restrict__ order, uint32_t n_queries,
                           const uint32_t *__restrict__ coarse2bfs, const uint2 *__restrict__ node_pair,
                           const uint32_t *__restrict__ parent, const uint32_t *__restrict__ stream, const uint32_t *__restrict__ table, uint32_t n_sites,
                           uint32_t *__restrict__ refined) {
-    __shared__ uint32_t f_node[4][DESC_FRONTIER], f_cb[4][DESC_FRONTIER], f_ce[4][DESC_FRONTIER];
-    __shared__ int f_d[4][DESC_FRONTIER];
-    const uint32_t wv = threadIdx.x >> 6, lane = threadIdx.x & 63u;
-    const uint32_t slot = blockIdx.x * 4u + wv;
-    if (slot >= n_queries) return;
-    const ugp_result r = coarse_res[order ? order[slot] : slot];
-    if (r.best_j == 0xFFFFFFFFu || r.best_set_difference < 0 || r.best_set_difference > 0x7F7F) { if (lane == 0) refined[slot] = 0x7F7Fu; return; }
+    __shared__ uint32_t f_node[16][DESC_FRONTIER], f_cb[16][DESC_FRONTIER], f_ce[16][DESC_FRONTIER];
+    __shared__ int f_d[16][DESC_FRONTIER];
+    const uint32_t g = threadIdx.x >> 4, gl = threadIdx.x & 15u;   // group (sample) within the block, lane within the group
+    const uint32_t gsh = (threadIdx.x & 48u);                        // bit offset of the group in a wave-wide ballot
+    const uint32_t slot = blockIdx.x * 16u + g;
+    ugp_result r;
+    r.best_set_difference = -1; r.best_j = 0xFFFFFFFFu; r.num_best = 0; r.best_has_unique = 0;
+    if (slot < n_queries) r = coarse_res[order ? order[slot] : slot];
+    const bool alive = slot < n_queries && r.best_j != 0xFFFFFFFFu && r.best_set_difference >= 0 && r.best_set_difference <= 0x7F7F;
     const uint32_t *trow = table + ((uint64_t)(slot >> 9) * (n_sites + TABLE_CONST_ROWS) + TABLE_CONST_ROWS) * 64 + ((slot & 511u) >> 3);
     const uint32_t sh = (slot & 7u) * 4u;
     // one node for one sample: sum of delta over all words, sum of min(delta, 0) and shared mutations before the first masked one
@@ -1371,12 +1375,12 @@ __global__ void __launch_bounds__(256) k_descend(const ugp_result *__restrict__ 
             for (uint32_t k = 2; k < nw; k++) { const uint32_t w = rec[2 + k]; one(w, (trow[(uint64_t)(w & 0x3FFFFFu) * 64] >> sh) & 15u); }
         }
     };
-    int best = r.best_set_difference;
-    uint32_t n_f = 0;   // uniform: frontier entries
-    uint32_t start[DESC_UP + 1];   // uniform: the start nodes (an ancestor's expansion must not enter the next one again)
+    int best = alive ? r.best_set_difference : 0x7F7F;
+    uint32_t n_f = 0;   // uniform within the group: frontier entries
+    uint32_t start[DESC_UP + 1];   // the start nodes (an ancestor's expansion must not enter the next one again)
 #pragma unroll
     for (uint32_t i = 0; i <= DESC_UP; i++) start[i] = 0xFFFFFFFFu;
-    {
+    if (alive) {   // (every lane of the group does the same loads: broadcasts)
         uint32_t node = coarse2bfs[r.best_j];
         start[0] = node;
         uint2 pr = node_pair[node];
@@ -1385,7 +1389,7 @@ __global__ void __launch_bounds__(256) k_descend(const ugp_result *__restrict__ 
         eval(pr.y, dsum, neg, common, w0);
         // cost(node) = D(parent) + neg = best  ->  D(parent) = best - neg, D(node) = D(parent) + dsum;  the root's cost is its D
         int D = (w0 & F_ROOT) ? best : best - neg + dsum;
-        if (lane == 0) { f_node[wv][0] = node; f_d[wv][0] = D; f_cb[wv][0] = pr.x + 1u; f_ce[wv][0] = ce + 1u; }
+        if (gl == 0) { f_node[g][0] = node; f_d[g][0] = D; f_cb[g][0] = pr.x + 1u; f_ce[g][0] = ce + 1u; }
         n_f = 1;
         for (uint32_t up = 0; up < DESC_UP && node != 0; up++) {   // D(ancestor) = D(child) - (sum of the child's deltas)
             D -= dsum;
@@ -1393,27 +1397,35 @@ __global__ void __launch_bounds__(256) k_descend(const ugp_result *__restrict__ 
             start[up + 1] = node;
             pr = node_pair[node];
             ce = node_pair[node + 1].x;
-            if (lane == 0) { f_node[wv][n_f] = node; f_d[wv][n_f] = D; f_cb[wv][n_f] = pr.x + 1u; f_ce[wv][n_f] = ce + 1u; }
+            if (gl == 0) { f_node[g][n_f] = node; f_d[g][n_f] = D; f_cb[g][n_f] = pr.x + 1u; f_ce[g][n_f] = ce + 1u; }
             n_f++;
             eval(pr.y, dsum, neg, common, w0);
         }
     }
-    for (uint32_t it = 0; it < DESC_MAX_EXPANSIONS && n_f; it++) {
-        // pop the entry with the smallest D
-        unsigned long long kk = lane < n_f ? (((unsigned long long)(uint32_t)f_d[wv][lane] << 32) | lane) : ~0ull;
+    for (uint32_t it = 0; it < DESC_MAX_EXPANSIONS; it++) {
+        const bool act = n_f != 0;   // this group still has something to expand
+        if (__builtin_amdgcn_ballot_w64(act) == 0) break;
+        // pop the entry with the smallest D (two candidates per lane: DESC_FRONTIER = 2 x 16)
+        unsigned long long kk = ~0ull;
+        if (act && gl < n_f) kk = ((unsigned long long)(uint32_t)f_d[g][gl] << 32) | gl;
+        if (act && gl + 16u < n_f) { const unsigned long long k2 = ((unsigned long long)(uint32_t)f_d[g][gl + 16u] << 32) | (gl + 16u); kk = k2 < kk ? k2 : kk; }
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) { const unsigned long long other = __shfl_xor(kk, o); kk = other < kk ? other : kk; }
-        const uint32_t e = (uint32_t)kk & 63u;
-        const int D = f_d[wv][e];
-        const uint32_t cb = f_cb[wv][e], ce = f_ce[wv][e];   // children: BFS indices [cb, ce)
-        n_f--;
-        if (lane == 0 && e != n_f) { f_node[wv][e] = f_node[wv][n_f]; f_d[wv][e] = f_d[wv][n_f]; f_cb[wv][e] = f_cb[wv][n_f]; f_ce[wv][e] = f_ce[wv][n_f]; }
-        for (uint32_t c0 = cb; c0 < ce; c0 += 64) {
-            const uint32_t c = c0 + lane;
+        for (int o = 8; o > 0; o >>= 1) { const unsigned long long other = __shfl_xor(kk, o, 16); kk = other < kk ? other : kk; }
+        const uint32_t e = act ? ((uint32_t)kk & 31u) : 0u;
+        const int D = f_d[g][e];
+        const uint32_t cb = act ? f_cb[g][e] : 0u, ce = act ? f_ce[g][e] : 0u;   // children: BFS indices [cb, ce)
+        if (act) {
+            n_f--;
+            if (gl == 0 && e != n_f) { f_node[g][e] = f_node[g][n_f]; f_d[g][e] = f_d[g][n_f]; f_cb[g][e] = f_cb[g][n_f]; f_ce[g][e] = f_ce[g][n_f]; }
+        }
+        for (uint32_t c0 = cb;; c0 += 16) {
+            const bool more = c0 < ce;
+            if (__builtin_amdgcn_ballot_w64(more) == 0) break;
+            const uint32_t c = c0 + gl;
             int cost = 0x7FFFFFFF, dc = 0;
             bool push = false;
             uint32_t ccb = 0, cce = 0;
-            if (c < ce) {
+            if (more && c < ce) {
                 const uint2 pr = node_pair[c];
                 cce = node_pair[c + 1].x + 1u;
                 ccb = pr.x + 1u;
@@ -1429,17 +1441,17 @@ __global__ void __launch_bounds__(256) k_descend(const ugp_result *__restrict__ 
                 for (uint32_t i = 0; i < DESC_UP; i++) push = push && c != start[i];   // (already in the frontier)
             }
 #pragma unroll
-            for (int o = 32; o > 0; o >>= 1) cost = min(cost, __shfl_xor(cost, o));
+            for (int o = 8; o > 0; o >>= 1) cost = min(cost, __shfl_xor(cost, o, 16));
             best = min(best, cost);
-            const unsigned long long pm = __builtin_amdgcn_ballot_w64(push);
+            const uint32_t pm = (uint32_t)(__builtin_amdgcn_ballot_w64(push) >> gsh) & 0xFFFFu;
             if (push) {
-                const uint32_t at = n_f + (uint32_t)__builtin_popcountll(pm & ((1ull << lane) - 1ull));
-                if (at < DESC_FRONTIER) { f_node[wv][at] = c; f_d[wv][at] = dc; f_cb[wv][at] = ccb; f_ce[wv][at] = cce; }
+                const uint32_t at = n_f + (uint32_t)__builtin_popcount(pm & ((1u << gl) - 1u));
+                if (at < DESC_FRONTIER) { f_node[g][at] = c; f_d[g][at] = dc; f_cb[g][at] = ccb; f_ce[g][at] = cce; }
             }
-            n_f = min(n_f + (uint32_t)__builtin_popcountll(pm), DESC_FRONTIER);
+            n_f = min(n_f + (uint32_t)__builtin_popcount(pm), DESC_FRONTIER);
         }
     }
-    if (lane == 0) refined[slot] = (uint32_t)max(0, min(best, 0x7F7F));
+    if (slot < n_queries && gl == 0) refined[slot] = alive ? (uint32_t)max(0, min(best, 0x7F7F)) : 0x7F7Fu;
 }
 
 // Where in the chunk order do a tile's own samples sit?  keys_sorted[q] = DFS rank of the coarse best node of
@@ -1497,7 +1509,7 @@ hipError_t launch_descend(const ugp_result *coarse_res, const uint32_t *order, u
                           const uint32_t *node_pair, const uint32_t *parent, const uint32_t *stream, const uint32_t *table,
                           uint32_t n_sites, uint32_t *refined, hipStream_t s) {
     if (!n_queries) return hipSuccess;
-    hipLaunchKernelGGL(k_descend, dim3((n_queries + 3) / 4), dim3(256), 0, s, coarse_res, order, n_queries, coarse2bfs, (const uint2 *)node_pair, parent,
+    hipLaunchKernelGGL(k_descend, dim3((n_queries + 15) / 16), dim3(256), 0, s, coarse_res, order, n_queries, coarse2bfs, (const uint2 *)node_pair, parent,
                        stream, table, n_sites, refined);
     return hipGetLastError();
 }
