@@ -93,6 +93,7 @@ struct ugp_mat {
     // locality sort (speed only): a coarse MAT of the top of the tree and the map coarse BFS index -> DFS rank in the full tree
     ugp_mat *coarse = nullptr;
     DevBuf<uint32_t> d_coarse2bfs, d_node_pair, d_parent, d_refined;   // seed descent (k_descend)
+    bool wide_descent = false;
     DevBuf<uint32_t> d_coarse2dfs, d_keys, d_keys2, d_idx, d_order, d_slot;
     DevBuf<ugp_result> d_coarse_res, d_prev_res;
     bool prev_valid = false;
@@ -285,7 +286,7 @@ int run_place(ugp_mat *m, ugp_qset *qs, int mode, ugp_result *d_out, int32_t *d_
                 if (m->d_node_pair.p && !getenv("UGP_NO_DESCENT")) {
                     HIP_TRY(m->d_refined.reserve(nq));
                     HIP_TRY(ugp::launch_descend(m->d_coarse_res.p + q0, order, (uint32_t)nq, m->d_coarse2bfs.p, m->d_node_pair.p,
-                                                m->d_parent.p, m->d_stream.p, m->d_table.p, n_sites, m->d_refined.p, s));
+                                                m->d_parent.p, m->d_stream.p, m->d_table.p, n_sites, m->d_refined.p, m->wide_descent, s));
                     refined = m->d_refined.p;
                     if (getenv("UGP_STATS") && getenv("UGP_SEED_CHECK") && m->prev_valid && m->d_prev_res.cap >= Q) {   // debug: seeds against the previous call's answers
                         std::vector<uint32_t> ref(nq), ord(nq);
@@ -455,6 +456,7 @@ struct HostFlat {
     std::vector<uint32_t> parent;   // copy of the caller's BFS parent array (extended searches need the topology)
     std::vector<uint32_t> coarse2dfs, coarse2bfs;
     ugp::UVec<uint32_t> node_pair;   // full tree, for the seed descent (empty: input not in breadth-first order)
+    bool wide_descent = false;       // more than 5 % of the nodes hang off a node with more than 16 children
     HostFlat *coarse = nullptr;
     ~HostFlat() { delete coarse; }
 };
@@ -536,7 +538,7 @@ static int host_flatten(const ugp_tree_desc *tree, const ugp::Options &opt, bool
         if (rc == UGP_OK && with_coarse) {
             rc = build_coarse(tree, opt, ex, hf);
             if (rc != UGP_OK) return rc;   // (message already set)
-            if (hf.coarse) hf.node_pair.swap(ex.node_pair);
+            if (hf.coarse) { hf.node_pair.swap(ex.node_pair); hf.wide_descent = ex.children_of_wide_nodes * 20 > tree->n_nodes; }
         }
     } catch (const std::bad_alloc &) {
         return fail(UGP_ERR_NOMEM, "out of host memory while flattening the tree");
@@ -595,6 +597,7 @@ static int upload_flat(const HostFlat &hf, int device, ugp_mat **out) {
         if (!hf.node_pair.empty() && !getenv("UGP_NO_DESCENT")) {
             if ((e = m->d_coarse2bfs.upload(hf.coarse2bfs)) != hipSuccess) return bail(e, "upload coarse table");
             if ((e = m->d_node_pair.upload(hf.node_pair)) != hipSuccess) return bail(e, "upload node table");
+            m->wide_descent = getenv("UGP_DESCENT_LANES") ? atoi(getenv("UGP_DESCENT_LANES")) > 16 : hf.wide_descent;
             if ((e = m->d_parent.upload(hf.parent)) != hipSuccess) return bail(e, "upload parent table");
         }
     }

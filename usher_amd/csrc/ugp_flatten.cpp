@@ -794,6 +794,14 @@ int flatten(const ugp_tree_desc &t, const Options &opt, FlatMat &out, std::strin
                 for (uint64_t j = b; j < e; j++) { extras->node_pair[2 * j] = child_off[j]; extras->node_pair[2 * j + 1] = rec_off_d[dfsidx[j]]; }
             });
             extras->node_pair[2 * N] = child_off[N]; extras->node_pair[2 * N + 1] = 0;
+            std::vector<uint64_t> wide(T, 0);
+            par.run(N, [&](uint64_t b, uint64_t e, unsigned tid) {
+                uint64_t w = 0;
+                for (uint64_t j = b; j < e; j++) { const uint32_t c = child_off[j + 1] - child_off[j]; if (c > 16) w += c; }
+                wide[tid] = w;
+            });
+            extras->children_of_wide_nodes = 0;
+            for (uint64_t w : wide) extras->children_of_wide_nodes += w;
         }
         extras->sub.swap(sub); extras->dfsidx.swap(dfsidx);
     }

@@ -175,6 +175,7 @@ struct FlatExtras {
     // (the children of node j are the nodes child_begin[j] + 1 .. child_begin[j + 1]), node_pair[2j + 1] = dword offset of
     // j's record in FlatMat::stream; n_nodes + 1 pairs
     UVec<uint32_t> node_pair;
+    uint64_t children_of_wide_nodes = 0;   // nodes that are a child of a node with more than 16 children
 };
 
 // Returns UGP_OK or a negative UGP_ERR_* with `err` filled.

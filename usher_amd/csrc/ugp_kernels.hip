@@ -494,7 +494,7 @@ __device__ __forceinline__ uint32_t padd(uint32_t a, uint32_t b) { return a + b;
 __device__ __forceinline__ uint32_t psub(uint32_t a, uint32_t b) { return a - b; }
 
 template <bool STATS>   // STATS: per-unit accounting for tuning (UGP_STATS); off in production, it costs SGPRs
-__global__ void __launch_bounds__(64) k_best8(Best8Args a) {
+__global__ void __launch_bounds__(64, 5) k_best8(Best8Args a) {
     extern __shared__ __attribute__((aligned(16))) u32x4 slots8[];   // [lds_slots][64] x 16 B: the hot saved-D slots
     const uint32_t lane = threadIdx.x;
     const uint32_t lane16 = lane * 16u;
@@ -1337,17 +1337,20 @@ constexpr uint32_t DESC_FRONTIER = 32, DESC_MAX_EXPANSIONS = 96, DESC_UP = 2;
 // The search is a chain of dependent loads (children range -> record -> table rows), a few per expansion: the frontier
 // keeps each entry's children range so that an expansion starts with the children's pairs, a record's first words are
 // fetched together before its length is known (the stream is padded), and the rows of a node's mutations are in flight together.
-// A sample is served by 16 lanes (nodes rarely have more children than that at once; more take further rounds), four
-// samples per wave: a quarter of the waves, all of them resident at once, for the same chain per sample.
+// A sample is served by G lanes: 16 (four samples per wave: a quarter of the waves, all resident at once, for the same
+// chain per sample) when nodes rarely have more children than that, a whole wave when the tree has large polytomies
+// (the SARS-CoV-2-shaped benchmark tree: 16 lanes cost 2.5x there).
+template <uint32_t G>
 __global__ void __launch_bounds__(256) k_descend(const ugp_result *__restrict__ coarse_res, const uint32_t *__restrict__ order, uint32_t n_queries,
                           const uint32_t *__restrict__ coarse2bfs, const uint2 *__restrict__ node_pair,
                           const uint32_t *__restrict__ parent, const uint32_t *__restrict__ stream, const uint32_t *__restrict__ table, uint32_t n_sites,
                           uint32_t *__restrict__ refined) {
-    __shared__ uint32_t f_node[16][DESC_FRONTIER], f_cb[16][DESC_FRONTIER], f_ce[16][DESC_FRONTIER];
-    __shared__ int f_d[16][DESC_FRONTIER];
-    const uint32_t g = threadIdx.x >> 4, gl = threadIdx.x & 15u;   // group (sample) within the block, lane within the group
-    const uint32_t gsh = (threadIdx.x & 48u);                        // bit offset of the group in a wave-wide ballot
-    const uint32_t slot = blockIdx.x * 16u + g;
+    constexpr uint32_t NG = 256u / G;   // samples per block
+    __shared__ uint32_t f_node[NG][DESC_FRONTIER], f_cb[NG][DESC_FRONTIER], f_ce[NG][DESC_FRONTIER];
+    __shared__ int f_d[NG][DESC_FRONTIER];
+    const uint32_t g = threadIdx.x / G, gl = threadIdx.x % G;       // group (sample) within the block, lane within the group
+    const uint32_t gsh = (threadIdx.x & 63u) / G * G;                // bit offset of the group in a wave-wide ballot
+    const uint32_t slot = blockIdx.x * NG + g;
     ugp_result r;
     r.best_set_difference = -1; r.best_j = 0xFFFFFFFFu; r.num_best = 0; r.best_has_unique = 0;
     if (slot < n_queries) r = coarse_res[order ? order[slot] : slot];
@@ -1405,12 +1408,12 @@ __global__ void __launch_bounds__(256) k_descend(const ugp_result *__restrict__ 
     for (uint32_t it = 0; it < DESC_MAX_EXPANSIONS; it++) {
         const bool act = n_f != 0;   // this group still has something to expand
         if (__builtin_amdgcn_ballot_w64(act) == 0) break;
-        // pop the entry with the smallest D (two candidates per lane: DESC_FRONTIER = 2 x 16)
+        // pop the entry with the smallest D (G = 16: two candidates per lane, DESC_FRONTIER = 2 x 16)
         unsigned long long kk = ~0ull;
         if (act && gl < n_f) kk = ((unsigned long long)(uint32_t)f_d[g][gl] << 32) | gl;
-        if (act && gl + 16u < n_f) { const unsigned long long k2 = ((unsigned long long)(uint32_t)f_d[g][gl + 16u] << 32) | (gl + 16u); kk = k2 < kk ? k2 : kk; }
+        if (G < DESC_FRONTIER && act && gl + G < n_f) { const unsigned long long k2 = ((unsigned long long)(uint32_t)f_d[g][gl + G] << 32) | (gl + G); kk = k2 < kk ? k2 : kk; }
 #pragma unroll
-        for (int o = 8; o > 0; o >>= 1) { const unsigned long long other = __shfl_xor(kk, o, 16); kk = other < kk ? other : kk; }
+        for (int o = (int)G / 2; o > 0; o >>= 1) { const unsigned long long other = __shfl_xor(kk, o, (int)G); kk = other < kk ? other : kk; }
         const uint32_t e = act ? ((uint32_t)kk & 31u) : 0u;
         const int D = f_d[g][e];
         const uint32_t cb = act ? f_cb[g][e] : 0u, ce = act ? f_ce[g][e] : 0u;   // children: BFS indices [cb, ce)
@@ -1418,7 +1421,7 @@ __global__ void __launch_bounds__(256) k_descend(const ugp_result *__restrict__ 
             n_f--;
             if (gl == 0 && e != n_f) { f_node[g][e] = f_node[g][n_f]; f_d[g][e] = f_d[g][n_f]; f_cb[g][e] = f_cb[g][n_f]; f_ce[g][e] = f_ce[g][n_f]; }
         }
-        for (uint32_t c0 = cb;; c0 += 16) {
+        for (uint32_t c0 = cb;; c0 += G) {
             const bool more = c0 < ce;
             if (__builtin_amdgcn_ballot_w64(more) == 0) break;
             const uint32_t c = c0 + gl;
@@ -1441,14 +1444,14 @@ __global__ void __launch_bounds__(256) k_descend(const ugp_result *__restrict__ 
                 for (uint32_t i = 0; i < DESC_UP; i++) push = push && c != start[i];   // (already in the frontier)
             }
 #pragma unroll
-            for (int o = 8; o > 0; o >>= 1) cost = min(cost, __shfl_xor(cost, o, 16));
+            for (int o = (int)G / 2; o > 0; o >>= 1) cost = min(cost, __shfl_xor(cost, o, (int)G));
             best = min(best, cost);
-            const uint32_t pm = (uint32_t)(__builtin_amdgcn_ballot_w64(push) >> gsh) & 0xFFFFu;
+            const unsigned long long pm = (__builtin_amdgcn_ballot_w64(push) >> gsh) & (G == 64 ? ~0ull : ((1ull << (G & 63u)) - 1ull));
             if (push) {
-                const uint32_t at = n_f + (uint32_t)__builtin_popcount(pm & ((1u << gl) - 1u));
+                const uint32_t at = n_f + (uint32_t)__builtin_popcountll(pm & ((1ull << gl) - 1ull));
                 if (at < DESC_FRONTIER) { f_node[g][at] = c; f_d[g][at] = dc; f_cb[g][at] = ccb; f_ce[g][at] = cce; }
             }
-            n_f = min(n_f + (uint32_t)__builtin_popcount(pm), DESC_FRONTIER);
+            n_f = min(n_f + (uint32_t)__builtin_popcountll(pm), DESC_FRONTIER);
         }
     }
     if (slot < n_queries && gl == 0) refined[slot] = alive ? (uint32_t)max(0, min(best, 0x7F7F)) : 0x7F7Fu;
@@ -1507,10 +1510,14 @@ hipError_t launch_seed_ub(const ugp_result *coarse_res, const uint32_t *order, u
 
 hipError_t launch_descend(const ugp_result *coarse_res, const uint32_t *order, uint32_t n_queries, const uint32_t *coarse2bfs,
                           const uint32_t *node_pair, const uint32_t *parent, const uint32_t *stream, const uint32_t *table,
-                          uint32_t n_sites, uint32_t *refined, hipStream_t s) {
+                          uint32_t n_sites, uint32_t *refined, bool wide, hipStream_t s) {
     if (!n_queries) return hipSuccess;
-    hipLaunchKernelGGL(k_descend, dim3((n_queries + 15) / 16), dim3(256), 0, s, coarse_res, order, n_queries, coarse2bfs, (const uint2 *)node_pair, parent,
-                       stream, table, n_sites, refined);
+    if (wide)
+        hipLaunchKernelGGL(k_descend<64>, dim3((n_queries + 3) / 4), dim3(256), 0, s, coarse_res, order, n_queries, coarse2bfs, (const uint2 *)node_pair, parent,
+                           stream, table, n_sites, refined);
+    else
+        hipLaunchKernelGGL(k_descend<16>, dim3((n_queries + 15) / 16), dim3(256), 0, s, coarse_res, order, n_queries, coarse2bfs, (const uint2 *)node_pair, parent,
+                           stream, table, n_sites, refined);
     return hipGetLastError();
 }
 

@@ -90,7 +90,8 @@ hipError_t launch_tile_ranges(const uint32_t *keys_sorted, uint32_t n_queries, u
 // greedy descent from the coarse best node: refined[slot] = smallest cost of an eligible node met (a valid upper bound of best(s))
 hipError_t launch_descend(const ugp_result *coarse_res, const uint32_t *order, uint32_t n_queries, const uint32_t *coarse2bfs,
                           const uint32_t *node_pair /* [n_nodes + 1][2]: child_begin, rec_off */, const uint32_t *parent, const uint32_t *stream,
-                          const uint32_t *table, uint32_t n_sites, uint32_t *refined, hipStream_t s);
+                          const uint32_t *table, uint32_t n_sites, uint32_t *refined, bool wide /* a whole wave per sample: trees with large polytomies */,
+                          hipStream_t s);
 hipError_t launch_seed_ub(const ugp_result *coarse_res, const uint32_t *order, uint32_t n_queries, uint32_t n_tiles512, uint32_t *ub,
                           const uint32_t *refined /* [n_queries] by sorted slot, or null */, hipStream_t s);
 hipError_t launch_locality_sort(const ugp_result *coarse_res, const uint32_t *coarse2dfs, uint32_t n, uint32_t *keys,
