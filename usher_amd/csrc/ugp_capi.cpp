@@ -278,7 +278,7 @@ int run_place(ugp_mat *m, ugp_qset *qs, int mode, ugp_result *d_out, int32_t *d_
                                     f.max_pos, n_sites, e1 - e0, (uint32_t)q0, d_active, active_words, slot_of, use8 ? d_vrows : nullptr, s));
         if (use8) {   // upper bounds of best(s) the pruning starts from
             if (sorted && getenv("UGP_SEED_PREV") && m->d_prev_res.cap >= Q && m->prev_valid)   // (experiment: bounds = the previous call's exact answers)
-                HIP_TRY(ugp::launch_seed_ub(m->d_prev_res.p + q0, order, (uint32_t)nq, n_tiles512, m->d_ub.p, nullptr, s));
+                HIP_TRY(ugp::launch_seed_ub(m->d_prev_res.p + q0, order, (uint32_t)nq, n_tiles512, m->d_ub.p, nullptr, nullptr, 0, s));
             else if (sorted && !getenv("UGP_NO_SEED")) {
                 // the coarse pass's best costs (real costs of real nodes), tightened by a greedy descent from the coarse best node
                 // through the full tree (k_descend; it reads the sample's alleles from the tiles just built)
@@ -332,7 +332,10 @@ int run_place(ugp_mat *m, ugp_qset *qs, int mode, ugp_result *d_out, int32_t *d_
                         fprintf(stderr, "\n");
                     }
                 }
-                HIP_TRY(ugp::launch_seed_ub(m->d_coarse_res.p + q0, order, (uint32_t)nq, n_tiles512, m->d_ub.p, refined, s));
+                // (the unused slots of the last tile: far from everything, see k_seed_ub; 16-bit safe by the guard of the packed path)
+                const uint32_t pad_d = getenv("UGP_NO_PAD_FIX") ? 0u : (uint32_t)std::min<uint64_t>(4096, 0x7F7Eu - 2u - std::min<uint64_t>(f.max_path_muts, 0x7F00u));
+                HIP_TRY(ugp::launch_seed_ub(m->d_coarse_res.p + q0, order, (uint32_t)nq, n_tiles512, m->d_ub.p, refined,
+                                            getenv("UGP_NO_PAD_FIX") ? nullptr : d_dbottom, pad_d, s));
             } else
                 HIP_TRY(hipMemsetAsync(m->d_ub.p, 0x7F, (size_t)n_tiles512 * 256 * sizeof(uint32_t), s));   // 0x7F7F: above every valid cost
         }

@@ -1304,13 +1304,18 @@ __global__ void k_invert(const uint32_t *__restrict__ order, uint32_t n, uint32_
 // MAT is the top of the tree with every kept node's own mutations, so a node that is eligible there is
 // eligible in the full tree with the same cost (a kept node that is a leaf only in the coarse tree is
 // eligible there iff common > 0, which makes an internal node eligible too): the value is a real cost.
+// The unused sample slots of the last tile must not hold the tile back (all 512 lanes have to be far for a jump): left
+// alone they are 240 copies of a sample identical to the reference, an outlier that sits at the root.  They get D(bottom) =
+// pad_d (a count no real cost undercuts within 16 bits) and the bound 0: with V = 0 the second test, D - hrev > 0, then
+// holds for them everywhere.  Their results are never read.
 __global__ void k_seed_ub(const ugp_result *__restrict__ coarse_res, const uint32_t *__restrict__ order, uint32_t n_queries,
-                          uint32_t n_words, uint32_t *__restrict__ ub, const uint32_t *__restrict__ refined) {
+                          uint32_t n_words, uint32_t *__restrict__ ub, const uint32_t *__restrict__ refined, uint32_t *__restrict__ dbottom,
+                          uint32_t pad_d) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;   // word (tile*64 + lane)*4 + jj holds samples jj and jj+4 of the lane
     if (i >= n_words) return;
     const uint32_t slot = (i >> 2) * 8 + (i & 3u);
     auto val = [&](uint32_t q) -> uint32_t {
-        if (q >= n_queries) return 0x7F7Fu;
+        if (q >= n_queries) { if (dbottom) dbottom[q] = pad_d; return dbottom ? 0u : 0x7F7Fu; }
         const int32_t b = coarse_res[order[q]].best_set_difference;
         const uint32_t v = b < 0 || b > 0x7F7F ? 0x7F7Fu : (uint32_t)b;
         return refined ? min(v, refined[q]) : v;   // (the descent below: also the cost of a real eligible node)
@@ -1502,9 +1507,9 @@ hipError_t launch_tile_ranges(const uint32_t *keys_sorted, uint32_t n_queries, u
 }
 
 hipError_t launch_seed_ub(const ugp_result *coarse_res, const uint32_t *order, uint32_t n_queries, uint32_t n_tiles512, uint32_t *ub,
-                          const uint32_t *refined, hipStream_t s) {
+                          const uint32_t *refined, uint32_t *dbottom, uint32_t pad_d, hipStream_t s) {
     const uint32_t n_words = n_tiles512 * 256;
-    hipLaunchKernelGGL(k_seed_ub, dim3((n_words + 255) / 256), dim3(256), 0, s, coarse_res, order, n_queries, n_words, ub, refined);
+    hipLaunchKernelGGL(k_seed_ub, dim3((n_words + 255) / 256), dim3(256), 0, s, coarse_res, order, n_queries, n_words, ub, refined, dbottom, pad_d);
     return hipGetLastError();
 }
 

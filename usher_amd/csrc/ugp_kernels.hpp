@@ -93,7 +93,9 @@ hipError_t launch_descend(const ugp_result *coarse_res, const uint32_t *order, u
                           const uint32_t *table, uint32_t n_sites, uint32_t *refined, bool wide /* a whole wave per sample: trees with large polytomies */,
                           hipStream_t s);
 hipError_t launch_seed_ub(const ugp_result *coarse_res, const uint32_t *order, uint32_t n_queries, uint32_t n_tiles512, uint32_t *ub,
-                          const uint32_t *refined /* [n_queries] by sorted slot, or null */, hipStream_t s);
+                          const uint32_t *refined /* [n_queries] by sorted slot, or null */,
+                          uint32_t *dbottom /* or null: D(bottom) of the unused slots of the last tile is set to pad_d, their bound to 0 */, uint32_t pad_d,
+                          hipStream_t s);
 hipError_t launch_locality_sort(const ugp_result *coarse_res, const uint32_t *coarse2dfs, uint32_t n, uint32_t *keys,
                                 uint32_t *keys_sorted, uint32_t *idx, uint32_t *order, uint32_t *slot_of, void *temp,
                                 size_t *temp_bytes, hipStream_t s);
