@@ -169,25 +169,47 @@ hipError_t launch_rows_prepare(const uint64_t *ent_off, uint32_t n_queries, uint
 // One sample per lane, 32-bit walk (scores, tie lists, phase 2, fallback)
 // ====================================================================
 
+// Stream reader of the one-sample-per-lane walks: 64 words at a time, one per lane -- and, with each such window, the tile's
+// 32-byte piece of the table row every word names (a header or key word names none, or a harmless one) staged in LDS, so
+// that the mutation words of the window are served from there: one exposed memory latency per 64 words instead of one per
+// mutation (these walks are chains of dependent loads).  One wave per block.
 struct Reader {
     const uint32_t *p;
     uint32_t base, end;   // dword offsets; uniform
     uint32_t buf;         // lane l holds p[base + l]
     uint32_t cur;         // uniform
-    __device__ __forceinline__ void init(const uint32_t *ptr, uint32_t begin, uint32_t end_, uint32_t lane) {
-        p = ptr; base = begin; end = end_; cur = 0;
+    const uint32_t *tab8; // the 64-sample tile's 8 dwords of row 0 (+ 64 * site)
+    uint32_t *rowbuf;     // LDS [64][8]
+    uint32_t n_sites;
+    __device__ __forceinline__ void window(uint32_t lane) {
         buf = (base + lane < end) ? p[base + lane] : 0u;
+        const uint32_t site = buf & 0x3FFFFFu;
+        __syncthreads();   // (orders the previous window's LDS reads before these writes)
+        if (base + lane < end && site < n_sites) {
+            const uint4 *src = (const uint4 *)(tab8 + (uint64_t)site * 64);
+            const uint4 lo = src[0], hi = src[1];
+            uint4 *dst = (uint4 *)(rowbuf + lane * 8u);
+            dst[0] = lo; dst[1] = hi;
+        }
+        __syncthreads();
+    }
+    __device__ __forceinline__ void init(const uint32_t *ptr, uint32_t begin, uint32_t end_, uint32_t lane, const uint32_t *tab8_, uint32_t *rowbuf_,
+                                         uint32_t n_sites_) {
+        p = ptr; base = begin; end = end_; cur = 0; tab8 = tab8_; rowbuf = rowbuf_; n_sites = n_sites_;
+        window(lane);
     }
     __device__ __forceinline__ bool done() const { return base + cur >= end; }
     __device__ __forceinline__ uint32_t next(uint32_t lane) {
         if (cur == 64) {
             base += 64; cur = 0;
-            buf = (base + lane < end) ? p[base + lane] : 0u;
+            window(lane);
         }
         uint32_t w = rdlane(buf, cur);
         cur++;
         return w;
     }
+    // the sample column `col` (= lane >> 3) of the row named by the word that next() returned last
+    __device__ __forceinline__ uint32_t row(uint32_t col) const { return rowbuf[(cur - 1u) * 8u + col]; }
 };
 
 struct WalkOut { uint32_t best, cnt, key; };
@@ -298,9 +320,10 @@ __device__ __forceinline__ WalkOut walk_ties(const PlaceArgs &a, uint32_t *slots
 // EX: the extended search of the other mapper2_body callers -- a node counts only if the shared mask admits it and it
 // is not the sample's excluded node; ties are ranked by a.alt_rank; indices are reported through a.out_index.
 template <int MODE, bool EX>
-__device__ __forceinline__ WalkOut walk(const PlaceArgs &a, uint32_t *slots, uint32_t tile, uint32_t c0, uint32_t c1,
+__device__ __forceinline__ WalkOut walk(const PlaceArgs &a, uint32_t *slots, uint32_t *rowbuf, uint32_t tile, uint32_t c0, uint32_t c1,
                                         uint32_t lane, uint32_t want_best) {
-    const uint32_t *tab = a.table + ((uint64_t)(tile >> 3) * (a.n_sites + TABLE_CONST_ROWS) + TABLE_CONST_ROWS) * 64 + (tile & 7u) * 8 + (lane >> 3);
+    const uint32_t *tab8 = a.table + ((uint64_t)(tile >> 3) * (a.n_sites + TABLE_CONST_ROWS) + TABLE_CONST_ROWS) * 64 + (tile & 7u) * 8;
+    const uint32_t col = lane >> 3;
     const uint32_t sh = (lane & 7u) * 4u;
     const uint32_t q = tile * 64 + lane;
     const uint32_t dbot = a.dbottom[q];
@@ -310,8 +333,8 @@ __device__ __forceinline__ WalkOut walk(const PlaceArgs &a, uint32_t *slots, uin
     const uint32_t skip_bfs = (EX && a.skip && q < a.n_queries) ? a.skip[q] : 0xFFFFFFFFu;
     for (int phase = 0; phase < 2; phase++) {
         Reader rd;
-        if (phase == 0) rd.init(a.pre_stream, a.chunk_pre_off[c0], a.chunk_pre_off[c0 + 1], lane);
-        else rd.init(a.stream, a.chunk_body_off[c0], a.chunk_body_off[c1], lane);
+        if (phase == 0) rd.init(a.pre_stream, a.chunk_pre_off[c0], a.chunk_pre_off[c0 + 1], lane, tab8, rowbuf, a.n_sites);
+        else rd.init(a.stream, a.chunk_body_off[c0], a.chunk_body_off[c1], lane, tab8, rowbuf, a.n_sites);
         while (!rd.done()) {
             const uint32_t w0 = rd.next(lane);
             const uint32_t key = rd.next(lane);
@@ -325,9 +348,8 @@ __device__ __forceinline__ WalkOut walk(const PlaceArgs &a, uint32_t *slots, uin
             uint32_t common = 0, n_before = 0;
             for (uint32_t m = 0; m < nmut; m++) {
                 const uint32_t w = rd.next(lane);
-                const uint32_t site = w & 0x3FFFFFu, mi = (w >> 22) & 3u, pi = (w >> 24) & 3u;
-                const uint32_t x = tab[(uint64_t)site * 64];
-                const uint32_t nib = (x >> sh) & 15u;
+                const uint32_t mi = (w >> 22) & 3u, pi = (w >> 24) & 3u;
+                const uint32_t nib = (rd.row(col) >> sh) & 15u;
                 const int c = (int)((nib >> mi) & 1u), p = (int)((nib >> pi) & 1u);
                 const int d = p - c;
                 tsum += d;
@@ -390,6 +412,7 @@ __device__ __forceinline__ WalkOut walk(const PlaceArgs &a, uint32_t *slots, uin
 template <int MODE, bool EX>   // MODE 0, 1, 2 (see walk)
 __global__ void __launch_bounds__(64) k_place(PlaceArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint32_t slots[];   // [max_slots][64]
+    __shared__ __attribute__((aligned(16))) uint32_t rowbuf[64 * 8];
     const uint32_t lane = threadIdx.x;
     uint32_t tile, g;
     {
@@ -413,7 +436,7 @@ __global__ void __launch_bounds__(64) k_place(PlaceArgs a) {
     const uint32_t q = tile * 64 + lane;
     uint32_t want_best = 0;
     if (MODE == 2) want_best = (q < a.n_queries) ? (uint32_t)a.best_in[q] : 0xffffffffu;
-    WalkOut r = walk<MODE, EX>(a, slots, tile, c0, c1, lane, want_best);
+    WalkOut r = walk<MODE, EX>(a, slots, rowbuf, tile, c0, c1, lane, want_best);
     if (MODE == 0) { a.part_best[o] = r.best; a.part_cnt[o] = r.cnt; a.part_key[o] = r.key; }
 }
 
