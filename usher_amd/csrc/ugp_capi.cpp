@@ -283,7 +283,9 @@ int run_place(ugp_mat *m, ugp_qset *qs, int mode, ugp_result *d_out, int32_t *d_
                 // the coarse pass's best costs (real costs of real nodes), tightened by a greedy descent from the coarse best node
                 // through the full tree (k_descend; it reads the sample's alleles from the tiles just built)
                 const uint32_t *refined = nullptr;
-                if (m->d_node_pair.p && !getenv("UGP_NO_DESCENT")) {
+                // (not with UGP_COARSE_FAST: the descent derives D of its start node from "cost(best_j) == best", which only
+                // the exact coarse placement guarantees)
+                if (m->d_node_pair.p && !getenv("UGP_NO_DESCENT") && !getenv("UGP_COARSE_FAST")) {
                     HIP_TRY(m->d_refined.reserve(nq));
                     HIP_TRY(ugp::launch_descend(m->d_coarse_res.p + q0, order, (uint32_t)nq, m->d_coarse2bfs.p, m->d_node_pair.p,
                                                 m->d_parent.p, m->d_stream.p, m->d_table.p, n_sites, m->d_refined.p, m->wide_descent, s));
