@@ -555,13 +555,19 @@ __global__ void __launch_bounds__(64, 5) k_best8(Best8Args a) {
             if (drained & (1u << x)) continue;
             const uint32_t tlo = x * a.n_tiles / 8u, thi = (x + 1u) * a.n_tiles / 8u;
             const uint32_t HU = a.heavy_chunks;
-            uint32_t heavy = 0, light = 0;
+            // Light units are handed out nearest first: rank k of every tile of the queue before rank k + 1 of any, and within
+            // a tile alternating between the chunks behind its own region (A, ascending) and in front of it (B, descending).
+            // The units next to the own region are the ones pruning helps least; handed out last (B used to run towards
+            // the region) they were the tail of the kernel.
+            // (a.light_order 1: one tile after the other instead, each nearest first -- keeps a tile's rows in L2)
+            uint32_t heavy = 0, max_light = 0, sum_light = 0;
             for (uint32_t tt = tlo; tt < thi; tt++) {
                 const uint32_t h0 = a.tile_hstart ? a.tile_hstart[tt] : 0u, hl = a.tile_hstart ? a.tile_hlen[tt] : 0u;
                 heavy += (hl + HU - 1u) / HU;
-                light += (a.n_chunks - h0 - hl + U - 1u) / U + (h0 + U - 1u) / U;
+                const uint32_t nl = (a.n_chunks - h0 - hl + U - 1u) / U + (h0 + U - 1u) / U;
+                max_light = max(max_light, nl); sum_light += nl;
             }
-            const uint32_t ux = heavy + light;
+            const uint32_t ux = heavy + (a.light_order == 1u ? sum_light : max_light * (thi - tlo));
             uint32_t v = 0xFFFFFFFFu;
             if (ux) {
                 if (lane == 0) v = atomicAdd(&a.queue[x], 1u);
@@ -575,20 +581,34 @@ __global__ void __launch_bounds__(64, 5) k_best8(Best8Args a) {
                 while (r >= (a.tile_hlen[tt] + HU - 1u) / HU) { r -= (a.tile_hlen[tt] + HU - 1u) / HU; tt++; }
                 tile = tt; c0 = a.tile_hstart[tt] + r * HU; c1 = min(c0 + HU, a.tile_hstart[tt] + a.tile_hlen[tt]);
             } else {
-                uint32_t tt = tlo, r = v - heavy;
-                for (;; tt++) {
-                    const uint32_t h0 = a.tile_hstart ? a.tile_hstart[tt] : 0u, hl = a.tile_hstart ? a.tile_hlen[tt] : 0u;
-                    const uint32_t nA = (a.n_chunks - h0 - hl + U - 1u) / U, nB = (h0 + U - 1u) / U;
-                    if (r < nA) { c0 = h0 + hl + r * U; c1 = min(c0 + U, a.n_chunks); break; }
-                    if (r < nA + nB) { c0 = (r - nA) * U; c1 = min(c0 + U, h0); break; }
-                    r -= nA + nB;
+                const uint32_t T = thi - tlo;
+                uint32_t k = (v - heavy) / T, tt = tlo + (v - heavy) % T;
+                if (a.light_order == 1u) {   // tile-major
+                    k = v - heavy;
+                    for (tt = tlo;; tt++) {
+                        const uint32_t h0 = a.tile_hstart ? a.tile_hstart[tt] : 0u, hl = a.tile_hstart ? a.tile_hlen[tt] : 0u;
+                        const uint32_t nl = (a.n_chunks - h0 - hl + U - 1u) / U + (h0 + U - 1u) / U;
+                        if (k < nl) break;
+                        k -= nl;
+                    }
                 }
+                const uint32_t h0 = a.tile_hstart ? a.tile_hstart[tt] : 0u, hl = a.tile_hstart ? a.tile_hlen[tt] : 0u;
+                const uint32_t nA = (a.n_chunks - h0 - hl + U - 1u) / U, nB = (h0 + U - 1u) / U, m = min(nA, nB);
+                uint32_t ia = 0xFFFFFFFFu, ib = 0xFFFFFFFFu;   // index into A (ascending from the region) / B (descending towards chunk 0)
+                if (k < 2u * m) { if (k & 1u) ib = k >> 1; else ia = k >> 1; }
+                else if (k < nA + nB) { if (nA > nB) ia = k - m; else ib = k - m; }
+                if (ia != 0xFFFFFFFFu) { c0 = h0 + hl + ia * U; c1 = min(c0 + U, a.n_chunks); }
+                else if (ib != 0xFFFFFFFFu) { const uint32_t j = nB - 1u - ib; c0 = j * U; c1 = min(c0 + U, h0); }
+                else { c0 = 0; c1 = 0; }   // this tile has fewer light units than the longest of the queue: nothing to do
                 tile = tt;
             }
         }
         if (!got) return;
     }
     if (c0 >= c1) continue;
+    // The dense units of the tiles' own regions are the kernel's critical path (one wave walks ~10k words; everything else
+    // fits beside them): their waves get the SIMD's issue slots first, the far units run in the gaps.
+    if (a.heavy_prio) { if (unit_heavy) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(0); }
     // table rows through a buffer resource: address = tile base + 4*lane (VGPR) + 256*row (SGPR soffset);
     // rows 0..3 are the constant rows, site s is row s + 4
     const uint32_t n_rows = a.n_sites + CONST_ROWS;

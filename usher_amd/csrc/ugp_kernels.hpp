@@ -56,6 +56,8 @@ struct Best8Args {
                                                // sit in and that region's length in chunks (scheduled first)
     uint32_t ub_every;         // exchange the shared upper bounds at every ub_every-th chunk end
     uint32_t refill_all_rows;  // experiment (UGP_REFILL_ALL): a refill fetches the real row of every word of its first group
+    uint32_t heavy_prio;       // raise the wave priority while a unit of a tile's own region is walked
+    uint32_t light_order;      // light units: 0 = nearest first across the queue's tiles, 1 = tile after tile (each nearest first)
     uint32_t unit_chunks, heavy_chunks;        // chunks per unit outside / inside that region
     uint64_t *stats;           // optional: [0] += stream words skipped by pruning (debug / bench)
     uint32_t *ub;              // [n_tiles][64][4] packed upper bounds of best(s) shared by the waves of a tile; nullptr = no pruning
