@@ -60,7 +60,7 @@ def self_launch(args) -> int:
     code.  Nothing in this process has initialised a GPU (device_count() does not)."""
     import torch
     have = torch.cuda.device_count()
-    if have < args.gpus:
+    if have < args.gpus and not (have and os.environ.get("BENCH_SHARE_DEVICE")):
         print("bench.py: --gpus %d requested but only %d device(s) are visible" % (args.gpus, have), file=sys.stderr)
         return 2
     import socket
@@ -137,11 +137,18 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the placement path has no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # BENCH_SHARE_DEVICE=1 (test hook for one-GPU boxes): the ranks share the visible devices and gather through gloo, so that
+    # the multi-rank flow (shared tree, sharding, gather, one JSON line) can be exercised without N GPUs; not a measurement
+    share = world > 1 and bool(os.environ.get("BENCH_SHARE_DEVICE"))
+    dev_index = local_rank % torch.cuda.device_count() if share else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if share:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     from usher_amd import Placer, QueryBatch, synth
     from usher_amd.dist import shard_bounds
@@ -151,7 +158,7 @@ def main():
     st = shared_tree(args, n_sites, world, local_rank)
     t_gen = time.time() - t0
     t0 = time.time()
-    pl = Placer(st.arrays, device=local_rank)
+    pl = Placer(st.arrays, device=dev_index)
     t_flat = time.time() - t0
     info = pl.info()
     kw = dict(n_lo=100, n_hi=5000, iupac_hi=30) if args.ambiguous else {}
@@ -183,13 +190,13 @@ def main():
     qset = pl.upload(batch)
     Q = len(batch)
     out = torch.zeros((cap, 4), dtype=torch.int32, device=dev)        # (shards differ by at most one sample: padded to `cap`)
-    gathered = torch.zeros((world * cap, 4), dtype=torch.int32, device=dev) if world > 1 else None
+    gathered = torch.zeros((world * cap, 4), dtype=torch.int32, device="cpu" if share else dev) if world > 1 else None
     stream = torch.cuda.current_stream().cuda_stream
 
     def step():
         pl.place_device(qset, out.data_ptr(), stream)
         if world > 1:
-            dist.all_gather_into_tensor(gathered, out)
+            dist.all_gather_into_tensor(gathered, out.cpu() if share else out)
 
     for _ in range(args.warmup):
         step()
@@ -212,7 +219,7 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if share else dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
@@ -232,7 +239,7 @@ def main():
             hres = pl.place(batch)
         dt = time.perf_counter() - t1
         if world > 1:
-            tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+            tt = torch.tensor([dt], dtype=torch.float64, device="cpu" if share else dev)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             dt = float(tt.item())
         dt /= n_host

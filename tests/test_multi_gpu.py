@@ -65,3 +65,21 @@ def test_cli_devices_list_equals_default(flags, tmp_path):
         outs.append({n: open(str(d / n)).read() for n in sorted(os.listdir(str(d)))})
     for o in outs[1:]:
         assert o == outs[0]
+
+
+def test_bench_multi_rank_flow_on_one_box(tmp_path):
+    """bench.py --gpus 2 starts its own ranks (torch.distributed.run child), the ranks share one generated tree through
+    /dev/shm, shard the queries and print ONE JSON line with the aggregate.  On a one-GPU box the BENCH_SHARE_DEVICE hook
+    lets both ranks use the same device and gather through gloo -- the flow is what is tested, not the figure."""
+    import json
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    if _n_devices() < 2:
+        env["BENCH_SHARE_DEVICE"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--nodes", "300000", "--queries", "1500", "--steps", "2", "--warmup", "1",
+                        "--strong"], capture_output=True, text=True, timeout=1200, env=env)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["rccl_ranks"] == 2 and d["config"]["queries_total"] == 1500
+    assert d["value"] > 0 and d["host_buffer_path"]["identical_to_device_path"] is True
