@@ -114,7 +114,7 @@ constexpr uint32_t SUM_W_SHIFT = 22, SUM_W_MAX = 63, SUM_POS_MASK = (1u << 22) -
 constexpr uint32_t SUM_A_POS_MASK = (1u << 19) - 1u, SUM_HR_SHIFT = 19;   // (a run longer than 2^19 words: no summaries at all, super_chunks = 0)
 constexpr uint32_t SUPER_CHUNKS = 16;       // chunks per summary (= the light work units of k_best8)
 constexpr uint32_t PRUNE_MIN_WORDS = 4;     // only subtrees at least this long carry a pruning record
-constexpr uint32_t LDS_SLOTS = 7;           // saved-D slots k_best8 keeps in LDS (1 KB each per wave); the colder ones live in a global scratch
+constexpr uint32_t LDS_SLOTS = 9;           // saved-D slots k_best8 keeps in LDS (1 KB each per wave); the colder ones live in a global scratch
 constexpr uint32_t M_FLUSH = 1u << 28, M_END = 1u << 30;
 constexpr uint32_t MAX_SITES = 1u << 22;
 constexpr uint32_t MAX_NODE_MUTS = 65534;   // 0xFFFF marks a pruning pseudo-record of the tie stream
@@ -125,7 +125,8 @@ struct Options {
     bool sibling_records = true;   // emit H_INFO | H_SIB records
     uint32_t lds_slots = LDS_SLOTS; // headers whose (renumbered) slots are >= this are flagged H_SLOW
     uint32_t super_chunks = SUPER_CHUNKS;   // chunks per summary
-    uint32_t pre_weight = 0;    // weight of the preambles' slot accesses when the hot (LDS) slots are chosen
+    uint32_t pre_weight = 32;   // weight of the preambles' slot accesses when the hot (LDS) slots are chosen: every unit replays one,
+                                // the body is mostly skipped (0: body counts only)
     uint32_t threads = 0;       // host threads (0 = UGP_FLATTEN_THREADS, else min(32, hardware threads)); the output does not depend on it
 };
 
