@@ -128,6 +128,81 @@ __global__ void k_scatter_entries(uint32_t *__restrict__ table, uint32_t *__rest
     }
 }
 
+// ---- tile build for batches with many rows per sample (high-ambiguity queries: thousands of N cells each) ------------------
+// k_scatter_entries does one global atomic per row, each on a different 64-byte line of a 200 MB table: 41 M rows took
+// 1.8 ms, twice per step.  Here a workgroup owns (tile, block of TB_SITES sites): it keeps those rows of the table in LDS,
+// every thread finds its samples' rows that fall into the block's position range (the rows of a sample are sorted by
+// position: one binary search), applies them with LDS atomics, and the block is written out coalesced -- which also
+// replaces k_fill_table.  D(bottom) and V come from k_row_counts, one wave per sample.
+constexpr uint32_t TB_SITES = 128;
+__global__ void __launch_bounds__(256) k_build_tiles(uint32_t *__restrict__ table, uint32_t *__restrict__ active, uint32_t active_words,
+                                                     const uint64_t *__restrict__ ent_off, uint32_t q0, const uint32_t *__restrict__ order, uint32_t nq,
+                                                     const int32_t *__restrict__ pos, const uint8_t *__restrict__ ref, const uint8_t *__restrict__ nuc,
+                                                     const uint8_t *__restrict__ is_missing, const int32_t *__restrict__ pos2site,
+                                                     const int32_t *__restrict__ site_pos, const uint8_t *__restrict__ site_ref, uint32_t n_sites,
+                                                     uint32_t max_pos) {
+    __shared__ uint32_t rows[TB_SITES * 64];
+    __shared__ uint32_t act[TB_SITES];
+    const uint32_t tile = blockIdx.y, s0 = blockIdx.x * TB_SITES, s1 = min(s0 + TB_SITES, n_sites), tid = threadIdx.x;
+    for (uint32_t i = tid; i < TB_SITES * 64; i += 256) {
+        const uint32_t s = s0 + (i >> 6);
+        rows[i] = s < n_sites ? (uint32_t)site_ref[s] * 0x11111111u : 0u;
+    }
+    if (tid < TB_SITES) act[tid] = 0;
+    __syncthreads();
+    const int32_t P0 = site_pos[s0];                                     // positions of the block's sites: [P0, P1)
+    const int64_t P1 = s1 < n_sites ? (int64_t)site_pos[s1] : (int64_t)max_pos + 1;
+    for (uint32_t i = tid; i < 512; i += 256) {
+        const uint32_t slot = tile * 512 + i;
+        if (slot >= nq) continue;
+        const uint32_t q = q0 + (order ? order[slot] : slot);
+        uint64_t lo = ent_off[q], hi = ent_off[q + 1];
+        const uint64_t re = hi;
+        while (lo < hi) { const uint64_t mid = (lo + hi) >> 1; if (pos[mid] < P0) lo = mid + 1; else hi = mid; }   // first row at or behind P0
+        const uint32_t sh = (i & 7u) * 4u, col = i >> 3;
+        for (uint64_t r = lo; r < re; r++) {
+            const int32_t p = pos[r];
+            if ((int64_t)p >= P1) break;
+            const int32_t site = pos2site[p];
+            if (site < 0) continue;
+            const uint32_t rr = ref[r], a = is_missing[r] ? 15u : (uint32_t)nuc[r];
+            atomicXor(&rows[((uint32_t)site - s0) * 64 + col], ((rr ^ a) & 15u) << sh);   // nibble was the reference base; rows are unique per (sample, position)
+            if (rr != a) act[(uint32_t)site - s0] = 1;
+        }
+    }
+    __syncthreads();
+    const uint64_t n_rows = (uint64_t)n_sites + TABLE_CONST_ROWS;
+    uint32_t *out = table + ((uint64_t)tile * n_rows + TABLE_CONST_ROWS + s0) * 64;
+    for (uint32_t i = tid; i < (s1 - s0) * 64; i += 256) out[i] = rows[i];
+    if (blockIdx.x == 0)   // the four constant rows of the tile
+        table[(uint64_t)tile * n_rows * 64 + tid] = 0x11111111u << (tid >> 6);
+    if (tid < TB_SITES / 32) {   // "some sample of the tile is not reference here" bits of 32 sites
+        uint32_t bits = 0;
+        for (uint32_t k = 0; k < 32; k++) bits |= (act[tid * 32 + k] ? 1u : 0u) << k;
+        if ((s0 >> 5) + tid < active_words) active[(uint64_t)tile * active_words + (s0 >> 5) + tid] = bits;
+    }
+}
+
+// D(bottom) = #{non-missing rows whose allele set excludes the reference base} and V = #{rows whose set is neither missing
+// nor just the reference base}, one wave per sample slot (usher_mapper.cpp:292-388 with an empty ancestral list).
+__global__ void __launch_bounds__(256) k_row_counts(const uint64_t *__restrict__ ent_off, uint32_t q0, const uint32_t *__restrict__ order, uint32_t nq,
+                                                    const uint8_t *__restrict__ ref, const uint8_t *__restrict__ nuc, const uint8_t *__restrict__ is_missing,
+                                                    uint32_t *__restrict__ dbottom, uint32_t *__restrict__ vrows) {
+    const uint32_t slot = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63u;
+    if (slot >= nq) return;
+    const uint32_t q = q0 + (order ? order[slot] : slot);
+    const uint64_t rb = ent_off[q], re = ent_off[q + 1];
+    uint32_t d = 0, v = 0;
+    for (uint64_t r = rb + lane; r < re; r += 64) {
+        const uint32_t rr = ref[r], a = is_missing[r] ? 15u : (uint32_t)nuc[r];
+        d += (!is_missing[r] && (a & rr) == 0) ? 1u : 0u;
+        v += (!is_missing[r] && a != rr) ? 1u : 0u;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { d += __shfl_xor(d, o); v += __shfl_xor(v, o); }
+    if (lane == 0) { dbottom[slot] = d; if (vrows) vrows[slot] = v; }
+}
+
 // Query rows on arrival (one thread per VCF row): the sample each row belongs to (binary search in the CSR
 // offsets) and the checks that validate_queries() used to run on the host -- rows of a sample sorted by
 // position without duplicates, REF one of A,C,G,T, allele mask in range, REF equal to the tree's reference
@@ -1588,6 +1663,17 @@ hipError_t launch_fill_table(uint32_t *table, const uint8_t *site_ref, uint32_t 
     uint64_t blocks = (total_dwords + 255) / 256;
     if (blocks > 16384) blocks = 16384;
     hipLaunchKernelGGL(k_fill_table, dim3((uint32_t)blocks), dim3(256), 0, s, table, site_ref, n_sites + TABLE_CONST_ROWS, total_dwords);
+    return hipGetLastError();
+}
+
+hipError_t launch_build_tiles(uint32_t *table, uint32_t *active, uint32_t active_words, uint32_t n_tiles512, const uint64_t *ent_off, uint32_t q0,
+                              const uint32_t *order, uint32_t nq, const int32_t *pos, const uint8_t *ref, const uint8_t *nuc, const uint8_t *is_missing,
+                              const int32_t *pos2site, const int32_t *site_pos, const uint8_t *site_ref, uint32_t n_sites, uint32_t max_pos,
+                              uint32_t *dbottom, uint32_t *vrows, hipStream_t s) {
+    if (!n_tiles512 || !n_sites) return hipSuccess;
+    hipLaunchKernelGGL(k_build_tiles, dim3((n_sites + TB_SITES - 1) / TB_SITES, n_tiles512), dim3(256), 0, s, table, active, active_words, ent_off, q0, order, nq,
+                       pos, ref, nuc, is_missing, pos2site, site_pos, site_ref, n_sites, max_pos);
+    hipLaunchKernelGGL(k_row_counts, dim3((nq + 3) / 4), dim3(256), 0, s, ent_off, q0, order, nq, ref, nuc, is_missing, dbottom, vrows);
     return hipGetLastError();
 }
 

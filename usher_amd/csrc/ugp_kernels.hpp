@@ -82,6 +82,11 @@ hipError_t launch_rows_prepare(const uint64_t *ent_off, uint32_t n_queries, uint
                                uint32_t max_pos, uint32_t n_sites, uint32_t *ent_q, unsigned long long *err, hipStream_t s);
 hipError_t launch_fill_table(uint32_t *table, const uint8_t *site_ref, uint32_t n_sites, uint64_t total_dwords,
                              hipStream_t s);
+// the whole tile build (fill + scatter + row counts) for batches with many rows per sample: (tile, 128-site block) in LDS
+hipError_t launch_build_tiles(uint32_t *table, uint32_t *active, uint32_t active_words, uint32_t n_tiles512, const uint64_t *ent_off, uint32_t q0,
+                              const uint32_t *order /* slot -> sample of the sub-batch, or null */, uint32_t nq, const int32_t *pos, const uint8_t *ref,
+                              const uint8_t *nuc, const uint8_t *is_missing, const int32_t *pos2site, const int32_t *site_pos, const uint8_t *site_ref,
+                              uint32_t n_sites, uint32_t max_pos, uint32_t *dbottom, uint32_t *vrows /* or null */, hipStream_t s);
 hipError_t launch_scatter(uint32_t *table, uint32_t *dbottom, const int32_t *pos, const uint8_t *ref,
                           const uint8_t *nuc, const uint8_t *is_missing, const uint32_t *ent_q,
                           const int32_t *pos2site, uint32_t max_pos, uint32_t n_sites, uint64_t n_ent, uint32_t q_base,
