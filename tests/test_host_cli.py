@@ -412,3 +412,30 @@ def test_out_of_order_and_duplicated_rows_follow_the_reference_scans(seed, tmp_p
     want = usher_model.run(T2, refio.read_vcf(T2, odd_vcf))
     for name in want:
         assert open(str(d / name)).read() == want[name], name
+
+
+def test_samples_already_in_the_tree_are_ignored(tmp_path, capfd):
+    """A VCF column named like a leaf of the loaded MAT is not a new sample: the reader warns and skips it
+    (mutation_annotated_tree.cpp:2216-2226), and the run writes what it writes without that column."""
+    import re
+    pb = os.path.join(SURVEY, "syn", "tree.pb")
+    vcf = os.path.join(SURVEY, "syn", "query.vcf")
+    leaf = re.findall(r"[(,]([^(),:;]+)", _read(os.path.join(SURVEY, "syn", "tree.nh")))[3]
+    lines = _read(vcf).splitlines()
+    extra = str(tmp_path / "extra.vcf")
+    with open(extra, "w") as f:
+        for l in lines:
+            if l.startswith("##"):
+                f.write(l + "\n")
+            elif l.startswith("#CHROM"):
+                f.write(l + "\t" + leaf + "\n")
+            else:
+                f.write(l + "\t1\n")          # the column carries calls: they must not reach the placement
+    outs = []
+    for k, v in enumerate((vcf, extra)):
+        d = tmp_path / ("o%d" % k)
+        d.mkdir()
+        assert run_usher(["-i", pb, "-v", v, "-u", "-d", str(d)]) == 0
+        outs.append({n: _read(str(d / n)) for n in ("placement_stats.tsv", "mutation-paths.txt", "uncondensed-final-tree.nh")})
+    assert outs[0] == outs[1]
+    assert "already in the tree" in capfd.readouterr().err
