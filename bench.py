@@ -228,21 +228,25 @@ def main():
     # row checks, the same kernels, result download.  Reported beside `value` (the contract keeps `value`
     # HBM-resident); timed on every rank the same way (barrier + max).
     host_path = None
+    # (the collectives run on every rank, also on one whose shard is empty: only the place() calls depend on Q)
     if Q:
         pl.place(batch)   # warm
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        n_host = max(2, min(args.steps, 5))
-        t1 = time.perf_counter()
-        for _ in range(n_host):
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    n_host = max(2, min(args.steps, 5))
+    t1 = time.perf_counter()
+    hres = None
+    for _ in range(n_host):
+        if Q:
             hres = pl.place(batch)
-        dt = time.perf_counter() - t1
-        if world > 1:
-            tt = torch.tensor([dt], dtype=torch.float64, device="cpu" if share else dev)
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            dt = float(tt.item())
-        dt /= n_host
+    dt = time.perf_counter() - t1
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device="cpu" if share else dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    dt /= n_host
+    if Q:
         same = bool((np.stack([hres[k] for k in ("best_set_difference", "num_best", "best_j", "best_has_unique")], 1).astype(np.int64) == res.astype(np.int64)).all())
         host_path = {"metric": "SURVEY 8(d): Q / wall time of ugp_place_batch (query upload + kernels + result download)",
                      "placements_per_s": round(total_q / dt, 2), "ms_per_batch": round(dt * 1e3, 3), "identical_to_device_path": same}

@@ -121,6 +121,37 @@ def make_case(seed: int, n_leaves: int, n_queries: int, genome_len: int = 2000, 
     return arrays, queries
 
 
+def relabel_preorder(arrays):
+    """The same tree with its nodes renumbered in depth-first preorder (children in their stored order): parents still
+    precede their children -- all the C ABI asks of parent[] -- but the numbering is no breadth-first expansion, so the
+    children of a node are not contiguous.  Returns (arrays, new_index_of_old)."""
+    par = np.asarray(arrays["parent"]).astype(np.int64)
+    n = len(par)
+    kids = [[] for _ in range(n)]
+    for j in range(1, n):
+        kids[par[j]].append(j)
+    stack, order = [0], []
+    while stack:
+        v = stack.pop()
+        order.append(v)
+        stack.extend(reversed(kids[v]))
+    new = np.empty(n, np.int64)
+    new[order] = np.arange(n)
+    off = np.asarray(arrays["mut_off"]).astype(np.int64)
+    cnt = np.diff(off)[order]
+    noff = np.concatenate([[0], np.cumsum(cnt)])
+    take = np.concatenate([np.arange(off[v], off[v + 1]) for v in order]) if off[-1] else np.zeros(0, np.int64)
+    out = dict(arrays)
+    out["parent"] = np.array([-1 if par[v] < 0 else new[par[v]] for v in order], dtype=np.asarray(arrays["parent"]).dtype)
+    out["mut_off"] = noff.astype(np.asarray(arrays["mut_off"]).dtype)
+    for k in ("mut_pos", "mut_ref", "mut_par", "mut_nuc"):
+        if k in arrays:
+            out[k] = np.asarray(arrays[k])[take]
+    if "names" in arrays:
+        out["names"] = [arrays["names"][v] for v in order]
+    return out, new
+
+
 def caterpillar_case(seed: int, depth: int, muts_per_node: int, n_queries: int, genome_len: int = 29000, n_sites: int = 3000):
     """A maximally deep tree: a chain of `depth` internal nodes, each with one leaf child and the next
     chain node (BFS order: chain node 2k-1, leaf 2k at level k).  Root paths carry depth*muts_per_node

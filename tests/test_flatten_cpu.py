@@ -60,6 +60,20 @@ def test_stream_matches_oracle_random(seed):
     _check(arrays, queries, chunk_nodes=0, n_groups=1, scores=False)
 
 
+def test_stream_matches_oracle_when_the_numbering_is_not_breadth_first():
+    """parent[j] < j is all the boundary asks for: the same tree numbered in preorder gives the same placements
+    (node indices translated), through the serial fallback of the flattening's level passes."""
+    arrays, queries = synth.make_case(27, n_leaves=160, n_queries=8, n_sites=60, p_masked=0.05, root_muts=1)
+    pre, new = synth.relabel_preorder(arrays)
+    assert (np.diff(pre["parent"][1:]) < 0).any()           # really not a breadth-first expansion
+    _check(pre, queries, chunk_nodes=13, n_groups=5)
+    ot, otp = capi.OracleTree(arrays), capi.OracleTree(pre)
+    for s in queries:
+        a, b = ot.place(s, compute_scores=True), otp.place(s, compute_scores=True)
+        assert (a["best"], a["num_best"]) == (b["best"], b["num_best"])
+        assert b["scores"][new].tolist() == a["scores"].tolist()
+
+
 def test_stream_on_syn_fixture():
     T = refio.load_mutation_annotated_tree(os.path.join(GOLD, "survey_ref", "syn", "tree.pb"))
     samples = [refio.sample_to_arrays(s) for s in refio.read_vcf(T, os.path.join(GOLD, "survey_ref", "syn", "query.vcf"))]
@@ -208,29 +222,7 @@ def test_flattening_does_not_depend_on_the_thread_count(kind, monkeypatch):
         arrays, kw = gsynth.SynthTree(200_000, n_sites=3000, seed=9, shape="sars2").arrays, {}
     else:   # parents before children but not a breadth-first order: the serial fallback of the level passes
         arrays, _ = synth.make_case(6, n_leaves=300, n_queries=1, n_sites=80)
-        par = np.asarray(arrays["parent"]).astype(np.int64)
-        n = len(par)
-        order = [0]
-        kids = [[] for _ in range(n)]
-        for j in range(1, n):
-            kids[par[j]].append(j)
-        stack, order = [0], []
-        while stack:                       # preorder: every parent still precedes its children
-            v = stack.pop()
-            order.append(v)
-            stack.extend(reversed(kids[v]))
-        new = np.empty(n, np.int64)
-        new[order] = np.arange(n)
-        off = np.asarray(arrays["mut_off"]).astype(np.int64)
-        cnt = np.diff(off)[order]
-        noff = np.concatenate([[0], np.cumsum(cnt)])
-        take = np.concatenate([np.arange(off[v], off[v + 1]) for v in order]) if off[-1] else np.zeros(0, np.int64)
-        arrays = dict(arrays)
-        arrays["parent"] = np.array([-1 if par[v] < 0 else new[par[v]] for v in order], dtype=np.asarray(arrays["parent"]).dtype)
-        arrays["mut_off"] = noff.astype(np.asarray(arrays["mut_off"]).dtype)
-        for k in ("mut_pos", "mut_ref", "mut_par", "mut_nuc"):
-            if k in arrays:
-                arrays[k] = np.asarray(arrays[k])[take]
+        arrays, _ = synth.relabel_preorder(arrays)
     monkeypatch.setenv("UGP_FLATTEN_THREADS", "1")
     ref = _flat_arrays(arrays, **kw)
     if kind != "synth200k":

@@ -24,8 +24,12 @@ def test_place_sharded_on_two_devices_rccl():
     if _n_devices() < 2:
         pytest.skip("needs two GPUs")
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import socket
+    with socket.socket() as sk:   # a free port, as bench.py's self-launch picks one
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                        "--master-port", "29731", os.path.join(ROOT, "tests", "_dist_worker.py")], capture_output=True, text=True, timeout=1200, env=env)
+                        "--master-port", str(port), os.path.join(ROOT, "tests", "_dist_worker.py")], capture_output=True, text=True, timeout=1200, env=env)
     assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
     assert "rank 0 OK" in r.stdout and "rank 1 OK" in r.stdout
 

@@ -109,3 +109,47 @@ def test_merge_style_level_capped_subtree():
                 else:
                     _same(res, i, w)
     pl.close()
+
+
+def test_depth_first_order_of_a_tree_that_is_not_numbered_breadth_first():
+    """The boundary only promises parent[j] < j.  A tree numbered in preorder IS its own depth-first expansion, so
+    ugp_node_order(DFS) is the identity there, DFS-order calls equal BFS-order calls, and both equal the oracle
+    (the children of a node are not contiguous in such a numbering)."""
+    arrays0, queries = synth.make_case(613, n_leaves=420, n_queries=50, n_sites=90, p_masked=0.02)
+    arrays, new = synth.relabel_preorder(arrays0)
+    n = arrays["n"]
+    assert (np.diff(arrays["parent"][1:]) < 0).any()
+    pl = Placer(arrays, chunk_nodes=32)
+    dfs = pl.node_order("dfs").astype(np.int64)
+    assert dfs.tolist() == list(range(n))
+    batch = QueryBatch(queries)
+    ot = capi.OracleTree(arrays)
+    res = pl.place(batch)
+    rng = np.random.default_rng(3)
+    skip = rng.integers(0, n, len(queries)).astype(np.uint32)
+    res_b = pl.place_ex(batch, order="bfs", skip_node=skip)
+    res_d = pl.place_ex(batch, order="dfs", skip_node=skip)
+    ties_d, hu_d, tc_d = pl.tied_nodes_ex(batch, 256, order="dfs", skip_node=skip)
+    allj = np.arange(n)
+    for i, s in enumerate(queries):
+        _same(res, i, ot.place(s))
+        keep = allj != skip[i]
+        w = ot.place_list(s, allj[keep], jidx=allj[keep])
+        _same(res_b, i, w)
+        _same(res_d, i, w)
+        assert int(tc_d[i]) == w["num_best"] and ties_d[i].tolist() == w["ties"].tolist() and hu_d[i].tolist() == w["ties_has_unique"].tolist()
+    # level-capped subtree masks, both orders, against a plain walk over parent[]
+    par = arrays["parent"]
+    depth = np.zeros(n, np.int64)
+    for j in range(1, n):
+        depth[j] = depth[par[j]] + 1
+    root = int(np.flatnonzero(np.bincount(par[1:], minlength=n) >= 2)[5])
+    inside = np.zeros(n, bool)
+    inside[root] = True
+    for j in range(root + 1, n):
+        inside[j] = inside[par[j]]
+    for lv in (1, 3, 1000):
+        want = inside & (depth - depth[root] <= lv)
+        assert pl.subtree_mask(root, lv, order="bfs").astype(bool).tolist() == want.tolist()
+        assert pl.subtree_mask(root, lv, order="dfs").astype(bool).tolist() == want.tolist()
+    pl.close()

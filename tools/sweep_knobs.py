@@ -32,12 +32,14 @@ q = st.queries(args.queries, seed=1017, **kw)
 batch = QueryBatch.from_csr(q["ent_off"], q["pos"], q["ref"], q["nuc"], q["is_missing"])
 out = torch.zeros((len(batch), 4), dtype=torch.int32, device="cuda")
 stream = torch.cuda.current_stream().cuda_stream
-KNOBS = ("UGP_CHUNK_NODES", "UGP_UNIT_CHUNKS", "UGP_HEAVY_CHUNKS", "UGP_LDS_SLOTS", "UGP_UB_EVERY", "UGP_PRUNE_MIN_WORDS", "UGP_COARSE_DIV",
-         "UGP_COARSE_CHUNK_NODES", "UGP_WAVES_PER_CU", "UGP_NO_SIB", "UGP_NO_LPT", "UGP_NO_SEED", "UGP_NO_SORT", "UGP_GROUPS", "UGP_TARGET_WAVES")
+BASE_ENV = dict(os.environ)   # every UGP_* switch that is not in here belongs to a previous setting and is removed before the next
 ref = None
 for setting in ["(default)"] + args.settings:
-    for k in KNOBS:
-        os.environ.pop(k, None)
+    for k in [k for k in os.environ if k.startswith("UGP_") and k not in BASE_ENV]:
+        del os.environ[k]
+    for k, v in BASE_ENV.items():
+        if k.startswith("UGP_"):
+            os.environ[k] = v
     if setting != "(default)":
         for kv in setting.split():
             k, v = kv.split("=")

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <climits>
 #include <chrono>
 #include <cstdio>
@@ -96,7 +97,7 @@ struct ugp_mat {
     bool wide_descent = false;
     DevBuf<uint32_t> d_coarse2dfs, d_keys, d_keys2, d_idx, d_order, d_slot;
     DevBuf<ugp_result> d_coarse_res, d_prev_res;
-    bool prev_valid = false;
+    uint64_t prev_serial = 0;   // (UGP_SEED_PREV / UGP_SEED_CHECK diagnostics) content serial of the query set d_prev_res belongs to; 0 = none
     DevBuf<uint8_t> d_sort_tmp;
     bool last_used_best8 = false;
     // extended searches (ugp_place_batch_ex): host copy of the topology, the reference's depth-first order and its tie rank
@@ -120,6 +121,7 @@ struct ugp_qset {
     int device = 0;
     uint64_t n_queries = 0, n_ent = 0;
     uint64_t max_rows = 0;           // largest number of rows of one sample
+    uint64_t serial = 0;             // changes whenever the set is (re)filled: results remembered for one content never seed another
     DevBuf<int32_t> d_pos;
     DevBuf<uint8_t> d_ref, d_nuc, d_missing;
     DevBuf<uint32_t> d_ent_q;
@@ -289,7 +291,7 @@ int run_place(ugp_mat *m, ugp_qset *qs, int mode, ugp_result *d_out, int32_t *d_
                                     f.max_pos, n_sites, e1 - e0, (uint32_t)q0, d_active, active_words, slot_of, use8 ? d_vrows : nullptr, s));
         }
         if (use8) {   // upper bounds of best(s) the pruning starts from
-            if (sorted && getenv("UGP_SEED_PREV") && m->d_prev_res.cap >= Q && m->prev_valid)   // (experiment: bounds = the previous call's exact answers)
+            if (sorted && getenv("UGP_SEED_PREV") && m->d_prev_res.cap >= Q && m->prev_serial == qs->serial)   // (experiment: bounds = the previous call's exact answers)
                 HIP_TRY(ugp::launch_seed_ub(m->d_prev_res.p + q0, order, (uint32_t)nq, n_tiles512, m->d_ub.p, nullptr, nullptr, 0, s));
             else if (sorted && !getenv("UGP_NO_SEED")) {
                 // the coarse pass's best costs (real costs of real nodes), tightened by a greedy descent from the coarse best node
@@ -302,7 +304,7 @@ int run_place(ugp_mat *m, ugp_qset *qs, int mode, ugp_result *d_out, int32_t *d_
                     HIP_TRY(ugp::launch_descend(m->d_coarse_res.p + q0, order, (uint32_t)nq, m->d_coarse2bfs.p, m->d_node_pair.p,
                                                 m->d_parent.p, m->d_stream.p, m->d_table.p, n_sites, m->d_refined.p, m->wide_descent, s));
                     refined = m->d_refined.p;
-                    if (getenv("UGP_STATS") && getenv("UGP_SEED_CHECK") && m->prev_valid && m->d_prev_res.cap >= Q) {   // debug: seeds against the previous call's answers
+                    if (getenv("UGP_STATS") && getenv("UGP_SEED_CHECK") && m->prev_serial == qs->serial && m->d_prev_res.cap >= Q) {   // debug: seeds against the previous call's answers
                         std::vector<uint32_t> ref(nq), ord(nq);
                         std::vector<ugp_result> prev(nq), coarse(nq);
                         HIP_TRY(hipStreamSynchronize(s));
@@ -449,7 +451,7 @@ int run_place(ugp_mat *m, ugp_qset *qs, int mode, ugp_result *d_out, int32_t *d_
         if ((getenv("UGP_SEED_PREV") || getenv("UGP_SEED_CHECK")) && use8 && !coarse_only && mode == 0) {
             HIP_TRY(m->d_prev_res.reserve(Q));
             HIP_TRY(hipMemcpyAsync(m->d_prev_res.p + q0, d_out + q0, nq * sizeof(ugp_result), hipMemcpyDeviceToDevice, s));
-            m->prev_valid = true;
+            m->prev_serial = (q0 + nq >= Q) ? qs->serial : 0;   // valid once every sub-batch of THIS query set has been stored
         }
         HIP_TRY(hipEventRecord(es.ev[3], s));
         m->last_used_best8 = use8;
@@ -714,6 +716,10 @@ static int qset_fill(ugp_mat *m, const ugp_queries *q, ugp_qset *qs) {
     qs->n_queries = q->n_queries;
     qs->n_ent = n_ent;
     qs->max_rows = max_rows;
+    {
+        static std::atomic<uint64_t> next_serial{0};
+        qs->serial = ++next_serial;
+    }
     try {
         if (q->n_queries) qs->ent_off.assign(q->ent_off, q->ent_off + q->n_queries + 1);
         else qs->ent_off.assign(1, 0);
@@ -864,9 +870,16 @@ static void ensure_dfs_order(ugp_mat *m) {
     if (!m->h_dfs2bfs.empty()) return;
     const uint64_t N = m->flat.n_nodes;
     const auto &par = m->h_parent;
-    std::vector<uint32_t> first(N + 1, 0);
+    // Child lists by count, prefix sum and fill (children of a node in increasing index = the reference's stored order).
+    // A true breadth-first expansion has them contiguous (1 + first[j] ..), but the boundary only promises
+    // parent[j] < j, and ugp_flatten.cpp accepts such topological-but-not-level-ordered arrays too.
+    std::vector<uint32_t> first(N + 1, 0), kids(N ? N - 1 : 0);
     for (uint64_t j = 1; j < N; j++) first[par[j] + 1]++;
-    for (uint64_t j = 0; j < N; j++) first[j + 1] += first[j];   // BFS order: the children of j are 1 + first[j] .. 1 + first[j+1]
+    for (uint64_t j = 0; j < N; j++) first[j + 1] += first[j];   // the children of j are kids[first[j] .. first[j+1])
+    {
+        std::vector<uint32_t> fill(first.begin(), first.end() - 1);
+        for (uint64_t j = 1; j < N; j++) kids[fill[par[j]]++] = (uint32_t)j;
+    }
     m->h_dfs2bfs.resize(N); m->h_bfs2dfs.resize(N);
     std::vector<std::pair<uint32_t, uint32_t>> st;   // (node, next child offset)
     st.push_back({0u, 0u});
@@ -874,9 +887,9 @@ static void ensure_dfs_order(ugp_mat *m) {
     m->h_dfs2bfs[d] = 0; m->h_bfs2dfs[0] = 0; d++;
     while (!st.empty()) {
         auto &fr = st.back();
-        const uint32_t b = 1 + first[fr.first], e = 1 + first[fr.first + 1];
+        const uint32_t b = first[fr.first], e = first[fr.first + 1];
         if (b + fr.second < e) {
-            const uint32_t c = b + fr.second++;
+            const uint32_t c = kids[b + fr.second++];
             m->h_dfs2bfs[d] = c; m->h_bfs2dfs[c] = (uint32_t)d; d++;
             st.push_back({c, 0u});
         } else st.pop_back();
