@@ -246,10 +246,7 @@ enum {
     UGP_FLAT_MAX_PATH_MUTS = 14, /* count only */
     UGP_FLAT_STREAM_T = 15,     /* uint32: tie stream walked by phase 2 (chunk bodies + pruning pseudo-records) */
     UGP_FLAT_CHUNK_T_OFF = 16,  /* uint32 [n_chunks+1] */
-    UGP_FLAT_LDS_SLOTS = 17,    /* count only: saved-D slots the packed stream keeps on the fast path */
-    UGP_FLAT_SUM8 = 18,         /* uint32: summaries of the top-level subtrees of every run of super_chunks chunks */
-    UGP_FLAT_SUM8_OFF = 19,     /* uint32 [ceil(n_chunks / super_chunks) + 1] */
-    UGP_FLAT_SUPER_CHUNKS = 20  /* count only */
+    UGP_FLAT_LDS_SLOTS = 17     /* count only: saved-D slots the packed stream keeps on the fast path */
 };
 int ugp_flat_create(const ugp_tree_desc *tree, uint32_t chunk_nodes, ugp_flat **out);
 void ugp_flat_destroy(ugp_flat *flat);

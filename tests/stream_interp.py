@@ -121,8 +121,9 @@ def place(flat, sample, n_groups=1, want_scores=False):
 # --------------------------------------------------------------------------
 # layout of ugp_flatten.hpp (final encoding)
 H_TAG, H_INFO, H_RARE, H_SIB = 1 << 31, 1 << 30, 1 << 29, 1 << 21
-H_REG, H_STORE, H_NOSCORE8, H_END, H_FREE, H_SKIPD, H_BOTTOM, H_SLOW, H_CHUNK_END, H_NOP = (1 << k for k in range(10))
+H_REG, H_STORE, H_NOSCORE8, H_END, H_FREE, H_SKIPD, _H_UNUSED6, H_SLOW, H_CHUNK_END, H_NOP = (1 << k for k in range(10))
 H_RSLOT_SHIFT, H_WSLOT_SHIFT, INFO_HS_SHIFT = 10, 20, 22
+CE_LEN_SHIFT, CE_LEN_MASK = 10, (1 << 19) - 1
 INFO_HR_SHIFT, INFO_HR_NONE, INFO_JUMP_MASK, PRE_HS_NONE = 18, 7, (1 << 18) - 1, 127
 
 
@@ -137,64 +138,14 @@ M_FLUSH, M_END = 1 << 28, 1 << 30
 U16 = 0xFFFF
 
 
-SUM_FORCED, SUM_W_SHIFT, SUM_POS_MASK = 1 << 28, 22, (1 << 22) - 1
-SUM_A_POS_MASK, SUM_HR_SHIFT = (1 << 19) - 1, 19
-
-
-def summary_ranges(flat, nib, c0, slots, dcur, ub, stats=None, vrow=None, body_start=0):
-    """The summary pass of k_best8 for the run of chunks starting at c0 (one sample): the ranges of the body
-    (relative positions, adjacent ones merged) whose top-level subtree survives both bounds."""
-    g = c0 // flat.super_chunks
-    words = flat.sum8
-    i, hi_ = int(flat.sum8_off[g]), int(flat.sum8_off[g + 1])
-    ranges = []
-    while i < hi_:
-        a, b, h = int(words[i]), int(words[i + 1]), int(words[i + 2])
-        i += 3
-        assert (a & (H_TAG | H_INFO | H_RARE)) == (H_TAG | H_INFO | H_RARE) and (b & (H_TAG | H_INFO | H_RARE)) == (H_TAG | H_INFO)
-        assert (h & H_TAG) and not (h & (H_INFO | H_NOP | H_CHUNK_END | H_STORE))
-        forced = bool(b & SUM_FORCED) or bool(h & H_RARE)
-        accP = accC = 0
-        if not (h & H_END):
-            while True:
-                w = int(words[i]); i += 1
-                assert not (w & H_TAG)
-                x = int(nib[w & 0x3FFFFF])
-                accP += (x >> ((w >> 24) & 3)) & 1
-                accC += (x >> ((w >> 22) & 3)) & 1
-                if w & M_END:
-                    break
-        lo, hi = a & SUM_A_POS_MASK, b & SUM_POS_MASK
-        assert lo < hi
-        dead = hi <= body_start          # inside the subtree the preamble replay ruled out (its parent's slot may not exist)
-        assert dead or lo >= body_start
-        keep = forced and not dead
-        if not forced and not dead:
-            spar = dcur if h & H_REG else slots[(h >> H_RSLOT_SHIFT) & 63]
-            dn = (spar + accP - accC) & U16
-            hs, wn, hr = (a >> INFO_HS_SHIFT) & 0x7F, (b >> SUM_W_SHIFT) & 63, (a >> SUM_HR_SHIFT) & 7
-            far_below = dn >= ub[0] + 1 + hs or (vrow is not None and hr != INFO_HR_NONE and dn - hr >= min(ub[0] + 1 + vrow, 0x7F80))
-            keep = not (far_below and spar >= ub[0] + 1 + wn)
-        if keep:
-            if ranges and ranges[-1][1] == lo:
-                ranges[-1][1] = hi
-            else:
-                assert not ranges or ranges[-1][1] < lo
-                ranges.append([lo, hi])
-        elif stats is not None:
-            stats["summary_skipped"] = stats.get("summary_skipped", 0) + hi - lo
-    return ranges
-
-
-def best8_group(flat, nib, dbot, c0, c1, ub=None, stats=None, use_summary=True, vrow=None, use_pre_records=True):
+def best8_group(flat, nib, dbot, c0, c1, ub=None, stats=None, vrow=None, use_pre_records=True):
     """Chunk-local minima of one sample for chunks [c0, c1), as k_best8 computes them.
     ub: None = no pruning; otherwise a one-element list holding an upper bound of the sample's best
-    score, used (and tightened at chunk ends) exactly like the kernel's shared bound.  When the unit
-    coincides with a summary (and pruning is on) the body is walked range by range, as the kernel does."""
+    score, used (and tightened at chunk ends) exactly like the kernel's shared bound."""
     slots = {}
     lbest = {}
     best = U16
-    dcur = dpar = 0
+    dcur, dpar = dbot, 0        # (the root reads "the previous node's D": every unit starts from D(bottom))
     accP = accC = accN = 0
     carryD = carryN = carryC = 0
     flushed = False
@@ -221,8 +172,6 @@ def best8_group(flat, nib, dbot, c0, c1, ub=None, stats=None, use_summary=True, 
     sinfo = None
     body_start = 0
     n_chunks = len(flat.chunk8_body_off) - 1
-    sc = getattr(flat, "super_chunks", 0)
-    summarise = (use_summary and ub is not None and sc and c0 % sc == 0 and c1 == min(c0 + sc, n_chunks))
     body0 = int(flat.chunk8_body_off[c0])
     segments = [(0, flat.pre8_stream, int(flat.chunk8_pre_off[c0]), int(flat.chunk8_pre_off[c0 + 1]))]
     for phase, words, lo, hi in segments:   # (the body segments are appended once the preamble has been replayed)
@@ -243,7 +192,7 @@ def best8_group(flat, nib, dbot, c0, c1, ub=None, stats=None, use_summary=True, 
                 if w & (H_INFO | H_CHUNK_END | H_NOP) or (w & H_SLOW):
                     assert w & H_RARE   # everything off the fast path carries the one bit the kernel tests first
                 else:
-                    assert not (w & H_RARE) and not (w & H_BOTTOM)
+                    assert not (w & H_RARE)
                 if w & H_INFO:          # first: the jump length of a pruning record overlaps the other flag bits
                     if ub is not None and phase == 1:
                         if w & H_SIB:
@@ -257,6 +206,11 @@ def best8_group(flat, nib, dbot, c0, c1, ub=None, stats=None, use_summary=True, 
                 if w & H_NOP:
                     continue
                 if w & H_CHUNK_END:
+                    # the end word names the length of the chunk it opens (the kernel's cend, no table lookup)
+                    ln = (w >> CE_LEN_SHIFT) & CE_LEN_MASK
+                    assert phase == 1 and i == int(flat.chunk8_body_off[chunk + 1]) - 1
+                    want = int(flat.chunk8_body_off[chunk + 2]) - int(flat.chunk8_body_off[chunk + 1]) if chunk + 1 < n_chunks else 0
+                    assert ln == (want if want <= CE_LEN_MASK else 0)
                     lbest[chunk] = best
                     if ub is not None:
                         ub[0] = min(ub[0], best)
@@ -264,13 +218,13 @@ def best8_group(flat, nib, dbot, c0, c1, ub=None, stats=None, use_summary=True, 
                     chunk += 1
                     continue
                 hdr = w
-                if w & H_SLOW:          # cold slot (beyond the LDS-resident ones) or the root
+                if w & H_SLOW:          # cold slot (beyond the LDS-resident ones)
                     rs, ws = (w >> H_RSLOT_SHIFT) & 63, (w >> H_WSLOT_SHIFT) & 63
-                    assert (w & H_BOTTOM) or (not (w & H_REG) and rs >= flat.lds_slots) or ((w & H_STORE) and ws >= flat.lds_slots)
+                    assert (not (w & H_REG) and rs >= flat.lds_slots) or ((w & H_STORE) and ws >= flat.lds_slots)
                 else:
                     assert (w & H_REG) or ((w >> H_RSLOT_SHIFT) & 63) < flat.lds_slots
                     assert not (w & H_STORE) or ((w >> H_WSLOT_SHIFT) & 63) < flat.lds_slots
-                dpar = dcur if w & H_REG else (dbot if w & H_BOTTOM else slots[(w >> H_RSLOT_SHIFT) & 63])
+                dpar = dcur if w & H_REG else slots[(w >> H_RSLOT_SHIFT) & 63]
                 if sinfo is not None:   # sibling record: skip this child and the non-last siblings after it?
                     rec, jump = sinfo, sinfo & INFO_JUMP_MASK
                     sinfo = None
@@ -330,12 +284,7 @@ def best8_group(flat, nib, dbot, c0, c1, ub=None, stats=None, use_summary=True, 
         if phase == 0:
             body_end = int(flat.chunk8_body_off[c1])
             info = None
-            if summarise and body_start < body_end - body0:
-                for r0, r1 in summary_ranges(flat, nib, c0, slots, dcur, ub, stats, vrow, body_start):
-                    segments.append((1, flat.stream8, body0 + r0, min(body0 + r1, body_end)))
-                segments.append((1, flat.stream8, body_end, body_end))   # closes the remaining chunks
-            else:
-                segments.append((1, flat.stream8, min(body0 + body_start, body_end), body_end))
+            segments.append((1, flat.stream8, min(body0 + body_start, body_end), body_end))
     assert chunk == c1
     return lbest
 

@@ -160,40 +160,6 @@ def test_sibling_records_skip_runs_of_siblings_exactly():
     assert jumps > 10
 
 
-@pytest.mark.parametrize("seed,chunk_nodes", [(71, 9), (72, 25), (73, 4)])
-def test_summaries_of_top_level_subtrees_are_exact(seed, chunk_nodes, monkeypatch):
-    """Summary streams (ugp_flatten.cpp): work units that coincide with a run of super_chunks chunks evaluate the
-    run's top-level subtrees first and walk only the survivors.  With units of exactly that size the model takes
-    the summary path for every unit; results must equal the oracle's with loose and with tight bounds, some
-    subtrees must really be skipped by it, and the summary path must agree with the plain walk chunk by chunk."""
-    monkeypatch.setenv("UGP_LDS_SLOTS", "3")          # cold slots: some summary entries are forced survivors
-    arrays, queries = synth.make_case(seed, n_leaves=2500, n_queries=8, n_sites=300, n_ambig=(0, 0, 2), p_masked=0.02,
-                                      mut_counts=(0, 0, 1, 1, 1, 2, 3, 17))
-    flat = FlatTreeView(arrays, chunk_nodes=chunk_nodes)
-    SC = flat.super_chunks
-    assert SC == 16 and len(flat.sum8_off) == (len(flat.chunk8_body_off) - 1 + SC - 1) // SC + 1
-    n_chunks = len(flat.chunk8_body_off) - 1
-    n_units = (n_chunks + SC - 1) // SC
-    ot = capi.OracleTree(arrays)
-    skipped = 0
-    for s in queries:
-        want = ot.place(s)
-        nib, dbot = stream_interp.sample_site_alleles(flat, s)
-        for ub0 in (0x7F7F, want["best"] + 1, want["best"]):
-            st = {}
-            lb_sum, lb_plain = {}, {}
-            ub_a, ub_b = [ub0], [ub0]
-            for u in range(n_units):
-                c0, c1 = SC * u, min(SC * u + SC, n_chunks)
-                lb_sum.update(stream_interp.best8_group(flat, nib, dbot, c0, c1, ub_a, st, vrow=stream_interp.variant_rows(s), use_pre_records=False))
-                lb_plain.update(stream_interp.best8_group(flat, nib, dbot, c0, c1, ub_b, None, use_summary=False, vrow=stream_interp.variant_rows(s)))
-            assert min(lb_sum.values()) == want["best"] == min(lb_plain.values())
-            # wherever a chunk holds the optimum both walks must have found it there (phase 2 re-walks those chunks)
-            assert [c for c in range(n_chunks) if lb_sum[c] == want["best"]] == [c for c in range(n_chunks) if lb_plain[c] == want["best"]]
-            skipped += st.get("summary_skipped", 0)
-    assert skipped > len(flat.stream8)
-
-
 def _flat_arrays(arrays, **kw):
     v = FlatTreeView(arrays, **kw)
     out = {}
@@ -253,14 +219,14 @@ def test_preamble_records_skip_far_units_exactly(seed, chunk_nodes, monkeypatch)
         nib, dbot = stream_interp.sample_site_alleles(flat, s)
         v = stream_interp.variant_rows(s)
         for ub0 in (0x7F7F, want["best"] + 2, want["best"]):
-            for unit in (1, 3, 8, flat.super_chunks):   # (units of super_chunks chunks also run the summary pass behind the cut replay)
+            for unit in (1, 3, 8, 16):
                 st = {}
                 lb_pre, lb_plain = {}, {}
                 ub_a, ub_b = [ub0], [ub0]
                 for c0 in range(0, n_chunks, unit):
                     c1 = min(c0 + unit, n_chunks)
-                    lb_pre.update(stream_interp.best8_group(flat, nib, dbot, c0, c1, ub_a, st, use_summary=(unit == flat.super_chunks), vrow=v))
-                    lb_plain.update(stream_interp.best8_group(flat, nib, dbot, c0, c1, ub_b, None, use_summary=False, vrow=None, use_pre_records=False))
+                    lb_pre.update(stream_interp.best8_group(flat, nib, dbot, c0, c1, ub_a, st, vrow=v))
+                    lb_plain.update(stream_interp.best8_group(flat, nib, dbot, c0, c1, ub_b, None, vrow=None, use_pre_records=False))
                 assert min(lb_pre.values()) == want["best"] == min(lb_plain.values())
                 assert [c for c in range(n_chunks) if lb_pre[c] == want["best"]] == [c for c in range(n_chunks) if lb_plain[c] == want["best"]]
                 if ub0 == want["best"]:

@@ -257,6 +257,16 @@ def test_full_size_properties_1m_nodes(monkeypatch):
     slow = pl.place(batch)                                                          # 32-bit, one sample per lane, no pruning
     monkeypatch.delenv("UGP_FORCE_V1")
     assert (slow.view(np.int32) == fast.view(np.int32)).all()
+    # the work-unit machinery at its extremes: units that are never cut, units cut at every opportunity (thousands of
+    # entries through the shared list, every wave waiting and exiting through it), one unit per side of a tile's ring
+    for env in ({"UGP_SPLIT_CYCLES": "0"}, {"UGP_SPLIT_CYCLES": "1"}, {"UGP_SPLIT_CYCLES": "1", "UGP_UNIT_GROW": "1", "UGP_UNIT_MAX": "1000000"},
+                {"UGP_UNIT_GROW": "0", "UGP_SPLIT_CYCLES": "5000"}):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        other = pl.place(batch)
+        for k in env:
+            monkeypatch.delenv(k)
+        assert (other.view(np.int32) == fast.view(np.int32)).all(), env
     ot = capi.OracleTree(st.arrays)
     for i in range(0, 3000, 500):
         w = ot.place_mt(gsynth.csr_sample(q, i), 8)
@@ -369,13 +379,15 @@ def test_randomised_trees_and_scheduling_knobs(seed, monkeypatch):
     if rng.random() < 0.3:
         knobs["UGP_NO_BOUND2"] = "1"         # first lower bound only
     if rng.random() < 0.5:
-        knobs["UGP_UNIT_CHUNKS"] = "16"      # units that coincide with the summaries ...
-        if rng.random() < 0.7:
-            knobs["UGP_SUMMARY"] = "1"       # ... and use them
+        knobs["UGP_UNIT_CHUNKS"] = "16"
+    if rng.random() < 0.7:   # units that grow with the distance from the tile's own region, and units cut while they run
+        knobs["UGP_UNIT_GROW"] = str(int(rng.choice([0, 1, 3])))
+        knobs["UGP_UNIT_MAX"] = str(int(rng.choice([2, 40, 100000])))
+        knobs["UGP_SPLIT_CYCLES"] = str(int(rng.choice([0, 1, 3000, 400000])))   # 1: a unit is cut at every restart while anyone waits
     if rng.random() < 0.3:
         knobs["UGP_PRE_WEIGHT"] = "50"
     for k in ("UGP_COARSE_MIN_NODES", "UGP_UNIT_CHUNKS", "UGP_HEAVY_CHUNKS", "UGP_UB_EVERY", "UGP_PRUNE_MIN_WORDS", "UGP_NO_LPT", "UGP_NO_SEED",
-              "UGP_NO_SORT", "UGP_NO_PRUNE", "UGP_FORCE_V1", "UGP_LDS_SLOTS", "UGP_NO_DESCENT", "UGP_NO_BOUND2", "UGP_SUMMARY", "UGP_PRE_WEIGHT"):
+              "UGP_NO_SORT", "UGP_NO_PRUNE", "UGP_FORCE_V1", "UGP_LDS_SLOTS", "UGP_NO_DESCENT", "UGP_NO_BOUND2", "UGP_UNIT_GROW", "UGP_UNIT_MAX", "UGP_SPLIT_CYCLES", "UGP_PRE_WEIGHT"):
         monkeypatch.delenv(k, raising=False)
     for k, v in knobs.items():
         monkeypatch.setenv(k, v)

@@ -13,7 +13,7 @@ from tests import synth  # noqa: E402
 from usher_amd import Placer, QueryBatch  # noqa: E402
 
 KNOBS = ("UGP_COARSE_MIN_NODES", "UGP_UNIT_CHUNKS", "UGP_HEAVY_CHUNKS", "UGP_UB_EVERY", "UGP_PRUNE_MIN_WORDS", "UGP_NO_LPT", "UGP_NO_SEED",
-         "UGP_LDS_SLOTS", "UGP_NO_SIB", "UGP_NO_SORT", "UGP_NO_DESCENT", "UGP_NO_BOUND2", "UGP_SUMMARY", "UGP_PRE_WEIGHT")
+         "UGP_LDS_SLOTS", "UGP_NO_SIB", "UGP_NO_SORT", "UGP_NO_DESCENT", "UGP_NO_BOUND2", "UGP_SPLIT_CYCLES", "UGP_UNIT_GROW", "UGP_UNIT_MAX", "UGP_PRE_WEIGHT")
 
 
 def main():
@@ -39,9 +39,13 @@ def main():
                  "UGP_UB_EVERY": str(int(rng.choice([1, 2, 7, 1000]))), "UGP_PRUNE_MIN_WORDS": str(int(rng.choice([1, 2, 4, 8, 40]))),
                  "UGP_LDS_SLOTS": str(int(rng.integers(1, 12)))}
         if rng.random() < 0.4:
-            knobs["UGP_UNIT_CHUNKS"] = "16"   # units that coincide with the summaries
+            knobs["UGP_UNIT_CHUNKS"] = "16"
+        if rng.random() < 0.5:
+            knobs["UGP_SPLIT_CYCLES"] = str(int(rng.choice([0, 1, 2000, 400000])))
+            knobs["UGP_UNIT_GROW"] = str(int(rng.choice([0, 1, 4])))
+            knobs["UGP_UNIT_MAX"] = str(int(rng.choice([3, 64, 100000])))
         for k, p in (("UGP_NO_LPT", 0.3), ("UGP_NO_SEED", 0.2), ("UGP_NO_SIB", 0.2), ("UGP_NO_SORT", 0.1), ("UGP_NO_DESCENT", 0.3), ("UGP_NO_BOUND2", 0.2),
-                     ("UGP_SUMMARY", 0.4), ("UGP_PRE_WEIGHT", 0.2)):
+                     ("UGP_PRE_WEIGHT", 0.2)):
             if rng.random() < p:
                 knobs[k] = "1"
         os.environ.update(knobs)

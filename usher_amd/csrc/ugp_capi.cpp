@@ -80,13 +80,15 @@ struct ugp_mat {
     ugp::FlatMat flat;   // the scalars of the flattening only (counts, depths); the arrays live on the device
     uint64_t stream_dwords = 0, pre_dwords = 0;
     DevBuf<uint32_t> d_stream, d_pre, d_chunk_body, d_chunk_pre, d_chunk_node, d_rank2bfs, d_dfs2bfs;
-    DevBuf<uint32_t> d_stream8, d_pre8, d_chunk8_body, d_chunk8_pre, d_stream_t, d_chunk_t, d_sum8, d_sum8_off;
+    DevBuf<uint32_t> d_stream8, d_pre8, d_chunk8_body, d_chunk8_pre, d_stream_t, d_chunk_t;
     uint64_t stream8_dwords = 0;
     DevBuf<int32_t> d_pos2site, d_site_pos;   // position -> site, site -> position
     DevBuf<uint8_t> d_site_ref;
     // per-call workspaces (grown on demand)
     DevBuf<uint32_t> d_table, d_zero, d_part_best, d_part_cnt, d_part_key;
-    DevBuf<uint32_t> d_lbest, d_gbest, d_gbest_part, d_items, d_ub, d_gstart, d_hlen, d_cold, d_list;
+    DevBuf<uint32_t> d_lbest, d_gbest, d_gbest_part, d_items, d_ub, d_gstart, d_hlen, d_cold, d_list, d_units, d_unit_info;
+    DevBuf<uint64_t> d_dyn;
+    uint32_t dyn_epoch = 0;
     DevBuf<uint64_t> d_stats;
     uint64_t last_words_total = 0;
     const uint32_t *last_list_n = nullptr;   // (UGP_STATS) record counts of the last packed launch, per 512-sample tile
@@ -388,28 +390,66 @@ int run_place(ugp_mat *m, ugp_qset *qs, int mode, ugp_result *d_out, int32_t *d_
             m->last_list_n = d_list_n; m->last_list_tiles = n_tiles512;
             b.queue = d_queue;
             b.ub = getenv("UGP_NO_PRUNE") ? nullptr : m->d_ub.p;
+            const uint32_t *hstart = nullptr, *hlen = nullptr;
             if (sorted && !getenv("UGP_NO_LPT")) {   // hand out every tile's own region first (scheduling only)
                 HIP_TRY(m->d_gstart.reserve(n_tiles512)); HIP_TRY(m->d_hlen.reserve(n_tiles512));
                 HIP_TRY(ugp::launch_tile_ranges(m->d_keys2.p, (uint32_t)nq, n_tiles512, m->d_chunk_node.p, f.n_chunks,
                                                 std::max<uint32_t>(1, (f.n_chunks + G - 1) / G), m->d_gstart.p, m->d_hlen.p, s));
-                b.tile_hstart = m->d_gstart.p; b.tile_hlen = m->d_hlen.p;
+                hstart = m->d_gstart.p; hlen = m->d_hlen.p;
             }
-            b.unit_chunks = std::max<uint32_t>(1, (f.n_chunks + G - 1) / G);
-            // light units that coincide with the summaries of the flattening evaluate those first (k_best8)
-            // (measured on the random-attachment benchmark tree: 9 % fewer pipeline restarts, no net gain; kept behind a
-            // switch for polytomy-dominated trees, where a unit holds hundreds of top-level subtrees)
-            if (f.super_chunks && b.unit_chunks == f.super_chunks && getenv("UGP_SUMMARY")) { b.sum8 = m->d_sum8.p; b.sum8_off = m->d_sum8_off.p; }
-            b.super_chunks = std::max<uint32_t>(1, f.super_chunks);
+            const uint32_t unit_chunks = std::max<uint32_t>(1, (f.n_chunks + G - 1) / G);
             b.ub_every = 128;
             if (const char *e = getenv("UGP_UB_EVERY")) b.ub_every = (uint32_t)std::max(1, atoi(e));
             b.refill_all_rows = getenv("UGP_REFILL_ALL") ? 1u : 0u;
             b.heavy_prio = getenv("UGP_HEAVY_PRIO") ? (uint32_t)atoi(getenv("UGP_HEAVY_PRIO")) : 0u;
             // (trees with large polytomies keep the tile-after-tile order: measured, 7 % apart in either direction)
-            b.light_order = getenv("UGP_LIGHT_ORDER") ? (uint32_t)atoi(getenv("UGP_LIGHT_ORDER")) : (m->wide_descent ? 1u : 0u);
-            b.heavy_chunks = 16;
-            if (const char *e = getenv("UGP_HEAVY_CHUNKS")) b.heavy_chunks = (uint32_t)std::max(1, atoi(e));
-            HIP_TRY(m->d_stats.reserve(48));
-            if (q0 == 0) { HIP_TRY(hipMemsetAsync(m->d_stats.p, 0, 48 * sizeof(uint64_t), s)); m->last_words_total = 0; }
+            const uint32_t light_order = getenv("UGP_LIGHT_ORDER") ? (uint32_t)atoi(getenv("UGP_LIGHT_ORDER")) : (m->wide_descent ? 1u : 0u);
+            uint32_t heavy_chunks = 16;
+            if (const char *e = getenv("UGP_HEAVY_CHUNKS")) heavy_chunks = (uint32_t)std::max(1, atoi(e));
+            // Units outside the tiles' own regions grow with the distance from the region (they end in their preamble or after a
+            // few jumps: what they cost is the replay, not their length) -- only when there is a region to measure from and bounds
+            // to prune with.
+            uint32_t grow_every = (hstart && b.ub) ? 4u : 0u, unit_max = unit_chunks * 16u;
+            if (const char *e = getenv("UGP_UNIT_GROW")) grow_every = (hstart && b.ub) ? (uint32_t)std::max(0, atoi(e)) : 0u;
+            if (const char *e = getenv("UGP_UNIT_MAX")) unit_max = (uint32_t)std::max(1, atoi(e));
+            // A preamble record says where the body goes on behind a path node's subtree in INFO_JUMP_MASK's 18 bits, the largest
+            // value meaning "beyond the unit": no unit may be longer than that many words.  (Should even the basic units be --
+            // chunks of thousands of words: nodes with thousands of mutations -- the replay runs without those records.)
+            {
+                const uint64_t reach = ugp::INFO_JUMP_MASK - 1u, cw = std::max<uint32_t>(1, f.max_chunk8_words);
+                unit_max = (uint32_t)std::max<uint64_t>(unit_chunks, std::min<uint64_t>(unit_max, reach / cw));
+                b.no_pre_records = ((uint64_t)std::max(unit_chunks, heavy_chunks) * cw > reach) ? 1u : 0u;
+            }
+            {
+                auto len_of = [&](uint32_t i) -> uint64_t {
+                    if (!grow_every) return unit_chunks;
+                    return std::min<uint64_t>((uint64_t)unit_chunks << std::min<uint32_t>(i / grow_every, 16u), std::max(unit_max, unit_chunks));
+                };
+                uint32_t n_side = 0;
+                for (uint64_t done = 0; done < f.n_chunks; n_side++) done += len_of(n_side);
+                const uint32_t per_tile_cap = (f.n_chunks + heavy_chunks - 1) / heavy_chunks + 2u * n_side + 2u;
+                HIP_TRY(m->d_units.reserve((size_t)n_tiles512 * per_tile_cap * 4));
+                HIP_TRY(m->d_unit_info.reserve(32 + 96));
+                // units that run long are cut while they run: the shared list of split-off halves (k_best8)
+                uint32_t split_cycles = 400000, split_heavy = 400000;
+                if (const char *e = getenv("UGP_SPLIT_CYCLES")) split_cycles = split_heavy = (uint32_t)std::max(0, atoi(e));
+                if (const char *e = getenv("UGP_SPLIT_HEAVY")) split_heavy = (uint32_t)std::max(0, atoi(e));
+                if (!split_heavy) split_heavy = 0xFFFFFFFFu;
+                if (!split_cycles || f.n_chunks >= (1u << 20) || n_tiles512 > 4096) split_cycles = split_heavy = 0xFFFFFFFFu;   // (never; the entry's fields)
+                constexpr uint32_t kDynCap = 1u << 17;
+                if (!m->d_dyn.p) {
+                    HIP_TRY(m->d_dyn.reserve(kDynCap));
+                    m->dyn_epoch = 2047;
+                }
+                if (++m->dyn_epoch >= 2048u) { HIP_TRY(hipMemsetAsync(m->d_dyn.p, 0, (size_t)kDynCap * 8, s)); m->dyn_epoch = 1; }   // (11 bits: stale entries never alias)
+                uint32_t *dyn_ctl = m->d_unit_info.p + 32;
+                b.dyn_ctl = dyn_ctl; b.dyn_units = (unsigned long long *)m->d_dyn.p; b.dyn_cap = kDynCap; b.dyn_epoch = m->dyn_epoch; b.split_cycles = split_cycles; b.split_heavy = split_heavy;
+                HIP_TRY(ugp::launch_build_units(hstart, hlen, n_tiles512, f.n_chunks, unit_chunks, heavy_chunks, grow_every, unit_max, light_order, per_tile_cap,
+                                                m->d_units.p, m->d_unit_info.p, m->d_unit_info.p + 8, dyn_ctl, s));
+                b.units = (const uint4 *)m->d_units.p; b.unit_base = m->d_unit_info.p; b.unit_count = m->d_unit_info.p + 8;
+            }
+            HIP_TRY(m->d_stats.reserve(64));
+            if (q0 == 0) { HIP_TRY(hipMemsetAsync(m->d_stats.p, 0, 64 * sizeof(uint64_t), s)); m->last_words_total = 0; }
             b.stats = getenv("UGP_STATS") ? m->d_stats.p : nullptr;   // the counters are two contended atomics per skip: debug only
             m->last_words_total += (uint64_t)n_tiles512 * m->stream8_dwords;
             b.max_slots = f.max_slots;
@@ -586,7 +626,7 @@ static int upload_flat(const HostFlat &hf, int device, ugp_mat **out) {
     {   // scalars
         auto &g = m->flat;
         g.n_nodes = f.n_nodes; g.n_muts = f.n_muts; g.n_sites = f.n_sites; g.max_pos = f.max_pos; g.max_slots = f.max_slots;
-        g.n_chunks = f.n_chunks; g.max_path_muts = f.max_path_muts; g.mask_not_first = f.mask_not_first; g.lds_slots = f.lds_slots; g.super_chunks = f.super_chunks;
+        g.n_chunks = f.n_chunks; g.max_path_muts = f.max_path_muts; g.max_chunk8_words = f.max_chunk8_words; g.mask_not_first = f.mask_not_first; g.lds_slots = f.lds_slots;
     }
     if ((e = m->d_stream.upload(f.stream)) != hipSuccess) return bail(e, "upload stream");
     if ((e = m->d_pre.upload(f.pre_stream)) != hipSuccess) return bail(e, "upload preambles");
@@ -610,8 +650,6 @@ static int upload_flat(const HostFlat &hf, int device, ugp_mat **out) {
     if ((e = m->d_pre8.upload(f.pre8_stream)) != hipSuccess) return bail(e, "upload packed preambles");
     if ((e = m->d_chunk8_body.upload(f.chunk8_body_off)) != hipSuccess) return bail(e, "upload chunk table");
     if ((e = m->d_chunk8_pre.upload(f.chunk8_pre_off)) != hipSuccess) return bail(e, "upload chunk table");
-    if ((e = m->d_sum8.upload(f.sum8)) != hipSuccess) return bail(e, "upload summaries");
-    if ((e = m->d_sum8_off.upload(f.sum8_off)) != hipSuccess) return bail(e, "upload summaries");
     if ((e = m->d_stream_t.upload(f.stream_t)) != hipSuccess) return bail(e, "upload tie stream");
     if ((e = m->d_chunk_t.upload(f.chunk_t_off)) != hipSuccess) return bail(e, "upload chunk table");
     m->stream8_dwords = f.stream8.size();
@@ -639,7 +677,6 @@ static ugp::Options default_options() {
     if (getenv("UGP_NO_SIB")) opt.sibling_records = false;
     if (const char *e = getenv("UGP_LDS_SLOTS")) opt.lds_slots = (uint32_t)std::max(1, std::min(60, atoi(e)));
     if (const char *e = getenv("UGP_PRE_WEIGHT")) opt.pre_weight = (uint32_t)std::max(0, atoi(e));
-    if (const char *e = getenv("UGP_UNIT_CHUNKS")) opt.super_chunks = (uint32_t)std::max(1, atoi(e));   // summaries follow the light units
     return opt;
 }
 
@@ -1091,7 +1128,7 @@ int ugp_get_timing(ugp_mat *m, ugp_timing *out) {
         m->last.words_total = m->last_words_total;
         m->last.words_skipped = 0;
         if (m->last_used_best8 && m->d_stats.p) {
-            uint64_t v[48] = {0};
+            uint64_t v[64] = {0};
             HIP_TRY(hipMemcpy(v, m->d_stats.p, sizeof v, hipMemcpyDeviceToHost));
             m->last.words_skipped = v[0];
             m->last.reserved = (uint32_t)std::min<uint64_t>(v[1], 0xFFFFFFFFull);   // pipeline (re)starts
@@ -1106,6 +1143,13 @@ int ugp_get_timing(ugp_mat *m, ugp_timing *out) {
                                 "nothing %llu (cycles %llu)\n[ugp stats] units skipped whole: cycles pulling %llu, replaying the preamble %llu, closing %llu\n", (unsigned long long)v[32], (unsigned long long)v[33],
                         (unsigned long long)v[34], (unsigned long long)v[35], (unsigned long long)v[36], (unsigned long long)v[37], (unsigned long long)v[38],
                         (unsigned long long)v[39], (unsigned long long)v[40]);
+                fprintf(stderr, "[ugp stats] restarts by cause (own-region / other units): jump %llu / %llu, sibling jump %llu / %llu, chunk end %llu / %llu, slow header %llu / %llu\n",
+                        (unsigned long long)v[48], (unsigned long long)v[49], (unsigned long long)v[50], (unsigned long long)v[51], (unsigned long long)v[52],
+                        (unsigned long long)v[53], (unsigned long long)v[54], (unsigned long long)v[55]);
+                fprintf(stderr, "[ugp stats] units split while running: %llu\n", (unsigned long long)v[31]);
+                fprintf(stderr, "[ugp stats] jump lengths in words (<8 <16 <32 <64 <128 <512 <4096 more):");
+                for (int i = 0; i < 8; i++) fprintf(stderr, " %llu", (unsigned long long)v[56 + i]);
+                fprintf(stderr, "\n");
                 if (m->last_list_n && m->last_list_tiles) {
                     std::vector<uint32_t> ln(m->last_list_tiles);
                     HIP_TRY(hipMemcpy(ln.data(), m->last_list_n, ln.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
@@ -1178,9 +1222,6 @@ int ugp_flat_get(const ugp_flat *fl, int which, const void **ptr, uint64_t *coun
         case UGP_FLAT_CHUNK_T_OFF: *ptr = f.chunk_t_off.data(); *count = f.chunk_t_off.size(); break;
         case UGP_FLAT_MAX_PATH_MUTS: *ptr = nullptr; *count = f.max_path_muts; break;
         case UGP_FLAT_LDS_SLOTS: *ptr = nullptr; *count = f.lds_slots; break;
-        case UGP_FLAT_SUM8: *ptr = f.sum8.data(); *count = f.sum8.size(); break;
-        case UGP_FLAT_SUM8_OFF: *ptr = f.sum8_off.data(); *count = f.sum8_off.size(); break;
-        case UGP_FLAT_SUPER_CHUNKS: *ptr = nullptr; *count = f.super_chunks; break;
         default: return fail(UGP_ERR_INVALID, "unknown array id");
     }
     return UGP_OK;

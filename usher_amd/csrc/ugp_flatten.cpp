@@ -475,7 +475,9 @@ int flatten(const ugp_tree_desc &t, const Options &opt, FlatMat &out, std::strin
         const uint32_t nwords = rec[0] & 0xFFFFu;
         const bool root = (j == 0);
         const uint32_t nch = child_off[j + 1] - child_off[j];
-        const uint32_t rslot = root ? RS_BOTTOM : ((preamble || first_eff[j]) ? RS_REG : slot[t.parent[j]]);
+        // (the root reads "the previous node's D" too: k_best8 starts every unit with D = D(bottom), and the root is the
+        // first record of any unit that contains or replays it)
+        const uint32_t rslot = (root || preamble || first_eff[j]) ? RS_REG : slot[t.parent[j]];
         const uint32_t wslot = (eff_children[j] >= 2) ? slot[j] : WS_NONE;
         uint32_t h = H_TAG | rslot | (wslot << 6);
         if (eff_children[j] == 0 && !root) h |= E_SKIPD;
@@ -551,6 +553,8 @@ int flatten(const ugp_tree_desc &t, const Options &opt, FlatMat &out, std::strin
     const uint64_t total8 = par.exclusive_scan(out.chunk8_body_off.data(), NC);
     if (total8 >= (1ull << 32)) { err = "tree too large: the packed stream exceeds 2^32 words"; return UGP_ERR_UNSUPPORTED; }
     out.chunk8_body_off[NC] = (uint32_t)total8;
+    out.max_chunk8_words = 0;
+    for (uint32_t c = 0; c < NC; c++) out.max_chunk8_words = std::max(out.max_chunk8_words, out.chunk8_body_off[c + 1] - out.chunk8_body_off[c]);
     pos8_at[N] = (uint32_t)total8;
     par.run(NC, [&](uint64_t b, uint64_t e, unsigned) {
         for (uint64_t c = b; c < e; c++) {
@@ -718,7 +722,6 @@ int flatten(const ugp_tree_desc &t, const Options &opt, FlatMat &out, std::strin
                     uint32_t h = H_TAG;
                     bool slow = false;
                     if (rs == RS_REG) h |= H_REG;
-                    else if (rs == RS_BOTTOM) { h |= H_BOTTOM; slow = true; }
                     else { rs = remap[rs]; h |= rs << H_RSLOT_SHIFT; slow |= rs >= hot; }
                     if (ws != WS_NONE) { ws = remap[ws]; h |= H_STORE | (ws << H_WSLOT_SHIFT); slow |= ws >= hot; }
                     if (w & E_SKIPD) h |= H_SKIPD;
@@ -732,60 +735,17 @@ int flatten(const ugp_tree_desc &t, const Options &opt, FlatMat &out, std::strin
         };
         finalize8(out.stream8);
         finalize8(out.pre8_stream);
+        // every chunk-end word names the length of the chunk behind it (its own end word included; 0: does not fit / none):
+        // the walk always knows where the open chunk ends without a table lookup
+        par.run(NC, [&](uint64_t b, uint64_t e, unsigned) {
+            for (uint64_t c = b; c < e; c++) {
+                const uint64_t ln = c + 1 < NC ? (uint64_t)out.chunk8_body_off[c + 2] - out.chunk8_body_off[c + 1] : 0;
+                out.stream8[out.chunk8_body_off[c + 1] - 1] |= (ln <= CE_LEN_MASK ? (uint32_t)ln : 0u) << CE_LEN_SHIFT;
+            }
+        }, 1u << 12);
     }
     flat_lap("slot renumbering");
 
-    // ---- summaries: the top-level subtrees of every run of super_chunks chunks, as one dense stream ----------
-    // Seen from the first node f of such a run, every later node of the run lies in the subtree of f, of a later
-    // sibling of f, or of a later sibling of one of f's ancestors: the "top-level" nodes, whose parents are on the
-    // root path of f (their D is in the slots once the preamble has been replayed).  The summary lists them back
-    // to back ({SUM_A, SUM_B, header copy, mutation words} each) so they can be evaluated in the pipelined loop
-    // without a restart; only the survivors' subtrees are then walked in the main stream (opt-in, UGP_SUMMARY).
-    {
-        out.super_chunks = std::max<uint32_t>(1, opt.super_chunks);
-        const uint32_t SC = out.super_chunks;
-        const uint32_t n_units = (NC + SC - 1) / SC;
-        out.sum8_off.assign(n_units + 1, 0);
-        auto walk_unit = [&](uint32_t u, uint32_t *dst) -> uint32_t {   // dst == nullptr: count only
-            const uint32_t c0 = u * SC, c1 = std::min<uint32_t>(NC, c0 + SC);
-            const uint32_t base = out.chunk8_body_off[c0], body_end = out.chunk8_body_off[c1];
-            const uint32_t d_end = cno[c1];
-            uint32_t n = 0;
-            for (uint32_t d = cno[c0]; d < d_end;) {
-                const uint32_t j = d2b[d];
-                const uint32_t d_next = (uint32_t)std::min<uint64_t>((uint64_t)d + sub[j], d_end);
-                if (!dropped[j]) {
-                    const uint32_t hpos = pos8_hdr[d];
-                    // the end of the subtree inside this run (a subtree that reaches beyond it ends with the run)
-                    const uint32_t end_pos = ((uint64_t)d + sub[j] >= d_end ? body_end : pos8_at[d_next]) - base;
-                    const bool forced = hsub[j] > INFO_HS_MAX || nw[j] >= 15 || nw[j] > SUM_W_MAX;   // (no test: always walked)
-                    if (dst) {
-                        uint32_t h = out.stream8[hpos] & ~H_STORE;
-                        if (forced) h |= H_END;
-                        dst[n] = SUM_A | (std::min<uint32_t>(hsub[j], INFO_HS_MAX) << INFO_HS_SHIFT) | (std::min<uint32_t>(hrev[j], INFO_HR_NONE) << SUM_HR_SHIFT) |
-                                 (pos8_start[d] - base);
-                        dst[n + 1] = SUM_B | (forced ? SUM_FORCED : 0u) | (std::min<uint32_t>(nw[j], SUM_W_MAX) << SUM_W_SHIFT) | end_pos;
-                        dst[n + 2] = h;
-                        if (!forced) for (uint32_t k = 0; k < nw[j]; k++) dst[n + 3 + k] = out.stream8[hpos + 1 + k];
-                    }
-                    n += 3u + (forced ? 0u : nw[j]);
-                }
-                d = d_next;
-            }
-            return n;
-        };
-        bool fits = true;   // every position of a run has to fit SUM_A's field
-        for (uint32_t u = 0; u < n_units; u++)
-            fits = fits && out.chunk8_body_off[std::min<uint32_t>(NC, (u + 1) * SC)] - out.chunk8_body_off[u * SC] <= SUM_A_POS_MASK;
-        if (!fits) { out.super_chunks = 0; out.sum8.clear(); out.sum8_off.assign(1, 0); }
-        else {
-            par.run(n_units, [&](uint64_t b, uint64_t e, unsigned) { for (uint64_t u = b; u < e; u++) out.sum8_off[u] = walk_unit((uint32_t)u, nullptr); }, 16);
-            out.sum8.resize(par.exclusive_scan(out.sum8_off.data(), n_units));
-            out.sum8_off[n_units] = (uint32_t)out.sum8.size();
-            par.run(n_units, [&](uint64_t b, uint64_t e, unsigned) { for (uint64_t u = b; u < e; u++) walk_unit((uint32_t)u, out.sum8.data() + out.sum8_off[u]); }, 16);
-        }
-    }
-    flat_lap("summaries");
     if (extras) {
         extras->node_pair.clear();
         if (bfs_levels) {

@@ -60,9 +60,9 @@ constexpr uint32_t T_PRUNE_MIN_DWORDS = 24;  // subtrees shorter than this are n
 //       H_FREE    every sample is eligible (internal node without mutations)
 //       H_SKIPD   D(node) is not needed (no effective children); informational -- computing it anyway is harmless
 //       H_RARE    the word leaves the fast path: a pruning record, a chunk end, padding, or a header that
-//                 needs the general code (H_SLOW: one of its slots is not among the LDS-resident ones, or
-//                 H_BOTTOM: the root, whose D(parent) is D_bottom)
-//       H_CHUNK_END (with H_RARE) closes a chunk: publish the chunk-local minimum and reset
+//                 needs the general code (H_SLOW: one of its slots is not among the LDS-resident ones)
+//       H_CHUNK_END (with H_RARE) closes a chunk: publish the chunk-local minimum and reset;
+//                 [28:10] = words of the chunk that follows, its own end word included (0: none / does not fit)
 //       H_NOP     (with H_RARE) padding
 //       H_INFO    (with H_RARE, in front of the header of a node with a large subtree) pruning record:
 //                 [17:0] jump = stream words occupied by the node's descendants,
@@ -85,17 +85,19 @@ constexpr uint32_t T_PRUNE_MIN_DWORDS = 24;  // subtrees shorter than this are n
 //                 those subtrees has cost(d) >= D(p) - min(hs, V_s + hr), so when that exceeds the upper bound of
 //                 best(s) for all s they are all skipped with one jump.  The non-last children are emitted in
 //                 descending order of hs, so hs only shrinks.
-//     The root is emitted as two records: its D record (H_BOTTOM, H_NOSCORE) followed by a scoring
-//     pseudo-node (H_REG | H_SKIPD | H_FREE | H_END) whose cost is D(parent) = D(root): cost(root) = D(root),
-//     always eligible (usher_mapper.cpp:454).
+//     The root is emitted as two records: its D record (H_REG, H_NOSCORE: "the previous node's D" is D_bottom, which
+//     k_best8 loads at the start of every work unit -- the root is the first record of any unit that contains or
+//     replays it) followed by a scoring pseudo-node (H_REG | H_SKIPD | H_FREE | H_END) whose cost is D(parent) =
+//     D(root): cost(root) = D(root), always eligible (usher_mapper.cpp:454).
 //   MUT word (bit 31 clear):
 //       [21:0] site  [23:22] mutated allele  [25:24] parent-state allele  [27:26] reference allele
 //       M_FLUSH  15 mutations accumulated in the 4-bit counters: spill them
 //       M_END    last mutation word of the node
 constexpr uint32_t H_TAG = 1u << 31, H_INFO = 1u << 30, H_RARE = 1u << 29, H_SIB = 1u << 21;
 constexpr uint32_t H_REG = 1u << 0, H_STORE = 1u << 1, H_NOSCORE = 1u << 2, H_END = 1u << 3, H_FREE = 1u << 4,
-                   H_SKIPD = 1u << 5, H_BOTTOM = 1u << 6, H_SLOW = 1u << 7, H_CHUNK_END = 1u << 8, H_NOP = 1u << 9;
+                   H_SKIPD = 1u << 5, /* bit 6: unused */ H_SLOW = 1u << 7, H_CHUNK_END = 1u << 8, H_NOP = 1u << 9;
 constexpr uint32_t H_RSLOT_SHIFT = 10, H_WSLOT_SHIFT = 20;
+constexpr uint32_t CE_LEN_SHIFT = 10, CE_LEN_MASK = (1u << 19) - 1u;   // chunk-end word: length of the next chunk
 constexpr uint32_t INFO_JUMP_MASK = (1u << 18) - 1u, INFO_HS_SHIFT = 22, INFO_HS_MAX = 127;
 constexpr uint32_t INFO_HR_SHIFT = 18, INFO_HR_NONE = 7;   // hrev field; 7 = not available (more than 6 reversions on some path)
 // Preamble copies (pre8) carry a pruning record too, in front of every path node below the root: same hs / hr fields
@@ -103,16 +105,6 @@ constexpr uint32_t INFO_HR_SHIFT = 18, INFO_HR_NONE = 7;   // hrev field; 7 = no
 // the chunk's first body word, where the body goes on behind that node's subtree (INFO_JUMP_MASK = beyond any unit).
 // When the record's test holds during the replay, the rest of the preamble and the body up to that position are skipped.
 constexpr uint32_t PRE_HS_NONE = 127;
-// summary stream ("sum8", see ugp_flatten.cpp): per top-level subtree of a run of super_chunks chunks
-//   SUM_A  [28:22] hsub of the node (capped)   [21:19] hrev (INFO_HR_NONE: not available)   [18:0] position of the node's first word (pruning record or header,
-//          behind a sibling record) in the packed stream, relative to the run's first body word
-//   SUM_B  SUM_FORCED: no test, the subtree is always walked   [27:22] mutation words of the node   [21:0] position
-//          behind the subtree (relative, capped at the end of the run)
-//   a copy of the node's header without H_STORE (H_END when forced), then its mutation words (unless forced)
-constexpr uint32_t SUM_A = H_TAG | H_INFO | H_RARE, SUM_B = H_TAG | H_INFO, SUM_FORCED = 1u << 28;   // (B: H_INFO without H_RARE)
-constexpr uint32_t SUM_W_SHIFT = 22, SUM_W_MAX = 63, SUM_POS_MASK = (1u << 22) - 1u;
-constexpr uint32_t SUM_A_POS_MASK = (1u << 19) - 1u, SUM_HR_SHIFT = 19;   // (a run longer than 2^19 words: no summaries at all, super_chunks = 0)
-constexpr uint32_t SUPER_CHUNKS = 16;       // chunks per summary (= the light work units of k_best8)
 constexpr uint32_t PRUNE_MIN_WORDS = 4;     // only subtrees at least this long carry a pruning record
 constexpr uint32_t LDS_SLOTS = 9;           // saved-D slots k_best8 keeps in LDS (1 KB each per wave); the colder ones live in a global scratch
 constexpr uint32_t M_FLUSH = 1u << 28, M_END = 1u << 30;
@@ -124,7 +116,6 @@ struct Options {
     uint32_t prune_min_words = PRUNE_MIN_WORDS;   // subtrees at least this long (stream words) carry a pruning record
     bool sibling_records = true;   // emit H_INFO | H_SIB records
     uint32_t lds_slots = LDS_SLOTS; // headers whose (renumbered) slots are >= this are flagged H_SLOW
-    uint32_t super_chunks = SUPER_CHUNKS;   // chunks per summary
     uint32_t pre_weight = 32;   // weight of the preambles' slot accesses when the hot (LDS) slots are chosen: every unit replays one,
                                 // the body is mostly skipped (0: body counts only)
     uint32_t threads = 0;       // host threads (0 = UGP_FLATTEN_THREADS, else min(32, hardware threads)); the output does not depend on it
@@ -156,14 +147,13 @@ struct FlatMat {
     // packed stream for k_best8 (same chunk cut points, by DFS node index)
     UVec<uint32_t> stream8, pre8_stream;
     std::vector<uint32_t> chunk8_body_off, chunk8_pre_off;   // [n_chunks+1]
-    UVec<uint32_t> sum8, sum8_off;  // summaries: words, [ceil(n_chunks / super_chunks) + 1] offsets
-    uint32_t super_chunks = 0;
     // Tie stream (phase 2): the chunk bodies of `stream` without the leaves that can never be eligible and
     // with pruning pseudo-records {w0 = T_INFO_MARK, w1 = hsub << 24 | jump}: the node that follows may be
     // skipped together with its descendants (`jump` dwords behind its own record, inside the chunk)
     // when D(node) - hsub exceeds the wanted score of every sample that still looks for ties here.
     UVec<uint32_t> stream_t, chunk_t_off;             // chunk_t_off: [n_chunks+1]
     uint32_t max_path_muts = 0;            // max over nodes of the mutation count on the root path
+    uint32_t max_chunk8_words = 0;         // longest chunk of the packed stream (a work unit must stay below the reach of a preamble record's jump field)
     uint32_t lds_slots = 0;                // the Options value the packed stream was encoded for (<= max_slots)
     bool mask_not_first = false;           // some non-root node lists a masked mutation behind an ordinary one: only the
                                            // 32-bit walk (M_AFTER_MASK) scores such a node the way usher_mapper.cpp:190-270 does

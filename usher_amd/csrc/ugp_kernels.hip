@@ -583,6 +583,8 @@ struct Pk4 { uint32_t v[4]; };
 #define UGP_GRP 8
 #endif
 constexpr uint32_t GRP = UGP_GRP;   // stream words per pipeline group (= unroll factor of the walk)
+constexpr uint32_t DYN_HEAD = 0, DYN_TAIL = 1, DYN_ACTIVE = 32;   // dyn_ctl: tickets taken / entries pushed (one line), live work (another)
+constexpr unsigned long long DYN_EXIT = (1ull << 53) - 1ull;              // entry payload "no more work" (tile, c0, c1, flag bits all set)
 constexpr uint32_t CONST_ROWS = TABLE_CONST_ROWS;  // rows 0..3 of every tile's table: all samples carry A / C / G / T
 
 __device__ __forceinline__ uint32_t ex4(uint32_t acc, int j) { return (acc >> (4 * j)) & 0x000F000Fu; }
@@ -605,6 +607,9 @@ __global__ void __launch_bounds__(64, 5) k_best8(Best8Args a) {
     // by >10x and the in-order, round-robin-per-XCD workgroup dispatcher stalls behind the slow XCD.
     const uint32_t home = blockIdx.x & 7u;
     uint32_t drained = 0;   // bit x: queue x is known to be empty
+    // (dyn_ctl[DYN_ACTIVE] counts the waves that have started and are not waiting: a block that has not been scheduled yet -- the
+    // device may be shared with another launch -- must never be waited for)
+    if (lane == 0) atomicAdd(a.dyn_ctl + DYN_ACTIVE, 1u);
     // Upper bounds (+1) of the tile this wave worked on last, kept across units: the shared copy is read and
     // written with agent-scope accesses that leave the XCD, ~40 us of wave time per exchange, so it is
     // consulted when the wave moves to another tile and every a.ub_every chunk ends, not at every chunk end.
@@ -617,69 +622,77 @@ __global__ void __launch_bounds__(64, 5) k_best8(Best8Args a) {
     const uint64_t t_pull0 = STATS ? __builtin_amdgcn_s_memtime() : 0;
     uint32_t tile = 0, c0 = 0, c1 = 0;   // the unit: chunks [c0, c1) of the stream for one tile
     bool unit_heavy = false;             // (STATS) the unit lies in the tile's own region
+    uint32_t uflags = 2u;   // bit 0: the unit lies in its tile's own region; bit 1: nothing left (exit)
     {
-        // Units of a tile.  Its own region H = [h0, h0 + hl) (the chunks its samples sit in, from the
-        // locality sort; hl = 0 without it) cannot be pruned and is dense work: a.heavy_chunks chunks per unit, and
-        // the queue hands out every tile's H first (longest first).  The rest of the ring, A = [h0 + hl,
-        // n_chunks) and B = [0, h0), is mostly jumped over: a.unit_chunks chunks per unit, which amortises
-        // the preamble replay.
-        const uint32_t U = a.unit_chunks;
-        bool got = false;
-        for (uint32_t t = 0; t < 8 && !got; t++) {
+        // The units of queue x are listed in a.units (k_build_units: every tile's own region first, then the rest of the ring
+        // nearest first); a ticket from the queue's counter names one.
+        // (every value read here goes through readfirstlane: a condition on a per-lane value is formally divergent)
+        auto uload = [&](const uint32_t *p_) -> uint32_t {
+            return (uint32_t)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(p_, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        };
+        for (uint32_t t = 0; t < 8 && (uflags & 2u); t++) {
             const uint32_t x = (home + t) & 7u;
             if (drained & (1u << x)) continue;
-            const uint32_t tlo = x * a.n_tiles / 8u, thi = (x + 1u) * a.n_tiles / 8u;
-            const uint32_t HU = a.heavy_chunks;
-            // Light units are handed out nearest first: rank k of every tile of the queue before rank k + 1 of any, and within
-            // a tile alternating between the chunks behind its own region (A, ascending) and in front of it (B, descending).
-            // The units next to the own region are the ones pruning helps least; handed out last (B used to run towards
-            // the region) they were the tail of the kernel.
-            // (a.light_order 1: one tile after the other instead, each nearest first -- keeps a tile's rows in L2)
-            uint32_t heavy = 0, max_light = 0, sum_light = 0;
-            for (uint32_t tt = tlo; tt < thi; tt++) {
-                const uint32_t h0 = a.tile_hstart ? a.tile_hstart[tt] : 0u, hl = a.tile_hstart ? a.tile_hlen[tt] : 0u;
-                heavy += (hl + HU - 1u) / HU;
-                const uint32_t nl = (a.n_chunks - h0 - hl + U - 1u) / U + (h0 + U - 1u) / U;
-                max_light = max(max_light, nl); sum_light += nl;
-            }
-            const uint32_t ux = heavy + (a.light_order == 1u ? sum_light : max_light * (thi - tlo));
+            const uint32_t ux = a.unit_count[x];
             uint32_t v = 0xFFFFFFFFu;
             if (ux) {
                 if (lane == 0) v = atomicAdd(&a.queue[x], 1u);
                 v = (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
             }
             if (v >= ux) { drained |= 1u << x; continue; }
-            got = true;
-            unit_heavy = v < heavy;
-            if (v < heavy) {
-                uint32_t tt = tlo, r = v;
-                while (r >= (a.tile_hlen[tt] + HU - 1u) / HU) { r -= (a.tile_hlen[tt] + HU - 1u) / HU; tt++; }
-                tile = tt; c0 = a.tile_hstart[tt] + r * HU; c1 = min(c0 + HU, a.tile_hstart[tt] + a.tile_hlen[tt]);
-            } else {
-                const uint32_t T = thi - tlo;
-                uint32_t k = (v - heavy) / T, tt = tlo + (v - heavy) % T;
-                if (a.light_order == 1u) {   // tile-major
-                    k = v - heavy;
-                    for (tt = tlo;; tt++) {
-                        const uint32_t h0 = a.tile_hstart ? a.tile_hstart[tt] : 0u, hl = a.tile_hstart ? a.tile_hlen[tt] : 0u;
-                        const uint32_t nl = (a.n_chunks - h0 - hl + U - 1u) / U + (h0 + U - 1u) / U;
-                        if (k < nl) break;
-                        k -= nl;
+            const uint4 d = a.units[(uint64_t)a.unit_base[x] + v];
+            tile = (uint32_t)__builtin_amdgcn_readfirstlane((int)d.x);
+            c0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)d.y);
+            c1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)d.z);
+            uflags = (uint32_t)__builtin_amdgcn_readfirstlane((int)d.w) & 1u;
+        }
+        // Static lists drained: the shared list of split-off units (see the split in the restart path below).  Tickets, not
+        // races: a wave takes the next ticket h (one atomic) and waits for entry h -- its own word, so the waiting waves never
+        // crowd one address (a compare-and-swap pop did: every push woke thousands of waves into one retry loop).
+        // dyn_ctl[DYN_ACTIVE] counts running waves plus entries pushed but not yet finished; the wave that brings it to zero
+        // knows that nothing can be pushed any more and writes an exit mark into the entries of all tickets that are or may
+        // still be waiting.  (Which wave runs an entry never matters to the results.)
+        if (uflags & 2u) {
+            uint32_t last = 0;
+            if (lane == 0) last = atomicAdd(a.dyn_ctl + DYN_ACTIVE, 0xFFFFFFFFu);   // this wave stops running ...
+            last = (uint32_t)__builtin_amdgcn_readfirstlane((int)last);
+            if (last == 1u) {   // ... and was the last thing alive: release every waiter, present and future (at most one more ticket per block)
+                const uint32_t tl = uload(a.dyn_ctl + DYN_TAIL);
+                const unsigned long long bye = ((unsigned long long)a.dyn_epoch << 53) | DYN_EXIT;
+                for (uint32_t i = tl + lane; i < min(tl + gridDim.x + 64u, a.dyn_cap); i += 64u)
+                    __hip_atomic_store(a.dyn_units + i, bye, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            uint32_t h = 0;
+            if (lane == 0) h = atomicAdd(a.dyn_ctl + DYN_HEAD, 1u);
+            h = (uint32_t)__builtin_amdgcn_readfirstlane((int)h);
+            if (h < a.dyn_cap) {
+                // An entry is ONE 64-bit word {epoch:11 | own region:1 | tile:12 | c1:20 | c0:20}, written and read with single
+                // relaxed agent-scope accesses: nothing to order, hence no acquire / release (on this multi-die part those
+                // write back or invalidate a die's whole L2).
+                uint32_t naps = 1;
+                for (;;) {
+                    const unsigned long long ev = __hip_atomic_load(a.dyn_units + h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)ev), hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(ev >> 32));
+                    if ((hi >> 21) == a.dyn_epoch) {
+                        if ((hi & 0x1FFFFFu) != 0x1FFFFFu || lo != 0xFFFFFFFFu) {   // a unit (else: the exit mark)
+                            c0 = lo & 0xFFFFFu; c1 = (lo >> 20) | ((hi & 0xFFu) << 12); tile = (hi >> 8) & 0xFFFu;
+                            uflags = (hi >> 20) & 1u;
+                        }
+                        break;
                     }
+                    for (uint32_t i = 0; i < naps; i++) __builtin_amdgcn_s_sleep(127);   // ~3.4 us each
+                    naps = min(naps + 1u, 3u);
                 }
-                const uint32_t h0 = a.tile_hstart ? a.tile_hstart[tt] : 0u, hl = a.tile_hstart ? a.tile_hlen[tt] : 0u;
-                const uint32_t nA = (a.n_chunks - h0 - hl + U - 1u) / U, nB = (h0 + U - 1u) / U, m = min(nA, nB);
-                uint32_t ia = 0xFFFFFFFFu, ib = 0xFFFFFFFFu;   // index into A (ascending from the region) / B (descending towards chunk 0)
-                if (k < 2u * m) { if (k & 1u) ib = k >> 1; else ia = k >> 1; }
-                else if (k < nA + nB) { if (nA > nB) ia = k - m; else ib = k - m; }
-                if (ia != 0xFFFFFFFFu) { c0 = h0 + hl + ia * U; c1 = min(c0 + U, a.n_chunks); }
-                else if (ib != 0xFFFFFFFFu) { const uint32_t j = nB - 1u - ib; c0 = j * U; c1 = min(c0 + U, h0); }
-                else { c0 = 0; c1 = 0; }   // this tile has fewer light units than the longest of the queue: nothing to do
-                tile = tt;
             }
         }
-        if (!got) return;
     }
+    // (opaque to the optimizer: without it the paths above are threaded through the whole unit body -- the kernel doubled in
+    // size and spilled its pipelined loop)
+    tile = (uint32_t)__builtin_amdgcn_readfirstlane((int)tile); c0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)c0);
+    c1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)c1); uflags = (uint32_t)__builtin_amdgcn_readfirstlane((int)uflags);
+    asm volatile("" : "+s"(tile), "+s"(c0), "+s"(c1), "+s"(uflags));
+    if (uflags & 2u) return;
+    unit_heavy = (uflags & 1u) != 0;
     if (c0 >= c1) continue;
     // The dense units of the tiles' own regions are the kernel's critical path (one wave walks ~10k words; everything else
     // fits beside them): their waves get the SIMD's issue slots first, the far units run in the gaps.
@@ -710,11 +723,17 @@ __global__ void __launch_bounds__(64, 5) k_best8(Best8Args a) {
     };
     Pk4 best, dcur, dpar, carryD, carryN, carryC;
 #pragma unroll
-    for (int j = 0; j < 4; j++) { best.v[j] = 0xFFFFFFFFu; dcur.v[j] = 0; dpar.v[j] = 0; carryD.v[j] = 0; carryN.v[j] = 0; carryC.v[j] = 0; }
+    for (int j = 0; j < 4; j++) { best.v[j] = 0xFFFFFFFFu; dcur.v[j] = dbot.v[j]; dpar.v[j] = 0; carryD.v[j] = 0; carryN.v[j] = 0; carryC.v[j] = 0; }   // (dcur: the root reads D(bottom) as "the previous node's D")
     uint32_t accP = 0, accC = 0, accN = 0;
     uint32_t hdr = 0;          // uniform: header of the open node
     bool flushed = false;      // uniform
     uint32_t chunk = c0;       // uniform: chunk whose body is being walked
+    // The unit ends in front of chunk `stop`: c1, or less once its second half has been handed to another wave.  Kept in a
+    // vector register on purpose (the same value in every lane, read back with readfirstlane at chunk ends and restarts
+    // only): the kernel sits at the scalar-register limit, and one more scalar that lives across the pipelined loop
+    // sends its allocation over a cliff (500 more spill moves).
+    uint32_t stop_v;
+    asm volatile("v_mov_b32 %0, %1" : "=v"(stop_v) : "s"(c1));
     const uint32_t NOPW = H_TAG | H_RARE | H_NOP;
     // pruning: ub1 = (upper bound of best(s)) + 1 per sample, refreshed from / published to a.ub at chunk ends
     bool prune = false;        // uniform; only while walking the body (phase 1)
@@ -726,10 +745,18 @@ __global__ void __launch_bounds__(64, 5) k_best8(Best8Args a) {
     uint32_t info = 0;         // uniform: pending pruning record
     uint32_t skip_to = 0;      // uniform: restart request (0 = none)
     uint32_t cend = 0xFFFFFFFFu;   // uniform: position of the open chunk's end marker (phase 1)
-    bool cend_stale = false;       // uniform: `chunk` advanced inside the pipeline since cend was loaded
+    bool cend_stale = false;       // uniform: `chunk` advanced inside the pipeline and the end word did not say where the next chunk ends
+    uint32_t t_mark = (uint32_t)__builtin_amdgcn_s_memtime();   // uniform: start of the unit / its last look at the shared list (low word: differences only)
+    uint32_t n_split = 0;      // uniform (STATS)
     uint64_t n_skipped = 0;    // uniform (STATS): words jumped over
     uint32_t run_nodes = 0;    // uniform (STATS): nodes completed since the last restart
     uint64_t n_first_skip = 0; // uniform (STATS): jumps decided by the first node after a restart
+    uint32_t n_cause[4] = {0, 0, 0, 0};   // uniform (STATS): restarts by cause -- jump, sibling jump, chunk end, slow header
+    uint32_t n_jlen[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // uniform (STATS): jump lengths
+    auto count_jump = [&](uint32_t len, int cause) {
+        n_cause[cause]++;
+        n_jlen[len < 8 ? 0 : len < 16 ? 1 : len < 32 ? 2 : len < 64 ? 3 : len < 128 ? 4 : len < 512 ? 5 : len < 4096 ? 6 : 7]++;
+    };
     // (the tests below use the kernel argument, not the per-lane pointer: a condition derived from `lane`
     // is formally divergent, and one such flag turned the whole walk's control flow -- jump target, open
     // header, position -- into vector registers with exec-mask branches)
@@ -881,7 +908,7 @@ __global__ void __launch_bounds__(64, 5) k_best8(Best8Args a) {
                     return true;
                 }
                 skip_to = pos + 1 + (info & INFO_JUMP_MASK);
-                if (STATS) { n_skipped += info & INFO_JUMP_MASK; if (run_nodes == 1) n_first_skip++; }
+                if (STATS) { n_skipped += info & INFO_JUMP_MASK; if (run_nodes == 1) n_first_skip++; count_jump(info & INFO_JUMP_MASK, 0); }
                 return true;
             }
         }
@@ -904,7 +931,7 @@ __global__ void __launch_bounds__(64, 5) k_best8(Best8Args a) {
         if (!all_far(dpar, sinfo)) return false;
         skip_to = pos + (sinfo & INFO_JUMP_MASK);   // the start of the parent's last child
         have_info = false;
-        if (STATS) n_skipped += sinfo & INFO_JUMP_MASK;
+        if (STATS) { n_skipped += sinfo & INFO_JUMP_MASK; count_jump(sinfo & INFO_JUMP_MASK, 1); }
         return true;
     };
     // words that leave the fast path (H_RARE); true: the pipeline has to restart at skip_to
@@ -919,16 +946,21 @@ __global__ void __launch_bounds__(64, 5) k_best8(Best8Args a) {
         if (w & H_CHUNK_END) {
             // a chunk with a candidate (or a due exchange of bounds) is closed by the restart code, which may
             // store; any other chunk just ends here, inside the pipeline
-            if (chunk_has_candidate() || ub_age + 1 >= a.ub_every) { skip_to = pos + 1; return true; }
+            // (also when the unit ends with this chunk because its rest has been handed to another wave)
+            if (chunk_has_candidate() || ub_age + 1 >= a.ub_every || chunk + 1u >= (uint32_t)__builtin_amdgcn_readfirstlane((int)stop_v)) { skip_to = pos + 1; if (STATS) n_cause[2]++; return true; }
             ub_age++;
 #pragma unroll
             for (int j = 0; j < 4; j++) best.v[j] = 0xFFFFFFFFu;
             chunk++;
-            cend_stale = true;
+            {   // the end word names the length of the chunk it opens
+                const uint32_t ln = (w >> CE_LEN_SHIFT) & CE_LEN_MASK;
+                if (ln) cend = pos + ln; else cend_stale = true;
+            }
             return false;
         }
         if (w & H_NOP) return false;
         replay = true; skip_to = pos + 1;   // slow header (nothing of this node has been touched yet)
+        if (STATS) n_cause[3]++;
         return true;
     };
 
@@ -942,9 +974,6 @@ __global__ void __launch_bounds__(64, 5) k_best8(Best8Args a) {
         if (w & H_REG) {
 #pragma unroll
             for (int j = 0; j < 4; j++) dpar.v[j] = dcur.v[j];
-        } else if (w & H_BOTTOM) {
-#pragma unroll
-            for (int j = 0; j < 4; j++) dpar.v[j] = dbot.v[j];
         } else {
             const u32x4 t = rs >= a.lds_slots ? *(const u32x4 *)(coldp + (uint64_t)(rs - a.lds_slots) * 256) : *lds_at(rs * 1024u + lane16);
             dpar.v[0] = t.x; dpar.v[1] = t.y; dpar.v[2] = t.z; dpar.v[3] = t.w;
@@ -979,21 +1008,13 @@ __global__ void __launch_bounds__(64, 5) k_best8(Best8Args a) {
     const uint32_t *abm = a.active + (uint64_t)tile * a.active_words;
     const uint64_t t_wave0 = STATS ? __builtin_amdgcn_s_memtime() : 0;
     uint64_t t_restart = 0, n_restart = 0;
-    // Light units that coincide with a summary (a run of a.super_chunks chunks, see ugp_flatten.cpp) first evaluate
-    // the summary -- the top-level subtrees of the run, densely -- and walk only the survivors in the main stream.
-    // sv_lo / sv_hi: lane i = range i of the main stream still to be walked (relative positions), adjacent ranges merged.
-    const bool summarise = can_prune && !unit_heavy && a.sum8 != nullptr && c0 % a.super_chunks == 0 &&
-                           c1 == min(c0 + a.super_chunks, a.n_chunks);
-    uint32_t sv_lo = 0, sv_hi = 0;   // per lane
-    uint32_t n_sv = 0;               // uniform
     body_start = 0;
     uint64_t t_pre_end = 0;
-    for (int phase = 0; phase < 3; phase++) {
+    for (int phase = 0; phase < 2; phase++) {   // 0: replay of the preamble (the root path of the unit's first node), 1: the body
         if (STATS && phase == 1) t_pre_end = __builtin_amdgcn_s_memtime();
-        if (phase == 1 && (!summarise || body_start >= a.chunk8_body_off[c1] - a.chunk8_body_off[c0])) continue;   // (nothing left to summarise)
-        sp = phase == 0 ? a.pre8 : (phase == 1 ? a.sum8 : a.stream8);
-        const uint32_t begin = phase == 0 ? a.chunk8_pre_off[c0] : (phase == 1 ? a.sum8_off[c0 / a.super_chunks] : a.chunk8_body_off[c0]);
-        const uint32_t end = phase == 0 ? a.chunk8_pre_off[c0 + 1] : (phase == 1 ? a.sum8_off[c0 / a.super_chunks + 1] : a.chunk8_body_off[c1]);
+        sp = phase == 0 ? a.pre8 : a.stream8;
+        const uint32_t begin = phase == 0 ? a.chunk8_pre_off[c0] : a.chunk8_body_off[c0];
+        const uint32_t end = phase == 0 ? a.chunk8_pre_off[c0 + 1] : a.chunk8_body_off[c1];
         if (begin >= end) continue;
         const uint32_t n = end - begin;
         sp += begin;
@@ -1016,10 +1037,10 @@ __global__ void __launch_bounds__(64, 5) k_best8(Best8Args a) {
             const bool act = !is_hdr && ((bits >> (wv & 31u)) & 1u);
             return (act ? (wv & 0x3FFFFFu) + CONST_ROWS : (is_hdr ? 0u : (wv >> 26) & 3u)) << 8;
         };
-        prune = (phase >= 1) && can_prune;
-        pre_prune = phase == 0 && can_prune && !unit_heavy;
+        prune = phase == 1 && can_prune;
+        pre_prune = phase == 0 && can_prune && !unit_heavy && !a.no_pre_records;
         have_info = false;
-        cend = phase == 2 ? (uint32_t)__builtin_amdgcn_readfirstlane((int)(a.chunk8_body_off[c0 + 1] - 1u - begin)) : 0xFFFFFFFFu;
+        cend = phase == 1 ? (uint32_t)__builtin_amdgcn_readfirstlane((int)(a.chunk8_body_off[c0 + 1] - 1u - begin)) : 0xFFFFFFFFu;
         cend_stale = false;
         if ((prune || pre_prune) && ub_tile != tile) {   // start from what earlier waves of this tile already know
 #pragma unroll
@@ -1057,126 +1078,12 @@ __global__ void __launch_bounds__(64, 5) k_best8(Best8Args a) {
             }
             return node_end(pos, -1);
         };
-        if (phase == 1) {
-            // ---- summary pass: no restarts, no stores, no scoring; dcur and the slots are left as the preamble set them
-            uint32_t sA = 0, sB = 0;     // uniform: the open entry's records
-            bool forced = false;         // uniform: the open entry is walked whatever its bounds say
-            Pk4 spar;                    // D(parent) of the open entry
-#pragma unroll
-            for (int j = 0; j < 4; j++) spar.v[j] = 0;
-            auto sum_step = [&](uint32_t w0v, int k, uint32_t x) {
-                const uint32_t w = rdlane(w0v, k);
-                if (w & H_TAG) {
-                    if (w & H_INFO) {                            // SUM_A carries H_RARE, SUM_B does not
-                        if (w & H_RARE) sA = w; else sB = w;
-                        return;
-                    }
-                    if (w & H_NOP) return;                       // padding behind the last entry
-                    forced = (sB & SUM_FORCED) || (w & H_RARE);  // H_RARE on a header: a cold slot or the root
-                    if (!forced) {
-                        if (w & H_REG) {
-#pragma unroll
-                            for (int j = 0; j < 4; j++) spar.v[j] = dcur.v[j];
-                        } else {
-                            const u32x4 t = *lds_at((w & (63u << H_RSLOT_SHIFT)) | lane16);
-                            spar.v[0] = t.x; spar.v[1] = t.y; spar.v[2] = t.z; spar.v[3] = t.w;
-                        }
-                    }
-                    if (!(w & H_END)) return;
-                } else {
-                    const uint32_t mi = (w >> 22) & 3u, pi = (w >> 24) & 3u;
-                    const uint32_t C = (x >> mi) & 0x11111111u, P = (x >> pi) & 0x11111111u;
-                    accP += P; accC += C;
-                    if (!(w & M_END)) return;
-                }
-                // end of the entry: the node costs at least D(parent) - (its words), its descendants at least
-                // D(node) - hsub; if both exceed the upper bound of every sample nothing of this subtree is needed
-                // (descendants: either lower bound of ugp_flatten.hpp; the node itself: each of its words lowers its cost by at most 1)
-                // An entry that ends at or before body_start lies inside the subtree the preamble replay ruled out: dropped
-                // whatever it says (its parent's slot was not even written).
-                const bool dead = (sB & SUM_POS_MASK) <= body_start;
-                bool keep = forced && !dead;
-                if (!forced && !dead) {
-                    const uint32_t K1 = 0x80008000u - ((sA >> INFO_HS_SHIFT) & 0x7Fu) * 0x00010001u;
-                    const uint32_t K2 = 0x80008000u - ((sB >> SUM_W_SHIFT) & 63u) * 0x00010001u;
-                    const uint32_t hr = (sA >> SUM_HR_SHIFT) & 7u;
-                    uint32_t r = 0xFFFFFFFFu;
-                    if (hr != INFO_HR_NONE) {
-                        const uint32_t K3 = 0x80008000u - hr * 0x00010001u;
-#pragma unroll
-                        for (int j = 0; j < 4; j++) {
-                            const uint32_t dn = psub(padd(spar.v[j], ex4(accP, j)), ex4(accC, j));
-                            r &= (psub(padd(dn, K1), ub1.v[j]) | psub(padd(dn, K3), ubv1.v[j])) & psub(padd(spar.v[j], K2), ub1.v[j]);
-                        }
-                    } else {
-#pragma unroll
-                        for (int j = 0; j < 4; j++) {
-                            const uint32_t dn = psub(padd(spar.v[j], ex4(accP, j)), ex4(accC, j));
-                            r &= psub(padd(dn, K1), ub1.v[j]) & psub(padd(spar.v[j], K2), ub1.v[j]);
-                        }
-                    }
-                    keep = __builtin_amdgcn_ballot_w64((r & 0x80008000u) != 0x80008000u) != 0;
-                }
-                accP = accC = 0;
-                if (keep) {
-                    const uint32_t lo = sA & SUM_A_POS_MASK, hi = sB & SUM_POS_MASK;
-                    if (n_sv > 0 && rdlane(sv_hi, (n_sv - 1u) & 63u) == lo) {          // adjacent to the last range: extend it
-                        sv_hi = lane == ((n_sv - 1u) & 63u) ? hi : sv_hi;
-                    } else if (n_sv < 64u) {
-                        sv_lo = lane == n_sv ? lo : sv_lo;
-                        sv_hi = lane == n_sv ? hi : sv_hi;
-                        n_sv++;
-                    } else {                                                            // list full: everything from here on is walked
-                        sv_hi = lane == 63u ? SUM_POS_MASK : sv_hi;
-                    }
-                } else if (STATS) n_skipped += (sB & SUM_POS_MASK) - (sA & SUM_A_POS_MASK);
-            };
-            uint32_t w0 = load_words(0), w1 = load_words(GRP), w2 = load_words(2 * GRP);
-            const uint32_t o0 = a.refill_all_rows ? decode(w0, 0xFFFFFFFFu) : decode(w0, load_bits(w0));   // (experiment: no bitmap round trip in front of the first rows)
-            uint32_t b1 = load_bits(w1);
-            uint32_t X[GRP];
-#pragma unroll
-            for (int k = 0; k < (int)GRP; k++) X[k] = __builtin_amdgcn_raw_buffer_load_b32(trsrc, lane4, rdlane(o0, k), 0);
-            for (uint32_t off = 0; off < n; off += GRP) {
-                const uint32_t w3 = load_words(off + 3 * GRP);
-                const uint32_t b2 = load_bits(w2);
-                const uint32_t o1 = decode(w1, b1);
-#pragma unroll
-                for (int k = 0; k < (int)GRP; k++) {
-                    sum_step(w0, k, X[k]);
-                    X[k] = __builtin_amdgcn_raw_buffer_load_b32(trsrc, lane4, rdlane(o1, k), 0);
-                }
-                w0 = w1; w1 = w2; w2 = w3; b1 = b2;
-            }
-            continue;
-        }
-        // body ranges to walk: everything, or the survivors of the summary
         uint32_t off = 0;
-        uint32_t sv_next = 0;        // uniform: next survivor range
-        const bool ranged = phase == 2 && summarise;
-        auto next_range = [&]() -> bool {   // position the walk at the next survivor range, closing the chunks in between
-            const bool more = sv_next < n_sv;
-            const uint32_t lo = more ? rdlane(sv_lo, sv_next & 63u) : n;
-            lim = more ? min(rdlane(sv_hi, sv_next & 63u), n) : n;
-            sv_next++;
-            if (cend_stale) {
-                cend_stale = false;
-                cend = chunk < c1 ? (uint32_t)__builtin_amdgcn_readfirstlane((int)(a.chunk8_body_off[chunk + 1] - 1u - begin)) : 0xFFFFFFFFu;
-            }
-            while (chunk < c1 && lo > cend) {
-                chunk_end();
-                cend = chunk < c1 ? (uint32_t)__builtin_amdgcn_readfirstlane((int)(a.chunk8_body_off[chunk + 1] - 1u - begin)) : 0xFFFFFFFFu;
-            }
-            off = lo;
-            return more;
-        };
-        if (ranged && !next_range()) continue;
-        if (phase == 2 && body_start && !ranged) {   // the replay ended at a path node whose subtree is not needed: close the chunks in front of its end
+        if (phase == 1 && body_start) {   // the replay ended at a path node whose subtree is not needed: close the chunks in front of its end
             off = min(body_start, n);
             cend = close_empty_chunks(off, begin);   // (nothing has been walked yet: no chunk in front of `off` holds a candidate)
         }
         bool cautious = false;   // uniform: the last run was cut short by a jump inside its first group
-        for (;;) {
         while (off < lim) {
             // (re)fill the pipeline at `off`
             const uint64_t t_r0 = STATS ? __builtin_amdgcn_s_memtime() : 0;
@@ -1245,11 +1152,39 @@ __global__ void __launch_bounds__(64, 5) k_best8(Best8Args a) {
                 chunk_end();
                 cend = close_empty_chunks(skip_to, begin);
             }
+            // Units are cut while they run: how long one takes is known only by walking it (most of a far unit is jumped over,
+            // the part next to the tile's samples is not), so they start out large, and a wave that has been on one for
+            // a.split_cycles while others wait for work (tickets taken minus entries pushed, read now and then, never waited for) hands the
+            // second half of what is left to the shared list.  That half starts at a chunk boundary: every chunk has a preamble.
+            const uint32_t stop = (uint32_t)__builtin_amdgcn_readfirstlane((int)stop_v);
+            if (chunk >= stop) break;   // (the rest of the unit belongs to another wave now)
+            if (phase == 1 && stop - chunk >= 2u && (uint32_t)__builtin_amdgcn_s_memtime() - t_mark > (unit_heavy ? a.split_heavy : a.split_cycles)) {
+                // how many waves wait for an entry: tickets taken - entries pushed (one look per a.split_cycles, and only from
+                // units that have been running that long)
+                const unsigned long long pr = __hip_atomic_load((const unsigned long long *)(a.dyn_ctl + DYN_HEAD), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const uint32_t hd = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)pr), tl = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(pr >> 32));
+                if (hd > tl) {
+                    const uint32_t mid = chunk + (stop - chunk + 1u) / 2u;
+                    uint32_t slot = 0xFFFFFFFFu;
+                    if (lane == 0) {
+                        atomicAdd(a.dyn_ctl + DYN_ACTIVE, 1u);   // the entry counts as live work from before it can be seen
+                        slot = atomicAdd(a.dyn_ctl + DYN_TAIL, 1u);
+                    }
+                    slot = (uint32_t)__builtin_amdgcn_readfirstlane((int)slot);
+                    if (slot < a.dyn_cap) {
+                        if (lane == 0) {
+                            const unsigned long long ev = (unsigned long long)mid | ((unsigned long long)stop << 20) | ((unsigned long long)tile << 40) |
+                                                          ((unsigned long long)(unit_heavy ? 1u : 0u) << 52) | ((unsigned long long)a.dyn_epoch << 53);
+                            __hip_atomic_store(a.dyn_units + slot, ev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        }
+                        asm volatile("v_mov_b32 %0, %1" : "=v"(stop_v) : "s"(mid));
+                        if (STATS) n_split++;
+                    } else if (lane == 0) atomicAdd(a.dyn_ctl + DYN_ACTIVE, 0xFFFFFFFFu);   // (list full: nothing was pushed)
+                }
+                t_mark = (uint32_t)__builtin_amdgcn_s_memtime();
+            }
             off = skip_to;
         }
-        if (!ranged || !next_range()) break;
-        cautious = false;
-        }   // next survivor range
     }
     if (STATS && lane == 0) {   // debug accounting, one update per unit
         const unsigned long long tw = __builtin_amdgcn_s_memtime() - t_wave0;
@@ -1261,6 +1196,9 @@ __global__ void __launch_bounds__(64, 5) k_best8(Best8Args a) {
         atomicAdd(st + 3, tw);
         atomicAdd(st + (unit_heavy ? 27 : 28), tw);   // wave cycles inside / outside the tiles' own regions
         atomicAdd(st + (unit_heavy ? 29 : 30), 1ull);
+        atomicAdd(st + 31, (unsigned long long)n_split);
+        for (int i = 0; i < 4; i++) atomicAdd(st + 48 + 2 * i + (unit_heavy ? 0 : 1), (unsigned long long)n_cause[i]);
+        for (int i = 0; i < 8; i++) atomicAdd(st + 56 + i, (unsigned long long)n_jlen[i]);
         if (!unit_heavy) {   // what the preamble records decided for this unit
             const uint32_t body_words = a.chunk8_body_off[c1] - a.chunk8_body_off[c0];
             const int cls = body_start >= body_words ? 0 : (body_start ? 1 : 2);
@@ -1604,6 +1542,70 @@ __global__ void k_tile_ranges(const uint32_t *__restrict__ keys_sorted, uint32_t
     hlen[t] = h1 - h0;
 }
 
+// The work units of k_best8, one list per queue (= XCD; queue x owns the tiles [x T / 8, (x + 1) T / 8)).
+// Units of a tile: its own region H = [h0, h0 + hl) (the chunks its samples sit in, from the locality sort; hl = 0
+// without it) cannot be pruned and is dense work -- heavy_chunks chunks per unit, and every tile's H comes first in the
+// list.  The rest of the ring, A = [h0 + hl, n_chunks) ascending and B = [0, h0) descending, is mostly jumped over; its
+// units are listed nearest first (rank k of every tile before rank k + 1 of any, alternating between A and B; with
+// light_order 1 one tile after the other, each nearest first), since the ones next to the region are pruned least and
+// would otherwise be the tail of the kernel.  A unit far from the region almost always ends in the replay of its
+// preamble or after a few jumps, so what it costs is the replay, not its length: the units grow with the distance --
+// `unit_chunks` chunks for the first `grow_every` units of a side, twice that for the next `grow_every`, ... up to
+// `unit_max` (grow_every = 0: all the same size).  Entry = {tile, c0, c1, flags (bit 0: own region)}; c0 == c1: filler.
+// One block per queue; thread t lists the tiles tlo + t, tlo + t + 256, ...
+__global__ void __launch_bounds__(256) k_build_units(const uint32_t *__restrict__ hstart, const uint32_t *__restrict__ hlen, uint32_t n_tiles, uint32_t n_chunks,
+                                                     uint32_t unit_chunks, uint32_t heavy_chunks, uint32_t grow_every, uint32_t unit_max, uint32_t light_order,
+                                                     uint32_t per_tile_cap, uint4 *__restrict__ units, uint32_t *__restrict__ unit_base, uint32_t *__restrict__ unit_count,
+                                                     uint32_t *__restrict__ dyn_ctl) {
+    __shared__ uint32_t s_heavy[512], s_light[512], s_hoff[512], s_loff[512];   // (at most 4,096 tiles per launch: 512 per queue)
+    __shared__ uint32_t s_max_light, s_heavy_total;
+    const uint32_t x = blockIdx.x, tlo = x * n_tiles / 8u, thi = (x + 1u) * n_tiles / 8u, T = thi - tlo;
+    const uint32_t U = max(unit_chunks, 1u), HU = max(heavy_chunks, 1u), UM = max(unit_max, U);
+    auto len_of = [&](uint32_t i) -> uint32_t {   // length of the i-th unit of a side
+        if (!grow_every) return U;
+        const uint32_t sh = min(i / grow_every, 16u);
+        return (uint32_t)min((uint64_t)U << sh, (uint64_t)UM);
+    };
+    auto count_side = [&](uint32_t chunks) -> uint32_t { uint32_t n = 0; for (uint32_t done = 0; done < chunks; n++) done += len_of(n); return n; };
+    for (uint32_t t = threadIdx.x; t < T; t += blockDim.x) {
+        const uint32_t h0 = hstart ? hstart[tlo + t] : 0u, hl = hstart ? hlen[tlo + t] : 0u;
+        s_heavy[t] = (hl + HU - 1u) / HU;
+        s_light[t] = count_side(n_chunks - h0 - hl) + count_side(h0);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t ho = 0, lo = 0, ml = 0;
+        for (uint32_t t = 0; t < T; t++) { s_hoff[t] = ho; s_loff[t] = lo; ho += s_heavy[t]; lo += s_light[t]; ml = max(ml, s_light[t]); }
+        s_heavy_total = ho; s_max_light = ml;
+        unit_base[x] = tlo * per_tile_cap;
+        if (x == 0 && dyn_ctl) { dyn_ctl[DYN_HEAD] = 0; dyn_ctl[DYN_TAIL] = 0; dyn_ctl[DYN_ACTIVE] = 0; }
+        unit_count[x] = ho + (light_order == 1u ? lo : ml * T);
+    }
+    __syncthreads();
+    uint4 *out = units + (uint64_t)tlo * per_tile_cap;
+    for (uint32_t t = threadIdx.x; t < T; t += blockDim.x) {
+        const uint32_t tile = tlo + t;
+        const uint32_t h0 = hstart ? hstart[tile] : 0u, hl = hstart ? hlen[tile] : 0u;
+        for (uint32_t r = 0; r < s_heavy[t]; r++) {
+            const uint32_t c0 = h0 + r * HU;
+            out[s_hoff[t] + r] = make_uint4(tile, c0, min(c0 + HU, h0 + hl), 1u);
+        }
+        const uint32_t nA = count_side(n_chunks - h0 - hl), nB = count_side(h0), m = min(nA, nB);
+        uint32_t a_at = h0 + hl, b_at = h0, ia = 0, ib = 0;
+        const uint32_t n_rank = light_order == 1u ? nA + nB : s_max_light;   // (rank-major lists are padded with fillers to the longest tile)
+        for (uint32_t k = 0; k < n_rank; k++) {
+            uint32_t c0 = 0, c1 = 0;
+            if (k < nA + nB) {
+                const bool side_a = k < 2u * m ? !(k & 1u) : nA > nB;
+                if (side_a) { c0 = a_at; c1 = min(a_at + len_of(ia), n_chunks); a_at = c1; ia++; }
+                else { const uint32_t l = min(len_of(ib), b_at); c1 = b_at; c0 = b_at - l; b_at = c0; ib++; }
+            }
+            const uint32_t at = s_heavy_total + (light_order == 1u ? s_loff[t] + k : k * T + t);
+            out[at] = make_uint4(tile, c0, c1, 0u);
+        }
+    }
+}
+
 __global__ void k_extract_best(const ugp_result *__restrict__ res, uint32_t n, int32_t *__restrict__ best) {
     const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
     if (q < n) best[q] = res[q].best_set_difference;
@@ -1621,6 +1623,14 @@ hipError_t launch_tile_ranges(const uint32_t *keys_sorted, uint32_t n_queries, u
                               uint32_t n_chunks, uint32_t align, uint32_t *hstart, uint32_t *hlen, hipStream_t s) {
     hipLaunchKernelGGL(k_tile_ranges, dim3((n_tiles512 + 63) / 64), dim3(64), 0, s, keys_sorted, n_queries, n_tiles512, chunk_node_off,
                        n_chunks, align, hstart, hlen);
+    return hipGetLastError();
+}
+
+hipError_t launch_build_units(const uint32_t *hstart, const uint32_t *hlen, uint32_t n_tiles512, uint32_t n_chunks, uint32_t unit_chunks, uint32_t heavy_chunks,
+                              uint32_t grow_every, uint32_t unit_max, uint32_t light_order, uint32_t per_tile_cap, void *units, uint32_t *unit_base,
+                              uint32_t *unit_count, uint32_t *dyn_ctl, hipStream_t s) {
+    hipLaunchKernelGGL(k_build_units, dim3(8), dim3(256), 0, s, hstart, hlen, n_tiles512, n_chunks, unit_chunks, heavy_chunks, grow_every, unit_max, light_order,
+                       per_tile_cap, (uint4 *)units, unit_base, unit_count, dyn_ctl);
     return hipGetLastError();
 }
 

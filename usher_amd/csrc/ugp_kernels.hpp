@@ -38,8 +38,6 @@ struct PlaceArgs {
 struct Best8Args {
     const uint32_t *stream8, *pre8;
     const uint32_t *chunk8_body_off, *chunk8_pre_off;   // [n_chunks+1]
-    const uint32_t *sum8, *sum8_off;   // summaries of the runs of super_chunks chunks (nullptr: not used)
-    uint32_t super_chunks;
     const uint32_t *table;     // [n_tiles][4 + n_sites][64]
     const uint32_t *dbottom;   // [n_tiles*512]
     const uint32_t *vrows;     // [n_tiles*512] rows per sample whose allele set is neither missing nor just the reference base
@@ -52,17 +50,25 @@ struct Best8Args {
     uint32_t *lbest;           // [n_chunks][n_tiles][64][4] packed u16 pairs; a record exists only for the chunks in `list`
     uint32_t *list, *list_n;   // [n_tiles][n_chunks] chunks of each tile that left a record, [n_tiles] their number (zeroed before the launch)
     uint32_t *queue;           // [8] work-queue heads, one per XCD, zeroed before the launch
-    const uint32_t *tile_hstart, *tile_hlen;   // [n_tiles] or null: per tile, the first chunk of the region its own samples
-                                               // sit in and that region's length in chunks (scheduled first)
+    const uint4 *units;        // work units {tile, c0, c1, flags}, one list per queue (k_build_units)
+    const uint32_t *unit_base, *unit_count;    // [8] first entry / number of entries of each queue's list
+    uint32_t *dyn_ctl;         // head, tail, active and waiting waves of the shared list of split-off units (one 128-byte line each)
+    unsigned long long *dyn_units;   // [dyn_cap] {epoch:11 | own region:1 | tile:12 | c1:20 | c0:20}: an entry counts once it carries this launch's epoch
+    uint32_t dyn_cap, dyn_epoch;
+    uint32_t no_pre_records;   // the preamble replay ignores its pruning records (units longer than their jump field reaches)
+    uint32_t split_heavy;      // the same for the units of the tiles' own regions (dense: both halves are real work)
+    uint32_t split_cycles;     // a unit running longer than this hands half of its remainder to the shared list when waves wait for work (0xFFFFFFFF: never)
     uint32_t ub_every;         // exchange the shared upper bounds at every ub_every-th chunk end
     uint32_t refill_all_rows;  // experiment (UGP_REFILL_ALL): a refill fetches the real row of every word of its first group
     uint32_t heavy_prio;       // raise the wave priority while a unit of a tile's own region is walked
-    uint32_t light_order;      // light units: 0 = nearest first across the queue's tiles, 1 = tile after tile (each nearest first)
-    uint32_t unit_chunks, heavy_chunks;        // chunks per unit outside / inside that region
     uint64_t *stats;           // optional: [0] += stream words skipped by pruning (debug / bench)
     uint32_t *ub;              // [n_tiles][64][4] packed upper bounds of best(s) shared by the waves of a tile; nullptr = no pruning
 };
 
+// hstart / hlen: [n_tiles] or null: per tile, the first chunk of the region its own samples sit in and its length in chunks
+hipError_t launch_build_units(const uint32_t *hstart, const uint32_t *hlen, uint32_t n_tiles512, uint32_t n_chunks, uint32_t unit_chunks, uint32_t heavy_chunks,
+                              uint32_t grow_every, uint32_t unit_max, uint32_t light_order, uint32_t per_tile_cap, void *units, uint32_t *unit_base,
+                              uint32_t *unit_count, uint32_t *dyn_ctl, hipStream_t s);
 hipError_t best8_occupancy(size_t lds_bytes, int *per_cu);
 hipError_t launch_best8(const Best8Args &a, uint32_t blocks, hipStream_t s);
 // a.n_tiles = number of 64-sample tiles; lbest/gbest in the packed 512-tile layout

@@ -101,8 +101,7 @@ class FlatTreeView:
            "chunk_pre_off": (3, np.uint32), "chunk_node_off": (4, np.uint32), "pos2site": (5, np.int32),
            "site_ref": (6, np.uint8), "rank2bfs": (7, np.uint32), "dfs2bfs": (8, np.uint32),
            "stream8": (10, np.uint32), "pre8_stream": (11, np.uint32), "chunk8_body_off": (12, np.uint32),
-           "chunk8_pre_off": (13, np.uint32), "stream_t": (15, np.uint32), "chunk_t_off": (16, np.uint32),
-           "sum8": (18, np.uint32), "sum8_off": (19, np.uint32)}
+           "chunk8_pre_off": (13, np.uint32), "stream_t": (15, np.uint32), "chunk_t_off": (16, np.uint32)}
 
     def __init__(self, arrays: Dict, chunk_nodes: int = 0):
         L = _lib.lib()
@@ -127,8 +126,6 @@ class FlatTreeView:
             self.max_path_muts = int(n.value)
             _check(L.ugp_flat_get(h, 17, C.byref(p), C.byref(n)))
             self.lds_slots = int(n.value)
-            _check(L.ugp_flat_get(h, 20, C.byref(p), C.byref(n)))
-            self.super_chunks = int(n.value)
         finally:
             L.ugp_flat_destroy(h)
 
