@@ -89,7 +89,7 @@ struct ugp_mat {
     DevBuf<uint32_t> d_lbest, d_gbest, d_gbest_part, d_items, d_ub, d_gstart, d_hlen, d_cold, d_list, d_units, d_unit_info;
     DevBuf<uint64_t> d_dyn;
     uint32_t dyn_epoch = 0;
-    DevBuf<uint64_t> d_stats;
+    DevBuf<uint64_t> d_stats, d_trace;
     uint64_t last_words_total = 0;
     const uint32_t *last_list_n = nullptr;   // (UGP_STATS) record counts of the last packed launch, per 512-sample tile
     uint32_t last_list_tiles = 0;
@@ -451,6 +451,12 @@ int run_place(ugp_mat *m, ugp_qset *qs, int mode, ugp_result *d_out, int32_t *d_
             HIP_TRY(m->d_stats.reserve(64));
             if (q0 == 0) { HIP_TRY(hipMemsetAsync(m->d_stats.p, 0, 64 * sizeof(uint64_t), s)); m->last_words_total = 0; }
             b.stats = getenv("UGP_STATS") ? m->d_stats.p : nullptr;   // the counters are two contended atomics per skip: debug only
+            if (b.stats && getenv("UGP_TRACE") && !coarse_only) {   // per-unit records of this launch, dumped by ugp_get_timing
+                constexpr size_t kTraceCap = 1u << 20;
+                HIP_TRY(m->d_trace.reserve(8 + kTraceCap * 6));
+                HIP_TRY(hipMemsetAsync(m->d_trace.p, 0, 64, s));
+                b.trace = m->d_trace.p; b.trace_cap = kTraceCap;
+            }
             m->last_words_total += (uint64_t)n_tiles512 * m->stream8_dwords;
             b.max_slots = f.max_slots;
             // LDS holds the hot slots only (the kernel's registers allow 6 waves per SIMD, 13 KB of LDS per wave
@@ -1132,6 +1138,17 @@ int ugp_get_timing(ugp_mat *m, ugp_timing *out) {
             HIP_TRY(hipMemcpy(v, m->d_stats.p, sizeof v, hipMemcpyDeviceToHost));
             m->last.words_skipped = v[0];
             m->last.reserved = (uint32_t)std::min<uint64_t>(v[1], 0xFFFFFFFFull);   // pipeline (re)starts
+            if (const char *tf = getenv("UGP_TRACE")) {
+                if (m->d_trace.p) {
+                    uint64_t n = 0;
+                    HIP_TRY(hipMemcpy(&n, m->d_trace.p, 8, hipMemcpyDeviceToHost));
+                    n = std::min<uint64_t>(n, 1u << 20);
+                    std::vector<uint64_t> rec(n * 6);
+                    if (n) HIP_TRY(hipMemcpy(rec.data(), m->d_trace.p + 8, n * 48, hipMemcpyDeviceToHost));
+                    if (FILE *fp = fopen(tf, "wb")) { fwrite(rec.data(), 8, rec.size(), fp); fclose(fp); }
+                    fprintf(stderr, "[ugp stats] %llu unit records written to %s\n", (unsigned long long)n, tf);
+                }
+            }
             if (getenv("UGP_STATS")) {
                 fprintf(stderr, "[ugp stats] restarts=%llu restart_cycles=%llu wave_cycles=%llu max_wave=%llu hist:", (unsigned long long)v[1],
                         (unsigned long long)v[2], (unsigned long long)v[3], (unsigned long long)v[4]);

@@ -598,7 +598,12 @@ __global__ void __launch_bounds__(64, 5) k_best8(Best8Args a) {
     extern __shared__ __attribute__((aligned(16))) u32x4 slots8[];   // [lds_slots][64] x 16 B: the hot saved-D slots
     const uint32_t lane = threadIdx.x;
     const uint32_t lane16 = lane * 16u;
-    auto lds_at = [&](uint32_t byte_off) -> u32x4 * { return (u32x4 *)((char *)slots8 + byte_off); };
+    // (explicit address spaces for the slot rows and the cold scratch: through a plain pointer some of these became FLAT
+    // accesses, which return out of order with the row loads -- with one of them possibly in flight the compiler turns
+    // every later wait into a wait for all loads)
+    typedef __attribute__((address_space(3))) u32x4 lds_row;
+    typedef __attribute__((address_space(1))) u32x4 glb_row;
+    auto lds_at = [&](uint32_t byte_off) -> lds_row * { return (lds_row *)((__attribute__((address_space(3))) char *)slots8 + byte_off); };
     // Persistent wave: work units u = (tile, chunk range) are pulled from 8 queues, one per XCD.
     // Queue x owns a contiguous run of tiles, so an XCD walks few tiles at a time and their
     // non-reference table rows stay resident in its 4 MiB L2 (block b is observed to land on XCD
@@ -620,6 +625,7 @@ __global__ void __launch_bounds__(64, 5) k_best8(Best8Args a) {
     uint32_t ub_age = 0;              // uniform: chunk ends since the last exchange
     for (;;) {
     const uint64_t t_pull0 = STATS ? __builtin_amdgcn_s_memtime() : 0;
+    const uint64_t tr_pull = STATS ? __builtin_amdgcn_s_memrealtime() : 0;   // (trace: the device-wide 100 MHz clock, comparable across dies)
     uint32_t tile = 0, c0 = 0, c1 = 0;   // the unit: chunks [c0, c1) of the stream for one tile
     bool unit_heavy = false;             // (STATS) the unit lies in the tile's own region
     uint32_t uflags = 2u;   // bit 0: the unit lies in its tile's own region; bit 1: nothing left (exit)
@@ -676,7 +682,7 @@ __global__ void __launch_bounds__(64, 5) k_best8(Best8Args a) {
                     if ((hi >> 21) == a.dyn_epoch) {
                         if ((hi & 0x1FFFFFu) != 0x1FFFFFu || lo != 0xFFFFFFFFu) {   // a unit (else: the exit mark)
                             c0 = lo & 0xFFFFFu; c1 = (lo >> 20) | ((hi & 0xFFu) << 12); tile = (hi >> 8) & 0xFFFu;
-                            uflags = (hi >> 20) & 1u;
+                            uflags = ((hi >> 20) & 1u) | 4u;   // (bit 2: a split-off unit; statistics only)
                         }
                         break;
                     }
@@ -849,7 +855,7 @@ __global__ void __launch_bounds__(64, 5) k_best8(Best8Args a) {
     // there would share vmcnt with the row loads and force vmcnt(0) waits: a header that reads or writes a cold
     // slot (or the root, whose parent value is D_bottom) carries H_SLOW | H_RARE, asks for a restart at its
     // own position, and the restart code walks that one node with `slow_node`, the general form of the step.
-    uint32_t *coldp = a.cold + ((uint64_t)blockIdx.x * (a.max_slots > a.lds_slots ? a.max_slots - a.lds_slots : 0u) * 64 + lane) * 4;
+    __attribute__((address_space(1))) uint32_t *coldp = (__attribute__((address_space(1))) uint32_t *)a.cold + ((uint64_t)blockIdx.x * (a.max_slots > a.lds_slots ? a.max_slots - a.lds_slots : 0u) * 64 + lane) * 4;
     bool replay = false;       // uniform: restart at skip_to - 1 and walk one node with slow_node
 
     // ---- end of the open node (shared by the fast and the slow step); wa = LDS byte offset of the write slot,
@@ -893,7 +899,7 @@ __global__ void __launch_bounds__(64, 5) k_best8(Best8Args a) {
         }
         if (hdr & H_STORE) {
             const u32x4 v = u32x4{dcur.v[0], dcur.v[1], dcur.v[2], dcur.v[3]};
-            if (cold_ws >= 0) *(u32x4 *)(coldp + (uint64_t)cold_ws * 256) = v;
+            if (cold_ws >= 0) *(glb_row *)(coldp + (uint64_t)cold_ws * 256) = v;
             else *lds_at(((hdr >> (H_WSLOT_SHIFT - 10)) & (63u << 10)) | lane16) = v;
         }
         accP = accC = accN = 0;
@@ -975,7 +981,9 @@ __global__ void __launch_bounds__(64, 5) k_best8(Best8Args a) {
 #pragma unroll
             for (int j = 0; j < 4; j++) dpar.v[j] = dcur.v[j];
         } else {
-            const u32x4 t = rs >= a.lds_slots ? *(const u32x4 *)(coldp + (uint64_t)(rs - a.lds_slots) * 256) : *lds_at(rs * 1024u + lane16);
+            u32x4 t;   // (two loads, not one through a selected pointer: that would be a FLAT access, whose out-of-order return makes every later wait a wait for everything)
+            if (rs >= a.lds_slots) t = *(const glb_row *)(coldp + (uint64_t)(rs - a.lds_slots) * 256);
+            else t = *lds_at(rs * 1024u + lane16);
             dpar.v[0] = t.x; dpar.v[1] = t.y; dpar.v[2] = t.z; dpar.v[3] = t.w;
         }
         const int cold_ws = ((w & H_STORE) && ws >= a.lds_slots) ? (int)(ws - a.lds_slots) : -1;
@@ -1007,6 +1015,7 @@ __global__ void __launch_bounds__(64, 5) k_best8(Best8Args a) {
     // (s_waitcnt vmcnt(N) with the younger loads still in flight).
     const uint32_t *abm = a.active + (uint64_t)tile * a.active_words;
     const uint64_t t_wave0 = STATS ? __builtin_amdgcn_s_memtime() : 0;
+    const uint64_t tr_start = STATS ? __builtin_amdgcn_s_memrealtime() : 0;
     uint64_t t_restart = 0, n_restart = 0;
     body_start = 0;
     uint64_t t_pre_end = 0;
@@ -1088,8 +1097,13 @@ __global__ void __launch_bounds__(64, 5) k_best8(Best8Args a) {
             // (re)fill the pipeline at `off`
             const uint64_t t_r0 = STATS ? __builtin_amdgcn_s_memtime() : 0;
             uint32_t w0 = load_words(off), w1 = load_words(off + GRP), w2 = load_words(off + 2 * GRP);
-            const uint32_t o0 = a.refill_all_rows ? decode(w0, 0xFFFFFFFFu) : decode(w0, load_bits(w0));   // (experiment: no bitmap round trip in front of the first rows)
-            uint32_t b1 = load_bits(w1);
+            // (the decoded row offsets of the NEXT group, o1, are carried around the loop rather than its active-row bits: the
+            // decode then sits at the bottom of an iteration, behind the loads it depends on and in front of nothing -- at the
+            // top of the next one the compiler's wait for those bits was a wait for every load in flight, rows included)
+            const uint32_t bb0 = a.refill_all_rows ? 0xFFFFFFFFu : load_bits(w0);   // (experiment: no bitmap round trip in front of the first rows)
+            const uint32_t bb1 = load_bits(w1);
+            const uint32_t o0 = decode(w0, bb0);
+            uint32_t o1 = decode(w1, bb1);
             uint32_t X[GRP];
 #pragma unroll
             for (int k = 0; k < (int)GRP; k++) X[k] = __builtin_amdgcn_raw_buffer_load_b32(trsrc, lane4, rdlane(o0, k), 0);
@@ -1105,13 +1119,13 @@ __global__ void __launch_bounds__(64, 5) k_best8(Best8Args a) {
                 for (int k = 0; k < (int)GRP; k++) {
                     if (step(w0, k, X[k], off + k)) { hit = true; break; }
                 }
-                if (!hit) {   // the run goes on: bring the pipeline to its steady state one group further
-                    const uint32_t o1 = decode(w1, b1);
+                if (!hit) {   // the run goes on: bring the pipeline to its steady state one group further (words and bits before the rows)
+                    const uint32_t w3 = load_words(off + 3 * GRP);
+                    const uint32_t b2 = load_bits(w2);
 #pragma unroll
                     for (int k = 0; k < (int)GRP; k++) X[k] = __builtin_amdgcn_raw_buffer_load_b32(trsrc, lane4, rdlane(o1, k), 0);
-                    w0 = w1;
-                    w1 = w2; w2 = load_words(off + 3 * GRP);
-                    b1 = load_bits(w1);
+                    o1 = decode(w2, b2);
+                    w0 = w1; w1 = w2; w2 = w3;
                     off += GRP;
                     first = false;
                 }
@@ -1120,14 +1134,14 @@ __global__ void __launch_bounds__(64, 5) k_best8(Best8Args a) {
             for (; off < lim; off += GRP) {
                 const uint32_t w3 = load_words(off + 3 * GRP);
                 const uint32_t b2 = load_bits(w2);
-                const uint32_t o1 = decode(w1, b1);
 #pragma unroll
                 for (int k = 0; k < (int)GRP; k++) {
                     if (step(w0, k, X[k], off + k)) { hit = true; break; }
                     X[k] = __builtin_amdgcn_raw_buffer_load_b32(trsrc, lane4, rdlane(o1, k), 0);
                 }
                 if (hit) break;
-                w0 = w1; w1 = w2; w2 = w3; b1 = b2;
+                o1 = decode(w2, b2);
+                w0 = w1; w1 = w2; w2 = w3;
                 first = false;
             }
             if (!hit) break;   // walked to the end of the range
@@ -1159,7 +1173,7 @@ __global__ void __launch_bounds__(64, 5) k_best8(Best8Args a) {
             const uint32_t stop = (uint32_t)__builtin_amdgcn_readfirstlane((int)stop_v);
             if (chunk >= stop) break;   // (the rest of the unit belongs to another wave now)
             if (phase == 1 && stop - chunk >= 2u && (uint32_t)__builtin_amdgcn_s_memtime() - t_mark > (unit_heavy ? a.split_heavy : a.split_cycles)) {
-                // how many waves wait for an entry: tickets taken - entries pushed (one look per a.split_cycles, and only from
+                // how many waves wait for an entry: tickets taken - entries pushed (one look per threshold, and only from
                 // units that have been running that long)
                 const unsigned long long pr = __hip_atomic_load((const unsigned long long *)(a.dyn_ctl + DYN_HEAD), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 const uint32_t hd = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)pr), tl = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(pr >> 32));
@@ -1186,7 +1200,17 @@ __global__ void __launch_bounds__(64, 5) k_best8(Best8Args a) {
             off = skip_to;
         }
     }
-    if (STATS && lane == 0) {   // debug accounting, one update per unit
+    if (STATS && a.trace && lane == 0) {   // one record per unit: who ran what, when (UGP_TRACE; tools/analysis/unit_trace.py)
+        const unsigned long long i = atomicAdd((unsigned long long *)a.trace, 1ull);
+        if (i < a.trace_cap) {
+            unsigned long long *r = (unsigned long long *)a.trace + 8 + i * 6;
+            r[0] = ((unsigned long long)blockIdx.x << 32) | (tile << 4) | (unit_heavy ? 1u : 0u) | ((uflags & 4u) ? 2u : 0u);
+            r[1] = ((unsigned long long)c0 << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)stop_v);
+            r[2] = tr_pull; r[3] = tr_start; r[4] = __builtin_amdgcn_s_memrealtime();
+            r[5] = ((unsigned long long)n_restart << 32) | ((unsigned long long)(n_split & 0xFFu) << 24) | (c1 & 0xFFFFFFu);
+        }
+    }
+    if (STATS && !a.trace && lane == 0) {   // debug accounting, one update per unit
         const unsigned long long tw = __builtin_amdgcn_s_memtime() - t_wave0;
         unsigned long long *st = (unsigned long long *)a.stats;
         atomicAdd(st + 0, (unsigned long long)n_skipped);

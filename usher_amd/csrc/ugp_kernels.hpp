@@ -61,6 +61,8 @@ struct Best8Args {
     uint32_t ub_every;         // exchange the shared upper bounds at every ub_every-th chunk end
     uint32_t refill_all_rows;  // experiment (UGP_REFILL_ALL): a refill fetches the real row of every word of its first group
     uint32_t heavy_prio;       // raise the wave priority while a unit of a tile's own region is walked
+    uint64_t *trace;           // optional (with stats): [0] = records written, records of 6 words from [8] on; trace_cap = room for that many
+    uint64_t trace_cap;
     uint64_t *stats;           // optional: [0] += stream words skipped by pruning (debug / bench)
     uint32_t *ub;              // [n_tiles][64][4] packed upper bounds of best(s) shared by the waves of a tile; nullptr = no pruning
 };
