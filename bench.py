@@ -204,26 +204,42 @@ def main():
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    place_ms = table_ms = merge_ms = coarse_ms = 0.0
-    tiles = groups = packed = skipped = wtotal = nskips = 0
+    pl.timing_sum()   # (reset the library's running totals: the timed region starts here)
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        step()
-        tm = pl.timing()   # HIP events recorded by the library on `stream` around each kernel of this step
-        place_ms += tm["place_ms"]; table_ms += tm["table_ms"]; merge_ms += tm["merge_ms"]; coarse_ms += tm["coarse_ms"]
-        tiles, groups, packed = tm["n_tiles"], tm["n_groups"], tm["packed_path"]
-        skipped, wtotal, nskips = tm["words_skipped"], tm["words_total"], tm["reserved"]
+        step()   # no synchronisation between steps: consecutive ugp_place_device calls overlap on the device
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    # HIP events recorded by the library on the streams its kernels ran on, summed over the timed steps
+    tm = pl.timing_sum()
+    assert tm["calls"] == args.steps, tm
+    place_ms, table_ms, merge_ms, coarse_ms = tm["place_ms"], tm["table_ms"], tm["merge_ms"], tm["coarse_ms"]
+    tiles, groups, packed = tm["n_tiles"], tm["n_groups"], tm["packed_path"]
+    skipped, wtotal, nskips = tm["words_skipped"], tm["words_total"], tm["reserved"]
     if world > 1:
         tt = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if share else dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
     res = out.cpu().numpy()[:Q]
+    # The same kernels one call at a time (a synchronisation after every step), outside the timed region: in the timed region
+    # two consecutive calls share the device (ugp_place_device overlaps them), so a kernel's event-bracketed duration there is
+    # the duration of a kernel that has company.  Reported beside it as kernel_ms_alone / frac_alone.
+    alone = {"place_ms": 0.0, "coarse_ms": 0.0, "table_ms": 0.0, "merge_ms": 0.0}
+    n_alone = max(2, min(args.steps, 5))
+    pl.timing_sum()
+    torch.cuda.synchronize()
+    t_alone = time.perf_counter()
+    for _ in range(n_alone):
+        pl.place_device(qset, out.data_ptr(), stream)
+        torch.cuda.synchronize()
+    t_alone = (time.perf_counter() - t_alone) / n_alone
+    tma = pl.timing_sum()
+    for k in alone:
+        alone[k] = tma[k] / max(1, tma["calls"])
     # SURVEY 8(d)'s metric: wall time of ugp_place_batch -- host buffers in and out, i.e. query upload over PCIe,
     # row checks, the same kernels, result download.  Reported beside `value` (the contract keeps `value`
     # HBM-resident); timed on every rank the same way (barrier + max).
@@ -276,6 +292,11 @@ def main():
                     "valu_active_frac_measured": prof.get("valu_active_frac_measured"), "salu_busy_frac_measured": prof.get("salu_busy_frac_measured"),
                     "wave_wait_frac": prof.get("wave_wait_frac"),
                     "kernel": "k_best8" if packed else "k_place<0>", "tile_samples": T, "kernel_ms": round(k_ms, 4), "algo_bytes_per_launch": int(algo_bytes),
+                    # one call at a time (see above): the kernel without a second batch on the device, and that step's wall time
+                    "kernel_ms_alone": round(alone["place_ms"], 4),
+                    "frac_alone": round(algo_bytes / (alone["place_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if alone["place_ms"] > 0 else None,
+                    "ms_per_step_alone": round(t_alone * 1e3, 3),
+                    "overlap": "consecutive ugp_place_device calls run on two internal streams (UGP_NO_OVERLAP=1: off)" if not os.environ.get("UGP_NO_OVERLAP") else "off",
                     "node_plus_mut_evals_decided_per_s": round(node_evals / (k_ms * 1e-3), 1) if k_ms > 0 else 0.0,
                     "coarse_ms": round(coarse_ms / args.steps, 4), "table_ms": round(table_ms / args.steps, 4), "merge_ms": round(merge_ms / args.steps, 4),
                     # the two pruning counters exist only in the instrumented kernel variant (UGP_STATS=1)

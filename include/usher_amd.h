@@ -187,10 +187,19 @@ int ugp_qset_upload(ugp_mat *mat, const ugp_queries *q, ugp_qset **out);
 void ugp_qset_destroy(ugp_qset *qs);
 uint64_t ugp_qset_size(const ugp_qset *qs);
 int ugp_place_device(ugp_mat *mat, ugp_qset *qs, void *d_out, void *stream);
+/* Consecutive ugp_place_device calls on one handle overlap on the device (two internal streams, two sets of workspaces:
+ * the small kernels around the tree walk of one batch run in the gaps of the other's); `stream` receives each call's
+ * completion, in call order.  A call waits for earlier calls on the handle where it must, NOT for other work queued on
+ * `stream` before it: do not hand it an output buffer that earlier stream work still reads.  UGP_NO_OVERLAP=1 in the
+ * environment runs every call on `stream` itself. */
 
 /* Per-kernel durations of the last ugp_place_* call on this handle, measured
  * with HIP events on the stream the kernels ran on (synchronises that stream). */
 int ugp_get_timing(ugp_mat *mat, ugp_timing *out);
+/* The same durations summed over every ugp_place_* call on this handle since the previous ugp_get_timing_sum (the other
+ * fields are those of the last call); waits for the calls still in flight.  Lets a caller time a pipelined sequence of
+ * ugp_place_device calls without synchronising after each of them. */
+int ugp_get_timing_sum(ugp_mat *mat, ugp_timing *sum, uint32_t *n_calls);
 
 /* Message for the last non-zero return on the calling thread. */
 const char *ugp_last_error(void);

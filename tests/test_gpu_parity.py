@@ -274,6 +274,48 @@ def test_full_size_properties_1m_nodes(monkeypatch):
     pl.close()
 
 
+def test_consecutive_device_calls_share_the_device_and_stay_exact(monkeypatch):
+    """ugp_place_device overlaps consecutive calls on one handle (two internal streams, two sets of workspaces).  A sequence
+    of calls on different query sets and output buffers, with no synchronisation in between and a host-buffer call
+    (workspace set 0 on the default stream) thrown in, must give each batch its own exact answers; the summed timing
+    reports every call; UGP_NO_OVERLAP gives the same results on the caller's stream."""
+    import torch
+    from usher_amd import synth as gsynth
+    st = gsynth.SynthTree(400_000, n_sites=5000, seed=21)
+    qs = [st.queries(n, seed=50 + i, max_subst=3, n_lo=0, n_hi=20, iupac_hi=3) for i, n in enumerate((2100, 700, 4096))]
+    batches = [QueryBatch.from_csr(q["ent_off"], q["pos"], q["ref"], q["nuc"], q["is_missing"]) for q in qs]
+    pl = Placer(st.arrays)
+    want = [pl.place(b).view(np.int32).reshape(-1, 4).copy() for b in batches]
+    cf = capi.ClosedFormC(capi.OracleTree(st.arrays))
+    for q, w in zip(qs, want):
+        c = cf.place_csr(q["ent_off"], q["pos"], q["ref"], q["nuc"], q["is_missing"])
+        assert (w[:, 0] == c["best"]).all() and (w[:, 1] == c["num_best"]).all() and (w[:, 2] == c["best_j"]).all()
+    handles = [pl.upload(b) for b in batches]
+    stream = torch.cuda.current_stream().cuda_stream
+    pl.timing_sum()
+    outs = []
+    for rnd in range(4):
+        for i in (0, 1, 2, 1, 0):
+            o = torch.full((len(batches[i]), 4), -7, dtype=torch.int32, device="cuda")
+            pl.place_device(handles[i], o.data_ptr(), stream)
+            outs.append((i, o))
+        if rnd == 1:
+            mid = pl.place(batches[2]).view(np.int32).reshape(-1, 4)     # host buffers, synchronous, in the middle of the pipeline
+            assert (mid == want[2]).all()
+    torch.cuda.synchronize()
+    assert pl.timing_sum()["calls"] == 21
+    for i, o in outs:
+        assert (o.cpu().numpy() == want[i]).all(), i
+    monkeypatch.setenv("UGP_NO_OVERLAP", "1")     # (read once per process: this only checks that the switch is harmless here)
+    o = torch.zeros((len(batches[0]), 4), dtype=torch.int32, device="cuda")
+    pl.place_device(handles[0], o.data_ptr(), stream)
+    torch.cuda.synchronize()
+    assert (o.cpu().numpy() == want[0]).all()
+    for h in handles:
+        pl.free_qset(h)
+    pl.close()
+
+
 def test_sub_batching_and_tiny_batches():
     """More than 262,144 samples in one call (the library splits into sub-batches) and batches smaller
     than one tile give the same per-sample answers."""

@@ -66,6 +66,7 @@ SYMBOLS = {
     "ugp_qset_size": (C.c_uint64, [P]),
     "ugp_place_device": (C.c_int, [P, P, P, P]),
     "ugp_get_timing": (C.c_int, [P, C.POINTER(ugp_timing)]),
+    "ugp_get_timing_sum": (C.c_int, [P, C.POINTER(ugp_timing), C.POINTER(C.c_uint32)]),
     "ugp_last_error": (C.c_char_p, []),
     "ugp_fitch_sankoff": (C.c_int, [C.c_int, C.c_uint64, P, C.POINTER(ugp_sites), C.POINTER(P)]),
     "ugp_fitch_count": (C.c_uint64, [P]),

@@ -234,6 +234,15 @@ class Placer:
         _check(_lib.lib().ugp_get_timing(self._h, C.byref(out)))
         return {k: getattr(out, k) for k, _ in out._fields_}
 
+    def timing_sum(self) -> Dict:
+        """Durations summed over every call since the previous timing_sum() (waits for calls in flight); 'calls' = how many."""
+        out = _lib.ugp_timing()
+        n = C.c_uint32()
+        _check(_lib.lib().ugp_get_timing_sum(self._h, C.byref(out), C.byref(n)))
+        d = {k: getattr(out, k) for k, _ in out._fields_}
+        d["calls"] = int(n.value)
+        return d
+
 
 class MultiPlacer:
     """The same tree on several devices of one node (ugp_mat_create_multi: flattened once, uploaded n times).
