@@ -17,3 +17,15 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+def pytest_sessionstart(session):
+    """On a GPU box, let torch bring up ITS copy of the HIP runtime before libusher_amd.so (linked against /opt/rocm's)
+    loads its own: the other order leaves torch with "No HIP GPUs are available" in tests that use both (bench.py imports
+    torch first for the same reason).  device_count() itself does not touch the GPU."""
+    try:
+        import torch
+        if torch.cuda.device_count() > 0:
+            torch.cuda.init()
+    except Exception:
+        pass

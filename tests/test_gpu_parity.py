@@ -292,6 +292,10 @@ def test_consecutive_device_calls_share_the_device_and_stay_exact(monkeypatch):
         assert (w[:, 0] == c["best"]).all() and (w[:, 1] == c["num_best"]).all() and (w[:, 2] == c["best_j"]).all()
     handles = [pl.upload(b) for b in batches]
     stream = torch.cuda.current_stream().cuda_stream
+    first = torch.zeros((len(batches[1]), 4), dtype=torch.int32, device="cuda")
+    pl.place_device(handles[1], first.data_ptr(), stream)        # (the handle's first such call also sets up its second workspace set)
+    torch.cuda.synchronize()
+    assert (first.cpu().numpy() == want[1]).all()
     pl.timing_sum()
     outs = []
     for rnd in range(4):

@@ -134,6 +134,7 @@ struct ugp_mat {
     uint32_t tsum_calls = 0;
     int last_work = 0;       // set used by the most recent call (ugp_get_timing reports it)
     int next_work = 0;       // set the next ugp_place_device call takes
+    bool primed = false;     // both sets have been through one call
 };
 
 struct ugp_qset {
@@ -868,6 +869,16 @@ int ugp_place_device(ugp_mat *m, ugp_qset *qs, void *d_out, void *stream) {
     static const bool overlap = !getenv("UGP_NO_OVERLAP");
     if (!overlap) return run_place(m, qs, 0, (ugp_result *)d_out, nullptr, nullptr, nullptr, nullptr, nullptr, 0, (hipStream_t)stream);
     HIP_TRY(hipSetDevice(m->device));
+    if (!m->primed) {
+        // The handle's first call runs once on each workspace set (the second run is the one whose results stay): the buffers
+        // of both sets exist from then on, instead of the second call stalling the pipeline on device allocations.
+        m->primed = true;
+        ugp_mat::Work &W1 = m->work[1];
+        if (!W1.stream) HIP_TRY(hipStreamCreateWithFlags(&W1.stream, hipStreamNonBlocking));
+        if (int rc = run_place(m, qs, 0, (ugp_result *)d_out, nullptr, nullptr, nullptr, nullptr, nullptr, 0, W1.stream, false, nullptr, 1)) return rc;
+        HIP_TRY(hipStreamSynchronize(W1.stream));
+        m->next_work = 0;
+    }
     const int wi = m->next_work;
     m->next_work ^= 1;
     ugp_mat::Work &W = m->work[wi];
