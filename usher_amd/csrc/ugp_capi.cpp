@@ -135,6 +135,8 @@ struct ugp_mat {
     int last_work = 0;       // set used by the most recent call (ugp_get_timing reports it)
     int next_work = 0;       // set the next ugp_place_device call takes
     bool primed = false;     // both sets have been through one call
+    hipEvent_t kb_done = nullptr;    // behind the latest k_best8 launch of this handle ...
+    hipStream_t kb_done_on = nullptr;   // ... on this stream
 };
 
 struct ugp_qset {
@@ -513,7 +515,17 @@ int run_place(ugp_mat *m, ugp_qset *qs, int mode, ugp_result *d_out, int32_t *d_
             HIP_TRY(W.d_cold.reserve((size_t)blocks * std::max<uint32_t>(f.max_slots - b.lds_slots, 1) * 256));
             b.cold = W.d_cold.p;
             b.active = d_active; b.active_words = active_words;
+            // (UGP_KBEST_EXCLUSIVE: of the two calls that may be on the device at a time, ugp_place_device, only one runs this
+            // kernel at any moment -- measured: 2.77 against 2.71 ms per step when the two persistent grids simply share the
+            // chip; the small kernels in front of the second walk are slowed by the first and become the critical path)
+            static const bool exclusive = getenv("UGP_KBEST_EXCLUSIVE") != nullptr;
+            if (exclusive && !coarse_only && m->kb_done && m->kb_done_on != s) HIP_TRY(hipStreamWaitEvent(s, m->kb_done, 0));
             HIP_TRY(ugp::launch_best8(b, (uint32_t)blocks, s));
+            if (exclusive && !coarse_only) {
+                if (!m->kb_done) HIP_TRY(hipEventCreateWithFlags(&m->kb_done, hipEventDisableTiming));
+                HIP_TRY(hipEventRecord(m->kb_done, s));
+                m->kb_done_on = s;
+            }
             HIP_TRY(hipEventRecord(es.ev[2], s));
             if (coarse_only)
                 HIP_TRY(ugp::launch_coarse_result(W.d_lbest.p, W.d_list.p, d_list_n, f.n_chunks, n_tiles512, (uint32_t)nq, m->d_chunk_node.p,
@@ -770,6 +782,7 @@ void ugp_mat_destroy(ugp_mat *m) {
             for (int i = 0; i < 2; i++) if (G.ev_coarse[i]) (void)hipEventDestroy(G.ev_coarse[i]);
         }
     }
+    if (m->kb_done) (void)hipEventDestroy(m->kb_done);
     if (m->coarse) ugp_mat_destroy(m->coarse);
     delete m->own_qs;
     delete m;
