@@ -259,7 +259,7 @@ def test_full_size_properties_1m_nodes(monkeypatch):
     assert (slow.view(np.int32) == fast.view(np.int32)).all()
     # the work-unit machinery at its extremes: units that are never cut, units cut at every opportunity (thousands of
     # entries through the shared list, every wave waiting and exiting through it), one unit per side of a tile's ring
-    for env in ({"UGP_SPLIT_CYCLES": "0"}, {"UGP_SPLIT_CYCLES": "1"}, {"UGP_SPLIT_CYCLES": "1", "UGP_UNIT_GROW": "1", "UGP_UNIT_MAX": "1000000"},
+    for env in ({"UGP_SPLIT_CYCLES": "0"}, {"UGP_SPLIT_CYCLES": "1"}, {"UGP_LDS_BITS": "1"}, {"UGP_LDS_BITS": "1", "UGP_SPLIT_CYCLES": "1"}, {"UGP_SPLIT_CYCLES": "1", "UGP_UNIT_GROW": "1", "UGP_UNIT_MAX": "1000000"},
                 {"UGP_UNIT_GROW": "0", "UGP_SPLIT_CYCLES": "5000"}):
         for k, v in env.items():
             monkeypatch.setenv(k, v)
@@ -430,10 +430,12 @@ def test_randomised_trees_and_scheduling_knobs(seed, monkeypatch):
         knobs["UGP_UNIT_GROW"] = str(int(rng.choice([0, 1, 3])))
         knobs["UGP_UNIT_MAX"] = str(int(rng.choice([2, 40, 100000])))
         knobs["UGP_SPLIT_CYCLES"] = str(int(rng.choice([0, 1, 3000, 400000])))   # 1: a unit is cut at every restart while anyone waits
+    if rng.random() < 0.5:
+        knobs["UGP_LDS_BITS"] = str(int(rng.integers(0, 2)))    # the kernel variant with the tiles' active-row bitmaps in LDS
     if rng.random() < 0.3:
         knobs["UGP_PRE_WEIGHT"] = "50"
     for k in ("UGP_COARSE_MIN_NODES", "UGP_UNIT_CHUNKS", "UGP_HEAVY_CHUNKS", "UGP_UB_EVERY", "UGP_PRUNE_MIN_WORDS", "UGP_NO_LPT", "UGP_NO_SEED",
-              "UGP_NO_SORT", "UGP_NO_PRUNE", "UGP_FORCE_V1", "UGP_LDS_SLOTS", "UGP_NO_DESCENT", "UGP_NO_BOUND2", "UGP_UNIT_GROW", "UGP_UNIT_MAX", "UGP_SPLIT_CYCLES", "UGP_PRE_WEIGHT"):
+              "UGP_NO_SORT", "UGP_NO_PRUNE", "UGP_FORCE_V1", "UGP_LDS_SLOTS", "UGP_NO_DESCENT", "UGP_NO_BOUND2", "UGP_UNIT_GROW", "UGP_UNIT_MAX", "UGP_SPLIT_CYCLES", "UGP_LDS_BITS", "UGP_PRE_WEIGHT"):
         monkeypatch.delenv(k, raising=False)
     for k, v in knobs.items():
         monkeypatch.setenv(k, v)

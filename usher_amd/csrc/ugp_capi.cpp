@@ -501,7 +501,13 @@ int run_place(ugp_mat *m, ugp_qset *qs, int mode, ugp_result *d_out, int32_t *d_
             b.lds_slots = f.lds_slots;   // fixed when the tree was flattened (headers touching colder slots are flagged there)
             // persistent grid: as many one-wave blocks as the device keeps resident (cached per handle and LDS
             // size), never more than there are units; the cold-slot scratch is sized for exactly that grid
-            const size_t lds_bytes = (size_t)b.lds_slots * 64 * 16;
+            // The variant with the tile's active-row bitmap in LDS (up to 4 KB of it, i.e. 32,768 sites): a restart of the walk is two
+            // memory round trips instead of three, for 3 KB more LDS per wave (13 resident waves per CU instead of 17).  Measured:
+            // k_best8 4.52 -> 4.09 ms at 65,536 samples, where the launch is long enough to be bound by its throughput; 1.87 -> 1.97 ms
+            // at 16,384, where the tail of the launch and the number of resident waves matter more.  Hence: from 64 tiles on.
+            b.lds_bits = (!b.stats && (size_t)active_words * 4 <= 4096 && n_tiles512 >= 64) ? 1u : 0u;
+            if (const char *e = getenv("UGP_LDS_BITS")) b.lds_bits = (!b.stats && (size_t)active_words * 4 <= 4096 && atoi(e) != 0) ? 1u : 0u;
+            const size_t lds_bytes = (size_t)b.lds_slots * 64 * 16 + (b.lds_bits ? (((size_t)active_words * 4 + 15) & ~(size_t)15) : 0);
             if (m->occ_lds != lds_bytes) {
                 HIP_TRY(hipDeviceGetAttribute(&m->n_cu, hipDeviceAttributeMultiprocessorCount, m->device));
                 HIP_TRY(ugp::best8_occupancy(lds_bytes, &m->occ_per_cu));

@@ -593,7 +593,11 @@ __device__ __forceinline__ uint32_t ex4(uint32_t acc, int j) { return (acc >> (4
 __device__ __forceinline__ uint32_t padd(uint32_t a, uint32_t b) { return a + b; }
 __device__ __forceinline__ uint32_t psub(uint32_t a, uint32_t b) { return a - b; }
 
-template <bool STATS>   // STATS: per-unit accounting for tuning (UGP_STATS); off in production, it costs SGPRs
+// LBITS: the tile's active-row bitmap (one bit per site, a.active_words dwords) lives in LDS behind the slot rows, copied there
+// whenever the wave moves to another tile.  A restart of the pipelined loop is then two dependent memory round trips (stream
+// words, table rows) instead of three (words, bitmap bits, rows), and the steady loop issues one load less per group.  Costs
+// ~3 KB of LDS per wave (fewer resident waves); the host takes this variant when the bitmap is small enough.
+template <bool STATS, bool LBITS>   // STATS: per-unit accounting for tuning (UGP_STATS); off in production, it costs SGPRs
 __global__ void __launch_bounds__(64, 5) k_best8(Best8Args a) {
     extern __shared__ __attribute__((aligned(16))) u32x4 slots8[];   // [lds_slots][64] x 16 B: the hot saved-D slots
     const uint32_t lane = threadIdx.x;
@@ -622,6 +626,7 @@ __global__ void __launch_bounds__(64, 5) k_best8(Best8Args a) {
 #pragma unroll
     for (int j = 0; j < 4; j++) { ub1.v[j] = 0x80008000u; ubv1.v[j] = 0x7F807F80u; }
     uint32_t ub_tile = 0xFFFFFFFFu;   // uniform: tile whose bounds are in ub1
+    uint32_t bits_tile = 0xFFFFFFFFu; // uniform (LBITS): tile whose active-row bitmap is in LDS
     uint32_t ub_age = 0;              // uniform: chunk ends since the last exchange
     for (;;) {
     const uint64_t t_pull0 = STATS ? __builtin_amdgcn_s_memtime() : 0;
@@ -1014,6 +1019,12 @@ __global__ void __launch_bounds__(64, 5) k_best8(Best8Args a) {
     // Every load is in a fixed order, which keeps the compiler's vmcnt bookkeeping exact
     // (s_waitcnt vmcnt(N) with the younger loads still in flight).
     const uint32_t *abm = a.active + (uint64_t)tile * a.active_words;
+    __attribute__((address_space(3))) uint32_t *lbits = (__attribute__((address_space(3))) uint32_t *)((__attribute__((address_space(3))) char *)slots8 + a.lds_slots * 1024u);
+    if (LBITS && bits_tile != tile) {   // (one coalesced copy per change of tile, in flight together with the unit's other first loads)
+        for (uint32_t i = lane; i < a.active_words; i += 64u) lbits[i] = abm[i];
+        bits_tile = tile;
+        __syncthreads();   // (one wave per block: orders the writes before the other lanes' reads)
+    }
     const uint64_t t_wave0 = STATS ? __builtin_amdgcn_s_memtime() : 0;
     const uint64_t tr_start = STATS ? __builtin_amdgcn_s_memrealtime() : 0;
     uint64_t t_restart = 0, n_restart = 0;
@@ -1036,7 +1047,7 @@ __global__ void __launch_bounds__(64, 5) k_best8(Best8Args a) {
         };
         auto load_bits = [&](uint32_t wv) -> uint32_t {     // per lane: bitmap dword of its word's site
             const uint32_t site = (wv & H_TAG) ? 0u : (wv & 0x3FFFFFu);
-            return abm[site >> 5];
+            return LBITS ? lbits[site >> 5] : abm[site >> 5];
         };
         // Per-lane decoding of a group (lane k of every 8 holds word k): byte offset of the word's table row -- the
         // site's own row if some sample of the tile is non-reference there, else the constant row of the site's
@@ -1744,14 +1755,15 @@ hipError_t launch_merge(const uint32_t *part_best, const uint32_t *part_cnt, con
 
 // Resident one-wave blocks of k_best8 per CU for a given dynamic LDS size, on the current device.
 hipError_t best8_occupancy(size_t lds_bytes, int *per_cu) {
-    return hipOccupancyMaxActiveBlocksPerMultiprocessor(per_cu, k_best8<false>, 64, lds_bytes);
+    return hipOccupancyMaxActiveBlocksPerMultiprocessor(per_cu, k_best8<false, false>, 64, lds_bytes);
 }
 
 // Persistent grid of `blocks` one-wave workgroups (the caller sizes a.cold for exactly that many).
 hipError_t launch_best8(const Best8Args &a, uint32_t blocks, hipStream_t s) {
     const size_t lds = (size_t)a.lds_slots * 64 * 16;
-    if (a.stats) hipLaunchKernelGGL(k_best8<true>, dim3(blocks), dim3(64), lds, s, a);
-    else hipLaunchKernelGGL(k_best8<false>, dim3(blocks), dim3(64), lds, s, a);
+    if (a.stats) hipLaunchKernelGGL((k_best8<true, false>), dim3(blocks), dim3(64), lds, s, a);
+    else if (a.lds_bits) hipLaunchKernelGGL((k_best8<false, true>), dim3(blocks), dim3(64), lds + (((size_t)a.active_words * 4 + 15) & ~(size_t)15), s, a);
+    else hipLaunchKernelGGL((k_best8<false, false>), dim3(blocks), dim3(64), lds, s, a);
     return hipGetLastError();
 }
 

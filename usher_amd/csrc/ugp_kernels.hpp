@@ -55,6 +55,7 @@ struct Best8Args {
     uint32_t *dyn_ctl;         // head, tail, active and waiting waves of the shared list of split-off units (one 128-byte line each)
     unsigned long long *dyn_units;   // [dyn_cap] {epoch:11 | own region:1 | tile:12 | c1:20 | c0:20}: an entry counts once it carries this launch's epoch
     uint32_t dyn_cap, dyn_epoch;
+    uint32_t lds_bits;         // the kernel variant that keeps the tile's active-row bitmap in LDS
     uint32_t no_pre_records;   // the preamble replay ignores its pruning records (units longer than their jump field reaches)
     uint32_t split_heavy;      // the same for the units of the tiles' own regions (dense: both halves are real work)
     uint32_t split_cycles;     // a unit running longer than this hands half of its remainder to the shared list when waves wait for work (0xFFFFFFFF: never)
