@@ -135,6 +135,7 @@ struct ugp_mat {
     int last_work = 0;       // set used by the most recent call (ugp_get_timing reports it)
     int next_work = 0;       // set the next ugp_place_device call takes
     bool primed = false;     // both sets have been through one call
+    bool sharing = false;    // (during a ugp_place_device call) the other set's call was still running when this one was queued
     hipEvent_t kb_done = nullptr;    // behind the latest k_best8 launch of this handle ...
     hipStream_t kb_done_on = nullptr;   // ... on this stream
 };
@@ -244,6 +245,7 @@ int run_place(ugp_mat *m, ugp_qset *qs, int mode, ugp_result *d_out, int32_t *d_
         HIP_TRY(hipEventRecord(TG.ev_coarse[0], s));
         // (UGP_COARSE_FAST: skip the pre-pass's phase 2 and sort by the chunk of the minimum instead of the exact node --
         // measured: pre-pass 0.64 -> 0.45 ms, but the coarser tiles cost the main pass 0.3 ms; off by default)
+        m->coarse->sharing = m->sharing;
         if (int rc = run_place(m->coarse, qs, 0, W.d_coarse_res.p, nullptr, nullptr, nullptr, nullptr, nullptr, 0, s, getenv("UGP_COARSE_FAST") != nullptr, nullptr, wi)) return rc;
         HIP_TRY(hipSetDevice(m->device));
         HIP_TRY(hipEventRecord(TG.ev_coarse[1], s));
@@ -505,7 +507,9 @@ int run_place(ugp_mat *m, ugp_qset *qs, int mode, ugp_result *d_out, int32_t *d_
             // memory round trips instead of three, for 3 KB more LDS per wave (13 resident waves per CU instead of 17).  Measured:
             // k_best8 4.52 -> 4.09 ms at 65,536 samples, where the launch is long enough to be bound by its throughput; 1.87 -> 1.97 ms
             // at 16,384, where the tail of the launch and the number of resident waves matter more.  Hence: from 64 tiles on.
-            b.lds_bits = (!b.stats && (size_t)active_words * 4 <= 4096 && n_tiles512 >= 64) ? 1u : 0u;
+            // (not when two calls share the device: the grids are halved then, and the LDS is better spent on resident waves --
+            // 65,536 samples per call, pipelined: 10.5 M/s with, 11.0 M/s without)
+            b.lds_bits = (!b.stats && (size_t)active_words * 4 <= 4096 && n_tiles512 >= 64 && !m->sharing) ? 1u : 0u;
             if (const char *e = getenv("UGP_LDS_BITS")) b.lds_bits = (!b.stats && (size_t)active_words * 4 <= 4096 && atoi(e) != 0) ? 1u : 0u;
             const size_t lds_bytes = (size_t)b.lds_slots * 64 * 16 + (b.lds_bits ? (((size_t)active_words * 4 + 15) & ~(size_t)15) : 0);
             if (m->occ_lds != lds_bytes) {
@@ -514,7 +518,12 @@ int run_place(ugp_mat *m, ugp_qset *qs, int mode, ugp_result *d_out, int32_t *d_
                 m->occ_lds = lds_bytes;
             }
             int waves_cu = std::max(m->occ_per_cu, 1);
-            if (const char *e = getenv("UGP_WAVES_PER_CU")) waves_cu = std::max(1, std::min(waves_cu, atoi(e)));   // tuning
+            // Two calls on the device (ugp_place_device, the other set's call still running when this one is queued): each walk
+            // takes half of what the device keeps resident, so that both grids ARE resident instead of one waiting for the other's
+            // waves to exit -- measured at 16,384 samples per call: 2.71 -> 2.29 ms per call (6.05 -> 7.2 M placements/s), best at
+            // 8 of 17 waves per CU (7: 2.32, 9: 2.39, 12: 2.51).  A call that finds the device to itself keeps the full grid.
+            if (m->sharing) waves_cu = std::max(1, getenv("UGP_SHARED_WAVES") ? atoi(getenv("UGP_SHARED_WAVES")) : waves_cu / 2);
+            if (const char *e = getenv("UGP_WAVES_PER_CU")) waves_cu = std::max(1, std::min(std::max(m->occ_per_cu, 1), atoi(e)));   // tuning
             uint64_t blocks = (uint64_t)waves_cu * std::max(m->n_cu, 1);
             blocks = std::min<uint64_t>(blocks, (uint64_t)n_tiles512 * G);
             blocks = ((blocks + 7) / 8) * 8;
@@ -902,6 +911,13 @@ int ugp_place_device(ugp_mat *m, ugp_qset *qs, void *d_out, void *stream) {
     m->next_work ^= 1;
     ugp_mat::Work &W = m->work[wi];
     if (!W.stream) HIP_TRY(hipStreamCreateWithFlags(&W.stream, hipStreamNonBlocking));
+    {   // is the other set's call still on the device?  (then this call's tree walk leaves it half of the chip)
+        const ugp_mat::Work &O = m->work[wi ^ 1];
+        m->sharing = O.done && hipEventQuery(O.done) == hipErrorNotReady;
+        (void)hipGetLastError();   // (hipErrorNotReady is not an error)
+        if (getenv("UGP_DEBUG_SHARING")) fprintf(stderr, "[ugp] call on set %d: sharing=%d\n", wi, (int)m->sharing);
+    }
+    struct Unshare { ugp_mat *m; ~Unshare() { m->sharing = false; } } unshare{m};
     if (int rc = run_place(m, qs, 0, (ugp_result *)d_out, nullptr, nullptr, nullptr, nullptr, nullptr, 0, W.stream, false, nullptr, wi)) return rc;
     if (W.done) HIP_TRY(hipStreamWaitEvent((hipStream_t)stream, W.done, 0));   // (recorded at the end of run_place)
     return UGP_OK;
