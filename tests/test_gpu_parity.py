@@ -320,6 +320,28 @@ def test_consecutive_device_calls_share_the_device_and_stay_exact(monkeypatch):
     pl.close()
 
 
+@pytest.mark.parametrize("seed,n_queries", [(61, 70), (62, 33), (63, 1), (64, 257)])
+def test_per_node_scores_by_levels_and_by_depth_first_walk(seed, n_queries, monkeypatch):
+    """ugp_scores_per_node (-p): the level-by-level kernel (k_scores_level: one thread per node, 32 samples per step, 4-bit
+    counters with the plain-sum path for branches of more than 15 mutations) and the depth-first walk (UGP_SCORES_DFS) against
+    the oracle's per-node scores -- long branches, masked mutations, root mutations, N / IUPAC cells, batches that are no
+    multiple of 8 or 32 samples."""
+    arrays, queries = synth.make_case(seed, n_leaves=700, n_queries=n_queries, n_sites=150, p_masked=0.04, root_muts=seed % 3,
+                                      mut_counts=(0, 0, 1, 1, 1, 2, 3, 17, 40), n_ambig=(0, 0, 2, 5, 30))
+    ot = capi.OracleTree(arrays)
+    want = np.stack([ot.place(s, compute_scores=True)["scores"] for s in queries])
+    batch = QueryBatch(queries)
+    for env in ({}, {"UGP_SCORES_DFS": "1"}):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        pl = Placer(arrays, chunk_nodes=40)
+        got = pl.scores_per_node(batch)
+        pl.close()
+        for k in env:
+            monkeypatch.delenv(k)
+        assert got.shape == want.shape and (got == want).all(), (env, np.argwhere(got != want)[:5])
+
+
 def test_sub_batching_and_tiny_batches():
     """More than 262,144 samples in one call (the library splits into sub-batches) and batches smaller
     than one tile give the same per-sample answers."""

@@ -26,6 +26,11 @@ tm = pl.timing()
 cells = Q * n
 print("scores_per_node: %d samples x %d nodes: %.3f s wall (%.1f samples/s, %.2f GB/s of int32 output incl. PCIe); kernel %.3f ms = %.1f GB/s of output written"
       % (Q, n, dt, Q / dt, cells * 4 / dt / 1e9, tm["place_ms"], cells * 4 / (tm["place_ms"] * 1e-3) / 1e9))
+# k_scores_level's algorithmic bytes per (node, sample): 4 out + 2 D read (16-bit D) + 2 D written by the nodes that have children
+internal = len(np.unique(st.arrays["parent"][1:]))
+algo = cells * 6.0 + internal * Q * 2.0
+print("roofline (HBM, level-by-level kernel): %.2f GB algorithmic per call / %.3f ms = %.0f GB/s = %.1f %% of 8 TB/s"
+      % (algo / 1e9, tm["place_ms"], algo / (tm["place_ms"] * 1e-3) / 1e9, algo / (tm["place_ms"] * 1e-3) / 8e12 * 100))
 ot = capi.OracleTree(st.arrays)
 cf = capi.ClosedFormC(ot)
 for i in (0, Q // 2, Q - 1):

@@ -89,6 +89,8 @@ struct ugp_mat {
     DevBuf<uint32_t> d_coarse2bfs, d_node_pair, d_parent;   // seed descent (k_descend)
     bool wide_descent = false;
     DevBuf<uint32_t> d_coarse2dfs;
+    std::vector<uint32_t> h_level_off;   // breadth-first level boundaries (empty: the input is not a breadth-first expansion)
+    uint32_t max_level_width = 0;
     // extended searches (ugp_place_batch_ex): host copy of the topology, the reference's depth-first order and its tie rank
     std::vector<uint32_t> h_parent, h_dfs2bfs, h_bfs2dfs;
     DevBuf<uint32_t> d_dfs_rank, d_dfs_rank2out, d_bfs2dfs;
@@ -340,7 +342,7 @@ int run_place(ugp_mat *m, ugp_qset *qs, int mode, ugp_result *d_out, int32_t *d_
                 const uint32_t *refined = nullptr;
                 // (not with UGP_COARSE_FAST: the descent derives D of its start node from "cost(best_j) == best", which only
                 // the exact coarse placement guarantees)
-                if (m->d_node_pair.p && !getenv("UGP_NO_DESCENT") && !getenv("UGP_COARSE_FAST")) {
+                if (m->d_node_pair.p && m->d_coarse2bfs.p && !getenv("UGP_NO_DESCENT") && !getenv("UGP_COARSE_FAST")) {
                     HIP_TRY(W.d_refined.reserve(nq));
                     HIP_TRY(ugp::launch_descend(W.d_coarse_res.p + q0, order, (uint32_t)nq, m->d_coarse2bfs.p, m->d_node_pair.p,
                                                 m->d_parent.p, m->d_stream.p, W.d_table.p, n_sites, W.d_refined.p, m->wide_descent, s));
@@ -549,6 +551,17 @@ int run_place(ugp_mat *m, ugp_qset *qs, int mode, ugp_result *d_out, int32_t *d_
                 HIP_TRY(ugp::launch_phase2(a, W.d_lbest.p, W.d_list.p, d_list_n, W.d_gbest_part.p, W.d_gbest.p, n_tiles512, W.d_items.p, d_nitems,
                                            (uint32_t)std::min<uint64_t>(pairs, 0xFFFFFFFFull), d_cnt, d_key,
                                            m->d_rank2bfs.p, d_out + q0, order, f.max_slots, s));
+        } else if (mode == 1 && !ex && !m->h_level_off.empty() && !getenv("UGP_SCORES_DFS")) {
+            // -p in the output's own order: level by level of the breadth-first expansion, 64 consecutive scores of one sample per
+            // wave store (k_scores_level); the depth-first walk below writes 4 bytes per 32-byte sector
+            const uint32_t qpad = (uint32_t)((nq + 7) / 8 * 8);
+            const bool d16 = qs->max_rows + f.max_path_muts + 2 < 0xFFFFull;
+            const size_t d_words = ((size_t)m->max_level_width * ((qpad + 31) / 32 * 32) * (d16 ? 2 : 4) + 3) / 4;
+            HIP_TRY(W.d_part_best.reserve(d_words)); HIP_TRY(W.d_part_cnt.reserve(d_words));   // (the two D arrays; this mode has no partial results)
+            HIP_TRY(ugp::launch_scores_levels(m->d_node_pair.p, m->d_parent.p, m->d_stream.p, W.d_table.p, n_sites, d_dbottom, m->h_level_off.data(),
+                                              (uint32_t)m->h_level_off.size() - 1, W.d_part_best.p, W.d_part_cnt.p, d16, m->max_level_width, qpad, (uint32_t)nq, f.n_nodes,
+                                              a.scores, s));
+            HIP_TRY(hipEventRecord(es.ev[2], s));
         } else {
             HIP_TRY(ugp::launch_place(a, ex ? mode + 4 : mode, f.max_slots, s));
             HIP_TRY(hipEventRecord(es.ev[2], s));
@@ -668,7 +681,8 @@ static int host_flatten(const ugp_tree_desc *tree, const ugp::Options &opt, bool
         if (rc == UGP_OK && with_coarse) {
             rc = build_coarse(tree, opt, ex, hf);
             if (rc != UGP_OK) return rc;   // (message already set)
-            if (hf.coarse) { hf.node_pair.swap(ex.node_pair); hf.wide_descent = ex.children_of_wide_nodes * 20 > tree->n_nodes; }
+            hf.node_pair.swap(ex.node_pair);   // (empty when the input is not a breadth-first expansion)
+            if (hf.coarse) hf.wide_descent = ex.children_of_wide_nodes * 20 > tree->n_nodes;
         }
     } catch (const std::bad_alloc &) {
         return fail(UGP_ERR_NOMEM, "out of host memory while flattening the tree");
@@ -724,14 +738,28 @@ static int upload_flat(const HostFlat &hf, int device, ugp_mat **out) {
     m->stream_dwords = f.stream.size();
     m->pre_dwords = f.pre_stream.size();
     m->h_parent = hf.parent;
+    if (!hf.node_pair.empty()) {
+        // A breadth-first expansion: {first child - 1, record offset} per node and the parent array on the device (seed descent,
+        // per-node scores by levels), and the level boundaries (a level is an index range).
+        if ((e = m->d_node_pair.upload(hf.node_pair)) != hipSuccess) return bail(e, "upload node table");
+        if ((e = m->d_parent.upload(hf.parent)) != hipSuccess) return bail(e, "upload parent table");
+        const uint64_t N = f.n_nodes;
+        std::vector<uint32_t> level(N, 0);
+        m->h_level_off.assign(1, 0);
+        for (uint64_t j = 1; j < N; j++) {
+            level[j] = level[hf.parent[j]] + 1;
+            if (level[j] != level[j - 1]) m->h_level_off.push_back((uint32_t)j);   // (levels are non-decreasing in a breadth-first numbering)
+        }
+        m->h_level_off.push_back((uint32_t)N);
+        m->max_level_width = 0;
+        for (size_t l = 0; l + 1 < m->h_level_off.size(); l++) m->max_level_width = std::max(m->max_level_width, m->h_level_off[l + 1] - m->h_level_off[l]);
+    }
     if (hf.coarse) {
         if (int rc = upload_flat(*hf.coarse, device, &m->coarse)) { ugp_mat_destroy(m); return rc; }
         if ((e = m->d_coarse2dfs.upload(hf.coarse2dfs)) != hipSuccess) return bail(e, "upload coarse table");
-        if (!hf.node_pair.empty() && !getenv("UGP_NO_DESCENT")) {
+        if (!hf.node_pair.empty()) {
             if ((e = m->d_coarse2bfs.upload(hf.coarse2bfs)) != hipSuccess) return bail(e, "upload coarse table");
-            if ((e = m->d_node_pair.upload(hf.node_pair)) != hipSuccess) return bail(e, "upload node table");
             m->wide_descent = getenv("UGP_DESCENT_LANES") ? atoi(getenv("UGP_DESCENT_LANES")) > 16 : hf.wide_descent;
-            if ((e = m->d_parent.upload(hf.parent)) != hipSuccess) return bail(e, "upload parent table");
         }
     }
     *out = m;

@@ -541,6 +541,128 @@ __global__ void k_merge(const uint32_t *__restrict__ part_best, const uint32_t *
 }
 
 // ====================================================================
+// Per-node scores (-p), level by level
+// ====================================================================
+//
+// out[q * n_nodes + j] for every sample q and every node j in the reference's breadth-first index
+// (usher_common.cpp:406-412, 557-578): the product is its own output, 4 bytes per (node, sample), laid out with the
+// NODE index running fastest.  A depth-first walk (k_place<1>) writes one sample's scores to addresses all over its
+// 40 MB row -- one 4-byte store per 32-byte sector, 3.6 % of the HBM write rate.  Here the tree is walked in the
+// output's own order: one launch per level of the breadth-first expansion (a level is an index range), one thread
+// per node, so the 64 lanes of a wave store 64 consecutive scores of one sample: 256-byte stores.  What a depth-
+// first walk gets for free, D(parent), comes from the previous level's D array (children of a node are neighbours:
+// their lanes read the same 16 bytes), and each level leaves its own D behind -- only for nodes that have children.
+// Per (node, 8 samples): one 16- or 32-byte D read, one table dword per mutation (a 32-byte sector out of L2), 8
+// coalesced stores, one D write.  Algorithmic bytes per (node, sample): 4 out + 2 x sizeof(D) = 8 (12 with 32-bit D).
+// The node's record is the 32-bit stream's (w0: mutation count, leaf / root / masked flags; one word per mutation).
+// Needs a tree numbered as a breadth-first expansion (node_pair: {first child - 1, record offset} per node).
+template <typename DT>
+__global__ void __launch_bounds__(256) k_scores_level(const uint2 *__restrict__ node_pair, const uint32_t *__restrict__ parent,
+                                                      const uint32_t *__restrict__ stream, const uint32_t *__restrict__ table, uint32_t n_sites,
+                                                      const uint32_t *__restrict__ dbottom, uint32_t lv_begin, uint32_t lv_end, uint32_t prev_begin,
+                                                      const DT *__restrict__ d_prev, DT *__restrict__ d_cur, uint32_t d_stride /* nodes per 32-sample block */,
+                                                      uint32_t qpad, uint32_t n_queries, uint64_t n_nodes, int32_t *__restrict__ scores) {
+    const uint32_t n = lv_begin + blockIdx.x * 256u + threadIdx.x;
+    if (n >= lv_end) return;
+    const uint32_t *rec = stream + node_pair[n].y;
+    const uint32_t w0 = rec[0];
+    const uint32_t nmut = w0 & 0xFFFFu;
+    const bool root = (w0 & F_ROOT) != 0, leaf = (w0 & F_LEAF) != 0, masked = (w0 & F_MASKED) != 0;
+    const uint32_t m0 = nmut > 0 ? rec[2] : 0u, m1 = nmut > 1 ? rec[3] : 0u;   // (most nodes carry at most two mutations: kept in registers)
+    // D arrays: [block of 32 samples][node of the level][32] -- the lanes of a wave (consecutive nodes) read and write
+    // consecutive 64- or 128-byte pieces; the children of a node read the same piece
+    const uint64_t prow = root ? 0 : (uint64_t)(parent[n] - prev_begin) * 32u;
+    const uint64_t crow = (uint64_t)(n - lv_begin) * 32u;
+    const uint32_t n_rows = n_sites + TABLE_CONST_ROWS;
+    const bool free_internal = !leaf && !masked && nmut == 0;
+    for (uint32_t qb = blockIdx.y; qb * 32u < qpad; qb += gridDim.y) {   // 32 samples = four dwords (16 bytes) of a table row
+        const uint32_t q0 = qb * 32u;
+        const uint32_t *trow = table + ((uint64_t)(q0 >> 9) * n_rows + TABLE_CONST_ROWS) * 64 + ((q0 & 511u) >> 3);   // + 64 * site: 16-byte aligned
+        // per dword (8 samples) 4-bit counters, as in k_best8: P = prev in S, C = mut in S over all words (D), Cb / N = C and C & ~P over
+        // the words in front of the node's first masked mutation (eligibility, cost).  A node with more than 15 words (rare) takes
+        // the plain sums instead.
+        uint32_t aP[4] = {0, 0, 0, 0}, aC[4] = {0, 0, 0, 0}, aN[4] = {0, 0, 0, 0}, aCb[4] = {0, 0, 0, 0};
+        const bool small = nmut <= 15u;
+        if (small) {
+            for (uint32_t m = 0; m < nmut; m++) {
+                const uint32_t w = m == 0 ? m0 : (m == 1 ? m1 : rec[2 + m]);
+                const uint4 xv = *(const uint4 *)(trow + (uint64_t)(w & 0x3FFFFFu) * 64);
+                const uint32_t x[4] = {xv.x, xv.y, xv.z, xv.w};
+                const uint32_t mi = (w >> 22) & 3u, pi = (w >> 24) & 3u;
+                const uint32_t bm = (w & M_AFTER_MASK) ? 0u : 0x11111111u;   // in front of the node's first masked mutation (usher_mapper.cpp:197-200)
+#pragma unroll
+                for (int t = 0; t < 4; t++) {
+                    const uint32_t C = (x[t] >> mi) & 0x11111111u, P = (x[t] >> pi) & 0x11111111u;
+                    aP[t] += P; aC[t] += C; aN[t] += C & ~P & bm; aCb[t] += C & bm;
+                }
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            const uint32_t qg = q0 + t * 8;
+            if (qg >= qpad) break;
+            uint32_t dpar[8];
+            if (root) {
+#pragma unroll
+                for (int j = 0; j < 8; j++) dpar[j] = dbottom[qg + j];
+            } else {
+                const DT *src = d_prev + (uint64_t)qb * d_stride * 32u + prow + t * 8;
+                if (sizeof(DT) == 2) {
+                    const uint4 v = *(const uint4 *)src;
+                    dpar[0] = v.x & 0xFFFFu; dpar[1] = v.x >> 16; dpar[2] = v.y & 0xFFFFu; dpar[3] = v.y >> 16;
+                    dpar[4] = v.z & 0xFFFFu; dpar[5] = v.z >> 16; dpar[6] = v.w & 0xFFFFu; dpar[7] = v.w >> 16;
+                } else {
+                    const uint4 v0 = *(const uint4 *)src, v1 = *((const uint4 *)src + 1);
+                    dpar[0] = v0.x; dpar[1] = v0.y; dpar[2] = v0.z; dpar[3] = v0.w; dpar[4] = v1.x; dpar[5] = v1.y; dpar[6] = v1.z; dpar[7] = v1.w;
+                }
+            }
+            uint32_t dnew[8], negs[8], comm[8];
+            if (small) {
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    dnew[j] = dpar[j] + ((aP[t] >> (4 * j)) & 15u) - ((aC[t] >> (4 * j)) & 15u);
+                    negs[j] = (aN[t] >> (4 * j)) & 15u;
+                    comm[j] = (aCb[t] >> (4 * j)) & 15u;
+                }
+            } else {   // a long branch: plain sums, one dword of the row per word
+                int ts[8];
+#pragma unroll
+                for (int j = 0; j < 8; j++) { ts[j] = 0; negs[j] = 0; comm[j] = 0; }
+                for (uint32_t m = 0; m < nmut; m++) {
+                    const uint32_t w = rec[2 + m];
+                    const uint32_t x = trow[(uint64_t)(w & 0x3FFFFFu) * 64 + t];
+                    const uint32_t mi = (w >> 22) & 3u, pi = (w >> 24) & 3u;
+                    const bool before = !(w & M_AFTER_MASK);
+#pragma unroll
+                    for (int j = 0; j < 8; j++) {
+                        const uint32_t nib = (x >> (4 * j)) & 15u;
+                        const uint32_t c = (nib >> mi) & 1u, pp = (nib >> pi) & 1u;
+                        ts[j] += (int)pp - (int)c;
+                        if (before) { comm[j] += c; negs[j] += c & ~pp & 1u; }
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < 8; j++) dnew[j] = dpar[j] + (uint32_t)ts[j];
+            }
+            if (!leaf) {
+                DT *dst = d_cur + (uint64_t)qb * d_stride * 32u + crow + t * 8;
+                if (sizeof(DT) == 2)
+                    *(uint4 *)dst = make_uint4((dnew[0] & 0xFFFFu) | (dnew[1] << 16), (dnew[2] & 0xFFFFu) | (dnew[3] << 16), (dnew[4] & 0xFFFFu) | (dnew[5] << 16),
+                                               (dnew[6] & 0xFFFFu) | (dnew[7] << 16));
+                else { *(uint4 *)dst = make_uint4(dnew[0], dnew[1], dnew[2], dnew[3]); *((uint4 *)dst + 1) = make_uint4(dnew[4], dnew[5], dnew[6], dnew[7]); }
+            }
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                uint32_t sc;
+                if (root) sc = dnew[j];                                        // cost(root) = D(root), always eligible (usher_mapper.cpp:454)
+                else sc = dpar[j] - negs[j] + ((comm[j] > 0 || free_internal) ? 0u : 1u);   // + 1 when not eligible (:498-502)
+                if (qg + j < n_queries) scores[(uint64_t)(qg + j) * n_nodes + n] = (int32_t)sc;
+            }
+        }
+    }
+}
+
+// ====================================================================
 // Phase 1: 8 samples per lane, packed 16-bit, minimum only
 // ====================================================================
 //
@@ -1741,6 +1863,28 @@ hipError_t launch_place(const PlaceArgs &a, int mode, uint32_t max_slots, hipStr
     else if (mode == 2) hipLaunchKernelGGL((k_place<2, false>), dim3(blocks), dim3(64), lds, s, a);
     else if (mode == 4) hipLaunchKernelGGL((k_place<0, true>), dim3(blocks), dim3(64), lds, s, a);
     else hipLaunchKernelGGL((k_place<2, true>), dim3(blocks), dim3(64), lds, s, a);
+    return hipGetLastError();
+}
+
+// One launch per level; level_off: host array of the breadth-first level boundaries.  d16: D fits 16 bits.
+hipError_t launch_scores_levels(const uint32_t *node_pair, const uint32_t *parent, const uint32_t *stream, const uint32_t *table, uint32_t n_sites,
+                                const uint32_t *dbottom, const uint32_t *level_off, uint32_t n_levels, void *d_a, void *d_b, bool d16, uint32_t d_stride,
+                                uint32_t qpad, uint32_t n_queries, uint64_t n_nodes, int32_t *scores, hipStream_t s) {
+    for (uint32_t l = 0; l < n_levels; l++) {
+        const uint32_t b = level_off[l], e = level_off[l + 1], pb = l ? level_off[l - 1] : 0u;
+        if (e <= b) continue;
+        const uint32_t bx = (e - b + 255u) / 256u;
+        // narrow levels: the sample groups spread over blockIdx.y so that the top of the tree does not run on a handful of waves
+        uint32_t by = 1;
+        while (by < (qpad + 31u) / 32u && (uint64_t)bx * by < 2048u) by *= 2;
+        void *prev = (l & 1u) ? d_a : d_b, *cur = (l & 1u) ? d_b : d_a;
+        if (d16)
+            hipLaunchKernelGGL(k_scores_level<uint16_t>, dim3(bx, by), dim3(256), 0, s, (const uint2 *)node_pair, parent, stream, table, n_sites, dbottom, b, e, pb,
+                               (const uint16_t *)prev, (uint16_t *)cur, d_stride, qpad, n_queries, n_nodes, scores);
+        else
+            hipLaunchKernelGGL(k_scores_level<uint32_t>, dim3(bx, by), dim3(256), 0, s, (const uint2 *)node_pair, parent, stream, table, n_sites, dbottom, b, e, pb,
+                               (const uint32_t *)prev, (uint32_t *)cur, d_stride, qpad, n_queries, n_nodes, scores);
+    }
     return hipGetLastError();
 }
 
