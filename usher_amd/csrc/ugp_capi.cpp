@@ -556,7 +556,7 @@ int run_place(ugp_mat *m, ugp_qset *qs, int mode, ugp_result *d_out, int32_t *d_
             // wave store (k_scores_level); the depth-first walk below writes 4 bytes per 32-byte sector
             const uint32_t qpad = (uint32_t)((nq + 7) / 8 * 8);
             const bool d16 = qs->max_rows + f.max_path_muts + 2 < 0xFFFFull;
-            const size_t d_words = ((size_t)m->max_level_width * ((qpad + 31) / 32 * 32) * (d16 ? 2 : 4) + 3) / 4;
+            const size_t d_words = ((size_t)m->max_level_width * ((qpad + ugp::SCORES_SB - 1) / ugp::SCORES_SB * ugp::SCORES_SB) * (d16 ? 2 : 4) + 3) / 4;
             HIP_TRY(W.d_part_best.reserve(d_words)); HIP_TRY(W.d_part_cnt.reserve(d_words));   // (the two D arrays; this mode has no partial results)
             HIP_TRY(ugp::launch_scores_levels(m->d_node_pair.p, m->d_parent.p, m->d_stream.p, W.d_table.p, n_sites, d_dbottom, m->h_level_off.data(),
                                               (uint32_t)m->h_level_off.size() - 1, W.d_part_best.p, W.d_part_cnt.p, d16, m->max_level_width, qpad, (uint32_t)nq, f.n_nodes,

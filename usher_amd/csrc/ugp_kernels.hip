@@ -557,48 +557,57 @@ __global__ void k_merge(const uint32_t *__restrict__ part_best, const uint32_t *
 // The node's record is the 32-bit stream's (w0: mutation count, leaf / root / masked flags; one word per mutation).
 // Needs a tree numbered as a breadth-first expansion (node_pair: {first child - 1, record offset} per node).
 template <typename DT>
-__global__ void __launch_bounds__(256) k_scores_level(const uint2 *__restrict__ node_pair, const uint32_t *__restrict__ parent,
+__global__ void __launch_bounds__(1024) k_scores_level(const uint2 *__restrict__ node_pair, const uint32_t *__restrict__ parent,
                                                       const uint32_t *__restrict__ stream, const uint32_t *__restrict__ table, uint32_t n_sites,
                                                       const uint32_t *__restrict__ dbottom, uint32_t lv_begin, uint32_t lv_end, uint32_t prev_begin,
-                                                      const DT *__restrict__ d_prev, DT *__restrict__ d_cur, uint32_t d_stride /* nodes per 32-sample block */,
+                                                      const DT *__restrict__ d_prev, DT *__restrict__ d_cur, uint32_t d_stride /* nodes per block of SB samples */,
                                                       uint32_t qpad, uint32_t n_queries, uint64_t n_nodes, int32_t *__restrict__ scores) {
-    const uint32_t n = lv_begin + blockIdx.x * 256u + threadIdx.x;
+    const uint32_t n = lv_begin + blockIdx.x * blockDim.x + threadIdx.x;
     if (n >= lv_end) return;
     const uint32_t *rec = stream + node_pair[n].y;
     const uint32_t w0 = rec[0];
     const uint32_t nmut = w0 & 0xFFFFu;
     const bool root = (w0 & F_ROOT) != 0, leaf = (w0 & F_LEAF) != 0, masked = (w0 & F_MASKED) != 0;
     const uint32_t m0 = nmut > 0 ? rec[2] : 0u, m1 = nmut > 1 ? rec[3] : 0u;   // (most nodes carry at most two mutations: kept in registers)
-    // D arrays: [block of 32 samples][node of the level][32] -- the lanes of a wave (consecutive nodes) read and write
-    // consecutive 64- or 128-byte pieces; the children of a node read the same piece
-    const uint64_t prow = root ? 0 : (uint64_t)(parent[n] - prev_begin) * 32u;
-    const uint64_t crow = (uint64_t)(n - lv_begin) * 32u;
+    // D arrays: [block of SB samples][node of the level][SB] -- the lanes of a wave (consecutive nodes) read and write
+    // consecutive 128- or 256-byte pieces; the children of a node read the same piece
+    constexpr uint32_t SB = SCORES_SB, NW = SB / 8u;   // samples per step, table dwords per step
+    const uint64_t prow = root ? 0 : (uint64_t)(parent[n] - prev_begin) * SB;
+    const uint64_t crow = (uint64_t)(n - lv_begin) * SB;
     const uint32_t n_rows = n_sites + TABLE_CONST_ROWS;
     const bool free_internal = !leaf && !masked && nmut == 0;
-    for (uint32_t qb = blockIdx.y; qb * 32u < qpad; qb += gridDim.y) {   // 32 samples = four dwords (16 bytes) of a table row
-        const uint32_t q0 = qb * 32u;
+    // SB samples = NW dwords of a table row per step.  (SB = 64 reads a row's 32-byte sector once instead of twice -- a third fewer
+    // bytes fetched, the same time: the kernel is bound by its writes -- and costs registers: 32.)
+    for (uint32_t qb = blockIdx.y; qb * SB < qpad; qb += gridDim.y) {
+        const uint32_t q0 = qb * SB;
         const uint32_t *trow = table + ((uint64_t)(q0 >> 9) * n_rows + TABLE_CONST_ROWS) * 64 + ((q0 & 511u) >> 3);   // + 64 * site: 16-byte aligned
         // per dword (8 samples) 4-bit counters, as in k_best8: P = prev in S, C = mut in S over all words (D), Cb / N = C and C & ~P over
         // the words in front of the node's first masked mutation (eligibility, cost).  A node with more than 15 words (rare) takes
         // the plain sums instead.
-        uint32_t aP[4] = {0, 0, 0, 0}, aC[4] = {0, 0, 0, 0}, aN[4] = {0, 0, 0, 0}, aCb[4] = {0, 0, 0, 0};
+        uint32_t aP[NW], aC[NW], aN[NW], aCb[NW];
+#pragma unroll
+        for (uint32_t t = 0; t < NW; t++) { aP[t] = 0; aC[t] = 0; aN[t] = 0; aCb[t] = 0; }
         const bool small = nmut <= 15u;
         if (small) {
             for (uint32_t m = 0; m < nmut; m++) {
                 const uint32_t w = m == 0 ? m0 : (m == 1 ? m1 : rec[2 + m]);
-                const uint4 xv = *(const uint4 *)(trow + (uint64_t)(w & 0x3FFFFFu) * 64);
-                const uint32_t x[4] = {xv.x, xv.y, xv.z, xv.w};
+                uint32_t x[NW];
+#pragma unroll
+                for (uint32_t v = 0; v < NW / 4u; v++) {
+                    const uint4 xv = *((const uint4 *)(trow + (uint64_t)(w & 0x3FFFFFu) * 64) + v);
+                    x[4 * v] = xv.x; x[4 * v + 1] = xv.y; x[4 * v + 2] = xv.z; x[4 * v + 3] = xv.w;
+                }
                 const uint32_t mi = (w >> 22) & 3u, pi = (w >> 24) & 3u;
                 const uint32_t bm = (w & M_AFTER_MASK) ? 0u : 0x11111111u;   // in front of the node's first masked mutation (usher_mapper.cpp:197-200)
 #pragma unroll
-                for (int t = 0; t < 4; t++) {
+                for (uint32_t t = 0; t < NW; t++) {
                     const uint32_t C = (x[t] >> mi) & 0x11111111u, P = (x[t] >> pi) & 0x11111111u;
                     aP[t] += P; aC[t] += C; aN[t] += C & ~P & bm; aCb[t] += C & bm;
                 }
             }
         }
 #pragma unroll
-        for (int t = 0; t < 4; t++) {
+        for (uint32_t t = 0; t < NW; t++) {
             const uint32_t qg = q0 + t * 8;
             if (qg >= qpad) break;
             uint32_t dpar[8];
@@ -606,7 +615,7 @@ __global__ void __launch_bounds__(256) k_scores_level(const uint2 *__restrict__ 
 #pragma unroll
                 for (int j = 0; j < 8; j++) dpar[j] = dbottom[qg + j];
             } else {
-                const DT *src = d_prev + (uint64_t)qb * d_stride * 32u + prow + t * 8;
+                const DT *src = d_prev + (uint64_t)qb * d_stride * SB + prow + t * 8;
                 if (sizeof(DT) == 2) {
                     const uint4 v = *(const uint4 *)src;
                     dpar[0] = v.x & 0xFFFFu; dpar[1] = v.x >> 16; dpar[2] = v.y & 0xFFFFu; dpar[3] = v.y >> 16;
@@ -645,7 +654,7 @@ __global__ void __launch_bounds__(256) k_scores_level(const uint2 *__restrict__ 
                 for (int j = 0; j < 8; j++) dnew[j] = dpar[j] + (uint32_t)ts[j];
             }
             if (!leaf) {
-                DT *dst = d_cur + (uint64_t)qb * d_stride * 32u + crow + t * 8;
+                DT *dst = d_cur + (uint64_t)qb * d_stride * SB + crow + t * 8;
                 if (sizeof(DT) == 2)
                     *(uint4 *)dst = make_uint4((dnew[0] & 0xFFFFu) | (dnew[1] << 16), (dnew[2] & 0xFFFFu) | (dnew[3] << 16), (dnew[4] & 0xFFFFu) | (dnew[5] << 16),
                                                (dnew[6] & 0xFFFFu) | (dnew[7] << 16));
@@ -656,7 +665,9 @@ __global__ void __launch_bounds__(256) k_scores_level(const uint2 *__restrict__ 
                 uint32_t sc;
                 if (root) sc = dnew[j];                                        // cost(root) = D(root), always eligible (usher_mapper.cpp:454)
                 else sc = dpar[j] - negs[j] + ((comm[j] > 0 || free_internal) ? 0u : 1u);   // + 1 when not eligible (:498-502)
-                if (qg + j < n_queries) scores[(uint64_t)(qg + j) * n_nodes + n] = (int32_t)sc;
+                // (streaming stores: the matrix is written once and never read here -- it must not evict the 3 MB of table lines
+                // that every thread gathers from)
+                if (qg + j < n_queries) __builtin_nontemporal_store((int32_t)sc, &scores[(uint64_t)(qg + j) * n_nodes + n]);
             }
         }
     }
@@ -1873,16 +1884,17 @@ hipError_t launch_scores_levels(const uint32_t *node_pair, const uint32_t *paren
     for (uint32_t l = 0; l < n_levels; l++) {
         const uint32_t b = level_off[l], e = level_off[l + 1], pb = l ? level_off[l - 1] : 0u;
         if (e <= b) continue;
-        const uint32_t bx = (e - b + 255u) / 256u;
+        static const uint32_t bs = getenv("UGP_SCORES_BLOCK") ? (uint32_t)std::min(1024, std::max(64, atoi(getenv("UGP_SCORES_BLOCK")) / 64 * 64)) : 1024u;
+        const uint32_t bx = (e - b + bs - 1u) / bs;
         // narrow levels: the sample groups spread over blockIdx.y so that the top of the tree does not run on a handful of waves
         uint32_t by = 1;
-        while (by < (qpad + 31u) / 32u && (uint64_t)bx * by < 2048u) by *= 2;
+        while (by < (qpad + SCORES_SB - 1u) / SCORES_SB && (uint64_t)bx * by < 2048u) by *= 2;
         void *prev = (l & 1u) ? d_a : d_b, *cur = (l & 1u) ? d_b : d_a;
         if (d16)
-            hipLaunchKernelGGL(k_scores_level<uint16_t>, dim3(bx, by), dim3(256), 0, s, (const uint2 *)node_pair, parent, stream, table, n_sites, dbottom, b, e, pb,
+            hipLaunchKernelGGL(k_scores_level<uint16_t>, dim3(bx, by), dim3(bs), 0, s, (const uint2 *)node_pair, parent, stream, table, n_sites, dbottom, b, e, pb,
                                (const uint16_t *)prev, (uint16_t *)cur, d_stride, qpad, n_queries, n_nodes, scores);
         else
-            hipLaunchKernelGGL(k_scores_level<uint32_t>, dim3(bx, by), dim3(256), 0, s, (const uint2 *)node_pair, parent, stream, table, n_sites, dbottom, b, e, pb,
+            hipLaunchKernelGGL(k_scores_level<uint32_t>, dim3(bx, by), dim3(bs), 0, s, (const uint2 *)node_pair, parent, stream, table, n_sites, dbottom, b, e, pb,
                                (const uint32_t *)prev, (uint32_t *)cur, d_stride, qpad, n_queries, n_nodes, scores);
     }
     return hipGetLastError();

@@ -72,7 +72,8 @@ struct Best8Args {
 hipError_t launch_build_units(const uint32_t *hstart, const uint32_t *hlen, uint32_t n_tiles512, uint32_t n_chunks, uint32_t unit_chunks, uint32_t heavy_chunks,
                               uint32_t grow_every, uint32_t unit_max, uint32_t light_order, uint32_t per_tile_cap, void *units, uint32_t *unit_base,
                               uint32_t *unit_count, uint32_t *dyn_ctl, hipStream_t s);
-// -p by levels of the breadth-first expansion (see k_scores_level): d_a / d_b = two D arrays of max level width x qpad entries
+constexpr uint32_t SCORES_SB = 32;   // samples per step of k_scores_level (a multiple of 32): the D arrays are laid out in blocks of this many
+// -p by levels of the breadth-first expansion (see k_scores_level): d_a / d_b = two D arrays of max level width x qpad (rounded up to SCORES_SB) entries
 hipError_t launch_scores_levels(const uint32_t *node_pair, const uint32_t *parent, const uint32_t *stream, const uint32_t *table, uint32_t n_sites,
                                 const uint32_t *dbottom, const uint32_t *level_off, uint32_t n_levels, void *d_a, void *d_b, bool d16, uint32_t d_stride,
                                 uint32_t qpad, uint32_t n_queries, uint64_t n_nodes, int32_t *scores, hipStream_t s);
