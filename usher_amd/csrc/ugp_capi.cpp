@@ -137,7 +137,8 @@ struct ugp_mat {
     int last_work = 0;       // set used by the most recent call (ugp_get_timing reports it)
     int next_work = 0;       // set the next ugp_place_device call takes
     bool primed = false;     // both sets have been through one call
-    bool sharing = false;    // (during a ugp_place_device call) the other set's call was still running when this one was queued
+    bool sharing = false;    // (during a ugp_place_device call) the other set's call was still running when this one, or the one before it, was queued
+    bool was_busy = false;   // ... when the previous call was queued
     hipEvent_t kb_done = nullptr;    // behind the latest k_best8 launch of this handle ...
     hipStream_t kb_done_on = nullptr;   // ... on this stream
 };
@@ -940,9 +941,13 @@ int ugp_place_device(ugp_mat *m, ugp_qset *qs, void *d_out, void *stream) {
     ugp_mat::Work &W = m->work[wi];
     if (!W.stream) HIP_TRY(hipStreamCreateWithFlags(&W.stream, hipStreamNonBlocking));
     {   // is the other set's call still on the device?  (then this call's tree walk leaves it half of the chip)
+        // (or was it when the previous call was queued?  The first call of a burst finds the device idle; a caller that has just
+        // been issuing calls back to back is about to do so again.)
         const ugp_mat::Work &O = m->work[wi ^ 1];
-        m->sharing = O.done && hipEventQuery(O.done) == hipErrorNotReady;
+        const bool busy = O.done && hipEventQuery(O.done) == hipErrorNotReady;
         (void)hipGetLastError();   // (hipErrorNotReady is not an error)
+        m->sharing = busy || m->was_busy;
+        m->was_busy = busy;
         if (getenv("UGP_DEBUG_SHARING")) fprintf(stderr, "[ugp] call on set %d: sharing=%d\n", wi, (int)m->sharing);
     }
     struct Unshare { ugp_mat *m; ~Unshare() { m->sharing = false; } } unshare{m};
