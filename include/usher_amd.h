@@ -193,6 +193,17 @@ int ugp_place_device(ugp_mat *mat, ugp_qset *qs, void *d_out, void *stream);
  * `stream` before it: do not hand it an output buffer that earlier stream work still reads.  UGP_NO_OVERLAP=1 in the
  * environment runs every call on `stream` itself. */
 
+/* ugp_place_batch with two batches in flight: host buffers in, host buffers out, asynchronous.  The rows are copied out of
+ * `q` before the call returns (pinned staging), `out` is written by ugp_job_wait.  At most two jobs per handle may be
+ * outstanding (the third call fails until the oldest has been waited for); jobs complete in the order they were started.
+ * ugp_job_wait returns the call's status -- the row checks of ugp_place_batch surface here -- and frees the job.
+ *   ugp_job *a, *b; ugp_place_batch_async(mat, &q0, r0, &a);
+ *   for (i = 1; i < n; i++) { ugp_place_batch_async(mat, &q[i], r[i], &b); ugp_job_wait(a); a = b; }   ugp_job_wait(a);
+ * keeps the device busy with the kernels of one batch while the next one's rows are on their way. */
+typedef struct ugp_job ugp_job;
+int ugp_place_batch_async(ugp_mat *mat, const ugp_queries *q, ugp_result *out /* [n_queries], valid until ugp_job_wait */, ugp_job **job);
+int ugp_job_wait(ugp_job *job);
+
 /* Per-kernel durations of the last ugp_place_* call on this handle, measured
  * with HIP events on the stream the kernels ran on (synchronises that stream). */
 int ugp_get_timing(ugp_mat *mat, ugp_timing *out);

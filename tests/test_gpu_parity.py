@@ -342,6 +342,53 @@ def test_per_node_scores_by_levels_and_by_depth_first_walk(seed, n_queries, monk
         assert got.shape == want.shape and (got == want).all(), (env, np.argwhere(got != want)[:5])
 
 
+def test_host_buffer_batches_two_in_flight():
+    """ugp_place_batch_async / ugp_job_wait: batches from host buffers with two in flight give the answers of ugp_place_batch;
+    the batch's arrays may be overwritten as soon as the call returns; a third job is refused until the oldest has been waited
+    for; a batch with out-of-order rows is reported by ITS ugp_job_wait and leaves the handle usable."""
+    from usher_amd import synth as gsynth
+    from usher_amd.placement import UgpError
+    st = gsynth.SynthTree(300_000, n_sites=4000, seed=33)
+    qs = [st.queries(n, seed=70 + i, max_subst=3, n_lo=0, n_hi=10, iupac_hi=2) for i, n in enumerate((1500, 600, 2600, 40))]
+    batches = [QueryBatch.from_csr(q["ent_off"], q["pos"], q["ref"], q["nuc"], q["is_missing"]) for q in qs]
+    pl = Placer(st.arrays)
+    want = [pl.place(b).copy() for b in batches]
+    jobs = []
+    got = {}
+    order = [0, 1, 2, 3, 2, 1, 0, 3, 3, 0]
+    for k, i in enumerate(order):
+        b = batches[i]
+        scratch = QueryBatch.from_csr(b.ent_off.copy(), b.pos.copy(), b.ref.copy(), b.nuc.copy(), b.is_missing.copy())
+        jobs.append((k, i, pl.place_async(scratch)))
+        scratch.pos[:] = 0; scratch.nuc[:] = 0     # the rows were copied out before the call returned
+        if len(jobs) == 2:
+            with pytest.raises(UgpError):           # a third job while two are outstanding
+                pl.place_async(batches[3])
+            k0, i0, j0 = jobs.pop(0)
+            got[k0] = (i0, pl.job_wait(j0))
+    while jobs:
+        k0, i0, j0 = jobs.pop(0)
+        got[k0] = (i0, pl.job_wait(j0))
+    assert len(got) == len(order)
+    for k, (i, r) in got.items():
+        assert (r.view(np.int32) == want[i].view(np.int32)).all(), (k, i)
+    # a bad batch between two good ones
+    bad = QueryBatch.from_csr(batches[1].ent_off.copy(), batches[1].pos.copy(), batches[1].ref.copy(), batches[1].nuc.copy(), batches[1].is_missing.copy())
+    smp = int(np.flatnonzero(np.diff(bad.ent_off.astype(np.int64)) >= 2)[3])                     # a sample with at least two rows ...
+    e0 = int(bad.ent_off[smp])                                                                   # ... gets them out of order
+    for a in (bad.pos, bad.ref, bad.nuc, bad.is_missing):
+        a[e0], a[e0 + 1] = a[e0 + 1], a[e0]
+    ja = pl.place_async(batches[0]); jb = pl.place_async(bad)
+    assert (pl.job_wait(ja).view(np.int32) == want[0].view(np.int32)).all()
+    jc = pl.place_async(batches[2])
+    with pytest.raises(UgpError) as ei:
+        pl.job_wait(jb)
+    assert ei.value.code == -2 and ("sample %d " % smp) in str(ei.value), str(ei.value)
+    assert (pl.job_wait(jc).view(np.int32) == want[2].view(np.int32)).all()
+    assert (pl.place(batches[3]).view(np.int32) == want[3].view(np.int32)).all()
+    pl.close()
+
+
 def test_sub_batching_and_tiny_batches():
     """More than 262,144 samples in one call (the library splits into sub-batches) and batches smaller
     than one tile give the same per-sample answers."""

@@ -65,6 +65,8 @@ SYMBOLS = {
     "ugp_qset_destroy": (None, [P]),
     "ugp_qset_size": (C.c_uint64, [P]),
     "ugp_place_device": (C.c_int, [P, P, P, P]),
+    "ugp_place_batch_async": (C.c_int, [P, C.POINTER(ugp_queries), P, C.POINTER(P)]),
+    "ugp_job_wait": (C.c_int, [P]),
     "ugp_get_timing": (C.c_int, [P, C.POINTER(ugp_timing)]),
     "ugp_get_timing_sum": (C.c_int, [P, C.POINTER(ugp_timing), C.POINTER(C.c_uint32)]),
     "ugp_last_error": (C.c_char_p, []),

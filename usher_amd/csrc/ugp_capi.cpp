@@ -66,6 +66,21 @@ struct DevBuf {
     }
 };
 
+// Pinned host memory (grown on demand): staging for copies that have to be asynchronous.
+struct PinBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    ~PinBuf() { if (p) (void)hipHostFree(p); }
+    int reserve(size_t n) {
+        if (n <= cap) return UGP_OK;
+        if (p) (void)hipHostFree(p);
+        p = nullptr; cap = 0;
+        if (hipHostMalloc(&p, std::max<size_t>(n, 1), hipHostMallocDefault) != hipSuccess) { p = nullptr; return fail(UGP_ERR_HIP, "hipHostMalloc (staging buffer)"); }
+        cap = n;
+        return UGP_OK;
+    }
+};
+
 struct EventSet {
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     bool used = false;
@@ -128,6 +143,11 @@ struct ugp_mat {
             bool timing_pending = false;
         } gens[4];
         uint32_t cur = 0;   // ring entry of the set's latest call
+        // ugp_place_batch_async: the set's reusable query set, result buffer and pinned staging (rows in, results out)
+        ugp_qset *job_qs = nullptr;
+        DevBuf<ugp_result> d_job_out;
+        PinBuf job_in, job_out;
+        bool job_busy = false;           // a job on this set has been started and not yet waited for
         hipStream_t stream = nullptr;    // the handle's own stream for this set (ugp_place_device)
         hipEvent_t done = nullptr;       // recorded behind the last call that used this set
         hipStream_t done_on = nullptr;   // ... on this stream
@@ -826,6 +846,7 @@ void ugp_mat_destroy(ugp_mat *m) {
             for (int i = 0; i < 2; i++) if (G.ev_coarse[i]) (void)hipEventDestroy(G.ev_coarse[i]);
         }
     }
+    for (auto &W : m->work) delete W.job_qs;
     if (m->kb_done) (void)hipEventDestroy(m->kb_done);
     if (m->coarse) ugp_mat_destroy(m->coarse);
     delete m->own_qs;
@@ -849,7 +870,24 @@ int ugp_mat_info(const ugp_mat *m, ugp_info *out) {
 }
 
 // Upload the rows of a batch into `qs` (buffers grow on demand and are reused) and check them on the device.
-static int qset_fill(ugp_mat *m, const ugp_queries *q, ugp_qset *qs) {
+// Translate the first offending row recorded by k_rows_prepare (~0: none) into an error.
+static int rows_error(const ugp_qset *qs, const ugp_queries *q, unsigned long long err) {
+    if (err == ~0ull) return UGP_OK;
+    const uint64_t row = err >> 3;
+    const uint64_t smp = (uint64_t)(std::upper_bound(qs->ent_off.begin(), qs->ent_off.end(), row) - qs->ent_off.begin()) - 1;
+    switch ((int)(err & 7)) {
+        case ugp::ROWS_UNSORTED:
+            return fail(UGP_ERR_UNSUPPORTED, "rows of sample " + std::to_string(smp) + " are not sorted by position / contain a duplicate position");
+        case ugp::ROWS_BAD_REF: return fail(UGP_ERR_UNSUPPORTED, "VCF REF base of a row is not one of A,C,G,T");
+        case ugp::ROWS_BAD_MASK: return fail(UGP_ERR_INVALID, "allele mask out of range");
+        default:
+            return fail(UGP_ERR_UNSUPPORTED, "VCF REF differs from the tree's reference base at position " + (q ? std::to_string(q->pos[row]) : std::string("of row ") + std::to_string(row)));
+    }
+}
+
+// `stage` (pinned host memory, or null): the rows go through it, so that the copies to the device are asynchronous on `s` and
+// the caller's arrays are free on return; the row check is then left to the caller (qs->d_err, after the stream has run).
+static int qset_fill(ugp_mat *m, const ugp_queries *q, ugp_qset *qs, hipStream_t s = nullptr, PinBuf *stage = nullptr) {
     uint64_t n_ent = 0, max_rows = 0;
     if (int rc = validate_offsets(q, n_ent, max_rows)) return rc;
     HIP_TRY(hipSetDevice(m->device));
@@ -872,29 +910,28 @@ static int qset_fill(ugp_mat *m, const ugp_queries *q, ugp_qset *qs) {
     HIP_TRY(qs->d_pos.reserve(n_ent)); HIP_TRY(qs->d_ref.reserve(n_ent)); HIP_TRY(qs->d_nuc.reserve(n_ent));
     HIP_TRY(qs->d_missing.reserve(n_ent)); HIP_TRY(qs->d_ent_q.reserve(n_ent));
     HIP_TRY(qs->d_ent_off.reserve(q->n_queries + 1)); HIP_TRY(qs->d_err.reserve(1));
-    hipStream_t s = nullptr;
-    HIP_TRY(hipMemcpyAsync(qs->d_pos.p, q->pos, n_ent * 4, hipMemcpyHostToDevice, s));
-    HIP_TRY(hipMemcpyAsync(qs->d_ref.p, q->ref, n_ent, hipMemcpyHostToDevice, s));
-    HIP_TRY(hipMemcpyAsync(qs->d_nuc.p, q->nuc, n_ent, hipMemcpyHostToDevice, s));
-    HIP_TRY(hipMemcpyAsync(qs->d_missing.p, q->is_missing, n_ent, hipMemcpyHostToDevice, s));
-    HIP_TRY(hipMemcpyAsync(qs->d_ent_off.p, q->ent_off, (q->n_queries + 1) * 8, hipMemcpyHostToDevice, s));
+    const void *h_pos = q->pos, *h_ref = q->ref, *h_nuc = q->nuc, *h_mis = q->is_missing, *h_off = q->ent_off;
+    if (stage) {
+        const size_t o_ref = n_ent * 4, o_nuc = o_ref + n_ent, o_mis = o_nuc + n_ent, o_off = (o_mis + n_ent + 7) & ~(size_t)7,
+                     total = o_off + (q->n_queries + 1) * 8;
+        if (int rc = stage->reserve(total)) return rc;
+        char *b = (char *)stage->p;
+        memcpy(b, q->pos, n_ent * 4); memcpy(b + o_ref, q->ref, n_ent); memcpy(b + o_nuc, q->nuc, n_ent); memcpy(b + o_mis, q->is_missing, n_ent);
+        memcpy(b + o_off, q->ent_off, (q->n_queries + 1) * 8);
+        h_pos = b; h_ref = b + o_ref; h_nuc = b + o_nuc; h_mis = b + o_mis; h_off = b + o_off;
+    }
+    HIP_TRY(hipMemcpyAsync(qs->d_pos.p, h_pos, n_ent * 4, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(qs->d_ref.p, h_ref, n_ent, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(qs->d_nuc.p, h_nuc, n_ent, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(qs->d_missing.p, h_mis, n_ent, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(qs->d_ent_off.p, h_off, (q->n_queries + 1) * 8, hipMemcpyHostToDevice, s));
     HIP_TRY(hipMemsetAsync(qs->d_err.p, 0xFF, sizeof(unsigned long long), s));
     HIP_TRY(ugp::launch_rows_prepare(qs->d_ent_off.p, (uint32_t)q->n_queries, n_ent, qs->d_pos.p, qs->d_ref.p, qs->d_nuc.p, qs->d_missing.p,
                                      m->d_pos2site.p, m->d_site_ref.p, f.max_pos, (uint32_t)f.n_sites, qs->d_ent_q.p, qs->d_err.p, s));
+    if (stage) return UGP_OK;   // (checked by the caller once the stream has run)
     unsigned long long err = ~0ull;
     HIP_TRY(hipMemcpy(&err, qs->d_err.p, sizeof err, hipMemcpyDeviceToHost));
-    if (err != ~0ull) {
-        const uint64_t row = err >> 3;
-        const uint64_t smp = (uint64_t)(std::upper_bound(qs->ent_off.begin(), qs->ent_off.end(), row) - qs->ent_off.begin()) - 1;
-        switch ((int)(err & 7)) {
-            case ugp::ROWS_UNSORTED:
-                return fail(UGP_ERR_UNSUPPORTED, "rows of sample " + std::to_string(smp) + " are not sorted by position / contain a duplicate position");
-            case ugp::ROWS_BAD_REF: return fail(UGP_ERR_UNSUPPORTED, "VCF REF base of a row is not one of A,C,G,T");
-            case ugp::ROWS_BAD_MASK: return fail(UGP_ERR_INVALID, "allele mask out of range");
-            default:
-                return fail(UGP_ERR_UNSUPPORTED, "VCF REF differs from the tree's reference base at position " + std::to_string(q->pos[row]));
-        }
-    }
+    if (int rc = rows_error(qs, q, err)) return rc;
     return UGP_OK;
 }
 
@@ -954,6 +991,81 @@ int ugp_place_device(ugp_mat *m, ugp_qset *qs, void *d_out, void *stream) {
     if (int rc = run_place(m, qs, 0, (ugp_result *)d_out, nullptr, nullptr, nullptr, nullptr, nullptr, 0, W.stream, false, nullptr, wi)) return rc;
     if (W.done) HIP_TRY(hipStreamWaitEvent((hipStream_t)stream, W.done, 0));   // (recorded at the end of run_place)
     return UGP_OK;
+}
+
+// ---- host buffers in, host buffers out, two batches in flight -------------------------------------------------------------
+struct ugp_job {
+    ugp_mat *m = nullptr;
+    int wi = 0;
+    ugp_result *out = nullptr;
+    uint64_t n = 0;
+};
+
+int ugp_place_batch_async(ugp_mat *m, const ugp_queries *q, ugp_result *out, ugp_job **job) {
+    if (!m || !q || !job || (!out && q->n_queries)) return fail(UGP_ERR_INVALID, "null argument");
+    *job = nullptr;
+    HIP_TRY(hipSetDevice(m->device));
+    if (!m->primed) {   // both workspace sets through one (synchronous) call first, as ugp_place_device does
+        std::vector<ugp_result> tmp(q->n_queries);
+        ugp_qset *qs = nullptr;
+        if (int rc = ugp_qset_upload(m, q, &qs)) return rc;
+        DevBuf<ugp_result> d_tmp;
+        int rc = d_tmp.reserve(q->n_queries) == hipSuccess ? UGP_OK : fail(UGP_ERR_HIP, "hipMalloc");
+        if (rc == UGP_OK) rc = ugp_place_device(m, qs, d_tmp.p, nullptr);
+        (void)hipDeviceSynchronize();
+        ugp_qset_destroy(qs);
+        if (rc != UGP_OK) return rc;
+    }
+    const int wi = m->next_work;
+    ugp_mat::Work &W = m->work[wi];
+    if (W.job_busy) return fail(UGP_ERR_INVALID, "two jobs are in flight on this handle: ugp_job_wait the oldest first");
+    if (!W.stream) HIP_TRY(hipStreamCreateWithFlags(&W.stream, hipStreamNonBlocking));
+    if (!W.job_qs) { W.job_qs = new (std::nothrow) ugp_qset(); if (!W.job_qs) return fail(UGP_ERR_NOMEM, "out of host memory"); }
+    // the previous use of this set (a job two calls ago, or any other entry point) has to be over before its staging is overwritten
+    if (W.done) HIP_TRY(hipEventSynchronize(W.done));
+    if (int rc = qset_fill(m, q, W.job_qs, W.stream, &W.job_in)) return rc;
+    HIP_TRY(W.d_job_out.reserve(q->n_queries));
+    if (int rc = W.job_out.reserve(std::max<size_t>(q->n_queries, 1) * sizeof(ugp_result) + 8)) return rc;
+    {   // (as in ugp_place_device: is the other set's job still on the device?)
+        const ugp_mat::Work &O = m->work[wi ^ 1];
+        const bool busy = O.done && hipEventQuery(O.done) == hipErrorNotReady;
+        (void)hipGetLastError();
+        m->sharing = busy || m->was_busy;
+        m->was_busy = busy;
+    }
+    int rc = run_place(m, W.job_qs, 0, W.d_job_out.p, nullptr, nullptr, nullptr, nullptr, nullptr, 0, W.stream, false, nullptr, wi);
+    m->sharing = false;
+    if (rc != UGP_OK) return rc;
+    // results and the row check's verdict into pinned memory, behind the kernels; W.done is recorded again behind them
+    if (q->n_queries) HIP_TRY(hipMemcpyAsync(W.job_out.p, W.d_job_out.p, q->n_queries * sizeof(ugp_result), hipMemcpyDeviceToHost, W.stream));
+    if (W.job_qs->n_ent) HIP_TRY(hipMemcpyAsync((char *)W.job_out.p + q->n_queries * sizeof(ugp_result), W.job_qs->d_err.p, 8, hipMemcpyDeviceToHost, W.stream));
+    else memset((char *)W.job_out.p + q->n_queries * sizeof(ugp_result), 0xFF, 8);
+    HIP_TRY(hipEventRecord(W.done, W.stream));
+    W.done_on = W.stream;
+    ugp_job *j = new (std::nothrow) ugp_job();
+    if (!j) return fail(UGP_ERR_NOMEM, "out of host memory");
+    j->m = m; j->wi = wi; j->out = out; j->n = q->n_queries;
+    W.job_busy = true;
+    m->next_work ^= 1;
+    *job = j;
+    return UGP_OK;
+}
+
+int ugp_job_wait(ugp_job *j) {
+    if (!j) return fail(UGP_ERR_INVALID, "null argument");
+    ugp_mat *m = j->m;
+    ugp_mat::Work &W = m->work[j->wi];
+    int rc = UGP_OK;
+    if (hipSetDevice(m->device) != hipSuccess || hipEventSynchronize(W.done) != hipSuccess) rc = fail(UGP_ERR_HIP, "waiting for the job");
+    if (rc == UGP_OK) {
+        unsigned long long err;
+        memcpy(&err, (char *)W.job_out.p + j->n * sizeof(ugp_result), 8);
+        rc = rows_error(W.job_qs, nullptr, err);
+        if (rc == UGP_OK && j->n) memcpy(j->out, W.job_out.p, j->n * sizeof(ugp_result));
+    }
+    W.job_busy = false;
+    delete j;
+    return rc;
 }
 
 int ugp_place_batch(ugp_mat *m, const ugp_queries *q, ugp_result *out) {

@@ -166,6 +166,19 @@ class Placer:
         _check(_lib.lib().ugp_place_batch(self._h, C.byref(batch.desc), _ptr(out)))
         return out
 
+    def place_async(self, batch: QueryBatch):
+        """ugp_place_batch_async: starts the batch and returns a job; job_wait(job) gives the same array as place().  At most two
+        jobs may be outstanding; the batch's arrays may be reused as soon as this returns."""
+        out = np.zeros(len(batch), dtype=RESULT_DTYPE)
+        job = C.c_void_p()
+        _check(_lib.lib().ugp_place_batch_async(self._h, C.byref(batch.desc), _ptr(out), C.byref(job)))
+        return (job, out)
+
+    def job_wait(self, job) -> np.ndarray:
+        h, out = job
+        _check(_lib.lib().ugp_job_wait(h))
+        return out
+
     def scores_per_node(self, batch: QueryBatch) -> np.ndarray:
         out = np.zeros((len(batch), self.n_nodes), dtype=np.int32)
         _check(_lib.lib().ugp_scores_per_node(self._h, C.byref(batch.desc), _ptr(out)))
