@@ -40,7 +40,11 @@ extern "C" {
 #define UGP_ERR_NOMEM       -4   /* host allocation failed                                    */
 
 /* Opaque handle: the flattened mutation-annotated tree resident in the HBM of
- * one device (replaces MAT::Tree* + the BFS vector of usher_common.cpp:342). */
+ * one device (replaces MAT::Tree* + the BFS vector of usher_common.cpp:342).
+ * Threading: a handle owns its per-call workspaces, so calls on ONE handle must come from one thread at a time (the
+ * reference serialises samples behind its global locks the same way, usher_mapper.cpp:3-4); different handles -- on the
+ * same or on different devices -- are independent and may be driven by different host threads.  Overlap of batches on one
+ * handle is what ugp_place_device / ugp_place_batch_async are for.  ugp_last_error() is per thread. */
 typedef struct ugp_mat ugp_mat;
 /* Opaque handle: a validated query batch resident in HBM. */
 typedef struct ugp_qset ugp_qset;
