@@ -389,6 +389,33 @@ def test_host_buffer_batches_two_in_flight():
     pl.close()
 
 
+def test_tie_lists_from_phase_two_and_from_the_full_walk(monkeypatch):
+    """ugp_tied_nodes: on the packed path the lists are written by phase 2 itself (k_ties<LIST>, from the chunks that attain the
+    minimum); UGP_TIES_DFS keeps the second, one-sample-per-lane walk of the whole tree.  Both against the oracle's tie sets on a
+    multi-tile batch with the locality sort on, and with a cap smaller than some tie sets (true counts, a subset of the ties)."""
+    arrays, queries = synth.make_case(91, n_leaves=5000, n_queries=1100, n_sites=260, n_ambig=(0, 0, 2, 5, 30), p_masked=0.02)
+    monkeypatch.setenv("UGP_COARSE_MIN_NODES", "0")
+    ot = capi.OracleTree(arrays)
+    want = [ot.place(s) for s in queries]
+    batch = QueryBatch(queries)
+    assert max(w["num_best"] for w in want) > 3
+    for env in ({}, {"UGP_TIES_DFS": "1"}):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        pl = Placer(arrays, chunk_nodes=48)
+        ties, hu, tc = pl.tied_nodes(batch, 64)
+        ties2, hu2, tc2 = pl.tied_nodes(batch, 2)
+        pl.close()
+        for k in env:
+            monkeypatch.delenv(k)
+        for i, w in enumerate(want):
+            assert int(tc[i]) == w["num_best"] == int(tc2[i]), (env, i)
+            if w["num_best"] <= 64:
+                assert ties[i].tolist() == w["ties"].tolist() and hu[i].tolist() == w["ties_has_unique"].tolist(), (env, i)
+            full = dict(zip(w["ties"].tolist(), w["ties_has_unique"].tolist()))
+            assert len(ties2[i]) == min(2, w["num_best"]) and all(full.get(int(j)) == bool(h) for j, h in zip(ties2[i], hu2[i])), (env, i)
+
+
 def test_sub_batching_and_tiny_batches():
     """More than 262,144 samples in one call (the library splits into sub-batches) and batches smaller
     than one tile give the same per-sample answers."""

@@ -156,6 +156,7 @@ struct ugp_mat {
     uint32_t tsum_calls = 0;
     int last_work = 0;       // set used by the most recent call (ugp_get_timing reports it)
     int next_work = 0;       // set the next ugp_place_device call takes
+    uint32_t tie_lists_filled = 0, tie_sub_batches = 0;   // sub-batches of the current call whose tie lists phase 2 has filled / all of them (ugp_tied_nodes)
     bool primed = false;     // both sets have been through one call
     bool sharing = false;    // (during a ugp_place_device call) the other set's call was still running when this one, or the one before it, was queued
     bool was_busy = false;   // ... when the previous call was queued
@@ -280,6 +281,7 @@ int run_place(ugp_mat *m, ugp_qset *qs, int mode, ugp_result *d_out, int32_t *d_
     if (m->flat.n_chunks) sub_tiles = std::min<uint64_t>(sub_tiles, std::max<uint64_t>(8, ((8ull << 30) / ((uint64_t)m->flat.n_chunks * 128)) & ~7ull));
     for (uint64_t q0 = 0; q0 < Q; q0 += sub_tiles * 64) {
         const uint64_t nq = std::min<uint64_t>(Q - q0, sub_tiles * 64);
+        if (mode == 0 && d_tie_count) m->tie_sub_batches++;
         const uint32_t n_tiles = (uint32_t)((nq + 63) / 64);
         const uint32_t n_tiles512 = (uint32_t)((nq + 511) / 512);
         // 16-bit packed phase 1 is exact while every D / cost stays below 0x8000 (bit 15 is the ineligible flag)
@@ -571,7 +573,8 @@ int run_place(ugp_mat *m, ugp_qset *qs, int mode, ugp_result *d_out, int32_t *d_
             else
                 HIP_TRY(ugp::launch_phase2(a, W.d_lbest.p, W.d_list.p, d_list_n, W.d_gbest_part.p, W.d_gbest.p, n_tiles512, W.d_items.p, d_nitems,
                                            (uint32_t)std::min<uint64_t>(pairs, 0xFFFFFFFFull), d_cnt, d_key,
-                                           m->d_rank2bfs.p, d_out + q0, order, f.max_slots, s));
+                                           m->d_rank2bfs.p, d_out + q0, order, f.max_slots, d_tie_count != nullptr, s));
+                if (d_tie_count) m->tie_lists_filled++;
         } else if (mode == 1 && !ex && !m->h_level_off.empty() && !getenv("UGP_SCORES_DFS")) {
             // -p in the output's own order: level by level of the breadth-first expansion, 64 consecutive scores of one sample per
             // wave store (k_scores_level); the depth-first walk below writes 4 bytes per 32-byte sector
@@ -1120,12 +1123,18 @@ int ugp_tied_nodes(ugp_mat *m, const ugp_queries *q, uint32_t cap, uint32_t *tie
     chk(d_cnt.reserve(padded), "hipMalloc");
     chk(d_j.reserve((size_t)Q * std::max<uint32_t>(cap, 1)), "hipMalloc");
     chk(d_hu.reserve((size_t)Q * std::max<uint32_t>(cap, 1)), "hipMalloc");
-    if (rc == UGP_OK) rc = run_place(m, qs, 0, d_res.p, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr);
-    if (rc == UGP_OK) {   // the wanted scores stay on the device
+    // On the packed path the lists come out of phase 2 itself: the tied nodes lie in the chunks that attain the sample's minimum,
+    // which phase 2 re-walks anyway (k_ties<LIST>) -- no second pass over the tree.  Otherwise (32-bit fallback): the best scores
+    // first, then the one-sample-per-lane walk of the whole tree that appends every node attaining them.
+    if (rc == UGP_OK) chk(hipMemsetAsync(d_cnt.p, 0, padded * sizeof(uint32_t), nullptr), "memset");
+    m->tie_lists_filled = m->tie_sub_batches = 0;
+    if (rc == UGP_OK) rc = run_place(m, qs, 0, d_res.p, nullptr, nullptr, getenv("UGP_TIES_DFS") ? nullptr : d_cnt.p, d_j.p, d_hu.p, cap, nullptr);
+    const bool filled = rc == UGP_OK && m->tie_sub_batches > 0 && m->tie_lists_filled == m->tie_sub_batches;
+    if (rc == UGP_OK && !filled) {   // the wanted scores stay on the device
         chk(ugp::launch_extract_best(d_res.p, (uint32_t)Q, d_best.p, nullptr), "extract best");
         chk(hipMemsetAsync(d_cnt.p, 0, padded * sizeof(uint32_t), nullptr), "memset");
+        if (rc == UGP_OK) rc = run_place(m, qs, 2, nullptr, nullptr, d_best.p, d_cnt.p, d_j.p, d_hu.p, cap, nullptr);
     }
-    if (rc == UGP_OK) rc = run_place(m, qs, 2, nullptr, nullptr, d_best.p, d_cnt.p, d_j.p, d_hu.p, cap, nullptr);
     if (rc == UGP_OK) {
         chk(hipMemcpy(tie_count, d_cnt.p, Q * sizeof(uint32_t), hipMemcpyDeviceToHost), "copy tie counts");
         if (cap) {

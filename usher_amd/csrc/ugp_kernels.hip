@@ -298,8 +298,11 @@ struct WalkOut { uint32_t best, cnt, key; };
 // into `rowbuf`; the mutation words of the window are then served from LDS.  One exposed memory latency per 64 words
 // instead of one per mutation: this walk is a chain of dependent loads (k_ties 0.43 -> 0.28 ms at 16,384 samples).
 // (Fetching the next window ahead into registers was tried: slower -- the walk jumps, and the registers cost occupancy.)
+// LIST: the tied nodes are also appended to the samples' lists (a.tie_count / tie_j / tie_hu, indexed by the sample's position in
+// the caller's batch: `list_q`) -- ugp_tied_nodes from the chunks that attain the minimum instead of a second walk of the tree.
+template <bool LIST>
 __device__ __forceinline__ WalkOut walk_ties(const PlaceArgs &a, uint32_t *slots, uint32_t *rowbuf, uint32_t tile, uint32_t c, uint32_t lane,
-                                             uint32_t want, bool relevant) {
+                                             uint32_t want, bool relevant, const uint32_t *rank2bfs, uint32_t list_q) {
     const uint32_t *tab8 = a.table + ((uint64_t)(tile >> 3) * (a.n_sites + TABLE_CONST_ROWS) + TABLE_CONST_ROWS) * 64 + (tile & 7u) * 8;   // + 64 * site: 8 dwords
     const uint32_t col = lane >> 3;
     const uint32_t sh = (lane & 7u) * 4u;
@@ -374,7 +377,16 @@ __device__ __forceinline__ WalkOut walk_ties(const PlaceArgs &a, uint32_t *slots
                     elig = (common > 0) || free_internal;
                     hu = (masked || common != n_before) ? 1u : 0u;
                 }
-                if (relevant && elig && cost == want) { o.cnt++; o.key = max(o.key, key | hu); }
+                if (relevant && elig && cost == want) {
+                    o.cnt++; o.key = max(o.key, key | hu);
+                    if (LIST) {
+                        const uint32_t i = atomicAdd(&a.tie_count[list_q], 1u);
+                        if (i < a.tie_cap) {
+                            a.tie_j[(uint64_t)list_q * a.tie_cap + i] = rank2bfs[key >> 1];
+                            a.tie_hu[(uint64_t)list_q * a.tie_cap + i] = (uint8_t)hu;
+                        }
+                    }
+                }
             }
             if (have_info) {
                 have_info = false;
@@ -1474,10 +1486,12 @@ __global__ void k_select(const uint32_t *__restrict__ lbest, const uint32_t *__r
 // Phase 2: re-walk only the selected (chunk, 64-sample tile) pairs, one sample
 // per lane, counting the nodes that attain the sample's global minimum and
 // keeping the reference's winner among them (usher_mapper.cpp:476-497).
+template <bool LIST>
 __global__ void __launch_bounds__(64) k_ties(PlaceArgs a, const uint32_t *__restrict__ lbest, const uint32_t *__restrict__ gbest,
                                              const uint32_t *__restrict__ items, const uint32_t *__restrict__ n_items,
                                              uint32_t cap, uint32_t n_t64 /* 8 * n_tiles512, as k_select encodes */,
-                                             uint32_t *__restrict__ cnt_out, uint32_t *__restrict__ key_out) {
+                                             uint32_t *__restrict__ cnt_out, uint32_t *__restrict__ key_out,
+                                             const uint32_t *__restrict__ rank2bfs, const uint32_t *__restrict__ order /* slot -> sample, or nullptr */) {
     extern __shared__ __attribute__((aligned(16))) uint32_t slots[];
     __shared__ __attribute__((aligned(16))) uint32_t rowbuf[64 * 8];
     const uint32_t lane = threadIdx.x;
@@ -1488,7 +1502,8 @@ __global__ void __launch_bounds__(64) k_ties(PlaceArgs a, const uint32_t *__rest
         const uint32_t q = t64 * 64 + lane;
         const uint32_t want = (q < a.n_queries) ? pk_lookup(gbest, q >> 9, q & 511u) : 0xFFFFFFFFu;
         const bool relevant = q < a.n_queries && pk_lookup(lbest + (uint64_t)c * (n_t64 / 8u) * 256u, q >> 9, q & 511u) == want;
-        WalkOut r = walk_ties(a, slots, rowbuf, t64, c, lane, want, relevant);
+        const uint32_t list_q = (LIST && q < a.n_queries) ? (order ? order[q] : q) : 0u;
+        WalkOut r = walk_ties<LIST>(a, slots, rowbuf, t64, c, lane, want, relevant, rank2bfs, list_q);
         if (r.cnt) {
             atomicAdd(&cnt_out[q], r.cnt);
             atomicMax(&key_out[q], r.key);
@@ -1933,7 +1948,7 @@ hipError_t launch_coarse_result(const uint32_t *lbest, const uint32_t *list, con
 hipError_t launch_phase2(const PlaceArgs &a, const uint32_t *lbest, const uint32_t *list, const uint32_t *list_n, uint32_t *gbest_part,
                          uint32_t *gbest, uint32_t n_tiles512,
                          uint32_t *items, uint32_t *n_items, uint32_t cap, uint32_t *cnt, uint32_t *key,
-                         const uint32_t *rank2bfs, ugp_result *out, const uint32_t *order, uint32_t max_slots, hipStream_t s) {
+                         const uint32_t *rank2bfs, ugp_result *out, const uint32_t *order, uint32_t max_slots, bool lists, hipStream_t s) {
     const uint32_t per_chunk = n_tiles512 * 256;
     const uint32_t slices = std::min<uint32_t>(GBEST_SLICES, a.n_chunks);
     hipLaunchKernelGGL(k_gbest, dim3(n_tiles512, slices), dim3(256), 0, s, lbest, list, list_n, a.n_chunks, n_tiles512, gbest_part);
@@ -1946,7 +1961,8 @@ hipError_t launch_phase2(const PlaceArgs &a, const uint32_t *lbest, const uint32
     const size_t lds = (size_t)max_slots * 64 * sizeof(uint32_t);
     uint32_t blocks = 256 * 32;   // latency-bound walk: as many waves as a CU holds (3.3 KB of LDS each)
     if ((uint64_t)blocks > pairs) blocks = (uint32_t)pairs;
-    hipLaunchKernelGGL(k_ties, dim3(blocks), dim3(64), lds, s, a, lbest, gbest, items, n_items, cap, n_tiles512 * 8, cnt, key);
+    if (lists) hipLaunchKernelGGL(k_ties<true>, dim3(blocks), dim3(64), lds, s, a, lbest, gbest, items, n_items, cap, n_tiles512 * 8, cnt, key, rank2bfs, order);
+    else hipLaunchKernelGGL(k_ties<false>, dim3(blocks), dim3(64), lds, s, a, lbest, gbest, items, n_items, cap, n_tiles512 * 8, cnt, key, rank2bfs, order);
     hipLaunchKernelGGL(k_final, dim3((a.n_queries + 255) / 256), dim3(256), 0, s, gbest, cnt, key, rank2bfs, a.n_queries, out, order);
     return hipGetLastError();
 }
