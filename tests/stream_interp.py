@@ -30,6 +30,19 @@ def sample_site_alleles(flat, sample):
     return nib, dbot
 
 
+def sample_site_alleles(flat, sample):
+    """nibble per site (reference base unless the sample has a row) and D_bottom."""
+    nib = flat.site_ref.astype(np.int64).copy()
+    dbot = 0
+    for p, r, a, mis in zip(sample["pos"], sample["ref"], sample["nuc"], sample["is_missing"]):
+        a = 15 if mis else int(a)
+        if not mis and (a & int(r)) == 0:
+            dbot += 1
+        if 0 <= p < len(flat.pos2site) and flat.pos2site[p] >= 0:
+            nib[flat.pos2site[p]] = a
+    return nib, dbot
+
+
 def variant_rows(sample):
     """V of the second pruning bound: rows whose allele set is neither missing nor just the reference base."""
     return sum(1 for r, a, mis in zip(sample["ref"], sample["nuc"], sample["is_missing"]) if not mis and int(a) != int(r))
@@ -127,18 +140,22 @@ CE_LEN_SHIFT, CE_LEN_MASK = 10, (1 << 19) - 1
 INFO_HR_SHIFT, INFO_HR_NONE, INFO_JUMP_MASK, PRE_HS_NONE = 18, 7, (1 << 18) - 1, 127
 
 
-def far(d, rec, ub, vrow, pre=False):
-    """The kernel's all_far for one sample: D - hs > ub, or D - (V + hr) > ub (second bound, when the record has hr).
+def far(d, b, rec, ub, pre=False):
+    """The kernel's all_far for one sample: D - hs > ub, or B - hr > ub (second bound, when the record has hr; B = the part
+    of D at sites where the sample's set holds the reference base, one byte in the kernel).
     pre: a preamble record, whose hs field may say "not available"."""
     hs, hr = (rec >> INFO_HS_SHIFT) & 0x7F, (rec >> INFO_HR_SHIFT) & 7
     if not (pre and hs == PRE_HS_NONE) and d >= ub + 1 + hs:
         return True
-    return vrow is not None and hr != INFO_HR_NONE and d - hr >= min(ub + 1 + vrow, 0x7F80)
+    if hr == INFO_HR_NONE:
+        return False
+    assert 0 <= b <= 255
+    return b >= ub + 1 + hr
 M_FLUSH, M_END = 1 << 28, 1 << 30
 U16 = 0xFFFF
 
 
-def best8_group(flat, nib, dbot, c0, c1, ub=None, stats=None, vrow=None, use_pre_records=True):
+def best8_group(flat, nib, dbot, c0, c1, ub=None, stats=None, use_pre_records=True):
     """Chunk-local minima of one sample for chunks [c0, c1), as k_best8 computes them.
     ub: None = no pruning; otherwise a one-element list holding an upper bound of the sample's best
     score, used (and tightened at chunk ends) exactly like the kernel's shared bound."""
@@ -146,26 +163,29 @@ def best8_group(flat, nib, dbot, c0, c1, ub=None, stats=None, vrow=None, use_pre
     lbest = {}
     best = U16
     dcur, dpar = dbot, 0        # (the root reads "the previous node's D": every unit starts from D(bottom))
-    accP = accC = accN = 0
-    carryD = carryN = carryC = 0
+    bcur, bpar = 0, 0           # B(bottom) = 0: every state is the reference base there
+    accP = accC = accN = accPB = accCB = 0
+    carryD = carryN = carryC = carryB = 0
     flushed = False
     hdr = 0
     chunk = c0
 
     def finish():
-        nonlocal best, dcur, accP, accC, accN, flushed, carryD, carryN, carryC
+        nonlocal best, dcur, bcur, accP, accC, accN, accPB, accCB, flushed, carryD, carryN, carryC, carryB
         assert accP <= 15 and accC <= 15 and accN <= 15
         # (the kernel computes D(node) for H_SKIPD nodes too; nothing reads it)
         dn = (dpar + accP - accC + (carryD if flushed else 0)) & U16
         dcur = dn
+        bcur = bpar + accPB - accCB + (carryB if flushed else 0)   # (a byte in the kernel; only read where a record offers the second bound)
+        assert 0 <= bcur <= dn
         if hdr & H_STORE:
-            slots[(hdr >> H_WSLOT_SHIFT) & 63] = dn
+            slots[(hdr >> H_WSLOT_SHIFT) & 63] = (dn, bcur)
         if not (hdr & H_NOSCORE8):
             cost = (dpar - accN - (carryN if flushed else 0)) & U16
             common = (accC + (carryC if flushed else 0) + (1 if hdr & H_FREE else 0)) & U16
             inelig = 0x8000 if common == 0 else 0   # bit 15 = ineligible flag; valid costs stay below 0x8000
             best = min(best, cost | inelig)
-        accP = accC = accN = 0
+        accP = accC = accN = accPB = accCB = 0
         flushed = False
 
     info = None
@@ -224,11 +244,11 @@ def best8_group(flat, nib, dbot, c0, c1, ub=None, stats=None, vrow=None, use_pre
                 else:
                     assert (w & H_REG) or ((w >> H_RSLOT_SHIFT) & 63) < flat.lds_slots
                     assert not (w & H_STORE) or ((w >> H_WSLOT_SHIFT) & 63) < flat.lds_slots
-                dpar = dcur if w & H_REG else slots[(w >> H_RSLOT_SHIFT) & 63]
+                dpar, bpar = (dcur, bcur) if w & H_REG else slots[(w >> H_RSLOT_SHIFT) & 63]
                 if sinfo is not None:   # sibling record: skip this child and the non-last siblings after it?
                     rec, jump = sinfo, sinfo & INFO_JUMP_MASK
                     sinfo = None
-                    if far(dpar, rec, ub[0], vrow):
+                    if far(dpar, bpar, rec, ub[0]):
                         target = i + jump
                         info = None
                         if stats is not None:
@@ -245,17 +265,20 @@ def best8_group(flat, nib, dbot, c0, c1, ub=None, stats=None, vrow=None, use_pre
                     finish()
                     ended = True
             else:
-                site, mi, pi = w & 0x3FFFFF, (w >> 22) & 3, (w >> 24) & 3
+                site, mi, pi, ri = w & 0x3FFFFF, (w >> 22) & 3, (w >> 24) & 3, (w >> 26) & 3
                 x = int(nib[site])
-                c, p = (x >> mi) & 1, (x >> pi) & 1
+                c, p, r = (x >> mi) & 1, (x >> pi) & 1, (x >> ri) & 1
                 accP += p
                 accC += c
                 accN += c & (1 - p)
+                accPB += p & r
+                accCB += c & r
                 if w & M_FLUSH:
                     carryD = ((carryD if flushed else 0) + accP - accC) & U16
                     carryN = ((carryN if flushed else 0) + accN) & U16
                     carryC = ((carryC if flushed else 0) + accC) & U16
-                    accP = accC = accN = 0
+                    carryB = (carryB if flushed else 0) + accPB - accCB
+                    accP = accC = accN = accPB = accCB = 0
                     flushed = True
                 if w & M_END:
                     finish()
@@ -263,7 +286,7 @@ def best8_group(flat, nib, dbot, c0, c1, ub=None, stats=None, vrow=None, use_pre
             if ended and info is not None and phase == 0:
                 # preamble record of a path node: nothing of its subtree is needed -> stop the replay, start the body behind it
                 rec, info = info, None
-                if far(dcur, rec, ub[0], vrow, pre=True):
+                if far(dcur, bcur, rec, ub[0], pre=True):
                     body_start = rec & INFO_JUMP_MASK
                     if stats is not None:
                         stats["pre_skipped"] = stats.get("pre_skipped", 0) + min(body_start, int(flat.chunk8_body_off[c1]) - body0)
@@ -271,7 +294,7 @@ def best8_group(flat, nib, dbot, c0, c1, ub=None, stats=None, vrow=None, use_pre
             elif ended and info is not None:
                 rec, jump = info, info & INFO_JUMP_MASK
                 info = None
-                if far(dcur, rec, ub[0], vrow):     # D(node) - bound > upper bound: no descendant can tie or win
+                if far(dcur, bcur, rec, ub[0]):     # D(node) - bound > upper bound: no descendant can tie or win
                     target = i + 1 + jump
                     if stats is not None:
                         stats["skipped"] = stats.get("skipped", 0) + min(target, hi) - (i + 1)
@@ -301,7 +324,7 @@ def place8(flat, sample, n_groups=1, prune_ub=None, stats=None):
     for g in range(n_groups):
         c0, c1 = g * n_chunks // n_groups, (g + 1) * n_chunks // n_groups
         if c0 < c1:
-            lbest.update(best8_group(flat, nib, dbot, c0, c1, ub, stats, vrow=variant_rows(sample)))
+            lbest.update(best8_group(flat, nib, dbot, c0, c1, ub, stats))
     assert len(lbest) == n_chunks
     gbest = min(lbest.values())
     cnt, key = 0, 0

@@ -208,7 +208,7 @@ def test_preamble_records_skip_far_units_exactly(seed, chunk_nodes, monkeypatch)
     replay a few nodes below the point where its root path leaves the sample's and skips most of its body; the chunk
     minima that matter must be unchanged, for loose and tight upper bounds, units of 1, 3 and 8 chunks."""
     monkeypatch.setenv("UGP_LDS_SLOTS", "3")
-    arrays, queries = synth.make_case(seed, n_leaves=2500, n_queries=8, n_sites=300, n_ambig=(0, 0, 2), p_masked=0.02,
+    arrays, queries = synth.make_case(seed, n_leaves=2500, n_queries=8, n_sites=3000, n_ambig=(0, 0, 2), p_masked=0.02,
                                       mut_counts=(0, 0, 1, 1, 1, 2, 3, 17))
     flat = FlatTreeView(arrays, chunk_nodes=chunk_nodes)
     n_chunks = len(flat.chunk8_body_off) - 1
@@ -217,7 +217,6 @@ def test_preamble_records_skip_far_units_exactly(seed, chunk_nodes, monkeypatch)
     for s in queries:
         want = ot.place(s)
         nib, dbot = stream_interp.sample_site_alleles(flat, s)
-        v = stream_interp.variant_rows(s)
         for ub0 in (0x7F7F, want["best"] + 2, want["best"]):
             for unit in (1, 3, 8, 16):
                 st = {}
@@ -225,8 +224,8 @@ def test_preamble_records_skip_far_units_exactly(seed, chunk_nodes, monkeypatch)
                 ub_a, ub_b = [ub0], [ub0]
                 for c0 in range(0, n_chunks, unit):
                     c1 = min(c0 + unit, n_chunks)
-                    lb_pre.update(stream_interp.best8_group(flat, nib, dbot, c0, c1, ub_a, st, vrow=v))
-                    lb_plain.update(stream_interp.best8_group(flat, nib, dbot, c0, c1, ub_b, None, vrow=None, use_pre_records=False))
+                    lb_pre.update(stream_interp.best8_group(flat, nib, dbot, c0, c1, ub_a, st))
+                    lb_plain.update(stream_interp.best8_group(flat, nib, dbot, c0, c1, ub_b, None, use_pre_records=False))
                 assert min(lb_pre.values()) == want["best"] == min(lb_plain.values())
                 assert [c for c in range(n_chunks) if lb_pre[c] == want["best"]] == [c for c in range(n_chunks) if lb_plain[c] == want["best"]]
                 if ub0 == want["best"]:

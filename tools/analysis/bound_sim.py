@@ -55,16 +55,19 @@ print("nodes", n, "mutations", M, "levels", len(starts) - 1)
 mpar = np.asarray(A["mut_par"]).astype(np.uint8)
 is_rev = (mnuc == mref).astype(np.int64)
 rev_n = np.bincount(node_of_mut, weights=is_rev, minlength=n).astype(np.int64)
+sec_n = np.bincount(node_of_mut, weights=(mpar != mref).astype(np.int64), minlength=n).astype(np.int64)   # mutations of a site that is not at the reference base
 
 # bottom-up: hsub, hrev, subtree words
-hsub = np.zeros(n, np.int64); hrev = np.zeros(n, np.int64); subw = np.zeros(n, np.int64)
+hsub = np.zeros(n, np.int64); hrev = np.zeros(n, np.int64); subw = np.zeros(n, np.int64); hsec = np.zeros(n, np.int64)
 for li in range(len(starts) - 2, 0, -1):
     lo, hi = starts[li], starts[li + 1]
     p = par[lo:hi]
     np.maximum.at(hsub, p, nw[lo:hi] + hsub[lo:hi])
     np.maximum.at(hrev, p, rev_n[lo:hi] + hrev[lo:hi])
+    np.maximum.at(hsec, p, sec_n[lo:hi] + hsec[lo:hi])
     np.add.at(subw, p, subw[lo:hi] + 1 + nw[lo:hi])
 has_rec = (subw >= 4) & (hsub <= 127)
+print("hsec max", hsec.max(), "nodes with hsec > 0:", int((hsec > 0).sum()))
 print("hsub max", hsub.max(), "hrev max", hrev.max(), "nodes with hrev > 0:", int((hrev > 0).sum()), "records", int(has_rec.sum()))
 
 # queries, sorted by the DFS position of their source node ~ the locality sort
@@ -112,14 +115,23 @@ common = ((Sm & mnuc[None, :]) != 0)
 idx = off[:-1][nw > 0]
 dn = np.zeros((512, n), np.int16); cn = np.zeros((512, n), np.int16); en = np.zeros((512, n), bool)
 dn[:, nw > 0] = np.add.reduceat(delta, idx, axis=1)
+# A(n, s) = mismatching sites whose sample set excludes the reference base (the sample's true variants not matched at n)
+refin = ((Sm & mref[None, :]) != 0)
+an = np.zeros((512, n), np.int16)
+an[:, nw > 0] = np.add.reduceat(np.where(refin, 0, delta).astype(np.int8), idx, axis=1)
+del refin
 cn[:, nw > 0] = np.add.reduceat(neg, idx, axis=1)
 en[:, nw > 0] = np.add.reduceat(common, idx, axis=1) > 0
 del delta, neg, common, Sm
 D = np.zeros((512, n), np.int16)
 D[:, 0] = dbot + dn[:, 0]
+Aout = np.zeros((512, n), np.int16)
+Aout[:, 0] = dbot + an[:, 0]                                  # below the root every mismatch is an unmatched true variant
 for li in range(1, len(starts) - 1):
     lo, hi = starts[li], starts[li + 1]
     D[:, lo:hi] = D[:, par[lo:hi]] + dn[:, lo:hi]
+    Aout[:, lo:hi] = Aout[:, par[lo:hi]] + an[:, lo:hi]
+del an
 leaf = np.ones(n, bool); leaf[par[1:]] = False
 cost = np.empty((512, n), np.int32)
 cost[:, 0] = D[:, 0]
@@ -145,9 +157,20 @@ def walk(bound_fn, name, slack=0):
     print("%-34s slack %d: visited nodes %9d (%.2f %%)  words %9d  jumps %8d" % (name, slack, int(visited.sum()), 100.0 * visited.sum() / n, words, jumps))
     return visited, pruned_at
 
+# floor: a perfect test (a subtree is walked iff some sample has a tie or better on an eligible node inside it)
+hit = (np.where(elig, cost, 1 << 20) <= best[:, None]).any(axis=0)
+need = np.zeros(n, bool)
+for li in range(len(starts) - 2, 0, -1):
+    lo, hi = starts[li], starts[li + 1]
+    np.logical_or.at(need, par[lo:hi], need[lo:hi] | hit[lo:hi])
+vis = np.ones(n, bool); vis[1:] = need[par[1:]]
+print("floor (perfect subtree test): visited nodes %d (%.2f %%) words %d; nodes with a tie or better: %d" % (int(vis.sum()), 100.0 * vis.sum() / n, int((1 + nw)[vis].sum()), int(hit.sum())))
+
 for slack in (0, 2, 4, 8):
     va, pa = walk(lambda k: hsub, "A: D - hsub", slack)
     vb, pb = walk(lambda k: np.minimum(hsub, V[k] + hrev), "B: D - min(hsub, V_s + hrev)", slack)
+    vc, pc = walk(lambda k: np.minimum(hsub, Aout[k].astype(np.int64) + hsec), "C: D - min(hsub, A(n,s) + hsec)", slack)
+    vd, pd = walk(lambda k: np.minimum(hsub, np.minimum(V[k] + hrev, Aout[k].astype(np.int64) + hsec)), "B and C", slack)
     if slack == 0:
         # where do the extra jumps of B sit?
         extra = pb & vb & ~pa

@@ -302,11 +302,11 @@ int run_place(ugp_mat *m, ugp_qset *qs, int mode, ugp_result *d_out, int32_t *d_
         // D(bottom) counters, active-row bitmap, work-queue heads, record lists' lengths, phase-2 item count, tie counts / keys
         const size_t z_dbottom = 0, z_active = z_dbottom + (size_t)n_tiles512 * 512, z_queue = z_active + (size_t)n_tiles512 * active_words,
                      z_list_n = z_queue + 8, z_nitems = z_list_n + n_tiles512, z_cnt = z_nitems + 8, z_key = z_cnt + (size_t)n_tiles512 * 512,
-                     z_vrows = z_key + (size_t)n_tiles512 * 512, z_end = z_vrows + (size_t)n_tiles512 * 512;
+                     z_end = z_key + (size_t)n_tiles512 * 512;
         HIP_TRY(W.d_zero.reserve(z_end));
         uint32_t *const d_dbottom = W.d_zero.p + z_dbottom, *const d_active = W.d_zero.p + z_active, *const d_queue = W.d_zero.p + z_queue,
                  *const d_list_n = W.d_zero.p + z_list_n, *const d_nitems = W.d_zero.p + z_nitems, *const d_cnt = W.d_zero.p + z_cnt,
-                 *const d_key = W.d_zero.p + z_key, *const d_vrows = W.d_zero.p + z_vrows;
+                 *const d_key = W.d_zero.p + z_key;
         if (use8) {
             HIP_TRY(W.d_lbest.reserve((size_t)f.n_chunks * n_tiles512 * 256));
             HIP_TRY(W.d_list.reserve((size_t)f.n_chunks * n_tiles512));
@@ -349,12 +349,12 @@ int run_place(ugp_mat *m, ugp_qset *qs, int mode, ugp_result *d_out, int32_t *d_
         if (lds_build)
             HIP_TRY(ugp::launch_build_tiles(W.d_table.p, d_active, active_words, n_tiles512, qs->d_ent_off.p, (uint32_t)q0, order, (uint32_t)nq, qs->d_pos.p,
                                             qs->d_ref.p, qs->d_nuc.p, qs->d_missing.p, m->d_pos2site.p, m->d_site_pos.p, m->d_site_ref.p, n_sites, f.max_pos,
-                                            d_dbottom, d_vrows, s));
+                                            d_dbottom, nullptr, s));
         else {
         HIP_TRY(ugp::launch_fill_table(W.d_table.p, m->d_site_ref.p, n_sites, table_dwords, s));
         HIP_TRY(ugp::launch_scatter(W.d_table.p, d_dbottom, qs->d_pos.p + e0, qs->d_ref.p + e0,
                                     qs->d_nuc.p + e0, qs->d_missing.p + e0, qs->d_ent_q.p + e0, m->d_pos2site.p,
-                                    f.max_pos, n_sites, e1 - e0, (uint32_t)q0, d_active, active_words, slot_of, use8 ? d_vrows : nullptr, s));
+                                    f.max_pos, n_sites, e1 - e0, (uint32_t)q0, d_active, active_words, slot_of, nullptr, s));
         }
         if (use8) {   // upper bounds of best(s) the pruning starts from
             if (sorted && getenv("UGP_SEED_PREV") && W.d_prev_res.cap >= Q && W.prev_serial == qs->serial)   // (experiment: bounds = the previous call's exact answers)
@@ -447,7 +447,7 @@ int run_place(ugp_mat *m, ugp_qset *qs, int mode, ugp_result *d_out, int32_t *d_
             memset(&b, 0, sizeof(b));
             b.stream8 = m->d_stream8.p; b.pre8 = m->d_pre8.p;
             b.chunk8_body_off = m->d_chunk8_body.p; b.chunk8_pre_off = m->d_chunk8_pre.p;
-            b.table = W.d_table.p; b.dbottom = d_dbottom; b.vrows = getenv("UGP_NO_BOUND2") ? nullptr : d_vrows;
+            b.table = W.d_table.p; b.dbottom = d_dbottom;
             b.n_sites = n_sites; b.n_chunks = f.n_chunks; b.n_groups = G; b.n_tiles = n_tiles512;
             b.lbest = W.d_lbest.p;
             b.list = W.d_list.p; b.list_n = d_list_n;
@@ -552,7 +552,7 @@ int run_place(ugp_mat *m, ugp_qset *qs, int mode, ugp_result *d_out, int32_t *d_
             uint64_t blocks = (uint64_t)waves_cu * std::max(m->n_cu, 1);
             blocks = std::min<uint64_t>(blocks, (uint64_t)n_tiles512 * G);
             blocks = ((blocks + 7) / 8) * 8;
-            HIP_TRY(W.d_cold.reserve((size_t)blocks * std::max<uint32_t>(f.max_slots - b.lds_slots, 1) * 256));
+            HIP_TRY(W.d_cold.reserve((size_t)blocks * std::max<uint32_t>(f.max_slots - b.lds_slots, 1) * 512));   // 32 B per lane and cold slot
             b.cold = W.d_cold.p;
             b.active = d_active; b.active_words = active_words;
             // (UGP_KBEST_EXCLUSIVE: of the two calls that may be on the device at a time, ugp_place_device, only one runs this

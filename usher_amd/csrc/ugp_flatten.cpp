@@ -182,14 +182,14 @@ int flatten(const ugp_tree_desc &t, const Options &opt, FlatMat &out, std::strin
 
     // ---- own mutation words, never-eligible leaves --------------------------------------------------------------
     Buf<uint32_t> nw(N);            // non-masked mutations of the node
-    Buf<uint8_t> rev(N);            // ... of which back to the reference base (saturating at 255)
+    Buf<uint8_t> rev(N);            // ... of which hit a site that is NOT at the reference base in the parent (saturating at 255; filled by the DFS emission, which tracks the states)
     Buf<uint8_t> dropped(N);        // leaf without mutation words: never eligible, no descendants (packed / tie streams skip it)
     par.run(N, [&](uint64_t b, uint64_t e, unsigned) {
         for (uint64_t j = b; j < e; j++) {
-            uint32_t c = 0, r = 0;
-            for (uint64_t i = t.mut_off[j]; i < t.mut_off[j + 1] && i < M; i++) { c += t.mut_pos[i] >= 0; r += t.mut_pos[i] >= 0 && t.mut_nuc[i] == t.mut_ref[i]; }
+            uint32_t c = 0;
+            for (uint64_t i = t.mut_off[j]; i < t.mut_off[j + 1] && i < M; i++) c += t.mut_pos[i] >= 0;
             nw[j] = c;
-            rev[j] = (uint8_t)std::min<uint32_t>(r, 255);
+            rev[j] = 0;
             dropped[j] = j != 0 && child_off[j + 1] == child_off[j] && c == 0;
         }
     });
@@ -199,19 +199,17 @@ int flatten(const ugp_tree_desc &t, const Options &opt, FlatMat &out, std::strin
     // tie-stream dwords of j's descendants (without pruning records)
     UVec<uint32_t> sub(N);
     Buf<uint32_t> leaves(N), hsub(N), subw(N), subd(N);
-    Buf<uint8_t> hrev(N);   // largest number of reversions on a path j -> descendant, without j's own (saturating at 255)
+    Buf<uint8_t> hrev(N);   // largest number of second hits (rev) on a path j -> descendant, without j's own (saturating at 255; second pass below)
     bottom_up([&](uint64_t p, unsigned) {
-        uint32_t s = 1, lv = 0, h = 0, w = 0, d = 0, hr = 0;
+        uint32_t s = 1, lv = 0, h = 0, w = 0, d = 0;
         for (uint32_t k = child_off[p]; k < child_off[p + 1]; k++) {
             const uint32_t c = children[k];
             s += sub[c]; lv += leaves[c];
             h = std::max(h, nw[c] + hsub[c]);
-            hr = std::max<uint32_t>(hr, (uint32_t)rev[c] + hrev[c]);
             w += subw[c] + (dropped[c] ? 0u : 1u + nw[c]);
             d += subd[c] + (dropped[c] ? 0u : 2u + nw[c]);
         }
         sub[p] = s; leaves[p] = (child_off[p + 1] == child_off[p]) ? 1u : lv; hsub[p] = h; subw[p] = w; subd[p] = d;
-        hrev[p] = (uint8_t)std::min<uint32_t>(hr, 255);
     });
     // largest subtree last; the others by descending hdown (the sibling pruning records rely on it)
     par.run(N, [&](uint64_t b0, uint64_t e0, unsigned) {
@@ -315,7 +313,7 @@ int flatten(const ugp_tree_desc &t, const Options &opt, FlatMat &out, std::strin
     // path, <= log2 N because the largest subtree goes last
     UVec<uint32_t> dfsidx(N);
     Buf<uint32_t> pathm(N), eff_children(N), last_eff(N), suffix_h(N), big_after(N);   // (suffix_h / big_after: non-last effective children only)
-    Buf<uint8_t> slot(N), first_child(N), first_eff(N), suffix_hr(N);   // (suffix_hr: like suffix_h, over reversions)
+    Buf<uint8_t> slot(N), first_child(N), first_eff(N), suffix_hr(N);   // (suffix_hr: like suffix_h, over second hits)
     slot[0] = 0; first_child[0] = 0; first_eff[0] = 0;
     struct alignas(64) Maxima { uint32_t path = 0, slot = 0; };   // one cache line per thread
     std::vector<Maxima> mx(T);
@@ -341,15 +339,13 @@ int flatten(const ugp_tree_desc &t, const Options &opt, FlatMat &out, std::strin
         last_eff[p] = last;
         // sibling records: for a non-last effective child c, suffix_h[c] = max hdown over c and the non-last effective
         // siblings after it, big_after[c] = how many of those later siblings carry a pruning record of their own
-        uint32_t run_h = 0, run_big = 0, run_hr = 0;
+        uint32_t run_h = 0, run_big = 0;
         for (uint32_t k = e; k-- > b;) {
             const uint32_t c = children[k];
             if (dropped[c] || c == last) continue;
             big_after[c] = run_big;
             run_h = std::max(run_h, nw[c] + hsub[c]);
             suffix_h[c] = run_h;
-            run_hr = std::max<uint32_t>(run_hr, (uint32_t)rev[c] + hrev[c]);
-            suffix_hr[c] = (uint8_t)std::min<uint32_t>(run_hr, 255);
             if (subw[c] >= opt.prune_min_words && hsub[c] <= INFO_HS_MAX) run_big++;
         }
     });
@@ -411,7 +407,7 @@ int flatten(const ugp_tree_desc &t, const Options &opt, FlatMat &out, std::strin
             if (root) w0 |= F_ROOT;
             uint32_t *rec = &out.stream[rec_off_d[d]];
             stack.push_back({d + sub[j], (uint32_t)undo.size()});
-            uint32_t nwords = 0;
+            uint32_t nwords = 0, second = 0;
             bool masked = false;
             int32_t last_pos = -1;
             for (uint64_t i = b; i < e; i++) {
@@ -422,6 +418,7 @@ int flatten(const ugp_tree_desc &t, const Options &opt, FlatMat &out, std::strin
                 const uint32_t site = (uint32_t)out.pos2site[p];
                 const uint32_t mi = (uint32_t)nuc_index(t.mut_nuc[i]), pi = cur[site], ri = (uint32_t)nuc_index(out.site_ref[site]);
                 uint32_t w = site | (mi << 22) | (pi << 24) | (ri << 26);
+                second += pi != ri;
                 if (masked && !root) w |= M_AFTER_MASK;
                 rec[2 + nwords] = w;
                 undo.push_back({site, cur[site]});
@@ -430,6 +427,7 @@ int flatten(const ugp_tree_desc &t, const Options &opt, FlatMat &out, std::strin
             }
             if (nwords > MAX_NODE_MUTS) { ferr.report(3, d, UGP_ERR_UNSUPPORTED, "node with more than 65534 mutations"); return; }
             node_masked[j] = masked && !root;
+            rev[j] = (uint8_t)std::min<uint32_t>(second, 255);
             if (masked && !root) w0 |= F_MASKED;   // root: masked mutations are inert (usher_mapper.cpp:266-269, 309-311, 401-403)
             rec[0] = w0 | nwords | (rslot << 16) | (wslot << 22);
             rec[1] = rank[j] << 1;
@@ -439,6 +437,29 @@ int flatten(const ugp_tree_desc &t, const Options &opt, FlatMat &out, std::strin
     if (ferr.any) return failed();
     out.mask_not_first = mask_not_first;
     flat_lap("DFS emission");
+
+    // ---- second pruning bound (ugp_flatten.hpp): hrev[j] = largest number of second hits on a path j -> descendant, and the
+    // same over the later non-last siblings (sibling records).  Needs the parent states, hence after the emission.
+    // B(n, s) of k_best8 is kept in 8 bits per sample and never exceeds the mutations on a root path: on a tree deeper than
+    // that the records say "not available".
+    const bool second_bound = out.max_path_muts <= 255;
+    bottom_up([&](uint64_t p, unsigned) {
+        uint32_t hr = 0;
+        for (uint32_t k = child_off[p]; k < child_off[p + 1]; k++) { const uint32_t c = children[k]; hr = std::max<uint32_t>(hr, (uint32_t)rev[c] + hrev[c]); }
+        hrev[p] = second_bound ? (uint8_t)std::min<uint32_t>(hr, 255) : 255;
+    });
+    par.run(N, [&](uint64_t b0, uint64_t e0, unsigned) {
+        for (uint64_t p = b0; p < e0; p++) {
+            uint32_t run_hr = 0;
+            for (uint32_t k = child_off[p + 1]; k-- > child_off[p];) {
+                const uint32_t c = children[k];
+                if (dropped[c] || c == last_eff[p]) continue;
+                run_hr = std::max<uint32_t>(run_hr, (uint32_t)rev[c] + hrev[c]);
+                suffix_hr[c] = (uint8_t)std::min<uint32_t>(run_hr, 255);
+            }
+        }
+    }, 4096);
+    flat_lap("second bound");
 
     // ---- chunks: equal dword budgets, cut at node boundaries ---------------------------------------------------------
     // ~300 nodes per chunk on a 10M-node tree: chunks are the granule of the phase-1 minima (short phase-2

@@ -67,22 +67,26 @@ constexpr uint32_t T_PRUNE_MIN_DWORDS = 24;  // subtrees shorter than this are n
 //       H_INFO    (with H_RARE, in front of the header of a node with a large subtree) pruning record:
 //                 [17:0] jump = stream words occupied by the node's descendants,
 //                 [28:22] hsub = largest number of mutation words on any path node -> descendant,
-//                 [20:18] hrev = largest number of mutations BACK TO THE REFERENCE BASE on any such path
-//                 (INFO_HR_NONE = 7: more than 6, the second bound below is not available).
+//                 [20:18] hrev = largest number of SECOND HITS on any such path: mutations of a site that is not at its
+//                 reference base in the parent (INFO_HR_NONE = 7: more than 6, or a tree with more than 255 mutations on
+//                 some root path; the second bound below is not available).
 //                 Two lower bounds hold for every descendant d and sample s:
 //                   cost(d,s) >= D(node,s) - hsub          each mutation lowers D by at most 1
-//                   cost(d,s) >= D(node,s) - (V_s + hrev)  V_s = rows of s with an allele set other than {reference}:
-//                     along a path a site lowers D at most once more often than it raises it, and only a site whose
-//                     state at `node` lies outside the sample's set can do that -- a site where the sample has such
-//                     a row (at most V_s of them) or a site that the path turns back to the reference base
-//                 so the subtree is skipped when D(node,s) - min(hsub, V_s + hrev) > upper bound of best(s) for
-//                 all s.  Near the top of the tree hsub is large (the deepest path below) and the second bound
-//                 decides; deep down hsub is small and the first one does.
+//                   cost(d,s) >= B(node,s) - hrev          B(n,s) = sites where the sample's set holds the reference base
+//                     but not the state at n (D = A + B, A = mismatching sites whose set excludes the reference base).
+//                     Along a path a site lowers D at most once more often than it raises it, and only a site whose
+//                     state at `node` lies outside the sample's set can do that: one of the A(node,s) sites, or one of
+//                     the B(node,s) sites -- whose state at `node` is not the reference base, so that its first mutation
+//                     on the path is a second hit.  Hence cost(d,s) >= D - (A + hrev) = B - hrev.
+//                 so the subtree is skipped when max(D - hsub, B - hrev) > upper bound of best(s) for
+//                 all s.  B counts the mutations that the node has and the sample has not, whatever the sample's own
+//                 variants are: a branch leaves a sample's neighbourhood a few foreign mutations away from its lineage,
+//                 however deep the subtree below (hsub) is.
 //       H_INFO | H_SIB (in front of a non-last child c_i of a node p, before c_i's own H_INFO):
 //                 sibling record: [17:0] jump = stream words from c_i's header to the start of p's last child,
 //                 [28:22] hs = max over the remaining non-last children c_j (j >= i) of (mutation words of c_j +
-//                 hsub(c_j)), [20:18] hr = the same maximum over (reversions of c_j + hrev(c_j)); every node d of
-//                 those subtrees has cost(d) >= D(p) - min(hs, V_s + hr), so when that exceeds the upper bound of
+//                 hsub(c_j)), [20:18] hr = the same maximum over (second hits of c_j + hrev(c_j)); every node d of
+//                 those subtrees has cost(d) >= max(D(p) - hs, B(p) - hr), so when that exceeds the upper bound of
 //                 best(s) for all s they are all skipped with one jump.  The non-last children are emitted in
 //                 descending order of hs, so hs only shrinks.
 //     The root is emitted as two records: its D record (H_REG, H_NOSCORE: "the previous node's D" is D_bottom, which
@@ -99,14 +103,14 @@ constexpr uint32_t H_REG = 1u << 0, H_STORE = 1u << 1, H_NOSCORE = 1u << 2, H_EN
 constexpr uint32_t H_RSLOT_SHIFT = 10, H_WSLOT_SHIFT = 20;
 constexpr uint32_t CE_LEN_SHIFT = 10, CE_LEN_MASK = (1u << 19) - 1u;   // chunk-end word: length of the next chunk
 constexpr uint32_t INFO_JUMP_MASK = (1u << 18) - 1u, INFO_HS_SHIFT = 22, INFO_HS_MAX = 127;
-constexpr uint32_t INFO_HR_SHIFT = 18, INFO_HR_NONE = 7;   // hrev field; 7 = not available (more than 6 reversions on some path)
+constexpr uint32_t INFO_HR_SHIFT = 18, INFO_HR_NONE = 7;   // hrev field; 7 = not available (more than 6 second hits on some path)
 // Preamble copies (pre8) carry a pruning record too, in front of every path node below the root: same hs / hr fields
 // (hs = PRE_HS_NONE: hsub too large for the field, first bound not available), and [17:0] = the position, relative to
 // the chunk's first body word, where the body goes on behind that node's subtree (INFO_JUMP_MASK = beyond any unit).
 // When the record's test holds during the replay, the rest of the preamble and the body up to that position are skipped.
 constexpr uint32_t PRE_HS_NONE = 127;
 constexpr uint32_t PRUNE_MIN_WORDS = 4;     // only subtrees at least this long carry a pruning record
-constexpr uint32_t LDS_SLOTS = 9;           // saved-D slots k_best8 keeps in LDS (1 KB each per wave); the colder ones live in a global scratch
+constexpr uint32_t LDS_SLOTS = 9;           // saved (D, B) slots k_best8 keeps in LDS (1.5 KB each per wave); the colder ones live in a global scratch
 constexpr uint32_t M_FLUSH = 1u << 28, M_END = 1u << 30;
 constexpr uint32_t MAX_SITES = 1u << 22;
 constexpr uint32_t MAX_NODE_MUTS = 65534;   // 0xFFFF marks a pruning pseudo-record of the tie stream

@@ -41,6 +41,8 @@ namespace ugp {
 
 typedef unsigned short us2 __attribute__((ext_vector_type(2)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x16 __attribute__((ext_vector_type(16)));
 
 __device__ __forceinline__ uint32_t pk_add(uint32_t a, uint32_t b) {
     return __builtin_bit_cast(uint32_t, __builtin_bit_cast(us2, a) + __builtin_bit_cast(us2, b));
@@ -733,6 +735,8 @@ constexpr unsigned long long DYN_EXIT = (1ull << 53) - 1ull;              // ent
 constexpr uint32_t CONST_ROWS = TABLE_CONST_ROWS;  // rows 0..3 of every tile's table: all samples carry A / C / G / T
 
 __device__ __forceinline__ uint32_t ex4(uint32_t acc, int j) { return (acc >> (4 * j)) & 0x000F000Fu; }
+// ... and as bytes: i = 0: the counters of samples 0, 2, 4, 6; i = 1: of samples 1, 3, 5, 7
+__device__ __forceinline__ uint32_t ex8(uint32_t acc, int i) { return (acc >> (4 * i)) & 0x0F0F0F0Fu; }
 // Packed pairs with plain 32-bit arithmetic: exact as long as both halves of the true result lie in [0, 0xFFFF]
 // (no carry out of / borrow into the low half).  Used for D(par) + e - e' and D(par) - e, whose results are counts.
 __device__ __forceinline__ uint32_t padd(uint32_t a, uint32_t b) { return a + b; }
@@ -743,8 +747,8 @@ __device__ __forceinline__ uint32_t psub(uint32_t a, uint32_t b) { return a - b;
 // words, table rows) instead of three (words, bitmap bits, rows), and the steady loop issues one load less per group.  Costs
 // ~3 KB of LDS per wave (fewer resident waves); the host takes this variant when the bitmap is small enough.
 template <bool STATS, bool LBITS>   // STATS: per-unit accounting for tuning (UGP_STATS); off in production, it costs SGPRs
-__global__ void __launch_bounds__(64, 5) k_best8(Best8Args a) {
-    extern __shared__ __attribute__((aligned(16))) u32x4 slots8[];   // [lds_slots][64] x 16 B: the hot saved-D slots
+__global__ void __launch_bounds__(64, 4) k_best8(Best8Args a) {
+    extern __shared__ __attribute__((aligned(16))) u32x4 slots8[];   // the hot saved slots: [lds_slots][64] x 16 B of D (the 8 B of B per lane and slot are in registers)
     const uint32_t lane = threadIdx.x;
     const uint32_t lane16 = lane * 16u;
     // (explicit address spaces for the slot rows and the cold scratch: through a plain pointer some of these became FLAT
@@ -752,6 +756,7 @@ __global__ void __launch_bounds__(64, 5) k_best8(Best8Args a) {
     // every later wait into a wait for all loads)
     typedef __attribute__((address_space(3))) u32x4 lds_row;
     typedef __attribute__((address_space(1))) u32x4 glb_row;
+    typedef __attribute__((address_space(1))) u32x2 glb_row2;
     auto lds_at = [&](uint32_t byte_off) -> lds_row * { return (lds_row *)((__attribute__((address_space(3))) char *)slots8 + byte_off); };
     // Persistent wave: work units u = (tile, chunk range) are pulled from 8 queues, one per XCD.
     // Queue x owns a contiguous run of tiles, so an XCD walks few tiles at a time and their
@@ -767,9 +772,9 @@ __global__ void __launch_bounds__(64, 5) k_best8(Best8Args a) {
     // Upper bounds (+1) of the tile this wave worked on last, kept across units: the shared copy is read and
     // written with agent-scope accesses that leave the XCD, ~40 us of wave time per exchange, so it is
     // consulted when the wave moves to another tile and every a.ub_every chunk ends, not at every chunk end.
-    Pk4 ub1, ubv1;   // ubv1 = min(ub1 + V, 0x7F80) per sample, V = the sample's variant rows (second pruning bound)
+    Pk4 ub1;
 #pragma unroll
-    for (int j = 0; j < 4; j++) { ub1.v[j] = 0x80008000u; ubv1.v[j] = 0x7F807F80u; }
+    for (int j = 0; j < 4; j++) ub1.v[j] = 0x80008000u;
     uint32_t ub_tile = 0xFFFFFFFFu;   // uniform: tile whose bounds are in ub1
     uint32_t bits_tile = 0xFFFFFFFFu; // uniform (LBITS): tile whose active-row bitmap is in LDS
     uint32_t ub_age = 0;              // uniform: chunk ends since the last exchange
@@ -865,22 +870,18 @@ __global__ void __launch_bounds__(64, 5) k_best8(Best8Args a) {
 #pragma unroll
         for (int j = 0; j < 4; j++) dbot.v[j] = (db[j] & 0xFFFFu) | (db[j + 4] << 16);
     }
-    // ubv1 follows ub1 (chunk ends, exchanges: outside the pipelined loop).  V is read again each time rather than held in
-    // four more registers -- they would cost the fifth wave per SIMD.  (ub1 <= 0x8000 and V < 0x7F7F per half: the sum
-    // stays below 0x10000; the cap keeps the far test free of borrows.)
-    const uint32_t *vr = a.vrows + (uint64_t)tile * 512 + lane * 8;
-    auto refresh_ubv = [&]() {
-        if (!a.vrows) return;   // (UGP_NO_BOUND2: ubv1 stays at the cap, the second test never holds)
-        const uint4 lo = *(const uint4 *)vr, hi = *(const uint4 *)(vr + 4);
-        ubv1.v[0] = pk_min(padd(ub1.v[0], (lo.x & 0xFFFFu) | (hi.x << 16)), 0x7F807F80u);
-        ubv1.v[1] = pk_min(padd(ub1.v[1], (lo.y & 0xFFFFu) | (hi.y << 16)), 0x7F807F80u);
-        ubv1.v[2] = pk_min(padd(ub1.v[2], (lo.z & 0xFFFFu) | (hi.z << 16)), 0x7F807F80u);
-        ubv1.v[3] = pk_min(padd(ub1.v[3], (lo.w & 0xFFFFu) | (hi.w << 16)), 0x7F807F80u);
-    };
     Pk4 best, dcur, dpar, carryD, carryN, carryC;
 #pragma unroll
     for (int j = 0; j < 4; j++) { best.v[j] = 0xFFFFFFFFu; dcur.v[j] = dbot.v[j]; dpar.v[j] = 0; carryD.v[j] = 0; carryN.v[j] = 0; carryC.v[j] = 0; }   // (dcur: the root reads D(bottom) as "the previous node's D")
     uint32_t accP = 0, accC = 0, accN = 0;
+    // B(n, s) = the part of D at sites where the sample's set holds the reference base (second pruning bound, ugp_flatten.hpp):
+    // one byte per sample (b[0]: samples 0, 2, 4, 6 of the lane, b[1]: samples 1, 3, 5, 7), saved and restored with D.
+    // B(bottom) = 0: below the root every state is the reference base.
+    uint32_t bcur[2] = {0, 0}, bpar[2] = {0, 0}, carryB[2] = {0, 0};
+    uint32_t accPB = 0, accCB = 0;   // like accP / accC, over the samples whose set holds the site's reference base
+    // The B halves of the hot slots stay in registers (indexed with the slot number, which is uniform): the kernel's occupancy
+    // is set by its LDS, and 8 more bytes per lane and slot there cost a third of the resident waves; 32 registers cost none.
+    u32x16 bs0 = 0, bs1 = 0;
     uint32_t hdr = 0;          // uniform: header of the open node
     bool flushed = false;      // uniform
     uint32_t chunk = c0;       // uniform: chunk whose body is being walked
@@ -927,7 +928,6 @@ __global__ void __launch_bounds__(64, 5) k_best8(Best8Args a) {
             __hip_atomic_store(ubp + j, u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             ub1.v[j] = pk_add(u, 0x00010001u);
         }
-        refresh_ubv();
     };
     // A chunk's minima matter only if some sample's minimum is within its upper bound (the global minimum
     // never exceeds the bound): only then are they stored, and the chunk is appended to the tile's list of records
@@ -951,7 +951,6 @@ __global__ void __launch_bounds__(64, 5) k_best8(Best8Args a) {
 #pragma unroll
                 for (int j = 0; j < 4; j++)   // what this wave found itself ("no candidate" is 0xFFFF: take the minimum before the +1)
                     ub1.v[j] = pk_add(pk_min(pk_sub(ub1.v[j], 0x00010001u), best.v[j]), 0x00010001u);
-                refresh_ubv();
             }
         }
 #pragma unroll
@@ -975,25 +974,27 @@ __global__ void __launch_bounds__(64, 5) k_best8(Best8Args a) {
         }
     };
     // "can everything below / beside this node be skipped?": true when, for all 512 samples,
-    //     D - hs > ub   or   D - (V + hr) > ub            (ub = upper bound of best(s); the two lower bounds of ugp_flatten.hpp)
+    //     D - hs > ub   or   B - hr > ub            (ub = upper bound of best(s); the two lower bounds of ugp_flatten.hpp)
     // Per half: 0x8000 + D - hs - (ub + 1) keeps bit 15 exactly when D - hs > ub; D < 0x7F7F, ub + 1 + hs <= 0x7FFF, and
-    // in the second test min(ub + 1 + V, 0x7F80) + hr <= 0x7F86, so no half borrows from its neighbour and plain 32-bit
-    // arithmetic is exact (a capped sum only makes the test fail).
-    auto all_far = [&](const Pk4 &d, uint32_t rec) -> bool {
+    // in the second test B <= 255, hr <= 6, so no half borrows from its neighbour and plain 32-bit arithmetic is exact.
+    // (b[0] holds the lane's samples 0, 2, 4, 6 as bytes, b[1] 1, 3, 5, 7; d.v[j] holds samples j and j + 4 as halves.)
+    auto all_far = [&](const Pk4 &d, const uint32_t (&b)[2], uint32_t rec) -> bool {
         const uint32_t hs = (rec >> INFO_HS_SHIFT) & 0x7Fu;
         const uint32_t K = 0x80008000u - hs * 0x00010001u;
         const uint32_t hr = (rec >> INFO_HR_SHIFT) & 7u;
         uint32_t r = 0xFFFFFFFFu;
-        if (pre_prune && hs == PRE_HS_NONE) {   // preamble record whose hsub does not fit: the second bound only
-            if (hr == INFO_HR_NONE) return false;
+        if (hr != INFO_HR_NONE) {
             const uint32_t K2 = 0x80008000u - hr * 0x00010001u;
+            const uint32_t bj[4] = {b[0] & 0x00FF00FFu, b[1] & 0x00FF00FFu, (b[0] >> 8) & 0x00FF00FFu, (b[1] >> 8) & 0x00FF00FFu};
+            if (pre_prune && hs == PRE_HS_NONE) {   // preamble record whose hsub does not fit: the second bound only
 #pragma unroll
-            for (int j = 0; j < 4; j++) r &= psub(padd(d.v[j], K2), ubv1.v[j]);
-        } else if (hr != INFO_HR_NONE) {
-            const uint32_t K2 = 0x80008000u - hr * 0x00010001u;
+                for (int j = 0; j < 4; j++) r &= psub(padd(bj[j], K2), ub1.v[j]);
+            } else {
 #pragma unroll
-            for (int j = 0; j < 4; j++) r &= psub(padd(d.v[j], K), ub1.v[j]) | psub(padd(d.v[j], K2), ubv1.v[j]);
+                for (int j = 0; j < 4; j++) r &= psub(padd(d.v[j], K), ub1.v[j]) | psub(padd(bj[j], K2), ub1.v[j]);
+            }
         } else {
+            if (pre_prune && hs == PRE_HS_NONE) return false;
 #pragma unroll
             for (int j = 0; j < 4; j++) r &= psub(padd(d.v[j], K), ub1.v[j]);
         }
@@ -1005,7 +1006,7 @@ __global__ void __launch_bounds__(64, 5) k_best8(Best8Args a) {
     // there would share vmcnt with the row loads and force vmcnt(0) waits: a header that reads or writes a cold
     // slot (or the root, whose parent value is D_bottom) carries H_SLOW | H_RARE, asks for a restart at its
     // own position, and the restart code walks that one node with `slow_node`, the general form of the step.
-    __attribute__((address_space(1))) uint32_t *coldp = (__attribute__((address_space(1))) uint32_t *)a.cold + ((uint64_t)blockIdx.x * (a.max_slots > a.lds_slots ? a.max_slots - a.lds_slots : 0u) * 64 + lane) * 4;
+    __attribute__((address_space(1))) uint32_t *coldp = (__attribute__((address_space(1))) uint32_t *)a.cold + ((uint64_t)blockIdx.x * (a.max_slots > a.lds_slots ? a.max_slots - a.lds_slots : 0u) * 64 + lane) * 8;   // per lane and slot 32 B: D (16), B (8), unused (8)
     bool replay = false;       // uniform: restart at skip_to - 1 and walk one node with slow_node
 
     // ---- end of the open node (shared by the fast and the slow step); wa = LDS byte offset of the write slot,
@@ -1017,6 +1018,8 @@ __global__ void __launch_bounds__(64, 5) k_best8(Best8Args a) {
         if (flushed) {   // node with more than 15 mutations (rare): fold the carries in
 #pragma unroll
             for (int j = 0; j < 4; j++) dcur.v[j] = pk_add(pk_sub(pk_add(dpar.v[j], ex4(accP, j)), ex4(accC, j)), carryD.v[j]);
+#pragma unroll
+            for (int i = 0; i < 2; i++) { bcur[i] = bpar[i] + ex8(accPB, i) - ex8(accCB, i) + carryB[i]; carryB[i] = 0; }
             if (!(hdr & H_NOSCORE)) {
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
@@ -1034,6 +1037,8 @@ __global__ void __launch_bounds__(64, 5) k_best8(Best8Args a) {
             if (!(hdr & H_SKIPD)) {
 #pragma unroll
                 for (int j = 0; j < 4; j++) dcur.v[j] = psub(padd(dpar.v[j], ex4(accP, j)), ex4(accC, j));
+#pragma unroll
+                for (int i = 0; i < 2; i++) bcur[i] = bpar[i] + ex8(accPB, i) - ex8(accCB, i);
             }
             if (!(hdr & H_NOSCORE)) {
                 uint32_t z = accC | (accC >> 1);
@@ -1049,14 +1054,19 @@ __global__ void __launch_bounds__(64, 5) k_best8(Best8Args a) {
         }
         if (hdr & H_STORE) {
             const u32x4 v = u32x4{dcur.v[0], dcur.v[1], dcur.v[2], dcur.v[3]};
-            if (cold_ws >= 0) *(glb_row *)(coldp + (uint64_t)cold_ws * 256) = v;
-            else *lds_at(((hdr >> (H_WSLOT_SHIFT - 10)) & (63u << 10)) | lane16) = v;
+            const u32x2 vb = u32x2{bcur[0], bcur[1]};
+            if (cold_ws >= 0) { *(glb_row *)(coldp + (uint64_t)cold_ws * 512) = v; *(glb_row2 *)(coldp + (uint64_t)cold_ws * 512 + 4) = vb; }
+            else {
+                *lds_at(((hdr >> (H_WSLOT_SHIFT - 10)) & (63u << 10)) | lane16) = v;
+                const uint32_t wsi = (hdr >> H_WSLOT_SHIFT) & 15u;
+                bs0[wsi] = vb.x; bs1[wsi] = vb.y;
+            }
         }
-        accP = accC = accN = 0;
+        accP = accC = accN = accPB = accCB = 0;
         if (STATS) run_nodes++;
         if (have_info) {   // this node carries a pruning record: can its whole subtree be skipped?
             have_info = false;
-            if (all_far(dcur, info)) {
+            if (all_far(dcur, bcur, info)) {
                 if (pre_prune) {   // a path node: nothing of its subtree is needed -- end the replay, start the body behind it
                     body_start = info & INFO_JUMP_MASK;
                     skip_to = 0x7FFFFFFFu;
@@ -1078,13 +1088,15 @@ __global__ void __launch_bounds__(64, 5) k_best8(Best8Args a) {
             carryN.v[j] = pk_add(carryN.v[j], eN);
             carryC.v[j] = pk_add(carryC.v[j], eC);
         }
-        accP = accC = accN = 0;
+#pragma unroll
+        for (int i = 0; i < 2; i++) carryB[i] += ex8(accPB, i) - ex8(accCB, i);   // (bytes may borrow from each other here: the node's total is exact)
+        accP = accC = accN = accPB = accCB = 0;
         flushed = true;
     };
     // sibling record waiting at a header: can this child and the non-last siblings after it all be skipped?
     auto sibling_test = [&](uint32_t pos) -> bool {
         have_sinfo = false;
-        if (!all_far(dpar, sinfo)) return false;
+        if (!all_far(dpar, bpar, sinfo)) return false;
         skip_to = pos + (sinfo & INFO_JUMP_MASK);   // the start of the parent's last child
         have_info = false;
         if (STATS) { n_skipped += sinfo & INFO_JUMP_MASK; count_jump(sinfo & INFO_JUMP_MASK, 1); }
@@ -1130,11 +1142,14 @@ __global__ void __launch_bounds__(64, 5) k_best8(Best8Args a) {
         if (w & H_REG) {
 #pragma unroll
             for (int j = 0; j < 4; j++) dpar.v[j] = dcur.v[j];
+            bpar[0] = bcur[0]; bpar[1] = bcur[1];
         } else {
             u32x4 t;   // (two loads, not one through a selected pointer: that would be a FLAT access, whose out-of-order return makes every later wait a wait for everything)
-            if (rs >= a.lds_slots) t = *(const glb_row *)(coldp + (uint64_t)(rs - a.lds_slots) * 256);
-            else t = *lds_at(rs * 1024u + lane16);
+            u32x2 tb;
+            if (rs >= a.lds_slots) { t = *(const glb_row *)(coldp + (uint64_t)(rs - a.lds_slots) * 512); tb = *(const glb_row2 *)(coldp + (uint64_t)(rs - a.lds_slots) * 512 + 4); }
+            else { t = *lds_at(rs * 1024u + lane16); tb.x = bs0[rs & 15u]; tb.y = bs1[rs & 15u]; }
             dpar.v[0] = t.x; dpar.v[1] = t.y; dpar.v[2] = t.z; dpar.v[3] = t.w;
+            bpar[0] = tb.x; bpar[1] = tb.y;
         }
         const int cold_ws = ((w & H_STORE) && ws >= a.lds_slots) ? (int)(ws - a.lds_slots) : -1;
         if (have_sinfo && sibling_test(p)) return p + 1;
@@ -1143,9 +1158,9 @@ __global__ void __launch_bounds__(64, 5) k_best8(Best8Args a) {
             for (;;) {
                 const uint32_t m = (uint32_t)__builtin_amdgcn_readfirstlane((int)sp[p]);
                 const uint32_t x = __builtin_amdgcn_raw_buffer_load_b32(trsrc, lane4, ((m & 0x3FFFFFu) + CONST_ROWS) << 8, 0);
-                const uint32_t mi = (m >> 22) & 3u, pi = (m >> 24) & 3u;
-                const uint32_t C = (x >> mi) & 0x11111111u, P = (x >> pi) & 0x11111111u;
-                accP += P; accC += C; accN += C & ~P;
+                const uint32_t mi = (m >> 22) & 3u, pi = (m >> 24) & 3u, ri = (m >> 26) & 3u;
+                const uint32_t C = (x >> mi) & 0x11111111u, P = (x >> pi) & 0x11111111u, R = (x >> ri) & 0x11111111u;
+                accP += P; accC += C; accN += C & ~P; accPB += P & R; accCB += C & R;
                 p++;
                 if (m & M_END) break;
                 if (m & M_FLUSH) flush_acc();
@@ -1214,7 +1229,6 @@ __global__ void __launch_bounds__(64, 5) k_best8(Best8Args a) {
             ub_tile = tile;
             ub_age = 0;
         }
-        if (prune || pre_prune) refresh_ubv();   // (V belongs to the unit's tile)
         // One stream word of the group being evaluated: w0v = the group's words (lane k = word k),
         // x = the lane's dword of the word's table row.  Returns true when the pipeline has to restart at
         // skip_to (chunk end that stores, pruning jump, slow header).
@@ -1226,16 +1240,19 @@ __global__ void __launch_bounds__(64, 5) k_best8(Best8Args a) {
                 if (w & H_REG) {
 #pragma unroll
                     for (int j = 0; j < 4; j++) dpar.v[j] = dcur.v[j];
+                    bpar[0] = bcur[0]; bpar[1] = bcur[1];
                 } else {
                     const u32x4 t = *lds_at((w & (63u << H_RSLOT_SHIFT)) | lane16);
+                    const uint32_t rsi = (w >> H_RSLOT_SHIFT) & 15u;
                     dpar.v[0] = t.x; dpar.v[1] = t.y; dpar.v[2] = t.z; dpar.v[3] = t.w;
+                    bpar[0] = bs0[rsi]; bpar[1] = bs1[rsi];
                 }
                 if (have_sinfo && sibling_test(pos)) return true;
                 if (!(w & H_END)) return false;
             } else {
-                const uint32_t mi = (w >> 22) & 3u, pi = (w >> 24) & 3u;
-                const uint32_t C = (x >> mi) & 0x11111111u, P = (x >> pi) & 0x11111111u;
-                accP += P; accC += C; accN += C & ~P;
+                const uint32_t mi = (w >> 22) & 3u, pi = (w >> 24) & 3u, ri = (w >> 26) & 3u;
+                const uint32_t C = (x >> mi) & 0x11111111u, P = (x >> pi) & 0x11111111u, R = (x >> ri) & 0x11111111u;
+                accP += P; accC += C; accN += C & ~P; accPB += P & R; accCB += C & R;
                 if (!(w & M_END)) {
                     if (w & M_FLUSH) flush_acc();
                     return false;
@@ -1931,7 +1948,7 @@ hipError_t best8_occupancy(size_t lds_bytes, int *per_cu) {
 
 // Persistent grid of `blocks` one-wave workgroups (the caller sizes a.cold for exactly that many).
 hipError_t launch_best8(const Best8Args &a, uint32_t blocks, hipStream_t s) {
-    const size_t lds = (size_t)a.lds_slots * 64 * 16;
+    const size_t lds = (size_t)a.lds_slots * 64 * 16;   // the D rows of the hot slots (their B halves live in registers)
     if (a.stats) hipLaunchKernelGGL((k_best8<true, false>), dim3(blocks), dim3(64), lds, s, a);
     else if (a.lds_bits) hipLaunchKernelGGL((k_best8<false, true>), dim3(blocks), dim3(64), lds + (((size_t)a.active_words * 4 + 15) & ~(size_t)15), s, a);
     else hipLaunchKernelGGL((k_best8<false, false>), dim3(blocks), dim3(64), lds, s, a);

@@ -40,7 +40,6 @@ struct Best8Args {
     const uint32_t *chunk8_body_off, *chunk8_pre_off;   // [n_chunks+1]
     const uint32_t *table;     // [n_tiles][4 + n_sites][64]
     const uint32_t *dbottom;   // [n_tiles*512]
-    const uint32_t *vrows;     // [n_tiles*512] rows per sample whose allele set is neither missing nor just the reference base
     uint32_t n_sites, n_chunks, n_groups, n_tiles;   // n_tiles = 512-sample tiles
     uint32_t max_slots;
     uint32_t lds_slots;        // saved-D slots kept in LDS (1 KB each per wave); the colder ones live in `cold`
