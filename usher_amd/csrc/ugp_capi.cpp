@@ -96,6 +96,7 @@ struct ugp_mat {
     uint64_t stream_dwords = 0, pre_dwords = 0;
     DevBuf<uint32_t> d_stream, d_pre, d_chunk_body, d_chunk_pre, d_chunk_node, d_rank2bfs, d_dfs2bfs;
     DevBuf<uint32_t> d_stream8, d_pre8, d_chunk8_body, d_chunk8_pre, d_stream_t, d_chunk_t;
+    DevBuf<uint32_t> d_node_pos8;   // (the coarse MAT) packed-stream position of every node's words, by DFS index
     uint64_t stream8_dwords = 0;
     DevBuf<int32_t> d_pos2site, d_site_pos;   // position -> site, site -> position
     DevBuf<uint8_t> d_site_ref;
@@ -120,6 +121,7 @@ struct ugp_mat {
     // points use set 0 on the caller's stream.
     struct Work {
         DevBuf<uint32_t> d_table, d_zero, d_part_best, d_part_cnt, d_part_key;
+        DevBuf<uint32_t> d_lpos;    // (coarse pass) which node set each chunk minimum
         DevBuf<uint32_t> d_lbest, d_gbest, d_gbest_part, d_items, d_ub, d_gstart, d_hlen, d_cold, d_list, d_units, d_unit_info;
         DevBuf<uint64_t> d_dyn;
         uint32_t dyn_epoch = 0;
@@ -267,10 +269,12 @@ int run_place(ugp_mat *m, ugp_qset *qs, int mode, ugp_result *d_out, int32_t *d_
         HIP_TRY(W.d_coarse_res.reserve(Q));
         if (!TG.ev_coarse[0]) { HIP_TRY(hipEventCreate(&TG.ev_coarse[0])); HIP_TRY(hipEventCreate(&TG.ev_coarse[1])); }
         HIP_TRY(hipEventRecord(TG.ev_coarse[0], s));
-        // (UGP_COARSE_FAST: skip the pre-pass's phase 2 and sort by the chunk of the minimum instead of the exact node --
-        // measured: pre-pass 0.64 -> 0.45 ms, but the coarser tiles cost the main pass 0.3 ms; off by default)
+        // The pre-pass has no phase 2: its walk records which node set every chunk minimum (k_best8<ARG>, k_coarse_result) -- any
+        // node of minimal cost serves the sort and the descent.  (UGP_COARSE_PHASE2=1: the full phase 2 instead, i.e. the
+        // reference's tie-break winner: 0.2 ms more per 16,384 samples, the same answers.)
         m->coarse->sharing = m->sharing;
-        if (int rc = run_place(m->coarse, qs, 0, W.d_coarse_res.p, nullptr, nullptr, nullptr, nullptr, nullptr, 0, s, getenv("UGP_COARSE_FAST") != nullptr, nullptr, wi)) return rc;
+        const bool coarse_arg = m->coarse->d_node_pos8.p && m->coarse->flat.max_chunk8_words < 65536u && !getenv("UGP_COARSE_PHASE2");
+        if (int rc = run_place(m->coarse, qs, 0, W.d_coarse_res.p, nullptr, nullptr, nullptr, nullptr, nullptr, 0, s, coarse_arg, nullptr, wi)) return rc;
         HIP_TRY(hipSetDevice(m->device));
         HIP_TRY(hipEventRecord(TG.ev_coarse[1], s));
         TG.coarse_timed = true;
@@ -363,9 +367,9 @@ int run_place(ugp_mat *m, ugp_qset *qs, int mode, ugp_result *d_out, int32_t *d_
                 // the coarse pass's best costs (real costs of real nodes), tightened by a greedy descent from the coarse best node
                 // through the full tree (k_descend; it reads the sample's alleles from the tiles just built)
                 const uint32_t *refined = nullptr;
-                // (not with UGP_COARSE_FAST: the descent derives D of its start node from "cost(best_j) == best", which only
-                // the exact coarse placement guarantees)
-                if (m->d_node_pair.p && m->d_coarse2bfs.p && !getenv("UGP_NO_DESCENT") && !getenv("UGP_COARSE_FAST")) {
+                // (the descent derives D of its start node from "cost(best_j) == best", which both forms of the pre-pass's result
+                // guarantee)
+                if (m->d_node_pair.p && m->d_coarse2bfs.p && !getenv("UGP_NO_DESCENT")) {
                     HIP_TRY(W.d_refined.reserve(nq));
                     HIP_TRY(ugp::launch_descend(W.d_coarse_res.p + q0, order, (uint32_t)nq, m->d_coarse2bfs.p, m->d_node_pair.p,
                                                 m->d_parent.p, m->d_stream.p, W.d_table.p, n_sites, W.d_refined.p, m->wide_descent, s));
@@ -450,6 +454,7 @@ int run_place(ugp_mat *m, ugp_qset *qs, int mode, ugp_result *d_out, int32_t *d_
             b.table = W.d_table.p; b.dbottom = d_dbottom;
             b.n_sites = n_sites; b.n_chunks = f.n_chunks; b.n_groups = G; b.n_tiles = n_tiles512;
             b.lbest = W.d_lbest.p;
+            if (coarse_only) { HIP_TRY(W.d_lpos.reserve((size_t)f.n_chunks * n_tiles512 * 256)); b.lpos = W.d_lpos.p; }
             b.list = W.d_list.p; b.list_n = d_list_n;
             W.last_list_n = d_list_n; W.last_list_tiles = n_tiles512;
             b.queue = d_queue;
@@ -507,7 +512,7 @@ int run_place(ugp_mat *m, ugp_qset *qs, int mode, ugp_result *d_out, int32_t *d_
                 }
                 if (++W.dyn_epoch >= 2048u) { HIP_TRY(hipMemsetAsync(W.d_dyn.p, 0, (size_t)kDynCap * 8, s)); W.dyn_epoch = 1; }   // (11 bits: stale entries never alias)
                 uint32_t *dyn_ctl = W.d_unit_info.p + 32;
-                b.dyn_ctl = dyn_ctl; b.dyn_units = (unsigned long long *)W.d_dyn.p; b.dyn_cap = kDynCap; b.dyn_epoch = W.dyn_epoch; b.split_cycles = split_cycles; b.split_heavy = split_heavy;
+                b.dyn_ctl = dyn_ctl; b.dyn_units = (unsigned long long *)W.d_dyn.p; b.dyn_cap = kDynCap; b.dyn_epoch = W.dyn_epoch; b.split_cycles = split_cycles; b.split_heavy = split_heavy; b.split_dense = getenv("UGP_SPLIT_DENSE") ? (uint32_t)std::max(0, atoi(getenv("UGP_SPLIT_DENSE"))) : 0xFFFFFFFFu;
                 HIP_TRY(ugp::launch_build_units(hstart, hlen, n_tiles512, f.n_chunks, unit_chunks, heavy_chunks, grow_every, unit_max, light_order, per_tile_cap,
                                                 W.d_units.p, W.d_unit_info.p, W.d_unit_info.p + 8, dyn_ctl, s));
                 b.units = (const uint4 *)W.d_units.p; b.unit_base = W.d_unit_info.p; b.unit_count = W.d_unit_info.p + 8;
@@ -568,8 +573,8 @@ int run_place(ugp_mat *m, ugp_qset *qs, int mode, ugp_result *d_out, int32_t *d_
             }
             HIP_TRY(hipEventRecord(es.ev[2], s));
             if (coarse_only)
-                HIP_TRY(ugp::launch_coarse_result(W.d_lbest.p, W.d_list.p, d_list_n, f.n_chunks, n_tiles512, (uint32_t)nq, m->d_chunk_node.p,
-                                                  m->d_dfs2bfs.p, d_out + q0, s));
+                HIP_TRY(ugp::launch_coarse_result(W.d_lbest.p, W.d_lpos.p, W.d_list.p, d_list_n, f.n_chunks, n_tiles512, (uint32_t)nq, m->d_chunk_node.p,
+                                                  m->d_chunk8_body.p, m->d_node_pos8.p, m->d_dfs2bfs.p, d_out + q0, s));
             else
                 HIP_TRY(ugp::launch_phase2(a, W.d_lbest.p, W.d_list.p, d_list_n, W.d_gbest_part.p, W.d_gbest.p, n_tiles512, W.d_items.p, d_nitems,
                                            (uint32_t)std::min<uint64_t>(pairs, 0xFFFFFFFFull), d_cnt, d_key,
@@ -685,6 +690,7 @@ static int build_coarse(const ugp_tree_desc *t, const ugp::Options &opt, ugp::Fl
     ugp_tree_desc d{keep.size(), parent.data(), mut_off.data(), pos.data(), ref.data(), par.data(), nuc.data()};
     ugp::Options copt;
     copt.chunk_nodes = 256;   // (the coarse pass is bound by row fetches and by the replay in front of every chunk: long chunks)
+    copt.keep_node_pos8 = true;
     if (const char *e = getenv("UGP_LDS_SLOTS")) copt.lds_slots = (uint32_t)std::max(1, std::min(60, atoi(e)));
     if (const char *e = getenv("UGP_COARSE_CHUNK_NODES")) copt.chunk_nodes = (uint32_t)std::max(1, atoi(e));
     hf.coarse = new HostFlat();
@@ -758,6 +764,7 @@ static int upload_flat(const HostFlat &hf, int device, ugp_mat **out) {
     if ((e = m->d_chunk8_pre.upload(f.chunk8_pre_off)) != hipSuccess) return bail(e, "upload chunk table");
     if ((e = m->d_stream_t.upload(f.stream_t)) != hipSuccess) return bail(e, "upload tie stream");
     if ((e = m->d_chunk_t.upload(f.chunk_t_off)) != hipSuccess) return bail(e, "upload chunk table");
+    if (!f.node_pos8.empty() && (e = m->d_node_pos8.upload(f.node_pos8)) != hipSuccess) return bail(e, "upload node positions");
     m->stream8_dwords = f.stream8.size();
     m->stream_dwords = f.stream.size();
     m->pre_dwords = f.pre_stream.size();

@@ -746,7 +746,9 @@ __device__ __forceinline__ uint32_t psub(uint32_t a, uint32_t b) { return a - b;
 // whenever the wave moves to another tile.  A restart of the pipelined loop is then two dependent memory round trips (stream
 // words, table rows) instead of three (words, bitmap bits, rows), and the steady loop issues one load less per group.  Costs
 // ~3 KB of LDS per wave (fewer resident waves); the host takes this variant when the bitmap is small enough.
-template <bool STATS, bool LBITS>   // STATS: per-unit accounting for tuning (UGP_STATS); off in production, it costs SGPRs
+// ARG (the coarse pass): next to every chunk minimum, which node set it -- the low 16 bits of its last word's stream position, per
+// sample -- so that the pass needs no phase 2 (k_coarse_result maps the position back to the node).
+template <bool STATS, bool LBITS, bool ARG>   // STATS: per-unit accounting for tuning (UGP_STATS); off in production, it costs SGPRs
 __global__ void __launch_bounds__(64, 4) k_best8(Best8Args a) {
     extern __shared__ __attribute__((aligned(16))) u32x4 slots8[];   // the hot saved slots: [lds_slots][64] x 16 B of D (the 8 B of B per lane and slot are in registers)
     const uint32_t lane = threadIdx.x;
@@ -874,6 +876,20 @@ __global__ void __launch_bounds__(64, 4) k_best8(Best8Args a) {
 #pragma unroll
     for (int j = 0; j < 4; j++) { best.v[j] = 0xFFFFFFFFu; dcur.v[j] = dbot.v[j]; dpar.v[j] = 0; carryD.v[j] = 0; carryN.v[j] = 0; carryC.v[j] = 0; }   // (dcur: the root reads D(bottom) as "the previous node's D")
     uint32_t accP = 0, accC = 0, accN = 0;
+    Pk4 bpos;                  // (ARG) per sample: position (low 16 bits) of the node that set `best`
+#pragma unroll
+    for (int j = 0; j < 4; j++) bpos.v[j] = 0;
+    uint32_t pos_base = 0;     // (ARG) uniform: stream position of the word at relative position 0 of the range being walked
+    // best = min(best, c) per half; with ARG the halves that improve take the position p2 (both halves = the node's position)
+    auto take_min = [&](int j, uint32_t c, uint32_t p2) {
+        const uint32_t nb = pk_min(best.v[j], c);
+        if (ARG) {
+            const uint32_t t = pk_min(nb ^ best.v[j], 0x00010001u);   // 1 per half that changed
+            const uint32_t msk = (t << 16) - t;                        // 0xFFFF per such half
+            bpos.v[j] = (bpos.v[j] & ~msk) | (p2 & msk);
+        }
+        best.v[j] = nb;
+    };
     // B(n, s) = the part of D at sites where the sample's set holds the reference base (second pruning bound, ugp_flatten.hpp):
     // one byte per sample (b[0]: samples 0, 2, 4, 6 of the lane, b[1]: samples 1, 3, 5, 7), saved and restored with D.
     // B(bottom) = 0: below the root every state is the reference base.
@@ -891,6 +907,8 @@ __global__ void __launch_bounds__(64, 4) k_best8(Best8Args a) {
     // sends its allocation over a cliff (500 more spill moves).
     uint32_t stop_v;
     asm volatile("v_mov_b32 %0, %1" : "=v"(stop_v) : "s"(c1));
+    uint32_t mark_v;   // (same trick) the chunk the wave was in at its last look at the shared list: how fast is it getting on?
+    asm volatile("v_mov_b32 %0, %1" : "=v"(mark_v) : "s"(c0));
     const uint32_t NOPW = H_TAG | H_RARE | H_NOP;
     // pruning: ub1 = (upper bound of best(s)) + 1 per sample, refreshed from / published to a.ub at chunk ends
     bool prune = false;        // uniform; only while walking the body (phase 1)
@@ -943,6 +961,7 @@ __global__ void __launch_bounds__(64, 4) k_best8(Best8Args a) {
         if (chunk_has_candidate()) {
             uint4 *dst = (uint4 *)(a.lbest + (((uint64_t)chunk * a.n_tiles + tile) * 64 + lane) * 4);
             *dst = make_uint4(best.v[0], best.v[1], best.v[2], best.v[3]);
+            if (ARG) *(uint4 *)(a.lpos + (((uint64_t)chunk * a.n_tiles + tile) * 64 + lane) * 4) = make_uint4(bpos.v[0], bpos.v[1], bpos.v[2], bpos.v[3]);
             if (lane == 0) a.list[(uint64_t)tile * a.n_chunks + atomicAdd(&a.list_n[tile], 1u)] = chunk;   // (order is irrelevant to phase 2)
         }
         if (can_prune) {
@@ -1012,6 +1031,7 @@ __global__ void __launch_bounds__(64, 4) k_best8(Best8Args a) {
     // ---- end of the open node (shared by the fast and the slow step); wa = LDS byte offset of the write slot,
     // or 0xFFFFFFFF with `cold_ws` >= 0 for a cold one
     auto node_end = [&](uint32_t pos, int cold_ws) -> bool {   // true: a pruning jump was requested (skip_to)
+        const uint32_t p2 = ARG ? ((pos_base + pos) & 0xFFFFu) * 0x00010001u : 0u;
         // A sample is ineligible here when it shares no mutation with the branch (common == 0,
         // usher_mapper.cpp:454-455) unless the node is "free": z has bit 4j set for such samples
         // and is turned into a 0x8000 penalty on the 16-bit cost (valid costs stay below 0x8000).
@@ -1027,7 +1047,7 @@ __global__ void __launch_bounds__(64, 4) k_best8(Best8Args a) {
                     const uint32_t common = pk_add(ex4(accC, j), carryC.v[j]);
                     uint32_t pen = 0;
                     if (!(hdr & H_FREE)) pen = (((common & 0xFFFFu) ? 0u : 0x8000u) | ((common >> 16) ? 0u : 0x80000000u));
-                    best.v[j] = pk_min(best.v[j], cost | pen);
+                    take_min(j, cost | pen, p2);
                 }
             }
 #pragma unroll
@@ -1048,7 +1068,7 @@ __global__ void __launch_bounds__(64, 4) k_best8(Best8Args a) {
                 for (int j = 0; j < 4; j++) {
                     const uint32_t cost = psub(dpar.v[j], ex4(accN, j));
                     const uint32_t pen = (j == 3 ? (z << 3) : (z << (15 - 4 * j))) & 0x80008000u;
-                    best.v[j] = pk_min(best.v[j], cost | pen);
+                    take_min(j, cost | pen, p2);
                 }
             }
         }
@@ -1198,6 +1218,7 @@ __global__ void __launch_bounds__(64, 4) k_best8(Best8Args a) {
         if (begin >= end) continue;
         const uint32_t n = end - begin;
         sp += begin;
+        if (ARG) pos_base = begin;
         const uint32_t l8 = lane & (GRP - 1u);
         uint32_t lim = n;   // uniform: end of the range being walked (words behind it read as padding)
         auto load_words = [&](uint32_t off) -> uint32_t {   // words off .. off+7 in lanes 0..7 (replicated x8)
@@ -1223,9 +1244,10 @@ __global__ void __launch_bounds__(64, 4) k_best8(Best8Args a) {
         cend = phase == 1 ? (uint32_t)__builtin_amdgcn_readfirstlane((int)(a.chunk8_body_off[c0 + 1] - 1u - begin)) : 0xFFFFFFFFu;
         cend_stale = false;
         if ((prune || pre_prune) && ub_tile != tile) {   // start from what earlier waves of this tile already know
-#pragma unroll
-            for (int j = 0; j < 4; j++)
-                ub1.v[j] = pk_add(__hip_atomic_load(ubp + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), 0x00010001u);
+            // (one plain cached load, not four agent-scope ones that leave the die: whatever copy it finds -- the seeds at
+            // worst -- was once written as the cost of a real eligible node, so it is a valid if older bound)
+            const uint4 u = *(const uint4 *)ubp;
+            ub1.v[0] = pk_add(u.x, 0x00010001u); ub1.v[1] = pk_add(u.y, 0x00010001u); ub1.v[2] = pk_add(u.z, 0x00010001u); ub1.v[3] = pk_add(u.w, 0x00010001u);
             ub_tile = tile;
             ub_age = 0;
         }
@@ -1348,9 +1370,14 @@ __global__ void __launch_bounds__(64, 4) k_best8(Best8Args a) {
             if (phase == 1 && stop - chunk >= 2u && (uint32_t)__builtin_amdgcn_s_memtime() - t_mark > (unit_heavy ? a.split_heavy : a.split_cycles)) {
                 // how many waves wait for an entry: tickets taken - entries pushed (one look per threshold, and only from
                 // units that have been running that long)
+                // Only a unit that is getting on slowly is worth cutting: one that has closed many chunks since the last look is
+                // jumping over most of what it was given -- its second half would cost the other wave a replay of the root path
+                // to find out the same.
                 const unsigned long long pr = __hip_atomic_load((const unsigned long long *)(a.dyn_ctl + DYN_HEAD), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 const uint32_t hd = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)pr), tl = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(pr >> 32));
-                if (hd > tl) {
+                const uint32_t adv = chunk - (uint32_t)__builtin_amdgcn_readfirstlane((int)mark_v);
+                asm volatile("v_mov_b32 %0, %1" : "=v"(mark_v) : "s"(chunk));
+                if (hd > tl && adv <= a.split_dense) {
                     const uint32_t mid = chunk + (stop - chunk + 1u) / 2u;
                     uint32_t slot = 0xFFFFFFFFu;
                     if (lane == 0) {
@@ -1413,12 +1440,15 @@ __global__ void __launch_bounds__(64, 4) k_best8(Best8Args a) {
     }   // next work unit
 }
 
-// Locality pre-pass only (the coarse MAT): per sample the minimum over the recorded chunks and the chunk that
-// attains it (the smallest such chunk); the "node" reported is that chunk's first node -- all the sort needs.
+// The coarse pass needs no phase 2: per sample the minimum over the recorded chunks (ineligible nodes carry bit 15 and lose
+// against any eligible one; the root always is), the smallest chunk that attains it, and the node that set that chunk's minimum --
+// k_best8<ARG> stored the low 16 bits of its stream position (chunks are shorter than 2^16 words), node_pos8 maps a position back
+// to the node.  Any node of minimal cost will do: the result seeds the sort and the descent, never an answer.
 // Block = one 512-sample tile, thread = one dword of its 1 KB records (two samples).
-__global__ void k_coarse_result(const uint32_t *__restrict__ lbest, const uint32_t *__restrict__ list, const uint32_t *__restrict__ list_n,
-                                uint32_t n_chunks, uint32_t n_tiles, uint32_t n_queries, const uint32_t *__restrict__ chunk_node_off,
-                                const uint32_t *__restrict__ dfs2bfs, ugp_result *__restrict__ out) {
+__global__ void k_coarse_result(const uint32_t *__restrict__ lbest, const uint32_t *__restrict__ lpos, const uint32_t *__restrict__ list,
+                                const uint32_t *__restrict__ list_n, uint32_t n_chunks, uint32_t n_tiles, uint32_t n_queries,
+                                const uint32_t *__restrict__ chunk_node_off, const uint32_t *__restrict__ chunk8_body_off,
+                                const uint32_t *__restrict__ node_pos8, const uint32_t *__restrict__ dfs2bfs, ugp_result *__restrict__ out) {
     const uint32_t tile = blockIdx.x, i = tile * 256 + threadIdx.x;
     const uint32_t per_chunk = n_tiles * 256;
     const uint32_t n = list_n[tile];
@@ -1431,11 +1461,19 @@ __global__ void k_coarse_result(const uint32_t *__restrict__ lbest, const uint32
         if (lo < mlo || (lo == mlo && c < clo)) { mlo = lo; clo = c; }
         if (hi < mhi || (hi == mhi && c < chi)) { mhi = hi; chi = c; }
     }
+    auto node_of = [&](uint32_t c, uint32_t p16) -> uint32_t {   // DFS index of the node of chunk c whose words hold the position
+        const uint32_t start = chunk8_body_off[c];
+        const uint32_t pos = start + ((p16 - start) & 0xFFFFu);
+        uint32_t lo = chunk_node_off[c], hi = chunk_node_off[c + 1];   // the last d in [lo, hi) with node_pos8[d] <= pos
+        while (hi - lo > 1) { const uint32_t mid = (lo + hi) / 2; if (node_pos8[mid] <= pos) lo = mid; else hi = mid; }
+        return lo;
+    };
+    const uint32_t plo = lpos[(uint64_t)clo * per_chunk + i] & 0xFFFFu, phi = lpos[(uint64_t)chi * per_chunk + i] >> 16;
     // dword (lane l, j): samples 8l + j and 8l + j + 4 of the tile
     const uint32_t l64 = threadIdx.x >> 2, j = threadIdx.x & 3u;
     const uint32_t q0 = tile * 512 + l64 * 8 + j;
-    if (q0 < n_queries) out[q0] = ugp_result{(int32_t)mlo, 1u, dfs2bfs[chunk_node_off[clo]], 0u};
-    if (q0 + 4 < n_queries) out[q0 + 4] = ugp_result{(int32_t)mhi, 1u, dfs2bfs[chunk_node_off[chi]], 0u};
+    if (q0 < n_queries) out[q0] = ugp_result{(int32_t)mlo, 1u, dfs2bfs[node_of(clo, plo)], 0u};
+    if (q0 + 4 < n_queries) out[q0 + 4] = ugp_result{(int32_t)mhi, 1u, dfs2bfs[node_of(chi, phi)], 0u};
 }
 
 // Global minimum per sample over the chunk-local minima that were recorded: the list of a tile is cut into
@@ -1943,22 +1981,24 @@ hipError_t launch_merge(const uint32_t *part_best, const uint32_t *part_cnt, con
 
 // Resident one-wave blocks of k_best8 per CU for a given dynamic LDS size, on the current device.
 hipError_t best8_occupancy(size_t lds_bytes, int *per_cu) {
-    return hipOccupancyMaxActiveBlocksPerMultiprocessor(per_cu, k_best8<false, false>, 64, lds_bytes);
+    return hipOccupancyMaxActiveBlocksPerMultiprocessor(per_cu, k_best8<false, false, false>, 64, lds_bytes);
 }
 
 // Persistent grid of `blocks` one-wave workgroups (the caller sizes a.cold for exactly that many).
 hipError_t launch_best8(const Best8Args &a, uint32_t blocks, hipStream_t s) {
     const size_t lds = (size_t)a.lds_slots * 64 * 16;   // the D rows of the hot slots (their B halves live in registers)
-    if (a.stats) hipLaunchKernelGGL((k_best8<true, false>), dim3(blocks), dim3(64), lds, s, a);
-    else if (a.lds_bits) hipLaunchKernelGGL((k_best8<false, true>), dim3(blocks), dim3(64), lds + (((size_t)a.active_words * 4 + 15) & ~(size_t)15), s, a);
-    else hipLaunchKernelGGL((k_best8<false, false>), dim3(blocks), dim3(64), lds, s, a);
+    if (a.lpos) hipLaunchKernelGGL((k_best8<false, false, true>), dim3(blocks), dim3(64), lds, s, a);   // (the coarse pass; no statistics there)
+    else if (a.stats) hipLaunchKernelGGL((k_best8<true, false, false>), dim3(blocks), dim3(64), lds, s, a);
+    else if (a.lds_bits) hipLaunchKernelGGL((k_best8<false, true, false>), dim3(blocks), dim3(64), lds + (((size_t)a.active_words * 4 + 15) & ~(size_t)15), s, a);
+    else hipLaunchKernelGGL((k_best8<false, false, false>), dim3(blocks), dim3(64), lds, s, a);
     return hipGetLastError();
 }
 
-hipError_t launch_coarse_result(const uint32_t *lbest, const uint32_t *list, const uint32_t *list_n, uint32_t n_chunks, uint32_t n_tiles512,
-                                uint32_t n_queries, const uint32_t *chunk_node_off, const uint32_t *dfs2bfs, ugp_result *out, hipStream_t s) {
-    hipLaunchKernelGGL(k_coarse_result, dim3(n_tiles512), dim3(256), 0, s, lbest, list, list_n, n_chunks, n_tiles512, n_queries, chunk_node_off,
-                       dfs2bfs, out);
+hipError_t launch_coarse_result(const uint32_t *lbest, const uint32_t *lpos, const uint32_t *list, const uint32_t *list_n, uint32_t n_chunks, uint32_t n_tiles512,
+                                uint32_t n_queries, const uint32_t *chunk_node_off, const uint32_t *chunk8_body_off, const uint32_t *node_pos8,
+                                const uint32_t *dfs2bfs, ugp_result *out, hipStream_t s) {
+    hipLaunchKernelGGL(k_coarse_result, dim3(n_tiles512), dim3(256), 0, s, lbest, lpos, list, list_n, n_chunks, n_tiles512, n_queries, chunk_node_off,
+                       chunk8_body_off, node_pos8, dfs2bfs, out);
     return hipGetLastError();
 }
 

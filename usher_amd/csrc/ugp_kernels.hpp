@@ -47,6 +47,7 @@ struct Best8Args {
     const uint32_t *active;    // [n_tiles][active_words] bit per site: some sample of the tile is not reference there
     uint32_t active_words;
     uint32_t *lbest;           // [n_chunks][n_tiles][64][4] packed u16 pairs; a record exists only for the chunks in `list`
+    uint32_t *lpos;            // (coarse pass) or null: same layout as lbest -- low 16 bits of the stream position of the node that set each chunk minimum
     uint32_t *list, *list_n;   // [n_tiles][n_chunks] chunks of each tile that left a record, [n_tiles] their number (zeroed before the launch)
     uint32_t *queue;           // [8] work-queue heads, one per XCD, zeroed before the launch
     const uint4 *units;        // work units {tile, c0, c1, flags}, one list per queue (k_build_units)
@@ -57,6 +58,7 @@ struct Best8Args {
     uint32_t lds_bits;         // the kernel variant that keeps the tile's active-row bitmap in LDS
     uint32_t no_pre_records;   // the preamble replay ignores its pruning records (units longer than their jump field reaches)
     uint32_t split_heavy;      // the same for the units of the tiles' own regions (dense: both halves are real work)
+    uint32_t split_dense;      // ... and only a unit that closed at most this many chunks since its last look is cut
     uint32_t split_cycles;     // a unit running longer than this hands half of its remainder to the shared list when waves wait for work (0xFFFFFFFF: never)
     uint32_t ub_every;         // exchange the shared upper bounds at every ub_every-th chunk end
     uint32_t refill_all_rows;  // experiment (UGP_REFILL_ALL): a refill fetches the real row of every word of its first group
@@ -81,8 +83,9 @@ hipError_t launch_best8(const Best8Args &a, uint32_t blocks, hipStream_t s);
 // a.n_tiles = number of 64-sample tiles; lbest/gbest in the packed 512-tile layout
 constexpr uint32_t GBEST_SLICES = 64;   // chunk-axis slices of the global-minimum reduction
 // gbest_part: [GBEST_SLICES][n_tiles512*256] scratch
-hipError_t launch_coarse_result(const uint32_t *lbest, const uint32_t *list, const uint32_t *list_n, uint32_t n_chunks, uint32_t n_tiles512,
-                                uint32_t n_queries, const uint32_t *chunk_node_off, const uint32_t *dfs2bfs, ugp_result *out, hipStream_t s);
+hipError_t launch_coarse_result(const uint32_t *lbest, const uint32_t *lpos, const uint32_t *list, const uint32_t *list_n, uint32_t n_chunks, uint32_t n_tiles512,
+                                uint32_t n_queries, const uint32_t *chunk_node_off, const uint32_t *chunk8_body_off, const uint32_t *node_pos8,
+                                const uint32_t *dfs2bfs, ugp_result *out, hipStream_t s);
 hipError_t launch_phase2(const PlaceArgs &a, const uint32_t *lbest, const uint32_t *list, const uint32_t *list_n, uint32_t *gbest_part,
                          uint32_t *gbest, uint32_t n_tiles512,
                          uint32_t *items, uint32_t *n_items, uint32_t cap, uint32_t *cnt, uint32_t *key,
