@@ -99,6 +99,16 @@ def test_slot_depth_is_logarithmic():
     assert FlatTreeView(arrays2).max_slots <= int(np.log2(arrays2["n"])) + 2
 
 
+def test_hot_slots_are_capped(monkeypatch):
+    """k_best8 keeps the B halves of the on-chip slots in two 16-element register vectors: however many are asked for, the
+    stream is encoded for at most 16 (the rest go through the cold path)."""
+    monkeypatch.setenv("UGP_LDS_SLOTS", "40")
+    # a comb of combs: many non-last-child edges on the deepest path
+    arrays, _ = synth.polytomy_case(5, fanouts=(3, 3, 3, 3, 3, 3, 3), n_queries=0) if hasattr(synth, "polytomy_case") else synth.make_case(3, n_leaves=2000, n_queries=0)
+    flat = FlatTreeView(arrays)
+    assert flat.lds_slots <= 16 and flat.lds_slots <= max(flat.max_slots, 1)
+
+
 def test_flatten_rejects_bad_trees():
     from usher_amd import UgpError
     base = {"n": 2, "parent": np.array([-1, 0]), "mut_off": np.array([0, 0, 1]), "mut_pos": np.array([7], np.int32),

@@ -478,7 +478,7 @@ int run_place(ugp_mat *m, ugp_qset *qs, int mode, ugp_result *d_out, int32_t *d_
             // Units outside the tiles' own regions grow with the distance from the region (they end in their preamble or after a
             // few jumps: what they cost is the replay, not their length) -- only when there is a region to measure from and bounds
             // to prune with.
-            uint32_t grow_every = (hstart && b.ub) ? 4u : 0u, unit_max = unit_chunks * 16u;
+            uint32_t grow_every = (hstart && b.ub) ? 8u : 0u, unit_max = unit_chunks * 16u;
             if (const char *e = getenv("UGP_UNIT_GROW")) grow_every = (hstart && b.ub) ? (uint32_t)std::max(0, atoi(e)) : 0u;
             if (const char *e = getenv("UGP_UNIT_MAX")) unit_max = (uint32_t)std::max(1, atoi(e));
             // A preamble record says where the body goes on behind a path node's subtree in INFO_JUMP_MASK's 18 bits, the largest
@@ -802,6 +802,7 @@ static ugp::Options default_options() {
     if (const char *e = getenv("UGP_CHUNK_NODES")) opt.chunk_nodes = (uint32_t)std::max(1, atoi(e));
     if (const char *e = getenv("UGP_PRUNE_MIN_WORDS")) opt.prune_min_words = (uint32_t)std::max(1, atoi(e));
     if (getenv("UGP_NO_SIB")) opt.sibling_records = false;
+    if (getenv("UGP_NO_BOUND2")) opt.second_bound = false;   // first lower bound only (tests, tuning)
     if (const char *e = getenv("UGP_LDS_SLOTS")) opt.lds_slots = (uint32_t)std::max(1, std::min(60, atoi(e)));
     if (const char *e = getenv("UGP_PRE_WEIGHT")) opt.pre_weight = (uint32_t)std::max(0, atoi(e));
     return opt;

@@ -442,7 +442,7 @@ int flatten(const ugp_tree_desc &t, const Options &opt, FlatMat &out, std::strin
     // same over the later non-last siblings (sibling records).  Needs the parent states, hence after the emission.
     // B(n, s) of k_best8 is kept in 8 bits per sample and never exceeds the mutations on a root path: on a tree deeper than
     // that the records say "not available".
-    const bool second_bound = out.max_path_muts <= 255;
+    const bool second_bound = opt.second_bound && out.max_path_muts <= 255;
     bottom_up([&](uint64_t p, unsigned) {
         uint32_t hr = 0;
         for (uint32_t k = child_off[p]; k < child_off[p + 1]; k++) { const uint32_t c = children[k]; hr = std::max<uint32_t>(hr, (uint32_t)rev[c] + hrev[c]); }
@@ -727,7 +727,7 @@ int flatten(const ugp_tree_desc &t, const Options &opt, FlatMat &out, std::strin
         std::stable_sort(order, order + out.max_slots, [&](uint32_t a, uint32_t b) { return freq[a] > freq[b]; });
         for (uint32_t i = 0; i < 64; i++) remap[i] = i;
         for (uint32_t i = 0; i < out.max_slots; i++) remap[order[i]] = i;
-        out.lds_slots = std::max<uint32_t>(1, std::min<uint32_t>(opt.lds_slots, out.max_slots));
+        out.lds_slots = std::max<uint32_t>(1, std::min<uint32_t>(std::min<uint32_t>(opt.lds_slots, MAX_HOT_SLOTS), out.max_slots));
         const uint32_t hot = out.lds_slots;
         auto finalize8 = [&](UVec<uint32_t> &v) {
             par.run(v.size(), [&](uint64_t b, uint64_t e, unsigned) {

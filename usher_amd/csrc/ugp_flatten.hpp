@@ -110,6 +110,7 @@ constexpr uint32_t INFO_HR_SHIFT = 18, INFO_HR_NONE = 7;   // hrev field; 7 = no
 // When the record's test holds during the replay, the rest of the preamble and the body up to that position are skipped.
 constexpr uint32_t PRE_HS_NONE = 127;
 constexpr uint32_t PRUNE_MIN_WORDS = 4;     // only subtrees at least this long carry a pruning record
+constexpr uint32_t MAX_HOT_SLOTS = 16;      // the B halves of the hot slots are two 16-element register vectors in k_best8
 constexpr uint32_t LDS_SLOTS = 9;           // saved (D, B) slots k_best8 keeps in LDS (1.5 KB each per wave); the colder ones live in a global scratch
 constexpr uint32_t M_FLUSH = 1u << 28, M_END = 1u << 30;
 constexpr uint32_t MAX_SITES = 1u << 22;
@@ -119,6 +120,7 @@ struct Options {
     uint32_t chunk_nodes = 0;   // 0 = automatic (about N/32768, at least 128)
     uint32_t prune_min_words = PRUNE_MIN_WORDS;   // subtrees at least this long (stream words) carry a pruning record
     bool sibling_records = true;   // emit H_INFO | H_SIB records
+    bool second_bound = true;      // records carry the second-hit counts of the second pruning bound (false: "not available" everywhere)
     bool keep_node_pos8 = false;   // export FlatMat::node_pos8 (the coarse MAT: k_best8 reports its winners by stream position)
     uint32_t lds_slots = LDS_SLOTS; // headers whose (renumbered) slots are >= this are flagged H_SLOW
     uint32_t pre_weight = 32;   // weight of the preambles' slot accesses when the hot (LDS) slots are chosen: every unit replays one,

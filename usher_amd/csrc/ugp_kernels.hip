@@ -1600,8 +1600,8 @@ __global__ void k_invert(const uint32_t *__restrict__ order, uint32_t n, uint32_
 // eligible there iff common > 0, which makes an internal node eligible too): the value is a real cost.
 // The unused sample slots of the last tile must not hold the tile back (all 512 lanes have to be far for a jump): left
 // alone they are 240 copies of a sample identical to the reference, an outlier that sits at the root.  They get D(bottom) =
-// pad_d (a count no real cost undercuts within 16 bits) and the bound 0: with V = 0 the second test, D - hrev > 0, then
-// holds for them everywhere.  Their results are never read.
+// pad_d (a count no real cost undercuts within 16 bits, and larger than any hsub) and the bound 0: the first test, D - hsub > 0,
+// then holds for them everywhere.  Their results are never read.
 __global__ void k_seed_ub(const ugp_result *__restrict__ coarse_res, const uint32_t *__restrict__ order, uint32_t n_queries,
                           uint32_t n_words, uint32_t *__restrict__ ub, const uint32_t *__restrict__ refined, uint32_t *__restrict__ dbottom,
                           uint32_t pad_d) {
@@ -1643,7 +1643,7 @@ template <uint32_t G>
 __global__ void __launch_bounds__(256) k_descend(const ugp_result *__restrict__ coarse_res, const uint32_t *__restrict__ order, uint32_t n_queries,
                           const uint32_t *__restrict__ coarse2bfs, const uint2 *__restrict__ node_pair,
                           const uint32_t *__restrict__ parent, const uint32_t *__restrict__ stream, const uint32_t *__restrict__ table, uint32_t n_sites,
-                          uint32_t *__restrict__ refined) {
+                          uint32_t *__restrict__ refined, uint32_t max_expansions) {
     constexpr uint32_t NG = 256u / G;   // samples per block
     __shared__ uint32_t f_node[NG][DESC_FRONTIER], f_cb[NG][DESC_FRONTIER], f_ce[NG][DESC_FRONTIER];
     __shared__ int f_d[NG][DESC_FRONTIER];
@@ -1704,7 +1704,7 @@ __global__ void __launch_bounds__(256) k_descend(const ugp_result *__restrict__ 
             eval(pr.y, dsum, neg, common, w0);
         }
     }
-    for (uint32_t it = 0; it < DESC_MAX_EXPANSIONS; it++) {
+    for (uint32_t it = 0; it < max_expansions; it++) {
         const bool act = n_f != 0;   // this group still has something to expand
         if (__builtin_amdgcn_ballot_w64(act) == 0) break;
         // pop the entry with the smallest D (G = 16: two candidates per lane, DESC_FRONTIER = 2 x 16)
@@ -1883,12 +1883,13 @@ hipError_t launch_descend(const ugp_result *coarse_res, const uint32_t *order, u
                           const uint32_t *node_pair, const uint32_t *parent, const uint32_t *stream, const uint32_t *table,
                           uint32_t n_sites, uint32_t *refined, bool wide, hipStream_t s) {
     if (!n_queries) return hipSuccess;
+    static const uint32_t max_exp = getenv("UGP_DESCENT_MAX") ? (uint32_t)std::max(1, atoi(getenv("UGP_DESCENT_MAX"))) : DESC_MAX_EXPANSIONS;   // (tuning)
     if (wide)
         hipLaunchKernelGGL(k_descend<64>, dim3((n_queries + 3) / 4), dim3(256), 0, s, coarse_res, order, n_queries, coarse2bfs, (const uint2 *)node_pair, parent,
-                           stream, table, n_sites, refined);
+                           stream, table, n_sites, refined, max_exp);
     else
         hipLaunchKernelGGL(k_descend<16>, dim3((n_queries + 15) / 16), dim3(256), 0, s, coarse_res, order, n_queries, coarse2bfs, (const uint2 *)node_pair, parent,
-                           stream, table, n_sites, refined);
+                           stream, table, n_sites, refined, max_exp);
     return hipGetLastError();
 }
 
