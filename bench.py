@@ -48,6 +48,7 @@ def parse_args():
     ap.add_argument("--genome", type=int, default=29903)
     ap.add_argument("--shape", choices=["random", "sars2"], default="random",
                     help="tree shape: random attachment (SURVEY 8d recipe) or SARS-CoV-2-like (shallow, polytomy-dominated)")
+    ap.add_argument("--iupac-true", action="store_true", help="with --ambiguous: every IUPAC cell holds the sample's own base (default: any set of 2-3 bases)")
     ap.add_argument("--ambiguous", action="store_true", help="BASELINE config 5: 100-5000 N cells + 0-30 IUPAC cells per query")
     ap.add_argument("--cpu-queries", type=int, default=-1, help="queries timed on the CPU oracle (0 = skip; default: sized for ~10-30 s)")
     ap.add_argument("--seed", type=int, default=1)
@@ -162,6 +163,8 @@ def main():
     t_flat = time.time() - t0
     info = pl.info()
     kw = dict(n_lo=100, n_hi=5000, iupac_hi=30) if args.ambiguous else {}
+    if args.iupac_true:
+        kw["iupac_true"] = True
     if args.shape == "sars2":
         kw["recent"] = True
     if args.strong:   # one global batch; this rank owns a contiguous shard of it
@@ -354,7 +357,7 @@ def main():
             "config": {"workload": "synthetic %s MAT %d nodes / %d mutations / %d variable sites, L=%d; %s%s"
                                    % (args.shape, info["n_nodes"], info["n_muts"], info["n_sites"], args.genome,
                                       ("%d queries in total, sharded" % total_q) if args.strong else ("%d queries per GPU per step" % Q),
-                                      " (100-5000 N + 0-30 IUPAC cells each)" if args.ambiguous else ""),
+                                      (" (100-5000 N + 0-30 IUPAC cells each%s)" % (", every code holding the sample's own base" if args.iupac_true else "")) if args.ambiguous else ""),
                        "nodes": int(info["n_nodes"]), "queries_per_gpu": Q, "queries_total": total_q, "tile": T, "tiles": tiles, "waves_per_tile": groups,
                        "parallelism": "queries sharded x%d, MAT replicated, RCCL all-gather of results" % world,
                        "rccl_ranks": world, "devices_visible": torch.cuda.device_count(),

@@ -530,10 +530,12 @@ def test_randomised_trees_and_scheduling_knobs(seed, monkeypatch):
         knobs["UGP_LDS_BITS"] = str(int(rng.integers(0, 2)))    # the kernel variant with the tiles' active-row bitmaps in LDS
     if rng.random() < 0.3:
         knobs["UGP_PRE_WEIGHT"] = "50"
+    if rng.random() < 0.4:
+        knobs["UGP_NMASK"] = "1"             # tiles built from per-sample N bit masks (the path of batches with many missing rows)
     if rng.random() < 0.3:
         knobs["UGP_COARSE_PHASE2"] = "1"     # the coarse pass with its full phase 2 (the tie-break winner seeds the sort and the descent)
     for k in ("UGP_COARSE_MIN_NODES", "UGP_UNIT_CHUNKS", "UGP_HEAVY_CHUNKS", "UGP_UB_EVERY", "UGP_PRUNE_MIN_WORDS", "UGP_NO_LPT", "UGP_NO_SEED",
-              "UGP_NO_SORT", "UGP_NO_PRUNE", "UGP_FORCE_V1", "UGP_LDS_SLOTS", "UGP_NO_DESCENT", "UGP_NO_BOUND2", "UGP_UNIT_GROW", "UGP_UNIT_MAX", "UGP_SPLIT_CYCLES", "UGP_LDS_BITS", "UGP_PRE_WEIGHT", "UGP_COARSE_PHASE2"):
+              "UGP_NO_SORT", "UGP_NO_PRUNE", "UGP_FORCE_V1", "UGP_LDS_SLOTS", "UGP_NO_DESCENT", "UGP_NO_BOUND2", "UGP_UNIT_GROW", "UGP_UNIT_MAX", "UGP_SPLIT_CYCLES", "UGP_LDS_BITS", "UGP_PRE_WEIGHT", "UGP_COARSE_PHASE2", "UGP_NMASK"):
         monkeypatch.delenv(k, raising=False)
     for k, v in knobs.items():
         monkeypatch.setenv(k, v)

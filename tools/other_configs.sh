@@ -5,6 +5,8 @@ run() { echo "$1 | $2 | $(env $1 timeout 900 python bench.py --cpu-queries 0 --s
 run A=1 ""
 run UGP_NO_OVERLAP=1 ""
 run A=1 "--ambiguous"
+run A=1 "--ambiguous --iupac-true"
+run UGP_NMASK=0 "--ambiguous"
 run A=1 "--nodes 100000 --queries 1024"
 run UGP_COARSE_MIN_NODES=0 "--nodes 100000 --queries 1024"
 run A=1 "--nodes 100000 --queries 16384"

@@ -269,7 +269,7 @@ ugs_queries *ugs_queries_create2(const ugs_tree *t, uint64_t n_queries, uint64_t
         for (const Row &r : rows) row_of_pos[r.pos] = -1;
         rows.clear();
         uint32_t node = (uint32_t)rng.below(N);
-        if (recent && !t->recent.empty()) node = t->recent[rng.below(t->recent.size())];
+        if ((recent & 1u) && !t->recent.empty()) node = t->recent[rng.below(t->recent.size())];
         q->source_node.push_back(node);
         // genotype of `node`: most recent mutation per position on the root path
         for (uint32_t v = node; v != UINT32_MAX; v = t->parent[v]) {
@@ -306,6 +306,11 @@ ugs_queries *ugs_queries_create2(const ugs_tree *t, uint64_t n_queries, uint64_t
             int32_t p = (int32_t)t->sites[rng.below(t->sites.size())];
             uint8_t mask = (uint8_t)(1 + rng.below(14));
             if ((mask & (mask - 1)) == 0) mask |= kOneHot[rng.below(4)];
+            if (recent & 2u) {   // an ambiguity code that holds the sample's own base, as a real mixed call does (default: any set)
+                uint8_t curr = kOneHot[t->ref[p]];
+                if (row_of_pos[p] >= 0) { if (rows[row_of_pos[p]].missing) continue; curr = rows[row_of_pos[p]].nuc; }
+                mask |= curr;
+            }
             if (mask == 15) set_row(p, 15, 1); else set_row(p, mask, 0);
         }
         // drop rows equal to the reference base (a VCF would not carry them), sort

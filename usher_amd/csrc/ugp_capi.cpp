@@ -176,6 +176,11 @@ struct ugp_qset {
     DevBuf<uint32_t> d_ent_q;
     DevBuf<uint64_t> d_ent_off;
     DevBuf<unsigned long long> d_err;
+    // Many missing rows per sample (N runs): one bit per (sample, site) per tree the set is placed on -- the MAT and its coarse
+    // MAT number their sites differently -- and the list of the rows that are NOT missing (k_nmask_build, k_ntiles)
+    DevBuf<uint32_t> d_nmask[2], d_plain_rows, d_n_plain;
+    const ugp_mat *nmask_for[2] = {nullptr, nullptr};
+    uint32_t nmask_words[2] = {0, 0};
     std::vector<uint64_t> ent_off;   // host copy, for sub-batching
 };
 
@@ -350,7 +355,14 @@ int run_place(ugp_mat *m, ugp_qset *qs, int mode, ugp_result *d_out, int32_t *d_
         // coarse pass 2.72 -> 2.33 ms, sorted build 1.77 -> 2.03 ms)
         bool lds_build = use8 && n_sites && !order && (e1 - e0) >= (uint64_t)nq * 128;
         if (const char *e = getenv("UGP_TILE_BUILD")) lds_build = use8 && n_sites && atoi(e) != 0;
-        if (lds_build)
+        int nmi = -1;   // the query set carries N masks for this tree
+        for (int i = 0; i < 2; i++) if (qs->nmask_for[i] == m && use8 && n_sites) nmi = i;
+        if (nmi >= 0) {
+            HIP_TRY(ugp::launch_ntiles(W.d_table.p, d_active, active_words, n_tiles512, qs->d_nmask[nmi].p, qs->nmask_words[nmi], order, (uint32_t)q0, (uint32_t)nq,
+                                       m->d_site_ref.p, n_sites, s));
+            HIP_TRY(ugp::launch_scatter_list(W.d_table.p, d_dbottom, qs->d_pos.p, qs->d_ref.p, qs->d_nuc.p, qs->d_missing.p, qs->d_ent_q.p, m->d_pos2site.p,
+                                             f.max_pos, n_sites, (uint32_t)q0, (uint32_t)nq, d_active, active_words, slot_of, qs->d_plain_rows.p, qs->d_n_plain.p, s));
+        } else if (lds_build)
             HIP_TRY(ugp::launch_build_tiles(W.d_table.p, d_active, active_words, n_tiles512, qs->d_ent_off.p, (uint32_t)q0, order, (uint32_t)nq, qs->d_pos.p,
                                             qs->d_ref.p, qs->d_nuc.p, qs->d_missing.p, m->d_pos2site.p, m->d_site_pos.p, m->d_site_ref.p, n_sites, f.max_pos,
                                             d_dbottom, nullptr, s));
@@ -939,6 +951,25 @@ static int qset_fill(ugp_mat *m, const ugp_queries *q, ugp_qset *qs, hipStream_t
     HIP_TRY(hipMemsetAsync(qs->d_err.p, 0xFF, sizeof(unsigned long long), s));
     HIP_TRY(ugp::launch_rows_prepare(qs->d_ent_off.p, (uint32_t)q->n_queries, n_ent, qs->d_pos.p, qs->d_ref.p, qs->d_nuc.p, qs->d_missing.p,
                                      m->d_pos2site.p, m->d_site_ref.p, f.max_pos, (uint32_t)f.n_sites, qs->d_ent_q.p, qs->d_err.p, s));
+    // N masks: from 128 rows per sample on, for trees whose mask fits a workgroup's LDS (up to 524,288 sites)
+    qs->nmask_for[0] = qs->nmask_for[1] = nullptr;
+    {
+        bool want = n_ent >= (uint64_t)q->n_queries * 128 && n_ent < (1ull << 32) && q->n_queries < (1ull << 32);
+        if (const char *e = getenv("UGP_NMASK")) want = atoi(e) != 0 && n_ent < (1ull << 32);
+        const ugp_mat *trees[2] = {m, m->coarse};
+        for (int i = 0; want && i < 2; i++) {
+            const ugp_mat *t = trees[i];
+            if (!t || !t->flat.n_sites) continue;
+            const uint32_t words = (uint32_t)(((t->flat.n_sites + 31) / 32 + 15) & ~(uint64_t)15);
+            if ((size_t)words * 4 > 65536) continue;
+            HIP_TRY(qs->d_nmask[i].reserve((size_t)q->n_queries * words));
+            if (i == 0) { HIP_TRY(qs->d_plain_rows.reserve(n_ent)); HIP_TRY(qs->d_n_plain.reserve(1)); HIP_TRY(hipMemsetAsync(qs->d_n_plain.p, 0, 4, s)); }
+            HIP_TRY(ugp::launch_nmask_build(qs->d_ent_off.p, (uint32_t)q->n_queries, qs->d_pos.p, qs->d_missing.p, t->d_pos2site.p, t->flat.max_pos, words,
+                                            qs->d_nmask[i].p, i == 0 ? qs->d_plain_rows.p : nullptr, qs->d_n_plain.p, s));
+            qs->nmask_for[i] = t; qs->nmask_words[i] = words;
+        }
+        if (!qs->nmask_for[0]) qs->nmask_for[1] = nullptr;   // (the row list comes with the first)
+    }
     if (stage) return UGP_OK;   // (checked by the caller once the stream has run)
     unsigned long long err = ~0ull;
     HIP_TRY(hipMemcpy(&err, qs->d_err.p, sizeof err, hipMemcpyDeviceToHost));

@@ -84,11 +84,17 @@ __global__ void k_scatter_entries(uint32_t *__restrict__ table, uint32_t *__rest
                                   const uint32_t *__restrict__ ent_q, const int32_t *__restrict__ pos2site,
                                   uint32_t max_pos, uint32_t n_sites, uint64_t n_ent, uint32_t q_base,
                                   uint32_t *__restrict__ active, uint32_t active_words,
-                                  const uint32_t *__restrict__ slot_of, uint32_t *__restrict__ vrows) {
-    const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const bool valid = e < n_ent;
+                                  const uint32_t *__restrict__ slot_of, uint32_t *__restrict__ vrows,
+                                  const uint32_t *__restrict__ row_list, const uint32_t *__restrict__ n_listed, uint32_t n_q) {
+    // (with a row list -- the rows that are not missing, k_nmask_build -- the kernel strides over it: its length is only known
+    // on the device; rows of samples outside [q_base, q_base + n_q) belong to another sub-batch)
+    const uint64_t n_items = row_list ? (uint64_t)*n_listed : n_ent;
+    for (uint64_t it = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; __builtin_amdgcn_ballot_w64(it < n_items) != 0; it += (uint64_t)gridDim.x * blockDim.x) {
+    const uint64_t e = (it < n_items) ? (row_list ? (uint64_t)row_list[it] : it) : 0;
+    bool valid = it < n_items;
     uint32_t q = 0, r = 0, a = 0, miss = 1;
     int32_t p = -1;
+    if (valid && row_list) { const uint32_t qa = ent_q[e]; valid = qa >= q_base && qa - q_base < n_q; }
     if (valid) {
         q = ent_q[e] - q_base;                  // sample index within this launch
         if (slot_of) q = slot_of[q];            // ... and its place in the locality-sorted tiles
@@ -114,9 +120,9 @@ __global__ void k_scatter_entries(uint32_t *__restrict__ table, uint32_t *__rest
             if (vm && (threadIdx.x & 63u) == (uint32_t)__builtin_ctzll(vm)) atomicAdd(&vrows[q0], (uint32_t)__builtin_popcountll(vm));
         } else if (var) atomicAdd(&vrows[q], 1u);
     }
-    if (!valid || p < 0 || (uint32_t)p > max_pos) return;
+    if (!valid || p < 0 || (uint32_t)p > max_pos) continue;
     const int32_t site = pos2site[p];
-    if (site < 0) return;
+    if (site < 0) continue;
     const uint32_t tile = q >> 9, within = q & 511;
     uint32_t *w = table + ((uint64_t)tile * (n_sites + TABLE_CONST_ROWS) + TABLE_CONST_ROWS + (uint32_t)site) * 64 + (within >> 3);
     const uint32_t sh = (within & 7) * 4;
@@ -128,6 +134,88 @@ __global__ void k_scatter_entries(uint32_t *__restrict__ table, uint32_t *__rest
         const uint32_t bit = 1u << ((uint32_t)site & 31u);
         if (!(__hip_atomic_load(aw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & bit)) atomicOr(aw, bit);
     }
+    if (!row_list) break;   // (one row per thread)
+    }
+}
+
+// ---- tiles of batches with many MISSING rows (N cells come in runs of hundreds to thousands per sample) ---------------------
+// One atomic per row into a 200 MB table (k_scatter_entries) or a binary search and a serial row loop per (sample, site block)
+// (k_build_tiles) cost 1.4-1.7 ms per build for 41 M rows, twice per call.  The N cells are turned into one bit per
+// (sample, site) when the query set arrives -- nmask[sample][word], k_nmask_build, one workgroup per sample, LDS atomics, rows
+// read once and coalesced -- and every tile build is then a bit-matrix transpose of those masks into nibbles (k_ntiles: reads
+// 3 KB per sample, writes the table once, coalesced, no atomics); the few rows that are not missing go through the scatter
+// kernel by way of a list.
+__global__ void __launch_bounds__(256) k_nmask_build(const uint64_t *__restrict__ ent_off, const int32_t *__restrict__ pos, const uint8_t *__restrict__ is_missing,
+                                                     const int32_t *__restrict__ pos2site, uint32_t max_pos, uint32_t words, uint32_t *__restrict__ nmask,
+                                                     uint32_t *__restrict__ plain_rows, uint32_t *__restrict__ n_plain) {
+    extern __shared__ uint32_t nm_lds[];   // [words]
+    const uint32_t q = blockIdx.x, tid = threadIdx.x;
+    for (uint32_t i = tid; i < words; i += 256) nm_lds[i] = 0;
+    __syncthreads();
+    const uint64_t rb = ent_off[q], re = ent_off[q + 1];
+    for (uint64_t r0 = rb; r0 < re; r0 += 256) {
+        const uint64_t r = r0 + tid;
+        const bool in = r < re;
+        const bool miss = in && is_missing[r] != 0;
+        if (miss) {
+            const int32_t p = pos[r];
+            if (p >= 0 && (uint32_t)p <= max_pos) {
+                const int32_t site = pos2site[p];
+                if (site >= 0) atomicOr(&nm_lds[(uint32_t)site >> 5], 1u << ((uint32_t)site & 31u));
+            }
+        }
+        if (plain_rows) {   // the other rows, in row order within a wave
+            const bool plain = in && !miss;
+            const unsigned long long pm = __builtin_amdgcn_ballot_w64(plain);
+            if (pm) {
+                uint32_t base = 0;
+                if ((tid & 63u) == (uint32_t)__builtin_ctzll(pm)) base = atomicAdd(n_plain, (uint32_t)__builtin_popcountll(pm));
+                base = (uint32_t)__builtin_amdgcn_readlane((int)base, __builtin_ctzll(pm));
+                if (plain) plain_rows[base + (uint32_t)__builtin_popcountll(pm & ((1ull << (tid & 63u)) - 1ull))] = (uint32_t)r;
+            }
+        }
+    }
+    __syncthreads();
+    for (uint32_t i = tid; i < words; i += 256) nmask[(uint64_t)q * words + i] = nm_lds[i];
+}
+
+// Workgroup = (16 mask words = 512 sites, tile): the words of the tile's 512 samples staged in LDS, then thread (column l,
+// word group g) builds dword l of the rows of its sites -- nibble j = 0xF where sample 8l + j is N, else the reference base --
+// and a wave stores one 256-byte row per instruction.  Also writes the tile's constant rows and the active-row bits of its
+// sites (plain stores: the scatter of the remaining rows ORs its own in afterwards).
+__global__ void __launch_bounds__(256) k_ntiles(uint32_t *__restrict__ table, uint32_t *__restrict__ active, uint32_t active_words,
+                                                const uint32_t *__restrict__ nmask, uint32_t words, const uint32_t *__restrict__ order, uint32_t q0,
+                                                uint32_t nq, const uint8_t *__restrict__ site_ref, uint32_t n_sites) {
+    __shared__ uint32_t m[16][512 + 8];
+    const uint32_t tile = blockIdx.y, wb = blockIdx.x * 16, tid = threadIdx.x;
+    for (uint32_t i = tid; i < 512 * 16; i += 256) {
+        const uint32_t slot = tile * 512 + (i >> 4), w = i & 15u;
+        uint32_t v = 0;
+        if (slot < nq && wb + w < words) v = nmask[(uint64_t)(q0 + (order ? order[slot] : slot)) * words + wb + w];
+        m[w][i >> 4] = v;
+    }
+    __syncthreads();
+    const uint64_t n_rows = (uint64_t)n_sites + TABLE_CONST_ROWS;
+    const uint32_t l = tid & 63u, g = tid >> 6;
+    for (uint32_t w = g * 4; w < g * 4 + 4; w++) {
+        uint32_t mw[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) mw[j] = m[w][8 * l + j];
+        uint32_t act = 0;
+        const uint32_t s0 = (wb + w) * 32;
+        for (uint32_t k = 0; k < 32 && s0 + k < n_sites; k++) {
+            uint32_t b = 0;
+#pragma unroll
+            for (int j = 0; j < 8; j++) b |= ((mw[j] >> k) & 1u) << j;
+            uint32_t t = (b | (b << 12)) & 0x000F000Fu;   // bit j of b -> bit 4j
+            t = (t | (t << 6)) & 0x03030303u;
+            t = (t | (t << 3)) & 0x11111111u;
+            table[((uint64_t)tile * n_rows + TABLE_CONST_ROWS + s0 + k) * 64 + l] = (uint32_t)site_ref[s0 + k] * 0x11111111u | (t * 15u);
+            if (__builtin_amdgcn_ballot_w64(b != 0) != 0) act |= 1u << k;
+        }
+        if (l == 0 && wb + w < active_words) active[(uint64_t)tile * active_words + wb + w] = act;
+    }
+    if (blockIdx.x == 0) table[(uint64_t)tile * n_rows * 64 + tid] = 0x11111111u << (tid >> 6);   // the four constant rows
 }
 
 // ---- tile build for batches with many rows per sample (high-ambiguity queries: thousands of N cells each) ------------------
@@ -1643,7 +1731,7 @@ template <uint32_t G>
 __global__ void __launch_bounds__(256) k_descend(const ugp_result *__restrict__ coarse_res, const uint32_t *__restrict__ order, uint32_t n_queries,
                           const uint32_t *__restrict__ coarse2bfs, const uint2 *__restrict__ node_pair,
                           const uint32_t *__restrict__ parent, const uint32_t *__restrict__ stream, const uint32_t *__restrict__ table, uint32_t n_sites,
-                          uint32_t *__restrict__ refined, uint32_t max_expansions) {
+                          uint32_t *__restrict__ refined, uint32_t max_expansions, int slack) {
     constexpr uint32_t NG = 256u / G;   // samples per block
     __shared__ uint32_t f_node[NG][DESC_FRONTIER], f_cb[NG][DESC_FRONTIER], f_ce[NG][DESC_FRONTIER];
     __shared__ int f_d[NG][DESC_FRONTIER];
@@ -1715,8 +1803,12 @@ __global__ void __launch_bounds__(256) k_descend(const ugp_result *__restrict__ 
         for (int o = (int)G / 2; o > 0; o >>= 1) { const unsigned long long other = __shfl_xor(kk, o, (int)G); kk = other < kk ? other : kk; }
         const uint32_t e = act ? ((uint32_t)kk & 31u) : 0u;
         const int D = f_d[g][e];
-        const uint32_t cb = act ? f_cb[g][e] : 0u, ce = act ? f_ce[g][e] : 0u;   // children: BFS indices [cb, ce)
-        if (act) {
+        // (the entry with the smallest D lies more than `slack` above the best cost seen: nothing left in the frontier is on the
+        // sample's lineage any more -- there D and the best cost fall together -- and the search ends)
+        const bool go = act && D <= best + slack;
+        if (act && !go) n_f = 0;
+        const uint32_t cb = go ? f_cb[g][e] : 0u, ce = go ? f_ce[g][e] : 0u;   // children: BFS indices [cb, ce)
+        if (go) {
             n_f--;
             if (gl == 0 && e != n_f) { f_node[g][e] = f_node[g][n_f]; f_d[g][e] = f_d[g][n_f]; f_cb[g][e] = f_cb[g][n_f]; f_ce[g][e] = f_ce[g][n_f]; }
         }
@@ -1883,13 +1975,14 @@ hipError_t launch_descend(const ugp_result *coarse_res, const uint32_t *order, u
                           const uint32_t *node_pair, const uint32_t *parent, const uint32_t *stream, const uint32_t *table,
                           uint32_t n_sites, uint32_t *refined, bool wide, hipStream_t s) {
     if (!n_queries) return hipSuccess;
-    static const uint32_t max_exp = getenv("UGP_DESCENT_MAX") ? (uint32_t)std::max(1, atoi(getenv("UGP_DESCENT_MAX"))) : DESC_MAX_EXPANSIONS;   // (tuning)
+    const uint32_t max_exp = getenv("UGP_DESCENT_MAX") ? (uint32_t)std::max(1, atoi(getenv("UGP_DESCENT_MAX"))) : DESC_MAX_EXPANSIONS;   // (tuning)
+    const int slack = getenv("UGP_DESCENT_SLACK") ? atoi(getenv("UGP_DESCENT_SLACK")) : 2;   // (measured at 10M nodes: 0 costs the main walk 60 %, 1..5 are alike, none is 8 % more descent)
     if (wide)
         hipLaunchKernelGGL(k_descend<64>, dim3((n_queries + 3) / 4), dim3(256), 0, s, coarse_res, order, n_queries, coarse2bfs, (const uint2 *)node_pair, parent,
-                           stream, table, n_sites, refined, max_exp);
+                           stream, table, n_sites, refined, max_exp, slack);
     else
         hipLaunchKernelGGL(k_descend<16>, dim3((n_queries + 15) / 16), dim3(256), 0, s, coarse_res, order, n_queries, coarse2bfs, (const uint2 *)node_pair, parent,
-                           stream, table, n_sites, refined, max_exp);
+                           stream, table, n_sites, refined, max_exp, slack);
     return hipGetLastError();
 }
 
@@ -1933,7 +2026,33 @@ hipError_t launch_scatter(uint32_t *table, uint32_t *dbottom, const int32_t *pos
     if (n_ent == 0) return hipSuccess;
     uint64_t blocks = (n_ent + 255) / 256;
     hipLaunchKernelGGL(k_scatter_entries, dim3((uint32_t)blocks), dim3(256), 0, s, table, dbottom, pos, ref, nuc,
-                       is_missing, ent_q, pos2site, max_pos, n_sites, n_ent, q_base, active, active_words, slot_of, vrows);
+                       is_missing, ent_q, pos2site, max_pos, n_sites, n_ent, q_base, active, active_words, slot_of, vrows, nullptr, nullptr, 0u);
+    return hipGetLastError();
+}
+
+// the rows listed in row_list (their number is on the device: n_listed), restricted to the samples [q_base, q_base + n_q)
+hipError_t launch_scatter_list(uint32_t *table, uint32_t *dbottom, const int32_t *pos, const uint8_t *ref, const uint8_t *nuc, const uint8_t *is_missing,
+                               const uint32_t *ent_q, const int32_t *pos2site, uint32_t max_pos, uint32_t n_sites, uint32_t q_base, uint32_t n_q,
+                               uint32_t *active, uint32_t active_words, const uint32_t *slot_of, const uint32_t *row_list, const uint32_t *n_listed,
+                               hipStream_t s) {
+    hipLaunchKernelGGL(k_scatter_entries, dim3(2048), dim3(256), 0, s, table, dbottom, pos, ref, nuc, is_missing, ent_q, pos2site, max_pos, n_sites,
+                       (uint64_t)0, q_base, active, active_words, slot_of, (uint32_t *)nullptr, row_list, n_listed, n_q);
+    return hipGetLastError();
+}
+
+hipError_t launch_nmask_build(const uint64_t *ent_off, uint32_t n_queries, const int32_t *pos, const uint8_t *is_missing, const int32_t *pos2site,
+                              uint32_t max_pos, uint32_t words, uint32_t *nmask, uint32_t *plain_rows, uint32_t *n_plain, hipStream_t s) {
+    if (!n_queries) return hipSuccess;
+    hipLaunchKernelGGL(k_nmask_build, dim3(n_queries), dim3(256), (size_t)words * 4, s, ent_off, pos, is_missing, pos2site, max_pos, words, nmask,
+                       plain_rows, n_plain);
+    return hipGetLastError();
+}
+
+hipError_t launch_ntiles(uint32_t *table, uint32_t *active, uint32_t active_words, uint32_t n_tiles512, const uint32_t *nmask, uint32_t words,
+                         const uint32_t *order, uint32_t q0, uint32_t nq, const uint8_t *site_ref, uint32_t n_sites, hipStream_t s) {
+    if (!n_tiles512 || !n_sites) return hipSuccess;
+    hipLaunchKernelGGL(k_ntiles, dim3((words + 15) / 16, n_tiles512), dim3(256), 0, s, table, active, active_words, nmask, words, order, q0, nq, site_ref,
+                       n_sites);
     return hipGetLastError();
 }
 

@@ -88,10 +88,12 @@ class SynthTree:
         }
         self.genome_len = genome_len
 
-    def queries(self, n_queries: int, seed: int = 1, max_subst: int = 3, n_lo: int = 0, n_hi: int = 0, iupac_hi: int = 0, recent: bool = False):
-        """CSR query arrays: (ent_off, pos, ref, nuc, is_missing, source_node)."""
+    def queries(self, n_queries: int, seed: int = 1, max_subst: int = 3, n_lo: int = 0, n_hi: int = 0, iupac_hi: int = 0, recent: bool = False,
+                iupac_true: bool = False):
+        """CSR query arrays: (ent_off, pos, ref, nuc, is_missing, source_node).  iupac_true: every ambiguity code holds the
+        sample's own base (default: any set of 2-3 bases, i.e. most such cells are mismatches)."""
         L = _L()
-        q = L.ugs_queries_create2(self._h, n_queries, seed, max_subst, n_lo, n_hi, iupac_hi, 1 if recent else 0)
+        q = L.ugs_queries_create2(self._h, n_queries, seed, max_subst, n_lo, n_hi, iupac_hi, (1 if recent else 0) | (2 if iupac_true else 0))
         if not q:
             raise MemoryError("ugs_queries_create failed")
         try:
