@@ -343,8 +343,9 @@ def _ties_chunk(flat, nib, dbot, c, want):
     scores = {}
     slots = {}
     cnt, key_best = 0, 0
-    dcur = 0
+    dcur = bcur = 0
     info = None
+    info_hr = 255
     for words, lo, hi in ((flat.pre_stream, int(flat.chunk_pre_off[c]), int(flat.chunk_pre_off[c + 1])),
                           (flat.stream_t, int(flat.chunk_t_off[c]), int(flat.chunk_t_off[c + 1]))):
         i = lo
@@ -353,25 +354,29 @@ def _ties_chunk(flat, nib, dbot, c, want):
             nmut = w0 & 0xFFFF
             if nmut == 0xFFFF:          # pruning pseudo-record of the tie stream (walk_ties)
                 info = key
+                info_hr = (w0 >> 16) & 0xFF
                 continue
             rslot, wslot = (w0 >> 16) & 63, (w0 >> 22) & 63
-            dpar = dcur if rslot == RS_REG else (dbot if rslot == RS_BOTTOM else slots[rslot])
-            tsum = neg = common = n_before = 0
+            dpar, bpar = (dcur, bcur) if rslot == RS_REG else ((dbot, 0) if rslot == RS_BOTTOM else slots[rslot])
+            tsum = tsum_b = neg = common = n_before = 0
             for _ in range(nmut):
                 w = int(words[i]); i += 1
-                site, mi, pi = w & 0x3FFFFF, (w >> 22) & 3, (w >> 24) & 3
+                site, mi, pi, ri = w & 0x3FFFFF, (w >> 22) & 3, (w >> 24) & 3, (w >> 26) & 3
                 x = int(nib[site])
                 cc, pp = (x >> mi) & 1, (x >> pi) & 1
                 d = pp - cc
                 tsum += d
+                tsum_b += d if (x >> ri) & 1 else 0
                 if not (w & M_AFTER_MASK):
                     n_before += 1
                     common += cc
                     neg += min(d, 0)
             dn = dpar + tsum
+            bn = bpar + tsum_b          # (the kernel keeps D | B << 16 in one word)
+            assert 0 <= bn <= dn < 0x8000
             if wslot != WS_NONE:
-                slots[wslot] = dn
-            dcur = dn
+                slots[wslot] = (dn, bn)
+            dcur, bcur = dn, bn
             if not (w0 & F_NOSCORE):
                 if w0 & F_ROOT:
                     cost, elig, hu = dn, True, 0
@@ -386,7 +391,7 @@ def _ties_chunk(flat, nib, dbot, c, want):
             if info is not None:
                 hs, jump = info >> 24, info & 0xFFFFFF
                 info = None
-                if not dn <= want + hs:     # D - hsub > want: no descendant can tie
+                if not (dn <= want + hs and (info_hr == 255 or bn <= want + info_hr)):     # D - hsub > want or B - second hits > want: no descendant can tie
                     i += jump
                     assert i <= hi
     return want, cnt, key_best

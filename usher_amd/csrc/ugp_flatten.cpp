@@ -680,7 +680,7 @@ int flatten(const ugp_tree_desc &t, const Options &opt, FlatMat &out, std::strin
                         const uint64_t d_end = (uint64_t)d + sub[j];
                         const uint32_t target = d_end >= cno[c + 1] ? len : post_at[d_end];
                         const uint32_t own_end = pos + 4u + nwords;
-                        st[pos++] = T_INFO_MARK;
+                        st[pos++] = T_INFO_MARK | ((uint32_t)hrev[j] << 16);   // (second hits below; 255: not available)
                         st[pos++] = (hsub[j] << 24) | std::min<uint32_t>(target - own_end, 0xFFFFFFu);
                     }
                     for (uint32_t k = 0; k < 2u + nwords; k++) st[pos++] = rec[k];

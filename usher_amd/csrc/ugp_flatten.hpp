@@ -155,7 +155,7 @@ struct FlatMat {
     UVec<uint32_t> stream8, pre8_stream;
     std::vector<uint32_t> chunk8_body_off, chunk8_pre_off;   // [n_chunks+1]
     // Tie stream (phase 2): the chunk bodies of `stream` without the leaves that can never be eligible and
-    // with pruning pseudo-records {w0 = T_INFO_MARK, w1 = hsub << 24 | jump}: the node that follows may be
+    // with pruning pseudo-records {w0 = T_INFO_MARK | second hits below << 16 (255: not available), w1 = hsub << 24 | jump}: the node that follows may be
     // skipped together with its descendants (`jump` dwords behind its own record, inside the chunk)
     // when D(node) - hsub exceeds the wanted score of every sample that still looks for ties here.
     UVec<uint32_t> stream_t, chunk_t_off;             // chunk_t_off: [n_chunks+1]

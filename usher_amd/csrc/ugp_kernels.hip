@@ -398,6 +398,8 @@ __device__ __forceinline__ WalkOut walk_ties(const PlaceArgs &a, uint32_t *slots
     const uint32_t sh = (lane & 7u) * 4u;
     const uint32_t dbot = a.dbottom[tile * 64 + lane];
     WalkOut o; o.best = 0; o.cnt = 0; o.key = 0;
+    // D in the low half, B in the high half of one word (both below 2^15 on the packed path): B = the part of D at sites where
+    // the sample's set holds the reference base -- the second pruning bound of k_best8 (ugp_flatten.hpp), here as well
     uint32_t dcur = 0;
     for (int phase = 0; phase < 2; phase++) {
         const uint32_t *p = phase == 0 ? a.pre_stream : a.stream_t;
@@ -425,36 +427,38 @@ __device__ __forceinline__ WalkOut walk_ties(const PlaceArgs &a, uint32_t *slots
             return w;
         };
         bool have_info = false;
-        uint32_t info = 0;
+        uint32_t info = 0, info_hr = 255;
         while (pos < end) {
             const uint32_t w0 = next();
             const uint32_t key = next();
             const uint32_t nmut = w0 & 0xFFFFu;
-            if (nmut == T_INFO_MARK) { have_info = true; info = key; continue; }
+            if (nmut == T_INFO_MARK) { have_info = true; info = key; info_hr = (w0 >> 16) & 0xFFu; continue; }
             const uint32_t rslot = (w0 >> 16) & 63u, wslot = (w0 >> 22) & 63u;
-            uint32_t dpar;
-            if (rslot == RS_REG) dpar = dcur;
-            else if (rslot == RS_BOTTOM) dpar = dbot;
-            else dpar = slots[rslot * 64 + lane];
+            uint32_t xpar;   // (D | B << 16) of the parent
+            if (rslot == RS_REG) xpar = dcur;
+            else if (rslot == RS_BOTTOM) xpar = dbot;   // (B = 0 below the root)
+            else xpar = slots[rslot * 64 + lane];
+            const uint32_t dpar = xpar & 0xFFFFu;
             int tsum = 0, neg = 0;
             uint32_t common = 0, n_before = 0;
             for (uint32_t m = 0; m < nmut; m++) {
                 const uint32_t w = next();
-                const uint32_t mi = (w >> 22) & 3u, pi = (w >> 24) & 3u;
+                const uint32_t mi = (w >> 22) & 3u, pi = (w >> 24) & 3u, ri = (w >> 26) & 3u;
                 const uint32_t x = rowbuf[(pos - 1u - base) * 8u + col];
                 const uint32_t nib = (x >> sh) & 15u;
                 const int cc = (int)((nib >> mi) & 1u), pp = (int)((nib >> pi) & 1u);
                 const int d = pp - cc;
-                tsum += d;
+                tsum += d + (((nib >> ri) & 1u) ? d * 65536 : 0);
                 if (!(w & M_AFTER_MASK)) {
                     n_before++;
                     common += (uint32_t)cc;
                     neg += min(d, 0);
                 }
             }
-            const uint32_t dn = dpar + (uint32_t)tsum;
-            if (wslot != WS_NONE) slots[wslot * 64 + lane] = dn;
-            dcur = dn;
+            const uint32_t xn = xpar + (uint32_t)tsum;   // (both halves are counts of a real state: no borrow survives the node)
+            if (wslot != WS_NONE) slots[wslot * 64 + lane] = xn;
+            dcur = xn;
+            const uint32_t dn = xn & 0xFFFFu;
             if (!(w0 & F_NOSCORE)) {
                 uint32_t cost, hu;
                 bool elig;
@@ -481,7 +485,8 @@ __device__ __forceinline__ WalkOut walk_ties(const PlaceArgs &a, uint32_t *slots
             if (have_info) {
                 have_info = false;
                 const uint32_t hs = info >> 24;
-                const bool near = relevant && dn <= want + hs;   // D - hsub <= want: a descendant may still tie
+                // D - hsub <= want and B - (second hits below) <= want: a descendant may still tie
+                const bool near = relevant && dn <= want + hs && (info_hr == 255u || (xn >> 16) <= want + info_hr);
                 if (__builtin_amdgcn_ballot_w64(near) == 0) {
                     pos += info & 0xFFFFFFu;
                     if (pos - base >= 64u && pos < end) { base = pos; window(); }
