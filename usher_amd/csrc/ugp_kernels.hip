@@ -1918,13 +1918,19 @@ __global__ void __launch_bounds__(256) k_build_units(const uint32_t *__restrict_
     }
     __syncthreads();
     uint4 *out = units + (uint64_t)tlo * per_tile_cap;
+    // own-region units: one thread each (a tile's run of them is found by bisection over the offsets); the units outside are
+    // a short sequential list per tile
+    for (uint32_t i = threadIdx.x; i < s_heavy_total; i += blockDim.x) {
+        uint32_t lo = 0, hi = T;   // the last t with s_hoff[t] <= i
+        while (hi - lo > 1u) { const uint32_t mid = (lo + hi) / 2u; if (s_hoff[mid] <= i) lo = mid; else hi = mid; }
+        const uint32_t tile = tlo + lo, r = i - s_hoff[lo];
+        const uint32_t h0 = hstart[tile], hl = hlen[tile];
+        const uint32_t c0 = h0 + r * HU;
+        out[i] = make_uint4(tile, c0, min(c0 + HU, h0 + hl), 1u);
+    }
     for (uint32_t t = threadIdx.x; t < T; t += blockDim.x) {
         const uint32_t tile = tlo + t;
         const uint32_t h0 = hstart ? hstart[tile] : 0u, hl = hstart ? hlen[tile] : 0u;
-        for (uint32_t r = 0; r < s_heavy[t]; r++) {
-            const uint32_t c0 = h0 + r * HU;
-            out[s_hoff[t] + r] = make_uint4(tile, c0, min(c0 + HU, h0 + hl), 1u);
-        }
         const uint32_t nA = count_side(n_chunks - h0 - hl), nB = count_side(h0), m = min(nA, nB);
         uint32_t a_at = h0 + hl, b_at = h0, ia = 0, ib = 0;
         const uint32_t n_rank = light_order == 1u ? nA + nB : s_max_light;   // (rank-major lists are padded with fillers to the longest tile)
