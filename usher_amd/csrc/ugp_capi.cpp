@@ -365,12 +365,12 @@ int run_place(ugp_mat *m, ugp_qset *qs, int mode, ugp_result *d_out, int32_t *d_
         } else if (lds_build)
             HIP_TRY(ugp::launch_build_tiles(W.d_table.p, d_active, active_words, n_tiles512, qs->d_ent_off.p, (uint32_t)q0, order, (uint32_t)nq, qs->d_pos.p,
                                             qs->d_ref.p, qs->d_nuc.p, qs->d_missing.p, m->d_pos2site.p, m->d_site_pos.p, m->d_site_ref.p, n_sites, f.max_pos,
-                                            d_dbottom, nullptr, s));
+                                            d_dbottom, s));
         else {
         HIP_TRY(ugp::launch_fill_table(W.d_table.p, m->d_site_ref.p, n_sites, table_dwords, s));
         HIP_TRY(ugp::launch_scatter(W.d_table.p, d_dbottom, qs->d_pos.p + e0, qs->d_ref.p + e0,
                                     qs->d_nuc.p + e0, qs->d_missing.p + e0, qs->d_ent_q.p + e0, m->d_pos2site.p,
-                                    f.max_pos, n_sites, e1 - e0, (uint32_t)q0, d_active, active_words, slot_of, nullptr, s));
+                                    f.max_pos, n_sites, e1 - e0, (uint32_t)q0, d_active, active_words, slot_of, s));
         }
         if (use8) {   // upper bounds of best(s) the pruning starts from
             if (sorted && getenv("UGP_SEED_PREV") && W.d_prev_res.cap >= Q && W.prev_serial == qs->serial)   // (experiment: bounds = the previous call's exact answers)

@@ -84,7 +84,7 @@ __global__ void k_scatter_entries(uint32_t *__restrict__ table, uint32_t *__rest
                                   const uint32_t *__restrict__ ent_q, const int32_t *__restrict__ pos2site,
                                   uint32_t max_pos, uint32_t n_sites, uint64_t n_ent, uint32_t q_base,
                                   uint32_t *__restrict__ active, uint32_t active_words,
-                                  const uint32_t *__restrict__ slot_of, uint32_t *__restrict__ vrows,
+                                  const uint32_t *__restrict__ slot_of,
                                   const uint32_t *__restrict__ row_list, const uint32_t *__restrict__ n_listed, uint32_t n_q) {
     // (with a row list -- the rows that are not missing, k_nmask_build -- the kernel strides over it: its length is only known
     // on the device; rows of samples outside [q_base, q_base + n_q) belong to another sub-batch)
@@ -111,15 +111,6 @@ __global__ void k_scatter_entries(uint32_t *__restrict__ table, uint32_t *__rest
     if (__builtin_amdgcn_ballot_w64(valid && q != q0) == 0) {
         if (mm && (threadIdx.x & 63u) == (uint32_t)__builtin_ctzll(mm)) atomicAdd(&dbottom[q0], (uint32_t)__builtin_popcountll(mm));
     } else if (mism) atomicAdd(&dbottom[q], 1u);
-    // V = #{rows whose allele set is neither missing nor just the reference base}: the sites at which the sample can
-    // gain from a mutation away from the reference (second pruning bound of k_best8, ugp_flatten.hpp)
-    if (vrows) {
-        const bool var = valid && !miss && a != r;
-        const unsigned long long vm = __builtin_amdgcn_ballot_w64(var);
-        if (__builtin_amdgcn_ballot_w64(valid && q != q0) == 0) {
-            if (vm && (threadIdx.x & 63u) == (uint32_t)__builtin_ctzll(vm)) atomicAdd(&vrows[q0], (uint32_t)__builtin_popcountll(vm));
-        } else if (var) atomicAdd(&vrows[q], 1u);
-    }
     if (!valid || p < 0 || (uint32_t)p > max_pos) continue;
     const int32_t site = pos2site[p];
     if (site < 0) continue;
@@ -223,7 +214,7 @@ __global__ void __launch_bounds__(256) k_ntiles(uint32_t *__restrict__ table, ui
 // 1.8 ms, twice per step.  Here a workgroup owns (tile, block of TB_SITES sites): it keeps those rows of the table in LDS,
 // every thread finds its samples' rows that fall into the block's position range (the rows of a sample are sorted by
 // position: one binary search), applies them with LDS atomics, and the block is written out coalesced -- which also
-// replaces k_fill_table.  D(bottom) and V come from k_row_counts, one wave per sample.
+// replaces k_fill_table.  D(bottom) comes from k_row_counts, one wave per sample.
 constexpr uint32_t TB_SITES = 128;
 __global__ void __launch_bounds__(256) k_build_tiles(uint32_t *__restrict__ table, uint32_t *__restrict__ active, uint32_t active_words,
                                                      const uint64_t *__restrict__ ent_off, uint32_t q0, const uint32_t *__restrict__ order, uint32_t nq,
@@ -273,24 +264,23 @@ __global__ void __launch_bounds__(256) k_build_tiles(uint32_t *__restrict__ tabl
     }
 }
 
-// D(bottom) = #{non-missing rows whose allele set excludes the reference base} and V = #{rows whose set is neither missing
-// nor just the reference base}, one wave per sample slot (usher_mapper.cpp:292-388 with an empty ancestral list).
+// D(bottom) = #{non-missing rows whose allele set excludes the reference base}, one wave per sample slot
+// (usher_mapper.cpp:292-388 with an empty ancestral list).
 __global__ void __launch_bounds__(256) k_row_counts(const uint64_t *__restrict__ ent_off, uint32_t q0, const uint32_t *__restrict__ order, uint32_t nq,
                                                     const uint8_t *__restrict__ ref, const uint8_t *__restrict__ nuc, const uint8_t *__restrict__ is_missing,
-                                                    uint32_t *__restrict__ dbottom, uint32_t *__restrict__ vrows) {
+                                                    uint32_t *__restrict__ dbottom) {
     const uint32_t slot = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63u;
     if (slot >= nq) return;
     const uint32_t q = q0 + (order ? order[slot] : slot);
     const uint64_t rb = ent_off[q], re = ent_off[q + 1];
-    uint32_t d = 0, v = 0;
+    uint32_t d = 0;
     for (uint64_t r = rb + lane; r < re; r += 64) {
         const uint32_t rr = ref[r], a = is_missing[r] ? 15u : (uint32_t)nuc[r];
         d += (!is_missing[r] && (a & rr) == 0) ? 1u : 0u;
-        v += (!is_missing[r] && a != rr) ? 1u : 0u;
     }
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { d += __shfl_xor(d, o); v += __shfl_xor(v, o); }
-    if (lane == 0) { dbottom[slot] = d; if (vrows) vrows[slot] = v; }
+    for (int o = 32; o > 0; o >>= 1) d += __shfl_xor(d, o);
+    if (lane == 0) dbottom[slot] = d;
 }
 
 // Query rows on arrival (one thread per VCF row): the sample each row belongs to (binary search in the CSR
@@ -2022,22 +2012,22 @@ hipError_t launch_fill_table(uint32_t *table, const uint8_t *site_ref, uint32_t 
 hipError_t launch_build_tiles(uint32_t *table, uint32_t *active, uint32_t active_words, uint32_t n_tiles512, const uint64_t *ent_off, uint32_t q0,
                               const uint32_t *order, uint32_t nq, const int32_t *pos, const uint8_t *ref, const uint8_t *nuc, const uint8_t *is_missing,
                               const int32_t *pos2site, const int32_t *site_pos, const uint8_t *site_ref, uint32_t n_sites, uint32_t max_pos,
-                              uint32_t *dbottom, uint32_t *vrows, hipStream_t s) {
+                              uint32_t *dbottom, hipStream_t s) {
     if (!n_tiles512 || !n_sites) return hipSuccess;
     hipLaunchKernelGGL(k_build_tiles, dim3((n_sites + TB_SITES - 1) / TB_SITES, n_tiles512), dim3(256), 0, s, table, active, active_words, ent_off, q0, order, nq,
                        pos, ref, nuc, is_missing, pos2site, site_pos, site_ref, n_sites, max_pos);
-    hipLaunchKernelGGL(k_row_counts, dim3((nq + 3) / 4), dim3(256), 0, s, ent_off, q0, order, nq, ref, nuc, is_missing, dbottom, vrows);
+    hipLaunchKernelGGL(k_row_counts, dim3((nq + 3) / 4), dim3(256), 0, s, ent_off, q0, order, nq, ref, nuc, is_missing, dbottom);
     return hipGetLastError();
 }
 
 hipError_t launch_scatter(uint32_t *table, uint32_t *dbottom, const int32_t *pos, const uint8_t *ref,
                           const uint8_t *nuc, const uint8_t *is_missing, const uint32_t *ent_q,
                           const int32_t *pos2site, uint32_t max_pos, uint32_t n_sites, uint64_t n_ent, uint32_t q_base,
-                          uint32_t *active, uint32_t active_words, const uint32_t *slot_of, uint32_t *vrows, hipStream_t s) {
+                          uint32_t *active, uint32_t active_words, const uint32_t *slot_of, hipStream_t s) {
     if (n_ent == 0) return hipSuccess;
     uint64_t blocks = (n_ent + 255) / 256;
     hipLaunchKernelGGL(k_scatter_entries, dim3((uint32_t)blocks), dim3(256), 0, s, table, dbottom, pos, ref, nuc,
-                       is_missing, ent_q, pos2site, max_pos, n_sites, n_ent, q_base, active, active_words, slot_of, vrows, nullptr, nullptr, 0u);
+                       is_missing, ent_q, pos2site, max_pos, n_sites, n_ent, q_base, active, active_words, slot_of, nullptr, nullptr, 0u);
     return hipGetLastError();
 }
 
@@ -2047,7 +2037,7 @@ hipError_t launch_scatter_list(uint32_t *table, uint32_t *dbottom, const int32_t
                                uint32_t *active, uint32_t active_words, const uint32_t *slot_of, const uint32_t *row_list, const uint32_t *n_listed,
                                hipStream_t s) {
     hipLaunchKernelGGL(k_scatter_entries, dim3(2048), dim3(256), 0, s, table, dbottom, pos, ref, nuc, is_missing, ent_q, pos2site, max_pos, n_sites,
-                       (uint64_t)0, q_base, active, active_words, slot_of, (uint32_t *)nullptr, row_list, n_listed, n_q);
+                       (uint64_t)0, q_base, active, active_words, slot_of, row_list, n_listed, n_q);
     return hipGetLastError();
 }
 

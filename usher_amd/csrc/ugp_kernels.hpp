@@ -102,11 +102,11 @@ hipError_t launch_fill_table(uint32_t *table, const uint8_t *site_ref, uint32_t 
 hipError_t launch_build_tiles(uint32_t *table, uint32_t *active, uint32_t active_words, uint32_t n_tiles512, const uint64_t *ent_off, uint32_t q0,
                               const uint32_t *order /* slot -> sample of the sub-batch, or null */, uint32_t nq, const int32_t *pos, const uint8_t *ref,
                               const uint8_t *nuc, const uint8_t *is_missing, const int32_t *pos2site, const int32_t *site_pos, const uint8_t *site_ref,
-                              uint32_t n_sites, uint32_t max_pos, uint32_t *dbottom, uint32_t *vrows /* or null */, hipStream_t s);
+                              uint32_t n_sites, uint32_t max_pos, uint32_t *dbottom, hipStream_t s);
 hipError_t launch_scatter(uint32_t *table, uint32_t *dbottom, const int32_t *pos, const uint8_t *ref,
                           const uint8_t *nuc, const uint8_t *is_missing, const uint32_t *ent_q,
                           const int32_t *pos2site, uint32_t max_pos, uint32_t n_sites, uint64_t n_ent, uint32_t q_base,
-                          uint32_t *active, uint32_t active_words, const uint32_t *slot_of, uint32_t *vrows /* or null */, hipStream_t s);
+                          uint32_t *active, uint32_t active_words, const uint32_t *slot_of, hipStream_t s);
 // tiles of batches with many missing rows: N bits per (sample, site) built once per query set, tiles transposed from them
 hipError_t launch_nmask_build(const uint64_t *ent_off, uint32_t n_queries, const int32_t *pos, const uint8_t *is_missing, const int32_t *pos2site,
                               uint32_t max_pos, uint32_t words, uint32_t *nmask, uint32_t *plain_rows /* or null */, uint32_t *n_plain, hipStream_t s);
