@@ -99,6 +99,27 @@ def test_slot_depth_is_logarithmic():
     assert FlatTreeView(arrays2).max_slots <= int(np.log2(arrays2["n"])) + 2
 
 
+def test_second_bound_is_withheld_on_deep_trees():
+    """k_best8 keeps B (the part of D at sites where the sample holds the reference base) in one byte per sample; B never
+    exceeds the mutations on a root path, so a tree with more than 255 of them gets pruning records that say "second hits:
+    not available" everywhere -- and the walk stays exact with the first bound alone."""
+    arrays, queries = synth.caterpillar_case(7, depth=200, muts_per_node=2, n_queries=3)
+    flat = FlatTreeView(arrays, chunk_nodes=40)
+    assert flat.max_path_muts > 255
+    recs = [int(w) for w in flat.stream8 if (int(w) >> 31) and (int(w) >> 30) & 1]
+    assert recs and all((w >> stream_interp.INFO_HR_SHIFT) & 7 == stream_interp.INFO_HR_NONE for w in recs)
+    ot = capi.OracleTree(arrays)
+    n_chunks = len(flat.chunk8_body_off) - 1
+    for s in queries:
+        want = ot.place(s)
+        res = stream_interp.place8(flat, s, n_groups=max(1, n_chunks // 3), prune_ub=want["best"] + 1)
+        assert (res["best"], res["num_best"], res["best_j"]) == (want["best"], want["num_best"], want["best_j"])
+    arrays2, _ = synth.make_case(5, n_leaves=300, n_queries=0)
+    flat2 = FlatTreeView(arrays2, chunk_nodes=40)   # a shallow tree: the records carry counts
+    recs2 = [int(w) for w in flat2.stream8 if (int(w) >> 31) and (int(w) >> 30) & 1]
+    assert flat2.max_path_muts <= 255 and any((w >> stream_interp.INFO_HR_SHIFT) & 7 != stream_interp.INFO_HR_NONE for w in recs2)
+
+
 def test_hot_slots_are_capped(monkeypatch):
     """k_best8 keeps the B halves of the on-chip slots in two 16-element register vectors: however many are asked for, the
     stream is encoded for at most 16 (the rest go through the cold path)."""
