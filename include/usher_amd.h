@@ -188,6 +188,9 @@ int ugp_subtree_mask(ugp_mat *mat, uint32_t order, uint32_t root_j, uint32_t max
  * times.  `stream` is a hipStream_t (NULL = the default stream); d_out is a
  * device pointer to n_queries ugp_result records.  Asynchronous on `stream`. */
 int ugp_qset_upload(ugp_mat *mat, const ugp_queries *q, ugp_qset **out);
+/* (A query set belongs to the handle it was uploaded for.  Sets with many rows per sample -- from 128 on average: the runs of N
+ * of low-coverage samples -- also get one bit per (sample, tree site) on the device, about 3 KB per sample at 25,000 sites for
+ * the tree and again for its coarse copy, from which every placement call builds its allele tiles.) */
 void ugp_qset_destroy(ugp_qset *qs);
 uint64_t ugp_qset_size(const ugp_qset *qs);
 int ugp_place_device(ugp_mat *mat, ugp_qset *qs, void *d_out, void *stream);
