@@ -1595,11 +1595,11 @@ __device__ __forceinline__ uint32_t pk_lookup(const uint32_t *packed, uint32_t t
 __global__ void k_select(const uint32_t *__restrict__ lbest, const uint32_t *__restrict__ list, const uint32_t *__restrict__ list_n,
                          const uint32_t *__restrict__ gbest, uint32_t n_chunks, uint32_t n_tiles, uint32_t n_queries,
                          uint32_t *__restrict__ items, uint32_t *__restrict__ n_items, uint32_t cap) {
-    // block = one tile; threads stride over (recorded chunk, 64-sample sub-tile) pairs
+    // blocks (tile, 0..gridDim.y-1) share one tile; their threads stride over its (recorded chunk, 64-sample sub-tile) pairs
     const uint32_t tile = blockIdx.x;
     const uint32_t n = list_n[tile], n_t64 = n_tiles * 8;
     const uint32_t *l = list + (uint64_t)tile * n_chunks;
-    for (uint32_t p = threadIdx.x; p < n * 8u; p += blockDim.x) {
+    for (uint32_t p = blockIdx.y * blockDim.x + threadIdx.x; p < n * 8u; p += gridDim.y * blockDim.x) {
         const uint32_t c = l[p >> 3], t8 = p & 7u;
         const uint32_t t64 = tile * 8 + t8;
         if ((uint64_t)t64 * 64 >= n_queries) continue;
@@ -2132,7 +2132,7 @@ hipError_t launch_phase2(const PlaceArgs &a, const uint32_t *lbest, const uint32
     hipLaunchKernelGGL(k_gbest, dim3(n_tiles512, slices), dim3(256), 0, s, lbest, list, list_n, a.n_chunks, n_tiles512, gbest_part);
     hipLaunchKernelGGL(k_gbest2, dim3((per_chunk + 255) / 256), dim3(256), 0, s, gbest_part, slices, per_chunk, gbest);
     const uint64_t pairs = (uint64_t)a.n_chunks * n_tiles512 * 8;
-    hipLaunchKernelGGL(k_select, dim3(n_tiles512), dim3(256), 0, s, lbest, list, list_n, gbest, a.n_chunks, n_tiles512, a.n_queries, items,
+    hipLaunchKernelGGL(k_select, dim3(n_tiles512, n_tiles512 < 256 ? 8 : 1), dim3(256), 0, s, lbest, list, list_n, gbest, a.n_chunks, n_tiles512, a.n_queries, items,
                        n_items, cap);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
