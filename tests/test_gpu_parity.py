@@ -298,9 +298,13 @@ def test_consecutive_device_calls_share_the_device_and_stay_exact(monkeypatch):
     assert (first.cpu().numpy() == want[1]).all()
     pl.timing_sum()
     outs = []
+    # (the output buffers are made up front: a call does not wait for work queued on the caller's stream before it -- include/usher_amd.h --
+    # and a fill queued there sits behind the completion events of the calls before it)
+    bufs = [[torch.full((len(batches[i]), 4), -7, dtype=torch.int32, device="cuda") for i in (0, 1, 2, 1, 0)] for _ in range(4)]
+    torch.cuda.synchronize()
     for rnd in range(4):
-        for i in (0, 1, 2, 1, 0):
-            o = torch.full((len(batches[i]), 4), -7, dtype=torch.int32, device="cuda")
+        for k, i in enumerate((0, 1, 2, 1, 0)):
+            o = bufs[rnd][k]
             pl.place_device(handles[i], o.data_ptr(), stream)
             outs.append((i, o))
         if rnd == 1:
@@ -530,12 +534,14 @@ def test_randomised_trees_and_scheduling_knobs(seed, monkeypatch):
         knobs["UGP_LDS_BITS"] = str(int(rng.integers(0, 2)))    # the kernel variant with the tiles' active-row bitmaps in LDS
     if rng.random() < 0.3:
         knobs["UGP_PRE_WEIGHT"] = "50"
+    if rng.random() < 0.3:
+        knobs["UGP_PHASE2_PACKED"] = "1"     # phase 2 as a mode of the packed walk (k_best8<TIES>) instead of k_ties
     if rng.random() < 0.4:
         knobs["UGP_NMASK"] = "1"             # tiles built from per-sample N bit masks (the path of batches with many missing rows)
     if rng.random() < 0.3:
         knobs["UGP_COARSE_PHASE2"] = "1"     # the coarse pass with its full phase 2 (the tie-break winner seeds the sort and the descent)
     for k in ("UGP_COARSE_MIN_NODES", "UGP_UNIT_CHUNKS", "UGP_HEAVY_CHUNKS", "UGP_UB_EVERY", "UGP_PRUNE_MIN_WORDS", "UGP_NO_LPT", "UGP_NO_SEED",
-              "UGP_NO_SORT", "UGP_NO_PRUNE", "UGP_FORCE_V1", "UGP_LDS_SLOTS", "UGP_NO_DESCENT", "UGP_NO_BOUND2", "UGP_UNIT_GROW", "UGP_UNIT_MAX", "UGP_SPLIT_CYCLES", "UGP_LDS_BITS", "UGP_PRE_WEIGHT", "UGP_COARSE_PHASE2", "UGP_NMASK"):
+              "UGP_NO_SORT", "UGP_NO_PRUNE", "UGP_FORCE_V1", "UGP_LDS_SLOTS", "UGP_NO_DESCENT", "UGP_NO_BOUND2", "UGP_UNIT_GROW", "UGP_UNIT_MAX", "UGP_SPLIT_CYCLES", "UGP_LDS_BITS", "UGP_PRE_WEIGHT", "UGP_COARSE_PHASE2", "UGP_NMASK", "UGP_PHASE2_PACKED"):
         monkeypatch.delenv(k, raising=False)
     for k, v in knobs.items():
         monkeypatch.setenv(k, v)

@@ -96,7 +96,7 @@ struct ugp_mat {
     uint64_t stream_dwords = 0, pre_dwords = 0;
     DevBuf<uint32_t> d_stream, d_pre, d_chunk_body, d_chunk_pre, d_chunk_node, d_rank2bfs, d_dfs2bfs;
     DevBuf<uint32_t> d_stream8, d_pre8, d_chunk8_body, d_chunk8_pre, d_stream_t, d_chunk_t;
-    DevBuf<uint32_t> d_node_pos8;   // (the coarse MAT) packed-stream position of every node's words, by DFS index
+    DevBuf<uint32_t> d_node_pos8, d_rank_dfs;   // packed-stream position of every node's words and its tie rank, by DFS index (k_best8 names nodes by position)
     uint64_t stream8_dwords = 0;
     DevBuf<int32_t> d_pos2site, d_site_pos;   // position -> site, site -> position
     DevBuf<uint8_t> d_site_ref;
@@ -122,6 +122,7 @@ struct ugp_mat {
     struct Work {
         DevBuf<uint32_t> d_table, d_zero, d_part_best, d_part_cnt, d_part_key;
         DevBuf<uint32_t> d_lpos;    // (coarse pass) which node set each chunk minimum
+        DevBuf<uint32_t> d_tie_units, d_tie_info;   // phase 2 as a mode of the packed walk: its unit lists (room for every (tile, chunk)) and counters
         DevBuf<uint32_t> d_lbest, d_gbest, d_gbest_part, d_items, d_ub, d_gstart, d_hlen, d_cold, d_list, d_units, d_unit_info;
         DevBuf<uint64_t> d_dyn;
         uint32_t dyn_epoch = 0;
@@ -587,7 +588,16 @@ int run_place(ugp_mat *m, ugp_qset *qs, int mode, ugp_result *d_out, int32_t *d_
             if (coarse_only)
                 HIP_TRY(ugp::launch_coarse_result(W.d_lbest.p, W.d_lpos.p, W.d_list.p, d_list_n, f.n_chunks, n_tiles512, (uint32_t)nq, m->d_chunk_node.p,
                                                   m->d_chunk8_body.p, m->d_node_pos8.p, m->d_dfs2bfs.p, d_out + q0, s));
-            else
+            else if (!d_tie_count && m->d_node_pos8.p && m->d_rank_dfs.p && b.ub && !b.stats && getenv("UGP_PHASE2_PACKED")) {
+                // (experiment, UGP_PHASE2_PACKED=1) phase 2 as a mode of the packed walk: one unit per (tile, chunk) record that holds some
+                // sample's global minimum.  Exact, but 6x slower than k_ties as it stands (1.8 against 0.3 ms per 16,384 samples): its
+                // units re-walk half of their chunks; DESIGN.md 7.2
+                HIP_TRY(W.d_tie_units.reserve((size_t)((n_tiles512 + 7) / 8) * 8 * f.n_chunks * 4));
+                HIP_TRY(W.d_tie_info.reserve(128));
+                HIP_TRY(ugp::launch_phase2_packed(b, W.d_list.p, d_list_n, W.d_gbest_part.p, W.d_gbest.p, n_tiles512, W.d_tie_units.p, W.d_tie_info.p, d_cnt, d_key,
+                                                  m->d_node_pos8.p, m->d_rank_dfs.p, m->d_chunk_node.p, m->d_rank2bfs.p, (uint32_t)nq, d_out + q0, order,
+                                                  (uint32_t)blocks, s));
+            } else
                 HIP_TRY(ugp::launch_phase2(a, W.d_lbest.p, W.d_list.p, d_list_n, W.d_gbest_part.p, W.d_gbest.p, n_tiles512, W.d_items.p, d_nitems,
                                            (uint32_t)std::min<uint64_t>(pairs, 0xFFFFFFFFull), d_cnt, d_key,
                                            m->d_rank2bfs.p, d_out + q0, order, f.max_slots, d_tie_count != nullptr, s));
@@ -777,6 +787,7 @@ static int upload_flat(const HostFlat &hf, int device, ugp_mat **out) {
     if ((e = m->d_stream_t.upload(f.stream_t)) != hipSuccess) return bail(e, "upload tie stream");
     if ((e = m->d_chunk_t.upload(f.chunk_t_off)) != hipSuccess) return bail(e, "upload chunk table");
     if (!f.node_pos8.empty() && (e = m->d_node_pos8.upload(f.node_pos8)) != hipSuccess) return bail(e, "upload node positions");
+    if (!f.rank_dfs.empty() && (e = m->d_rank_dfs.upload(f.rank_dfs)) != hipSuccess) return bail(e, "upload node ranks");
     m->stream8_dwords = f.stream8.size();
     m->stream_dwords = f.stream.size();
     m->pre_dwords = f.pre_stream.size();
@@ -814,6 +825,7 @@ static ugp::Options default_options() {
     if (const char *e = getenv("UGP_CHUNK_NODES")) opt.chunk_nodes = (uint32_t)std::max(1, atoi(e));
     if (const char *e = getenv("UGP_PRUNE_MIN_WORDS")) opt.prune_min_words = (uint32_t)std::max(1, atoi(e));
     if (getenv("UGP_NO_SIB")) opt.sibling_records = false;
+    opt.keep_node_pos8 = getenv("UGP_PHASE2_PACKED") != nullptr;   // (the experiment's node tables: 8 bytes per node on the device)
     if (getenv("UGP_NO_BOUND2")) opt.second_bound = false;   // first lower bound only (tests, tuning)
     if (const char *e = getenv("UGP_LDS_SLOTS")) opt.lds_slots = (uint32_t)std::max(1, std::min(60, atoi(e)));
     if (const char *e = getenv("UGP_PRE_WEIGHT")) opt.pre_weight = (uint32_t)std::max(0, atoi(e));

@@ -586,7 +586,11 @@ int flatten(const ugp_tree_desc &t, const Options &opt, FlatMat &out, std::strin
             }
         }
     }, 16);
-    if (opt.keep_node_pos8) out.node_pos8.assign(pos8_at.data(), pos8_at.data() + N + 1); else out.node_pos8.clear();
+    if (opt.keep_node_pos8) {
+        out.node_pos8.assign(pos8_at.data(), pos8_at.data() + N + 1);
+        out.rank_dfs.resize(N);
+        par.run(N, [&](uint64_t b, uint64_t e, unsigned) { for (uint64_t d = b; d < e; d++) out.rank_dfs[d] = rank[d2b[d]]; });
+    } else { out.node_pos8.clear(); out.rank_dfs.clear(); }
     out.stream8.resize(total8);
     par.run(NC, [&](uint64_t b, uint64_t e, unsigned) {
         uint32_t *s8 = out.stream8.data();

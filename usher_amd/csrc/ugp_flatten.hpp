@@ -121,7 +121,7 @@ struct Options {
     uint32_t prune_min_words = PRUNE_MIN_WORDS;   // subtrees at least this long (stream words) carry a pruning record
     bool sibling_records = true;   // emit H_INFO | H_SIB records
     bool second_bound = true;      // records carry the second-hit counts of the second pruning bound (false: "not available" everywhere)
-    bool keep_node_pos8 = false;   // export FlatMat::node_pos8 (the coarse MAT: k_best8 reports its winners by stream position)
+    bool keep_node_pos8 = false;   // export FlatMat::node_pos8 / rank_dfs (k_best8 names nodes by stream position: the coarse pass's winners, phase 2's ties)
     uint32_t lds_slots = LDS_SLOTS; // headers whose (renumbered) slots are >= this are flagged H_SLOW
     uint32_t pre_weight = 32;   // weight of the preambles' slot accesses when the hot (LDS) slots are chosen: every unit replays one,
                                 // the body is mostly skipped (0: body counts only)
@@ -160,6 +160,7 @@ struct FlatMat {
     // when D(node) - hsub exceeds the wanted score of every sample that still looks for ties here.
     UVec<uint32_t> stream_t, chunk_t_off;             // chunk_t_off: [n_chunks+1]
     uint32_t max_path_muts = 0;            // max over nodes of the mutation count on the root path
+    std::vector<uint32_t> rank_dfs;        // (Options::keep_node_pos8) [n_nodes] by DFS index: the node's tie rank
     std::vector<uint32_t> node_pos8;       // (Options::keep_node_pos8) [n_nodes + 1] by DFS index: packed-stream position where the node's words begin
     uint32_t max_chunk8_words = 0;         // longest chunk of the packed stream (a work unit must stay below the reach of a preamble record's jump field)
     uint32_t lds_slots = 0;                // the Options value the packed stream was encoded for (<= max_slots)

@@ -831,8 +831,14 @@ __device__ __forceinline__ uint32_t psub(uint32_t a, uint32_t b) { return a - b;
 // ~3 KB of LDS per wave (fewer resident waves); the host takes this variant when the bitmap is small enough.
 // ARG (the coarse pass): next to every chunk minimum, which node set it -- the low 16 bits of its last word's stream position, per
 // sample -- so that the pass needs no phase 2 (k_coarse_result maps the position back to the node).
-template <bool STATS, bool LBITS, bool ARG>   // STATS: per-unit accounting for tuning (UGP_STATS); off in production, it costs SGPRs
-__global__ void __launch_bounds__(64, 4) k_best8(Best8Args a) {
+// TIES (phase 2 on the packed path; an experiment, UGP_PHASE2_PACKED=1 -- exact, but with exact bounds and a handful of samples that
+// matter its units are chains of jumps, one pipeline restart per 1.5 words, where k_ties' 64-word windows absorb a jump for free: 1.8
+// against 0.3 ms per 16,384 samples): the units are the (tile, chunk) pairs that left a record and hold some sample's global minimum; a.ub
+// holds the samples' global minima; the samples of the tile whose minimum lies elsewhere take no part in the far tests (and tie with
+// nothing: their costs in this chunk exceed their minimum); where a node's cost equals a sample's minimum -- a rare, uniform branch -- the node
+// is found from its stream position and counted for that sample (a.tie_cnt, a.tie_key: what k_ties computes one sample per lane).
+template <bool STATS, bool LBITS, bool ARG, bool TIES>   // STATS: per-unit accounting for tuning (UGP_STATS); off in production, it costs SGPRs
+__global__ void __launch_bounds__(64, TIES ? 3 : 4) k_best8(Best8Args a) {
     extern __shared__ __attribute__((aligned(16))) u32x4 slots8[];   // the hot saved slots: [lds_slots][64] x 16 B of D (the 8 B of B per lane and slot are in registers)
     const uint32_t lane = threadIdx.x;
     const uint32_t lane16 = lane * 16u;
@@ -955,6 +961,15 @@ __global__ void __launch_bounds__(64, 4) k_best8(Best8Args a) {
 #pragma unroll
         for (int j = 0; j < 4; j++) dbot.v[j] = (db[j] & 0xFFFFu) | (db[j + 4] << 16);
     }
+    Pk4 irr;   // (TIES) 0x8000 per sample whose global minimum is not attained in this chunk: it takes no part in the far tests
+#pragma unroll
+    for (int j = 0; j < 4; j++) irr.v[j] = 0;
+    if (TIES) {
+        const uint4 lb = *(const uint4 *)(a.lbest + (((uint64_t)c0 * a.n_tiles + tile) * 64 + lane) * 4);
+        const uint4 gb = *(const uint4 *)(a.ub + ((uint64_t)tile * 64 + lane) * 4);
+        irr.v[0] = pk_min(lb.x ^ gb.x, 0x00010001u) << 15; irr.v[1] = pk_min(lb.y ^ gb.y, 0x00010001u) << 15;
+        irr.v[2] = pk_min(lb.z ^ gb.z, 0x00010001u) << 15; irr.v[3] = pk_min(lb.w ^ gb.w, 0x00010001u) << 15;
+    }
     Pk4 best, dcur, dpar, carryD, carryN, carryC;
 #pragma unroll
     for (int j = 0; j < 4; j++) { best.v[j] = 0xFFFFFFFFu; dcur.v[j] = dbot.v[j]; dpar.v[j] = 0; carryD.v[j] = 0; carryN.v[j] = 0; carryC.v[j] = 0; }   // (dcur: the root reads D(bottom) as "the previous node's D")
@@ -964,7 +979,20 @@ __global__ void __launch_bounds__(64, 4) k_best8(Best8Args a) {
     for (int j = 0; j < 4; j++) bpos.v[j] = 0;
     uint32_t pos_base = 0;     // (ARG) uniform: stream position of the word at relative position 0 of the range being walked
     // best = min(best, c) per half; with ARG the halves that improve take the position p2 (both halves = the node's position)
+    Pk4 tie_t;                 // (TIES) per half: 1 where the open node's cost equals the sample's global minimum
+    uint32_t tie_any = 0, accU = 0;   // (TIES) accU: like accC, the node's mutations the sample does NOT share (has_unique); never flushed: bits only
+    // (TIES) a tie is handled outside the pipelined loop, like a pruning jump: the node's end asks for a restart behind itself and leaves
+    // what the handler needs -- its position (in a vector register, same value in every lane: see stop_v; 0xFFFFFFFF = none) and accU
+    uint32_t tie_u = 0, tie_pos_v;
+    asm volatile("v_mov_b32 %0, %1" : "=v"(tie_pos_v) : "s"(0xFFFFFFFFu));
+#pragma unroll
+    for (int j = 0; j < 4; j++) tie_t.v[j] = 0;
     auto take_min = [&](int j, uint32_t c, uint32_t p2) {
+        if (TIES) {
+            tie_t.v[j] = pk_min(c ^ pk_sub(ub1.v[j], 0x00010001u), 0x00010001u) ^ 0x00010001u;
+            tie_any |= tie_t.v[j];
+            return;
+        }
         const uint32_t nb = pk_min(best.v[j], c);
         if (ARG) {
             const uint32_t t = pk_min(nb ^ best.v[j], 0x00010001u);   // 1 per half that changed
@@ -1021,7 +1049,7 @@ __global__ void __launch_bounds__(64, 4) k_best8(Best8Args a) {
     const bool can_prune = a.ub != nullptr;   // uniform
     uint32_t *ubp = a.ub + ((uint64_t)tile * 64 + lane) * 4;
     auto exchange_ub = [&]() {   // ub = min(ub, what other waves found, this chunk's minimum); racy but every value is a real cost
-        if (!can_prune) return;
+        if (!can_prune || TIES) return;
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             uint32_t u = __hip_atomic_load(ubp + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1034,13 +1062,14 @@ __global__ void __launch_bounds__(64, 4) k_best8(Best8Args a) {
     // never exceeds the bound): only then are they stored, and the chunk is appended to the tile's list of records
     // for phase 2.  Most chunks are far from the tile's samples and end without a store.
     auto chunk_has_candidate = [&]() -> bool {
-        if (!can_prune) return true;
+        if (!can_prune || TIES) return true;
         uint32_t t = 0;
 #pragma unroll
         for (int j = 0; j < 4; j++) t |= pk_min(best.v[j], ub1.v[j]) ^ ub1.v[j];   // non-zero where best < ub + 1
         return __builtin_amdgcn_ballot_w64(t != 0) != 0;
     };
     auto chunk_end = [&]() {     // publish the chunk-local minimum, start the next chunk
+        if (TIES) { chunk++; return; }
         if (chunk_has_candidate()) {
             uint4 *dst = (uint4 *)(a.lbest + (((uint64_t)chunk * a.n_tiles + tile) * 64 + lane) * 4);
             *dst = make_uint4(best.v[0], best.v[1], best.v[2], best.v[3]);
@@ -1090,15 +1119,15 @@ __global__ void __launch_bounds__(64, 4) k_best8(Best8Args a) {
             const uint32_t bj[4] = {b[0] & 0x00FF00FFu, b[1] & 0x00FF00FFu, (b[0] >> 8) & 0x00FF00FFu, (b[1] >> 8) & 0x00FF00FFu};
             if (pre_prune && hs == PRE_HS_NONE) {   // preamble record whose hsub does not fit: the second bound only
 #pragma unroll
-                for (int j = 0; j < 4; j++) r &= psub(padd(bj[j], K2), ub1.v[j]);
+                for (int j = 0; j < 4; j++) r &= psub(padd(bj[j], K2), ub1.v[j]) | (TIES ? irr.v[j] : 0u);
             } else {
 #pragma unroll
-                for (int j = 0; j < 4; j++) r &= psub(padd(d.v[j], K), ub1.v[j]) | psub(padd(bj[j], K2), ub1.v[j]);
+                for (int j = 0; j < 4; j++) r &= psub(padd(d.v[j], K), ub1.v[j]) | psub(padd(bj[j], K2), ub1.v[j]) | (TIES ? irr.v[j] : 0u);
             }
         } else {
             if (pre_prune && hs == PRE_HS_NONE) return false;
 #pragma unroll
-            for (int j = 0; j < 4; j++) r &= psub(padd(d.v[j], K), ub1.v[j]);
+            for (int j = 0; j < 4; j++) r &= psub(padd(d.v[j], K), ub1.v[j]) | (TIES ? irr.v[j] : 0u);
         }
         return __builtin_amdgcn_ballot_w64((r & 0x80008000u) != 0x80008000u) == 0;
     };
@@ -1113,6 +1142,38 @@ __global__ void __launch_bounds__(64, 4) k_best8(Best8Args a) {
 
     // ---- end of the open node (shared by the fast and the slow step); wa = LDS byte offset of the write slot,
     // or 0xFFFFFFFF with `cold_ws` >= 0 for a cold one
+    // (TIES) the open node ties for some sample of the tile: which node is it -- the last one whose words begin at or in front of
+    // the position, found by all lanes together in two or three steps -- and for whom
+    auto tie_event = [&]() {
+        const uint32_t pos = (uint32_t)__builtin_amdgcn_readfirstlane((int)tie_pos_v);
+        asm volatile("v_mov_b32 %0, %1" : "=v"(tie_pos_v) : "s"(0xFFFFFFFFu));
+        if (pos == 0xFFFFFFFFu) return;
+        const uint32_t apos = pos_base + pos;
+        uint32_t lo = a.chunk_node_off[chunk], hi = a.chunk_node_off[chunk + 1u];   // uniform
+        while (hi - lo > 1u) {
+            const uint32_t st = (hi - lo + 63u) / 64u;
+            const uint32_t idx = lo + lane * st;
+            const bool le = idx < hi && a.node_pos8[idx] <= apos;   // (a prefix of the lanes: positions ascend with the DFS index)
+            const uint32_t k = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(le));
+            lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(lo + (k ? k - 1u : 0u) * st));
+            hi = min(lo + st, hi);
+        }
+        const uint32_t key = (uint32_t)__builtin_amdgcn_readfirstlane((int)a.rank_dfs[lo]) << 1;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                if ((tie_t.v[j] >> (16 * h)) & 1u) {
+                    const uint32_t q = tile * 512u + lane * 8u + (uint32_t)j + 4u * (uint32_t)h;
+                    if (q < a.n_queries) {
+                        const uint32_t hu = (tie_u >> (4 * (j + 4 * h))) & 1u;   // some mutation of the node is not the sample's
+                        atomicAdd(&a.tie_cnt[q], 1u);
+                        atomicMax(&a.tie_key[q], key | hu);
+                    }
+                }
+            }
+        }
+    };
     auto node_end = [&](uint32_t pos, int cold_ws) -> bool {   // true: a pruning jump was requested (skip_to)
         const uint32_t p2 = ARG ? ((pos_base + pos) & 0xFFFFu) * 0x00010001u : 0u;
         // A sample is ineligible here when it shares no mutation with the branch (common == 0,
@@ -1165,6 +1226,15 @@ __global__ void __launch_bounds__(64, 4) k_best8(Best8Args a) {
                 bs0[wsi] = vb.x; bs1[wsi] = vb.y;
             }
         }
+        bool tie_here = false;   // uniform
+        if (TIES) {
+            if (__builtin_amdgcn_ballot_w64(tie_any != 0) != 0) {
+                tie_here = true;
+                tie_u = accU;
+                asm volatile("v_mov_b32 %0, %1" : "=v"(tie_pos_v) : "s"(pos));
+            }
+            tie_any = 0; accU = 0;
+        }
         accP = accC = accN = accPB = accCB = 0;
         if (STATS) run_nodes++;
         if (have_info) {   // this node carries a pruning record: can its whole subtree be skipped?
@@ -1181,6 +1251,7 @@ __global__ void __launch_bounds__(64, 4) k_best8(Best8Args a) {
                 return true;
             }
         }
+        if (TIES && tie_here) { skip_to = pos + 1; return true; }   // (the walk goes on behind the node once the tie has been booked)
         return false;
     };
     auto flush_acc = [&]() {   // 15 mutations in the 4-bit counters: spill to the packed carries (rare)
@@ -1264,6 +1335,7 @@ __global__ void __launch_bounds__(64, 4) k_best8(Best8Args a) {
                 const uint32_t mi = (m >> 22) & 3u, pi = (m >> 24) & 3u, ri = (m >> 26) & 3u;
                 const uint32_t C = (x >> mi) & 0x11111111u, P = (x >> pi) & 0x11111111u, R = (x >> ri) & 0x11111111u;
                 accP += P; accC += C; accN += C & ~P; accPB += P & R; accCB += C & R;
+                if (TIES) accU |= ~C & 0x11111111u;
                 p++;
                 if (m & M_END) break;
                 if (m & M_FLUSH) flush_acc();
@@ -1301,7 +1373,7 @@ __global__ void __launch_bounds__(64, 4) k_best8(Best8Args a) {
         if (begin >= end) continue;
         const uint32_t n = end - begin;
         sp += begin;
-        if (ARG) pos_base = begin;
+        if (ARG || TIES) pos_base = begin;
         const uint32_t l8 = lane & (GRP - 1u);
         uint32_t lim = n;   // uniform: end of the range being walked (words behind it read as padding)
         auto load_words = [&](uint32_t off) -> uint32_t {   // words off .. off+7 in lanes 0..7 (replicated x8)
@@ -1358,6 +1430,7 @@ __global__ void __launch_bounds__(64, 4) k_best8(Best8Args a) {
                 const uint32_t mi = (w >> 22) & 3u, pi = (w >> 24) & 3u, ri = (w >> 26) & 3u;
                 const uint32_t C = (x >> mi) & 0x11111111u, P = (x >> pi) & 0x11111111u, R = (x >> ri) & 0x11111111u;
                 accP += P; accC += C; accN += C & ~P; accPB += P & R; accCB += C & R;
+                if (TIES) accU |= ~C & 0x11111111u;
                 if (!(w & M_END)) {
                     if (w & M_FLUSH) flush_acc();
                     return false;
@@ -1433,6 +1506,7 @@ __global__ void __launch_bounds__(64, 4) k_best8(Best8Args a) {
                 __builtin_amdgcn_s_waitcnt(0);   // (a cold slot written here may be read by the very next node)
                 if (!skip_to) { off = q; continue; }
             }
+            if (TIES) tie_event();   // (a node that tied asked for this restart, or did so on top of a jump)
             // restart request: close every chunk whose end marker lies before the new position
             // (the end-marker position of the open chunk is kept in a register: loading it here put a memory round
             // trip, behind every load still in flight, in front of each refill)
@@ -1617,6 +1691,31 @@ __global__ void k_select(const uint32_t *__restrict__ lbest, const uint32_t *__r
         if (hit) {
             const uint32_t idx = atomicAdd(n_items, 1u);
             if (idx < cap) items[idx] = c * n_t64 + t64;
+        }
+    }
+}
+
+// Phase 2 on the packed path: the records (tile, chunk) in which some sample of the tile attains its global minimum become the work
+// units of k_best8<TIES>, appended to the list of one of its eight queues (tile mod 8: a queue's tiles stay on one XCD).  One wave
+// per record: lane l compares its four dwords (eight samples) of the record with the tile's minima.
+// info: [0..7] first entry of each queue's list, [8..15] entries (zeroed before), [16..23] queue heads, [32..] the walk's counters.
+__global__ void __launch_bounds__(256) k_select8(const uint32_t *__restrict__ lbest, const uint32_t *__restrict__ list, const uint32_t *__restrict__ list_n,
+                                                 const uint32_t *__restrict__ gbest, uint32_t n_chunks, uint32_t n_tiles, uint4 *__restrict__ units,
+                                                 uint32_t *__restrict__ info) {
+    const uint32_t tile = blockIdx.x, lane = threadIdx.x & 63u;
+    const uint32_t n = list_n[tile];
+    const uint32_t *l = list + (uint64_t)tile * n_chunks;
+    const uint4 gb = *(const uint4 *)(gbest + ((uint64_t)tile * 64 + lane) * 4);
+    const uint32_t x = tile & 7u, cap_q = ((n_tiles + 7u) / 8u) * n_chunks;
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < 8) info[threadIdx.x] = threadIdx.x * cap_q;
+    for (uint32_t e = blockIdx.y * 4u + (threadIdx.x >> 6); e < n; e += gridDim.y * 4u) {
+        const uint32_t c = l[e];
+        const uint4 lb = *(const uint4 *)(lbest + (((uint64_t)c * n_tiles + tile) * 64 + lane) * 4);
+        const uint32_t t = pk_min(lb.x ^ gb.x, 0x00010001u) & pk_min(lb.y ^ gb.y, 0x00010001u) & pk_min(lb.z ^ gb.z, 0x00010001u) &
+                           pk_min(lb.w ^ gb.w, 0x00010001u);   // a half is 0 where some pair of halves is equal
+        if (__builtin_amdgcn_ballot_w64(t != 0x00010001u) != 0 && lane == 0) {
+            const uint32_t idx = atomicAdd(&info[8 + x], 1u);
+            units[(uint64_t)x * cap_q + idx] = make_uint4(tile, c, c + 1u, 0u);
         }
     }
 }
@@ -2102,16 +2201,17 @@ hipError_t launch_merge(const uint32_t *part_best, const uint32_t *part_cnt, con
 
 // Resident one-wave blocks of k_best8 per CU for a given dynamic LDS size, on the current device.
 hipError_t best8_occupancy(size_t lds_bytes, int *per_cu) {
-    return hipOccupancyMaxActiveBlocksPerMultiprocessor(per_cu, k_best8<false, false, false>, 64, lds_bytes);
+    return hipOccupancyMaxActiveBlocksPerMultiprocessor(per_cu, k_best8<false, false, false, false>, 64, lds_bytes);
 }
 
 // Persistent grid of `blocks` one-wave workgroups (the caller sizes a.cold for exactly that many).
 hipError_t launch_best8(const Best8Args &a, uint32_t blocks, hipStream_t s) {
     const size_t lds = (size_t)a.lds_slots * 64 * 16;   // the D rows of the hot slots (their B halves live in registers)
-    if (a.lpos) hipLaunchKernelGGL((k_best8<false, false, true>), dim3(blocks), dim3(64), lds, s, a);   // (the coarse pass; no statistics there)
-    else if (a.stats) hipLaunchKernelGGL((k_best8<true, false, false>), dim3(blocks), dim3(64), lds, s, a);
-    else if (a.lds_bits) hipLaunchKernelGGL((k_best8<false, true, false>), dim3(blocks), dim3(64), lds + (((size_t)a.active_words * 4 + 15) & ~(size_t)15), s, a);
-    else hipLaunchKernelGGL((k_best8<false, false, false>), dim3(blocks), dim3(64), lds, s, a);
+    if (a.tie_cnt) hipLaunchKernelGGL((k_best8<false, false, false, true>), dim3(blocks), dim3(64), lds, s, a);   // (phase 2)
+    else if (a.lpos) hipLaunchKernelGGL((k_best8<false, false, true, false>), dim3(blocks), dim3(64), lds, s, a);   // (the coarse pass; no statistics there)
+    else if (a.stats) hipLaunchKernelGGL((k_best8<true, false, false, false>), dim3(blocks), dim3(64), lds, s, a);
+    else if (a.lds_bits) hipLaunchKernelGGL((k_best8<false, true, false, false>), dim3(blocks), dim3(64), lds + (((size_t)a.active_words * 4 + 15) & ~(size_t)15), s, a);
+    else hipLaunchKernelGGL((k_best8<false, false, false, false>), dim3(blocks), dim3(64), lds, s, a);
     return hipGetLastError();
 }
 
@@ -2120,6 +2220,32 @@ hipError_t launch_coarse_result(const uint32_t *lbest, const uint32_t *lpos, con
                                 const uint32_t *dfs2bfs, ugp_result *out, hipStream_t s) {
     hipLaunchKernelGGL(k_coarse_result, dim3(n_tiles512), dim3(256), 0, s, lbest, lpos, list, list_n, n_chunks, n_tiles512, n_queries, chunk_node_off,
                        chunk8_body_off, node_pos8, dfs2bfs, out);
+    return hipGetLastError();
+}
+
+// Phase 2 as a mode of the packed walk (k_best8<TIES>): b = the arguments of the phase-1 walk it follows; units: room for n_chunks entries per
+// tile, info: 128 dwords, blocks: the walk's grid (its cold-slot scratch is reused).
+hipError_t launch_phase2_packed(const Best8Args &b1, const uint32_t *list, const uint32_t *list_n, uint32_t *gbest_part, uint32_t *gbest, uint32_t n_tiles512,
+                                void *units, uint32_t *info, uint32_t *cnt, uint32_t *key, const uint32_t *node_pos8, const uint32_t *rank_dfs,
+                                const uint32_t *chunk_node_off, const uint32_t *rank2bfs, uint32_t n_queries, ugp_result *out, const uint32_t *order,
+                                uint32_t blocks, hipStream_t s) {
+    const uint32_t per_chunk = n_tiles512 * 256;
+    const uint32_t slices = std::min<uint32_t>(GBEST_SLICES, b1.n_chunks);
+    hipLaunchKernelGGL(k_gbest, dim3(n_tiles512, slices), dim3(256), 0, s, b1.lbest, list, list_n, b1.n_chunks, n_tiles512, gbest_part);
+    hipLaunchKernelGGL(k_gbest2, dim3((per_chunk + 255) / 256), dim3(256), 0, s, gbest_part, slices, per_chunk, gbest);
+    hipError_t e = hipMemsetAsync(info, 0, 128 * sizeof(uint32_t), s);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_select8, dim3(n_tiles512, n_tiles512 < 256 ? 8 : 1), dim3(256), 0, s, b1.lbest, list, list_n, gbest, b1.n_chunks, n_tiles512,
+                       (uint4 *)units, info);
+    Best8Args b = b1;
+    b.ub = gbest;
+    b.units = (const uint4 *)units; b.unit_base = info; b.unit_count = info + 8; b.queue = info + 16; b.dyn_ctl = info + 32;
+    b.dyn_units = nullptr; b.dyn_cap = 0; b.split_cycles = b.split_heavy = 0xFFFFFFFFu;   // (units of one chunk: nothing to cut, nothing to wait for)
+    b.lpos = nullptr; b.stats = nullptr; b.trace = nullptr; b.lds_bits = 0; b.heavy_prio = 0; b.ub_every = 0x7FFFFFFFu;
+    b.tie_cnt = cnt; b.tie_key = key; b.node_pos8 = node_pos8; b.rank_dfs = rank_dfs; b.chunk_node_off = chunk_node_off; b.n_queries = n_queries;
+    e = launch_best8(b, blocks, s);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_final, dim3((n_queries + 255) / 256), dim3(256), 0, s, gbest, cnt, key, rank2bfs, n_queries, out, order);
     return hipGetLastError();
 }
 

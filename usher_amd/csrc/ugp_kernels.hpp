@@ -67,6 +67,12 @@ struct Best8Args {
     uint64_t trace_cap;
     uint64_t *stats;           // optional: [0] += stream words skipped by pruning (debug / bench)
     uint32_t *ub;              // [n_tiles][64][4] packed upper bounds of best(s) shared by the waves of a tile; nullptr = no pruning
+    // phase 2 on the packed path (k_best8<..., TIES>): ub = the samples' global minima; every node whose cost equals a sample's is counted
+    uint32_t *tie_cnt, *tie_key;       // [n_queries] number of such nodes / largest (rank << 1 | has_unique) among them; null: not this mode
+    const uint32_t *node_pos8;         // [n_nodes + 1] by DFS index: stream position where the node's words begin
+    const uint32_t *rank_dfs;          // [n_nodes] by DFS index: tie rank
+    const uint32_t *chunk_node_off;    // [n_chunks + 1] first DFS index of every chunk
+    uint32_t n_queries;
 };
 
 // hstart / hlen: [n_tiles] or null: per tile, the first chunk of the region its own samples sit in and its length in chunks
@@ -86,6 +92,10 @@ constexpr uint32_t GBEST_SLICES = 64;   // chunk-axis slices of the global-minim
 hipError_t launch_coarse_result(const uint32_t *lbest, const uint32_t *lpos, const uint32_t *list, const uint32_t *list_n, uint32_t n_chunks, uint32_t n_tiles512,
                                 uint32_t n_queries, const uint32_t *chunk_node_off, const uint32_t *chunk8_body_off, const uint32_t *node_pos8,
                                 const uint32_t *dfs2bfs, ugp_result *out, hipStream_t s);
+hipError_t launch_phase2_packed(const Best8Args &b1, const uint32_t *list, const uint32_t *list_n, uint32_t *gbest_part, uint32_t *gbest, uint32_t n_tiles512,
+                                void *units, uint32_t *info, uint32_t *cnt, uint32_t *key, const uint32_t *node_pos8, const uint32_t *rank_dfs,
+                                const uint32_t *chunk_node_off, const uint32_t *rank2bfs, uint32_t n_queries, ugp_result *out, const uint32_t *order,
+                                uint32_t blocks, hipStream_t s);
 hipError_t launch_phase2(const PlaceArgs &a, const uint32_t *lbest, const uint32_t *list, const uint32_t *list_n, uint32_t *gbest_part,
                          uint32_t *gbest, uint32_t n_tiles512,
                          uint32_t *items, uint32_t *n_items, uint32_t cap, uint32_t *cnt, uint32_t *key,
