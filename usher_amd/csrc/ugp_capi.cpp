@@ -564,7 +564,7 @@ int run_place(ugp_mat *m, ugp_qset *qs, int mode, ugp_result *d_out, int32_t *d_
             // Two calls on the device (ugp_place_device, the other set's call still running when this one is queued): each walk
             // takes half of what the device keeps resident, so that both grids ARE resident instead of one waiting for the other's
             // waves to exit -- measured at 16,384 samples per call: 2.71 -> 2.29 ms per call (6.05 -> 7.2 M placements/s), best at
-            // 8 of 17 waves per CU (7: 2.32, 9: 2.39, 12: 2.51).  A call that finds the device to itself keeps the full grid.
+            // 8 of the 17 waves per CU of that time (7: 2.32, 9: 2.39, 12: 2.51); with 16 resident since the B halves moved into registers, 8 again (6: 1.85, 8: 1.75, 10: 1.86 ms).  A call that finds the device to itself keeps the full grid.
             if (m->sharing) waves_cu = std::max(1, getenv("UGP_SHARED_WAVES") ? atoi(getenv("UGP_SHARED_WAVES")) : waves_cu / 2);
             if (const char *e = getenv("UGP_WAVES_PER_CU")) waves_cu = std::max(1, std::min(std::max(m->occ_per_cu, 1), atoi(e)));   // tuning
             uint64_t blocks = (uint64_t)waves_cu * std::max(m->n_cu, 1);
