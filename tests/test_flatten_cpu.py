@@ -99,6 +99,51 @@ def test_slot_depth_is_logarithmic():
     assert FlatTreeView(arrays2).max_slots <= int(np.log2(arrays2["n"])) + 2
 
 
+def test_pruning_records_carry_the_true_depth_and_second_hit_counts():
+    """Every pruning pseudo-record of the tie stream names the node behind it (its key word) and carries hsub = the largest
+    number of mutations on a path node -> descendant and the largest number of SECOND HITS on such a path: mutations of a
+    site that is not at its reference base in the parent.  Recomputed here from the tree arrays by brute force (states
+    tracked down every root path); an undercount would make the pruning of both phases skip real ties."""
+    arrays, _ = synth.make_case(17, n_leaves=700, n_queries=0, n_sites=60, p_masked=0.03, mut_counts=(0, 0, 1, 1, 2, 3, 6))
+    n = int(arrays["n"])
+    par = np.asarray(arrays["parent"]).astype(np.int64)
+    off = np.asarray(arrays["mut_off"]).astype(np.int64)
+    pos, ref, nuc = (np.asarray(arrays[k]) for k in ("mut_pos", "mut_ref", "mut_nuc"))
+    state = [None] * n            # per node: {position: allele} of the sites off the reference on its root path
+    own = np.zeros(n, np.int64); sec = np.zeros(n, np.int64)
+    for j in range(n):            # BFS numbering: parents first
+        st = dict(state[par[j]]) if j else {}
+        for i in range(off[j], off[j + 1]):
+            if pos[i] < 0:
+                continue          # masked mutations carry no site
+            own[j] += 1
+            sec[j] += int(pos[i]) in st        # the parent's state at this site is not the reference base
+            if nuc[i] == ref[i]:
+                st.pop(int(pos[i]), None)
+            else:
+                st[int(pos[i])] = int(nuc[i])
+        state[j] = st
+    hsub = np.zeros(n, np.int64); hsec = np.zeros(n, np.int64)
+    for j in range(n - 1, 0, -1):
+        hsub[par[j]] = max(hsub[par[j]], own[j] + hsub[j])
+        hsec[par[j]] = max(hsec[par[j]], sec[j] + hsec[j])
+    flat = FlatTreeView(arrays, chunk_nodes=50)
+    st_words = flat.stream_t
+    seen = 0
+    for c in range(len(flat.chunk_t_off) - 1):
+        i, hi = int(flat.chunk_t_off[c]), int(flat.chunk_t_off[c + 1])
+        while i < hi:
+            w0 = int(st_words[i]); w1 = int(st_words[i + 1]); i += 2
+            if (w0 & 0xFFFF) == 0xFFFF:       # a pruning pseudo-record: the node's own record follows
+                node = int(flat.rank2bfs[int(st_words[i + 1]) >> 1])
+                assert (w1 >> 24) == hsub[node], (node, w1 >> 24, hsub[node])
+                assert ((w0 >> 16) & 0xFF) == min(int(hsec[node]), 255), (node, (w0 >> 16) & 0xFF, hsec[node])
+                seen += 1
+                continue
+            i += w0 & 0xFFFF
+    assert seen > 20 and hsec.max() >= 2      # (60 sites: second hits are common in this tree)
+
+
 def test_second_bound_is_withheld_on_deep_trees():
     """k_best8 keeps B (the part of D at sites where the sample holds the reference base) in one byte per sample; B never
     exceeds the mutations on a root path, so a tree with more than 255 of them gets pruning records that say "second hits:
