@@ -144,6 +144,75 @@ def test_pruning_records_carry_the_true_depth_and_second_hit_counts():
     assert seen > 20 and hsec.max() >= 2      # (60 sites: second hits are common in this tree)
 
 
+@pytest.mark.parametrize("seed", [3, 4, 5])
+def test_both_lower_bounds_hold_for_every_node_and_sample(seed):
+    """The two bounds the pruning rests on, checked as stated, by brute force: for every node n, every strict
+    descendant d and every sample s,   cost(d, s) >= D(n, s) - hsub(n)   and   cost(d, s) >= B(n, s) - hsec(n),
+    with B = the mismatching sites at which the sample's set holds the reference base.  Samples with N and IUPAC cells, trees
+    with masked mutations, few sites (second hits and reversions are common)."""
+    arrays, queries = synth.make_case(seed, n_leaves=350, n_queries=30, n_sites=40, p_masked=0.03, mut_counts=(0, 0, 1, 1, 2, 3, 5),
+                                      n_ambig=(0, 2, 5, 12))
+    n = int(arrays["n"])
+    par = np.asarray(arrays["parent"]).astype(np.int64)
+    off = np.asarray(arrays["mut_off"]).astype(np.int64)
+    pos, ref, nuc = (np.asarray(arrays[k]).astype(np.int64) for k in ("mut_pos", "mut_ref", "mut_nuc"))
+    state = [None] * n
+    prev = np.zeros(len(pos), np.int64)
+    own = np.zeros(n, np.int64); sec = np.zeros(n, np.int64)
+    for j in range(n):
+        st = dict(state[par[j]]) if j else {}
+        for i in range(off[j], off[j + 1]):
+            if pos[i] < 0:
+                continue
+            p = int(pos[i])
+            prev[i] = st.get(p, int(ref[i]))
+            own[j] += 1
+            sec[j] += p in st
+            if nuc[i] == ref[i]:
+                st.pop(p, None)
+            else:
+                st[p] = int(nuc[i])
+        state[j] = st
+    hsub = np.zeros(n, np.int64); hsec = np.zeros(n, np.int64)
+    for j in range(n - 1, 0, -1):
+        hsub[par[j]] = max(hsub[par[j]], own[j] + hsub[j])
+        hsec[par[j]] = max(hsec[par[j]], sec[j] + hsec[j])
+    checked = tight = 0
+    for s in queries:
+        S = {}
+        d_bot = 0
+        for p, r, a, mis in zip(s["pos"], s["ref"], s["nuc"], s["is_missing"]):
+            S[int(p)] = 0xF if mis else int(a)
+            d_bot += (not mis) and (int(a) & int(r)) == 0
+        D = np.zeros(n, np.int64); B = np.zeros(n, np.int64); cost = np.zeros(n, np.int64)
+        for j in range(n):
+            dp, bp = (D[par[j]], B[par[j]]) if j else (d_bot, 0)
+            dsum = bsum = neg = 0
+            masked = False
+            for i in range(off[j], off[j + 1]):
+                if pos[i] < 0:
+                    masked = True
+                    continue
+                sp = S.get(int(pos[i]), int(ref[i]))
+                delta = (1 if sp & prev[i] else 0) - (1 if sp & nuc[i] else 0)
+                dsum += delta
+                bsum += delta if sp & ref[i] else 0
+                if not masked:
+                    neg += min(delta, 0)
+            D[j], B[j] = dp + dsum, bp + bsum
+            cost[j] = D[j] if j == 0 else dp + neg
+            assert 0 <= B[j] <= D[j]
+        below = np.full(n, 1 << 30, np.int64)     # smallest cost among the strict descendants
+        for j in range(n - 1, 0, -1):
+            below[par[j]] = min(below[par[j]], cost[j], below[j])
+        inner = below < (1 << 30)
+        assert (below[inner] >= D[inner] - hsub[inner]).all()
+        assert (below[inner] >= B[inner] - hsec[inner]).all()
+        checked += int(inner.sum())
+        tight += int((below[inner] == np.maximum(D[inner] - hsub[inner], B[inner] - hsec[inner])).sum())
+    assert checked > 5000 and tight > 0      # (the bounds are attained somewhere: they are not vacuous)
+
+
 def test_second_bound_is_withheld_on_deep_trees():
     """k_best8 keeps B (the part of D at sites where the sample holds the reference base) in one byte per sample; B never
     exceeds the mutations on a root path, so a tree with more than 255 of them gets pruning records that say "second hits:
