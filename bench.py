@@ -39,8 +39,8 @@ HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--nodes", type=int, default=10_000_000)
     ap.add_argument("--sites", type=int, default=0, help="variable sites (default 25000 at >=1M nodes, else 1500)")
     ap.add_argument("--queries", type=int, default=16384, help="query samples per GPU per step (total samples with --strong)")
