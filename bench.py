@@ -53,6 +53,9 @@ def parse_args():
     ap.add_argument("--cpu-queries", type=int, default=-1, help="queries timed on the CPU oracle (0 = skip; default: sized for ~10-30 s)")
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--sort-by-source", action="store_true", help="experiment: hand the queries over already ordered by their generator source node")
+    ap.add_argument("--no-overlap", action="store_true", help="time the stream-ordered ugp_place_device (one call at a time) instead of ugp_place_device_overlapped")
+    ap.add_argument("--no-extra", action="store_true", help="skip the extra keys (BASELINE configs 3 and 4 on one device, the end-to-end CLI run)")
+    ap.add_argument("--repeats", type=int, default=3, help="windows of --steps steps timed in all (the first is `value`; min / median over all are extra keys)")
     return ap.parse_args()
 
 
@@ -159,7 +162,7 @@ def main():
     st = shared_tree(args, n_sites, world, local_rank)
     t_gen = time.time() - t0
     t0 = time.time()
-    pl = Placer(st.arrays, device=dev_index)
+    pl = Placer(st.arrays, device=dev_index, experiments=bool(os.environ.get("UGP_STATS")))   # (UGP_STATS: the instrumented build, libusher_amd_exp.so)
     t_flat = time.time() - t0
     info = pl.info()
     kw = dict(n_lo=100, n_hi=5000, iupac_hi=30) if args.ambiguous else {}
@@ -192,14 +195,26 @@ def main():
     batch = QueryBatch.from_csr(q["ent_off"], q["pos"], q["ref"], q["nuc"], q["is_missing"])
     qset = pl.upload(batch)
     Q = len(batch)
-    out = torch.zeros((cap, 4), dtype=torch.int32, device=dev)        # (shards differ by at most one sample: padded to `cap`)
+    # Two output buffers used alternately: consecutive ugp_place_device_overlapped calls share the device, and call k + 2 is
+    # ordered behind whatever the caller's stream held when call k + 1 was made -- the all-gather that reads call k's buffer
+    # included (include/usher_amd.h: one call of lag).  (shards differ by at most one sample: padded to `cap`)
+    outs = [torch.zeros((cap, 4), dtype=torch.int32, device=dev) for _ in range(2)]
     gathered = torch.zeros((world * cap, 4), dtype=torch.int32, device="cpu" if share else dev) if world > 1 else None
     stream = torch.cuda.current_stream().cuda_stream
+    n_step = [0]
+    gather_s = [0.0]
 
     def step():
-        pl.place_device(qset, out.data_ptr(), stream)
+        out = outs[n_step[0] & 1]
+        n_step[0] += 1
+        if args.no_overlap:
+            pl.place_device(qset, out.data_ptr(), stream)
+        else:
+            pl.place_device_overlapped(qset, out.data_ptr(), stream)
         if world > 1:
+            tg = time.perf_counter()
             dist.all_gather_into_tensor(gathered, out.cpu() if share else out)
+            gather_s[0] += time.perf_counter() - tg   # (host time spent issuing the collective; it runs behind the call's completion)
 
     for _ in range(args.warmup):
         step()
@@ -216,9 +231,10 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    last_out = outs[(n_step[0] - 1) & 1]
     # HIP events recorded by the library on the streams its kernels ran on, summed over the timed steps
     tm = pl.timing_sum()
-    assert tm["calls"] >= args.steps, tm   # (+1 without warm-up: the handle's first call also runs on its second workspace set)
+    assert tm["calls"] == args.steps, tm
     scale = args.steps / max(1, tm["calls"])
     place_ms, table_ms, merge_ms, coarse_ms = tm["place_ms"] * scale, tm["table_ms"] * scale, tm["merge_ms"] * scale, tm["coarse_ms"] * scale
     tiles, groups, packed = tm["n_tiles"], tm["n_groups"], tm["packed_path"]
@@ -228,7 +244,28 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
-    res = out.cpu().numpy()[:Q]
+    res = last_out.cpu().numpy()[:Q]
+    # the same window again (--repeats - 1 times): spread of the figure; `value` stays the first window
+    windows = [elapsed]
+    for _ in range(max(0, args.repeats - 1)):
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        tw = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        tw = time.perf_counter() - tw
+        if world > 1:
+            tt = torch.tensor([tw], dtype=torch.float64, device="cpu" if share else dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            tw = float(tt.item())
+        windows.append(tw)
+    pl.timing_sum()
+    out = outs[0]
     # The same kernels one call at a time (a synchronisation after every step), outside the timed region: in the timed region
     # two consecutive calls share the device (ugp_place_device overlaps them), so a kernel's event-bracketed duration there is
     # the duration of a kernel that has company.  Reported beside it as kernel_ms_alone / frac_alone.
@@ -281,13 +318,54 @@ def main():
             ares = pl.job_wait(prev)
             prev = cur
         ares = pl.job_wait(prev)
-        dta = (time.perf_counter() - t1) / n_async
+        dta = time.perf_counter() - t1
+    if world > 1:   # (every rank, also one with an empty shard: max over ranks, as for the other figures)
+        tt = torch.tensor([dta or 0.0], dtype=torch.float64, device="cpu" if share else dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dta = float(tt.item()) or None
+    if dta:
+        dta /= n_async
     if Q:
         same = bool((np.stack([hres[k] for k in ("best_set_difference", "num_best", "best_j", "best_has_unique")], 1).astype(np.int64) == res.astype(np.int64)).all())
         host_path = {"metric": "SURVEY 8(d): Q / wall time of ugp_place_batch (query upload + kernels + result download)",
                      "placements_per_s": round(total_q / dt, 2), "ms_per_batch": round(dt * 1e3, 3), "identical_to_device_path": same,
-                     "two_in_flight": {"entry": "ugp_place_batch_async / ugp_job_wait", "placements_per_s": round(Q / dta, 2), "ms_per_batch": round(dta * 1e3, 3),
-                                       "identical_to_device_path": bool((np.stack([ares[k] for k in ("best_set_difference", "num_best", "best_j", "best_has_unique")], 1).astype(np.int64) == res.astype(np.int64)).all())} if dta else None}
+                     "two_in_flight": {"entry": "ugp_place_batch_async / ugp_job_wait", "placements_per_s": round(total_q / dta, 2), "ms_per_batch": round(dta * 1e3, 3),
+                                       "identical_to_device_path": bool((np.stack([ares[k] for k in ("best_set_difference", "num_best", "best_j", "best_has_unique")], 1).astype(np.int64) == res.astype(np.int64)).all())} if (dta and ares is not None) else None}
+    # ---- extra keys: BASELINE configs 3 and 4 on this one device, the end-to-end CLI (default headline run only)
+    extra = None
+    headline = (args.nodes == 10_000_000 and args.queries == 16384 and args.shape == "random" and not args.ambiguous and not args.strong and not args.sort_by_source)
+    if world == 1 and headline and not args.no_extra:
+        extra = {}
+
+        def timed_config(placer, tree, nq, steps, warm, **qkw):
+            qq = tree.queries(nq, seed=args.seed * 1000 + 4, **qkw)
+            bb = QueryBatch.from_csr(qq["ent_off"], qq["pos"], qq["ref"], qq["nuc"], qq["is_missing"])
+            hq = placer.upload(bb)
+            oo = [torch.zeros((nq, 4), dtype=torch.int32, device=dev) for _ in range(2)]
+            for k in range(warm):
+                placer.place_device_overlapped(hq, oo[k & 1].data_ptr(), stream)
+            torch.cuda.synchronize()
+            placer.timing_sum()
+            tq = time.perf_counter()
+            for k in range(steps):
+                placer.place_device_overlapped(hq, oo[k & 1].data_ptr(), stream)
+            torch.cuda.synchronize()
+            tq = time.perf_counter() - tq
+            tmq = placer.timing_sum()
+            strict = torch.zeros((nq, 4), dtype=torch.int32, device=dev)
+            placer.place_device(hq, strict.data_ptr(), stream)   # the stream-ordered entry point, one call alone
+            torch.cuda.synchronize()
+            same = bool((strict == oo[(steps - 1) & 1]).all().item())
+            placer.free_qset(hq)
+            return {"queries": nq, "steps": steps, "placements_per_s": round(nq * steps / tq, 2), "ms_per_step": round(tq * 1e3 / steps, 3),
+                    "k_best8_ms": round(tmq["place_ms"] / max(1, tmq["calls"]), 4), "sub_batches": int(tmq["place_launches"] // max(1, tmq["calls"])),
+                    "identical_to_stream_ordered_call": same}
+
+        # config 4's workload on one device: 1,000,000 queries on the 10M-node tree in one call (4 sub-batches of 262,144)
+        c4 = timed_config(pl, st, 1_000_000, 3, 1)
+        c4["workload"] = "BASELINE config 4 on one device: 1,000,000 queries on the %d-node MAT, one ugp_place_device_overlapped call per step" % info["n_nodes"]
+        extra["config4_1m_queries_one_gpu"] = c4
+
     result = None
     if rank == 0:
         ms_per_step = elapsed * 1e3 / args.steps
@@ -301,13 +379,32 @@ def main():
         node_evals = float(Q) * (info["n_nodes"] + info["n_muts"])
         prof_name, prof = stored_profile(info, Q, packed)
         traffic = int(prof["hbm_read_bytes_per_dispatch_corrected"] + prof.get("hbm_write_bytes_per_dispatch", 0)) if prof else None
-        roofline = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        # What the counters of the stored profile say bounds the kernel: instruction issue when a pipe is busy most of the time, HBM
+        # when the measured traffic is most of the peak, else the waves are waiting -- exposed memory latency.  The issue floor is
+        # the time the kernel's own instructions need on the busier of the two pipes (VALU: 2 cycles per wave64 instruction per
+        # SIMD; scalar unit: one instruction per cycle per CU), from the profile's instruction counts and ITS duration.
+        prof_ms = prof["avg_duration_ns_full_dispatch"] * 1e-6 if prof.get("avg_duration_ns_full_dispatch") else None
+        issue_floor_ms = round(max(prof.get("valu_issue_frac") or 0.0, prof.get("salu_issue_frac") or 0.0) * prof_ms, 4) if prof_ms else None
+        prof_hbm_frac = round(traffic / (prof_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if traffic and prof_ms else None
+        if not prof:
+            bound = "hbm"   # (no stored counters for this workload: SURVEY 8d's declared roofline)
+        elif max(prof.get("valu_active_frac_measured") or 0.0, prof.get("salu_busy_frac_measured") or 0.0) > 0.6:
+            bound = "issue"
+        elif (prof_hbm_frac or 0.0) > 0.5:
+            bound = "hbm"
+        else:
+            bound = "latency"
+        roofline = {"bound": bound, "bound_declared": "hbm (SURVEY 8d)", "bound_is": "what the stored profile's counters say limits the kernel: a pipe busy > 60 % = issue, measured traffic > 50 % of peak = hbm, else latency (waves waiting)",
+                    "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                     # `achieved` is NOMINAL: bytes a full tree pass per tile is entitled to read / kernel time; exact pruning skips
                     # most of the pass, so the bytes actually moved are `traffic` (from the stored PMC profile, not this run)
                     "achieved_is": "nominal (SURVEY 8d algorithmic bytes / measured kernel time)",
                     "traffic_source": prof_name,
-                    "measured_hbm_frac": round(traffic / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if traffic and k_ms > 0 else None,
+                    # measured traffic / the PROFILE's own kernel duration / peak (both from the same rocprofv3 passes)
+                    "measured_hbm_frac": prof_hbm_frac, "profile_kernel_ms": round(prof_ms, 4) if prof_ms else None,
+                    "issue_floor_ms": issue_floor_ms,
+                    "frac_of_issue_floor": round(issue_floor_ms / alone["place_ms"], 4) if issue_floor_ms and alone["place_ms"] > 0 else None,
                     # the kernel is bound by instruction issue, not HBM: fractions of the chip's VALU / scalar issue slots
                     # over the kernel's duration, from the same stored profile
                     "valu_issue_frac": prof.get("valu_issue_frac"), "salu_issue_frac": prof.get("salu_issue_frac"),
@@ -318,7 +415,7 @@ def main():
                     "kernel_ms_alone": round(alone["place_ms"], 4),
                     "frac_alone": round(algo_bytes / (alone["place_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if alone["place_ms"] > 0 else None,
                     "ms_per_step_alone": round(t_alone * 1e3, 3),
-                    "overlap": "consecutive ugp_place_device calls run on two internal streams (UGP_NO_OVERLAP=1: off)" if not os.environ.get("UGP_NO_OVERLAP") else "off",
+                    "overlap": "off (--no-overlap: ugp_place_device, stream-ordered)" if args.no_overlap else "consecutive ugp_place_device_overlapped calls run on two internal streams, two output buffers",
                     "node_plus_mut_evals_decided_per_s": round(node_evals / (k_ms * 1e-3), 1) if k_ms > 0 else 0.0,
                     "coarse_ms": round(coarse_ms / args.steps, 4), "table_ms": round(table_ms / args.steps, 4), "merge_ms": round(merge_ms / args.steps, 4),
                     # the two pruning counters exist only in the instrumented kernel variant (UGP_STATS=1)
@@ -348,6 +445,11 @@ def main():
                    "sample": "first %d queries of rank 0's batch on the same MAT, oracle/ugp_oracle.c orc_place_sample_pool (pass 1 of "
                              "usher_common.cpp:389-414, one sample at a time, persistent pool of %d threads pulling 2,048-node ranges)" % (n_cpu, cores),
                    "value_1thread": round(1.0 / dt1, 4), "sample_1thread": "1 query, 1 thread",
+                   # BASELINE.md / SURVEY 6: the true reference measured 12.8 placements/s/thread on a 44,483-node tree; its cost per
+                   # sample is O(N x depth), so at N nodes one thread of it would do at most 12.8 x 44,483 / N (depth grows too:
+                   # an upper estimate).  calibration = this port's one-thread rate / that figure.
+                   "calibration": {"reference_1thread_scaled": round(12.8 * 44483.0 / info["n_nodes"], 5), "port_over_reference": round((1.0 / dt1) / (12.8 * 44483.0 / info["n_nodes"]), 3),
+                                   "basis": "BASELINE.md: 12.8 placements/s/thread at 44,483 nodes, scaled by 44,483 / N"},
                    "mismatches_vs_gpu": bad}
         result = {
             "metric": "sample placements/sec on 10M-node MAT; bit-exact parsimony score vs reference",
@@ -362,6 +464,15 @@ def main():
                        "parallelism": "queries sharded x%d, MAT replicated, RCCL all-gather of results" % world,
                        "rccl_ranks": world, "devices_visible": torch.cuda.device_count(),
                        "seed": args.seed, "gen_s": round(t_gen, 2), "flatten_upload_s": round(t_flat, 2)},
+            # the K-step window again, --repeats times in all: spread of `value` (which is the first window)
+            "windows": {"n": len(windows), "ms_per_step": [round(w * 1e3 / args.steps, 3) for w in windows],
+                        "value_min": round(total_q * args.steps / max(windows), 2), "value_median": round(total_q * args.steps / sorted(windows)[len(windows) // 2], 2),
+                        "value_max": round(total_q * args.steps / min(windows), 2)},
+            # SURVEY 8(d) defines the metric with query upload and result download inside the clock: this is that figure (two
+            # batches in flight from and to host buffers), next to `value` (rows resident in HBM, as the bench contract asks)
+            "value_pcie_inclusive": (host_path or {}).get("two_in_flight", {}).get("placements_per_s") if host_path and host_path.get("two_in_flight") else None,
+            "per_rank": {"flatten_upload_s": round(t_flat, 2), "gather_issue_ms_per_step": round(gather_s[0] * 1e3 / max(1, n_step[0]), 4) if world > 1 else None},
+            "other_configs": extra,
             "roofline": roofline, "cpu_baseline": cpu,
             # `value` has the query rows resident in HBM when the timed region starts (bench contract); the same batch through
             # the host-buffer entry point -- SURVEY 8(d)'s definition of the metric -- is this:
@@ -369,6 +480,22 @@ def main():
         }
     pl.free_qset(qset)
     pl.close()
+    if extra is not None:
+        # config 3's size: a 15M-node SARS-CoV-2-shaped tree (the public MAT is not in the image), 10,000 queries
+        t0 = time.time()
+        st3 = synth.SynthTree(15_000_000, genome_len=args.genome, n_sites=25000, seed=args.seed, shape="sars2")
+        t_gen3 = time.time() - t0
+        t0 = time.time()
+        pl3 = Placer(st3.arrays, device=dev_index)
+        t_flat3 = time.time() - t0
+        free_b, total_b = torch.cuda.mem_get_info(dev)
+        c3 = timed_config(pl3, st3, 10_000, 10, 3, recent=True)
+        i3 = pl3.info()
+        c3.update({"workload": "BASELINE config 3's size: synthetic sars2-shaped MAT %d nodes / %d mutations, 10,000 queries per step" % (i3["n_nodes"], i3["n_muts"]),
+                   "gen_s": round(t_gen3, 2), "flatten_upload_s": round(t_flat3, 2), "device_bytes_in_use": int(total_b - free_b)})
+        extra["config3_15m_nodes_10k_queries"] = c3
+        pl3.close()
+        del st3
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -186,7 +186,9 @@ int ugp_subtree_mask(ugp_mat *mat, uint32_t order, uint32_t root_j, uint32_t max
 
 /* Device-resident variant (no PCIe in the timed path): upload once, place many
  * times.  `stream` is a hipStream_t (NULL = the default stream); d_out is a
- * device pointer to n_queries ugp_result records.  Asynchronous on `stream`. */
+ * device pointer to n_queries ugp_result records.  ugp_place_device is asynchronous
+ * and STREAM-ORDERED on `stream`, like a kernel launch: it runs behind everything
+ * queued on `stream` before it and in front of everything queued after it. */
 int ugp_qset_upload(ugp_mat *mat, const ugp_queries *q, ugp_qset **out);
 /* (A query set belongs to the handle it was uploaded for.  Sets with many rows per sample -- from 128 on average: the runs of N
  * of low-coverage samples -- also get one bit per (sample, tree site) on the device, about 3 KB per sample at 25,000 sites for
@@ -194,11 +196,17 @@ int ugp_qset_upload(ugp_mat *mat, const ugp_queries *q, ugp_qset **out);
 void ugp_qset_destroy(ugp_qset *qs);
 uint64_t ugp_qset_size(const ugp_qset *qs);
 int ugp_place_device(ugp_mat *mat, ugp_qset *qs, void *d_out, void *stream);
-/* Consecutive ugp_place_device calls on one handle overlap on the device (two internal streams, two sets of workspaces:
- * the small kernels around the tree walk of one batch run in the gaps of the other's); `stream` receives each call's
- * completion, in call order.  A call waits for earlier calls on the handle where it must, NOT for other work queued on
- * `stream` before it: do not hand it an output buffer that earlier stream work still reads.  UGP_NO_OVERLAP=1 in the
- * environment runs every call on `stream` itself. */
+/* Opt-in: consecutive ugp_place_device_overlapped calls on one handle overlap on the device (two internal streams, two
+ * sets of workspaces: the small latency-bound kernels around the tree walk of one batch run in the gaps of the other's;
+ * +50 % placements/s at 16,384 samples per call).  The price is a weaker ordering than a kernel launch has:
+ *   - `stream` receives every call's completion, in call order: work queued on `stream` after call k sees its results;
+ *   - call k runs behind the work that was on `stream` when call k-1 (the previous overlapped call on this handle) was
+ *     made -- ONE CALL OF LAG; work queued between the two calls sits behind call k-1's completion, and waiting for it
+ *     would serialise them.  (When no overlapped call is running any more, call k waits for everything on `stream`.)
+ * Hence: alternate between TWO output buffers.  Whatever is queued on `stream` to read buffer A between call k (which
+ * wrote A) and call k+1 is finished before call k+2 overwrites A.  Do not prepare d_out or the query set on `stream`
+ * right before the call and expect the call to wait for it -- use ugp_place_device for that. */
+int ugp_place_device_overlapped(ugp_mat *mat, ugp_qset *qs, void *d_out, void *stream);
 
 /* ugp_place_batch with two batches in flight: host buffers in, host buffers out, asynchronous.  The rows are copied out of
  * `q` before the call returns (pinned staging), `out` is written by ugp_job_wait.  At most two jobs per handle may be
@@ -247,6 +255,13 @@ int ugp_fitch_get(const ugp_fitch *f, uint32_t *site, uint32_t *node, uint8_t *p
 void ugp_fitch_destroy(ugp_fitch *f);
 
 /* ---- test / tuning hooks (not part of the drop-in surface) ---------------- */
+
+/* The tuning switches (UGP_* environment variables) are read ONCE, when a handle is created; no placement
+ * call reads the environment.  A tool that sweeps switches on one handle re-reads them with this. */
+int ugp_mat_reload_knobs(ugp_mat *mat);
+/* 1: built with -DUGP_EXPERIMENTS (libusher_amd_exp.so: statistics build of the walk, UGP_STATS / UGP_TRACE /
+ * UGP_SEED_PREV / UGP_SEED_CHECK / UGP_PHASE2_PACKED / UGP_KBEST_EXCLUSIVE); 0: the release library ignores those. */
+int ugp_has_experiments(void);
 
 /* ugp_mat_create with an explicit chunk size (nodes per DFS chunk), so small
  * fixtures exercise multi-chunk launches. */

@@ -254,8 +254,10 @@ def test_full_size_properties_1m_nodes(monkeypatch):
     z = pl.place(batch0)
     assert (z["best_set_difference"] == 0).all() and (z["num_best"] >= 1).all()     # self-placement costs nothing
     monkeypatch.setenv("UGP_FORCE_V1", "1")
+    pl.reload_knobs()                                                               # (the switches are read when the handle is made)
     slow = pl.place(batch)                                                          # 32-bit, one sample per lane, no pruning
     monkeypatch.delenv("UGP_FORCE_V1")
+    pl.reload_knobs()
     assert (slow.view(np.int32) == fast.view(np.int32)).all()
     # the work-unit machinery at its extremes: units that are never cut, units cut at every opportunity (thousands of
     # entries through the shared list, every wave waiting and exiting through it), one unit per side of a tile's ring
@@ -263,9 +265,11 @@ def test_full_size_properties_1m_nodes(monkeypatch):
                 {"UGP_UNIT_GROW": "0", "UGP_SPLIT_CYCLES": "5000"}):
         for k, v in env.items():
             monkeypatch.setenv(k, v)
+        pl.reload_knobs()
         other = pl.place(batch)
         for k in env:
             monkeypatch.delenv(k)
+        pl.reload_knobs()
         assert (other.view(np.int32) == fast.view(np.int32)).all(), env
     ot = capi.OracleTree(st.arrays)
     for i in range(0, 3000, 500):
@@ -275,10 +279,10 @@ def test_full_size_properties_1m_nodes(monkeypatch):
 
 
 def test_consecutive_device_calls_share_the_device_and_stay_exact(monkeypatch):
-    """ugp_place_device overlaps consecutive calls on one handle (two internal streams, two sets of workspaces).  A sequence
-    of calls on different query sets and output buffers, with no synchronisation in between and a host-buffer call
+    """ugp_place_device_overlapped overlaps consecutive calls on one handle (two internal streams, two sets of workspaces).  A
+    sequence of calls on different query sets and output buffers, with no synchronisation in between and a host-buffer call
     (workspace set 0 on the default stream) thrown in, must give each batch its own exact answers; the summed timing
-    reports every call; UGP_NO_OVERLAP gives the same results on the caller's stream."""
+    reports every call; the stream-ordered ugp_place_device gives the same results on the caller's stream."""
     import torch
     from usher_amd import synth as gsynth
     st = gsynth.SynthTree(400_000, n_sites=5000, seed=21)
@@ -293,19 +297,19 @@ def test_consecutive_device_calls_share_the_device_and_stay_exact(monkeypatch):
     handles = [pl.upload(b) for b in batches]
     stream = torch.cuda.current_stream().cuda_stream
     first = torch.zeros((len(batches[1]), 4), dtype=torch.int32, device="cuda")
-    pl.place_device(handles[1], first.data_ptr(), stream)        # (the handle's first such call also sets up its second workspace set)
+    pl.place_device_overlapped(handles[1], first.data_ptr(), stream)
     torch.cuda.synchronize()
     assert (first.cpu().numpy() == want[1]).all()
     pl.timing_sum()
     outs = []
-    # (the output buffers are made up front: a call does not wait for work queued on the caller's stream before it -- include/usher_amd.h --
-    # and a fill queued there sits behind the completion events of the calls before it)
+    # (the output buffers are made up front: an overlapped call waits for what was on the caller's stream when the call BEFORE it
+    # was made -- include/usher_amd.h -- a fill queued right in front of a call sits behind the completion of the call before it)
     bufs = [[torch.full((len(batches[i]), 4), -7, dtype=torch.int32, device="cuda") for i in (0, 1, 2, 1, 0)] for _ in range(4)]
     torch.cuda.synchronize()
     for rnd in range(4):
         for k, i in enumerate((0, 1, 2, 1, 0)):
             o = bufs[rnd][k]
-            pl.place_device(handles[i], o.data_ptr(), stream)
+            pl.place_device_overlapped(handles[i], o.data_ptr(), stream)
             outs.append((i, o))
         if rnd == 1:
             mid = pl.place(batches[2]).view(np.int32).reshape(-1, 4)     # host buffers, synchronous, in the middle of the pipeline
@@ -314,9 +318,20 @@ def test_consecutive_device_calls_share_the_device_and_stay_exact(monkeypatch):
     assert pl.timing_sum()["calls"] == 21
     for i, o in outs:
         assert (o.cpu().numpy() == want[i]).all(), i
-    monkeypatch.setenv("UGP_NO_OVERLAP", "1")     # (read once per process: this only checks that the switch is harmless here)
+    # two output buffers used alternately, each result consumed on the caller's stream before the next call is made: the consumer
+    # of call k's buffer is finished before call k + 2 overwrites it (one call of lag), whatever the calls' own overlap
+    two = [torch.zeros((max(len(b) for b in batches), 4), dtype=torch.int32, device="cuda") for _ in range(2)]
+    sums = []
+    for k in range(40):
+        i = (0, 1, 2)[k % 3]
+        o = two[k & 1]
+        pl.place_device_overlapped(handles[i], o.data_ptr(), stream)
+        sums.append((i, o[:len(batches[i])].to(torch.int64).sum(0)))     # (queued on the caller's stream behind the call's completion)
+    torch.cuda.synchronize()
+    for i, sm in sums:
+        assert (sm.cpu().numpy() == want[i].astype(np.int64).sum(0)).all(), i
     o = torch.zeros((len(batches[0]), 4), dtype=torch.int32, device="cuda")
-    pl.place_device(handles[0], o.data_ptr(), stream)
+    pl.place_device(handles[0], o.data_ptr(), stream)          # stream-ordered form
     torch.cuda.synchronize()
     assert (o.cpu().numpy() == want[0]).all()
     for h in handles:
@@ -545,7 +560,7 @@ def test_randomised_trees_and_scheduling_knobs(seed, monkeypatch):
         monkeypatch.delenv(k, raising=False)
     for k, v in knobs.items():
         monkeypatch.setenv(k, v)
-    pl = Placer(arrays, chunk_nodes=int(rng.integers(3, 80)))
+    pl = Placer(arrays, chunk_nodes=int(rng.integers(3, 80)), experiments="UGP_PHASE2_PACKED" in knobs)   # (the experiment exists in libusher_amd_exp.so only)
     res = pl.place(QueryBatch(queries))
     for i, w in enumerate(want):
         _assert_same(res, i, w, "%s #%d" % (knobs, i))
@@ -630,6 +645,7 @@ def test_config3_10m_nodes_10k_queries(monkeypatch):
     shuffled = pl.place(QueryBatch([gsynth.csr_sample(q, int(i)) for i in perm]))
     assert (_rows(shuffled) == _rows(fast)[perm]).all()
     monkeypatch.setenv("UGP_FORCE_V1", "1")
+    pl.reload_knobs()
     slow = pl.place(batch)
     assert pl.timing()["packed_path"] == 0
     monkeypatch.delenv("UGP_FORCE_V1")
@@ -697,6 +713,7 @@ def test_sars2_shape_10m_nodes_full_size(monkeypatch):
     shuffled = pl.place(QueryBatch([gsynth.csr_sample(q, int(i)) for i in perm]))
     assert (_rows(shuffled) == _rows(fast)[perm]).all()
     monkeypatch.setenv("UGP_FORCE_V1", "1")
+    pl.reload_knobs()
     slow = pl.place(batch)
     assert pl.timing()["packed_path"] == 0
     monkeypatch.delenv("UGP_FORCE_V1")
@@ -767,3 +784,215 @@ def test_usher_cli_multiple_placements_on_gpu(tmp_path):
     for name in want:
         assert got[name] == want[name], name
     assert "final-tree-4.nh" in got
+
+
+# ---------------------------------------------------------------------------
+# Round 4: BASELINE config 4's workload and config 3's size on one device; the boundary's ordering and threading rules
+# ---------------------------------------------------------------------------
+
+def test_config4_workload_one_million_queries_on_one_device(monkeypatch):
+    """BASELINE config 4's workload (1,000,000 queries against the 10M-node MAT, the loop usher_common.cpp:310 shards) on ONE
+    device, in one call: four sub-batches of 262,144 samples.  Size-independent properties: a permuted copy of the batch gives
+    every sample the same answer (a sample's result depends neither on its tile, its sub-batch nor its neighbours); a 16,384
+    slice placed on its own and through the plain 32-bit kernel agrees with its rows of the big call; 4,096 samples against the
+    C closed form; 32 against the literal oracle."""
+    from usher_amd import synth as gsynth
+    for k in ("UGP_FORCE_V1", "UGP_NO_SORT", "UGP_NO_PRUNE", "UGP_COARSE_MIN_NODES"):
+        monkeypatch.delenv(k, raising=False)
+    st = gsynth.SynthTree(10_000_000, n_sites=25000, seed=1)
+    Q = 1_000_000
+    q = st.queries(Q, seed=31337)
+    batch = _csr_batch(q)
+    pl = Placer(st.arrays)
+    big = pl.place(batch)
+    tm = pl.timing()
+    assert tm["packed_path"] == 1 and tm["place_launches"] == 4          # 262,144 samples per launch sequence
+    # the same samples in another order (each lands in another tile and, mostly, another sub-batch)
+    perm = np.random.default_rng(11).permutation(Q)
+    lens = np.diff(q["ent_off"].astype(np.int64))
+    starts = q["ent_off"].astype(np.int64)[:-1]
+    new_off = np.zeros(Q + 1, np.uint64); new_off[1:] = np.cumsum(lens[perm])
+    idx = np.repeat(starts[perm] - new_off[:-1].astype(np.int64), lens[perm]) + np.arange(int(new_off[-1]))
+    shuffled = pl.place(QueryBatch.from_csr(new_off, q["pos"][idx], q["ref"][idx], q["nuc"][idx], q["is_missing"][idx]))
+    assert (_rows(shuffled) == _rows(big)[perm]).all()
+    # a slice on its own, packed and 32-bit
+    lo, hi = 500_000, 516_384
+    part = batch.slice(lo, hi)
+    alone = pl.place(part)
+    assert (_rows(alone) == _rows(big)[lo:hi]).all()
+    monkeypatch.setenv("UGP_FORCE_V1", "1")
+    pl.reload_knobs()
+    slow = pl.place(part)
+    assert pl.timing()["packed_path"] == 0
+    monkeypatch.delenv("UGP_FORCE_V1")
+    assert (_rows(slow) == _rows(big)[lo:hi]).all()
+    pl.close()
+    ot = capi.OracleTree(st.arrays)
+    n_cf, base = 4096, 300_000                                          # (a slice that straddles the second sub-batch boundary region)
+    e0, e1 = int(q["ent_off"][base]), int(q["ent_off"][base + n_cf])
+    cf = capi.ClosedFormC(ot).place_csr(q["ent_off"][base:base + n_cf + 1] - q["ent_off"][base], q["pos"][e0:e1], q["ref"][e0:e1], q["nuc"][e0:e1],
+                                        q["is_missing"][e0:e1])
+    assert (_rows(big)[base:base + n_cf] == _cf_rows(cf)).all()
+    threads = os.cpu_count() or 1
+    for i in list(range(262_140, 262_156)) + list(range(999_984, 1_000_000)):   # around a sub-batch boundary and at the very end
+        w = ot.place_mt(gsynth.csr_sample(q, i), threads)
+        assert (w["best"], w["num_best"], w["best_j"]) == (int(big["best_set_difference"][i]), int(big["num_best"][i]), int(big["best_j"][i])), i
+
+
+def test_config3_size_15m_node_sars2_tree(monkeypatch):
+    """BASELINE config 3's size: a 15M-node SARS-CoV-2-shaped MAT (the public .pb.gz is not in the image) x 10,000 queries next
+    to recent leaves.  Packed path == 32-bit kernel == permuted batch for every sample, 2,048 samples against the closed form,
+    16 against the literal oracle; the device footprint of the handle stays far below one GPU's 288 GB."""
+    import torch
+    from usher_amd import synth as gsynth
+    for k in ("UGP_FORCE_V1", "UGP_NO_SORT", "UGP_NO_PRUNE", "UGP_COARSE_MIN_NODES"):
+        monkeypatch.delenv(k, raising=False)
+    torch.cuda.synchronize()
+    free0, _ = torch.cuda.mem_get_info()
+    st = gsynth.SynthTree(15_000_000, n_sites=25000, seed=7, shape="sars2")
+    q = st.queries(10_000, seed=123, recent=True)
+    batch = _csr_batch(q)
+    pl = Placer(st.arrays)
+    assert pl.info()["n_nodes"] == 15_000_000
+    fast = pl.place(batch)
+    assert pl.timing()["packed_path"] == 1
+    free1, _ = torch.cuda.mem_get_info()
+    assert free0 - free1 < 8 << 30, (free0 - free1)                    # streams + tables + one batch's workspaces: a few GB
+    perm = np.random.default_rng(5).permutation(len(batch))
+    shuffled = pl.place(QueryBatch([gsynth.csr_sample(q, int(i)) for i in perm]))
+    assert (_rows(shuffled) == _rows(fast)[perm]).all()
+    monkeypatch.setenv("UGP_FORCE_V1", "1")
+    pl.reload_knobs()
+    slow = pl.place(batch)
+    assert pl.timing()["packed_path"] == 0
+    monkeypatch.delenv("UGP_FORCE_V1")
+    assert (_rows(slow) == _rows(fast)).all()
+    pl.close()
+    ot = capi.OracleTree(st.arrays)
+    n_cf = 2048
+    e1 = int(q["ent_off"][n_cf])
+    cf = capi.ClosedFormC(ot).place_csr(q["ent_off"][:n_cf + 1], q["pos"][:e1], q["ref"][:e1], q["nuc"][:e1], q["is_missing"][:e1])
+    assert (_rows(fast)[:n_cf] == _cf_rows(cf)).all()
+    threads = os.cpu_count() or 1
+    for i in range(7000, 7016):
+        w = ot.place_mt(gsynth.csr_sample(q, i), threads)
+        assert (w["best"], w["num_best"], w["best_j"]) == (int(fast["best_set_difference"][i]), int(fast["num_best"][i]), int(fast["best_j"][i])), i
+
+
+def test_place_device_is_stream_ordered():
+    """ugp_place_device behaves like a kernel launch on the caller's stream: work queued there before the call (a fill of the
+    output buffer) is finished before the call writes, and work queued behind it (a copy of the results) sees them -- 100 times
+    in a row with no host synchronisation, on a side stream."""
+    import torch
+    from usher_amd import synth as gsynth
+    st = gsynth.SynthTree(300_000, n_sites=4000, seed=44)
+    qs = [st.queries(n, seed=90 + i, max_subst=3, n_lo=0, n_hi=10, iupac_hi=2) for i, n in enumerate((1800, 600))]
+    batches = [_csr_batch(q) for q in qs]
+    pl = Placer(st.arrays)
+    want = [pl.place(b).view(np.int32).reshape(-1, 4).copy() for b in batches]
+    handles = [pl.upload(b) for b in batches]
+    side = torch.cuda.Stream()
+    out = torch.zeros((1800, 4), dtype=torch.int32, device="cuda")
+    copies = []
+    torch.cuda.synchronize()
+    with torch.cuda.stream(side):
+        for k in range(100):
+            i = k & 1
+            out.fill_(-7)                                          # queued on `side` in front of the call
+            pl.place_device(handles[i], out.data_ptr(), side.cuda_stream)
+            copies.append((i, out[:len(batches[i])].clone()))       # queued behind it
+    side.synchronize()
+    for i, c in copies:
+        assert (c.cpu().numpy() == want[i]).all(), i
+    for h in handles:
+        pl.free_qset(h)
+    pl.close()
+
+
+def test_two_handles_two_threads_while_the_environment_changes(monkeypatch):
+    """The tuning switches are read when a handle is made: two handles driven by two host threads give exact answers on the packed
+    path while a third thread keeps calling setenv on switches that would change the path (UGP_FORCE_V1) or the schedule -- no
+    placement call reads the environment."""
+    import ctypes
+    import threading
+    from usher_amd import synth as gsynth
+    for k in ("UGP_FORCE_V1", "UGP_UNIT_CHUNKS", "UGP_NO_SORT"):
+        monkeypatch.delenv(k, raising=False)
+    st = gsynth.SynthTree(300_000, n_sites=4000, seed=45)
+    q = st.queries(1500, seed=3, max_subst=3, n_lo=0, n_hi=10, iupac_hi=2)
+    batch = _csr_batch(q)
+    pls = [Placer(st.arrays), Placer(st.arrays)]
+    want = pls[0].place(batch).view(np.int32).copy()
+    libc = ctypes.CDLL(None)
+    stop = threading.Event()
+    errs = []
+
+    def churn():
+        n = 0
+        while not stop.is_set():
+            for k in (b"UGP_FORCE_V1", b"UGP_UNIT_CHUNKS", b"UGP_NO_SORT", b"UGP_FILLER_%d" % (n % 64)):
+                libc.setenv(k, b"%d" % (1 + n % 7), 1)
+            libc.unsetenv(b"UGP_FORCE_V1")
+            n += 1
+
+    def work(pl):
+        try:
+            for _ in range(30):
+                got = pl.place(batch).view(np.int32)
+                assert (got == want).all()
+                assert pl.timing()["packed_path"] == 1
+        except BaseException as e:   # noqa: BLE001
+            errs.append(e)
+
+    tc = threading.Thread(target=churn)
+    tc.start()
+    ts = [threading.Thread(target=work, args=(pl,)) for pl in pls]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    stop.set()
+    tc.join()
+    for k in (b"UGP_FORCE_V1", b"UGP_UNIT_CHUNKS", b"UGP_NO_SORT"):
+        libc.unsetenv(k)
+    for pl in pls:
+        pl.close()
+    assert not errs, errs
+
+
+def test_async_batches_with_bad_rows_are_reported_and_never_placed():
+    """ugp_place_batch_async queues the whole pipeline before the row check's verdict is read; a batch that fails the check is
+    built as if it had no rows (k_scatter_entries / k_build_tiles look at the verdict), so no kernel sees duplicate positions, a
+    bad allele mask or a REF mismatch; ITS ugp_job_wait reports the error, and the batches around it get their exact answers."""
+    from usher_amd import synth as gsynth
+    from usher_amd.placement import UgpError
+    st = gsynth.SynthTree(300_000, n_sites=4000, seed=46)
+    qa, qb = st.queries(1500, seed=1, max_subst=3, n_lo=0, n_hi=10), st.queries(900, seed=2, max_subst=3, n_lo=0, n_hi=200)
+    good_a, good_b = _csr_batch(qa), _csr_batch(qb)
+    pl = Placer(st.arrays)
+    want_a, want_b = pl.place(good_a).copy(), pl.place(good_b).copy()
+
+    def corrupt(kind):
+        b = QueryBatch.from_csr(good_b.ent_off.copy(), good_b.pos.copy(), good_b.ref.copy(), good_b.nuc.copy(), good_b.is_missing.copy())
+        smp = int(np.flatnonzero(np.diff(b.ent_off.astype(np.int64)) >= 3)[5])
+        e0 = int(b.ent_off[smp])
+        if kind == "duplicate":
+            b.pos[e0 + 1] = b.pos[e0]
+        elif kind == "mask":
+            b.is_missing[e0] = 0; b.nuc[e0] = 0
+        elif kind == "ref":
+            tree_pos = np.unique(st.arrays["mut_pos"][st.arrays["mut_pos"] > 0])
+            k = int(np.flatnonzero(np.isin(b.pos, tree_pos))[0])          # a row at a position the tree mutates: its REF is checked
+            b.ref[k] = 1 if b.ref[k] != 1 else 2
+        return b
+    for kind, code in (("duplicate", -2), ("mask", -1), ("ref", -2)):
+        j1 = pl.place_async(good_a)
+        j2 = pl.place_async(corrupt(kind))
+        assert (pl.job_wait(j1).view(np.int32) == want_a.view(np.int32)).all(), kind
+        j3 = pl.place_async(good_b)
+        with pytest.raises(UgpError) as ei:
+            pl.job_wait(j2)
+        assert ei.value.code == code, (kind, str(ei.value))
+        assert (pl.job_wait(j3).view(np.int32) == want_b.view(np.int32)).all(), kind
+    assert (pl.place(good_a).view(np.int32) == want_a.view(np.int32)).all()
+    pl.close()

@@ -45,7 +45,7 @@ def main():
         q = st.queries(nq, seed=int(rng.integers(1, 1 << 20)), max_subst=int(rng.integers(0, 6)), n_lo=50 if amb else 0, n_hi=3000 if amb else int(rng.integers(0, 4)),
                        iupac_hi=20 if amb else 0, recent=(shape == "sars2" and rng.random() < 0.7))
         batch = QueryBatch.from_csr(q["ent_off"], q["pos"], q["ref"], q["nuc"], q["is_missing"])
-        pl = Placer(st.arrays)
+        pl = Placer(st.arrays, experiments="UGP_PHASE2_PACKED" in knobs)
         res = pl.place(batch)
         packed = pl.timing()["packed_path"]
         pl.close()

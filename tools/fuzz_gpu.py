@@ -52,7 +52,7 @@ def main():
                 knobs[k] = "1"
         os.environ.update(knobs)
         ot = capi.OracleTree(arrays)
-        pl = Placer(arrays, chunk_nodes=int(rng.integers(2, 90)))
+        pl = Placer(arrays, chunk_nodes=int(rng.integers(2, 90)), experiments="UGP_PHASE2_PACKED" in knobs)
         res = pl.place(QueryBatch(queries))
         for i, s in enumerate(queries):
             w = ot.place(s, want_ties=False)

@@ -6,7 +6,7 @@
 TAG=${1:-r02}
 EXTRA=${2:-}
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
-B="python3 bench.py --queries 16384 --steps 3 --warmup 1 --cpu-queries 0 $EXTRA"
+B="python3 bench.py --queries 16384 --steps 3 --warmup 1 --cpu-queries 0 --no-extra --repeats 1 $EXTRA"
 rocprofv3 --kernel-trace --stats -d gpurun_out/${TAG}_stats -o p --output-format csv -- $B > gpurun_out/${TAG}_stats.log 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d gpurun_out/${TAG}_fetch -o p --output-format csv -- $B > gpurun_out/${TAG}_fetch.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d gpurun_out/${TAG}_write -o p --output-format csv -- $B > gpurun_out/${TAG}_write.log 2>&1

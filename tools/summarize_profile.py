@@ -16,7 +16,7 @@ os.makedirs(prof, exist_ok=True)
 stats = glob.glob(os.path.join(go, tag + "_stats", "*kernel_stats.csv"))
 if stats:
     shutil.copy(stats[0], os.path.join(prof, tag + "_kernel_stats.csv"))
-summary = {"tag": tag, "command": "python3 bench.py --queries 16384 --steps 3 --warmup 1 --cpu-queries 0" + (" " + sys.argv[2] if len(sys.argv) > 2 else ""), "kernels": {}}
+summary = {"tag": tag, "command": "python3 bench.py --queries 16384 --steps 3 --warmup 1 --cpu-queries 0 --no-extra --repeats 1" + (" " + sys.argv[2] if len(sys.argv) > 2 else ""), "kernels": {}}
 log = os.path.join(go, tag + "_stats.log")
 if os.path.exists(log):
     with open(log) as f:

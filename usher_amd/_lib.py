@@ -8,7 +8,9 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libusher_amd.so")
+EXP_LIB_PATH = os.path.join(_HERE, "libusher_amd_exp.so")   # the same sources with -DUGP_EXPERIMENTS (diagnostics, experiments)
 _lib = None
+_lib_exp = None
 
 
 class ugp_tree_desc(C.Structure):
@@ -65,6 +67,9 @@ SYMBOLS = {
     "ugp_qset_destroy": (None, [P]),
     "ugp_qset_size": (C.c_uint64, [P]),
     "ugp_place_device": (C.c_int, [P, P, P, P]),
+    "ugp_place_device_overlapped": (C.c_int, [P, P, P, P]),
+    "ugp_mat_reload_knobs": (C.c_int, [P]),
+    "ugp_has_experiments": (C.c_int, []),
     "ugp_place_batch_async": (C.c_int, [P, C.POINTER(ugp_queries), P, C.POINTER(P)]),
     "ugp_job_wait": (C.c_int, [P]),
     "ugp_get_timing": (C.c_int, [P, C.POINTER(ugp_timing)]),
@@ -91,17 +96,26 @@ def build_library(force: bool = False) -> str:
     return LIB_PATH
 
 
-def lib():
-    global _lib
+def _load(path):
+    if not os.path.exists(path):
+        raise RuntimeError(
+            "%s is not built (%s); run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C usher_amd/csrc`. There is no CPU fallback." % (os.path.basename(path), path))
+    L = C.CDLL(path)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(L, name)
+        fn.restype = res
+        fn.argtypes = args
+    return L
+
+
+def lib(experiments: bool = False):
+    """The release library, or (experiments=True) the build with -DUGP_EXPERIMENTS; each is loaded once per process."""
+    global _lib, _lib_exp
+    if experiments:
+        if _lib_exp is None:
+            _lib_exp = _load(EXP_LIB_PATH)
+        return _lib_exp
     if _lib is None:
-        if not os.path.exists(LIB_PATH):
-            raise RuntimeError(
-                "libusher_amd.so is not built (%s); run `python -c 'import __graft_entry__ as g; g.build()'` "
-                "or `make -C usher_amd/csrc`. There is no CPU fallback." % LIB_PATH)
-        L = C.CDLL(LIB_PATH)
-        for name, (res, args) in SYMBOLS.items():
-            fn = getattr(L, name)
-            fn.restype = res
-            fn.argtypes = args
-        _lib = L
+        _lib = _load(LIB_PATH)
     return _lib

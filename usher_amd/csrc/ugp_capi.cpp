@@ -16,6 +16,7 @@
 
 #include "ugp_flatten.hpp"
 #include "ugp_kernels.hpp"
+#include "ugp_knobs.hpp"
 #include "usher_amd.h"
 
 namespace {
@@ -92,6 +93,7 @@ constexpr uint32_t kMaxTilesPerLaunch = 4096;   // 262,144 samples per sub-batch
 
 struct ugp_mat {
     int device = 0;
+    ugp::Knobs knobs;    // tuning switches, read from the environment when the handle is made (ugp_knobs.hpp); no getenv in a call
     ugp::FlatMat flat;   // the scalars of the flattening only (counts, depths); the arrays live on the device
     uint64_t stream_dwords = 0, pre_dwords = 0;
     DevBuf<uint32_t> d_stream, d_pre, d_chunk_body, d_chunk_pre, d_chunk_node, d_rank2bfs, d_dfs2bfs;
@@ -114,7 +116,7 @@ struct ugp_mat {
     ugp_qset *own_qs = nullptr;          // reusable query set / result buffer of the host-buffer entry points
     DevBuf<ugp_result> d_own_out;
     size_t occ_lds = ~(size_t)0;   // k_best8 occupancy cache: LDS bytes it was queried for
-    int occ_per_cu = 0, n_cu = 0;
+    int occ_per_cu = 0, n_cu = 0, occ_variant = -1;
     // Everything one call writes on the device, twice: consecutive ugp_place_device calls alternate between the two sets and
     // run on two streams of the handle's own, so the small latency-bound kernels around k_best8 (row checks, coarse pass,
     // sort, tile build, seed descent, phase 2) of one batch fill the idle issue slots of the other's.  The other entry
@@ -153,6 +155,8 @@ struct ugp_mat {
         bool job_busy = false;           // a job on this set has been started and not yet waited for
         hipStream_t stream = nullptr;    // the handle's own stream for this set (ugp_place_device)
         hipEvent_t done = nullptr;       // recorded behind the last call that used this set
+        hipEvent_t entry = nullptr;      // (ugp_place_device_overlapped) the caller's stream at the moment of the set's latest call
+        bool entry_valid = false;
         hipStream_t done_on = nullptr;   // ... on this stream
     } work[2];
     ugp_timing tsum = {};    // durations of all calls since the last ugp_get_timing_sum
@@ -160,7 +164,6 @@ struct ugp_mat {
     int last_work = 0;       // set used by the most recent call (ugp_get_timing reports it)
     int next_work = 0;       // set the next ugp_place_device call takes
     uint32_t tie_lists_filled = 0, tie_sub_batches = 0;   // sub-batches of the current call whose tie lists phase 2 has filled / all of them (ugp_tied_nodes)
-    bool primed = false;     // both sets have been through one call
     bool sharing = false;    // (during a ugp_place_device call) the other set's call was still running when this one, or the one before it, was queued
     bool was_busy = false;   // ... when the previous call was queued
     hipEvent_t kb_done = nullptr;    // behind the latest k_best8 launch of this handle ...
@@ -188,9 +191,9 @@ struct ugp_qset {
 namespace {
 
 uint32_t pick_groups(const ugp_mat *m, uint32_t n_tiles, uint32_t target_waves = 4096) {
-    if (const char *e = getenv("UGP_TARGET_WAVES")) target_waves = (uint32_t)std::max(1, atoi(e));
+    if (m->knobs.target_waves) target_waves = m->knobs.target_waves;
     uint32_t g = (target_waves + n_tiles - 1) / n_tiles;
-    if (const char *e = getenv("UGP_GROUPS")) g = (uint32_t)std::max(1, atoi(e));
+    if (m->knobs.groups) g = m->knobs.groups;
     g = std::min<uint32_t>(g, m->flat.n_chunks);
     g = std::max<uint32_t>(g, 1);
     if (g >= 8) g &= ~7u;   // XCD-aware block mapping wants a multiple of 8
@@ -239,6 +242,7 @@ int run_place(ugp_mat *m, ugp_qset *qs, int mode, ugp_result *d_out, int32_t *d_
               const ExDev *ex = nullptr, int wi = 0) {
     HIP_TRY(hipSetDevice(m->device));
     const auto &f = m->flat;
+    const ugp::Knobs &K = m->knobs;
     const uint64_t Q = qs->n_queries;
     ugp_mat::Work &W = m->work[wi];
     m->last_work = wi;
@@ -268,8 +272,8 @@ int run_place(ugp_mat *m, ugp_qset *qs, int mode, ugp_result *d_out, int32_t *d_
     // (16-bit phase 1: every D / cost must stay below 0x7F7F, the value the shared upper bounds start from;
     // a tree with a masked mutation behind an ordinary one on the same node -- never produced by the reference's
     // sorted Node::add_mutation, mutation_annotated_tree.cpp:720-752 -- needs the order-aware 32-bit walk)
-    const bool packed_ok = (mode == 0) && !ex && !getenv("UGP_FORCE_V1") && !f.mask_not_first && (qs->max_rows + f.max_path_muts + 2 < 0x7F7Full);
-    const bool sorted = packed_ok && m->coarse && Q > 512 && !getenv("UGP_NO_SORT") && !getenv("UGP_NO_PRUNE");
+    const bool packed_ok = (mode == 0) && !ex && !K.force_v1 && !f.mask_not_first && (qs->max_rows + f.max_path_muts + 2 < 0x7F7Full);
+    const bool sorted = packed_ok && m->coarse && Q > 512 && !K.no_sort && !K.no_prune;
     TG.coarse_timed = false;
     if (sorted) {
         HIP_TRY(W.d_coarse_res.reserve(Q));
@@ -279,7 +283,7 @@ int run_place(ugp_mat *m, ugp_qset *qs, int mode, ugp_result *d_out, int32_t *d_
         // node of minimal cost serves the sort and the descent.  (UGP_COARSE_PHASE2=1: the full phase 2 instead, i.e. the
         // reference's tie-break winner: 0.2 ms more per 16,384 samples, the same answers.)
         m->coarse->sharing = m->sharing;
-        const bool coarse_arg = m->coarse->d_node_pos8.p && m->coarse->flat.max_chunk8_words < 65536u && !getenv("UGP_COARSE_PHASE2");
+        const bool coarse_arg = m->coarse->d_node_pos8.p && m->coarse->flat.max_chunk8_words < 65536u && !K.coarse_phase2;
         if (int rc = run_place(m->coarse, qs, 0, W.d_coarse_res.p, nullptr, nullptr, nullptr, nullptr, nullptr, 0, s, coarse_arg, nullptr, wi)) return rc;
         HIP_TRY(hipSetDevice(m->device));
         HIP_TRY(hipEventRecord(TG.ev_coarse[1], s));
@@ -299,11 +303,11 @@ int run_place(ugp_mat *m, ugp_qset *qs, int mode, ugp_result *d_out, int32_t *d_
         uint32_t G = pick_groups(m, n_tiles);
         if (use8) {   // work units of a few chunks each, pulled from per-XCD queues by persistent waves (see k_best8)
             uint32_t unit_chunks = 16;   // (most far units end in their preamble: the replay is the cost to amortise)
-            if (const char *e = getenv("UGP_UNIT_CHUNKS")) unit_chunks = (uint32_t)std::max(1, atoi(e));
+            if (K.unit_chunks) unit_chunks = K.unit_chunks;
             G = std::max<uint32_t>(1, (f.n_chunks + unit_chunks - 1) / unit_chunks);
             // a small batch still has to fill the chip: at least ~4096 units in total
             while (G < f.n_chunks && (uint64_t)G * n_tiles512 < 4096) G = std::min<uint32_t>(f.n_chunks, G * 2);
-            if (const char *e = getenv("UGP_GROUPS")) G = std::min<uint32_t>(f.n_chunks, (uint32_t)std::max(1, atoi(e)));
+            if (K.groups) G = std::min<uint32_t>(f.n_chunks, K.groups);
         }
         const uint64_t table_dwords = (uint64_t)n_tiles512 * (n_sites + ugp::TABLE_CONST_ROWS) * 64;
         HIP_TRY(W.d_table.reserve(table_dwords));
@@ -355,39 +359,43 @@ int run_place(ugp_mat *m, ugp_qset *qs, int mode, ugp_result *d_out, int32_t *d_
         // the locality sort the builder's uncoalesced row reads cost more than the scatter's atomics -- measured on config 5:
         // coarse pass 2.72 -> 2.33 ms, sorted build 1.77 -> 2.03 ms)
         bool lds_build = use8 && n_sites && !order && (e1 - e0) >= (uint64_t)nq * 128;
-        if (const char *e = getenv("UGP_TILE_BUILD")) lds_build = use8 && n_sites && atoi(e) != 0;
+        if (K.tile_build >= 0) lds_build = use8 && n_sites && K.tile_build != 0;
         int nmi = -1;   // the query set carries N masks for this tree
         for (int i = 0; i < 2; i++) if (qs->nmask_for[i] == m && use8 && n_sites) nmi = i;
         if (nmi >= 0) {
             HIP_TRY(ugp::launch_ntiles(W.d_table.p, d_active, active_words, n_tiles512, qs->d_nmask[nmi].p, qs->nmask_words[nmi], order, (uint32_t)q0, (uint32_t)nq,
                                        m->d_site_ref.p, n_sites, s));
             HIP_TRY(ugp::launch_scatter_list(W.d_table.p, d_dbottom, qs->d_pos.p, qs->d_ref.p, qs->d_nuc.p, qs->d_missing.p, qs->d_ent_q.p, m->d_pos2site.p,
-                                             f.max_pos, n_sites, (uint32_t)q0, (uint32_t)nq, d_active, active_words, slot_of, qs->d_plain_rows.p, qs->d_n_plain.p, s));
+                                             f.max_pos, n_sites, (uint32_t)q0, (uint32_t)nq, d_active, active_words, slot_of, qs->d_plain_rows.p, qs->d_n_plain.p, qs->d_err.p, s));
         } else if (lds_build)
             HIP_TRY(ugp::launch_build_tiles(W.d_table.p, d_active, active_words, n_tiles512, qs->d_ent_off.p, (uint32_t)q0, order, (uint32_t)nq, qs->d_pos.p,
                                             qs->d_ref.p, qs->d_nuc.p, qs->d_missing.p, m->d_pos2site.p, m->d_site_pos.p, m->d_site_ref.p, n_sites, f.max_pos,
-                                            d_dbottom, s));
+                                            d_dbottom, qs->d_err.p, s));
         else {
         HIP_TRY(ugp::launch_fill_table(W.d_table.p, m->d_site_ref.p, n_sites, table_dwords, s));
         HIP_TRY(ugp::launch_scatter(W.d_table.p, d_dbottom, qs->d_pos.p + e0, qs->d_ref.p + e0,
                                     qs->d_nuc.p + e0, qs->d_missing.p + e0, qs->d_ent_q.p + e0, m->d_pos2site.p,
-                                    f.max_pos, n_sites, e1 - e0, (uint32_t)q0, d_active, active_words, slot_of, s));
+                                    f.max_pos, n_sites, e1 - e0, (uint32_t)q0, d_active, active_words, slot_of, qs->d_err.p, s));
         }
         if (use8) {   // upper bounds of best(s) the pruning starts from
-            if (sorted && getenv("UGP_SEED_PREV") && W.d_prev_res.cap >= Q && W.prev_serial == qs->serial)   // (experiment: bounds = the previous call's exact answers)
+#ifdef UGP_EXPERIMENTS
+            if (sorted && K.seed_prev && W.d_prev_res.cap >= Q && W.prev_serial == qs->serial)   // (experiment: bounds = the previous call's exact answers)
                 HIP_TRY(ugp::launch_seed_ub(W.d_prev_res.p + q0, order, (uint32_t)nq, n_tiles512, W.d_ub.p, nullptr, nullptr, 0, s));
-            else if (sorted && !getenv("UGP_NO_SEED")) {
+            else
+#endif
+            if (sorted && !K.no_seed) {
                 // the coarse pass's best costs (real costs of real nodes), tightened by a greedy descent from the coarse best node
                 // through the full tree (k_descend; it reads the sample's alleles from the tiles just built)
                 const uint32_t *refined = nullptr;
                 // (the descent derives D of its start node from "cost(best_j) == best", which both forms of the pre-pass's result
                 // guarantee)
-                if (m->d_node_pair.p && m->d_coarse2bfs.p && !getenv("UGP_NO_DESCENT")) {
+                if (m->d_node_pair.p && m->d_coarse2bfs.p && !K.no_descent) {
                     HIP_TRY(W.d_refined.reserve(nq));
                     HIP_TRY(ugp::launch_descend(W.d_coarse_res.p + q0, order, (uint32_t)nq, m->d_coarse2bfs.p, m->d_node_pair.p,
-                                                m->d_parent.p, m->d_stream.p, W.d_table.p, n_sites, W.d_refined.p, m->wide_descent, s));
+                                                m->d_parent.p, m->d_stream.p, W.d_table.p, n_sites, W.d_refined.p, m->wide_descent, K.descent_max, K.descent_slack, s));
                     refined = W.d_refined.p;
-                    if (getenv("UGP_STATS") && getenv("UGP_SEED_CHECK") && W.prev_serial == qs->serial && W.d_prev_res.cap >= Q) {   // debug: seeds against the previous call's answers
+#ifdef UGP_EXPERIMENTS
+                    if (K.stats && K.seed_check && W.prev_serial == qs->serial && W.d_prev_res.cap >= Q) {   // debug: seeds against the previous call's answers
                         std::vector<uint32_t> ref(nq), ord(nq);
                         std::vector<ugp_result> prev(nq), coarse(nq);
                         HIP_TRY(hipStreamSynchronize(s));
@@ -430,11 +438,12 @@ int run_place(ugp_mat *m, ugp_qset *qs, int mode, ugp_result *d_out, int32_t *d_
                         for (int i = 0; i < 18; i++) fprintf(stderr, " %llu", (unsigned long long)hist_c[i]);
                         fprintf(stderr, "\n");
                     }
+#endif
                 }
                 // (the unused slots of the last tile: far from everything, see k_seed_ub; 16-bit safe by the guard of the packed path)
-                const uint32_t pad_d = getenv("UGP_NO_PAD_FIX") ? 0u : (uint32_t)std::min<uint64_t>(4096, 0x7F7Eu - 2u - std::min<uint64_t>(f.max_path_muts, 0x7F00u));
+                const uint32_t pad_d = K.no_pad_fix ? 0u : (uint32_t)std::min<uint64_t>(4096, 0x7F7Eu - 2u - std::min<uint64_t>(f.max_path_muts, 0x7F00u));
                 HIP_TRY(ugp::launch_seed_ub(W.d_coarse_res.p + q0, order, (uint32_t)nq, n_tiles512, W.d_ub.p, refined,
-                                            getenv("UGP_NO_PAD_FIX") ? nullptr : d_dbottom, pad_d, s));
+                                            K.no_pad_fix ? nullptr : d_dbottom, pad_d, s));
             } else
                 HIP_TRY(hipMemsetAsync(W.d_ub.p, 0x7F, (size_t)n_tiles512 * 256 * sizeof(uint32_t), s));   // 0x7F7F: above every valid cost
         }
@@ -471,9 +480,9 @@ int run_place(ugp_mat *m, ugp_qset *qs, int mode, ugp_result *d_out, int32_t *d_
             b.list = W.d_list.p; b.list_n = d_list_n;
             W.last_list_n = d_list_n; W.last_list_tiles = n_tiles512;
             b.queue = d_queue;
-            b.ub = getenv("UGP_NO_PRUNE") ? nullptr : W.d_ub.p;
+            b.ub = K.no_prune ? nullptr : W.d_ub.p;
             const uint32_t *hstart = nullptr, *hlen = nullptr;
-            if (sorted && !getenv("UGP_NO_LPT")) {   // hand out every tile's own region first (scheduling only)
+            if (sorted && !K.no_lpt) {   // hand out every tile's own region first (scheduling only)
                 HIP_TRY(W.d_gstart.reserve(n_tiles512)); HIP_TRY(W.d_hlen.reserve(n_tiles512));
                 HIP_TRY(ugp::launch_tile_ranges(W.d_keys2.p, (uint32_t)nq, n_tiles512, m->d_chunk_node.p, f.n_chunks,
                                                 std::max<uint32_t>(1, (f.n_chunks + G - 1) / G), W.d_gstart.p, W.d_hlen.p, s));
@@ -481,19 +490,19 @@ int run_place(ugp_mat *m, ugp_qset *qs, int mode, ugp_result *d_out, int32_t *d_
             }
             const uint32_t unit_chunks = std::max<uint32_t>(1, (f.n_chunks + G - 1) / G);
             b.ub_every = 128;
-            if (const char *e = getenv("UGP_UB_EVERY")) b.ub_every = (uint32_t)std::max(1, atoi(e));
-            b.refill_all_rows = getenv("UGP_REFILL_ALL") ? 1u : 0u;
-            b.heavy_prio = getenv("UGP_HEAVY_PRIO") ? (uint32_t)atoi(getenv("UGP_HEAVY_PRIO")) : 0u;
+            if (K.ub_every) b.ub_every = K.ub_every;
+            b.refill_all_rows = K.refill_all ? 1u : 0u;
+            b.heavy_prio = K.heavy_prio;
             // (trees with large polytomies keep the tile-after-tile order: measured, 7 % apart in either direction)
-            const uint32_t light_order = getenv("UGP_LIGHT_ORDER") ? (uint32_t)atoi(getenv("UGP_LIGHT_ORDER")) : (m->wide_descent ? 1u : 0u);
+            const uint32_t light_order = K.light_order >= 0 ? (uint32_t)K.light_order : (m->wide_descent ? 1u : 0u);
             uint32_t heavy_chunks = 16;
-            if (const char *e = getenv("UGP_HEAVY_CHUNKS")) heavy_chunks = (uint32_t)std::max(1, atoi(e));
+            if (K.heavy_chunks) heavy_chunks = K.heavy_chunks;
             // Units outside the tiles' own regions grow with the distance from the region (they end in their preamble or after a
             // few jumps: what they cost is the replay, not their length) -- only when there is a region to measure from and bounds
             // to prune with.
             uint32_t grow_every = (hstart && b.ub) ? 8u : 0u, unit_max = unit_chunks * 16u;
-            if (const char *e = getenv("UGP_UNIT_GROW")) grow_every = (hstart && b.ub) ? (uint32_t)std::max(0, atoi(e)) : 0u;
-            if (const char *e = getenv("UGP_UNIT_MAX")) unit_max = (uint32_t)std::max(1, atoi(e));
+            if (K.unit_grow >= 0) grow_every = (hstart && b.ub) ? (uint32_t)K.unit_grow : 0u;
+            if (K.unit_max) unit_max = K.unit_max;
             // A preamble record says where the body goes on behind a path node's subtree in INFO_JUMP_MASK's 18 bits, the largest
             // value meaning "beyond the unit": no unit may be longer than that many words.  (Should even the basic units be --
             // chunks of thousands of words: nodes with thousands of mutations -- the replay runs without those records.)
@@ -514,8 +523,8 @@ int run_place(ugp_mat *m, ugp_qset *qs, int mode, ugp_result *d_out, int32_t *d_
                 HIP_TRY(W.d_unit_info.reserve(32 + 96));
                 // units that run long are cut while they run: the shared list of split-off halves (k_best8)
                 uint32_t split_cycles = 400000, split_heavy = 400000;
-                if (const char *e = getenv("UGP_SPLIT_CYCLES")) split_cycles = split_heavy = (uint32_t)std::max(0, atoi(e));
-                if (const char *e = getenv("UGP_SPLIT_HEAVY")) split_heavy = (uint32_t)std::max(0, atoi(e));
+                if (K.split_cycles >= 0) split_cycles = (uint32_t)K.split_cycles;
+                if (K.split_heavy >= 0) split_heavy = (uint32_t)K.split_heavy;
                 if (!split_heavy) split_heavy = 0xFFFFFFFFu;
                 if (!split_cycles || f.n_chunks >= (1u << 20) || n_tiles512 > 4096) split_cycles = split_heavy = 0xFFFFFFFFu;   // (never; the entry's fields)
                 constexpr uint32_t kDynCap = 1u << 17;
@@ -525,15 +534,15 @@ int run_place(ugp_mat *m, ugp_qset *qs, int mode, ugp_result *d_out, int32_t *d_
                 }
                 if (++W.dyn_epoch >= 2048u) { HIP_TRY(hipMemsetAsync(W.d_dyn.p, 0, (size_t)kDynCap * 8, s)); W.dyn_epoch = 1; }   // (11 bits: stale entries never alias)
                 uint32_t *dyn_ctl = W.d_unit_info.p + 32;
-                b.dyn_ctl = dyn_ctl; b.dyn_units = (unsigned long long *)W.d_dyn.p; b.dyn_cap = kDynCap; b.dyn_epoch = W.dyn_epoch; b.split_cycles = split_cycles; b.split_heavy = split_heavy; b.split_dense = getenv("UGP_SPLIT_DENSE") ? (uint32_t)std::max(0, atoi(getenv("UGP_SPLIT_DENSE"))) : 0xFFFFFFFFu;
+                b.dyn_ctl = dyn_ctl; b.dyn_units = (unsigned long long *)W.d_dyn.p; b.dyn_cap = kDynCap; b.dyn_epoch = W.dyn_epoch; b.split_cycles = split_cycles; b.split_heavy = split_heavy; b.split_dense = K.split_dense >= 0 ? (uint32_t)K.split_dense : 0xFFFFFFFFu;
                 HIP_TRY(ugp::launch_build_units(hstart, hlen, n_tiles512, f.n_chunks, unit_chunks, heavy_chunks, grow_every, unit_max, light_order, per_tile_cap,
                                                 W.d_units.p, W.d_unit_info.p, W.d_unit_info.p + 8, dyn_ctl, s));
                 b.units = (const uint4 *)W.d_units.p; b.unit_base = W.d_unit_info.p; b.unit_count = W.d_unit_info.p + 8;
             }
             HIP_TRY(W.d_stats.reserve(64));
             if (q0 == 0) { HIP_TRY(hipMemsetAsync(W.d_stats.p, 0, 64 * sizeof(uint64_t), s)); W.last_words_total = 0; }
-            b.stats = getenv("UGP_STATS") ? W.d_stats.p : nullptr;   // the counters are two contended atomics per skip: debug only
-            if (b.stats && getenv("UGP_TRACE") && !coarse_only) {   // per-unit records of this launch, dumped by ugp_get_timing
+            b.stats = K.stats ? W.d_stats.p : nullptr;   // the counters are two contended atomics per skip: debug only
+            if (b.stats && !K.trace.empty() && !coarse_only) {   // per-unit records of this launch, dumped by ugp_get_timing
                 constexpr size_t kTraceCap = 1u << 20;
                 HIP_TRY(W.d_trace.reserve(8 + kTraceCap * 6));
                 HIP_TRY(hipMemsetAsync(W.d_trace.p, 0, 64, s));
@@ -553,20 +562,21 @@ int run_place(ugp_mat *m, ugp_qset *qs, int mode, ugp_result *d_out, int32_t *d_
             // (not when two calls share the device: the grids are halved then, and the LDS is better spent on resident waves --
             // 65,536 samples per call, pipelined: 10.5 M/s with, 11.0 M/s without)
             b.lds_bits = (!b.stats && (size_t)active_words * 4 <= 4096 && n_tiles512 >= 64 && !m->sharing) ? 1u : 0u;
-            if (const char *e = getenv("UGP_LDS_BITS")) b.lds_bits = (!b.stats && (size_t)active_words * 4 <= 4096 && atoi(e) != 0) ? 1u : 0u;
+            if (K.lds_bits >= 0) b.lds_bits = (!b.stats && (size_t)active_words * 4 <= 4096 && K.lds_bits != 0) ? 1u : 0u;
             const size_t lds_bytes = (size_t)b.lds_slots * 64 * 16 + (b.lds_bits ? (((size_t)active_words * 4 + 15) & ~(size_t)15) : 0);
-            if (m->occ_lds != lds_bytes) {
+            const int variant = coarse_only ? 2 : (b.lds_bits ? 1 : 0);   // (the kernel launch_best8 will pick)
+            if (m->occ_lds != lds_bytes || m->occ_variant != variant) {
                 HIP_TRY(hipDeviceGetAttribute(&m->n_cu, hipDeviceAttributeMultiprocessorCount, m->device));
-                HIP_TRY(ugp::best8_occupancy(lds_bytes, &m->occ_per_cu));
-                m->occ_lds = lds_bytes;
+                HIP_TRY(ugp::best8_occupancy(lds_bytes, variant, &m->occ_per_cu));
+                m->occ_lds = lds_bytes; m->occ_variant = variant;
             }
             int waves_cu = std::max(m->occ_per_cu, 1);
             // Two calls on the device (ugp_place_device, the other set's call still running when this one is queued): each walk
             // takes half of what the device keeps resident, so that both grids ARE resident instead of one waiting for the other's
             // waves to exit -- measured at 16,384 samples per call: 2.71 -> 2.29 ms per call (6.05 -> 7.2 M placements/s), best at
             // 8 of the 17 waves per CU of that time (7: 2.32, 9: 2.39, 12: 2.51); with 16 resident since the B halves moved into registers, 8 again (6: 1.85, 8: 1.75, 10: 1.86 ms).  A call that finds the device to itself keeps the full grid.
-            if (m->sharing) waves_cu = std::max(1, getenv("UGP_SHARED_WAVES") ? atoi(getenv("UGP_SHARED_WAVES")) : waves_cu / 2);
-            if (const char *e = getenv("UGP_WAVES_PER_CU")) waves_cu = std::max(1, std::min(std::max(m->occ_per_cu, 1), atoi(e)));   // tuning
+            if (m->sharing) waves_cu = std::max(1, K.shared_waves ? (int)K.shared_waves : waves_cu / 2);
+            if (K.waves_per_cu) waves_cu = std::max(1, std::min(std::max(m->occ_per_cu, 1), (int)K.waves_per_cu));   // tuning
             uint64_t blocks = (uint64_t)waves_cu * std::max(m->n_cu, 1);
             blocks = std::min<uint64_t>(blocks, (uint64_t)n_tiles512 * G);
             blocks = ((blocks + 7) / 8) * 8;
@@ -576,7 +586,7 @@ int run_place(ugp_mat *m, ugp_qset *qs, int mode, ugp_result *d_out, int32_t *d_
             // (UGP_KBEST_EXCLUSIVE: of the two calls that may be on the device at a time, ugp_place_device, only one runs this
             // kernel at any moment -- measured: 2.77 against 2.71 ms per step when the two persistent grids simply share the
             // chip; the small kernels in front of the second walk are slowed by the first and become the critical path)
-            static const bool exclusive = getenv("UGP_KBEST_EXCLUSIVE") != nullptr;
+            const bool exclusive = K.kbest_exclusive;
             if (exclusive && !coarse_only && m->kb_done && m->kb_done_on != s) HIP_TRY(hipStreamWaitEvent(s, m->kb_done, 0));
             HIP_TRY(ugp::launch_best8(b, (uint32_t)blocks, s));
             if (exclusive && !coarse_only) {
@@ -588,7 +598,8 @@ int run_place(ugp_mat *m, ugp_qset *qs, int mode, ugp_result *d_out, int32_t *d_
             if (coarse_only)
                 HIP_TRY(ugp::launch_coarse_result(W.d_lbest.p, W.d_lpos.p, W.d_list.p, d_list_n, f.n_chunks, n_tiles512, (uint32_t)nq, m->d_chunk_node.p,
                                                   m->d_chunk8_body.p, m->d_node_pos8.p, m->d_dfs2bfs.p, d_out + q0, s));
-            else if (!d_tie_count && m->d_node_pos8.p && m->d_rank_dfs.p && b.ub && !b.stats && getenv("UGP_PHASE2_PACKED")) {
+#ifdef UGP_EXPERIMENTS
+            else if (!d_tie_count && m->d_node_pos8.p && m->d_rank_dfs.p && b.ub && !b.stats && K.phase2_packed) {
                 // (experiment, UGP_PHASE2_PACKED=1) phase 2 as a mode of the packed walk: one unit per (tile, chunk) record that holds some
                 // sample's global minimum.  Exact, but 6x slower than k_ties as it stands (1.8 against 0.3 ms per 16,384 samples): its
                 // units re-walk half of their chunks; DESIGN.md 7.2
@@ -597,12 +608,14 @@ int run_place(ugp_mat *m, ugp_qset *qs, int mode, ugp_result *d_out, int32_t *d_
                 HIP_TRY(ugp::launch_phase2_packed(b, W.d_list.p, d_list_n, W.d_gbest_part.p, W.d_gbest.p, n_tiles512, W.d_tie_units.p, W.d_tie_info.p, d_cnt, d_key,
                                                   m->d_node_pos8.p, m->d_rank_dfs.p, m->d_chunk_node.p, m->d_rank2bfs.p, (uint32_t)nq, d_out + q0, order,
                                                   (uint32_t)blocks, s));
-            } else
+            }
+#endif
+            else
                 HIP_TRY(ugp::launch_phase2(a, W.d_lbest.p, W.d_list.p, d_list_n, W.d_gbest_part.p, W.d_gbest.p, n_tiles512, W.d_items.p, d_nitems,
                                            (uint32_t)std::min<uint64_t>(pairs, 0xFFFFFFFFull), d_cnt, d_key,
                                            m->d_rank2bfs.p, d_out + q0, order, f.max_slots, d_tie_count != nullptr, s));
                 if (d_tie_count) m->tie_lists_filled++;
-        } else if (mode == 1 && !ex && !m->h_level_off.empty() && !getenv("UGP_SCORES_DFS")) {
+        } else if (mode == 1 && !ex && !m->h_level_off.empty() && !K.scores_dfs) {
             // -p in the output's own order: level by level of the breadth-first expansion, 64 consecutive scores of one sample per
             // wave store (k_scores_level); the depth-first walk below writes 4 bytes per 32-byte sector
             const uint32_t qpad = (uint32_t)((nq + 7) / 8 * 8);
@@ -611,7 +624,7 @@ int run_place(ugp_mat *m, ugp_qset *qs, int mode, ugp_result *d_out, int32_t *d_
             HIP_TRY(W.d_part_best.reserve(d_words)); HIP_TRY(W.d_part_cnt.reserve(d_words));   // (the two D arrays; this mode has no partial results)
             HIP_TRY(ugp::launch_scores_levels(m->d_node_pair.p, m->d_parent.p, m->d_stream.p, W.d_table.p, n_sites, d_dbottom, m->h_level_off.data(),
                                               (uint32_t)m->h_level_off.size() - 1, W.d_part_best.p, W.d_part_cnt.p, d16, m->max_level_width, qpad, (uint32_t)nq, f.n_nodes,
-                                              a.scores, s));
+                                              a.scores, K.scores_block, s));
             HIP_TRY(hipEventRecord(es.ev[2], s));
         } else {
             HIP_TRY(ugp::launch_place(a, ex ? mode + 4 : mode, f.max_slots, s));
@@ -620,7 +633,7 @@ int run_place(ugp_mat *m, ugp_qset *qs, int mode, ugp_result *d_out, int32_t *d_
                 HIP_TRY(ugp::launch_merge(W.d_part_best.p, W.d_part_cnt.p, W.d_part_key.p, (ex && ex->rank2out) ? ex->rank2out : m->d_rank2bfs.p, G,
                                           (uint32_t)nq, d_out + q0, s));
         }
-        if ((getenv("UGP_SEED_PREV") || getenv("UGP_SEED_CHECK")) && use8 && !coarse_only && mode == 0) {
+        if ((K.seed_prev || K.seed_check) && use8 && !coarse_only && mode == 0) {
             HIP_TRY(W.d_prev_res.reserve(Q));
             HIP_TRY(hipMemcpyAsync(W.d_prev_res.p + q0, d_out + q0, nq * sizeof(ugp_result), hipMemcpyDeviceToDevice, s));
             W.prev_serial = (q0 + nq >= Q) ? qs->serial : 0;   // valid once every sub-batch of THIS query set has been stored
@@ -749,6 +762,7 @@ static int upload_flat(const HostFlat &hf, int device, ugp_mat **out) {
     ugp_mat *m = new (std::nothrow) ugp_mat();
     if (!m) return fail(UGP_ERR_NOMEM, "out of host memory");
     m->device = device;
+    m->knobs = ugp::Knobs::from_env();   // (the only place a handle reads its tuning switches: no getenv in a placement call)
     auto bail = [&](hipError_t e, const char *what) {
         std::string msg = std::string(what) + ": " + hipGetErrorString(e);
         ugp_mat_destroy(m);
@@ -825,7 +839,9 @@ static ugp::Options default_options() {
     if (const char *e = getenv("UGP_CHUNK_NODES")) opt.chunk_nodes = (uint32_t)std::max(1, atoi(e));
     if (const char *e = getenv("UGP_PRUNE_MIN_WORDS")) opt.prune_min_words = (uint32_t)std::max(1, atoi(e));
     if (getenv("UGP_NO_SIB")) opt.sibling_records = false;
+#ifdef UGP_EXPERIMENTS
     opt.keep_node_pos8 = getenv("UGP_PHASE2_PACKED") != nullptr;   // (the experiment's node tables: 8 bytes per node on the device)
+#endif
     if (getenv("UGP_NO_BOUND2")) opt.second_bound = false;   // first lower bound only (tests, tuning)
     if (const char *e = getenv("UGP_LDS_SLOTS")) opt.lds_slots = (uint32_t)std::max(1, std::min(60, atoi(e)));
     if (const char *e = getenv("UGP_PRE_WEIGHT")) opt.pre_weight = (uint32_t)std::max(0, atoi(e));
@@ -874,6 +890,7 @@ void ugp_mat_destroy(ugp_mat *m) {
     for (auto &W : m->work) {
         if (W.stream) { (void)hipStreamSynchronize(W.stream); (void)hipStreamDestroy(W.stream); }
         if (W.done) { (void)hipEventSynchronize(W.done); (void)hipEventDestroy(W.done); }
+        if (W.entry) (void)hipEventDestroy(W.entry);
         for (auto &G : W.gens) {
             for (auto &es : G.events)
                 for (int i = 0; i < 4; i++)
@@ -967,7 +984,7 @@ static int qset_fill(ugp_mat *m, const ugp_queries *q, ugp_qset *qs, hipStream_t
     qs->nmask_for[0] = qs->nmask_for[1] = nullptr;
     {
         bool want = n_ent >= (uint64_t)q->n_queries * 128 && n_ent < (1ull << 32) && q->n_queries < (1ull << 32);
-        if (const char *e = getenv("UGP_NMASK")) want = atoi(e) != 0 && n_ent < (1ull << 32);
+        if (m->knobs.nmask >= 0) want = m->knobs.nmask != 0 && n_ent < (1ull << 32);
         const ugp_mat *trees[2] = {m, m->coarse};
         for (int i = 0; want && i < 2; i++) {
             const ugp_mat *t = trees[i];
@@ -1007,41 +1024,51 @@ void ugp_qset_destroy(ugp_qset *qs) {
 
 uint64_t ugp_qset_size(const ugp_qset *qs) { return qs ? qs->n_queries : 0; }
 
+// Stream-ordered: behaves like a kernel launched on `stream` (waits for the work queued there before it, its results are
+// visible to the work queued behind it).  One call at a time per handle; workspace set 0.
 int ugp_place_device(ugp_mat *m, ugp_qset *qs, void *d_out, void *stream) {
     if (!m || !qs || (!d_out && qs->n_queries)) return fail(UGP_ERR_INVALID, "null argument");
     if (qs->device != m->device) return fail(UGP_ERR_INVALID, "query set lives on another device");
-    // Consecutive calls alternate between the handle's two workspace sets and run on two streams of its own; `stream` gets
-    // the call's completion event.  Two batches are then on the device at a time, and the small latency-bound kernels around
-    // k_best8 of one fill the idle issue slots of the other's: measured +18 % placements/s at 16,384 samples per call.
-    // (A call therefore does not wait for earlier work on `stream` other than calls on this handle: see usher_amd.h.)
-    static const bool overlap = !getenv("UGP_NO_OVERLAP");
-    if (!overlap) return run_place(m, qs, 0, (ugp_result *)d_out, nullptr, nullptr, nullptr, nullptr, nullptr, 0, (hipStream_t)stream);
+    return run_place(m, qs, 0, (ugp_result *)d_out, nullptr, nullptr, nullptr, nullptr, nullptr, 0, (hipStream_t)stream);
+}
+
+// Is the other workspace set's call still on the device?  (Then this call's tree walks leave it half of the chip.)  Or was it
+// when the previous call was queued?  The first call of a burst finds the device idle; a caller that has just been issuing
+// calls back to back is about to do so again.
+static void note_sharing(ugp_mat *m, int wi) {
+    const ugp_mat::Work &O = m->work[wi ^ 1];
+    const bool busy = O.done && hipEventQuery(O.done) == hipErrorNotReady;
+    (void)hipGetLastError();   // (hipErrorNotReady is not an error)
+    m->sharing = busy || m->was_busy;
+    m->was_busy = busy;
+    if (m->knobs.debug_sharing) fprintf(stderr, "[ugp] call on set %d: sharing=%d\n", wi, (int)m->sharing);
+}
+
+// The opt-in form: consecutive calls alternate between the handle's two workspace sets and run on two streams of its own,
+// so that two batches are on the device at a time and the small latency-bound kernels around k_best8 of one fill the idle
+// issue slots of the other's (measured +18 % placements/s at 16,384 samples per call, +50 % with the half-size grids).
+// Ordering (include/usher_amd.h): `stream` receives every call's completion, in call order; a call is ordered behind the
+// work that was queued on `stream` before the PREVIOUS overlapped call on this handle (one call of lag: work queued since
+// then sits behind that call's completion and would serialise the two) -- and behind all of it when the handle is idle.
+int ugp_place_device_overlapped(ugp_mat *m, ugp_qset *qs, void *d_out, void *stream) {
+    if (!m || !qs || (!d_out && qs->n_queries)) return fail(UGP_ERR_INVALID, "null argument");
+    if (qs->device != m->device) return fail(UGP_ERR_INVALID, "query set lives on another device");
     HIP_TRY(hipSetDevice(m->device));
-    if (!m->primed) {
-        // The handle's first call runs once on each workspace set (the second run is the one whose results stay): the buffers
-        // of both sets exist from then on, instead of the second call stalling the pipeline on device allocations.
-        m->primed = true;
-        ugp_mat::Work &W1 = m->work[1];
-        if (!W1.stream) HIP_TRY(hipStreamCreateWithFlags(&W1.stream, hipStreamNonBlocking));
-        if (int rc = run_place(m, qs, 0, (ugp_result *)d_out, nullptr, nullptr, nullptr, nullptr, nullptr, 0, W1.stream, false, nullptr, 1)) return rc;
-        HIP_TRY(hipStreamSynchronize(W1.stream));
-        m->next_work = 0;
-    }
     const int wi = m->next_work;
     m->next_work ^= 1;
     ugp_mat::Work &W = m->work[wi];
     if (!W.stream) HIP_TRY(hipStreamCreateWithFlags(&W.stream, hipStreamNonBlocking));
-    {   // is the other set's call still on the device?  (then this call's tree walk leaves it half of the chip)
-        // (or was it when the previous call was queued?  The first call of a burst finds the device idle; a caller that has just
-        // been issuing calls back to back is about to do so again.)
-        const ugp_mat::Work &O = m->work[wi ^ 1];
-        const bool busy = O.done && hipEventQuery(O.done) == hipErrorNotReady;
-        (void)hipGetLastError();   // (hipErrorNotReady is not an error)
-        m->sharing = busy || m->was_busy;
-        m->was_busy = busy;
-        if (getenv("UGP_DEBUG_SHARING")) fprintf(stderr, "[ugp] call on set %d: sharing=%d\n", wi, (int)m->sharing);
-    }
+    if (!W.entry) HIP_TRY(hipEventCreateWithFlags(&W.entry, hipEventDisableTiming));
+    note_sharing(m, wi);
     struct Unshare { ugp_mat *m; ~Unshare() { m->sharing = false; } } unshare{m};
+    // what was on the caller's stream when this call was made ...
+    HIP_TRY(hipEventRecord(W.entry, (hipStream_t)stream));
+    W.entry_valid = true;
+    // ... is waited for by the NEXT call (which has to wait for the call before this one anyway: same workspaces); this call
+    // waits for what the previous call saw -- or, when that call is no longer running, for everything (nothing to overlap with)
+    const ugp_mat::Work &O = m->work[wi ^ 1];
+    if (!m->was_busy) HIP_TRY(hipStreamWaitEvent(W.stream, W.entry, 0));
+    else if (O.entry_valid) HIP_TRY(hipStreamWaitEvent(W.stream, O.entry, 0));
     if (int rc = run_place(m, qs, 0, (ugp_result *)d_out, nullptr, nullptr, nullptr, nullptr, nullptr, 0, W.stream, false, nullptr, wi)) return rc;
     if (W.done) HIP_TRY(hipStreamWaitEvent((hipStream_t)stream, W.done, 0));   // (recorded at the end of run_place)
     return UGP_OK;
@@ -1059,17 +1086,6 @@ int ugp_place_batch_async(ugp_mat *m, const ugp_queries *q, ugp_result *out, ugp
     if (!m || !q || !job || (!out && q->n_queries)) return fail(UGP_ERR_INVALID, "null argument");
     *job = nullptr;
     HIP_TRY(hipSetDevice(m->device));
-    if (!m->primed) {   // both workspace sets through one (synchronous) call first, as ugp_place_device does
-        std::vector<ugp_result> tmp(q->n_queries);
-        ugp_qset *qs = nullptr;
-        if (int rc = ugp_qset_upload(m, q, &qs)) return rc;
-        DevBuf<ugp_result> d_tmp;
-        int rc = d_tmp.reserve(q->n_queries) == hipSuccess ? UGP_OK : fail(UGP_ERR_HIP, "hipMalloc");
-        if (rc == UGP_OK) rc = ugp_place_device(m, qs, d_tmp.p, nullptr);
-        (void)hipDeviceSynchronize();
-        ugp_qset_destroy(qs);
-        if (rc != UGP_OK) return rc;
-    }
     const int wi = m->next_work;
     ugp_mat::Work &W = m->work[wi];
     if (W.job_busy) return fail(UGP_ERR_INVALID, "two jobs are in flight on this handle: ugp_job_wait the oldest first");
@@ -1080,13 +1096,7 @@ int ugp_place_batch_async(ugp_mat *m, const ugp_queries *q, ugp_result *out, ugp
     if (int rc = qset_fill(m, q, W.job_qs, W.stream, &W.job_in)) return rc;
     HIP_TRY(W.d_job_out.reserve(q->n_queries));
     if (int rc = W.job_out.reserve(std::max<size_t>(q->n_queries, 1) * sizeof(ugp_result) + 8)) return rc;
-    {   // (as in ugp_place_device: is the other set's job still on the device?)
-        const ugp_mat::Work &O = m->work[wi ^ 1];
-        const bool busy = O.done && hipEventQuery(O.done) == hipErrorNotReady;
-        (void)hipGetLastError();
-        m->sharing = busy || m->was_busy;
-        m->was_busy = busy;
-    }
+    note_sharing(m, wi);   // (is the other set's job still on the device?)
     int rc = run_place(m, W.job_qs, 0, W.d_job_out.p, nullptr, nullptr, nullptr, nullptr, nullptr, 0, W.stream, false, nullptr, wi);
     m->sharing = false;
     if (rc != UGP_OK) return rc;
@@ -1179,7 +1189,7 @@ int ugp_tied_nodes(ugp_mat *m, const ugp_queries *q, uint32_t cap, uint32_t *tie
     // first, then the one-sample-per-lane walk of the whole tree that appends every node attaining them.
     if (rc == UGP_OK) chk(hipMemsetAsync(d_cnt.p, 0, padded * sizeof(uint32_t), nullptr), "memset");
     m->tie_lists_filled = m->tie_sub_batches = 0;
-    if (rc == UGP_OK) rc = run_place(m, qs, 0, d_res.p, nullptr, nullptr, getenv("UGP_TIES_DFS") ? nullptr : d_cnt.p, d_j.p, d_hu.p, cap, nullptr);
+    if (rc == UGP_OK) rc = run_place(m, qs, 0, d_res.p, nullptr, nullptr, m->knobs.ties_dfs ? nullptr : d_cnt.p, d_j.p, d_hu.p, cap, nullptr);
     const bool filled = rc == UGP_OK && m->tie_sub_batches > 0 && m->tie_lists_filled == m->tie_sub_batches;
     if (rc == UGP_OK && !filled) {   // the wanted scores stay on the device
         chk(ugp::launch_extract_best(d_res.p, (uint32_t)Q, d_best.p, nullptr), "extract best");
@@ -1435,12 +1445,12 @@ static int harvest_timing(ugp_mat *m, ugp_mat::Work &W, ugp_mat::Work::Gen &G) {
         if (G.coarse_timed) { HIP_TRY(hipEventSynchronize(G.ev_coarse[1])); HIP_TRY(hipEventElapsedTime(&G.last.coarse_ms, G.ev_coarse[0], G.ev_coarse[1])); }
         G.last.words_total = W.last_words_total;
         G.last.words_skipped = 0;
-        if (W.last_used_best8 && W.d_stats.p && getenv("UGP_STATS")) {   // (debug counters: a blocking copy)
+        if (W.last_used_best8 && W.d_stats.p && m->knobs.stats) {   // (debug counters: a blocking copy)
             uint64_t v[64] = {0};
             HIP_TRY(hipMemcpy(v, W.d_stats.p, sizeof v, hipMemcpyDeviceToHost));
             G.last.words_skipped = v[0];
             G.last.reserved = (uint32_t)std::min<uint64_t>(v[1], 0xFFFFFFFFull);   // pipeline (re)starts
-            if (const char *tf = getenv("UGP_TRACE")) {
+            if (const char *tf = m->knobs.trace.empty() ? nullptr : m->knobs.trace.c_str()) {
                 if (W.d_trace.p) {
                     uint64_t n = 0;
                     HIP_TRY(hipMemcpy(&n, W.d_trace.p, 8, hipMemcpyDeviceToHost));
@@ -1451,7 +1461,7 @@ static int harvest_timing(ugp_mat *m, ugp_mat::Work &W, ugp_mat::Work::Gen &G) {
                     fprintf(stderr, "[ugp stats] %llu unit records written to %s\n", (unsigned long long)n, tf);
                 }
             }
-            if (getenv("UGP_STATS")) {
+            {
                 fprintf(stderr, "[ugp stats] restarts=%llu restart_cycles=%llu wave_cycles=%llu max_wave=%llu hist:", (unsigned long long)v[1],
                         (unsigned long long)v[2], (unsigned long long)v[3], (unsigned long long)v[4]);
                 for (int i = 0; i < 16; i++) fprintf(stderr, " %llu", (unsigned long long)v[5 + i]);
@@ -1510,6 +1520,25 @@ int ugp_get_timing_sum(ugp_mat *m, ugp_timing *sum, uint32_t *n_calls) {
     m->tsum = {};
     m->tsum_calls = 0;
     return UGP_OK;
+}
+
+// Test / tuning hook: read the handle's per-call tuning switches from the environment again (tools that sweep knobs on one
+// handle; the switches that shape the flattening -- chunk size, pruning records, LDS slots -- need a new handle).
+int ugp_mat_reload_knobs(ugp_mat *m) {
+    if (!m) return fail(UGP_ERR_INVALID, "null argument");
+    m->knobs = ugp::Knobs::from_env();
+    if (m->coarse) m->coarse->knobs = m->knobs;
+    return UGP_OK;
+}
+
+// 1 when this library was built with the experiments and diagnostics (UGP_STATS, UGP_TRACE, UGP_SEED_PREV / _CHECK,
+// UGP_PHASE2_PACKED, UGP_KBEST_EXCLUSIVE), 0 for the release build, which ignores those variables.
+int ugp_has_experiments(void) {
+#ifdef UGP_EXPERIMENTS
+    return 1;
+#else
+    return 0;
+#endif
 }
 
 // Test / tuning hook (not part of the drop-in surface): ugp_mat_create with an

@@ -85,7 +85,12 @@ __global__ void k_scatter_entries(uint32_t *__restrict__ table, uint32_t *__rest
                                   uint32_t max_pos, uint32_t n_sites, uint64_t n_ent, uint32_t q_base,
                                   uint32_t *__restrict__ active, uint32_t active_words,
                                   const uint32_t *__restrict__ slot_of,
-                                  const uint32_t *__restrict__ row_list, const uint32_t *__restrict__ n_listed, uint32_t n_q) {
+                                  const uint32_t *__restrict__ row_list, const uint32_t *__restrict__ n_listed, uint32_t n_q,
+                                  const unsigned long long *__restrict__ err) {
+    // A batch whose rows failed k_rows_prepare's checks (its verdict is read by the host only after the whole pipeline has been
+    // queued: ugp_place_batch_async) is placed as if it had no rows at all: the table stays "reference everywhere", D(bottom) 0,
+    // so that nothing downstream ever sees duplicate or unsorted rows.  The caller gets the error, never these results.
+    if (err && *err != ~0ull) return;
     // (with a row list -- the rows that are not missing, k_nmask_build -- the kernel strides over it: its length is only known
     // on the device; rows of samples outside [q_base, q_base + n_q) belong to another sub-batch)
     const uint64_t n_items = row_list ? (uint64_t)*n_listed : n_ent;
@@ -221,8 +226,9 @@ __global__ void __launch_bounds__(256) k_build_tiles(uint32_t *__restrict__ tabl
                                                      const int32_t *__restrict__ pos, const uint8_t *__restrict__ ref, const uint8_t *__restrict__ nuc,
                                                      const uint8_t *__restrict__ is_missing, const int32_t *__restrict__ pos2site,
                                                      const int32_t *__restrict__ site_pos, const uint8_t *__restrict__ site_ref, uint32_t n_sites,
-                                                     uint32_t max_pos) {
+                                                     uint32_t max_pos, const unsigned long long *__restrict__ err) {
     __shared__ uint32_t rows[TB_SITES * 64];
+    const bool bad_rows = err && *err != ~0ull;   // (see k_scatter_entries: such a batch is built as if it had no rows)
     __shared__ uint32_t act[TB_SITES];
     const uint32_t tile = blockIdx.y, s0 = blockIdx.x * TB_SITES, s1 = min(s0 + TB_SITES, n_sites), tid = threadIdx.x;
     for (uint32_t i = tid; i < TB_SITES * 64; i += 256) {
@@ -235,7 +241,7 @@ __global__ void __launch_bounds__(256) k_build_tiles(uint32_t *__restrict__ tabl
     const int64_t P1 = s1 < n_sites ? (int64_t)site_pos[s1] : (int64_t)max_pos + 1;
     for (uint32_t i = tid; i < 512; i += 256) {
         const uint32_t slot = tile * 512 + i;
-        if (slot >= nq) continue;
+        if (slot >= nq || bad_rows) continue;
         const uint32_t q = q0 + (order ? order[slot] : slot);
         uint64_t lo = ent_off[q], hi = ent_off[q + 1];
         const uint64_t re = hi;
@@ -268,11 +274,11 @@ __global__ void __launch_bounds__(256) k_build_tiles(uint32_t *__restrict__ tabl
 // (usher_mapper.cpp:292-388 with an empty ancestral list).
 __global__ void __launch_bounds__(256) k_row_counts(const uint64_t *__restrict__ ent_off, uint32_t q0, const uint32_t *__restrict__ order, uint32_t nq,
                                                     const uint8_t *__restrict__ ref, const uint8_t *__restrict__ nuc, const uint8_t *__restrict__ is_missing,
-                                                    uint32_t *__restrict__ dbottom) {
+                                                    uint32_t *__restrict__ dbottom, const unsigned long long *__restrict__ err) {
     const uint32_t slot = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63u;
     if (slot >= nq) return;
     const uint32_t q = q0 + (order ? order[slot] : slot);
-    const uint64_t rb = ent_off[q], re = ent_off[q + 1];
+    const uint64_t rb = ent_off[q], re = (err && *err != ~0ull) ? rb : ent_off[q + 1];
     uint32_t d = 0;
     for (uint64_t r = rb + lane; r < re; r += 64) {
         const uint32_t rr = ref[r], a = is_missing[r] ? 15u : (uint32_t)nuc[r];
@@ -2073,10 +2079,10 @@ hipError_t launch_seed_ub(const ugp_result *coarse_res, const uint32_t *order, u
 
 hipError_t launch_descend(const ugp_result *coarse_res, const uint32_t *order, uint32_t n_queries, const uint32_t *coarse2bfs,
                           const uint32_t *node_pair, const uint32_t *parent, const uint32_t *stream, const uint32_t *table,
-                          uint32_t n_sites, uint32_t *refined, bool wide, hipStream_t s) {
+                          uint32_t n_sites, uint32_t *refined, bool wide, uint32_t max_expansions, int slack, hipStream_t s) {
     if (!n_queries) return hipSuccess;
-    const uint32_t max_exp = getenv("UGP_DESCENT_MAX") ? (uint32_t)std::max(1, atoi(getenv("UGP_DESCENT_MAX"))) : DESC_MAX_EXPANSIONS;   // (tuning)
-    const int slack = getenv("UGP_DESCENT_SLACK") ? atoi(getenv("UGP_DESCENT_SLACK")) : 2;   // (measured at 10M nodes: 0 costs the main walk 60 %, 1..5 are alike, none is 8 % more descent)
+    const uint32_t max_exp = max_expansions ? max_expansions : DESC_MAX_EXPANSIONS;   // (tuning)
+    // (slack, measured at 10M nodes: 0 costs the main walk 60 %, 1..5 are alike, none is 8 % more descent)
     if (wide)
         hipLaunchKernelGGL(k_descend<64>, dim3((n_queries + 3) / 4), dim3(256), 0, s, coarse_res, order, n_queries, coarse2bfs, (const uint2 *)node_pair, parent,
                            stream, table, n_sites, refined, max_exp, slack);
@@ -2111,22 +2117,22 @@ hipError_t launch_fill_table(uint32_t *table, const uint8_t *site_ref, uint32_t 
 hipError_t launch_build_tiles(uint32_t *table, uint32_t *active, uint32_t active_words, uint32_t n_tiles512, const uint64_t *ent_off, uint32_t q0,
                               const uint32_t *order, uint32_t nq, const int32_t *pos, const uint8_t *ref, const uint8_t *nuc, const uint8_t *is_missing,
                               const int32_t *pos2site, const int32_t *site_pos, const uint8_t *site_ref, uint32_t n_sites, uint32_t max_pos,
-                              uint32_t *dbottom, hipStream_t s) {
+                              uint32_t *dbottom, const unsigned long long *err, hipStream_t s) {
     if (!n_tiles512 || !n_sites) return hipSuccess;
     hipLaunchKernelGGL(k_build_tiles, dim3((n_sites + TB_SITES - 1) / TB_SITES, n_tiles512), dim3(256), 0, s, table, active, active_words, ent_off, q0, order, nq,
-                       pos, ref, nuc, is_missing, pos2site, site_pos, site_ref, n_sites, max_pos);
-    hipLaunchKernelGGL(k_row_counts, dim3((nq + 3) / 4), dim3(256), 0, s, ent_off, q0, order, nq, ref, nuc, is_missing, dbottom);
+                       pos, ref, nuc, is_missing, pos2site, site_pos, site_ref, n_sites, max_pos, err);
+    hipLaunchKernelGGL(k_row_counts, dim3((nq + 3) / 4), dim3(256), 0, s, ent_off, q0, order, nq, ref, nuc, is_missing, dbottom, err);
     return hipGetLastError();
 }
 
 hipError_t launch_scatter(uint32_t *table, uint32_t *dbottom, const int32_t *pos, const uint8_t *ref,
                           const uint8_t *nuc, const uint8_t *is_missing, const uint32_t *ent_q,
                           const int32_t *pos2site, uint32_t max_pos, uint32_t n_sites, uint64_t n_ent, uint32_t q_base,
-                          uint32_t *active, uint32_t active_words, const uint32_t *slot_of, hipStream_t s) {
+                          uint32_t *active, uint32_t active_words, const uint32_t *slot_of, const unsigned long long *err, hipStream_t s) {
     if (n_ent == 0) return hipSuccess;
     uint64_t blocks = (n_ent + 255) / 256;
     hipLaunchKernelGGL(k_scatter_entries, dim3((uint32_t)blocks), dim3(256), 0, s, table, dbottom, pos, ref, nuc,
-                       is_missing, ent_q, pos2site, max_pos, n_sites, n_ent, q_base, active, active_words, slot_of, nullptr, nullptr, 0u);
+                       is_missing, ent_q, pos2site, max_pos, n_sites, n_ent, q_base, active, active_words, slot_of, nullptr, nullptr, 0u, err);
     return hipGetLastError();
 }
 
@@ -2134,9 +2140,9 @@ hipError_t launch_scatter(uint32_t *table, uint32_t *dbottom, const int32_t *pos
 hipError_t launch_scatter_list(uint32_t *table, uint32_t *dbottom, const int32_t *pos, const uint8_t *ref, const uint8_t *nuc, const uint8_t *is_missing,
                                const uint32_t *ent_q, const int32_t *pos2site, uint32_t max_pos, uint32_t n_sites, uint32_t q_base, uint32_t n_q,
                                uint32_t *active, uint32_t active_words, const uint32_t *slot_of, const uint32_t *row_list, const uint32_t *n_listed,
-                               hipStream_t s) {
+                               const unsigned long long *err, hipStream_t s) {
     hipLaunchKernelGGL(k_scatter_entries, dim3(2048), dim3(256), 0, s, table, dbottom, pos, ref, nuc, is_missing, ent_q, pos2site, max_pos, n_sites,
-                       (uint64_t)0, q_base, active, active_words, slot_of, row_list, n_listed, n_q);
+                       (uint64_t)0, q_base, active, active_words, slot_of, row_list, n_listed, n_q, err);
     return hipGetLastError();
 }
 
@@ -2170,11 +2176,11 @@ hipError_t launch_place(const PlaceArgs &a, int mode, uint32_t max_slots, hipStr
 // One launch per level; level_off: host array of the breadth-first level boundaries.  d16: D fits 16 bits.
 hipError_t launch_scores_levels(const uint32_t *node_pair, const uint32_t *parent, const uint32_t *stream, const uint32_t *table, uint32_t n_sites,
                                 const uint32_t *dbottom, const uint32_t *level_off, uint32_t n_levels, void *d_a, void *d_b, bool d16, uint32_t d_stride,
-                                uint32_t qpad, uint32_t n_queries, uint64_t n_nodes, int32_t *scores, hipStream_t s) {
+                                uint32_t qpad, uint32_t n_queries, uint64_t n_nodes, int32_t *scores, uint32_t block, hipStream_t s) {
+    const uint32_t bs = block ? block : 1024u;   // (tuning: threads per block)
     for (uint32_t l = 0; l < n_levels; l++) {
         const uint32_t b = level_off[l], e = level_off[l + 1], pb = l ? level_off[l - 1] : 0u;
         if (e <= b) continue;
-        static const uint32_t bs = getenv("UGP_SCORES_BLOCK") ? (uint32_t)std::min(1024, std::max(64, atoi(getenv("UGP_SCORES_BLOCK")) / 64 * 64)) : 1024u;
         const uint32_t bx = (e - b + bs - 1u) / bs;
         // narrow levels: the sample groups spread over blockIdx.y so that the top of the tree does not run on a handful of waves
         uint32_t by = 1;
@@ -2200,16 +2206,22 @@ hipError_t launch_merge(const uint32_t *part_best, const uint32_t *part_cnt, con
 }
 
 // Resident one-wave blocks of k_best8 per CU for a given dynamic LDS size, on the current device.
-hipError_t best8_occupancy(size_t lds_bytes, int *per_cu) {
+// variant: 0 = the main walk, 1 = with the active-row bitmap in LDS, 2 = the coarse pass (records which node set each minimum) --
+// their register and LDS needs differ, and the persistent grid and its cold-slot scratch are sized from this number.
+hipError_t best8_occupancy(size_t lds_bytes, int variant, int *per_cu) {
+    if (variant == 1) return hipOccupancyMaxActiveBlocksPerMultiprocessor(per_cu, k_best8<false, true, false, false>, 64, lds_bytes);
+    if (variant == 2) return hipOccupancyMaxActiveBlocksPerMultiprocessor(per_cu, k_best8<false, false, true, false>, 64, lds_bytes);
     return hipOccupancyMaxActiveBlocksPerMultiprocessor(per_cu, k_best8<false, false, false, false>, 64, lds_bytes);
 }
 
 // Persistent grid of `blocks` one-wave workgroups (the caller sizes a.cold for exactly that many).
 hipError_t launch_best8(const Best8Args &a, uint32_t blocks, hipStream_t s) {
     const size_t lds = (size_t)a.lds_slots * 64 * 16;   // the D rows of the hot slots (their B halves live in registers)
-    if (a.tie_cnt) hipLaunchKernelGGL((k_best8<false, false, false, true>), dim3(blocks), dim3(64), lds, s, a);   // (phase 2)
-    else if (a.lpos) hipLaunchKernelGGL((k_best8<false, false, true, false>), dim3(blocks), dim3(64), lds, s, a);   // (the coarse pass; no statistics there)
-    else if (a.stats) hipLaunchKernelGGL((k_best8<true, false, false, false>), dim3(blocks), dim3(64), lds, s, a);
+#ifdef UGP_EXPERIMENTS   // (the statistics build of the walk and phase 2 as a mode of it exist only in libusher_amd_exp.so)
+    if (a.tie_cnt) { hipLaunchKernelGGL((k_best8<false, false, false, true>), dim3(blocks), dim3(64), lds, s, a); return hipGetLastError(); }   // (phase 2)
+    if (a.stats && !a.lpos) { hipLaunchKernelGGL((k_best8<true, false, false, false>), dim3(blocks), dim3(64), lds, s, a); return hipGetLastError(); }
+#endif
+    if (a.lpos) hipLaunchKernelGGL((k_best8<false, false, true, false>), dim3(blocks), dim3(64), lds, s, a);   // (the coarse pass; no statistics there)
     else if (a.lds_bits) hipLaunchKernelGGL((k_best8<false, true, false, false>), dim3(blocks), dim3(64), lds + (((size_t)a.active_words * 4 + 15) & ~(size_t)15), s, a);
     else hipLaunchKernelGGL((k_best8<false, false, false, false>), dim3(blocks), dim3(64), lds, s, a);
     return hipGetLastError();
@@ -2223,6 +2235,7 @@ hipError_t launch_coarse_result(const uint32_t *lbest, const uint32_t *lpos, con
     return hipGetLastError();
 }
 
+#ifdef UGP_EXPERIMENTS
 // Phase 2 as a mode of the packed walk (k_best8<TIES>): b = the arguments of the phase-1 walk it follows; units: room for n_chunks entries per
 // tile, info: 128 dwords, blocks: the walk's grid (its cold-slot scratch is reused).
 hipError_t launch_phase2_packed(const Best8Args &b1, const uint32_t *list, const uint32_t *list_n, uint32_t *gbest_part, uint32_t *gbest, uint32_t n_tiles512,
@@ -2248,6 +2261,7 @@ hipError_t launch_phase2_packed(const Best8Args &b1, const uint32_t *list, const
     hipLaunchKernelGGL(k_final, dim3((n_queries + 255) / 256), dim3(256), 0, s, gbest, cnt, key, rank2bfs, n_queries, out, order);
     return hipGetLastError();
 }
+#endif
 
 hipError_t launch_phase2(const PlaceArgs &a, const uint32_t *lbest, const uint32_t *list, const uint32_t *list_n, uint32_t *gbest_part,
                          uint32_t *gbest, uint32_t n_tiles512,

@@ -83,8 +83,8 @@ constexpr uint32_t SCORES_SB = 32;   // samples per step of k_scores_level (a mu
 // -p by levels of the breadth-first expansion (see k_scores_level): d_a / d_b = two D arrays of max level width x qpad (rounded up to SCORES_SB) entries
 hipError_t launch_scores_levels(const uint32_t *node_pair, const uint32_t *parent, const uint32_t *stream, const uint32_t *table, uint32_t n_sites,
                                 const uint32_t *dbottom, const uint32_t *level_off, uint32_t n_levels, void *d_a, void *d_b, bool d16, uint32_t d_stride,
-                                uint32_t qpad, uint32_t n_queries, uint64_t n_nodes, int32_t *scores, hipStream_t s);
-hipError_t best8_occupancy(size_t lds_bytes, int *per_cu);
+                                uint32_t qpad, uint32_t n_queries, uint64_t n_nodes, int32_t *scores, uint32_t block /* 0: default */, hipStream_t s);
+hipError_t best8_occupancy(size_t lds_bytes, int variant /* 0 main, 1 LDS bitmap, 2 coarse pass */, int *per_cu);
 hipError_t launch_best8(const Best8Args &a, uint32_t blocks, hipStream_t s);
 // a.n_tiles = number of 64-sample tiles; lbest/gbest in the packed 512-tile layout
 constexpr uint32_t GBEST_SLICES = 64;   // chunk-axis slices of the global-minimum reduction
@@ -112,11 +112,12 @@ hipError_t launch_fill_table(uint32_t *table, const uint8_t *site_ref, uint32_t 
 hipError_t launch_build_tiles(uint32_t *table, uint32_t *active, uint32_t active_words, uint32_t n_tiles512, const uint64_t *ent_off, uint32_t q0,
                               const uint32_t *order /* slot -> sample of the sub-batch, or null */, uint32_t nq, const int32_t *pos, const uint8_t *ref,
                               const uint8_t *nuc, const uint8_t *is_missing, const int32_t *pos2site, const int32_t *site_pos, const uint8_t *site_ref,
-                              uint32_t n_sites, uint32_t max_pos, uint32_t *dbottom, hipStream_t s);
+                              uint32_t n_sites, uint32_t max_pos, uint32_t *dbottom, const unsigned long long *err /* k_rows_prepare's verdict, or null */,
+                              hipStream_t s);
 hipError_t launch_scatter(uint32_t *table, uint32_t *dbottom, const int32_t *pos, const uint8_t *ref,
                           const uint8_t *nuc, const uint8_t *is_missing, const uint32_t *ent_q,
                           const int32_t *pos2site, uint32_t max_pos, uint32_t n_sites, uint64_t n_ent, uint32_t q_base,
-                          uint32_t *active, uint32_t active_words, const uint32_t *slot_of, hipStream_t s);
+                          uint32_t *active, uint32_t active_words, const uint32_t *slot_of, const unsigned long long *err, hipStream_t s);
 // tiles of batches with many missing rows: N bits per (sample, site) built once per query set, tiles transposed from them
 hipError_t launch_nmask_build(const uint64_t *ent_off, uint32_t n_queries, const int32_t *pos, const uint8_t *is_missing, const int32_t *pos2site,
                               uint32_t max_pos, uint32_t words, uint32_t *nmask, uint32_t *plain_rows /* or null */, uint32_t *n_plain, hipStream_t s);
@@ -125,7 +126,7 @@ hipError_t launch_ntiles(uint32_t *table, uint32_t *active, uint32_t active_word
 hipError_t launch_scatter_list(uint32_t *table, uint32_t *dbottom, const int32_t *pos, const uint8_t *ref, const uint8_t *nuc, const uint8_t *is_missing,
                                const uint32_t *ent_q, const int32_t *pos2site, uint32_t max_pos, uint32_t n_sites, uint32_t q_base, uint32_t n_q,
                                uint32_t *active, uint32_t active_words, const uint32_t *slot_of, const uint32_t *row_list, const uint32_t *n_listed,
-                               hipStream_t s);
+                               const unsigned long long *err, hipStream_t s);
 // locality sort (see k_sort_keys); temp == nullptr: only *temp_bytes is filled
 hipError_t launch_tile_ranges(const uint32_t *keys_sorted, uint32_t n_queries, uint32_t n_tiles512, const uint32_t *chunk_node_off,
                               uint32_t n_chunks, uint32_t align, uint32_t *hstart, uint32_t *hlen, hipStream_t s);
@@ -133,7 +134,7 @@ hipError_t launch_tile_ranges(const uint32_t *keys_sorted, uint32_t n_queries, u
 hipError_t launch_descend(const ugp_result *coarse_res, const uint32_t *order, uint32_t n_queries, const uint32_t *coarse2bfs,
                           const uint32_t *node_pair /* [n_nodes + 1][2]: child_begin, rec_off */, const uint32_t *parent, const uint32_t *stream,
                           const uint32_t *table, uint32_t n_sites, uint32_t *refined, bool wide /* a whole wave per sample: trees with large polytomies */,
-                          hipStream_t s);
+                          uint32_t max_expansions /* 0: default */, int slack, hipStream_t s);
 hipError_t launch_seed_ub(const ugp_result *coarse_res, const uint32_t *order, uint32_t n_queries, uint32_t n_tiles512, uint32_t *ub,
                           const uint32_t *refined /* [n_queries] by sorted slot, or null */,
                           uint32_t *dbottom /* or null: D(bottom) of the unused slots of the last tile is set to pad_d, their bound to 0 */, uint32_t pad_d,

@@ -133,20 +133,31 @@ class FlatTreeView:
 class Placer:
     """A flattened MAT resident on one GPU (ugp_mat) plus the batch entry points."""
 
-    def __init__(self, arrays: Dict, device: int = 0, chunk_nodes: Optional[int] = None):
-        L = _lib.lib()
+    def __init__(self, arrays: Dict, device: int = 0, chunk_nodes: Optional[int] = None, experiments: bool = False):
+        """experiments=True binds libusher_amd_exp.so (built with -DUGP_EXPERIMENTS: UGP_STATS, UGP_TRACE, UGP_SEED_*,
+        UGP_PHASE2_PACKED, UGP_KBEST_EXCLUSIVE); the release library ignores those variables.  The tuning switches are read
+        from the environment here, once; reload_knobs() reads them again."""
+        L = self._L = _lib.lib(experiments)
         self._t = _TreeArrays(arrays)
         self.n_nodes = self._t.n
         self._h = C.c_void_p()
         if chunk_nodes is None:
-            _check(L.ugp_mat_create(C.byref(self._t.desc), device, C.byref(self._h)))
+            self._ck(L.ugp_mat_create(C.byref(self._t.desc), device, C.byref(self._h)))
         else:
-            _check(L.ugp_mat_create_chunked(C.byref(self._t.desc), device, int(chunk_nodes), C.byref(self._h)))
+            self._ck(L.ugp_mat_create_chunked(C.byref(self._t.desc), device, int(chunk_nodes), C.byref(self._h)))
         self.device = device
+
+    def _ck(self, rc: int) -> None:
+        if rc != 0:
+            raise UgpError(rc, (self._L.ugp_last_error() or b"").decode())
+
+    def reload_knobs(self) -> None:
+        """ugp_mat_reload_knobs: the per-call tuning switches from the environment again (test / tuning hook)."""
+        self._ck(self._L.ugp_mat_reload_knobs(self._h))
 
     def close(self) -> None:
         if getattr(self, "_h", None) and self._h.value:
-            _lib.lib().ugp_mat_destroy(self._h)
+            self._L.ugp_mat_destroy(self._h)
             self._h = C.c_void_p()
 
     def __del__(self):
@@ -157,13 +168,13 @@ class Placer:
 
     def info(self) -> Dict:
         out = _lib.ugp_info()
-        _check(_lib.lib().ugp_mat_info(self._h, C.byref(out)))
+        self._ck(self._L.ugp_mat_info(self._h, C.byref(out)))
         return {k: getattr(out, k) for k, _ in out._fields_}
 
     def place(self, batch: QueryBatch) -> np.ndarray:
         """ugp_place_batch: structured array (best_set_difference, num_best, best_j, best_has_unique)."""
         out = np.zeros(len(batch), dtype=RESULT_DTYPE)
-        _check(_lib.lib().ugp_place_batch(self._h, C.byref(batch.desc), _ptr(out)))
+        self._ck(self._L.ugp_place_batch(self._h, C.byref(batch.desc), _ptr(out)))
         return out
 
     def place_async(self, batch: QueryBatch):
@@ -171,24 +182,24 @@ class Placer:
         jobs may be outstanding; the batch's arrays may be reused as soon as this returns."""
         out = np.zeros(len(batch), dtype=RESULT_DTYPE)
         job = C.c_void_p()
-        _check(_lib.lib().ugp_place_batch_async(self._h, C.byref(batch.desc), _ptr(out), C.byref(job)))
+        self._ck(self._L.ugp_place_batch_async(self._h, C.byref(batch.desc), _ptr(out), C.byref(job)))
         return (job, out)
 
     def job_wait(self, job) -> np.ndarray:
         h, out = job
-        _check(_lib.lib().ugp_job_wait(h))
+        self._ck(self._L.ugp_job_wait(h))
         return out
 
     def scores_per_node(self, batch: QueryBatch) -> np.ndarray:
         out = np.zeros((len(batch), self.n_nodes), dtype=np.int32)
-        _check(_lib.lib().ugp_scores_per_node(self._h, C.byref(batch.desc), _ptr(out)))
+        self._ck(self._L.ugp_scores_per_node(self._h, C.byref(batch.desc), _ptr(out)))
         return out
 
     def tied_nodes(self, batch: QueryBatch, cap: int):
         tj = np.zeros((len(batch), max(cap, 1)), dtype=np.uint32)
         th = np.zeros((len(batch), max(cap, 1)), dtype=np.uint8)
         tc = np.zeros(len(batch), dtype=np.uint32)
-        _check(_lib.lib().ugp_tied_nodes(self._h, C.byref(batch.desc), cap, _ptr(tj), _ptr(th), _ptr(tc)))
+        self._ck(self._L.ugp_tied_nodes(self._h, C.byref(batch.desc), cap, _ptr(tj), _ptr(th), _ptr(tc)))
         return [tj[i, :min(int(tc[i]), cap)].copy() for i in range(len(batch))], \
                [th[i, :min(int(tc[i]), cap)].astype(bool) for i in range(len(batch))], tc
 
@@ -208,7 +219,7 @@ class Placer:
         out = np.zeros(len(batch), dtype=RESULT_DTYPE)
         scores = np.zeros((len(batch), self.n_nodes), dtype=np.int32) if want_scores else None
         o, keep = self._opts(batch, order, node_mask, skip_node, distance, scores)
-        _check(_lib.lib().ugp_place_batch_ex(self._h, C.byref(batch.desc), C.byref(o), _ptr(out)))
+        self._ck(self._L.ugp_place_batch_ex(self._h, C.byref(batch.desc), C.byref(o), _ptr(out)))
         return (out, scores) if want_scores else out
 
     def tied_nodes_ex(self, batch: QueryBatch, cap: int, order: str = "bfs", node_mask=None, skip_node=None, distance=None):
@@ -216,42 +227,48 @@ class Placer:
         th = np.zeros((len(batch), max(cap, 1)), dtype=np.uint8)
         tc = np.zeros(len(batch), dtype=np.uint32)
         o, keep = self._opts(batch, order, node_mask, skip_node, distance, None)
-        _check(_lib.lib().ugp_tied_nodes_ex(self._h, C.byref(batch.desc), C.byref(o), cap, _ptr(tj), _ptr(th), _ptr(tc)))
+        self._ck(self._L.ugp_tied_nodes_ex(self._h, C.byref(batch.desc), C.byref(o), cap, _ptr(tj), _ptr(th), _ptr(tc)))
         return [tj[i, :min(int(tc[i]), cap)].copy() for i in range(len(batch))], \
                [th[i, :min(int(tc[i]), cap)].astype(bool) for i in range(len(batch))], tc
 
     def node_order(self, order: str) -> np.ndarray:
         out = np.zeros(self.n_nodes, dtype=np.uint32)
-        _check(_lib.lib().ugp_node_order(self._h, {"bfs": 0, "dfs": 1}[order], _ptr(out)))
+        self._ck(self._L.ugp_node_order(self._h, {"bfs": 0, "dfs": 1}[order], _ptr(out)))
         return out
 
     def subtree_mask(self, root_j: int, max_levels: int, order: str = "bfs") -> np.ndarray:
         out = np.zeros(self.n_nodes, dtype=np.uint8)
-        _check(_lib.lib().ugp_subtree_mask(self._h, {"bfs": 0, "dfs": 1}[order], int(root_j), int(max_levels), _ptr(out)))
+        self._ck(self._L.ugp_subtree_mask(self._h, {"bfs": 0, "dfs": 1}[order], int(root_j), int(max_levels), _ptr(out)))
         return out
 
     # ---- device-resident path (bench / multi-GPU) ---------------------------
     def upload(self, batch: QueryBatch):
         h = C.c_void_p()
-        _check(_lib.lib().ugp_qset_upload(self._h, C.byref(batch.desc), C.byref(h)))
+        self._ck(self._L.ugp_qset_upload(self._h, C.byref(batch.desc), C.byref(h)))
         return h
 
     def free_qset(self, h) -> None:
-        _lib.lib().ugp_qset_destroy(h)
+        self._L.ugp_qset_destroy(h)
 
     def place_device(self, qset, d_out_ptr: int, stream: int = 0) -> None:
-        _check(_lib.lib().ugp_place_device(self._h, qset, C.c_void_p(d_out_ptr), C.c_void_p(stream)))
+        """ugp_place_device: stream-ordered on `stream`, like a kernel launch."""
+        self._ck(self._L.ugp_place_device(self._h, qset, C.c_void_p(d_out_ptr), C.c_void_p(stream)))
+
+    def place_device_overlapped(self, qset, d_out_ptr: int, stream: int = 0) -> None:
+        """ugp_place_device_overlapped: consecutive calls share the device; `stream` gets each call's completion; a call is
+        ordered behind what was on `stream` when the PREVIOUS overlapped call was made (alternate between two output buffers)."""
+        self._ck(self._L.ugp_place_device_overlapped(self._h, qset, C.c_void_p(d_out_ptr), C.c_void_p(stream)))
 
     def timing(self) -> Dict:
         out = _lib.ugp_timing()
-        _check(_lib.lib().ugp_get_timing(self._h, C.byref(out)))
+        self._ck(self._L.ugp_get_timing(self._h, C.byref(out)))
         return {k: getattr(out, k) for k, _ in out._fields_}
 
     def timing_sum(self) -> Dict:
         """Durations summed over every call since the previous timing_sum() (waits for calls in flight); 'calls' = how many."""
         out = _lib.ugp_timing()
         n = C.c_uint32()
-        _check(_lib.lib().ugp_get_timing_sum(self._h, C.byref(out), C.byref(n)))
+        self._ck(self._L.ugp_get_timing_sum(self._h, C.byref(out), C.byref(n)))
         d = {k: getattr(out, k) for k, _ in out._fields_}
         d["calls"] = int(n.value)
         return d
