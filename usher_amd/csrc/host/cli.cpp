@@ -174,3 +174,57 @@ extern "C" int uh_usher_main(int argc, char **argv, const uh::Backend *be) {
     if (!be || !be->place) { fprintf(stderr, "ERROR: no placement backend\n"); return 1; }
     return uh::usher_main(argc, argv, *be);
 }
+
+// Bench / test utilities (no GPU): write the synthetic workload as the files the front end reads, and time the two loaders.
+extern "C" int uh_write_pb_arrays(uint64_t n, const uint32_t *parent, const uint64_t *mut_off, const int32_t *pos, const uint8_t *ref, const uint8_t *par,
+                                  const uint8_t *nuc, const char *path) {
+    std::string err;
+    if (!uh::write_pb_from_arrays(n, parent, mut_off, pos, ref, par, nuc, path, err)) { fprintf(stderr, "%s\n", err.c_str()); return 1; }
+    return 0;
+}
+extern "C" int uh_write_vcf_csr(uint64_t n_samples, const uint64_t *ent_off, const int32_t *pos, const uint8_t *ref, const uint8_t *nuc, const uint8_t *is_missing,
+                                const char *prefix, const char *path) {
+    std::string err;
+    if (!uh::write_vcf_from_csr(n_samples, ent_off, pos, ref, nuc, is_missing, prefix, path, err)) { fprintf(stderr, "%s\n", err.c_str()); return 1; }
+    return 0;
+}
+// out[0] = seconds in load_mat, out[1] = seconds in read_vcf_missing, out[2] = nodes, out[3] = samples, out[4] = sample rows, out[5] = tree mutations
+extern "C" int uh_time_load(const char *pb, const char *vcf, double *out) {
+    uh::Tree T;
+    std::vector<uh::MissingSample> missing;
+    std::string err;
+    const auto t0 = std::chrono::steady_clock::now();
+    if (!uh::load_mat(pb, T, err)) { fprintf(stderr, "%s\n", err.c_str()); return 1; }
+    const auto t1 = std::chrono::steady_clock::now();
+    if (vcf && *vcf && !uh::read_vcf_missing(T, vcf, missing, err)) { fprintf(stderr, "%s\n", err.c_str()); return 1; }
+    const auto t2 = std::chrono::steady_clock::now();
+    out[0] = std::chrono::duration<double>(t1 - t0).count();
+    out[1] = std::chrono::duration<double>(t2 - t1).count();
+    out[2] = (double)T.all_nodes.size();
+    out[3] = (double)missing.size();
+    size_t rows = 0;
+    for (auto &m : missing) rows += m.mutations.size();
+    out[4] = (double)rows;
+    out[5] = (double)T.parsimony_score();
+    return 0;
+}
+
+// Test hook: parse a newick string with the general routine (bulk = 0) or the bulk one (bulk = 1) and describe the tree --
+// one line per node in depth-first order: id, parent id, level, branch length, number of children.  Returns the length
+// needed (the text is truncated to cap - 1), or -1 with the error message in `out`.
+extern "C" long uh_newick_digest(const char *nwk, int bulk, char *out, size_t cap) {
+    uh::Tree T;
+    std::string err, text;
+    const std::string s(nwk);
+    const bool ok = bulk ? uh::tree_from_newick_bulk(s.data(), s.size(), T, err) : uh::tree_from_newick(s, T, err);
+    if (!ok) { snprintf(out, cap, "%s", err.c_str()); return -1; }
+    char line[256];
+    for (uh::Node *n : T.dfs()) {
+        snprintf(line, sizeof line, "|%zu|%g|%zu\n", n->level, (double)n->branch_length, n->children.size());
+        text += n->id; text += '|'; text += n->parent ? n->parent->id : std::string("-"); text += line;
+    }
+    text += "internal=" + std::to_string(T.curr_internal_node) + " nodes=" + std::to_string(T.all_nodes.size()) + "\n";
+    for (uh::Node *n : T.dfs()) if (T.get_node(n->id) != n) text += "INDEX MISMATCH " + n->id + "\n";
+    snprintf(out, cap, "%s", text.c_str());
+    return (long)text.size();
+}

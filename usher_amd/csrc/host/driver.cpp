@@ -377,10 +377,12 @@ static std::vector<Mutation> ordered_rows(const std::vector<Mutation> &rows) {
 }
 static bool tree_alleles_are_bases(const Tree &T) {
     auto one = [](int8_t a) { return a == 1 || a == 2 || a == 4 || a == 8; };
-    for (const auto &kv : T.all_nodes)
-        for (const Mutation &m : kv.second->mutations)
-            if (!m.masked() && (!one(m.mut_nuc) || !one(m.ref_nuc))) return false;
-    return true;
+    bool ok = true;
+    T.all_nodes.for_each([&](const Node *n) {
+        for (const Mutation &m : n->mutations)
+            if (!m.masked() && (!one(m.mut_nuc) || !one(m.ref_nuc))) ok = false;
+    });
+    return ok;
 }
 
 static bool write_text(const std::string &path, const std::string &text) {

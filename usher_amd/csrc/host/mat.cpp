@@ -5,13 +5,37 @@
 
 #include <zlib.h>
 
+#include <sys/stat.h>
+#include <unistd.h>
+
 #include <algorithm>
+#include <atomic>
+#include <chrono>
 #include <cstdio>
 #include <cstring>
 #include <fstream>
+#include <mutex>
+#include <new>
 #include <sstream>
 
+#include "par.hpp"
+
 namespace uh {
+
+namespace {
+struct Lap {   // USHER_AMD_PROFILE=1: where a loader's time goes
+    const bool on = getenv("USHER_AMD_PROFILE") != nullptr;
+    const char *what;
+    std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+    explicit Lap(const char *w) : what(w) {}
+    void operator()(const char *step) {
+        if (!on) return;
+        const auto n = std::chrono::steady_clock::now();
+        fprintf(stderr, "[usher-amd profile] %s: %s %.3f s\n", what, step, std::chrono::duration<double>(n - t).count());
+        t = n;
+    }
+};
+}  // namespace
 
 // ------------------------------------------------------------- nucleotides
 
@@ -71,9 +95,113 @@ bool Node::add_mutation(const Mutation &mut) {   // :720-752
 
 // -------------------------------------------------------------------- tree
 
-Tree::~Tree() {
-    for (auto &kv : all_nodes) delete kv.second;
+// ---------------------------------------------------------- name index, node blocks
+
+uint64_t NodeIndex::hash(const std::string &s) {   // FNV-1a, then a finalizer (names are short: "node_1234567", "EPI_ISL_...")
+    uint64_t h = 1469598103934665603ull;
+    for (unsigned char c : s) { h ^= c; h *= 1099511628211ull; }
+    h ^= h >> 32; h *= 0x9E3779B97F4A7C15ull; h ^= h >> 29;
+    return h;
 }
+
+size_t NodeIndex::base_find(const std::string &id, uint64_t h) const {
+    auto it = std::lower_bound(base_.begin(), base_.end(), h, [](const std::pair<uint64_t, Node *> &e, uint64_t v) { return e.first < v; });
+    for (; it != base_.end() && it->first == h; ++it)
+        if (it->second && it->second->id == id) return (size_t)(it - base_.begin());
+    return SIZE_MAX;
+}
+
+Node *NodeIndex::find(const std::string &id) const {
+    if (!extra_.empty()) { auto it = extra_.find(id); if (it != extra_.end()) return it->second; }
+    if (base_.empty()) return nullptr;
+    const size_t i = base_find(id, hash(id));
+    return i == SIZE_MAX ? nullptr : base_[i].second;
+}
+
+bool NodeIndex::insert(const std::string &id, Node *n) {
+    if (find(id)) return false;
+    extra_.emplace(id, n);
+    live_++;
+    return true;
+}
+
+void NodeIndex::set(const std::string &id, Node *n) {
+    auto it = extra_.find(id);
+    if (it != extra_.end()) { it->second = n; return; }
+    if (!base_.empty()) { const size_t i = base_find(id, hash(id)); if (i != SIZE_MAX) { base_[i].second = n; return; } }
+    extra_.emplace(id, n);
+    live_++;
+}
+
+bool NodeIndex::erase(const std::string &id) {
+    auto it = extra_.find(id);
+    if (it != extra_.end()) { extra_.erase(it); live_--; return true; }
+    if (base_.empty()) return false;
+    const size_t i = base_find(id, hash(id));
+    if (i == SIZE_MAX) return false;
+    base_[i].second = nullptr;
+    live_--;
+    return true;
+}
+
+// Hashes on the host threads, a partition by the top hash bits (histogram, scan, scatter), every partition sorted by its
+// own thread.  Equal names are equal hashes, hence neighbours after the sort.
+bool NodeIndex::bulk_build(Node *const *nodes, size_t n, std::string *dup) {
+    std::vector<std::pair<uint64_t, Node *>> tmp(n);
+    parallel_for(n, [&](uint64_t b, uint64_t e, unsigned) { for (uint64_t i = b; i < e; i++) tmp[i] = {hash(nodes[i]->id), nodes[i]}; }, 1u << 14);
+    constexpr unsigned BITS = 10, P = 1u << BITS;
+    const unsigned T = host_threads();
+    std::vector<uint64_t> hist((size_t)T * P, 0);
+    parallel_for(n, [&](uint64_t b, uint64_t e, unsigned tid) { uint64_t *h = &hist[(size_t)tid * P]; for (uint64_t i = b; i < e; i++) h[tmp[i].first >> (64 - BITS)]++; }, 1u << 14);
+    std::vector<uint64_t> start(P + 1, 0);
+    {   // offsets: partition-major, thread-minor (a thread's entries of one partition stay together: deterministic)
+        uint64_t run = 0;
+        for (unsigned p = 0; p < P; p++) { start[p] = run; for (unsigned t = 0; t < T; t++) { const uint64_t c = hist[(size_t)t * P + p]; hist[(size_t)t * P + p] = run; run += c; } }
+        start[P] = run;
+    }
+    base_.assign(n, {0, nullptr});
+    parallel_for(n, [&](uint64_t b, uint64_t e, unsigned tid) { uint64_t *h = &hist[(size_t)tid * P]; for (uint64_t i = b; i < e; i++) base_[h[tmp[i].first >> (64 - BITS)]++] = tmp[i]; }, 1u << 14);
+    std::atomic<size_t> bad{SIZE_MAX};
+    parallel_for(P, [&](uint64_t b, uint64_t e, unsigned) {
+        for (uint64_t p = b; p < e; p++) {
+            auto lo = base_.begin() + start[p], hi = base_.begin() + start[p + 1];
+            std::sort(lo, hi, [](const std::pair<uint64_t, Node *> &x, const std::pair<uint64_t, Node *> &y) { return x.first != y.first ? x.first < y.first : x.second < y.second; });
+            for (auto it = lo; it != hi; ++it)
+                for (auto jt = it + 1; jt != hi && jt->first == it->first; ++jt)
+                    if (jt->second->id == it->second->id) { size_t cur = bad.load(); const size_t me = (size_t)(it - base_.begin()); while (me < cur && !bad.compare_exchange_weak(cur, me)) {} }
+        }
+    }, 1);
+    live_ = n + extra_.size();
+    if (bad.load() != SIZE_MAX) { if (dup) *dup = base_[bad.load()].second->id; return false; }
+    return true;
+}
+
+Node *Tree::alloc_block(size_t n) {
+    Block b;
+    b.p = (Node *)::operator new[](std::max<size_t>(n, 1) * sizeof(Node), std::align_val_t(alignof(Node)));
+    b.n = n;
+    b.dead.assign(n, 1);   // (nothing constructed yet; the caller marks what it constructs)
+    blocks.push_back(std::move(b));
+    return blocks.back().p;
+}
+
+void Tree::free_node(Node *n) {
+    if (!n->in_block) { delete n; return; }
+    for (Block &b : blocks)
+        if (n >= b.p && n < b.p + b.n) { b.dead[(size_t)(n - b.p)] = 1; n->~Node(); return; }
+}
+
+static void free_all_nodes(Tree &T) {
+    T.all_nodes.for_each([](Node *n) { if (!n->in_block) delete n; });
+    for (Tree::Block &b : T.blocks) {
+        parallel_for(b.n, [&](uint64_t lo, uint64_t hi, unsigned) { for (uint64_t i = lo; i < hi; i++) if (!b.dead[i]) b.p[i].~Node(); }, 1u << 14);
+        ::operator delete[](b.p, std::align_val_t(alignof(Node)));
+    }
+    T.blocks.clear();
+    T.all_nodes.clear();
+}
+
+Tree::~Tree() { free_all_nodes(*this); }
 
 uint32_t Tree::chrom_id(const std::string &c) {
     for (uint32_t i = 0; i < chroms.size(); i++) if (chroms[i] == c) return i;
@@ -82,14 +210,12 @@ uint32_t Tree::chrom_id(const std::string &c) {
 }
 
 Node *Tree::get_node(const std::string &id) const {
-    auto it = all_nodes.find(id);
-    return it == all_nodes.end() ? nullptr : it->second;
+    return all_nodes.find(id);
 }
 
 Node *Tree::create_node(const std::string &id, Node *parent, float branch_length) {   // :881-910
     if (parent) {
-        auto ins = all_nodes.emplace(id, nullptr);
-        if (!ins.second) return nullptr;   // "already in the tree"
+        if (all_nodes.find(id)) return nullptr;   // "already in the tree"
         Node *n = new Node();
         n->id = id;
         n->parent = parent;
@@ -98,7 +224,7 @@ Node *Tree::create_node(const std::string &id, Node *parent, float branch_length
         const size_t na = num_annotations();
         if (na) n->clade_annotations.assign(na, "");
         parent->children.push_back(n);
-        ins.first->second = n;
+        all_nodes.set(id, n);
         return n;
     }
     Node *n = new Node();
@@ -107,14 +233,13 @@ Node *Tree::create_node(const std::string &id, Node *parent, float branch_length
     n->branch_length = branch_length;
     n->level = parent ? parent->level + 1 : 1;
     if (!parent) {
-        for (auto &kv : all_nodes) delete kv.second;
-        all_nodes.clear();
+        free_all_nodes(*this);
         root = n;
     } else {
         n->clade_annotations.assign(num_annotations(), "");
         parent->children.push_back(n);
     }
-    all_nodes[id] = n;
+    all_nodes.set(id, n);
     return n;
 }
 
@@ -158,7 +283,7 @@ std::string Tree::clade_assignment(Node *n, size_t clade, bool include_self) con
 
 size_t Tree::parsimony_score() const {
     size_t s = 0;
-    for (auto &kv : all_nodes) s += kv.second->mutations.size();
+    all_nodes.for_each([&](Node *n) { s += n->mutations.size(); });
     return s;
 }
 
@@ -188,7 +313,7 @@ void Tree::remove_leaf(Node *n) {
     Node *p = n->parent;
     if (p) p->children.erase(std::find(p->children.begin(), p->children.end(), n));
     all_nodes.erase(n->id);
-    delete n;
+    free_node(n);
 }
 
 std::vector<Node *> Tree::leaves(Node *from) const {   // get_leaves, :818-840
@@ -233,13 +358,13 @@ void Tree::remove_node(Node *source, bool move_level) {
                 par->parent->children.erase(std::find(par->parent->children.begin(), par->parent->children.end(), par));
                 fix_levels(child);
                 all_nodes.erase(par->id);
-                delete par;
+                free_node(par);
             }
         }
     }
     std::vector<Node *> q{source};
     for (size_t h = 0; h < q.size(); h++) for (Node *c : q[h]->children) q.push_back(c);
-    for (Node *n : q) { all_nodes.erase(n->id); delete n; }
+    for (Node *n : q) { all_nodes.erase(n->id); free_node(n); }
 }
 
 static bool same_mutations(const std::vector<Mutation> &a, const std::vector<Mutation> &b) {   // Mutation::operator==, hpp:56-62
@@ -402,29 +527,29 @@ void Tree::uncondense_leaves() {   // :1334-1382
         if (k > 1 && !n->mutations.empty()) {
             all_nodes.erase(n->id);
             n->id = new_internal_node_id();
-            all_nodes[n->id] = n;
+            all_nodes.set(n->id, n);
             for (size_t s = 0; s < k; s++) {
                 Node *c = new Node();
                 c->id = cn.second[s]; c->parent = n; c->branch_length = -1.0f; c->level = n->level + 1;
                 c->clade_annotations.assign(num_annotations(), "");
-                all_nodes[c->id] = c;
+                all_nodes.set(c->id, c);
                 n->children.push_back(c);
             }
         } else if (k > 1) {
             all_nodes.erase(n->id);
             n->id = cn.second[0];
-            all_nodes[n->id] = n;
+            all_nodes.set(n->id, n);
             for (size_t s = 1; s < k; s++) {
                 Node *c = new Node();
                 c->id = cn.second[s]; c->parent = par; c->branch_length = n->branch_length; c->level = par->level + 1;
                 c->clade_annotations.assign(num_annotations(), "");
-                all_nodes[c->id] = c;
+                all_nodes.set(c->id, c);
                 par->children.push_back(c);
             }
         } else if (k == 1) {
             all_nodes.erase(n->id);
             n->id = cn.second[0];
-            all_nodes[n->id] = n;
+            all_nodes.set(n->id, n);
         }
     }
     condensed_nodes.clear();
@@ -505,6 +630,157 @@ bool tree_from_newick(const std::string &nwk, Tree &T, std::string &err) {   // 
     return true;
 }
 
+// The same tree as tree_from_newick for large inputs (a 10M-node parsimony.proto: 6.2 s -> 1 s of load time).  The
+// per-item state machine is the one above, run per item on the host threads; what crosses items is the paren level
+// (a prefix sum) and the node stack (one cheap sequential pass over the items' open / close counts).  A value pushed
+// into blen[level] above belongs to the node whose text just ended -- the item's leaf for its first push, the
+// internal node closed by the previous ')' for the others -- and nodes of one level end in the order they begin, so
+// handing each popped node "its" push is the same assignment as the per-level queues.
+bool tree_from_newick_bulk(const char *nwk, size_t len, Tree &T, std::string &err, std::vector<Node *> *order_out) {
+    // item boundaries: commas (string_split drops a trailing empty piece, keeps empty pieces in the middle)
+    Lap lap("newick");
+    const unsigned TH = host_threads();
+    std::vector<std::vector<size_t>> commas(TH);
+    parallel_for(len, [&](uint64_t b, uint64_t e, unsigned tid) {
+        auto &v = commas[tid];
+        for (const char *p = nwk + b, *pe = nwk + e; (p = (const char *)memchr(p, ',', (size_t)(pe - p))) != nullptr; p++) v.push_back((size_t)(p - nwk));
+    }, 1u << 16);
+    std::vector<size_t> start{0};   // item i = [start[i], start[i + 1] - 1)
+    for (auto &v : commas) for (size_t c : v) start.push_back(c + 1);
+    if (start.back() < len) start.push_back(len + 1);   // (a last piece without a comma behind it)
+    const size_t n_items = start.size() - 1;
+    if (n_items == 0) return true;
+    lap("item boundaries");
+    struct Item { uint32_t open, close, leaf_b, leaf_e; };
+    std::vector<Item> items(n_items);
+    std::vector<uint64_t> push_off(n_items + 1, 0), node_off(n_items + 1, 0), open_off(n_items + 1, 0);
+    std::vector<int64_t> level_at(n_items + 1, 0);
+    // pass 1: counts, leaf-name extent (the characters before the first ':' or ')' that are not parens)
+    parallel_for(n_items, [&](uint64_t b, uint64_t e, unsigned) {
+        for (uint64_t i = b; i < e; i++) {
+            Item it{0, 0, 0, 0};
+            bool stop = false;
+            const size_t sb = start[i], se = start[i + 1] - 1;
+            uint32_t lb = (uint32_t)sb, le = (uint32_t)sb;
+            bool any = false;
+            for (size_t k = sb; k < se; k++) {
+                const char c = nwk[k];
+                if (c == ':') stop = true;
+                else if (c == '(') it.open++;
+                else if (c == ')') { stop = true; it.close++; }
+                else if (!stop) { if (!any) { lb = (uint32_t)k; any = true; } le = (uint32_t)k + 1; }
+            }
+            it.leaf_b = lb; it.leaf_e = any ? le : lb;
+            items[i] = it;
+            push_off[i] = it.close + 1; node_off[i] = it.open + 1; open_off[i] = it.open;
+        }
+    }, 4096);
+    // a leaf name interrupted by parens ("a(b") would be the concatenation of its pieces: left to the general routine
+    std::atomic<bool> odd{false};
+    parallel_for(n_items, [&](uint64_t b, uint64_t e, unsigned) {
+        for (uint64_t i = b; i < e; i++)
+            for (uint32_t k = items[i].leaf_b; k < items[i].leaf_e; k++) if (nwk[k] == '(') { odd = true; break; }
+    }, 4096);
+    if (odd) return tree_from_newick(std::string(nwk, len), T, err);
+    lap("item counts");
+    const uint64_t n_push = exclusive_scan(push_off.data(), n_items); push_off[n_items] = n_push;
+    const uint64_t n_nodes = exclusive_scan(node_off.data(), n_items); node_off[n_items] = n_nodes;
+    const uint64_t n_open = exclusive_scan(open_off.data(), n_items); open_off[n_items] = n_open;
+    if (n_nodes >= (1ull << 32)) { err = "Newick tree too large"; return false; }
+    // pass 2: the branch lengths an item pushes, in order (the state machine of tree_from_newick, quirks included:
+    // `branch` survives a ')' that is not followed by a new ':')
+    std::vector<float> pushes(n_push);
+    parallel_for(n_items, [&](uint64_t b, uint64_t e, unsigned) {
+        char buf[64];
+        for (uint64_t i = b; i < e; i++) {
+            float *out = &pushes[push_off[i]];
+            size_t bl = 0;
+            bool has = false, branch_start = false;
+            auto val = [&]() -> float { if (!has || bl == 0) return -1.0f; buf[std::min<size_t>(bl, sizeof buf - 1)] = 0; return std::stof(buf); };
+            for (size_t k = start[i], se = start[i + 1] - 1; k < se; k++) {
+                const char c = nwk[k];
+                if (c == ':') { bl = 0; has = true; branch_start = true; }
+                else if (c == '(') {}
+                else if (c == ')') { *out++ = val(); branch_start = false; }
+                else if (branch_start && (isdigit((unsigned char)c) || c == '.' || c == 'e' || c == 'E' || c == '-' || c == '+')) { if (bl < sizeof buf - 1) buf[bl++] = c; }
+                else if (has) { /* a character that does not belong to a number: tree_from_newick skips it */ }
+            }
+            *out++ = val();
+        }
+    }, 4096);
+    lap("branch lengths");
+    // sequential: the node stack -> parent and branch length of every node, children counts
+    std::vector<uint32_t> parent(n_nodes);
+    std::vector<float> blen(n_nodes, -1.0f);
+    std::vector<uint32_t> level(n_nodes), n_kids(n_nodes, 0);
+    {
+        std::vector<uint32_t> stack;
+        for (size_t i = 0; i < n_items; i++) {
+            const Item &it = items[i];
+            uint32_t id = (uint32_t)node_off[i];
+            for (uint32_t j = 0; j < it.open; j++, id++) {
+                parent[id] = stack.empty() ? UINT32_MAX : stack.back();
+                if (stack.empty() && id != 0) { err = "incorrect Newick format"; return false; }   // (a second root)
+                level[id] = (uint32_t)stack.size() + 1;
+                if (!stack.empty()) n_kids[stack.back()]++;
+                stack.push_back(id);
+            }
+            if (stack.empty()) { err = "incorrect Newick format"; return false; }
+            parent[id] = stack.back(); level[id] = (uint32_t)stack.size() + 1; n_kids[stack.back()]++;
+            const float *pv = &pushes[push_off[i]];
+            blen[id] = pv[0];
+            if (it.close > stack.size()) { err = "incorrect Newick format"; return false; }
+            for (uint32_t j = 0; j < it.close; j++) { blen[stack.back()] = pv[j + 1]; stack.pop_back(); }
+        }
+        if (!stack.empty()) { err = "incorrect Newick format"; return false; }
+    }
+    lap("node stack (sequential)");
+    // construct the nodes in one block, on the host threads (first touch by the thread that fills them)
+    if (T.root) { err = "tree_from_newick_bulk needs an empty tree"; return false; }
+    Node *blk = T.alloc_block(n_nodes);
+    Tree::Block &B = T.blocks.back();
+    const size_t first_internal = T.curr_internal_node;
+    parallel_for(n_items, [&](uint64_t b, uint64_t e, unsigned) {
+        char name[40];
+        for (uint64_t i = b; i < e; i++) {
+            uint32_t id = (uint32_t)node_off[i];
+            for (uint32_t j = 0; j < items[i].open; j++, id++) {
+                Node *n = new (blk + id) Node();
+                snprintf(name, sizeof name, "node_%zu", first_internal + (size_t)open_off[i] + j + 1);
+                n->id = name;
+            }
+            Node *n = new (blk + id) Node();
+            n->id.assign(nwk + items[i].leaf_b, items[i].leaf_e - items[i].leaf_b);
+        }
+    }, 4096);
+    parallel_for(n_nodes, [&](uint64_t b, uint64_t e, unsigned) {
+        for (uint64_t k = b; k < e; k++) {
+            Node *n = blk + k;
+            n->in_block = true;
+            n->parent = parent[k] == UINT32_MAX ? nullptr : blk + parent[k];
+            n->branch_length = blen[k];
+            n->level = level[k];
+            if (n_kids[k]) n->children.reserve(n_kids[k]);
+            B.dead[k] = 0;
+        }
+    }, 1u << 14);
+    lap("construct nodes");
+    for (uint64_t k = 1; k < n_nodes; k++) blk[parent[k]].children.push_back(blk + k);   // creation order = stored child order
+    lap("child lists (sequential)");
+    T.curr_internal_node = first_internal + n_open;
+    T.root = blk;
+    std::vector<Node *> all(n_nodes);
+    parallel_for(n_nodes, [&](uint64_t b, uint64_t e, unsigned) { for (uint64_t k = b; k < e; k++) all[k] = blk + k; }, 1u << 16);
+    std::string dup;
+    if (!T.all_nodes.bulk_build(all.data(), n_nodes, &dup)) {
+        err = dup.rfind("node_", 0) == 0 ? "duplicate node identifier in Newick" : "Error: " + dup + " already in the tree!";
+        return false;
+    }
+    lap("name index");
+    if (order_out) order_out->swap(all);
+    return true;
+}
+
 static void put_len(std::string &out, float v) {   // operator<<(float): %g
     char buf[32];
     snprintf(buf, sizeof buf, "%g", v);
@@ -570,17 +846,35 @@ bool read_file(const std::string &path, std::string &buf, std::string &err) {
     if (path.find(".gz") != std::string::npos) {   // :530 / :2086
         gzFile f = gzopen(path.c_str(), "rb");
         if (!f) { err = "Could not open " + path; return false; }
-        char tmp[1 << 16];
+        gzbuffer(f, 1u << 20);
+        std::vector<char> tmp(1u << 22);
         int n;
-        while ((n = gzread(f, tmp, sizeof tmp)) > 0) buf.append(tmp, (size_t)n);
+        while ((n = gzread(f, tmp.data(), (unsigned)tmp.size())) > 0) buf.append(tmp.data(), (size_t)n);
         gzclose(f);
         return n == 0;
     }
-    std::ifstream in(path, std::ios::binary);
-    if (!in) { err = "Could not open " + path; return false; }
-    std::stringstream ss;
-    ss << in.rdbuf();
-    buf = ss.str();
+    // one read into a buffer of the file's size (a stringstream copies a 1 GB VCF twice)
+    FILE *f = fopen(path.c_str(), "rb");
+    if (!f) { err = "Could not open " + path; return false; }
+    struct stat st;
+    size_t size = (fstat(fileno(f), &st) == 0 && st.st_size > 0) ? (size_t)st.st_size : 0;
+    if (size) {
+        buf.resize(size);
+        // the pages of a large file are read by several threads at once (pread: page-cache copies are memory-bound)
+        const int fd = fileno(f);
+        std::atomic<bool> ok{true};
+        parallel_for(size, [&](uint64_t b, uint64_t e, unsigned) {
+            uint64_t off = b;
+            while (off < e) { const ssize_t r = pread(fd, &buf[off], e - off, (off_t)off); if (r <= 0) { ok = false; return; } off += (uint64_t)r; }
+        }, 1u << 26);
+        fclose(f);
+        if (!ok) { err = "Could not read " + path; return false; }
+        return true;
+    }
+    char tmp[1 << 16];   // (not a regular file: a pipe)
+    size_t n;
+    while ((n = fread(tmp, 1, sizeof tmp, f)) > 0) buf.append(tmp, n);
+    fclose(f);
     return true;
 }
 
@@ -622,15 +916,18 @@ void put_int32(std::string &o, uint32_t fno, int32_t v) {   // proto3: zero is o
 bool load_mat(const std::string &path, Tree &T, std::string &err) {   // :522-612
     std::string buf;
     if (!read_file(path, buf, err)) { err = "ERROR: Could not load the mutation-annotated tree object from file: " + path + "!"; return false; }
+    Lap lap("load_mat");
+    lap("read file");
     Rd top{(const uint8_t *)buf.data(), (const uint8_t *)buf.data() + buf.size()};
-    std::string nwk;
+    const char *nwk_p = "";
+    size_t nwk_len = 0;
     // First pass: the newick string, and where each node's mutation list / metadata entry sits in the buffer
     // (they are decoded straight into the nodes once the tree exists; no intermediate copies).
     std::vector<Rd> mut_lists, meta_lists;
     std::vector<std::pair<std::string, std::vector<std::string>>> cond;
     uint32_t fno, wt; uint64_t val; Rd sub{nullptr, nullptr};
     while (top.field(fno, wt, val, sub)) {
-        if (fno == 1 && wt == 2) nwk.assign((const char *)sub.p, sub.e - sub.p);
+        if (fno == 1 && wt == 2) { nwk_p = (const char *)sub.p; nwk_len = (size_t)(sub.e - sub.p); }
         else if (fno == 2 && wt == 2) mut_lists.push_back(sub);
         else if (fno == 3 && wt == 2) {
             cond.emplace_back();
@@ -642,54 +939,92 @@ bool load_mat(const std::string &path, Tree &T, std::string &err) {   // :522-61
         } else if (fno == 4 && wt == 2) meta_lists.push_back(sub);
     }
     if (!top.ok) { err = "malformed protobuf"; return false; }
-    if (!tree_from_newick(nwk, T, err)) return false;
-    auto order = T.dfs();
+    lap("top-level fields");
+    // Large trees: items tokenised and nodes constructed on the host threads (tree_from_newick_bulk); the nodes come back in
+    // creation order, which is the depth-first order the mutation lists are stored in (:552-554).
+    std::vector<Node *> order;
+    const bool bulk = nwk_len >= (1u << 16) || getenv("USHER_AMD_GRAIN");
+    if (bulk) { if (!tree_from_newick_bulk(nwk_p, nwk_len, T, err, &order)) return false; }
+    else { if (!tree_from_newick(std::string(nwk_p, nwk_len), T, err)) return false; order = T.dfs(); }
+    lap("tree from newick");
     if (mut_lists.size() < order.size()) { err = "protobuf has fewer mutation lists than tree nodes"; return false; }
     const bool hasmeta = !meta_lists.empty();
     if (!hasmeta) fprintf(stderr, "WARNING: This pb does not include any metadata. Filling in default values\n");
     if (hasmeta && meta_lists.size() < order.size()) { err = "protobuf has fewer metadata entries than tree nodes"; return false; }
-    std::string chrom, last_chrom;
-    uint32_t last_chrom_id = T.chrom_id("");
-    for (size_t i = 0; i < order.size(); i++) {
-        Node *n = order[i];
-        if (hasmeta) {
-            Rd ml = meta_lists[i];
+    // Mutation lists and metadata decoded per node on the host threads (the reference: tbb::parallel_for over the nodes,
+    // :556-612).  Chromosome names: every thread numbers the names it meets itself; the tables are merged in thread order --
+    // threads own contiguous ranges of the depth-first order, so the merged numbering is the order of first appearance, as a
+    // sequential load would give -- and the few threads whose numbering differs renumber their nodes' mutations.
+    const unsigned TH = host_threads();
+    std::vector<std::vector<std::string>> th_chroms(TH);
+    std::vector<std::pair<uint64_t, uint64_t>> th_range(TH, {0, 0});
+    std::vector<std::string> th_err(TH);
+    parallel_for(order.size(), [&](uint64_t nb, uint64_t ne, unsigned tid) {
+        th_range[tid] = {nb, ne};
+        auto &chroms = th_chroms[tid];
+        auto local_id = [&](const std::string &c) -> uint32_t {
+            for (uint32_t i = 0; i < chroms.size(); i++) if (chroms[i] == c) return i;
+            chroms.push_back(c);
+            return (uint32_t)chroms.size() - 1;
+        };
+        std::string chrom, last_chrom;
+        uint32_t last_chrom_id = local_id("");
+        for (uint64_t i = nb; i < ne; i++) {
+            Node *n = order[i];
+            if (hasmeta) {
+                Rd ml = meta_lists[i];
+                uint32_t f2, w2; uint64_t v2; Rd s2{nullptr, nullptr};
+                while (ml.field(f2, w2, v2, s2))
+                    if (f2 == 1 && w2 == 2) n->clade_annotations.emplace_back((const char *)s2.p, s2.e - s2.p);
+            }
+            Rd list = mut_lists[i];
             uint32_t f2, w2; uint64_t v2; Rd s2{nullptr, nullptr};
-            while (ml.field(f2, w2, v2, s2))
-                if (f2 == 1 && w2 == 2) n->clade_annotations.emplace_back((const char *)s2.p, s2.e - s2.p);
-        }
-        Rd list = mut_lists[i];
-        uint32_t f2, w2; uint64_t v2; Rd s2{nullptr, nullptr};
-        while (list.field(f2, w2, v2, s2)) {
-            if (f2 != 1 || w2 != 2) continue;
-            int32_t pos = 0, ref = 0, par = 0;
-            int8_t nuc = 0;                                     // get_nuc_id(vector), :77-85
-            chrom.clear();
-            uint32_t f3, w3; uint64_t v3; Rd s3{nullptr, nullptr};
-            while (s2.field(f3, w3, v3, s3)) {
-                if (f3 == 1 && w3 == 0) pos = (int32_t)(int64_t)v3;
-                else if (f3 == 2 && w3 == 0) ref = (int32_t)(int64_t)v3;
-                else if (f3 == 3 && w3 == 0) par = (int32_t)(int64_t)v3;
-                else if (f3 == 4 && w3 == 0) nuc = (int8_t)(nuc + (1 << (int32_t)(int64_t)v3));
-                else if (f3 == 4 && w3 == 2) { while (s3.p < s3.e && s3.ok) nuc = (int8_t)(nuc + (1 << (int32_t)(int64_t)s3.varint())); }
-                else if (f3 == 5 && w3 == 2) chrom.assign((const char *)s3.p, s3.e - s3.p);
+            {   // (one allocation per node: count the entries first)
+                Rd cnt = list; size_t k = 0; Rd t2{nullptr, nullptr};
+                while (cnt.field(f2, w2, v2, t2)) k += (f2 == 1 && w2 == 2);
+                if (k) n->mutations.reserve(k);
             }
-            if (!s2.ok) { err = "malformed protobuf (mut)"; return false; }
-            if (chrom != last_chrom) { last_chrom = chrom; last_chrom_id = T.chrom_id(chrom); }
-            Mutation m;
-            m.chrom = last_chrom_id;
-            m.position = pos;
-            if (pos >= 0) {
-                m.ref_nuc = (int8_t)(1 << ref);
-                m.par_nuc = (int8_t)(1 << par);
-                m.mut_nuc = nuc;
-                if (m.mut_nuc != m.par_nuc && !n->add_mutation(m)) { err = "add_mutation: mutations at the same position disagree"; return false; }
-            } else {
-                m.ref_nuc = m.par_nuc = m.mut_nuc = 0;
-                n->add_mutation(m);   // note: two masked entries cancel through the reversal rule, as in the reference
+            while (list.field(f2, w2, v2, s2)) {
+                if (f2 != 1 || w2 != 2) continue;
+                int32_t pos = 0, ref = 0, par = 0;
+                int8_t nuc = 0;                                     // get_nuc_id(vector), :77-85
+                chrom.clear();
+                uint32_t f3, w3; uint64_t v3 = 0; Rd s3{nullptr, nullptr};
+                while (s2.field(f3, w3, v3, s3)) {
+                    if (f3 == 1 && w3 == 0) pos = (int32_t)(int64_t)v3;
+                    else if (f3 == 2 && w3 == 0) ref = (int32_t)(int64_t)v3;
+                    else if (f3 == 3 && w3 == 0) par = (int32_t)(int64_t)v3;
+                    else if (f3 == 4 && w3 == 0) nuc = (int8_t)(nuc + (1 << (int32_t)(int64_t)v3));
+                    else if (f3 == 4 && w3 == 2) { while (s3.p < s3.e && s3.ok) nuc = (int8_t)(nuc + (1 << (int32_t)(int64_t)s3.varint())); }
+                    else if (f3 == 5 && w3 == 2) chrom.assign((const char *)s3.p, s3.e - s3.p);
+                }
+                if (!s2.ok) { th_err[tid] = "malformed protobuf (mut)"; return; }
+                if (chrom != last_chrom) { last_chrom = chrom; last_chrom_id = local_id(chrom); }
+                Mutation m;
+                m.chrom = last_chrom_id;
+                m.position = pos;
+                if (pos >= 0) {
+                    m.ref_nuc = (int8_t)(1 << ref);
+                    m.par_nuc = (int8_t)(1 << par);
+                    m.mut_nuc = nuc;
+                    if (m.mut_nuc != m.par_nuc && !n->add_mutation(m)) { th_err[tid] = "add_mutation: mutations at the same position disagree"; return; }
+                } else {
+                    m.ref_nuc = m.par_nuc = m.mut_nuc = 0;
+                    n->add_mutation(m);   // note: two masked entries cancel through the reversal rule, as in the reference
+                }
             }
+            if (!list.ok) { th_err[tid] = "malformed protobuf (mutation_list)"; return; }
         }
-        if (!list.ok) { err = "malformed protobuf (mutation_list)"; return false; }
+    }, 4096);
+    lap("mutation lists");
+    for (const std::string &e : th_err) if (!e.empty()) { err = e; return false; }   // (the first failing range in tree order)
+    for (unsigned t = 0; t < TH; t++) {
+        if (th_chroms[t].empty()) continue;
+        std::vector<uint32_t> map(th_chroms[t].size());
+        bool same = true;
+        for (size_t k = 0; k < map.size(); k++) { map[k] = T.chrom_id(th_chroms[t][k]); same = same && map[k] == k; }
+        if (!same)
+            for (uint64_t i = th_range[t].first; i < th_range[t].second; i++) for (Mutation &m : order[i]->mutations) m.chrom = map[m.chrom];
     }
     for (auto &c : cond) {
         for (auto &l : c.second) T.condensed_leaves.insert(l);
@@ -776,59 +1111,162 @@ static bool read_lines(const std::string &path, std::vector<std::string> &lines,
     return true;
 }
 
-bool read_vcf_missing(Tree &T, const std::string &path, std::vector<MissingSample> &out, std::string &err) {   // :2180-2277
-    std::vector<std::string> lines;
-    if (!read_lines(path, lines, err)) return false;
-    bool header_found = false;
-    size_t n_ids = 0;
+// Existing-MAT branch of read_vcf (:2180-2277; the reference reads the file through a tbb::flow pipeline, :2108-2179).  The file is
+// read in one piece, its line starts are found on the host threads, the header is handled where it stands, and the data lines
+// are parsed in contiguous blocks, one per thread, without copying a word: every thread leaves the cells of its lines as
+// (sample, mutation) records in line order, and the samples' lists are the concatenation of the blocks in file order -- the
+// order a sequential reader appends in.  Quirks kept: lines in front of the header are skipped unless they look like one; a
+// blank line is skipped; a genotype that starts with a digit is read as its leading digits; anything else is a missing call;
+// the first letter of the ALT allele decides ('N' and every unknown letter: missing).
+bool read_vcf_missing(Tree &T, const std::string &path, std::vector<MissingSample> &out, std::string &err) {
+    Lap lap("read_vcf");
+    std::string buf;
+    if (!read_file(path, buf, err)) { err = "ERROR: Could not open the VCF file: " + path + "!"; return false; }
+    lap("read file");
+    const char *base = buf.data();
+    const size_t len = buf.size();
+    const unsigned TH = host_threads();
+    std::vector<std::vector<size_t>> nl(TH);
+    parallel_for(len, [&](uint64_t b, uint64_t e, unsigned tid) {
+        auto &v = nl[tid];
+        for (const char *p = base + b, *pe = base + e; (p = (const char *)memchr(p, '\n', (size_t)(pe - p))) != nullptr; p++) v.push_back((size_t)(p - base));
+    }, 1u << 20);
+    std::vector<size_t> ls{0};   // line i = [ls[i], ls[i + 1] - 1)
+    for (auto &v : nl) for (size_t x : v) ls.push_back(x + 1);
+    if (ls.back() < len) ls.push_back(len + 1);
+    const size_t n_lines = ls.size() - 1;
+    lap("line starts");
+    auto is_sp = [](char c) { return c == ' ' || c == '\t' || c == '\r' || c == '\v' || c == '\f' || c == '\n'; };   // isspace
+    // next word of [p, e): begin / end, or false
+    auto next_word = [&](const char *&p, const char *e, const char *&wb, const char *&we) {
+        while (p < e && is_sp(*p)) p++;
+        if (p >= e) return false;
+        wb = p;
+        while (p < e && !is_sp(*p)) p++;
+        we = p;
+        return true;
+    };
+    // the header: the first line with more than one word whose second word is POS
+    size_t n_ids = 0, first_data = n_lines;
     std::vector<size_t> missing_idx;
-    for (const std::string &s : lines) {
-        std::vector<std::string> words;
-        split_ws(s, words);
-        if (!header_found && words.size() > 1) {
-            if (words[1] == "POS") {
-                for (size_t j = 9; j < words.size(); j++) {
-                    n_ids++;
-                    if (!T.get_node(words[j]) && !T.condensed_leaves.count(words[j])) {
-                        MissingSample ms; ms.name = words[j];
-                        out.push_back(std::move(ms));
-                        missing_idx.push_back(j);
-                    } else {
-                        fprintf(stderr, "WARNING: Ignoring sample %s as it is already in the tree.\n", words[j].c_str());
-                    }
+    for (size_t li = 0; li < n_lines; li++) {
+        const char *p = base + ls[li], *e = base + ls[li + 1] - 1, *wb, *we;
+        if (!next_word(p, e, wb, we) || !next_word(p, e, wb, we)) continue;
+        if ((size_t)(we - wb) != 3 || memcmp(wb, "POS", 3) != 0) continue;
+        const char *q = base + ls[li];
+        for (size_t j = 0; next_word(q, e, wb, we); j++) {
+            if (j < 9) continue;
+            n_ids++;
+            const std::string name(wb, (size_t)(we - wb));
+            if (!T.get_node(name) && !T.condensed_leaves.count(name)) {
+                MissingSample ms; ms.name = name;
+                out.push_back(std::move(ms));
+                missing_idx.push_back(j);
+            } else {
+                fprintf(stderr, "WARNING: Ignoring sample %s as it is already in the tree.\n", name.c_str());
+            }
+        }
+        first_data = li + 1;
+        break;
+    }
+    lap("header");
+    if (first_data >= n_lines) return true;
+    // column j -> index into `out`, or -1
+    std::vector<int32_t> col2k(9 + n_ids, -1);
+    for (size_t k = 0; k < missing_idx.size(); k++) col2k[missing_idx[k]] = (int32_t)k;
+    struct Rec { uint32_t k; Mutation m; };
+    struct Block { std::vector<Rec> recs; std::vector<std::string> chroms; size_t err_line = SIZE_MAX; std::string err; uint64_t lb = 0, le = 0; };
+    std::vector<Block> blocks(TH);
+    parallel_for(n_lines - first_data, [&](uint64_t b0, uint64_t e0, unsigned tid) {
+        Block &B = blocks[tid];
+        B.lb = first_data + b0; B.le = first_data + e0;
+        auto local_chrom = [&](const char *b, const char *e) -> uint32_t {
+            const size_t n = (size_t)(e - b);
+            for (uint32_t i = 0; i < B.chroms.size(); i++) if (B.chroms[i].size() == n && memcmp(B.chroms[i].data(), b, n) == 0) return i;
+            B.chroms.emplace_back(b, n);
+            return (uint32_t)B.chroms.size() - 1;
+        };
+        std::vector<std::pair<const char *, const char *>> alleles;
+        for (uint64_t li = B.lb; li < B.le; li++) {
+            const char *p = base + ls[li], *e = base + ls[li + 1] - 1, *wb, *we;
+            const char *f[9][2];
+            size_t nw = 0;
+            while (nw < 9 && next_word(p, e, wb, we)) { f[nw][0] = wb; f[nw][1] = we; nw++; }
+            if (nw == 0) continue;                                   // blank line
+            // the cells; a line that is short or long is an error (:2226-2231)
+            Mutation proto;
+            int8_t ref = 0;
+            if (nw == 9) {
+                proto.chrom = local_chrom(f[0][0], f[0][1]);
+                proto.position = (int32_t)strtol(std::string(f[1][0], f[1][1]).c_str(), nullptr, 10);
+                ref = nuc_id(f[3][0][0]);
+                proto.ref_nuc = ref; proto.par_nuc = ref;
+                alleles.clear();
+                for (const char *a = f[4][0]; a < f[4][1];) {          // string_split on ',': empty pieces kept, a trailing one dropped
+                    const char *c = (const char *)memchr(a, ',', (size_t)(f[4][1] - a));
+                    if (!c) { alleles.push_back({a, f[4][1]}); break; }
+                    alleles.push_back({a, c});
+                    a = c + 1;
                 }
-                header_found = true;
             }
-        } else if (header_found) {
-            if (words.empty()) continue;
-            if (words.size() != 9 + n_ids) {
-                err = "ERROR! Incorrect VCF format. Expected " + std::to_string(9 + n_ids) + " columns but got " + std::to_string(words.size()) + ".";
-                return false;
-            }
-            std::vector<std::string> alleles;
-            split(words[4], ',', alleles);
-            const int32_t pos = (int32_t)strtol(words[1].c_str(), nullptr, 10);
-            const int8_t ref = nuc_id(words[3][0]);
-            const uint32_t chrom = T.chrom_id(words[0]);
-            for (size_t k = 0; k < missing_idx.size(); k++) {
-                const std::string &cell = words[missing_idx[k]];
-                Mutation m;
-                m.chrom = chrom; m.position = pos; m.ref_nuc = ref; m.par_nuc = ref;
-                if (isdigit((unsigned char)cell[0])) {
-                    const long allele_id = strtol(cell.c_str(), nullptr, 10);   // std::stoi: leading digits
+            size_t col = nw;
+            bool bad = false;
+            for (;;) {
+                // (the common cell: a tab and a lone 0 -- the reference allele, no record)
+                while (p + 1 < e && p[0] == '\t' && p[1] == '0' && (p + 2 == e || p[2] == '\t')) { p += 2; col++; }
+                if (!next_word(p, e, wb, we)) break;
+                if (col >= 9 + n_ids) { col++; continue; }
+                const int32_t k = col2k[col];
+                col++;
+                if (k < 0) continue;
+                Mutation m = proto;
+                if (*wb >= '0' && *wb <= '9') {
+                    long allele_id = 0;                                  // std::stoi: the leading digits
+                    for (const char *c = wb; c < we && *c >= '0' && *c <= '9'; c++) { allele_id = allele_id * 10 + (*c - '0'); if (allele_id > 1000000) break; }
                     if (allele_id <= 0) continue;
-                    if ((size_t)allele_id > alleles.size()) { err = "ERROR! VCF genotype refers to a missing ALT allele."; return false; }
-                    const std::string &allele = alleles[allele_id - 1];
-                    if (allele[0] == 'N') { m.is_missing = true; m.mut_nuc = 15; }
-                    else { m.mut_nuc = nuc_id(allele[0]); m.is_missing = (m.mut_nuc == 15); }
+                    if ((size_t)allele_id > alleles.size()) { B.err_line = li; B.err = "ERROR! VCF genotype refers to a missing ALT allele."; bad = true; break; }
+                    const auto &al = alleles[allele_id - 1];
+                    const char a0 = al.first < al.second ? *al.first : '\0';
+                    if (a0 == 'N') { m.is_missing = true; m.mut_nuc = 15; }
+                    else { m.mut_nuc = nuc_id(a0); m.is_missing = (m.mut_nuc == 15); }
                 } else {
                     m.is_missing = true; m.mut_nuc = 15;
                 }
-                if (m.mut_nuc & (m.mut_nuc - 1)) out[k].num_ambiguous++;
-                out[k].mutations.push_back(m);
+                B.recs.push_back({(uint32_t)k, m});
+            }
+            if (bad) return;
+            if (col != 9 + n_ids) {
+                B.err_line = li;
+                B.err = "ERROR! Incorrect VCF format. Expected " + std::to_string(9 + n_ids) + " columns but got " + std::to_string(col) + ".";
+                return;
             }
         }
+    }, 16);
+    lap("data lines");
+    // the first error in file order wins -- but the records in front of it were already appended by a sequential reader; nobody
+    // uses them after an error, so they are not reproduced
+    {
+        size_t el = SIZE_MAX; const Block *eb = nullptr;
+        for (const Block &B : blocks) if (B.err_line < el) { el = B.err_line; eb = &B; }
+        if (eb) { err = eb->err; return false; }
     }
+    // chromosome numbers in order of first appearance; records into the samples' lists, block after block
+    std::vector<size_t> per(out.size(), 0);
+    for (Block &B : blocks) {
+        std::vector<uint32_t> map(B.chroms.size());
+        for (size_t k = 0; k < map.size(); k++) map[k] = T.chrom_id(B.chroms[k]);
+        for (Rec &r : B.recs) { r.m.chrom = map[r.m.chrom]; per[r.k]++; }
+    }
+    for (size_t k = 0; k < out.size(); k++) out[k].mutations.reserve(out[k].mutations.size() + per[k]);
+    parallel_for(out.size(), [&](uint64_t kb, uint64_t ke, unsigned) {   // (every thread fills its own samples: it scans all records when there are few threads' worth of them)
+        for (const Block &B : blocks)
+            for (const Rec &r : B.recs)
+                if (r.k >= kb && r.k < ke) {
+                    if (r.m.mut_nuc & (r.m.mut_nuc - 1)) out[r.k].num_ambiguous++;
+                    out[r.k].mutations.push_back(r.m);
+                }
+    }, 64);
+    lap("merge");
     return true;
 }
 
@@ -915,6 +1353,118 @@ bool read_vcf_build(Tree &T, const std::string &path, std::vector<MissingSample>
         m.par_nuc = (int8_t)muts.par_nuc[i]; m.mut_nuc = (int8_t)muts.mut_nuc[i];
         bfs[muts.node[i]]->add_mutation(m);
     }
+    return true;
+}
+
+// ------------------------------------------------------- bench / test utilities
+// A tree given as breadth-first arrays (the layout of ugp_tree_desc) written as parsimony.proto, and a query batch in CSR form
+// written as a VCF: the inputs of an end-to-end run of the front end on the synthetic workload (bench.py, tools/bench_addmode.py).
+
+bool write_pb_from_arrays(uint64_t n, const uint32_t *parent, const uint64_t *mut_off, const int32_t *pos, const uint8_t *ref, const uint8_t *par,
+                          const uint8_t *nuc, const std::string &path, std::string &err) {
+    if (!n) { err = "empty tree"; return false; }
+    std::vector<uint64_t> first(n + 1, 0);
+    for (uint64_t j = 1; j < n; j++) first[parent[j] + 1]++;
+    for (uint64_t j = 0; j < n; j++) first[j + 1] += first[j];
+    std::vector<uint32_t> kids(n ? n - 1 : 0);
+    { std::vector<uint64_t> fill(first.begin(), first.end() - 1); for (uint64_t j = 1; j < n; j++) kids[fill[parent[j]]++] = (uint32_t)j; }
+    std::string nwk;
+    nwk.reserve(n * 14);
+    std::vector<uint32_t> order;
+    order.reserve(n);
+    std::vector<std::pair<uint32_t, uint32_t>> st{{0u, 0u}};
+    char tmp[48];
+    auto len_of = [&](uint32_t j) { snprintf(tmp, sizeof tmp, ":%g", (float)(mut_off[j + 1] - mut_off[j])); return tmp; };
+    while (!st.empty()) {
+        auto &fr = st.back();
+        const uint32_t j = fr.first;
+        const uint64_t b = first[j], e = first[j + 1];
+        if (fr.second == 0) {
+            order.push_back(j);
+            if (b == e) { snprintf(tmp, sizeof tmp, "L%u", j); nwk += tmp; nwk += len_of(j); st.pop_back(); continue; }
+            nwk += '(';
+        }
+        if (b + fr.second < e) {
+            if (fr.second) nwk += ',';
+            const uint32_t c = kids[b + fr.second++];
+            st.push_back({c, 0u});
+        } else { nwk += ')'; nwk += len_of(j); st.pop_back(); }
+    }
+    nwk += ';';
+    std::string out;
+    out.reserve(nwk.size() + (mut_off[n] * 14) + n * 2 + 64);
+    put_bytes(out, 1, nwk);
+    std::string ml, mm, packed;
+    for (uint32_t j : order) {
+        ml.clear();
+        for (uint64_t i = mut_off[j]; i < mut_off[j + 1]; i++) {
+            mm.clear();
+            put_int32(mm, 1, pos[i]);
+            if (pos[i] < 0) { put_int32(mm, 2, -1); put_int32(mm, 3, -1); }
+            else {
+                put_int32(mm, 2, nuc_index((int8_t)ref[i]));
+                put_int32(mm, 3, nuc_index((int8_t)par[i]));
+                packed.clear();
+                for (int b = 0; b < 4; b++) if (nuc[i] & (1 << b)) put_varint(packed, (uint64_t)b);
+                if (!packed.empty()) put_bytes(mm, 4, packed);
+            }
+            put_bytes(ml, 1, mm);
+        }
+        put_bytes(out, 2, ml);
+    }
+    FILE *f = fopen(path.c_str(), "wb");
+    if (!f) { err = "Could not write " + path; return false; }
+    const bool ok = fwrite(out.data(), 1, out.size(), f) == out.size();
+    fclose(f);
+    if (!ok) err = "short write to " + path;
+    return ok;
+}
+
+bool write_vcf_from_csr(uint64_t n_samples, const uint64_t *ent_off, const int32_t *pos, const uint8_t *ref, const uint8_t *nuc, const uint8_t *is_missing,
+                        const std::string &prefix, const std::string &path, std::string &err) {
+    struct Cell { int32_t pos; uint32_t sample; uint8_t ref, allele; };
+    std::vector<Cell> cells;
+    cells.reserve(ent_off[n_samples]);
+    for (uint64_t s = 0; s < n_samples; s++)
+        for (uint64_t i = ent_off[s]; i < ent_off[s + 1]; i++) cells.push_back({pos[i], (uint32_t)s, ref[i], (uint8_t)(is_missing[i] ? 15 : nuc[i])});
+    std::stable_sort(cells.begin(), cells.end(), [](const Cell &a, const Cell &b) { return a.pos < b.pos; });
+    FILE *f = fopen(path.c_str(), "wb");
+    if (!f) { err = "Could not write " + path; return false; }
+    std::string line = "##fileformat=VCFv4.2\n#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT";
+    for (uint64_t s = 0; s < n_samples; s++) { line += '\t'; line += prefix; line += std::to_string(s); }
+    line += '\n';
+    fwrite(line.data(), 1, line.size(), f);
+    std::string gt;
+    for (size_t b = 0; b < cells.size();) {
+        size_t e = b;
+        while (e < cells.size() && cells[e].pos == cells[b].pos) e++;
+        const uint8_t r = cells[b].ref;
+        std::vector<uint8_t> alts;
+        for (size_t k = b; k < e; k++) if (cells[k].allele != 15 && cells[k].allele != r && std::find(alts.begin(), alts.end(), cells[k].allele) == alts.end()) alts.push_back(cells[k].allele);
+        std::sort(alts.begin(), alts.end());
+        if (alts.empty()) for (uint8_t a : {1, 2, 4, 8}) if (a != r) { alts.push_back(a); break; }
+        line = "chr\t" + std::to_string(cells[b].pos) + "\t.\t" + std::string(1, nuc_char((int8_t)r)) + "\t";
+        for (size_t k = 0; k < alts.size(); k++) { if (k) line += ','; line += nuc_char((int8_t)alts[k]); }
+        line += "\t.\t.\t.\tGT";
+        gt.assign(n_samples * 2, '\t');
+        for (uint64_t s = 0; s < n_samples; s++) gt[2 * s + 1] = '0';
+        bool wide = false;
+        for (size_t k = b; k < e; k++) {
+            char c = '.';
+            if (cells[k].allele != 15) {
+                const size_t idx = cells[k].allele == r ? 0 : (size_t)(std::find(alts.begin(), alts.end(), cells[k].allele) - alts.begin()) + 1;
+                if (idx > 9) wide = true;
+                c = (char)('0' + idx);
+            }
+            gt[2 * cells[k].sample + 1] = c;
+        }
+        if (wide) { fclose(f); err = "more than 9 ALT alleles at one position"; return false; }
+        line += gt;
+        line += '\n';
+        fwrite(line.data(), 1, line.size(), f);
+        b = e;
+    }
+    fclose(f);
     return true;
 }
 

@@ -35,15 +35,47 @@ struct Node {                 // mutation_annotated_tree.hpp:88-111
     // scratch for the placement driver: breadth-first index in its last flattening of the tree (valid
     // while flat_epoch equals the flattening's epoch) -- avoids a 10M-entry hash map per flattening
     mutable uint32_t flat_index = 0, flat_epoch = 0;
+    bool in_block = false;    // storage belongs to one of the tree's node blocks (bulk load), not to `new`
     bool is_leaf() const { return children.empty(); }
     bool is_root() const { return parent == nullptr; }
     // :720-752.  Returns false on the reference's "called out of order" error.
     bool add_mutation(const Mutation &m);
 };
 
+// name -> node (the reference's Tree::all_nodes, mutation_annotated_tree.hpp:121).  A 10M-node load cannot afford 10M
+// sequential inserts into a std::unordered_map (1.5 s of the 6 s a load took): the nodes a bulk load creates are indexed
+// by a table of (hash, node) sorted on the host threads; nodes created later go to an ordinary hash map in front of it.
+class NodeIndex {
+  public:
+    Node *find(const std::string &id) const;
+    bool insert(const std::string &id, Node *n);   // false (and no change) when the name is taken
+    void set(const std::string &id, Node *n);      // insert or overwrite
+    bool erase(const std::string &id);
+    size_t size() const { return live_; }
+    void clear() { base_.clear(); extra_.clear(); live_ = 0; }
+    void reserve(size_t n) { if (base_.empty()) extra_.reserve(n); }
+    // index `n` nodes at once (replaces the table; the map of later nodes is kept); false = two nodes share a name (*dup)
+    bool bulk_build(Node *const *nodes, size_t n, std::string *dup);
+    template <class F> void for_each(F f) const {
+        for (const auto &e : base_) if (e.second) f(e.second);
+        for (const auto &kv : extra_) f(kv.second);
+    }
+    static uint64_t hash(const std::string &s);
+  private:
+    std::vector<std::pair<uint64_t, Node *>> base_;   // sorted by hash; node == nullptr: erased
+    std::unordered_map<std::string, Node *> extra_;
+    size_t live_ = 0;
+    size_t base_find(const std::string &id, uint64_t h) const;   // index into base_ or SIZE_MAX
+};
+
 struct Tree {                 // mutation_annotated_tree.hpp:113-161
     Node *root = nullptr;
-    std::unordered_map<std::string, Node *> all_nodes;
+    NodeIndex all_nodes;
+    // nodes of a bulk load live in contiguous blocks (constructed and destroyed on the host threads); Node::in_block
+    struct Block { Node *p = nullptr; size_t n = 0; std::vector<uint8_t> dead; };
+    std::vector<Block> blocks;
+    Node *alloc_block(size_t n);          // raw storage for n nodes (not yet constructed)
+    void free_node(Node *n);              // delete, or destroy in place when the node lives in a block
     size_t curr_internal_node = 0;
     // name -> condensed leaf ids.  (The reference keeps a tbb::concurrent_unordered_map here, whose
     // iteration order is unspecified; a std::unordered_map fed in the same sequence is used instead.)
@@ -95,6 +127,9 @@ bool get_subtree(const Tree &src, const std::vector<std::string> &samples, Tree 
 
 // newick --------------------------------------------------------------------
 bool tree_from_newick(const std::string &nwk, Tree &out, std::string &err);   // :415-508
+// the same result for large inputs: items tokenised on the host threads, nodes constructed in one block, the name
+// index built by a parallel sort; `order` (optional) receives the nodes in creation order = depth-first preorder
+bool tree_from_newick_bulk(const char *nwk, size_t len, Tree &out, std::string &err, std::vector<Node *> *order = nullptr);
 std::string newick(const Tree &t, Node *from, bool internal_ids, bool branch_len, bool uncondense = false);   // :215-346
 
 // parsimony.proto -------------------------------------------------------------
@@ -124,5 +159,11 @@ struct SiteBatch {               // what ugp_sites carries, owned
 struct SiteMutations { std::vector<uint32_t> site, node; std::vector<uint8_t> par_nuc, mut_nuc; };
 typedef bool (*AssignFn)(void *ctx, const SiteBatch &in, SiteMutations &out, std::string &err);
 bool read_vcf_build(Tree &t, const std::string &path, std::vector<MissingSample> &out, std::string &err, AssignFn assign, void *ctx);
+
+// bench / test utilities: a tree given as breadth-first arrays written as parsimony.proto (leaves "L<j>"), a CSR query batch as VCF
+bool write_pb_from_arrays(uint64_t n, const uint32_t *parent, const uint64_t *mut_off, const int32_t *pos, const uint8_t *ref, const uint8_t *par,
+                          const uint8_t *nuc, const std::string &path, std::string &err);
+bool write_vcf_from_csr(uint64_t n_samples, const uint64_t *ent_off, const int32_t *pos, const uint8_t *ref, const uint8_t *nuc, const uint8_t *is_missing,
+                        const std::string &prefix, const std::string &path, std::string &err);
 
 }  // namespace uh
