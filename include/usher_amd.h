@@ -219,6 +219,53 @@ typedef struct ugp_job ugp_job;
 int ugp_place_batch_async(ugp_mat *mat, const ugp_queries *q, ugp_result *out /* [n_queries], valid until ugp_job_wait */, ugp_job **job);
 int ugp_job_wait(ugp_job *job);
 
+/* ---- add mode: the tree changes between samples ------------------------------------------------------------------------
+ * Default `usher` inserts every sample before it searches for the next (usher_common.cpp:310, the tree edits :652-765), and
+ * the reference therefore re-expands and re-searches the whole tree per sample (:342).  An insertion changes very little:
+ * it creates a leaf (and, for a sibling placement, an internal node) and rewrites the branch of best_node; the root-path
+ * mutation set of every OTHER node -- hence its cost, eligibility and has_unique for any sample (usher_mapper.cpp:167-504) --
+ * stays what it was.  This library keeps the flattened tree of ugp_mat_create on the device and takes the edits beside it:
+ *
+ *   ugp_mat_update   the caller reports the nodes it created or rewrote ("touched") as records: own mutations + the state of
+ *                    the node's parent wherever that differs from the reference base.  Records of nodes that exist in the
+ *                    flattened tree (flat_j != UINT32_MAX) also take that node OUT of the candidate set of every later
+ *                    ugp_place_* / ugp_tied_nodes call on the handle: those calls then return the exact best score, tie count
+ *                    and winner over the flattened nodes that are still what they were (winner by the leaf counts and order of
+ *                    the flattened tree -- a caller whose tree has grown re-ranks the tie list itself).
+ *   ugp_touched_*    score the live records against a batch of pending samples on the device: per sample the minimum cost
+ *                    over the eligible records and the records that attain it.  The answer on the tree as it is NOW is the
+ *                    merge of the two -- usher_amd/csrc/host/driver.cpp does exactly that, INTEGRATION.md 2a.
+ * Records get ids 0, 1, 2 ... in the order they are handed over.  A node that is rewritten again gets a new record; the old
+ * one is retired.  Needs a tree of fewer than 2^30 nodes (one bit of the 32-bit record streams marks an excluded node). */
+#define UGP_T_LEAF   1u   /* the node is a leaf */
+#define UGP_T_MASKED 2u   /* the node carries a masked mutation: `own` lists the mutations in front of it (usher_mapper.cpp:197-200) */
+typedef struct ugp_touched {
+    uint64_t n;                  /* records in this call                                                                       */
+    const uint32_t *flat_j;      /* [n] index of the node in the tree given to ugp_mat_create; UINT32_MAX: created since       */
+    const uint8_t *flags;        /* [n] UGP_T_*                                                                                */
+    const uint32_t *n_path;      /* [n] how many of the record's entries describe the parent's state (they come first)         */
+    const uint64_t *ent_off;     /* [n + 1] CSR into the entry arrays: the parent-state entries, then the own mutations        */
+    const int32_t *pos;          /* [n_ent] position                                                                           */
+    const uint8_t *allele;       /* [n_ent] parent-state entry: the state (one-hot, != ref); own mutation: the mutated allele  */
+    const uint8_t *prev;         /* [n_ent] own mutation: the true parent state at pos (one-hot); parent-state entry: unused   */
+    const uint8_t *ref;          /* [n_ent] reference base at pos (one-hot)                                                    */
+} ugp_touched;
+/* Appends `recs` (may be NULL / n = 0), retires the records listed in `retired` (ids of earlier calls), excludes the flattened
+ * nodes named by the new records.  *first_id = id of the first new record. */
+int ugp_mat_update(ugp_mat *mat, const ugp_touched *recs, const uint32_t *retired, uint64_t n_retired, uint32_t *first_id);
+/* Begin scoring for a batch of pending samples: uploads their rows (checked like ugp_place_batch's), scores every live record. */
+int ugp_touched_open(ugp_mat *mat, const ugp_queries *batch);
+/* Records with id >= first_id against the samples first_sample .. end of the open batch, merged into the running results
+ * (after ugp_mat_update: the samples in front of first_sample have been consumed already). */
+int ugp_touched_score(ugp_mat *mat, uint32_t first_id, uint64_t first_sample);
+/* One sample again from every live record (its list held retired records only). */
+int ugp_touched_rescore(ugp_mat *mat, uint64_t sample);
+/* Results of samples [first_sample, first_sample + n): best[i] = minimum cost over the eligible live records (INT32_MAX: none),
+ * count[i] = how many attain it (true count), ids / has_unique [i * cap ..] = the first min(count, cap) of them.  A record retired
+ * after it entered a list is still listed: the caller knows which ids it retired. */
+int ugp_touched_fetch(ugp_mat *mat, uint64_t first_sample, uint64_t n, uint32_t cap, int32_t *best, uint32_t *count, uint32_t *ids,
+                      uint8_t *has_unique);
+
 /* Per-kernel durations of the last ugp_place_* call on this handle, measured
  * with HIP events on the stream the kernels ran on (synchronises that stream). */
 int ugp_get_timing(ugp_mat *mat, ugp_timing *out);

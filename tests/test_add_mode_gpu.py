@@ -1,0 +1,143 @@
+"""Add mode on the device (ugp_mat_update / ugp_touched_*): the flattened tree stays on the device, the nodes created or rewritten
+by insertions are scored from records, rewritten nodes leave the flattened tree's candidate set -- and the merge of the two is
+the answer of a full search of the tree as it is now.  Checked against the oracle searching the EDITED tree (tests/usher_model's
+restatement of usher_common.cpp:652-765 does the insertions), never against the product itself."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import capi, refio
+from tests import synth, usher_model
+from usher_amd import Placer, QueryBatch
+
+pytestmark = pytest.mark.gpu
+INT_MAX = 2 ** 31 - 1
+
+
+def tree_from_arrays(arrays):
+    """refio.Tree with the nodes of `arrays` (names n<j>), children in index order."""
+    T = refio.Tree()
+    nodes = []
+    for j in range(int(arrays["n"])):
+        p = int(arrays["parent"][j])
+        nd = T.create_node("n%d" % j, nodes[p] if p >= 0 else None)
+        for i in range(int(arrays["mut_off"][j]), int(arrays["mut_off"][j + 1])):
+            m = refio.Mutation(int(arrays["mut_pos"][i]), int(arrays["mut_ref"][i]), int(arrays["mut_par"][i]), int(arrays["mut_nuc"][i]))
+            nd.mutations.append(m)           # (already in the stored order)
+        nodes.append(nd)
+    return T, nodes
+
+
+def record_of(node, flat_index):
+    """What the driver reports for a touched node: the parent's state wherever it is not the reference base, the own mutations in
+    front of the first masked one with their true parent state."""
+    state, ref = {}, {}
+    a = node.parent
+    chain = []
+    while a is not None:
+        chain.append(a)
+        a = a.parent
+    for a in reversed(chain):                       # root first: later mutations overwrite
+        for m in a.mutations:
+            if m.is_masked():
+                continue
+            state[m.position] = m.mut_nuc
+            ref[m.position] = m.ref_nuc
+    path = [(p, s, ref[p]) for p, s in state.items() if s != ref[p]]
+    own, masked = [], False
+    for m in node.mutations:
+        if m.is_masked():
+            masked = True
+            break
+        own.append((m.position, m.mut_nuc, state.get(m.position, m.ref_nuc), m.ref_nuc))
+    return {"flat_j": flat_index, "leaf": node.is_leaf(), "masked": masked, "path": path, "own": own}
+
+
+def merged_answer(flat_best, flat_ties, t_best, t_ties):
+    """(best, {node: has_unique}) from the flattened tree's untouched nodes and the records."""
+    best = min(flat_best, t_best)
+    out = {}
+    if flat_best == best:
+        out.update(flat_ties)
+    if t_best == best:
+        out.update(t_ties)
+    return best, out
+
+
+@pytest.mark.parametrize("seed,n_leaves,n_new,chunk", [(5, 400, 60, 16), (6, 1500, 90, 64), (7, 120, 40, 8)])
+def test_flattened_tree_plus_records_equal_a_search_of_the_edited_tree(seed, n_leaves, n_new, chunk, monkeypatch):
+    monkeypatch.setenv("UGP_COARSE_MIN_NODES", "0")     # the locality pre-pass and its coarse tree too (their nodes are excluded as well)
+    arrays, queries = synth.make_case(seed, n_leaves=n_leaves, n_queries=n_new, n_sites=90, n_ambig=(0, 0, 1, 3), p_masked=0.01)
+    T, flat_nodes = tree_from_arrays(arrays)
+    flat_of = {id(n): j for j, n in enumerate(flat_nodes)}
+    pl = Placer(arrays, chunk_nodes=chunk)
+    batch = QueryBatch(queries)
+    pl.touched_open(batch)
+    rec_of_node = {}          # id(node) -> live record id
+    node_of_rec = {}
+    retired = set()
+    rng = np.random.default_rng(seed)
+    multi = 0
+    for i, s in enumerate(queries):
+        # ---- the answer for sample i on the tree as it is now, from the device: flattened part + records
+        # (a few pending samples at a time, in front of 600 others so that the locality pre-pass, its coarse tree and the seed descent run)
+        part = QueryBatch(queries[i:i + 3] + [queries[(7 * k + i) % len(queries)] for k in range(600)])
+        fr = pl.place(part)
+        tj, th, tc = pl.tied_nodes(part, 4096)
+        tb, tcnt, tids, thu = pl.touched_fetch(i, min(3, len(batch) - i))
+        bfs_now = T.breadth_first_expansion()
+        ot = capi.OracleTree(refio.tree_to_bfs_arrays(T))
+        for k in range(min(3, len(batch) - i)):
+            want = ot.place(queries[i + k])
+            flat_ties = {id(flat_nodes[int(j)]): bool(h) for j, h in zip(tj[k], th[k])}
+            assert int(tc[k]) == len(flat_ties) == int(fr["num_best"][k])
+            assert all(id(flat_nodes[int(j)]) not in rec_of_node for j in tj[k])   # rewritten nodes are no candidates any more
+            live = [(int(r), bool(h)) for r, h in zip(tids[k][:int(tcnt[k])], thu[k][:int(tcnt[k])]) if int(r) not in retired]
+            assert int(tcnt[k]) <= 64
+            if int(tcnt[k]) and not live:                  # every listed record was retired since: ask again
+                pl.touched_rescore(i + k)
+                b2, c2, i2, h2 = pl.touched_fetch(i + k, 1)
+                tb[k], live = b2[0], [(int(r), bool(h)) for r, h in zip(i2[0][:int(c2[0])], h2[0][:int(c2[0])])]
+                assert all(r not in retired for r, _ in live)
+            t_ties = {id(node_of_rec[r]): h for r, h in live}
+            best, ties = merged_answer(int(fr["best_set_difference"][k]), flat_ties, int(tb[k]) if live else INT_MAX, t_ties)
+            want_ties = {id(bfs_now[int(j)]): bool(h) for j, h in zip(want["ties"], want["ties_has_unique"])}
+            assert best == want["best"], (i, k, best, want["best"])
+            assert ties == want_ties, (i, k)
+            multi += len(ties) > 1
+        # ---- insert sample i where the oracle puts it (the reference's rule), report the touched nodes
+        want = ot.place(s)
+        node = bfs_now[want["best_j"]]
+        nv = ot.node_vecs(s, want["best_j"])
+        excess = [refio.Mutation(p, rf, pa, mu) for (p, rf, pa, mu) in nv["excess"]]
+        as_sibling = node.is_leaf() or want["has_unique"]
+        usher_model.insert(T, node, as_sibling, "NEW%d" % i, excess)
+        leaf = T.get_node("NEW%d" % i)
+        touched = [leaf.parent, leaf, node] if as_sibling else [leaf]
+        gone = []
+        recs = []
+        for nd in touched:
+            if id(nd) in rec_of_node:
+                gone.append(rec_of_node[id(nd)])
+            recs.append(record_of(nd, flat_of.get(id(nd))))
+        first = pl.update(recs, gone)
+        retired.update(gone)
+        for k, nd in enumerate(touched):
+            rec_of_node[id(nd)] = first + k
+            node_of_rec[first + k] = nd
+        pl.touched_score(first, i + 1)
+        if rng.random() < 0.15:        # now and then: the running results equal a fresh evaluation of every live record
+            a = pl.touched_fetch(i + 1, len(batch) - i - 1)
+            pl.touched_open(batch)
+            b = pl.touched_fetch(i + 1, len(batch) - i - 1)
+            for q in range(len(a[0])):
+                la = sorted(int(r) for r in a[2][q][:min(64, int(a[1][q]))] if int(r) not in retired)
+                lb = sorted(int(r) for r in b[2][q][:min(64, int(b[1][q]))])
+                # (a running list may hold retired records; when every holder of its minimum was retired the minimum is too low)
+                if la:
+                    assert a[0][q] == b[0][q] and (la == lb or int(a[1][q]) > 64), (i, q)
+                else:
+                    assert a[0][q] <= b[0][q], (i, q)
+    assert multi > 3
+    pl.close()

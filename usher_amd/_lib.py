@@ -44,6 +44,11 @@ class ugp_place_opts(C.Structure):
     _fields_ = [("order", C.c_uint32), ("node_mask", C.c_void_p), ("skip_node", C.c_void_p), ("distance", C.c_void_p), ("scores", C.c_void_p)]
 
 
+class ugp_touched(C.Structure):
+    _fields_ = [("n", C.c_uint64), ("flat_j", C.c_void_p), ("flags", C.c_void_p), ("n_path", C.c_void_p), ("ent_off", C.c_void_p), ("pos", C.c_void_p),
+                ("allele", C.c_void_p), ("prev", C.c_void_p), ("ref", C.c_void_p)]
+
+
 class ugp_sites(C.Structure):
     _fields_ = [("n_sites", C.c_uint64), ("ref", C.c_void_p), ("var_off", C.c_void_p), ("var_node", C.c_void_p),
                 ("var_nuc", C.c_void_p)]
@@ -68,6 +73,11 @@ SYMBOLS = {
     "ugp_qset_size": (C.c_uint64, [P]),
     "ugp_place_device": (C.c_int, [P, P, P, P]),
     "ugp_place_device_overlapped": (C.c_int, [P, P, P, P]),
+    "ugp_mat_update": (C.c_int, [P, C.POINTER(ugp_touched), P, C.c_uint64, C.POINTER(C.c_uint32)]),
+    "ugp_touched_open": (C.c_int, [P, C.POINTER(ugp_queries)]),
+    "ugp_touched_score": (C.c_int, [P, C.c_uint32, C.c_uint64]),
+    "ugp_touched_rescore": (C.c_int, [P, C.c_uint64]),
+    "ugp_touched_fetch": (C.c_int, [P, C.c_uint64, C.c_uint64, C.c_uint32, P, P, P, P]),
     "ugp_mat_reload_knobs": (C.c_int, [P]),
     "ugp_has_experiments": (C.c_int, []),
     "ugp_place_batch_async": (C.c_int, [P, C.POINTER(ugp_queries), P, C.POINTER(P)]),

@@ -17,6 +17,7 @@
 #include "ugp_flatten.hpp"
 #include "ugp_kernels.hpp"
 #include "ugp_knobs.hpp"
+#include "ugp_update.hpp"
 #include "usher_amd.h"
 
 namespace {
@@ -58,6 +59,19 @@ struct DevBuf {
         hipError_t e = hipMalloc((void **)&p, std::max<size_t>(n, 1) * sizeof(T));
         if (e == hipSuccess) cap = n; else p = nullptr;
         return e;
+    }
+    // grow to at least n elements, keeping the first `used` (doubling: appended to many times)
+    hipError_t grow_keep(size_t n, size_t used) {
+        if (n <= cap) return hipSuccess;
+        const size_t want = std::max<size_t>(n, cap * 2);
+        T *np = nullptr;
+        hipError_t e = hipMalloc((void **)&np, std::max<size_t>(want, 1) * sizeof(T));
+        if (e != hipSuccess) return e;
+        if (p && used) e = hipMemcpy(np, p, used * sizeof(T), hipMemcpyDeviceToDevice);
+        if (e != hipSuccess) { (void)hipFree(np); return e; }
+        if (p) (void)hipFree(p);
+        p = np; cap = want;
+        return hipSuccess;
     }
     template <class V>
     hipError_t upload(const V &v) {
@@ -166,6 +180,23 @@ struct ugp_mat {
     uint32_t tie_lists_filled = 0, tie_sub_batches = 0;   // sub-batches of the current call whose tie lists phase 2 has filled / all of them (ugp_tied_nodes)
     bool sharing = false;    // (during a ugp_place_device call) the other set's call was still running when this one, or the one before it, was queued
     bool was_busy = false;   // ... when the previous call was queued
+    // ---- add mode (ugp_mat_update / ugp_touched_*): where each node's words sit in the record streams (by BFS index; the coarse
+    // tree's by coarse index), the records of the nodes created or rewritten since, and the open batch's scoring state
+    struct Upd {
+        std::vector<uint32_t> hdr8, rec, post, coarse2bfs;
+        DevBuf<ugp::TouchedRec> d_rec;
+        DevBuf<ugp::TouchedEnt> d_ent;
+        DevBuf<uint8_t> d_alive;
+        DevBuf<uint32_t> d_tmp;
+        uint64_t n_rec = 0, n_ent = 0, n_excluded = 0;
+        ugp_qset *qs = nullptr;
+        DevBuf<uint8_t> d_dense, d_hu;
+        DevBuf<int32_t> d_dbot, d_best, d_list_best;
+        DevBuf<uint32_t> d_cnt, d_ids;
+        uint32_t n_pos = 0, qpad = 0;
+        uint64_t Q = 0;
+        bool open = false;
+    } upd;
     hipEvent_t kb_done = nullptr;    // behind the latest k_best8 launch of this handle ...
     hipStream_t kb_done_on = nullptr;   // ... on this stream
 };
@@ -726,6 +757,7 @@ static int build_coarse(const ugp_tree_desc *t, const ugp::Options &opt, ugp::Fl
     ugp::Options copt;
     copt.chunk_nodes = 256;   // (the coarse pass is bound by row fetches and by the replay in front of every chunk: long chunks)
     copt.keep_node_pos8 = true;
+    copt.keep_update_maps = opt.keep_update_maps;
     if (const char *e = getenv("UGP_LDS_SLOTS")) copt.lds_slots = (uint32_t)std::max(1, std::min(60, atoi(e)));
     if (const char *e = getenv("UGP_COARSE_CHUNK_NODES")) copt.chunk_nodes = (uint32_t)std::max(1, atoi(e));
     hf.coarse = new HostFlat();
@@ -776,6 +808,10 @@ static int upload_flat(const HostFlat &hf, int device, ugp_mat **out) {
         g.n_nodes = f.n_nodes; g.n_muts = f.n_muts; g.n_sites = f.n_sites; g.max_pos = f.max_pos; g.max_slots = f.max_slots;
         g.n_chunks = f.n_chunks; g.max_path_muts = f.max_path_muts; g.max_chunk8_words = f.max_chunk8_words; g.mask_not_first = f.mask_not_first; g.lds_slots = f.lds_slots;
     }
+    m->upd.hdr8.assign(f.hdr8_of_bfs.begin(), f.hdr8_of_bfs.end());   // (empty unless the flattening kept them: Options::keep_update_maps)
+    m->upd.rec.assign(f.rec_of_bfs.begin(), f.rec_of_bfs.end());
+    m->upd.post.assign(f.post_of_bfs.begin(), f.post_of_bfs.end());
+    m->upd.coarse2bfs = hf.coarse2bfs;
     if ((e = m->d_stream.upload(f.stream)) != hipSuccess) return bail(e, "upload stream");
     if ((e = m->d_pre.upload(f.pre_stream)) != hipSuccess) return bail(e, "upload preambles");
     if ((e = m->d_chunk_body.upload(f.chunk_body_off)) != hipSuccess) return bail(e, "upload chunk table");
@@ -836,6 +872,7 @@ static int upload_flat(const HostFlat &hf, int device, ugp_mat **out) {
 
 static ugp::Options default_options() {
     ugp::Options opt;
+    opt.keep_update_maps = !getenv("UGP_NO_UPDATE_MAPS");   // 12 bytes per node on the host: what ugp_mat_update needs to exclude a rewritten node
     if (const char *e = getenv("UGP_CHUNK_NODES")) opt.chunk_nodes = (uint32_t)std::max(1, atoi(e));
     if (const char *e = getenv("UGP_PRUNE_MIN_WORDS")) opt.prune_min_words = (uint32_t)std::max(1, atoi(e));
     if (getenv("UGP_NO_SIB")) opt.sibling_records = false;
@@ -899,6 +936,7 @@ void ugp_mat_destroy(ugp_mat *m) {
         }
     }
     for (auto &W : m->work) delete W.job_qs;
+    delete m->upd.qs;
     if (m->kb_done) (void)hipEventDestroy(m->kb_done);
     if (m->coarse) ugp_mat_destroy(m->coarse);
     delete m->own_qs;
@@ -1426,6 +1464,189 @@ int ugp_tied_nodes_ex(ugp_mat *m, const ugp_queries *q, const ugp_place_opts *op
     }
     ugp_qset_destroy(qs);
     return rc;
+}
+
+// ---- add mode ---------------------------------------------------------------------------------------------------------------
+
+namespace {
+constexpr uint32_t kTouchedCap = 64;   // list entries kept per sample on the device (the true count is kept beside them)
+
+// calls of ugp_place_device_overlapped / _async still in flight on the handle's own streams: the entry points below run on the
+// default stream and change what those calls read
+int drain(ugp_mat *m) {
+    HIP_TRY(hipSetDevice(m->device));
+    for (auto &W : m->work) if (W.done) HIP_TRY(hipEventSynchronize(W.done));
+    if (m->coarse) for (auto &W : m->coarse->work) if (W.done) HIP_TRY(hipEventSynchronize(W.done));
+    return UGP_OK;
+}
+
+int or_words(ugp_mat *m, uint32_t *stream, const std::vector<uint32_t> &pos, uint32_t bits) {
+    if (pos.empty()) return UGP_OK;
+    HIP_TRY(m->upd.d_tmp.upload(pos));
+    HIP_TRY(ugp::launch_or_words(stream, m->upd.d_tmp.p, (uint32_t)pos.size(), bits, nullptr));
+    HIP_TRY(hipStreamSynchronize(nullptr));   // (d_tmp is reused by the next list)
+    return UGP_OK;
+}
+
+ugp::TouchedArgs touched_args(ugp_mat *m, uint32_t id0, uint32_t id1, uint32_t q0, uint32_t q1) {
+    auto &U = m->upd;
+    ugp::TouchedArgs a{};
+    a.rec = U.d_rec.p; a.ent = U.d_ent.p; a.alive = U.d_alive.p; a.id0 = id0; a.id1 = id1;
+    a.dense = U.d_dense.p; a.n_pos = U.n_pos; a.qpad = U.qpad; a.dbot = U.d_dbot.p; a.q0 = q0; a.q1 = q1;
+    a.best = U.d_best.p; a.cnt = U.d_cnt.p; a.ids = U.d_ids.p; a.hu = U.d_hu.p; a.cap = kTouchedCap;
+    return a;
+}
+}  // namespace
+
+int ugp_mat_update(ugp_mat *m, const ugp_touched *recs, const uint32_t *retired, uint64_t n_retired, uint32_t *first_id) {
+    if (!m || (n_retired && !retired)) return fail(UGP_ERR_INVALID, "null argument");
+    auto &U = m->upd;
+    const uint64_t N = m->flat.n_nodes, n_new = recs ? recs->n : 0;
+    if (first_id) *first_id = (uint32_t)U.n_rec;
+    if (n_new && (!recs->flat_j || !recs->flags || !recs->n_path || !recs->ent_off)) return fail(UGP_ERR_INVALID, "null record arrays");
+    if (N >= (1ull << 30)) return fail(UGP_ERR_UNSUPPORTED, "ugp_mat_update needs a tree of fewer than 2^30 nodes");
+    if (U.rec.size() != N) return fail(UGP_ERR_UNSUPPORTED, "this handle was flattened without the update maps (UGP_NO_UPDATE_MAPS)");
+    if (U.n_rec + n_new >= (1ull << 32)) return fail(UGP_ERR_UNSUPPORTED, "more than 2^32 records");
+    if (int rc = drain(m)) return rc;
+    try {
+        // retired records
+        if (n_retired) {
+            for (uint64_t i = 0; i < n_retired; i++) if (retired[i] >= U.n_rec) return fail(UGP_ERR_INVALID, "retired record id out of range");
+            std::vector<uint32_t> pos(retired, retired + n_retired);
+            HIP_TRY(U.d_tmp.upload(pos));
+            // (alive is a byte per record: clear it through the word that holds it)
+            for (uint64_t i = 0; i < n_retired; i++) HIP_TRY(hipMemsetAsync(U.d_alive.p + retired[i], 0, 1, nullptr));
+        }
+        if (!n_new) { HIP_TRY(hipStreamSynchronize(nullptr)); return UGP_OK; }
+        const uint64_t n_ent = recs->ent_off[n_new];
+        if (n_ent && (!recs->pos || !recs->allele || !recs->prev || !recs->ref)) return fail(UGP_ERR_INVALID, "null entry arrays");
+        std::vector<ugp::TouchedRec> hr(n_new);
+        std::vector<ugp::TouchedEnt> he(n_ent);
+        std::vector<uint32_t> p8, pr, pt, c8, cr, ct;
+        auto one_hot = [](uint8_t a) { return a == 1 || a == 2 || a == 4 || a == 8; };
+        for (uint64_t i = 0; i < n_new; i++) {
+            const uint64_t b = recs->ent_off[i], e = recs->ent_off[i + 1];
+            if (e < b || e > n_ent || recs->n_path[i] > e - b) return fail(UGP_ERR_INVALID, "record offsets are not monotone");
+            if (U.n_ent + b >= (1ull << 32)) return fail(UGP_ERR_UNSUPPORTED, "more than 2^32 record entries");
+            hr[i] = {(uint32_t)(U.n_ent + b), recs->n_path[i], (uint32_t)(e - b) - recs->n_path[i], (uint32_t)recs->flags[i]};
+            for (uint64_t k = b; k < e; k++) {
+                const bool own = k - b >= recs->n_path[i];
+                if (!one_hot(recs->allele[k]) || !one_hot(recs->ref[k]) || (own && !one_hot(recs->prev[k]))) return fail(UGP_ERR_UNSUPPORTED, "record alleles must be single bases");
+                he[k] = {recs->pos[k], (uint32_t)recs->allele[k] | ((uint32_t)(own ? recs->prev[k] : 0) << 8) | ((uint32_t)recs->ref[k] << 16)};
+            }
+            const uint32_t j = recs->flat_j[i];
+            if (j == UINT32_MAX) continue;
+            if (j == 0 || j >= N) return fail(j == 0 ? UGP_ERR_UNSUPPORTED : UGP_ERR_INVALID, j == 0 ? "the root cannot be taken out of the candidate set" : "flat_j out of range");
+            if (U.hdr8[j] != UINT32_MAX) p8.push_back(U.hdr8[j]);
+            pr.push_back(U.rec[j] + 1u);
+            if (U.post[j] != UINT32_MAX) pt.push_back(U.post[j] + 1u);
+            if (m->coarse) {
+                auto it = std::lower_bound(U.coarse2bfs.begin(), U.coarse2bfs.end(), j);
+                if (it != U.coarse2bfs.end() && *it == j) {
+                    const size_t k = (size_t)(it - U.coarse2bfs.begin());
+                    auto &C = m->coarse->upd;
+                    if (C.rec.size() == m->coarse->flat.n_nodes && k != 0) {
+                        if (C.hdr8[k] != UINT32_MAX) c8.push_back(C.hdr8[k]);
+                        cr.push_back(C.rec[k] + 1u);
+                        if (C.post[k] != UINT32_MAX) ct.push_back(C.post[k] + 1u);
+                    }
+                }
+            }
+            U.n_excluded++;
+        }
+        HIP_TRY(U.d_rec.grow_keep(U.n_rec + n_new, U.n_rec));
+        HIP_TRY(U.d_alive.grow_keep(U.n_rec + n_new, U.n_rec));
+        HIP_TRY(U.d_ent.grow_keep(U.n_ent + n_ent, U.n_ent));
+        HIP_TRY(hipMemcpy(U.d_rec.p + U.n_rec, hr.data(), n_new * sizeof(ugp::TouchedRec), hipMemcpyHostToDevice));
+        if (n_ent) HIP_TRY(hipMemcpy(U.d_ent.p + U.n_ent, he.data(), n_ent * sizeof(ugp::TouchedEnt), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemset(U.d_alive.p + U.n_rec, 1, n_new));
+        U.n_rec += n_new; U.n_ent += n_ent;
+        // the flattened nodes among them leave the candidate set: one bit in their words of the packed stream (H_NOSCORE), of the
+        // 32-bit stream and of the tie stream (bit 31 of the key word), here and in the coarse tree of the locality pre-pass
+        if (int rc = or_words(m, m->d_stream8.p, p8, ugp::H_NOSCORE)) return rc;
+        if (int rc = or_words(m, m->d_stream.p, pr, ugp::KEY_EXCLUDED)) return rc;
+        if (int rc = or_words(m, m->d_stream_t.p, pt, ugp::KEY_EXCLUDED)) return rc;
+        if (m->coarse) {
+            if (int rc = or_words(m, m->coarse->d_stream8.p, c8, ugp::H_NOSCORE)) return rc;
+            if (int rc = or_words(m, m->coarse->d_stream.p, cr, ugp::KEY_EXCLUDED)) return rc;
+            if (int rc = or_words(m, m->coarse->d_stream_t.p, ct, ugp::KEY_EXCLUDED)) return rc;
+        }
+    } catch (const std::bad_alloc &) { return fail(UGP_ERR_NOMEM, "out of host memory"); }
+    return UGP_OK;
+}
+
+int ugp_touched_open(ugp_mat *m, const ugp_queries *q) {
+    if (!m || !q) return fail(UGP_ERR_INVALID, "null argument");
+    auto &U = m->upd;
+    U.open = false;
+    if (int rc = drain(m)) return rc;
+    if (!U.qs) { U.qs = new (std::nothrow) ugp_qset(); if (!U.qs) return fail(UGP_ERR_NOMEM, "out of host memory"); }
+    if (int rc = qset_fill(m, q, U.qs)) return rc;
+    const uint64_t Q = q->n_queries, n_ent = U.qs->n_ent;
+    if (Q >= (1ull << 31)) return fail(UGP_ERR_UNSUPPORTED, "batch too large");
+    int32_t max_pos = (int32_t)m->flat.max_pos;
+    for (uint64_t e = 0; e < n_ent; e++) max_pos = std::max(max_pos, q->pos[e]);
+    U.n_pos = (uint32_t)max_pos + 1u;
+    U.qpad = (uint32_t)((Q + 63) / 64 * 64);
+    U.Q = Q;
+    if (!Q) { U.open = true; return UGP_OK; }
+    HIP_TRY(U.d_dense.reserve((size_t)U.n_pos * U.qpad));
+    HIP_TRY(U.d_dbot.reserve(U.qpad)); HIP_TRY(U.d_best.reserve(U.qpad)); HIP_TRY(U.d_list_best.reserve(U.qpad)); HIP_TRY(U.d_cnt.reserve(U.qpad));
+    HIP_TRY(U.d_ids.reserve((size_t)U.qpad * kTouchedCap)); HIP_TRY(U.d_hu.reserve((size_t)U.qpad * kTouchedCap));
+    HIP_TRY(hipMemsetAsync(U.d_dense.p, 0, (size_t)U.n_pos * U.qpad, nullptr));
+    HIP_TRY(hipMemsetAsync(U.d_dbot.p, 0, (size_t)U.qpad * 4, nullptr));
+    HIP_TRY(hipMemsetAsync(U.d_cnt.p, 0, (size_t)U.qpad * 4, nullptr));
+    HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)U.d_best.p, INT32_MAX, U.qpad, nullptr));
+    HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)U.d_list_best.p, INT32_MAX, U.qpad, nullptr));
+    if (n_ent)
+        HIP_TRY(ugp::launch_dense_scatter(U.d_dense.p, U.n_pos, U.qpad, U.d_dbot.p, U.qs->d_pos.p, U.qs->d_ref.p, U.qs->d_nuc.p, U.qs->d_missing.p, U.qs->d_ent_q.p,
+                                          n_ent, nullptr));
+    U.open = true;
+    if (U.n_rec) HIP_TRY(ugp::launch_touched(touched_args(m, 0, (uint32_t)U.n_rec, 0, (uint32_t)Q), U.d_list_best.p, nullptr));
+    return UGP_OK;
+}
+
+int ugp_touched_score(ugp_mat *m, uint32_t first_id, uint64_t first_sample) {
+    if (!m) return fail(UGP_ERR_INVALID, "null argument");
+    auto &U = m->upd;
+    if (!U.open) return fail(UGP_ERR_INVALID, "no batch is open (ugp_touched_open)");
+    if (first_id > U.n_rec || first_sample > U.Q) return fail(UGP_ERR_INVALID, "record id / sample out of range");
+    HIP_TRY(hipSetDevice(m->device));
+    HIP_TRY(ugp::launch_touched(touched_args(m, first_id, (uint32_t)U.n_rec, (uint32_t)first_sample, (uint32_t)U.Q), U.d_list_best.p, nullptr));
+    return UGP_OK;
+}
+
+int ugp_touched_rescore(ugp_mat *m, uint64_t sample) {
+    if (!m) return fail(UGP_ERR_INVALID, "null argument");
+    auto &U = m->upd;
+    if (!U.open || sample >= U.Q) return fail(UGP_ERR_INVALID, "no batch is open / sample out of range");
+    HIP_TRY(hipSetDevice(m->device));
+    HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)(U.d_best.p + sample), INT32_MAX, 1, nullptr));
+    HIP_TRY(hipMemsetD32Async((hipDeviceptr_t)(U.d_list_best.p + sample), INT32_MAX, 1, nullptr));
+    HIP_TRY(hipMemsetAsync(U.d_cnt.p + sample, 0, 4, nullptr));
+    if (U.n_rec) HIP_TRY(ugp::launch_touched(touched_args(m, 0, (uint32_t)U.n_rec, (uint32_t)sample, (uint32_t)sample + 1u), U.d_list_best.p, nullptr));
+    return UGP_OK;
+}
+
+int ugp_touched_fetch(ugp_mat *m, uint64_t first_sample, uint64_t n, uint32_t cap, int32_t *best, uint32_t *count, uint32_t *ids, uint8_t *has_unique) {
+    if (!m || (n && (!best || !count || (cap && (!ids || !has_unique))))) return fail(UGP_ERR_INVALID, "null argument");
+    auto &U = m->upd;
+    if (!U.open || first_sample + n > U.Q) return fail(UGP_ERR_INVALID, "no batch is open / samples out of range");
+    if (!n) return UGP_OK;
+    HIP_TRY(hipSetDevice(m->device));
+    HIP_TRY(hipMemcpy(best, U.d_best.p + first_sample, n * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(count, U.d_cnt.p + first_sample, n * 4, hipMemcpyDeviceToHost));
+    if (cap) {
+        const uint32_t k = std::min(cap, kTouchedCap);
+        if (k == kTouchedCap && cap == kTouchedCap) {
+            HIP_TRY(hipMemcpy(ids, U.d_ids.p + first_sample * kTouchedCap, n * kTouchedCap * 4, hipMemcpyDeviceToHost));
+            HIP_TRY(hipMemcpy(has_unique, U.d_hu.p + first_sample * kTouchedCap, n * kTouchedCap, hipMemcpyDeviceToHost));
+        } else {
+            HIP_TRY(hipMemcpy2D(ids, (size_t)cap * 4, U.d_ids.p + first_sample * kTouchedCap, (size_t)kTouchedCap * 4, (size_t)k * 4, n, hipMemcpyDeviceToHost));
+            HIP_TRY(hipMemcpy2D(has_unique, cap, U.d_hu.p + first_sample * kTouchedCap, kTouchedCap, k, n, hipMemcpyDeviceToHost));
+        }
+    }
+    return UGP_OK;
 }
 
 // Durations of the set's last call from its HIP events (waits for that call), added to the handle's running totals.

@@ -591,6 +591,12 @@ int flatten(const ugp_tree_desc &t, const Options &opt, FlatMat &out, std::strin
         out.rank_dfs.resize(N);
         par.run(N, [&](uint64_t b, uint64_t e, unsigned) { for (uint64_t d = b; d < e; d++) out.rank_dfs[d] = rank[d2b[d]]; });
     } else { out.node_pos8.clear(); out.rank_dfs.clear(); }
+    if (opt.keep_update_maps) {
+        out.hdr8_of_bfs.resize(N); out.rec_of_bfs.resize(N);
+        par.run(N, [&](uint64_t b, uint64_t e, unsigned) {
+            for (uint64_t d = b; d < e; d++) { const uint32_t j = d2b[d]; out.hdr8_of_bfs[j] = dropped[j] ? UINT32_MAX : pos8_hdr[d]; out.rec_of_bfs[j] = rec_off_d[d]; }
+        });
+    } else { out.hdr8_of_bfs.clear(); out.rec_of_bfs.clear(); }
     out.stream8.resize(total8);
     par.run(NC, [&](uint64_t b, uint64_t e, unsigned) {
         uint32_t *s8 = out.stream8.data();
@@ -670,8 +676,14 @@ int flatten(const ugp_tree_desc &t, const Options &opt, FlatMat &out, std::strin
         const uint64_t total_t = par.exclusive_scan(out.chunk_t_off.data(), NC);
         out.chunk_t_off[NC] = (uint32_t)total_t;
         out.stream_t.resize(total_t);
+        if (opt.keep_update_maps) out.post_of_bfs.resize(N); else out.post_of_bfs.clear();
         par.run(NC, [&](uint64_t b, uint64_t e, unsigned) {
             for (uint64_t c = b; c < e; c++) {
+                if (opt.keep_update_maps)
+                    for (uint32_t d = cno[c]; d < cno[c + 1]; d++) {
+                        const uint32_t j = d2b[d];
+                        out.post_of_bfs[j] = dropped[j] ? UINT32_MAX : out.chunk_t_off[c] + post_at[d] + (t_big(j) ? 2u : 0u);
+                    }
                 uint32_t *st = out.stream_t.data() + out.chunk_t_off[c];
                 const uint32_t len = out.chunk_t_off[c + 1] - out.chunk_t_off[c];
                 for (uint32_t d = cno[c]; d < cno[c + 1]; d++) {

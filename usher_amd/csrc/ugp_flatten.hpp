@@ -125,6 +125,8 @@ struct Options {
     uint32_t lds_slots = LDS_SLOTS; // headers whose (renumbered) slots are >= this are flagged H_SLOW
     uint32_t pre_weight = 32;   // weight of the preambles' slot accesses when the hot (LDS) slots are chosen: every unit replays one,
                                 // the body is mostly skipped (0: body counts only)
+    bool keep_update_maps = false;  // export FlatMat::hdr8_of_bfs / rec_of_bfs / post_of_bfs: where each node's record sits in the three streams
+                                    // (ugp_mat_update takes rewritten nodes out of the candidate set by patching those words on the device)
     uint32_t threads = 0;       // host threads (0 = UGP_FLATTEN_THREADS, else min(32, hardware threads)); the output does not depend on it
 };
 
@@ -162,6 +164,9 @@ struct FlatMat {
     uint32_t max_path_muts = 0;            // max over nodes of the mutation count on the root path
     std::vector<uint32_t> rank_dfs;        // (Options::keep_node_pos8) [n_nodes] by DFS index: the node's tie rank
     std::vector<uint32_t> node_pos8;       // (Options::keep_node_pos8) [n_nodes + 1] by DFS index: packed-stream position where the node's words begin
+    // (Options::keep_update_maps) by BFS index: position of the node's header word in stream8, of its record (w0) in stream and in
+    // stream_t; UINT32_MAX = the node has no record there (leaves without mutation words are dropped from stream8 / stream_t)
+    UVec<uint32_t> hdr8_of_bfs, rec_of_bfs, post_of_bfs;
     uint32_t max_chunk8_words = 0;         // longest chunk of the packed stream (a work unit must stay below the reach of a preamble record's jump field)
     uint32_t lds_slots = 0;                // the Options value the packed stream was encoded for (<= max_slots)
     bool mask_not_first = false;           // some non-root node lists a masked mutation behind an ordinary one: only the

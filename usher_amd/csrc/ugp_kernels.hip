@@ -36,6 +36,7 @@
 #include <type_traits>
 
 #include "ugp_kernels.hpp"
+#include "ugp_update.hpp"
 
 namespace ugp {
 
@@ -426,9 +427,12 @@ __device__ __forceinline__ WalkOut walk_ties(const PlaceArgs &a, uint32_t *slots
         uint32_t info = 0, info_hr = 255;
         while (pos < end) {
             const uint32_t w0 = next();
-            const uint32_t key = next();
+            const uint32_t key_w = next();
             const uint32_t nmut = w0 & 0xFFFFu;
-            if (nmut == T_INFO_MARK) { have_info = true; info = key; info_hr = (w0 >> 16) & 0xFFu; continue; }
+            if (nmut == T_INFO_MARK) { have_info = true; info = key_w; info_hr = (w0 >> 16) & 0xFFu; continue; }
+            // (bit 31 of the key word: the node was rewritten since the tree was flattened, ugp_mat_update -- no candidate any more)
+            const uint32_t key = key_w & ~KEY_EXCLUDED;
+            const bool excluded = (key_w & KEY_EXCLUDED) != 0;
             const uint32_t rslot = (w0 >> 16) & 63u, wslot = (w0 >> 22) & 63u;
             uint32_t xpar;   // (D | B << 16) of the parent
             if (rslot == RS_REG) xpar = dcur;
@@ -467,7 +471,7 @@ __device__ __forceinline__ WalkOut walk_ties(const PlaceArgs &a, uint32_t *slots
                     elig = (common > 0) || free_internal;
                     hu = (masked || common != n_before) ? 1u : 0u;
                 }
-                if (relevant && elig && cost == want) {
+                if (relevant && elig && !excluded && cost == want) {
                     o.cnt++; o.key = max(o.key, key | hu);
                     if (LIST) {
                         const uint32_t i = atomicAdd(&a.tie_count[list_q], 1u);
@@ -515,7 +519,9 @@ __device__ __forceinline__ WalkOut walk(const PlaceArgs &a, uint32_t *slots, uin
         else rd.init(a.stream, a.chunk_body_off[c0], a.chunk_body_off[c1], lane, tab8, rowbuf, a.n_sites);
         while (!rd.done()) {
             const uint32_t w0 = rd.next(lane);
-            const uint32_t key = rd.next(lane);
+            const uint32_t key_w = rd.next(lane);
+            const uint32_t key = key_w & ~KEY_EXCLUDED;
+            const bool excluded = (key_w & KEY_EXCLUDED) != 0;   // rewritten since the tree was flattened (ugp_mat_update): scored, but no candidate
             const uint32_t nmut = w0 & 0xFFFFu;
             const uint32_t rslot = (w0 >> 16) & 63u, wslot = (w0 >> 22) & 63u;
             uint32_t dpar;
@@ -553,10 +559,10 @@ __device__ __forceinline__ WalkOut walk(const PlaceArgs &a, uint32_t *slots, uin
                     hu = (masked || common != n_before) ? 1u : 0u;
                 }
                 uint32_t bfs = 0, rkey = key;
-                bool cand = true;
+                bool cand = !excluded;
                 if (EX || MODE == 1 || MODE == 2) bfs = a.dfs2bfs[node_idx];
                 if (EX) {
-                    cand = (!a.node_mask || a.node_mask[bfs]) && bfs != skip_bfs;
+                    cand = cand && (!a.node_mask || a.node_mask[bfs]) && bfs != skip_bfs;
                     if (a.alt_rank) rkey = a.alt_rank[bfs] << 1;
                 }
                 const uint32_t oidx = (EX && a.out_index) ? a.out_index[bfs] : bfs;
@@ -578,7 +584,7 @@ __device__ __forceinline__ WalkOut walk(const PlaceArgs &a, uint32_t *slots, uin
                         }
                     }
                 } else {
-                    if (elig && cost == want_best) { o.cnt++; o.key = max(o.key, key | hu); }
+                    if (elig && cand && cost == want_best) { o.cnt++; o.key = max(o.key, key | hu); }
                 }
                 node_idx++;
             }
@@ -1845,9 +1851,10 @@ __global__ void __launch_bounds__(256) k_descend(const ugp_result *__restrict__ 
     const uint32_t *trow = table + ((uint64_t)(slot >> 9) * (n_sites + TABLE_CONST_ROWS) + TABLE_CONST_ROWS) * 64 + ((slot & 511u) >> 3);
     const uint32_t sh = (slot & 7u) * 4u;
     // one node for one sample: sum of delta over all words, sum of min(delta, 0) and shared mutations before the first masked one
-    auto eval = [&](uint32_t rec_at, int &dsum, int &neg, uint32_t &common, uint32_t &w0) {
+    auto eval = [&](uint32_t rec_at, int &dsum, int &neg, uint32_t &common, uint32_t &w0, bool &excluded) {
         const uint32_t *rec = stream + rec_at;
         w0 = rec[0];
+        excluded = (rec[1] & KEY_EXCLUDED) != 0;   // rewritten since the tree was flattened: its cost is no bound of best(s)
         const uint32_t m0 = rec[2], m1 = rec[3];   // (fetched with w0; real only if the record is that long)
         const uint32_t nw = w0 & 0xFFFFu;
         dsum = 0; neg = 0; common = 0;
@@ -1875,8 +1882,8 @@ __global__ void __launch_bounds__(256) k_descend(const ugp_result *__restrict__ 
         start[0] = node;
         uint2 pr = node_pair[node];
         uint32_t ce = node_pair[node + 1].x;
-        int dsum, neg; uint32_t common, w0;
-        eval(pr.y, dsum, neg, common, w0);
+        int dsum, neg; uint32_t common, w0; bool excl;
+        eval(pr.y, dsum, neg, common, w0, excl);
         // cost(node) = D(parent) + neg = best  ->  D(parent) = best - neg, D(node) = D(parent) + dsum;  the root's cost is its D
         int D = (w0 & F_ROOT) ? best : best - neg + dsum;
         if (gl == 0) { f_node[g][0] = node; f_d[g][0] = D; f_cb[g][0] = pr.x + 1u; f_ce[g][0] = ce + 1u; }
@@ -1889,7 +1896,7 @@ __global__ void __launch_bounds__(256) k_descend(const ugp_result *__restrict__ 
             ce = node_pair[node + 1].x;
             if (gl == 0) { f_node[g][n_f] = node; f_d[g][n_f] = D; f_cb[g][n_f] = pr.x + 1u; f_ce[g][n_f] = ce + 1u; }
             n_f++;
-            eval(pr.y, dsum, neg, common, w0);
+            eval(pr.y, dsum, neg, common, w0, excl);
         }
     }
     for (uint32_t it = 0; it < max_expansions; it++) {
@@ -1923,10 +1930,10 @@ __global__ void __launch_bounds__(256) k_descend(const ugp_result *__restrict__ 
                 const uint2 pr = node_pair[c];
                 cce = node_pair[c + 1].x + 1u;
                 ccb = pr.x + 1u;
-                int dsum, neg; uint32_t common, w0;
-                eval(pr.y, dsum, neg, common, w0);
+                int dsum, neg; uint32_t common, w0; bool excl;
+                eval(pr.y, dsum, neg, common, w0, excl);
                 const bool leaf = (w0 & F_LEAF) != 0, masked = (w0 & F_MASKED) != 0;
-                if (!masked && (common > 0 || (!leaf && (w0 & 0xFFFFu) == 0))) cost = D + neg;
+                if (!masked && !excl && (common > 0 || (!leaf && (w0 & 0xFFFFu) == 0))) cost = D + neg;
                 dc = D + dsum;
                 // follow a child whose D does not grow -- or grows by one while it shares a mutation with the sample (the sample's
                 // lineage passing a node of which it lacks one mutation; a sibling branch shares one only by homoplasy)

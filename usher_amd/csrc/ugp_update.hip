@@ -1,0 +1,111 @@
+// ugp_update.hip -- gfx950 kernels of the add mode: scoring of the nodes created or rewritten since the tree was flattened
+// against a batch of pending samples, and the exclusion of rewritten nodes from the flattened tree's candidate set.
+// See ugp_update.hpp.  Integer work, lanes = samples, record data wave-uniform.
+#include "ugp_update.hpp"
+
+#include <climits>
+
+namespace ugp {
+
+__global__ void k_or_words(uint32_t *__restrict__ stream, const uint32_t *__restrict__ pos, uint32_t n, uint32_t bits) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && pos[i] != 0xFFFFFFFFu) atomicOr(&stream[pos[i]], bits);   // (a node may be listed twice in one call)
+}
+
+hipError_t launch_or_words(uint32_t *stream, const uint32_t *pos, uint32_t n, uint32_t bits, hipStream_t s) {
+    if (!n) return hipSuccess;
+    hipLaunchKernelGGL(k_or_words, dim3((n + 255) / 256), dim3(256), 0, s, stream, pos, n, bits);
+    return hipGetLastError();
+}
+
+// dense[pos][q] = allele mask of the sample's row at pos (15 for a missing call); D(bottom) = rows whose set excludes the
+// reference base (usher_mapper.cpp:292-388 with an empty ancestral list).  Rows are unique per (sample, position).
+__global__ void k_dense_scatter(uint8_t *__restrict__ dense, uint32_t n_pos, uint32_t qpad, int32_t *__restrict__ dbot, const int32_t *__restrict__ pos,
+                                const uint8_t *__restrict__ ref, const uint8_t *__restrict__ nuc, const uint8_t *__restrict__ is_missing,
+                                const uint32_t *__restrict__ ent_q, uint64_t n_ent) {
+    const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n_ent) return;
+    const int32_t p = pos[e];
+    const uint32_t q = ent_q[e];
+    const uint32_t a = is_missing[e] ? 15u : (uint32_t)nuc[e];
+    if (!is_missing[e] && (a & ref[e]) == 0) atomicAdd(&dbot[q], 1);
+    if (p >= 0 && (uint32_t)p < n_pos) dense[(uint64_t)p * qpad + q] = (uint8_t)a;
+}
+
+hipError_t launch_dense_scatter(uint8_t *dense, uint32_t n_pos, uint32_t qpad, int32_t *dbot, const int32_t *pos, const uint8_t *ref, const uint8_t *nuc,
+                                const uint8_t *is_missing, const uint32_t *ent_q, uint64_t n_ent, hipStream_t s) {
+    if (!n_ent) return hipSuccess;
+    hipLaunchKernelGGL(k_dense_scatter, dim3((uint32_t)((n_ent + 255) / 256)), dim3(256), 0, s, dense, n_pos, qpad, dbot, pos, ref, nuc, is_missing, ent_q, n_ent);
+    return hipGetLastError();
+}
+
+// One wave = 64 samples x a run of records.  For record x and sample s (closed form, SURVEY 8a / DESIGN 2):
+//   D(parent) = D(bottom) + sum over the positions where the parent's state is not the reference base of
+//               ([state not in S] - [ref not in S]);   cost = D(parent) + sum over own mutations of min(delta, 0)
+//   eligible  = common > 0 or (internal and no mutations);   has_unique = masked or common != #mutations
+// The entries of a record are read through scalar loads (the record index is wave-uniform); a lane's share is one byte of the
+// dense table per entry -- 64 consecutive bytes per wave.
+constexpr uint32_t T_RECS_PER_BLOCK = 16;
+template <int PASS>
+__global__ void __launch_bounds__(64) k_touched(TouchedArgs a) {
+    const uint32_t lane = threadIdx.x;
+    const uint32_t q = a.q0 + blockIdx.y * 64u + lane;
+    const bool in = q < a.q1;
+    const uint32_t qc = in ? q : a.q0;   // (lanes past the end read a valid column and write nothing)
+    const uint32_t id_b = a.id0 + blockIdx.x * T_RECS_PER_BLOCK, id_e = min(a.id1, id_b + T_RECS_PER_BLOCK);
+    const int dbot = a.dbot[qc];
+    const int want = PASS == 2 ? a.best[qc] : 0;
+    int lmin = INT_MAX;
+    for (uint32_t id = id_b; id < id_e; id++) {
+        if (!a.alive[id]) continue;
+        const TouchedRec r = a.rec[id];
+        const TouchedEnt *e = a.ent + r.ent_off;
+        int D = dbot;
+        for (uint32_t k = 0; k < r.n_path; k++) {
+            const int32_t p = e[k].pos;
+            const uint32_t bits = e[k].bits, al = bits & 15u, rf = (bits >> 16) & 15u;
+            const uint32_t row = (uint32_t)p < a.n_pos ? (uint32_t)a.dense[(uint64_t)(uint32_t)p * a.qpad + qc] : 0u;
+            const uint32_t sp = row ? row : rf;
+            D += (int)((sp & al) == 0) - (int)((sp & rf) == 0);
+        }
+        int neg = 0;
+        uint32_t common = 0;
+        for (uint32_t k = r.n_path; k < r.n_path + r.n_own; k++) {
+            const int32_t p = e[k].pos;
+            const uint32_t bits = e[k].bits, mu = bits & 15u, pv = (bits >> 8) & 15u, rf = (bits >> 16) & 15u;
+            const uint32_t row = (uint32_t)p < a.n_pos ? (uint32_t)a.dense[(uint64_t)(uint32_t)p * a.qpad + qc] : 0u;
+            const uint32_t sp = row ? row : rf;
+            const int c = (sp & mu) != 0, pr = (sp & pv) != 0;
+            common += (uint32_t)c;
+            neg += min(pr - c, 0);
+        }
+        const bool masked = (r.flags & T_MASKED) != 0;
+        const uint32_t num_mut = r.n_own + (masked ? 1u : 0u);
+        const int cost = D + neg;
+        const bool elig = common > 0 || (!(r.flags & T_LEAF) && num_mut == 0);
+        if (PASS == 1) { if (elig) lmin = min(lmin, cost); }
+        else if (in && elig && cost == want) {
+            const uint32_t i = atomicAdd(&a.cnt[q], 1u);
+            if (i < a.cap) { a.ids[(uint64_t)q * a.cap + i] = id; a.hu[(uint64_t)q * a.cap + i] = (masked || common != num_mut) ? 1 : 0; }
+        }
+    }
+    if (PASS == 1 && in && lmin != INT_MAX) atomicMin(&a.best[q], lmin);
+}
+
+// Between the passes: where the minimum fell below the cost the sample's list was built for, the list starts over.
+__global__ void k_touched_reset(const int32_t *__restrict__ best, int32_t *__restrict__ list_best, uint32_t *__restrict__ cnt, uint32_t q0, uint32_t q1) {
+    const uint32_t q = q0 + blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= q1) return;
+    if (best[q] < list_best[q]) { list_best[q] = best[q]; cnt[q] = 0; }
+}
+
+hipError_t launch_touched(const TouchedArgs &a, int32_t *list_best, hipStream_t s) {
+    if (a.id1 <= a.id0 || a.q1 <= a.q0) return hipSuccess;
+    const dim3 grid((a.id1 - a.id0 + T_RECS_PER_BLOCK - 1) / T_RECS_PER_BLOCK, (a.q1 - a.q0 + 63) / 64);
+    hipLaunchKernelGGL(k_touched<1>, grid, dim3(64), 0, s, a);
+    hipLaunchKernelGGL(k_touched_reset, dim3((a.q1 - a.q0 + 255) / 256), dim3(256), 0, s, a.best, list_best, a.cnt, a.q0, a.q1);
+    hipLaunchKernelGGL(k_touched<2>, grid, dim3(64), 0, s, a);
+    return hipGetLastError();
+}
+
+}  // namespace ugp

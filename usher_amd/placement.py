@@ -241,6 +241,46 @@ class Placer:
         self._ck(self._L.ugp_subtree_mask(self._h, {"bfs": 0, "dfs": 1}[order], int(root_j), int(max_levels), _ptr(out)))
         return out
 
+    # ---- add mode: records of the nodes created or rewritten since the tree was flattened -----------------------------
+    def update(self, records: Sequence[Dict] = (), retired: Sequence[int] = ()) -> int:
+        """ugp_mat_update.  A record is a dict: flat_j (index in the flattened tree, or None for a node created since), leaf, masked,
+        path = [(pos, state, ref)] -- the parent's state wherever it is not the reference base --, own = [(pos, mut, prev, ref)].
+        Returns the id of the first new record."""
+        n = len(records)
+        flat_j = np.array([0xFFFFFFFF if r.get("flat_j") is None else r["flat_j"] for r in records], np.uint32)
+        flags = np.array([(1 if r.get("leaf") else 0) | (2 if r.get("masked") else 0) for r in records], np.uint8)
+        n_path = np.array([len(r["path"]) for r in records], np.uint32)
+        off = np.zeros(n + 1, np.uint64)
+        pos, al, pv, rf = [], [], [], []
+        for i, r in enumerate(records):
+            for (p, a, f) in r["path"]:
+                pos.append(p); al.append(a); pv.append(0); rf.append(f)
+            for (p, m, pr, f) in r["own"]:
+                pos.append(p); al.append(m); pv.append(pr); rf.append(f)
+            off[i + 1] = len(pos)
+        pos = np.array(pos, np.int32); al = np.array(al, np.uint8); pv = np.array(pv, np.uint8); rf = np.array(rf, np.uint8)
+        t = _lib.ugp_touched(n, _ptr(flat_j), _ptr(flags), _ptr(n_path), _ptr(off), _ptr(pos), _ptr(al), _ptr(pv), _ptr(rf))
+        ret = np.ascontiguousarray(list(retired), dtype=np.uint32)
+        first = C.c_uint32()
+        self._ck(self._L.ugp_mat_update(self._h, C.byref(t), _ptr(ret), len(ret), C.byref(first)))
+        return int(first.value)
+
+    def touched_open(self, batch: QueryBatch) -> None:
+        self._ck(self._L.ugp_touched_open(self._h, C.byref(batch.desc)))
+
+    def touched_score(self, first_id: int, first_sample: int) -> None:
+        self._ck(self._L.ugp_touched_score(self._h, first_id, first_sample))
+
+    def touched_rescore(self, sample: int) -> None:
+        self._ck(self._L.ugp_touched_rescore(self._h, sample))
+
+    def touched_fetch(self, first_sample: int, n: int, cap: int = 64):
+        """(best [n] int32 -- INT32_MAX when no record is eligible --, count [n], ids [n][cap], has_unique [n][cap])"""
+        best = np.zeros(n, np.int32); cnt = np.zeros(n, np.uint32)
+        ids = np.zeros((n, max(cap, 1)), np.uint32); hu = np.zeros((n, max(cap, 1)), np.uint8)
+        self._ck(self._L.ugp_touched_fetch(self._h, first_sample, n, cap, _ptr(best), _ptr(cnt), _ptr(ids), _ptr(hu)))
+        return best, cnt, ids, hu
+
     # ---- device-resident path (bench / multi-GPU) ---------------------------
     def upload(self, batch: QueryBatch):
         h = C.c_void_p()
