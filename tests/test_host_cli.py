@@ -513,3 +513,121 @@ def test_threaded_loaders_write_the_same_files(fixture, tmp_path, monkeypatch):
         assert o.keys() == outs[0].keys()
         for n in o:
             assert o[n] == outs[0][n], n
+
+
+@pytest.mark.parametrize("seed,n_leaves,n_new,batch,rnd", [(11, 60, 90, "32", "8"), (12, 150, 160, "64", "5"), (13, 30, 220, "4096", "64"),
+                                                           (14, 12, 130, "16", "1"), (15, 200, 260, "50", "16")])
+def test_add_mode_with_the_edits_on_the_device_equals_per_sample_research(tmp_path, monkeypatch, seed, n_leaves, n_new, batch, rnd):
+    """The add mode that keeps the flattened tree and reports the edits (Backend::update / touched_*, include/usher_amd.h "add mode"):
+    one flattening for the whole run, batches and rounds of several sizes -- including rounds of one sample and batches shorter than
+    the list of samples -- against the reference's loop (a full search of the current tree per sample, USHER_AMD_MAX_TOUCHED=0) and
+    against tests/usher_model.py (the oracle searching, the restated tree edits).  The backend here restates the device library's
+    semantics in numpy (running minima that go stale when their holders are rewritten, excluded nodes), so every "ask again" path of
+    the driver is exercised on CPU; on the GPU box the same driver runs on the HIP library (tests/test_add_mode_gpu.py)."""
+    import numpy as np
+    from tests import usher_model
+    from tests.host_harness import OracleBackend
+    rng = np.random.default_rng(seed)
+    nh, old, new = str(tmp_path / "t.nh"), str(tmp_path / "old.vcf"), str(tmp_path / "new.vcf")
+    _evolve_vcf(rng, n_leaves, 70, n_new, nh, old, new)
+    pb = str(tmp_path / "base.pb")
+    assert run_usher(["-t", nh, "-v", old, "-o", pb, "-d", str(tmp_path)]) == 0
+    outs = {}
+    for mode in ("research", "device"):
+        for k in ("USHER_AMD_MAX_TOUCHED", "USHER_AMD_BATCH", "USHER_AMD_ROUND"):
+            monkeypatch.delenv(k, raising=False)
+        if mode == "research":
+            monkeypatch.setenv("USHER_AMD_MAX_TOUCHED", "0")
+        else:
+            monkeypatch.setenv("USHER_AMD_BATCH", batch)
+            monkeypatch.setenv("USHER_AMD_ROUND", rnd)
+        d = tmp_path / mode
+        d.mkdir()
+        be = OracleBackend(add_mode=(mode == "device"))
+        assert run_usher(["-i", pb, "-v", new, "-u", "-o", str(d / "out.pb"), "-d", str(d)], backend=be) == 0
+        outs[mode] = {n: _read(str(d / n)) for n in ("placement_stats.tsv", "mutation-paths.txt", "uncondensed-final-tree.nh")}
+        outs[mode]["pb"] = _pb_semantic(str(d / "out.pb"))
+        if mode == "device":
+            assert be.stat["update"] > 0 and be.stat["open"] >= (n_new + int(batch) - 1) // int(batch) and be.calls >= be.stat["open"]
+            assert len(be.records) >= n_new        # every insertion left at least its leaf
+    assert outs["device"] == outs["research"]
+    # ... and the restated driver loop with the oracle doing every search
+    T = refio.load_mutation_annotated_tree(pb)
+    want = usher_model.run(T, refio.read_vcf(T, new))
+    assert outs["device"]["placement_stats.tsv"] == want["placement_stats.tsv"]
+    assert outs["device"]["mutation-paths.txt"] == want["mutation-paths.txt"]
+    assert sum(1 for l in want["placement_stats.tsv"].splitlines() if l.split("\t")[2] != "1") > 5      # ties were exercised
+
+
+@pytest.mark.parametrize("tcap", [None, "1"])
+def test_add_mode_asks_again_when_the_holders_of_a_minimum_were_rewritten(tmp_path, monkeypatch, capfd, tcap):
+    """The three "ask again" paths of the device add mode, on a tree built to need them.  K leaves with branch {a, b, c} each.
+    Batch 1: t1 = {a, b} + a private site -> sibling of the leaf: the leaf is rewritten (excluded from the flattened tree's search).
+    Batch 2, round 1: t2 = {a} + private -> splits the new internal node {a, b} into {a} above {b}; round 2: t3 = {b}, whose
+    record minimum was held by the node t2 rewrote, and everything that replaced it costs one more -> the record results of t3
+    are stale (asked again on the device).  t4 = {c} in batch 1 behind t1: its only optimal flattened node is the leaf t1 rewrote,
+    and the rewritten leaf {c} under {a, b} costs more -> the flattened tree is searched again for t4.  With lists of one entry
+    (USHER_AMD_TCAP=1) every tie among records is a truncated list (all records evaluated on the host).  Outputs equal the
+    per-sample research and tests/usher_model.py."""
+    from tests import usher_model
+    from tests.host_harness import OracleBackend
+    K = 12
+    nuc = "ACGT"
+    sites = [100 + 10 * i for i in range(3 * K + 3 * K + 2)]     # 3 per group, then private sites, then 2 for the outgroup
+    def write(path, names, alts_of):
+        with open(path, "w") as f:
+            f.write("##fileformat=VCFv4.2\n#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\t" + "\t".join(names) + "\n")
+            for si, p in enumerate(sites):
+                f.write("chr\t%d\t.\tA\tC\t.\t.\t.\tGT\t%s\n" % (p, "\t".join("1" if si in alts_of[n] else "0" for n in names)))
+    old_names = ["L%d" % k for k in range(K)] + ["OUT1", "OUT2"]
+    old_alts = {"L%d" % k: {3 * k, 3 * k + 1, 3 * k + 2} for k in range(K)}
+    old_alts["OUT1"] = {6 * K}; old_alts["OUT2"] = {6 * K + 1}
+    nh, old, new = str(tmp_path / "t.nh"), str(tmp_path / "old.vcf"), str(tmp_path / "new.vcf")
+    with open(nh, "w") as f:
+        f.write("(" + ",".join(old_names) + ");\n")
+    write(old, old_names, old_alts)
+    new_names, new_alts = [], {}
+    for k in range(K):            # batch 1 (2K samples): t1_k then t4_k
+        new_names.append("T1_%d" % k); new_alts[new_names[-1]] = {3 * k, 3 * k + 1, 3 * K + 3 * k}
+    for k in range(K):
+        new_names.append("T4_%d" % k); new_alts[new_names[-1]] = {3 * k + 2}
+    for k in range(K):            # batch 2: t2_k (round 1 ..), then t3_k
+        new_names.append("T2_%d" % k); new_alts[new_names[-1]] = {3 * k, 3 * K + 3 * k + 1}
+    for k in range(K):
+        new_names.append("T3_%d" % k); new_alts[new_names[-1]] = {3 * k + 1}
+    for k in range(0, K, 3):      # t6 = {a, b, c} + t1's private site: the new leaf of t1 and the rewritten leaf {c} tie -- two records
+        new_names.append("T6_%d" % k); new_alts[new_names[-1]] = {3 * k, 3 * k + 1, 3 * k + 2, 3 * K + 3 * k}
+    write(new, new_names, new_alts)
+    pb = str(tmp_path / "base.pb")
+    assert run_usher(["-t", nh, "-v", old, "-o", pb, "-d", str(tmp_path)]) == 0
+    outs = {}
+    for mode in ("research", "device"):
+        for kk in ("USHER_AMD_MAX_TOUCHED", "USHER_AMD_BATCH", "USHER_AMD_ROUND", "USHER_AMD_TCAP", "USHER_AMD_PROFILE"):
+            monkeypatch.delenv(kk, raising=False)
+        if mode == "research":
+            monkeypatch.setenv("USHER_AMD_MAX_TOUCHED", "0")
+        else:
+            monkeypatch.setenv("USHER_AMD_BATCH", str(2 * K))
+            monkeypatch.setenv("USHER_AMD_ROUND", str(K // 2))
+            monkeypatch.setenv("USHER_AMD_PROFILE", "1")
+            if tcap:
+                monkeypatch.setenv("USHER_AMD_TCAP", tcap)
+        d = tmp_path / mode
+        d.mkdir()
+        be = OracleBackend(add_mode=(mode == "device"))
+        capfd.readouterr()
+        assert run_usher(["-i", pb, "-v", new, "-u", "-d", str(d)], backend=be) == 0
+        err = capfd.readouterr().err
+        outs[mode] = {n: _read(str(d / n)) for n in ("placement_stats.tsv", "mutation-paths.txt", "uncondensed-final-tree.nh")}
+        if mode == "device":
+            line = [l for l in err.splitlines() if "add mode on the device" in l][0]
+            again = [int(x) for x in line.split("asked again:")[1].replace(",", " ").split() if x.isdigit()]
+            assert again[0] >= K // 2 and again[1] >= 1, line            # the flattened tree and the records were asked again
+            if tcap:
+                assert again[2] >= 1, line                                # ... and truncated lists went to the host
+            assert be.stat["rescore"] == again[1]
+    assert outs["device"] == outs["research"]
+    T = refio.load_mutation_annotated_tree(pb)
+    want = usher_model.run(T, refio.read_vcf(T, new))
+    assert outs["device"]["placement_stats.tsv"] == want["placement_stats.tsv"]
+    assert outs["device"]["mutation-paths.txt"] == want["mutation-paths.txt"]

@@ -967,6 +967,126 @@ int run_usher(const Options &opt, Tree &T, std::vector<MissingSample> &missing, 
         };
         struct Tie { Node *n; bool hu; };
         std::vector<Tie> tie_now;   // the tie set of the current sample on the tree as it is now (when it had to be rebuilt)
+        // ---- Add mode with the edits on the device (Backend::update, touched_*; include/usher_amd.h "add mode").  The tree is
+        // flattened ONCE.  Every node created or rewritten since becomes a record on the device; rewritten flattened nodes leave
+        // the candidate set of the device's searches.  Samples are taken in batches (one search of the flattened tree + one
+        // scoring of all live records per batch) and in rounds within a batch: the records of a round's insertions are uploaded
+        // and merged into the batch's results when the round ends, the nodes touched within the round are evaluated here.  The
+        // answer for a sample is the merge of three exact parts -- flattened nodes that are still what they were (device),
+        // records (device), this round's nodes (host) -- or, when a part has lost the holders of its minimum to later edits
+        // and that could matter, the part is asked again for this one sample.
+        struct DevAdd {
+            bool on = false, flat_done = false;
+            size_t batch = 4096, round = 64;
+            size_t base = 0, len = 0;       // the open batch: indexes [base, base + len)
+            std::vector<ugp_result> res;
+            std::vector<std::vector<std::pair<uint32_t, uint8_t>>> ties;
+            size_t rbase = 0, rlen = 0;     // record results fetched for indexes [rbase, rbase + rlen)
+            std::vector<int32_t> t_best;
+            std::vector<uint32_t> t_cnt, t_ids;
+            std::vector<uint8_t> t_hu;
+            std::vector<Node *> rec_node;   // record id -> node
+            std::vector<uint8_t> rec_dead;
+            std::unordered_map<const Node *, uint32_t> rec_of;   // live record of a node
+            std::vector<Node *> pending;    // touched since the last upload: evaluated on the host until then
+            std::unordered_set<const Node *> pending_set;
+            std::vector<uint32_t> pending_retired;
+            std::unordered_set<const Node *> since_batch;   // flattened nodes rewritten since the open batch was searched
+            size_t n_flush = 0, n_replace = 0, n_rescore = 0, n_host_all = 0, n_batches = 0;
+            double t_flush = 0, t_fetch = 0, t_batch = 0;
+        } dev;
+        uint32_t kTCap = 64;   // list entries per sample the device keeps (USHER_AMD_TCAP: the tests shorten it to reach the truncated-list path)
+        if (const char *e = getenv("USHER_AMD_TCAP")) kTCap = (uint32_t)std::max(1, std::min(64, atoi(e)));
+        dev.on = !static_tree && be.update && be.touched_open && be.touched_score && be.touched_rescore && be.touched_fetch && be.ties && !fixed_cap &&
+                 !literal_touched && !getenv("USHER_AMD_HOST_ADDMODE");
+        if (const char *e = getenv("USHER_AMD_BATCH")) dev.batch = (size_t)std::max(1, atoi(e));
+        if (const char *e = getenv("USHER_AMD_ROUND")) dev.round = (size_t)std::max(1, atoi(e));
+        uint64_t flat_version_dev = 0;
+        // records of the nodes touched since the last upload -> device; merged into the open batch's results from index ii on
+        auto dev_flush = [&](size_t ii) -> bool {
+            if (dev.pending.empty() && dev.pending_retired.empty()) return true;
+            const double t0 = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+            std::vector<uint32_t> flat_j, n_path;
+            std::vector<uint8_t> flags, al, pv, rf;
+            std::vector<uint64_t> off{0};
+            std::vector<int32_t> pos;
+            for (Node *x : dev.pending) {
+                const TouchedInfo &ti = tcache.info.at(x);
+                flat_j.push_back(flat.has(x) ? x->flat_index : UINT32_MAX);
+                flags.push_back((uint8_t)((x->is_leaf() ? UGP_T_LEAF : 0u) | (ti.masked ? UGP_T_MASKED : 0u)));
+                n_path.push_back((uint32_t)ti.path.size());
+                for (const auto &e : ti.path) { pos.push_back(e.pos); al.push_back(e.allele); pv.push_back(0); rf.push_back(e.ref); }
+                for (const auto &o : ti.own) { pos.push_back(o.pos); al.push_back(o.mut); pv.push_back(o.prev); rf.push_back(o.ref); }
+                off.push_back(pos.size());
+            }
+            ugp_touched t{};
+            t.n = dev.pending.size(); t.flat_j = flat_j.data(); t.flags = flags.data(); t.n_path = n_path.data(); t.ent_off = off.data();
+            t.pos = pos.data(); t.allele = al.data(); t.prev = pv.data(); t.ref = rf.data();
+            uint32_t first = 0;
+            if (be.update(be.ctx, &t, dev.pending_retired.data(), dev.pending_retired.size(), &first) != 0) return false;
+            if (first != dev.rec_node.size()) return false;   // (ids count up across calls: ours and the device's must agree)
+            for (Node *x : dev.pending) { dev.rec_of[x] = (uint32_t)dev.rec_node.size(); dev.rec_node.push_back(x); dev.rec_dead.push_back(0); }
+            dev.pending.clear(); dev.pending_set.clear(); dev.pending_retired.clear();
+            if (ii < dev.base + dev.len && be.touched_score(be.ctx, first, ii - dev.base) != 0) return false;
+            dev.rlen = 0;   // (what was fetched is out of date)
+            dev.n_flush++;
+            dev.t_flush += std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count() - t0;
+            return true;
+        };
+        auto dev_fetch = [&](size_t ii) -> bool {
+            const double t0 = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+            dev.rbase = ii; dev.rlen = std::min(dev.round, dev.base + dev.len - ii);
+            dev.t_best.resize(dev.rlen); dev.t_cnt.resize(dev.rlen); dev.t_ids.resize(dev.rlen * kTCap); dev.t_hu.resize(dev.rlen * kTCap);
+            const bool ok = be.touched_fetch(be.ctx, ii - dev.base, dev.rlen, kTCap, dev.t_best.data(), dev.t_cnt.data(), dev.t_ids.data(), dev.t_hu.data()) == 0;
+            dev.t_fetch += std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count() - t0;
+            return ok;
+        };
+        const uint32_t kTieCapDev = 256;
+        auto dev_batch = [&](size_t ii) -> bool {   // the next batch: searched on the flattened tree (rewritten nodes excluded), scored against every live record
+            const double t0 = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+            if (!dev.flat_done) {
+                flat.build(T);
+                prof.build += std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count() - t0; prof.flats++;
+                flat_version_dev = tree_version;
+                dev.flat_done = true;
+            }
+            dev.base = ii; dev.len = 0;           // (no batch is open while the pending records go up)
+            if (dev.flat_done && dev.n_batches && !dev_flush(ii)) return false;
+            dev.len = std::min(dev.batch, indexes.size() - ii);
+            FlatQueries rest;
+            for (size_t k = ii; k < ii + dev.len; k++) rest.add(rows_of(indexes[k]));
+            rest.finish();
+            dev.res.assign(dev.len, ugp_result{});
+            const double tp = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+            if (be.place(be.ctx, &flat.desc, flat_version_dev, &rest.desc, dev.res.data()) != 0) return false;
+            prof.place += std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count() - tp; prof.batches++;
+            if (dev.n_batches == 0 && !dev_flush(ii + dev.len)) return false;   // (first batch: the handle exists only now; nothing is pending yet)
+            dev.ties.assign(dev.len, {});
+            {
+                FlatQueries tq;
+                std::vector<size_t> who;
+                for (size_t k = 0; k < dev.len; k++)
+                    if (!odd[indexes[ii + k]] && dev.res[k].num_best > 1 && dev.res[k].num_best <= kTieCapDev) { who.push_back(k); tq.add(missing[indexes[ii + k]].mutations); }
+                if (!who.empty()) {
+                    tq.finish();
+                    std::vector<uint32_t> tj(who.size() * (size_t)kTieCapDev), tc(who.size());
+                    std::vector<uint8_t> th(who.size() * (size_t)kTieCapDev);
+                    const double tt = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+                    if (be.ties(be.ctx, &flat.desc, flat_version_dev, &tq.desc, kTieCapDev, tj.data(), th.data(), tc.data()) != 0) return false;
+                    prof.ties += std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count() - tt;
+                    for (size_t w = 0; w < who.size(); w++) {
+                        if (tc[w] != dev.res[who[w]].num_best) continue;   // (cannot happen; the list is then asked for again when the sample's turn comes)
+                        for (uint32_t k = 0; k < tc[w]; k++) dev.ties[who[w]].push_back({tj[w * kTieCapDev + k], th[w * kTieCapDev + k]});
+                    }
+                }
+            }
+            if (be.touched_open(be.ctx, &rest.desc) != 0) return false;
+            dev.since_batch.clear();
+            dev.rlen = 0;
+            dev.n_batches++;
+            dev.t_batch += std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count() - t0;
+            return true;
+        };
         FILE *stats = fopen((outdir + "/placement_stats.tsv").c_str(), "w");
         if (!stats) { fprintf(stderr, "ERROR: cannot write to %s\n", outdir.c_str()); return 1; }
         FILE *scores_file = nullptr;
@@ -995,7 +1115,110 @@ int run_usher(const Options &opt, Tree &T, std::vector<MissingSample> &missing, 
                 patched = true; patched_best = hs.best; patched_node = hs.best_node; patched_hu = hs.best_has_unique;
                 r = ugp_result{};
             } else if (static_tree) r = batch_res[s];
-            else {
+            else if (dev.on) {
+                if (ii >= dev.base + dev.len && !dev_batch(ii)) { fclose(stats); return be_fail("placement (add mode)"); }
+                if (dev.rlen == 0 || ii >= dev.rbase + dev.rlen) {
+                    if (!dev_flush(ii) || !dev_fetch(ii)) { fclose(stats); return be_fail("record scoring (add mode)"); }
+                }
+                const size_t k = ii - dev.base;
+                ugp_result fr = dev.res[k];
+                std::vector<std::pair<uint32_t, uint8_t>> own_list;
+                const std::vector<std::pair<uint32_t, uint8_t>> *flst = &dev.ties[k];
+                auto list_for = [&](const ugp_result &x) -> bool {   // the tie list of a flattened-tree answer that came without one
+                    FlatQueries q1;
+                    q1.add(rows_of(s));
+                    q1.finish();
+                    const uint32_t cap = x.num_best;
+                    std::vector<uint32_t> tj(cap), tc(1);
+                    std::vector<uint8_t> th(cap);
+                    if (be.ties(be.ctx, &flat.desc, flat_version_dev, &q1.desc, cap, tj.data(), th.data(), tc.data()) != 0) return false;
+                    own_list.clear();
+                    for (uint32_t i = 0; i < std::min(tc[0], cap); i++) own_list.push_back({tj[i], th[i]});
+                    flst = &own_list;
+                    return true;
+                };
+                if (!dev.pending.empty()) dense.set(ms.mutations);
+                bool dense_set = !dev.pending.empty();
+                bool host_all = false;
+                int best_now = 0;
+                for (int attempt = 0;; attempt++) {
+                    const size_t kk = ii - dev.rbase;
+                    // flattened nodes that are still what they were (rewritten ones are excluded on the device as of the search; those
+                    // rewritten since are dropped here)
+                    std::vector<Tie> F, Dv, H;
+                    if (fr.num_best > 1 && flst->empty() && !list_for(fr)) { fclose(stats); return be_fail("tie listing"); }
+                    if (fr.num_best == 1) { Node *bn = flat.bfs[fr.best_j]; if (!dev.since_batch.count(bn)) F.push_back({bn, fr.best_has_unique != 0}); }
+                    else for (const auto &e : *flst) if (!dev.since_batch.count(flat.bfs[e.first])) F.push_back({flat.bfs[e.first], e.second != 0});
+                    const int f_best = fr.best_set_difference;
+                    const bool f_exact = !F.empty();            // else: the remaining flattened nodes cost more than f_best
+                    // records on the device
+                    int d_best = host_all ? INT32_MAX : dev.t_best[kk];
+                    int d_state = 0;                            // 0 none, 1 exact, 2 truncated list, 3 every holder of the minimum was rewritten since
+                    if (d_best != INT32_MAX) {
+                        const uint32_t cnt = dev.t_cnt[kk];
+                        for (uint32_t i = 0; i < std::min(cnt, kTCap); i++) {
+                            const uint32_t id = dev.t_ids[kk * kTCap + i];
+                            if (!dev.rec_dead[id]) Dv.push_back({dev.rec_node[id], dev.t_hu[kk * kTCap + i] != 0});
+                        }
+                        d_state = cnt > kTCap ? 2 : (Dv.empty() ? 3 : 1);
+                    }
+                    // this round's nodes (and, after a truncated list, every live record) on the host
+                    int h_best = INT32_MAX;
+                    const double te = now_s();
+                    auto host_eval = [&](Node *tn) {
+                        bool el, hu; int cost;
+                        if (tn->is_root()) { node_vecs(tn, ms.mutations, probe); el = probe.eligible; hu = probe.has_unique; cost = probe.set_difference; }
+                        else tcache.eval(tn, dense, el, cost, hu);
+                        if (!el) return;
+                        if (cost < h_best) { h_best = cost; H.clear(); }
+                        if (cost == h_best) H.push_back({tn, hu});
+                    };
+                    if ((host_all || !dev.pending.empty()) && !dense_set) { dense.set(ms.mutations); dense_set = true; }
+                    for (Node *tn : dev.pending) host_eval(tn);
+                    prof.evals += dev.pending.size();
+                    if (host_all) { for (size_t id = 0; id < dev.rec_node.size(); id++) if (!dev.rec_dead[id]) host_eval(dev.rec_node[id]); prof.evals += dev.rec_node.size(); }
+                    prof.touched += now_s() - te;
+                    int km = h_best;                            // the minimum over the parts that are exact
+                    if (f_exact) km = std::min(km, f_best);
+                    if (d_state == 1) km = std::min(km, d_best);
+                    const bool need_f = !f_exact && km > f_best;                                       // an unlisted flattened node may tie or win
+                    const bool need_d = (d_state == 2 && km >= d_best) || (d_state == 3 && km > d_best);   // an unlisted record may tie or win
+                    if ((!need_f && !need_d) || attempt >= 3) {
+                        if (need_f || need_d) { fclose(stats); fprintf(stderr, "ERROR: add mode: the answer for sample %s could not be re-derived\n", ms.name.c_str()); return 1; }
+                        best_now = km;
+                        tie_now.clear();
+                        if (f_exact && f_best == km) tie_now.insert(tie_now.end(), F.begin(), F.end());
+                        if (d_state == 1 && d_best == km) tie_now.insert(tie_now.end(), Dv.begin(), Dv.end());
+                        if (h_best == km) tie_now.insert(tie_now.end(), H.begin(), H.end());
+                        break;
+                    }
+                    // ask again, for this one sample: everything touched so far goes to the device first (records, exclusions)
+                    if (!dev_flush(ii)) { fclose(stats); return be_fail("record upload (add mode)"); }
+                    if (need_f) {
+                        FlatQueries q1;
+                        q1.add(rows_of(s));
+                        q1.finish();
+                        if (be.place(be.ctx, &flat.desc, flat_version_dev, &q1.desc, &fr) != 0) { fclose(stats); return be_fail("placement (add mode)"); }
+                        own_list.clear(); flst = &own_list;
+                        dev.n_replace++;
+                    }
+                    if (need_d) {
+                        if (d_state == 2) { host_all = true; dev.n_host_all++; }
+                        else { if (be.touched_rescore(be.ctx, ii - dev.base) != 0) { fclose(stats); return be_fail("record scoring (add mode)"); } dev.n_rescore++; }
+                    }
+                    if (!dev_fetch(ii)) { fclose(stats); return be_fail("record scoring (add mode)"); }
+                }
+                if (dense_set) dense.clear(ms.mutations);
+                if (tie_now.empty()) { fclose(stats); fprintf(stderr, "ERROR: add mode: no candidate for sample %s\n", ms.name.c_str()); return 1; }
+                const Tie *w = &tie_now[0];
+                size_t w_leaves = leaves_now(w->n);
+                for (size_t t = 1; t < tie_now.size(); t++) {
+                    const size_t l = leaves_now(tie_now[t].n);
+                    if (l > w_leaves || (l == w_leaves && bfs_before(w->n, tie_now[t].n))) { w = &tie_now[t]; w_leaves = l; }
+                }
+                patched = true; patched_best = best_now; patched_node = w->n; patched_hu = w->hu;
+                r = ugp_result{};
+            } else {
                 // need_flat: flatten the current tree again; need_batch: place the next batch of samples (on the
                 // tree as flattened last -- not necessarily the current one)
                 bool need_flat = !have_spec || touched.size() > max_touched;
@@ -1185,9 +1408,24 @@ int run_usher(const Options &opt, Tree &T, std::vector<MissingSample> &missing, 
                         for (size_t k = t0; k < touched.size(); k++) {
                             if (touched[k]->is_leaf() && touched[k] != best_node) leaf = touched[k];
                             if (!touched[k]->is_root()) tcache.build(touched[k]);   // (again if it was touched before: its branch changed)
+                            if (dev.on) {
+                                Node *x = touched[k];
+                                if (x->is_root()) {   // (the root itself rewritten: left to the host-side scheme, which flattens again)
+                                    dev.on = false; have_spec = false;
+                                    continue;
+                                }
+                                if (!dev.pending_set.count(x)) {
+                                    auto it = dev.rec_of.find(x);
+                                    if (it != dev.rec_of.end()) { dev.rec_dead[it->second] = 1; dev.pending_retired.push_back(it->second); dev.rec_of.erase(it); }
+                                    dev.pending.push_back(x); dev.pending_set.insert(x);
+                                }
+                                if (flat.has(x)) dev.since_batch.insert(x);
+                                continue;
+                            }
                             if (touched_set.insert(touched[k]).second) touched[keep++] = touched[k];
                         }
                         touched.resize(keep);
+                        if (!dev.on && dev.flat_done && !have_spec) { touched.clear(); touched_set.clear(); }
                         if (leaf) {
                             if (leaf->parent != best_node) added_leaves[leaf->parent] = best_leaves;   // the new internal node starts with best_node's leaves
                             added_leaves[leaf] = 1;
@@ -1214,6 +1452,10 @@ int run_usher(const Options &opt, Tree &T, std::vector<MissingSample> &missing, 
             fprintf(stderr, "[usher-amd profile] tree -> arrays %.3f s (%zu times), batched placement %.3f s (%zu batches), tie lists %.3f s, "
                             "touched-node evaluation %.3f s (%zu node evaluations)\n", prof.build, prof.flats, prof.place, prof.batches, prof.ties,
                     prof.touched, prof.evals);
+        if (getenv("USHER_AMD_PROFILE") && dev.flat_done)
+            fprintf(stderr, "[usher-amd profile] add mode on the device: %zu batches %.3f s, %zu record uploads %.3f s, result fetches %.3f s, %zu records; "
+                            "asked again: flattened tree %zu, records %zu, all records on the host %zu\n", dev.n_batches, dev.t_batch, dev.n_flush, dev.t_flush,
+                    dev.t_fetch, dev.rec_node.size(), dev.n_replace, dev.n_rescore, dev.n_host_all);
     }
     if (opt.print_scores) return 0;                                             // :800-805
     std::vector<Tree *> trees{&T};

@@ -40,6 +40,13 @@ struct Backend {
     // `fitch` computes and keeps the result in the backend, `fitch_get` copies it out and releases it.
     int (*fitch)(void *ctx, uint64_t n_nodes, const uint32_t *parent, const ugp_sites *sites, uint64_t *n_out) = nullptr;
     int (*fitch_get)(void *ctx, uint32_t *site, uint32_t *node, uint8_t *par_nuc, uint8_t *mut_nuc) = nullptr;
+    // Add mode on the device (include/usher_amd.h, "add mode"): all optional -- without them the driver re-derives batched answers on
+    // the host and flattens the tree again when too many nodes have changed.  They act on the tree most recently given to `place`.
+    int (*update)(void *ctx, const ugp_touched *recs, const uint32_t *retired, uint64_t n_retired, uint32_t *first_id) = nullptr;
+    int (*touched_open)(void *ctx, const ugp_queries *batch) = nullptr;
+    int (*touched_score)(void *ctx, uint32_t first_id, uint64_t first_sample) = nullptr;
+    int (*touched_rescore)(void *ctx, uint64_t sample) = nullptr;
+    int (*touched_fetch)(void *ctx, uint64_t first_sample, uint64_t n, uint32_t cap, int32_t *best, uint32_t *count, uint32_t *ids, uint8_t *has_unique) = nullptr;
 };
 
 // Returns the process exit code (usher_common.cpp:6).

@@ -105,6 +105,26 @@ int gpu_ties(void *ctx, const ugp_tree_desc *t, uint64_t v, const ugp_queries *q
         return ugp_tied_nodes(c->mats[d], &part, cap, tj + lo * cap, th + lo * cap, tc + lo);
     });
 }
+// Add mode: the edits go to every replica (each keeps excluding the rewritten nodes from its searches); the records are scored on
+// the first device.
+int gpu_update(void *ctx, const ugp_touched *recs, const uint32_t *retired, uint64_t n_retired, uint32_t *first_id) {
+    GpuCtx *c = (GpuCtx *)ctx;
+    if (c->mats.empty()) { c->err = "no tree on the device"; return UGP_ERR_INVALID; }
+    for (size_t d = 0; d < c->mats.size(); d++) {
+        uint32_t f = 0;
+        if (int rc = ugp_mat_update(c->mats[d], recs, retired, n_retired, &f)) { c->err = ugp_last_error(); return rc; }
+        if (d == 0 && first_id) *first_id = f;
+    }
+    return UGP_OK;
+}
+#define GPU_FWD(call) GpuCtx *c = (GpuCtx *)ctx; if (c->mats.empty()) { c->err = "no tree on the device"; return UGP_ERR_INVALID; } \
+                      const int rc = call; if (rc != UGP_OK) c->err = ugp_last_error(); return rc;
+int gpu_touched_open(void *ctx, const ugp_queries *q) { GPU_FWD(ugp_touched_open(c->mats[0], q)) }
+int gpu_touched_score(void *ctx, uint32_t first_id, uint64_t first_sample) { GPU_FWD(ugp_touched_score(c->mats[0], first_id, first_sample)) }
+int gpu_touched_rescore(void *ctx, uint64_t sample) { GPU_FWD(ugp_touched_rescore(c->mats[0], sample)) }
+int gpu_touched_fetch(void *ctx, uint64_t first_sample, uint64_t n, uint32_t cap, int32_t *best, uint32_t *count, uint32_t *ids, uint8_t *hu) {
+    GPU_FWD(ugp_touched_fetch(c->mats[0], first_sample, n, cap, best, count, ids, hu))
+}
 const char *gpu_err(void *ctx) { return ((GpuCtx *)ctx)->err.c_str(); }
 int gpu_fitch(void *ctx, uint64_t n_nodes, const uint32_t *parent, const ugp_sites *sites, uint64_t *n_out) {
     GpuCtx *c = (GpuCtx *)ctx;
@@ -163,6 +183,8 @@ int main(int argc, char **argv) {
     uh::Backend be;
     be.ctx = &ctx; be.place = gpu_place; be.scores = gpu_scores; be.ties = gpu_ties; be.last_error = gpu_err;
     be.fitch = gpu_fitch; be.fitch_get = gpu_fitch_get;
+    be.update = gpu_update; be.touched_open = gpu_touched_open; be.touched_score = gpu_touched_score; be.touched_rescore = gpu_touched_rescore;
+    be.touched_fetch = gpu_touched_fetch;
     int rc = uh::usher_main(argc, argv, be);
     drop_mats(&ctx);
     if (ctx.fitch) ugp_fitch_destroy(ctx.fitch);
