@@ -365,6 +365,35 @@ def main():
         c4 = timed_config(pl, st, 1_000_000, 3, 1)
         c4["workload"] = "BASELINE config 4 on one device: 1,000,000 queries on the %d-node MAT, one ugp_place_device_overlapped call per step" % info["n_nodes"]
         extra["config4_1m_queries_one_gpu"] = c4
+        # the drop-in CLI end to end: the same tree as parsimony.proto, 10,000 queries as a VCF, `usher-amd -i .. -v .. -n` (load the
+        # MAT, read the VCF, flatten + upload, place, write placement_stats.tsv and the tree) -- wall time of the whole process
+        try:
+            import shutil
+            import tempfile
+            from tools.time_load import host_lib, write_workload
+            dcli = tempfile.mkdtemp(prefix="ugp_cli_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+            nq_cli = 10_000
+            qc = st.queries(nq_cli, seed=args.seed * 1000 + 5)
+            tw = time.time()
+            write_workload(host_lib(), st, qc, nq_cli, os.path.join(dcli, "base.pb"), os.path.join(dcli, "q.vcf"))
+            tw = time.time() - tw
+            exe = os.path.join(ROOT, "usher_amd", "bin", "usher-amd")
+            tc = time.perf_counter()
+            rr = subprocess.run([exe, "-i", os.path.join(dcli, "base.pb"), "-v", os.path.join(dcli, "q.vcf"), "-n", "-d", os.path.join(dcli, "out"), "--device", str(dev_index)],
+                                capture_output=True, text=True, env=dict(os.environ, USHER_AMD_PROFILE="1"))
+            tc = time.perf_counter() - tc
+            lines = open(os.path.join(dcli, "out", "placement_stats.tsv")).read().splitlines() if rr.returncode == 0 else []
+            # the same samples through the library (this process): score and number of optimal placements per sample
+            bq = QueryBatch.from_csr(qc["ent_off"], qc["pos"], qc["ref"], qc["nuc"], qc["is_missing"])
+            lib_res = pl.place(bq)
+            same = len(lines) == nq_cli and all(l.split("\t")[1:3] == [str(int(lib_res["best_set_difference"][i])), str(int(lib_res["num_best"][i]))] for i, l in enumerate(lines))
+            extra["cli_end_to_end"] = {"command": "usher-amd -i base.pb -v q.vcf -n -d out", "nodes": int(info["n_nodes"]), "queries": nq_cli, "exit_code": rr.returncode,
+                                       "wall_s": round(tc, 3), "placements_per_s": round(nq_cli / tc, 1), "stats_equal_library_results": bool(same),
+                                       "pb_bytes": os.path.getsize(os.path.join(dcli, "base.pb")), "vcf_bytes": os.path.getsize(os.path.join(dcli, "q.vcf")),
+                                       "write_inputs_s": round(tw, 2), "profile": [l for l in rr.stderr.splitlines() if l.startswith("[usher-amd profile]") and ":" not in l.split("]", 1)[1][:12]][:8]}
+            shutil.rmtree(dcli, ignore_errors=True)
+        except Exception as ex:   # (the extra key must never cost the bench line)
+            extra["cli_end_to_end"] = {"error": repr(ex)[:300]}
 
     result = None
     if rank == 0:

@@ -141,3 +141,43 @@ def test_flattened_tree_plus_records_equal_a_search_of_the_edited_tree(seed, n_l
                     assert a[0][q] <= b[0][q], (i, q)
     assert multi > 3
     pl.close()
+
+
+EXE = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "usher_amd", "bin", "usher-amd")
+
+
+@pytest.mark.parametrize("seed,n_leaves,n_new,env", [(21, 300, 620, {}), (22, 80, 520, {"USHER_AMD_BATCH": "128", "USHER_AMD_ROUND": "7"}),
+                                                     (23, 500, 700, {"USHER_AMD_BATCH": "200", "USHER_AMD_ROUND": "64", "USHER_AMD_TCAP": "2"})])
+def test_usher_cli_add_mode_on_the_device_equals_the_restated_driver_loop(seed, n_leaves, n_new, env, tmp_path):
+    """bin/usher-amd in its default mode (sequential insertion, usher_common.cpp:310-792) with the edits kept on the device: more than
+    500 insertions, multi-way ties among flattened nodes, new nodes and both; every line of placement_stats.tsv (score, number of
+    optimal placements, imputed mutations) and every mutation path equal tests/usher_model.py -- the reference's loop restated in python
+    with the ORACLE searching the current tree for every sample -- and the tree written equals the per-sample-research run of the same
+    binary (a full search per sample: USHER_AMD_MAX_TOUCHED=0)."""
+    import subprocess
+    from tests.test_host_cli import _evolve_vcf, _read
+    from tests.host_harness import run_usher
+    rng = np.random.default_rng(seed)
+    nh, old, new = str(tmp_path / "t.nh"), str(tmp_path / "old.vcf"), str(tmp_path / "new.vcf")
+    _evolve_vcf(rng, n_leaves, 110, n_new, nh, old, new)
+    pb = str(tmp_path / "base.pb")
+    assert run_usher(["-t", nh, "-v", old, "-o", pb, "-d", str(tmp_path)]) == 0      # (MAT construction on the host harness: not what is tested here)
+    outs = {}
+    for mode, e in (("device", dict(env, USHER_AMD_PROFILE="1")), ("research", {"USHER_AMD_MAX_TOUCHED": "0"})):
+        d = tmp_path / mode
+        d.mkdir()
+        r = subprocess.run([EXE, "-i", pb, "-v", new, "-u", "-d", str(d)], capture_output=True, text=True, timeout=1500, env=dict(os.environ, **e))
+        assert r.returncode == 0, r.stderr[-3000:]
+        outs[mode] = {n: _read(str(d / n)) for n in ("placement_stats.tsv", "mutation-paths.txt", "uncondensed-final-tree.nh")}
+        if mode == "device":
+            line = [l for l in r.stderr.splitlines() if "add mode on the device" in l]
+            assert line and "tree -> arrays" in r.stderr
+            flat = [l for l in r.stderr.splitlines() if "tree -> arrays" in l][0]
+            assert "(1 times)" in flat, flat                                       # one flattening for the whole run
+    assert outs["device"] == outs["research"]
+    T = refio.load_mutation_annotated_tree(pb)
+    want = usher_model.run(T, refio.read_vcf(T, new))
+    assert outs["device"]["placement_stats.tsv"] == want["placement_stats.tsv"]
+    assert outs["device"]["mutation-paths.txt"] == want["mutation-paths.txt"]
+    n_ties = sum(1 for l in want["placement_stats.tsv"].splitlines() if l.split("\t")[2] != "1")
+    assert n_ties > 40 and len(want["placement_stats.tsv"].splitlines()) == n_new
