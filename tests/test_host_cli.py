@@ -631,3 +631,29 @@ def test_add_mode_asks_again_when_the_holders_of_a_minimum_were_rewritten(tmp_pa
     want = usher_model.run(T, refio.read_vcf(T, new))
     assert outs["device"]["placement_stats.tsv"] == want["placement_stats.tsv"]
     assert outs["device"]["mutation-paths.txt"] == want["mutation-paths.txt"]
+
+
+@pytest.mark.parametrize("seed", [31, 32, 33])
+def test_newick_written_on_threads_equals_the_loop(seed, tmp_path, monkeypatch):
+    """final-tree.nh (internal names, branch length = number of mutations) and the newick inside the saved MAT (no internal names)
+    written by the threaded writer (lengths bottom-up, offsets top-down, every node writes its own pieces) are byte-identical to the
+    paren-by-paren loop that restates mutation_annotated_tree.cpp:215-346, after a run that added samples."""
+    import numpy as np
+    from tests.host_harness import OracleBackend
+    rng = np.random.default_rng(seed)
+    nh, old, new = str(tmp_path / "t.nh"), str(tmp_path / "old.vcf"), str(tmp_path / "new.vcf")
+    _evolve_vcf(rng, 40 + 30 * (seed % 3), 60, 25, nh, old, new)
+    pb = str(tmp_path / "base.pb")
+    assert run_usher(["-t", nh, "-v", old, "-o", pb, "-d", str(tmp_path)]) == 0
+    outs = []
+    for env in ({"USHER_AMD_NEWICK_LOOP": "1"}, {"USHER_AMD_GRAIN": "1", "USHER_AMD_THREADS": "6"}, {"USHER_AMD_GRAIN": "3", "USHER_AMD_THREADS": "2"}):
+        for k in ("USHER_AMD_NEWICK_LOOP", "USHER_AMD_GRAIN", "USHER_AMD_THREADS"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        d = tmp_path / ("o%d" % len(outs))
+        d.mkdir()
+        assert run_usher(["-i", pb, "-v", new, "-o", str(d / "out.pb"), "-d", str(d)], backend=OracleBackend()) == 0
+        outs.append({n: open(str(d / n), "rb").read() for n in ("final-tree.nh", "out.pb", "mutation-paths.txt")})
+    assert outs[0]["final-tree.nh"].count(b"(") > 30
+    assert outs[1] == outs[0] and outs[2] == outs[0]

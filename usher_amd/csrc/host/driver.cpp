@@ -14,6 +14,7 @@
 #include <numeric>
 #include <random>
 #include <chrono>
+#include <functional>
 #include <climits>
 #include <cmath>
 #include <unordered_map>
@@ -937,7 +938,8 @@ int run_usher(const Options &opt, Tree &T, std::vector<MissingSample> &missing, 
         // max_touched, when a tie list was too long to keep, or when every batched optimum was rewritten
         // and no touched node is at least as good.
         // USHER_AMD_PROFILE=1: where the add mode spends its time (printed once at the end)
-        struct Prof { double build = 0, place = 0, ties = 0, touched = 0; size_t flats = 0, batches = 0, evals = 0; } prof;
+        struct Prof { double build = 0, place = 0, ties = 0, touched = 0, vecs = 0, insert = 0, book = 0, loop = 0; size_t flats = 0, batches = 0, evals = 0; } prof;
+        const double t_loop0 = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
         auto now_s = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
         std::vector<ugp_result> spec_res;
         size_t spec_base = 0, spec_len = 0, spec_next = 64;   // batch length adapts to how long answers survive
@@ -1396,12 +1398,18 @@ int run_usher(const Options &opt, Tree &T, std::vector<MissingSample> &missing, 
                         std::sort(ms.clade_assignments[c].begin(), ms.clade_assignments[c].end());
                     }
                 }
+                const double tv0 = now_s();
                 node_vecs(best_node, ms.mutations, vec);                        // pass 2 for the winner, :426-449
+                prof.vecs += now_s() - tv0;
                 if (!opt.no_add) {
                     const size_t t0 = touched.size();
                     const size_t best_leaves = leaves_now(best_node);
+                    const double ti0 = now_s();
                     insert_sample(T, best_node, best_node->is_leaf() || best_has_unique, ms.name, vec.excess, touched);
+                    prof.insert += now_s() - ti0;
                     tree_version++;
+                    const double tb0 = now_s();
+                    struct Book { double &acc, t0; std::function<double()> now; ~Book() { acc += now() - t0; } } book{prof.book, tb0, now_s};
                     if (!static_tree) {   // bookkeeping for re-deriving later batched answers on the changed tree
                         Node *leaf = nullptr;
                         size_t keep = t0;   // `touched` lists every node once
@@ -1452,6 +1460,10 @@ int run_usher(const Options &opt, Tree &T, std::vector<MissingSample> &missing, 
             fprintf(stderr, "[usher-amd profile] tree -> arrays %.3f s (%zu times), batched placement %.3f s (%zu batches), tie lists %.3f s, "
                             "touched-node evaluation %.3f s (%zu node evaluations)\n", prof.build, prof.flats, prof.place, prof.batches, prof.ties,
                     prof.touched, prof.evals);
+        prof.loop = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count() - t_loop0;
+        if (getenv("USHER_AMD_PROFILE"))
+            fprintf(stderr, "[usher-amd profile] per-sample loop %.3f s in all: vectors of the winning node (pass 2) %.3f s, tree edits %.3f s, bookkeeping of the edits %.3f s\n",
+                    prof.loop, prof.vecs, prof.insert, prof.book);
         if (getenv("USHER_AMD_PROFILE") && dev.flat_done)
             fprintf(stderr, "[usher-amd profile] add mode on the device: %zu batches %.3f s, %zu record uploads %.3f s, result fetches %.3f s, %zu records; "
                             "asked again: flattened tree %zu, records %zu, all records on the host %zu\n", dev.n_batches, dev.t_batch, dev.n_flush, dev.t_flush,

@@ -787,10 +787,74 @@ static void put_len(std::string &out, float v) {   // operator<<(float): %g
     out += buf;
 }
 
+// The same text for large trees, written on the host threads: text(n) = name[:len] for a leaf, "(" text(c1) "," ... ")" [name] [:len]
+// for an internal node (what the loop below emits, paren by paren).  Lengths bottom-up over the depth-first order (a subtree is a
+// contiguous range of it), offsets top-down, then every node writes its own pieces.  Condensed leaves are left to the loop.
+static std::string newick_threads(const Tree &T, Node *start, bool internal_ids, bool branch_len) {
+    const std::vector<Node *> order = T.dfs(start);
+    const size_t n = order.size();
+    std::vector<uint32_t> sub(n), lab(n);      // subtree size (nodes), length of the node's own label text (name + ":len")
+    std::vector<uint64_t> len(n), off(n);
+    auto len_text = [](float v, char *buf) { return snprintf(buf, 32, "%g", v); };
+    parallel_for(n, [&](uint64_t b, uint64_t e, unsigned) {
+        char buf[32];
+        for (uint64_t i = b; i < e; i++) {
+            const Node *x = order[i];
+            const bool leaf = x->is_leaf();
+            uint32_t l = (leaf || internal_ids) ? (uint32_t)x->id.size() : 0u;
+            if (branch_len) l += 1u + (uint32_t)len_text((float)x->mutations.size(), buf);
+            lab[i] = l;
+        }
+    }, 1u << 14);
+    for (size_t i = n; i-- > 0;) {             // children of i: i + 1, then one subtree after the other
+        const Node *x = order[i];
+        uint32_t s = 1;
+        uint64_t l = lab[i];
+        const size_t k = x->children.size();
+        if (k) {
+            l += 2 + (k - 1);                  // parens and commas
+            size_t c = i + 1;
+            for (size_t j = 0; j < k; j++) { s += sub[c]; l += len[c]; c += sub[c]; }
+        }
+        sub[i] = s; len[i] = l;
+    }
+    off[0] = 0;
+    for (size_t i = 0; i < n; i++) {
+        const size_t k = order[i]->children.size();
+        uint64_t o = off[i] + 1;
+        size_t c = i + 1;
+        for (size_t j = 0; j < k; j++) { off[c] = o; o += len[c] + 1; c += sub[c]; }
+    }
+    std::string out;
+    out.resize(len[0] + 1);
+    char *dst = &out[0];
+    parallel_for(n, [&](uint64_t b, uint64_t e, unsigned) {
+        char buf[32];
+        for (uint64_t i = b; i < e; i++) {
+            const Node *x = order[i];
+            const bool leaf = x->is_leaf();
+            char *p = dst + off[i];
+            if (!leaf) {
+                *p = '(';
+                size_t c = i + 1;
+                for (size_t j = 0; j + 1 < x->children.size(); j++) { c += sub[c]; dst[off[c] - 1] = ','; }
+                p = dst + off[i] + len[i] - lab[i];
+                p[-1] = ')';
+            }
+            if (leaf || internal_ids) { memcpy(p, x->id.data(), x->id.size()); p += x->id.size(); }
+            if (branch_len) { *p++ = ':'; const int k = len_text((float)x->mutations.size(), buf); memcpy(p, buf, (size_t)k); }
+        }
+    }, 1u << 14);
+    out[len[0]] = ';';
+    return out;
+}
+
 std::string newick(const Tree &T, Node *from, bool internal_ids, bool branch_len, bool uncondense) {   // :215-346
     std::string out;
     Node *start = from ? from : T.root;
     if (!start) return ";";
+    if ((!uncondense || T.condensed_nodes.empty()) && (T.all_nodes.size() >= (1u << 16) || getenv("USHER_AMD_GRAIN")) && !getenv("USHER_AMD_NEWICK_LOOP"))
+        return newick_threads(T, start, internal_ids, branch_len);
     std::unordered_map<std::string, const std::vector<std::string> *> cmap;
     if (uncondense) for (auto &cn : T.condensed_nodes) cmap[cn.first] = &cn.second;
     const size_t level_offset = start->level - 1;
