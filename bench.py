@@ -161,6 +161,12 @@ def main():
     t0 = time.time()
     st = shared_tree(args, n_sites, world, local_rank)
     t_gen = time.time() - t0
+    # several ranks on one host: each flattens the tree for itself -- on its share of the host's cores, not 32 threads each
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+    if local_world > 1 and "UGP_FLATTEN_THREADS" not in os.environ:
+        os.environ["UGP_FLATTEN_THREADS"] = str(max(1, min(32, (os.cpu_count() or 1) // local_world)))
+    if world > 1:
+        dist.barrier()   # (every rank starts its flattening at the same time: what an N-rank launch costs, not what a lone rank would)
     t0 = time.time()
     pl = Placer(st.arrays, device=dev_index, experiments=bool(os.environ.get("UGP_STATS")))   # (UGP_STATS: the instrumented build, libusher_amd_exp.so)
     t_flat = time.time() - t0
@@ -244,6 +250,19 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
+    # per-rank set-up times and the all-gather on its own (N > 1): what the ranks cost each other outside the kernels
+    flat_all, gather_ms = [round(t_flat, 3)], None
+    if world > 1:
+        tf = torch.tensor([t_flat], dtype=torch.float64, device="cpu" if share else dev)
+        tfs = [torch.zeros_like(tf) for _ in range(world)]
+        dist.all_gather(tfs, tf)
+        flat_all = [round(float(x.item()), 3) for x in tfs]
+        torch.cuda.synchronize(); dist.barrier()
+        tg = time.perf_counter()
+        for _ in range(5):
+            dist.all_gather_into_tensor(gathered, last_out.cpu() if share else last_out)
+        torch.cuda.synchronize()
+        gather_ms = round((time.perf_counter() - tg) * 1e3 / 5, 4)
     res = last_out.cpu().numpy()[:Q]
     # the same window again (--repeats - 1 times): spread of the figure; `value` stays the first window
     windows = [elapsed]
@@ -500,7 +519,9 @@ def main():
             # SURVEY 8(d) defines the metric with query upload and result download inside the clock: this is that figure (two
             # batches in flight from and to host buffers), next to `value` (rows resident in HBM, as the bench contract asks)
             "value_pcie_inclusive": (host_path or {}).get("two_in_flight", {}).get("placements_per_s") if host_path and host_path.get("two_in_flight") else None,
-            "per_rank": {"flatten_upload_s": round(t_flat, 2), "gather_issue_ms_per_step": round(gather_s[0] * 1e3 / max(1, n_step[0]), 4) if world > 1 else None},
+            "per_rank": {"flatten_upload_s": flat_all, "flatten_threads": os.environ.get("UGP_FLATTEN_THREADS"),
+                         "all_gather_ms": gather_ms, "all_gather_bytes": int(world * cap * 16) if world > 1 else None,
+                         "gather_issue_ms_per_step": round(gather_s[0] * 1e3 / max(1, n_step[0]), 4) if world > 1 else None},
             "other_configs": extra,
             "roofline": roofline, "cpu_baseline": cpu,
             # `value` has the query rows resident in HBM when the timed region starts (bench contract); the same batch through

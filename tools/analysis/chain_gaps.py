@@ -1,0 +1,29 @@
+#!/usr/bin/env python3
+"""The kernel chain of ONE batch inside the pipelined window of `bench.py`: from a `rocprofv3 --kernel-trace` CSV, the kernels
+of one hardware queue between two consecutive main walks, each with its duration and the gap since the previous kernel of the same
+queue ended -- where a step's dependent chain spends its time (kernels vs launch gaps).
+    python tools/analysis/chain_gaps.py gpurun_out/<dir>/p_kernel_trace.csv"""
+import csv
+import sys
+from collections import defaultdict
+
+rows = list(csv.DictReader(open(sys.argv[1])))
+qkey = "Queue_Id" if "Queue_Id" in rows[0] else ("Stream_Id" if "Stream_Id" in rows[0] else None)
+by_q = defaultdict(list)
+for r in rows:
+    by_q[r[qkey] if qkey else "0"].append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"].split("(")[0].replace("void ", "")[-60:]))
+for q, ev in sorted(by_q.items(), key=lambda kv: -len(kv[1]))[:2]:
+    ev.sort()
+    walks = [i for i, (s, e, n) in enumerate(ev) if "k_best8<false, false, false, false>" in n and e - s > 500_000]
+    if len(walks) < 6:
+        continue
+    a, b = walks[len(walks) // 2], walks[len(walks) // 2 + 1]      # from the end of one main walk to the end of the next: one batch
+    print("queue %s: %d kernels, %d main walks; one batch (walk end -> next walk end) = %.3f ms" % (q, len(ev), len(walks), (ev[b][1] - ev[a][1]) / 1e6))
+    tk = tg = 0
+    prev_end = ev[a][1]
+    for s, e, n in ev[a + 1:b + 1]:
+        print("   gap %7.1f us   run %8.1f us   %s" % ((s - prev_end) / 1e3, (e - s) / 1e3, n))
+        tk += e - s
+        tg += max(0, s - prev_end)
+        prev_end = e
+    print("   kernels %.3f ms, gaps %.3f ms" % (tk / 1e6, tg / 1e6))
