@@ -55,6 +55,7 @@ def parse_args():
     ap.add_argument("--sort-by-source", action="store_true", help="experiment: hand the queries over already ordered by their generator source node")
     ap.add_argument("--no-overlap", action="store_true", help="time the stream-ordered ugp_place_device (one call at a time) instead of ugp_place_device_overlapped")
     ap.add_argument("--no-extra", action="store_true", help="skip the extra keys (BASELINE configs 3 and 4 on one device, the end-to-end CLI run)")
+    ap.add_argument("--depth", type=int, default=0, help="overlapped calls kept on the device at a time (2..4; 0 = the library's default)")
     ap.add_argument("--repeats", type=int, default=3, help="windows of --steps steps timed in all (the first is `value`; min / median over all are extra keys)")
     return ap.parse_args()
 
@@ -165,6 +166,8 @@ def main():
     local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
     if local_world > 1 and "UGP_FLATTEN_THREADS" not in os.environ:
         os.environ["UGP_FLATTEN_THREADS"] = str(max(1, min(32, (os.cpu_count() or 1) // local_world)))
+    if args.depth:
+        os.environ["UGP_PIPELINE_DEPTH"] = str(args.depth)
     if world > 1:
         dist.barrier()   # (every rank starts its flattening at the same time: what an N-rank launch costs, not what a lone rank would)
     t0 = time.time()
@@ -204,14 +207,15 @@ def main():
     # Two output buffers used alternately: consecutive ugp_place_device_overlapped calls share the device, and call k + 2 is
     # ordered behind whatever the caller's stream held when call k + 1 was made -- the all-gather that reads call k's buffer
     # included (include/usher_amd.h: one call of lag).  (shards differ by at most one sample: padded to `cap`)
-    outs = [torch.zeros((cap, 4), dtype=torch.int32, device=dev) for _ in range(2)]
+    depth = pl.pipeline_depth()
+    outs = [torch.zeros((cap, 4), dtype=torch.int32, device=dev) for _ in range(depth)]
     gathered = torch.zeros((world * cap, 4), dtype=torch.int32, device="cpu" if share else dev) if world > 1 else None
     stream = torch.cuda.current_stream().cuda_stream
     n_step = [0]
     gather_s = [0.0]
 
     def step():
-        out = outs[n_step[0] & 1]
+        out = outs[n_step[0] % depth]
         n_step[0] += 1
         if args.no_overlap:
             pl.place_device(qset, out.data_ptr(), stream)
@@ -237,7 +241,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    last_out = outs[(n_step[0] - 1) & 1]
+    last_out = outs[(n_step[0] - 1) % depth]
     # HIP events recorded by the library on the streams its kernels ran on, summed over the timed steps
     tm = pl.timing_sum()
     assert tm["calls"] == args.steps, tm
@@ -360,21 +364,22 @@ def main():
             qq = tree.queries(nq, seed=args.seed * 1000 + 4, **qkw)
             bb = QueryBatch.from_csr(qq["ent_off"], qq["pos"], qq["ref"], qq["nuc"], qq["is_missing"])
             hq = placer.upload(bb)
-            oo = [torch.zeros((nq, 4), dtype=torch.int32, device=dev) for _ in range(2)]
+            dd = placer.pipeline_depth()
+            oo = [torch.zeros((nq, 4), dtype=torch.int32, device=dev) for _ in range(dd)]
             for k in range(warm):
-                placer.place_device_overlapped(hq, oo[k & 1].data_ptr(), stream)
+                placer.place_device_overlapped(hq, oo[k % dd].data_ptr(), stream)
             torch.cuda.synchronize()
             placer.timing_sum()
             tq = time.perf_counter()
             for k in range(steps):
-                placer.place_device_overlapped(hq, oo[k & 1].data_ptr(), stream)
+                placer.place_device_overlapped(hq, oo[k % dd].data_ptr(), stream)
             torch.cuda.synchronize()
             tq = time.perf_counter() - tq
             tmq = placer.timing_sum()
             strict = torch.zeros((nq, 4), dtype=torch.int32, device=dev)
             placer.place_device(hq, strict.data_ptr(), stream)   # the stream-ordered entry point, one call alone
             torch.cuda.synchronize()
-            same = bool((strict == oo[(steps - 1) & 1]).all().item())
+            same = bool((strict == oo[(steps - 1) % dd]).all().item())
             placer.free_qset(hq)
             return {"queries": nq, "steps": steps, "placements_per_s": round(nq * steps / tq, 2), "ms_per_step": round(tq * 1e3 / steps, 3),
                     "k_best8_ms": round(tmq["place_ms"] / max(1, tmq["calls"]), 4), "sub_batches": int(tmq["place_launches"] // max(1, tmq["calls"])),
@@ -463,7 +468,7 @@ def main():
                     "kernel_ms_alone": round(alone["place_ms"], 4),
                     "frac_alone": round(algo_bytes / (alone["place_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if alone["place_ms"] > 0 else None,
                     "ms_per_step_alone": round(t_alone * 1e3, 3),
-                    "overlap": "off (--no-overlap: ugp_place_device, stream-ordered)" if args.no_overlap else "consecutive ugp_place_device_overlapped calls run on two internal streams, two output buffers",
+                    "overlap": "off (--no-overlap: ugp_place_device, stream-ordered)" if args.no_overlap else "consecutive ugp_place_device_overlapped calls: %d on the device at a time (internal streams, workspace sets, output buffers)" % depth,
                     "node_plus_mut_evals_decided_per_s": round(node_evals / (k_ms * 1e-3), 1) if k_ms > 0 else 0.0,
                     "coarse_ms": round(coarse_ms / args.steps, 4), "table_ms": round(table_ms / args.steps, 4), "merge_ms": round(merge_ms / args.steps, 4),
                     # the two pruning counters exist only in the instrumented kernel variant (UGP_STATS=1)

@@ -196,17 +196,21 @@ int ugp_qset_upload(ugp_mat *mat, const ugp_queries *q, ugp_qset **out);
 void ugp_qset_destroy(ugp_qset *qs);
 uint64_t ugp_qset_size(const ugp_qset *qs);
 int ugp_place_device(ugp_mat *mat, ugp_qset *qs, void *d_out, void *stream);
-/* Opt-in: consecutive ugp_place_device_overlapped calls on one handle overlap on the device (two internal streams, two
- * sets of workspaces: the small latency-bound kernels around the tree walk of one batch run in the gaps of the other's;
- * +50 % placements/s at 16,384 samples per call).  The price is a weaker ordering than a kernel launch has:
+/* Opt-in: consecutive ugp_place_device_overlapped calls on one handle overlap on the device -- up to d = ugp_pipeline_depth(mat)
+ * of them at a time (internal streams, workspace sets; d = 3 by default: the small latency-bound kernels around the tree walk of one
+ * batch run in the gaps of the others', and each walk takes its share of the resident wave slots; +15 % placements/s at 16,384
+ * samples per call over two at a time, +65 % over one).  The price is a weaker ordering than a kernel launch has:
  *   - `stream` receives every call's completion, in call order: work queued on `stream` after call k sees its results;
- *   - call k runs behind the work that was on `stream` when call k-1 (the previous overlapped call on this handle) was
- *     made -- ONE CALL OF LAG; work queued between the two calls sits behind call k-1's completion, and waiting for it
- *     would serialise them.  (When no overlapped call is running any more, call k waits for everything on `stream`.)
- * Hence: alternate between TWO output buffers.  Whatever is queued on `stream` to read buffer A between call k (which
- * wrote A) and call k+1 is finished before call k+2 overwrites A.  Do not prepare d_out or the query set on `stream`
- * right before the call and expect the call to wait for it -- use ugp_place_device for that. */
+ *   - call k runs behind the work that was on `stream` when call k - (d - 1) was made -- d - 1 CALLS OF LAG; work queued since
+ *     sits behind the completion of a call that is still running, and waiting for it would serialise the calls.  (When no
+ *     overlapped call is running any more, call k waits for everything on `stream`.)
+ * Hence: cycle through d output buffers.  Whatever is queued on `stream` to read buffer A between call k (which wrote A) and call
+ * k + 1 is finished before call k + d overwrites A.  Do not prepare d_out or the query set on `stream` right before the call and
+ * expect the call to wait for it -- use ugp_place_device for that. */
 int ugp_place_device_overlapped(ugp_mat *mat, ugp_qset *qs, void *d_out, void *stream);
+/* How many overlapped calls the handle keeps on the device at a time (its workspace sets: 3 by default, 2..4 with
+ * UGP_PIPELINE_DEPTH in the environment when the handle is made) = the number of output buffers to cycle through. */
+int ugp_pipeline_depth(const ugp_mat *mat);
 
 /* ugp_place_batch with two batches in flight: host buffers in, host buffers out, asynchronous.  The rows are copied out of
  * `q` before the call returns (pinned staging), `out` is written by ugp_job_wait.  At most two jobs per handle may be

@@ -318,13 +318,15 @@ def test_consecutive_device_calls_share_the_device_and_stay_exact(monkeypatch):
     assert pl.timing_sum()["calls"] == 21
     for i, o in outs:
         assert (o.cpu().numpy() == want[i]).all(), i
-    # two output buffers used alternately, each result consumed on the caller's stream before the next call is made: the consumer
-    # of call k's buffer is finished before call k + 2 overwrites it (one call of lag), whatever the calls' own overlap
-    two = [torch.zeros((max(len(b) for b in batches), 4), dtype=torch.int32, device="cuda") for _ in range(2)]
+    # as many output buffers as calls in flight, used in turn, each result consumed on the caller's stream before the next call is
+    # made: the consumer of call k's buffer is finished before call k + depth overwrites it (depth - 1 calls of lag)
+    depth = pl.pipeline_depth()                     # calls kept on the device at a time = output buffers to cycle through
+    assert 2 <= depth <= 4
+    two = [torch.zeros((max(len(b) for b in batches), 4), dtype=torch.int32, device="cuda") for _ in range(depth)]
     sums = []
     for k in range(40):
         i = (0, 1, 2)[k % 3]
-        o = two[k & 1]
+        o = two[k % depth]
         pl.place_device_overlapped(handles[i], o.data_ptr(), stream)
         sums.append((i, o[:len(batches[i])].to(torch.int64).sum(0)))     # (queued on the caller's stream behind the call's completion)
     torch.cuda.synchronize()

@@ -73,6 +73,7 @@ SYMBOLS = {
     "ugp_qset_size": (C.c_uint64, [P]),
     "ugp_place_device": (C.c_int, [P, P, P, P]),
     "ugp_place_device_overlapped": (C.c_int, [P, P, P, P]),
+    "ugp_pipeline_depth": (C.c_int, [P]),
     "ugp_mat_update": (C.c_int, [P, C.POINTER(ugp_touched), P, C.c_uint64, C.POINTER(C.c_uint32)]),
     "ugp_touched_open": (C.c_int, [P, C.POINTER(ugp_queries)]),
     "ugp_touched_score": (C.c_int, [P, C.c_uint32, C.c_uint64]),

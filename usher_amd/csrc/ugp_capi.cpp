@@ -102,6 +102,7 @@ struct EventSet {
 };
 
 constexpr uint32_t kMaxTilesPerLaunch = 4096;   // 262,144 samples per sub-batch
+constexpr int kMaxSets = 4;                     // workspace sets per handle = calls of ugp_place_device_overlapped that can be on the device at a time
 
 }  // namespace
 
@@ -169,17 +170,20 @@ struct ugp_mat {
         bool job_busy = false;           // a job on this set has been started and not yet waited for
         hipStream_t stream = nullptr;    // the handle's own stream for this set (ugp_place_device)
         hipEvent_t done = nullptr;       // recorded behind the last call that used this set
-        hipEvent_t entry = nullptr;      // (ugp_place_device_overlapped) the caller's stream at the moment of the set's latest call
-        bool entry_valid = false;
         hipStream_t done_on = nullptr;   // ... on this stream
-    } work[2];
+    } work[kMaxSets];
     ugp_timing tsum = {};    // durations of all calls since the last ugp_get_timing_sum
     uint32_t tsum_calls = 0;
     int last_work = 0;       // set used by the most recent call (ugp_get_timing reports it)
-    int next_work = 0;       // set the next ugp_place_device call takes
+    int next_work = 0;       // set the next ugp_place_device_overlapped call takes (cycles through knobs.depth sets)
+    int next_job = 0;        // set the next ugp_place_batch_async job takes (sets 0 and 1)
+    uint64_t n_overlapped = 0;                  // calls of ugp_place_device_overlapped so far
+    hipEvent_t entry_ring[kMaxSets] = {};       // the caller's stream at the moment of the last kMaxSets such calls
+    int share_n = 1;         // (during a call) tree walks expected on the device at a time: this call's grid is its share of the resident wave slots
     uint32_t tie_lists_filled = 0, tie_sub_batches = 0;   // sub-batches of the current call whose tie lists phase 2 has filled / all of them (ugp_tied_nodes)
-    bool sharing = false;    // (during a ugp_place_device call) the other set's call was still running when this one, or the one before it, was queued
+    bool sharing = false;    // (during a call) another set's call was still running when this one, or the one before it, was queued
     bool was_busy = false;   // ... when the previous call was queued
+    int was_n = 1;           // share_n of the previous call
     // ---- add mode (ugp_mat_update / ugp_touched_*): where each node's words sit in the record streams (by BFS index; the coarse
     // tree's by coarse index), the records of the nodes created or rewritten since, and the open batch's scoring state
     struct Upd {
@@ -313,7 +317,7 @@ int run_place(ugp_mat *m, ugp_qset *qs, int mode, ugp_result *d_out, int32_t *d_
         // The pre-pass has no phase 2: its walk records which node set every chunk minimum (k_best8<ARG>, k_coarse_result) -- any
         // node of minimal cost serves the sort and the descent.  (UGP_COARSE_PHASE2=1: the full phase 2 instead, i.e. the
         // reference's tie-break winner: 0.2 ms more per 16,384 samples, the same answers.)
-        m->coarse->sharing = m->sharing;
+        m->coarse->sharing = m->sharing; m->coarse->share_n = m->share_n;
         const bool coarse_arg = m->coarse->d_node_pos8.p && m->coarse->flat.max_chunk8_words < 65536u && !K.coarse_phase2;
         if (int rc = run_place(m->coarse, qs, 0, W.d_coarse_res.p, nullptr, nullptr, nullptr, nullptr, nullptr, 0, s, coarse_arg, nullptr, wi)) return rc;
         HIP_TRY(hipSetDevice(m->device));
@@ -606,7 +610,7 @@ int run_place(ugp_mat *m, ugp_qset *qs, int mode, ugp_result *d_out, int32_t *d_
             // takes half of what the device keeps resident, so that both grids ARE resident instead of one waiting for the other's
             // waves to exit -- measured at 16,384 samples per call: 2.71 -> 2.29 ms per call (6.05 -> 7.2 M placements/s), best at
             // 8 of the 17 waves per CU of that time (7: 2.32, 9: 2.39, 12: 2.51); with 16 resident since the B halves moved into registers, 8 again (6: 1.85, 8: 1.75, 10: 1.86 ms).  A call that finds the device to itself keeps the full grid.
-            if (m->sharing) waves_cu = std::max(1, K.shared_waves ? (int)K.shared_waves : waves_cu / 2);
+            if (m->sharing) waves_cu = std::max(1, K.shared_waves ? (int)K.shared_waves : waves_cu / std::max(2, m->share_n));
             if (K.waves_per_cu) waves_cu = std::max(1, std::min(std::max(m->occ_per_cu, 1), (int)K.waves_per_cu));   // tuning
             uint64_t blocks = (uint64_t)waves_cu * std::max(m->n_cu, 1);
             blocks = std::min<uint64_t>(blocks, (uint64_t)n_tiles512 * G);
@@ -927,7 +931,6 @@ void ugp_mat_destroy(ugp_mat *m) {
     for (auto &W : m->work) {
         if (W.stream) { (void)hipStreamSynchronize(W.stream); (void)hipStreamDestroy(W.stream); }
         if (W.done) { (void)hipEventSynchronize(W.done); (void)hipEventDestroy(W.done); }
-        if (W.entry) (void)hipEventDestroy(W.entry);
         for (auto &G : W.gens) {
             for (auto &es : G.events)
                 for (int i = 0; i < 4; i++)
@@ -937,6 +940,7 @@ void ugp_mat_destroy(ugp_mat *m) {
     }
     for (auto &W : m->work) delete W.job_qs;
     delete m->upd.qs;
+    for (hipEvent_t e : m->entry_ring) if (e) (void)hipEventDestroy(e);
     if (m->kb_done) (void)hipEventDestroy(m->kb_done);
     if (m->coarse) ugp_mat_destroy(m->coarse);
     delete m->own_qs;
@@ -1073,13 +1077,22 @@ int ugp_place_device(ugp_mat *m, ugp_qset *qs, void *d_out, void *stream) {
 // Is the other workspace set's call still on the device?  (Then this call's tree walks leave it half of the chip.)  Or was it
 // when the previous call was queued?  The first call of a burst finds the device idle; a caller that has just been issuing
 // calls back to back is about to do so again.
-static void note_sharing(ugp_mat *m, int wi) {
-    const ugp_mat::Work &O = m->work[wi ^ 1];
-    const bool busy = O.done && hipEventQuery(O.done) == hipErrorNotReady;
+static void note_sharing(ugp_mat *m, int wi, int depth) {
+    int n_busy = 0;
+    for (int o = 0; o < depth; o++) {
+        if (o == wi) continue;
+        const ugp_mat::Work &O = m->work[o];
+        if (O.done && hipEventQuery(O.done) == hipErrorNotReady) n_busy++;
+    }
     (void)hipGetLastError();   // (hipErrorNotReady is not an error)
+    const bool busy = n_busy > 0;
     m->sharing = busy || m->was_busy;
+    // a caller that keeps `depth` calls in flight has depth - 1 others on the device when the pipeline is full; while it fills
+    // (or drains) the calls found running, or found by the previous call, say how many walks share the chip
+    m->share_n = std::max(n_busy + 1, m->was_busy ? m->was_n : 1);
     m->was_busy = busy;
-    if (m->knobs.debug_sharing) fprintf(stderr, "[ugp] call on set %d: sharing=%d\n", wi, (int)m->sharing);
+    m->was_n = n_busy + 1;
+    if (m->knobs.debug_sharing) fprintf(stderr, "[ugp] call on set %d: sharing=%d among %d\n", wi, (int)m->sharing, m->share_n);
 }
 
 // The opt-in form: consecutive calls alternate between the handle's two workspace sets and run on two streams of its own,
@@ -1088,25 +1101,33 @@ static void note_sharing(ugp_mat *m, int wi) {
 // Ordering (include/usher_amd.h): `stream` receives every call's completion, in call order; a call is ordered behind the
 // work that was queued on `stream` before the PREVIOUS overlapped call on this handle (one call of lag: work queued since
 // then sits behind that call's completion and would serialise the two) -- and behind all of it when the handle is idle.
+int ugp_pipeline_depth(const ugp_mat *m) { return m ? std::max(2, std::min(kMaxSets, (int)m->knobs.depth)) : 0; }
+
 int ugp_place_device_overlapped(ugp_mat *m, ugp_qset *qs, void *d_out, void *stream) {
     if (!m || !qs || (!d_out && qs->n_queries)) return fail(UGP_ERR_INVALID, "null argument");
     if (qs->device != m->device) return fail(UGP_ERR_INVALID, "query set lives on another device");
     HIP_TRY(hipSetDevice(m->device));
-    const int wi = m->next_work;
-    m->next_work ^= 1;
+    const int depth = std::max(2, std::min(kMaxSets, (int)m->knobs.depth));
+    // Long calls gain nothing from a third batch on the device (measured: 65,536 samples per call 17.4 M/s with two, 16.9 with three;
+    // thousands of N rows per sample 3.1 against 2.9), short ones do (16,384: 10.2 -> 11.3; 1,024 on a 100k-node tree 5.7 -> 6.8):
+    // they cycle through two of the handle's sets.  The ordering promise is the handle's (depth - 1 calls of lag) either way.
+    const int use = (qs->n_queries > 32768 || qs->n_ent > qs->n_queries * 128) ? 2 : depth;
+    const int wi = m->next_work % use;
+    m->next_work = (wi + 1) % use;
     ugp_mat::Work &W = m->work[wi];
     if (!W.stream) HIP_TRY(hipStreamCreateWithFlags(&W.stream, hipStreamNonBlocking));
-    if (!W.entry) HIP_TRY(hipEventCreateWithFlags(&W.entry, hipEventDisableTiming));
-    note_sharing(m, wi);
-    struct Unshare { ugp_mat *m; ~Unshare() { m->sharing = false; } } unshare{m};
-    // what was on the caller's stream when this call was made ...
-    HIP_TRY(hipEventRecord(W.entry, (hipStream_t)stream));
-    W.entry_valid = true;
-    // ... is waited for by the NEXT call (which has to wait for the call before this one anyway: same workspaces); this call
-    // waits for what the previous call saw -- or, when that call is no longer running, for everything (nothing to overlap with)
-    const ugp_mat::Work &O = m->work[wi ^ 1];
-    if (!m->was_busy) HIP_TRY(hipStreamWaitEvent(W.stream, W.entry, 0));
-    else if (O.entry_valid) HIP_TRY(hipStreamWaitEvent(W.stream, O.entry, 0));
+    note_sharing(m, wi, use);
+    struct Unshare { ugp_mat *m; ~Unshare() { m->sharing = false; m->share_n = 1; } } unshare{m};
+    // What was on the caller's stream when this call was made (a ring of events by call number) is waited for by the call
+    // depth - 1 calls later: that call has to wait for the call `depth` calls before it anyway (its workspaces), and whatever was
+    // queued on `stream` in front of the call after THAT one sits behind its completion -- waiting for it serialises nothing.
+    // When no other call is running this call waits for everything queued so far (nothing to overlap with).
+    const uint64_t kc = m->n_overlapped++;
+    hipEvent_t &mine = m->entry_ring[kc % kMaxSets];
+    if (!mine) HIP_TRY(hipEventCreateWithFlags(&mine, hipEventDisableTiming));
+    HIP_TRY(hipEventRecord(mine, (hipStream_t)stream));
+    if (!m->was_busy) HIP_TRY(hipStreamWaitEvent(W.stream, mine, 0));
+    else if (kc + 1 >= (uint64_t)depth) HIP_TRY(hipStreamWaitEvent(W.stream, m->entry_ring[(kc - (uint64_t)(depth - 1)) % kMaxSets], 0));
     if (int rc = run_place(m, qs, 0, (ugp_result *)d_out, nullptr, nullptr, nullptr, nullptr, nullptr, 0, W.stream, false, nullptr, wi)) return rc;
     if (W.done) HIP_TRY(hipStreamWaitEvent((hipStream_t)stream, W.done, 0));   // (recorded at the end of run_place)
     return UGP_OK;
@@ -1124,7 +1145,7 @@ int ugp_place_batch_async(ugp_mat *m, const ugp_queries *q, ugp_result *out, ugp
     if (!m || !q || !job || (!out && q->n_queries)) return fail(UGP_ERR_INVALID, "null argument");
     *job = nullptr;
     HIP_TRY(hipSetDevice(m->device));
-    const int wi = m->next_work;
+    const int wi = m->next_job;
     ugp_mat::Work &W = m->work[wi];
     if (W.job_busy) return fail(UGP_ERR_INVALID, "two jobs are in flight on this handle: ugp_job_wait the oldest first");
     if (!W.stream) HIP_TRY(hipStreamCreateWithFlags(&W.stream, hipStreamNonBlocking));
@@ -1134,9 +1155,9 @@ int ugp_place_batch_async(ugp_mat *m, const ugp_queries *q, ugp_result *out, ugp
     if (int rc = qset_fill(m, q, W.job_qs, W.stream, &W.job_in)) return rc;
     HIP_TRY(W.d_job_out.reserve(q->n_queries));
     if (int rc = W.job_out.reserve(std::max<size_t>(q->n_queries, 1) * sizeof(ugp_result) + 8)) return rc;
-    note_sharing(m, wi);   // (is the other set's job still on the device?)
+    note_sharing(m, wi, 2);   // (is the other set's job still on the device?)
     int rc = run_place(m, W.job_qs, 0, W.d_job_out.p, nullptr, nullptr, nullptr, nullptr, nullptr, 0, W.stream, false, nullptr, wi);
-    m->sharing = false;
+    m->sharing = false; m->share_n = 1;
     if (rc != UGP_OK) return rc;
     // results and the row check's verdict into pinned memory, behind the kernels; W.done is recorded again behind them
     if (q->n_queries) HIP_TRY(hipMemcpyAsync(W.job_out.p, W.d_job_out.p, q->n_queries * sizeof(ugp_result), hipMemcpyDeviceToHost, W.stream));
@@ -1148,7 +1169,7 @@ int ugp_place_batch_async(ugp_mat *m, const ugp_queries *q, ugp_result *out, ugp
     if (!j) return fail(UGP_ERR_NOMEM, "out of host memory");
     j->m = m; j->wi = wi; j->out = out; j->n = q->n_queries;
     W.job_busy = true;
-    m->next_work ^= 1;
+    m->next_job ^= 1;
     *job = j;
     return UGP_OK;
 }

@@ -68,11 +68,14 @@ __device__ __forceinline__ uint32_t rdlane(uint32_t v, uint32_t l) {
 // row of a site's reference base instead of the site's own row wherever no sample of the tile differs from it.
 __global__ void k_fill_table(uint32_t *__restrict__ table, const uint8_t *__restrict__ site_ref,
                              uint32_t n_rows, uint64_t total_dwords) {
+    // (16 bytes per thread and store: a row is 64 dwords = 16 such pieces, so a wave writes four rows per instruction)
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-    for (; i < total_dwords; i += stride) {
-        const uint32_t row = (uint32_t)((i >> 6) % n_rows);
-        table[i] = row < TABLE_CONST_ROWS ? (0x11111111u << row) : (uint32_t)site_ref[row - TABLE_CONST_ROWS] * 0x11111111u;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x, total4 = total_dwords >> 2;
+    uint4 *t4 = (uint4 *)table;
+    for (; i < total4; i += stride) {
+        const uint32_t row = (uint32_t)((i >> 4) % n_rows);
+        const uint32_t v = row < TABLE_CONST_ROWS ? (0x11111111u << row) : (uint32_t)site_ref[row - TABLE_CONST_ROWS] * 0x11111111u;
+        t4[i] = make_uint4(v, v, v, v);
     }
 }
 
@@ -2003,7 +2006,20 @@ __global__ void __launch_bounds__(256) k_build_units(const uint32_t *__restrict_
         const uint32_t sh = min(i / grow_every, 16u);
         return (uint32_t)min((uint64_t)U << sh, (uint64_t)UM);
     };
-    auto count_side = [&](uint32_t chunks) -> uint32_t { uint32_t n = 0; for (uint32_t done = 0; done < chunks; n++) done += len_of(n); return n; };
+    // units a side of `chunks` chunks is cut into: by growth step, not unit by unit (every thread of the block runs this for every
+    // tile of its queue: unit by unit it was 70-100 us of a step's dependent chain)
+    auto count_side = [&](uint32_t chunks) -> uint32_t {
+        if (!chunks) return 0u;
+        if (!grow_every) return (chunks + U - 1u) / U;
+        uint32_t n = 0;
+        uint64_t done = 0;
+        for (uint32_t g = 0;; g++) {
+            const uint64_t L = min((uint64_t)U << min(g, 16u), (uint64_t)UM);
+            const uint64_t left = chunks - done;
+            if (L == UM || g >= 16u || (uint64_t)grow_every * L >= left) return n + (uint32_t)((left + L - 1u) / L);
+            n += grow_every; done += (uint64_t)grow_every * L;
+        }
+    };
     for (uint32_t t = threadIdx.x; t < T; t += blockDim.x) {
         const uint32_t h0 = hstart ? hstart[tlo + t] : 0u, hl = hstart ? hlen[tlo + t] : 0u;
         s_heavy[t] = (hl + HU - 1u) / HU;
@@ -2030,18 +2046,33 @@ __global__ void __launch_bounds__(256) k_build_units(const uint32_t *__restrict_
         const uint32_t c0 = h0 + r * HU;
         out[i] = make_uint4(tile, c0, min(c0 + HU, h0 + hl), 1u);
     }
-    for (uint32_t t = threadIdx.x; t < T; t += blockDim.x) {
+    // the units outside: one thread per (tile, rank) -- the k-th unit of a tile is the (k / 2)-th of alternating sides while both
+    // last, then the rest of the longer one; where the i-th unit of a side begins is a sum over the growth steps in front of it
+    // (a tile's list used to be written by ONE thread, ~150 dependent iterations: 100 us of a step's dependent chain)
+    auto start_of = [&](uint32_t i) -> uint64_t {   // chunks covered by the units 0 .. i-1 of a side
+        if (!grow_every) return (uint64_t)i * U;
+        uint64_t sum = 0;
+        for (uint32_t g = 0; g * grow_every < i; g++) {
+            const uint32_t cnt = min(grow_every, i - g * grow_every);
+            sum += (uint64_t)cnt * min((uint64_t)U << min(g, 16u), (uint64_t)UM);
+        }
+        return sum;
+    };
+    const uint32_t n_rank_max = light_order == 1u ? 0u : s_max_light;
+    for (uint32_t t = 0; t < T; t++) {
         const uint32_t tile = tlo + t;
         const uint32_t h0 = hstart ? hstart[tile] : 0u, hl = hstart ? hlen[tile] : 0u;
-        const uint32_t nA = count_side(n_chunks - h0 - hl), nB = count_side(h0), m = min(nA, nB);
-        uint32_t a_at = h0 + hl, b_at = h0, ia = 0, ib = 0;
-        const uint32_t n_rank = light_order == 1u ? nA + nB : s_max_light;   // (rank-major lists are padded with fillers to the longest tile)
-        for (uint32_t k = 0; k < n_rank; k++) {
+        const uint32_t lenA = n_chunks - h0 - hl, lenB = h0;
+        const uint32_t nA = count_side(lenA), nB = count_side(lenB), m = min(nA, nB);
+        const uint32_t n_rank = light_order == 1u ? nA + nB : n_rank_max;   // (rank-major lists are padded with fillers to the longest tile)
+        for (uint32_t k = threadIdx.x; k < n_rank; k += blockDim.x) {
             uint32_t c0 = 0, c1 = 0;
             if (k < nA + nB) {
                 const bool side_a = k < 2u * m ? !(k & 1u) : nA > nB;
-                if (side_a) { c0 = a_at; c1 = min(a_at + len_of(ia), n_chunks); a_at = c1; ia++; }
-                else { const uint32_t l = min(len_of(ib), b_at); c1 = b_at; c0 = b_at - l; b_at = c0; ib++; }
+                const uint32_t i = k < 2u * m ? k / 2u : k - m;
+                const uint64_t before = start_of(i);
+                if (side_a) { c0 = h0 + hl + (uint32_t)min(before, (uint64_t)lenA); c1 = (uint32_t)min((uint64_t)c0 + len_of(i), (uint64_t)n_chunks); }
+                else { c1 = lenB - (uint32_t)min(before, (uint64_t)lenB); c0 = c1 - min(len_of(i), c1); }
             }
             const uint32_t at = s_heavy_total + (light_order == 1u ? s_loff[t] + k : k * T + t);
             out[at] = make_uint4(tile, c0, c1, 0u);
@@ -2115,7 +2146,7 @@ hipError_t launch_locality_sort(const ugp_result *coarse_res, const uint32_t *co
 hipError_t launch_fill_table(uint32_t *table, const uint8_t *site_ref, uint32_t n_sites, uint64_t total_dwords,
                              hipStream_t s) {
     if (total_dwords == 0) return hipSuccess;
-    uint64_t blocks = (total_dwords + 255) / 256;
+    uint64_t blocks = (total_dwords / 4 + 255) / 256;   // (the table is a whole number of 64-dword rows)
     if (blocks > 16384) blocks = 16384;
     hipLaunchKernelGGL(k_fill_table, dim3((uint32_t)blocks), dim3(256), 0, s, table, site_ref, n_sites + TABLE_CONST_ROWS, total_dwords);
     return hipGetLastError();

@@ -299,6 +299,10 @@ class Placer:
         ordered behind what was on `stream` when the PREVIOUS overlapped call was made (alternate between two output buffers)."""
         self._ck(self._L.ugp_place_device_overlapped(self._h, qset, C.c_void_p(d_out_ptr), C.c_void_p(stream)))
 
+    def pipeline_depth(self) -> int:
+        """ugp_pipeline_depth: overlapped calls kept on the device at a time = output buffers to cycle through."""
+        return int(self._L.ugp_pipeline_depth(self._h))
+
     def timing(self) -> Dict:
         out = _lib.ugp_timing()
         self._ck(self._L.ugp_get_timing(self._h, C.byref(out)))
