@@ -153,3 +153,47 @@ def test_depth_first_order_of_a_tree_that_is_not_numbered_breadth_first():
         assert pl.subtree_mask(root, lv, order="bfs").astype(bool).tolist() == want.tolist()
         assert pl.subtree_mask(root, lv, order="dfs").astype(bool).tolist() == want.tolist()
     pl.close()
+
+
+def test_extended_searches_on_the_packed_pruned_path(monkeypatch):
+    """Round 4: an extended search whose options the packed path can express runs there -- a node order / a distance is a tie rank
+    of phase 2, a node mask is a temporary exclusion (the "no candidate" bit, set in the tree and in the coarse tree of the locality
+    pre-pass for the call, cleared behind it).  annotate-style (depth-first indices), ripples-style without the score matrix (mask by
+    descendant leaves + distance) and merge-style from the root (level-capped subtree), each with its tie lists: packed == the
+    one-sample-per-lane kernel (UGP_EX_SLOW=1) == the oracle's restatement of the call sites; a plain search afterwards sees every
+    node again."""
+    monkeypatch.setenv("UGP_COARSE_MIN_NODES", "0")
+    monkeypatch.delenv("UGP_EX_SLOW", raising=False)
+    arrays, queries = synth.make_case(777, n_leaves=2500, n_queries=700, n_sites=140, n_ambig=(0, 0, 2, 5), p_masked=0.01)
+    n = arrays["n"]
+    ot = capi.OracleTree(arrays)
+    batch = QueryBatch(queries)
+    fast = Placer(arrays, chunk_nodes=48)
+    monkeypatch.setenv("UGP_EX_SLOW", "1")
+    slow = Placer(arrays, chunk_nodes=48)
+    monkeypatch.delenv("UGP_EX_SLOW")
+    plain = fast.place(batch).copy()
+    dfs = fast.node_order("dfs").astype(np.int64)
+    leaves_below = np.array([ot.num_leaves(j) for j in range(n)])
+    rng = np.random.default_rng(9)
+    dist = rng.integers(0, 3, n).astype(np.uint32)
+    m_leaves = (leaves_below >= 3).astype(np.uint8); m_leaves[0] = 1
+    m_levels = fast.subtree_mask(0, 6)
+    cases = [("annotate", dict(order="dfs"), dfs, np.arange(n), None),
+             ("ripples", dict(order="bfs", node_mask=m_leaves, distance=dist), np.flatnonzero(m_leaves), np.flatnonzero(m_leaves), dist),
+             ("merge", dict(order="bfs", node_mask=m_levels), np.flatnonzero(m_levels), np.flatnonzero(m_levels), None)]
+    for name, kw, nodes, jidx, d in cases:
+        a = fast.place_ex(batch, **kw)
+        assert fast.timing()["packed_path"] == 1, name
+        b = slow.place_ex(batch, **kw)
+        assert slow.timing()["packed_path"] == 0, name
+        assert (a.view(np.int32) == b.view(np.int32)).all(), name
+        ta, ha, ca = fast.tied_nodes_ex(batch, 256, **kw)
+        tb, hb, cb = slow.tied_nodes_ex(batch, 256, **kw)
+        assert (ca == cb).all() and all(x.tolist() == y.tolist() for x, y in zip(ta, tb)) and all(x.tolist() == y.tolist() for x, y in zip(ha, hb)), name
+        for i in range(0, len(queries), 7):
+            w = ot.place_list(queries[i], nodes, jidx=jidx, distance=None if d is None else d[nodes])
+            _same(a, i, w)
+            assert int(ca[i]) == w["num_best"] and ta[i].tolist() == w["ties"].tolist() and ha[i].tolist() == w["ties_has_unique"].tolist(), (name, i)
+        assert (fast.place(batch).view(np.int32) == plain.view(np.int32)).all(), name        # the mask is gone again
+    fast.close(); slow.close()

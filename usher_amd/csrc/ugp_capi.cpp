@@ -187,7 +187,8 @@ struct ugp_mat {
     // ---- add mode (ugp_mat_update / ugp_touched_*): where each node's words sit in the record streams (by BFS index; the coarse
     // tree's by coarse index), the records of the nodes created or rewritten since, and the open batch's scoring state
     struct Upd {
-        std::vector<uint32_t> hdr8, rec, post, coarse2bfs;
+        std::vector<uint32_t> hdr8, rec, post, coarse2bfs, excluded_j;
+        DevBuf<uint32_t> d_hdr8, d_rec_pos, d_post;   // the same maps on the device (node masks of the extended searches), uploaded on first use
         DevBuf<ugp::TouchedRec> d_rec;
         DevBuf<ugp::TouchedEnt> d_ent;
         DevBuf<uint8_t> d_alive;
@@ -307,7 +308,11 @@ int run_place(ugp_mat *m, ugp_qset *qs, int mode, ugp_result *d_out, int32_t *d_
     // (16-bit phase 1: every D / cost must stay below 0x7F7F, the value the shared upper bounds start from;
     // a tree with a masked mutation behind an ordinary one on the same node -- never produced by the reference's
     // sorted Node::add_mutation, mutation_annotated_tree.cpp:720-752 -- needs the order-aware 32-bit walk)
-    const bool packed_ok = (mode == 0) && !ex && !K.force_v1 && !f.mask_not_first && (qs->max_rows + f.max_path_muts + 2 < 0x7F7Full);
+    // (the extended searches take the packed path too when their options are the kind it can express: a node order / distance is a
+    // tie rank of phase 2, a node mask has been turned into exclusions by the caller; a per-sample excluded node and per-node
+    // scores stay on the one-sample-per-lane kernel)
+    const bool ex_packable = ex && !ex->mask && !ex->skip && !ex->scores;
+    const bool packed_ok = (mode == 0) && (!ex || ex_packable) && !K.force_v1 && !f.mask_not_first && (qs->max_rows + f.max_path_muts + 2 < 0x7F7Full);
     const bool sorted = packed_ok && m->coarse && Q > 512 && !K.no_sort && !K.no_prune;
     TG.coarse_timed = false;
     if (sorted) {
@@ -648,7 +653,7 @@ int run_place(ugp_mat *m, ugp_qset *qs, int mode, ugp_result *d_out, int32_t *d_
             else
                 HIP_TRY(ugp::launch_phase2(a, W.d_lbest.p, W.d_list.p, d_list_n, W.d_gbest_part.p, W.d_gbest.p, n_tiles512, W.d_items.p, d_nitems,
                                            (uint32_t)std::min<uint64_t>(pairs, 0xFFFFFFFFull), d_cnt, d_key,
-                                           m->d_rank2bfs.p, d_out + q0, order, f.max_slots, d_tie_count != nullptr, s));
+                                           m->d_rank2bfs.p, ex ? ex->rank2out : nullptr, d_out + q0, order, f.max_slots, d_tie_count != nullptr, s));
                 if (d_tie_count) m->tie_lists_filled++;
         } else if (mode == 1 && !ex && !m->h_level_off.empty() && !K.scores_dfs) {
             // -p in the output's own order: level by level of the breadth-first expansion, 64 consecutive scores of one sample per
@@ -1418,6 +1423,32 @@ int prepare_ex(ugp_mat *m, const ugp_queries *q, const ugp_place_opts *o, ExHost
 }
 }  // namespace
 
+namespace {
+int drain(ugp_mat *m);
+// Can this extended search run on the packed, pruned path?  Its node order / distance becomes the tie rank of phase 2; its node
+// mask becomes a temporary exclusion (the "no candidate" bit of ugp_mat_update, set for the call and cleared behind it -- the
+// pruning bounds stay valid with fewer candidates, and the coarse tree of the locality pre-pass is masked alike, so that its
+// seeds are costs of admitted nodes).  Not with a per-sample excluded node or per-node scores, not when the mask drops the
+// root (it always scores), not on a handle that carries exclusions of its own.
+bool ex_packs(const ugp_mat *m, const ugp_place_opts *o) {
+    if (o->skip_node || o->scores || m->knobs.ex_slow) return false;
+    if (o->node_mask && (!o->node_mask[0] || m->upd.rec.size() != m->flat.n_nodes || m->upd.n_excluded || m->flat.n_nodes >= (1ull << 30))) return false;
+    return true;
+}
+int mask_words(ugp_mat *m, const uint8_t *d_mask, bool set) {
+    ugp_mat *trees[2] = {m, m->coarse};
+    for (ugp_mat *t : trees) {
+        if (!t) continue;
+        auto &U = t->upd;
+        if (U.rec.size() != t->flat.n_nodes) { if (t == m) return fail(UGP_ERR_UNSUPPORTED, "no update maps"); continue; }
+        if (!U.d_rec_pos.p) { HIP_TRY(U.d_hdr8.upload(U.hdr8)); HIP_TRY(U.d_rec_pos.upload(U.rec)); HIP_TRY(U.d_post.upload(U.post)); }
+        HIP_TRY(ugp::launch_mask_words(d_mask, t == m ? nullptr : m->d_coarse2bfs.p, (uint32_t)t->flat.n_nodes, U.d_hdr8.p, U.d_rec_pos.p, U.d_post.p,
+                                       t->d_stream8.p, t->d_stream.p, t->d_stream_t.p, ugp::H_NOSCORE, set, nullptr));
+    }
+    return UGP_OK;
+}
+}  // namespace
+
 int ugp_place_batch_ex(ugp_mat *m, const ugp_queries *q, const ugp_place_opts *opts, ugp_result *out) {
     if (!m || !q || !opts || (!out && q->n_queries)) return fail(UGP_ERR_INVALID, "null argument");
     if (q->n_queries == 0) return UGP_OK;
@@ -1427,6 +1458,16 @@ int ugp_place_batch_ex(ugp_mat *m, const ugp_queries *q, const ugp_place_opts *o
     DevBuf<ugp_result> d_out;
     int rc = prepare_ex(m, q, opts, x, true);
     if (rc == UGP_OK && d_out.reserve(q->n_queries) != hipSuccess) rc = fail(UGP_ERR_HIP, "hipMalloc results");
+    const bool pack = rc == UGP_OK && ex_packs(m, opts) && (!m->coarse || m->d_coarse2bfs.p || !opts->node_mask);
+    if (pack) {
+        if (rc == UGP_OK) rc = drain(m);
+        ExDev xd = x.dev;
+        if (rc == UGP_OK && xd.mask) rc = mask_words(m, xd.mask, true);
+        const uint8_t *masked = xd.mask;
+        xd.mask = nullptr;
+        if (rc == UGP_OK) rc = run_place(m, qs, 0, d_out.p, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, false, &xd);
+        if (masked) { const int rc2 = mask_words(m, masked, false); if (rc == UGP_OK) rc = rc2; }
+    } else
     if (rc == UGP_OK) rc = run_place(m, qs, 0, d_out.p, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, false, &x.dev);
     if (rc == UGP_OK && hipMemcpy(out, d_out.p, q->n_queries * sizeof(ugp_result), hipMemcpyDeviceToHost) != hipSuccess)
         rc = fail(UGP_ERR_HIP, "copy results");
@@ -1460,12 +1501,26 @@ int ugp_tied_nodes_ex(ugp_mat *m, const ugp_queries *q, const ugp_place_opts *op
     };
     chk(d_res.reserve(Q), "hipMalloc"); chk(d_best.reserve(Q), "hipMalloc"); chk(d_cnt.reserve(padded), "hipMalloc");
     chk(d_j.reserve((size_t)Q * std::max<uint32_t>(cap, 1)), "hipMalloc"); chk(d_hu.reserve((size_t)Q * std::max<uint32_t>(cap, 1)), "hipMalloc");
-    if (rc == UGP_OK) rc = run_place(m, qs, 0, d_res.p, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, false, &x.dev);
-    if (rc == UGP_OK) {
+    bool listed = false;
+    if (rc == UGP_OK && ex_packs(m, opts) && (!m->coarse || m->d_coarse2bfs.p || !opts->node_mask)) {
+        // the packed path: phase 2 writes the lists itself, from the chunks that attain the minimum
+        rc = drain(m);
+        ExDev xd = x.dev;
+        if (rc == UGP_OK && xd.mask) rc = mask_words(m, xd.mask, true);
+        const uint8_t *masked = xd.mask;
+        xd.mask = nullptr;
+        if (rc == UGP_OK) chk(hipMemsetAsync(d_cnt.p, 0, padded * sizeof(uint32_t), nullptr), "memset");
+        m->tie_lists_filled = m->tie_sub_batches = 0;
+        if (rc == UGP_OK) rc = run_place(m, qs, 0, d_res.p, nullptr, nullptr, d_cnt.p, d_j.p, d_hu.p, cap, nullptr, false, &xd);
+        listed = rc == UGP_OK && m->tie_sub_batches > 0 && m->tie_lists_filled == m->tie_sub_batches;
+        if (masked) { const int rc2 = mask_words(m, masked, false); if (rc == UGP_OK) rc = rc2; }
+    }
+    if (rc == UGP_OK && !listed) rc = run_place(m, qs, 0, d_res.p, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, false, &x.dev);
+    if (rc == UGP_OK && !listed) {
         chk(ugp::launch_extract_best(d_res.p, (uint32_t)Q, d_best.p, nullptr), "extract best");
         chk(hipMemsetAsync(d_cnt.p, 0, padded * sizeof(uint32_t), nullptr), "memset");
     }
-    if (rc == UGP_OK) rc = run_place(m, qs, 2, nullptr, nullptr, d_best.p, d_cnt.p, d_j.p, d_hu.p, cap, nullptr, false, &x.dev);
+    if (rc == UGP_OK && !listed) rc = run_place(m, qs, 2, nullptr, nullptr, d_best.p, d_cnt.p, d_j.p, d_hu.p, cap, nullptr, false, &x.dev);
     if (rc == UGP_OK) {
         chk(hipMemcpy(tie_count, d_cnt.p, Q * sizeof(uint32_t), hipMemcpyDeviceToHost), "copy tie counts");
         if (cap) {
@@ -1574,6 +1629,7 @@ int ugp_mat_update(ugp_mat *m, const ugp_touched *recs, const uint32_t *retired,
                 }
             }
             U.n_excluded++;
+            U.excluded_j.push_back(j);
         }
         HIP_TRY(U.d_rec.grow_keep(U.n_rec + n_new, U.n_rec));
         HIP_TRY(U.d_alive.grow_keep(U.n_rec + n_new, U.n_rec));

@@ -475,11 +475,15 @@ __device__ __forceinline__ WalkOut walk_ties(const PlaceArgs &a, uint32_t *slots
                     hu = (masked || common != n_before) ? 1u : 0u;
                 }
                 if (relevant && elig && !excluded && cost == want) {
-                    o.cnt++; o.key = max(o.key, key | hu);
+                    // (the extended searches rank ties by the caller's rule -- its node order, its distances -- and name nodes by their
+                    // position in the caller's order: a.alt_rank / a.out_index by BFS index; a tie is a rare event)
+                    const uint32_t rk = a.alt_rank ? (a.alt_rank[rank2bfs[key >> 1]] << 1) : key;
+                    o.cnt++; o.key = max(o.key, rk | hu);
                     if (LIST) {
                         const uint32_t i = atomicAdd(&a.tie_count[list_q], 1u);
                         if (i < a.tie_cap) {
-                            a.tie_j[(uint64_t)list_q * a.tie_cap + i] = rank2bfs[key >> 1];
+                            const uint32_t bfs = rank2bfs[key >> 1];
+                            a.tie_j[(uint64_t)list_q * a.tie_cap + i] = a.out_index ? a.out_index[bfs] : bfs;
                             a.tie_hu[(uint64_t)list_q * a.tie_cap + i] = (uint8_t)hu;
                         }
                     }
@@ -2304,7 +2308,7 @@ hipError_t launch_phase2_packed(const Best8Args &b1, const uint32_t *list, const
 hipError_t launch_phase2(const PlaceArgs &a, const uint32_t *lbest, const uint32_t *list, const uint32_t *list_n, uint32_t *gbest_part,
                          uint32_t *gbest, uint32_t n_tiles512,
                          uint32_t *items, uint32_t *n_items, uint32_t cap, uint32_t *cnt, uint32_t *key,
-                         const uint32_t *rank2bfs, ugp_result *out, const uint32_t *order, uint32_t max_slots, bool lists, hipStream_t s) {
+                         const uint32_t *rank2bfs, const uint32_t *rank2out, ugp_result *out, const uint32_t *order, uint32_t max_slots, bool lists, hipStream_t s) {
     const uint32_t per_chunk = n_tiles512 * 256;
     const uint32_t slices = std::min<uint32_t>(GBEST_SLICES, a.n_chunks);
     hipLaunchKernelGGL(k_gbest, dim3(n_tiles512, slices), dim3(256), 0, s, lbest, list, list_n, a.n_chunks, n_tiles512, gbest_part);
@@ -2319,7 +2323,7 @@ hipError_t launch_phase2(const PlaceArgs &a, const uint32_t *lbest, const uint32
     if ((uint64_t)blocks > pairs) blocks = (uint32_t)pairs;
     if (lists) hipLaunchKernelGGL(k_ties<true>, dim3(blocks), dim3(64), lds, s, a, lbest, gbest, items, n_items, cap, n_tiles512 * 8, cnt, key, rank2bfs, order);
     else hipLaunchKernelGGL(k_ties<false>, dim3(blocks), dim3(64), lds, s, a, lbest, gbest, items, n_items, cap, n_tiles512 * 8, cnt, key, rank2bfs, order);
-    hipLaunchKernelGGL(k_final, dim3((a.n_queries + 255) / 256), dim3(256), 0, s, gbest, cnt, key, rank2bfs, a.n_queries, out, order);
+    hipLaunchKernelGGL(k_final, dim3((a.n_queries + 255) / 256), dim3(256), 0, s, gbest, cnt, key, rank2out ? rank2out : rank2bfs, a.n_queries, out, order);
     return hipGetLastError();
 }
 

@@ -99,7 +99,8 @@ hipError_t launch_phase2_packed(const Best8Args &b1, const uint32_t *list, const
 hipError_t launch_phase2(const PlaceArgs &a, const uint32_t *lbest, const uint32_t *list, const uint32_t *list_n, uint32_t *gbest_part,
                          uint32_t *gbest, uint32_t n_tiles512,
                          uint32_t *items, uint32_t *n_items, uint32_t cap, uint32_t *cnt, uint32_t *key,
-                         const uint32_t *rank2bfs, ugp_result *out, const uint32_t *order, uint32_t max_slots, bool lists /* also a.tie_* */, hipStream_t s);
+                         const uint32_t *rank2bfs, const uint32_t *rank2out /* tie key -> index reported (extended searches), or null = rank2bfs */,
+                         ugp_result *out, const uint32_t *order, uint32_t max_slots, bool lists /* also a.tie_* */, hipStream_t s);
 
 // row checks of k_rows_prepare: *err = (row << 3) | kind of the first offending row, ~0 when clean
 enum { ROWS_UNSORTED = 1, ROWS_BAD_REF = 2, ROWS_BAD_MASK = 3, ROWS_REF_MISMATCH = 4 };

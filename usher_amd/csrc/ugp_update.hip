@@ -18,6 +18,32 @@ hipError_t launch_or_words(uint32_t *stream, const uint32_t *pos, uint32_t n, ui
     return hipGetLastError();
 }
 
+// A node mask shared by all samples of one extended search (ugp_place_opts::node_mask) as a temporary exclusion: the words of every
+// node the mask leaves out get (set != 0) or lose the "no candidate" bit.  i = index in this tree, map_j[i] = its index in the mask's
+// tree (the coarse tree of the locality pre-pass: its node's index in the full tree; null: the same).  The root is left alone.
+__global__ void k_mask_words(const uint8_t *__restrict__ mask, const uint32_t *__restrict__ map_j, uint32_t n, const uint32_t *__restrict__ hdr8,
+                             const uint32_t *__restrict__ rec, const uint32_t *__restrict__ post, uint32_t *__restrict__ stream8, uint32_t *__restrict__ stream,
+                             uint32_t *__restrict__ stream_t, uint32_t bit8, int set) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0 || i >= n || mask[map_j ? map_j[i] : i]) return;
+    if (set) {
+        if (hdr8[i] != 0xFFFFFFFFu) stream8[hdr8[i]] |= bit8;
+        stream[rec[i] + 1u] |= KEY_EXCLUDED;
+        if (post[i] != 0xFFFFFFFFu) stream_t[post[i] + 1u] |= KEY_EXCLUDED;
+    } else {
+        if (hdr8[i] != 0xFFFFFFFFu) stream8[hdr8[i]] &= ~bit8;
+        stream[rec[i] + 1u] &= ~KEY_EXCLUDED;
+        if (post[i] != 0xFFFFFFFFu) stream_t[post[i] + 1u] &= ~KEY_EXCLUDED;
+    }
+}
+
+hipError_t launch_mask_words(const uint8_t *mask, const uint32_t *map_j, uint32_t n, const uint32_t *hdr8, const uint32_t *rec, const uint32_t *post,
+                             uint32_t *stream8, uint32_t *stream, uint32_t *stream_t, uint32_t bit8, bool set, hipStream_t s) {
+    if (!n) return hipSuccess;
+    hipLaunchKernelGGL(k_mask_words, dim3((n + 255) / 256), dim3(256), 0, s, mask, map_j, n, hdr8, rec, post, stream8, stream, stream_t, bit8, set ? 1 : 0);
+    return hipGetLastError();
+}
+
 // dense[pos][q] = allele mask of the sample's row at pos (15 for a missing call); D(bottom) = rows whose set excludes the
 // reference base (usher_mapper.cpp:292-388 with an empty ancestral list).  Rows are unique per (sample, position).
 __global__ void k_dense_scatter(uint8_t *__restrict__ dense, uint32_t n_pos, uint32_t qpad, int32_t *__restrict__ dbot, const int32_t *__restrict__ pos,

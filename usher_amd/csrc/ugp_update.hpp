@@ -32,6 +32,9 @@ struct TouchedArgs {
 };
 
 hipError_t launch_or_words(uint32_t *stream, const uint32_t *pos, uint32_t n, uint32_t bits, hipStream_t s);
+// a node mask as a temporary exclusion (every node has one thread; each node's words are its own: plain read-modify-write)
+hipError_t launch_mask_words(const uint8_t *mask, const uint32_t *map_j, uint32_t n, const uint32_t *hdr8, const uint32_t *rec, const uint32_t *post,
+                             uint32_t *stream8, uint32_t *stream, uint32_t *stream_t, uint32_t bit8 /* H_NOSCORE */, bool set, hipStream_t s);
 // rows of the batch into the dense table (zeroed by the caller) and D(bottom): one thread per row
 hipError_t launch_dense_scatter(uint8_t *dense, uint32_t n_pos, uint32_t qpad, int32_t *dbot, const int32_t *pos, const uint8_t *ref, const uint8_t *nuc,
                                 const uint8_t *is_missing, const uint32_t *ent_q, uint64_t n_ent, hipStream_t s);
