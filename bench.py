@@ -468,6 +468,12 @@ def main():
                     "kernel_ms_alone": round(alone["place_ms"], 4),
                     "frac_alone": round(algo_bytes / (alone["place_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if alone["place_ms"] > 0 else None,
                     "ms_per_step_alone": round(t_alone * 1e3, 3),
+                    # In the timed region several launches of this kernel share the chip (each on its share of the resident wave slots):
+                    # a launch's duration there is that of a kernel with a third of the machine, so `frac` -- the contract's definition,
+                    # bytes per launch / in-region duration -- falls when the pipeline gets deeper even as `value` rises.  Per second of
+                    # chip time the kernel accounts for algo_bytes / ms_per_step:
+                    "walks_on_device_avg": round(k_ms / ms_per_step, 2) if ms_per_step > 0 else None,
+                    "frac_per_chip_second": round(algo_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if ms_per_step > 0 else None,
                     "overlap": "off (--no-overlap: ugp_place_device, stream-ordered)" if args.no_overlap else "consecutive ugp_place_device_overlapped calls: %d on the device at a time (internal streams, workspace sets, output buffers)" % depth,
                     "node_plus_mut_evals_decided_per_s": round(node_evals / (k_ms * 1e-3), 1) if k_ms > 0 else 0.0,
                     "coarse_ms": round(coarse_ms / args.steps, 4), "table_ms": round(table_ms / args.steps, 4), "merge_ms": round(merge_ms / args.steps, 4),

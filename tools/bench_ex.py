@@ -1,0 +1,56 @@
+#!/usr/bin/env python3
+"""Timings of the extended searches (the other callers of mapper2_body, include/usher_amd.h ugp_place_batch_ex) at 10M nodes:
+ripples-style (nodes with at least k descendant leaves, a per-node distance) and annotate-style (depth-first indices), on the packed
+pruned path and on the one-sample-per-lane kernel (UGP_EX_SLOW=1), results compared.
+    python tools/bench_ex.py [--nodes 10000000] [--queries 4096]"""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from usher_amd import Placer, QueryBatch, synth   # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--nodes", type=int, default=10_000_000)
+ap.add_argument("--queries", type=int, default=4096)
+ap.add_argument("--min-leaves", type=int, default=10)
+a = ap.parse_args()
+st = synth.SynthTree(a.nodes, n_sites=25000 if a.nodes >= 1_000_000 else 1500, seed=1)
+q = st.queries(a.queries, seed=77)
+batch = QueryBatch.from_csr(q["ent_off"], q["pos"], q["ref"], q["nuc"], q["is_missing"])
+par = np.asarray(st.arrays["parent"]).astype(np.int64)
+n = int(st.arrays["n"])
+leaves = np.zeros(n, np.int64)
+has_child = np.zeros(n, bool)
+has_child[par[1:]] = True
+leaves[~has_child] = 1
+for j in range(n - 1, 0, -1):          # (parents before children in the numbering: one reverse pass)
+    leaves[par[j]] += leaves[j]
+mask = (leaves >= a.min_leaves).astype(np.uint8)
+mask[0] = 1
+dist = np.random.default_rng(3).integers(0, 4, n).astype(np.uint32)
+print("tree %d nodes, %d admitted by the mask (>= %d leaves below), %d queries" % (n, int(mask.sum()), a.min_leaves, a.queries), flush=True)
+res = {}
+for label, env in (("packed", None), ("one sample per lane", "1")):
+    if env:
+        os.environ["UGP_EX_SLOW"] = env
+    else:
+        os.environ.pop("UGP_EX_SLOW", None)
+    pl = Placer(st.arrays)
+    for name, kw in (("ripples-style (mask + distance)", dict(order="bfs", node_mask=mask, distance=dist)), ("annotate-style (depth-first indices)", dict(order="dfs")),
+                     ("merge-style (root subtree, 12 levels)", dict(order="bfs", node_mask=pl.subtree_mask(0, 12)))):
+        pl.place_ex(batch, **kw)            # warm (allocations, the depth-first order and its rank)
+        t0 = time.perf_counter()
+        r = pl.place_ex(batch, **kw)
+        dt = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        tj, th, tc = pl.tied_nodes_ex(batch, 64, **kw)
+        dt2 = time.perf_counter() - t0
+        res.setdefault(name, []).append(r.copy())
+        print("%-22s %-40s place_ex %8.1f ms = %9.0f samples/s   tied_nodes_ex %8.1f ms   (packed_path=%d)" % (label, name, dt * 1e3, a.queries / dt, dt2 * 1e3, pl.timing()["packed_path"]), flush=True)
+    pl.close()
+for name, (x, y) in res.items():
+    print("%-40s identical results on both paths: %s" % (name, bool((x.view(np.int32) == y.view(np.int32)).all())))

@@ -3,6 +3,8 @@
 // See ugp_update.hpp.  Integer work, lanes = samples, record data wave-uniform.
 #include "ugp_update.hpp"
 
+#include <hipcub/hipcub.hpp>
+
 #include <climits>
 
 namespace ugp {
@@ -18,6 +20,23 @@ hipError_t launch_or_words(uint32_t *stream, const uint32_t *pos, uint32_t n, ui
     return hipGetLastError();
 }
 
+// Tie rank of an extended search: caller indices 0..n-1 sorted (stably) by a 64-bit key, worst first; rank2out[r] = caller index of
+// rank r, rank_bfs[BFS index of that node] = r (to_bfs: caller index -> BFS index, or null = the same).
+__global__ void k_iota(uint32_t *__restrict__ v, uint32_t n) { const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; if (i < n) v[i] = i; }
+__global__ void k_rank_scatter(const uint32_t *__restrict__ rank2out, const uint32_t *__restrict__ to_bfs, uint32_t n, uint32_t *__restrict__ rank_bfs) {
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < n) { const uint32_t k = rank2out[r]; rank_bfs[to_bfs ? to_bfs[k] : k] = r; }
+}
+hipError_t launch_rank_sort(void *temp, size_t *temp_bytes, const uint64_t *keys, uint64_t *keys_out, uint32_t *iota, uint32_t *rank2out, uint32_t n,
+                            const uint32_t *to_bfs, uint32_t *rank_bfs, hipStream_t s) {
+    if (!temp) return hipcub::DeviceRadixSort::SortPairs(nullptr, *temp_bytes, keys, keys_out, iota, rank2out, (int)n, 0, 64, s);
+    hipLaunchKernelGGL(k_iota, dim3((n + 255) / 256), dim3(256), 0, s, iota, n);
+    hipError_t e = hipcub::DeviceRadixSort::SortPairs(temp, *temp_bytes, keys, keys_out, iota, rank2out, (int)n, 0, 64, s);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_rank_scatter, dim3((n + 255) / 256), dim3(256), 0, s, rank2out, to_bfs, n, rank_bfs);
+    return hipGetLastError();
+}
+
 // A node mask shared by all samples of one extended search (ugp_place_opts::node_mask) as a temporary exclusion: the words of every
 // node the mask leaves out get (set != 0) or lose the "no candidate" bit.  i = index in this tree, map_j[i] = its index in the mask's
 // tree (the coarse tree of the locality pre-pass: its node's index in the full tree; null: the same).  The root is left alone.
@@ -26,6 +45,14 @@ __global__ void k_mask_words(const uint8_t *__restrict__ mask, const uint32_t *_
                              uint32_t *__restrict__ stream_t, uint32_t bit8, int set) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i == 0 || i >= n || mask[map_j ? map_j[i] : i]) return;
+    // (a node that carries a masked mutation has that bit in its packed header already -- it is never eligible -- and keeps it)
+    const bool own8 = (stream[rec[i]] & (1u << 31)) != 0;   // F_MASKED of the 32-bit record
+    if (own8) hdr8 = nullptr;
+    if (!hdr8) {
+        if (set) { stream[rec[i] + 1u] |= KEY_EXCLUDED; if (post[i] != 0xFFFFFFFFu) stream_t[post[i] + 1u] |= KEY_EXCLUDED; }
+        else { stream[rec[i] + 1u] &= ~KEY_EXCLUDED; if (post[i] != 0xFFFFFFFFu) stream_t[post[i] + 1u] &= ~KEY_EXCLUDED; }
+        return;
+    }
     if (set) {
         if (hdr8[i] != 0xFFFFFFFFu) stream8[hdr8[i]] |= bit8;
         stream[rec[i] + 1u] |= KEY_EXCLUDED;

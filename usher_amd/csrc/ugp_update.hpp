@@ -32,6 +32,9 @@ struct TouchedArgs {
 };
 
 hipError_t launch_or_words(uint32_t *stream, const uint32_t *pos, uint32_t n, uint32_t bits, hipStream_t s);
+// tie rank of an extended search by a stable device radix sort of 64-bit keys (temp == nullptr: only *temp_bytes is filled)
+hipError_t launch_rank_sort(void *temp, size_t *temp_bytes, const uint64_t *keys, uint64_t *keys_out, uint32_t *iota, uint32_t *rank2out, uint32_t n,
+                            const uint32_t *to_bfs, uint32_t *rank_bfs, hipStream_t s);
 // a node mask as a temporary exclusion (every node has one thread; each node's words are its own: plain read-modify-write)
 hipError_t launch_mask_words(const uint8_t *mask, const uint32_t *map_j, uint32_t n, const uint32_t *hdr8, const uint32_t *rec, const uint32_t *post,
                              uint32_t *stream8, uint32_t *stream, uint32_t *stream_t, uint32_t bit8 /* H_NOSCORE */, bool set, hipStream_t s);
