@@ -386,7 +386,7 @@ def main():
                     "identical_to_stream_ordered_call": same}
 
         # config 4's workload on one device: 1,000,000 queries on the 10M-node tree in one call (4 sub-batches of 262,144)
-        c4 = timed_config(pl, st, 1_000_000, 3, 1)
+        c4 = timed_config(pl, st, 1_000_000, 4, 3)   # (3 warm-up calls: every workspace set a long call cycles through is allocated before the clock starts)
         c4["workload"] = "BASELINE config 4 on one device: 1,000,000 queries on the %d-node MAT, one ugp_place_device_overlapped call per step" % info["n_nodes"]
         extra["config4_1m_queries_one_gpu"] = c4
         # the drop-in CLI end to end: the same tree as parsimony.proto, 10,000 queries as a VCF, `usher-amd -i .. -v .. -n` (load the

@@ -808,7 +808,7 @@ def test_config4_workload_one_million_queries_on_one_device(monkeypatch):
     pl = Placer(st.arrays)
     big = pl.place(batch)
     tm = pl.timing()
-    assert tm["packed_path"] == 1 and tm["place_launches"] >= 4          # (sub-batches of at most 262,144 samples; 131,072 at this tree size: the 8 GiB cap on the per-(chunk, sample) minima)
+    assert tm["packed_path"] == 1 and tm["place_launches"] >= 4          # sub-batches of at most 262,144 samples
     # the same samples in another order (each lands in another tile and, mostly, another sub-batch)
     perm = np.random.default_rng(11).permutation(Q)
     lens = np.diff(q["ent_off"].astype(np.int64))

@@ -332,9 +332,10 @@ int run_place(ugp_mat *m, ugp_qset *qs, int mode, ugp_result *d_out, int32_t *d_
         TG.coarse_timed = true;
     }
     // samples per sub-batch: at most 262,144, and few enough that the per-(chunk, sample) minima of phase 1
-    // (2 bytes each) stay below 8 GiB
+    // (2 bytes each) stay below 24 GiB (8 until round 4: 131,072 samples per launch sequence at 10M nodes; the walk does
+    // 16,384 samples' worth of work in 0.55 ms at 262,144 per launch against 0.68 at 65,536 -- 1M queries per call 20.0 -> 23.1 M/s)
     uint64_t sub_tiles = kMaxTilesPerLaunch;
-    if (m->flat.n_chunks) sub_tiles = std::min<uint64_t>(sub_tiles, std::max<uint64_t>(8, ((8ull << 30) / ((uint64_t)m->flat.n_chunks * 128)) & ~7ull));
+    if (m->flat.n_chunks) sub_tiles = std::min<uint64_t>(sub_tiles, std::max<uint64_t>(8, ((K.lbest_gib ? (uint64_t)K.lbest_gib : 24ull) << 30) / ((uint64_t)m->flat.n_chunks * 128) & ~7ull));
     for (uint64_t q0 = 0; q0 < Q; q0 += sub_tiles * 64) {
         const uint64_t nq = std::min<uint64_t>(Q - q0, sub_tiles * 64);
         if (mode == 0 && d_tie_count) m->tie_sub_batches++;
