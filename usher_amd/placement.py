@@ -295,8 +295,8 @@ class Placer:
         self._ck(self._L.ugp_place_device(self._h, qset, C.c_void_p(d_out_ptr), C.c_void_p(stream)))
 
     def place_device_overlapped(self, qset, d_out_ptr: int, stream: int = 0) -> None:
-        """ugp_place_device_overlapped: consecutive calls share the device; `stream` gets each call's completion; a call is
-        ordered behind what was on `stream` when the PREVIOUS overlapped call was made (alternate between two output buffers)."""
+        """ugp_place_device_overlapped: up to pipeline_depth() consecutive calls share the device; `stream` gets each call's completion;
+        a call is ordered behind what was on `stream` pipeline_depth() - 1 calls ago (cycle through that many output buffers)."""
         self._ck(self._L.ugp_place_device_overlapped(self._h, qset, C.c_void_p(d_out_ptr), C.c_void_p(stream)))
 
     def pipeline_depth(self) -> int:
