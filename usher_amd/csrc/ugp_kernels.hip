@@ -1657,7 +1657,8 @@ __global__ void k_coarse_result(const uint32_t *__restrict__ lbest, const uint32
 // one dword of the tile's 1 KB record.
 __global__ void k_gbest(const uint32_t *__restrict__ lbest, const uint32_t *__restrict__ list, const uint32_t *__restrict__ list_n,
                         uint32_t n_chunks, uint32_t n_tiles, uint32_t *__restrict__ part /* [gridDim.y][n_tiles*256] */) {
-    const uint32_t tile = blockIdx.x, i = tile * 256 + threadIdx.x;
+    // (one-wave blocks, four per tile: see k_descend -- a CU next to the other batches' walks has room for one more wave)
+    const uint32_t tile = blockIdx.x >> 2, i = blockIdx.x * 64 + threadIdx.x;
     const uint32_t per_chunk = n_tiles * 256;
     const uint32_t n = list_n[tile];
     const uint32_t e0 = (uint32_t)((uint64_t)blockIdx.y * n / gridDim.y), e1 = (uint32_t)((uint64_t)(blockIdx.y + 1) * n / gridDim.y);
@@ -1840,12 +1841,15 @@ constexpr uint32_t DESC_FRONTIER = 32, DESC_MAX_EXPANSIONS = 96, DESC_UP = 2;
 // A sample is served by G lanes: 16 (four samples per wave: a quarter of the waves, all resident at once, for the same
 // chain per sample) when nodes rarely have more children than that, a whole wave when the tree has large polytomies
 // (the SARS-CoV-2-shaped benchmark tree: 16 lanes cost 2.5x there).
+// (one-wave blocks since round 4: next to the persistent walks of the other batches -- 118 VGPRs, a quarter of a SIMD's register file
+// per wave -- a CU usually has room for ONE more wave, not for the four of a 256-thread block, which then waits for a whole CU)
+constexpr uint32_t DESC_BLOCK = 64;
 template <uint32_t G>
-__global__ void __launch_bounds__(256) k_descend(const ugp_result *__restrict__ coarse_res, const uint32_t *__restrict__ order, uint32_t n_queries,
+__global__ void __launch_bounds__(DESC_BLOCK) k_descend(const ugp_result *__restrict__ coarse_res, const uint32_t *__restrict__ order, uint32_t n_queries,
                           const uint32_t *__restrict__ coarse2bfs, const uint2 *__restrict__ node_pair,
                           const uint32_t *__restrict__ parent, const uint32_t *__restrict__ stream, const uint32_t *__restrict__ table, uint32_t n_sites,
                           uint32_t *__restrict__ refined, uint32_t max_expansions, int slack) {
-    constexpr uint32_t NG = 256u / G;   // samples per block
+    constexpr uint32_t NG = DESC_BLOCK / G;   // samples per block
     __shared__ uint32_t f_node[NG][DESC_FRONTIER], f_cb[NG][DESC_FRONTIER], f_ce[NG][DESC_FRONTIER];
     __shared__ int f_d[NG][DESC_FRONTIER];
     const uint32_t g = threadIdx.x / G, gl = threadIdx.x % G;       // group (sample) within the block, lane within the group
@@ -2115,7 +2119,7 @@ hipError_t launch_build_units(const uint32_t *hstart, const uint32_t *hlen, uint
 hipError_t launch_seed_ub(const ugp_result *coarse_res, const uint32_t *order, uint32_t n_queries, uint32_t n_tiles512, uint32_t *ub,
                           const uint32_t *refined, uint32_t *dbottom, uint32_t pad_d, hipStream_t s) {
     const uint32_t n_words = n_tiles512 * 256;
-    hipLaunchKernelGGL(k_seed_ub, dim3((n_words + 255) / 256), dim3(256), 0, s, coarse_res, order, n_queries, n_words, ub, refined, dbottom, pad_d);
+    hipLaunchKernelGGL(k_seed_ub, dim3((n_words + 63) / 64), dim3(64), 0, s, coarse_res, order, n_queries, n_words, ub, refined, dbottom, pad_d);
     return hipGetLastError();
 }
 
@@ -2126,10 +2130,10 @@ hipError_t launch_descend(const ugp_result *coarse_res, const uint32_t *order, u
     const uint32_t max_exp = max_expansions ? max_expansions : DESC_MAX_EXPANSIONS;   // (tuning)
     // (slack, measured at 10M nodes: 0 costs the main walk 60 %, 1..5 are alike, none is 8 % more descent)
     if (wide)
-        hipLaunchKernelGGL(k_descend<64>, dim3((n_queries + 3) / 4), dim3(256), 0, s, coarse_res, order, n_queries, coarse2bfs, (const uint2 *)node_pair, parent,
+        hipLaunchKernelGGL(k_descend<64>, dim3((n_queries + DESC_BLOCK / 64 - 1) / (DESC_BLOCK / 64)), dim3(DESC_BLOCK), 0, s, coarse_res, order, n_queries, coarse2bfs, (const uint2 *)node_pair, parent,
                            stream, table, n_sites, refined, max_exp, slack);
     else
-        hipLaunchKernelGGL(k_descend<16>, dim3((n_queries + 15) / 16), dim3(256), 0, s, coarse_res, order, n_queries, coarse2bfs, (const uint2 *)node_pair, parent,
+        hipLaunchKernelGGL(k_descend<16>, dim3((n_queries + DESC_BLOCK / 16 - 1) / (DESC_BLOCK / 16)), dim3(DESC_BLOCK), 0, s, coarse_res, order, n_queries, coarse2bfs, (const uint2 *)node_pair, parent,
                            stream, table, n_sites, refined, max_exp, slack);
     return hipGetLastError();
 }
@@ -2140,19 +2144,19 @@ hipError_t launch_locality_sort(const ugp_result *coarse_res, const uint32_t *co
     if (!temp) {   // size query
         return hipcub::DeviceRadixSort::SortPairs(nullptr, *temp_bytes, keys, keys_sorted, idx, order, (int)n, 0, 32, s);
     }
-    hipLaunchKernelGGL(k_sort_keys, dim3((n + 255) / 256), dim3(256), 0, s, coarse_res, coarse2dfs, n, keys, idx);
+    hipLaunchKernelGGL(k_sort_keys, dim3((n + 63) / 64), dim3(64), 0, s, coarse_res, coarse2dfs, n, keys, idx);
     hipError_t e = hipcub::DeviceRadixSort::SortPairs(temp, *temp_bytes, keys, keys_sorted, idx, order, (int)n, 0, 32, s);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_invert, dim3((n + 255) / 256), dim3(256), 0, s, order, n, slot_of);
+    hipLaunchKernelGGL(k_invert, dim3((n + 63) / 64), dim3(64), 0, s, order, n, slot_of);
     return hipGetLastError();
 }
 
 hipError_t launch_fill_table(uint32_t *table, const uint8_t *site_ref, uint32_t n_sites, uint64_t total_dwords,
                              hipStream_t s) {
     if (total_dwords == 0) return hipSuccess;
-    uint64_t blocks = (total_dwords / 4 + 255) / 256;   // (the table is a whole number of 64-dword rows)
-    if (blocks > 16384) blocks = 16384;
-    hipLaunchKernelGGL(k_fill_table, dim3((uint32_t)blocks), dim3(256), 0, s, table, site_ref, n_sites + TABLE_CONST_ROWS, total_dwords);
+    uint64_t blocks = (total_dwords / 4 + 63) / 64;   // (the table is a whole number of 64-dword rows; one-wave blocks: see k_descend)
+    if (blocks > 65536) blocks = 65536;
+    hipLaunchKernelGGL(k_fill_table, dim3((uint32_t)blocks), dim3(64), 0, s, table, site_ref, n_sites + TABLE_CONST_ROWS, total_dwords);
     return hipGetLastError();
 }
 
@@ -2172,8 +2176,8 @@ hipError_t launch_scatter(uint32_t *table, uint32_t *dbottom, const int32_t *pos
                           const int32_t *pos2site, uint32_t max_pos, uint32_t n_sites, uint64_t n_ent, uint32_t q_base,
                           uint32_t *active, uint32_t active_words, const uint32_t *slot_of, const unsigned long long *err, hipStream_t s) {
     if (n_ent == 0) return hipSuccess;
-    uint64_t blocks = (n_ent + 255) / 256;
-    hipLaunchKernelGGL(k_scatter_entries, dim3((uint32_t)blocks), dim3(256), 0, s, table, dbottom, pos, ref, nuc,
+    uint64_t blocks = (n_ent + 63) / 64;
+    hipLaunchKernelGGL(k_scatter_entries, dim3((uint32_t)blocks), dim3(64), 0, s, table, dbottom, pos, ref, nuc,
                        is_missing, ent_q, pos2site, max_pos, n_sites, n_ent, q_base, active, active_words, slot_of, nullptr, nullptr, 0u, err);
     return hipGetLastError();
 }
@@ -2183,7 +2187,7 @@ hipError_t launch_scatter_list(uint32_t *table, uint32_t *dbottom, const int32_t
                                const uint32_t *ent_q, const int32_t *pos2site, uint32_t max_pos, uint32_t n_sites, uint32_t q_base, uint32_t n_q,
                                uint32_t *active, uint32_t active_words, const uint32_t *slot_of, const uint32_t *row_list, const uint32_t *n_listed,
                                const unsigned long long *err, hipStream_t s) {
-    hipLaunchKernelGGL(k_scatter_entries, dim3(2048), dim3(256), 0, s, table, dbottom, pos, ref, nuc, is_missing, ent_q, pos2site, max_pos, n_sites,
+    hipLaunchKernelGGL(k_scatter_entries, dim3(8192), dim3(64), 0, s, table, dbottom, pos, ref, nuc, is_missing, ent_q, pos2site, max_pos, n_sites,
                        (uint64_t)0, q_base, active, active_words, slot_of, row_list, n_listed, n_q, err);
     return hipGetLastError();
 }
@@ -2286,7 +2290,7 @@ hipError_t launch_phase2_packed(const Best8Args &b1, const uint32_t *list, const
                                 uint32_t blocks, hipStream_t s) {
     const uint32_t per_chunk = n_tiles512 * 256;
     const uint32_t slices = std::min<uint32_t>(GBEST_SLICES, b1.n_chunks);
-    hipLaunchKernelGGL(k_gbest, dim3(n_tiles512, slices), dim3(256), 0, s, b1.lbest, list, list_n, b1.n_chunks, n_tiles512, gbest_part);
+    hipLaunchKernelGGL(k_gbest, dim3(n_tiles512 * 4, slices), dim3(64), 0, s, b1.lbest, list, list_n, b1.n_chunks, n_tiles512, gbest_part);
     hipLaunchKernelGGL(k_gbest2, dim3((per_chunk + 255) / 256), dim3(256), 0, s, gbest_part, slices, per_chunk, gbest);
     hipError_t e = hipMemsetAsync(info, 0, 128 * sizeof(uint32_t), s);
     if (e != hipSuccess) return e;
@@ -2311,10 +2315,10 @@ hipError_t launch_phase2(const PlaceArgs &a, const uint32_t *lbest, const uint32
                          const uint32_t *rank2bfs, const uint32_t *rank2out, ugp_result *out, const uint32_t *order, uint32_t max_slots, bool lists, hipStream_t s) {
     const uint32_t per_chunk = n_tiles512 * 256;
     const uint32_t slices = std::min<uint32_t>(GBEST_SLICES, a.n_chunks);
-    hipLaunchKernelGGL(k_gbest, dim3(n_tiles512, slices), dim3(256), 0, s, lbest, list, list_n, a.n_chunks, n_tiles512, gbest_part);
-    hipLaunchKernelGGL(k_gbest2, dim3((per_chunk + 255) / 256), dim3(256), 0, s, gbest_part, slices, per_chunk, gbest);
+    hipLaunchKernelGGL(k_gbest, dim3(n_tiles512 * 4, slices), dim3(64), 0, s, lbest, list, list_n, a.n_chunks, n_tiles512, gbest_part);
+    hipLaunchKernelGGL(k_gbest2, dim3((per_chunk + 63) / 64), dim3(64), 0, s, gbest_part, slices, per_chunk, gbest);
     const uint64_t pairs = (uint64_t)a.n_chunks * n_tiles512 * 8;
-    hipLaunchKernelGGL(k_select, dim3(n_tiles512, n_tiles512 < 256 ? 8 : 1), dim3(256), 0, s, lbest, list, list_n, gbest, a.n_chunks, n_tiles512, a.n_queries, items,
+    hipLaunchKernelGGL(k_select, dim3(n_tiles512, n_tiles512 < 256 ? 32 : 4), dim3(64), 0, s, lbest, list, list_n, gbest, a.n_chunks, n_tiles512, a.n_queries, items,
                        n_items, cap);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
@@ -2323,7 +2327,7 @@ hipError_t launch_phase2(const PlaceArgs &a, const uint32_t *lbest, const uint32
     if ((uint64_t)blocks > pairs) blocks = (uint32_t)pairs;
     if (lists) hipLaunchKernelGGL(k_ties<true>, dim3(blocks), dim3(64), lds, s, a, lbest, gbest, items, n_items, cap, n_tiles512 * 8, cnt, key, rank2bfs, order);
     else hipLaunchKernelGGL(k_ties<false>, dim3(blocks), dim3(64), lds, s, a, lbest, gbest, items, n_items, cap, n_tiles512 * 8, cnt, key, rank2bfs, order);
-    hipLaunchKernelGGL(k_final, dim3((a.n_queries + 255) / 256), dim3(256), 0, s, gbest, cnt, key, rank2out ? rank2out : rank2bfs, a.n_queries, out, order);
+    hipLaunchKernelGGL(k_final, dim3((a.n_queries + 63) / 64), dim3(64), 0, s, gbest, cnt, key, rank2out ? rank2out : rank2bfs, a.n_queries, out, order);
     return hipGetLastError();
 }
 
