@@ -1554,22 +1554,35 @@ __global__ void __launch_bounds__(64, TIES ? 3 : 4) k_best8(Best8Args a) {
                 const uint32_t adv = chunk - (uint32_t)__builtin_amdgcn_readfirstlane((int)mark_v);
                 asm volatile("v_mov_b32 %0, %1" : "=v"(mark_v) : "s"(chunk));
                 if (hd > tl && adv <= a.split_dense) {
-                    const uint32_t mid = chunk + (stop - chunk + 1u) / 2u;
+                    // As many pieces as waves wait (round 4; at most 63, each at least one chunk, the wave keeps the first): the unit
+                    // trace of a launch showed half of the waves idle from 60 % of its span on while a handful of dense units were
+                    // halved once per look -- a unit with 500 us of work left reached the idle waves in log2 steps of 170 us.  Lane i
+                    // writes entry i.
+                    const uint32_t R = stop - chunk;
+                    // (a.split_many = the fewest chunks a piece may have: a one-chunk piece costs its wave 105 us -- the fixed part of a
+                    // unit and a walk without the bounds its neighbours found -- where the same chunk takes 47 us inside its unit)
+                    const uint32_t cap_p = R / max(a.split_many, 1u) > 1u ? R / max(a.split_many, 1u) - 1u : 1u;
+                    const uint32_t pieces = a.split_many ? min(min(hd - tl, 63u), cap_p) : 1u;
+                    const uint32_t per = a.split_many ? max(1u, R / (pieces + 1u)) : R / 2u;   // (one piece: the second half, rounded down)
                     uint32_t slot = 0xFFFFFFFFu;
                     if (lane == 0) {
-                        atomicAdd(a.dyn_ctl + DYN_ACTIVE, 1u);   // the entry counts as live work from before it can be seen
-                        slot = atomicAdd(a.dyn_ctl + DYN_TAIL, 1u);
+                        atomicAdd(a.dyn_ctl + DYN_ACTIVE, pieces);   // the entries count as live work from before they can be seen
+                        slot = atomicAdd(a.dyn_ctl + DYN_TAIL, pieces);
                     }
                     slot = (uint32_t)__builtin_amdgcn_readfirstlane((int)slot);
-                    if (slot < a.dyn_cap) {
-                        if (lane == 0) {
-                            const unsigned long long ev = (unsigned long long)mid | ((unsigned long long)stop << 20) | ((unsigned long long)tile << 40) |
+                    const uint32_t n_ok = slot < a.dyn_cap ? min(pieces, a.dyn_cap - slot) : 0u;   // (list full: the rest is not pushed)
+                    if (n_ok) {
+                        if (lane < n_ok) {   // piece i = the i-th run of `per` chunks counted back from the unit's end
+                            const uint32_t pc1 = stop - lane * per, pc0 = pc1 - per;
+                            const unsigned long long ev = (unsigned long long)pc0 | ((unsigned long long)pc1 << 20) | ((unsigned long long)tile << 40) |
                                                           ((unsigned long long)(unit_heavy ? 1u : 0u) << 52) | ((unsigned long long)a.dyn_epoch << 53);
-                            __hip_atomic_store(a.dyn_units + slot, ev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            __hip_atomic_store(a.dyn_units + slot + lane, ev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         }
-                        asm volatile("v_mov_b32 %0, %1" : "=v"(stop_v) : "s"(mid));
-                        if (STATS) n_split++;
-                    } else if (lane == 0) atomicAdd(a.dyn_ctl + DYN_ACTIVE, 0xFFFFFFFFu);   // (list full: nothing was pushed)
+                        const uint32_t new_stop = stop - n_ok * per;
+                        asm volatile("v_mov_b32 %0, %1" : "=v"(stop_v) : "s"(new_stop));
+                        if (STATS) n_split += n_ok;
+                    }
+                    if (n_ok < pieces && lane == 0) atomicAdd(a.dyn_ctl + DYN_ACTIVE, 0u - (pieces - n_ok));
                 }
                 t_mark = (uint32_t)__builtin_amdgcn_s_memtime();
             }

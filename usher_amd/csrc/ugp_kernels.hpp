@@ -59,6 +59,7 @@ struct Best8Args {
     uint32_t no_pre_records;   // the preamble replay ignores its pruning records (units longer than their jump field reaches)
     uint32_t split_heavy;      // the same for the units of the tiles' own regions (dense: both halves are real work)
     uint32_t split_dense;      // ... and only a unit that closed at most this many chunks since its last look is cut
+    uint32_t split_many;       // != 0: a cut hands out as many pieces as waves wait (up to 63), each of at least this many chunks; 0: one half
     uint32_t split_cycles;     // a unit running longer than this hands half of its remainder to the shared list when waves wait for work (0xFFFFFFFF: never)
     uint32_t ub_every;         // exchange the shared upper bounds at every ub_every-th chunk end
     uint32_t refill_all_rows;  // experiment (UGP_REFILL_ALL): a refill fetches the real row of every word of its first group
