@@ -559,6 +559,96 @@ def test_add_mode_with_the_edits_on_the_device_equals_per_sample_research(tmp_pa
     assert sum(1 for l in want["placement_stats.tsv"].splitlines() if l.split("\t")[2] != "1") > 5      # ties were exercised
 
 
+@pytest.mark.parametrize("seed", [21, 22])
+def test_add_mode_on_the_device_with_host_searched_samples_in_front_of_the_first_batch(tmp_path, monkeypatch, seed):
+    """Samples whose rows are out of order are searched on the host (the reference's scans depend on the order); when they come in
+    front of the first batch, their insertions are part of the one flattening -- not edits of it -- and the leaf counts used by the
+    tie-break must not count them twice.  Mixed list (out-of-order and ordinary samples) against the per-sample re-search and the model."""
+    import numpy as np
+    from tests import usher_model
+    from tests.host_harness import OracleBackend
+    rng = np.random.default_rng(seed)
+    nh, old, new = str(tmp_path / "t.nh"), str(tmp_path / "old.vcf"), str(tmp_path / "new.vcf")
+    _evolve_vcf(rng, 80, 60, 70, nh, old, new)
+    pb = str(tmp_path / "base.pb")
+    assert run_usher(["-t", nh, "-v", old, "-o", pb, "-d", str(tmp_path)]) == 0
+    lines = open(new).read().splitlines()
+    head = [l for l in lines if l.startswith("#")]
+    body = [l for l in lines if not l.startswith("#")]
+    # move late rows that the first samples carry to the top: those samples become out of order, most others stay ordinary
+    moved = [l for l in body[len(body) // 2:] if l.split("\t")[9] != "0"][:3]
+    assert moved
+    body = moved + [l for l in body if l not in moved]
+    odd_vcf = str(tmp_path / "odd.vcf")
+    open(odd_vcf, "w").write("\n".join(head + body) + "\n")
+    T = refio.load_mutation_annotated_tree(pb)
+    missing = refio.read_vcf(T, odd_vcf)
+    is_odd = [any(b.position <= a.position for a, b in zip(m.mutations, m.mutations[1:])) for m in missing]
+    assert is_odd[0] and not all(is_odd) and sum(is_odd) >= 3
+    outs = {}
+    for mode in ("research", "device"):
+        for k in ("USHER_AMD_MAX_TOUCHED", "USHER_AMD_BATCH", "USHER_AMD_ROUND"):
+            monkeypatch.delenv(k, raising=False)
+        if mode == "research":
+            monkeypatch.setenv("USHER_AMD_MAX_TOUCHED", "0")
+        else:
+            monkeypatch.setenv("USHER_AMD_BATCH", "16")
+            monkeypatch.setenv("USHER_AMD_ROUND", "4")
+        d = tmp_path / mode
+        d.mkdir()
+        be = OracleBackend(add_mode=(mode == "device"))
+        assert run_usher(["-i", pb, "-v", odd_vcf, "-u", "-d", str(d)], backend=be) == 0
+        outs[mode] = {n: _read(str(d / n)) for n in ("placement_stats.tsv", "mutation-paths.txt", "uncondensed-final-tree.nh")}
+    assert outs["device"] == outs["research"]
+    T2 = refio.load_mutation_annotated_tree(pb)
+    want = usher_model.run(T2, refio.read_vcf(T2, odd_vcf))
+    for n in ("placement_stats.tsv", "mutation-paths.txt"):
+        assert outs["device"][n] == want[n], n
+
+
+def test_add_mode_on_the_device_counts_leaves_added_in_front_of_the_flattening_once(tmp_path, monkeypatch):
+    """Targeted: A = {a1, a2} (mutation m1) and B = {b1, b2, b3} (m2).  The first sample (its last two rows out of order -> searched
+    and inserted on the host before the one flattening) lands below A: A and B now hold 3 leaves each.  The second sample {m1, m2}
+    ties between A and B, and the tie-break compares the sizes of the two subtrees (usher_mapper.cpp:455-494): counting the first
+    sample's leaf both in the flattening and in the driver's "leaves added since" table makes A look larger than B and flips the
+    choice.  Outputs equal the per-sample re-search and tests/usher_model.py."""
+    from tests import usher_model
+    from tests.host_harness import OracleBackend
+    site = {"m1": 100, "m2": 110, "x1": 120, "x2": 130, "y1": 140, "y2": 150, "y3": 160, "z": 170, "o": 180, "w": 190}
+    def write(path, names, alts_of, order):
+        with open(path, "w") as f:
+            f.write("##fileformat=VCFv4.2\n#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\t" + "\t".join(names) + "\n")
+            for k in order:
+                f.write("chr\t%d\t.\tA\tC\t.\t.\t.\tGT\t%s\n" % (site[k], "\t".join("1" if k in alts_of[n] else "0" for n in names)))
+    nh, old, new = str(tmp_path / "t.nh"), str(tmp_path / "old.vcf"), str(tmp_path / "new.vcf")
+    open(nh, "w").write("((a1,a2),(b1,b2,b3),OUT);\n")
+    in_order = sorted(site, key=lambda k: site[k])
+    write(old, ["a1", "a2", "b1", "b2", "b3", "OUT"], {"a1": {"m1", "x1"}, "a2": {"m1", "x2"}, "b1": {"m2", "y1"}, "b2": {"m2", "y2"},
+                                                        "b3": {"m2", "y3"}, "OUT": {"o"}}, in_order)
+    write(new, ["O", "S"], {"O": {"m1", "z", "w"}, "S": {"m1", "m2"}}, [k for k in in_order if k not in "zw"] + ["w", "z"])
+    pb = str(tmp_path / "base.pb")
+    assert run_usher(["-t", nh, "-v", old, "-o", pb, "-d", str(tmp_path)]) == 0
+    outs = {}
+    for mode in ("research", "device"):
+        for k in ("USHER_AMD_MAX_TOUCHED", "USHER_AMD_BATCH", "USHER_AMD_ROUND"):
+            monkeypatch.delenv(k, raising=False)
+        if mode == "research":
+            monkeypatch.setenv("USHER_AMD_MAX_TOUCHED", "0")
+        d = tmp_path / mode
+        d.mkdir()
+        be = OracleBackend(add_mode=(mode == "device"))
+        assert run_usher(["-i", pb, "-v", new, "-u", "-d", str(d)], backend=be) == 0
+        outs[mode] = {n: _read(str(d / n)) for n in ("placement_stats.tsv", "mutation-paths.txt", "uncondensed-final-tree.nh")}
+        if mode == "device":
+            assert be.stat["open"] == 1            # one batch: the second sample; the first went through the host search
+    assert outs["device"] == outs["research"]
+    T = refio.load_mutation_annotated_tree(pb)
+    want = usher_model.run(T, refio.read_vcf(T, new))
+    assert want["placement_stats.tsv"].splitlines()[1].split("\t")[2] == "2"        # the tie was there
+    assert outs["device"]["placement_stats.tsv"] == want["placement_stats.tsv"]
+    assert outs["device"]["mutation-paths.txt"] == want["mutation-paths.txt"]
+
+
 @pytest.mark.parametrize("tcap", [None, "1"])
 def test_add_mode_asks_again_when_the_holders_of_a_minimum_were_rewritten(tmp_path, monkeypatch, capfd, tcap):
     """The three "ask again" paths of the device add mode, on a tree built to need them.  K leaves with branch {a, b, c} each.

@@ -1051,6 +1051,10 @@ int run_usher(const Options &opt, Tree &T, std::vector<MissingSample> &missing, 
                 prof.build += std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count() - t0; prof.flats++;
                 flat_version_dev = tree_version;
                 dev.flat_done = true;
+                // (samples searched on the host in front of the first batch -- rows out of order -- have been inserted already: their
+                // nodes are part of this flattening, not edits of it)
+                added_leaves.clear(); tcache.info.clear();
+                dev.pending.clear(); dev.pending_set.clear(); dev.pending_retired.clear(); dev.since_batch.clear();
             }
             dev.base = ii; dev.len = 0;           // (no batch is open while the pending records go up)
             if (dev.flat_done && dev.n_batches && !dev_flush(ii)) return false;
