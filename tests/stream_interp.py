@@ -238,12 +238,21 @@ def best8_group(flat, nib, dbot, c0, c1, ub=None, stats=None, use_pre_records=Tr
                     chunk += 1
                     continue
                 hdr = w
-                if w & H_SLOW:          # cold slot (beyond the LDS-resident ones)
+                # words of this node: a node with more than 15 of them overflows the kernel's 4-bit counters and takes the general step
+                n_mut = 0
+                if not (w & H_END):
+                    k = i + 1
+                    while not (int(words[k]) & M_END):
+                        k += 1
+                    n_mut = k - i
+                hdr_slow = bool(w & H_SLOW)
+                if w & H_SLOW:          # cold slot (beyond the LDS-resident ones), or a long node
                     rs, ws = (w >> H_RSLOT_SHIFT) & 63, (w >> H_WSLOT_SHIFT) & 63
-                    assert (not (w & H_REG) and rs >= flat.lds_slots) or ((w & H_STORE) and ws >= flat.lds_slots)
+                    assert (not (w & H_REG) and rs >= flat.lds_slots) or ((w & H_STORE) and ws >= flat.lds_slots) or n_mut > 15
                 else:
                     assert (w & H_REG) or ((w >> H_RSLOT_SHIFT) & 63) < flat.lds_slots
                     assert not (w & H_STORE) or ((w >> H_WSLOT_SHIFT) & 63) < flat.lds_slots
+                    assert n_mut <= 15
                 dpar, bpar = (dcur, bcur) if w & H_REG else slots[(w >> H_RSLOT_SHIFT) & 63]
                 if sinfo is not None:   # sibling record: skip this child and the non-last siblings after it?
                     rec, jump = sinfo, sinfo & INFO_JUMP_MASK
@@ -274,6 +283,7 @@ def best8_group(flat, nib, dbot, c0, c1, ub=None, stats=None, use_pre_records=Tr
                 accPB += p & r
                 accCB += c & r
                 if w & M_FLUSH:
+                    assert hdr_slow     # (the pipelined loop of k_best8 has no spill code: only the general step handles M_FLUSH)
                     carryD = ((carryD if flushed else 0) + accP - accC) & U16
                     carryN = ((carryN if flushed else 0) + accN) & U16
                     carryC = ((carryC if flushed else 0) + accC) & U16

@@ -35,7 +35,7 @@ namespace ugp {
 // flags below; pruning records {E_INFO, hs [29:22], E_SIB, hr [20:18], jump [17:0]}.  finalize8() converts to the
 // layout of ugp_flatten.hpp.
 namespace {
-constexpr uint32_t E_SKIPD = 1u << 12, E_NOSCORE = 1u << 13, E_END = 1u << 16, E_FREE = 1u << 17, E_CHUNK_END = 1u << 18,
+constexpr uint32_t E_SKIPD = 1u << 12, E_NOSCORE = 1u << 13, E_LONG = 1u << 14, E_END = 1u << 16, E_FREE = 1u << 17, E_CHUNK_END = 1u << 18,
                    E_NOP = 1u << 19, E_SIB = 1u << 21, E_INFO = 1u << 30;
 
 inline int nuc_index(uint8_t onehot) {
@@ -504,6 +504,7 @@ int flatten(const ugp_tree_desc &t, const Options &opt, FlatMat &out, std::strin
         if (eff_children[j] == 0 && !root) h |= E_SKIPD;
         if (preamble || root || node_masked[j]) h |= E_NOSCORE;
         if (nwords == 0) h |= E_END;
+        if (nwords > 15) h |= E_LONG;   // (the 4-bit counters of k_best8 overflow: the node takes the general step, which spills them at every M_FLUSH)
         if (!root && nch > 0 && nwords == 0 && !node_masked[j]) h |= E_FREE;
         uint32_t n = 0;
         dst[n++] = h;
@@ -758,7 +759,7 @@ int flatten(const ugp_tree_desc &t, const Options &opt, FlatMat &out, std::strin
                     if (w & E_NOP) { w = H_TAG | H_RARE | H_NOP; continue; }
                     uint32_t rs = w & 63u, ws = (w >> 6) & 63u;
                     uint32_t h = H_TAG;
-                    bool slow = false;
+                    bool slow = (w & E_LONG) != 0;
                     if (rs == RS_REG) h |= H_REG;
                     else { rs = remap[rs]; h |= rs << H_RSLOT_SHIFT; slow |= rs >= hot; }
                     if (ws != WS_NONE) { ws = remap[ws]; h |= H_STORE | (ws << H_WSLOT_SHIFT); slow |= ws >= hot; }

@@ -60,7 +60,8 @@ constexpr uint32_t T_PRUNE_MIN_DWORDS = 24;  // subtrees shorter than this are n
 //       H_FREE    every sample is eligible (internal node without mutations)
 //       H_SKIPD   D(node) is not needed (no effective children); informational -- computing it anyway is harmless
 //       H_RARE    the word leaves the fast path: a pruning record, a chunk end, padding, or a header that
-//                 needs the general code (H_SLOW: one of its slots is not among the LDS-resident ones)
+//                 needs the general code (H_SLOW: one of its slots is not among the LDS-resident ones, or the
+//                 node has more than 15 mutation words)
 //       H_CHUNK_END (with H_RARE) closes a chunk: publish the chunk-local minimum and reset;
 //                 [28:10] = words of the chunk that follows, its own end word included (0: none / does not fit)
 //       H_NOP     (with H_RARE) padding
@@ -95,7 +96,7 @@ constexpr uint32_t T_PRUNE_MIN_DWORDS = 24;  // subtrees shorter than this are n
 //     D(root): cost(root) = D(root), always eligible (usher_mapper.cpp:454).
 //   MUT word (bit 31 clear):
 //       [21:0] site  [23:22] mutated allele  [25:24] parent-state allele  [27:26] reference allele
-//       M_FLUSH  15 mutations accumulated in the 4-bit counters: spill them
+//       M_FLUSH  15 mutations accumulated in the 4-bit counters: spill them (only in nodes whose header is H_SLOW)
 //       M_END    last mutation word of the node
 constexpr uint32_t H_TAG = 1u << 31, H_INFO = 1u << 30, H_RARE = 1u << 29, H_SIB = 1u << 21;
 constexpr uint32_t H_REG = 1u << 0, H_STORE = 1u << 1, H_NOSCORE = 1u << 2, H_END = 1u << 3, H_FREE = 1u << 4,
@@ -110,7 +111,10 @@ constexpr uint32_t INFO_HR_SHIFT = 18, INFO_HR_NONE = 7;   // hrev field; 7 = no
 // When the record's test holds during the replay, the rest of the preamble and the body up to that position are skipped.
 constexpr uint32_t PRE_HS_NONE = 127;
 constexpr uint32_t PRUNE_MIN_WORDS = 4;     // only subtrees at least this long carry a pruning record
-constexpr uint32_t MAX_HOT_SLOTS = 16;      // the B halves of the hot slots are two 16-element register vectors in k_best8
+#ifndef UGP_HOT_SLOTS
+#define UGP_HOT_SLOTS 16
+#endif
+constexpr uint32_t MAX_HOT_SLOTS = UGP_HOT_SLOTS;      // the B halves of the hot slots are two register vectors of this many elements in k_best8 (8 or 16)
 constexpr uint32_t LDS_SLOTS = 9;           // saved (D, B) slots k_best8 keeps in LDS (1.5 KB each per wave); the colder ones live in a global scratch
 constexpr uint32_t M_FLUSH = 1u << 28, M_END = 1u << 30;
 constexpr uint32_t MAX_SITES = 1u << 22;

@@ -44,6 +44,9 @@ typedef unsigned short us2 __attribute__((ext_vector_type(2)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 typedef uint32_t u32x16 __attribute__((ext_vector_type(16)));
+typedef uint32_t u32xhot __attribute__((ext_vector_type(UGP_HOT_SLOTS)));   // one element per hot slot
+constexpr uint32_t HOT_MASK = UGP_HOT_SLOTS - 1u;
+static_assert(UGP_HOT_SLOTS == 8 || UGP_HOT_SLOTS == 16, "hot slots: 8 or 16");
 
 __device__ __forceinline__ uint32_t pk_add(uint32_t a, uint32_t b) {
     return __builtin_bit_cast(uint32_t, __builtin_bit_cast(us2, a) + __builtin_bit_cast(us2, b));
@@ -829,7 +832,8 @@ __global__ void __launch_bounds__(1024) k_scores_level(const uint2 *__restrict__
 
 struct Pk4 { uint32_t v[4]; };
 #ifndef UGP_GRP
-#define UGP_GRP 8
+#define UGP_GRP 16   // (8 until round 4: with the long-node carries out of the loop there is room for 16 rows in flight -- 106 -> 114 VGPRs;
+                     //  the walk alone 1.16 -> 1.14 ms at 10M nodes, 1.44 -> 1.34 on the SARS-CoV-2 shape, 1.08 -> 0.93 with 10,000 samples)
 #endif
 constexpr uint32_t GRP = UGP_GRP;   // stream words per pipeline group (= unroll factor of the walk)
 constexpr uint32_t DYN_HEAD = 0, DYN_TAIL = 1, DYN_ACTIVE = 32;   // dyn_ctl: tickets taken / entries pushed (one line), live work (another)
@@ -989,9 +993,13 @@ __global__ void __launch_bounds__(64, TIES ? 3 : 4) k_best8(Best8Args a) {
         irr.v[0] = pk_min(lb.x ^ gb.x, 0x00010001u) << 15; irr.v[1] = pk_min(lb.y ^ gb.y, 0x00010001u) << 15;
         irr.v[2] = pk_min(lb.z ^ gb.z, 0x00010001u) << 15; irr.v[3] = pk_min(lb.w ^ gb.w, 0x00010001u) << 15;
     }
-    Pk4 best, dcur, dpar, carryD, carryN, carryC;
+    Pk4 best, dcur, dpar;
 #pragma unroll
-    for (int j = 0; j < 4; j++) { best.v[j] = 0xFFFFFFFFu; dcur.v[j] = dbot.v[j]; dpar.v[j] = 0; carryD.v[j] = 0; carryN.v[j] = 0; carryC.v[j] = 0; }   // (dcur: the root reads D(bottom) as "the previous node's D")
+    for (int j = 0; j < 4; j++) { best.v[j] = 0xFFFFFFFFu; dcur.v[j] = dbot.v[j]; dpar.v[j] = 0; }   // (dcur: the root reads D(bottom) as "the previous node's D")
+    // A node with more than 15 mutation words overflows the 4-bit counters: its header carries H_SLOW, so it is walked by slow_node
+    // (outside the pipelined loop), which spills the counters into these packed carries every 15 words (M_FLUSH).  They exist only
+    // there: held across the pipelined loop they cost 14 vector registers that the loop needs for rows in flight.
+    struct Carry { Pk4 D, N, C; uint32_t B[2]; bool flushed; };
     uint32_t accP = 0, accC = 0, accN = 0;
     Pk4 bpos;                  // (ARG) per sample: position (low 16 bits) of the node that set `best`
 #pragma unroll
@@ -1023,13 +1031,12 @@ __global__ void __launch_bounds__(64, TIES ? 3 : 4) k_best8(Best8Args a) {
     // B(n, s) = the part of D at sites where the sample's set holds the reference base (second pruning bound, ugp_flatten.hpp):
     // one byte per sample (b[0]: samples 0, 2, 4, 6 of the lane, b[1]: samples 1, 3, 5, 7), saved and restored with D.
     // B(bottom) = 0: below the root every state is the reference base.
-    uint32_t bcur[2] = {0, 0}, bpar[2] = {0, 0}, carryB[2] = {0, 0};
+    uint32_t bcur[2] = {0, 0}, bpar[2] = {0, 0};
     uint32_t accPB = 0, accCB = 0;   // like accP / accC, over the samples whose set holds the site's reference base
     // The B halves of the hot slots stay in registers (indexed with the slot number, which is uniform): the kernel's occupancy
     // is set by its LDS, and 8 more bytes per lane and slot there cost a third of the resident waves; 32 registers cost none.
-    u32x16 bs0 = 0, bs1 = 0;
+    u32xhot bs0 = 0, bs1 = 0;
     uint32_t hdr = 0;          // uniform: header of the open node
-    bool flushed = false;      // uniform
     uint32_t chunk = c0;       // uniform: chunk whose body is being walked
     // The unit ends in front of chunk `stop`: c1, or less once its second half has been handed to another wave.  Kept in a
     // vector register on purpose (the same value in every lane, read back with readfirstlane at chunk ends and restarts
@@ -1193,29 +1200,26 @@ __global__ void __launch_bounds__(64, TIES ? 3 : 4) k_best8(Best8Args a) {
             }
         }
     };
-    auto node_end = [&](uint32_t pos, int cold_ws) -> bool {   // true: a pruning jump was requested (skip_to)
+    auto node_end = [&](uint32_t pos, int cold_ws, Carry *cy) -> bool {   // true: a pruning jump was requested (skip_to); cy: the carries of a long node (slow_node), else nullptr
         const uint32_t p2 = ARG ? ((pos_base + pos) & 0xFFFFu) * 0x00010001u : 0u;
         // A sample is ineligible here when it shares no mutation with the branch (common == 0,
         // usher_mapper.cpp:454-455) unless the node is "free": z has bit 4j set for such samples
         // and is turned into a 0x8000 penalty on the 16-bit cost (valid costs stay below 0x8000).
-        if (flushed) {   // node with more than 15 mutations (rare): fold the carries in
+        if (cy && cy->flushed) {   // node with more than 15 mutations (rare): fold the carries in
 #pragma unroll
-            for (int j = 0; j < 4; j++) dcur.v[j] = pk_add(pk_sub(pk_add(dpar.v[j], ex4(accP, j)), ex4(accC, j)), carryD.v[j]);
+            for (int j = 0; j < 4; j++) dcur.v[j] = pk_add(pk_sub(pk_add(dpar.v[j], ex4(accP, j)), ex4(accC, j)), cy->D.v[j]);
 #pragma unroll
-            for (int i = 0; i < 2; i++) { bcur[i] = bpar[i] + ex8(accPB, i) - ex8(accCB, i) + carryB[i]; carryB[i] = 0; }
+            for (int i = 0; i < 2; i++) bcur[i] = bpar[i] + ex8(accPB, i) - ex8(accCB, i) + cy->B[i];
             if (!(hdr & H_NOSCORE)) {
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
-                    const uint32_t cost = pk_sub(pk_sub(dpar.v[j], ex4(accN, j)), carryN.v[j]);
-                    const uint32_t common = pk_add(ex4(accC, j), carryC.v[j]);
+                    const uint32_t cost = pk_sub(pk_sub(dpar.v[j], ex4(accN, j)), cy->N.v[j]);
+                    const uint32_t common = pk_add(ex4(accC, j), cy->C.v[j]);
                     uint32_t pen = 0;
                     if (!(hdr & H_FREE)) pen = (((common & 0xFFFFu) ? 0u : 0x8000u) | ((common >> 16) ? 0u : 0x80000000u));
                     take_min(j, cost | pen, p2);
                 }
             }
-#pragma unroll
-            for (int j = 0; j < 4; j++) { carryD.v[j] = 0; carryN.v[j] = 0; carryC.v[j] = 0; }
-            flushed = false;
         } else {
             if (!(hdr & H_SKIPD)) {
 #pragma unroll
@@ -1241,7 +1245,7 @@ __global__ void __launch_bounds__(64, TIES ? 3 : 4) k_best8(Best8Args a) {
             if (cold_ws >= 0) { *(glb_row *)(coldp + (uint64_t)cold_ws * 512) = v; *(glb_row2 *)(coldp + (uint64_t)cold_ws * 512 + 4) = vb; }
             else {
                 *lds_at(((hdr >> (H_WSLOT_SHIFT - 10)) & (63u << 10)) | lane16) = v;
-                const uint32_t wsi = (hdr >> H_WSLOT_SHIFT) & 15u;
+                const uint32_t wsi = (hdr >> H_WSLOT_SHIFT) & HOT_MASK;
                 bs0[wsi] = vb.x; bs1[wsi] = vb.y;
             }
         }
@@ -1273,18 +1277,18 @@ __global__ void __launch_bounds__(64, TIES ? 3 : 4) k_best8(Best8Args a) {
         if (TIES && tie_here) { skip_to = pos + 1; return true; }   // (the walk goes on behind the node once the tie has been booked)
         return false;
     };
-    auto flush_acc = [&]() {   // 15 mutations in the 4-bit counters: spill to the packed carries (rare)
+    auto flush_acc = [&](Carry &cy) {   // 15 mutations in the 4-bit counters: spill to the packed carries (slow_node only)
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             const uint32_t eP = ex4(accP, j), eC = ex4(accC, j), eN = ex4(accN, j);
-            carryD.v[j] = pk_sub(pk_add(carryD.v[j], eP), eC);   // carries are zero outside a long node
-            carryN.v[j] = pk_add(carryN.v[j], eN);
-            carryC.v[j] = pk_add(carryC.v[j], eC);
+            cy.D.v[j] = pk_sub(pk_add(cy.D.v[j], eP), eC);
+            cy.N.v[j] = pk_add(cy.N.v[j], eN);
+            cy.C.v[j] = pk_add(cy.C.v[j], eC);
         }
 #pragma unroll
-        for (int i = 0; i < 2; i++) carryB[i] += ex8(accPB, i) - ex8(accCB, i);   // (bytes may borrow from each other here: the node's total is exact)
+        for (int i = 0; i < 2; i++) cy.B[i] += ex8(accPB, i) - ex8(accCB, i);   // (bytes may borrow from each other here: the node's total is exact)
         accP = accC = accN = accPB = accCB = 0;
-        flushed = true;
+        cy.flushed = true;
     };
     // sibling record waiting at a header: can this child and the non-last siblings after it all be skipped?
     auto sibling_test = [&](uint32_t pos) -> bool {
@@ -1340,13 +1344,17 @@ __global__ void __launch_bounds__(64, TIES ? 3 : 4) k_best8(Best8Args a) {
             u32x4 t;   // (two loads, not one through a selected pointer: that would be a FLAT access, whose out-of-order return makes every later wait a wait for everything)
             u32x2 tb;
             if (rs >= a.lds_slots) { t = *(const glb_row *)(coldp + (uint64_t)(rs - a.lds_slots) * 512); tb = *(const glb_row2 *)(coldp + (uint64_t)(rs - a.lds_slots) * 512 + 4); }
-            else { t = *lds_at(rs * 1024u + lane16); tb.x = bs0[rs & 15u]; tb.y = bs1[rs & 15u]; }
+            else { t = *lds_at(rs * 1024u + lane16); tb.x = bs0[rs & HOT_MASK]; tb.y = bs1[rs & HOT_MASK]; }
             dpar.v[0] = t.x; dpar.v[1] = t.y; dpar.v[2] = t.z; dpar.v[3] = t.w;
             bpar[0] = tb.x; bpar[1] = tb.y;
         }
         const int cold_ws = ((w & H_STORE) && ws >= a.lds_slots) ? (int)(ws - a.lds_slots) : -1;
         if (have_sinfo && sibling_test(p)) return p + 1;
         p++;
+        Carry cy;
+#pragma unroll
+        for (int j = 0; j < 4; j++) { cy.D.v[j] = 0; cy.N.v[j] = 0; cy.C.v[j] = 0; }
+        cy.B[0] = cy.B[1] = 0; cy.flushed = false;
         if (!(w & H_END)) {
             for (;;) {
                 const uint32_t m = (uint32_t)__builtin_amdgcn_readfirstlane((int)sp[p]);
@@ -1357,10 +1365,10 @@ __global__ void __launch_bounds__(64, TIES ? 3 : 4) k_best8(Best8Args a) {
                 if (TIES) accU |= ~C & 0x11111111u;
                 p++;
                 if (m & M_END) break;
-                if (m & M_FLUSH) flush_acc();
+                if (m & M_FLUSH) flush_acc(cy);
             }
         }
-        node_end(p - 1, cold_ws);
+        node_end(p - 1, cold_ws, &cy);
         return p;
     };
 
@@ -1439,7 +1447,7 @@ __global__ void __launch_bounds__(64, TIES ? 3 : 4) k_best8(Best8Args a) {
                     bpar[0] = bcur[0]; bpar[1] = bcur[1];
                 } else {
                     const u32x4 t = *lds_at((w & (63u << H_RSLOT_SHIFT)) | lane16);
-                    const uint32_t rsi = (w >> H_RSLOT_SHIFT) & 15u;
+                    const uint32_t rsi = (w >> H_RSLOT_SHIFT) & HOT_MASK;
                     dpar.v[0] = t.x; dpar.v[1] = t.y; dpar.v[2] = t.z; dpar.v[3] = t.w;
                     bpar[0] = bs0[rsi]; bpar[1] = bs1[rsi];
                 }
@@ -1450,12 +1458,9 @@ __global__ void __launch_bounds__(64, TIES ? 3 : 4) k_best8(Best8Args a) {
                 const uint32_t C = (x >> mi) & 0x11111111u, P = (x >> pi) & 0x11111111u, R = (x >> ri) & 0x11111111u;
                 accP += P; accC += C; accN += C & ~P; accPB += P & R; accCB += C & R;
                 if (TIES) accU |= ~C & 0x11111111u;
-                if (!(w & M_END)) {
-                    if (w & M_FLUSH) flush_acc();
-                    return false;
-                }
+                if (!(w & M_END)) return false;   // (a node with an M_FLUSH word never gets here: its header is H_SLOW)
             }
-            return node_end(pos, -1);
+            return node_end(pos, -1, nullptr);
         };
         uint32_t off = 0;
         if (phase == 1 && body_start) {   // the replay ended at a path node whose subtree is not needed: close the chunks in front of its end
@@ -1481,6 +1486,10 @@ __global__ void __launch_bounds__(64, TIES ? 3 : 4) k_best8(Best8Args a) {
             if (STATS) { t_restart += __builtin_amdgcn_s_memtime() - t_r0 + (X[0] & 0u); n_restart++; run_nodes = 0; }
             bool first = true;   // uniform: still inside the first group of this run
             bool hit = false;    // uniform: a step asked for a restart
+            // (Tried in round 4 and removed: taking a short pruning jump -- a third of all jumps lead to a word that is already in
+            // registers -- without a restart, by overwriting the skipped words with padding.  213k of 690k restarts per launch went
+            // away and the launch did not get faster: a short jump's restart hits the lines its words came from, it was never one of
+            // the expensive ones, and the extra code in the unrolled steps cost 6 % by itself.)
             if (cautious) {
                 // Sparse regime (runs of a few words between jumps): evaluate the first group before
                 // anything is requested for the second one, so a jump does not leave eight dead row loads
