@@ -197,3 +197,63 @@ def test_extended_searches_on_the_packed_pruned_path(monkeypatch):
             assert int(ca[i]) == w["num_best"] and ta[i].tolist() == w["ties"].tolist() and ha[i].tolist() == w["ties_has_unique"].tolist(), (name, i)
         assert (fast.place(batch).view(np.int32) == plain.view(np.int32)).all(), name        # the mask is gone again
     fast.close(); slow.close()
+
+
+@pytest.mark.parametrize("seed", [5, 6])
+def test_self_exclusion_on_the_packed_pruned_path(seed, monkeypatch):
+    """Round 4: a search that leaves one node out per sample (matUtils uncertainty: a sample is never mapped onto its own node,
+    uncertainty.cpp:216) runs on the packed, pruned path too: bounds that never rely on the excluded node (seeds that skip it, no
+    tightening from chunk minima), then the one chunk minimum it may have set is recomputed without it, and phase 2 leaves it out of
+    the ties.  Samples = the mutation sets of tree nodes -- leaves, internal nodes, nodes of the coarse tree of the locality pre-pass --
+    with their own node left out, some with nothing left out, plus ordinary queries with a random node left out; depth-first
+    indices, and once with a node mask and a distance on top.  packed == one sample per lane (UGP_EX_SLOW=1) == the oracle."""
+    monkeypatch.setenv("UGP_COARSE_MIN_NODES", "0")
+    monkeypatch.delenv("UGP_EX_SLOW", raising=False)
+    arrays, queries = synth.make_case(880 + seed, n_leaves=2600, n_queries=260, n_sites=150, n_ambig=(0, 0, 2), p_masked=0.01 if seed == 6 else 0.0)
+    n = arrays["n"]
+    ot = capi.OracleTree(arrays)
+    fast = Placer(arrays, chunk_nodes=48)
+    monkeypatch.setenv("UGP_EX_SLOW", "1")
+    slow = Placer(arrays, chunk_nodes=48)
+    monkeypatch.delenv("UGP_EX_SLOW")
+    rng = np.random.default_rng(seed)
+    dfs = fast.node_order("dfs").astype(np.int64)
+    pos_of = np.empty(n, np.int64); pos_of[dfs] = np.arange(n)
+    size = np.ones(n, np.int64)
+    for j in range(n - 1, 0, -1):
+        size[arrays["parent"][j]] += size[j]
+    big = np.argsort(-size)[1:40]                                   # the top of the tree: nodes of the coarse tree
+    picks = np.concatenate([rng.choice(np.arange(1, n), 420, replace=False), big])
+    samples = [_node_sample(arrays, None, int(j), "n%d" % j) for j in picks] + list(queries)
+    skip_bfs = np.concatenate([picks, rng.integers(0, n, len(queries))]).astype(np.int64)
+    none = rng.random(len(samples)) < 0.1
+    batch = QueryBatch(samples)
+    assert len(samples) > 512
+    leaves_below = np.array([ot.num_leaves(j) for j in range(n)])
+    m_leaves = (leaves_below >= 2).astype(np.uint8); m_leaves[0] = 1
+    dist = rng.integers(0, 2, n).astype(np.uint32)
+    root_muts = int(arrays["mut_off"][1])
+    for name, kw, order_nodes in (("dfs", dict(order="dfs"), dfs), ("bfs+mask+distance", dict(order="bfs", node_mask=m_leaves, distance=dist), np.arange(n))):
+        idx_of = pos_of if name == "dfs" else np.arange(n)
+        skip = np.where(none, 0xFFFFFFFF, idx_of[skip_bfs]).astype(np.uint32)
+        a = fast.place_ex(batch, skip_node=skip, **kw)
+        assert fast.timing()["packed_path"] == 1, name
+        b = slow.place_ex(batch, skip_node=skip, **kw)
+        assert slow.timing()["packed_path"] == 0, name
+        bad = np.flatnonzero((a.view(np.int32) != b.view(np.int32)).reshape(len(samples), -1).any(axis=1))
+        assert len(bad) == 0, (name, bad[:10], a[bad[:3]], b[bad[:3]])
+        ta, ha, ca = fast.tied_nodes_ex(batch, 128, skip_node=skip, **kw)
+        tb, hb, cb = slow.tied_nodes_ex(batch, 128, skip_node=skip, **kw)
+        assert (ca == cb).all() and all(x.tolist() == y.tolist() for x, y in zip(ta, tb)) and all(x.tolist() == y.tolist() for x, y in zip(ha, hb)), name
+        for i in list(range(0, len(samples), 9)) + list(range(420, 459)):
+            keep = np.ones(n, bool)
+            if not none[i]:
+                keep[idx_of[skip_bfs[i]]] = False
+            if "node_mask" in kw:
+                keep &= m_leaves[order_nodes].astype(bool)
+            nodes = order_nodes[keep]
+            w = ot.place_list(samples[i], nodes, jidx=np.arange(n)[keep], distance=dist[nodes] if "distance" in kw else None,
+                              init_best=len(samples[i]["pos"]) + root_muts + 1)
+            _same(a, i, w)
+            assert int(ca[i]) == w["num_best"] and ta[i].tolist() == w["ties"][:128].tolist(), (name, i)
+    fast.close(); slow.close()

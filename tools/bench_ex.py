@@ -20,7 +20,7 @@ ap.add_argument("--min-leaves", type=int, default=10)
 a = ap.parse_args()
 st = synth.SynthTree(a.nodes, n_sites=25000 if a.nodes >= 1_000_000 else 1500, seed=1)
 q = st.queries(a.queries, seed=77)
-batch = QueryBatch.from_csr(q["ent_off"], q["pos"], q["ref"], q["nuc"], q["is_missing"])
+batch_q = QueryBatch.from_csr(q["ent_off"], q["pos"], q["ref"], q["nuc"], q["is_missing"])
 par = np.asarray(st.arrays["parent"]).astype(np.int64)
 n = int(st.arrays["n"])
 leaves = np.zeros(n, np.int64)
@@ -33,6 +33,10 @@ mask = (leaves >= a.min_leaves).astype(np.uint8)
 mask[0] = 1
 dist = np.random.default_rng(3).integers(0, 4, n).astype(np.uint32)
 print("tree %d nodes, %d admitted by the mask (>= %d leaves below), %d queries" % (n, int(mask.sum()), a.min_leaves, a.queries), flush=True)
+# uncertainty-style: every sample is the mutation set of a tree node, and that node is left out of its search (uncertainty.cpp:216)
+q_own = st.queries(a.queries, seed=78, max_subst=0)
+batch_own = QueryBatch.from_csr(q_own["ent_off"], q_own["pos"], q_own["ref"], q_own["nuc"], q_own["is_missing"])
+own = np.asarray(q_own["source"]).astype(np.int64)
 res = {}
 for label, env in (("packed", None), ("one sample per lane", "1")):
     if env:
@@ -40,8 +44,12 @@ for label, env in (("packed", None), ("one sample per lane", "1")):
     else:
         os.environ.pop("UGP_EX_SLOW", None)
     pl = Placer(st.arrays)
+    dfs = pl.node_order("dfs").astype(np.int64)
+    pos_of = np.empty(n, np.int64); pos_of[dfs] = np.arange(n)
     for name, kw in (("ripples-style (mask + distance)", dict(order="bfs", node_mask=mask, distance=dist)), ("annotate-style (depth-first indices)", dict(order="dfs")),
-                     ("merge-style (root subtree, 12 levels)", dict(order="bfs", node_mask=pl.subtree_mask(0, 12)))):
+                     ("merge-style (root subtree, 12 levels)", dict(order="bfs", node_mask=pl.subtree_mask(0, 12))),
+                     ("uncertainty-style (own node left out)", dict(order="dfs", skip_node=pos_of[own].astype(np.uint32)))):
+        batch = batch_own if "skip_node" in kw else batch_q
         pl.place_ex(batch, **kw)            # warm (allocations, the depth-first order and its rank)
         t0 = time.perf_counter()
         r = pl.place_ex(batch, **kw)

@@ -12,6 +12,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "ugp_flatten.hpp"
@@ -96,6 +97,51 @@ struct PinBuf {
     }
 };
 
+// A large device -> pageable host copy (the -p score matrix: 5 GB per 128 samples at 10M nodes) through two pinned staging buffers:
+// the DMA of piece i runs while a few host threads move piece i - 1 to its place.  A plain hipMemcpy into pageable memory reaches
+// ~21 GB/s on this platform, the link more than twice that.
+int copy_d2h_staged(void *dst, const void *src, size_t bytes) {
+    constexpr size_t kPiece = 32u << 20;
+    if (bytes < 4 * kPiece) {
+        if (bytes && hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost) != hipSuccess) return fail(UGP_ERR_HIP, "copy to the host");
+        return UGP_OK;
+    }
+    PinBuf pin[2];
+    hipStream_t st = nullptr;
+    hipEvent_t ev[2] = {nullptr, nullptr};
+    int rc = UGP_OK;
+    if (pin[0].reserve(kPiece) != UGP_OK || pin[1].reserve(kPiece) != UGP_OK) return UGP_ERR_HIP;
+    if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&ev[0], hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&ev[1], hipEventDisableTiming) != hipSuccess) rc = fail(UGP_ERR_HIP, "staged copy: stream / events");
+    const size_t n_pieces = (bytes + kPiece - 1) / kPiece;
+    const unsigned n_thr = std::max(1u, std::min(8u, std::thread::hardware_concurrency() / 2));
+    auto drain = [&](size_t i) {   // piece i: pinned -> dst, on n_thr threads
+        const size_t off = i * kPiece, n = std::min(kPiece, bytes - off);
+        const char *from = (const char *)pin[i & 1].p;
+        char *to = (char *)dst + off;
+        std::vector<std::thread> th;
+        const size_t per = ((n + n_thr - 1) / n_thr + 4095) & ~(size_t)4095;
+        for (unsigned t = 1; t < n_thr; t++)
+            if ((size_t)t * per < n) th.emplace_back([=]() { memcpy(to + (size_t)t * per, from + (size_t)t * per, std::min(per, n - (size_t)t * per)); });
+        memcpy(to, from, std::min(per, n));
+        for (auto &x : th) x.join();
+    };
+    for (size_t i = 0; i <= n_pieces && rc == UGP_OK; i++) {
+        if (i < n_pieces) {   // (buffer i & 1 was drained in iteration i - 1, as piece i - 2)
+            const size_t off = i * kPiece, n = std::min(kPiece, bytes - off);
+            if (hipMemcpyAsync(pin[i & 1].p, (const char *)src + off, n, hipMemcpyDeviceToHost, st) != hipSuccess || hipEventRecord(ev[i & 1], st) != hipSuccess)
+                rc = fail(UGP_ERR_HIP, "staged copy: hipMemcpyAsync");
+        }
+        if (i > 0 && rc == UGP_OK) {
+            if (hipEventSynchronize(ev[(i - 1) & 1]) != hipSuccess) rc = fail(UGP_ERR_HIP, "staged copy: wait");
+            else drain(i - 1);
+        }
+    }
+    if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
+    for (auto e : ev) if (e) (void)hipEventDestroy(e);
+    return rc;
+}
+
 struct EventSet {
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     bool used = false;
@@ -126,6 +172,8 @@ struct ugp_mat {
     uint32_t max_level_width = 0;
     // extended searches (ugp_place_batch_ex): host copy of the topology, the reference's depth-first order and its tie rank
     std::vector<uint32_t> h_parent, h_dfs2bfs, h_bfs2dfs, h_leaves;
+    std::vector<uint32_t> h_flat_chunk_node;   // chunk cuts by the flattener's depth-first index (host copy, with h_flat_bfs2dfs)
+    std::vector<uint32_t> h_flat_bfs2dfs;   // inverse of flat.dfs2bfs (the flattener's own depth-first order), built by the first search that leaves nodes out per sample
     DevBuf<uint32_t> d_dfs2bfs_caller;   // the reference's depth-first expansion on the device (position -> BFS index)
     DevBuf<uint32_t> d_dfs_rank, d_dfs_rank2out, d_bfs2dfs;
     bool dfs_rank_ready = false;
@@ -268,8 +316,9 @@ int ensure_events(ugp_mat::Work::Gen &G, size_t n) {
 // Device-side options of an extended search (the other callers of mapper2_body); null members = not used.
 struct ExDev {
     const uint8_t *mask = nullptr; const uint32_t *skip = nullptr, *alt_rank = nullptr, *out_index = nullptr, *rank2out = nullptr;
+    const uint32_t *skip_chunk = nullptr;   // [n_queries] with skip: the chunk of the flattened tree that holds the sample's excluded node
     int32_t *scores = nullptr;
-    bool packed = false;   // the caller has arranged for the packed path (mask turned into exclusions; no skip, no scores)
+    bool packed = false;   // the caller has arranged for the packed path (mask turned into exclusions; no scores)
 };
 
 // mode 0: results to d_out (device ugp_result[n_queries]);
@@ -311,9 +360,10 @@ int run_place(ugp_mat *m, ugp_qset *qs, int mode, ugp_result *d_out, int32_t *d_
     // a tree with a masked mutation behind an ordinary one on the same node -- never produced by the reference's
     // sorted Node::add_mutation, mutation_annotated_tree.cpp:720-752 -- needs the order-aware 32-bit walk)
     // (the extended searches take the packed path too when their options are the kind it can express: a node order / distance is a
-    // tie rank of phase 2, a node mask has been turned into exclusions by the caller; a per-sample excluded node and per-node
-    // scores stay on the one-sample-per-lane kernel)
-    const bool ex_packable = ex && ex->packed && !ex->mask && !ex->skip && !ex->scores;
+    // tie rank of phase 2, a node mask has been turned into exclusions by the caller, a per-sample excluded node is taken out of
+    // the one chunk minimum it can have set, behind phase 1 (k_fix_skip); per-node scores stay on the one-sample-per-lane kernel)
+    const bool ex_packable = ex && ex->packed && !ex->mask && (!ex->skip || ex->skip_chunk) && !ex->scores;
+    const uint32_t *const ex_skip = (ex_packable && ex->skip) ? ex->skip : nullptr;   // (caller order; + q0 per sub-batch)
     const bool packed_ok = (mode == 0) && (!ex || ex_packable) && !K.force_v1 && !f.mask_not_first && (qs->max_rows + f.max_path_muts + 2 < 0x7F7Full);
     const bool sorted = packed_ok && m->coarse && Q > 512 && !K.no_sort && !K.no_prune;
     TG.coarse_timed = false;
@@ -423,7 +473,7 @@ int run_place(ugp_mat *m, ugp_qset *qs, int mode, ugp_result *d_out, int32_t *d_
         if (use8) {   // upper bounds of best(s) the pruning starts from
 #ifdef UGP_EXPERIMENTS
             if (sorted && K.seed_prev && W.d_prev_res.cap >= Q && W.prev_serial == qs->serial)   // (experiment: bounds = the previous call's exact answers)
-                HIP_TRY(ugp::launch_seed_ub(W.d_prev_res.p + q0, order, (uint32_t)nq, n_tiles512, W.d_ub.p, nullptr, nullptr, 0, s));
+                HIP_TRY(ugp::launch_seed_ub(W.d_prev_res.p + q0, order, (uint32_t)nq, n_tiles512, W.d_ub.p, nullptr, nullptr, 0, nullptr, nullptr, s));
             else
 #endif
             if (sorted && !K.no_seed) {
@@ -435,7 +485,8 @@ int run_place(ugp_mat *m, ugp_qset *qs, int mode, ugp_result *d_out, int32_t *d_
                 if (m->d_node_pair.p && m->d_coarse2bfs.p && !K.no_descent) {
                     HIP_TRY(W.d_refined.reserve(nq));
                     HIP_TRY(ugp::launch_descend(W.d_coarse_res.p + q0, order, (uint32_t)nq, m->d_coarse2bfs.p, m->d_node_pair.p,
-                                                m->d_parent.p, m->d_stream.p, W.d_table.p, n_sites, W.d_refined.p, m->wide_descent, K.descent_max, K.descent_slack, s));
+                                                m->d_parent.p, m->d_stream.p, W.d_table.p, n_sites, W.d_refined.p, m->wide_descent, K.descent_max, K.descent_slack,
+                                                ex_skip ? ex_skip + q0 : nullptr, s));
                     refined = W.d_refined.p;
 #ifdef UGP_EXPERIMENTS
                     if (K.stats && K.seed_check && W.prev_serial == qs->serial && W.d_prev_res.cap >= Q) {   // debug: seeds against the previous call's answers
@@ -486,7 +537,7 @@ int run_place(ugp_mat *m, ugp_qset *qs, int mode, ugp_result *d_out, int32_t *d_
                 // (the unused slots of the last tile: far from everything, see k_seed_ub; 16-bit safe by the guard of the packed path)
                 const uint32_t pad_d = K.no_pad_fix ? 0u : (uint32_t)std::min<uint64_t>(4096, 0x7F7Eu - 2u - std::min<uint64_t>(f.max_path_muts, 0x7F00u));
                 HIP_TRY(ugp::launch_seed_ub(W.d_coarse_res.p + q0, order, (uint32_t)nq, n_tiles512, W.d_ub.p, refined,
-                                            K.no_pad_fix ? nullptr : d_dbottom, pad_d, s));
+                                            K.no_pad_fix ? nullptr : d_dbottom, pad_d, ex_skip ? ex_skip + q0 : nullptr, m->d_coarse2bfs.p, s));
             } else
                 HIP_TRY(hipMemsetAsync(W.d_ub.p, 0x7F, (size_t)n_tiles512 * 256 * sizeof(uint32_t), s));   // 0x7F7F: above every valid cost
         }
@@ -534,6 +585,7 @@ int run_place(ugp_mat *m, ugp_qset *qs, int mode, ugp_result *d_out, int32_t *d_
             const uint32_t unit_chunks = std::max<uint32_t>(1, (f.n_chunks + G - 1) / G);
             b.ub_every = 128;
             if (K.ub_every) b.ub_every = K.ub_every;
+            b.freeze_ub = ex_skip ? 1u : 0u;   // (the chunk minima include the samples' excluded nodes: no bound may be taken from them)
             b.refill_all_rows = K.refill_all ? 1u : 0u;
             b.heavy_prio = K.heavy_prio;
             // (trees with large polytomies keep the tile-after-tile order: measured, 7 % apart in either direction)
@@ -638,6 +690,8 @@ int run_place(ugp_mat *m, ugp_qset *qs, int mode, ugp_result *d_out, int32_t *d_
                 m->kb_done_on = s;
             }
             HIP_TRY(hipEventRecord(es.ev[2], s));
+            if (ex_skip && !coarse_only)   // the one chunk minimum per sample that its excluded node may have set, again without it
+                HIP_TRY(ugp::launch_fix_skip(a, W.d_lbest.p, ex->skip_chunk + q0, n_tiles512, m->d_rank2bfs.p, order, f.max_slots, s));
             if (coarse_only)
                 HIP_TRY(ugp::launch_coarse_result(W.d_lbest.p, W.d_lpos.p, W.d_list.p, d_list_n, f.n_chunks, n_tiles512, (uint32_t)nq, m->d_chunk_node.p,
                                                   m->d_chunk8_body.p, m->d_node_pos8.p, m->d_dfs2bfs.p, d_out + q0, s));
@@ -1222,8 +1276,7 @@ int ugp_scores_per_node(ugp_mat *m, const ugp_queries *q, int32_t *out) {
     if (e != hipSuccess) rc = fail(UGP_ERR_HIP, std::string("hipMalloc scores: ") + hipGetErrorString(e));
     if (rc == UGP_OK) rc = run_place(m, qs, 1, nullptr, d_scores.p, nullptr, nullptr, nullptr, nullptr, 0, nullptr);
     if (rc == UGP_OK && total) {
-        e = hipMemcpy(out, d_scores.p, total * sizeof(int32_t), hipMemcpyDeviceToHost);
-        if (e != hipSuccess) rc = fail(UGP_ERR_HIP, std::string("copy scores: ") + hipGetErrorString(e));
+        rc = copy_d2h_staged(out, d_scores.p, total * sizeof(int32_t));
     }
     ugp_qset_destroy(qs);
     return rc;
@@ -1355,7 +1408,7 @@ namespace {
 // Everything an extended call needs on the device, converted from the caller's node order to BFS indexing.
 struct ExHost {
     DevBuf<uint8_t> d_mask;
-    DevBuf<uint32_t> d_skip, d_rank, d_rank2out, d_out_index;
+    DevBuf<uint32_t> d_skip, d_skip_chunk, d_rank, d_rank2out, d_out_index;
     DevBuf<int32_t> d_scores;
     ExDev dev;
 };
@@ -1383,6 +1436,24 @@ int prepare_ex(ugp_mat *m, const ugp_queries *q, const ugp_place_opts *o, ExHost
             }
             HIP_TRY(x.d_skip.upload(sk));
             x.dev.skip = x.d_skip.p;
+            // the packed path needs to know which chunk of the flattened tree holds each excluded node (k_fix_skip)
+            // (the flattener's own depth-first order and chunk cuts: the handle keeps them on the device only; fetched once)
+            if (m->d_dfs2bfs.p && m->d_chunk_node.p) {
+                if (m->h_flat_bfs2dfs.size() != N) {
+                    std::vector<uint32_t> d2b(N);
+                    m->h_flat_chunk_node.resize((size_t)m->flat.n_chunks + 1);
+                    HIP_TRY(hipMemcpy(d2b.data(), m->d_dfs2bfs.p, N * sizeof(uint32_t), hipMemcpyDeviceToHost));
+                    HIP_TRY(hipMemcpy(m->h_flat_chunk_node.data(), m->d_chunk_node.p, m->h_flat_chunk_node.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+                    m->h_flat_bfs2dfs.resize(N);
+                    for (uint64_t d = 0; d < N; d++) m->h_flat_bfs2dfs[d2b[d]] = (uint32_t)d;
+                }
+                std::vector<uint32_t> sc(Q, UINT32_MAX);
+                const auto &cno = m->h_flat_chunk_node;
+                for (uint64_t i = 0; i < Q; i++)
+                    if (sk[i] != UINT32_MAX) sc[i] = (uint32_t)(std::upper_bound(cno.begin(), cno.end(), m->h_flat_bfs2dfs[sk[i]]) - cno.begin()) - 1u;
+                HIP_TRY(x.d_skip_chunk.upload(sc));
+                x.dev.skip_chunk = x.d_skip_chunk.p;
+            }
         }
         if (dfs || o->distance) {
             // tie rank of usher_mapper.cpp:483-486 in the caller's terms: smaller distance, then more descendant leaves,
@@ -1438,10 +1509,11 @@ int drain(ugp_mat *m);
 // Can this extended search run on the packed, pruned path?  Its node order / distance becomes the tie rank of phase 2; its node
 // mask becomes a temporary exclusion (the "no candidate" bit of ugp_mat_update, set for the call and cleared behind it -- the
 // pruning bounds stay valid with fewer candidates, and the coarse tree of the locality pre-pass is masked alike, so that its
-// seeds are costs of admitted nodes).  Not with a per-sample excluded node or per-node scores, not when the mask drops the
+// seeds are costs of admitted nodes); a per-sample excluded node is handled behind phase 1 (k_fix_skip: the chunk minimum it may
+// have set is recomputed without it; seeds and bounds never rely on it).  Not with per-node scores, not when the mask drops the
 // root (it always scores), not on a handle that carries exclusions of its own.
 bool ex_packs(const ugp_mat *m, const ugp_place_opts *o) {
-    if (o->skip_node || o->scores || m->knobs.ex_slow) return false;
+    if (o->scores || m->knobs.ex_slow) return false;
     if (o->node_mask && (!o->node_mask[0] || m->upd.rec.size() != m->flat.n_nodes || m->upd.n_excluded || m->flat.n_nodes >= (1ull << 30))) return false;
     return true;
 }
@@ -1481,9 +1553,7 @@ int ugp_place_batch_ex(ugp_mat *m, const ugp_queries *q, const ugp_place_opts *o
     if (rc == UGP_OK) rc = run_place(m, qs, 0, d_out.p, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, false, &x.dev);
     if (rc == UGP_OK && hipMemcpy(out, d_out.p, q->n_queries * sizeof(ugp_result), hipMemcpyDeviceToHost) != hipSuccess)
         rc = fail(UGP_ERR_HIP, "copy results");
-    if (rc == UGP_OK && opts->scores &&
-        hipMemcpy(opts->scores, x.d_scores.p, (size_t)q->n_queries * m->flat.n_nodes * sizeof(int32_t), hipMemcpyDeviceToHost) != hipSuccess)
-        rc = fail(UGP_ERR_HIP, "copy scores");
+    if (rc == UGP_OK && opts->scores) rc = copy_d2h_staged(opts->scores, x.d_scores.p, (size_t)q->n_queries * m->flat.n_nodes * sizeof(int32_t));
     if (rc == UGP_OK) {   // no candidate was eligible: the reference's callers would be left with their initial values
         for (uint64_t i = 0; i < q->n_queries; i++)
             if (out[i].num_best == 0) { out[i].best_set_difference = INT32_MAX; out[i].best_j = UINT32_MAX; out[i].best_has_unique = 0; }

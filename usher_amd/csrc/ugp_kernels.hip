@@ -393,14 +393,14 @@ struct WalkOut { uint32_t best, cnt, key; };
 // (Fetching the next window ahead into registers was tried: slower -- the walk jumps, and the registers cost occupancy.)
 // LIST: the tied nodes are also appended to the samples' lists (a.tie_count / tie_j / tie_hu, indexed by the sample's position in
 // the caller's batch: `list_q`) -- ugp_tied_nodes from the chunks that attain the minimum instead of a second walk of the tree.
-template <bool LIST>
+template <bool LIST, bool MIN = false>
 __device__ __forceinline__ WalkOut walk_ties(const PlaceArgs &a, uint32_t *slots, uint32_t *rowbuf, uint32_t tile, uint32_t c, uint32_t lane,
-                                             uint32_t want, bool relevant, const uint32_t *rank2bfs, uint32_t list_q) {
+                                             uint32_t want, bool relevant, const uint32_t *rank2bfs, uint32_t list_q, uint32_t skip_bfs = 0xFFFFFFFFu) {
     const uint32_t *tab8 = a.table + ((uint64_t)(tile >> 3) * (a.n_sites + TABLE_CONST_ROWS) + TABLE_CONST_ROWS) * 64 + (tile & 7u) * 8;   // + 64 * site: 8 dwords
     const uint32_t col = lane >> 3;
     const uint32_t sh = (lane & 7u) * 4u;
     const uint32_t dbot = a.dbottom[tile * 64 + lane];
-    WalkOut o; o.best = 0; o.cnt = 0; o.key = 0;
+    WalkOut o; o.best = MIN ? 0xFFFFu : 0u; o.cnt = 0; o.key = 0;
     // D in the low half, B in the high half of one word (both below 2^15 on the packed path): B = the part of D at sites where
     // the sample's set holds the reference base -- the second pruning bound of k_best8 (ugp_flatten.hpp), here as well
     uint32_t dcur = 0;
@@ -477,7 +477,11 @@ __device__ __forceinline__ WalkOut walk_ties(const PlaceArgs &a, uint32_t *slots
                     elig = (common > 0) || free_internal;
                     hu = (masked || common != n_before) ? 1u : 0u;
                 }
-                if (relevant && elig && !excluded && cost == want) {
+                // MIN (k_fix_skip): the smallest cost of a candidate of this chunk other than the lane's excluded node, instead of the ties
+                if (MIN) {
+                    if (elig && !excluded && cost < o.best && rank2bfs[key >> 1] != skip_bfs) o.best = cost;
+                } else
+                if (relevant && elig && !excluded && cost == want && (skip_bfs == 0xFFFFFFFFu || rank2bfs[key >> 1] != skip_bfs)) {
                     // (the extended searches rank ties by the caller's rule -- its node order, its distances -- and name nodes by their
                     // position in the caller's order: a.alt_rank / a.out_index by BFS index; a tie is a rare event)
                     const uint32_t rk = a.alt_rank ? (a.alt_rank[rank2bfs[key >> 1]] << 1) : key;
@@ -496,7 +500,7 @@ __device__ __forceinline__ WalkOut walk_ties(const PlaceArgs &a, uint32_t *slots
                 have_info = false;
                 const uint32_t hs = info >> 24;
                 // D - hsub <= want and B - (second hits below) <= want: a descendant may still tie
-                const bool near = relevant && dn <= want + hs && (info_hr == 255u || (xn >> 16) <= want + info_hr);
+                const bool near = MIN || (relevant && dn <= want + hs && (info_hr == 255u || (xn >> 16) <= want + info_hr));
                 if (__builtin_amdgcn_ballot_w64(near) == 0) {
                     pos += info & 0xFFFFFFu;
                     if (pos - base >= 64u && pos < end) { base = pos; window(); }
@@ -1102,7 +1106,7 @@ __global__ void __launch_bounds__(64, TIES ? 3 : 4) k_best8(Best8Args a) {
             if (ARG) *(uint4 *)(a.lpos + (((uint64_t)chunk * a.n_tiles + tile) * 64 + lane) * 4) = make_uint4(bpos.v[0], bpos.v[1], bpos.v[2], bpos.v[3]);
             if (lane == 0) a.list[(uint64_t)tile * a.n_chunks + atomicAdd(&a.list_n[tile], 1u)] = chunk;   // (order is irrelevant to phase 2)
         }
-        if (can_prune) {
+        if (can_prune && !a.freeze_ub) {
             if (++ub_age >= a.ub_every) { exchange_ub(); ub_age = 0; }
             else {
 #pragma unroll
@@ -1125,7 +1129,7 @@ __global__ void __launch_bounds__(64, TIES ? 3 : 4) k_best8(Best8Args a) {
             const uint32_t k = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(lane < left && to > mark));
             if (k) {
                 chunk += k;
-                if (can_prune) { ub_age += k; if (ub_age >= a.ub_every) { exchange_ub(); ub_age = 0; } }
+                if (can_prune && !a.freeze_ub) { ub_age += k; if (ub_age >= a.ub_every) { exchange_ub(); ub_age = 0; } }
             }
             if (k < (left < 64u ? left : 64u)) return rdlane(mark, k);
         }
@@ -1782,11 +1786,34 @@ __global__ void __launch_bounds__(64) k_ties(PlaceArgs a, const uint32_t *__rest
         const uint32_t want = (q < a.n_queries) ? pk_lookup(gbest, q >> 9, q & 511u) : 0xFFFFFFFFu;
         const bool relevant = q < a.n_queries && pk_lookup(lbest + (uint64_t)c * (n_t64 / 8u) * 256u, q >> 9, q & 511u) == want;
         const uint32_t list_q = (LIST && q < a.n_queries) ? (order ? order[q] : q) : 0u;
-        WalkOut r = walk_ties<LIST>(a, slots, rowbuf, t64, c, lane, want, relevant, rank2bfs, list_q);
+        const uint32_t skipn = (a.skip && q < a.n_queries) ? a.skip[order ? order[q] : q] : 0xFFFFFFFFu;   // (extended search: one node left out for this sample)
+        WalkOut r = walk_ties<LIST>(a, slots, rowbuf, t64, c, lane, want, relevant, rank2bfs, list_q, skipn);
         if (r.cnt) {
             atomicAdd(&cnt_out[q], r.cnt);
             atomicMax(&key_out[q], r.key);
         }
+    }
+}
+
+// An extended search that leaves one node x out for a sample (ugp_place_opts::skip_node: matUtils uncertainty never maps a sample
+// onto its own node, uncertainty.cpp:216) on the packed path: phase 1 runs as always -- with bounds that never relied on x (seeds
+// that skip it, no tightening from the chunk minima, which do include it: Best8Args::freeze_ub) -- and the ONE chunk minimum that
+// may be x's is then recomputed for that sample without x: the chunk that holds x, walked one sample per lane like phase 2.
+// Phase 2 then sees minima of the search it was asked for.  One wave per sample slot; only the slot's own lane stores (a 16-bit
+// half of the packed record).  A record of a chunk that phase 1 did not list is written too and never read.
+__global__ void __launch_bounds__(64) k_fix_skip(PlaceArgs a, uint32_t *__restrict__ lbest, const uint32_t *__restrict__ skip_chunk, uint32_t n_tiles512,
+                                                  const uint32_t *__restrict__ rank2bfs, const uint32_t *__restrict__ order) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t slots[];
+    __shared__ __attribute__((aligned(16))) uint32_t rowbuf[64 * 8];
+    const uint32_t slot = blockIdx.x, lane = threadIdx.x;
+    const uint32_t qi = order ? order[slot] : slot;
+    const uint32_t x = a.skip[qi], c = skip_chunk[qi];   // uniform
+    if (x == 0xFFFFFFFFu || c == 0xFFFFFFFFu) return;
+    const WalkOut r = walk_ties<false, true>(a, slots, rowbuf, slot >> 6, c, lane, 0u, true, rank2bfs, 0u, x);   // (the other lanes walk along for their own samples: unused)
+    if (lane == (slot & 63u)) {
+        const uint32_t within = slot & 511u, l = within >> 3, j = within & 7u;
+        uint16_t *rec = (uint16_t *)(lbest + (((uint64_t)c * n_tiles512 + (slot >> 9)) * 64 + l) * 4 + (j & 3u));
+        rec[j >> 2] = (uint16_t)r.best;
     }
 }
 
@@ -1828,14 +1855,17 @@ __global__ void k_invert(const uint32_t *__restrict__ order, uint32_t n, uint32_
 // then holds for them everywhere.  Their results are never read.
 __global__ void k_seed_ub(const ugp_result *__restrict__ coarse_res, const uint32_t *__restrict__ order, uint32_t n_queries,
                           uint32_t n_words, uint32_t *__restrict__ ub, const uint32_t *__restrict__ refined, uint32_t *__restrict__ dbottom,
-                          uint32_t pad_d) {
+                          uint32_t pad_d, const uint32_t *__restrict__ skip, const uint32_t *__restrict__ coarse2bfs) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;   // word (tile*64 + lane)*4 + jj holds samples jj and jj+4 of the lane
     if (i >= n_words) return;
     const uint32_t slot = (i >> 2) * 8 + (i & 3u);
     auto val = [&](uint32_t q) -> uint32_t {
         if (q >= n_queries) { if (dbottom) dbottom[q] = pad_d; return dbottom ? 0u : 0x7F7Fu; }
         const int32_t b = coarse_res[order[q]].best_set_difference;
-        const uint32_t v = b < 0 || b > 0x7F7F ? 0x7F7Fu : (uint32_t)b;
+        uint32_t v = b < 0 || b > 0x7F7F ? 0x7F7Fu : (uint32_t)b;
+        // (a search that leaves one node out for this sample, ugp_place_opts::skip_node: the coarse best cost is a bound only when
+        // some other node attains it -- unknown when the coarse winner is that very node)
+        if (skip && skip[order[q]] != 0xFFFFFFFFu && coarse_res[order[q]].best_j != 0xFFFFFFFFu && coarse2bfs[coarse_res[order[q]].best_j] == skip[order[q]]) v = 0x7F7Fu;
         return refined ? min(v, refined[q]) : v;   // (the descent below: also the cost of a real eligible node)
     };
     ub[i] = val(slot) | (val(slot + 4) << 16);
@@ -1870,7 +1900,7 @@ template <uint32_t G>
 __global__ void __launch_bounds__(DESC_BLOCK) k_descend(const ugp_result *__restrict__ coarse_res, const uint32_t *__restrict__ order, uint32_t n_queries,
                           const uint32_t *__restrict__ coarse2bfs, const uint2 *__restrict__ node_pair,
                           const uint32_t *__restrict__ parent, const uint32_t *__restrict__ stream, const uint32_t *__restrict__ table, uint32_t n_sites,
-                          uint32_t *__restrict__ refined, uint32_t max_expansions, int slack) {
+                          uint32_t *__restrict__ refined, uint32_t max_expansions, int slack, const uint32_t *__restrict__ skip) {
     constexpr uint32_t NG = DESC_BLOCK / G;   // samples per block
     __shared__ uint32_t f_node[NG][DESC_FRONTIER], f_cb[NG][DESC_FRONTIER], f_ce[NG][DESC_FRONTIER];
     __shared__ int f_d[NG][DESC_FRONTIER];
@@ -1906,6 +1936,8 @@ __global__ void __launch_bounds__(DESC_BLOCK) k_descend(const ugp_result *__rest
         }
     };
     int best = alive ? r.best_set_difference : 0x7F7F;
+    // one node left out for this sample (ugp_place_opts::skip_node): its cost is never a bound; the search still passes through it
+    const uint32_t skipn = (skip && slot < n_queries) ? skip[order ? order[slot] : slot] : 0xFFFFFFFFu;
     uint32_t n_f = 0;   // uniform within the group: frontier entries
     uint32_t start[DESC_UP + 1];   // the start nodes (an ancestor's expansion must not enter the next one again)
 #pragma unroll
@@ -1919,6 +1951,7 @@ __global__ void __launch_bounds__(DESC_BLOCK) k_descend(const ugp_result *__rest
         eval(pr.y, dsum, neg, common, w0, excl);
         // cost(node) = D(parent) + neg = best  ->  D(parent) = best - neg, D(node) = D(parent) + dsum;  the root's cost is its D
         int D = (w0 & F_ROOT) ? best : best - neg + dsum;
+        if (node == skipn) best = 0x7F7F;   // (D above is derived from the node's true cost; as a bound it does not count)
         if (gl == 0) { f_node[g][0] = node; f_d[g][0] = D; f_cb[g][0] = pr.x + 1u; f_ce[g][0] = ce + 1u; }
         n_f = 1;
         for (uint32_t up = 0; up < DESC_UP && node != 0; up++) {   // D(ancestor) = D(child) - (sum of the child's deltas)
@@ -1966,7 +1999,7 @@ __global__ void __launch_bounds__(DESC_BLOCK) k_descend(const ugp_result *__rest
                 int dsum, neg; uint32_t common, w0; bool excl;
                 eval(pr.y, dsum, neg, common, w0, excl);
                 const bool leaf = (w0 & F_LEAF) != 0, masked = (w0 & F_MASKED) != 0;
-                if (!masked && !excl && (common > 0 || (!leaf && (w0 & 0xFFFFu) == 0))) cost = D + neg;
+                if (!masked && !excl && c != skipn && (common > 0 || (!leaf && (w0 & 0xFFFFu) == 0))) cost = D + neg;
                 dc = D + dsum;
                 // follow a child whose D does not grow -- or grows by one while it shares a mutation with the sample (the sample's
                 // lineage passing a node of which it lacks one mutation; a sibling branch shares one only by homoplasy)
@@ -2139,24 +2172,25 @@ hipError_t launch_build_units(const uint32_t *hstart, const uint32_t *hlen, uint
 }
 
 hipError_t launch_seed_ub(const ugp_result *coarse_res, const uint32_t *order, uint32_t n_queries, uint32_t n_tiles512, uint32_t *ub,
-                          const uint32_t *refined, uint32_t *dbottom, uint32_t pad_d, hipStream_t s) {
+                          const uint32_t *refined, uint32_t *dbottom, uint32_t pad_d, const uint32_t *skip, const uint32_t *coarse2bfs, hipStream_t s) {
     const uint32_t n_words = n_tiles512 * 256;
-    hipLaunchKernelGGL(k_seed_ub, dim3((n_words + 63) / 64), dim3(64), 0, s, coarse_res, order, n_queries, n_words, ub, refined, dbottom, pad_d);
+    hipLaunchKernelGGL(k_seed_ub, dim3((n_words + 63) / 64), dim3(64), 0, s, coarse_res, order, n_queries, n_words, ub, refined, dbottom, pad_d,
+                       coarse2bfs ? skip : nullptr, coarse2bfs);
     return hipGetLastError();
 }
 
 hipError_t launch_descend(const ugp_result *coarse_res, const uint32_t *order, uint32_t n_queries, const uint32_t *coarse2bfs,
                           const uint32_t *node_pair, const uint32_t *parent, const uint32_t *stream, const uint32_t *table,
-                          uint32_t n_sites, uint32_t *refined, bool wide, uint32_t max_expansions, int slack, hipStream_t s) {
+                          uint32_t n_sites, uint32_t *refined, bool wide, uint32_t max_expansions, int slack, const uint32_t *skip, hipStream_t s) {
     if (!n_queries) return hipSuccess;
     const uint32_t max_exp = max_expansions ? max_expansions : DESC_MAX_EXPANSIONS;   // (tuning)
     // (slack, measured at 10M nodes: 0 costs the main walk 60 %, 1..5 are alike, none is 8 % more descent)
     if (wide)
         hipLaunchKernelGGL(k_descend<64>, dim3((n_queries + DESC_BLOCK / 64 - 1) / (DESC_BLOCK / 64)), dim3(DESC_BLOCK), 0, s, coarse_res, order, n_queries, coarse2bfs, (const uint2 *)node_pair, parent,
-                           stream, table, n_sites, refined, max_exp, slack);
+                           stream, table, n_sites, refined, max_exp, slack, skip);
     else
         hipLaunchKernelGGL(k_descend<16>, dim3((n_queries + DESC_BLOCK / 16 - 1) / (DESC_BLOCK / 16)), dim3(DESC_BLOCK), 0, s, coarse_res, order, n_queries, coarse2bfs, (const uint2 *)node_pair, parent,
-                           stream, table, n_sites, refined, max_exp, slack);
+                           stream, table, n_sites, refined, max_exp, slack, skip);
     return hipGetLastError();
 }
 
@@ -2330,6 +2364,13 @@ hipError_t launch_phase2_packed(const Best8Args &b1, const uint32_t *list, const
     return hipGetLastError();
 }
 #endif
+
+hipError_t launch_fix_skip(const PlaceArgs &a, uint32_t *lbest, const uint32_t *skip_chunk, uint32_t n_tiles512, const uint32_t *rank2bfs, const uint32_t *order,
+                           uint32_t max_slots, hipStream_t s) {
+    if (!a.n_queries || !a.skip) return hipSuccess;
+    hipLaunchKernelGGL(k_fix_skip, dim3(a.n_queries), dim3(64), (size_t)max_slots * 64 * sizeof(uint32_t), s, a, lbest, skip_chunk, n_tiles512, rank2bfs, order);
+    return hipGetLastError();
+}
 
 hipError_t launch_phase2(const PlaceArgs &a, const uint32_t *lbest, const uint32_t *list, const uint32_t *list_n, uint32_t *gbest_part,
                          uint32_t *gbest, uint32_t n_tiles512,

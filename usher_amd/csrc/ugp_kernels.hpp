@@ -62,6 +62,7 @@ struct Best8Args {
     uint32_t split_many;       // != 0: a cut hands out as many pieces as waves wait (up to 63), each of at least this many chunks; 0: one half
     uint32_t split_cycles;     // a unit running longer than this hands half of its remainder to the shared list when waves wait for work (0xFFFFFFFF: never)
     uint32_t ub_every;         // exchange the shared upper bounds at every ub_every-th chunk end
+    uint32_t freeze_ub;        // the bounds stay what they were seeded with (a search that leaves a node out per sample: the chunk minima include it)
     uint32_t refill_all_rows;  // experiment (UGP_REFILL_ALL): a refill fetches the real row of every word of its first group
     uint32_t heavy_prio;       // raise the wave priority while a unit of a tile's own region is walked
     uint64_t *trace;           // optional (with stats): [0] = records written, records of 6 words from [8] on; trace_cap = room for that many
@@ -136,11 +137,15 @@ hipError_t launch_tile_ranges(const uint32_t *keys_sorted, uint32_t n_queries, u
 hipError_t launch_descend(const ugp_result *coarse_res, const uint32_t *order, uint32_t n_queries, const uint32_t *coarse2bfs,
                           const uint32_t *node_pair /* [n_nodes + 1][2]: child_begin, rec_off */, const uint32_t *parent, const uint32_t *stream,
                           const uint32_t *table, uint32_t n_sites, uint32_t *refined, bool wide /* a whole wave per sample: trees with large polytomies */,
-                          uint32_t max_expansions /* 0: default */, int slack, hipStream_t s);
+                          uint32_t max_expansions /* 0: default */, int slack, const uint32_t *skip /* [n_queries] by sample, or null: BFS index of a node whose cost is no bound for that sample */,
+                          hipStream_t s);
 hipError_t launch_seed_ub(const ugp_result *coarse_res, const uint32_t *order, uint32_t n_queries, uint32_t n_tiles512, uint32_t *ub,
                           const uint32_t *refined /* [n_queries] by sorted slot, or null */,
                           uint32_t *dbottom /* or null: D(bottom) of the unused slots of the last tile is set to pad_d, their bound to 0 */, uint32_t pad_d,
-                          hipStream_t s);
+                          const uint32_t *skip /* as launch_descend */, const uint32_t *coarse2bfs, hipStream_t s);
+// skip_node on the packed path: recompute, without the sample's excluded node, the minimum of the chunk that holds it (k_fix_skip)
+hipError_t launch_fix_skip(const PlaceArgs &a, uint32_t *lbest, const uint32_t *skip_chunk /* [n_queries] by sample */, uint32_t n_tiles512, const uint32_t *rank2bfs,
+                           const uint32_t *order, uint32_t max_slots, hipStream_t s);
 hipError_t launch_locality_sort(const ugp_result *coarse_res, const uint32_t *coarse2dfs, uint32_t n, uint32_t *keys,
                                 uint32_t *keys_sorted, uint32_t *idx, uint32_t *order, uint32_t *slot_of, void *temp,
                                 size_t *temp_bytes, hipStream_t s);
