@@ -167,7 +167,8 @@ struct ugp_mat {
     ugp_mat *coarse = nullptr;
     DevBuf<uint32_t> d_coarse2bfs, d_node_pair, d_parent;   // seed descent (k_descend)
     bool wide_descent = false;
-    DevBuf<uint32_t> d_coarse2dfs;
+    DevBuf<uint32_t> d_coarse2dfs, d_coarse_bin;   // coarse node -> depth-first rank in the full tree / its position among the coarse nodes in that order
+    uint32_t n_coarse_bins = 0;
     std::vector<uint32_t> h_level_off;   // breadth-first level boundaries (empty: the input is not a breadth-first expansion)
     uint32_t max_level_width = 0;
     // extended searches (ugp_place_batch_ex): host copy of the topology, the reference's depth-first order and its tie rank
@@ -196,7 +197,7 @@ struct ugp_mat {
         uint64_t last_words_total = 0;
         const uint32_t *last_list_n = nullptr;   // (UGP_STATS) record counts of the last packed launch, per 512-sample tile
         uint32_t last_list_tiles = 0;
-        DevBuf<uint32_t> d_refined, d_keys, d_keys2, d_idx, d_order, d_slot;
+        DevBuf<uint32_t> d_refined, d_keys, d_keys2, d_idx, d_order, d_slot, d_bins;
         DevBuf<ugp_result> d_coarse_res, d_prev_res;
         uint64_t prev_serial = 0;   // (UGP_SEED_PREV / UGP_SEED_CHECK diagnostics) content serial of the query set d_prev_res belongs to; 0 = none
         DevBuf<uint8_t> d_sort_tmp;
@@ -437,13 +438,13 @@ int run_place(ugp_mat *m, ugp_qset *qs, int mode, ugp_result *d_out, int32_t *d_
         const uint32_t *slot_of = nullptr, *order = nullptr;
         if (sorted) {
             HIP_TRY(W.d_keys.reserve(nq)); HIP_TRY(W.d_keys2.reserve(nq)); HIP_TRY(W.d_idx.reserve(nq));
-            HIP_TRY(W.d_order.reserve(nq)); HIP_TRY(W.d_slot.reserve(nq));
+            HIP_TRY(W.d_order.reserve(nq)); HIP_TRY(W.d_slot.reserve(nq)); HIP_TRY(W.d_bins.reserve(std::max<uint32_t>(m->n_coarse_bins, 1)));
             size_t tmp_bytes = 0;
             HIP_TRY(ugp::launch_locality_sort(nullptr, nullptr, (uint32_t)nq, W.d_keys.p, W.d_keys2.p, W.d_idx.p, W.d_order.p,
-                                              W.d_slot.p, nullptr, &tmp_bytes, s));
+                                              W.d_slot.p, nullptr, &tmp_bytes, nullptr, 0, nullptr, s));
             HIP_TRY(W.d_sort_tmp.reserve(tmp_bytes));
             HIP_TRY(ugp::launch_locality_sort(W.d_coarse_res.p + q0, m->d_coarse2dfs.p, (uint32_t)nq, W.d_keys.p, W.d_keys2.p,
-                                              W.d_idx.p, W.d_order.p, W.d_slot.p, W.d_sort_tmp.p, &tmp_bytes, s));
+                                              W.d_idx.p, W.d_order.p, W.d_slot.p, W.d_sort_tmp.p, &tmp_bytes, K.radix_sort ? nullptr : m->d_coarse_bin.p, m->n_coarse_bins, W.d_bins.p, s));
             slot_of = W.d_slot.p; order = W.d_order.p;
         }
         HIP_TRY(hipMemsetAsync(W.d_zero.p, 0, z_end * sizeof(uint32_t), s));
@@ -927,6 +928,14 @@ static int upload_flat(const HostFlat &hf, int device, ugp_mat **out) {
     if (hf.coarse) {
         if (int rc = upload_flat(*hf.coarse, device, &m->coarse)) { ugp_mat_destroy(m); return rc; }
         if ((e = m->d_coarse2dfs.upload(hf.coarse2dfs)) != hipSuccess) return bail(e, "upload coarse table");
+        {   // bins of the counting sort of the samples (k_locality_sort1): the coarse nodes in depth-first order
+            std::vector<uint32_t> by_rank(hf.coarse2dfs.size()), bin(hf.coarse2dfs.size());
+            for (uint32_t i = 0; i < by_rank.size(); i++) by_rank[i] = i;
+            std::sort(by_rank.begin(), by_rank.end(), [&](uint32_t a, uint32_t b) { return hf.coarse2dfs[a] < hf.coarse2dfs[b]; });
+            for (uint32_t i = 0; i < by_rank.size(); i++) bin[by_rank[i]] = i;
+            if ((e = m->d_coarse_bin.upload(bin)) != hipSuccess) return bail(e, "upload coarse table");
+            m->n_coarse_bins = (uint32_t)bin.size();
+        }
         if (!hf.node_pair.empty()) {
             if ((e = m->d_coarse2bfs.upload(hf.coarse2bfs)) != hipSuccess) return bail(e, "upload coarse table");
             m->wide_descent = getenv("UGP_DESCENT_LANES") ? atoi(getenv("UGP_DESCENT_LANES")) > 16 : hf.wide_descent;

@@ -2194,9 +2194,56 @@ hipError_t launch_descend(const ugp_result *coarse_res, const uint32_t *order, u
     return hipGetLastError();
 }
 
+// The locality sort without the device radix sort (round 4; it had been k_sort_keys + five rocprim kernels + k_invert, ~95 us of a
+// batch's chain).  The keys take few distinct values -- the nodes of the coarse tree, 4,882 at 10M nodes -- so a counting sort does:
+// histogram over the bins (coarse_bin[c] = position of coarse node c among the coarse nodes in depth-first order; one thread per
+// sample, global atomics on `bins`, zeroed by the caller), exclusive scan of the bins (one block), scatter (one thread per sample
+// again).  Samples of one bin come out in the order the scatter's atomics fall: the order is a scheduling hint, results never
+// depend on it.  (One block doing all three steps in LDS was tried first: 16 serial rounds of dependent loads per thread, slower
+// than the radix sort.)
+constexpr uint32_t LSORT_MAX_BINS = 16384;
+__global__ void k_lsort_hist(const ugp_result *__restrict__ coarse_res, const uint32_t *__restrict__ coarse_bin, uint32_t n, uint32_t *__restrict__ bins) {
+    const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q < n) atomicAdd(&bins[coarse_bin[coarse_res[q].best_j]], 1u);
+}
+__global__ void __launch_bounds__(256) k_lsort_scan(uint32_t *__restrict__ bins, uint32_t n_bins) {
+    __shared__ uint32_t part[256];
+    const uint32_t t = threadIdx.x;
+    const uint32_t per = (n_bins + 255u) / 256u, b0 = min(t * per, n_bins), b1 = min(b0 + per, n_bins);   // every thread owns a run of bins
+    uint32_t sum = 0;
+    for (uint32_t b = b0; b < b1; b++) sum += bins[b];
+    part[t] = sum;
+    __syncthreads();
+    for (uint32_t o = 1; o < 256u; o <<= 1) {   // (Hillis-Steele over the partial sums)
+        const uint32_t v = t >= o ? part[t - o] : 0u;
+        __syncthreads();
+        part[t] += v;
+        __syncthreads();
+    }
+    uint32_t run = part[t] - sum;
+    for (uint32_t b = b0; b < b1; b++) { const uint32_t c = bins[b]; bins[b] = run; run += c; }
+}
+__global__ void k_lsort_scatter(const ugp_result *__restrict__ coarse_res, const uint32_t *__restrict__ coarse2dfs, const uint32_t *__restrict__ coarse_bin,
+                                uint32_t n, uint32_t *__restrict__ bins, uint32_t *__restrict__ keys_sorted, uint32_t *__restrict__ order,
+                                uint32_t *__restrict__ slot_of) {
+    const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= n) return;
+    const uint32_t c = coarse_res[q].best_j;
+    const uint32_t pos = atomicAdd(&bins[coarse_bin[c]], 1u);
+    order[pos] = q; keys_sorted[pos] = coarse2dfs[c]; slot_of[q] = pos;
+}
+
 hipError_t launch_locality_sort(const ugp_result *coarse_res, const uint32_t *coarse2dfs, uint32_t n, uint32_t *keys,
                                 uint32_t *keys_sorted, uint32_t *idx, uint32_t *order, uint32_t *slot_of, void *temp,
-                                size_t *temp_bytes, hipStream_t s) {
+                                size_t *temp_bytes, const uint32_t *coarse_bin, uint32_t n_bins, uint32_t *bins, hipStream_t s) {
+    if (temp && coarse_bin && bins && n_bins && n_bins <= LSORT_MAX_BINS) {
+        hipError_t e = hipMemsetAsync(bins, 0, (size_t)n_bins * sizeof(uint32_t), s);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(k_lsort_hist, dim3((n + 63) / 64), dim3(64), 0, s, coarse_res, coarse_bin, n, bins);
+        hipLaunchKernelGGL(k_lsort_scan, dim3(1), dim3(256), 0, s, bins, n_bins);
+        hipLaunchKernelGGL(k_lsort_scatter, dim3((n + 63) / 64), dim3(64), 0, s, coarse_res, coarse2dfs, coarse_bin, n, bins, keys_sorted, order, slot_of);
+        return hipGetLastError();
+    }
     if (!temp) {   // size query
         return hipcub::DeviceRadixSort::SortPairs(nullptr, *temp_bytes, keys, keys_sorted, idx, order, (int)n, 0, 32, s);
     }

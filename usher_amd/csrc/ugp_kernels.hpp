@@ -146,9 +146,11 @@ hipError_t launch_seed_ub(const ugp_result *coarse_res, const uint32_t *order, u
 // skip_node on the packed path: recompute, without the sample's excluded node, the minimum of the chunk that holds it (k_fix_skip)
 hipError_t launch_fix_skip(const PlaceArgs &a, uint32_t *lbest, const uint32_t *skip_chunk /* [n_queries] by sample */, uint32_t n_tiles512, const uint32_t *rank2bfs,
                            const uint32_t *order, uint32_t max_slots, hipStream_t s);
+// coarse_bin / n_bins / bins: position of every coarse node among the coarse nodes in depth-first order and n_bins counters, or
+// null -- with them the samples are sorted by a counting sort (k_lsort_*: three small launches) instead of the device radix sort
 hipError_t launch_locality_sort(const ugp_result *coarse_res, const uint32_t *coarse2dfs, uint32_t n, uint32_t *keys,
                                 uint32_t *keys_sorted, uint32_t *idx, uint32_t *order, uint32_t *slot_of, void *temp,
-                                size_t *temp_bytes, hipStream_t s);
+                                size_t *temp_bytes, const uint32_t *coarse_bin, uint32_t n_bins, uint32_t *bins, hipStream_t s);
 hipError_t launch_extract_best(const ugp_result *res, uint32_t n, int32_t *best, hipStream_t s);
 hipError_t launch_place(const PlaceArgs &a, int mode, uint32_t max_slots, hipStream_t s);   // mode 0/1/2, +4: extended (a.node_mask etc.)
 hipError_t launch_merge(const uint32_t *part_best, const uint32_t *part_cnt, const uint32_t *part_key,
