@@ -2207,11 +2207,14 @@ __global__ void k_lsort_hist(const ugp_result *__restrict__ coarse_res, const ui
     if (q < n) atomicAdd(&bins[coarse_bin[coarse_res[q].best_j]], 1u);
 }
 __global__ void __launch_bounds__(256) k_lsort_scan(uint32_t *__restrict__ bins, uint32_t n_bins) {
-    __shared__ uint32_t part[256];
+    extern __shared__ uint32_t lb[];   // [n_bins]: the counters are staged through LDS -- every global access coalesced and independent
+    __shared__ uint32_t part[256];     // (a thread summing its run of bins straight from global memory was 20 dependent round trips: 77 us)
     const uint32_t t = threadIdx.x;
+    for (uint32_t b = t; b < n_bins; b += 256u) lb[b] = bins[b];
+    __syncthreads();
     const uint32_t per = (n_bins + 255u) / 256u, b0 = min(t * per, n_bins), b1 = min(b0 + per, n_bins);   // every thread owns a run of bins
     uint32_t sum = 0;
-    for (uint32_t b = b0; b < b1; b++) sum += bins[b];
+    for (uint32_t b = b0; b < b1; b++) sum += lb[b];
     part[t] = sum;
     __syncthreads();
     for (uint32_t o = 1; o < 256u; o <<= 1) {   // (Hillis-Steele over the partial sums)
@@ -2221,7 +2224,9 @@ __global__ void __launch_bounds__(256) k_lsort_scan(uint32_t *__restrict__ bins,
         __syncthreads();
     }
     uint32_t run = part[t] - sum;
-    for (uint32_t b = b0; b < b1; b++) { const uint32_t c = bins[b]; bins[b] = run; run += c; }
+    for (uint32_t b = b0; b < b1; b++) { const uint32_t c = lb[b]; lb[b] = run; run += c; }
+    __syncthreads();
+    for (uint32_t b = t; b < n_bins; b += 256u) bins[b] = lb[b];
 }
 __global__ void k_lsort_scatter(const ugp_result *__restrict__ coarse_res, const uint32_t *__restrict__ coarse2dfs, const uint32_t *__restrict__ coarse_bin,
                                 uint32_t n, uint32_t *__restrict__ bins, uint32_t *__restrict__ keys_sorted, uint32_t *__restrict__ order,
@@ -2240,7 +2245,7 @@ hipError_t launch_locality_sort(const ugp_result *coarse_res, const uint32_t *co
         hipError_t e = hipMemsetAsync(bins, 0, (size_t)n_bins * sizeof(uint32_t), s);
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL(k_lsort_hist, dim3((n + 63) / 64), dim3(64), 0, s, coarse_res, coarse_bin, n, bins);
-        hipLaunchKernelGGL(k_lsort_scan, dim3(1), dim3(256), 0, s, bins, n_bins);
+        hipLaunchKernelGGL(k_lsort_scan, dim3(1), dim3(256), (size_t)n_bins * sizeof(uint32_t), s, bins, n_bins);
         hipLaunchKernelGGL(k_lsort_scatter, dim3((n + 63) / 64), dim3(64), 0, s, coarse_res, coarse2dfs, coarse_bin, n, bins, keys_sorted, order, slot_of);
         return hipGetLastError();
     }
