@@ -163,7 +163,10 @@ int ugp_tied_nodes(ugp_mat *mat, const ugp_queries *q, uint32_t cap,
  * vector as an order (breadth-first or the reference's depth-first expansion, mutation_annotated_tree.cpp:1253-1273)
  * plus a mask; every node index going in or out is a position in the chosen order.  (A breadth-first expansion of a
  * subtree lists its nodes in the same relative order as the whole tree's, so merge's sub-BFS is order BFS + mask.)
- * They run the general one-sample-per-lane kernel (no pruning): exact for any combination of options. */
+ * Exact for any combination of options.  An order, a distance, a mask and an excluded node per sample run on the packed,
+ * pruned path of ugp_place_batch (the order / distance is the tie rank of its second phase, the mask a temporary "no
+ * candidate" bit in the tree on the device, the excluded node is taken out of the one chunk minimum it may have set);
+ * the score matrix and a mask that drops the root take the general one-sample-per-lane kernel (no pruning). */
 #define UGP_ORDER_BFS 0u
 #define UGP_ORDER_DFS 1u
 typedef struct ugp_place_opts {
