@@ -141,6 +141,72 @@ __global__ void k_scatter_entries(uint32_t *__restrict__ table, uint32_t *__rest
     }
 }
 
+// The same for the plain case (every row of the launch, no row list), K rows per thread: a row is a chain of five dependent
+// accesses (sample -> slot, position -> site, the table word, the active-row word), and next to the persistent walks of the
+// batches in front a CU has room for about one more wave -- with one row per thread the launch was 5,600 waves taking turns
+// (64 us in the pipelined trace, twice per batch); four independent chains per thread need a quarter of the waves for the same
+// latency each.
+template <int K>
+__global__ void __launch_bounds__(64) k_scatter_rows(uint32_t *__restrict__ table, uint32_t *__restrict__ dbottom,
+                                                     const int32_t *__restrict__ pos, const uint8_t *__restrict__ ref,
+                                                     const uint8_t *__restrict__ nuc, const uint8_t *__restrict__ is_missing,
+                                                     const uint32_t *__restrict__ ent_q, const int32_t *__restrict__ pos2site,
+                                                     uint32_t max_pos, uint32_t n_sites, uint64_t n_ent, uint32_t q_base,
+                                                     uint32_t *__restrict__ active, uint32_t active_words, const uint32_t *__restrict__ slot_of,
+                                                     const unsigned long long *__restrict__ err) {
+    if (err && *err != ~0ull) return;   // (as k_scatter_entries: a batch with bad rows is built as if it had none)
+    const uint64_t base = (uint64_t)blockIdx.x * 64u * K + threadIdx.x;
+    bool valid[K];
+    uint32_t q[K], r[K], a[K], miss[K];
+    int32_t p[K], site[K];
+#pragma unroll
+    for (int j = 0; j < K; j++) {
+        const uint64_t e = base + (uint64_t)j * 64u;
+        valid[j] = e < n_ent;
+        q[j] = valid[j] ? ent_q[e] - q_base : 0u;
+        p[j] = valid[j] ? pos[e] : -1;
+        r[j] = valid[j] ? ref[e] : 0u;
+        miss[j] = valid[j] ? is_missing[e] : 1u;
+        a[j] = valid[j] ? (uint32_t)nuc[e] : 0u;
+    }
+#pragma unroll
+    for (int j = 0; j < K; j++) {
+        if (valid[j] && slot_of) q[j] = slot_of[q[j]];
+        if (miss[j]) a[j] = 15u;
+        site[j] = (valid[j] && p[j] >= 0 && (uint32_t)p[j] <= max_pos) ? pos2site[p[j]] : -1;
+    }
+#pragma unroll
+    for (int j = 0; j < K; j++) {
+        // D_bottom: the rows of a sample are consecutive, so a wave usually serves one sample -- one atomic per wave
+        const bool mism = valid[j] && !miss[j] && (a[j] & r[j]) == 0;
+        const unsigned long long mm = __builtin_amdgcn_ballot_w64(mism);
+        const uint32_t q0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)q[j]);
+        if (__builtin_amdgcn_ballot_w64(valid[j] && q[j] != q0) == 0) {
+            if (mm && threadIdx.x == (uint32_t)__builtin_ctzll(mm)) atomicAdd(&dbottom[q0], (uint32_t)__builtin_popcountll(mm));
+        } else if (mism) atomicAdd(&dbottom[q[j]], 1u);
+    }
+    uint32_t *aw[K];
+    uint32_t have[K];
+#pragma unroll
+    for (int j = 0; j < K; j++) {
+        aw[j] = nullptr; have[j] = 0;
+        if (site[j] < 0) continue;
+        const uint32_t tile = q[j] >> 9, within = q[j] & 511u;
+        uint32_t *w = table + ((uint64_t)tile * (n_sites + TABLE_CONST_ROWS) + TABLE_CONST_ROWS + (uint32_t)site[j]) * 64 + (within >> 3);
+        atomicXor(w, ((r[j] ^ a[j]) & 15u) << ((within & 7u) * 4u));   // nibble was r (k_fill_table); rows are unique per (sample, position)
+        if (r[j] != a[j]) {
+            aw[j] = &active[(uint64_t)tile * active_words + ((uint32_t)site[j] >> 5)];
+            have[j] = __hip_atomic_load(aw[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (look before setting)
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < K; j++) {
+        if (!aw[j]) continue;
+        const uint32_t bit = 1u << ((uint32_t)site[j] & 31u);
+        if (!(have[j] & bit)) atomicOr(aw[j], bit);
+    }
+}
+
 // ---- tiles of batches with many MISSING rows (N cells come in runs of hundreds to thousands per sample) ---------------------
 // One atomic per row into a 200 MB table (k_scatter_entries) or a binary search and a serial row loop per (sample, site block)
 // (k_build_tiles) cost 1.4-1.7 ms per build for 41 M rows, twice per call.  The N cells are turned into one bit per
@@ -2166,7 +2232,9 @@ hipError_t launch_tile_ranges(const uint32_t *keys_sorted, uint32_t n_queries, u
 hipError_t launch_build_units(const uint32_t *hstart, const uint32_t *hlen, uint32_t n_tiles512, uint32_t n_chunks, uint32_t unit_chunks, uint32_t heavy_chunks,
                               uint32_t grow_every, uint32_t unit_max, uint32_t light_order, uint32_t per_tile_cap, void *units, uint32_t *unit_base,
                               uint32_t *unit_count, uint32_t *dyn_ctl, hipStream_t s) {
-    hipLaunchKernelGGL(k_build_units, dim3(8), dim3(256), 0, s, hstart, hlen, n_tiles512, n_chunks, unit_chunks, heavy_chunks, grow_every, unit_max, light_order,
+    // (one-wave blocks unless the lists are long: next to the persistent walks of the batches in front a CU has room for one more
+    // wave, and a four-wave block waits for a CU to drain -- 105 us for the coarse pass's eight tiny lists in the pipelined trace)
+    hipLaunchKernelGGL(k_build_units, dim3(8), dim3(n_tiles512 <= 512 ? 64 : 256), 0, s, hstart, hlen, n_tiles512, n_chunks, unit_chunks, heavy_chunks, grow_every, unit_max, light_order,
                        per_tile_cap, (uint4 *)units, unit_base, unit_count, dyn_ctl);
     return hipGetLastError();
 }
@@ -2284,9 +2352,10 @@ hipError_t launch_scatter(uint32_t *table, uint32_t *dbottom, const int32_t *pos
                           const int32_t *pos2site, uint32_t max_pos, uint32_t n_sites, uint64_t n_ent, uint32_t q_base,
                           uint32_t *active, uint32_t active_words, const uint32_t *slot_of, const unsigned long long *err, hipStream_t s) {
     if (n_ent == 0) return hipSuccess;
-    uint64_t blocks = (n_ent + 63) / 64;
-    hipLaunchKernelGGL(k_scatter_entries, dim3((uint32_t)blocks), dim3(64), 0, s, table, dbottom, pos, ref, nuc,
-                       is_missing, ent_q, pos2site, max_pos, n_sites, n_ent, q_base, active, active_words, slot_of, nullptr, nullptr, 0u, err);
+    constexpr int K = 4;
+    const uint64_t blocks = (n_ent + 64 * K - 1) / (64 * K);
+    hipLaunchKernelGGL(k_scatter_rows<K>, dim3((uint32_t)blocks), dim3(64), 0, s, table, dbottom, pos, ref, nuc,
+                       is_missing, ent_q, pos2site, max_pos, n_sites, n_ent, q_base, active, active_words, slot_of, err);
     return hipGetLastError();
 }
 
