@@ -360,7 +360,7 @@ def main():
     if world == 1 and headline and not args.no_extra:
         extra = {}
 
-        def timed_config(placer, tree, nq, steps, warm, **qkw):
+        def timed_config(placer, tree, nq, steps, warm, ties_cap=0, **qkw):
             qq = tree.queries(nq, seed=args.seed * 1000 + 4, **qkw)
             bb = QueryBatch.from_csr(qq["ent_off"], qq["pos"], qq["ref"], qq["nuc"], qq["is_missing"])
             hq = placer.upload(bb)
@@ -381,7 +381,18 @@ def main():
             torch.cuda.synchronize()
             same = bool((strict == oo[(steps - 1) % dd]).all().item())
             placer.free_qset(hq)
-            return {"queries": nq, "steps": steps, "placements_per_s": round(nq * steps / tq, 2), "ms_per_step": round(tq * 1e3 / steps, 3),
+            ties = None
+            if ties_cap:   # tie reporting (-M / -D of the CLI): ugp_tied_nodes from and to host buffers, wall time of the second call
+                import ctypes as C
+                tj = np.zeros((nq, ties_cap), dtype=np.uint32); th = np.zeros((nq, ties_cap), dtype=np.uint8); tcnt = np.zeros(nq, dtype=np.uint32)
+                ptr = lambda x: x.ctypes.data_as(C.c_void_p)
+                for _ in range(2):   # (the second call is timed: buffers allocated)
+                    tt0 = time.perf_counter()
+                    placer._ck(placer._L.ugp_tied_nodes(placer._h, C.byref(bb.desc), ties_cap, ptr(tj), ptr(th), ptr(tcnt)))
+                    tt1 = time.perf_counter()
+                ties = {"entry": "ugp_tied_nodes (host buffers in, host buffers out)", "cap": ties_cap, "wall_ms": round((tt1 - tt0) * 1e3, 2),
+                        "samples_with_ties": int((tcnt > 1).sum()), "counts_equal_num_best": bool((tcnt == strict[:, 1].cpu().numpy().astype(np.uint32)).all())}
+            return {**({"tie_lists": ties} if ties else {}), "queries": nq, "steps": steps, "placements_per_s": round(nq * steps / tq, 2), "ms_per_step": round(tq * 1e3 / steps, 3),
                     "k_best8_ms": round(tmq["place_ms"] / max(1, tmq["calls"]), 4), "sub_batches": int(tmq["place_launches"] // max(1, tmq["calls"])),
                     "identical_to_stream_ordered_call": same}
 
@@ -389,6 +400,10 @@ def main():
         c4 = timed_config(pl, st, 1_000_000, 4, 3)   # (3 warm-up calls: every workspace set a long call cycles through is allocated before the clock starts)
         c4["workload"] = "BASELINE config 4 on one device: 1,000,000 queries on the %d-node MAT, one ugp_place_device_overlapped call per step" % info["n_nodes"]
         extra["config4_1m_queries_one_gpu"] = c4
+        # config 5's workload on one device: high-ambiguity queries (100-5,000 N cells + 0-30 IUPAC cells of any 2-3 bases each) and tie lists
+        c5 = timed_config(pl, st, 16384, 6, 3, ties_cap=64, n_lo=100, n_hi=5000, iupac_hi=30)
+        c5["workload"] = "BASELINE config 5 on one device: 16,384 queries with 100-5,000 N cells and 0-30 IUPAC cells each on the %d-node MAT, tie lists of up to 64 nodes" % info["n_nodes"]
+        extra["config5_high_ambiguity_one_gpu"] = c5
         # the drop-in CLI end to end: the same tree as parsimony.proto, 10,000 queries as a VCF, `usher-amd -i .. -v .. -n` (load the
         # MAT, read the VCF, flatten + upload, place, write placement_stats.tsv and the tree) -- wall time of the whole process
         try:
