@@ -561,8 +561,9 @@ def test_randomised_trees_and_scheduling_knobs(seed, monkeypatch):
         knobs["UGP_RADIX_SORT"] = "1"        # the samples sorted by the device radix sort instead of the counting sort over the coarse nodes
     if rng.random() < 0.3:
         knobs["UGP_SPLIT_MANY"] = str(int(rng.choice([0, 1, 8])))   # how a running unit is cut: one half / as many pieces as waves wait
+        knobs["UGP_SPLIT_MANY_HEAVY"] = str(int(rng.choice([0, 1, 5])))
     for k in ("UGP_COARSE_MIN_NODES", "UGP_UNIT_CHUNKS", "UGP_HEAVY_CHUNKS", "UGP_UB_EVERY", "UGP_PRUNE_MIN_WORDS", "UGP_NO_LPT", "UGP_NO_SEED",
-              "UGP_NO_SORT", "UGP_NO_PRUNE", "UGP_FORCE_V1", "UGP_LDS_SLOTS", "UGP_NO_DESCENT", "UGP_NO_BOUND2", "UGP_UNIT_GROW", "UGP_UNIT_MAX", "UGP_SPLIT_CYCLES", "UGP_LDS_BITS", "UGP_PRE_WEIGHT", "UGP_COARSE_PHASE2", "UGP_NMASK", "UGP_PHASE2_PACKED", "UGP_RADIX_SORT", "UGP_SPLIT_MANY"):
+              "UGP_NO_SORT", "UGP_NO_PRUNE", "UGP_FORCE_V1", "UGP_LDS_SLOTS", "UGP_NO_DESCENT", "UGP_NO_BOUND2", "UGP_UNIT_GROW", "UGP_UNIT_MAX", "UGP_SPLIT_CYCLES", "UGP_LDS_BITS", "UGP_PRE_WEIGHT", "UGP_COARSE_PHASE2", "UGP_NMASK", "UGP_PHASE2_PACKED", "UGP_RADIX_SORT", "UGP_SPLIT_MANY", "UGP_SPLIT_MANY_HEAVY"):
         monkeypatch.delenv(k, raising=False)
     for k, v in knobs.items():
         monkeypatch.setenv(k, v)

@@ -630,7 +630,7 @@ int run_place(ugp_mat *m, ugp_qset *qs, int mode, ugp_result *d_out, int32_t *d_
                 }
                 if (++W.dyn_epoch >= 2048u) { HIP_TRY(hipMemsetAsync(W.d_dyn.p, 0, (size_t)kDynCap * 8, s)); W.dyn_epoch = 1; }   // (11 bits: stale entries never alias)
                 uint32_t *dyn_ctl = W.d_unit_info.p + 32;
-                b.dyn_ctl = dyn_ctl; b.dyn_units = (unsigned long long *)W.d_dyn.p; b.dyn_cap = kDynCap; b.dyn_epoch = W.dyn_epoch; b.split_cycles = split_cycles; b.split_heavy = split_heavy; b.split_dense = K.split_dense >= 0 ? (uint32_t)K.split_dense : 0xFFFFFFFFu; b.split_many = K.split_many;
+                b.dyn_ctl = dyn_ctl; b.dyn_units = (unsigned long long *)W.d_dyn.p; b.dyn_cap = kDynCap; b.dyn_epoch = W.dyn_epoch; b.split_cycles = split_cycles; b.split_heavy = split_heavy; b.split_dense = K.split_dense >= 0 ? (uint32_t)K.split_dense : 0xFFFFFFFFu; b.split_many = K.split_many ? ((K.split_many & 0xFFFFu) | (std::max(1u, K.split_many_heavy ? K.split_many_heavy : K.split_many) << 16)) : 0u;
                 HIP_TRY(ugp::launch_build_units(hstart, hlen, n_tiles512, f.n_chunks, unit_chunks, heavy_chunks, grow_every, unit_max, light_order, per_tile_cap,
                                                 W.d_units.p, W.d_unit_info.p, W.d_unit_info.p + 8, dyn_ctl, s));
                 b.units = (const uint4 *)W.d_units.p; b.unit_base = W.d_unit_info.p; b.unit_count = W.d_unit_info.p + 8;

@@ -1640,7 +1640,10 @@ __global__ void __launch_bounds__(64, TIES ? 3 : 4) k_best8(Best8Args a) {
                     const uint32_t R = stop - chunk;
                     // (a.split_many = the fewest chunks a piece may have: a one-chunk piece costs its wave 105 us -- the fixed part of a
                     // unit and a walk without the bounds its neighbours found -- where the same chunk takes 47 us inside its unit)
-                    const uint32_t cap_p = R / max(a.split_many, 1u) > 1u ? R / max(a.split_many, 1u) - 1u : 1u;
+                    // (the units of a tile's own region are dense -- a chunk there is 50-130 us of walking, as much as a piece's fixed
+                    // part -- and short: they have their own, smaller minimum, the high half of the argument)
+                    const uint32_t sm = unit_heavy ? (a.split_many >> 16) : (a.split_many & 0xFFFFu);
+                    const uint32_t cap_p = R / max(sm, 1u) > 1u ? R / max(sm, 1u) - 1u : 1u;
                     const uint32_t pieces = a.split_many ? min(min(hd - tl, 63u), cap_p) : 1u;
                     const uint32_t per = a.split_many ? max(1u, R / (pieces + 1u)) : R / 2u;   // (one piece: the second half, rounded down)
                     uint32_t slot = 0xFFFFFFFFu;

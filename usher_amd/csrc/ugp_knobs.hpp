@@ -21,6 +21,7 @@ struct Knobs {
     // 0 = the library's own choice
     uint32_t target_waves = 0, groups = 0, unit_chunks = 0, heavy_chunks = 0, unit_max = 0, shared_waves = 0, waves_per_cu = 0, ub_every = 0,
              heavy_prio = 0, descent_max = 0, scores_block = 0;
+    uint32_t split_many_heavy = 2;   // the same minimum for the units of a tile's own region: dense and short (UGP_SPLIT_MANY_HEAVY; 0: as split_many)
     uint32_t split_many = 4;   // a unit that is cut hands out as many pieces as waves wait, of at least this many chunks each (UGP_SPLIT_MANY; 0: one half, as until round 4)
     uint32_t lbest_gib = 0;   // cap of the per-(chunk, sample) minima of one sub-batch in GiB (UGP_LBEST_GIB; 0: 24 -- 262,144 samples per launch sequence at 10M nodes)
     uint32_t depth = 3;   // calls of ugp_place_device_overlapped on the device at a time (2..4 workspace sets; UGP_PIPELINE_DEPTH)
@@ -52,6 +53,7 @@ struct Knobs {
         k.descent_max = pos("UGP_DESCENT_MAX");
         k.lbest_gib = pos("UGP_LBEST_GIB");
         if (getenv("UGP_SPLIT_MANY")) k.split_many = pos("UGP_SPLIT_MANY", 0);
+        if (getenv("UGP_SPLIT_MANY_HEAVY")) k.split_many_heavy = pos("UGP_SPLIT_MANY_HEAVY", 0);
         if (getenv("UGP_PIPELINE_DEPTH")) k.depth = pos("UGP_PIPELINE_DEPTH", 2);
         if (const char *e = getenv("UGP_SCORES_BLOCK")) { int v = atoi(e) / 64 * 64; k.scores_block = (uint32_t)(v < 64 ? 64 : v > 1024 ? 1024 : v); }
 #ifdef UGP_EXPERIMENTS
