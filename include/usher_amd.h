@@ -166,7 +166,8 @@ int ugp_tied_nodes(ugp_mat *mat, const ugp_queries *q, uint32_t cap,
  * Exact for any combination of options.  An order, a distance, a mask and an excluded node per sample run on the packed,
  * pruned path of ugp_place_batch (the order / distance is the tie rank of its second phase, the mask a temporary "no
  * candidate" bit in the tree on the device, the excluded node is taken out of the one chunk minimum it may have set);
- * the score matrix and a mask that drops the root take the general one-sample-per-lane kernel (no pruning). */
+ * the score matrix of a breadth-first search comes from the level-by-level kernel of ugp_scores_per_node; the score matrix in
+ * depth-first indices and a mask that drops the root take the general one-sample-per-lane kernel (no pruning). */
 #define UGP_ORDER_BFS 0u
 #define UGP_ORDER_DFS 1u
 typedef struct ugp_place_opts {

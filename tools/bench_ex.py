@@ -59,6 +59,14 @@ for label, env in (("packed", None), ("one sample per lane", "1")):
         dt2 = time.perf_counter() - t0
         res.setdefault(name, []).append(r.copy())
         print("%-22s %-40s place_ex %8.1f ms = %9.0f samples/s   tied_nodes_ex %8.1f ms   (packed_path=%d)" % (label, name, dt * 1e3, a.queries / dt, dt2 * 1e3, pl.timing()["packed_path"]), flush=True)
+    # ripples proper: the score of every admitted node for one pruned sample at a time (ripples/main.cpp:343-377) -- 8 samples here
+    few = QueryBatch.from_csr(q["ent_off"][:9], q["pos"][:int(q["ent_off"][8])], q["ref"][:int(q["ent_off"][8])], q["nuc"][:int(q["ent_off"][8])], q["is_missing"][:int(q["ent_off"][8])])
+    pl.place_ex(few, order="bfs", node_mask=mask, distance=dist, want_scores=True)
+    t0 = time.perf_counter()
+    r8, sc8 = pl.place_ex(few, order="bfs", node_mask=mask, distance=dist, want_scores=True)
+    dt = time.perf_counter() - t0
+    res.setdefault("ripples-style with the score matrix (8 samples)", []).append(np.concatenate([r8.view(np.int32).ravel(), sc8.ravel()[::997]]))
+    print("%-22s %-40s place_ex %8.1f ms for 8 samples x %d scores (packed_path=%d)" % (label, "ripples-style + scores", dt * 1e3, n, pl.timing()["packed_path"]), flush=True)
     pl.close()
 for name, (x, y) in res.items():
     print("%-40s identical results on both paths: %s" % (name, bool((x.view(np.int32) == y.view(np.int32)).all())))

@@ -1552,15 +1552,29 @@ int ugp_place_batch_ex(ugp_mat *m, const ugp_queries *q, const ugp_place_opts *o
     DevBuf<ugp_result> d_out;
     int rc = prepare_ex(m, q, opts, x, true);
     if (rc == UGP_OK && d_out.reserve(q->n_queries) != hipSuccess) rc = fail(UGP_ERR_HIP, "hipMalloc results");
-    const bool pack = rc == UGP_OK && ex_packs(m, opts) && (!m->coarse || m->d_coarse2bfs.p || !opts->node_mask);
+    // The score matrix of a search in breadth-first indices (ripples: ripples/main.cpp:343-377) does not need the one-sample-per-lane
+    // kernel either: the results come from the packed path as without it, the scores from the level-by-level kernel of -p (a node's
+    // score does not depend on who else is a candidate), and the nodes that were not scored -- outside the mask, a sample's excluded
+    // node -- are set to 0 behind it.
+    ugp_place_opts no_scores = *opts;
+    no_scores.scores = nullptr;
+    const bool scores_by_levels = rc == UGP_OK && opts->scores && opts->order == UGP_ORDER_BFS && !m->h_level_off.empty() && !m->knobs.scores_dfs &&
+                                  !m->knobs.ex_slow && !m->knobs.force_v1 && !m->upd.n_excluded;
+    const ugp_place_opts *popts = scores_by_levels ? &no_scores : opts;
+    const bool pack = rc == UGP_OK && ex_packs(m, popts) && (!m->coarse || m->d_coarse2bfs.p || !opts->node_mask);
     if (pack) {
         if (rc == UGP_OK) rc = drain(m);
         ExDev xd = x.dev;
         if (rc == UGP_OK && xd.mask) rc = mask_words(m, xd.mask, true);
         const uint8_t *masked = xd.mask;
-        xd.mask = nullptr; xd.packed = true;
+        xd.mask = nullptr; xd.packed = true; xd.scores = nullptr;
         if (rc == UGP_OK) rc = run_place(m, qs, 0, d_out.p, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, false, &xd);
         if (masked) { const int rc2 = mask_words(m, masked, false); if (rc == UGP_OK) rc = rc2; }
+        if (rc == UGP_OK && scores_by_levels) {
+            rc = run_place(m, qs, 1, nullptr, x.d_scores.p, nullptr, nullptr, nullptr, nullptr, 0, nullptr);
+            if (rc == UGP_OK && ugp::launch_scores_mask(x.d_scores.p, q->n_queries, m->flat.n_nodes, x.dev.mask, x.dev.skip, nullptr) != hipSuccess)
+                rc = fail(UGP_ERR_HIP, "masking the scores");
+        }
     } else
     if (rc == UGP_OK) rc = run_place(m, qs, 0, d_out.p, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, false, &x.dev);
     if (rc == UGP_OK && hipMemcpy(out, d_out.p, q->n_queries * sizeof(ugp_result), hipMemcpyDeviceToHost) != hipSuccess)

@@ -161,4 +161,21 @@ hipError_t launch_touched(const TouchedArgs &a, int32_t *list_best, hipStream_t 
     return hipGetLastError();
 }
 
+__global__ void k_scores_mask(int32_t *__restrict__ scores, uint64_t n_queries, uint64_t n_nodes, const uint8_t *__restrict__ mask) {
+    for (uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n_nodes; j += (uint64_t)gridDim.x * blockDim.x) {
+        if (mask[j]) continue;
+        for (uint64_t q = 0; q < n_queries; q++) scores[q * n_nodes + j] = 0;
+    }
+}
+__global__ void k_scores_skip(int32_t *__restrict__ scores, uint64_t n_queries, uint64_t n_nodes, const uint32_t *__restrict__ skip) {
+    const uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q < n_queries && skip[q] != 0xFFFFFFFFu) scores[q * n_nodes + skip[q]] = 0;
+}
+hipError_t launch_scores_mask(int32_t *scores, uint64_t n_queries, uint64_t n_nodes, const uint8_t *mask, const uint32_t *skip, hipStream_t s) {
+    if (!n_queries || !n_nodes) return hipSuccess;
+    if (mask) hipLaunchKernelGGL(k_scores_mask, dim3((uint32_t)std::min<uint64_t>((n_nodes + 255) / 256, 65536)), dim3(256), 0, s, scores, n_queries, n_nodes, mask);
+    if (skip) hipLaunchKernelGGL(k_scores_skip, dim3((uint32_t)((n_queries + 255) / 256)), dim3(256), 0, s, scores, n_queries, n_nodes, skip);
+    return hipGetLastError();
+}
+
 }  // namespace ugp
