@@ -364,15 +364,18 @@ def test_per_node_scores_by_levels_and_by_depth_first_walk(seed, n_queries, monk
 
 
 def test_host_buffer_batches_two_in_flight():
-    """ugp_place_batch_async / ugp_job_wait: batches from host buffers with two in flight give the answers of ugp_place_batch;
-    the batch's arrays may be overwritten as soon as the call returns; a third job is refused until the oldest has been waited
-    for; a batch with out-of-order rows is reported by ITS ugp_job_wait and leaves the handle usable."""
+    """ugp_place_batch_async / ugp_job_wait: batches from host buffers with as many in flight as the handle keeps on the device
+    (ugp_pipeline_depth: three by default) give the answers of ugp_place_batch; the batch's arrays may be overwritten as soon as
+    the call returns; one job more is refused until the oldest has been waited for; a batch with out-of-order rows is reported by
+    ITS ugp_job_wait and leaves the handle usable."""
     from usher_amd import synth as gsynth
     from usher_amd.placement import UgpError
     st = gsynth.SynthTree(300_000, n_sites=4000, seed=33)
     qs = [st.queries(n, seed=70 + i, max_subst=3, n_lo=0, n_hi=10, iupac_hi=2) for i, n in enumerate((1500, 600, 2600, 40))]
     batches = [QueryBatch.from_csr(q["ent_off"], q["pos"], q["ref"], q["nuc"], q["is_missing"]) for q in qs]
     pl = Placer(st.arrays)
+    depth = pl.pipeline_depth()
+    assert depth == 3
     want = [pl.place(b).copy() for b in batches]
     jobs = []
     got = {}
@@ -382,8 +385,8 @@ def test_host_buffer_batches_two_in_flight():
         scratch = QueryBatch.from_csr(b.ent_off.copy(), b.pos.copy(), b.ref.copy(), b.nuc.copy(), b.is_missing.copy())
         jobs.append((k, i, pl.place_async(scratch)))
         scratch.pos[:] = 0; scratch.nuc[:] = 0     # the rows were copied out before the call returned
-        if len(jobs) == 2:
-            with pytest.raises(UgpError):           # a third job while two are outstanding
+        if len(jobs) == depth:
+            with pytest.raises(UgpError):           # one job more than the handle keeps in flight
                 pl.place_async(batches[3])
             k0, i0, j0 = jobs.pop(0)
             got[k0] = (i0, pl.job_wait(j0))

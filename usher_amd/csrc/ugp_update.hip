@@ -178,4 +178,13 @@ hipError_t launch_scores_mask(int32_t *scores, uint64_t n_queries, uint64_t n_no
     return hipGetLastError();
 }
 
+__global__ void k_copy_words(uint32_t *__restrict__ dst, const uint32_t *__restrict__ src, uint64_t n) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) dst[i] = src[i];
+}
+hipError_t launch_copy_words(uint32_t *dst, const uint32_t *src, uint64_t n, hipStream_t s) {
+    if (!n) return hipSuccess;
+    hipLaunchKernelGGL(k_copy_words, dim3((uint32_t)std::min<uint64_t>((n + 63) / 64, 4096)), dim3(64), 0, s, dst, src, n);
+    return hipGetLastError();
+}
+
 }  // namespace ugp

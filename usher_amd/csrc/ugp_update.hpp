@@ -41,6 +41,8 @@ hipError_t launch_mask_words(const uint8_t *mask, const uint32_t *map_j, uint32_
 // rows of the batch into the dense table (zeroed by the caller) and D(bottom): one thread per row
 hipError_t launch_dense_scatter(uint8_t *dense, uint32_t n_pos, uint32_t qpad, int32_t *dbot, const int32_t *pos, const uint8_t *ref, const uint8_t *nuc,
                                 const uint8_t *is_missing, const uint32_t *ent_q, uint64_t n_ent, hipStream_t s);
+// dst[i] = src[i], i < n: a copy by a kernel on the stream (dst may be pinned host memory: see ugp_place_batch_async)
+hipError_t launch_copy_words(uint32_t *dst, const uint32_t *src, uint64_t n, hipStream_t s);
 // per-node scores of an extended search that came from the unrestricted level-by-level kernel: the nodes its mask does not admit
 // and each sample's excluded node read 0 ("not scored"), as the one-sample-per-lane kernel leaves them
 hipError_t launch_scores_mask(int32_t *scores, uint64_t n_queries, uint64_t n_nodes, const uint8_t *mask /* by BFS index, or null */,

@@ -178,8 +178,9 @@ class Placer:
         return out
 
     def place_async(self, batch: QueryBatch):
-        """ugp_place_batch_async: starts the batch and returns a job; job_wait(job) gives the same array as place().  At most two
-        jobs may be outstanding; the batch's arrays may be reused as soon as this returns."""
+        """ugp_place_batch_async: starts the batch and returns a job; job_wait(job) gives the same array as place().  At most
+        pipeline_depth() jobs may be outstanding (two for batches of more than 32,768 samples or of 128 rows per sample and more); the
+        batch's arrays may be reused as soon as this returns."""
         out = np.zeros(len(batch), dtype=RESULT_DTYPE)
         job = C.c_void_p()
         self._ck(self._L.ugp_place_batch_async(self._h, C.byref(batch.desc), _ptr(out), C.byref(job)))
