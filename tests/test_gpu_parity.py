@@ -363,6 +363,26 @@ def test_per_node_scores_by_levels_and_by_depth_first_walk(seed, n_queries, monk
         assert got.shape == want.shape and (got == want).all(), (env, np.argwhere(got != want)[:5])
 
 
+def test_score_matrix_larger_than_the_staging_buffers():
+    """-p at a size where the matrix (48 samples x 1M nodes x 4 bytes = 192 MB) leaves the device through the two pinned staging
+    buffers of copy_d2h_staged (pieces of 32 MB moved to their place by host threads while the next piece is on the link) instead of
+    one hipMemcpy: every row equals the C closed form, and equals the row of a one-sample call (a matrix below the threshold)."""
+    from usher_amd import synth as gsynth
+    st = gsynth.SynthTree(1_000_000, n_sites=8000, seed=5)
+    q = st.queries(48, seed=9, max_subst=3, n_lo=0, n_hi=20, iupac_hi=3)
+    batch = QueryBatch.from_csr(q["ent_off"], q["pos"], q["ref"], q["nuc"], q["is_missing"])
+    pl = Placer(st.arrays)
+    n = pl.info()["n_nodes"]
+    assert 48 * n * 4 >= 4 * (32 << 20)            # (the staged path's threshold)
+    got = pl.scores_per_node(batch)
+    cf = capi.ClosedFormC(capi.OracleTree(st.arrays))
+    for i in range(48):
+        assert (cf.scores(gsynth.csr_sample(q, i)) == got[i]).all(), i
+    for i in (0, 17, 47):
+        assert (pl.scores_per_node(batch.slice(i, i + 1))[0] == got[i]).all(), i
+    pl.close()
+
+
 def test_host_buffer_batches_two_in_flight():
     """ugp_place_batch_async / ugp_job_wait: batches from host buffers with as many in flight as the handle keeps on the device
     (ugp_pipeline_depth: three by default) give the answers of ugp_place_batch; the batch's arrays may be overwritten as soon as
