@@ -87,11 +87,13 @@ struct PinBuf {
     void *p = nullptr;
     size_t cap = 0;
     ~PinBuf() { if (p) (void)hipHostFree(p); }
-    int reserve(size_t n) {
+    // device_writes: a kernel stores into the buffer (results of ugp_place_batch_async) -- mapped and coherent, so that what it wrote
+    // is in host memory when its stream's event has been waited for, whatever the platform's default for pinned memory is
+    int reserve(size_t n, bool device_writes = false) {
         if (n <= cap) return UGP_OK;
         if (p) (void)hipHostFree(p);
         p = nullptr; cap = 0;
-        if (hipHostMalloc(&p, std::max<size_t>(n, 1), hipHostMallocDefault) != hipSuccess) { p = nullptr; return fail(UGP_ERR_HIP, "hipHostMalloc (staging buffer)"); }
+        if (hipHostMalloc(&p, std::max<size_t>(n, 1), device_writes ? (hipHostMallocMapped | hipHostMallocCoherent) : hipHostMallocDefault) != hipSuccess) { p = nullptr; return fail(UGP_ERR_HIP, "hipHostMalloc (staging buffer)"); }
         cap = n;
         return UGP_OK;
     }
@@ -1229,7 +1231,7 @@ int ugp_place_batch_async(ugp_mat *m, const ugp_queries *q, ugp_result *out, ugp
     if (W.done) HIP_TRY(hipEventSynchronize(W.done));
     if (int rc = qset_fill(m, q, W.job_qs, W.stream, &W.job_in)) return rc;
     HIP_TRY(W.d_job_out.reserve(q->n_queries));
-    if (int rc = W.job_out.reserve(std::max<size_t>(q->n_queries, 1) * sizeof(ugp_result) + 8)) return rc;
+    if (int rc = W.job_out.reserve(std::max<size_t>(q->n_queries, 1) * sizeof(ugp_result) + 8, true)) return rc;
     note_sharing(m, wi, use);   // (is the other set's job still on the device?)
     int rc = run_place(m, W.job_qs, 0, W.d_job_out.p, nullptr, nullptr, nullptr, nullptr, nullptr, 0, W.stream, false, nullptr, wi);
     m->sharing = false; m->share_n = 1;
