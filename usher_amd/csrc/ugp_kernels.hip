@@ -2272,7 +2272,7 @@ hipError_t launch_descend(const ugp_result *coarse_res, const uint32_t *order, u
 // again).  Samples of one bin come out in the order the scatter's atomics fall: the order is a scheduling hint, results never
 // depend on it.  (One block doing all three steps in LDS was tried first: 16 serial rounds of dependent loads per thread, slower
 // than the radix sort.)
-constexpr uint32_t LSORT_MAX_BINS = 16384;
+constexpr uint32_t LSORT_MAX_BINS = 15360;   // (60 KB of LDS for the scan, beside its 1 KB of partial sums: within the 64 KB a block gets without asking)
 __global__ void k_lsort_hist(const ugp_result *__restrict__ coarse_res, const uint32_t *__restrict__ coarse_bin, uint32_t n, uint32_t *__restrict__ bins) {
     const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
     if (q < n) atomicAdd(&bins[coarse_bin[coarse_res[q].best_j]], 1u);
