@@ -19,7 +19,9 @@ for q, ev in sorted(by_q.items(), key=lambda kv: -len(kv[1]))[:2]:
         continue
     # from the end of one main walk to the end of the next: one batch -- a pair inside the pipelined window (the trace also holds the
     # bench's other sections: pairs across their boundaries are milliseconds apart), the one of median length among those
-    pairs = sorted((ev[walks[k + 1]][1] - ev[walks[k]][1], k) for k in range(len(walks) - 1))
+    # (... and not one of the bench's host-buffer sections: no upload-side kernel between the two walks)
+    pairs = sorted((ev[walks[k + 1]][1] - ev[walks[k]][1], k) for k in range(len(walks) - 1)
+                   if not any("k_rows_prepare" in n or "k_copy_words" in n for _, _, n in ev[walks[k]:walks[k + 1]]))
     near = [p for p in pairs if p[0] < 2 * pairs[0][0]]
     k = near[len(near) // 2][1]
     a, b = walks[k], walks[k + 1]
