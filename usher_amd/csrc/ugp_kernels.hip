@@ -1766,8 +1766,19 @@ __global__ void k_gbest2(const uint32_t *__restrict__ part, uint32_t n_slices, u
                          uint32_t *__restrict__ gbest /* [n_tiles][64][4] packed */) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= per_chunk) return;
+    // (eight independent loads in flight per thread: one after the other the 64 slices were 64 round trips, 21 us of a batch's chain)
+    uint32_t m8[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) m8[j] = 0xFFFFFFFFu;
+    uint32_t k = 0;
+    for (; k + 8 <= n_slices; k += 8) {
+#pragma unroll
+        for (int j = 0; j < 8; j++) m8[j] = pk_min(m8[j], part[(uint64_t)(k + j) * per_chunk + i]);
+    }
     uint32_t m = 0xFFFFFFFFu;
-    for (uint32_t k = 0; k < n_slices; k++) m = pk_min(m, part[(uint64_t)k * per_chunk + i]);
+    for (; k < n_slices; k++) m = pk_min(m, part[(uint64_t)k * per_chunk + i]);
+#pragma unroll
+    for (int j = 0; j < 8; j++) m = pk_min(m, m8[j]);
     gbest[i] = m;
 }
 
@@ -1794,14 +1805,22 @@ __global__ void k_select(const uint32_t *__restrict__ lbest, const uint32_t *__r
         if ((uint64_t)t64 * 64 >= n_queries) continue;
         // the 64 samples of t64 are lanes (t64&7)*8 .. +8 of tile t64>>3: 32 consecutive dwords
         const uint64_t off = ((uint64_t)tile * 64 + t8 * 8) * 4;
-        const uint32_t *lb = lbest + (uint64_t)c * n_tiles * 256 + off;
-        const uint32_t *gb = gbest + off;
+        const uint4 *lb = (const uint4 *)(lbest + (uint64_t)c * n_tiles * 256 + off);   // (16-byte loads, all sixteen in flight together)
+        const uint4 *gb = (const uint4 *)(gbest + off);
+        uint4 xl[8], xg[8];
+#pragma unroll
+        for (int v = 0; v < 8; v++) { xl[v] = lb[v]; xg[v] = gb[v]; }
         bool hit = false;
-        for (uint32_t k = 0; k < 32; k++) {
-            const uint32_t x = lb[k] ^ gb[k];
-            const uint32_t q0 = t64 * 64 + (k >> 2) * 8 + (k & 3u);   // low half: nibble (k&3); high half: +4
-            if ((x & 0xFFFFu) == 0 && q0 < n_queries) hit = true;
-            if ((x >> 16) == 0 && q0 + 4 < n_queries) hit = true;
+#pragma unroll
+        for (int v = 0; v < 8; v++) {
+            const uint32_t xs[4] = {xl[v].x ^ xg[v].x, xl[v].y ^ xg[v].y, xl[v].z ^ xg[v].z, xl[v].w ^ xg[v].w};
+#pragma unroll
+            for (int w = 0; w < 4; w++) {
+                const uint32_t k = (uint32_t)(v * 4 + w), x = xs[w];
+                const uint32_t q0 = t64 * 64 + (k >> 2) * 8 + (k & 3u);   // low half: nibble (k&3); high half: +4
+                if ((x & 0xFFFFu) == 0 && q0 < n_queries) hit = true;
+                if ((x >> 16) == 0 && q0 + 4 < n_queries) hit = true;
+            }
         }
         if (hit) {
             const uint32_t idx = atomicAdd(n_items, 1u);
