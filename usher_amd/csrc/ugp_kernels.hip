@@ -979,6 +979,10 @@ __global__ void __launch_bounds__(64, TIES ? 3 : 4) k_best8(Best8Args a) {
             const uint32_t x = (home + t) & 7u;
             if (drained & (1u << x)) continue;
             const uint32_t ux = a.unit_count[x];
+            // (Every ticket comes from the counter, also a wave's first.  Reserving ticket blockIdx.x / 8 for the first pull -- to spare
+            // the start of a launch its storm of atomics, 25-50 us per wave in the unit trace -- was tried in round 4 and HANGS: a
+            // block that is scheduled late then owns a unit nobody else may take, starts after the others have seen the live-work
+            // count reach zero and released the list, cuts its unit, and its pieces land behind tickets that are already spent.)
             uint32_t v = 0xFFFFFFFFu;
             if (ux) {
                 if (lane == 0) v = atomicAdd(&a.queue[x], 1u);
