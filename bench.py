@@ -56,7 +56,8 @@ def parse_args():
     ap.add_argument("--no-overlap", action="store_true", help="time the stream-ordered ugp_place_device (one call at a time) instead of ugp_place_device_overlapped")
     ap.add_argument("--no-extra", action="store_true", help="skip the extra keys (BASELINE configs 3 and 4 on one device, the end-to-end CLI run)")
     ap.add_argument("--depth", type=int, default=0, help="overlapped calls kept on the device at a time (2..4; 0 = the library's default)")
-    ap.add_argument("--repeats", type=int, default=3, help="windows of --steps steps timed in all (the first is `value`; min / median over all are extra keys)")
+    ap.add_argument("--repeats", type=int, default=3, help="windows of --steps steps timed in all (`value` is the MEDIAN window; min / max are extra keys)")
+    ap.add_argument("--qsets", type=int, default=4, help="distinct uploaded query sets the timed loop rotates through (no step places the samples of the step before it)")
     return ap.parse_args()
 
 
@@ -121,10 +122,21 @@ def stored_profile(info, Q, packed):
             want = "ugp::k_best8" if packed else "ugp::k_place<0>"
             k = next((v for n, v in ps.get("kernels", {}).items() if n.startswith(want)), {})
             if cfg.get("nodes") == int(info["n_nodes"]) and cfg.get("queries_per_gpu") == Q and "hbm_read_bytes_per_dispatch_corrected" in k:
-                return os.path.basename(fn), k
+                # bytes of ALL kernels of one step: a kernel that runs n times per call has n x the dispatches of k_final (once per call);
+                # kernels with fewer dispatches than calls (row checks at upload, host-buffer copies) are not part of a device-resident step
+                ks = ps.get("kernels", {})
+                calls = next((v.get("full_dispatches") for n, v in ks.items() if n.startswith("ugp::k_final") or n.startswith("ugp::k_merge")), None)
+                total = None
+                if calls:
+                    total = 0.0
+                    for n, v in ks.items():
+                        d = v.get("full_dispatches") or 0
+                        if d >= calls and "hbm_read_bytes_per_dispatch_corrected" in v:
+                            total += (v["hbm_read_bytes_per_dispatch_corrected"] + v.get("hbm_write_bytes_per_dispatch", 0.0)) * (d / calls)
+                return os.path.basename(fn), k, (int(total) if total else None)
     except Exception:
         pass
-    return None, {}
+    return None, {}, None
 
 
 def main():
@@ -179,16 +191,23 @@ def main():
         kw["iupac_true"] = True
     if args.shape == "sars2":
         kw["recent"] = True
-    if args.strong:   # one global batch; this rank owns a contiguous shard of it
-        q = st.queries(args.queries, seed=args.seed * 1000 + 17, **kw)
-        lo, hi = shard_bounds(args.queries, world, rank)
-        e0, e1 = int(q["ent_off"][lo]), int(q["ent_off"][hi])
-        q = {"ent_off": q["ent_off"][lo:hi + 1] - q["ent_off"][lo], "pos": q["pos"][e0:e1], "ref": q["ref"][e0:e1], "nuc": q["nuc"][e0:e1],
-             "is_missing": q["is_missing"][e0:e1], "source": q["source"][lo:hi]}
+    # The timed loop rotates through --qsets DISTINCT query sets (all uploaded before the clock starts): no step places the samples --
+    # or walks the tree regions -- of the step before it.  Set k is drawn with its own seed; set 0 is the one the CPU baseline checks.
+    n_sets = max(1, args.qsets)
+
+    def draw(k):
+        if args.strong:   # one global batch; this rank owns a contiguous shard of it
+            qq = st.queries(args.queries, seed=args.seed * 1000 + 17 + 7919 * k, **kw)
+            lo, hi = shard_bounds(args.queries, world, rank)
+            e0, e1 = int(qq["ent_off"][lo]), int(qq["ent_off"][hi])
+            return {"ent_off": qq["ent_off"][lo:hi + 1] - qq["ent_off"][lo], "pos": qq["pos"][e0:e1], "ref": qq["ref"][e0:e1], "nuc": qq["nuc"][e0:e1],
+                    "is_missing": qq["is_missing"][e0:e1], "source": qq["source"][lo:hi]}
+        return st.queries(args.queries, seed=args.seed * 1000 + 17 + rank + 7919 * k, **kw)
+    q = draw(0)
+    if args.strong:
         total_q = args.queries
         cap = (args.queries + world - 1) // world
     else:
-        q = st.queries(args.queries, seed=args.seed * 1000 + 17 + rank, **kw)
         total_q = args.queries * world
         cap = args.queries
     if args.sort_by_source:
@@ -204,6 +223,11 @@ def main():
     batch = QueryBatch.from_csr(q["ent_off"], q["pos"], q["ref"], q["nuc"], q["is_missing"])
     qset = pl.upload(batch)
     Q = len(batch)
+    qsets = [qset]
+    for k in range(1, n_sets):
+        qk = draw(k)
+        qsets.append(pl.upload(QueryBatch.from_csr(qk["ent_off"], qk["pos"], qk["ref"], qk["nuc"], qk["is_missing"])))
+        del qk
     # Two output buffers used alternately: consecutive ugp_place_device_overlapped calls share the device, and call k + 2 is
     # ordered behind whatever the caller's stream held when call k + 1 was made -- the all-gather that reads call k's buffer
     # included (include/usher_amd.h: one call of lag).  (shards differ by at most one sample: padded to `cap`)
@@ -216,11 +240,12 @@ def main():
 
     def step():
         out = outs[n_step[0] % depth]
+        qs_k = qsets[n_step[0] % n_sets]
         n_step[0] += 1
         if args.no_overlap:
-            pl.place_device(qset, out.data_ptr(), stream)
+            pl.place_device(qs_k, out.data_ptr(), stream)
         else:
-            pl.place_device_overlapped(qset, out.data_ptr(), stream)
+            pl.place_device_overlapped(qs_k, out.data_ptr(), stream)
         if world > 1:
             tg = time.perf_counter()
             dist.all_gather_into_tensor(gathered, out.cpu() if share else out)
@@ -242,6 +267,8 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     last_out = outs[(n_step[0] - 1) % depth]
+    last_set = (n_step[0] - 1) % n_sets
+    res_last = last_out.cpu().numpy()[:Q].copy()   # (results of the timed region's last step: query set `last_set`)
     # HIP events recorded by the library on the streams its kernels ran on, summed over the timed steps
     tm = pl.timing_sum()
     assert tm["calls"] == args.steps, tm
@@ -267,8 +294,7 @@ def main():
             dist.all_gather_into_tensor(gathered, last_out.cpu() if share else last_out)
         torch.cuda.synchronize()
         gather_ms = round((time.perf_counter() - tg) * 1e3 / 5, 4)
-    res = last_out.cpu().numpy()[:Q]
-    # the same window again (--repeats - 1 times): spread of the figure; `value` stays the first window
+    # the same window again (--repeats - 1 times); `value` is the MEDIAN window, min / max beside it
     windows = [elapsed]
     for _ in range(max(0, args.repeats - 1)):
         torch.cuda.synchronize()
@@ -289,6 +315,18 @@ def main():
         windows.append(tw)
     pl.timing_sum()
     out = outs[0]
+    # every query set once through the stream-ordered entry point: set 0's results are what the host-buffer path and the CPU baseline
+    # are compared with, and the timed region's last step must have produced exactly these for ITS set
+    res = None
+    rotation_exact = True
+    for k in range(n_sets):
+        pl.place_device(qsets[k], out.data_ptr(), stream)
+        torch.cuda.synchronize()
+        rk = out.cpu().numpy()[:Q].copy()
+        if k == 0:
+            res = rk
+        if k == last_set:
+            rotation_exact = bool((rk == res_last).all())
     # The same kernels one call at a time (a synchronisation after every step), outside the timed region: in the timed region
     # two consecutive calls share the device (ugp_place_device overlaps them), so a kernel's event-bracketed duration there is
     # the duration of a kernel that has company.  Reported beside it as kernel_ms_alone / frac_alone.
@@ -298,8 +336,8 @@ def main():
     torch.cuda.synchronize()
     pl.timing_sum()
     t_alone = time.perf_counter()
-    for _ in range(n_alone):
-        pl.place_device(qset, out.data_ptr(), stream)
+    for i_alone in range(n_alone):
+        pl.place_device(qsets[i_alone % n_sets], out.data_ptr(), stream)
         torch.cuda.synchronize()
     t_alone = (time.perf_counter() - t_alone) / n_alone
     tma = pl.timing_sum()
@@ -444,16 +482,23 @@ def main():
 
     result = None
     if rank == 0:
-        ms_per_step = elapsed * 1e3 / args.steps
-        value = total_q * args.steps / elapsed
+        # `value` = the MEDIAN of the --repeats windows of K steps each (the first window is `windows.ms_per_step[0]`)
+        w_med = sorted(windows)[len(windows) // 2]
+        ms_per_step = w_med * 1e3 / args.steps
+        value = total_q * args.steps / w_med
         # roofline of the dominant kernel: algorithmic bytes per launch, SURVEY 8(d):
         # every T-sample tile makes one pass over the tree: B_tree + T * (L/2 + 16); T = 512 on the packed path
         T = 512 if packed else 64
         algo_bytes = tiles * (info["algo_tree_bytes"] + T * info["algo_tile_bytes"])
-        k_ms = place_ms / args.steps
+        # The dominant kernel's average launch duration: measured with the device to itself (one call at a time, right behind the timed
+        # region, HIP events on the launch stream) -- `kernel_ms`.  Inside the timed region up to `depth` such launches share the
+        # chip, each on its share of the resident wave slots, and a launch's event-bracketed duration there (`kernel_ms_in_region`) is
+        # that of a kernel with a third of the machine: kept as the extra key.
+        k_ms_region = place_ms / args.steps
+        k_ms = alone["place_ms"] if alone["place_ms"] > 0 else k_ms_region
         achieved = algo_bytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
         node_evals = float(Q) * (info["n_nodes"] + info["n_muts"])
-        prof_name, prof = stored_profile(info, Q, packed)
+        prof_name, prof, prof_all = stored_profile(info, Q, packed)
         traffic = int(prof["hbm_read_bytes_per_dispatch_corrected"] + prof.get("hbm_write_bytes_per_dispatch", 0)) if prof else None
         # What the counters of the stored profile say bounds the kernel: instruction issue when a pipe is busy most of the time, HBM
         # when the measured traffic is most of the peak, else the waves are waiting -- exposed memory latency.  The issue floor is
@@ -487,15 +532,23 @@ def main():
                     "valu_active_frac_measured": prof.get("valu_active_frac_measured"), "salu_busy_frac_measured": prof.get("salu_busy_frac_measured"),
                     "wave_wait_frac": prof.get("wave_wait_frac"),
                     "kernel": "k_best8" if packed else "k_place<0>", "tile_samples": T, "kernel_ms": round(k_ms, 4), "algo_bytes_per_launch": int(algo_bytes),
+                    "kernel_ms_is": "average launch duration with the device to itself (HIP events on the launch stream, %d stream-ordered calls right behind the timed region)" % n_alone,
                     # one call at a time (see above): the kernel without a second batch on the device, and that step's wall time
                     "kernel_ms_alone": round(alone["place_ms"], 4),
                     "frac_alone": round(algo_bytes / (alone["place_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if alone["place_ms"] > 0 else None,
                     "ms_per_step_alone": round(t_alone * 1e3, 3),
+                    # the same launch inside the timed region, where it shares the chip with the walks of the other batches in flight
+                    "kernel_ms_in_region": round(k_ms_region, 4),
+                    "frac_in_region": round(algo_bytes / (k_ms_region * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if k_ms_region > 0 else None,
+                    # all kernels of a step: HBM bytes by the counters of the stored profile (every kernel that runs once or twice per step,
+                    # per-dispatch bytes x dispatches per step) / this run's ms_per_step / peak
+                    "hbm_bytes_all_kernels_per_step": prof_all,
+                    "hbm_frac_all_kernels": round(prof_all / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if prof_all and ms_per_step > 0 else None,
                     # In the timed region several launches of this kernel share the chip (each on its share of the resident wave slots):
                     # a launch's duration there is that of a kernel with a third of the machine, so `frac` -- the contract's definition,
                     # bytes per launch / in-region duration -- falls when the pipeline gets deeper even as `value` rises.  Per second of
                     # chip time the kernel accounts for algo_bytes / ms_per_step:
-                    "walks_on_device_avg": round(k_ms / ms_per_step, 2) if ms_per_step > 0 else None,
+                    "walks_on_device_avg": round(k_ms_region / ms_per_step, 2) if ms_per_step > 0 else None,
                     "frac_per_chip_second": round(algo_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if ms_per_step > 0 else None,
                     "overlap": "off (--no-overlap: ugp_place_device, stream-ordered)" if args.no_overlap else "consecutive ugp_place_device_overlapped calls: %d on the device at a time (internal streams, workspace sets, output buffers)" % depth,
                     "node_plus_mut_evals_decided_per_s": round(node_evals / (k_ms * 1e-3), 1) if k_ms > 0 else 0.0,
@@ -543,11 +596,13 @@ def main():
                                       ("%d queries in total, sharded" % total_q) if args.strong else ("%d queries per GPU per step" % Q),
                                       (" (100-5000 N + 0-30 IUPAC cells each%s)" % (", every code holding the sample's own base" if args.iupac_true else "")) if args.ambiguous else ""),
                        "nodes": int(info["n_nodes"]), "queries_per_gpu": Q, "queries_total": total_q, "tile": T, "tiles": tiles, "waves_per_tile": groups,
+                       "query_sets_rotated": n_sets, "last_step_equals_stream_ordered_call": rotation_exact,
                        "parallelism": "queries sharded x%d, MAT replicated, RCCL all-gather of results" % world,
                        "rccl_ranks": world, "devices_visible": torch.cuda.device_count(),
                        "seed": args.seed, "gen_s": round(t_gen, 2), "flatten_upload_s": round(t_flat, 2)},
-            # the K-step window again, --repeats times in all: spread of `value` (which is the first window)
-            "windows": {"n": len(windows), "ms_per_step": [round(w * 1e3 / args.steps, 3) for w in windows],
+            # the K-step window --repeats times in all: `value` is the median window
+            "windows": {"n": len(windows), "value_is": "median window", "ms_per_step": [round(w * 1e3 / args.steps, 3) for w in windows],
+                        "value_first_window": round(total_q * args.steps / windows[0], 2),
                         "value_min": round(total_q * args.steps / max(windows), 2), "value_median": round(total_q * args.steps / sorted(windows)[len(windows) // 2], 2),
                         "value_max": round(total_q * args.steps / min(windows), 2)},
             # SURVEY 8(d) defines the metric with query upload and result download inside the clock: this is that figure (two
@@ -562,7 +617,8 @@ def main():
             # the host-buffer entry point -- SURVEY 8(d)'s definition of the metric -- is this:
             "host_buffer_path": host_path,
         }
-    pl.free_qset(qset)
+    for h in qsets:
+        pl.free_qset(h)
     pl.close()
     if extra is not None:
         # config 3's size: a 15M-node SARS-CoV-2-shaped tree (the public MAT is not in the image), 10,000 queries

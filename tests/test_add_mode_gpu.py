@@ -181,3 +181,59 @@ def test_usher_cli_add_mode_on_the_device_equals_the_restated_driver_loop(seed, 
     assert outs["device"]["mutation-paths.txt"] == want["mutation-paths.txt"]
     n_ties = sum(1 for l in want["placement_stats.tsv"].splitlines() if l.split("\t")[2] != "1")
     assert n_ties > 40 and len(want["placement_stats.tsv"].splitlines()) == n_new
+
+
+def test_add_mode_at_one_million_nodes_device_equals_research_and_the_oracle_on_the_edited_tree(tmp_path):
+    """the default mode at scale.  A 1M-node MAT, 1,000 sequential insertions through bin/usher-amd: the run that keeps
+    the edits on the device (one flattening, records, exclusions) writes the same files as the run that searches the whole tree again
+    for every sample (USHER_AMD_MAX_TOUCHED=0: the reference's loop, usher_common.cpp:310-792) -- and at 20 sampled steps k the tree
+    after k insertions (saved by a run over the first k samples, read back as arrays) is searched by the literal ORACLE for sample k:
+    score and number of optimal placements equal line k of placement_stats.tsv."""
+    import ctypes as C
+    import subprocess
+    from tools.time_load import host_lib, write_workload, ptr
+    from usher_amd import synth as gsynth
+    n_new = 1000
+    st = gsynth.SynthTree(1_000_000, n_sites=25000, seed=2)
+    q = st.queries(n_new, seed=9, max_subst=3, n_lo=0, n_hi=3, iupac_hi=0)
+    L = host_lib()
+    L.uh_pb_to_arrays.argtypes = [C.c_char_p] + [C.c_void_p] * 8
+    pb, vcf = str(tmp_path / "base.pb"), str(tmp_path / "new.vcf")
+    write_workload(L, st, q, n_new, pb, vcf)
+
+    def run(vcf_path, out, env, extra=()):
+        os.makedirs(out, exist_ok=True)
+        e = dict(os.environ)
+        e.pop("USHER_AMD_MAX_TOUCHED", None)
+        e.update(env)
+        r = subprocess.run([EXE, "-i", pb, "-v", vcf_path, "-d", out] + list(extra), capture_output=True, text=True, timeout=3000, env=e)
+        assert r.returncode == 0, r.stderr[-3000:]
+        return r.stderr
+
+    err = run(vcf, str(tmp_path / "device"), {"USHER_AMD_PROFILE": "1"})
+    flat = [l for l in err.splitlines() if "tree -> arrays" in l]
+    assert flat and "(1 times)" in flat[0], err[-2000:]                       # one flattening for the whole run: the device mode ran
+    run(vcf, str(tmp_path / "research"), {"USHER_AMD_MAX_TOUCHED": "0"})
+    files = ("placement_stats.tsv", "final-tree.nh")
+    got = {n: open(str(tmp_path / "device" / n)).read() for n in files}
+    for n in files:
+        assert got[n] == open(str(tmp_path / "research" / n)).read(), n
+    stats = [l.split("\t") for l in got["placement_stats.tsv"].splitlines()]
+    assert len(stats) == n_new
+    assert sum(1 for l in stats if l[2] != "1") > 100                         # multi-way ties are common
+    rng = np.random.default_rng(4)
+    threads = os.cpu_count() or 1
+    for k in sorted(rng.choice(np.arange(50, n_new), 20, replace=False).tolist()):
+        vk, dk = str(tmp_path / ("first%d.vcf" % k)), str(tmp_path / ("step%d" % k))
+        write_workload(L, st, q, k, None, vk)
+        run(vk, dk, {}, ["-o", os.path.join(dk, "step.pb")])
+        counts = (C.c_uint64 * 2)()
+        assert L.uh_pb_to_arrays(os.path.join(dk, "step.pb").encode(), counts, None, None, None, None, None, None, None) == 0
+        n, m = int(counts[0]), int(counts[1])
+        assert n >= int(st.arrays["n"]) + k                                   # k new leaves (and the internal nodes of sibling placements)
+        arr = {"n": n, "parent": np.zeros(n, np.int64), "mut_off": np.zeros(n + 1, np.int64), "mut_pos": np.zeros(m, np.int32),
+               "mut_ref": np.zeros(m, np.int8), "mut_par": np.zeros(m, np.int8), "mut_nuc": np.zeros(m, np.int8)}
+        assert L.uh_pb_to_arrays(os.path.join(dk, "step.pb").encode(), counts, ptr(arr["parent"]), ptr(arr["mut_off"]), ptr(arr["mut_pos"]), ptr(arr["mut_ref"]),
+                                 ptr(arr["mut_par"]), ptr(arr["mut_nuc"]), None) == 0
+        w = capi.OracleTree(arr).place_mt(gsynth.csr_sample(q, k), threads)
+        assert [str(w["best"]), str(w["num_best"])] == stats[k][1:3], (k, w, stats[k][:3])

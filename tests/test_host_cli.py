@@ -485,6 +485,13 @@ def test_bulk_newick_parse_equals_the_general_routine(threads, monkeypatch):
     # malformed input is refused by both; a duplicated leaf name too
     for bad in ("((A,B);", "(A,B));", "(A,B,A);"):
         assert _newick_digest(bad, 0)[0] == -1 and _newick_digest(bad, 1)[0] == -1, bad
+    # a branch length that is no number (std::stof would throw -- on a worker thread: std::terminate) is an error, not a
+    # crash, in both routines; one longer than the bulk routine's buffer is parsed in full (by the general routine)
+    for bad in ("(A:-,B:1);", "(A:1,B:e);", "((A:1,B:2):+,C);", "(A:1e99,B);"):
+        assert _newick_digest(bad, 0)[0] == -1 and _newick_digest(bad, 1)[0] == -1, bad
+    long_len = "(A:1." + "0" * 80 + "5,B:3);"
+    a, b = _newick_digest(long_len, 0), _newick_digest(long_len, 1)
+    assert a[0] > 0 and a == b
 
 
 @pytest.mark.parametrize("fixture", ["global", "syn", "big"])

@@ -257,3 +257,47 @@ def test_self_exclusion_on_the_packed_pruned_path(seed, monkeypatch):
             _same(a, i, w)
             assert int(ca[i]) == w["num_best"] and ta[i].tolist() == w["ties"][:128].tolist(), (name, i)
     fast.close(); slow.close()
+
+
+def test_self_exclusion_on_a_preorder_numbered_tree_through_the_sorted_path(monkeypatch):
+    """a tree that is not numbered breadth-first has no seed descent, and the bounds of a search that leaves
+    one node out per sample are then the coarse pass's alone -- which must not be taken from the excluded node itself.  More than
+    512 samples (the sorted, seeded, packed path), every sample the mutation set of a tree node with that node left out: the coarse
+    winner IS the excluded node for the nodes of the coarse tree.  packed == one sample per lane == the oracle."""
+    monkeypatch.setenv("UGP_COARSE_MIN_NODES", "0")
+    monkeypatch.delenv("UGP_EX_SLOW", raising=False)
+    arrays0, queries = synth.make_case(990, n_leaves=2600, n_queries=120, n_sites=150, n_ambig=(0, 0, 2))
+    arrays, new = synth.relabel_preorder(arrays0)
+    n = arrays["n"]
+    assert (np.diff(arrays["parent"][1:]) < 0).any()
+    ot = capi.OracleTree(arrays)
+    fast = Placer(arrays, chunk_nodes=48)
+    monkeypatch.setenv("UGP_EX_SLOW", "1")
+    slow = Placer(arrays, chunk_nodes=48)
+    monkeypatch.delenv("UGP_EX_SLOW")
+    rng = np.random.default_rng(17)
+    size = np.ones(n, np.int64)
+    for j in range(n - 1, 0, -1):
+        size[arrays["parent"][j]] += size[j]
+    big = np.argsort(-size)[1:80]                                   # the top of the tree: nodes of the coarse tree
+    picks = np.concatenate([rng.choice(np.arange(1, n), 500, replace=False), big])
+    samples = [_node_sample(arrays, None, int(j), "n%d" % j) for j in picks] + list(queries)
+    skip = np.concatenate([picks, rng.integers(0, n, len(queries))]).astype(np.uint32)
+    batch = QueryBatch(samples)
+    assert len(samples) > 512
+    root_muts = int(arrays["mut_off"][1])
+    a = fast.place_ex(batch, order="bfs", skip_node=skip)
+    assert fast.timing()["packed_path"] == 1
+    b = slow.place_ex(batch, order="bfs", skip_node=skip)
+    assert slow.timing()["packed_path"] == 0
+    bad = np.flatnonzero((a.view(np.int32) != b.view(np.int32)).reshape(len(samples), -1).any(axis=1))
+    assert len(bad) == 0, (bad[:10], a[bad[:3]], b[bad[:3]])
+    ta, ha, ca = fast.tied_nodes_ex(batch, 128, order="bfs", skip_node=skip)
+    tb, hb, cb = slow.tied_nodes_ex(batch, 128, order="bfs", skip_node=skip)
+    assert (ca == cb).all() and all(x.tolist() == y.tolist() for x, y in zip(ta, tb))
+    allj = np.arange(n)
+    for i in list(range(0, len(samples), 11)) + list(range(500, 579, 2)):
+        keep = allj != skip[i]
+        w = ot.place_list(samples[i], allj[keep], jidx=allj[keep], init_best=len(samples[i]["pos"]) + root_muts + 1)
+        _same(a, i, w)
+    fast.close(); slow.close()

@@ -209,6 +209,32 @@ extern "C" int uh_time_load(const char *pb, const char *vcf, double *out) {
     return 0;
 }
 
+// Test utility: a parsimony.proto file as the breadth-first arrays of ugp_tree_desc (what the oracle takes).  Call with null arrays
+// for the sizes (counts[0] = nodes, counts[1] = mutations), then with arrays of those sizes; name_of_leaf (optional, n x 24 bytes)
+// receives the first 23 characters of every node's name.
+extern "C" int uh_pb_to_arrays(const char *pb, uint64_t *counts, int64_t *parent, int64_t *mut_off, int32_t *pos, int8_t *ref, int8_t *par, int8_t *nuc,
+                               char *names24) {
+    uh::Tree T;
+    std::string err;
+    if (!uh::load_mat(pb, T, err)) { fprintf(stderr, "%s\n", err.c_str()); return 1; }
+    const std::vector<uh::Node *> bfs = T.bfs();
+    uint64_t m = 0;
+    for (const uh::Node *n : bfs) m += n->mutations.size();
+    counts[0] = bfs.size(); counts[1] = m;
+    if (!parent) return 0;
+    for (size_t j = 0; j < bfs.size(); j++) { bfs[j]->flat_index = (uint32_t)j; }
+    uint64_t k = 0;
+    for (size_t j = 0; j < bfs.size(); j++) {
+        const uh::Node *n = bfs[j];
+        parent[j] = n->parent ? (int64_t)n->parent->flat_index : -1;
+        mut_off[j] = (int64_t)k;
+        for (const uh::Mutation &mu : n->mutations) { pos[k] = mu.position; ref[k] = mu.ref_nuc; par[k] = mu.par_nuc; nuc[k] = mu.mut_nuc; k++; }
+        if (names24) { snprintf(names24 + j * 24, 24, "%s", n->id.c_str()); }
+    }
+    mut_off[bfs.size()] = (int64_t)k;
+    return 0;
+}
+
 // Test hook: parse a newick string with the general routine (bulk = 0) or the bulk one (bulk = 1) and describe the tree --
 // one line per node in depth-first order: id, parent id, level, branch length, number of children.  Returns the length
 // needed (the text is truncated to cap - 1), or -1 with the error message in `out`.

@@ -1130,10 +1130,15 @@ int run_usher(const Options &opt, Tree &T, std::vector<MissingSample> &missing, 
                 ugp_result fr = dev.res[k];
                 std::vector<std::pair<uint32_t, uint8_t>> own_list;
                 const std::vector<std::pair<uint32_t, uint8_t>> *flst = &dev.ties[k];
-                auto list_for = [&](const ugp_result &x) -> bool {   // the tie list of a flattened-tree answer that came without one
+                auto list_for = [&](ugp_result &x) -> bool {   // the tie list of a flattened-tree answer that came without one
                     FlatQueries q1;
                     q1.add(rows_of(s));
                     q1.finish();
+                    // The device lists the ties of the search as it stands NOW -- nodes rewritten since the batch was searched have left
+                    // its candidate set, and when they held the old minimum the list belongs to a higher cost.  The answer the list is
+                    // merged under is therefore taken again first, at the same exclusion state as the list.
+                    if (be.place(be.ctx, &flat.desc, flat_version_dev, &q1.desc, &x) != 0) return false;
+                    if (x.num_best <= 1) { own_list.clear(); flst = &own_list; return true; }
                     const uint32_t cap = x.num_best;
                     std::vector<uint32_t> tj(cap), tc(1);
                     std::vector<uint8_t> th(cap);

@@ -9,6 +9,7 @@
 #include <unistd.h>
 
 #include <algorithm>
+#include <cerrno>
 #include <atomic>
 #include <chrono>
 #include <cstdio>
@@ -586,6 +587,17 @@ static void split(const std::string &s, char delim, std::vector<std::string> &ou
     if (start < s.size()) out.push_back(s.substr(start));
 }
 
+// A branch length as std::stof reads it (leading number, anything behind it ignored) -- without its exceptions: the reference
+// terminates on ":-" or ":e" (mutation_annotated_tree.cpp:447-456 calls std::stof unguarded); here the loaders report an error.
+static bool parse_len(const char *text, float &out) {
+    errno = 0;
+    char *end = nullptr;
+    const float v = strtof(text, &end);
+    if (end == text || errno == ERANGE) return false;
+    out = v;
+    return true;
+}
+
 bool tree_from_newick(const std::string &nwk, Tree &T, std::string &err) {   // :415-508
     std::vector<std::string> parts;
     split(nwk, ',', parts);
@@ -593,7 +605,8 @@ bool tree_from_newick(const std::string &nwk, Tree &T, std::string &err) {   // 
     std::vector<Item> items;
     std::vector<std::vector<float>> blen(128);
     size_t level = 0;
-    auto to_len = [](const std::string &b) { return b.empty() ? -1.0f : std::stof(b); };
+    bool bad_len = false;
+    auto to_len = [&](const std::string &b) { float v = -1.0f; if (!b.empty() && !parse_len(b.c_str(), v)) bad_len = true; return v; };
     for (const std::string &s : parts) {
         Item it;
         bool stop = false, branch_start = false;
@@ -612,7 +625,7 @@ bool tree_from_newick(const std::string &nwk, Tree &T, std::string &err) {   // 
         blen[level].push_back(to_len(branch));
         items.push_back(std::move(it));
     }
-    if (level != 0) { err = "incorrect Newick format"; return false; }
+    if (level != 0 || bad_len) { err = "incorrect Newick format"; return false; }
     T.all_nodes.reserve(items.size() * 2 + 16);
     std::vector<size_t> head(blen.size(), 0);
     std::vector<Node *> stack;
@@ -690,24 +703,33 @@ bool tree_from_newick_bulk(const char *nwk, size_t len, Tree &T, std::string &er
     // pass 2: the branch lengths an item pushes, in order (the state machine of tree_from_newick, quirks included:
     // `branch` survives a ')' that is not followed by a new ':')
     std::vector<float> pushes(n_push);
+    std::atomic<int> len_err{0};   // 1: a branch length that is no number; 2: one longer than the buffer (left to the general routine)
     parallel_for(n_items, [&](uint64_t b, uint64_t e, unsigned) {
         char buf[64];
         for (uint64_t i = b; i < e; i++) {
             float *out = &pushes[push_off[i]];
             size_t bl = 0;
             bool has = false, branch_start = false;
-            auto val = [&]() -> float { if (!has || bl == 0) return -1.0f; buf[std::min<size_t>(bl, sizeof buf - 1)] = 0; return std::stof(buf); };
+            auto val = [&]() -> float {
+                if (!has || bl == 0) return -1.0f;
+                buf[bl] = 0;
+                float v = -1.0f;
+                if (!parse_len(buf, v)) len_err = 1;
+                return v;
+            };
             for (size_t k = start[i], se = start[i + 1] - 1; k < se; k++) {
                 const char c = nwk[k];
                 if (c == ':') { bl = 0; has = true; branch_start = true; }
                 else if (c == '(') {}
                 else if (c == ')') { *out++ = val(); branch_start = false; }
-                else if (branch_start && (isdigit((unsigned char)c) || c == '.' || c == 'e' || c == 'E' || c == '-' || c == '+')) { if (bl < sizeof buf - 1) buf[bl++] = c; }
+                else if (branch_start && (isdigit((unsigned char)c) || c == '.' || c == 'e' || c == 'E' || c == '-' || c == '+')) { if (bl < sizeof buf - 1) buf[bl++] = c; else if (!len_err) len_err = 2; }
                 else if (has) { /* a character that does not belong to a number: tree_from_newick skips it */ }
             }
             *out++ = val();
         }
     }, 4096);
+    if (len_err == 1) { err = "incorrect Newick format"; return false; }
+    if (len_err == 2) return tree_from_newick(std::string(nwk, len), T, err);
     lap("branch lengths");
     // sequential: the node stack -> parent and branch length of every node, children counts
     std::vector<uint32_t> parent(n_nodes);

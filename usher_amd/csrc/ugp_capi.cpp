@@ -938,8 +938,10 @@ static int upload_flat(const HostFlat &hf, int device, ugp_mat **out) {
             if ((e = m->d_coarse_bin.upload(bin)) != hipSuccess) return bail(e, "upload coarse table");
             m->n_coarse_bins = (uint32_t)bin.size();
         }
+        // (always: the seeds of a search that leaves one node out per sample compare the coarse winner with that node, k_seed_ub --
+        // also on a tree that is not numbered breadth-first, where the descent below does not run)
+        if ((e = m->d_coarse2bfs.upload(hf.coarse2bfs)) != hipSuccess) return bail(e, "upload coarse table");
         if (!hf.node_pair.empty()) {
-            if ((e = m->d_coarse2bfs.upload(hf.coarse2bfs)) != hipSuccess) return bail(e, "upload coarse table");
             m->wide_descent = getenv("UGP_DESCENT_LANES") ? atoi(getenv("UGP_DESCENT_LANES")) > 16 : hf.wide_descent;
         }
     }
@@ -1224,7 +1226,11 @@ int ugp_place_batch_async(ugp_mat *m, const ugp_queries *q, ugp_result *out, ugp
     const int depth = std::max(2, std::min(kMaxSets, (int)m->knobs.depth));
     const uint64_t n_rows = q->n_queries ? q->ent_off[q->n_queries] - q->ent_off[0] : 0;
     const int use = (q->n_queries > 32768 || n_rows > q->n_queries * 128) ? 2 : depth;
-    const int wi = m->next_job % use;
+    // the next free set from the cursor on (jobs of different lengths cycle through different numbers of sets: a long job resets
+    // the cursor of the short ones, and the set behind it may still hold a job although fewer than `use` are outstanding)
+    int wi = -1;
+    for (int i = 0; i < use && wi < 0; i++) if (!m->work[(m->next_job + i) % use].job_busy) wi = (m->next_job + i) % use;
+    if (wi < 0) return fail(UGP_ERR_INVALID, "as many jobs as the handle keeps in flight (ugp_pipeline_depth; two for long batches) are outstanding: ugp_job_wait the oldest first");
     ugp_mat::Work &W = m->work[wi];
     if (W.job_busy) return fail(UGP_ERR_INVALID, "as many jobs as the handle keeps in flight (ugp_pipeline_depth) are outstanding: ugp_job_wait the oldest first");
     if (!W.stream) HIP_TRY(hipStreamCreateWithFlags(&W.stream, hipStreamNonBlocking));
@@ -1542,6 +1548,9 @@ bool ex_packs(const ugp_mat *m, const ugp_place_opts *o) {
     return true;
 }
 int mask_words(ugp_mat *m, const uint8_t *d_mask, bool set) {
+    // (the unmask pass clears the "no candidate" bit of every node outside the mask, also one that ugp_mat_update set for good:
+    // a handle with exclusions of its own never comes here -- ex_packs -- and this keeps it so)
+    if (m->upd.n_excluded) return fail(UGP_ERR_UNSUPPORTED, "node masks on the packed path need a handle without ugp_mat_update exclusions");
     ugp_mat *trees[2] = {m, m->coarse};
     for (ugp_mat *t : trees) {
         if (!t) continue;
@@ -1704,19 +1713,18 @@ int ugp_mat_update(ugp_mat *m, const ugp_touched *recs, const uint32_t *retired,
     if (int rc = drain(m)) return rc;
     try {
         // retired records
-        if (n_retired) {
-            for (uint64_t i = 0; i < n_retired; i++) if (retired[i] >= U.n_rec) return fail(UGP_ERR_INVALID, "retired record id out of range");
-            std::vector<uint32_t> pos(retired, retired + n_retired);
-            HIP_TRY(U.d_tmp.upload(pos));
-            // (alive is a byte per record: clear it through the word that holds it)
+        // (everything is validated before anything is committed: a call that fails leaves the handle as it was)
+        for (uint64_t i = 0; i < n_retired; i++) if (retired[i] >= U.n_rec) return fail(UGP_ERR_INVALID, "retired record id out of range");
+        auto retire = [&]() -> int {   // (alive is a byte per record)
             for (uint64_t i = 0; i < n_retired; i++) HIP_TRY(hipMemsetAsync(U.d_alive.p + retired[i], 0, 1, nullptr));
-        }
-        if (!n_new) { HIP_TRY(hipStreamSynchronize(nullptr)); return UGP_OK; }
+            return UGP_OK;
+        };
+        if (!n_new) { if (int rc = retire()) return rc; HIP_TRY(hipStreamSynchronize(nullptr)); return UGP_OK; }
         const uint64_t n_ent = recs->ent_off[n_new];
         if (n_ent && (!recs->pos || !recs->allele || !recs->prev || !recs->ref)) return fail(UGP_ERR_INVALID, "null entry arrays");
         std::vector<ugp::TouchedRec> hr(n_new);
         std::vector<ugp::TouchedEnt> he(n_ent);
-        std::vector<uint32_t> p8, pr, pt, c8, cr, ct;
+        std::vector<uint32_t> p8, pr, pt, c8, cr, ct, new_excl;
         auto one_hot = [](uint8_t a) { return a == 1 || a == 2 || a == 4 || a == 8; };
         for (uint64_t i = 0; i < n_new; i++) {
             const uint64_t b = recs->ent_off[i], e = recs->ent_off[i + 1];
@@ -1746,9 +1754,11 @@ int ugp_mat_update(ugp_mat *m, const ugp_touched *recs, const uint32_t *retired,
                     }
                 }
             }
-            U.n_excluded++;
-            U.excluded_j.push_back(j);
+            new_excl.push_back(j);
         }
+        if (int rc = retire()) return rc;
+        U.n_excluded += new_excl.size();
+        U.excluded_j.insert(U.excluded_j.end(), new_excl.begin(), new_excl.end());
         HIP_TRY(U.d_rec.grow_keep(U.n_rec + n_new, U.n_rec));
         HIP_TRY(U.d_alive.grow_keep(U.n_rec + n_new, U.n_rec));
         HIP_TRY(U.d_ent.grow_keep(U.n_ent + n_ent, U.n_ent));

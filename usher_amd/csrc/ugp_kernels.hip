@@ -1957,7 +1957,9 @@ __global__ void k_seed_ub(const ugp_result *__restrict__ coarse_res, const uint3
         uint32_t v = b < 0 || b > 0x7F7F ? 0x7F7Fu : (uint32_t)b;
         // (a search that leaves one node out for this sample, ugp_place_opts::skip_node: the coarse best cost is a bound only when
         // some other node attains it -- unknown when the coarse winner is that very node)
-        if (skip && skip[order[q]] != 0xFFFFFFFFu && coarse_res[order[q]].best_j != 0xFFFFFFFFu && coarse2bfs[coarse_res[order[q]].best_j] == skip[order[q]]) v = 0x7F7Fu;
+        // (without the coarse -> caller index map nothing is known about the winner: no seed for such a sample)
+        if (skip && skip[order[q]] != 0xFFFFFFFFu && coarse_res[order[q]].best_j != 0xFFFFFFFFu &&
+            (!coarse2bfs || coarse2bfs[coarse_res[order[q]].best_j] == skip[order[q]])) v = 0x7F7Fu;
         return refined ? min(v, refined[q]) : v;   // (the descent below: also the cost of a real eligible node)
     };
     ub[i] = val(slot) | (val(slot + 4) << 16);
@@ -2269,7 +2271,7 @@ hipError_t launch_seed_ub(const ugp_result *coarse_res, const uint32_t *order, u
                           const uint32_t *refined, uint32_t *dbottom, uint32_t pad_d, const uint32_t *skip, const uint32_t *coarse2bfs, hipStream_t s) {
     const uint32_t n_words = n_tiles512 * 256;
     hipLaunchKernelGGL(k_seed_ub, dim3((n_words + 63) / 64), dim3(64), 0, s, coarse_res, order, n_queries, n_words, ub, refined, dbottom, pad_d,
-                       coarse2bfs ? skip : nullptr, coarse2bfs);
+                       skip, coarse2bfs);
     return hipGetLastError();
 }
 
