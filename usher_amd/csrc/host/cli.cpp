@@ -217,6 +217,7 @@ extern "C" int uh_pb_to_arrays(const char *pb, uint64_t *counts, int64_t *parent
     uh::Tree T;
     std::string err;
     if (!uh::load_mat(pb, T, err)) { fprintf(stderr, "%s\n", err.c_str()); return 1; }
+    if (!T.condensed_nodes.empty()) T.uncondense_leaves();   // (a MAT is saved with identical sequences condensed; the search runs on the full tree)
     const std::vector<uh::Node *> bfs = T.bfs();
     uint64_t m = 0;
     for (const uh::Node *n : bfs) m += n->mutations.size();

@@ -660,9 +660,13 @@ int run_place(ugp_mat *m, ugp_qset *qs, int mode, ugp_result *d_out, int32_t *d_
             // (not when two calls share the device: the grids are halved then, and the LDS is better spent on resident waves --
             // 65,536 samples per call, pipelined: 10.5 M/s with, 11.0 M/s without)
             b.lds_bits = (!b.stats && (size_t)active_words * 4 <= 4096 && n_tiles512 >= 64 && !m->sharing) ? 1u : 0u;
-            if (K.lds_bits >= 0) b.lds_bits = (!b.stats && (size_t)active_words * 4 <= 4096 && K.lds_bits != 0) ? 1u : 0u;
-            const size_t lds_bytes = (size_t)b.lds_slots * 64 * 16 + (b.lds_bits ? (((size_t)active_words * 4 + 15) & ~(size_t)15) : 0);
-            const int variant = coarse_only ? 2 : (b.lds_bits ? 1 : 0);   // (the kernel launch_best8 will pick)
+            // Batches with thousands of N cells per sample (their tiles come from the N masks: nmi >= 0): every site row of every tile is
+            // live, the bitmap says "fetch the row" for every word -- the variant without a bitmap saves each restart a dependent round
+            // trip and each group a load (round 5; exact for any batch: a site's own row is always right, the constant row is the shortcut)
+            if (nmi >= 0 && !b.stats) b.lds_bits = 2u;
+            if (K.lds_bits >= 0) b.lds_bits = b.stats ? 0u : (K.lds_bits == 2 ? 2u : (((size_t)active_words * 4 <= 4096 && K.lds_bits != 0) ? 1u : 0u));
+            const size_t lds_bytes = (size_t)b.lds_slots * 64 * 16 + (b.lds_bits == 1 ? (((size_t)active_words * 4 + 15) & ~(size_t)15) : 0);
+            const int variant = coarse_only ? (b.lds_bits == 2 ? 4 : 2) : (b.lds_bits == 2 ? 3 : (b.lds_bits ? 1 : 0));   // (the kernel launch_best8 will pick)
             if (m->occ_lds != lds_bytes || m->occ_variant != variant) {
                 HIP_TRY(hipDeviceGetAttribute(&m->n_cu, hipDeviceAttributeMultiprocessorCount, m->device));
                 HIP_TRY(ugp::best8_occupancy(lds_bytes, variant, &m->occ_per_cu));

@@ -930,7 +930,10 @@ __device__ __forceinline__ uint32_t psub(uint32_t a, uint32_t b) { return a - b;
 // holds the samples' global minima; the samples of the tile whose minimum lies elsewhere take no part in the far tests (and tie with
 // nothing: their costs in this chunk exceed their minimum); where a node's cost equals a sample's minimum -- a rare, uniform branch -- the node
 // is found from its stream position and counted for that sample (a.tie_cnt, a.tie_key: what k_ties computes one sample per lane).
-template <bool STATS, bool LBITS, bool ARG, bool TIES>   // STATS: per-unit accounting for tuning (UGP_STATS); off in production, it costs SGPRs
+// LBITS == 2 (round 5): no bitmap at all -- every mutation word fetches its site's own row.  For batches whose tiles have (almost) every
+// row live -- thousands of N cells per sample: BASELINE config 5 -- the constant-row shortcut never applies, and the bitmap costs every
+// restart a dependent round trip and every group a load for nothing.
+template <bool STATS, int LBITS, bool ARG, bool TIES>   // STATS: per-unit accounting for tuning (UGP_STATS); off in production, it costs SGPRs
 __global__ void __launch_bounds__(64, TIES ? 3 : 4) k_best8(Best8Args a) {
     extern __shared__ __attribute__((aligned(16))) u32x4 slots8[];   // the hot saved slots: [lds_slots][64] x 16 B of D (the 8 B of B per lane and slot are in registers)
     const uint32_t lane = threadIdx.x;
@@ -1456,7 +1459,7 @@ __global__ void __launch_bounds__(64, TIES ? 3 : 4) k_best8(Best8Args a) {
     // (s_waitcnt vmcnt(N) with the younger loads still in flight).
     const uint32_t *abm = a.active + (uint64_t)tile * a.active_words;
     __attribute__((address_space(3))) uint32_t *lbits = (__attribute__((address_space(3))) uint32_t *)((__attribute__((address_space(3))) char *)slots8 + a.lds_slots * 1024u);
-    if (LBITS && bits_tile != tile) {   // (one coalesced copy per change of tile, in flight together with the unit's other first loads)
+    if (LBITS == 1 && bits_tile != tile) {   // (one coalesced copy per change of tile, in flight together with the unit's other first loads)
         for (uint32_t i = lane; i < a.active_words; i += 64u) lbits[i] = abm[i];
         bits_tile = tile;
         __syncthreads();   // (one wave per block: orders the writes before the other lanes' reads)
@@ -1484,7 +1487,8 @@ __global__ void __launch_bounds__(64, TIES ? 3 : 4) k_best8(Best8Args a) {
         };
         auto load_bits = [&](uint32_t wv) -> uint32_t {     // per lane: bitmap dword of its word's site
             const uint32_t site = (wv & H_TAG) ? 0u : (wv & 0x3FFFFFu);
-            return LBITS ? lbits[site >> 5] : abm[site >> 5];
+            if (LBITS == 2) return 0xFFFFFFFFu;
+            return LBITS == 1 ? lbits[site >> 5] : abm[site >> 5];
         };
         // Per-lane decoding of a group (lane k of every 8 holds word k): byte offset of the word's table row -- the
         // site's own row if some sample of the tile is non-reference there, else the constant row of the site's
@@ -2297,32 +2301,29 @@ hipError_t launch_descend(const ugp_result *coarse_res, const uint32_t *order, u
 // again).  Samples of one bin come out in the order the scatter's atomics fall: the order is a scheduling hint, results never
 // depend on it.  (One block doing all three steps in LDS was tried first: 16 serial rounds of dependent loads per thread, slower
 // than the radix sort.)
-constexpr uint32_t LSORT_MAX_BINS = 15360;   // (60 KB of LDS for the scan, beside its 1 KB of partial sums: within the 64 KB a block gets without asking)
+constexpr uint32_t LSORT_MAX_BINS = 15360;   // (60 KB of LDS for the scan: within the 64 KB a block gets without asking)
 __global__ void k_lsort_hist(const ugp_result *__restrict__ coarse_res, const uint32_t *__restrict__ coarse_bin, uint32_t n, uint32_t *__restrict__ bins) {
     const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
     if (q < n) atomicAdd(&bins[coarse_bin[coarse_res[q].best_j]], 1u);
 }
-__global__ void __launch_bounds__(256) k_lsort_scan(uint32_t *__restrict__ bins, uint32_t n_bins) {
+// (one wave: next to the persistent walks of the batches in front a CU has room for one more wave, and a four-wave block waits for a
+// whole CU to drain -- 60 us on average, 906 us at worst in the round-4 trace, for 8 us of work.  Every lane owns a run of bins; the
+// partial sums are scanned across the lanes with DPP-free shuffles.)
+__global__ void __launch_bounds__(64) k_lsort_scan(uint32_t *__restrict__ bins, uint32_t n_bins) {
     extern __shared__ uint32_t lb[];   // [n_bins]: the counters are staged through LDS -- every global access coalesced and independent
-    __shared__ uint32_t part[256];     // (a thread summing its run of bins straight from global memory was 20 dependent round trips: 77 us)
     const uint32_t t = threadIdx.x;
-    for (uint32_t b = t; b < n_bins; b += 256u) lb[b] = bins[b];
+    for (uint32_t b = t; b < n_bins; b += 64u) lb[b] = bins[b];
     __syncthreads();
-    const uint32_t per = (n_bins + 255u) / 256u, b0 = min(t * per, n_bins), b1 = min(b0 + per, n_bins);   // every thread owns a run of bins
+    const uint32_t per = (n_bins + 63u) / 64u, b0 = min(t * per, n_bins), b1 = min(b0 + per, n_bins);   // every lane owns a run of bins
     uint32_t sum = 0;
     for (uint32_t b = b0; b < b1; b++) sum += lb[b];
-    part[t] = sum;
-    __syncthreads();
-    for (uint32_t o = 1; o < 256u; o <<= 1) {   // (Hillis-Steele over the partial sums)
-        const uint32_t v = t >= o ? part[t - o] : 0u;
-        __syncthreads();
-        part[t] += v;
-        __syncthreads();
-    }
-    uint32_t run = part[t] - sum;
+    uint32_t inc = sum;   // inclusive scan over the 64 lanes
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const uint32_t v = __shfl_up(inc, o); if ((int)t >= o) inc += v; }
+    uint32_t run = inc - sum;
     for (uint32_t b = b0; b < b1; b++) { const uint32_t c = lb[b]; lb[b] = run; run += c; }
     __syncthreads();
-    for (uint32_t b = t; b < n_bins; b += 256u) bins[b] = lb[b];
+    for (uint32_t b = t; b < n_bins; b += 64u) bins[b] = lb[b];
 }
 __global__ void k_lsort_scatter(const ugp_result *__restrict__ coarse_res, const uint32_t *__restrict__ coarse2dfs, const uint32_t *__restrict__ coarse_bin,
                                 uint32_t n, uint32_t *__restrict__ bins, uint32_t *__restrict__ keys_sorted, uint32_t *__restrict__ order,
@@ -2341,7 +2342,7 @@ hipError_t launch_locality_sort(const ugp_result *coarse_res, const uint32_t *co
         hipError_t e = hipMemsetAsync(bins, 0, (size_t)n_bins * sizeof(uint32_t), s);
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL(k_lsort_hist, dim3((n + 63) / 64), dim3(64), 0, s, coarse_res, coarse_bin, n, bins);
-        hipLaunchKernelGGL(k_lsort_scan, dim3(1), dim3(256), (size_t)n_bins * sizeof(uint32_t), s, bins, n_bins);
+        hipLaunchKernelGGL(k_lsort_scan, dim3(1), dim3(64), (size_t)n_bins * sizeof(uint32_t), s, bins, n_bins);
         hipLaunchKernelGGL(k_lsort_scatter, dim3((n + 63) / 64), dim3(64), 0, s, coarse_res, coarse2dfs, coarse_bin, n, bins, keys_sorted, order, slot_of);
         return hipGetLastError();
     }
@@ -2460,21 +2461,25 @@ hipError_t launch_merge(const uint32_t *part_best, const uint32_t *part_cnt, con
 // variant: 0 = the main walk, 1 = with the active-row bitmap in LDS, 2 = the coarse pass (records which node set each minimum) --
 // their register and LDS needs differ, and the persistent grid and its cold-slot scratch are sized from this number.
 hipError_t best8_occupancy(size_t lds_bytes, int variant, int *per_cu) {
-    if (variant == 1) return hipOccupancyMaxActiveBlocksPerMultiprocessor(per_cu, k_best8<false, true, false, false>, 64, lds_bytes);
-    if (variant == 2) return hipOccupancyMaxActiveBlocksPerMultiprocessor(per_cu, k_best8<false, false, true, false>, 64, lds_bytes);
-    return hipOccupancyMaxActiveBlocksPerMultiprocessor(per_cu, k_best8<false, false, false, false>, 64, lds_bytes);
+    if (variant == 1) return hipOccupancyMaxActiveBlocksPerMultiprocessor(per_cu, k_best8<false, 1, false, false>, 64, lds_bytes);
+    if (variant == 2) return hipOccupancyMaxActiveBlocksPerMultiprocessor(per_cu, k_best8<false, 0, true, false>, 64, lds_bytes);
+    if (variant == 3) return hipOccupancyMaxActiveBlocksPerMultiprocessor(per_cu, k_best8<false, 2, false, false>, 64, lds_bytes);
+    if (variant == 4) return hipOccupancyMaxActiveBlocksPerMultiprocessor(per_cu, k_best8<false, 2, true, false>, 64, lds_bytes);
+    return hipOccupancyMaxActiveBlocksPerMultiprocessor(per_cu, k_best8<false, 0, false, false>, 64, lds_bytes);
 }
 
 // Persistent grid of `blocks` one-wave workgroups (the caller sizes a.cold for exactly that many).
 hipError_t launch_best8(const Best8Args &a, uint32_t blocks, hipStream_t s) {
     const size_t lds = (size_t)a.lds_slots * 64 * 16;   // the D rows of the hot slots (their B halves live in registers)
 #ifdef UGP_EXPERIMENTS   // (the statistics build of the walk and phase 2 as a mode of it exist only in libusher_amd_exp.so)
-    if (a.tie_cnt) { hipLaunchKernelGGL((k_best8<false, false, false, true>), dim3(blocks), dim3(64), lds, s, a); return hipGetLastError(); }   // (phase 2)
-    if (a.stats && !a.lpos) { hipLaunchKernelGGL((k_best8<true, false, false, false>), dim3(blocks), dim3(64), lds, s, a); return hipGetLastError(); }
+    if (a.tie_cnt) { hipLaunchKernelGGL((k_best8<false, 0, false, true>), dim3(blocks), dim3(64), lds, s, a); return hipGetLastError(); }   // (phase 2)
+    if (a.stats && !a.lpos) { hipLaunchKernelGGL((k_best8<true, 0, false, false>), dim3(blocks), dim3(64), lds, s, a); return hipGetLastError(); }
 #endif
-    if (a.lpos) hipLaunchKernelGGL((k_best8<false, false, true, false>), dim3(blocks), dim3(64), lds, s, a);   // (the coarse pass; no statistics there)
-    else if (a.lds_bits) hipLaunchKernelGGL((k_best8<false, true, false, false>), dim3(blocks), dim3(64), lds + (((size_t)a.active_words * 4 + 15) & ~(size_t)15), s, a);
-    else hipLaunchKernelGGL((k_best8<false, false, false, false>), dim3(blocks), dim3(64), lds, s, a);
+    if (a.lpos && a.lds_bits == 2) hipLaunchKernelGGL((k_best8<false, 2, true, false>), dim3(blocks), dim3(64), lds, s, a);   // (the coarse pass of a batch whose rows are all live)
+    else if (a.lpos) hipLaunchKernelGGL((k_best8<false, 0, true, false>), dim3(blocks), dim3(64), lds, s, a);   // (the coarse pass; no statistics there)
+    else if (a.lds_bits == 2) hipLaunchKernelGGL((k_best8<false, 2, false, false>), dim3(blocks), dim3(64), lds, s, a);
+    else if (a.lds_bits) hipLaunchKernelGGL((k_best8<false, 1, false, false>), dim3(blocks), dim3(64), lds + (((size_t)a.active_words * 4 + 15) & ~(size_t)15), s, a);
+    else hipLaunchKernelGGL((k_best8<false, 0, false, false>), dim3(blocks), dim3(64), lds, s, a);
     return hipGetLastError();
 }
 

@@ -55,7 +55,7 @@ struct Best8Args {
     uint32_t *dyn_ctl;         // head, tail, active and waiting waves of the shared list of split-off units (one 128-byte line each)
     unsigned long long *dyn_units;   // [dyn_cap] {epoch:11 | own region:1 | tile:12 | c1:20 | c0:20}: an entry counts once it carries this launch's epoch
     uint32_t dyn_cap, dyn_epoch;
-    uint32_t lds_bits;         // the kernel variant that keeps the tile's active-row bitmap in LDS
+    uint32_t lds_bits;         // 1: the kernel variant that keeps the tile's active-row bitmap in LDS; 2: the variant without a bitmap (every word fetches its own row)
     uint32_t no_pre_records;   // the preamble replay ignores its pruning records (units longer than their jump field reaches)
     uint32_t split_heavy;      // the same for the units of the tiles' own regions (dense: both halves are real work)
     uint32_t split_dense;      // ... and only a unit that closed at most this many chunks since its last look is cut
@@ -86,7 +86,7 @@ constexpr uint32_t SCORES_SB = 32;   // samples per step of k_scores_level (a mu
 hipError_t launch_scores_levels(const uint32_t *node_pair, const uint32_t *parent, const uint32_t *stream, const uint32_t *table, uint32_t n_sites,
                                 const uint32_t *dbottom, const uint32_t *level_off, uint32_t n_levels, void *d_a, void *d_b, bool d16, uint32_t d_stride,
                                 uint32_t qpad, uint32_t n_queries, uint64_t n_nodes, int32_t *scores, uint32_t block /* 0: default */, hipStream_t s);
-hipError_t best8_occupancy(size_t lds_bytes, int variant /* 0 main, 1 LDS bitmap, 2 coarse pass */, int *per_cu);
+hipError_t best8_occupancy(size_t lds_bytes, int variant /* 0 main, 1 LDS bitmap, 2 coarse pass, 3 / 4 main / coarse without a bitmap */, int *per_cu);
 hipError_t launch_best8(const Best8Args &a, uint32_t blocks, hipStream_t s);
 // a.n_tiles = number of 64-sample tiles; lbest/gbest in the packed 512-tile layout
 constexpr uint32_t GBEST_SLICES = 64;   // chunk-axis slices of the global-minimum reduction
