@@ -183,7 +183,7 @@ def main():
     if world > 1:
         dist.barrier()   # (every rank starts its flattening at the same time: what an N-rank launch costs, not what a lone rank would)
     t0 = time.time()
-    pl = Placer(st.arrays, device=dev_index, experiments=bool(os.environ.get("UGP_STATS")))   # (UGP_STATS: the instrumented build, libusher_amd_exp.so)
+    pl = Placer(st.arrays, device=dev_index, experiments=bool(os.environ.get("UGP_STATS") or os.environ.get("BENCH_EXP_LIB")))   # (UGP_STATS / BENCH_EXP_LIB: the build with the experiments, libusher_amd_exp.so)
     t_flat = time.time() - t0
     info = pl.info()
     kw = dict(n_lo=100, n_hi=5000, iupac_hi=30) if args.ambiguous else {}
@@ -463,10 +463,13 @@ def main():
             write_workload(host_lib(), st, qc, nq_cli, os.path.join(dcli, "base.pb"), os.path.join(dcli, "q.vcf"))
             tw = time.time() - tw
             exe = os.path.join(ROOT, "usher_amd", "bin", "usher-amd")
-            tc = time.perf_counter()
-            rr = subprocess.run([exe, "-i", os.path.join(dcli, "base.pb"), "-v", os.path.join(dcli, "q.vcf"), "-n", "-d", os.path.join(dcli, "out"), "--device", str(dev_index)],
-                                capture_output=True, text=True, env=dict(os.environ, USHER_AMD_PROFILE="1"))
-            tc = time.perf_counter() - tc
+
+            def cli(pb_name, out_name):
+                t_ = time.perf_counter()
+                r_ = subprocess.run([exe, "-i", os.path.join(dcli, pb_name), "-v", os.path.join(dcli, "q.vcf"), "-n", "-d", os.path.join(dcli, out_name), "--device", str(dev_index)],
+                                    capture_output=True, text=True, env=dict(os.environ, USHER_AMD_PROFILE="1"))
+                return r_, time.perf_counter() - t_
+            rr, tc = cli("base.pb", "out")
             lines = open(os.path.join(dcli, "out", "placement_stats.tsv")).read().splitlines() if rr.returncode == 0 else []
             # the same samples through the library (this process): score and number of optimal placements per sample
             bq = QueryBatch.from_csr(qc["ent_off"], qc["pos"], qc["ref"], qc["nuc"], qc["is_missing"])
@@ -475,7 +478,19 @@ def main():
             extra["cli_end_to_end"] = {"command": "usher-amd -i base.pb -v q.vcf -n -d out", "nodes": int(info["n_nodes"]), "queries": nq_cli, "exit_code": rr.returncode,
                                        "wall_s": round(tc, 3), "placements_per_s": round(nq_cli / tc, 1), "stats_equal_library_results": bool(same),
                                        "pb_bytes": os.path.getsize(os.path.join(dcli, "base.pb")), "vcf_bytes": os.path.getsize(os.path.join(dcli, "q.vcf")),
-                                       "write_inputs_s": round(tw, 2), "profile": [l for l in rr.stderr.splitlines() if l.startswith("[usher-amd profile]") and ":" not in l.split("]", 1)[1][:12]][:8]}
+                                       "write_inputs_s": round(tw, 2), "profile": [l for l in rr.stderr.splitlines() if l.startswith("[usher-amd profile]") and ":" not in l.split("]", 1)[1][:12]][:10]}
+            # ... and from the gzip-compressed MAT (the public SARS-CoV-2 MAT ships as .pb.gz, mutation_annotated_tree.cpp:522-547)
+            try:
+                tz = time.time()
+                subprocess.run(["gzip", "-1", "-k", os.path.join(dcli, "base.pb")], check=True)
+                tz = time.time() - tz
+                rz, tcz = cli("base.pb.gz", "outz")
+                same_z = rz.returncode == 0 and all(open(os.path.join(dcli, "outz", n)).read() == open(os.path.join(dcli, "out", n)).read() for n in ("placement_stats.tsv", "final-tree.nh"))
+                extra["cli_end_to_end_gz"] = {"command": "usher-amd -i base.pb.gz -v q.vcf -n -d out", "exit_code": rz.returncode, "wall_s": round(tcz, 3), "over_plain": round(tcz / tc, 3) if tc > 0 else None,
+                                              "pb_gz_bytes": os.path.getsize(os.path.join(dcli, "base.pb.gz")), "gzip_s": round(tz, 2), "outputs_equal_plain_run": bool(same_z),
+                                              "profile": [l for l in rz.stderr.splitlines() if l.startswith("[usher-amd profile] load")][:8]}
+            except Exception as ex:
+                extra["cli_end_to_end_gz"] = {"error": repr(ex)[:300]}
             shutil.rmtree(dcli, ignore_errors=True)
         except Exception as ex:   # (the extra key must never cost the bench line)
             extra["cli_end_to_end"] = {"error": repr(ex)[:300]}

@@ -120,6 +120,11 @@ typedef struct ugp_timing {
     float reserved2;
 } ugp_timing;
 
+/* Optional: bring up the HIP runtime and the context of `device` now (what the first ugp_mat_create on that device would pay: a few
+ * tenths of a second) -- e.g. on a thread of its own while the caller is still reading its inputs.  Thread-safe; calling it again, or
+ * never, is harmless. */
+int ugp_device_warmup(int device);
+
 /* Flatten + upload.  device = HIP device ordinal.  Replaces the per-sample
  * BFS rebuild and 2N vector allocations of usher_common.cpp:342-365. */
 int ugp_mat_create(const ugp_tree_desc *tree, int device, ugp_mat **out);

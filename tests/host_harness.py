@@ -27,13 +27,15 @@ T_OPEN_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(_lib.ugp_queries))
 T_SCORE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_uint32, C.c_uint64)
 T_RESCORE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_uint64)
 T_FETCH_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p)
+WARM_FN = C.CFUNCTYPE(None, C.c_void_p)
+PREPARE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(_lib.ugp_tree_desc), C.c_uint64)
 INT_MAX = 2 ** 31 - 1
 
 
 class Backend(C.Structure):
     _fields_ = [("ctx", C.c_void_p), ("place", PLACE_FN), ("scores", SCORES_FN), ("ties", TIES_FN), ("last_error", ERR_FN),
                 ("fitch", FITCH_FN), ("fitch_get", FITCH_GET_FN), ("update", UPDATE_FN), ("touched_open", T_OPEN_FN), ("touched_score", T_SCORE_FN),
-                ("touched_rescore", T_RESCORE_FN), ("touched_fetch", T_FETCH_FN)]
+                ("touched_rescore", T_RESCORE_FN), ("touched_fetch", T_FETCH_FN), ("warm", WARM_FN), ("prepare", PREPARE_FN)]
 
 
 def _arr(ptr, n, dt):
@@ -263,14 +265,27 @@ class OracleBackend:
                 C.memmove(hu, a_hu.ctypes.data, n * cap)
             return 0
 
+        # Backend::warm / ::prepare (round 5): the front end hands the tree over on a thread of its own while the VCF is read; the
+        # oracle keeps it -- the first `place` with the same version must find it -- and counts the calls
+        self.prepared = []
+        self.warmed = 0
+
+        def warm(ctx):
+            self.warmed += 1
+
+        def prepare(ctx, t, version):
+            self.prepared.append(int(version))
+            tree_for(t, int(version))
+            return 0
+        self._pre = (WARM_FN(warm), PREPARE_FN(prepare))
         self._fitch = []
         self._cbs = (PLACE_FN(place), SCORES_FN(scores), TIES_FN(ties), ERR_FN(lambda ctx: b"oracle backend"),
                      FITCH_FN(fitch), FITCH_GET_FN(fitch_get))
         self._add = (UPDATE_FN(update), T_OPEN_FN(touched_open), T_SCORE_FN(touched_score), T_RESCORE_FN(touched_rescore), T_FETCH_FN(touched_fetch))
         if add_mode:
-            self.struct = Backend(None, *self._cbs, *self._add)
+            self.struct = Backend(None, *self._cbs, *self._add, *self._pre)
         else:
-            self.struct = Backend(None, *self._cbs, UPDATE_FN(), T_OPEN_FN(), T_SCORE_FN(), T_RESCORE_FN(), T_FETCH_FN())
+            self.struct = Backend(None, *self._cbs, UPDATE_FN(), T_OPEN_FN(), T_SCORE_FN(), T_RESCORE_FN(), T_FETCH_FN(), *self._pre)
 
 
 def run_usher(args, backend=None):

@@ -754,3 +754,74 @@ def test_newick_written_on_threads_equals_the_loop(seed, tmp_path, monkeypatch):
         outs.append({n: open(str(d / n), "rb").read() for n in ("final-tree.nh", "out.pb", "mutation-paths.txt")})
     assert outs[0]["final-tree.nh"].count(b"(") > 30
     assert outs[1] == outs[0] and outs[2] == outs[0]
+
+
+def test_large_pb_gz_is_inflated_in_a_pipeline_and_loads_the_same_tree(tmp_path, monkeypatch):
+    """Round 5: a large .pb.gz (the public MAT ships compressed, mutation_annotated_tree.cpp:522-547) is inflated on a thread of its own
+    while the field scan follows it and the newick string is parsed: the tree loaded equals the one loaded from the plain file -- also
+    for a file of several gzip members, whose trailer is no size hint (the loader starts over in one piece), with the pipeline switched
+    off, and on one host thread."""
+    import ctypes as C
+    import gzip
+    import shutil
+    from tools.time_load import host_lib, ptr, write_workload
+    from usher_amd import synth as gsynth
+    L = host_lib()
+    L.uh_pb_to_arrays.argtypes = [C.c_char_p] + [C.c_void_p] * 8
+    st = gsynth.SynthTree(150_000, n_sites=1500, seed=11)
+    pb = str(tmp_path / "t.pb")
+    write_workload(L, st, None, 0, pb, None)
+    raw = open(pb, "rb").read()
+    assert len(raw) > (2 << 20)
+    with gzip.open(pb + ".gz", "wb", compresslevel=1) as f:
+        f.write(raw)
+    with open(str(tmp_path / "two.pb.gz"), "wb") as f:                # two members: ISIZE names the second one's length only
+        cut = len(raw) - (1 << 20) - 12345
+        f.write(gzip.compress(raw[:cut], 1)); f.write(gzip.compress(raw[cut:], 1))
+
+    def arrays(path):
+        counts = (C.c_uint64 * 2)()
+        assert L.uh_pb_to_arrays(path.encode(), counts, None, None, None, None, None, None, None) == 0
+        n, m = int(counts[0]), int(counts[1])
+        a = [np.zeros(n, np.int64), np.zeros(n + 1, np.int64), np.zeros(m, np.int32), np.zeros(m, np.int8), np.zeros(m, np.int8), np.zeros(m, np.int8)]
+        assert L.uh_pb_to_arrays(path.encode(), counts, *[ptr(x) for x in a], None) == 0
+        return a
+    want = arrays(pb)
+    assert len(want[0]) == int(st.arrays["n"])
+    for env in ({}, {"USHER_AMD_THREADS": "1"}, {"USHER_AMD_NO_GZ_PIPELINE": "1"}):
+        for k in ("USHER_AMD_THREADS", "USHER_AMD_NO_GZ_PIPELINE"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        for name in ("t.pb.gz", "two.pb.gz"):
+            got = arrays(str(tmp_path / name))
+            assert all((a == b).all() for a, b in zip(want, got)), (env, name)
+    # a truncated file is an error, not a hang
+    with open(str(tmp_path / "cut.pb.gz"), "wb") as f:
+        z = open(pb + ".gz", "rb").read()
+        f.write(z[:len(z) // 2])
+    counts = (C.c_uint64 * 2)()
+    assert L.uh_pb_to_arrays(str(tmp_path / "cut.pb.gz").encode(), counts, None, None, None, None, None, None, None) != 0
+
+
+@pytest.mark.parametrize("flags", [["-n"], ["-n", "-u"], [], ["-s"]])
+def test_tree_handed_over_under_the_vcf_read_and_final_tree_written_ahead(flags, tmp_path, monkeypatch):
+    """Round 5 (end-to-end latency of the drop-in): the front end calls Backend::warm first thing and hands the loaded tree to
+    Backend::prepare on a thread of its own while the VCF is read; with -n the final tree's text is produced while the samples are
+    placed.  Every output file equals the run with both switched off (USHER_AMD_NO_PREBUILD), and the backend saw one `prepare`
+    of version 1 and no second flattening of the same tree."""
+    from tests import host_harness
+    pb, vcf = os.path.join(SURVEY, "syn", "tree.pb"), os.path.join(SURVEY, "syn", "query.vcf")
+    outs = []
+    for k, off in enumerate((False, True)):
+        monkeypatch.delenv("USHER_AMD_NO_PREBUILD", raising=False)
+        if off:
+            monkeypatch.setenv("USHER_AMD_NO_PREBUILD", "1")
+        d = tmp_path / ("o%d" % k)
+        d.mkdir()
+        be = host_harness.OracleBackend()
+        assert host_harness.run_usher(["-i", pb, "-v", vcf, "-d", str(d)] + flags, be) == 0
+        assert be.warmed == 1
+        assert be.prepared == ([] if off else [1])
+        outs.append({n: _read(str(d / n)) for n in sorted(os.listdir(str(d)))})
+    assert outs[0] == outs[1] and "placement_stats.tsv" in outs[0]

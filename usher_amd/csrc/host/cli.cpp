@@ -14,6 +14,8 @@
 
 namespace uh {
 
+bool g_leak_tree_at_exit = false;   // set by bin/usher-amd's main()
+
 static const char *kHelp =
     "Options:\n"
     "  -v [ --vcf ] arg                          Input VCF file (in uncompressed or gzip-compressed .gz format) [REQUIRED]\n"
@@ -131,9 +133,15 @@ int usher_main(int argc, char **argv, const Backend &be) {
     int pr = parse(argc, argv, opt);
     if (pr == 2) return 0;
     if (pr == 1) return 1;
-    Tree T;
+    if (be.warm) be.warm(be.ctx);   // (the device runtime starts while the inputs are read)
+    // (in the CLI process the tree of a run lives until the process ends: tearing down 10M nodes one by one before exit buys nothing;
+    // callers that run many trees in one process -- the tests' C entry -- leave the flag off)
+    Tree *Tp = new Tree();
+    struct Drop { Tree *t; ~Drop() { if (!g_leak_tree_at_exit) delete t; } } drop{Tp};
+    Tree &T = *Tp;
     std::vector<MissingSample> missing;
     std::string err;
+    Prebuilt *pre = nullptr;
     if (!opt.tree.empty()) {                                                    // usher.cpp:132-149
         fprintf(stderr, "Loading input tree.\n");
         FILE *f = fopen(opt.tree.c_str(), "r");
@@ -152,8 +160,9 @@ int usher_main(int argc, char **argv, const Backend &be) {
         if (!load_mat(opt.load_mat, T, err)) { fprintf(stderr, "%s\n", err.c_str()); return 1; }
         if (!T.root) { fprintf(stderr, "ERROR: Empty tree.\n"); return 1; }
         const auto t1 = std::chrono::steady_clock::now();
+        pre = prebuild_start(opt, T, be);   // tree -> arrays -> device, under the VCF read
         fprintf(stderr, "Loading VCF file\n");
-        if (!read_vcf_missing(T, opt.vcf, missing, err)) { fprintf(stderr, "%s\n", err.c_str()); return 1; }
+        if (!read_vcf_missing(T, opt.vcf, missing, err)) { prebuild_drop(pre); fprintf(stderr, "%s\n", err.c_str()); return 1; }
         if (getenv("USHER_AMD_PROFILE"))
             fprintf(stderr, "[usher-amd profile] load MAT %.3f s, read VCF %.3f s\n", std::chrono::duration<double>(t1 - t0).count(),
                     std::chrono::duration<double>(std::chrono::steady_clock::now() - t1).count());
@@ -162,7 +171,7 @@ int usher_main(int argc, char **argv, const Backend &be) {
         return 1;
     }
     const auto t2 = std::chrono::steady_clock::now();
-    const int rc = run_usher(opt, T, missing, be);
+    const int rc = run_usher(opt, T, missing, be, pre);
     if (getenv("USHER_AMD_PROFILE")) fprintf(stderr, "[usher-amd profile] run_usher (placement loop + output files) %.3f s\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - t2).count());
     return rc;
 }

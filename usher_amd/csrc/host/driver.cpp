@@ -17,6 +17,7 @@
 #include <functional>
 #include <climits>
 #include <cmath>
+#include <thread>
 #include <unordered_map>
 #include <unordered_set>
 
@@ -547,8 +548,21 @@ static void write_sample_subtrees(Tree &T, const std::vector<MissingSample> &mis
 
 // Every output of usher_common.cpp:808-1044 for the final tree(s); with several trees (--multiple-placements) the
 // file names carry the tree number (:836-838, :859-861, :893-895, :918-919) and only the first tree is saved (:1027-1034).
+// The final tree's text and parsimony score computed ahead of time (-n: the tree never changes, so the 10M-node newick is produced on
+// a thread of its own while the samples are placed and their statistics written)
+struct FinalText {
+    std::string text;
+    size_t parsimony = 0;
+    std::thread th;
+    void start(const Tree &T, bool uncondensed) {
+        th = std::thread([this, &T, uncondensed]() { text = newick(T, T.root, true, true, uncondensed); parsimony = T.parsimony_score(); });
+    }
+    void wait() { if (th.joinable()) th.join(); }
+    ~FinalText() { wait(); }
+};
+
 static int write_outputs(const Options &opt, std::vector<Tree *> &trees, std::vector<MissingSample> &missing,
-                         const std::vector<std::string> &low_confidence) {
+                         const std::vector<std::string> &low_confidence, FinalText *ready = nullptr) {
     Timer timer;
     const std::string &outdir = opt.outdir;
     const size_t num_trees = trees.size();
@@ -571,14 +585,16 @@ static int write_outputs(const Options &opt, std::vector<Tree *> &trees, std::ve
             const std::string fn = numbered("uncondensed-final-tree", ".nh", t, true);
             if (num_trees > 1) fprintf(stderr, "Writing uncondensed final tree %zu to file %s \n", t + 1, fn.c_str());
             else fprintf(stderr, "Writing uncondensed final tree to file %s \n", fn.c_str());
-            fprintf(stderr, "The parsimony score for this tree is: %zu \n", T.parsimony_score());
-            write_text(fn, newick(T, T.root, true, true, true));
+            if (ready) ready->wait();
+            fprintf(stderr, "The parsimony score for this tree is: %zu \n", ready ? ready->parsimony : T.parsimony_score());
+            write_text(fn, ready ? ready->text : newick(T, T.root, true, true, true));
         } else {
             const std::string fn = numbered("final-tree", ".nh", t, true);
             if (num_trees > 1) fprintf(stderr, "Writing final tree %zu to file %s \n", t + 1, fn.c_str());
             else fprintf(stderr, "Writing final tree to file %s \n", fn.c_str());
-            fprintf(stderr, "The parsimony score for this tree is: %zu \n", T.parsimony_score());
-            write_text(fn, newick(T, T.root, true, true));
+            if (ready) ready->wait();
+            fprintf(stderr, "The parsimony score for this tree is: %zu \n", ready ? ready->parsimony : T.parsimony_score());
+            write_text(fn, ready ? ready->text : newick(T, T.root, true, true));
         }
         fprintf(stderr, "Completed in %ld msec \n\n", timer.stop());
     }
@@ -793,7 +809,34 @@ static int run_multi(const Options &opt, Tree &T0, std::vector<MissingSample> &m
     return write_outputs(opt, trees, missing, low_confidence);
 }
 
-int run_usher(const Options &opt, Tree &T, std::vector<MissingSample> &missing, const Backend &be) {
+// The loaded tree as arrays, handed to the backend on a thread of its own while the VCF is read (driver.hpp)
+struct Prebuilt {
+    FlatTree flat;
+    std::thread th;
+    int rc = 0;
+    double secs = 0;
+};
+Prebuilt *prebuild_start(const Options &opt, const Tree &T, const Backend &be) {
+    // (-c changes the tree before anything is placed; -M works on copies of it)
+    if (!be.prepare || !T.root || opt.collapse_tree || opt.max_trees > 1 || getenv("USHER_AMD_NO_PREBUILD")) return nullptr;
+    Prebuilt *p = new Prebuilt();
+    const Backend b = be;
+    p->th = std::thread([p, &T, b]() {
+        const auto t0 = std::chrono::steady_clock::now();
+        p->flat.build(T);
+        p->rc = b.prepare(b.ctx, &p->flat.desc, 1);   // (version 1: run_usher's first)
+        p->secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    });
+    return p;
+}
+void prebuild_drop(Prebuilt *p) {
+    if (!p) return;
+    if (p->th.joinable()) p->th.join();
+    delete p;
+}
+
+int run_usher(const Options &opt, Tree &T, std::vector<MissingSample> &missing, const Backend &be, Prebuilt *pre) {
+    struct PreGuard { Prebuilt *&p; ~PreGuard() { prebuild_drop(p); p = nullptr; } } pre_guard{pre};
     // ---- option validation, usher_common.cpp:14-77
     if (opt.subtrees_size == 1) { fprintf(stderr, "ERROR: print-subtrees-size should be larger than 1\n"); return 1; }
     if ((int)opt.sort1 + (int)opt.sort2 + (int)opt.sort3 > 1) {
@@ -850,6 +893,26 @@ int run_usher(const Options &opt, Tree &T, std::vector<MissingSample> &missing, 
 
     uint64_t tree_version = 1;
     FlatTree flat;
+    FinalText final_text;
+    bool final_text_started = false;
+    // The first flattening of a run: taken over from the thread that built it under the VCF read -- when the tree is still the one
+    // that was loaded (no insertion yet) -- else built here.  false: the backend could not take the tree.
+    auto build_flat = [&]() -> bool {
+        if (pre && tree_version == 1) {
+            if (pre->th.joinable()) pre->th.join();
+            const int rc = pre->rc;
+            if (getenv("USHER_AMD_PROFILE")) fprintf(stderr, "[usher-amd profile] tree -> arrays -> device on its own thread %.3f s (under the VCF read)\n", pre->secs);
+            flat = std::move(pre->flat);
+            flat.desc.parent = flat.parent.data(); flat.desc.mut_off = flat.mut_off.data(); flat.desc.mut_pos = flat.pos.data();
+            flat.desc.mut_ref = flat.ref.data(); flat.desc.mut_par = flat.par.data(); flat.desc.mut_nuc = flat.nuc.data();
+            delete pre; pre = nullptr;
+            return rc == 0;
+        }
+        // (a flattening stamps the nodes with its index and epoch: never two at a time -- the thread's is over, and dropped, first)
+        if (pre) { prebuild_drop(pre); pre = nullptr; }
+        flat.build(T);
+        return true;
+    };
     if (!missing.empty()) {
         std::vector<size_t> indexes(missing.size());
         std::iota(indexes.begin(), indexes.end(), 0);
@@ -882,7 +945,7 @@ int run_usher(const Options &opt, Tree &T, std::vector<MissingSample> &missing, 
         } else if ((opt.sort1 || opt.sort2) && missing.size() > 1) {            // :187-301
             timer.start();
             fprintf(stderr, "Computing parsimony scores and number of parsimony-optimal placements for new samples and using them to sort the samples.\n");
-            flat.build(T);
+            if (!build_flat()) return be_fail("flattening");
             std::vector<ugp_result> r(missing.size());
             if (!host_all && be.place(be.ctx, &flat.desc, tree_version, &allq.desc, r.data()) != 0) return be_fail("placement");
             for (size_t i = 0; i < missing.size(); i++) if (odd[i]) {
@@ -900,7 +963,12 @@ int run_usher(const Options &opt, Tree &T, std::vector<MissingSample> &missing, 
         if (opt.max_trees > 1) return run_multi(opt, T, missing, indexes, be, tree_version);
 
         if (static_tree) {   // the tree never changes: one batch call serves every sample
-            flat.build(T);
+            if (!flat.epoch && !build_flat()) return be_fail("flattening");
+            // -n: what will be written as the final tree is this tree -- its text is produced under the placement and the statistics
+            if (opt.no_add && !opt.print_scores && !opt.collapse_output_tree && !getenv("USHER_AMD_NO_PREBUILD")) {
+                final_text.start(T, opt.write_uncondensed);
+                final_text_started = true;
+            }
             batch_res.resize(missing.size());
             if (!host_all && be.place(be.ctx, &flat.desc, tree_version, &allq.desc, batch_res.data()) != 0) return be_fail("placement");
         }
@@ -1047,7 +1115,7 @@ int run_usher(const Options &opt, Tree &T, std::vector<MissingSample> &missing, 
         auto dev_batch = [&](size_t ii) -> bool {   // the next batch: searched on the flattened tree (rewritten nodes excluded), scored against every live record
             const double t0 = std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
             if (!dev.flat_done) {
-                flat.build(T);
+                if (!build_flat()) return false;
                 prof.build += std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count() - t0; prof.flats++;
                 flat_version_dev = tree_version;
                 dev.flat_done = true;
@@ -1239,7 +1307,7 @@ int run_usher(const Options &opt, Tree &T, std::vector<MissingSample> &missing, 
                         const auto t_redo0 = std::chrono::steady_clock::now();
                         if (need_flat) {
                             const double tb = now_s();
-                            flat.build(T);
+                            if (!build_flat()) { fclose(stats); return be_fail("flattening"); }
                             prof.build += now_s() - tb; prof.flats++;
                             flat_version = tree_version;
                             touched.clear();
@@ -1481,7 +1549,7 @@ int run_usher(const Options &opt, Tree &T, std::vector<MissingSample> &missing, 
     if (opt.print_scores) return 0;                                             // :800-805
     std::vector<Tree *> trees{&T};
     const auto t_out = std::chrono::steady_clock::now();
-    const int rc = write_outputs(opt, trees, missing, low_confidence);
+    const int rc = write_outputs(opt, trees, missing, low_confidence, final_text_started ? &final_text : nullptr);
     if (getenv("USHER_AMD_PROFILE")) fprintf(stderr, "[usher-amd profile] output files %.3f s\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - t_out).count());
     return rc;
 }

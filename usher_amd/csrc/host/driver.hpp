@@ -47,10 +47,22 @@ struct Backend {
     int (*touched_score)(void *ctx, uint32_t first_id, uint64_t first_sample) = nullptr;
     int (*touched_rescore)(void *ctx, uint64_t sample) = nullptr;
     int (*touched_fetch)(void *ctx, uint64_t first_sample, uint64_t n, uint32_t cap, int32_t *best, uint32_t *count, uint32_t *ids, uint8_t *has_unique) = nullptr;
+    // End-to-end latency of the drop-in (round 5), both optional.  `warm`: start whatever the backend needs before its first call (the
+    // device runtime) in the background -- called first thing, while the inputs are still being read.  `prepare`: make this tree
+    // resident now (what the first `place` with this version would do): the front end calls it on a thread of its own while the VCF is
+    // read, so that flattening and upload are over when the samples arrive.
+    void (*warm)(void *ctx) = nullptr;
+    int (*prepare)(void *ctx, const ugp_tree_desc *, uint64_t tree_version) = nullptr;
 };
 
+// The tree as loaded, turned into the backend's arrays (and handed to Backend::prepare) on a thread of its own; run_usher takes it
+// over at its first flattening if the tree is still what it was.  Null when there is nothing to gain (no `prepare`).
+struct Prebuilt;
+Prebuilt *prebuild_start(const Options &opt, const Tree &T, const Backend &be);
+void prebuild_drop(Prebuilt *p);   // waits for the thread; for callers that never reach run_usher
+
 // Returns the process exit code (usher_common.cpp:6).
-int run_usher(const Options &opt, Tree &T, std::vector<MissingSample> &missing, const Backend &be);
+int run_usher(const Options &opt, Tree &T, std::vector<MissingSample> &missing, const Backend &be, Prebuilt *pre = nullptr);
 
 // mapper2_body(inp, true, true) for one node (usher_mapper.cpp:167-504): the
 // excess / imputed mutation vectors, score and has_unique the placement needs.

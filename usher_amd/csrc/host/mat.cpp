@@ -18,6 +18,7 @@
 #include <mutex>
 #include <new>
 #include <sstream>
+#include <thread>
 
 #include "par.hpp"
 
@@ -928,15 +929,83 @@ std::string newick(const Tree &T, Node *from, bool internal_ids, bool branch_len
 
 namespace {
 
+// ISIZE of a gzip file: the length of the (last member's) data modulo 2^32 -- a size hint, 0 when unreadable
+size_t gz_isize(const std::string &path) {
+    FILE *f = fopen(path.c_str(), "rb");
+    if (!f) return 0;
+    uint8_t t[4] = {0, 0, 0, 0};
+    size_t v = 0;
+    if (fseek(f, -4, SEEK_END) == 0 && fread(t, 1, 4, f) == 4) v = (size_t)t[0] | ((size_t)t[1] << 8) | ((size_t)t[2] << 16) | ((size_t)t[3] << 24);
+    fclose(f);
+    return v;
+}
+
+// A gzip file inflated on a thread of its own into a buffer of the size its trailer names, while the caller reads what is there
+// already (load_mat: the field scan and the newick parse run under the inflate of the rest of a .pb.gz -- the public MAT ships
+// compressed, mutation_annotated_tree.cpp:522-547, and one zlib stream inflates on one thread at ~0.3 GB/s).  state: 0 running,
+// 1 complete, -1 read error, -2 the data does not fit the hint (several members, or more than 4 GB): the caller starts over
+// with read_file.
+struct GzProgressive {
+    std::string buf;
+    std::atomic<size_t> avail{0};
+    std::atomic<int> state{0};
+    std::thread th;
+    ~GzProgressive() { if (th.joinable()) th.join(); }
+    bool start(const std::string &path) {
+        const size_t hint = gz_isize(path);
+        struct stat st;
+        if (hint < (1u << 20) || stat(path.c_str(), &st) != 0 || (size_t)st.st_size > hint) return false;   // (small, or not plausible: the simple way)
+        gzFile f = gzopen(path.c_str(), "rb");
+        if (!f) return false;
+        gzbuffer(f, 1u << 20);
+        buf.resize(hint);
+        th = std::thread([this, f]() {
+            size_t used = 0;
+            int n = 0;
+            while (used < buf.size()) {
+                n = gzread(f, &buf[used], (unsigned)std::min<size_t>(buf.size() - used, 1u << 22));
+                if (n <= 0) break;
+                used += (size_t)n;
+                avail.store(used, std::memory_order_release);
+            }
+            int fin = -1;
+            if (n < 0) fin = -1;
+            else if (used < buf.size()) fin = -2;                       // shorter than the trailer says
+            else { char c; fin = gzread(f, &c, 1) == 0 ? 1 : -2; }      // (exactly full: must be the end)
+            gzclose(f);
+            state.store(fin, std::memory_order_release);
+        });
+        return true;
+    }
+    // true when bytes [0, n) are there; false when the stream ended (or failed) before
+    bool wait_for(size_t n) {
+        for (unsigned spin = 0;; spin++) {
+            if (avail.load(std::memory_order_acquire) >= n) return true;
+            if (state.load(std::memory_order_acquire) != 0) return avail.load(std::memory_order_acquire) >= n;
+            if (spin < 64) std::this_thread::yield(); else usleep(200);
+        }
+    }
+    int finish() { if (th.joinable()) th.join(); return state.load(); }
+};
+
 bool read_file(const std::string &path, std::string &buf, std::string &err) {
     if (path.find(".gz") != std::string::npos) {   // :530 / :2086
         gzFile f = gzopen(path.c_str(), "rb");
         if (!f) { err = "Could not open " + path; return false; }
         gzbuffer(f, 1u << 20);
-        std::vector<char> tmp(1u << 22);
+        // (inflated straight into the result, which starts at the size the gzip trailer names -- a multiple of 2^32 short for huge
+        // files and for several members: it grows when that runs out)
+        size_t used = 0;
+        buf.resize(std::max<size_t>(gz_isize(path), 1u << 22));
         int n;
-        while ((n = gzread(f, tmp.data(), (unsigned)tmp.size())) > 0) buf.append(tmp.data(), (size_t)n);
+        for (;;) {
+            if (used == buf.size()) buf.resize(buf.size() + buf.size() / 2);
+            n = gzread(f, &buf[used], (unsigned)std::min<size_t>(buf.size() - used, 1u << 30));
+            if (n <= 0) break;
+            used += (size_t)n;
+        }
         gzclose(f);
+        buf.resize(used);
         return n == 0;
     }
     // one read into a buffer of the file's size (a stringstream copies a 1 GB VCF twice)
@@ -1001,37 +1070,89 @@ void put_int32(std::string &o, uint32_t fno, int32_t v) {   // proto3: zero is o
 
 bool load_mat(const std::string &path, Tree &T, std::string &err) {   // :522-612
     std::string buf;
-    if (!read_file(path, buf, err)) { err = "ERROR: Could not load the mutation-annotated tree object from file: " + path + "!"; return false; }
     Lap lap("load_mat");
-    lap("read file");
-    Rd top{(const uint8_t *)buf.data(), (const uint8_t *)buf.data() + buf.size()};
+    // A large .pb.gz is inflated on a thread of its own while this one scans the fields that are there already and the newick
+    // string -- the first field -- is parsed on the host threads (round 5); anything else is read in one piece first.
+    GzProgressive gz;
+    bool progressive = path.find(".gz") != std::string::npos && !getenv("USHER_AMD_NO_GZ_PIPELINE") && gz.start(path);
+    for (int attempt = 0; attempt < 2; attempt++) {
+    if (!progressive) {
+        if (!read_file(path, buf, err)) { err = "ERROR: Could not load the mutation-annotated tree object from file: " + path + "!"; return false; }
+        lap("read file");
+    }
+    const uint8_t *base = (const uint8_t *)(progressive ? gz.buf.data() : buf.data());
+    const size_t total = progressive ? gz.buf.size() : buf.size();
     const char *nwk_p = "";
     size_t nwk_len = 0;
     // First pass: the newick string, and where each node's mutation list / metadata entry sits in the buffer
     // (they are decoded straight into the nodes once the tree exists; no intermediate copies).
     std::vector<Rd> mut_lists, meta_lists;
     std::vector<std::pair<std::string, std::vector<std::string>>> cond;
-    uint32_t fno, wt; uint64_t val; Rd sub{nullptr, nullptr};
-    while (top.field(fno, wt, val, sub)) {
-        if (fno == 1 && wt == 2) { nwk_p = (const char *)sub.p; nwk_len = (size_t)(sub.e - sub.p); }
-        else if (fno == 2 && wt == 2) mut_lists.push_back(sub);
-        else if (fno == 3 && wt == 2) {
+    std::vector<Node *> order;
+    std::thread nwk_thread;
+    bool nwk_ok = true, nwk_started = false;
+    std::string nwk_err;
+    auto parse_newick = [&]() {
+        // Large trees: items tokenised and nodes constructed on the host threads (tree_from_newick_bulk); the nodes come back in
+        // creation order, which is the depth-first order the mutation lists are stored in (:552-554).
+        const bool bulk = nwk_len >= (1u << 16) || getenv("USHER_AMD_GRAIN");
+        if (bulk) nwk_ok = tree_from_newick_bulk(nwk_p, nwk_len, T, nwk_err, &order);
+        else { nwk_ok = tree_from_newick(std::string(nwk_p, nwk_len), T, nwk_err); if (nwk_ok) order = T.dfs(); }
+    };
+    bool scan_ok = true;
+    size_t off = 0;
+    for (;;) {
+        // (a field header is at most two varints: 20 bytes; the bytes of a field's body are only touched where noted)
+        size_t have = total;
+        if (progressive) { gz.wait_for(std::min(total, off + 20)); have = std::min(total, gz.avail.load(std::memory_order_acquire)); if (gz.state.load() < 0) break; }
+        if (off >= have) break;
+        Rd hd{base + off, base + have};
+        const uint64_t key = hd.varint();
+        const uint32_t fno = (uint32_t)(key >> 3), wt = (uint32_t)(key & 7);
+        if (!hd.ok) { scan_ok = false; break; }
+        if (wt == 0) { hd.varint(); if (!hd.ok) { scan_ok = false; break; } off = (size_t)(hd.p - base); continue; }
+        if (wt == 1 || wt == 5) { off = (size_t)(hd.p - base) + (wt == 1 ? 8 : 4); if (off > total) { scan_ok = false; break; } continue; }
+        if (wt != 2) { scan_ok = false; break; }
+        const uint64_t n = hd.varint();
+        if (!hd.ok) { scan_ok = false; break; }
+        const size_t body = (size_t)(hd.p - base);
+        if (n > total - body) { scan_ok = false; break; }
+        Rd sub{base + body, base + body + n};
+        off = body + (size_t)n;
+        if (fno == 1) {
+            nwk_p = (const char *)sub.p; nwk_len = (size_t)n;
+            if (progressive && !nwk_started) {   // the tree is built while the rest of the file is still being inflated
+                if (!gz.wait_for(off)) break;
+                nwk_started = true;
+                nwk_thread = std::thread(parse_newick);
+            }
+        } else if (fno == 2) mut_lists.push_back(sub);
+        else if (fno == 3) {
+            if (progressive && !gz.wait_for(off)) break;
             cond.emplace_back();
             uint32_t f2, w2; uint64_t v2; Rd s2{nullptr, nullptr};
             while (sub.field(f2, w2, v2, s2)) {
                 if (f2 == 1 && w2 == 2) cond.back().first.assign((const char *)s2.p, s2.e - s2.p);
                 else if (f2 == 2 && w2 == 2) cond.back().second.emplace_back((const char *)s2.p, s2.e - s2.p);
             }
-        } else if (fno == 4 && wt == 2) meta_lists.push_back(sub);
+        } else if (fno == 4) meta_lists.push_back(sub);
     }
-    if (!top.ok) { err = "malformed protobuf"; return false; }
-    lap("top-level fields");
-    // Large trees: items tokenised and nodes constructed on the host threads (tree_from_newick_bulk); the nodes come back in
-    // creation order, which is the depth-first order the mutation lists are stored in (:552-554).
-    std::vector<Node *> order;
-    const bool bulk = nwk_len >= (1u << 16) || getenv("USHER_AMD_GRAIN");
-    if (bulk) { if (!tree_from_newick_bulk(nwk_p, nwk_len, T, err, &order)) return false; }
-    else { if (!tree_from_newick(std::string(nwk_p, nwk_len), T, err)) return false; order = T.dfs(); }
+    if (progressive) {
+        const int fin = gz.finish();
+        if (nwk_thread.joinable()) nwk_thread.join();
+        if (fin == -2) {   // the trailer's size was no guide (several members, more than 4 GB): the simple way, from the start, on an empty tree
+            free_all_nodes(T);
+            T.root = nullptr; T.curr_internal_node = 0;
+            progressive = false;
+            continue;
+        }
+        if (fin != 1) { err = "ERROR: Could not load the mutation-annotated tree object from file: " + path + "!"; return false; }
+        lap("inflate + top-level fields (pipelined)");
+    }
+    if (!scan_ok || off != total) { if (nwk_thread.joinable()) nwk_thread.join(); err = "malformed protobuf"; return false; }
+    if (!progressive) lap("top-level fields");
+    if (!nwk_started) parse_newick();
+    if (!nwk_ok) { err = nwk_err; return false; }
     lap("tree from newick");
     if (mut_lists.size() < order.size()) { err = "protobuf has fewer mutation lists than tree nodes"; return false; }
     const bool hasmeta = !meta_lists.empty();
@@ -1117,6 +1238,9 @@ bool load_mat(const std::string &path, Tree &T, std::string &err) {   // :522-61
         T.add_condensed(c.first, c.second);
     }
     return true;
+    }   // (second attempt: a .gz whose trailer was no guide, read in one piece)
+    err = "ERROR: Could not load the mutation-annotated tree object from file: " + path + "!";
+    return false;
 }
 
 bool save_mat(Tree &T, const std::string &path, std::string &err) {   // :614-681

@@ -17,7 +17,7 @@
 #include "driver.hpp"
 #include "usher_amd.h"
 
-namespace uh { int usher_main(int argc, char **argv, const Backend &be); }
+namespace uh { int usher_main(int argc, char **argv, const Backend &be); extern bool g_leak_tree_at_exit; }
 
 namespace {
 
@@ -27,6 +27,7 @@ struct GpuCtx {
     ugp_fitch *fitch = nullptr;
     uint64_t version = 0;
     std::string err;
+    std::thread warm_th;   // Backend::warm: the device runtime comes up while the inputs are read
 };
 
 void drop_mats(GpuCtx *c) {
@@ -35,6 +36,7 @@ void drop_mats(GpuCtx *c) {
 }
 
 int ensure(GpuCtx *c, const ugp_tree_desc *t, uint64_t version) {
+    if (c->warm_th.joinable()) c->warm_th.join();
     if (!c->mats.empty() && c->version == version) return UGP_OK;
     drop_mats(c);
     c->mats.assign(c->devices.size(), nullptr);
@@ -126,6 +128,13 @@ int gpu_touched_fetch(void *ctx, uint64_t first_sample, uint64_t n, uint32_t cap
     GPU_FWD(ugp_touched_fetch(c->mats[0], first_sample, n, cap, best, count, ids, hu))
 }
 const char *gpu_err(void *ctx) { return ((GpuCtx *)ctx)->err.c_str(); }
+void gpu_warm(void *ctx) {
+    GpuCtx *c = (GpuCtx *)ctx;
+    if (c->warm_th.joinable()) return;
+    const std::vector<int> devs = c->devices;
+    c->warm_th = std::thread([devs]() { for (int d : devs) (void)ugp_device_warmup(d); });
+}
+int gpu_prepare(void *ctx, const ugp_tree_desc *t, uint64_t v) { return ensure((GpuCtx *)ctx, t, v); }
 int gpu_fitch(void *ctx, uint64_t n_nodes, const uint32_t *parent, const ugp_sites *sites, uint64_t *n_out) {
     GpuCtx *c = (GpuCtx *)ctx;
     if (c->fitch) { ugp_fitch_destroy(c->fitch); c->fitch = nullptr; }
@@ -185,8 +194,13 @@ int main(int argc, char **argv) {
     be.fitch = gpu_fitch; be.fitch_get = gpu_fitch_get;
     be.update = gpu_update; be.touched_open = gpu_touched_open; be.touched_score = gpu_touched_score; be.touched_rescore = gpu_touched_rescore;
     be.touched_fetch = gpu_touched_fetch;
+    be.warm = gpu_warm; be.prepare = gpu_prepare;
+    uh::g_leak_tree_at_exit = true;   // (this process ends with the run: the tree is not taken apart node by node first)
     int rc = uh::usher_main(argc, argv, be);
-    drop_mats(&ctx);
-    if (ctx.fitch) ugp_fitch_destroy(ctx.fitch);
+    if (ctx.warm_th.joinable()) ctx.warm_th.join();
+    // (the handles' device memory goes with the process: freeing 3 GB of tables buffer by buffer is 0.1-0.2 s of nothing; the
+    // tests and tools that embed the library destroy their handles)
+    if (getenv("USHER_AMD_TIDY_EXIT")) { drop_mats(&ctx); if (ctx.fitch) ugp_fitch_destroy(ctx.fitch); }
+    fflush(nullptr);
     return rc;
 }

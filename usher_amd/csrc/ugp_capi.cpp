@@ -759,6 +759,12 @@ extern "C" {
 
 const char *ugp_last_error(void) { return g_err.c_str(); }
 
+int ugp_device_warmup(int device) {
+    HIP_TRY(hipSetDevice(device));
+    HIP_TRY(hipFree(nullptr));   // (creates the context and loads this library's code objects)
+    return UGP_OK;
+}
+
 // Host side of a handle: the flattened tree plus, for trees large enough to profit from the locality sort, the
 // flattened coarse MAT (the top of the tree) and the map coarse BFS index -> DFS rank in the full tree.  Built
 // once per tree whatever the number of devices it is uploaded to.
