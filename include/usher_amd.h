@@ -188,6 +188,21 @@ typedef struct ugp_place_opts {
 int ugp_place_batch_ex(ugp_mat *mat, const ugp_queries *q, const ugp_place_opts *opts, ugp_result *out /* [n_queries] */);
 int ugp_tied_nodes_ex(ugp_mat *mat, const ugp_queries *q, const ugp_place_opts *opts, uint32_t cap, uint32_t *tie_j,
                       uint8_t *tie_has_unique, uint32_t *tie_count);
+/* The node-level options prepared once.  ripples (ripples/main.cpp:303-377) runs thousands of searches with ONE node vector -- the
+ * nodes with enough descendant leaves -- and ONE distance array; remapping a 10M-entry mask, ranking 10M (distance, leaves) keys and
+ * uploading both is then the call (40 of 43 ms per 4,096 samples at 10M nodes).  ugp_ex_prepare does that part once: `opts`
+ * contributes order, node_mask and distance (both copied: the arrays may be freed), its skip_node / scores are ignored.  The handle
+ * belongs to `mat` and must be destroyed before it.
+ * ugp_place_batch_prepared = ugp_place_batch_ex with those options plus, per call, skip_node ([n_queries] positions in the prepared
+ * order, or NULL) and d_scores: a DEVICE buffer of n_queries * n_nodes int32 (or NULL) that receives the score matrix as
+ * ugp_place_opts::scores describes it -- written by the level-by-level kernel of ugp_scores_per_node for a breadth-first order (no
+ * host copy: a caller that reduces the rows on the device, as ripples' per-node filter could, never moves the 40 MB per sample),
+ * valid when the call returns. */
+typedef struct ugp_ex ugp_ex;
+int ugp_ex_prepare(ugp_mat *mat, const ugp_place_opts *opts, ugp_ex **out);
+void ugp_ex_destroy(ugp_ex *ex);
+int ugp_place_batch_prepared(ugp_mat *mat, const ugp_queries *q, const ugp_ex *ex, const uint32_t *skip_node, ugp_result *out /* [n_queries], host */,
+                             int32_t *d_scores /* device, or NULL */);
 /* bfs_of[k] = breadth-first index of the node at position k of `order` (how a caller maps its own node vector). */
 int ugp_node_order(ugp_mat *mat, uint32_t order, uint32_t *bfs_of /* [n_nodes] */);
 /* mask_out[k] = 1 for the nodes of the subtree of root_j that lie at most max_levels below it (merge.cpp:253-256). */

@@ -135,6 +135,21 @@ def test_extended_searches_at_10m_nodes(big, monkeypatch):
         r = pl.place_ex(batch, **kw)
         assert pl.timing()["packed_path"] == 1, name
         fast[name] = (r.copy(),) + tuple(pl.tied_nodes_ex(batch, 64, **kw))
+    # the node-level options prepared once (ugp_ex_prepare): the same answers call after call, and the per-call time of the ripples
+    # style without the host's O(N) preparation (43 ms per 4,096 samples -> a few ms)
+    import time
+    for name, kw, batch, _ in styles:
+        node_kw = {k: v for k, v in kw.items() if k != "skip_node"}
+        ex = pl.prepare_ex(**node_kw)
+        pl.place_prepared(batch, ex, skip_node=kw.get("skip_node"))
+        t0 = time.perf_counter()
+        got = pl.place_prepared(batch, ex, skip_node=kw.get("skip_node"))
+        dt = time.perf_counter() - t0
+        assert pl.timing()["packed_path"] == 1, name
+        assert (got.view(np.int32) == fast[name][0].view(np.int32)).all(), name
+        print("prepared %-12s %.2f ms per %d samples" % (name, dt * 1e3, nq))
+        assert dt < 0.030, (name, dt)                         # (the one-shot ripples-style call is 40+ ms)
+        pl.free_ex(ex)
     monkeypatch.setenv("UGP_EX_SLOW", "1")
     pl.reload_knobs()
     for name, kw, batch, _ in styles:

@@ -301,3 +301,55 @@ def test_self_exclusion_on_a_preorder_numbered_tree_through_the_sorted_path(monk
         w = ot.place_list(samples[i], allj[keep], jidx=allj[keep], init_best=len(samples[i]["pos"]) + root_muts + 1)
         _same(a, i, w)
     fast.close(); slow.close()
+
+
+def test_prepared_options_equal_the_one_shot_calls(monkeypatch):
+    """Round 5: ugp_ex_prepare does the node-level part of an extended search once (the caller's order, its mask, its distance ranks --
+    ripples keeps one node vector and one distance array for a whole run, ripples/main.cpp:303-377); ugp_place_batch_prepared then
+    equals ugp_place_batch_ex call by call: ripples-style (mask + distance) with and without the score matrix -- written into a DEVICE
+    buffer by the level-by-level kernel --, merge-style, annotate- and uncertainty-style (depth-first indices, a node left out per
+    sample), on the packed path and on the one-sample-per-lane kernel."""
+    import torch
+    monkeypatch.setenv("UGP_COARSE_MIN_NODES", "0")
+    monkeypatch.delenv("UGP_EX_SLOW", raising=False)
+    arrays, queries = synth.make_case(1234, n_leaves=2400, n_queries=640, n_sites=140, n_ambig=(0, 0, 2, 5), p_masked=0.01)
+    n = arrays["n"]
+    ot = capi.OracleTree(arrays)
+    batch = QueryBatch(queries)
+    leaves_below = np.array([ot.num_leaves(j) for j in range(n)])
+    rng = np.random.default_rng(4)
+    dist = rng.integers(0, 3, n).astype(np.uint32)
+    m_leaves = (leaves_below >= 3).astype(np.uint8); m_leaves[0] = 1
+    for slow in (False, True):
+        if slow:
+            monkeypatch.setenv("UGP_EX_SLOW", "1")
+        pl = Placer(arrays, chunk_nodes=48)
+        dfs = pl.node_order("dfs").astype(np.int64)
+        pos_of = np.empty(n, np.int64); pos_of[dfs] = np.arange(n)
+        skip_b = rng.integers(0, n, len(queries)).astype(np.uint32)
+        m_levels = pl.subtree_mask(0, 6)
+        for name, kw, skip in (("ripples", dict(order="bfs", node_mask=m_leaves, distance=dist), None),
+                               ("merge", dict(order="bfs", node_mask=m_levels), None),
+                               ("annotate", dict(order="dfs"), None),
+                               ("uncertainty", dict(order="dfs"), pos_of[skip_b].astype(np.uint32)),
+                               ("ripples+skip", dict(order="bfs", node_mask=m_leaves, distance=dist), skip_b)):
+            ex = pl.prepare_ex(**kw)
+            want = pl.place_ex(batch, skip_node=skip, **kw)
+            for _ in range(2):                                     # (the handle serves any number of calls)
+                got = pl.place_prepared(batch, ex, skip_node=skip)
+                assert pl.timing()["packed_path"] == (0 if slow else 1), name
+                assert (got.view(np.int32) == want.view(np.int32)).all(), (name, slow)
+            if name.startswith("ripples"):                         # the score matrix in a device buffer
+                few = batch.slice(0, 24)
+                wr, ws = pl.place_ex(few, skip_node=None if skip is None else skip[:24], want_scores=True, **kw)
+                d = torch.full((24, n), -7, dtype=torch.int32, device="cuda")
+                gr = pl.place_prepared(few, ex, skip_node=None if skip is None else skip[:24], d_scores=d.data_ptr())
+                torch.cuda.synchronize()
+                assert (gr.view(np.int32) == wr.view(np.int32)).all(), name
+                assert (d.cpu().numpy() == ws).all(), (name, slow)
+            pl.free_ex(ex)
+        plain = pl.place(batch)
+        for i in range(0, len(queries), 40):                       # nothing is left masked behind the calls
+            _same(plain, i, ot.place(queries[i]))
+        pl.close()
+        monkeypatch.delenv("UGP_EX_SLOW", raising=False)

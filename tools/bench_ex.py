@@ -59,6 +59,33 @@ for label, env in (("packed", None), ("one sample per lane", "1")):
         dt2 = time.perf_counter() - t0
         res.setdefault(name, []).append(r.copy())
         print("%-22s %-40s place_ex %8.1f ms = %9.0f samples/s   tied_nodes_ex %8.1f ms   (packed_path=%d)" % (label, name, dt * 1e3, a.queries / dt, dt2 * 1e3, pl.timing()["packed_path"]), flush=True)
+    if not env:
+        # the node-level options prepared once (ugp_ex_prepare): what a caller with ONE node vector for a whole run pays per call
+        for name, kw in (("ripples-style (mask + distance)", dict(order="bfs", node_mask=mask, distance=dist)), ("annotate-style (depth-first indices)", dict(order="dfs")),
+                         ("merge-style (root subtree, 12 levels)", dict(order="bfs", node_mask=pl.subtree_mask(0, 12)))):
+            t0 = time.perf_counter(); ex = pl.prepare_ex(**kw); tp = time.perf_counter() - t0
+            pl.place_prepared(batch_q, ex)
+            t0 = time.perf_counter()
+            for _ in range(5):
+                rp = pl.place_prepared(batch_q, ex)
+            dt = (time.perf_counter() - t0) / 5
+            same = bool((rp.view(np.int32) == res[name][0].view(np.int32)).all())
+            print("%-22s %-40s prepare %7.1f ms once, then place_prepared %7.2f ms = %9.0f samples/s   (== one-shot call: %s)" % ("prepared", name, tp * 1e3, dt * 1e3, a.queries / dt, same), flush=True)
+            if name.startswith("ripples"):   # ... and with the score matrix, into a device buffer: 64 samples x N scores per call
+                import torch
+                nb = 64
+                e1 = int(q["ent_off"][nb])
+                some = QueryBatch.from_csr(q["ent_off"][:nb + 1], q["pos"][:e1], q["ref"][:e1], q["nuc"][:e1], q["is_missing"][:e1])
+                d = torch.zeros((nb, n), dtype=torch.int32, device="cuda")
+                pl.place_prepared(some, ex, d_scores=d.data_ptr())
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(5):
+                    pl.place_prepared(some, ex, d_scores=d.data_ptr())
+                torch.cuda.synchronize()
+                dt = (time.perf_counter() - t0) / 5
+                print("%-22s %-40s place_prepared + scores on the device %7.2f ms per %d samples = %9.0f samples/s (%.1f GB of scores per s)" % ("prepared", name, dt * 1e3, nb, nb / dt, nb * n * 4 / dt / 1e9), flush=True)
+            pl.free_ex(ex)
     # ripples proper: the score of every admitted node for one pruned sample at a time (ripples/main.cpp:343-377) -- 8 samples here
     few = QueryBatch.from_csr(q["ent_off"][:9], q["pos"][:int(q["ent_off"][8])], q["ref"][:int(q["ent_off"][8])], q["nuc"][:int(q["ent_off"][8])], q["is_missing"][:int(q["ent_off"][8])])
     pl.place_ex(few, order="bfs", node_mask=mask, distance=dist, want_scores=True)

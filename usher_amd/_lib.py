@@ -66,6 +66,10 @@ SYMBOLS = {
     "ugp_tied_nodes": (C.c_int, [P, C.POINTER(ugp_queries), C.c_uint32, P, P, P]),
     "ugp_place_batch_ex": (C.c_int, [P, C.POINTER(ugp_queries), C.POINTER(ugp_place_opts), P]),
     "ugp_tied_nodes_ex": (C.c_int, [P, C.POINTER(ugp_queries), C.POINTER(ugp_place_opts), C.c_uint32, P, P, P]),
+    "ugp_ex_prepare": (C.c_int, [P, C.POINTER(ugp_place_opts), C.POINTER(P)]),
+    "ugp_ex_destroy": (None, [P]),
+    "ugp_place_batch_prepared": (C.c_int, [P, C.POINTER(ugp_queries), P, P, P, P]),
+    "ugp_device_warmup": (C.c_int, [C.c_int]),
     "ugp_node_order": (C.c_int, [P, C.c_uint32, P]),
     "ugp_subtree_mask": (C.c_int, [P, C.c_uint32, C.c_uint32, C.c_uint32, P]),
     "ugp_qset_upload": (C.c_int, [P, C.POINTER(ugp_queries), C.POINTER(P)]),

@@ -815,11 +815,16 @@ struct Prebuilt {
     std::thread th;
     int rc = 0;
     double secs = 0;
+    std::unique_ptr<FinalText> final_text;   // -n: the text of the final tree (= the tree as loaded), produced under everything else
 };
 Prebuilt *prebuild_start(const Options &opt, const Tree &T, const Backend &be) {
     // (-c changes the tree before anything is placed; -M works on copies of it)
     if (!be.prepare || !T.root || opt.collapse_tree || opt.max_trees > 1 || getenv("USHER_AMD_NO_PREBUILD")) return nullptr;
     Prebuilt *p = new Prebuilt();
+    if (opt.no_add && !opt.print_scores && !opt.collapse_output_tree) {
+        p->final_text.reset(new FinalText());
+        p->final_text->start(T, opt.write_uncondensed);
+    }
     const Backend b = be;
     p->th = std::thread([p, &T, b]() {
         const auto t0 = std::chrono::steady_clock::now();
@@ -893,8 +898,7 @@ int run_usher(const Options &opt, Tree &T, std::vector<MissingSample> &missing, 
 
     uint64_t tree_version = 1;
     FlatTree flat;
-    FinalText final_text;
-    bool final_text_started = false;
+    std::unique_ptr<FinalText> final_text = pre ? std::move(pre->final_text) : nullptr;   // (started right behind the load, or below)
     // The first flattening of a run: taken over from the thread that built it under the VCF read -- when the tree is still the one
     // that was loaded (no insertion yet) -- else built here.  false: the backend could not take the tree.
     auto build_flat = [&]() -> bool {
@@ -965,9 +969,9 @@ int run_usher(const Options &opt, Tree &T, std::vector<MissingSample> &missing, 
         if (static_tree) {   // the tree never changes: one batch call serves every sample
             if (!flat.epoch && !build_flat()) return be_fail("flattening");
             // -n: what will be written as the final tree is this tree -- its text is produced under the placement and the statistics
-            if (opt.no_add && !opt.print_scores && !opt.collapse_output_tree && !getenv("USHER_AMD_NO_PREBUILD")) {
-                final_text.start(T, opt.write_uncondensed);
-                final_text_started = true;
+            if (!final_text && opt.no_add && !opt.print_scores && !opt.collapse_output_tree && !getenv("USHER_AMD_NO_PREBUILD")) {
+                final_text.reset(new FinalText());
+                final_text->start(T, opt.write_uncondensed);
             }
             batch_res.resize(missing.size());
             if (!host_all && be.place(be.ctx, &flat.desc, tree_version, &allq.desc, batch_res.data()) != 0) return be_fail("placement");
@@ -1549,7 +1553,7 @@ int run_usher(const Options &opt, Tree &T, std::vector<MissingSample> &missing, 
     if (opt.print_scores) return 0;                                             // :800-805
     std::vector<Tree *> trees{&T};
     const auto t_out = std::chrono::steady_clock::now();
-    const int rc = write_outputs(opt, trees, missing, low_confidence, final_text_started ? &final_text : nullptr);
+    const int rc = write_outputs(opt, trees, missing, low_confidence, (final_text && opt.no_add && !opt.collapse_output_tree) ? final_text.get() : nullptr);
     if (getenv("USHER_AMD_PROFILE")) fprintf(stderr, "[usher-amd profile] output files %.3f s\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - t_out).count());
     return rc;
 }

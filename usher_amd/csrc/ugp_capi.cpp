@@ -1453,21 +1453,16 @@ struct ExHost {
     ExDev dev;
 };
 
-int prepare_ex(ugp_mat *m, const ugp_queries *q, const ugp_place_opts *o, ExHost &x, bool want_scores) {
-    const uint64_t N = m->flat.n_nodes, Q = q->n_queries;
-    if (o->order > UGP_ORDER_DFS) return fail(UGP_ERR_INVALID, "unknown node order");
-    if (m->h_parent.size() != N) return fail(UGP_ERR_INVALID, "this handle has no host topology (created from a coarse tree?)");
-    const bool dfs = o->order == UGP_ORDER_DFS;
+// The per-sample part of the options: the excluded nodes (and the chunks that hold them).  `x` receives dev.skip / dev.skip_chunk.
+int prepare_samples(ugp_mat *m, uint64_t Q, uint32_t order, const uint32_t *skip_node, ExHost &x) {
+    const uint64_t N = m->flat.n_nodes;
+    const bool dfs = order == UGP_ORDER_DFS;
     HIP_TRY(hipSetDevice(m->device));
     try {
         if (dfs) ensure_dfs_order(m);
         auto to_bfs = [&](uint64_t k) -> uint32_t { return dfs ? m->h_dfs2bfs[k] : (uint32_t)k; };
-        if (o->node_mask) {
-            std::vector<uint8_t> mk(N);
-            for (uint64_t k = 0; k < N; k++) mk[to_bfs(k)] = o->node_mask[k] ? 1 : 0;
-            HIP_TRY(x.d_mask.upload(mk));
-            x.dev.mask = x.d_mask.p;
-        }
+        const ugp_place_opts oo{order, nullptr, skip_node, nullptr, nullptr};
+        const ugp_place_opts *o = &oo;
         if (o->skip_node) {
             std::vector<uint32_t> sk(Q);
             for (uint64_t i = 0; i < Q; i++) {
@@ -1494,6 +1489,27 @@ int prepare_ex(ugp_mat *m, const ugp_queries *q, const ugp_place_opts *o, ExHost
                 HIP_TRY(x.d_skip_chunk.upload(sc));
                 x.dev.skip_chunk = x.d_skip_chunk.p;
             }
+        }
+    } catch (const std::bad_alloc &) { return fail(UGP_ERR_NOMEM, "out of host memory"); }
+    return UGP_OK;
+}
+
+// The node-level part of the options -- the caller's node order, its mask, its distances: what ripples keeps for a whole run
+// (ripples/main.cpp:303-377) and ugp_ex_prepare therefore does once.  `x` receives dev.mask / alt_rank / rank2out / out_index.
+int prepare_nodes(ugp_mat *m, const ugp_place_opts *o, ExHost &x) {
+    const uint64_t N = m->flat.n_nodes;
+    if (o->order > UGP_ORDER_DFS) return fail(UGP_ERR_INVALID, "unknown node order");
+    if (m->h_parent.size() != N) return fail(UGP_ERR_INVALID, "this handle has no host topology (created from a coarse tree?)");
+    const bool dfs = o->order == UGP_ORDER_DFS;
+    HIP_TRY(hipSetDevice(m->device));
+    try {
+        if (dfs) ensure_dfs_order(m);
+        auto to_bfs = [&](uint64_t k) -> uint32_t { return dfs ? m->h_dfs2bfs[k] : (uint32_t)k; };
+        if (o->node_mask) {
+            std::vector<uint8_t> mk(N);
+            for (uint64_t k = 0; k < N; k++) mk[to_bfs(k)] = o->node_mask[k] ? 1 : 0;
+            HIP_TRY(x.d_mask.upload(mk));
+            x.dev.mask = x.d_mask.p;
         }
         if (dfs || o->distance) {
             // tie rank of usher_mapper.cpp:483-486 in the caller's terms: smaller distance, then more descendant leaves,
@@ -1535,6 +1551,13 @@ int prepare_ex(ugp_mat *m, const ugp_queries *q, const ugp_place_opts *o, ExHost
             x.dev.out_index = m->d_bfs2dfs.p;
         }
     } catch (const std::bad_alloc &) { return fail(UGP_ERR_NOMEM, "out of host memory"); }
+    return UGP_OK;
+}
+
+int prepare_ex(ugp_mat *m, const ugp_queries *q, const ugp_place_opts *o, ExHost &x, bool want_scores) {
+    const uint64_t N = m->flat.n_nodes, Q = q->n_queries;
+    if (int rc = prepare_nodes(m, o, x)) return rc;
+    if (int rc = prepare_samples(m, Q, o->order, o->skip_node, x)) return rc;
     if (want_scores && o->scores && Q) {
         HIP_TRY(x.d_scores.reserve((size_t)Q * N));
         HIP_TRY(hipMemset(x.d_scores.p, 0, (size_t)Q * N * sizeof(int32_t)));
@@ -1616,6 +1639,70 @@ int ugp_place_batch_ex(ugp_mat *m, const ugp_queries *q, const ugp_place_opts *o
             if (out[i].num_best == 0) { out[i].best_set_difference = INT32_MAX; out[i].best_j = UINT32_MAX; out[i].best_has_unique = 0; }
     }
     ugp_qset_destroy(qs);
+    return rc;
+}
+
+// ---- the node-level options of an extended search, prepared once ---------------------------------------------------------------
+struct ugp_ex {
+    ugp_mat *m = nullptr;
+    uint32_t order = UGP_ORDER_BFS;
+    bool has_mask = false, mask_keeps_root = true;
+    ExHost x;   // mask, tie rank, index maps on the device
+};
+
+int ugp_ex_prepare(ugp_mat *m, const ugp_place_opts *opts, ugp_ex **out) {
+    if (!m || !opts || !out) return fail(UGP_ERR_INVALID, "null argument");
+    *out = nullptr;
+    ugp_ex *e = new (std::nothrow) ugp_ex();
+    if (!e) return fail(UGP_ERR_NOMEM, "out of host memory");
+    e->m = m; e->order = opts->order;
+    e->has_mask = opts->node_mask != nullptr;
+    e->mask_keeps_root = !opts->node_mask || opts->node_mask[0] != 0;   // (position 0 is the root in either order)
+    if (int rc = prepare_nodes(m, opts, e->x)) { delete e; return rc; }
+    *out = e;
+    return UGP_OK;
+}
+void ugp_ex_destroy(ugp_ex *e) { delete e; }
+
+int ugp_place_batch_prepared(ugp_mat *m, const ugp_queries *q, const ugp_ex *e, const uint32_t *skip_node, ugp_result *out, int32_t *d_scores) {
+    if (!m || !q || !e || (!out && q->n_queries)) return fail(UGP_ERR_INVALID, "null argument");
+    if (e->m != m) return fail(UGP_ERR_INVALID, "the prepared options belong to another handle");
+    if (q->n_queries == 0) return UGP_OK;
+    const uint64_t N = m->flat.n_nodes, Q = q->n_queries;
+    // the handle's own query set and result buffer (no allocation in the steady state)
+    if (!m->own_qs) { m->own_qs = new (std::nothrow) ugp_qset(); if (!m->own_qs) return fail(UGP_ERR_NOMEM, "out of host memory"); }
+    ugp_qset *qs = m->own_qs;
+    if (int rc = qset_fill(m, q, qs)) return rc;
+    HIP_TRY(m->d_own_out.reserve(Q));
+    ExHost y;   // the per-sample part: excluded nodes
+    if (int rc = prepare_samples(m, Q, e->order, skip_node, y)) return rc;
+    ExDev xd = e->x.dev;
+    xd.skip = y.dev.skip; xd.skip_chunk = y.dev.skip_chunk; xd.scores = nullptr;
+    const bool by_levels = d_scores && e->order == UGP_ORDER_BFS && !m->h_level_off.empty() && !m->knobs.scores_dfs && !m->knobs.ex_slow && !m->knobs.force_v1 &&
+                           !m->upd.n_excluded;
+    const bool packs = !m->knobs.ex_slow && (!d_scores || by_levels) &&
+                       (!e->has_mask || (e->mask_keeps_root && m->upd.rec.size() == N && !m->upd.n_excluded && N < (1ull << 30) && (!m->coarse || m->d_coarse2bfs.p)));
+    int rc = UGP_OK;
+    if (packs) {
+        rc = drain(m);
+        const uint8_t *masked = xd.mask;
+        if (rc == UGP_OK && masked) rc = mask_words(m, masked, true);
+        ExDev xp = xd;
+        xp.mask = nullptr; xp.packed = true;
+        if (rc == UGP_OK) rc = run_place(m, qs, 0, m->d_own_out.p, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, false, &xp);
+        if (masked) { const int rc2 = mask_words(m, masked, false); if (rc == UGP_OK) rc = rc2; }
+        if (rc == UGP_OK && d_scores) {   // the score matrix straight into the caller's device buffer, level by level; what was not scored reads 0
+            rc = run_place(m, qs, 1, nullptr, d_scores, nullptr, nullptr, nullptr, nullptr, 0, nullptr);
+            if (rc == UGP_OK && ugp::launch_scores_mask(d_scores, Q, N, xd.mask, xd.skip, nullptr) != hipSuccess) rc = fail(UGP_ERR_HIP, "masking the scores");
+        }
+    } else {
+        if (d_scores) { HIP_TRY(hipMemsetAsync(d_scores, 0, (size_t)Q * N * sizeof(int32_t), nullptr)); xd.scores = d_scores; }
+        rc = run_place(m, qs, 0, m->d_own_out.p, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, false, &xd);
+    }
+    if (rc == UGP_OK && hipMemcpy(out, m->d_own_out.p, Q * sizeof(ugp_result), hipMemcpyDeviceToHost) != hipSuccess) rc = fail(UGP_ERR_HIP, "copy results");
+    if (rc == UGP_OK)
+        for (uint64_t i = 0; i < Q; i++)
+            if (out[i].num_best == 0) { out[i].best_set_difference = INT32_MAX; out[i].best_j = UINT32_MAX; out[i].best_has_unique = 0; }
     return rc;
 }
 

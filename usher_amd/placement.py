@@ -232,6 +232,27 @@ class Placer:
         return [tj[i, :min(int(tc[i]), cap)].copy() for i in range(len(batch))], \
                [th[i, :min(int(tc[i]), cap)].astype(bool) for i in range(len(batch))], tc
 
+    def prepare_ex(self, order: str = "bfs", node_mask=None, distance=None):
+        """ugp_ex_prepare: the node-level options of an extended search (order, mask, distance) made ready once; returns a handle for
+        place_prepared / free_ex."""
+        o, keep = self._opts(None, order, node_mask, None, distance, None)
+        h = C.c_void_p()
+        self._ck(self._L.ugp_ex_prepare(self._h, C.byref(o), C.byref(h)))
+        return h
+
+    def free_ex(self, h) -> None:
+        if h:
+            self._L.ugp_ex_destroy(h)
+
+    def place_prepared(self, batch: QueryBatch, ex, skip_node=None, d_scores: int = 0):
+        """ugp_place_batch_prepared; d_scores = device pointer to len(batch) * n_nodes int32 (e.g. torch tensor .data_ptr()), or 0."""
+        out = np.zeros(len(batch), dtype=RESULT_DTYPE)
+        sk = None if skip_node is None else np.ascontiguousarray(skip_node, dtype=np.uint32)
+        if sk is not None and len(sk) != len(batch):
+            raise ValueError("skip_node must have one entry per query")
+        self._ck(self._L.ugp_place_batch_prepared(self._h, C.byref(batch.desc), ex, None if sk is None else _ptr(sk), _ptr(out), C.c_void_p(d_scores) if d_scores else None))
+        return out
+
     def node_order(self, order: str) -> np.ndarray:
         out = np.zeros(self.n_nodes, dtype=np.uint32)
         self._ck(self._L.ugp_node_order(self._h, {"bfs": 0, "dfs": 1}[order], _ptr(out)))
