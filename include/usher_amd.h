@@ -131,6 +131,12 @@ int ugp_mat_create(const ugp_tree_desc *tree, int device, ugp_mat **out);
 /* Same tree on several devices of one node (flattened once, uploaded n times): the replicated read-only MAT of
  * the multi-GPU path -- query samples shard across the handles, one host thread per handle. */
 int ugp_mat_create_multi(const ugp_tree_desc *tree, const int *devices, int n_devices, ugp_mat **out /* [n_devices] */);
+/* One process per GPU (the ranks of a torch.distributed / MPI launch): the flattening is host work with the same result on every
+ * rank.  ugp_flat_save runs it once and writes the result to `path` (put it on /dev/shm: a memory copy of ~0.6 GB at 10M nodes);
+ * ugp_mat_create_from_flat uploads that file to `device` without flattening again.  The file is only valid for the library build
+ * and the flattening switches (UGP_CHUNK_NODES ...) it was written under -- checked, UGP_ERR_UNSUPPORTED otherwise. */
+int ugp_flat_save(const ugp_tree_desc *tree, const char *path);
+int ugp_mat_create_from_flat(const char *path, int device, ugp_mat **out);
 void ugp_mat_destroy(ugp_mat *mat);
 int ugp_mat_info(const ugp_mat *mat, ugp_info *out);
 

@@ -16,13 +16,20 @@ def main():
     from usher_amd import Placer, QueryBatch, synth
     from usher_amd.dist import place_sharded
     local = int(os.environ["LOCAL_RANK"])
-    torch.cuda.set_device(local)
-    dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    # DIST_SHARE_DEVICE=1 (a one-GPU box): the ranks share the visible device(s) and gather through gloo -- every line of this
+    # worker and of usher_amd.dist.place_sharded runs as on N GPUs except the collective's backend
+    share = bool(os.environ.get("DIST_SHARE_DEVICE"))
+    dev_index = local % torch.cuda.device_count() if share else local
+    torch.cuda.set_device(dev_index)
+    if share:
+        dist.init_process_group("gloo")
+    else:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
     st = synth.SynthTree(300_000, n_sites=4000, seed=12)
     q = st.queries(5001, seed=99, n_lo=0, n_hi=30, iupac_hi=3)      # odd count: shards differ in size
     batch = QueryBatch.from_csr(q["ent_off"], q["pos"], q["ref"], q["nuc"], q["is_missing"])
-    pl = Placer(st.arrays, device=local)
-    res = place_sharded(pl.place, batch, device="cuda")
+    pl = Placer(st.arrays, device=dev_index)
+    res = place_sharded(pl.place, batch, device=None if share else "cuda")
     pl.close()
     cf = capi.ClosedFormC(capi.OracleTree(st.arrays)).place_csr(q["ent_off"], q["pos"], q["ref"], q["nuc"], q["is_missing"])
     ok = (res["best_set_difference"].astype(np.int64) == cf["best"]).all() and (res["num_best"].astype(np.int64) == cf["num_best"]).all() \

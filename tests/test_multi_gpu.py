@@ -34,6 +34,23 @@ def test_place_sharded_on_two_devices_rccl():
     assert "rank 0 OK" in r.stdout and "rank 1 OK" in r.stdout
 
 
+@pytest.mark.parametrize("ranks", [2, 3])
+def test_place_sharded_worker_on_a_shared_device(ranks):
+    """The same worker on whatever devices there are (DIST_SHARE_DEVICE: ranks share a device, gloo carries the gather): the sharding,
+    the padded gather buffers and the reassembly of usher_amd.dist.place_sharded with real device placements on every rank, an
+    odd sample count and -- with three ranks -- shards of different sizes."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", DIST_SHARE_DEVICE="1")
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ranks), "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(ROOT, "tests", "_dist_worker.py")], capture_output=True, text=True, timeout=1200, env=env)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
+    for k in range(ranks):
+        assert "rank %d OK" % k in r.stdout
+
+
 def test_multiplacer_matches_single_device():
     from oracle import capi
     from usher_amd import MultiPlacer, Placer, QueryBatch, synth
@@ -91,5 +108,46 @@ def test_bench_multi_rank_flow_on_one_box(ranks, tmp_path):
     assert d["n_gpus"] == ranks and d["scaling"] == "strong" and d["config"]["rccl_ranks"] == ranks and d["config"]["queries_total"] == 2400
     assert d["value"] > 0 and d["host_buffer_path"]["identical_to_device_path"] is True
     pr = d["per_rank"]
-    assert len(pr["flatten_upload_s"]) == ranks and pr["all_gather_ms"] is not None and int(pr["flatten_threads"]) >= 1
+    assert len(pr["flatten_upload_s"]) == ranks and pr["all_gather_ms"] is not None
+    assert pr["flattened_once_per_node"] is True          # (round 5: local rank 0 flattens, the others upload its file from /dev/shm)
     assert max(pr["flatten_upload_s"]) <= 1.2 * min(pr["flatten_upload_s"]) + 1.0, pr     # (+1 s: at this size the figure is mostly process noise)
+
+
+def test_flattening_saved_once_and_uploaded_from_a_file(tmp_path, monkeypatch):
+    """ugp_flat_save / ugp_mat_create_from_flat (one flattening for the ranks of a node): a handle made from the file answers like
+    one made from the arrays -- placements, tie lists, an extended search and the add-mode exclusion maps; a file written under other
+    flattening switches, a truncated one and one that is no flattening are refused."""
+    from oracle import capi
+    from tests import synth
+    from usher_amd import Placer, QueryBatch, UgpError
+    monkeypatch.setenv("UGP_COARSE_MIN_NODES", "0")
+    arrays, queries = synth.make_case(4242, n_leaves=2200, n_queries=700, n_sites=130, n_ambig=(0, 0, 2), p_masked=0.01)
+    batch = QueryBatch(queries)
+    path = str(tmp_path / "flat.bin")
+    Placer.save_flat(arrays, path)
+    a, b = Placer(arrays), Placer(arrays, flat_file=path)
+    ra, rb = a.place(batch), b.place(batch)
+    assert (ra.view(np.int32) == rb.view(np.int32)).all() and b.timing()["packed_path"] == 1
+    ot = capi.OracleTree(arrays)
+    for i in range(0, len(queries), 25):
+        w = ot.place(queries[i])
+        assert (int(rb["best_set_difference"][i]), int(rb["num_best"][i]), int(rb["best_j"][i])) == (w["best"], w["num_best"], w["best_j"])
+    ta, tb = a.tied_nodes(batch, 64), b.tied_nodes(batch, 64)
+    assert (ta[2] == tb[2]).all() and all(x.tolist() == y.tolist() for x, y in zip(ta[0], tb[0]))
+    ea, eb = a.place_ex(batch, order="dfs"), b.place_ex(batch, order="dfs")
+    assert (ea.view(np.int32) == eb.view(np.int32)).all()
+    rec = [{"flat_j": int(ra["best_j"][0]), "leaf": False, "masked": False, "path": [], "own": []}] if int(ra["best_j"][0]) else []
+    if rec:                                                    # (the update maps travel with the file: a node can be excluded)
+        a.update(rec, []); b.update(rec, [])
+        xa, xb = a.place(batch), b.place(batch)
+        assert (xa.view(np.int32) == xb.view(np.int32)).all() and int(xb["best_j"][0]) != int(ra["best_j"][0])
+    a.close(); b.close()
+    raw = open(path, "rb").read()
+    for bad in (raw[:len(raw) // 2], b"not a flattening" * 10, raw + b"x"):
+        open(path, "wb").write(bad)
+        with pytest.raises(UgpError):
+            Placer(arrays, flat_file=path)
+    monkeypatch.setenv("UGP_CHUNK_NODES", "77")                # written under other switches: refused, not mis-walked
+    open(path, "wb").write(raw)
+    with pytest.raises(UgpError):
+        Placer(arrays, flat_file=path)

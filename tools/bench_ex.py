@@ -13,6 +13,8 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from usher_amd import Placer, QueryBatch, synth   # noqa: E402
 
+import torch   # (first: torch's lazy device initialisation fails once another library has brought the runtime up)
+torch.cuda.init()
 ap = argparse.ArgumentParser()
 ap.add_argument("--nodes", type=int, default=10_000_000)
 ap.add_argument("--queries", type=int, default=4096)

@@ -59,6 +59,8 @@ P = C.c_void_p
 SYMBOLS = {
     "ugp_mat_create": (C.c_int, [C.POINTER(ugp_tree_desc), C.c_int, C.POINTER(P)]),
     "ugp_mat_create_multi": (C.c_int, [C.POINTER(ugp_tree_desc), C.POINTER(C.c_int), C.c_int, C.POINTER(P)]),
+    "ugp_flat_save": (C.c_int, [C.POINTER(ugp_tree_desc), C.c_char_p]),
+    "ugp_mat_create_from_flat": (C.c_int, [C.c_char_p, C.c_int, C.POINTER(P)]),
     "ugp_mat_destroy": (None, [P]),
     "ugp_mat_info": (C.c_int, [P, C.POINTER(ugp_info)]),
     "ugp_place_batch": (C.c_int, [P, C.POINTER(ugp_queries), P]),

@@ -1010,6 +1010,94 @@ int ugp_mat_create(const ugp_tree_desc *tree, int device, ugp_mat **out) {
     return mat_create_impl(tree, device, default_options(), out);
 }
 
+// ---- one flattening for several processes (one process per GPU: the ranks of a torch.distributed launch) ----------------------
+// The flattening is host work whose result is the same for every rank.  ugp_flat_save writes it -- streams, tables, the coarse tree
+// of the locality pre-pass -- to a file (on /dev/shm: a memory copy), ugp_mat_create_from_flat uploads it: an 8-rank launch
+// flattens once instead of eight times over.  The file is valid for this library build and this environment's flattening switches
+// only (both are hashed into its header; a mismatch is refused).
+}   // extern "C" (templates below)
+namespace {
+constexpr uint64_t kFlatMagic = 0x3154414C46504755ull;   // "UGPFLAT1"
+uint64_t flat_signature() {
+    uint64_t h = 1469598103934665603ull;
+    auto mix = [&](const char *p) { for (; p && *p; p++) { h ^= (uint8_t)*p; h *= 1099511628211ull; } h ^= 0xFF; h *= 1099511628211ull; };
+    mix(__DATE__ " " __TIME__);
+    for (const char *k : {"UGP_CHUNK_NODES", "UGP_PRUNE_MIN_WORDS", "UGP_NO_SIB", "UGP_NO_BOUND2", "UGP_LDS_SLOTS", "UGP_PRE_WEIGHT", "UGP_NO_UPDATE_MAPS",
+                          "UGP_COARSE_MIN_NODES", "UGP_NO_SORT", "UGP_COARSE_DIV", "UGP_COARSE_CHUNK_NODES"}) { mix(k); mix(getenv(k)); }
+    return h;
+}
+struct FlatWriter {
+    FILE *f; bool ok = true;
+    void raw(const void *p, size_t n) { if (ok && n && fwrite(p, 1, n, f) != n) ok = false; }
+    template <class T> void pod(const T &v) { raw(&v, sizeof v); }
+    template <class V> void vec(const V &v) { const uint64_t n = v.size(); pod(n); raw(v.data(), n * sizeof(typename V::value_type)); }
+};
+struct FlatReader {
+    const uint8_t *p, *e; bool ok = true;
+    void raw(void *d, size_t n) { if (!ok || (size_t)(e - p) < n) { ok = false; return; } memcpy(d, p, n); p += n; }
+    template <class T> void pod(T &v) { raw(&v, sizeof v); }
+    template <class V> void vec(V &v) {
+        uint64_t n = 0; pod(n);
+        if (!ok || n > (uint64_t)(e - p) / sizeof(typename V::value_type)) { ok = false; return; }
+        v.resize(n); raw(v.data(), n * sizeof(typename V::value_type));
+    }
+};
+template <class IO> void flat_io(IO &io, HostFlat &hf) {
+    auto &f = hf.f;
+    io.pod(f.n_nodes); io.pod(f.n_muts); io.pod(f.n_sites); io.pod(f.max_pos); io.pod(f.max_slots); io.pod(f.n_chunks);
+    io.pod(f.max_path_muts); io.pod(f.max_chunk8_words); io.pod(f.lds_slots); io.pod(f.mask_not_first);
+    io.vec(f.stream); io.vec(f.pre_stream); io.vec(f.chunk_body_off); io.vec(f.chunk_pre_off); io.vec(f.chunk_node_off); io.vec(f.pos2site);
+    io.vec(f.site_ref); io.vec(f.rank2bfs); io.vec(f.dfs2bfs); io.vec(f.stream8); io.vec(f.pre8_stream); io.vec(f.chunk8_body_off); io.vec(f.chunk8_pre_off);
+    io.vec(f.stream_t); io.vec(f.chunk_t_off); io.vec(f.rank_dfs); io.vec(f.node_pos8); io.vec(f.hdr8_of_bfs); io.vec(f.rec_of_bfs); io.vec(f.post_of_bfs);
+    io.vec(hf.parent); io.vec(hf.coarse2dfs); io.vec(hf.coarse2bfs); io.vec(hf.node_pair); io.pod(hf.wide_descent);
+}
+}  // namespace
+extern "C" {
+
+int ugp_flat_save(const ugp_tree_desc *tree, const char *path) {
+    if (!tree || !path) return fail(UGP_ERR_INVALID, "null argument");
+    HostFlat hf;
+    if (int rc = host_flatten(tree, default_options(), true, hf)) return rc;
+    FILE *fp = fopen(path, "wb");
+    if (!fp) return fail(UGP_ERR_INVALID, std::string("cannot write ") + path);
+    FlatWriter w{fp};
+    w.pod(kFlatMagic); const uint64_t sig = flat_signature(); w.pod(sig);
+    const uint8_t has_coarse = hf.coarse ? 1 : 0;
+    w.pod(has_coarse);
+    flat_io(w, hf);
+    if (hf.coarse) flat_io(w, *hf.coarse);
+    const bool ok = w.ok && fclose(fp) == 0;
+    if (!ok) return fail(UGP_ERR_INVALID, std::string("short write to ") + path);
+    return UGP_OK;
+}
+
+int ugp_mat_create_from_flat(const char *path, int device, ugp_mat **out) {
+    if (!path || !out) return fail(UGP_ERR_INVALID, "null argument");
+    *out = nullptr;
+    FILE *fp = fopen(path, "rb");
+    if (!fp) return fail(UGP_ERR_INVALID, std::string("cannot read ") + path);
+    std::vector<uint8_t> buf;
+    try {
+        if (fseek(fp, 0, SEEK_END) != 0) { fclose(fp); return fail(UGP_ERR_INVALID, "cannot size the flattening file"); }
+        const long sz = ftell(fp);
+        rewind(fp);
+        buf.resize(sz > 0 ? (size_t)sz : 0);
+        const bool ok = buf.empty() || fread(buf.data(), 1, buf.size(), fp) == buf.size();
+        fclose(fp);
+        if (!ok) return fail(UGP_ERR_INVALID, std::string("short read from ") + path);
+        FlatReader r{buf.data(), buf.data() + buf.size()};
+        uint64_t magic = 0, sig = 0; uint8_t has_coarse = 0;
+        r.pod(magic); r.pod(sig); r.pod(has_coarse);
+        if (!r.ok || magic != kFlatMagic) return fail(UGP_ERR_INVALID, "not a flattening written by ugp_flat_save");
+        if (sig != flat_signature()) return fail(UGP_ERR_UNSUPPORTED, "the flattening was written by another library build or under other flattening switches");
+        HostFlat hf;
+        flat_io(r, hf);
+        if (has_coarse) { hf.coarse = new HostFlat(); flat_io(r, *hf.coarse); }
+        if (!r.ok || r.p != r.e) return fail(UGP_ERR_INVALID, "truncated or oversized flattening file");
+        return upload_flat(hf, device, out);
+    } catch (const std::bad_alloc &) { return fail(UGP_ERR_NOMEM, "out of host memory"); }
+}
+
 void ugp_mat_destroy(ugp_mat *m) {
     if (!m) return;
     (void)hipSetDevice(m->device);

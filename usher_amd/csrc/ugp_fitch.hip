@@ -30,6 +30,7 @@
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <string>
 #include <vector>
@@ -79,7 +80,7 @@ __global__ __launch_bounds__(256) void k_fs_init(uint32_t *__restrict__ F, const
 // Cells are grouped by site; v_off[s] is the first cell of site s of this pass.
 __global__ void k_fs_scatter(uint32_t *__restrict__ F, const uint32_t *__restrict__ refw, const uint32_t *__restrict__ n_children,
                              const uint64_t *__restrict__ v_off, uint32_t n_sites, const uint32_t *__restrict__ v_node,
-                             const uint8_t *__restrict__ v_nuc, uint64_t n_var, uint32_t W) {
+                             const uint8_t *__restrict__ v_nuc, uint64_t n_var, uint32_t W, uint32_t n_nodes, uint32_t *__restrict__ flags) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_var) return;
     uint32_t lo = 0, hi = n_sites;   // last s with v_off[s] <= i
@@ -88,9 +89,15 @@ __global__ void k_fs_scatter(uint32_t *__restrict__ F, const uint32_t *__restric
         if (v_off[mid] <= i) lo = mid; else hi = mid;
     }
     const uint32_t s = lo, n = v_node[i];
+    // the checks the host used to run over every cell: flags bit 0 = a node index out of range, bit 1 = an allele mask outside
+    // 1..15, bit 2 = the node indices of a site do not ascend (a node may then be named twice: the caller filters and comes again)
+    const uint32_t a = v_nuc[i];
+    if (n >= n_nodes) { atomicOr(flags, 1u); return; }
+    if ((a & 0xFu) == 0 || a > 15u) { atomicOr(flags, 2u); return; }
+    if (i > v_off[s] && n <= v_node[i - 1]) atomicOr(flags, 4u);
     const uint32_t w = s >> 3, sh = (s & 7) * 4;
     const uint32_t old = n_children[n] ? 0xFu : ((refw[w] >> sh) & 0xFu);
-    const uint32_t x = (old ^ (v_nuc[i] & 0xFu)) << sh;
+    const uint32_t x = (old ^ (a & 0xFu)) << sh;
     if (x) atomicXor(&F[(uint64_t)n * W + w], x);
 }
 
@@ -267,20 +274,73 @@ __global__ void k_fs_compact(const uint64_t *__restrict__ seg_key, const uint8_t
     }
 }
 
+// Device buffers are kept from call to call (a pool per device, below): alloc() only ever grows them.
 template <typename T>
 struct Dev {
     T *p = nullptr;
+    size_t cap = 0;
     ~Dev() { if (p) (void)hipFree(p); }
     hipError_t alloc(size_t n) {
-        if (p) { (void)hipFree(p); p = nullptr; }
-        return hipMalloc((void **)&p, std::max<size_t>(n, 1) * sizeof(T));
+        if (n <= cap && p) return hipSuccess;
+        if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+        hipError_t e = hipMalloc((void **)&p, std::max<size_t>(n, 1) * sizeof(T));
+        if (e == hipSuccess) cap = std::max<size_t>(n, 1); else p = nullptr;
+        return e;
     }
-    hipError_t upload(const T *src, size_t n) {
+    hipError_t upload(const T *src, size_t n, hipStream_t st = nullptr) {
         hipError_t e = alloc(n);
         if (e != hipSuccess || n == 0) return e;
-        return hipMemcpy(p, src, n * sizeof(T), hipMemcpyHostToDevice);
+        return hipMemcpyAsync(p, src, n * sizeof(T), hipMemcpyHostToDevice, st);
     }
 };
+
+// ---- topology on the device (round 5): the caller's breadth-first parent array is non-decreasing, so the children of a node are
+// one run of it.  k_fs_heads checks the order and flags the run heads; a stream compaction lists them (heads[k] = first child of
+// the k-th internal node); k_fs_topo turns the list into first_child / n_children / the internal nodes in index (= level) order.
+// The host used to do this in three sequential passes over the 10M-entry array: 90 ms of a call whose kernels take 14.
+__global__ void k_fs_heads(const uint32_t *__restrict__ parent, uint32_t n, uint8_t *__restrict__ flag, uint32_t *__restrict__ bad) {
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    if (j == 0) { flag[0] = 0; return; }
+    const uint32_t p = parent[j], q = j > 1 ? parent[j - 1] : 0u;
+    if (p >= j || (j > 1 && p < q)) atomicOr(bad, 1u);
+    flag[j] = (j == 1 || p != q) ? 1 : 0;
+}
+__global__ void k_fs_topo(const uint32_t *__restrict__ parent, uint32_t n, const uint32_t *__restrict__ heads, const uint32_t *__restrict__ n_heads_p,
+                          uint32_t *__restrict__ first_child, uint32_t *__restrict__ n_children, uint32_t *__restrict__ inodes) {
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x, nh = *n_heads_p;
+    if (k >= nh) return;
+    const uint32_t j = heads[k], e = k + 1 < nh ? heads[k + 1] : n, p = parent[j];
+    first_child[p] = j; n_children[p] = e - j; inodes[k] = p;
+}
+// ilvl_off[L] = internal nodes in front of level L = run heads among the nodes in front of level L + 1 (their children)
+__global__ void k_fs_level_ranks(const uint32_t *__restrict__ heads, const uint32_t *__restrict__ n_heads_p, const uint32_t *__restrict__ lvl_off, uint32_t n_levels,
+                                 uint32_t *__restrict__ ilvl_off) {
+    const uint32_t L = blockIdx.x * blockDim.x + threadIdx.x;
+    if (L > n_levels) return;
+    const uint32_t nh = *n_heads_p;
+    if (L == n_levels) { ilvl_off[L] = nh; return; }
+    const uint32_t lim = lvl_off[L + 1];   // children of levels < L sit in front of lvl_off[L + 1]
+    uint32_t lo = 0, hi = nh;              // first k with heads[k] >= lim
+    while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (heads[mid] < lim) lo = mid + 1; else hi = mid; }
+    ilvl_off[L] = lo;
+}
+
+struct FsPool {   // one per device, kept until the process ends: a call allocates nothing in the steady state
+    std::mutex mu;
+    Dev<uint32_t> d_parent, d_first, d_nchild, d_inodes, d_heads, d_small, d_F, d_refw, d_vnode;
+    Dev<uint8_t> d_flag, d_vnuc, d_oval, d_oval2, d_tmp, d_sel_tmp;
+    Dev<uint64_t> d_okey, d_okey2, d_voff;
+    Dev<unsigned long long> d_cnt, d_segb;
+};
+FsPool *fs_pool(int device) {
+    static std::mutex mu;
+    static std::vector<FsPool *> pools;
+    std::lock_guard<std::mutex> g(mu);
+    if ((size_t)device >= pools.size()) pools.resize((size_t)device + 1, nullptr);
+    if (!pools[device]) pools[device] = new FsPool();
+    return pools[device];
+}
 
 }  // namespace
 
@@ -316,64 +376,86 @@ extern "C" int ugp_fitch_sankoff(int device, uint64_t n_nodes, const uint32_t *p
     };
     double t_topo = 0, t_alloc = 0, t_prep = 0, t_kern = 0, t_out = 0;
     const uint32_t N = (uint32_t)n_nodes;
-    std::vector<uint32_t> first_child(N, 0), n_children(N, 0), level(N, 0);
-    for (uint32_t j = 1; j < N; j++) {
-        const uint32_t p = parent[j];
-        if (p >= j || (j > 1 && p < parent[j - 1])) return ugp::set_error(UGP_ERR_INVALID, "tree arrays are not in breadth-first order");
-        if (n_children[p]++ == 0) first_child[p] = j;
-        level[j] = level[p] + 1;
-    }
-    std::vector<uint32_t> lvl_off;   // nodes of level L are [lvl_off[L], lvl_off[L+1])
-    for (uint32_t j = 0; j < N; j++)
-        if (j == 0 || level[j] != level[j - 1]) lvl_off.push_back(j);
-    lvl_off.push_back(N);
-    const uint32_t n_levels = (uint32_t)lvl_off.size() - 1;
-    std::vector<uint32_t> inodes, ilvl_off(n_levels + 1, 0);   // internal nodes, grouped by level
-    for (uint32_t L = 0; L < n_levels; L++) {
-        ilvl_off[L] = (uint32_t)inodes.size();
-        for (uint32_t j = lvl_off[L]; j < lvl_off[L + 1]; j++)
-            if (n_children[j]) inodes.push_back(j);
-    }
-    ilvl_off[n_levels] = (uint32_t)inodes.size();
     for (uint64_t s = 0; s < S; s++) {
         const uint8_t r = sites->ref[s];
         if (r != 1 && r != 2 && r != 4 && r != 8) return ugp::set_error(UGP_ERR_INVALID, "site reference allele is not one of A,C,G,T");
         if (sites->var_off[s + 1] < sites->var_off[s]) return ugp::set_error(UGP_ERR_INVALID, "var_off is not monotone");
     }
-    for (uint64_t v = 0; v < n_var; v++) {
-        if (sites->var_node[v] >= N) return ugp::set_error(UGP_ERR_INVALID, "variant node index out of range");
-        if ((sites->var_nuc[v] & 0xF) == 0 || sites->var_nuc[v] > 15) return ugp::set_error(UGP_ERR_INVALID, "variant allele mask must be 1..15");
-    }
-
     ugp_fitch *res = new (std::nothrow) ugp_fitch();
     if (!res) return ugp::set_error(UGP_ERR_NOMEM, "out of host memory");
     struct Guard { ugp_fitch *r; ~Guard() { delete r; } } guard{res};
-    if (S == 0) { guard.r = nullptr; *out = res; return UGP_OK; }
 
-    t_topo = lap();
     FS_TRY(hipSetDevice(device));
     hipStream_t stream = nullptr;
-    Dev<uint32_t> d_parent, d_first, d_nchild, d_inodes;
-    FS_TRY(d_parent.upload(parent, N));
-    FS_TRY(d_first.upload(first_child.data(), N));
-    FS_TRY(d_nchild.upload(n_children.data(), N));
-    FS_TRY(d_inodes.upload(inodes.data(), inodes.size()));
+    FsPool &P = *fs_pool(device);
+    std::lock_guard<std::mutex> pool_lock(P.mu);   // (calls on one device take turns: they share the pooled buffers)
+    auto &d_parent = P.d_parent; auto &d_first = P.d_first; auto &d_nchild = P.d_nchild; auto &d_inodes = P.d_inodes;
+    // ---- topology, on the device: run heads of parent[] -> first child / child count / internal nodes in level order.  The level
+    // boundaries themselves are a handful of binary searches in the caller's array (a level is an index range; its children are
+    // the nodes whose parent lies in it), meaningful once the device has confirmed the order.
+    FS_TRY(d_parent.upload(parent, N, stream));
+    FS_TRY(d_first.alloc(N)); FS_TRY(d_nchild.alloc(N)); FS_TRY(d_inodes.alloc(N)); FS_TRY(P.d_heads.alloc(N)); FS_TRY(P.d_flag.alloc(N));
+    FS_TRY(P.d_small.alloc(4096));   // [0] order violated, [1] run heads, [2] cell flags, [8..] level tables
+    FS_TRY(hipMemsetAsync(P.d_small.p, 0, 8 * sizeof(uint32_t), stream));
+    FS_TRY(hipMemsetAsync(d_first.p, 0, (size_t)N * 4, stream));
+    FS_TRY(hipMemsetAsync(d_nchild.p, 0, (size_t)N * 4, stream));
+    hipLaunchKernelGGL(k_fs_heads, dim3((N + 255) / 256), dim3(256), 0, stream, d_parent.p, N, P.d_flag.p, P.d_small.p);
+    {
+        size_t sel_bytes = 0;
+        hipcub::CountingInputIterator<uint32_t> idx(0);
+        FS_TRY(hipcub::DeviceSelect::Flagged(nullptr, sel_bytes, idx, P.d_flag.p, P.d_heads.p, P.d_small.p + 1, (int)N, stream));
+        FS_TRY(P.d_sel_tmp.alloc(sel_bytes));
+        FS_TRY(hipcub::DeviceSelect::Flagged(P.d_sel_tmp.p, sel_bytes, idx, P.d_flag.p, P.d_heads.p, P.d_small.p + 1, (int)N, stream));
+    }
+    hipLaunchKernelGGL(k_fs_topo, dim3((N + 255) / 256), dim3(256), 0, stream, d_parent.p, N, P.d_heads.p, P.d_small.p + 1, d_first.p, d_nchild.p, d_inodes.p);
+    std::vector<uint32_t> lvl_off{0, 1};   // nodes of level L are [lvl_off[L], lvl_off[L+1])
+    while (lvl_off.back() < N) {
+        // first j whose parent is not in front of the end of the last level: std::lower_bound over parent[1..N)
+        const uint32_t lim = lvl_off.back();
+        const uint32_t nxt = (uint32_t)(std::lower_bound(parent + 1, parent + N, lim) - parent);
+        if (nxt <= lim || lvl_off.size() > 4096 - 16) break;   // (no progress: the array is not a breadth-first expansion -- the device says so below; or a tree deeper than the level table)
+        lvl_off.push_back(nxt);
+    }
+    if (lvl_off.back() != N) {
+        uint32_t bad = 0;
+        FS_TRY(hipMemcpyAsync(&bad, P.d_small.p, 4, hipMemcpyDeviceToHost, stream));
+        FS_TRY(hipStreamSynchronize(stream));
+        if (bad || N > 1) {
+            if (!bad && lvl_off.size() > 4096 - 16) return ugp::set_error(UGP_ERR_UNSUPPORTED, "tree deeper than 4,000 levels");
+            return ugp::set_error(UGP_ERR_INVALID, "tree arrays are not in breadth-first order");
+        }
+    }
+    const uint32_t n_levels = (uint32_t)lvl_off.size() - 1;
+    std::vector<uint32_t> ilvl_off(n_levels + 1, 0);
+    {
+        uint32_t *d_lvl = P.d_small.p + 8, *d_ilvl = P.d_small.p + 8 + (n_levels + 1);
+        FS_TRY(P.d_small.cap >= 8 + 2 * (size_t)(n_levels + 1) ? hipSuccess : hipErrorInvalidValue);
+        FS_TRY(hipMemcpyAsync(d_lvl, lvl_off.data(), (n_levels + 1) * 4, hipMemcpyHostToDevice, stream));
+        hipLaunchKernelGGL(k_fs_level_ranks, dim3((n_levels + 1 + 63) / 64), dim3(64), 0, stream, P.d_heads.p, P.d_small.p + 1, d_lvl, n_levels, d_ilvl);
+        uint32_t bad = 0;
+        FS_TRY(hipMemcpyAsync(ilvl_off.data(), d_ilvl, (n_levels + 1) * 4, hipMemcpyDeviceToHost, stream));
+        FS_TRY(hipMemcpyAsync(&bad, P.d_small.p, 4, hipMemcpyDeviceToHost, stream));
+        FS_TRY(hipStreamSynchronize(stream));
+        if (bad) return ugp::set_error(UGP_ERR_INVALID, "tree arrays are not in breadth-first order");
+    }
+    if (S == 0) { guard.r = nullptr; *out = res; return UGP_OK; }
+    t_topo = lap();
 
     // sites per pass: F takes N * W * 4 bytes.  Passes of up to 4 GiB (or half of the free HBM if that is
     // less; UGP_FITCH_BYTES overrides): larger buffers only add allocation time, the kernels are
     // already at full width with 512-site rows.
     size_t free_b = 0, total_b = 0;
     FS_TRY(hipMemGetInfo(&free_b, &total_b));
-    uint64_t budget = std::min<uint64_t>(free_b / 2, 4ull << 30);
+    uint64_t budget = std::min<uint64_t>((free_b + P.d_F.cap * 4) / 2, 4ull << 30);
     if (const char *e = getenv("UGP_FITCH_BYTES")) budget = strtoull(e, nullptr, 10);
     uint64_t W_max = std::max<uint64_t>(budget / ((uint64_t)N * 4), 1);
     if (W_max >= 64) W_max &= ~63ull;   // whole 512-site wave rows
     const uint64_t W_all = (S + 7) / 8;
     const uint32_t W_pass = (uint32_t)std::min<uint64_t>(W_max, W_all);
-    Dev<uint32_t> d_F, d_refw, d_vnode;
-    Dev<uint8_t> d_vnuc, d_oval, d_oval2, d_tmp;
-    Dev<uint64_t> d_okey, d_okey2, d_voff;
-    Dev<unsigned long long> d_cnt, d_segb;
+    auto &d_F = P.d_F; auto &d_refw = P.d_refw; auto &d_vnode = P.d_vnode;
+    auto &d_vnuc = P.d_vnuc; auto &d_oval = P.d_oval; auto &d_oval2 = P.d_oval2; auto &d_tmp = P.d_tmp;
+    auto &d_okey = P.d_okey; auto &d_okey2 = P.d_okey2; auto &d_voff = P.d_voff;
+    auto &d_cnt = P.d_cnt; auto &d_segb = P.d_segb;
     FS_TRY(d_F.alloc((size_t)N * W_pass));
     FS_TRY(d_refw.alloc(W_pass));
     FS_TRY(d_cnt.alloc((size_t)FS_SEG * 8 + 8));
@@ -399,19 +481,42 @@ extern "C" int ugp_fitch_sankoff(int device, uint64_t n_nodes, const uint32_t *p
         }
         // Genotype cells of this pass.  A node named twice at one site keeps the last cell (:47-62 runs in
         // order).  Cells whose node indices ascend within every site cannot repeat a node and are uploaded as
-        // they are; otherwise they are filtered through a last-seen table first.
+        // they are -- the scatter kernel checks that (and the cells' ranges) as it goes; when it finds them out of
+        // order the pass starts over with the cells filtered through a last-seen table on the host.
         const uint64_t v0 = sites->var_off[s0], v1 = sites->var_off[s1];
-        bool ascending = true;
-        for (uint64_t s = s0; s < s1 && ascending; s++)
-            for (uint64_t v = sites->var_off[s] + 1; v < sites->var_off[s + 1]; v++)
-                if (sites->var_node[v] <= sites->var_node[v - 1]) { ascending = false; break; }
         const uint32_t *cell_node = sites->var_node + v0;
         const uint8_t *cell_nuc = sites->var_nuc + v0;
         uint64_t n_cells = v1 - v0;
         voff.resize(n_s + 1);
-        if (ascending) {
-            for (uint32_t k = 0; k <= n_s; k++) voff[k] = sites->var_off[s0 + k] - v0;
-        } else {
+        for (uint32_t k = 0; k <= n_s; k++) voff[k] = sites->var_off[s0 + k] - v0;
+        const uint32_t gy = (W + 63) / 64;
+        auto blocks = [&](uint64_t items, int per_wave) { return dim3((unsigned)((items + 4ull * per_wave - 1) / (4ull * per_wave))); };
+        unsigned long long seg_cap = 0;
+        for (int attempt = 0; attempt < 2; attempt++) {
+            FS_TRY(hipMemcpyAsync(d_refw.p, refw.data(), (size_t)W * 4, hipMemcpyHostToDevice, stream));
+            FS_TRY(d_voff.upload(voff.data(), voff.size(), stream));
+            FS_TRY(d_vnode.upload(cell_node, n_cells, stream));
+            FS_TRY(d_vnuc.upload(cell_nuc, n_cells, stream));
+            FS_TRY(hipMemsetAsync(d_cnt.p, 0, ((size_t)FS_SEG * 8 + 8) * sizeof(unsigned long long), stream));
+            FS_TRY(hipMemsetAsync(P.d_small.p + 2, 0, 4, stream));
+            // room for the listed changes: without cells on internal nodes a site has at most (cells + 1) of
+            // them, and usually far fewer; anything beyond the guess is handled by the exact pass below
+            seg_cap = (n_cells + n_s) / FS_SEG * 3 / 2 + 256;
+            if (const char *e = getenv("UGP_FITCH_EMIT_CAP")) seg_cap = strtoull(e, nullptr, 10);
+            FS_TRY(d_okey.alloc(seg_cap * FS_SEG));
+            FS_TRY(d_oval.alloc(seg_cap * FS_SEG));
+            hipLaunchKernelGGL(k_fs_init, blocks((uint64_t)N * gy, FS_NB), dim3(256), 0, stream, d_F.p, d_refw.p, d_nchild.p, N, W, gy);
+            uint32_t cell_flags = 0;
+            if (n_cells) {
+                hipLaunchKernelGGL(k_fs_scatter, dim3((unsigned)((n_cells + 255) / 256)), dim3(256), 0, stream, d_F.p, d_refw.p, d_nchild.p,
+                                   d_voff.p, n_s, d_vnode.p, d_vnuc.p, n_cells, W, N, P.d_small.p + 2);
+                FS_TRY(hipMemcpyAsync(&cell_flags, P.d_small.p + 2, 4, hipMemcpyDeviceToHost, stream));
+                FS_TRY(hipStreamSynchronize(stream));   // (the upload buffers of the caller may be reused / the verdict is needed)
+            }
+            if (cell_flags & 1u) return ugp::set_error(UGP_ERR_INVALID, "variant node index out of range");
+            if (cell_flags & 2u) return ugp::set_error(UGP_ERR_INVALID, "variant allele mask must be 1..15");
+            if (!(cell_flags & 4u) || attempt == 1) break;
+            // (rare) some site names a node twice or out of order: keep the last cell of every (site, node), in order of first appearance
             if (seen_site.empty()) { seen_site.assign(N, 0); seen_at.assign(N, 0); }
             vnode.clear(); vnuc.clear();
             for (uint64_t s = s0; s < s1; s++) {
@@ -425,27 +530,11 @@ extern "C" int ugp_fitch_sankoff(int device, uint64_t n_nodes, const uint32_t *p
                 }
             }
             voff[n_s] = vnode.size();
+            // (the filtered list may still not ascend: that is fine -- no node is named twice any more; the flag is ignored on the second go)
             cell_node = vnode.data(); cell_nuc = vnuc.data(); n_cells = vnode.size();
         }
-        FS_TRY(hipMemcpy(d_refw.p, refw.data(), (size_t)W * 4, hipMemcpyHostToDevice));
-        FS_TRY(d_voff.upload(voff.data(), voff.size()));
-        FS_TRY(d_vnode.upload(cell_node, n_cells));
-        FS_TRY(d_vnuc.upload(cell_nuc, n_cells));
-        FS_TRY(hipMemsetAsync(d_cnt.p, 0, ((size_t)FS_SEG * 8 + 8) * sizeof(unsigned long long), stream));
-        // room for the listed changes: without cells on internal nodes a site has at most (cells + 1) of
-        // them, and usually far fewer; anything beyond the guess is handled by the exact pass below
-        unsigned long long seg_cap = (n_cells + n_s) / FS_SEG * 3 / 2 + 256;
-        if (const char *e = getenv("UGP_FITCH_EMIT_CAP")) seg_cap = strtoull(e, nullptr, 10);
-        FS_TRY(d_okey.alloc(seg_cap * FS_SEG));
-        FS_TRY(d_oval.alloc(seg_cap * FS_SEG));
         t_prep += lap();
 
-        const uint32_t gy = (W + 63) / 64;
-        auto blocks = [&](uint64_t items, int per_wave) { return dim3((unsigned)((items + 4ull * per_wave - 1) / (4ull * per_wave))); };
-        hipLaunchKernelGGL(k_fs_init, blocks((uint64_t)N * gy, FS_NB), dim3(256), 0, stream, d_F.p, d_refw.p, d_nchild.p, N, W, gy);
-        if (n_cells)
-            hipLaunchKernelGGL(k_fs_scatter, dim3((unsigned)((n_cells + 255) / 256)), dim3(256), 0, stream, d_F.p, d_refw.p, d_nchild.p,
-                               d_voff.p, n_s, d_vnode.p, d_vnuc.p, n_cells, W);
         for (uint32_t L = n_levels; L-- > 0;) {
             const uint32_t cnt = ilvl_off[L + 1] - ilvl_off[L];
             if (cnt)
@@ -480,6 +569,7 @@ extern "C" int ugp_fitch_sankoff(int device, uint64_t n_nodes, const uint32_t *p
             hipLaunchKernelGGL(k_fs_compact, dim3(FS_SEG), dim3(256), 0, stream, d_okey.p, d_oval.p, d_segb.p, seg_cap, d_okey2.p, d_oval2.p);
         }
         FS_TRY(hipGetLastError());
+        FS_TRY(hipStreamSynchronize(stream));   // (d_okey / d_oval are about to become the sort's output)
         FS_TRY(d_okey.alloc(n_mut));
         FS_TRY(d_oval.alloc(n_mut));
         // deterministic order: by site, then breadth-first node index

@@ -133,15 +133,18 @@ class FlatTreeView:
 class Placer:
     """A flattened MAT resident on one GPU (ugp_mat) plus the batch entry points."""
 
-    def __init__(self, arrays: Dict, device: int = 0, chunk_nodes: Optional[int] = None, experiments: bool = False):
+    def __init__(self, arrays: Dict, device: int = 0, chunk_nodes: Optional[int] = None, experiments: bool = False, flat_file: Optional[str] = None):
         """experiments=True binds libusher_amd_exp.so (built with -DUGP_EXPERIMENTS: UGP_STATS, UGP_TRACE, UGP_SEED_*,
         UGP_PHASE2_PACKED, UGP_KBEST_EXCLUSIVE); the release library ignores those variables.  The tuning switches are read
-        from the environment here, once; reload_knobs() reads them again."""
+        from the environment here, once; reload_knobs() reads them again.  flat_file: a flattening of these arrays written by
+        save_flat() (ugp_flat_save) -- uploaded as it is, no flattening in this process (the other ranks of a multi-GPU launch)."""
         L = self._L = _lib.lib(experiments)
         self._t = _TreeArrays(arrays)
         self.n_nodes = self._t.n
         self._h = C.c_void_p()
-        if chunk_nodes is None:
+        if flat_file is not None:
+            self._ck(L.ugp_mat_create_from_flat(flat_file.encode(), device, C.byref(self._h)))
+        elif chunk_nodes is None:
             self._ck(L.ugp_mat_create(C.byref(self._t.desc), device, C.byref(self._h)))
         else:
             self._ck(L.ugp_mat_create_chunked(C.byref(self._t.desc), device, int(chunk_nodes), C.byref(self._h)))
@@ -150,6 +153,15 @@ class Placer:
     def _ck(self, rc: int) -> None:
         if rc != 0:
             raise UgpError(rc, (self._L.ugp_last_error() or b"").decode())
+
+    @staticmethod
+    def save_flat(arrays: Dict, path: str, experiments: bool = False) -> None:
+        """ugp_flat_save: flatten `arrays` once and write the result to `path` for Placer(..., flat_file=path) in other processes."""
+        L = _lib.lib(experiments)
+        t = _TreeArrays(arrays)
+        rc = L.ugp_flat_save(C.byref(t.desc), path.encode())
+        if rc != 0:
+            raise UgpError(rc, (L.ugp_last_error() or b"").decode())
 
     def reload_knobs(self) -> None:
         """ugp_mat_reload_knobs: the per-call tuning switches from the environment again (test / tuning hook)."""
