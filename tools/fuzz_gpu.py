@@ -45,7 +45,7 @@ def main():
             knobs["UGP_UNIT_GROW"] = str(int(rng.choice([0, 1, 4])))
             knobs["UGP_UNIT_MAX"] = str(int(rng.choice([3, 64, 100000])))
         if rng.random() < 0.5:
-            knobs["UGP_LDS_BITS"] = str(int(rng.integers(0, 2)))
+            knobs["UGP_LDS_BITS"] = str(int(rng.integers(0, 3)))   # (2: the walk without the active-row bitmap, round 5)
         for k, p in (("UGP_NO_LPT", 0.3), ("UGP_NO_SEED", 0.2), ("UGP_NO_SIB", 0.2), ("UGP_NO_SORT", 0.1), ("UGP_NO_DESCENT", 0.3), ("UGP_NO_BOUND2", 0.2),
                      ("UGP_PRE_WEIGHT", 0.2), ("UGP_COARSE_PHASE2", 0.2), ("UGP_NMASK", 0.3), ("UGP_PHASE2_PACKED", 0.25), ("UGP_RADIX_SORT", 0.3)):
             if rng.random() < p:

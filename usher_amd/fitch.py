@@ -15,8 +15,11 @@ def fitch_sankoff(parent, ref, var_off, var_node, var_nuc, device: int = 0):
     (var_off, var_node, var_nuc): CSR of the non-REF genotype cells of tree nodes per site.
     Returns (site, node, par_nuc, mut_nuc) arrays, ordered by site then node."""
     L = _lib.lib()
-    par = np.asarray(parent).astype(np.int64)
-    par = np.where(par < 0, 0xFFFFFFFF, par).astype(np.uint32)
+    if isinstance(parent, np.ndarray) and parent.dtype == np.uint32 and parent.flags.c_contiguous:
+        par = parent            # (already what the C ABI takes: root = UINT32_MAX)
+    else:
+        par = np.asarray(parent).astype(np.int64)
+        par = np.where(par < 0, 0xFFFFFFFF, par).astype(np.uint32)
     ref = np.ascontiguousarray(ref, dtype=np.uint8)
     var_off = np.ascontiguousarray(var_off, dtype=np.uint64)
     var_node = np.ascontiguousarray(var_node, dtype=np.uint32)
@@ -26,7 +29,10 @@ def fitch_sankoff(parent, ref, var_off, var_node, var_nuc, device: int = 0):
     p = lambda a: a.ctypes.data_as(C.c_void_p)
     sites = _lib.ugp_sites(len(ref), p(ref), p(var_off), p(var_node), p(var_nuc))
     h = C.c_void_p()
+    import time
+    t0 = time.perf_counter()
     rc = L.ugp_fitch_sankoff(device, len(par), p(par), C.byref(sites), C.byref(h))
+    fitch_sankoff.last_call_s = time.perf_counter() - t0   # (the C call alone: what bench_fitch.py reports)
     if rc != 0:
         raise RuntimeError("ugp_fitch_sankoff failed (%d): %s" % (rc, L.ugp_last_error().decode()))
     try:
