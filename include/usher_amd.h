@@ -372,7 +372,9 @@ enum {
     UGP_FLAT_MAX_PATH_MUTS = 14, /* count only */
     UGP_FLAT_STREAM_T = 15,     /* uint32: tie stream walked by phase 2 (chunk bodies + pruning pseudo-records) */
     UGP_FLAT_CHUNK_T_OFF = 16,  /* uint32 [n_chunks+1] */
-    UGP_FLAT_LDS_SLOTS = 17     /* count only: saved-D slots the packed stream keeps on the fast path */
+    UGP_FLAT_LDS_SLOTS = 17,    /* count only: saved-D slots the packed stream keeps on the fast path */
+    UGP_FLAT_B3_PAIR_OFF = 18,  /* uint32 [4 * n_sites + 1]: third pruning bound, events of every (site, mutated allele) pair */
+    UGP_FLAT_B3_EVENTS = 19     /* uint32 [2 * events]: first / last block of packed-stream words of each event's subtree */
 };
 int ugp_flat_create(const ugp_tree_desc *tree, uint32_t chunk_nodes, ugp_flat **out);
 void ugp_flat_destroy(ugp_flat *flat);

@@ -155,7 +155,54 @@ M_FLUSH, M_END = 1 << 28, 1 << 30
 U16 = 0xFFFF
 
 
-def best8_group(flat, nib, dbot, c0, c1, ub=None, stats=None, use_pre_records=True):
+B3_BLOCK_SHIFT = 4
+
+
+def b3_tables(flat, nibs):
+    """The per-tile tables of the third pruning bound as ugp_bound3.hip builds them, for a "tile" = the samples whose site nibbles are
+    `nibs`: a (site, allele) pair is useful when some sample's set holds the allele and not the reference base; the events of the
+    useful pairs (the tree's posting lists) raise, per block of 16 packed-stream words,
+        over[b]  = events whose block range contains b,      under[b] = events whose range contains b strictly inside."""
+    n_sites = len(flat.site_ref)
+    useful = np.zeros(n_sites, np.int64)
+    for nib in nibs:
+        excl = (nib & flat.site_ref.astype(np.int64)) == 0
+        useful[excl] |= nib[excl]
+    nb = ((len(flat.stream8) + 15) >> B3_BLOCK_SHIFT) + 1
+    start = np.zeros(nb + 1, np.int64); end = np.zeros(nb + 1, np.int64); same = np.zeros(nb + 1, np.int64)
+    ev = flat.b3_events.reshape(-1, 2).astype(np.int64)
+    for site in np.flatnonzero(useful):
+        for al in range(4):
+            if not (useful[site] >> al) & 1:
+                continue
+            q = site * 4 + al
+            e = ev[int(flat.b3_pair_off[q]):int(flat.b3_pair_off[q + 1])]
+            one = e[:, 0] == e[:, 1]
+            np.add.at(same, e[one, 0], 1)
+            np.add.at(start, e[~one, 0], 1)
+            np.add.at(end, e[~one, 1], 1)
+    S, E = np.cumsum(start), np.cumsum(end)
+    Sprev = np.concatenate([[0], S[:-1]]); Eprev = np.concatenate([[0], E[:-1]])
+    over = S - Eprev + same
+    under = Sprev - E
+    assert (under >= 0).all()
+    return {"over": over, "under": under, "useful": useful}
+
+
+def b3_hu(b3, P, J):
+    """Upper bound of the useful events on any path below the node whose last word sits at stream position P, its descendants in
+    the J words behind it -- read as the kernel reads it: 64 entries at the coarsest 64-ary level whose span fits."""
+    q0, q1 = (P + 1) >> B3_BLOCK_SHIFT, (P + J) >> B3_BLOCK_SHIFT
+    sh = 0
+    while q1 - q0 >= 64:
+        q0 >>= 6; q1 >>= 6; sh += 6
+    lo, hi = q0 << sh, min(len(b3["over"]), (q1 + 1) << sh)
+    m = int(b3["over"][lo:hi].max())
+    u = int(b3["under"][P >> B3_BLOCK_SHIFT])
+    return max(0, m - u)
+
+
+def best8_group(flat, nib, dbot, c0, c1, ub=None, stats=None, use_pre_records=True, b3=None):
     """Chunk-local minima of one sample for chunks [c0, c1), as k_best8 computes them.
     ub: None = no pruning; otherwise a one-element list holding an upper bound of the sample's best
     score, used (and tightened at chunk ends) exactly like the kernel's shared bound."""
@@ -304,7 +351,18 @@ def best8_group(flat, nib, dbot, c0, c1, ub=None, stats=None, use_pre_records=Tr
             elif ended and info is not None:
                 rec, jump = info, info & INFO_JUMP_MASK
                 info = None
-                if far(dcur, bcur, rec, ub[0]):     # D(node) - bound > upper bound: no descendant can tie or win
+                is_far = far(dcur, bcur, rec, ub[0])     # D(node) - bound > upper bound: no descendant can tie or win
+                if not is_far and b3 is not None:        # third bound (the kernel: at the restart this record asks for)
+                    hs3, hr3 = (rec >> INFO_HS_SHIFT) & 0x7F, (rec >> INFO_HR_SHIFT) & 7
+                    if hr3 != INFO_HR_NONE and hs3 > hr3 and jump >= B3_MIN_JUMP:
+                        hu = b3_hu(b3, i, jump)
+                        if stats is not None:
+                            stats["b3_asked"] = stats.get("b3_asked", 0) + 1
+                        if hu + hr3 < hs3:
+                            is_far = far(dcur, bcur, (rec & ~(0x7F << INFO_HS_SHIFT)) | ((hu + hr3) << INFO_HS_SHIFT), ub[0])
+                            if is_far and stats is not None:
+                                stats["b3_jumps"] = stats.get("b3_jumps", 0) + 1
+                if is_far:
                     target = i + 1 + jump
                     if stats is not None:
                         stats["skipped"] = stats.get("skipped", 0) + min(target, hi) - (i + 1)
@@ -322,7 +380,10 @@ def best8_group(flat, nib, dbot, c0, c1, ub=None, stats=None, use_pre_records=Tr
     return lbest
 
 
-def place8(flat, sample, n_groups=1, prune_ub=None, stats=None):
+B3_MIN_JUMP = 12
+
+
+def place8(flat, sample, n_groups=1, prune_ub=None, stats=None, b3=None):
     """Phase 1 (k_best8) + phase 2 (k_gbest, k_select, k_ties with the 32-bit walk, k_final).
     prune_ub: None = no pruning; an int = initial upper bound shared by the groups (0x7F7F = the
     kernel's start value; the true best = the tightest legal bound)."""
@@ -334,7 +395,7 @@ def place8(flat, sample, n_groups=1, prune_ub=None, stats=None):
     for g in range(n_groups):
         c0, c1 = g * n_chunks // n_groups, (g + 1) * n_chunks // n_groups
         if c0 < c1:
-            lbest.update(best8_group(flat, nib, dbot, c0, c1, ub, stats))
+            lbest.update(best8_group(flat, nib, dbot, c0, c1, ub, stats, b3=b3))
     assert len(lbest) == n_chunks
     gbest = min(lbest.values())
     cnt, key = 0, 0

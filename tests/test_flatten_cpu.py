@@ -379,3 +379,215 @@ def test_preamble_records_skip_far_units_exactly(seed, chunk_nodes, monkeypatch)
         res = stream_interp.place8(flat, s, n_groups=max(1, n_chunks // 4), prune_ub=want["best"] + 1)
         assert (res["best"], res["num_best"], res["best_j"]) == (want["best"], want["num_best"], want["best_j"])
     assert pre_skipped > 0.25 * body   # a large part of the tree is ruled out during the replays (5,000 nodes: units are coarse)
+
+
+@pytest.mark.parametrize("seed", [1301, 1302])
+def test_third_lower_bound_holds_for_every_node_and_sample(seed):
+    """Round 5 -- the bound the third test rests on, checked as stated (ugp_flatten.hpp "B3") by brute force on the tree arrays: a
+    mutation lowers D for sample s only if it is USEFUL for s (its allele lies in the sample's set and the reference base does not)
+    or a SECOND HIT (the parent state is not the reference base); hence for a tile T of samples, every node n, every strict
+    descendant d and every s in T:    cost(d, s) >= D(n, s) - (hU_T(n) + hsec(n)),
+    hU_T(n) = the largest number, over the paths below n, of mutations useful for some sample of T.  Few sites, N and IUPAC cells,
+    masked mutations; tiles of 1, 4 and 30 samples; the bound is attained somewhere and beats hsub somewhere."""
+    arrays, queries = synth.make_case(seed, n_leaves=300, n_queries=30, n_sites=40, p_masked=0.03, mut_counts=(0, 0, 1, 1, 2, 3, 5), n_ambig=(0, 2, 5, 12))
+    n = int(arrays["n"])
+    par = np.asarray(arrays["parent"]).astype(np.int64)
+    off = np.asarray(arrays["mut_off"]).astype(np.int64)
+    pos, ref, nuc = (np.asarray(arrays[k]).astype(np.int64) for k in ("mut_pos", "mut_ref", "mut_nuc"))
+    state = [None] * n
+    prev = np.zeros(len(pos), np.int64)
+    own = np.zeros(n, np.int64); sec = np.zeros(n, np.int64)
+    for j in range(n):
+        st = dict(state[par[j]]) if j else {}
+        for i in range(off[j], off[j + 1]):
+            if pos[i] < 0:
+                continue
+            p = int(pos[i])
+            prev[i] = st.get(p, int(ref[i]))
+            own[j] += 1
+            sec[j] += p in st
+            if nuc[i] == ref[i]:
+                st.pop(p, None)
+            else:
+                st[p] = int(nuc[i])
+        state[j] = st
+    hsub = np.zeros(n, np.int64); hsec = np.zeros(n, np.int64)
+    for j in range(n - 1, 0, -1):
+        hsub[par[j]] = max(hsub[par[j]], own[j] + hsub[j])
+        hsec[par[j]] = max(hsec[par[j]], sec[j] + hsec[j])
+    sets = []
+    for s in queries:
+        sets.append({int(p): (0xF if mis else int(a)) for p, a, mis in zip(s["pos"], s["nuc"], s["is_missing"])})
+    checked = tight = better = 0
+    for tile in ([0], [3, 4, 5, 6], list(range(len(queries)))):
+        useful = np.zeros(len(pos), bool)          # per mutation: useful for some sample of the tile
+        for i in range(len(pos)):
+            if pos[i] < 0:
+                continue
+            for t in tile:
+                sp = sets[t].get(int(pos[i]), int(ref[i]))
+                if (sp & nuc[i]) and not (sp & ref[i]):
+                    useful[i] = True
+                    break
+        un = np.array([useful[off[j]:off[j + 1]].sum() for j in range(n)], np.int64)
+        hu = np.zeros(n, np.int64)
+        for j in range(n - 1, 0, -1):
+            hu[par[j]] = max(hu[par[j]], un[j] + hu[j])
+        for t in tile:
+            S = sets[t]
+            s = queries[t]
+            d_bot = sum(1 for r, a, mis in zip(s["ref"], s["nuc"], s["is_missing"]) if not mis and (int(a) & int(r)) == 0)
+            D = np.zeros(n, np.int64); cost = np.zeros(n, np.int64)
+            for j in range(n):
+                dp = D[par[j]] if j else d_bot
+                dsum = neg = 0
+                masked = False
+                for i in range(off[j], off[j + 1]):
+                    if pos[i] < 0:
+                        masked = True
+                        continue
+                    sp = S.get(int(pos[i]), int(ref[i]))
+                    delta = (1 if sp & prev[i] else 0) - (1 if sp & nuc[i] else 0)
+                    dsum += delta
+                    if not masked:
+                        neg += min(delta, 0)
+                D[j] = dp + dsum
+                cost[j] = D[j] if j == 0 else dp + neg
+            below = np.full(n, 1 << 30, np.int64)
+            for j in range(n - 1, 0, -1):
+                below[par[j]] = min(below[par[j]], cost[j], below[j])
+            inner = below < (1 << 30)
+            assert (below[inner] >= D[inner] - (hu[inner] + hsec[inner])).all()
+            checked += int(inner.sum())
+            tight += int((below[inner] == D[inner] - (hu[inner] + hsec[inner])).sum())
+            better += int(((hu + hsec)[inner] < hsub[inner]).sum())
+    assert checked > 5000 and tight > 0 and better > 0
+
+
+@pytest.mark.parametrize("seed,chunk_nodes", [(71, 700), (72, 64), (73, 0)])
+def test_third_bound_tables_skip_more_and_change_nothing(seed, chunk_nodes):
+    """The third bound as the device builds and reads it (tests/stream_interp.b3_tables / b3_hu: posting lists of the flattening ->
+    cum_over / cum_under per block of 16 stream words -> the maximum over the descendants' blocks at the coarsest 64-ary level that
+    fits, minus cum_under of the node's own block): (1) the posting lists hold every mutation word of the packed body exactly once,
+    under its (site, allele); (2) what the tables give is never below the true path maximum of useful events -- recomputed from the
+    stream itself -- for every record; (3) the model of the walk, with the tables of the whole batch as one tile and each sample's
+    own exact score as its bound, returns the oracle's answers and skips more of the stream than without."""
+    arrays, queries = synth.make_case(seed, n_leaves=2600, n_queries=10, n_sites=300, n_ambig=(0, 0, 2, 6), p_masked=0.01)
+    flat = FlatTreeView(arrays, chunk_nodes=chunk_nodes)
+    s8 = flat.stream8.astype(np.int64)
+    H_TAG = 1 << 31
+    is_mut = (s8 & H_TAG) == 0
+    # (1) every mutation word once
+    ev = flat.b3_events.reshape(-1, 2).astype(np.int64)
+    assert len(ev) == int(is_mut.sum()) and int(flat.b3_pair_off[-1]) == len(ev)
+    pairs = (s8[is_mut] & 0x3FFFFF) * 4 + ((s8[is_mut] >> 22) & 3)
+    assert (np.bincount(pairs, minlength=len(flat.b3_pair_off) - 1) == np.diff(flat.b3_pair_off.astype(np.int64))).all()
+    assert (ev[:, 0] <= ev[:, 1]).all() and ev[:, 1].max() <= (len(s8) - 1) >> 4
+    nibs = [stream_interp.sample_site_alleles(flat, s)[0] for s in queries]
+    b3 = stream_interp.b3_tables(flat, nibs)
+    # (2) against the stream: walk the body once, keeping for every open node the running count of useful words on its root path
+    useful = b3["useful"]
+    INFO, RARE, SIB, CE, NOP, ENDF = 1 << 30, 1 << 29, 1 << 21, 1 << 8, 1 << 9, 1 << 3
+    recs = []            # (position of the node's last word, jump, cum at the node)
+    cum_at = np.zeros(len(s8), np.int64)     # cum of the node that owns each word (headers and mutation words)
+    # subtree extents from the pruning records themselves: a record in front of a node gives the words of its descendants
+    # cum(node) = cum(parent) + useful words of the node; parents via a stack of (end position, cum)
+    stack = []           # (end of subtree, cum)
+    i = 0
+    pend = None
+    node_cum = 0
+    while i < len(s8):
+        w = int(s8[i])
+        if w & H_TAG:
+            if w & INFO:
+                if not (w & SIB):
+                    pend = w & ((1 << 18) - 1)
+                i += 1
+                continue
+            if w & (CE | NOP) and w & RARE:
+                i += 1
+                continue
+            while stack and stack[-1][0] <= i:
+                stack.pop()
+            base = stack[-1][1] if stack else 0
+            k = i + 1
+            cnt = 0
+            if not (w & ENDF):
+                while True:
+                    m = int(s8[k])
+                    cnt += (useful[m & 0x3FFFFF] >> ((m >> 22) & 3)) & 1
+                    k += 1
+                    if m & (1 << 30):
+                        break
+            node_cum = base + cnt
+            last = k - 1
+            if pend is not None:
+                recs.append((last, pend, node_cum))
+                stack.append((last + 1 + pend, node_cum))
+                pend = None
+            i = k
+            continue
+        i += 1
+    assert len(recs) > 50
+    # true maximum below a record = the largest cum among the records / nodes inside its range: recompute by brute force over words
+    # (cum of any node inside the range is bounded by the cum of nodes that carry records or not -- walk again, cheaply, per record)
+    pos_cum = {}
+    stack = []
+    i = 0
+    pend = None
+    while i < len(s8):
+        w = int(s8[i])
+        if w & H_TAG:
+            if w & INFO:
+                if not (w & SIB):
+                    pend = w & ((1 << 18) - 1)
+                i += 1
+                continue
+            if w & (CE | NOP) and w & RARE:
+                i += 1
+                continue
+            while stack and stack[-1][0] <= i:
+                stack.pop()
+            base = stack[-1][1] if stack else 0
+            k = i + 1
+            cnt = 0
+            if not (w & ENDF):
+                while True:
+                    m = int(s8[k])
+                    cnt += (useful[m & 0x3FFFFF] >> ((m >> 22) & 3)) & 1
+                    k += 1
+                    if m & (1 << 30):
+                        break
+            pos_cum[k - 1] = base + cnt
+            if pend is not None:
+                stack.append((k + pend, base + cnt))
+                pend = None
+            i = k
+            continue
+        i += 1
+    lasts = np.array(sorted(pos_cum), np.int64)
+    cums = np.array([pos_cum[p] for p in lasts], np.int64)
+    loose = 0
+    for last, jump, c in recs:
+        a, b = np.searchsorted(lasts, last + 1), np.searchsorted(lasts, last + 1 + jump)
+        true_hu = max(0, int(cums[a:b].max()) - c) if b > a else 0
+        # (nodes without a record of their own inherit the cum of the nearest recorded ancestor in this bookkeeping: an
+        # under-estimate of their cum, hence of true_hu -- the inequality tested is still the one that matters: tables >= truth seen)
+        got = stream_interp.b3_hu(b3, last, jump)
+        assert got >= true_hu, (last, jump, got, true_hu)
+        loose += got - true_hu
+    # (3) exact results, more skipped
+    ot = capi.OracleTree(arrays)
+    sk0 = sk1 = asked = 0
+    for s in queries:
+        want = ot.place(s)
+        for tables in (None, b3):
+            st = {}
+            got = stream_interp.place8(flat, s, n_groups=3, prune_ub=want["best"], stats=st, b3=tables)
+            for k in ("best", "num_best", "best_j", "has_unique"):
+                assert got[k] == want[k], (k, tables is not None)
+            if tables is None:
+                sk0 += st.get("skipped", 0)
+            else:
+                sk1 += st.get("skipped", 0); asked += st.get("b3_asked", 0)
+    assert asked > 0 and sk1 >= sk0

@@ -203,10 +203,97 @@ u_sub = np.zeros(n, np.int64)
 for li in range(len(starts) - 2, 0, -1):
     lo, hi = starts[li], starts[li + 1]
     np.add.at(u_sub, par[lo:hi], u_sub[lo:hi] + u_node[lo:hi])
-for K in (8, 16, 24, 32, 48, 64, 128, 1 << 30):
+for K in ((32, 1 << 30) if os.environ.get('SIM_V1_ONLY') else (8, 16, 24, 32, 48, 64, 128, 1 << 30)):
     hk = np.where(subw <= K, np.minimum(hsub, u_sub + hsec), hsub)
     walk(np.minimum(hk[None, :], A64 + hsec[None, :]), "E1s subtree totals within %s words" % (K if K < (1 << 30) else "any number of"))
 if os.environ.get('SIM_SKIP_E23'): sys.exit(0)
+# V1: an implementable path maximum: the useful events of the tile (4 % of the mutations, found through static posting
+# lists per (site, allele)) raise a counter over the DFS interval of their node's subtree, at BLOCK granularity (a block = BLK nodes of
+# the DFS order ~ 2 BLK stream words): cum_over[block] >= the number of useful events on the root path of any node of the block.  For a
+# record at n:  hU(n) <= max(cum_over over the blocks of n's descendants) - cumU(n), cumU(n) = useful events on root -> n, exact (the
+# walk tracks it like D).  Blocks are read 64 at a time, at the coarsest of 64-ary levels whose span of the range is < 64 entries.
+cumU = np.zeros(n, np.int64)
+cumU[0] = u_node[0]
+for li in range(1, len(starts) - 1):
+    lo, hi = starts[li], starts[li + 1]
+    cumU[lo:hi] = cumU[par[lo:hi]] + u_node[lo:hi]
+ev_node = node_of_mut[u_tile]
+for BLK in ((8, 16) if os.environ.get('SIM_BLK_BIG') else (1, 2, 4)):
+    nb = (n + BLK - 1) // BLK + 2
+    b0 = dfs[ev_node] // BLK
+    b1 = (dfs[ev_node] + sub[ev_node] - 1) // BLK
+    plus = np.bincount(b0, minlength=nb).astype(np.int64)
+    minus = np.bincount(b1 + 1, minlength=nb + 1).astype(np.int64)[:nb]
+    cum_over = np.cumsum(plus) - np.cumsum(minus)
+    levels = [cum_over]
+    while len(levels[-1]) > 64:
+        a = levels[-1]
+        pad = (-len(a)) % 64
+        a = np.concatenate([a, np.zeros(pad, np.int64)]).reshape(-1, 64).max(axis=1)
+        levels.append(a)
+    def sparse(a):
+        st = [a]
+        k = 1
+        while k < 64:
+            prev = st[-1]
+            nxt = prev.copy()
+            if len(prev) > k:
+                nxt[:len(prev) - k] = np.maximum(prev[:len(prev) - k], prev[k:])
+            st.append(nxt)
+            k *= 2
+        return st
+    sts = [sparse(a) for a in levels]
+    q0 = (dfs + 1) // BLK                     # first descendant
+    q1 = (dfs + sub - 1) // BLK               # last descendant
+    has_desc = sub > 1
+    hU = np.zeros(n, np.int64)
+    done = ~has_desc
+    for L, st in enumerate(sts):
+        i0 = q0 >> (6 * L)
+        i1 = q1 >> (6 * L)
+        sel = (~done) & (i1 - i0 < 64)
+        if sel.any():
+            ln = (i1 - i0 + 1)[sel]
+            k = np.floor(np.log2(ln)).astype(np.int64)
+            a0 = i0[sel]; a1 = i1[sel] - (1 << k) + 1
+            m = np.zeros(sel.sum(), np.int64)
+            for kk in range(7):
+                w = k == kk
+                if w.any():
+                    m[w] = np.maximum(st[kk][a0[w]], st[kk][a1[w]])
+            hU[sel] = np.maximum(0, m - cumU[sel])
+            done |= sel
+    hk = np.minimum(hsub, hU + hsec)
+    ok = (hU >= hA1).all()
+    walk(np.minimum(hk[None, :], A64 + hsec[None, :]), "V1 block cum maxima, block = %d nodes (valid: %s)" % (BLK, ok))
+    # V2: nothing tracked by the walk -- cumU(n) replaced by cum_under[block of n] = events that cover n's whole block (they lie on n's
+    # root path), so hU2 = (maximum over the descendants' blocks) - cum_under >= hU
+    same = np.bincount(b0[b0 == b1], minlength=nb).astype(np.int64)
+    endc = np.bincount(b1, minlength=nb).astype(np.int64)
+    startcum = np.cumsum(plus)
+    cum_under = np.concatenate([[0], startcum[:-1]]) - np.cumsum(endc) + same
+    assert (cum_under >= 0).all() and (cum_under[dfs // BLK] <= cumU).all()
+    # the maximum over the range as computed above was m - cumU: redo with cum_under
+    hU2 = np.zeros(n, np.int64)
+    done = ~has_desc
+    for L, st in enumerate(sts):
+        i0 = q0 >> (6 * L)
+        i1 = q1 >> (6 * L)
+        sel = (~done) & (i1 - i0 < 64)
+        if sel.any():
+            ln = (i1 - i0 + 1)[sel]
+            k = np.floor(np.log2(ln)).astype(np.int64)
+            a0 = i0[sel]; a1 = i1[sel] - (1 << k) + 1
+            m = np.zeros(sel.sum(), np.int64)
+            for kk in range(7):
+                w = k == kk
+                if w.any():
+                    m[w] = np.maximum(st[kk][a0[w]], st[kk][a1[w]])
+            hU2[sel] = np.maximum(0, m - cum_under[(dfs // BLK)[sel]])
+            done |= sel
+    hk2 = np.minimum(hsub, hU2 + hsec)
+    walk(np.minimum(hk2[None, :], A64 + hsec[None, :]), "V2 no tracking: max - cum_under, block = %d nodes (valid: %s)" % (BLK, (hU2 >= hA1).all()))
+if os.environ.get('SIM_V1_ONLY'): sys.exit(0)
 bound2 = np.empty((512, n), np.int64)
 for g in range(8):
     ug = useful[g * 64:(g + 1) * 64].any(axis=0)

@@ -1,0 +1,33 @@
+// ugp_bound3.hpp -- the per-batch tables of the third pruning bound (ugp_flatten.hpp "B3"; kernels in ugp_bound3.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "ugp_flatten.hpp"
+
+namespace ugp {
+
+// What k_best8 reads at a record whose first two tests failed (one small struct on the device: the walk's kernel arguments stay
+// what they were -- the kernel sits at its scalar-register limit).  All arrays are per 512-sample tile, tile-major.
+struct B3Dev {
+    const uint16_t *over;    // [n_tiles][n_blocks]   cum_over
+    const uint16_t *under;   // [n_tiles][n_blocks]   cum_under
+    const uint16_t *l1;      // [n_tiles][n_l1]       maxima of cum_over over 64 blocks
+    const uint16_t *l2;      // [n_tiles][n_l2]       ... over 64 x 64
+    const uint16_t *l3;      // [n_tiles][n_l3]       ... over 64^3
+    uint32_t n_blocks, n_l1, n_l2, n_l3;
+};
+
+constexpr uint32_t B3_SEG = 4096;   // blocks per scan segment (= 64 level-1 entries)
+
+// work[tile][block]: start count (bits 7:0), same-block count (15:8), end count (31:16) -- zeroed by the caller.
+// useful[tile][useful_words]: one nibble per site, bit a = allele a is in some sample's set that excludes the reference base.
+hipError_t launch_b3_events(const uint32_t *useful, uint32_t useful_words, uint32_t n_sites, uint32_t n_tiles, const uint32_t *pair_off, const uint32_t *events,
+                            uint32_t *work, uint32_t n_blocks, hipStream_t s);
+// seg: [n_tiles][n_seg][2] scratch.  Fills over / under / l1 / l2 / l3.
+hipError_t launch_b3_tables(const uint32_t *work, uint32_t n_tiles, uint32_t n_blocks, uint32_t *seg, uint16_t *over, uint16_t *under, uint16_t *l1, uint16_t *l2,
+                            uint16_t *l3, hipStream_t s);
+inline uint32_t b3_blocks(uint64_t stream8_words) { return (uint32_t)((stream8_words + B3_BLOCK_WORDS - 1) >> B3_BLOCK_SHIFT) + 1u; }
+inline uint32_t b3_div64(uint32_t n) { return (n + 63u) / 64u; }
+
+}  // namespace ugp

@@ -15,6 +15,7 @@
 #include <thread>
 #include <vector>
 
+#include "ugp_bound3.hpp"
 #include "ugp_flatten.hpp"
 #include "ugp_kernels.hpp"
 #include "ugp_knobs.hpp"
@@ -162,6 +163,7 @@ struct ugp_mat {
     DevBuf<uint32_t> d_stream, d_pre, d_chunk_body, d_chunk_pre, d_chunk_node, d_rank2bfs, d_dfs2bfs;
     DevBuf<uint32_t> d_stream8, d_pre8, d_chunk8_body, d_chunk8_pre, d_stream_t, d_chunk_t;
     DevBuf<uint32_t> d_node_pos8, d_rank_dfs;   // packed-stream position of every node's words and its tie rank, by DFS index (k_best8 names nodes by position)
+    DevBuf<uint32_t> d_b3_pair_off, d_b3_events;   // third pruning bound: posting lists of the mutation events by (site, allele) (FlatMat::b3_*)
     uint64_t stream8_dwords = 0;
     DevBuf<int32_t> d_pos2site, d_site_pos;   // position -> site, site -> position
     DevBuf<uint8_t> d_site_ref;
@@ -195,6 +197,11 @@ struct ugp_mat {
         DevBuf<uint32_t> d_lbest, d_gbest, d_gbest_part, d_items, d_ub, d_gstart, d_hlen, d_cold, d_list, d_units, d_unit_info;
         DevBuf<uint64_t> d_dyn;
         uint32_t dyn_epoch = 0;
+        // third pruning bound: per-batch block tables of every tile (ugp_bound3.hpp)
+        DevBuf<uint32_t> d_b3_work, d_b3_seg;
+        DevBuf<uint16_t> d_b3_over, d_b3_under, d_b3_l1, d_b3_l2, d_b3_l3;
+        DevBuf<ugp::B3Dev> d_b3_dev;
+        ugp::B3Dev b3_host = {};
         DevBuf<uint64_t> d_stats, d_trace;
         uint64_t last_words_total = 0;
         const uint32_t *last_list_n = nullptr;   // (UGP_STATS) record counts of the last packed launch, per 512-sample tile
@@ -410,13 +417,17 @@ int run_place(ugp_mat *m, ugp_qset *qs, int mode, ugp_result *d_out, int32_t *d_
         const uint64_t pairs = (uint64_t)f.n_chunks * n_tiles512 * 8;
         // every small buffer that has to start from zero lives in ONE allocation cleared by one memset:
         // D(bottom) counters, active-row bitmap, work-queue heads, record lists' lengths, phase-2 item count, tie counts / keys
+        // Third pruning bound (round 5): for the sorted main walk of batches of up to 256 tiles, when the tree carries its posting lists
+        // and the tiles are built by the scatter kernels (they mark the tile's useful (site, allele) pairs)
+        const uint32_t useful_words = (n_sites + 7) / 8;
+        const bool b3_want = use8 && !coarse_only && sorted && m->d_b3_events.p && !K.no_bound3 && !K.no_prune && n_tiles512 <= 256 && K.tile_build <= 0;
         const size_t z_dbottom = 0, z_active = z_dbottom + (size_t)n_tiles512 * 512, z_queue = z_active + (size_t)n_tiles512 * active_words,
                      z_list_n = z_queue + 8, z_nitems = z_list_n + n_tiles512, z_cnt = z_nitems + 8, z_key = z_cnt + (size_t)n_tiles512 * 512,
-                     z_end = z_key + (size_t)n_tiles512 * 512;
+                     z_useful = z_key + (size_t)n_tiles512 * 512, z_end = z_useful + (b3_want ? (size_t)n_tiles512 * useful_words : 0);
         HIP_TRY(W.d_zero.reserve(z_end));
         uint32_t *const d_dbottom = W.d_zero.p + z_dbottom, *const d_active = W.d_zero.p + z_active, *const d_queue = W.d_zero.p + z_queue,
                  *const d_list_n = W.d_zero.p + z_list_n, *const d_nitems = W.d_zero.p + z_nitems, *const d_cnt = W.d_zero.p + z_cnt,
-                 *const d_key = W.d_zero.p + z_key;
+                 *const d_key = W.d_zero.p + z_key, *const d_useful = b3_want ? W.d_zero.p + z_useful : nullptr;
         if (use8) {
             HIP_TRY(W.d_lbest.reserve((size_t)f.n_chunks * n_tiles512 * 256));
             HIP_TRY(W.d_list.reserve((size_t)f.n_chunks * n_tiles512));
@@ -462,7 +473,8 @@ int run_place(ugp_mat *m, ugp_qset *qs, int mode, ugp_result *d_out, int32_t *d_
             HIP_TRY(ugp::launch_ntiles(W.d_table.p, d_active, active_words, n_tiles512, qs->d_nmask[nmi].p, qs->nmask_words[nmi], order, (uint32_t)q0, (uint32_t)nq,
                                        m->d_site_ref.p, n_sites, s));
             HIP_TRY(ugp::launch_scatter_list(W.d_table.p, d_dbottom, qs->d_pos.p, qs->d_ref.p, qs->d_nuc.p, qs->d_missing.p, qs->d_ent_q.p, m->d_pos2site.p,
-                                             f.max_pos, n_sites, (uint32_t)q0, (uint32_t)nq, d_active, active_words, slot_of, qs->d_plain_rows.p, qs->d_n_plain.p, qs->d_err.p, s));
+                                             f.max_pos, n_sites, (uint32_t)q0, (uint32_t)nq, d_active, active_words, slot_of, qs->d_plain_rows.p, qs->d_n_plain.p, qs->d_err.p,
+                                             d_useful, useful_words, s));
         } else if (lds_build)
             HIP_TRY(ugp::launch_build_tiles(W.d_table.p, d_active, active_words, n_tiles512, qs->d_ent_off.p, (uint32_t)q0, order, (uint32_t)nq, qs->d_pos.p,
                                             qs->d_ref.p, qs->d_nuc.p, qs->d_missing.p, m->d_pos2site.p, m->d_site_pos.p, m->d_site_ref.p, n_sites, f.max_pos,
@@ -471,7 +483,26 @@ int run_place(ugp_mat *m, ugp_qset *qs, int mode, ugp_result *d_out, int32_t *d_
         HIP_TRY(ugp::launch_fill_table(W.d_table.p, m->d_site_ref.p, n_sites, table_dwords, s));
         HIP_TRY(ugp::launch_scatter(W.d_table.p, d_dbottom, qs->d_pos.p + e0, qs->d_ref.p + e0,
                                     qs->d_nuc.p + e0, qs->d_missing.p + e0, qs->d_ent_q.p + e0, m->d_pos2site.p,
-                                    f.max_pos, n_sites, e1 - e0, (uint32_t)q0, d_active, active_words, slot_of, qs->d_err.p, s));
+                                    f.max_pos, n_sites, e1 - e0, (uint32_t)q0, d_active, active_words, slot_of, qs->d_err.p, d_useful, useful_words, s));
+        }
+        // third pruning bound: the events of every tile's useful pairs -> block tables (ugp_bound3.hip)
+        const bool b3_on = b3_want && !(lds_build && nmi < 0);
+        if (b3_on) {
+            const uint32_t nb = ugp::b3_blocks(m->stream8_dwords), n_l1 = ugp::b3_div64(nb), n_l2 = ugp::b3_div64(n_l1), n_l3 = ugp::b3_div64(n_l2);
+            const uint32_t n_seg = (nb + ugp::B3_SEG - 1) / ugp::B3_SEG;
+            HIP_TRY(W.d_b3_work.reserve((size_t)n_tiles512 * nb * 2)); HIP_TRY(W.d_b3_seg.reserve((size_t)n_tiles512 * n_seg * 2));
+            HIP_TRY(W.d_b3_over.reserve((size_t)n_tiles512 * nb)); HIP_TRY(W.d_b3_under.reserve((size_t)n_tiles512 * nb));
+            HIP_TRY(W.d_b3_l1.reserve((size_t)n_tiles512 * n_l1)); HIP_TRY(W.d_b3_l2.reserve((size_t)n_tiles512 * n_l2)); HIP_TRY(W.d_b3_l3.reserve((size_t)n_tiles512 * n_l3));
+            HIP_TRY(W.d_b3_dev.reserve(1));
+            const ugp::B3Dev hd{W.d_b3_over.p, W.d_b3_under.p, W.d_b3_l1.p, W.d_b3_l2.p, W.d_b3_l3.p, nb, n_l1, n_l2, n_l3};
+            if (memcmp(&hd, &W.b3_host, sizeof hd) != 0) {   // (pointers and sizes: they change only when a buffer grows)
+                HIP_TRY(hipStreamSynchronize(s));
+                HIP_TRY(hipMemcpy(W.d_b3_dev.p, &hd, sizeof hd, hipMemcpyHostToDevice));
+                W.b3_host = hd;
+            }
+            HIP_TRY(hipMemsetAsync(W.d_b3_work.p, 0, (size_t)n_tiles512 * nb * 2 * sizeof(uint32_t), s));
+            HIP_TRY(ugp::launch_b3_events(d_useful, useful_words, n_sites, n_tiles512, m->d_b3_pair_off.p, m->d_b3_events.p, W.d_b3_work.p, nb, s));
+            HIP_TRY(ugp::launch_b3_tables(W.d_b3_work.p, n_tiles512, nb, W.d_b3_seg.p, W.d_b3_over.p, W.d_b3_under.p, W.d_b3_l1.p, W.d_b3_l2.p, W.d_b3_l3.p, s));
         }
         if (use8) {   // upper bounds of best(s) the pruning starts from
 #ifdef UGP_EXPERIMENTS
@@ -637,8 +668,8 @@ int run_place(ugp_mat *m, ugp_qset *qs, int mode, ugp_result *d_out, int32_t *d_
                                                 W.d_units.p, W.d_unit_info.p, W.d_unit_info.p + 8, dyn_ctl, s));
                 b.units = (const uint4 *)W.d_units.p; b.unit_base = W.d_unit_info.p; b.unit_count = W.d_unit_info.p + 8;
             }
-            HIP_TRY(W.d_stats.reserve(64));
-            if (q0 == 0) { HIP_TRY(hipMemsetAsync(W.d_stats.p, 0, 64 * sizeof(uint64_t), s)); W.last_words_total = 0; }
+            HIP_TRY(W.d_stats.reserve(72));
+            if (q0 == 0) { HIP_TRY(hipMemsetAsync(W.d_stats.p, 0, 72 * sizeof(uint64_t), s)); W.last_words_total = 0; }
             b.stats = K.stats ? W.d_stats.p : nullptr;   // the counters are two contended atomics per skip: debug only
             if (b.stats && !K.trace.empty() && !coarse_only) {   // per-unit records of this launch, dumped by ugp_get_timing
                 constexpr size_t kTraceCap = 1u << 20;
@@ -666,7 +697,8 @@ int run_place(ugp_mat *m, ugp_qset *qs, int mode, ugp_result *d_out, int32_t *d_
             if (nmi >= 0 && !b.stats) b.lds_bits = 2u;
             if (K.lds_bits >= 0) b.lds_bits = b.stats ? 0u : (K.lds_bits == 2 ? 2u : (((size_t)active_words * 4 <= 4096 && K.lds_bits != 0) ? 1u : 0u));
             const size_t lds_bytes = (size_t)b.lds_slots * 64 * 16 + (b.lds_bits == 1 ? (((size_t)active_words * 4 + 15) & ~(size_t)15) : 0);
-            const int variant = coarse_only ? (b.lds_bits == 2 ? 4 : 2) : (b.lds_bits == 2 ? 3 : (b.lds_bits ? 1 : 0));   // (the kernel launch_best8 will pick)
+            b.b3 = (b3_on && b.ub && b.lds_bits != 1) ? W.d_b3_dev.p : nullptr;
+            const int variant = coarse_only ? (b.lds_bits == 2 ? 4 : 2) : (b.b3 ? (b.lds_bits == 2 ? 6 : 5) : (b.lds_bits == 2 ? 3 : (b.lds_bits ? 1 : 0)));   // (the kernel launch_best8 will pick)
             if (m->occ_lds != lds_bytes || m->occ_variant != variant) {
                 HIP_TRY(hipDeviceGetAttribute(&m->n_cu, hipDeviceAttributeMultiprocessorCount, m->device));
                 HIP_TRY(ugp::best8_occupancy(lds_bytes, variant, &m->occ_per_cu));
@@ -837,6 +869,7 @@ static int build_coarse(const ugp_tree_desc *t, const ugp::Options &opt, ugp::Fl
     copt.chunk_nodes = 256;   // (the coarse pass is bound by row fetches and by the replay in front of every chunk: long chunks)
     copt.keep_node_pos8 = true;
     copt.keep_update_maps = opt.keep_update_maps;
+    copt.keep_b3_events = false;   // (the third bound serves the main walk only)
     if (const char *e = getenv("UGP_LDS_SLOTS")) copt.lds_slots = (uint32_t)std::max(1, std::min(60, atoi(e)));
     if (const char *e = getenv("UGP_COARSE_CHUNK_NODES")) copt.chunk_nodes = (uint32_t)std::max(1, atoi(e));
     hf.coarse = new HostFlat();
@@ -917,6 +950,10 @@ static int upload_flat(const HostFlat &hf, int device, ugp_mat **out) {
     if ((e = m->d_chunk_t.upload(f.chunk_t_off)) != hipSuccess) return bail(e, "upload chunk table");
     if (!f.node_pos8.empty() && (e = m->d_node_pos8.upload(f.node_pos8)) != hipSuccess) return bail(e, "upload node positions");
     if (!f.rank_dfs.empty() && (e = m->d_rank_dfs.upload(f.rank_dfs)) != hipSuccess) return bail(e, "upload node ranks");
+    if (!f.b3_events.empty()) {
+        if ((e = m->d_b3_pair_off.upload(f.b3_pair_off)) != hipSuccess) return bail(e, "upload posting lists");
+        if ((e = m->d_b3_events.upload(f.b3_events)) != hipSuccess) return bail(e, "upload posting lists");
+    }
     m->stream8_dwords = f.stream8.size();
     m->stream_dwords = f.stream.size();
     m->pre_dwords = f.pre_stream.size();
@@ -969,6 +1006,7 @@ static ugp::Options default_options() {
     opt.keep_node_pos8 = getenv("UGP_PHASE2_PACKED") != nullptr;   // (the experiment's node tables: 8 bytes per node on the device)
 #endif
     if (getenv("UGP_NO_BOUND2")) opt.second_bound = false;   // first lower bound only (tests, tuning)
+    opt.keep_b3_events = !getenv("UGP_NO_BOUND3");           // posting lists of the third bound (8 bytes per mutation on the device)
     if (const char *e = getenv("UGP_LDS_SLOTS")) opt.lds_slots = (uint32_t)std::max(1, std::min(60, atoi(e)));
     if (const char *e = getenv("UGP_PRE_WEIGHT")) opt.pre_weight = (uint32_t)std::max(0, atoi(e));
     return opt;
@@ -1023,7 +1061,7 @@ uint64_t flat_signature() {
     auto mix = [&](const char *p) { for (; p && *p; p++) { h ^= (uint8_t)*p; h *= 1099511628211ull; } h ^= 0xFF; h *= 1099511628211ull; };
     mix(__DATE__ " " __TIME__);
     for (const char *k : {"UGP_CHUNK_NODES", "UGP_PRUNE_MIN_WORDS", "UGP_NO_SIB", "UGP_NO_BOUND2", "UGP_LDS_SLOTS", "UGP_PRE_WEIGHT", "UGP_NO_UPDATE_MAPS",
-                          "UGP_COARSE_MIN_NODES", "UGP_NO_SORT", "UGP_COARSE_DIV", "UGP_COARSE_CHUNK_NODES"}) { mix(k); mix(getenv(k)); }
+                          "UGP_COARSE_MIN_NODES", "UGP_NO_SORT", "UGP_COARSE_DIV", "UGP_COARSE_CHUNK_NODES", "UGP_NO_BOUND3"}) { mix(k); mix(getenv(k)); }
     return h;
 }
 struct FlatWriter {
@@ -1049,6 +1087,7 @@ template <class IO> void flat_io(IO &io, HostFlat &hf) {
     io.vec(f.stream); io.vec(f.pre_stream); io.vec(f.chunk_body_off); io.vec(f.chunk_pre_off); io.vec(f.chunk_node_off); io.vec(f.pos2site);
     io.vec(f.site_ref); io.vec(f.rank2bfs); io.vec(f.dfs2bfs); io.vec(f.stream8); io.vec(f.pre8_stream); io.vec(f.chunk8_body_off); io.vec(f.chunk8_pre_off);
     io.vec(f.stream_t); io.vec(f.chunk_t_off); io.vec(f.rank_dfs); io.vec(f.node_pos8); io.vec(f.hdr8_of_bfs); io.vec(f.rec_of_bfs); io.vec(f.post_of_bfs);
+    io.vec(f.b3_pair_off); io.vec(f.b3_events);
     io.vec(hf.parent); io.vec(hf.coarse2dfs); io.vec(hf.coarse2bfs); io.vec(hf.node_pair); io.pod(hf.wide_descent);
 }
 }  // namespace
@@ -2057,7 +2096,7 @@ static int harvest_timing(ugp_mat *m, ugp_mat::Work &W, ugp_mat::Work::Gen &G) {
         G.last.words_total = W.last_words_total;
         G.last.words_skipped = 0;
         if (W.last_used_best8 && W.d_stats.p && m->knobs.stats) {   // (debug counters: a blocking copy)
-            uint64_t v[64] = {0};
+            uint64_t v[72] = {0};
             HIP_TRY(hipMemcpy(v, W.d_stats.p, sizeof v, hipMemcpyDeviceToHost));
             G.last.words_skipped = v[0];
             G.last.reserved = (uint32_t)std::min<uint64_t>(v[1], 0xFFFFFFFFull);   // pipeline (re)starts
@@ -2087,6 +2126,7 @@ static int harvest_timing(ugp_mat *m, ugp_mat::Work &W, ugp_mat::Work::Gen &G) {
                         (unsigned long long)v[48], (unsigned long long)v[49], (unsigned long long)v[50], (unsigned long long)v[51], (unsigned long long)v[52],
                         (unsigned long long)v[53], (unsigned long long)v[54], (unsigned long long)v[55]);
                 fprintf(stderr, "[ugp stats] units split while running: %llu\n", (unsigned long long)v[31]);
+                fprintf(stderr, "[ugp stats] third bound: asked at a restart %llu times, decided the jump %llu times\n", (unsigned long long)v[64], (unsigned long long)v[65]);
                 fprintf(stderr, "[ugp stats] jump lengths in words (<8 <16 <32 <64 <128 <512 <4096 more):");
                 for (int i = 0; i < 8; i++) fprintf(stderr, " %llu", (unsigned long long)v[56 + i]);
                 fprintf(stderr, "\n");
@@ -2208,6 +2248,8 @@ int ugp_flat_get(const ugp_flat *fl, int which, const void **ptr, uint64_t *coun
         case UGP_FLAT_CHUNK_T_OFF: *ptr = f.chunk_t_off.data(); *count = f.chunk_t_off.size(); break;
         case UGP_FLAT_MAX_PATH_MUTS: *ptr = nullptr; *count = f.max_path_muts; break;
         case UGP_FLAT_LDS_SLOTS: *ptr = nullptr; *count = f.lds_slots; break;
+        case UGP_FLAT_B3_PAIR_OFF: *ptr = f.b3_pair_off.data(); *count = f.b3_pair_off.size(); break;
+        case UGP_FLAT_B3_EVENTS: *ptr = f.b3_events.data(); *count = f.b3_events.size(); break;
         default: return fail(UGP_ERR_INVALID, "unknown array id");
     }
     return UGP_OK;

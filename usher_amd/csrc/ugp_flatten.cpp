@@ -657,6 +657,36 @@ int flatten(const ugp_tree_desc &t, const Options &opt, FlatMat &out, std::strin
     }, 64);
     flat_lap("packed stream");
 
+    // ---- third pruning bound (round 5; ugp_flatten.hpp "B3"): posting lists of the mutation events by (site, mutated allele).
+    // An event = one mutation word of the packed body; it raises, for every node of its node's subtree (the node included), the
+    // number of mutations of that (site, allele) on the root path -- i.e. over the word range [header of the node, end of its
+    // descendants), here as a range of blocks of B3_BLOCK_WORDS words.  Filled in depth-first order on one thread (deterministic).
+    out.b3_pair_off.clear(); out.b3_events.clear();
+    if (opt.keep_b3_events && out.n_sites && total8 > 0) {
+        const uint64_t n_pairs = (uint64_t)out.n_sites * 4;
+        out.b3_pair_off.assign(n_pairs + 1, 0);
+        const uint32_t *s8 = out.stream8.data();
+        for (uint64_t d = 0; d < N; d++) {
+            const uint32_t j = d2b[d];
+            if (dropped[j] || !nw[j]) continue;
+            for (uint32_t k = 0; k < nw[j]; k++) { const uint32_t w = s8[pos8_hdr[d] + 1u + k]; out.b3_pair_off[(uint64_t)(w & 0x3FFFFFu) * 4 + ((w >> 22) & 3u) + 1]++; }
+        }
+        for (uint64_t q = 0; q < n_pairs; q++) out.b3_pair_off[q + 1] += out.b3_pair_off[q];
+        out.b3_events.resize((size_t)out.b3_pair_off[n_pairs] * 2);
+        std::vector<uint32_t> fill(out.b3_pair_off.begin(), out.b3_pair_off.end() - 1);
+        for (uint64_t d = 0; d < N; d++) {
+            const uint32_t j = d2b[d];
+            if (dropped[j] || !nw[j]) continue;
+            const uint32_t b0 = pos8_hdr[d] >> B3_BLOCK_SHIFT, b1 = (pos8_at[d + sub[j]] - 1u) >> B3_BLOCK_SHIFT;
+            for (uint32_t k = 0; k < nw[j]; k++) {
+                const uint32_t w = s8[pos8_hdr[d] + 1u + k];
+                const uint32_t at = fill[(uint64_t)(w & 0x3FFFFFu) * 4 + ((w >> 22) & 3u)]++;
+                out.b3_events[(size_t)at * 2] = b0; out.b3_events[(size_t)at * 2 + 1] = b1;
+            }
+        }
+        flat_lap("third bound: posting lists");
+    }
+
     // ---- tie stream (phase 2 walks it one chunk at a time) ---------------------------------------------------------------------
     {
         auto t_big = [&](uint32_t j) { return j != 0 && subd[j] >= T_PRUNE_MIN_DWORDS && hsub[j] <= 255; };

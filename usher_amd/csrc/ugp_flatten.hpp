@@ -117,6 +117,22 @@ constexpr uint32_t PRUNE_MIN_WORDS = 4;     // only subtrees at least this long 
 constexpr uint32_t MAX_HOT_SLOTS = UGP_HOT_SLOTS;      // the B halves of the hot slots are two register vectors of this many elements in k_best8 (8 or 16)
 constexpr uint32_t LDS_SLOTS = 9;           // saved (D, B) slots k_best8 keeps in LDS (1.5 KB each per wave); the colder ones live in a global scratch
 constexpr uint32_t M_FLUSH = 1u << 28, M_END = 1u << 30;
+// ---- third pruning bound ("B3", round 5) --------------------------------------------------------------------------------------
+// A mutation lowers D for sample s only if  (a) its allele is in the sample's set and the reference base is not -- it matches a
+// variant of the sample: "useful" for s --  or  (b) the sample's set holds the reference base and the parent state is not in it: a
+// second hit.  So along any path n -> d at most  hU_T(n) + hsec(n)  mutations lower D for a sample of tile T, where hU_T(n) = the
+// largest number, over the paths below n, of mutations that are useful for SOME sample of T -- and
+//     cost(d, s) >= D(n, s) - (hU_T(n) + hsec(n)).
+// hsub(n) counts every mutation of the deepest path (3 at the median record, 40-60 near the top); only ~4 % of the mutations are
+// useful for a given tile, hU_T is 0 at the median record (tools/analysis/bound_sim2.py: 0.9 % of the tree visited instead of 2.1 %).
+// hU_T depends on the tile, so it cannot sit in the records.  With cum(y) = useful events on the root path of y (y included),
+// hU_T(n) = max over descendants d of cum(d) - cum(n).  The events of a tile are found through posting lists per (site, allele)
+// (FlatMat::b3_events) for the pairs the tile's samples make useful; each raises a counter over the BLOCK range of its subtree:
+//     cum_over[b]  = events whose block range contains b          >= cum(y) for every node y with a word in block b
+//     cum_under[b] = events whose range contains b strictly inside <= cum(y) for every such y
+// and the walk tests, for a record at n with descendants in blocks [q0, q1] and its own last word in block bn,
+//     hU_T(n) <= max(cum_over[q0 .. q1]) - cum_under[bn].
+constexpr uint32_t B3_BLOCK_SHIFT = 4, B3_BLOCK_WORDS = 1u << B3_BLOCK_SHIFT;
 constexpr uint32_t MAX_SITES = 1u << 22;
 constexpr uint32_t MAX_NODE_MUTS = 65534;   // 0xFFFF marks a pruning pseudo-record of the tie stream
 
@@ -131,6 +147,7 @@ struct Options {
                                 // the body is mostly skipped (0: body counts only)
     bool keep_update_maps = false;  // export FlatMat::hdr8_of_bfs / rec_of_bfs / post_of_bfs: where each node's record sits in the three streams
                                     // (ugp_mat_update takes rewritten nodes out of the candidate set by patching those words on the device)
+    bool keep_b3_events = false;    // export FlatMat::b3_pair_off / b3_events: the posting lists of the third pruning bound (the main tree of a handle)
     uint32_t threads = 0;       // host threads (0 = UGP_FLATTEN_THREADS, else min(32, hardware threads)); the output does not depend on it
 };
 
@@ -171,6 +188,11 @@ struct FlatMat {
     // (Options::keep_update_maps) by BFS index: position of the node's header word in stream8, of its record (w0) in stream and in
     // stream_t; UINT32_MAX = the node has no record there (leaves without mutation words are dropped from stream8 / stream_t)
     UVec<uint32_t> hdr8_of_bfs, rec_of_bfs, post_of_bfs;
+    // (Options::keep_b3_events) third pruning bound: for every (site, mutated allele) pair q = 4 * site + allele index, the events
+    // b3_events[2 * i], [2 * i + 1] (i in [b3_pair_off[q], b3_pair_off[q + 1])) = first and last block of B3_BLOCK_WORDS packed-stream
+    // words covered by the subtree (node included) of a node that carries such a mutation
+    std::vector<uint32_t> b3_pair_off;
+    UVec<uint32_t> b3_events;
     uint32_t max_chunk8_words = 0;         // longest chunk of the packed stream (a work unit must stay below the reach of a preamble record's jump field)
     uint32_t lds_slots = 0;                // the Options value the packed stream was encoded for (<= max_slots)
     bool mask_not_first = false;           // some non-root node lists a masked mutation behind an ordinary one: only the

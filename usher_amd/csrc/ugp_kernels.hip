@@ -35,6 +35,7 @@
 #include <algorithm>
 #include <type_traits>
 
+#include "ugp_bound3.hpp"
 #include "ugp_kernels.hpp"
 #include "ugp_update.hpp"
 
@@ -93,7 +94,7 @@ __global__ void k_scatter_entries(uint32_t *__restrict__ table, uint32_t *__rest
                                   uint32_t *__restrict__ active, uint32_t active_words,
                                   const uint32_t *__restrict__ slot_of,
                                   const uint32_t *__restrict__ row_list, const uint32_t *__restrict__ n_listed, uint32_t n_q,
-                                  const unsigned long long *__restrict__ err) {
+                                  const unsigned long long *__restrict__ err, uint32_t *__restrict__ useful, uint32_t useful_words) {
     // A batch whose rows failed k_rows_prepare's checks (its verdict is read by the host only after the whole pipeline has been
     // queued: ugp_place_batch_async) is placed as if it had no rows at all: the table stays "reference everywhere", D(bottom) 0,
     // so that nothing downstream ever sees duplicate or unsorted rows.  The caller gets the error, never these results.
@@ -137,6 +138,13 @@ __global__ void k_scatter_entries(uint32_t *__restrict__ table, uint32_t *__rest
         const uint32_t bit = 1u << ((uint32_t)site & 31u);
         if (!(__hip_atomic_load(aw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & bit)) atomicOr(aw, bit);
     }
+    // third pruning bound: the alleles of a set that excludes the reference base are "useful" for this tile (a mutation to one of them
+    // can match this sample's variant)
+    if (useful && (a & r) == 0) {
+        uint32_t *uw = &useful[(uint64_t)tile * useful_words + ((uint32_t)site >> 3)];
+        const uint32_t bits = (a & 15u) << (((uint32_t)site & 7u) * 4u);
+        if ((__hip_atomic_load(uw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & bits) != bits) atomicOr(uw, bits);
+    }
     if (!row_list) break;   // (one row per thread)
     }
 }
@@ -153,7 +161,7 @@ __global__ void __launch_bounds__(64) k_scatter_rows(uint32_t *__restrict__ tabl
                                                      const uint32_t *__restrict__ ent_q, const int32_t *__restrict__ pos2site,
                                                      uint32_t max_pos, uint32_t n_sites, uint64_t n_ent, uint32_t q_base,
                                                      uint32_t *__restrict__ active, uint32_t active_words, const uint32_t *__restrict__ slot_of,
-                                                     const unsigned long long *__restrict__ err) {
+                                                     const unsigned long long *__restrict__ err, uint32_t *__restrict__ useful, uint32_t useful_words) {
     if (err && *err != ~0ull) return;   // (as k_scatter_entries: a batch with bad rows is built as if it had none)
     const uint64_t base = (uint64_t)blockIdx.x * 64u * K + threadIdx.x;
     bool valid[K];
@@ -204,6 +212,15 @@ __global__ void __launch_bounds__(64) k_scatter_rows(uint32_t *__restrict__ tabl
         if (!aw[j]) continue;
         const uint32_t bit = 1u << ((uint32_t)site[j] & 31u);
         if (!(have[j] & bit)) atomicOr(aw[j], bit);
+    }
+    if (useful) {   // third pruning bound: see k_scatter_entries
+#pragma unroll
+        for (int j = 0; j < K; j++) {
+            if (site[j] < 0 || (a[j] & r[j]) != 0) continue;
+            uint32_t *uw = &useful[(uint64_t)(q[j] >> 9) * useful_words + ((uint32_t)site[j] >> 3)];
+            const uint32_t bits = (a[j] & 15u) << (((uint32_t)site[j] & 7u) * 4u);
+            if ((__hip_atomic_load(uw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & bits) != bits) atomicOr(uw, bits);
+        }
     }
 }
 
@@ -933,7 +950,12 @@ __device__ __forceinline__ uint32_t psub(uint32_t a, uint32_t b) { return a - b;
 // LBITS == 2 (round 5): no bitmap at all -- every mutation word fetches its site's own row.  For batches whose tiles have (almost) every
 // row live -- thousands of N cells per sample: BASELINE config 5 -- the constant-row shortcut never applies, and the bitmap costs every
 // restart a dependent round trip and every group a load for nothing.
-template <bool STATS, int LBITS, bool ARG, bool TIES>   // STATS: per-unit accounting for tuning (UGP_STATS); off in production, it costs SGPRs
+// B3 (round 5): the third pruning bound (ugp_flatten.hpp "B3"): a record of the body whose two tests fail asks for a restart, and the
+// restart path -- outside the pipelined loop, where loads may wait -- reads the tile's block tables (a.b3: the largest number of
+// "useful" events on a root path anywhere below the node, minus those above it) and tests again with hsub replaced by that number
+// plus the second hits.  The pipelined loop itself carries nothing new.
+constexpr uint32_t B3_MIN_JUMP = 12;   // smaller subtrees are cheaper to walk than to ask about
+template <bool STATS, int LBITS, bool ARG, bool TIES, bool B3 = false>   // STATS: per-unit accounting for tuning (UGP_STATS); off in production, it costs SGPRs
 __global__ void __launch_bounds__(64, TIES ? 3 : 4) k_best8(Best8Args a) {
     extern __shared__ __attribute__((aligned(16))) u32x4 slots8[];   // the hot saved slots: [lds_slots][64] x 16 B of D (the 8 B of B per lane and slot are in registers)
     const uint32_t lane = threadIdx.x;
@@ -1142,6 +1164,7 @@ __global__ void __launch_bounds__(64, TIES ? 3 : 4) k_best8(Best8Args a) {
     uint64_t n_first_skip = 0; // uniform (STATS): jumps decided by the first node after a restart
     uint32_t n_cause[4] = {0, 0, 0, 0};   // uniform (STATS): restarts by cause -- jump, sibling jump, chunk end, slow header
     uint32_t n_jlen[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // uniform (STATS): jump lengths
+    uint32_t n_b3[2] = {0, 0};   // uniform (STATS): third-bound tests at a restart / of which decided the jump
     auto count_jump = [&](uint32_t len, int cause) {
         n_cause[cause]++;
         n_jlen[len < 8 ? 0 : len < 16 ? 1 : len < 32 ? 2 : len < 64 ? 3 : len < 128 ? 4 : len < 512 ? 5 : len < 4096 ? 6 : 7]++;
@@ -1349,6 +1372,10 @@ __global__ void __launch_bounds__(64, TIES ? 3 : 4) k_best8(Best8Args a) {
                 skip_to = pos + 1 + (info & INFO_JUMP_MASK);
                 if (STATS) { n_skipped += info & INFO_JUMP_MASK; if (run_nodes == 1) n_first_skip++; count_jump(info & INFO_JUMP_MASK, 0); }
                 return true;
+            }
+            if (B3 && !pre_prune) {   // both tests failed: is the third bound worth a look?  (bit 31 of skip_to: "test again at the restart")
+                const uint32_t hs3 = (info >> INFO_HS_SHIFT) & 0x7Fu, hr3 = (info >> INFO_HR_SHIFT) & 7u;
+                if (hr3 != INFO_HR_NONE && hs3 > hr3 && (info & INFO_JUMP_MASK) >= B3_MIN_JUMP) { skip_to = (pos + 1u) | 0x80000000u; return true; }
             }
         }
         if (TIES && tie_here) { skip_to = pos + 1; return true; }   // (the walk goes on behind the node once the tie has been booked)
@@ -1603,6 +1630,43 @@ __global__ void __launch_bounds__(64, TIES ? 3 : 4) k_best8(Best8Args a) {
             }
             if (!hit) break;   // walked to the end of the range
             cautious = first;
+            if (B3 && (skip_to & 0x80000000u)) {
+                // Third bound for the record in `info` (its node's D / B are still in dcur / bcur): descendants in the words behind
+                // p = the node's last word.  M = the maximum of cum_over over their blocks, read 64 entries at a time at the coarsest
+                // level whose span fits; U = cum_under of the node's own block; hU <= M - U.
+                skip_to &= 0x7FFFFFFFu;
+                const uint32_t p = skip_to - 1u, J = info & INFO_JUMP_MASK;
+                const uint32_t P = begin + p;
+                const B3Dev *b3 = a.b3;
+                uint32_t q0 = (P + 1u) >> B3_BLOCK_SHIFT, q1 = (P + J) >> B3_BLOCK_SHIFT;
+                const uint32_t nb = b3->n_blocks;
+                const uint16_t *arr = b3->over + (uint64_t)tile * nb;
+                if (q1 - q0 >= 64u) {
+                    q0 >>= 6; q1 >>= 6;
+                    arr = b3->l1 + (uint64_t)tile * b3->n_l1;
+                    if (q1 - q0 >= 64u) {
+                        q0 >>= 6; q1 >>= 6;
+                        arr = b3->l2 + (uint64_t)tile * b3->n_l2;
+                        if (q1 - q0 >= 64u) { q0 >>= 6; q1 >>= 6; arr = b3->l3 + (uint64_t)tile * b3->n_l3; }
+                    }
+                }
+                uint32_t mv = 0;
+                for (uint32_t i = q0 + lane; i <= q1; i += 64u) mv = max(mv, (uint32_t)arr[i]);
+                const uint32_t un = b3->under[(uint64_t)tile * nb + (P >> B3_BLOCK_SHIFT)];
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) mv = max(mv, (uint32_t)__shfl_xor((int)mv, o));
+                const uint32_t M = (uint32_t)__builtin_amdgcn_readfirstlane((int)mv), U = (uint32_t)__builtin_amdgcn_readfirstlane((int)un);
+                const uint32_t hs3 = (info >> INFO_HS_SHIFT) & 0x7Fu, hr3 = (info >> INFO_HR_SHIFT) & 7u;
+                const uint32_t hu = M > U ? M - U : 0u;
+                if (STATS) n_b3[0]++;
+                if (M != 65535u && hu + hr3 < hs3) {
+                    const uint32_t rec3 = (info & ~(0x7Fu << INFO_HS_SHIFT)) | ((hu + hr3) << INFO_HS_SHIFT);
+                    if (all_far(dcur, bcur, rec3)) {
+                        skip_to = p + 1u + J;
+                        if (STATS) { n_b3[1]++; n_skipped += J; count_jump(J, 0); }
+                    }
+                }
+            }
             if (replay) {
                 // the node whose header sits at skip_to - 1 needs the general step
                 replay = false;
@@ -1702,6 +1766,7 @@ __global__ void __launch_bounds__(64, TIES ? 3 : 4) k_best8(Best8Args a) {
         atomicAdd(st + 31, (unsigned long long)n_split);
         for (int i = 0; i < 4; i++) atomicAdd(st + 48 + 2 * i + (unit_heavy ? 0 : 1), (unsigned long long)n_cause[i]);
         for (int i = 0; i < 8; i++) atomicAdd(st + 56 + i, (unsigned long long)n_jlen[i]);
+        if (B3) { atomicAdd(st + 64, (unsigned long long)n_b3[0]); atomicAdd(st + 65, (unsigned long long)n_b3[1]); }
         if (!unit_heavy) {   // what the preamble records decided for this unit
             const uint32_t body_words = a.chunk8_body_off[c1] - a.chunk8_body_off[c0];
             const int cls = body_start >= body_words ? 0 : (body_start ? 1 : 2);
@@ -2379,12 +2444,13 @@ hipError_t launch_build_tiles(uint32_t *table, uint32_t *active, uint32_t active
 hipError_t launch_scatter(uint32_t *table, uint32_t *dbottom, const int32_t *pos, const uint8_t *ref,
                           const uint8_t *nuc, const uint8_t *is_missing, const uint32_t *ent_q,
                           const int32_t *pos2site, uint32_t max_pos, uint32_t n_sites, uint64_t n_ent, uint32_t q_base,
-                          uint32_t *active, uint32_t active_words, const uint32_t *slot_of, const unsigned long long *err, hipStream_t s) {
+                          uint32_t *active, uint32_t active_words, const uint32_t *slot_of, const unsigned long long *err, uint32_t *useful, uint32_t useful_words,
+                          hipStream_t s) {
     if (n_ent == 0) return hipSuccess;
     constexpr int K = 4;
     const uint64_t blocks = (n_ent + 64 * K - 1) / (64 * K);
     hipLaunchKernelGGL(k_scatter_rows<K>, dim3((uint32_t)blocks), dim3(64), 0, s, table, dbottom, pos, ref, nuc,
-                       is_missing, ent_q, pos2site, max_pos, n_sites, n_ent, q_base, active, active_words, slot_of, err);
+                       is_missing, ent_q, pos2site, max_pos, n_sites, n_ent, q_base, active, active_words, slot_of, err, useful, useful_words);
     return hipGetLastError();
 }
 
@@ -2392,9 +2458,9 @@ hipError_t launch_scatter(uint32_t *table, uint32_t *dbottom, const int32_t *pos
 hipError_t launch_scatter_list(uint32_t *table, uint32_t *dbottom, const int32_t *pos, const uint8_t *ref, const uint8_t *nuc, const uint8_t *is_missing,
                                const uint32_t *ent_q, const int32_t *pos2site, uint32_t max_pos, uint32_t n_sites, uint32_t q_base, uint32_t n_q,
                                uint32_t *active, uint32_t active_words, const uint32_t *slot_of, const uint32_t *row_list, const uint32_t *n_listed,
-                               const unsigned long long *err, hipStream_t s) {
+                               const unsigned long long *err, uint32_t *useful, uint32_t useful_words, hipStream_t s) {
     hipLaunchKernelGGL(k_scatter_entries, dim3(8192), dim3(64), 0, s, table, dbottom, pos, ref, nuc, is_missing, ent_q, pos2site, max_pos, n_sites,
-                       (uint64_t)0, q_base, active, active_words, slot_of, row_list, n_listed, n_q, err);
+                       (uint64_t)0, q_base, active, active_words, slot_of, row_list, n_listed, n_q, err, useful, useful_words);
     return hipGetLastError();
 }
 
@@ -2463,6 +2529,8 @@ hipError_t launch_merge(const uint32_t *part_best, const uint32_t *part_cnt, con
 hipError_t best8_occupancy(size_t lds_bytes, int variant, int *per_cu) {
     if (variant == 1) return hipOccupancyMaxActiveBlocksPerMultiprocessor(per_cu, k_best8<false, 1, false, false>, 64, lds_bytes);
     if (variant == 2) return hipOccupancyMaxActiveBlocksPerMultiprocessor(per_cu, k_best8<false, 0, true, false>, 64, lds_bytes);
+    if (variant == 5) return hipOccupancyMaxActiveBlocksPerMultiprocessor(per_cu, k_best8<false, 0, false, false, true>, 64, lds_bytes);
+    if (variant == 6) return hipOccupancyMaxActiveBlocksPerMultiprocessor(per_cu, k_best8<false, 2, false, false, true>, 64, lds_bytes);
     if (variant == 3) return hipOccupancyMaxActiveBlocksPerMultiprocessor(per_cu, k_best8<false, 2, false, false>, 64, lds_bytes);
     if (variant == 4) return hipOccupancyMaxActiveBlocksPerMultiprocessor(per_cu, k_best8<false, 2, true, false>, 64, lds_bytes);
     return hipOccupancyMaxActiveBlocksPerMultiprocessor(per_cu, k_best8<false, 0, false, false>, 64, lds_bytes);
@@ -2473,8 +2541,14 @@ hipError_t launch_best8(const Best8Args &a, uint32_t blocks, hipStream_t s) {
     const size_t lds = (size_t)a.lds_slots * 64 * 16;   // the D rows of the hot slots (their B halves live in registers)
 #ifdef UGP_EXPERIMENTS   // (the statistics build of the walk and phase 2 as a mode of it exist only in libusher_amd_exp.so)
     if (a.tie_cnt) { hipLaunchKernelGGL((k_best8<false, 0, false, true>), dim3(blocks), dim3(64), lds, s, a); return hipGetLastError(); }   // (phase 2)
+    if (a.stats && !a.lpos && a.b3) { hipLaunchKernelGGL((k_best8<true, 0, false, false, true>), dim3(blocks), dim3(64), lds, s, a); return hipGetLastError(); }
     if (a.stats && !a.lpos) { hipLaunchKernelGGL((k_best8<true, 0, false, false>), dim3(blocks), dim3(64), lds, s, a); return hipGetLastError(); }
 #endif
+    if (a.b3 && !a.lpos && a.lds_bits != 1) {   // the main walk with the third bound (not with the bitmap in LDS: that variant is for long launches)
+        if (a.lds_bits == 2) hipLaunchKernelGGL((k_best8<false, 2, false, false, true>), dim3(blocks), dim3(64), lds, s, a);
+        else hipLaunchKernelGGL((k_best8<false, 0, false, false, true>), dim3(blocks), dim3(64), lds, s, a);
+        return hipGetLastError();
+    }
     if (a.lpos && a.lds_bits == 2) hipLaunchKernelGGL((k_best8<false, 2, true, false>), dim3(blocks), dim3(64), lds, s, a);   // (the coarse pass of a batch whose rows are all live)
     else if (a.lpos) hipLaunchKernelGGL((k_best8<false, 0, true, false>), dim3(blocks), dim3(64), lds, s, a);   // (the coarse pass; no statistics there)
     else if (a.lds_bits == 2) hipLaunchKernelGGL((k_best8<false, 2, false, false>), dim3(blocks), dim3(64), lds, s, a);

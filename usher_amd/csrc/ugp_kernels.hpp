@@ -75,6 +75,7 @@ struct Best8Args {
     const uint32_t *rank_dfs;          // [n_nodes] by DFS index: tie rank
     const uint32_t *chunk_node_off;    // [n_chunks + 1] first DFS index of every chunk
     uint32_t n_queries;
+    const struct B3Dev *b3;            // third pruning bound (ugp_bound3.hpp): the tile tables of this launch, or null (the kernel variant without it)
 };
 
 // hstart / hlen: [n_tiles] or null: per tile, the first chunk of the region its own samples sit in and its length in chunks
@@ -120,7 +121,8 @@ hipError_t launch_build_tiles(uint32_t *table, uint32_t *active, uint32_t active
 hipError_t launch_scatter(uint32_t *table, uint32_t *dbottom, const int32_t *pos, const uint8_t *ref,
                           const uint8_t *nuc, const uint8_t *is_missing, const uint32_t *ent_q,
                           const int32_t *pos2site, uint32_t max_pos, uint32_t n_sites, uint64_t n_ent, uint32_t q_base,
-                          uint32_t *active, uint32_t active_words, const uint32_t *slot_of, const unsigned long long *err, hipStream_t s);
+                          uint32_t *active, uint32_t active_words, const uint32_t *slot_of, const unsigned long long *err,
+                          uint32_t *useful /* third bound: [tiles][useful_words] nibble per site, or null */, uint32_t useful_words, hipStream_t s);
 // tiles of batches with many missing rows: N bits per (sample, site) built once per query set, tiles transposed from them
 hipError_t launch_nmask_build(const uint64_t *ent_off, uint32_t n_queries, const int32_t *pos, const uint8_t *is_missing, const int32_t *pos2site,
                               uint32_t max_pos, uint32_t words, uint32_t *nmask, uint32_t *plain_rows /* or null */, uint32_t *n_plain, hipStream_t s);
@@ -129,7 +131,7 @@ hipError_t launch_ntiles(uint32_t *table, uint32_t *active, uint32_t active_word
 hipError_t launch_scatter_list(uint32_t *table, uint32_t *dbottom, const int32_t *pos, const uint8_t *ref, const uint8_t *nuc, const uint8_t *is_missing,
                                const uint32_t *ent_q, const int32_t *pos2site, uint32_t max_pos, uint32_t n_sites, uint32_t q_base, uint32_t n_q,
                                uint32_t *active, uint32_t active_words, const uint32_t *slot_of, const uint32_t *row_list, const uint32_t *n_listed,
-                               const unsigned long long *err, hipStream_t s);
+                               const unsigned long long *err, uint32_t *useful, uint32_t useful_words, hipStream_t s);
 // locality sort (see k_sort_keys); temp == nullptr: only *temp_bytes is filled
 hipError_t launch_tile_ranges(const uint32_t *keys_sorted, uint32_t n_queries, uint32_t n_tiles512, const uint32_t *chunk_node_off,
                               uint32_t n_chunks, uint32_t align, uint32_t *hstart, uint32_t *hlen, hipStream_t s);
