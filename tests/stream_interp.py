@@ -354,7 +354,8 @@ def best8_group(flat, nib, dbot, c0, c1, ub=None, stats=None, use_pre_records=Tr
                 is_far = far(dcur, bcur, rec, ub[0])     # D(node) - bound > upper bound: no descendant can tie or win
                 if not is_far and b3 is not None:        # third bound (the kernel: at the restart this record asks for)
                     hs3, hr3 = (rec >> INFO_HS_SHIFT) & 0x7F, (rec >> INFO_HR_SHIFT) & 7
-                    if hr3 != INFO_HR_NONE and hs3 > hr3 and jump >= B3_MIN_JUMP:
+                    if hr3 != INFO_HR_NONE and hs3 > hr3 and jump >= B3_MIN_JUMP and \
+                            far(dcur, bcur, (rec & ~(0x7F << INFO_HS_SHIFT)) | (hr3 << INFO_HS_SHIFT), ub[0]):   # (asked only if hU = 0 would decide)
                         hu = b3_hu(b3, i, jump)
                         if stats is not None:
                             stats["b3_asked"] = stats.get("b3_asked", 0) + 1

@@ -78,20 +78,21 @@ __global__ void __launch_bounds__(256) k_b3_seg_scan(uint2 *__restrict__ seg, ui
     }
 }
 
-// the tables of one segment: thread t owns the blocks 16 t .. 16 t + 15 of the segment
+// the tables of one segment of B3_SEG blocks: the counters are staged through LDS (coalesced loads and stores; a thread then owns 16
+// consecutive blocks of the staged copy for the prefix sums)
 __global__ void __launch_bounds__(256) k_b3_tables(const uint2 *__restrict__ work, uint32_t n_blocks, uint32_t n_seg, const uint2 *__restrict__ seg,
                                                    uint16_t *__restrict__ over, uint16_t *__restrict__ under, uint16_t *__restrict__ l1, uint32_t n_l1) {
+    __shared__ uint2 wk[B3_SEG];          // 32 KB
+    __shared__ uint32_t res[B3_SEG];      // 16 KB: over | under << 16
     __shared__ uint32_t pa[256], pb[256], mx[256];
     const uint32_t tile = blockIdx.y, sg = blockIdx.x, t = threadIdx.x;
     const uint2 *W = work + (uint64_t)tile * n_blocks;
-    const uint32_t b0 = sg * B3_SEG + t * 16u;
-    uint2 w[16];
+    const uint32_t g0 = sg * B3_SEG;
+    for (uint32_t i = t; i < B3_SEG; i += 256u) wk[i] = g0 + i < n_blocks ? W[g0 + i] : make_uint2(0u, 0u);
+    __syncthreads();
     uint32_t a = 0, b = 0;
 #pragma unroll
-    for (int k = 0; k < 16; k++) {
-        w[k] = b0 + k < n_blocks ? W[b0 + k] : make_uint2(0u, 0u);
-        a += w[k].x & 0xFFFFu; b += w[k].y;
-    }
+    for (int k = 0; k < 16; k++) { const uint2 w = wk[t * 16 + k]; a += w.x & 0xFFFFu; b += w.y; }
     pa[t] = a; pb[t] = b;
     __syncthreads();
     for (uint32_t o = 1; o < 256u; o <<= 1) {
@@ -103,21 +104,27 @@ __global__ void __launch_bounds__(256) k_b3_tables(const uint2 *__restrict__ wor
     const uint2 base = seg[(uint64_t)tile * n_seg + sg];
     uint32_t S = base.x + pa[t] - a, E = base.y + pb[t] - b;   // inclusive prefixes in front of the thread's first block
     uint32_t m = 0;
-    uint16_t *O = over + (uint64_t)tile * n_blocks, *U = under + (uint64_t)tile * n_blocks;
 #pragma unroll
     for (int k = 0; k < 16; k++) {
-        const uint32_t st = w[k].x & 0xFFFFu, same = w[k].x >> 16, en = w[k].y;
-        const uint32_t ov = S + st - E + same;            // S(b) - E(b - 1) + same(b)
-        const uint32_t un = S - (E + en);                 // S(b - 1) - E(b)   (never negative: an event ends where or behind it starts)
+        const uint2 w = wk[t * 16 + k];
+        const uint32_t st = w.x & 0xFFFFu, same = w.x >> 16, en = w.y;
+        const uint32_t ov = min(S + st - E + same, 65535u);   // S(b) - E(b - 1) + same(b)   (65535: "no bound" for the walk -- cannot be reached on the packed path)
+        const uint32_t un = min(S - (E + en), 65535u);        // S(b - 1) - E(b)   (never negative: an event ends where or behind it starts)
         S += st; E += en;
-        if (b0 + k < n_blocks) {
-            O[b0 + k] = (uint16_t)min(ov, 65535u);        // (65535: "no bound" for the walk -- cannot be reached on the packed path)
-            U[b0 + k] = (uint16_t)min(un, 65535u);
-            m = max(m, min(ov, 65535u));
-        }
+        res[t * 16 + k] = ov | (un << 16);
+        if (g0 + t * 16 + k < n_blocks) m = max(m, ov);
     }
     mx[t] = m;
     __syncthreads();
+    uint16_t *O = over + (uint64_t)tile * n_blocks, *U = under + (uint64_t)tile * n_blocks;
+    for (uint32_t i = t; i < B3_SEG / 2; i += 256u) {   // two blocks per thread and store: 4-byte stores, coalesced
+        const uint32_t blk = g0 + 2u * i;
+        const uint32_t r0 = res[2 * i], r1 = res[2 * i + 1];
+        if (blk + 1 < n_blocks) {
+            *(uint32_t *)(O + blk) = (r0 & 0xFFFFu) | (r1 << 16);
+            *(uint32_t *)(U + blk) = (r0 >> 16) | (r1 & 0xFFFF0000u);
+        } else if (blk < n_blocks) { O[blk] = (uint16_t)r0; U[blk] = (uint16_t)(r0 >> 16); }
+    }
     if (t < 64) {   // level 1: 64 blocks = four threads
         const uint32_t v = max(max(mx[4 * t], mx[4 * t + 1]), max(mx[4 * t + 2], mx[4 * t + 3]));
         const uint32_t i = sg * 64u + t;

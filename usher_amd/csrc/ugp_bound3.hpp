@@ -27,7 +27,7 @@ hipError_t launch_b3_events(const uint32_t *useful, uint32_t useful_words, uint3
 // seg: [n_tiles][n_seg][2] scratch.  Fills over / under / l1 / l2 / l3.
 hipError_t launch_b3_tables(const uint32_t *work, uint32_t n_tiles, uint32_t n_blocks, uint32_t *seg, uint16_t *over, uint16_t *under, uint16_t *l1, uint16_t *l2,
                             uint16_t *l3, hipStream_t s);
-inline uint32_t b3_blocks(uint64_t stream8_words) { return (uint32_t)((stream8_words + B3_BLOCK_WORDS - 1) >> B3_BLOCK_SHIFT) + 1u; }
+inline uint32_t b3_blocks(uint64_t stream8_words) { return (((uint32_t)((stream8_words + B3_BLOCK_WORDS - 1) >> B3_BLOCK_SHIFT) + 1u) + 1u) & ~1u; }   // (even: the tables are stored two blocks at a time)
 inline uint32_t b3_div64(uint32_t n) { return (n + 63u) / 64u; }
 
 }  // namespace ugp

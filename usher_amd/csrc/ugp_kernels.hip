@@ -1375,7 +1375,10 @@ __global__ void __launch_bounds__(64, TIES ? 3 : 4) k_best8(Best8Args a) {
             }
             if (B3 && !pre_prune) {   // both tests failed: is the third bound worth a look?  (bit 31 of skip_to: "test again at the restart")
                 const uint32_t hs3 = (info >> INFO_HS_SHIFT) & 0x7Fu, hr3 = (info >> INFO_HR_SHIFT) & 7u;
-                if (hr3 != INFO_HR_NONE && hs3 > hr3 && (info & INFO_JUMP_MASK) >= B3_MIN_JUMP) { skip_to = (pos + 1u) | 0x80000000u; return true; }
+                // (... only if the best the third bound can give -- no useful mutation anywhere below: hsub replaced by the second hits --
+                // would decide the jump: on a sample's own lineage it never does, and every question costs a restart)
+                if (hr3 != INFO_HR_NONE && hs3 > hr3 && (info & INFO_JUMP_MASK) >= B3_MIN_JUMP &&
+                    all_far(dcur, bcur, (info & ~(0x7Fu << INFO_HS_SHIFT)) | (hr3 << INFO_HS_SHIFT))) { skip_to = (pos + 1u) | 0x80000000u; return true; }
             }
         }
         if (TIES && tie_here) { skip_to = pos + 1; return true; }   // (the walk goes on behind the node once the tie has been booked)
@@ -1630,6 +1633,16 @@ __global__ void __launch_bounds__(64, TIES ? 3 : 4) k_best8(Best8Args a) {
             }
             if (!hit) break;   // walked to the end of the range
             cautious = first;
+            if (replay) {
+                // the node whose header sits at skip_to - 1 needs the general step
+                replay = false;
+                const uint32_t p = skip_to - 1u;
+                skip_to = 0;
+                const uint32_t q = slow_node(p);
+                __builtin_amdgcn_s_waitcnt(0);   // (a cold slot written here may be read by the very next node)
+                if (!skip_to) { off = q; continue; }
+            }
+            // (also behind the general step: a node walked by slow_node may have asked too)
             if (B3 && (skip_to & 0x80000000u)) {
                 // Third bound for the record in `info` (its node's D / B are still in dcur / bcur): descendants in the words behind
                 // p = the node's last word.  M = the maximum of cum_over over their blocks, read 64 entries at a time at the coarsest
@@ -1666,15 +1679,6 @@ __global__ void __launch_bounds__(64, TIES ? 3 : 4) k_best8(Best8Args a) {
                         if (STATS) { n_b3[1]++; n_skipped += J; count_jump(J, 0); }
                     }
                 }
-            }
-            if (replay) {
-                // the node whose header sits at skip_to - 1 needs the general step
-                replay = false;
-                const uint32_t p = skip_to - 1u;
-                skip_to = 0;
-                const uint32_t q = slow_node(p);
-                __builtin_amdgcn_s_waitcnt(0);   // (a cold slot written here may be read by the very next node)
-                if (!skip_to) { off = q; continue; }
             }
             if (TIES) tie_event();   // (a node that tied asked for this restart, or did so on top of a jump)
             // restart request: close every chunk whose end marker lies before the new position
