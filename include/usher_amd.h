@@ -311,6 +311,11 @@ int ugp_get_timing(ugp_mat *mat, ugp_timing *out);
  * ugp_place_device calls without synchronising after each of them. */
 int ugp_get_timing_sum(ugp_mat *mat, ugp_timing *sum, uint32_t *n_calls);
 
+/* Test hook: the third pruning bound's tables of 512-sample tile `tile` as the handle's most recent placement
+ * call built them: cum_over / cum_under per block of 16 packed-stream words.  *n_blocks = entries per tile (0: that call did not
+ * use the bound); with over == NULL only the count is returned.  Blocking; the caller checks `tile` against its own batch. */
+int ugp_debug_bound3_tables(ugp_mat *mat, uint32_t tile, uint16_t *over, uint16_t *under, uint64_t cap, uint64_t *n_blocks);
+
 /* Message for the last non-zero return on the calling thread. */
 const char *ugp_last_error(void);
 
@@ -373,8 +378,8 @@ enum {
     UGP_FLAT_STREAM_T = 15,     /* uint32: tie stream walked by phase 2 (chunk bodies + pruning pseudo-records) */
     UGP_FLAT_CHUNK_T_OFF = 16,  /* uint32 [n_chunks+1] */
     UGP_FLAT_LDS_SLOTS = 17,    /* count only: saved-D slots the packed stream keeps on the fast path */
-    UGP_FLAT_B3_PAIR_OFF = 18,  /* uint32 [4 * n_sites + 1]: third pruning bound, events of every (site, mutated allele) pair */
-    UGP_FLAT_B3_EVENTS = 19     /* uint32 [2 * events]: first / last block of packed-stream words of each event's subtree */
+    UGP_FLAT_B3_GROUP_OFF = 18, /* uint32 [3][groups + 1]: third pruning bound, the three event lists of every group of 256 blocks of 16 packed-stream words */
+    UGP_FLAT_B3_EVENTS = 19     /* uint32 [events]: 4 * site + allele (bits 23:0) | block within the group (31:24) */
 };
 int ugp_flat_create(const ugp_tree_desc *tree, uint32_t chunk_nodes, ugp_flat **out);
 void ugp_flat_destroy(ugp_flat *flat);

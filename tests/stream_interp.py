@@ -30,19 +30,6 @@ def sample_site_alleles(flat, sample):
     return nib, dbot
 
 
-def sample_site_alleles(flat, sample):
-    """nibble per site (reference base unless the sample has a row) and D_bottom."""
-    nib = flat.site_ref.astype(np.int64).copy()
-    dbot = 0
-    for p, r, a, mis in zip(sample["pos"], sample["ref"], sample["nuc"], sample["is_missing"]):
-        a = 15 if mis else int(a)
-        if not mis and (a & int(r)) == 0:
-            dbot += 1
-        if 0 <= p < len(flat.pos2site) and flat.pos2site[p] >= 0:
-            nib[flat.pos2site[p]] = a
-    return nib, dbot
-
-
 def variant_rows(sample):
     """V of the second pruning bound: rows whose allele set is neither missing nor just the reference base."""
     return sum(1 for r, a, mis in zip(sample["ref"], sample["nuc"], sample["is_missing"]) if not mis and int(a) != int(r))
@@ -156,6 +143,7 @@ U16 = 0xFFFF
 
 
 B3_BLOCK_SHIFT = 4
+B3_GROUP_SHIFT = 8
 
 
 def b3_tables(flat, nibs):
@@ -168,19 +156,19 @@ def b3_tables(flat, nibs):
     for nib in nibs:
         excl = (nib & flat.site_ref.astype(np.int64)) == 0
         useful[excl] |= nib[excl]
-    nb = ((len(flat.stream8) + 15) >> B3_BLOCK_SHIFT) + 1
-    start = np.zeros(nb + 1, np.int64); end = np.zeros(nb + 1, np.int64); same = np.zeros(nb + 1, np.int64)
-    ev = flat.b3_events.reshape(-1, 2).astype(np.int64)
-    for site in np.flatnonzero(useful):
-        for al in range(4):
-            if not (useful[site] >> al) & 1:
-                continue
-            q = site * 4 + al
-            e = ev[int(flat.b3_pair_off[q]):int(flat.b3_pair_off[q + 1])]
-            one = e[:, 0] == e[:, 1]
-            np.add.at(same, e[one, 0], 1)
-            np.add.at(start, e[~one, 0], 1)
-            np.add.at(end, e[~one, 1], 1)
+    ng = (len(flat.b3_group_off) // 3) - 1
+    nb = ng << B3_GROUP_SHIFT
+    assert nb >= ((len(flat.stream8) + 15) >> B3_BLOCK_SHIFT) + 1
+    off = flat.b3_group_off.astype(np.int64).reshape(3, ng + 1)
+    ev = flat.b3_events.astype(np.int64)
+    cnt = np.zeros((3, nb), np.int64)       # 0: inside one block, 1: range starts, 2: range ends
+    for k in range(3):
+        e = ev[off[k, 0]:off[k, ng]]
+        grp = np.repeat(np.arange(ng), np.diff(off[k]))
+        pair = e & 0xFFFFFF
+        use = ((useful[pair >> 2] >> (pair & 3)) & 1) != 0
+        np.add.at(cnt[k], (grp[use] << B3_GROUP_SHIFT) + (e[use] >> 24), 1)
+    same, start, end = cnt[0], cnt[1], cnt[2]
     S, E = np.cumsum(start), np.cumsum(end)
     Sprev = np.concatenate([[0], S[:-1]]); Eprev = np.concatenate([[0], E[:-1]])
     over = S - Eprev + same
@@ -191,13 +179,9 @@ def b3_tables(flat, nibs):
 
 def b3_hu(b3, P, J):
     """Upper bound of the useful events on any path below the node whose last word sits at stream position P, its descendants in
-    the J words behind it -- read as the kernel reads it: 64 entries at the coarsest 64-ary level whose span fits."""
+    the J words behind it -- the exact maximum over the blocks (the kernel reads it through its 64-ary levels)."""
     q0, q1 = (P + 1) >> B3_BLOCK_SHIFT, (P + J) >> B3_BLOCK_SHIFT
-    sh = 0
-    while q1 - q0 >= 64:
-        q0 >>= 6; q1 >>= 6; sh += 6
-    lo, hi = q0 << sh, min(len(b3["over"]), (q1 + 1) << sh)
-    m = int(b3["over"][lo:hi].max())
+    m = int(b3["over"][q0:q1 + 1].max())
     u = int(b3["under"][P >> B3_BLOCK_SHIFT])
     return max(0, m - u)
 

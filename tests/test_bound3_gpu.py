@@ -1,0 +1,64 @@
+"""The third pruning bound's per-batch tables on the device (ugp_bound3.hip: pair masks -> group sums -> scan -> group
+tables) against the restatement in tests/stream_interp.py (b3_tables), block by block, through the test hook
+ugp_debug_bound3_tables; and the placements of the same batches against the oracle."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from oracle import capi
+from tests import stream_interp, synth
+from usher_amd import FlatTreeView, Placer, QueryBatch, _lib
+
+pytestmark = pytest.mark.gpu
+
+
+def _tables(placer, tile):
+    L = _lib.lib()
+    n = C.c_uint64()
+    assert L.ugp_debug_bound3_tables(placer._h, tile, None, None, 0, C.byref(n)) == 0
+    if n.value == 0:
+        return None, None
+    over, under = np.zeros(n.value, np.uint16), np.zeros(n.value, np.uint16)
+    assert L.ugp_debug_bound3_tables(placer._h, tile, over.ctypes.data_as(C.c_void_p), under.ctypes.data_as(C.c_void_p), n.value, C.byref(n)) == 0
+    return over.astype(np.int64), under.astype(np.int64)
+
+
+@pytest.mark.parametrize("seed,n_leaves,ambig", [(11, 3000, (0, 0, 2, 6)), (12, 9000, (0, 0, 0, 0)), (13, 9000, (3, 8, 0, 3))])
+def test_device_tables_equal_the_restatement(seed, n_leaves, ambig, monkeypatch):
+    monkeypatch.setenv("UGP_COARSE_MIN_NODES", "0")   # (the bound serves the sorted main walk: needs the locality pre-pass)
+    monkeypatch.delenv("UGP_NO_BOUND3", raising=False)
+    arrays, queries = synth.make_case(seed, n_leaves=n_leaves, n_queries=12, n_sites=400, n_ambig=ambig, p_masked=0.01)
+    flat = FlatTreeView(arrays)
+    placer = Placer(arrays)
+    orc = capi.OracleTree(arrays)
+    try:
+        # (a) every sample of the batch is the same sample: whatever the locality sort does, each tile's tables are that sample's
+        for q in queries[:3]:
+            res = placer.place(QueryBatch([dict(q, name="c%d" % i) for i in range(700)]))
+            want = orc.place(q)
+            assert (int(res["best_set_difference"][0]), int(res["num_best"][0]), int(res["best_j"][0])) == (want["best"], want["num_best"], want["best_j"])
+            assert (res == res[0]).all()
+            b3 = stream_interp.b3_tables(flat, [stream_interp.sample_site_alleles(flat, q)[0]])
+            for tile in (0, 1):
+                over, under = _tables(placer, tile)
+                assert over is not None, "the call did not build the tables"
+                n = len(b3["over"])
+                assert len(over) == n
+                np.testing.assert_array_equal(over, np.minimum(b3["over"], 65535))
+                np.testing.assert_array_equal(under, np.minimum(b3["under"], 65535))
+        # (b) a mixed batch: each tile's tables lie between those of its least useful sample and those of the whole batch
+        mixed = [dict(queries[i % len(queries)], name="m%d" % i) for i in range(1500)]
+        res = placer.place(QueryBatch(mixed))
+        for i in range(0, 1500, 97):
+            w = orc.place(mixed[i])
+            assert (int(res["best_set_difference"][i]), int(res["num_best"][i]), int(res["best_j"][i])) == (w["best"], w["num_best"], w["best_j"])
+        nibs = [stream_interp.sample_site_alleles(flat, q)[0] for q in queries]
+        whole = stream_interp.b3_tables(flat, nibs)
+        least = np.min([stream_interp.b3_tables(flat, [n])["over"] for n in nibs], axis=0)
+        for tile in range(3):
+            over, under = _tables(placer, tile)
+            assert (over <= whole["over"]).all() and (over >= least).all()
+    finally:
+        placer.close()
+        del orc

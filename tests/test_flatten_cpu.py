@@ -468,8 +468,7 @@ def test_third_lower_bound_holds_for_every_node_and_sample(seed):
 def test_third_bound_tables_skip_more_and_change_nothing(seed, chunk_nodes):
     """The third bound as the device builds and reads it (tests/stream_interp.b3_tables / b3_hu: posting lists of the flattening ->
     cum_over / cum_under per block of 16 stream words -> the maximum over the descendants' blocks at the coarsest 64-ary level that
-    fits, minus cum_under of the node's own block): (1) the posting lists hold every mutation word of the packed body exactly once,
-    under its (site, allele); (2) what the tables give is never below the true path maximum of useful events -- recomputed from the
+    fits, minus cum_under of the node's own block): (1) the event lists hold every mutation word of the packed body exactly once; (2) what the tables give is never below the true path maximum of useful events -- recomputed from the
     stream itself -- for every record; (3) the model of the walk, with the tables of the whole batch as one tile and each sample's
     own exact score as its bound, returns the oracle's answers and skips more of the stream than without."""
     arrays, queries = synth.make_case(seed, n_leaves=2600, n_queries=10, n_sites=300, n_ambig=(0, 0, 2, 6), p_masked=0.01)
@@ -478,11 +477,17 @@ def test_third_bound_tables_skip_more_and_change_nothing(seed, chunk_nodes):
     H_TAG = 1 << 31
     is_mut = (s8 & H_TAG) == 0
     # (1) every mutation word once
-    ev = flat.b3_events.reshape(-1, 2).astype(np.int64)
-    assert len(ev) == int(is_mut.sum()) and int(flat.b3_pair_off[-1]) == len(ev)
+    ng = len(flat.b3_group_off) // 3 - 1
+    off = flat.b3_group_off.astype(np.int64).reshape(3, ng + 1)
+    ev = flat.b3_events.astype(np.int64)
+    assert off[0, 0] == 0 and (np.diff(off, axis=1) >= 0).all() and off[1, 0] == off[0, ng] and off[2, 0] == off[1, ng] and off[2, ng] == len(ev)
+    assert off[1, ng] == int(is_mut.sum()) and off[2, ng] - off[2, 0] == off[1, ng] - off[1, 0]   # one start and one end per spanning event
     pairs = (s8[is_mut] & 0x3FFFFF) * 4 + ((s8[is_mut] >> 22) & 3)
-    assert (np.bincount(pairs, minlength=len(flat.b3_pair_off) - 1) == np.diff(flat.b3_pair_off.astype(np.int64))).all()
-    assert (ev[:, 0] <= ev[:, 1]).all() and ev[:, 1].max() <= (len(s8) - 1) >> 4
+    np.testing.assert_array_equal(np.bincount(pairs, minlength=4 * len(flat.site_ref)), np.bincount(ev[:off[1, ng]] & 0xFFFFFF, minlength=4 * len(flat.site_ref)))
+    np.testing.assert_array_equal(np.bincount(ev[off[1, 0]:off[1, ng]] & 0xFFFFFF), np.bincount(ev[off[2, 0]:] & 0xFFFFFF))
+    # lists 0 and 1 follow the stream: the k-th mutation word is the k-th event of the two lists merged by block
+    blk = lambda k: np.repeat(np.arange(ng), np.diff(off[k])) * 256 + (ev[off[k, 0]:off[k, ng]] >> 24)
+    assert (np.sort(np.concatenate([blk(0), blk(1)])) <= np.flatnonzero(is_mut) >> 4).all() and blk(2).max() <= (len(s8) - 1) >> 4
     nibs = [stream_interp.sample_site_alleles(flat, s)[0] for s in queries]
     b3 = stream_interp.b3_tables(flat, nibs)
     # (2) against the stream: walk the body once, keeping for every open node the running count of useful words on its root path

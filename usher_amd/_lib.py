@@ -91,6 +91,7 @@ SYMBOLS = {
     "ugp_job_wait": (C.c_int, [P]),
     "ugp_get_timing": (C.c_int, [P, C.POINTER(ugp_timing)]),
     "ugp_get_timing_sum": (C.c_int, [P, C.POINTER(ugp_timing), C.POINTER(C.c_uint32)]),
+    "ugp_debug_bound3_tables": (C.c_int, [P, C.c_uint32, P, P, C.c_uint64, C.POINTER(C.c_uint64)]),
     "ugp_last_error": (C.c_char_p, []),
     "ugp_fitch_sankoff": (C.c_int, [C.c_int, C.c_uint64, P, C.POINTER(ugp_sites), C.POINTER(P)]),
     "ugp_fitch_count": (C.c_uint64, [P]),

@@ -1,7 +1,8 @@
 // ugp_bound3.hip -- per-batch tables of the third pruning bound (ugp_flatten.hpp "B3", ugp_bound3.hpp), gfx950.
 //
-// Input: the tile's "useful" nibbles (which (site, allele) pairs match a variant of some sample of the tile -- written by the tile
-// builders) and the tree's static posting lists (FlatMat::b3_events: per pair, the block range of every event's subtree).
+// Input: the tiles' "useful" nibbles (which (site, allele) pairs match a variant of some sample of the tile -- written by the tile
+// builders) and the tree's static event lists in block order (FlatMat::b3_events: per group of B3_GROUP_BLOCKS blocks, the events
+// inside one block, the range starts and the range ends of the others).
 // Output, per tile and block of B3_BLOCK_WORDS packed-stream words:
 //     cum_over[b]  = #events whose block range [b0, b1] contains b                 (upper bound of the useful events on the root
 //                                                                                   path of any node with a word in b)
@@ -9,6 +10,15 @@
 // plus three 64-ary levels of maxima of cum_over, so that the walk reads the maximum over any block range with one 64-lane load.
 // With S(b) / E(b) = inclusive prefix counts of the range starts / ends of the events that span more than one block and same(b) =
 // events inside block b:   cum_over[b] = S(b) - E(b - 1) + same(b),   cum_under[b] = S(b - 1) - E(b).
+//
+// Four small steps, none with a global atomic and none that touches more than the tables themselves (4 bytes per tile and block):
+//   k_b3_pairmask     nibbles of 32 tiles -> one 32-bit tile mask per (site, allele) pair
+//   k_b3_group_sums   per group and tile: range starts and ends (reads the group's two lists once for 32 tiles)
+//   k_b3_seg_scan     exclusive scan of those sums along each tile's groups
+//   k_b3_group_tables per group: counts the events per (tile, block) in LDS, scans them, writes cum_over / cum_under / level 1
+//   k_b3_level2 / 3   the two upper levels of maxima
+// (first version of the round: one global atomic per event and tile into an 8-byte-per-block work array, zeroed per batch: 1.15 ms
+// for the atomics, 0.5 ms for the scan over 370 MB, per batch of 32 tiles -- five times what the bound saves the walk.)
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -16,158 +26,175 @@
 
 namespace ugp {
 
-// work[tile][block] = {start count | same count << 16, end count}.  One wave per 64 (site, allele) pairs: the lanes look their
-// pairs up in the tile's useful nibbles, then all 64 walk the posting list of each useful pair together.
-__global__ void __launch_bounds__(64) k_b3_events(const uint32_t *__restrict__ useful, uint32_t useful_words, uint32_t n_sites, const uint32_t *__restrict__ pair_off,
-                                                  const uint2 *__restrict__ events, uint2 *__restrict__ work, uint32_t n_blocks) {
-    const uint32_t tile = blockIdx.y, lane = threadIdx.x;
-    const uint32_t pair = blockIdx.x * 64u + lane, site = pair >> 2, al = pair & 3u;
-    const bool u = site < n_sites && ((useful[(uint64_t)tile * useful_words + (site >> 3)] >> ((site & 7u) * 4u + al)) & 1u);
-    unsigned long long mask = __builtin_amdgcn_ballot_w64(u);
-    uint32_t *W = (uint32_t *)(work + (uint64_t)tile * n_blocks);
-    while (mask) {
-        const uint32_t k = (uint32_t)__builtin_ctzll(mask);
-        mask &= mask - 1ull;
-        const uint32_t q = blockIdx.x * 64u + k;
-        const uint32_t i0 = pair_off[q], i1 = pair_off[q + 1];
-        for (uint32_t i = i0 + lane; i < i1; i += 64u) {
-            const uint2 e = events[i];
-            if (e.x == e.y) atomicAdd(&W[2u * e.x], 1u << 16);
-            else { atomicAdd(&W[2u * e.x], 1u); atomicAdd(&W[2u * e.y + 1u], 1u); }
+// pairmask[y][4 * site + allele]: bit t = the pair is useful for tile 32 * y + t
+__global__ void __launch_bounds__(256) k_b3_pairmask(const uint32_t *__restrict__ useful, uint32_t useful_words, uint32_t n_sites, uint32_t n_tiles,
+                                                     uint4 *__restrict__ pairmask) {
+    const uint32_t site = blockIdx.x * 256u + threadIdx.x, y = blockIdx.y;
+    if (site >= n_sites) return;
+    uint32_t m0 = 0, m1 = 0, m2 = 0, m3 = 0;
+    const uint32_t nt = min(32u, n_tiles - y * 32u);
+    for (uint32_t t = 0; t < nt; t++) {
+        const uint32_t nib = (useful[(uint64_t)(y * 32u + t) * useful_words + (site >> 3)] >> ((site & 7u) * 4u)) & 15u;
+        m0 |= (nib & 1u) << t; m1 |= ((nib >> 1) & 1u) << t; m2 |= ((nib >> 2) & 1u) << t; m3 |= (nib >> 3) << t;
+    }
+    pairmask[(uint64_t)y * n_sites + site] = make_uint4(m0, m1, m2, m3);
+}
+
+// gsum[tile][group] = {range starts, range ends} of the tile's useful events in the group (one wave per group and 32 tiles)
+__global__ void __launch_bounds__(64) k_b3_group_sums(const uint32_t *__restrict__ pairmask, uint32_t n_pairs, uint32_t n_tiles, const uint32_t *__restrict__ group_off,
+                                                      const uint32_t *__restrict__ events, uint32_t n_groups, uint2 *__restrict__ gsum) {
+    __shared__ uint32_t cnt[64];   // [0, 32): starts, [32, 64): ends
+    const uint32_t g = blockIdx.x, y = blockIdx.y, lane = threadIdx.x;
+    const uint32_t *pm = pairmask + (uint64_t)y * n_pairs;
+    cnt[lane] = 0;
+    __syncthreads();
+    for (uint32_t k = 1; k <= 2u; k++) {
+        const uint32_t i0 = group_off[(uint64_t)k * (n_groups + 1) + g], i1 = group_off[(uint64_t)k * (n_groups + 1) + g + 1];
+        for (uint32_t i = i0 + lane; i < i1; i += 256u) {   // (four events in flight per lane: event word -> tile mask is a dependent pair of loads)
+            uint32_t w[4], mk[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) w[u] = i + 64u * u < i1 ? events[i + 64u * u] : 0xFFFFFFFFu;
+#pragma unroll
+            for (int u = 0; u < 4; u++) mk[u] = w[u] != 0xFFFFFFFFu ? pm[w[u] & 0xFFFFFFu] : 0u;
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                uint32_t mask = mk[u];
+                while (mask) { const uint32_t t = (uint32_t)__builtin_ctz(mask); mask &= mask - 1u; atomicAdd(&cnt[(k - 1u) * 32u + t], 1u); }
+            }
         }
     }
-}
-
-// sums of the start and end counts of one segment of B3_SEG blocks
-__global__ void __launch_bounds__(256) k_b3_seg_sums(const uint2 *__restrict__ work, uint32_t n_blocks, uint32_t n_seg, uint2 *__restrict__ seg) {
-    __shared__ uint32_t ss[256], se[256];
-    const uint32_t tile = blockIdx.y, sg = blockIdx.x, t = threadIdx.x;
-    const uint2 *W = work + (uint64_t)tile * n_blocks;
-    uint32_t a = 0, b = 0;
-    for (uint32_t i = t; i < B3_SEG; i += 256u) {   // (strided: coalesced 8-byte loads)
-        const uint32_t blk = sg * B3_SEG + i;
-        if (blk < n_blocks) { const uint2 w = W[blk]; a += w.x & 0xFFFFu; b += w.y; }
-    }
-    ss[t] = a; se[t] = b;
     __syncthreads();
-    for (uint32_t o = 128; o > 0; o >>= 1) { if (t < o) { ss[t] += ss[t + o]; se[t] += se[t + o]; } __syncthreads(); }
-    if (t == 0) seg[(uint64_t)tile * n_seg + sg] = make_uint2(ss[0], se[0]);
+    if (lane < 32u && y * 32u + lane < n_tiles) gsum[(uint64_t)(y * 32u + lane) * n_groups + g] = make_uint2(cnt[lane], cnt[32u + lane]);
 }
 
-// exclusive scan of a tile's segment sums (one block per tile; a few hundred segments)
-__global__ void __launch_bounds__(256) k_b3_seg_scan(uint2 *__restrict__ seg, uint32_t n_seg) {
-    __shared__ uint32_t pa[256], pb[256];
-    const uint32_t tile = blockIdx.x, t = threadIdx.x;
+// exclusive scan of a tile's group sums in place (one block per tile: a run of consecutive groups per thread, the runs' totals scanned by
+// wave shuffles)
+__global__ void __launch_bounds__(1024) k_b3_seg_scan(uint2 *__restrict__ seg, uint32_t n_seg) {
+    __shared__ uint32_t wa[16], wb[16];
+    const uint32_t tile = blockIdx.x, t = threadIdx.x, lane = t & 63u, wv = t >> 6;
     uint2 *S = seg + (uint64_t)tile * n_seg;
-    uint32_t base_a = 0, base_b = 0;
-    for (uint32_t s0 = 0; s0 < n_seg; s0 += 256u) {
-        const uint32_t i = s0 + t;
-        const uint2 v = i < n_seg ? S[i] : make_uint2(0u, 0u);
-        pa[t] = v.x; pb[t] = v.y;
-        __syncthreads();
-        for (uint32_t o = 1; o < 256u; o <<= 1) {   // (Hillis-Steele)
-            const uint32_t xa = t >= o ? pa[t - o] : 0u, xb = t >= o ? pb[t - o] : 0u;
-            __syncthreads();
-            pa[t] += xa; pb[t] += xb;
-            __syncthreads();
-        }
-        if (i < n_seg) S[i] = make_uint2(base_a + pa[t] - v.x, base_b + pb[t] - v.y);
-        const uint32_t ta = pa[255], tb = pb[255];
-        __syncthreads();
-        base_a += ta; base_b += tb;
+    const uint32_t per = (n_seg + 1023u) / 1024u, i0 = min(n_seg, t * per), i1 = min(n_seg, i0 + per);
+    uint32_t a = 0, b = 0;
+    for (uint32_t i = i0; i < i1; i++) { const uint2 v = S[i]; a += v.x; b += v.y; }
+    uint32_t xa = a, xb = b;   // inclusive scan across the wave
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t ya = (uint32_t)__shfl_up((int)xa, o), yb = (uint32_t)__shfl_up((int)xb, o);
+        if (lane >= (uint32_t)o) { xa += ya; xb += yb; }
     }
+    if (lane == 63u) { wa[wv] = xa; wb[wv] = xb; }
+    __syncthreads();
+    uint32_t pa = xa - a, pb = xb - b;   // exclusive within the wave
+    for (uint32_t k = 0; k < wv; k++) { pa += wa[k]; pb += wb[k]; }
+    for (uint32_t i = i0; i < i1; i++) { const uint2 v = S[i]; S[i] = make_uint2(pa, pb); pa += v.x; pb += v.y; }
 }
 
-// the tables of one segment of B3_SEG blocks: the counters are staged through LDS (coalesced loads and stores; a thread then owns 16
-// consecutive blocks of the staged copy for the prefix sums)
-__global__ void __launch_bounds__(256) k_b3_tables(const uint2 *__restrict__ work, uint32_t n_blocks, uint32_t n_seg, const uint2 *__restrict__ seg,
-                                                   uint16_t *__restrict__ over, uint16_t *__restrict__ under, uint16_t *__restrict__ l1, uint32_t n_l1) {
-    __shared__ uint2 wk[B3_SEG];          // 32 KB
-    __shared__ uint32_t res[B3_SEG];      // 16 KB: over | under << 16
+// the tables of one group of B3_GROUP_BLOCKS blocks for 32 tiles: per (tile, block) one LDS word counts range starts (bits 7:0), events
+// inside the block (15:8; both at most B3_BLOCK_WORDS) and range ends (31:16); thread (tile, eighth of the group) then turns 32
+// of them into cum_over | cum_under << 16 in place, and the block writes the rows out four bytes (two blocks) at a time.
+constexpr uint32_t B3_ROW = B3_GROUP_BLOCKS + 1;   // (padded: a wave's 32 rows fall into 32 different LDS banks)
+__global__ void __launch_bounds__(256) k_b3_group_tables(const uint32_t *__restrict__ pairmask, uint32_t n_pairs, uint32_t n_tiles, const uint32_t *__restrict__ group_off,
+                                                         const uint32_t *__restrict__ events, uint32_t n_groups, const uint2 *__restrict__ gpre, uint32_t n_blocks,
+                                                         uint16_t *__restrict__ over, uint16_t *__restrict__ under, uint16_t *__restrict__ l1, uint32_t n_l1) {
+    __shared__ uint32_t cnt[32 * B3_ROW];
     __shared__ uint32_t pa[256], pb[256], mx[256];
-    const uint32_t tile = blockIdx.y, sg = blockIdx.x, t = threadIdx.x;
-    const uint2 *W = work + (uint64_t)tile * n_blocks;
-    const uint32_t g0 = sg * B3_SEG;
-    for (uint32_t i = t; i < B3_SEG; i += 256u) wk[i] = g0 + i < n_blocks ? W[g0 + i] : make_uint2(0u, 0u);
+    const uint32_t g = blockIdx.x, y = blockIdx.y, tid = threadIdx.x;
+    const uint32_t *pm = pairmask + (uint64_t)y * n_pairs;
+    for (uint32_t i = tid; i < 32u * B3_ROW; i += 256u) cnt[i] = 0;
     __syncthreads();
-    uint32_t a = 0, b = 0;
+    for (uint32_t k = 0; k < 3u; k++) {
+        const uint32_t i0 = group_off[(uint64_t)k * (n_groups + 1) + g], i1 = group_off[(uint64_t)k * (n_groups + 1) + g + 1];
+        const uint32_t inc = k == 0 ? 1u << 8 : k == 1 ? 1u : 1u << 16;
+        for (uint32_t i = i0 + tid; i < i1; i += 1024u) {   // (four events in flight per thread)
+            uint32_t w[4], mk[4];
 #pragma unroll
-    for (int k = 0; k < 16; k++) { const uint2 w = wk[t * 16 + k]; a += w.x & 0xFFFFu; b += w.y; }
-    pa[t] = a; pb[t] = b;
-    __syncthreads();
-    for (uint32_t o = 1; o < 256u; o <<= 1) {
-        const uint32_t xa = t >= o ? pa[t - o] : 0u, xb = t >= o ? pb[t - o] : 0u;
-        __syncthreads();
-        pa[t] += xa; pb[t] += xb;
-        __syncthreads();
+            for (int u = 0; u < 4; u++) w[u] = i + 256u * u < i1 ? events[i + 256u * u] : 0xFFFFFFFFu;
+#pragma unroll
+            for (int u = 0; u < 4; u++) mk[u] = w[u] != 0xFFFFFFFFu ? pm[w[u] & 0xFFFFFFu] : 0u;
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                uint32_t mask = mk[u];
+                while (mask) { const uint32_t t = (uint32_t)__builtin_ctz(mask); mask &= mask - 1u; atomicAdd(&cnt[t * B3_ROW + (w[u] >> 24)], inc); }
+            }
+        }
     }
-    const uint2 base = seg[(uint64_t)tile * n_seg + sg];
-    uint32_t S = base.x + pa[t] - a, E = base.y + pb[t] - b;   // inclusive prefixes in front of the thread's first block
+    __syncthreads();
+    const uint32_t t = tid & 31u, c = tid >> 5, tile = y * 32u + t;
+    uint32_t *row = cnt + t * B3_ROW + c * 32u;
+    uint32_t a = 0, b = 0;
+#pragma unroll 8
+    for (int k = 0; k < 32; k++) { const uint32_t w = row[k]; a += w & 0xFFu; b += w >> 16; }
+    pa[t * 8u + c] = a; pb[t * 8u + c] = b;
+    __syncthreads();
+    uint32_t S = 0, E = 0;
+    if (tile < n_tiles) { const uint2 base = gpre[(uint64_t)tile * n_groups + g]; S = base.x; E = base.y; }
+    for (uint32_t k = 0; k < c; k++) { S += pa[t * 8u + k]; E += pb[t * 8u + k]; }   // inclusive prefixes in front of the thread's first block
     uint32_t m = 0;
-#pragma unroll
-    for (int k = 0; k < 16; k++) {
-        const uint2 w = wk[t * 16 + k];
-        const uint32_t st = w.x & 0xFFFFu, same = w.x >> 16, en = w.y;
+#pragma unroll 8
+    for (int k = 0; k < 32; k++) {
+        const uint32_t w = row[k];
+        const uint32_t st = w & 0xFFu, same = (w >> 8) & 0xFFu, en = w >> 16;
         const uint32_t ov = min(S + st - E + same, 65535u);   // S(b) - E(b - 1) + same(b)   (65535: "no bound" for the walk -- cannot be reached on the packed path)
         const uint32_t un = min(S - (E + en), 65535u);        // S(b - 1) - E(b)   (never negative: an event ends where or behind it starts)
         S += st; E += en;
-        res[t * 16 + k] = ov | (un << 16);
-        if (g0 + t * 16 + k < n_blocks) m = max(m, ov);
+        row[k] = ov | (un << 16);
+        m = max(m, ov);
     }
-    mx[t] = m;
+    mx[t * 8u + c] = m;
     __syncthreads();
-    uint16_t *O = over + (uint64_t)tile * n_blocks, *U = under + (uint64_t)tile * n_blocks;
-    for (uint32_t i = t; i < B3_SEG / 2; i += 256u) {   // two blocks per thread and store: 4-byte stores, coalesced
-        const uint32_t blk = g0 + 2u * i;
-        const uint32_t r0 = res[2 * i], r1 = res[2 * i + 1];
-        if (blk + 1 < n_blocks) {
-            *(uint32_t *)(O + blk) = (r0 & 0xFFFFu) | (r1 << 16);
-            *(uint32_t *)(U + blk) = (r0 >> 16) | (r1 & 0xFFFF0000u);
-        } else if (blk < n_blocks) { O[blk] = (uint16_t)r0; U[blk] = (uint16_t)(r0 >> 16); }
+    const uint64_t g0 = (uint64_t)g * B3_GROUP_BLOCKS;
+    for (uint32_t it = 0; it < 16u; it++) {   // two tile rows per pass: 128 threads x two blocks
+        const uint32_t tt = it * 2u + (tid >> 7), i = tid & 127u, tl = y * 32u + tt;
+        if (tl >= n_tiles) continue;
+        const uint32_t r0 = cnt[tt * B3_ROW + 2u * i], r1 = cnt[tt * B3_ROW + 2u * i + 1u];
+        const uint64_t at = (uint64_t)tl * n_blocks + g0 + 2u * i;
+        *(uint32_t *)(over + at) = (r0 & 0xFFFFu) | (r1 << 16);
+        *(uint32_t *)(under + at) = (r0 >> 16) | (r1 & 0xFFFF0000u);
     }
-    if (t < 64) {   // level 1: 64 blocks = four threads
-        const uint32_t v = max(max(mx[4 * t], mx[4 * t + 1]), max(mx[4 * t + 2], mx[4 * t + 3]));
-        const uint32_t i = sg * 64u + t;
-        if (i < n_l1) l1[(uint64_t)tile * n_l1 + i] = (uint16_t)v;
-    }
-}
-
-// levels 2 and 3 of one tile (one block)
-__global__ void __launch_bounds__(256) k_b3_levels(const uint16_t *__restrict__ l1, uint32_t n_l1, uint16_t *__restrict__ l2, uint32_t n_l2, uint16_t *__restrict__ l3,
-                                                   uint32_t n_l3) {
-    const uint32_t tile = blockIdx.x, t = threadIdx.x;
-    const uint16_t *A = l1 + (uint64_t)tile * n_l1;
-    uint16_t *B = l2 + (uint64_t)tile * n_l2, *C = l3 + (uint64_t)tile * n_l3;
-    for (uint32_t i = t; i < n_l2; i += 256u) {
-        uint32_t m = 0;
-        for (uint32_t k = 0; k < 64u && i * 64u + k < n_l1; k++) m = max(m, (uint32_t)A[i * 64u + k]);
-        B[i] = (uint16_t)m;
-    }
-    __syncthreads();
-    __threadfence_block();
-    for (uint32_t i = t; i < n_l3; i += 256u) {
-        uint32_t m = 0;
-        for (uint32_t k = 0; k < 64u && i * 64u + k < n_l2; k++) m = max(m, (uint32_t)B[i * 64u + k]);
-        C[i] = (uint16_t)m;
+    if (tid < 128u) {   // level 1: 64 blocks = two threads' maxima
+        const uint32_t tt = tid >> 2, q = tid & 3u, tl = y * 32u + tt, i = g * (B3_GROUP_BLOCKS / 64u) + q;
+        if (tl < n_tiles && i < n_l1) l1[(uint64_t)tl * n_l1 + i] = (uint16_t)max(mx[tt * 8u + 2u * q], mx[tt * 8u + 2u * q + 1u]);
     }
 }
 
-hipError_t launch_b3_events(const uint32_t *useful, uint32_t useful_words, uint32_t n_sites, uint32_t n_tiles, const uint32_t *pair_off, const uint32_t *events,
-                            uint32_t *work, uint32_t n_blocks, hipStream_t s) {
-    if (!n_sites || !n_tiles) return hipSuccess;
-    hipLaunchKernelGGL(k_b3_events, dim3((n_sites * 4u + 63u) / 64u, n_tiles), dim3(64), 0, s, useful, useful_words, n_sites, pair_off, (const uint2 *)events, (uint2 *)work,
-                       n_blocks);
-    return hipGetLastError();
+// level 2 (grid: 64 entries per block, tile) and level 3 (one block per tile): a thread reads its 64 entries as sixteen 8-byte loads
+// (n_l1 is a multiple of four: whole groups of 256 blocks)
+__device__ inline uint32_t b3_max64(const uint16_t *A, uint32_t i, uint32_t n) {
+    uint32_t m = 0;
+    if (i * 64u + 64u <= n && (n & 3u) == 0) {
+        const uint2 *p = (const uint2 *)(A + i * 64u);
+        uint2 v[16];
+#pragma unroll
+        for (int k = 0; k < 16; k++) v[k] = p[k];
+#pragma unroll
+        for (int k = 0; k < 16; k++) m = max(max(m, max(v[k].x & 0xFFFFu, v[k].x >> 16)), max(v[k].y & 0xFFFFu, v[k].y >> 16));
+    } else {
+        for (uint32_t k = 0; k < 64u && i * 64u + k < n; k++) m = max(m, (uint32_t)A[i * 64u + k]);
+    }
+    return m;
+}
+__global__ void __launch_bounds__(64) k_b3_level2(const uint16_t *__restrict__ l1, uint32_t n_l1, uint16_t *__restrict__ l2, uint32_t n_l2) {
+    const uint32_t tile = blockIdx.y, i = blockIdx.x * 64u + threadIdx.x;
+    if (i < n_l2) l2[(uint64_t)tile * n_l2 + i] = (uint16_t)b3_max64(l1 + (uint64_t)tile * n_l1, i, n_l1);
+}
+__global__ void __launch_bounds__(64) k_b3_level3(const uint16_t *__restrict__ l2, uint32_t n_l2, uint16_t *__restrict__ l3, uint32_t n_l3) {
+    const uint32_t tile = blockIdx.x;
+    for (uint32_t i = threadIdx.x; i < n_l3; i += 64u) l3[(uint64_t)tile * n_l3 + i] = (uint16_t)b3_max64(l2 + (uint64_t)tile * n_l2, i, n_l2);
 }
 
-hipError_t launch_b3_tables(const uint32_t *work, uint32_t n_tiles, uint32_t n_blocks, uint32_t *seg, uint16_t *over, uint16_t *under, uint16_t *l1, uint16_t *l2,
-                            uint16_t *l3, hipStream_t s) {
-    if (!n_tiles || !n_blocks) return hipSuccess;
-    const uint32_t n_seg = (n_blocks + B3_SEG - 1) / B3_SEG, n_l1 = b3_div64(n_blocks), n_l2 = b3_div64(n_l1), n_l3 = b3_div64(n_l2);
-    hipLaunchKernelGGL(k_b3_seg_sums, dim3(n_seg, n_tiles), dim3(256), 0, s, (const uint2 *)work, n_blocks, n_seg, (uint2 *)seg);
-    hipLaunchKernelGGL(k_b3_seg_scan, dim3(n_tiles), dim3(256), 0, s, (uint2 *)seg, n_seg);
-    hipLaunchKernelGGL(k_b3_tables, dim3(n_seg, n_tiles), dim3(256), 0, s, (const uint2 *)work, n_blocks, n_seg, (const uint2 *)seg, over, under, l1, n_l1);
-    hipLaunchKernelGGL(k_b3_levels, dim3(n_tiles), dim3(256), 0, s, l1, n_l1, l2, n_l2, l3, n_l3);
+hipError_t launch_b3_tables(const uint32_t *useful, uint32_t useful_words, uint32_t n_sites, uint32_t n_tiles, const uint32_t *group_off, const uint32_t *events,
+                            uint32_t n_blocks, uint32_t *pairmask, uint32_t *gsum, uint16_t *over, uint16_t *under, uint16_t *l1, uint16_t *l2, uint16_t *l3,
+                            hipStream_t s) {
+    if (!n_sites || !n_tiles || !n_blocks) return hipSuccess;
+    const uint32_t ng = n_blocks >> B3_GROUP_SHIFT, ty = (n_tiles + 31u) / 32u, n_pairs = n_sites * 4u;
+    const uint32_t n_l1 = b3_div64(n_blocks), n_l2 = b3_div64(n_l1), n_l3 = b3_div64(n_l2);
+    hipLaunchKernelGGL(k_b3_pairmask, dim3((n_sites + 255u) / 256u, ty), dim3(256), 0, s, useful, useful_words, n_sites, n_tiles, (uint4 *)pairmask);
+    hipLaunchKernelGGL(k_b3_group_sums, dim3(ng, ty), dim3(64), 0, s, pairmask, n_pairs, n_tiles, group_off, events, ng, (uint2 *)gsum);
+    hipLaunchKernelGGL(k_b3_seg_scan, dim3(n_tiles), dim3(1024), 0, s, (uint2 *)gsum, ng);
+    hipLaunchKernelGGL(k_b3_group_tables, dim3(ng, ty), dim3(256), 0, s, pairmask, n_pairs, n_tiles, group_off, events, ng, (const uint2 *)gsum, n_blocks, over, under, l1,
+                       n_l1);
+    hipLaunchKernelGGL(k_b3_level2, dim3((n_l2 + 63u) / 64u, n_tiles), dim3(64), 0, s, l1, n_l1, l2, n_l2);
+    hipLaunchKernelGGL(k_b3_level3, dim3(n_tiles), dim3(64), 0, s, l2, n_l2, l3, n_l3);
     return hipGetLastError();
 }
 

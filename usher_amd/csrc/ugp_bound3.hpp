@@ -18,16 +18,13 @@ struct B3Dev {
     uint32_t n_blocks, n_l1, n_l2, n_l3;
 };
 
-constexpr uint32_t B3_SEG = 4096;   // blocks per scan segment (= 64 level-1 entries)
-
-// work[tile][block]: start count (bits 7:0), same-block count (15:8), end count (31:16) -- zeroed by the caller.
 // useful[tile][useful_words]: one nibble per site, bit a = allele a is in some sample's set that excludes the reference base.
-hipError_t launch_b3_events(const uint32_t *useful, uint32_t useful_words, uint32_t n_sites, uint32_t n_tiles, const uint32_t *pair_off, const uint32_t *events,
-                            uint32_t *work, uint32_t n_blocks, hipStream_t s);
-// seg: [n_tiles][n_seg][2] scratch.  Fills over / under / l1 / l2 / l3.
-hipError_t launch_b3_tables(const uint32_t *work, uint32_t n_tiles, uint32_t n_blocks, uint32_t *seg, uint16_t *over, uint16_t *under, uint16_t *l1, uint16_t *l2,
-                            uint16_t *l3, hipStream_t s);
-inline uint32_t b3_blocks(uint64_t stream8_words) { return (((uint32_t)((stream8_words + B3_BLOCK_WORDS - 1) >> B3_BLOCK_SHIFT) + 1u) + 1u) & ~1u; }   // (even: the tables are stored two blocks at a time)
+// group_off / events: FlatMat::b3_group_off / b3_events on the device; n_blocks = b3_blocks(packed-stream words) (whole groups).
+// Scratch: pairmask [ceil(n_tiles / 32)][4 * n_sites] words, gsum [n_tiles][n_blocks / B3_GROUP_BLOCKS][2] words.
+// Fills over / under ([n_tiles][n_blocks]) and l1 / l2 / l3.
+hipError_t launch_b3_tables(const uint32_t *useful, uint32_t useful_words, uint32_t n_sites, uint32_t n_tiles, const uint32_t *group_off, const uint32_t *events,
+                            uint32_t n_blocks, uint32_t *pairmask, uint32_t *gsum, uint16_t *over, uint16_t *under, uint16_t *l1, uint16_t *l2, uint16_t *l3,
+                            hipStream_t s);
 inline uint32_t b3_div64(uint32_t n) { return (n + 63u) / 64u; }
 
 }  // namespace ugp

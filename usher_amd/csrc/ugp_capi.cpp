@@ -163,7 +163,7 @@ struct ugp_mat {
     DevBuf<uint32_t> d_stream, d_pre, d_chunk_body, d_chunk_pre, d_chunk_node, d_rank2bfs, d_dfs2bfs;
     DevBuf<uint32_t> d_stream8, d_pre8, d_chunk8_body, d_chunk8_pre, d_stream_t, d_chunk_t;
     DevBuf<uint32_t> d_node_pos8, d_rank_dfs;   // packed-stream position of every node's words and its tie rank, by DFS index (k_best8 names nodes by position)
-    DevBuf<uint32_t> d_b3_pair_off, d_b3_events;   // third pruning bound: posting lists of the mutation events by (site, allele) (FlatMat::b3_*)
+    DevBuf<uint32_t> d_b3_group_off, d_b3_events;   // third pruning bound: the mutation events in block order (FlatMat::b3_*)
     uint64_t stream8_dwords = 0;
     DevBuf<int32_t> d_pos2site, d_site_pos;   // position -> site, site -> position
     DevBuf<uint8_t> d_site_ref;
@@ -198,7 +198,7 @@ struct ugp_mat {
         DevBuf<uint64_t> d_dyn;
         uint32_t dyn_epoch = 0;
         // third pruning bound: per-batch block tables of every tile (ugp_bound3.hpp)
-        DevBuf<uint32_t> d_b3_work, d_b3_seg;
+        DevBuf<uint32_t> d_b3_pairmask, d_b3_gsum;
         DevBuf<uint16_t> d_b3_over, d_b3_under, d_b3_l1, d_b3_l2, d_b3_l3;
         DevBuf<ugp::B3Dev> d_b3_dev;
         ugp::B3Dev b3_host = {};
@@ -489,8 +489,7 @@ int run_place(ugp_mat *m, ugp_qset *qs, int mode, ugp_result *d_out, int32_t *d_
         const bool b3_on = b3_want && !(lds_build && nmi < 0);
         if (b3_on) {
             const uint32_t nb = ugp::b3_blocks(m->stream8_dwords), n_l1 = ugp::b3_div64(nb), n_l2 = ugp::b3_div64(n_l1), n_l3 = ugp::b3_div64(n_l2);
-            const uint32_t n_seg = (nb + ugp::B3_SEG - 1) / ugp::B3_SEG;
-            HIP_TRY(W.d_b3_work.reserve((size_t)n_tiles512 * nb * 2)); HIP_TRY(W.d_b3_seg.reserve((size_t)n_tiles512 * n_seg * 2));
+            HIP_TRY(W.d_b3_pairmask.reserve((size_t)((n_tiles512 + 31) / 32) * n_sites * 4)); HIP_TRY(W.d_b3_gsum.reserve((size_t)n_tiles512 * (nb >> ugp::B3_GROUP_SHIFT) * 2));
             HIP_TRY(W.d_b3_over.reserve((size_t)n_tiles512 * nb)); HIP_TRY(W.d_b3_under.reserve((size_t)n_tiles512 * nb));
             HIP_TRY(W.d_b3_l1.reserve((size_t)n_tiles512 * n_l1)); HIP_TRY(W.d_b3_l2.reserve((size_t)n_tiles512 * n_l2)); HIP_TRY(W.d_b3_l3.reserve((size_t)n_tiles512 * n_l3));
             HIP_TRY(W.d_b3_dev.reserve(1));
@@ -500,9 +499,8 @@ int run_place(ugp_mat *m, ugp_qset *qs, int mode, ugp_result *d_out, int32_t *d_
                 HIP_TRY(hipMemcpy(W.d_b3_dev.p, &hd, sizeof hd, hipMemcpyHostToDevice));
                 W.b3_host = hd;
             }
-            HIP_TRY(hipMemsetAsync(W.d_b3_work.p, 0, (size_t)n_tiles512 * nb * 2 * sizeof(uint32_t), s));
-            HIP_TRY(ugp::launch_b3_events(d_useful, useful_words, n_sites, n_tiles512, m->d_b3_pair_off.p, m->d_b3_events.p, W.d_b3_work.p, nb, s));
-            HIP_TRY(ugp::launch_b3_tables(W.d_b3_work.p, n_tiles512, nb, W.d_b3_seg.p, W.d_b3_over.p, W.d_b3_under.p, W.d_b3_l1.p, W.d_b3_l2.p, W.d_b3_l3.p, s));
+            HIP_TRY(ugp::launch_b3_tables(d_useful, useful_words, n_sites, n_tiles512, m->d_b3_group_off.p, m->d_b3_events.p, nb, W.d_b3_pairmask.p, W.d_b3_gsum.p,
+                                          W.d_b3_over.p, W.d_b3_under.p, W.d_b3_l1.p, W.d_b3_l2.p, W.d_b3_l3.p, s));
         }
         if (use8) {   // upper bounds of best(s) the pruning starts from
 #ifdef UGP_EXPERIMENTS
@@ -668,8 +666,8 @@ int run_place(ugp_mat *m, ugp_qset *qs, int mode, ugp_result *d_out, int32_t *d_
                                                 W.d_units.p, W.d_unit_info.p, W.d_unit_info.p + 8, dyn_ctl, s));
                 b.units = (const uint4 *)W.d_units.p; b.unit_base = W.d_unit_info.p; b.unit_count = W.d_unit_info.p + 8;
             }
-            HIP_TRY(W.d_stats.reserve(72));
-            if (q0 == 0) { HIP_TRY(hipMemsetAsync(W.d_stats.p, 0, 72 * sizeof(uint64_t), s)); W.last_words_total = 0; }
+            HIP_TRY(W.d_stats.reserve(96));
+            if (q0 == 0) { HIP_TRY(hipMemsetAsync(W.d_stats.p, 0, 96 * sizeof(uint64_t), s)); W.last_words_total = 0; }
             b.stats = K.stats ? W.d_stats.p : nullptr;   // the counters are two contended atomics per skip: debug only
             if (b.stats && !K.trace.empty() && !coarse_only) {   // per-unit records of this launch, dumped by ugp_get_timing
                 constexpr size_t kTraceCap = 1u << 20;
@@ -951,8 +949,8 @@ static int upload_flat(const HostFlat &hf, int device, ugp_mat **out) {
     if (!f.node_pos8.empty() && (e = m->d_node_pos8.upload(f.node_pos8)) != hipSuccess) return bail(e, "upload node positions");
     if (!f.rank_dfs.empty() && (e = m->d_rank_dfs.upload(f.rank_dfs)) != hipSuccess) return bail(e, "upload node ranks");
     if (!f.b3_events.empty()) {
-        if ((e = m->d_b3_pair_off.upload(f.b3_pair_off)) != hipSuccess) return bail(e, "upload posting lists");
-        if ((e = m->d_b3_events.upload(f.b3_events)) != hipSuccess) return bail(e, "upload posting lists");
+        if ((e = m->d_b3_group_off.upload(f.b3_group_off)) != hipSuccess) return bail(e, "upload event lists");
+        if ((e = m->d_b3_events.upload(f.b3_events)) != hipSuccess) return bail(e, "upload event lists");
     }
     m->stream8_dwords = f.stream8.size();
     m->stream_dwords = f.stream.size();
@@ -1087,7 +1085,7 @@ template <class IO> void flat_io(IO &io, HostFlat &hf) {
     io.vec(f.stream); io.vec(f.pre_stream); io.vec(f.chunk_body_off); io.vec(f.chunk_pre_off); io.vec(f.chunk_node_off); io.vec(f.pos2site);
     io.vec(f.site_ref); io.vec(f.rank2bfs); io.vec(f.dfs2bfs); io.vec(f.stream8); io.vec(f.pre8_stream); io.vec(f.chunk8_body_off); io.vec(f.chunk8_pre_off);
     io.vec(f.stream_t); io.vec(f.chunk_t_off); io.vec(f.rank_dfs); io.vec(f.node_pos8); io.vec(f.hdr8_of_bfs); io.vec(f.rec_of_bfs); io.vec(f.post_of_bfs);
-    io.vec(f.b3_pair_off); io.vec(f.b3_events);
+    io.vec(f.b3_group_off); io.vec(f.b3_events);
     io.vec(hf.parent); io.vec(hf.coarse2dfs); io.vec(hf.coarse2bfs); io.vec(hf.node_pair); io.pod(hf.wide_descent);
 }
 }  // namespace
@@ -2096,7 +2094,7 @@ static int harvest_timing(ugp_mat *m, ugp_mat::Work &W, ugp_mat::Work::Gen &G) {
         G.last.words_total = W.last_words_total;
         G.last.words_skipped = 0;
         if (W.last_used_best8 && W.d_stats.p && m->knobs.stats) {   // (debug counters: a blocking copy)
-            uint64_t v[72] = {0};
+            uint64_t v[96] = {0};
             HIP_TRY(hipMemcpy(v, W.d_stats.p, sizeof v, hipMemcpyDeviceToHost));
             G.last.words_skipped = v[0];
             G.last.reserved = (uint32_t)std::min<uint64_t>(v[1], 0xFFFFFFFFull);   // pipeline (re)starts
@@ -2127,6 +2125,9 @@ static int harvest_timing(ugp_mat *m, ugp_mat::Work &W, ugp_mat::Work::Gen &G) {
                         (unsigned long long)v[53], (unsigned long long)v[54], (unsigned long long)v[55]);
                 fprintf(stderr, "[ugp stats] units split while running: %llu\n", (unsigned long long)v[31]);
                 fprintf(stderr, "[ugp stats] third bound: asked at a restart %llu times, decided the jump %llu times\n", (unsigned long long)v[64], (unsigned long long)v[65]);
+                fprintf(stderr, "[ugp stats] third bound by jump length (<16 <32 <64 <128 <256 <512 <1024 more), decided/asked:");
+                for (int i = 0; i < 8; i++) fprintf(stderr, " %llu/%llu", (unsigned long long)v[80 + i], (unsigned long long)v[72 + i]);
+                fprintf(stderr, "\n");
                 fprintf(stderr, "[ugp stats] jump lengths in words (<8 <16 <32 <64 <128 <512 <4096 more):");
                 for (int i = 0; i < 8; i++) fprintf(stderr, " %llu", (unsigned long long)v[56 + i]);
                 fprintf(stderr, "\n");
@@ -2154,6 +2155,20 @@ int ugp_get_timing(ugp_mat *m, ugp_timing *out) {
     ugp_mat::Work &W = m->work[m->last_work];
     if (int rc = harvest_timing(m, W, W.gens[W.cur])) return rc;
     *out = W.gens[W.cur].last;
+    return UGP_OK;
+}
+
+int ugp_debug_bound3_tables(ugp_mat *m, uint32_t tile, uint16_t *over, uint16_t *under, uint64_t cap, uint64_t *n_blocks) {
+    if (!m || !n_blocks) return fail(UGP_ERR_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(m->device));
+    ugp_mat::Work &W = m->work[m->last_work];
+    *n_blocks = W.b3_host.n_blocks;
+    if (!W.b3_host.over) { *n_blocks = 0; return UGP_OK; }   // (the last call did not build them)
+    if (!over || !under) return UGP_OK;
+    if (cap < W.b3_host.n_blocks) return fail(UGP_ERR_INVALID, "buffer too small");
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(over, W.b3_host.over + (uint64_t)tile * W.b3_host.n_blocks, (size_t)W.b3_host.n_blocks * 2, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(under, W.b3_host.under + (uint64_t)tile * W.b3_host.n_blocks, (size_t)W.b3_host.n_blocks * 2, hipMemcpyDeviceToHost));
     return UGP_OK;
 }
 
@@ -2248,7 +2263,7 @@ int ugp_flat_get(const ugp_flat *fl, int which, const void **ptr, uint64_t *coun
         case UGP_FLAT_CHUNK_T_OFF: *ptr = f.chunk_t_off.data(); *count = f.chunk_t_off.size(); break;
         case UGP_FLAT_MAX_PATH_MUTS: *ptr = nullptr; *count = f.max_path_muts; break;
         case UGP_FLAT_LDS_SLOTS: *ptr = nullptr; *count = f.lds_slots; break;
-        case UGP_FLAT_B3_PAIR_OFF: *ptr = f.b3_pair_off.data(); *count = f.b3_pair_off.size(); break;
+        case UGP_FLAT_B3_GROUP_OFF: *ptr = f.b3_group_off.data(); *count = f.b3_group_off.size(); break;
         case UGP_FLAT_B3_EVENTS: *ptr = f.b3_events.data(); *count = f.b3_events.size(); break;
         default: return fail(UGP_ERR_INVALID, "unknown array id");
     }

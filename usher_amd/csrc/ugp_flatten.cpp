@@ -661,30 +661,42 @@ int flatten(const ugp_tree_desc &t, const Options &opt, FlatMat &out, std::strin
     // An event = one mutation word of the packed body; it raises, for every node of its node's subtree (the node included), the
     // number of mutations of that (site, allele) on the root path -- i.e. over the word range [header of the node, end of its
     // descendants), here as a range of blocks of B3_BLOCK_WORDS words.  Filled in depth-first order on one thread (deterministic).
-    out.b3_pair_off.clear(); out.b3_events.clear();
-    if (opt.keep_b3_events && out.n_sites && total8 > 0) {
-        const uint64_t n_pairs = (uint64_t)out.n_sites * 4;
-        out.b3_pair_off.assign(n_pairs + 1, 0);
+    out.b3_group_off.clear(); out.b3_events.clear();
+    if (opt.keep_b3_events && out.n_sites && total8 > 0 && total8 < (1ull << 32) - 2 * B3_GROUP_BLOCKS * B3_BLOCK_WORDS) {
+        const uint32_t ng = b3_blocks(total8) >> B3_GROUP_SHIFT;
+        out.b3_group_off.assign((size_t)3 * (ng + 1), 0);
+        uint32_t *off[3] = {out.b3_group_off.data(), out.b3_group_off.data() + (ng + 1), out.b3_group_off.data() + 2 * (size_t)(ng + 1)};
         const uint32_t *s8 = out.stream8.data();
+        auto range_of = [&](uint64_t d, uint32_t j, uint32_t &b0, uint32_t &b1) { b0 = pos8_hdr[d] >> B3_BLOCK_SHIFT; b1 = (pos8_at[d + sub[j]] - 1u) >> B3_BLOCK_SHIFT; };
         for (uint64_t d = 0; d < N; d++) {
             const uint32_t j = d2b[d];
             if (dropped[j] || !nw[j]) continue;
-            for (uint32_t k = 0; k < nw[j]; k++) { const uint32_t w = s8[pos8_hdr[d] + 1u + k]; out.b3_pair_off[(uint64_t)(w & 0x3FFFFFu) * 4 + ((w >> 22) & 3u) + 1]++; }
+            uint32_t b0, b1; range_of(d, j, b0, b1);
+            if (b0 == b1) off[0][(b0 >> B3_GROUP_SHIFT) + 1] += nw[j];
+            else { off[1][(b0 >> B3_GROUP_SHIFT) + 1] += nw[j]; off[2][(b1 >> B3_GROUP_SHIFT) + 1] += nw[j]; }
         }
-        for (uint64_t q = 0; q < n_pairs; q++) out.b3_pair_off[q + 1] += out.b3_pair_off[q];
-        out.b3_events.resize((size_t)out.b3_pair_off[n_pairs] * 2);
-        std::vector<uint32_t> fill(out.b3_pair_off.begin(), out.b3_pair_off.end() - 1);
+        uint32_t run = 0;
+        for (int k = 0; k < 3; k++) {   // (the three lists one behind the other)
+            for (uint32_t g = 0; g <= ng; g++) { run += off[k][g]; off[k][g] = run; }
+        }
+        out.b3_events.resize(run);
+        std::vector<uint32_t> fill[3];
+        for (int k = 0; k < 3; k++) fill[k].assign(off[k], off[k] + ng);
         for (uint64_t d = 0; d < N; d++) {
             const uint32_t j = d2b[d];
             if (dropped[j] || !nw[j]) continue;
-            const uint32_t b0 = pos8_hdr[d] >> B3_BLOCK_SHIFT, b1 = (pos8_at[d + sub[j]] - 1u) >> B3_BLOCK_SHIFT;
+            uint32_t b0, b1; range_of(d, j, b0, b1);
             for (uint32_t k = 0; k < nw[j]; k++) {
                 const uint32_t w = s8[pos8_hdr[d] + 1u + k];
-                const uint32_t at = fill[(uint64_t)(w & 0x3FFFFFu) * 4 + ((w >> 22) & 3u)]++;
-                out.b3_events[(size_t)at * 2] = b0; out.b3_events[(size_t)at * 2 + 1] = b1;
+                const uint32_t pair = (w & 0x3FFFFFu) * 4u + ((w >> 22) & 3u);
+                if (b0 == b1) out.b3_events[fill[0][b0 >> B3_GROUP_SHIFT]++] = pair | ((b0 & (B3_GROUP_BLOCKS - 1u)) << 24);
+                else {
+                    out.b3_events[fill[1][b0 >> B3_GROUP_SHIFT]++] = pair | ((b0 & (B3_GROUP_BLOCKS - 1u)) << 24);
+                    out.b3_events[fill[2][b1 >> B3_GROUP_SHIFT]++] = pair | ((b1 & (B3_GROUP_BLOCKS - 1u)) << 24);
+                }
             }
         }
-        flat_lap("third bound: posting lists");
+        flat_lap("third bound: event lists");
     }
 
     // ---- tie stream (phase 2 walks it one chunk at a time) ---------------------------------------------------------------------

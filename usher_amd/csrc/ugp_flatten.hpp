@@ -132,7 +132,13 @@ constexpr uint32_t M_FLUSH = 1u << 28, M_END = 1u << 30;
 //     cum_under[b] = events whose range contains b strictly inside <= cum(y) for every such y
 // and the walk tests, for a record at n with descendants in blocks [q0, q1] and its own last word in block bn,
 //     hU_T(n) <= max(cum_over[q0 .. q1]) - cum_under[bn].
+// The events are kept in BLOCK order, in groups of B3_GROUP_BLOCKS blocks (one workgroup of ugp_bound3.hip builds the tables of a
+// group for 32 tiles at a time: it reads the group's events once and asks a per-batch bit mask "which tiles make this pair
+// useful"), as three lists per group: events inside one block, range starts and range ends of the events that span blocks.
 constexpr uint32_t B3_BLOCK_SHIFT = 4, B3_BLOCK_WORDS = 1u << B3_BLOCK_SHIFT;
+constexpr uint32_t B3_GROUP_SHIFT = 8, B3_GROUP_BLOCKS = 1u << B3_GROUP_SHIFT;
+// blocks per tile row of the tables (whole groups; one block more than the stream has words for)
+inline uint32_t b3_blocks(uint64_t stream8_words) { return (uint32_t)((((stream8_words + B3_BLOCK_WORDS - 1) >> B3_BLOCK_SHIFT) + 1u + B3_GROUP_BLOCKS - 1u) & ~(uint64_t)(B3_GROUP_BLOCKS - 1u)); }
 constexpr uint32_t MAX_SITES = 1u << 22;
 constexpr uint32_t MAX_NODE_MUTS = 65534;   // 0xFFFF marks a pruning pseudo-record of the tie stream
 
@@ -188,10 +194,12 @@ struct FlatMat {
     // (Options::keep_update_maps) by BFS index: position of the node's header word in stream8, of its record (w0) in stream and in
     // stream_t; UINT32_MAX = the node has no record there (leaves without mutation words are dropped from stream8 / stream_t)
     UVec<uint32_t> hdr8_of_bfs, rec_of_bfs, post_of_bfs;
-    // (Options::keep_b3_events) third pruning bound: for every (site, mutated allele) pair q = 4 * site + allele index, the events
-    // b3_events[2 * i], [2 * i + 1] (i in [b3_pair_off[q], b3_pair_off[q + 1])) = first and last block of B3_BLOCK_WORDS packed-stream
-    // words covered by the subtree (node included) of a node that carries such a mutation
-    std::vector<uint32_t> b3_pair_off;
+    // (Options::keep_b3_events) third pruning bound: the mutation events (one per mutation word of the packed body) in block order.
+    // b3_events[i] = 4 * site + allele index (bits 23:0) | block within its group (31:24); list k of group g =
+    // [b3_group_off[k * (n_groups + 1) + g], ...[.. + g + 1]) with k = 0: events whose subtree (node included) lies inside one block
+    // of B3_BLOCK_WORDS packed-stream words, listed under that block; 1: the others, under the block of the node's header word;
+    // 2: the same events again, under the last block of the subtree.  n_groups = b3_blocks(stream8 words) / B3_GROUP_BLOCKS.
+    std::vector<uint32_t> b3_group_off;
     UVec<uint32_t> b3_events;
     uint32_t max_chunk8_words = 0;         // longest chunk of the packed stream (a work unit must stay below the reach of a preamble record's jump field)
     uint32_t lds_slots = 0;                // the Options value the packed stream was encoded for (<= max_slots)

@@ -1645,38 +1645,43 @@ __global__ void __launch_bounds__(64, TIES ? 3 : 4) k_best8(Best8Args a) {
             // (also behind the general step: a node walked by slow_node may have asked too)
             if (B3 && (skip_to & 0x80000000u)) {
                 // Third bound for the record in `info` (its node's D / B are still in dcur / bcur): descendants in the words behind
-                // p = the node's last word.  M = the maximum of cum_over over their blocks, read 64 entries at a time at the coarsest
-                // level whose span fits; U = cum_under of the node's own block; hU <= M - U.
+                // p = the node's last word.  M = the maximum of cum_over over their blocks; U = cum_under of the node's own block; hU <= M - U.
                 skip_to &= 0x7FFFFFFFu;
                 const uint32_t p = skip_to - 1u, J = info & INFO_JUMP_MASK;
                 const uint32_t P = begin + p;
                 const B3Dev *b3 = a.b3;
                 uint32_t q0 = (P + 1u) >> B3_BLOCK_SHIFT, q1 = (P + J) >> B3_BLOCK_SHIFT;
                 const uint32_t nb = b3->n_blocks;
-                const uint16_t *arr = b3->over + (uint64_t)tile * nb;
-                if (q1 - q0 >= 64u) {
-                    q0 >>= 6; q1 >>= 6;
-                    arr = b3->l1 + (uint64_t)tile * b3->n_l1;
-                    if (q1 - q0 >= 64u) {
-                        q0 >>= 6; q1 >>= 6;
-                        arr = b3->l2 + (uint64_t)tile * b3->n_l2;
-                        if (q1 - q0 >= 64u) { q0 >>= 6; q1 >>= 6; arr = b3->l3 + (uint64_t)tile * b3->n_l3; }
+                // exact maximum over [q0, q1]: at each level the (up to 63) entries left and right of the whole 64-groups, the groups
+                // themselves one level up -- at most seven loads per lane, all in flight together
+                uint32_t mv = 0;
+                {
+                    const uint16_t *arr = b3->over + (uint64_t)tile * nb;
+#pragma unroll
+                    for (int lv = 0; lv < 4; lv++) {
+                        if (lv == 3 || q1 - q0 < 64u) { for (uint32_t i = q0 + lane; i <= q1; i += 64u) mv = max(mv, (uint32_t)arr[i]); break; }
+                        const uint32_t le = q0 | 63u, rs = q1 & ~63u;
+                        if (q0 + lane <= le) mv = max(mv, (uint32_t)arr[q0 + lane]);
+                        if (rs + lane <= q1) mv = max(mv, (uint32_t)arr[rs + lane]);
+                        q0 = (q0 >> 6) + 1u; q1 = (q1 >> 6);
+                        if (q0 >= q1) break;   // (no whole group between the two ends)
+                        q1 -= 1u;
+                        arr = lv == 0 ? b3->l1 + (uint64_t)tile * b3->n_l1 : lv == 1 ? b3->l2 + (uint64_t)tile * b3->n_l2 : b3->l3 + (uint64_t)tile * b3->n_l3;
                     }
                 }
-                uint32_t mv = 0;
-                for (uint32_t i = q0 + lane; i <= q1; i += 64u) mv = max(mv, (uint32_t)arr[i]);
                 const uint32_t un = b3->under[(uint64_t)tile * nb + (P >> B3_BLOCK_SHIFT)];
 #pragma unroll
                 for (int o = 32; o > 0; o >>= 1) mv = max(mv, (uint32_t)__shfl_xor((int)mv, o));
                 const uint32_t M = (uint32_t)__builtin_amdgcn_readfirstlane((int)mv), U = (uint32_t)__builtin_amdgcn_readfirstlane((int)un);
                 const uint32_t hs3 = (info >> INFO_HS_SHIFT) & 0x7Fu, hr3 = (info >> INFO_HR_SHIFT) & 7u;
                 const uint32_t hu = M > U ? M - U : 0u;
-                if (STATS) n_b3[0]++;
+                const uint32_t jb = STATS ? min(7u, (uint32_t)max(0, 28 - (int)__builtin_clz(J | 1u))) : 0u;   // (J < 16, < 32, ... >= 1024)
+                if (STATS) { n_b3[0]++; if (lane == 0) atomicAdd((unsigned long long *)a.stats + 72 + jb, 1ull); }
                 if (M != 65535u && hu + hr3 < hs3) {
                     const uint32_t rec3 = (info & ~(0x7Fu << INFO_HS_SHIFT)) | ((hu + hr3) << INFO_HS_SHIFT);
                     if (all_far(dcur, bcur, rec3)) {
                         skip_to = p + 1u + J;
-                        if (STATS) { n_b3[1]++; n_skipped += J; count_jump(J, 0); }
+                        if (STATS) { n_b3[1]++; n_skipped += J; count_jump(J, 0); if (lane == 0) atomicAdd((unsigned long long *)a.stats + 80 + jb, 1ull); }
                     }
                 }
             }

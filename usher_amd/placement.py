@@ -102,7 +102,7 @@ class FlatTreeView:
            "site_ref": (6, np.uint8), "rank2bfs": (7, np.uint32), "dfs2bfs": (8, np.uint32),
            "stream8": (10, np.uint32), "pre8_stream": (11, np.uint32), "chunk8_body_off": (12, np.uint32),
            "chunk8_pre_off": (13, np.uint32), "stream_t": (15, np.uint32), "chunk_t_off": (16, np.uint32),
-           "b3_pair_off": (18, np.uint32), "b3_events": (19, np.uint32)}
+           "b3_group_off": (18, np.uint32), "b3_events": (19, np.uint32)}
 
     def __init__(self, arrays: Dict, chunk_nodes: int = 0):
         L = _lib.lib()
