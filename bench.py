@@ -587,6 +587,9 @@ def main():
                     "overlap": "off (--no-overlap: ugp_place_device, stream-ordered)" if args.no_overlap else "consecutive ugp_place_device_overlapped calls: %d on the device at a time (internal streams, workspace sets, output buffers)" % depth,
                     "node_plus_mut_evals_decided_per_s": round(node_evals / (k_ms * 1e-3), 1) if k_ms > 0 else 0.0,
                     "coarse_ms": round(coarse_ms / args.steps, 4), "table_ms": round(table_ms / args.steps, 4), "merge_ms": round(merge_ms / args.steps, 4),
+                    # exact third pruning bound: the handle decides per block of eight calls, by its own measured throughput, whether
+                    # to build its per-batch tables (UGP_BOUND3=0/1 pins it); table_ms includes them when it did
+                    "third_bound_steps": int(tm.get("bound3", 0)), "third_bound_steps_alone": int(tma.get("bound3", 0)) if tma else None,
                     # the two pruning counters exist only in the instrumented kernel variant (UGP_STATS=1)
                     "pruned_frac": (round(skipped / wtotal, 4) if wtotal else 0.0) if os.environ.get("UGP_STATS") else None,
                     "prune_skips": nskips if os.environ.get("UGP_STATS") else None}

@@ -117,7 +117,7 @@ typedef struct ugp_timing {
     uint64_t words_total;   /* packed path: stream words x tiles the dominant kernel had to cover      */
     uint64_t words_skipped; /* ... of which exact lower-bound pruning skipped (0 with UGP_NO_PRUNE)    */
     float coarse_ms;     /* locality pre-pass of the last call (placement on the coarse top-of-tree MAT), 0 when not run */
-    float reserved2;
+    uint32_t bound3;     /* 1: the last call's main walk used the third pruning bound (its per-batch tables were built); ugp_get_timing_sum: how many calls did */
 } ugp_timing;
 
 /* Optional: bring up the HIP runtime and the context of `device` now (what the first ugp_mat_create on that device would pay: a few

@@ -37,7 +37,7 @@ class ugp_info(C.Structure):
 class ugp_timing(C.Structure):
     _fields_ = [("table_ms", C.c_float), ("place_ms", C.c_float), ("merge_ms", C.c_float),
                 ("place_launches", C.c_uint32), ("n_tiles", C.c_uint32), ("n_groups", C.c_uint32), ("packed_path", C.c_uint32),
-                ("reserved", C.c_uint32), ("words_total", C.c_uint64), ("words_skipped", C.c_uint64), ("coarse_ms", C.c_float), ("reserved2", C.c_float)]
+                ("reserved", C.c_uint32), ("words_total", C.c_uint64), ("words_skipped", C.c_uint64), ("coarse_ms", C.c_float), ("bound3", C.c_uint32)]
 
 
 class ugp_place_opts(C.Structure):

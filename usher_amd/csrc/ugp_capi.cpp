@@ -13,6 +13,7 @@
 #include <new>
 #include <string>
 #include <thread>
+#include <mutex>
 #include <vector>
 
 #include "ugp_bound3.hpp"
@@ -148,6 +149,56 @@ int copy_d2h_staged(void *dst, const void *src, size_t bytes) {
 struct EventSet {
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     bool used = false;
+    // third pruning bound: was it a choice for this sub-batch (-1: no), which way it went, its place in the tuner's sequence
+    int b3_class = -1;
+    bool b3_used = false;
+    uint32_t b3_tiles = 0, b3_pos = 0;
+    uint64_t b3_seq = 0;
+};
+
+// The third pruning bound is exact either way; whether its per-batch tables (ugp_bound3.hip: ~8 us per 512-sample tile on a
+// 10M-node tree) cost less than they save the walk depends on the tree and on the queries (measured, round 5: +5 % on the
+// headline batches, +67 % on config 5's ambiguous ones, -12 % on a SARS-CoV-2-shaped tree).  So the handle measures what counts --
+// throughput: sub-batches of one class (by rows per sample) run in blocks of eight in the same mode; the time between the
+// completions (HIP events every call records anyway, read without waiting) of a block's last five sub-batches -- by then the device
+// holds only that block's work, however many calls overlap -- gives the block's milliseconds per tile.  The first two blocks run
+// one with, one without; after that the faster mode runs, and every 32nd block is one of the other mode to keep its figure fresh.
+// UGP_BOUND3=1 / 0 (or UGP_NO_BOUND3) pins the choice.  (First version: each sub-batch's own first-to-last-kernel time -- with
+// three calls in flight that mostly measures the neighbours, and the choice flipped at random.)
+struct B3Tuner {
+    static constexpr int kClasses = 3;
+    static constexpr uint32_t kBlock = 8, kSkip = 3, kProbe = 32;
+    double ema[kClasses][2] = {};
+    uint32_t n[kClasses][2] = {};
+    uint32_t blocks[kClasses] = {};
+    int cls = -1;              // the open block: class, mode, sub-batches issued
+    bool mode = true;
+    uint32_t issued = 0;
+    uint64_t seq = 0;          // sub-batches issued in all
+    uint64_t next_seq = 0;     // completion side: the next one to account for, the completion event of the one before it
+    hipEvent_t prev_done = nullptr;
+    double acc = 0;
+    uint32_t acc_n = 0;
+    static int class_of(uint64_t rows, uint64_t samples) { const uint64_t r = samples ? rows / samples : 0; return r < 32 ? 0 : r < 256 ? 1 : 2; }
+    // issue side: mode and position of the next sub-batch of class c
+    bool next(int c, uint32_t *pos, uint64_t *sq) {
+        if (c != cls || issued == kBlock) {
+            cls = c; issued = 0;
+            const uint32_t k = blocks[c]++;
+            if (k < 2) mode = k == 0;                       // (one block each way first)
+            else if (!n[c][0] || !n[c][1]) mode = true;     // (their figures still on the way)
+            else { const bool best = ema[c][1] <= ema[c][0]; mode = (k % kProbe) == kProbe - 1 ? !best : best; }
+        }
+        *pos = issued++; *sq = seq++;
+        return mode;
+    }
+    void record(int c, bool used, double ms_per_tile) {
+        double &e = ema[c][used ? 1 : 0];
+        uint32_t &k = n[c][used ? 1 : 0];
+        e = k ? e + (ms_per_tile - e) * (k < 4 ? 1.0 / (k + 1) : 0.25) : ms_per_tile;   // (plain mean of the first four blocks, then a moving average)
+        k++;
+    }
+    void resync(uint64_t past) { next_seq = std::max(next_seq, past); prev_done = nullptr; acc = 0; acc_n = 0; }
 };
 
 constexpr uint32_t kMaxTilesPerLaunch = 4096;   // 262,144 samples per sub-batch
@@ -234,6 +285,7 @@ struct ugp_mat {
     ugp_timing tsum = {};    // durations of all calls since the last ugp_get_timing_sum
     uint32_t tsum_calls = 0;
     int last_work = 0;       // set used by the most recent call (ugp_get_timing reports it)
+    B3Tuner b3_tuner;        // third pruning bound: with or without, by measurement
     int next_work = 0;       // set the next ugp_place_device_overlapped call takes (cycles through knobs.depth sets)
     int next_job = 0;        // set the next ugp_place_batch_async job takes (sets 0 .. pipeline depth - 1)
     uint64_t n_overlapped = 0;                  // calls of ugp_place_device_overlapped so far
@@ -313,6 +365,7 @@ int validate_offsets(const ugp_queries *q, uint64_t &n_ent, uint64_t &max_rows) 
 
 }  // namespace
 static int harvest_timing(ugp_mat *m, ugp_mat::Work &W, ugp_mat::Work::Gen &G);
+static void tuner_poll(ugp_mat *m);
 namespace {
 int ensure_events(ugp_mat::Work::Gen &G, size_t n) {
     while (G.events.size() < n) {
@@ -420,7 +473,12 @@ int run_place(ugp_mat *m, ugp_qset *qs, int mode, ugp_result *d_out, int32_t *d_
         // Third pruning bound (round 5): for the sorted main walk of batches of up to 256 tiles, when the tree carries its posting lists
         // and the tiles are built by the scatter kernels (they mark the tile's useful (site, allele) pairs)
         const uint32_t useful_words = (n_sites + 7) / 8;
-        const bool b3_want = use8 && !coarse_only && sorted && m->d_b3_events.p && !K.no_bound3 && !K.no_prune && n_tiles512 <= 256 && K.tile_build <= 0;
+        const bool b3_can = use8 && !coarse_only && sorted && m->d_b3_events.p && !K.no_bound3 && K.bound3 != 0 && !K.no_prune && n_tiles512 <= 256 && K.tile_build <= 0;
+        bool b3_want = b3_can;
+        const int b3_class = B3Tuner::class_of(qs->ent_off[q0 + nq] - qs->ent_off[q0], nq);
+        uint32_t b3_pos = 0;
+        uint64_t b3_seq = 0;
+        if (b3_can && K.bound3 < 0) { tuner_poll(m); b3_want = m->b3_tuner.next(b3_class, &b3_pos, &b3_seq); }
         const size_t z_dbottom = 0, z_active = z_dbottom + (size_t)n_tiles512 * 512, z_queue = z_active + (size_t)n_tiles512 * active_words,
                      z_list_n = z_queue + 8, z_nitems = z_list_n + n_tiles512, z_cnt = z_nitems + 8, z_key = z_cnt + (size_t)n_tiles512 * 512,
                      z_useful = z_key + (size_t)n_tiles512 * 512, z_end = z_useful + (b3_want ? (size_t)n_tiles512 * useful_words : 0);
@@ -445,6 +503,7 @@ int run_place(ugp_mat *m, ugp_qset *qs, int mode, ugp_result *d_out, int32_t *d_
         }
         if (int rc = ensure_events(TG, TG.events_used + 1)) return rc;
         EventSet &es = TG.events[TG.events_used++];
+        es.b3_class = (b3_can && K.bound3 < 0) ? b3_class : -1; es.b3_used = b3_want; es.b3_tiles = n_tiles512; es.b3_pos = b3_pos; es.b3_seq = b3_seq;
         const uint64_t e0 = qs->ent_off[q0], e1 = qs->ent_off[q0 + nq];
 
         HIP_TRY(hipEventRecord(es.ev[0], s));
@@ -696,6 +755,7 @@ int run_place(ugp_mat *m, ugp_qset *qs, int mode, ugp_result *d_out, int32_t *d_
             if (K.lds_bits >= 0) b.lds_bits = b.stats ? 0u : (K.lds_bits == 2 ? 2u : (((size_t)active_words * 4 <= 4096 && K.lds_bits != 0) ? 1u : 0u));
             const size_t lds_bytes = (size_t)b.lds_slots * 64 * 16 + (b.lds_bits == 1 ? (((size_t)active_words * 4 + 15) & ~(size_t)15) : 0);
             b.b3 = (b3_on && b.ub && b.lds_bits != 1) ? W.d_b3_dev.p : nullptr;
+            if (b.b3) TG.last.bound3 = 1;
             const int variant = coarse_only ? (b.lds_bits == 2 ? 4 : 2) : (b.b3 ? (b.lds_bits == 2 ? 6 : 5) : (b.lds_bits == 2 ? 3 : (b.lds_bits ? 1 : 0)));   // (the kernel launch_best8 will pick)
             if (m->occ_lds != lds_bytes || m->occ_variant != variant) {
                 HIP_TRY(hipDeviceGetAttribute(&m->n_cu, hipDeviceAttributeMultiprocessorCount, m->device));
@@ -1138,6 +1198,11 @@ int ugp_mat_create_from_flat(const char *path, int device, ugp_mat **out) {
 void ugp_mat_destroy(ugp_mat *m) {
     if (!m) return;
     (void)hipSetDevice(m->device);
+    if (m->knobs.stats || getenv("UGP_BOUND3_VERBOSE"))
+        for (int c = 0; c < B3Tuner::kClasses; c++)
+            if (m->b3_tuner.blocks[c])
+                fprintf(stderr, "[ugp stats] third bound, batches of class %d: %u blocks; ms per tile with %.5f (%u blocks measured), without %.5f (%u)\n", c, m->b3_tuner.blocks[c],
+                        m->b3_tuner.ema[c][1], m->b3_tuner.n[c][1], m->b3_tuner.ema[c][0], m->b3_tuner.n[c][0]);
     for (auto &W : m->work) {
         if (W.stream) { (void)hipStreamSynchronize(W.stream); (void)hipStreamDestroy(W.stream); }
         if (W.done) { (void)hipEventSynchronize(W.done); (void)hipEventDestroy(W.done); }
@@ -2076,6 +2141,42 @@ int ugp_touched_fetch(ugp_mat *m, uint64_t first_sample, uint64_t n, uint32_t ca
     return UGP_OK;
 }
 
+// third pruning bound: the sub-batches that have completed by now, in the order they were issued, go to the handle's tuner (no
+// waiting: calls on a handle come from one thread)
+static void tuner_poll(ugp_mat *m) {
+    B3Tuner &T = m->b3_tuner;
+    for (;;) {
+        EventSet *hit = nullptr;
+        for (auto &W : m->work)
+            for (auto &G : W.gens)
+                if (G.timing_pending)
+                    for (size_t i = 0; i < G.events_used; i++)
+                        if (G.events[i].b3_class >= 0 && G.events[i].b3_seq == T.next_seq) hit = &G.events[i];
+        if (!hit && T.seq > T.next_seq + 16) { T.resync(T.next_seq + 1); continue; }   // (a call that failed half way left a hole)
+        if (!hit || hipEventQuery(hit->ev[3]) != hipSuccess) break;
+        if (hit->b3_pos == 0) { T.acc = 0; T.acc_n = 0; }
+        float gap = 0;
+        if (T.prev_done && hit->b3_pos >= B3Tuner::kSkip && hit->b3_tiles && hipEventElapsedTime(&gap, T.prev_done, hit->ev[3]) == hipSuccess && gap > 0) {
+            T.acc += (double)gap / hit->b3_tiles; T.acc_n++;
+        }
+        if (hit->b3_pos == B3Tuner::kBlock - 1 && T.acc_n) T.record(hit->b3_class, hit->b3_used, T.acc / T.acc_n);
+        T.prev_done = hit->ev[3];
+        T.next_seq++;
+        hit->b3_class = -1;
+    }
+    (void)hipGetLastError();   // (hipErrorNotReady of a query is not an error of the call)
+}
+// ... before a ring entry's events are recorded again: whatever of it the tuner has not seen is dropped
+static void tuner_release(ugp_mat *m, ugp_mat::Work::Gen &G) {
+    tuner_poll(m);
+    B3Tuner &T = m->b3_tuner;
+    for (size_t i = 0; i < G.events_used; i++) {
+        EventSet &es = G.events[i];
+        if (es.b3_class >= 0) { T.resync(es.b3_seq + 1); es.b3_class = -1; }
+        if (T.prev_done == es.ev[3]) T.prev_done = nullptr;
+    }
+}
+
 // Durations of the set's last call from its HIP events (waits for that call), added to the handle's running totals.
 static int harvest_timing(ugp_mat *m, ugp_mat::Work &W, ugp_mat::Work::Gen &G) {
     if (G.timing_pending) {
@@ -2142,8 +2243,9 @@ static int harvest_timing(ugp_mat *m, ugp_mat::Work &W, ugp_mat::Work::Gen &G) {
             }
         }
         m->tsum.table_ms += G.last.table_ms; m->tsum.place_ms += G.last.place_ms; m->tsum.merge_ms += G.last.merge_ms;
-        m->tsum.coarse_ms += G.last.coarse_ms; m->tsum.place_launches += G.last.place_launches;
+        m->tsum.coarse_ms += G.last.coarse_ms; m->tsum.place_launches += G.last.place_launches; m->tsum.bound3 += G.last.bound3;
         m->tsum_calls++;
+        tuner_release(m, G);
         G.timing_pending = false;
     }
     return UGP_OK;
@@ -2182,6 +2284,7 @@ int ugp_get_timing_sum(ugp_mat *m, ugp_timing *sum, uint32_t *n_calls) {
     *sum = l;
     sum->table_ms = m->tsum.table_ms; sum->place_ms = m->tsum.place_ms; sum->merge_ms = m->tsum.merge_ms; sum->coarse_ms = m->tsum.coarse_ms;
     sum->place_launches = m->tsum.place_launches;
+    sum->bound3 = m->tsum.bound3;   // (calls that used the third bound)
     *n_calls = m->tsum_calls;
     m->tsum = {};
     m->tsum_calls = 0;
