@@ -172,8 +172,8 @@ def test_usher_cli_add_mode_on_the_device_equals_the_restated_driver_loop(seed, 
         if mode == "device":
             line = [l for l in r.stderr.splitlines() if "add mode on the device" in l]
             assert line and "tree -> arrays" in r.stderr
-            flat = [l for l in r.stderr.splitlines() if "tree -> arrays" in l][0]
-            assert "(1 times)" in flat, flat                                       # one flattening for the whole run
+            flat = [l for l in r.stderr.splitlines() if "tree -> arrays" in l and "times)" in l][0]
+            assert "(1 times)" in flat, flat                                       # one flattening for the whole run (made under the VCF read and taken over, or the loop's own)
     assert outs["device"] == outs["research"]
     T = refio.load_mutation_annotated_tree(pb)
     want = usher_model.run(T, refio.read_vcf(T, new))
@@ -211,7 +211,7 @@ def test_add_mode_at_one_million_nodes_device_equals_research_and_the_oracle_on_
         return r.stderr
 
     err = run(vcf, str(tmp_path / "device"), {"USHER_AMD_PROFILE": "1"})
-    flat = [l for l in err.splitlines() if "tree -> arrays" in l]
+    flat = [l for l in err.splitlines() if "tree -> arrays" in l and "times)" in l]
     assert flat and "(1 times)" in flat[0], err[-2000:]                       # one flattening for the whole run: the device mode ran
     run(vcf, str(tmp_path / "research"), {"USHER_AMD_MAX_TOUCHED": "0"})
     files = ("placement_stats.tsv", "final-tree.nh")
