@@ -40,7 +40,7 @@ def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=30)   # (covers the handle's own trial of the third pruning bound: four blocks of six calls)
     ap.add_argument("--nodes", type=int, default=10_000_000)
     ap.add_argument("--sites", type=int, default=0, help="variable sites (default 25000 at >=1M nodes, else 1500)")
     ap.add_argument("--queries", type=int, default=16384, help="query samples per GPU per step (total samples with --strong)")
@@ -587,7 +587,7 @@ def main():
                     "overlap": "off (--no-overlap: ugp_place_device, stream-ordered)" if args.no_overlap else "consecutive ugp_place_device_overlapped calls: %d on the device at a time (internal streams, workspace sets, output buffers)" % depth,
                     "node_plus_mut_evals_decided_per_s": round(node_evals / (k_ms * 1e-3), 1) if k_ms > 0 else 0.0,
                     "coarse_ms": round(coarse_ms / args.steps, 4), "table_ms": round(table_ms / args.steps, 4), "merge_ms": round(merge_ms / args.steps, 4),
-                    # exact third pruning bound: the handle decides per block of eight calls, by its own measured throughput, whether
+                    # exact third pruning bound: the handle decides per block of six calls, by its own measured throughput, whether
                     # to build its per-batch tables (UGP_BOUND3=0/1 pins it); table_ms includes them when it did
                     "third_bound_steps": int(tm.get("bound3", 0)), "third_bound_steps_alone": int(tma.get("bound3", 0)) if tma else None,
                     # the two pruning counters exist only in the instrumented kernel variant (UGP_STATS=1)

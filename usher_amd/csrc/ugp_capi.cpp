@@ -153,26 +153,28 @@ struct EventSet {
     int b3_class = -1;
     bool b3_used = false;
     uint32_t b3_tiles = 0, b3_pos = 0;
+    bool b3_first = false;   // (of the class's very first block: not counted)
     uint64_t b3_seq = 0;
 };
 
 // The third pruning bound is exact either way; whether its per-batch tables (ugp_bound3.hip: ~8 us per 512-sample tile on a
 // 10M-node tree) cost less than they save the walk depends on the tree and on the queries (measured, round 5: +5 % on the
 // headline batches, +67 % on config 5's ambiguous ones, -12 % on a SARS-CoV-2-shaped tree).  So the handle measures what counts --
-// throughput: sub-batches of one class (by rows per sample) run in blocks of eight in the same mode; the time between the
-// completions (HIP events every call records anyway, read without waiting) of a block's last five sub-batches -- by then the device
-// holds only that block's work, however many calls overlap -- gives the block's milliseconds per tile.  The first two blocks run
-// one with, one without; after that the faster mode runs, and every 32nd block is one of the other mode to keep its figure fresh.
+// throughput: sub-batches of one class (by rows per sample) run in blocks of six in the same mode; the time between the
+// completions (HIP events every call records anyway, read without waiting) of a block's last four sub-batches -- by then the device
+// holds only that block's work, however many calls overlap -- gives the block's milliseconds per tile.  The first four blocks
+// alternate with / without; after that the faster mode runs, and every 16th block (64th when the two differ by a quarter) is one of
+// the other mode to keep its figure fresh.
 // UGP_BOUND3=1 / 0 (or UGP_NO_BOUND3) pins the choice.  (First version: each sub-batch's own first-to-last-kernel time -- with
 // three calls in flight that mostly measures the neighbours, and the choice flipped at random.)
 struct B3Tuner {
     static constexpr int kClasses = 3;
-    static constexpr uint32_t kBlock = 8, kSkip = 3, kProbe = 32;
+    static constexpr uint32_t kBlock = 6, kSkip = 2;
     double ema[kClasses][2] = {};
     uint32_t n[kClasses][2] = {};
     uint32_t blocks[kClasses] = {};
     int cls = -1;              // the open block: class, mode, sub-batches issued
-    bool mode = true;
+    bool mode = true, first = false;
     uint32_t issued = 0;
     uint64_t seq = 0;          // sub-batches issued in all
     uint64_t next_seq = 0;     // completion side: the next one to account for, the completion event of the one before it
@@ -185,9 +187,15 @@ struct B3Tuner {
         if (c != cls || issued == kBlock) {
             cls = c; issued = 0;
             const uint32_t k = blocks[c]++;
-            if (k < 2) mode = k == 0;                       // (one block each way first)
+            first = k == 0;
+            if (k < 4) mode = (k & 1u) == 0;                // (with, without, with, without; the very first block -- allocations, cold caches -- is not counted)
             else if (!n[c][0] || !n[c][1]) mode = true;     // (their figures still on the way)
-            else { const bool best = ema[c][1] <= ema[c][0]; mode = (k % kProbe) == kProbe - 1 ? !best : best; }
+            else {
+                const double a = ema[c][1], b = ema[c][0];
+                const bool best = a <= b;
+                const uint32_t probe = std::max(a, b) > 1.25 * std::min(a, b) ? 64u : 16u;   // (a clear case is looked at again less often)
+                mode = (k % probe) == probe - 1 ? !best : best;
+            }
         }
         *pos = issued++; *sq = seq++;
         return mode;
@@ -503,7 +511,7 @@ int run_place(ugp_mat *m, ugp_qset *qs, int mode, ugp_result *d_out, int32_t *d_
         }
         if (int rc = ensure_events(TG, TG.events_used + 1)) return rc;
         EventSet &es = TG.events[TG.events_used++];
-        es.b3_class = (b3_can && K.bound3 < 0) ? b3_class : -1; es.b3_used = b3_want; es.b3_tiles = n_tiles512; es.b3_pos = b3_pos; es.b3_seq = b3_seq;
+        es.b3_class = (b3_can && K.bound3 < 0) ? b3_class : -1; es.b3_used = b3_want; es.b3_tiles = n_tiles512; es.b3_pos = b3_pos; es.b3_seq = b3_seq; es.b3_first = m->b3_tuner.first;
         const uint64_t e0 = qs->ent_off[q0], e1 = qs->ent_off[q0 + nq];
 
         HIP_TRY(hipEventRecord(es.ev[0], s));
@@ -2159,7 +2167,7 @@ static void tuner_poll(ugp_mat *m) {
         if (T.prev_done && hit->b3_pos >= B3Tuner::kSkip && hit->b3_tiles && hipEventElapsedTime(&gap, T.prev_done, hit->ev[3]) == hipSuccess && gap > 0) {
             T.acc += (double)gap / hit->b3_tiles; T.acc_n++;
         }
-        if (hit->b3_pos == B3Tuner::kBlock - 1 && T.acc_n) T.record(hit->b3_class, hit->b3_used, T.acc / T.acc_n);
+        if (hit->b3_pos == B3Tuner::kBlock - 1 && T.acc_n && !hit->b3_first) T.record(hit->b3_class, hit->b3_used, T.acc / T.acc_n);
         T.prev_done = hit->ev[3];
         T.next_seq++;
         hit->b3_class = -1;
