@@ -120,7 +120,8 @@ def stored_profile(info, Q, packed):
                 ps = json.load(f)
             cfg = ps.get("bench", {}).get("config", {})
             want = "ugp::k_best8" if packed else "ugp::k_place<0>"
-            k = next((v for n, v in ps.get("kernels", {}).items() if n.startswith(want)), {})
+            # (two instantiations of the walk run per step -- coarse pass and main walk: the main walk is the one that moves more bytes)
+            k = max((v for n, v in ps.get("kernels", {}).items() if n.startswith(want)), key=lambda v: v.get("hbm_read_bytes_per_dispatch_corrected", 0.0), default={})
             if cfg.get("nodes") == int(info["n_nodes"]) and cfg.get("queries_per_gpu") == Q and "hbm_read_bytes_per_dispatch_corrected" in k:
                 # bytes of ALL kernels of one step: a kernel that runs n times per call has n x the dispatches of k_final (once per call);
                 # kernels with fewer dispatches than calls (row checks at upload, host-buffer copies) are not part of a device-resident step
