@@ -660,7 +660,7 @@ int flatten(const ugp_tree_desc &t, const Options &opt, FlatMat &out, std::strin
     // ---- third pruning bound (round 5; ugp_flatten.hpp "B3"): posting lists of the mutation events by (site, mutated allele).
     // An event = one mutation word of the packed body; it raises, for every node of its node's subtree (the node included), the
     // number of mutations of that (site, allele) on the root path -- i.e. over the word range [header of the node, end of its
-    // descendants), here as a range of blocks of B3_BLOCK_WORDS words.  Filled in depth-first order on one thread (deterministic).
+    // descendants), here as a range of blocks of B3_BLOCK_WORDS words.  Listed in depth-first order (deterministic).
     out.b3_group_off.clear(); out.b3_events.clear();
     if (opt.keep_b3_events && out.n_sites && total8 > 0 && total8 < (1ull << 32) - 2 * B3_GROUP_BLOCKS * B3_BLOCK_WORDS) {
         const uint32_t ng = b3_blocks(total8) >> B3_GROUP_SHIFT;
@@ -668,34 +668,49 @@ int flatten(const ugp_tree_desc &t, const Options &opt, FlatMat &out, std::strin
         uint32_t *off[3] = {out.b3_group_off.data(), out.b3_group_off.data() + (ng + 1), out.b3_group_off.data() + 2 * (size_t)(ng + 1)};
         const uint32_t *s8 = out.stream8.data();
         auto range_of = [&](uint64_t d, uint32_t j, uint32_t &b0, uint32_t &b1) { b0 = pos8_hdr[d] >> B3_BLOCK_SHIFT; b1 = (pos8_at[d + sub[j]] - 1u) >> B3_BLOCK_SHIFT; };
-        for (uint64_t d = 0; d < N; d++) {
-            const uint32_t j = d2b[d];
-            if (dropped[j] || !nw[j]) continue;
-            uint32_t b0, b1; range_of(d, j, b0, b1);
-            if (b0 == b1) off[0][(b0 >> B3_GROUP_SHIFT) + 1] += nw[j];
-            else { off[1][(b0 >> B3_GROUP_SHIFT) + 1] += nw[j]; off[2][(b1 >> B3_GROUP_SHIFT) + 1] += nw[j]; }
-        }
+        // Each thread owns one run of consecutive depth-first indices (Par::run's static split, the same in both sweeps): it counts
+        // its events per (list, group), the counts become cursors (groups in order, within a group the threads in order: the lists come
+        // out in depth-first order whatever the number of threads), then it writes its events at its cursors.
+        std::vector<std::vector<uint32_t>> cur(T);
+        par.run(N, [&](uint64_t b, uint64_t e, unsigned tid) {
+            std::vector<uint32_t> &c = cur[tid];
+            c.assign((size_t)3 * ng, 0);
+            for (uint64_t d = b; d < e; d++) {
+                const uint32_t j = d2b[d];
+                if (dropped[j] || !nw[j]) continue;
+                uint32_t b0, b1; range_of(d, j, b0, b1);
+                if (b0 == b1) c[b0 >> B3_GROUP_SHIFT] += nw[j];
+                else { c[(size_t)ng + (b0 >> B3_GROUP_SHIFT)] += nw[j]; c[(size_t)2 * ng + (b1 >> B3_GROUP_SHIFT)] += nw[j]; }
+            }
+        }, 1u << 16);
         uint32_t run = 0;
         for (int k = 0; k < 3; k++) {   // (the three lists one behind the other)
-            for (uint32_t g = 0; g <= ng; g++) { run += off[k][g]; off[k][g] = run; }
+            for (uint32_t g = 0; g < ng; g++) {
+                off[k][g] = run;
+                for (unsigned t2 = 0; t2 < T; t2++)
+                    if (!cur[t2].empty()) { uint32_t &c = cur[t2][(size_t)k * ng + g]; const uint32_t n = c; c = run; run += n; }
+            }
+            off[k][ng] = run;
         }
         out.b3_events.resize(run);
-        std::vector<uint32_t> fill[3];
-        for (int k = 0; k < 3; k++) fill[k].assign(off[k], off[k] + ng);
-        for (uint64_t d = 0; d < N; d++) {
-            const uint32_t j = d2b[d];
-            if (dropped[j] || !nw[j]) continue;
-            uint32_t b0, b1; range_of(d, j, b0, b1);
-            for (uint32_t k = 0; k < nw[j]; k++) {
-                const uint32_t w = s8[pos8_hdr[d] + 1u + k];
-                const uint32_t pair = (w & 0x3FFFFFu) * 4u + ((w >> 22) & 3u);
-                if (b0 == b1) out.b3_events[fill[0][b0 >> B3_GROUP_SHIFT]++] = pair | ((b0 & (B3_GROUP_BLOCKS - 1u)) << 24);
-                else {
-                    out.b3_events[fill[1][b0 >> B3_GROUP_SHIFT]++] = pair | ((b0 & (B3_GROUP_BLOCKS - 1u)) << 24);
-                    out.b3_events[fill[2][b1 >> B3_GROUP_SHIFT]++] = pair | ((b1 & (B3_GROUP_BLOCKS - 1u)) << 24);
+        uint32_t *ev = out.b3_events.data();
+        par.run(N, [&](uint64_t b, uint64_t e, unsigned tid) {
+            uint32_t *c = cur[tid].data();
+            for (uint64_t d = b; d < e; d++) {
+                const uint32_t j = d2b[d];
+                if (dropped[j] || !nw[j]) continue;
+                uint32_t b0, b1; range_of(d, j, b0, b1);
+                for (uint32_t k = 0; k < nw[j]; k++) {
+                    const uint32_t w = s8[pos8_hdr[d] + 1u + k];
+                    const uint32_t pair = (w & 0x3FFFFFu) * 4u + ((w >> 22) & 3u);
+                    if (b0 == b1) ev[c[b0 >> B3_GROUP_SHIFT]++] = pair | ((b0 & (B3_GROUP_BLOCKS - 1u)) << 24);
+                    else {
+                        ev[c[(size_t)ng + (b0 >> B3_GROUP_SHIFT)]++] = pair | ((b0 & (B3_GROUP_BLOCKS - 1u)) << 24);
+                        ev[c[(size_t)2 * ng + (b1 >> B3_GROUP_SHIFT)]++] = pair | ((b1 & (B3_GROUP_BLOCKS - 1u)) << 24);
+                    }
                 }
             }
-        }
+        }, 1u << 16);
         flat_lap("third bound: event lists");
     }
 
