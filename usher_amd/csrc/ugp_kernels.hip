@@ -1953,9 +1953,9 @@ __global__ void __launch_bounds__(64) k_ties(PlaceArgs a, const uint32_t *__rest
     // (tile, chunk) record next to each other, and they read the same stream windows and 32-byte pieces of the same 256-byte table
     // rows.  So the blocks of one XCD share a contiguous eighth of the list (round 5; before: item i on XCD i mod 8, nothing shared,
     // 8.6 % L2 hits and 437 MB from HBM per launch).
-    const uint32_t xcd = blockIdx.x & 7u, seg = (n + 7u) / 8u, on_xcd = (gridDim.x - xcd + 7u) / 8u;
+    const uint32_t nx = min(8u, gridDim.x), xcd = blockIdx.x % nx, seg = (n + nx - 1u) / nx, on_xcd = (gridDim.x - xcd + nx - 1u) / nx;
     const uint32_t it_end = min(n, (xcd + 1u) * seg);
-    for (uint32_t it = xcd * seg + (blockIdx.x >> 3); it < it_end; it += on_xcd) {
+    for (uint32_t it = xcd * seg + blockIdx.x / nx; it < it_end; it += on_xcd) {
         const uint32_t item = items[it];
         const uint32_t c = item / n_t64, t64 = item % n_t64;
         const uint32_t q = t64 * 64 + lane;
