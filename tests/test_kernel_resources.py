@@ -30,4 +30,6 @@ def test_the_walk_kernels_do_not_spill(tmp_path):
         assert v.get("ScratchSize", 0) == 0, (name, v)
         assert v.get("VGPRs Spill", 0) == 0, (name, v)
         assert v.get("VGPRs", 0) <= 128 and v.get("Occupancy", 4) >= 4, (name, v)     # four waves per SIMD: the grid and the LDS budget assume it
-        assert v.get("SGPRs Spill", 0) <= 64, (name, v)                                # (parked kernel arguments and unit-start values: outside the pipelined loop)
+        # (parked kernel arguments and unit-start values: outside the pipelined loop; the third-bound variants -- last template
+        # argument true -- park a few more around the question they ask in the restart path)
+        assert v.get("SGPRs Spill", 0) <= (80 if name.endswith("Lb1EEEvNS_9Best8ArgsE") else 64), (name, v)

@@ -1155,6 +1155,7 @@ __global__ void __launch_bounds__(64, TIES ? 3 : 4) k_best8(Best8Args a) {
     uint32_t sinfo = 0;        // uniform
     uint32_t info = 0;         // uniform: pending pruning record
     uint32_t skip_to = 0;      // uniform: restart request (0 = none)
+    uint32_t pre_off = 0xFFFFFFFFu, pre_w0 = 0, pre_w1 = 0, pre_w2 = 0;   // (B3) the first three word groups of the next refill, loaded beside a third-bound question
     uint32_t cend = 0xFFFFFFFFu;   // uniform: position of the open chunk's end marker (phase 1)
     bool cend_stale = false;       // uniform: `chunk` advanced inside the pipeline and the end word did not say where the next chunk ends
     uint32_t t_mark = (uint32_t)__builtin_amdgcn_s_memtime();   // uniform: start of the unit / its last look at the shared list (low word: differences only)
@@ -1571,6 +1572,7 @@ __global__ void __launch_bounds__(64, TIES ? 3 : 4) k_best8(Best8Args a) {
             return node_end(pos, -1, nullptr);
         };
         uint32_t off = 0;
+        if (B3) pre_off = 0xFFFFFFFFu;   // (words asked for in another unit or phase are not this one's)
         if (phase == 1 && body_start) {   // the replay ended at a path node whose subtree is not needed: close the chunks in front of its end
             off = min(body_start, n);
             cend = close_empty_chunks(off, begin);   // (nothing has been walked yet: no chunk in front of `off` holds a candidate)
@@ -1579,7 +1581,10 @@ __global__ void __launch_bounds__(64, TIES ? 3 : 4) k_best8(Best8Args a) {
         while (off < lim) {
             // (re)fill the pipeline at `off`
             const uint64_t t_r0 = STATS ? __builtin_amdgcn_s_memtime() : 0;
-            uint32_t w0 = load_words(off), w1 = load_words(off + GRP), w2 = load_words(off + 2 * GRP);
+            uint32_t w0, w1, w2;
+            if (B3 && pre_off == off) { w0 = pre_w0; w1 = pre_w1; w2 = pre_w2; }   // (already here: asked for beside the third bound's table loads)
+            else { w0 = load_words(off); w1 = load_words(off + GRP); w2 = load_words(off + 2 * GRP); }
+            if (B3) pre_off = 0xFFFFFFFFu;
             // (the decoded row offsets of the NEXT group, o1, are carried around the loop rather than its active-row bits: the
             // decode then sits at the bottom of an iteration, behind the loads it depends on and in front of nothing -- at the
             // top of the next one the compiler's wait for those bits was a wait for every load in flight, rows included)
@@ -1652,6 +1657,10 @@ __global__ void __launch_bounds__(64, TIES ? 3 : 4) k_best8(Best8Args a) {
                 const B3Dev *b3 = a.b3;
                 uint32_t q0 = (P + 1u) >> B3_BLOCK_SHIFT, q1 = (P + J) >> B3_BLOCK_SHIFT;
                 const uint32_t nb = b3->n_blocks;
+                // The refill's first round trip -- the stream words -- does not wait for the answer: both places it can start from are
+                // requested now, beside the table loads (a question then costs three round trips, like any restart, not four).
+                const uint32_t sa0 = load_words(p + 1u), sa1 = load_words(p + 1u + GRP), sa2 = load_words(p + 1u + 2 * GRP);
+                const uint32_t sb0 = load_words(p + 1u + J), sb1 = load_words(p + 1u + J + GRP), sb2 = load_words(p + 1u + J + 2 * GRP);
                 // exact maximum over [q0, q1]: at each level the (up to 63) entries left and right of the whole 64-groups, the groups
                 // themselves one level up -- at most seven loads per lane, all in flight together
                 uint32_t mv = 0;
@@ -1677,10 +1686,12 @@ __global__ void __launch_bounds__(64, TIES ? 3 : 4) k_best8(Best8Args a) {
                 const uint32_t hu = M > U ? M - U : 0u;
                 const uint32_t jb = STATS ? min(7u, (uint32_t)max(0, 28 - (int)__builtin_clz(J | 1u))) : 0u;   // (J < 16, < 32, ... >= 1024)
                 if (STATS) { n_b3[0]++; if (lane == 0) atomicAdd((unsigned long long *)a.stats + 72 + jb, 1ull); }
+                pre_off = p + 1u; pre_w0 = sa0; pre_w1 = sa1; pre_w2 = sa2;
                 if (M != 65535u && hu + hr3 < hs3) {
                     const uint32_t rec3 = (info & ~(0x7Fu << INFO_HS_SHIFT)) | ((hu + hr3) << INFO_HS_SHIFT);
                     if (all_far(dcur, bcur, rec3)) {
                         skip_to = p + 1u + J;
+                        pre_off = skip_to; pre_w0 = sb0; pre_w1 = sb1; pre_w2 = sb2;
                         if (STATS) { n_b3[1]++; n_skipped += J; count_jump(J, 0); if (lane == 0) atomicAdd((unsigned long long *)a.stats + 80 + jb, 1ull); }
                     }
                 }
