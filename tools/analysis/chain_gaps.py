@@ -4,6 +4,7 @@ of one hardware queue between two consecutive main walks, each with its duration
 queue ended -- where a step's dependent chain spends its time (kernels vs launch gaps).
     python tools/analysis/chain_gaps.py gpurun_out/<dir>/p_kernel_trace.csv"""
 import csv
+import re
 import sys
 from collections import defaultdict
 
@@ -14,7 +15,8 @@ for r in rows:
     by_q[r[qkey] if qkey else "0"].append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"].split("(")[0].replace("void ", "")[-60:]))
 for q, ev in sorted(by_q.items(), key=lambda kv: -len(kv[1]))[:2]:
     ev.sort()
-    walks = [i for i, (s, e, n) in enumerate(ev) if "k_best8<false, false, false, false>" in n and e - s > 500_000]
+    # the main walk: k_best8<STATS = false, LBITS, ARG = false, TIES = false[, B3]> (the coarse pass is the ARG variant)
+    walks = [i for i, (s, e, n) in enumerate(ev) if re.search(r"k_best8<false, \w+, false, false(, \w+)?>", n) and e - s > 500_000]
     if len(walks) < 6:
         continue
     # from the end of one main walk to the end of the next: one batch -- a pair inside the pipelined window (the trace also holds the

@@ -4,13 +4,14 @@
 running, and the summed duration per kernel per step.
     python tools/analysis/pipeline_timeline.py gpurun_out/<dir>/p_kernel_trace.csv [steps]"""
 import csv
+import re
 import sys
 from collections import defaultdict
 
 rows = list(csv.DictReader(open(sys.argv[1])))
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 20
 ev = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]) for r in rows)
-walks = [(s, e) for s, e, n in ev if "k_best8" in n and "Lb1EEE" not in n.replace(" ", "") and e - s > 600_000 or ("k_best8<false, false, false>" in n and e - s > 600_000)]
+walks = [(s, e) for s, e, n in ev if re.search(r"k_best8<false, \w+, false, false(, \w+)?>", n) and e - s > 600_000]   # main walks (not the coarse pass: ARG)
 # the timed loop: the longest run of main walks that start less than 3 ms apart
 best = (0, 0)
 i = 0
