@@ -1962,8 +1962,9 @@ __global__ void __launch_bounds__(64) k_ties(PlaceArgs a, const uint32_t *__rest
     const uint32_t n = min(*n_items, cap);
     // Blocks go round robin over the eight XCDs, each with its own L2; k_select appends the (up to eight) 64-sample sub-tiles of one
     // (tile, chunk) record next to each other, and they read the same stream windows and 32-byte pieces of the same 256-byte table
-    // rows.  So the blocks of one XCD share a contiguous eighth of the list (round 5; before: item i on XCD i mod 8, nothing shared,
-    // 8.6 % L2 hits and 437 MB from HBM per launch).
+    // rows.  So the blocks of one XCD share a contiguous eighth of the list (round 5; before: item i on XCD i mod 8).  Measured: next
+    // to nothing -- 437 -> 426 MB from HBM per launch, L2 hits 8.6 -> 10.7 %: few records have relevant samples in more than one
+    // sub-tile, so neighbouring items mostly name different chunks.
     const uint32_t nx = min(8u, gridDim.x), xcd = blockIdx.x % nx, seg = (n + nx - 1u) / nx, on_xcd = (gridDim.x - xcd + nx - 1u) / nx;
     const uint32_t it_end = min(n, (xcd + 1u) * seg);
     for (uint32_t it = xcd * seg + blockIdx.x / nx; it < it_end; it += on_xcd) {
