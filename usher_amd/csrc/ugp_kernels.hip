@@ -2083,6 +2083,9 @@ constexpr uint32_t DESC_FRONTIER = 32, DESC_MAX_EXPANSIONS = 96, DESC_UP = 2;
 // A sample is served by G lanes: 16 (four samples per wave: a quarter of the waves, all resident at once, for the same
 // chain per sample) when nodes rarely have more children than that, a whole wave when the tree has large polytomies
 // (the SARS-CoV-2-shaped benchmark tree: 16 lanes cost 2.5x there).
+// (Round 5, tried and removed: a second table {first record word, first mutation word} per node, loaded with the pair, so that the row
+// of a one-mutation node is requested in the second round trip instead of the third: 8 more bytes per node, k_descend 242 -> 245 us --
+// the chain of an expansion is not what bounds it; the four samples of a wave wait for the slowest, and the rounds of children do.)
 // (one-wave blocks since round 4: next to the persistent walks of the other batches -- 118 VGPRs, a quarter of a SIMD's register file
 // per wave -- a CU usually has room for ONE more wave, not for the four of a 256-thread block, which then waits for a whole CU)
 constexpr uint32_t DESC_BLOCK = 64;
