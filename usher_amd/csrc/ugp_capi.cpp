@@ -511,7 +511,8 @@ int run_place(ugp_mat *m, ugp_qset *qs, int mode, ugp_result *d_out, int32_t *d_
         }
         if (int rc = ensure_events(TG, TG.events_used + 1)) return rc;
         EventSet &es = TG.events[TG.events_used++];
-        es.b3_class = (b3_can && K.bound3 < 0) ? b3_class : -1; es.b3_used = b3_want; es.b3_tiles = n_tiles512; es.b3_pos = b3_pos; es.b3_seq = b3_seq; es.b3_first = m->b3_tuner.first;
+        es.b3_class = -1;   // (set behind this sub-batch's last event record: until then the events still hold their previous use)
+        es.b3_used = b3_want; es.b3_tiles = n_tiles512; es.b3_pos = b3_pos; es.b3_seq = b3_seq; es.b3_first = m->b3_tuner.first;
         const uint64_t e0 = qs->ent_off[q0], e1 = qs->ent_off[q0 + nq];
 
         HIP_TRY(hipEventRecord(es.ev[0], s));
@@ -841,6 +842,7 @@ int run_place(ugp_mat *m, ugp_qset *qs, int mode, ugp_result *d_out, int32_t *d_
             W.prev_serial = (q0 + nq >= Q) ? qs->serial : 0;   // valid once every sub-batch of THIS query set has been stored
         }
         HIP_TRY(hipEventRecord(es.ev[3], s));
+        if (b3_can && K.bound3 < 0) es.b3_class = b3_class;   // (from here on the tuner may read this sub-batch's events)
         W.last_used_best8 = use8;
         TG.last.packed_path = use8 ? 1u : 0u;
         es.used = true;
