@@ -378,7 +378,7 @@ enum {
     UGP_FLAT_STREAM_T = 15,     /* uint32: tie stream walked by phase 2 (chunk bodies + pruning pseudo-records) */
     UGP_FLAT_CHUNK_T_OFF = 16,  /* uint32 [n_chunks+1] */
     UGP_FLAT_LDS_SLOTS = 17,    /* count only: saved-D slots the packed stream keeps on the fast path */
-    UGP_FLAT_B3_GROUP_OFF = 18, /* uint32 [3][groups + 1]: third pruning bound, the three event lists of every group of 256 blocks of 16 packed-stream words */
+    UGP_FLAT_B3_GROUP_OFF = 18, /* uint32 [4][groups + 1]: third pruning bound, the four event lists of every group of 256 blocks of 16 packed-stream words */
     UGP_FLAT_B3_EVENTS = 19     /* uint32 [events]: 4 * site + allele (bits 23:0) | block within the group (31:24) */
 };
 int ugp_flat_create(const ugp_tree_desc *tree, uint32_t chunk_nodes, ugp_flat **out);

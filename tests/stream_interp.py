@@ -156,10 +156,10 @@ def b3_tables(flat, nibs):
     for nib in nibs:
         excl = (nib & flat.site_ref.astype(np.int64)) == 0
         useful[excl] |= nib[excl]
-    ng = (len(flat.b3_group_off) // 3) - 1
+    ng = (len(flat.b3_group_off) // 4) - 1
     nb = ng << B3_GROUP_SHIFT
     assert nb >= ((len(flat.stream8) + 15) >> B3_BLOCK_SHIFT) + 1
-    off = flat.b3_group_off.astype(np.int64).reshape(3, ng + 1)
+    off = flat.b3_group_off.astype(np.int64).reshape(4, ng + 1)
     ev = flat.b3_events.astype(np.int64)
     cnt = np.zeros((3, nb), np.int64)       # 0: inside one block, 1: range starts, 2: range ends
     for k in range(3):
@@ -171,6 +171,12 @@ def b3_tables(flat, nibs):
     same, start, end = cnt[0], cnt[1], cnt[2]
     S, E = np.cumsum(start), np.cumsum(end)
     Sprev = np.concatenate([[0], S[:-1]]); Eprev = np.concatenate([[0], E[:-1]])
+    # list 3: the events open at each group's first block -- what the device uses in place of a scan across the groups
+    e3 = ev[off[3, 0]:off[3, ng]]
+    use3 = ((useful[(e3 & 0xFFFFFF) >> 2] >> (e3 & 3)) & 1) != 0
+    open0 = np.bincount(np.repeat(np.arange(ng), np.diff(off[3]))[use3], minlength=ng)
+    first = np.arange(ng) << B3_GROUP_SHIFT
+    assert (open0 == (Sprev - Eprev)[first]).all()
     over = S - Eprev + same
     under = Sprev - E
     assert (under >= 0).all()

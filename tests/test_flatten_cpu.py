@@ -477,14 +477,15 @@ def test_third_bound_tables_skip_more_and_change_nothing(seed, chunk_nodes):
     H_TAG = 1 << 31
     is_mut = (s8 & H_TAG) == 0
     # (1) every mutation word once
-    ng = len(flat.b3_group_off) // 3 - 1
-    off = flat.b3_group_off.astype(np.int64).reshape(3, ng + 1)
+    ng = len(flat.b3_group_off) // 4 - 1
+    off = flat.b3_group_off.astype(np.int64).reshape(4, ng + 1)
     ev = flat.b3_events.astype(np.int64)
-    assert off[0, 0] == 0 and (np.diff(off, axis=1) >= 0).all() and off[1, 0] == off[0, ng] and off[2, 0] == off[1, ng] and off[2, ng] == len(ev)
+    assert off[0, 0] == 0 and (np.diff(off, axis=1) >= 0).all() and off[1, 0] == off[0, ng] and off[2, 0] == off[1, ng] and off[3, 0] == off[2, ng] and off[3, ng] == len(ev)
+    assert off[3, 1] == off[3, 0]   # (nothing is open in front of the first group)
     assert off[1, ng] == int(is_mut.sum()) and off[2, ng] - off[2, 0] == off[1, ng] - off[1, 0]   # one start and one end per spanning event
     pairs = (s8[is_mut] & 0x3FFFFF) * 4 + ((s8[is_mut] >> 22) & 3)
     np.testing.assert_array_equal(np.bincount(pairs, minlength=4 * len(flat.site_ref)), np.bincount(ev[:off[1, ng]] & 0xFFFFFF, minlength=4 * len(flat.site_ref)))
-    np.testing.assert_array_equal(np.bincount(ev[off[1, 0]:off[1, ng]] & 0xFFFFFF), np.bincount(ev[off[2, 0]:] & 0xFFFFFF))
+    np.testing.assert_array_equal(np.bincount(ev[off[1, 0]:off[1, ng]] & 0xFFFFFF), np.bincount(ev[off[2, 0]:off[2, ng]] & 0xFFFFFF))
     # lists 0 and 1 follow the stream: the k-th mutation word is the k-th event of the two lists merged by block
     blk = lambda k: np.repeat(np.arange(ng), np.diff(off[k])) * 256 + (ev[off[k, 0]:off[k, ng]] >> 24)
     assert (np.sort(np.concatenate([blk(0), blk(1)])) <= np.flatnonzero(is_mut) >> 4).all() and blk(2).max() <= (len(s8) - 1) >> 4

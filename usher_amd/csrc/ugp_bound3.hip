@@ -2,7 +2,7 @@
 //
 // Input: the tiles' "useful" nibbles (which (site, allele) pairs match a variant of some sample of the tile -- written by the tile
 // builders) and the tree's static event lists in block order (FlatMat::b3_events: per group of B3_GROUP_BLOCKS blocks, the events
-// inside one block, the range starts and the range ends of the others).
+// inside one block, the range starts and the range ends of the others, and the events open at the group's first block).
 // Output, per tile and block of B3_BLOCK_WORDS packed-stream words:
 //     cum_over[b]  = #events whose block range [b0, b1] contains b                 (upper bound of the useful events on the root
 //                                                                                   path of any node with a word in b)
@@ -11,14 +11,14 @@
 // With S(b) / E(b) = inclusive prefix counts of the range starts / ends of the events that span more than one block and same(b) =
 // events inside block b:   cum_over[b] = S(b) - E(b - 1) + same(b),   cum_under[b] = S(b - 1) - E(b).
 //
-// Four small steps, none with a global atomic and none that touches more than the tables themselves (4 bytes per tile and block):
+// Two steps, neither with a global atomic, and nothing touched but the tables themselves (4 bytes per tile and block):
 //   k_b3_pairmask     nibbles of 32 tiles -> one 32-bit tile mask per (site, allele) pair
-//   k_b3_group_sums   per group and tile: range starts and ends (reads the group's two lists once for 32 tiles)
-//   k_b3_seg_scan     exclusive scan of those sums along each tile's groups
-//   k_b3_group_tables per group: counts the events per (tile, block) in LDS, scans them, writes cum_over / cum_under / level 1
+//   k_b3_group_tables per group of 256 blocks: counts the events per (tile, block) in LDS -- and the events open at the group's first
+//                     block, a static list of their own: no scan across groups --, scans them, writes cum_over / cum_under / level 1
 //   k_b3_level2 / 3   the two upper levels of maxima
 // (first version of the round: one global atomic per event and tile into an 8-byte-per-block work array, zeroed per batch: 1.15 ms
-// for the atomics, 0.5 ms for the scan over 370 MB, per batch of 32 tiles -- five times what the bound saves the walk.)
+// for the atomics, 0.5 ms for the scan over 370 MB, per batch of 32 tiles -- five times what the bound saves the walk.  Second: group
+// sums + a scan along each tile's groups in front of the tables kernel, 70 us of the 257.)
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -40,69 +40,23 @@ __global__ void __launch_bounds__(256) k_b3_pairmask(const uint32_t *__restrict_
     pairmask[(uint64_t)y * n_sites + site] = make_uint4(m0, m1, m2, m3);
 }
 
-// gsum[tile][group] = {range starts, range ends} of the tile's useful events in the group (one wave per group and 32 tiles)
-__global__ void __launch_bounds__(64) k_b3_group_sums(const uint32_t *__restrict__ pairmask, uint32_t n_pairs, uint32_t n_tiles, const uint32_t *__restrict__ group_off,
-                                                      const uint32_t *__restrict__ events, uint32_t n_groups, uint2 *__restrict__ gsum) {
-    __shared__ uint32_t cnt[64];   // [0, 32): starts, [32, 64): ends
-    const uint32_t g = blockIdx.x, y = blockIdx.y, lane = threadIdx.x;
-    const uint32_t *pm = pairmask + (uint64_t)y * n_pairs;
-    cnt[lane] = 0;
-    __syncthreads();
-    for (uint32_t k = 1; k <= 2u; k++) {
-        const uint32_t i0 = group_off[(uint64_t)k * (n_groups + 1) + g], i1 = group_off[(uint64_t)k * (n_groups + 1) + g + 1];
-        for (uint32_t i = i0 + lane; i < i1; i += 256u) {   // (four events in flight per lane: event word -> tile mask is a dependent pair of loads)
-            uint32_t w[4], mk[4];
-#pragma unroll
-            for (int u = 0; u < 4; u++) w[u] = i + 64u * u < i1 ? events[i + 64u * u] : 0xFFFFFFFFu;
-#pragma unroll
-            for (int u = 0; u < 4; u++) mk[u] = w[u] != 0xFFFFFFFFu ? pm[w[u] & 0xFFFFFFu] : 0u;
-#pragma unroll
-            for (int u = 0; u < 4; u++) {
-                uint32_t mask = mk[u];
-                while (mask) { const uint32_t t = (uint32_t)__builtin_ctz(mask); mask &= mask - 1u; atomicAdd(&cnt[(k - 1u) * 32u + t], 1u); }
-            }
-        }
-    }
-    __syncthreads();
-    if (lane < 32u && y * 32u + lane < n_tiles) gsum[(uint64_t)(y * 32u + lane) * n_groups + g] = make_uint2(cnt[lane], cnt[32u + lane]);
-}
-
-// exclusive scan of a tile's group sums in place (one block per tile: a run of consecutive groups per thread, the runs' totals scanned by
-// wave shuffles)
-__global__ void __launch_bounds__(1024) k_b3_seg_scan(uint2 *__restrict__ seg, uint32_t n_seg) {
-    __shared__ uint32_t wa[16], wb[16];
-    const uint32_t tile = blockIdx.x, t = threadIdx.x, lane = t & 63u, wv = t >> 6;
-    uint2 *S = seg + (uint64_t)tile * n_seg;
-    const uint32_t per = (n_seg + 1023u) / 1024u, i0 = min(n_seg, t * per), i1 = min(n_seg, i0 + per);
-    uint32_t a = 0, b = 0;
-    for (uint32_t i = i0; i < i1; i++) { const uint2 v = S[i]; a += v.x; b += v.y; }
-    uint32_t xa = a, xb = b;   // inclusive scan across the wave
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const uint32_t ya = (uint32_t)__shfl_up((int)xa, o), yb = (uint32_t)__shfl_up((int)xb, o);
-        if (lane >= (uint32_t)o) { xa += ya; xb += yb; }
-    }
-    if (lane == 63u) { wa[wv] = xa; wb[wv] = xb; }
-    __syncthreads();
-    uint32_t pa = xa - a, pb = xb - b;   // exclusive within the wave
-    for (uint32_t k = 0; k < wv; k++) { pa += wa[k]; pb += wb[k]; }
-    for (uint32_t i = i0; i < i1; i++) { const uint2 v = S[i]; S[i] = make_uint2(pa, pb); pa += v.x; pb += v.y; }
-}
-
 // the tables of one group of B3_GROUP_BLOCKS blocks for 32 tiles: per (tile, block) one LDS word counts range starts (bits 7:0), events
 // inside the block (15:8; both at most B3_BLOCK_WORDS) and range ends (31:16); thread (tile, eighth of the group) then turns 32
 // of them into cum_over | cum_under << 16 in place, and the block writes the rows out four bytes (two blocks) at a time.
 constexpr uint32_t B3_ROW = B3_GROUP_BLOCKS + 1;   // (padded: a wave's 32 rows fall into 32 different LDS banks)
 __global__ void __launch_bounds__(256) k_b3_group_tables(const uint32_t *__restrict__ pairmask, uint32_t n_pairs, uint32_t n_tiles, const uint32_t *__restrict__ group_off,
-                                                         const uint32_t *__restrict__ events, uint32_t n_groups, const uint2 *__restrict__ gpre, uint32_t n_blocks,
+                                                         const uint32_t *__restrict__ events, uint32_t n_groups, uint32_t n_blocks,
                                                          uint16_t *__restrict__ over, uint16_t *__restrict__ under, uint16_t *__restrict__ l1, uint32_t n_l1) {
     __shared__ uint32_t cnt[32 * B3_ROW];
-    __shared__ uint32_t pa[256], pb[256], mx[256];
+    __shared__ uint32_t pa[256], pb[256], mx[256], open0[32];
     const uint32_t g = blockIdx.x, y = blockIdx.y, tid = threadIdx.x;
     const uint32_t *pm = pairmask + (uint64_t)y * n_pairs;
     for (uint32_t i = tid; i < 32u * B3_ROW; i += 256u) cnt[i] = 0;
+    if (tid < 32u) open0[tid] = 0;
     __syncthreads();
-    for (uint32_t k = 0; k < 3u; k++) {
+    // list 3 -> open0[tile] = the tile's useful events open at the group's first block (S - E in front of the group: all a group needs
+    // of the groups before it -- no scan across groups); lists 0..2 -> the counters
+    for (uint32_t k = 0; k < 4u; k++) {
         const uint32_t i0 = group_off[(uint64_t)k * (n_groups + 1) + g], i1 = group_off[(uint64_t)k * (n_groups + 1) + g + 1];
         const uint32_t inc = k == 0 ? 1u << 8 : k == 1 ? 1u : 1u << 16;
         for (uint32_t i = i0 + tid; i < i1; i += 1024u) {   // (four events in flight per thread)
@@ -114,7 +68,11 @@ __global__ void __launch_bounds__(256) k_b3_group_tables(const uint32_t *__restr
 #pragma unroll
             for (int u = 0; u < 4; u++) {
                 uint32_t mask = mk[u];
-                while (mask) { const uint32_t t = (uint32_t)__builtin_ctz(mask); mask &= mask - 1u; atomicAdd(&cnt[t * B3_ROW + (w[u] >> 24)], inc); }
+                while (mask) {
+                    const uint32_t t = (uint32_t)__builtin_ctz(mask);
+                    mask &= mask - 1u;
+                    if (k == 3u) atomicAdd(&open0[t], 1u); else atomicAdd(&cnt[t * B3_ROW + (w[u] >> 24)], inc);
+                }
             }
         }
     }
@@ -126,8 +84,7 @@ __global__ void __launch_bounds__(256) k_b3_group_tables(const uint32_t *__restr
     for (int k = 0; k < 32; k++) { const uint32_t w = row[k]; a += w & 0xFFu; b += w >> 16; }
     pa[t * 8u + c] = a; pb[t * 8u + c] = b;
     __syncthreads();
-    uint32_t S = 0, E = 0;
-    if (tile < n_tiles) { const uint2 base = gpre[(uint64_t)tile * n_groups + g]; S = base.x; E = base.y; }
+    uint32_t S = open0[t], E = 0;   // (only S - E matters)
     for (uint32_t k = 0; k < c; k++) { S += pa[t * 8u + k]; E += pb[t * 8u + k]; }   // inclusive prefixes in front of the thread's first block
     uint32_t m = 0;
 #pragma unroll 8
@@ -183,16 +140,12 @@ __global__ void __launch_bounds__(64) k_b3_level3(const uint16_t *__restrict__ l
 }
 
 hipError_t launch_b3_tables(const uint32_t *useful, uint32_t useful_words, uint32_t n_sites, uint32_t n_tiles, const uint32_t *group_off, const uint32_t *events,
-                            uint32_t n_blocks, uint32_t *pairmask, uint32_t *gsum, uint16_t *over, uint16_t *under, uint16_t *l1, uint16_t *l2, uint16_t *l3,
-                            hipStream_t s) {
+                            uint32_t n_blocks, uint32_t *pairmask, uint16_t *over, uint16_t *under, uint16_t *l1, uint16_t *l2, uint16_t *l3, hipStream_t s) {
     if (!n_sites || !n_tiles || !n_blocks) return hipSuccess;
     const uint32_t ng = n_blocks >> B3_GROUP_SHIFT, ty = (n_tiles + 31u) / 32u, n_pairs = n_sites * 4u;
     const uint32_t n_l1 = b3_div64(n_blocks), n_l2 = b3_div64(n_l1), n_l3 = b3_div64(n_l2);
     hipLaunchKernelGGL(k_b3_pairmask, dim3((n_sites + 255u) / 256u, ty), dim3(256), 0, s, useful, useful_words, n_sites, n_tiles, (uint4 *)pairmask);
-    hipLaunchKernelGGL(k_b3_group_sums, dim3(ng, ty), dim3(64), 0, s, pairmask, n_pairs, n_tiles, group_off, events, ng, (uint2 *)gsum);
-    hipLaunchKernelGGL(k_b3_seg_scan, dim3(n_tiles), dim3(1024), 0, s, (uint2 *)gsum, ng);
-    hipLaunchKernelGGL(k_b3_group_tables, dim3(ng, ty), dim3(256), 0, s, pairmask, n_pairs, n_tiles, group_off, events, ng, (const uint2 *)gsum, n_blocks, over, under, l1,
-                       n_l1);
+    hipLaunchKernelGGL(k_b3_group_tables, dim3(ng, ty), dim3(256), 0, s, pairmask, n_pairs, n_tiles, group_off, events, ng, n_blocks, over, under, l1, n_l1);
     hipLaunchKernelGGL(k_b3_level2, dim3((n_l2 + 63u) / 64u, n_tiles), dim3(64), 0, s, l1, n_l1, l2, n_l2);
     hipLaunchKernelGGL(k_b3_level3, dim3(n_tiles), dim3(64), 0, s, l2, n_l2, l3, n_l3);
     return hipGetLastError();

@@ -20,11 +20,10 @@ struct B3Dev {
 
 // useful[tile][useful_words]: one nibble per site, bit a = allele a is in some sample's set that excludes the reference base.
 // group_off / events: FlatMat::b3_group_off / b3_events on the device; n_blocks = b3_blocks(packed-stream words) (whole groups).
-// Scratch: pairmask [ceil(n_tiles / 32)][4 * n_sites] words, gsum [n_tiles][n_blocks / B3_GROUP_BLOCKS][2] words.
+// Scratch: pairmask [ceil(n_tiles / 32)][4 * n_sites] words.
 // Fills over / under ([n_tiles][n_blocks]) and l1 / l2 / l3.
 hipError_t launch_b3_tables(const uint32_t *useful, uint32_t useful_words, uint32_t n_sites, uint32_t n_tiles, const uint32_t *group_off, const uint32_t *events,
-                            uint32_t n_blocks, uint32_t *pairmask, uint32_t *gsum, uint16_t *over, uint16_t *under, uint16_t *l1, uint16_t *l2, uint16_t *l3,
-                            hipStream_t s);
+                            uint32_t n_blocks, uint32_t *pairmask, uint16_t *over, uint16_t *under, uint16_t *l1, uint16_t *l2, uint16_t *l3, hipStream_t s);
 inline uint32_t b3_div64(uint32_t n) { return (n + 63u) / 64u; }
 
 }  // namespace ugp

@@ -257,7 +257,7 @@ struct ugp_mat {
         DevBuf<uint64_t> d_dyn;
         uint32_t dyn_epoch = 0;
         // third pruning bound: per-batch block tables of every tile (ugp_bound3.hpp)
-        DevBuf<uint32_t> d_b3_pairmask, d_b3_gsum;
+        DevBuf<uint32_t> d_b3_pairmask;
         DevBuf<uint16_t> d_b3_over, d_b3_under, d_b3_l1, d_b3_l2, d_b3_l3;
         DevBuf<ugp::B3Dev> d_b3_dev;
         ugp::B3Dev b3_host = {};
@@ -557,7 +557,7 @@ int run_place(ugp_mat *m, ugp_qset *qs, int mode, ugp_result *d_out, int32_t *d_
         const bool b3_on = b3_want && !(lds_build && nmi < 0);
         if (b3_on) {
             const uint32_t nb = ugp::b3_blocks(m->stream8_dwords), n_l1 = ugp::b3_div64(nb), n_l2 = ugp::b3_div64(n_l1), n_l3 = ugp::b3_div64(n_l2);
-            HIP_TRY(W.d_b3_pairmask.reserve((size_t)((n_tiles512 + 31) / 32) * n_sites * 4)); HIP_TRY(W.d_b3_gsum.reserve((size_t)n_tiles512 * (nb >> ugp::B3_GROUP_SHIFT) * 2));
+            HIP_TRY(W.d_b3_pairmask.reserve((size_t)((n_tiles512 + 31) / 32) * n_sites * 4));
             HIP_TRY(W.d_b3_over.reserve((size_t)n_tiles512 * nb)); HIP_TRY(W.d_b3_under.reserve((size_t)n_tiles512 * nb));
             HIP_TRY(W.d_b3_l1.reserve((size_t)n_tiles512 * n_l1)); HIP_TRY(W.d_b3_l2.reserve((size_t)n_tiles512 * n_l2)); HIP_TRY(W.d_b3_l3.reserve((size_t)n_tiles512 * n_l3));
             HIP_TRY(W.d_b3_dev.reserve(1));
@@ -567,7 +567,7 @@ int run_place(ugp_mat *m, ugp_qset *qs, int mode, ugp_result *d_out, int32_t *d_
                 HIP_TRY(hipMemcpy(W.d_b3_dev.p, &hd, sizeof hd, hipMemcpyHostToDevice));
                 W.b3_host = hd;
             }
-            HIP_TRY(ugp::launch_b3_tables(d_useful, useful_words, n_sites, n_tiles512, m->d_b3_group_off.p, m->d_b3_events.p, nb, W.d_b3_pairmask.p, W.d_b3_gsum.p,
+            HIP_TRY(ugp::launch_b3_tables(d_useful, useful_words, n_sites, n_tiles512, m->d_b3_group_off.p, m->d_b3_events.p, nb, W.d_b3_pairmask.p,
                                           W.d_b3_over.p, W.d_b3_under.p, W.d_b3_l1.p, W.d_b3_l2.p, W.d_b3_l3.p, s));
         }
         if (use8) {   // upper bounds of best(s) the pruning starts from

@@ -664,34 +664,51 @@ int flatten(const ugp_tree_desc &t, const Options &opt, FlatMat &out, std::strin
     out.b3_group_off.clear(); out.b3_events.clear();
     if (opt.keep_b3_events && out.n_sites && total8 > 0 && total8 < (1ull << 32) - 2 * B3_GROUP_BLOCKS * B3_BLOCK_WORDS) {
         const uint32_t ng = b3_blocks(total8) >> B3_GROUP_SHIFT;
-        out.b3_group_off.assign((size_t)3 * (ng + 1), 0);
-        uint32_t *off[3] = {out.b3_group_off.data(), out.b3_group_off.data() + (ng + 1), out.b3_group_off.data() + 2 * (size_t)(ng + 1)};
+        out.b3_group_off.assign((size_t)4 * (ng + 1), 0);
+        uint32_t *off[4];
+        for (int k = 0; k < 4; k++) off[k] = out.b3_group_off.data() + (size_t)k * (ng + 1);
         const uint32_t *s8 = out.stream8.data();
         auto range_of = [&](uint64_t d, uint32_t j, uint32_t &b0, uint32_t &b1) { b0 = pos8_hdr[d] >> B3_BLOCK_SHIFT; b1 = (pos8_at[d + sub[j]] - 1u) >> B3_BLOCK_SHIFT; };
         // Each thread owns one run of consecutive depth-first indices (Par::run's static split, the same in both sweeps): it counts
         // its events per (list, group), the counts become cursors (groups in order, within a group the threads in order: the lists come
         // out in depth-first order whatever the number of threads), then it writes its events at its cursors.
+        // List 3 = the events that are open at a group's first block (started in an earlier group, not over before this one): the
+        // mutation words of the root path there -- a few dozen per group in a tree of logarithmic depth, the whole tree in a
+        // caterpillar; counted through a difference array (+ at the first group an event is open at, - behind the last).
         std::vector<std::vector<uint32_t>> cur(T);
         par.run(N, [&](uint64_t b, uint64_t e, unsigned tid) {
             std::vector<uint32_t> &c = cur[tid];
-            c.assign((size_t)3 * ng, 0);
+            c.assign((size_t)4 * ng + 1, 0);
+            uint32_t *c3 = c.data() + (size_t)3 * ng;
             for (uint64_t d = b; d < e; d++) {
                 const uint32_t j = d2b[d];
                 if (dropped[j] || !nw[j]) continue;
                 uint32_t b0, b1; range_of(d, j, b0, b1);
                 if (b0 == b1) c[b0 >> B3_GROUP_SHIFT] += nw[j];
-                else { c[(size_t)ng + (b0 >> B3_GROUP_SHIFT)] += nw[j]; c[(size_t)2 * ng + (b1 >> B3_GROUP_SHIFT)] += nw[j]; }
+                else {
+                    c[(size_t)ng + (b0 >> B3_GROUP_SHIFT)] += nw[j]; c[(size_t)2 * ng + (b1 >> B3_GROUP_SHIFT)] += nw[j];
+                    const uint32_t g0 = (b0 >> B3_GROUP_SHIFT) + 1u, g1 = b1 >> B3_GROUP_SHIFT;   // open at the first block of groups g0 .. g1
+                    if (g0 <= g1) { c3[g0] += nw[j]; c3[g1 + 1u] -= nw[j]; }
+                }
             }
+            uint32_t open = 0;
+            for (uint32_t g = 0; g < ng; g++) { open += c3[g]; c3[g] = open; }
         }, 1u << 16);
-        uint32_t run = 0;
-        for (int k = 0; k < 3; k++) {   // (the three lists one behind the other)
+        uint64_t run = 0;
+        for (int k = 0; k < 4; k++) {   // (the four lists one behind the other)
             for (uint32_t g = 0; g < ng; g++) {
-                off[k][g] = run;
+                off[k][g] = (uint32_t)std::min<uint64_t>(run, UINT32_MAX);
                 for (unsigned t2 = 0; t2 < T; t2++)
-                    if (!cur[t2].empty()) { uint32_t &c = cur[t2][(size_t)k * ng + g]; const uint32_t n = c; c = run; run += n; }
+                    if (!cur[t2].empty()) { uint32_t &c = cur[t2][(size_t)k * ng + g]; const uint32_t n = c; c = (uint32_t)std::min<uint64_t>(run, UINT32_MAX); run += n; }
             }
-            off[k][ng] = run;
+            off[k][ng] = (uint32_t)std::min<uint64_t>(run, UINT32_MAX);
         }
+        const uint64_t n_ev = off[2][0];   // (lists 0 and 1: every event once)
+        if (run >= (1ull << 32) || run > 6 * n_ev + (16ull << 20)) {
+            // (a tree so deep that the open lists dwarf the events themselves: no third bound for it)
+            out.b3_group_off.clear();
+            flat_lap("third bound: event lists (dropped: open lists too long)");
+        } else {
         out.b3_events.resize(run);
         uint32_t *ev = out.b3_events.data();
         par.run(N, [&](uint64_t b, uint64_t e, unsigned tid) {
@@ -707,11 +724,13 @@ int flatten(const ugp_tree_desc &t, const Options &opt, FlatMat &out, std::strin
                     else {
                         ev[c[(size_t)ng + (b0 >> B3_GROUP_SHIFT)]++] = pair | ((b0 & (B3_GROUP_BLOCKS - 1u)) << 24);
                         ev[c[(size_t)2 * ng + (b1 >> B3_GROUP_SHIFT)]++] = pair | ((b1 & (B3_GROUP_BLOCKS - 1u)) << 24);
+                        for (uint32_t g = (b0 >> B3_GROUP_SHIFT) + 1u; g <= (b1 >> B3_GROUP_SHIFT); g++) ev[c[(size_t)3 * ng + g]++] = pair;
                     }
                 }
             }
         }, 1u << 16);
         flat_lap("third bound: event lists");
+        }
     }
 
     // ---- tie stream (phase 2 walks it one chunk at a time) ---------------------------------------------------------------------

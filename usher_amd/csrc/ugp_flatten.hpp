@@ -134,7 +134,8 @@ constexpr uint32_t M_FLUSH = 1u << 28, M_END = 1u << 30;
 //     hU_T(n) <= max(cum_over[q0 .. q1]) - cum_under[bn].
 // The events are kept in BLOCK order, in groups of B3_GROUP_BLOCKS blocks (one workgroup of ugp_bound3.hip builds the tables of a
 // group for 32 tiles at a time: it reads the group's events once and asks a per-batch bit mask "which tiles make this pair
-// useful"), as three lists per group: events inside one block, range starts and range ends of the events that span blocks.
+// useful"), as four lists per group: events inside one block, range starts and range ends of the events that span blocks, and the
+// events open at the group's first block.
 constexpr uint32_t B3_BLOCK_SHIFT = 4, B3_BLOCK_WORDS = 1u << B3_BLOCK_SHIFT;
 constexpr uint32_t B3_GROUP_SHIFT = 8, B3_GROUP_BLOCKS = 1u << B3_GROUP_SHIFT;
 // blocks per tile row of the tables (whole groups; one block more than the stream has words for)
@@ -198,7 +199,9 @@ struct FlatMat {
     // b3_events[i] = 4 * site + allele index (bits 23:0) | block within its group (31:24); list k of group g =
     // [b3_group_off[k * (n_groups + 1) + g], ...[.. + g + 1]) with k = 0: events whose subtree (node included) lies inside one block
     // of B3_BLOCK_WORDS packed-stream words, listed under that block; 1: the others, under the block of the node's header word;
-    // 2: the same events again, under the last block of the subtree.  n_groups = b3_blocks(stream8 words) / B3_GROUP_BLOCKS.
+    // 2: the same events again, under the last block of the subtree; 3: the events that are open at the group's first block (header
+    // in an earlier group, subtree not over before this one: the root path's mutation words there) -- what a group needs to know of
+    // everything in front of it.  n_groups = b3_blocks(stream8 words) / B3_GROUP_BLOCKS.
     std::vector<uint32_t> b3_group_off;
     UVec<uint32_t> b3_events;
     uint32_t max_chunk8_words = 0;         // longest chunk of the packed stream (a work unit must stay below the reach of a preamble record's jump field)
