@@ -669,7 +669,7 @@ def main():
             pl3 = Placer(st3.arrays, device=dev_index)
             t_flat3 = time.time() - t0
             free_b, total_b = torch.cuda.mem_get_info(dev)
-            c3 = timed_config(pl3, st3, 10_000, 10, 3, recent=True)
+            c3 = timed_config(pl3, st3, 10_000, 12, 24, recent=True)   # (24 warm-up calls: a new handle, its trial of the third bound first)
             i3 = pl3.info()
             c3.update({"workload": "BASELINE config 3's size: synthetic sars2-shaped MAT %d nodes / %d mutations, 10,000 queries per step" % (i3["n_nodes"], i3["n_muts"]),
                        "gen_s": round(t_gen3, 2), "flatten_upload_s": round(t_flat3, 2), "device_bytes_in_use": int(total_b - free_b)})
