@@ -1,5 +1,5 @@
 #!/bin/bash
-# kernel time table of one short bench run (args: tag, then bench flags)
+# kernel time table (rocprofv3 --kernel-trace --stats) of one short bench run (args: tag, then bench flags)
 cd $GRAFT_REPO_ROOT
 TAG=$1; shift
 export TMPDIR=/tmp
