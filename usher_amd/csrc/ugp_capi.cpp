@@ -2186,6 +2186,9 @@ static int harvest_timing(ugp_mat *m, ugp_mat::Work &W, ugp_mat::Work::Gen &G) {
                         (unsigned long long)v[48], (unsigned long long)v[49], (unsigned long long)v[50], (unsigned long long)v[51], (unsigned long long)v[52],
                         (unsigned long long)v[53], (unsigned long long)v[54], (unsigned long long)v[55]);
                 fprintf(stderr, "[ugp stats] units split while running: %llu\n", (unsigned long long)v[31]);
+                fprintf(stderr, "[ugp stats] nodes evaluated: %llu in unit bodies = %.3f %% of nodes x tiles (%llu x %u), %llu in preamble replays\n", (unsigned long long)v[66],
+                        G.last.n_tiles ? 100.0 * (double)v[66] / ((double)m->flat.n_nodes * G.last.n_tiles) : 0.0, (unsigned long long)m->flat.n_nodes, G.last.n_tiles,
+                        (unsigned long long)v[67]);
                 fprintf(stderr, "[ugp stats] third bound: asked at a restart %llu times, decided the jump %llu times\n", (unsigned long long)v[64], (unsigned long long)v[65]);
                 fprintf(stderr, "[ugp stats] third bound by jump length (<16 <32 <64 <128 <256 <512 <1024 more), decided/asked:");
                 for (int i = 0; i < 8; i++) fprintf(stderr, " %llu/%llu", (unsigned long long)v[80 + i], (unsigned long long)v[72 + i]);

@@ -1160,7 +1160,9 @@ __global__ void __launch_bounds__(64, TIES ? 3 : 4) k_best8(Best8Args a) {
     bool cend_stale = false;       // uniform: `chunk` advanced inside the pipeline and the end word did not say where the next chunk ends
     uint32_t t_mark = (uint32_t)__builtin_amdgcn_s_memtime();   // uniform: start of the unit / its last look at the shared list (low word: differences only)
     uint32_t n_split = 0;      // uniform (STATS)
-    uint64_t n_skipped = 0;    // uniform (STATS): words jumped over
+    uint64_t n_skipped = 0;    // uniform (STATS): words jumped over (each jump counted up to the end of the unit's body: st_body words)
+    uint32_t st_body = 0;
+    uint64_t n_eval[2] = {0, 0};   // uniform (STATS): nodes evaluated in bodies / in preamble replays (and unpruned walks)
     uint32_t run_nodes = 0;    // uniform (STATS): nodes completed since the last restart
     uint64_t n_first_skip = 0; // uniform (STATS): jumps decided by the first node after a restart
     uint32_t n_cause[4] = {0, 0, 0, 0};   // uniform (STATS): restarts by cause -- jump, sibling jump, chunk end, slow header
@@ -1360,18 +1362,18 @@ __global__ void __launch_bounds__(64, TIES ? 3 : 4) k_best8(Best8Args a) {
             tie_any = 0; accU = 0;
         }
         accP = accC = accN = accPB = accCB = 0;
-        if (STATS) run_nodes++;
+        if (STATS) { run_nodes++; n_eval[pre_prune || !prune ? 1 : 0]++; }
         if (have_info) {   // this node carries a pruning record: can its whole subtree be skipped?
             have_info = false;
             if (all_far(dcur, bcur, info)) {
                 if (pre_prune) {   // a path node: nothing of its subtree is needed -- end the replay, start the body behind it
                     body_start = info & INFO_JUMP_MASK;
                     skip_to = 0x7FFFFFFFu;
-                    if (STATS) n_skipped += body_start;
+                    if (STATS) n_skipped += min(body_start, st_body);
                     return true;
                 }
                 skip_to = pos + 1 + (info & INFO_JUMP_MASK);
-                if (STATS) { n_skipped += info & INFO_JUMP_MASK; if (run_nodes == 1) n_first_skip++; count_jump(info & INFO_JUMP_MASK, 0); }
+                if (STATS) { n_skipped += min(info & INFO_JUMP_MASK, st_body > pos + 1u ? st_body - (pos + 1u) : 0u); if (run_nodes == 1) n_first_skip++; count_jump(info & INFO_JUMP_MASK, 0); }
                 return true;
             }
             if (B3 && !pre_prune) {   // both tests failed: is the third bound worth a look?  (bit 31 of skip_to: "test again at the restart")
@@ -1404,7 +1406,7 @@ __global__ void __launch_bounds__(64, TIES ? 3 : 4) k_best8(Best8Args a) {
         if (!all_far(dpar, bpar, sinfo)) return false;
         skip_to = pos + (sinfo & INFO_JUMP_MASK);   // the start of the parent's last child
         have_info = false;
-        if (STATS) { n_skipped += sinfo & INFO_JUMP_MASK; count_jump(sinfo & INFO_JUMP_MASK, 1); }
+        if (STATS) { n_skipped += min(sinfo & INFO_JUMP_MASK, st_body > pos ? st_body - pos : 0u); count_jump(sinfo & INFO_JUMP_MASK, 1); }
         return true;
     };
     // words that leave the fast path (H_RARE); true: the pipeline has to restart at skip_to
@@ -1502,6 +1504,7 @@ __global__ void __launch_bounds__(64, TIES ? 3 : 4) k_best8(Best8Args a) {
     uint64_t t_pre_end = 0;
     for (int phase = 0; phase < 2; phase++) {   // 0: replay of the preamble (the root path of the unit's first node), 1: the body
         if (STATS && phase == 1) t_pre_end = __builtin_amdgcn_s_memtime();
+        if (STATS) st_body = a.chunk8_body_off[c1] - a.chunk8_body_off[c0];
         sp = phase == 0 ? a.pre8 : a.stream8;
         const uint32_t begin = phase == 0 ? a.chunk8_pre_off[c0] : a.chunk8_body_off[c0];
         const uint32_t end = phase == 0 ? a.chunk8_pre_off[c0 + 1] : a.chunk8_body_off[c1];
@@ -1692,7 +1695,7 @@ __global__ void __launch_bounds__(64, TIES ? 3 : 4) k_best8(Best8Args a) {
                     if (all_far(dcur, bcur, rec3)) {
                         skip_to = p + 1u + J;
                         pre_off = skip_to; pre_w0 = sb0; pre_w1 = sb1; pre_w2 = sb2;
-                        if (STATS) { n_b3[1]++; n_skipped += J; count_jump(J, 0); if (lane == 0) atomicAdd((unsigned long long *)a.stats + 80 + jb, 1ull); }
+                        if (STATS) { n_b3[1]++; n_skipped += min(J, st_body > p + 1u ? st_body - (p + 1u) : 0u); count_jump(J, 0); if (lane == 0) atomicAdd((unsigned long long *)a.stats + 80 + jb, 1ull); }
                     }
                 }
             }
@@ -1787,6 +1790,7 @@ __global__ void __launch_bounds__(64, TIES ? 3 : 4) k_best8(Best8Args a) {
         for (int i = 0; i < 4; i++) atomicAdd(st + 48 + 2 * i + (unit_heavy ? 0 : 1), (unsigned long long)n_cause[i]);
         for (int i = 0; i < 8; i++) atomicAdd(st + 56 + i, (unsigned long long)n_jlen[i]);
         if (B3) { atomicAdd(st + 64, (unsigned long long)n_b3[0]); atomicAdd(st + 65, (unsigned long long)n_b3[1]); }
+        atomicAdd(st + 66, (unsigned long long)n_eval[0]); atomicAdd(st + 67, (unsigned long long)n_eval[1]);
         if (!unit_heavy) {   // what the preamble records decided for this unit
             const uint32_t body_words = a.chunk8_body_off[c1] - a.chunk8_body_off[c0];
             const int cls = body_start >= body_words ? 0 : (body_start ? 1 : 2);
