@@ -1401,6 +1401,11 @@ __global__ void __launch_bounds__(64, TIES ? 3 : 4) k_best8(Best8Args a) {
         cy.flushed = true;
     };
     // sibling record waiting at a header: can this child and the non-last siblings after it all be skipped?
+    // (Round 5, tried and removed: the third bound for the run -- the tile's useful mutations anywhere in the run, measured from
+    // cum_under of the header's block, which is a lower bound of the parent's count -- asked like a node's record.  Exact (model and
+    // GPU tests), but a run of siblings is long and some subtree in it nearly always holds a useful mutation: 124 k questions per
+    // launch, 40 k decided; restarts 404 k -> 425 k, the kernel 0.90 -> 0.94 ms; on the SARS-CoV-2 shape 201 k asked, 32 k decided,
+    // 1.30 -> 1.90 ms.  A failed question costs a restart the plain test never needed.)
     auto sibling_test = [&](uint32_t pos) -> bool {
         have_sinfo = false;
         if (!all_far(dpar, bpar, sinfo)) return false;
