@@ -2190,6 +2190,9 @@ static int harvest_timing(ugp_mat *m, ugp_mat::Work &W, ugp_mat::Work::Gen &G) {
                         G.last.n_tiles ? 100.0 * (double)v[66] / ((double)m->flat.n_nodes * G.last.n_tiles) : 0.0, (unsigned long long)m->flat.n_nodes, G.last.n_tiles,
                         (unsigned long long)v[67]);
                 fprintf(stderr, "[ugp stats] third bound: asked at a restart %llu times, decided the jump %llu times\n", (unsigned long long)v[64], (unsigned long long)v[65]);
+                fprintf(stderr, "[ugp stats] third bound by the record's hsub - hsec (1 2 3 more), decided/asked: %llu/%llu %llu/%llu %llu/%llu %llu/%llu\n", (unsigned long long)v[92],
+                        (unsigned long long)v[88], (unsigned long long)v[93], (unsigned long long)v[89], (unsigned long long)v[94], (unsigned long long)v[90], (unsigned long long)v[95],
+                        (unsigned long long)v[91]);
                 fprintf(stderr, "[ugp stats] third bound by jump length (<16 <32 <64 <128 <256 <512 <1024 more), decided/asked:");
                 for (int i = 0; i < 8; i++) fprintf(stderr, " %llu/%llu", (unsigned long long)v[80 + i], (unsigned long long)v[72 + i]);
                 fprintf(stderr, "\n");

@@ -1693,14 +1693,15 @@ __global__ void __launch_bounds__(64, TIES ? 3 : 4) k_best8(Best8Args a) {
                 const uint32_t hs3 = (info >> INFO_HS_SHIFT) & 0x7Fu, hr3 = (info >> INFO_HR_SHIFT) & 7u;
                 const uint32_t hu = M > U ? M - U : 0u;
                 const uint32_t jb = STATS ? min(7u, (uint32_t)max(0, 28 - (int)__builtin_clz(J | 1u))) : 0u;   // (J < 16, < 32, ... >= 1024)
-                if (STATS) { n_b3[0]++; if (lane == 0) atomicAdd((unsigned long long *)a.stats + 72 + jb, 1ull); }
+                const uint32_t gb = STATS ? min(hs3 - hr3, 4u) - 1u : 0u;   // (hsub - hsec of the record: 1, 2, 3, 4 and more)
+                if (STATS) { n_b3[0]++; if (lane == 0) { atomicAdd((unsigned long long *)a.stats + 72 + jb, 1ull); atomicAdd((unsigned long long *)a.stats + 88 + gb, 1ull); } }
                 pre_off = p + 1u; pre_w0 = sa0; pre_w1 = sa1; pre_w2 = sa2;
                 if (M != 65535u && hu + hr3 < hs3) {
                     const uint32_t rec3 = (info & ~(0x7Fu << INFO_HS_SHIFT)) | ((hu + hr3) << INFO_HS_SHIFT);
                     if (all_far(dcur, bcur, rec3)) {
                         skip_to = p + 1u + J;
                         pre_off = skip_to; pre_w0 = sb0; pre_w1 = sb1; pre_w2 = sb2;
-                        if (STATS) { n_b3[1]++; n_skipped += min(J, st_body > p + 1u ? st_body - (p + 1u) : 0u); count_jump(J, 0); if (lane == 0) atomicAdd((unsigned long long *)a.stats + 80 + jb, 1ull); }
+                        if (STATS) { n_b3[1]++; n_skipped += min(J, st_body > p + 1u ? st_body - (p + 1u) : 0u); count_jump(J, 0); if (lane == 0) { atomicAdd((unsigned long long *)a.stats + 80 + jb, 1ull); atomicAdd((unsigned long long *)a.stats + 92 + gb, 1ull); } }
                     }
                 }
             }
