@@ -62,3 +62,41 @@ def test_device_tables_equal_the_restatement(seed, n_leaves, ambig, monkeypatch)
     finally:
         placer.close()
         del orc
+
+
+@pytest.mark.parametrize("seed", [81, 83])
+def test_long_branches_shared_by_the_queries(seed, monkeypatch):
+    """nodes with 300-420 mutations, queries drawn from below them -- hundreds of useful events of one node.  The
+    table kernel counts range starts in 8 bits per (tile, block): with every event of a node listed under its header's block that
+    wrapped (cum_under 65535, subtree pruned, wrong placement); the events are now listed under their own word's block.  Device
+    tables == the restatement block by block, placements == the oracle, with the third bound pinned on."""
+    monkeypatch.setenv("UGP_COARSE_MIN_NODES", "0")
+    monkeypatch.setenv("UGP_BOUND3", "1")
+    monkeypatch.delenv("UGP_NO_BOUND3", raising=False)
+    arrays, queries = synth.make_case(seed, n_leaves=6000, n_queries=40, genome_len=4000, n_sites=900, n_ambig=(0, 0, 2),
+                                      mut_counts=(0, 1, 1, 1, 2, 3) * 8 + (300, 420))
+    flat = FlatTreeView(arrays)
+    placer = Placer(arrays)
+    orc = capi.OracleTree(arrays)
+    try:
+        deep = [q for q in queries if stream_interp.b3_tables(flat, [stream_interp.sample_site_alleles(flat, q)[0]])["over"].max() >= 256]
+        assert len(deep) >= 3, "no query below a long branch"
+        for q in deep[:3]:
+            res = placer.place(QueryBatch([dict(q, name="c%d" % i) for i in range(600)]))
+            want = orc.place(q)
+            assert (int(res["best_set_difference"][0]), int(res["num_best"][0]), int(res["best_j"][0])) == (want["best"], want["num_best"], want["best_j"])
+            assert (res == res[0]).all()
+            b3 = stream_interp.b3_tables(flat, [stream_interp.sample_site_alleles(flat, q)[0]])
+            over, under = _tables(placer, 0)
+            assert over is not None, "the call did not build the tables"
+            np.testing.assert_array_equal(over, b3["over"])
+            np.testing.assert_array_equal(under, b3["under"])
+            assert under.max() < 65535
+        mixed = [dict(queries[i % len(queries)], name="m%d" % i) for i in range(2000)]
+        res = placer.place(QueryBatch(mixed))
+        for i in range(len(queries)):
+            w = orc.place(mixed[i])
+            assert (int(res["best_set_difference"][i]), int(res["num_best"][i]), int(res["best_j"][i])) == (w["best"], w["num_best"], w["best_j"]), i
+    finally:
+        placer.close()
+        del orc

@@ -464,34 +464,12 @@ def test_third_lower_bound_holds_for_every_node_and_sample(seed):
     assert checked > 5000 and tight > 0 and better > 0
 
 
-@pytest.mark.parametrize("seed,chunk_nodes", [(71, 700), (72, 64), (73, 0)])
-def test_third_bound_tables_skip_more_and_change_nothing(seed, chunk_nodes):
-    """The third bound as the device builds and reads it (tests/stream_interp.b3_tables / b3_hu: posting lists of the flattening ->
-    cum_over / cum_under per block of 16 stream words -> the maximum over the descendants' blocks at the coarsest 64-ary level that
-    fits, minus cum_under of the node's own block): (1) the event lists hold every mutation word of the packed body exactly once; (2) what the tables give is never below the true path maximum of useful events -- recomputed from the
-    stream itself -- for every record; (3) the model of the walk, with the tables of the whole batch as one tile and each sample's
-    own exact score as its bound, returns the oracle's answers and skips more of the stream than without."""
-    arrays, queries = synth.make_case(seed, n_leaves=2600, n_queries=10, n_sites=300, n_ambig=(0, 0, 2, 6), p_masked=0.01)
-    flat = FlatTreeView(arrays, chunk_nodes=chunk_nodes)
+def _tables_never_below_the_stream_truth(flat, b3):
+    """What the tables give (stream_interp.b3_hu) against the true path maximum of useful events below every record, recomputed
+    from the packed stream itself."""
     s8 = flat.stream8.astype(np.int64)
     H_TAG = 1 << 31
-    is_mut = (s8 & H_TAG) == 0
-    # (1) every mutation word once
-    ng = len(flat.b3_group_off) // 4 - 1
-    off = flat.b3_group_off.astype(np.int64).reshape(4, ng + 1)
-    ev = flat.b3_events.astype(np.int64)
-    assert off[0, 0] == 0 and (np.diff(off, axis=1) >= 0).all() and off[1, 0] == off[0, ng] and off[2, 0] == off[1, ng] and off[3, 0] == off[2, ng] and off[3, ng] == len(ev)
-    assert off[3, 1] == off[3, 0]   # (nothing is open in front of the first group)
-    assert off[1, ng] == int(is_mut.sum()) and off[2, ng] - off[2, 0] == off[1, ng] - off[1, 0]   # one start and one end per spanning event
-    pairs = (s8[is_mut] & 0x3FFFFF) * 4 + ((s8[is_mut] >> 22) & 3)
-    np.testing.assert_array_equal(np.bincount(pairs, minlength=4 * len(flat.site_ref)), np.bincount(ev[:off[1, ng]] & 0xFFFFFF, minlength=4 * len(flat.site_ref)))
-    np.testing.assert_array_equal(np.bincount(ev[off[1, 0]:off[1, ng]] & 0xFFFFFF), np.bincount(ev[off[2, 0]:off[2, ng]] & 0xFFFFFF))
-    # lists 0 and 1 follow the stream: the k-th mutation word is the k-th event of the two lists merged by block
-    blk = lambda k: np.repeat(np.arange(ng), np.diff(off[k])) * 256 + (ev[off[k, 0]:off[k, ng]] >> 24)
-    assert (np.sort(np.concatenate([blk(0), blk(1)])) <= np.flatnonzero(is_mut) >> 4).all() and blk(2).max() <= (len(s8) - 1) >> 4
-    nibs = [stream_interp.sample_site_alleles(flat, s)[0] for s in queries]
-    b3 = stream_interp.b3_tables(flat, nibs)
-    # (2) against the stream: walk the body once, keeping for every open node the running count of useful words on its root path
+    # against the stream: walk the body once, keeping for every open node the running count of useful words on its root path
     useful = b3["useful"]
     INFO, RARE, SIB, CE, NOP, ENDF = 1 << 30, 1 << 29, 1 << 21, 1 << 8, 1 << 9, 1 << 3
     recs = []            # (position of the node's last word, jump, cum at the node)
@@ -582,6 +560,38 @@ def test_third_bound_tables_skip_more_and_change_nothing(seed, chunk_nodes):
         got = stream_interp.b3_hu(b3, last, jump)
         assert got >= true_hu, (last, jump, got, true_hu)
         loose += got - true_hu
+    return len(recs), loose
+
+
+@pytest.mark.parametrize("seed,chunk_nodes", [(71, 700), (72, 64), (73, 0)])
+def test_third_bound_tables_skip_more_and_change_nothing(seed, chunk_nodes):
+    """The third bound as the device builds and reads it (tests/stream_interp.b3_tables / b3_hu: posting lists of the flattening ->
+    cum_over / cum_under per block of 16 stream words -> the maximum over the descendants' blocks at the coarsest 64-ary level that
+    fits, minus cum_under of the node's own block): (1) the event lists hold every mutation word of the packed body exactly once; (2) what the tables give is never below the true path maximum of useful events -- recomputed from the
+    stream itself -- for every record; (3) the model of the walk, with the tables of the whole batch as one tile and each sample's
+    own exact score as its bound, returns the oracle's answers and skips more of the stream than without."""
+    arrays, queries = synth.make_case(seed, n_leaves=2600, n_queries=10, n_sites=300, n_ambig=(0, 0, 2, 6), p_masked=0.01)
+    flat = FlatTreeView(arrays, chunk_nodes=chunk_nodes)
+    s8 = flat.stream8.astype(np.int64)
+    H_TAG = 1 << 31
+    is_mut = (s8 & H_TAG) == 0
+    # (1) every mutation word once
+    ng = len(flat.b3_group_off) // 4 - 1
+    off = flat.b3_group_off.astype(np.int64).reshape(4, ng + 1)
+    ev = flat.b3_events.astype(np.int64)
+    assert off[0, 0] == 0 and (np.diff(off, axis=1) >= 0).all() and off[1, 0] == off[0, ng] and off[2, 0] == off[1, ng] and off[3, 0] == off[2, ng] and off[3, ng] == len(ev)
+    assert off[3, 1] == off[3, 0]   # (nothing is open in front of the first group)
+    assert off[1, ng] == int(is_mut.sum()) and off[2, ng] - off[2, 0] == off[1, ng] - off[1, 0]   # one start and one end per spanning event
+    pairs = (s8[is_mut] & 0x3FFFFF) * 4 + ((s8[is_mut] >> 22) & 3)
+    np.testing.assert_array_equal(np.bincount(pairs, minlength=4 * len(flat.site_ref)), np.bincount(ev[:off[1, ng]] & 0xFFFFFF, minlength=4 * len(flat.site_ref)))
+    np.testing.assert_array_equal(np.bincount(ev[off[1, 0]:off[1, ng]] & 0xFFFFFF), np.bincount(ev[off[2, 0]:off[2, ng]] & 0xFFFFFF))
+    # lists 0 and 1 follow the stream: an event is listed under the block of its own mutation word (round 6)
+    blk = lambda k: np.repeat(np.arange(ng), np.diff(off[k])) * 256 + (ev[off[k, 0]:off[k, ng]] >> 24)
+    assert (np.sort(np.concatenate([blk(0), blk(1)])) == np.flatnonzero(is_mut) >> 4).all() and blk(2).max() <= (len(s8) - 1) >> 4
+    nibs = [stream_interp.sample_site_alleles(flat, s)[0] for s in queries]
+    b3 = stream_interp.b3_tables(flat, nibs)
+    # (2) against the stream
+    _tables_never_below_the_stream_truth(flat, b3)
     # (3) exact results, more skipped
     ot = capi.OracleTree(arrays)
     sk0 = sk1 = asked = 0
@@ -597,3 +607,40 @@ def test_third_bound_tables_skip_more_and_change_nothing(seed, chunk_nodes):
             else:
                 sk1 += st.get("skipped", 0); asked += st.get("b3_asked", 0)
     assert asked > 0 and sk1 >= sk0
+
+
+@pytest.mark.parametrize("seed", [81, 82])
+def test_third_bound_tables_with_long_branches(seed):
+    """a branch with hundreds of mutations that the queries share.  Until round 6 every event of a node was listed
+    under the block of the node's HEADER word, so such a node put >= 256 range starts into one block and the table kernel's 8-bit
+    counter wrapped into its neighbour: cum_under came out as 65535 and the walk pruned a subtree that held the answer.  Now an
+    event is listed under the block of its own word: (1) no block starts more events than it has words, whatever the tile;
+    (2) ends per block stay below the 16-bit field; (3) the tables are still bounds; (4) the model of the walk returns the oracle."""
+    arrays, queries = synth.make_case(seed, n_leaves=900, n_queries=8, genome_len=4000, n_sites=900, n_ambig=(0, 0, 2),
+                                      mut_counts=(0, 1, 1, 1, 2, 3) * 8 + (300, 420))
+    nm = np.diff(np.asarray(arrays["mut_off"]))
+    assert (nm >= 300).sum() >= 5
+    flat = FlatTreeView(arrays, chunk_nodes=0)
+    ng = len(flat.b3_group_off) // 4 - 1
+    assert ng > 0, "no event lists"
+    off = flat.b3_group_off.astype(np.int64).reshape(4, ng + 1)
+    ev = flat.b3_events.astype(np.int64)
+    per_block = []
+    for k in range(3):
+        e = ev[off[k, 0]:off[k, ng]]
+        blk = np.repeat(np.arange(ng), np.diff(off[k])) * 256 + (e >> 24)
+        per_block.append(np.bincount(blk, minlength=ng * 256))
+    assert per_block[0].max() <= 16 and per_block[1].max() <= 16 and (per_block[0] + per_block[1]).max() <= 16
+    assert per_block[2].max() <= int(flat.max_path_muts) < 0x7F7F
+    # the queries below a long branch share its mutations: the pairs are useful for the tile
+    nibs = [stream_interp.sample_site_alleles(flat, s)[0] for s in queries]
+    b3 = stream_interp.b3_tables(flat, nibs)
+    assert b3["over"].max() >= 256, "no sample sits below a long branch: the case does not exercise the counters"
+    n_rec, _ = _tables_never_below_the_stream_truth(flat, b3)
+    assert n_rec > 20
+    ot = capi.OracleTree(arrays)
+    for s in queries:
+        want = ot.place(s)
+        got = stream_interp.place8(flat, s, n_groups=2, prune_ub=want["best"], stats={}, b3=b3)
+        for k in ("best", "num_best", "best_j", "has_unique"):
+            assert got[k] == want[k], k

@@ -41,7 +41,8 @@ __global__ void __launch_bounds__(256) k_b3_pairmask(const uint32_t *__restrict_
 }
 
 // the tables of one group of B3_GROUP_BLOCKS blocks for 32 tiles: per (tile, block) one LDS word counts range starts (bits 7:0), events
-// inside the block (15:8; both at most B3_BLOCK_WORDS) and range ends (31:16); thread (tile, sixteenth of the group) then turns 16
+// inside the block (15:8; both at most B3_BLOCK_WORDS: an event is listed under the block of its own mutation word, and a block has 16
+// words) and range ends (31:16; at most the mutation words of one root path, < 0x7F7F where the lists exist: ugp_flatten.cpp); thread (tile, sixteenth of the group) then turns 16
 // of them into cum_over | cum_under << 16 in place, and the block writes the rows out four bytes (two blocks) at a time.
 constexpr uint32_t B3_ROW = B3_GROUP_BLOCKS + 1;   // (padded: a wave's 32 rows fall into 32 different LDS banks)
 constexpr uint32_t B3_TB = 512, B3_CH = B3_TB / 32, B3_CB = B3_GROUP_BLOCKS / B3_CH;   // threads; scan pieces per tile row; blocks per piece

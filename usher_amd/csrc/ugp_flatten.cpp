@@ -662,13 +662,22 @@ int flatten(const ugp_tree_desc &t, const Options &opt, FlatMat &out, std::strin
     // number of mutations of that (site, allele) on the root path -- i.e. over the word range [header of the node, end of its
     // descendants), here as a range of blocks of B3_BLOCK_WORDS words.  Listed in depth-first order (deterministic).
     out.b3_group_off.clear(); out.b3_events.clear();
-    if (opt.keep_b3_events && out.n_sites && total8 > 0 && total8 < (1ull << 32) - 2 * B3_GROUP_BLOCKS * B3_BLOCK_WORDS) {
+    // (max_path_muts: the tables are 16-bit, 65535 = "no bound", and the kernel's per-block end counter is 16 bits wide; both are bounded
+    // by the mutation words of one root path + 16.  The packed walk -- the only reader -- needs max_path_muts < 0x7F7F anyway.)
+    if (opt.keep_b3_events && out.n_sites && total8 > 0 && total8 < (1ull << 32) - 2 * B3_GROUP_BLOCKS * B3_BLOCK_WORDS && out.max_path_muts < 0x7F7Fu) {
         const uint32_t ng = b3_blocks(total8) >> B3_GROUP_SHIFT;
         out.b3_group_off.assign((size_t)4 * (ng + 1), 0);
         uint32_t *off[4];
         for (int k = 0; k < 4; k++) off[k] = out.b3_group_off.data() + (size_t)k * (ng + 1);
         const uint32_t *s8 = out.stream8.data();
-        auto range_of = [&](uint64_t d, uint32_t j, uint32_t &b0, uint32_t &b1) { b0 = pos8_hdr[d] >> B3_BLOCK_SHIFT; b1 = (pos8_at[d + sub[j]] - 1u) >> B3_BLOCK_SHIFT; };
+        // An event's range starts at the block of ITS OWN word, not of the node's header (round 6): every node that counts the event
+        // on its root path -- the node itself, whose cum is read at its last word, and its descendants -- has its last word at or
+        // behind that block, so over / under stay bounds (tighter ones), and a block never starts more events than it has words:
+        // the 8-bit start / inside counters of k_b3_group_tables cannot overflow, whatever the length of a branch (a node with
+        // >= 256 mutation words useful for a tile used to wrap them).  Ends per block <= the mutation words of one root path (the
+        // nodes whose subtree ends in a block it did not start in all hold the block's first word): 16 bits, see the guard below.
+        auto word_block = [&](uint64_t d, uint32_t k) { return (uint32_t)((pos8_hdr[d] + 1u + k) >> B3_BLOCK_SHIFT); };
+        auto end_block = [&](uint64_t d, uint32_t j) { return (uint32_t)((pos8_at[d + sub[j]] - 1u) >> B3_BLOCK_SHIFT); };
         // Each thread owns one run of consecutive depth-first indices (Par::run's static split, the same in both sweeps): it counts
         // its events per (list, group), the counts become cursors (groups in order, within a group the threads in order: the lists come
         // out in depth-first order whatever the number of threads), then it writes its events at its cursors.
@@ -683,12 +692,15 @@ int flatten(const ugp_tree_desc &t, const Options &opt, FlatMat &out, std::strin
             for (uint64_t d = b; d < e; d++) {
                 const uint32_t j = d2b[d];
                 if (dropped[j] || !nw[j]) continue;
-                uint32_t b0, b1; range_of(d, j, b0, b1);
-                if (b0 == b1) c[b0 >> B3_GROUP_SHIFT] += nw[j];
-                else {
-                    c[(size_t)ng + (b0 >> B3_GROUP_SHIFT)] += nw[j]; c[(size_t)2 * ng + (b1 >> B3_GROUP_SHIFT)] += nw[j];
-                    const uint32_t g0 = (b0 >> B3_GROUP_SHIFT) + 1u, g1 = b1 >> B3_GROUP_SHIFT;   // open at the first block of groups g0 .. g1
-                    if (g0 <= g1) { c3[g0] += nw[j]; c3[g1 + 1u] -= nw[j]; }
+                const uint32_t b1 = end_block(d, j);
+                for (uint32_t k = 0; k < nw[j]; k++) {
+                    const uint32_t b0 = word_block(d, k);
+                    if (b0 == b1) c[b0 >> B3_GROUP_SHIFT]++;
+                    else {
+                        c[(size_t)ng + (b0 >> B3_GROUP_SHIFT)]++; c[(size_t)2 * ng + (b1 >> B3_GROUP_SHIFT)]++;
+                        const uint32_t g0 = (b0 >> B3_GROUP_SHIFT) + 1u, g1 = b1 >> B3_GROUP_SHIFT;   // open at the first block of groups g0 .. g1
+                        if (g0 <= g1) { c3[g0]++; c3[g1 + 1u]--; }
+                    }
                 }
             }
             uint32_t open = 0;
@@ -716,10 +728,11 @@ int flatten(const ugp_tree_desc &t, const Options &opt, FlatMat &out, std::strin
             for (uint64_t d = b; d < e; d++) {
                 const uint32_t j = d2b[d];
                 if (dropped[j] || !nw[j]) continue;
-                uint32_t b0, b1; range_of(d, j, b0, b1);
+                const uint32_t b1 = end_block(d, j);
                 for (uint32_t k = 0; k < nw[j]; k++) {
                     const uint32_t w = s8[pos8_hdr[d] + 1u + k];
                     const uint32_t pair = (w & 0x3FFFFFu) * 4u + ((w >> 22) & 3u);
+                    const uint32_t b0 = word_block(d, k);
                     if (b0 == b1) ev[c[b0 >> B3_GROUP_SHIFT]++] = pair | ((b0 & (B3_GROUP_BLOCKS - 1u)) << 24);
                     else {
                         ev[c[(size_t)ng + (b0 >> B3_GROUP_SHIFT)]++] = pair | ((b0 & (B3_GROUP_BLOCKS - 1u)) << 24);

@@ -197,9 +197,11 @@ struct FlatMat {
     UVec<uint32_t> hdr8_of_bfs, rec_of_bfs, post_of_bfs;
     // (Options::keep_b3_events) third pruning bound: the mutation events (one per mutation word of the packed body) in block order.
     // b3_events[i] = 4 * site + allele index (bits 23:0) | block within its group (31:24); list k of group g =
-    // [b3_group_off[k * (n_groups + 1) + g], ...[.. + g + 1]) with k = 0: events whose subtree (node included) lies inside one block
-    // of B3_BLOCK_WORDS packed-stream words, listed under that block; 1: the others, under the block of the node's header word;
-    // 2: the same events again, under the last block of the subtree; 3: the events that are open at the group's first block (header
+    // [b3_group_off[k * (n_groups + 1) + g], ...[.. + g + 1]) with k = 0: events whose range -- from the mutation word itself to the
+    // end of its node's subtree -- lies inside one block of B3_BLOCK_WORDS packed-stream words, listed under that block; 1: the
+    // others, under the block of the mutation word (round 6; the node's header word until then: a long branch put all its events
+    // into one block and overflowed the table kernel's 8-bit counter);
+    // 2: the same events again, under the last block of the subtree; 3: the events that are open at the group's first block (word
     // in an earlier group, subtree not over before this one: the root path's mutation words there) -- what a group needs to know of
     // everything in front of it.  n_groups = b3_blocks(stream8 words) / B3_GROUP_BLOCKS.
     std::vector<uint32_t> b3_group_off;
