@@ -264,3 +264,79 @@ extern "C" long uh_newick_digest(const char *nwk, int bulk, char *out, size_t ca
     snprintf(out, cap, "%s", text.c_str());
     return (long)text.size();
 }
+
+// Test utility (round 6, tools/pin_pb_with_reference.py): what load_mat() decoded from a parsimony.proto file, as JSON in the
+// shape of the message itself (parsimony.proto:1-31) -- newick as save_mat() would write it again, per node in depth-first
+// preorder (the order of data.node_mutations, mutation_annotated_tree.cpp:553-557) the mutations
+// [position, ref_nuc, par_nuc, [mut_nuc...], chromosome] with the nucleotides as the file's 0..3 indices (-1, -1, [] for a masked
+// mutation, :632-634) and the clade annotations, then the condensed nodes in file order.  The leaves are NOT uncondensed.  The
+// pinned dumps under tests/golden/pb_pinned/ come from the reference's own generated module (parsimony_pb2.py) reading the same bytes.
+static void json_str(std::string &o, const std::string &s) {
+    o += '"';
+    for (unsigned char c : s) {
+        if (c == '"' || c == '\\') { o += '\\'; o += (char)c; }
+        else if (c < 0x20) { char b[8]; snprintf(b, sizeof b, "\\u%04x", c); o += b; }
+        else o += (char)c;
+    }
+    o += '"';
+}
+extern "C" int uh_pb_dump(const char *pb, const char *out_path) {
+    uh::Tree T;
+    std::string err;
+    if (!uh::load_mat(pb, T, err)) { fprintf(stderr, "%s\n", err.c_str()); return 1; }
+    std::string o = "{\"newick\": ";
+    json_str(o, uh::newick(T, T.root, false, true));
+    o += ", \"node_mutations\": [";
+    const std::vector<uh::Node *> dfs = T.dfs();
+    auto idx = [](int8_t onehot) { return onehot == 1 ? 0 : onehot == 2 ? 1 : onehot == 4 ? 2 : onehot == 8 ? 3 : -1; };
+    for (size_t i = 0; i < dfs.size(); i++) {
+        o += i ? ", [" : "[";
+        bool first = true;
+        for (const uh::Mutation &m : dfs[i]->mutations) {
+            if (!first) o += ", ";
+            first = false;
+            o += "[" + std::to_string(m.position) + ", ";
+            if (m.masked()) o += "-1, -1, []";
+            else {
+                o += std::to_string(idx(m.ref_nuc)) + ", " + std::to_string(idx(m.par_nuc)) + ", [";
+                bool f2 = true;
+                for (int b = 0; b < 4; b++) if (m.mut_nuc & (1 << b)) { if (!f2) o += ", "; f2 = false; o += std::to_string(b); }
+                o += "]";
+            }
+            o += ", ";
+            json_str(o, T.chroms[m.chrom]);
+            o += "]";
+        }
+        o += "]";
+    }
+    o += "], \"metadata\": [";
+    for (size_t i = 0; i < dfs.size(); i++) {
+        o += i ? ", [" : "[";
+        for (size_t k = 0; k < dfs[i]->clade_annotations.size(); k++) { if (k) o += ", "; json_str(o, dfs[i]->clade_annotations[k]); }
+        o += "]";
+    }
+    o += "], \"condensed_nodes\": [";
+    bool first = true;
+    for (const std::string &name : T.condensed_order) {
+        if (!first) o += ", ";
+        first = false;
+        o += "[";
+        json_str(o, name);
+        o += ", [";
+        const auto &ids = T.condensed_nodes.at(name);
+        for (size_t k = 0; k < ids.size(); k++) { if (k) o += ", "; json_str(o, ids[k]); }
+        o += "]]";
+    }
+    o += "]}\n";
+    FILE *f = fopen(out_path, "wb");
+    if (!f) { fprintf(stderr, "cannot write %s\n", out_path); return 1; }
+    const bool ok = fwrite(o.data(), 1, o.size(), f) == o.size();
+    return (fclose(f) == 0 && ok) ? 0 : 1;
+}
+// load_mat() + save_mat(): a file written again from what was read (no uncondense / condense in between)
+extern "C" int uh_pb_resave(const char *pb, const char *out_path) {
+    uh::Tree T;
+    std::string err;
+    if (!uh::load_mat(pb, T, err) || !uh::save_mat(T, out_path, err)) { fprintf(stderr, "%s\n", err.c_str()); return 1; }
+    return 0;
+}

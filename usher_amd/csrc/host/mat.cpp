@@ -1622,6 +1622,9 @@ bool write_pb_from_arrays(uint64_t n, const uint32_t *parent, const uint64_t *mu
         }
         put_bytes(out, 2, ml);
     }
+    // one (empty) node_metadata per node, as save_mutation_annotated_tree always writes (:619-623); serialised behind the mutation
+    // lists (field 4).  Round 6: the file is then exactly what save_mat() gives for the same tree.
+    for (uint64_t j = 0; j < n; j++) put_bytes(out, 4, std::string());
     FILE *f = fopen(path.c_str(), "wb");
     if (!f) { err = "Could not write " + path; return false; }
     const bool ok = fwrite(out.data(), 1, out.size(), f) == out.size();
