@@ -57,6 +57,7 @@ def parse_args():
     ap.add_argument("--no-extra", action="store_true", help="skip the extra keys (BASELINE configs 3 and 4 on one device, the end-to-end CLI run)")
     ap.add_argument("--depth", type=int, default=0, help="overlapped calls kept on the device at a time (2..4; 0 = the library's default)")
     ap.add_argument("--repeats", type=int, default=3, help="windows of --steps steps timed in all (`value` is the MEDIAN window; min / max are extra keys)")
+    ap.add_argument("--dump-gathered", default="", help="test hook: rank 0 writes the records gathered by the first window's last step (all ranks' shards, padded) to this .npz")
     ap.add_argument("--qsets", type=int, default=4, help="distinct uploaded query sets the timed loop rotates through (no step places the samples of the step before it)")
     return ap.parse_args()
 
@@ -138,6 +139,112 @@ def stored_profile(info, Q, packed):
     except Exception:
         pass
     return None, {}, None
+
+
+VALU_LANE_OPS_PER_S = 256 * 4 * 16 * 2.4e9   # 256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz: int32 lane-operations per second (~3.9e13)
+
+
+def stored_dense_profile():
+    """Counters of the UNPRUNED walk from the newest committed profile of `UGP_NO_PRUNE=1 bench.py --queries 2048`
+    (tools/profile_round.sh rNN_dense "--queries 2048" -> profiles/rNN_dense_pmc_summary.json); {} when absent."""
+    try:
+        for fn in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_dense_pmc_summary.json")), reverse=True):
+            with open(fn) as f:
+                ps = json.load(f)
+            k = max((v for n, v in ps.get("kernels", {}).items() if n.startswith("ugp::k_best8")), key=lambda v: v.get("avg_duration_ns_full_dispatch", 0.0), default={})
+            if k:
+                return os.path.basename(fn), k, ps.get("bench", {}).get("config", {})
+    except Exception:
+        pass
+    return None, {}, {}
+
+
+def dense_walk(pl, st, batch, res_pruned, info, dev, stream, nq=2048):
+    """k_best8 with pruning OFF (UGP_NO_PRUNE: no bounds, no locality pre-pass, every tile walks every word of the packed stream) on
+    the bench's own tree for the first `nq` queries of set 0: HIP-event time of the kernel, results equal to the pruned path's.
+    THIS is the kernel SURVEY 7.1 prices (28 lane-ops per node evaluation, VALU-issue bound) and the one whose algorithmic bytes
+    (one tree pass per tile) are really moved -- its fractions are the walk's roofline credit; the headline's are nominal."""
+    import torch
+    nq = min(nq, len(batch))
+    sub = batch.slice(0, nq)
+    out = torch.zeros((nq, 4), dtype=torch.int32, device=dev)
+    os.environ["UGP_NO_PRUNE"] = "1"
+    hq = None
+    try:
+        pl.reload_knobs()
+        hq = pl.upload(sub)
+        pl.place_device(hq, out.data_ptr(), stream)
+        torch.cuda.synchronize()
+        pl.timing_sum()
+        t0 = time.perf_counter()
+        n_rep = 3
+        for _ in range(n_rep):
+            pl.place_device(hq, out.data_ptr(), stream)
+        torch.cuda.synchronize()
+        wall = (time.perf_counter() - t0) / n_rep
+        tmd = pl.timing_sum()
+    finally:
+        os.environ.pop("UGP_NO_PRUNE", None)
+        pl.reload_knobs()
+        if hq is not None:
+            pl.free_qset(hq)
+    k_ms = tmd["place_ms"] / max(1, tmd["calls"])
+    tiles = (nq + 511) // 512
+    same = bool((out.cpu().numpy()[:nq] == res_pruned[:nq]).all())
+    algo = tiles * (info["algo_tree_bytes"] + 512 * info["algo_tile_bytes"])
+    evals = float(nq) * (info["n_nodes"] + info["n_muts"])
+    node_evals = float(nq) * info["n_nodes"]
+    d = {"what": "k_best8 with UGP_NO_PRUNE=1 (no bounds, no pre-pass): every tile of 512 samples walks the whole packed stream",
+         "samples": nq, "tiles": tiles, "packed_path": int(tmd["packed_path"]) and 1, "kernel_ms": round(k_ms, 3), "call_wall_ms": round(wall * 1e3, 3),
+         "placements_per_s": round(nq / (k_ms * 1e-3), 1) if k_ms > 0 else None, "identical_to_pruned_path": same,
+         "algo_bytes_per_launch": int(algo), "hbm_frac_algorithmic": round(algo / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if k_ms > 0 else None,
+         "node_plus_mut_evals_per_s": round(evals / (k_ms * 1e-3), 1) if k_ms > 0 else None,
+         # SURVEY 7.1's yardstick: lane-operations the chip could issue per (node, sample) evaluation at this rate -- its budget for a
+         # straightforward kernel is 28 at 100 % VALU issue (= 140 k placements/s at 10 M nodes)
+         "valu_lane_ops_available_per_node_eval": round(VALU_LANE_OPS_PER_S * (k_ms * 1e-3) / node_evals, 3) if k_ms > 0 else None,
+         "survey_7_1": {"lane_ops_per_node_eval_budget": 28, "placements_per_s_at_full_issue": round(VALU_LANE_OPS_PER_S / 28 / info["n_nodes"], 1)}}
+    name, k, cfg = stored_dense_profile()
+    if k and cfg.get("nodes") == int(info["n_nodes"]):
+        pq = cfg.get("queries_per_gpu") or nq
+        p_ms = k.get("avg_duration_ns_full_dispatch", 0.0) * 1e-6
+        p_tiles = (pq + 511) // 512
+        p_algo = p_tiles * (info["algo_tree_bytes"] + 512 * info["algo_tile_bytes"])
+        traffic = k.get("hbm_read_bytes_per_dispatch_corrected", 0.0) + k.get("hbm_write_bytes_per_dispatch", 0.0)
+        valu = k.get("SQ_INSTS_VALU_per_dispatch")
+        d["profile"] = {"source": name, "samples": pq, "kernel_ms": round(p_ms, 3),
+                        "hbm_bytes_by_counters": int(traffic), "counter_over_algorithmic_bytes": round(traffic / p_algo, 3) if p_algo else None,
+                        "measured_hbm_frac": round(traffic / (p_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if p_ms > 0 else None,
+                        "l2_hit_rate": k.get("l2_hit_rate"),
+                        "valu_active_frac": k.get("valu_active_frac_measured"), "salu_busy_frac": k.get("salu_busy_frac_measured"),
+                        "valu_issue_frac": k.get("valu_issue_frac"), "salu_issue_frac": k.get("salu_issue_frac"), "wave_wait_frac": k.get("wave_wait_frac"),
+                        # wave64 VALU instructions x 64 lanes / (node, sample) evaluations: what the kernel SPENDS, against SURVEY 7.1's 28
+                        "valu_lane_ops_per_node_eval": round(valu * 64.0 / (float(pq) * info["n_nodes"]), 3) if valu else None,
+                        "valu_lane_ops_per_node_plus_mut_eval": round(valu * 64.0 / (float(pq) * (info["n_nodes"] + info["n_muts"])), 3) if valu else None}
+    return d
+
+
+def far_pruned_frac(st, dev_index, nq=16384):
+    """Fraction of the packed stream's words the main walk jumps over for a batch of far queries and for a batch of the headline's
+    queries (the instrumented build of the library, UGP_STATS=1: one call each on a handle of its own)."""
+    import torch
+    from usher_amd import Placer, QueryBatch
+    os.environ["UGP_STATS"] = "1"
+    pe = None
+    try:
+        pe = Placer(st.arrays, device=dev_index, experiments=True)
+        out = {}
+        for name, kw in (("far", dict(max_subst=200, min_subst=50, ref_every_8th=True)), ("headline", {})):
+            qq = st.queries(nq, seed=9001, **kw)
+            b_ = QueryBatch.from_csr(qq["ent_off"], qq["pos"], qq["ref"], qq["nuc"], qq["is_missing"])
+            for _ in range(2):
+                pe.place(b_)
+            t_ = pe.timing()
+            out[name] = round(t_["words_skipped"] / t_["words_total"], 5) if t_.get("words_total") else None
+        return out
+    finally:
+        os.environ.pop("UGP_STATS", None)
+        if pe is not None:
+            pe.close()
 
 
 def main():
@@ -251,25 +358,21 @@ def main():
     # Two output buffers used alternately: consecutive ugp_place_device_overlapped calls share the device, and call k + 2 is
     # ordered behind whatever the caller's stream held when call k + 1 was made -- the all-gather that reads call k's buffer
     # included (include/usher_amd.h: one call of lag).  (shards differ by at most one sample: padded to `cap`)
-    depth = pl.pipeline_depth()
-    outs = [torch.zeros((cap, 4), dtype=torch.int32, device=dev) for _ in range(depth)]
-    gathered = torch.zeros((world * cap, 4), dtype=torch.int32, device="cpu" if share else dev) if world > 1 else None
+    # The step IS the package's multi-GPU entry (usher_amd.dist.ShardedPlacer): the resident shard placed by
+    # ugp_place_device_overlapped straight into a device tensor, that tensor all-gathered on the device (RCCL), one output tensor per
+    # call in flight (include/usher_amd.h: a call is ordered behind what the stream held depth - 1 calls ago -- the all-gather that
+    # reads call k's tensor included).  (shards differ by at most one sample: padded to `cap`)
+    from usher_amd.dist import ShardedPlacer
+    sp = ShardedPlacer(pl, gather_on_host=share, device_index=dev_index)
+    depth = sp.depth
+    outs, gathered = sp.buffers(cap)
     stream = torch.cuda.current_stream().cuda_stream
     n_step = [0]
-    gather_s = [0.0]
 
     def step():
-        out = outs[n_step[0] % depth]
         qs_k = qsets[n_step[0] % n_sets]
         n_step[0] += 1
-        if args.no_overlap:
-            pl.place_device(qs_k, out.data_ptr(), stream)
-        else:
-            pl.place_device_overlapped(qs_k, out.data_ptr(), stream)
-        if world > 1:
-            tg = time.perf_counter()
-            dist.all_gather_into_tensor(gathered, out.cpu() if share else out)
-            gather_s[0] += time.perf_counter() - tg   # (host time spent issuing the collective; it runs behind the call's completion)
+        sp.step(qs_k, cap, overlapped=not args.no_overlap, stream=stream)
 
     for _ in range(args.warmup):
         step()
@@ -289,6 +392,9 @@ def main():
     last_out = outs[(n_step[0] - 1) % depth]
     last_set = (n_step[0] - 1) % n_sets
     res_last = last_out.cpu().numpy()[:Q].copy()   # (results of the timed region's last step: query set `last_set`)
+    if args.dump_gathered and rank == 0:   # (tests/test_multi_gpu.py checks every rank's shard of this against the closed form)
+        g = (gathered if world > 1 else last_out).cpu().numpy()
+        np.savez(args.dump_gathered, records=g, cap=cap, world=world, last_set=last_set, total=total_q, seed=args.seed, strong=int(args.strong))
     # HIP events recorded by the library on the streams its kernels ran on, summed over the timed steps
     tm = pl.timing_sum()
     assert tm["calls"] == args.steps, tm
@@ -420,27 +526,38 @@ def main():
     if world == 1 and headline and not args.no_extra:
         extra = {}
 
-        def timed_config(placer, tree, nq, steps, warm, ties_cap=0, **qkw):
-            qq = tree.queries(nq, seed=args.seed * 1000 + 4, **qkw)
-            bb = QueryBatch.from_csr(qq["ent_off"], qq["pos"], qq["ref"], qq["nuc"], qq["is_missing"])
-            hq = placer.upload(bb)
+        def timed_config(placer, tree, nq, steps, warm, ties_cap=0, n_rot=3, **qkw):
+            # (round 6) like the headline, the timed loop ROTATES through n_rot distinct uploaded query sets: no step places the samples --
+            # or walks the tree regions -- of the step before it
+            hqs, bb = [], None
+            for r_ in range(max(1, n_rot)):
+                qq = tree.queries(nq, seed=args.seed * 1000 + 4 + 104729 * r_, **qkw)
+                b_ = QueryBatch.from_csr(qq["ent_off"], qq["pos"], qq["ref"], qq["nuc"], qq["is_missing"])
+                hqs.append(placer.upload(b_))
+                if r_ == 0:
+                    bb = b_
+                del qq
             dd = placer.pipeline_depth()
             oo = [torch.zeros((nq, 4), dtype=torch.int32, device=dev) for _ in range(dd)]
             for k in range(warm):
-                placer.place_device_overlapped(hq, oo[k % dd].data_ptr(), stream)
+                placer.place_device_overlapped(hqs[k % len(hqs)], oo[k % dd].data_ptr(), stream)
             torch.cuda.synchronize()
             placer.timing_sum()
             tq = time.perf_counter()
             for k in range(steps):
-                placer.place_device_overlapped(hq, oo[k % dd].data_ptr(), stream)
+                placer.place_device_overlapped(hqs[k % len(hqs)], oo[k % dd].data_ptr(), stream)
             torch.cuda.synchronize()
             tq = time.perf_counter() - tq
             tmq = placer.timing_sum()
             strict = torch.zeros((nq, 4), dtype=torch.int32, device=dev)
-            placer.place_device(hq, strict.data_ptr(), stream)   # the stream-ordered entry point, one call alone
+            placer.place_device(hqs[(steps - 1) % len(hqs)], strict.data_ptr(), stream)   # the stream-ordered entry point, one call alone, the last step's set
             torch.cuda.synchronize()
             same = bool((strict == oo[(steps - 1) % dd]).all().item())
-            placer.free_qset(hq)
+            if (steps - 1) % len(hqs) != 0:   # (the tie lists below are of set 0)
+                placer.place_device(hqs[0], strict.data_ptr(), stream)
+                torch.cuda.synchronize()
+            for h_ in hqs:
+                placer.free_qset(h_)
             ties = None
             if ties_cap:   # tie reporting (-M / -D of the CLI): ugp_tied_nodes from and to host buffers, wall time of the second call
                 import ctypes as C
@@ -452,13 +569,13 @@ def main():
                     tt1 = time.perf_counter()
                 ties = {"entry": "ugp_tied_nodes (host buffers in, host buffers out)", "cap": ties_cap, "wall_ms": round((tt1 - tt0) * 1e3, 2),
                         "samples_with_ties": int((tcnt > 1).sum()), "counts_equal_num_best": bool((tcnt == strict[:, 1].cpu().numpy().astype(np.uint32)).all())}
-            return {**({"tie_lists": ties} if ties else {}), "queries": nq, "steps": steps, "placements_per_s": round(nq * steps / tq, 2), "ms_per_step": round(tq * 1e3 / steps, 3),
+            return {**({"tie_lists": ties} if ties else {}), "queries": nq, "steps": steps, "query_sets_rotated": len(hqs), "third_bound_steps": int(tmq.get("bound3", 0)), "placements_per_s": round(nq * steps / tq, 2), "ms_per_step": round(tq * 1e3 / steps, 3),
                     "k_best8_ms": round(tmq["place_ms"] / max(1, tmq["calls"]), 4), "sub_batches": int(tmq["place_launches"] // max(1, tmq["calls"])),
                     "identical_to_stream_ordered_call": same}
 
         # config 4's workload on one device: 1,000,000 queries on the 10M-node tree in one call (4 sub-batches of 262,144)
         try:   # (an extra key must never cost the bench line)
-            c4 = timed_config(pl, st, 1_000_000, 4, 3)   # (3 warm-up calls: every workspace set a long call cycles through is allocated before the clock starts)
+            c4 = timed_config(pl, st, 1_000_000, 4, 3, n_rot=2)   # (3 warm-up calls: every workspace set a long call cycles through is allocated before the clock starts)
             c4["workload"] = "BASELINE config 4 on one device: 1,000,000 queries on the %d-node MAT, one ugp_place_device_overlapped call per step" % info["n_nodes"]
             extra["config4_1m_queries_one_gpu"] = c4
         except Exception as ex:
@@ -471,6 +588,19 @@ def main():
             extra["config5_high_ambiguity_one_gpu"] = c5
         except Exception as ex:
             extra["config5_high_ambiguity_one_gpu"] = {"error": repr(ex)[:300]}
+        # ---- (round 6) the walk WITHOUT pruning -- the dense path SURVEY 7.1 budgets -- and queries far from the tree
+        try:
+            extra["dense_walk"] = dense_walk(pl, st, batch, res, info, dev, stream)
+        except Exception as ex:
+            extra["dense_walk"] = {"error": repr(ex)[:300]}
+        try:
+            fq = timed_config(pl, st, 16384, 12, 6, n_rot=3, max_subst=200, min_subst=50, ref_every_8th=True)
+            fq["workload"] = ("16,384 queries per step that are NOT near any node: a random node's genotype + 50-200 substitutions (70 %% at the tree's variable sites), "
+                              "every 8th the all-reference sample; %d-node MAT" % info["n_nodes"])
+            fq["pruned_frac"] = far_pruned_frac(st, dev_index)
+            extra["far_queries"] = fq
+        except Exception as ex:
+            extra["far_queries"] = {"error": repr(ex)[:300]}
         # the drop-in CLI end to end: the same tree as parsimony.proto, 10,000 queries as a VCF, `usher-amd -i .. -v .. -n` (load the
         # MAT, read the VCF, flatten + upload, place, write placement_stats.tsv and the tree) -- wall time of the whole process
         try:
@@ -649,7 +779,7 @@ def main():
             "value_pcie_inclusive": (host_path or {}).get("two_in_flight", {}).get("placements_per_s") if host_path and host_path.get("two_in_flight") else None,
             "per_rank": {"flatten_upload_s": flat_all, "flatten_threads": os.environ.get("UGP_FLATTEN_THREADS") or "library default", "flattened_once_per_node": bool(flat_file),
                          "all_gather_ms": gather_ms, "all_gather_bytes": int(world * cap * 16) if world > 1 else None,
-                         "gather_issue_ms_per_step": round(gather_s[0] * 1e3 / max(1, n_step[0]), 4) if world > 1 else None},
+                         "gather_issue_ms_per_step": round(sp.gather_host_s * 1e3 / max(1, n_step[0]), 4) if world > 1 else None},
             "other_configs": extra,
             "roofline": roofline, "cpu_baseline": cpu,
             # `value` has the query rows resident in HBM when the timed region starts (bench contract); the same batch through

@@ -29,7 +29,11 @@ def main():
     q = st.queries(5001, seed=99, n_lo=0, n_hi=30, iupac_hi=3)      # odd count: shards differ in size
     batch = QueryBatch.from_csr(q["ent_off"], q["pos"], q["ref"], q["nuc"], q["is_missing"])
     pl = Placer(st.arrays, device=dev_index)
-    res = place_sharded(pl.place, batch, device=None if share else "cuda")
+    # the Placer itself: the device path (resident shard -> ugp_place_device into a device tensor -> all-gather of that tensor)
+    res = place_sharded(pl, batch, device="cpu" if share else None)
+    # more ranks than samples: the empty shards still join the gather
+    tiny = place_sharded(pl, batch.slice(0, 1), device="cpu" if share else None)
+    assert len(tiny) == 1 and (tiny.view(np.int32) == res[:1].view(np.int32)).all()
     pl.close()
     cf = capi.ClosedFormC(capi.OracleTree(st.arrays)).place_csr(q["ent_off"], q["pos"], q["ref"], q["nuc"], q["is_missing"])
     ok = (res["best_set_difference"].astype(np.int64) == cf["best"]).all() and (res["num_best"].astype(np.int64) == cf["num_best"]).all() \

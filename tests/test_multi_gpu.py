@@ -113,6 +113,54 @@ def test_bench_multi_rank_flow_on_one_box(ranks, tmp_path):
     assert max(pr["flatten_upload_s"]) <= 1.2 * min(pr["flatten_upload_s"]) + 1.0, pr     # (+1 s: at this size the figure is mostly process noise)
 
 
+def test_config4_strong_scaling_flow_every_shard_against_the_closed_form(tmp_path):
+    """BASELINE config 4's workload as the driver's 8-GPU run launches it -- `bench.py --gpus 8 --strong --queries 1000000`: one global
+    batch of 1 M queries, every rank owns a contiguous shard (125 000), places it with ugp_place_device_overlapped from HBM into a
+    device tensor and joins the all-gather (usher_amd.dist.ShardedPlacer -- the package's exported path IS the benchmarked one).  On
+    a box with fewer GPUs the ranks share the device (BENCH_SHARE_DEVICE: gloo carries the gather).  The gathered records of the
+    timed region's last step -- all eight shards, 1 M records -- must equal one handle's answers for the whole batch, and 48 samples per
+    shard the C closed form's."""
+    import json
+    from oracle import capi
+    from usher_amd import synth
+    from usher_amd.dist import shard_bounds
+    ranks, nodes, total = 8, 2_000_000, 1_000_000
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    if _n_devices() < ranks:
+        env["BENCH_SHARE_DEVICE"] = "1"
+    dump = str(tmp_path / "gathered.npz")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(ranks), "--nodes", str(nodes), "--queries", str(total), "--steps", "2",
+                        "--warmup", "1", "--strong", "--repeats", "1", "--qsets", "2", "--no-extra", "--cpu-queries", "0", "--dump-gathered", dump],
+                       capture_output=True, text=True, timeout=1800, env=env)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert d["n_gpus"] == ranks and d["scaling"] == "strong" and d["config"]["queries_total"] == total
+    z = np.load(dump)
+    cap, world, last_set = int(z["cap"]), int(z["world"]), int(z["last_set"])
+    assert world == ranks and cap == (total + ranks - 1) // ranks and z["records"].shape == (ranks * cap, 4)
+    st = synth.SynthTree(nodes, n_sites=25000, seed=int(z["seed"]))
+    q = st.queries(total, seed=int(z["seed"]) * 1000 + 17 + 7919 * last_set)        # (bench.py draw(): the global batch of a --strong run)
+    # every one of the 1 M records against ONE handle placing the whole batch in this process (sharding, padding and gather lose or
+    # move nothing), and 48 samples of every rank's shard -- first, last and spread -- against the C closed form (6 ms per sample here)
+    from usher_amd import Placer, QueryBatch
+    pl = Placer(st.arrays)
+    one = pl.place(QueryBatch.from_csr(q["ent_off"], q["pos"], q["ref"], q["nuc"], q["is_missing"]))
+    pl.close()
+    cfc = capi.ClosedFormC(capi.OracleTree(st.arrays))
+    for rk in range(ranks):
+        lo, hi = shard_bounds(total, ranks, rk)
+        rec = z["records"][rk * cap: rk * cap + (hi - lo)]
+        assert (rec == one[lo:hi].view(np.int32).reshape(-1, 4)).all(), rk
+        pick = np.unique(np.concatenate([[lo, hi - 1], np.linspace(lo, hi - 1, 46).astype(np.int64)]))
+        off = q["ent_off"].astype(np.int64)
+        idx = np.concatenate([np.arange(off[i], off[i + 1]) for i in pick])
+        sub_off = np.zeros(len(pick) + 1, np.uint64); sub_off[1:] = np.cumsum(off[pick + 1] - off[pick])
+        cf = cfc.place_csr(sub_off, q["pos"][idx], q["ref"][idx], q["nuc"][idx], q["is_missing"][idx])
+        got = z["records"][rk * cap + (pick - lo)]
+        assert (got[:, 0].astype(np.int64) == cf["best"]).all() and (got[:, 1].astype(np.int64) == cf["num_best"]).all(), rk
+        assert (got[:, 2].astype(np.int64) == cf["best_j"]).all() and (got[:, 3].astype(bool) == cf["has_unique"].astype(bool)).all(), rk
+
+
 def test_flattening_saved_once_and_uploaded_from_a_file(tmp_path, monkeypatch):
     """ugp_flat_save / ugp_mat_create_from_flat (one flattening for the ranks of a node): a handle made from the file answers like
     one made from the arrays -- placements, tie lists, an extended search and the add-mode exclusion maps; a file written under other

@@ -83,3 +83,52 @@ def test_follows_a_change(tmp_path):
     bl = _blocks(_run(tmp_path, 6 * 140, 1.0, 1.1, 6 * 40, 1.3, 1.0)[0])
     assert sum(bl[4:40]) >= 33
     assert sum(bl[100:]) <= 4, bl[100:]
+
+
+STATIC_DRIVER = r"""
+#include <cstdio>
+#include <cstdlib>
+#include "ugp_tuner.hpp"
+#include "ugp_knobs.hpp"
+int main(int argc, char **argv) {
+    // the static rule for every (tree shape, batch class), then what the knob parser makes of UGP_BOUND3
+    for (int poly = 0; poly < 2; poly++) { for (int c = 0; c < 3; c++) putchar(ugp::b3_static_choice(poly != 0, c) ? '1' : '0'); putchar(' '); }
+    printf("%d\n", ugp::Knobs::from_env().bound3);
+    // two classes taking turns: no block of either ever completes, nothing is ever recorded
+    ugp::B3Tuner T;
+    for (int i = 0; i < 600; i++) { uint32_t pos; uint64_t sq; putchar(T.next(i & 1 ? 2 : 0, &pos, &sq) ? '1' : '0'); }
+    putchar('\n');
+    return 0;
+}
+"""
+
+
+def _static(tmp_path, env_value):
+    src, exe = tmp_path / "static_driver.cpp", tmp_path / "static_driver"
+    if not exe.exists():
+        src.write_text(STATIC_DRIVER)
+        subprocess.run(["g++", "-O1", "-std=c++17", "-I", os.path.join(ROOT, "usher_amd", "csrc"), str(src), "-o", str(exe)], check=True)
+    env = {k: v for k, v in os.environ.items() if k != "UGP_BOUND3"}
+    if env_value is not None:
+        env["UGP_BOUND3"] = env_value
+    return subprocess.run([str(exe)], capture_output=True, text=True, check=True, env=env).stdout.split("\n")
+
+
+def test_static_choice_and_the_knob(tmp_path):
+    """Round 6: by default the third bound is decided from the tree's shape and the batch's class -- no A/B in
+    the caller's steps: every call of a kind runs the same way from the first one on.  UGP_BOUND3=auto keeps the run-time tuner,
+    1 / 0 pin it."""
+    out = _static(tmp_path, None)
+    rule, knob = out[0].split()[:2], out[0].split()[2]
+    assert rule == ["111", "001"]        # random-attachment shape: always; polytomy-dominated shape: only for hundreds of rows per sample
+    assert knob == "-2"
+    assert _static(tmp_path, "auto")[0].split()[2] == "-1"
+    assert _static(tmp_path, "1")[0].split()[2] == "1" and _static(tmp_path, "0")[0].split()[2] == "0"
+
+
+def test_tuner_never_pins_a_mode_it_has_no_figure_for(tmp_path):
+    """classes of batches that take turns reopen the tuner's block at every call, so no block completes and nothing is
+    recorded; behind the four trial blocks the mode used to stay `with` for good, unmeasured.  It keeps alternating now."""
+    modes = _static(tmp_path, "auto")[1]
+    tail = modes[100:]
+    assert 0.3 < tail.count("1") / len(tail) < 0.7

@@ -283,7 +283,12 @@ ugs_queries *ugs_queries_create2(const ugs_tree *t, uint64_t n_queries, uint64_t
             row_of_pos[p] = (int32_t)rows.size();
             rows.push_back({p, nuc, missing});
         };
-        uint32_t ns = max_subst ? (uint32_t)rng.below(max_subst + 1) : 0;
+        // `recent` carries more switches (round 6, "far" queries: samples that are NOT near any node of the tree): bits 31:8 = the least
+        // number of substitutions (the count is then uniform in [min, max_subst]); bit 2 = every 8th sample is the all-reference
+        // sample -- no rows at all
+        const uint32_t min_subst = std::min(recent >> 8, max_subst);
+        uint32_t ns = max_subst ? min_subst + (uint32_t)rng.below(max_subst - min_subst + 1) : 0;
+        if ((recent & 4u) && (i & 7u) == 7u) { rows.clear(); ns = 0; for (uint32_t v = node; v != UINT32_MAX; v = t->parent[v]) for (uint64_t m = t->mut_off[v]; m < t->mut_off[v + 1]; m++) row_of_pos[t->mut_pos[m]] = -1; }
         for (uint32_t k = 0; k < ns; k++) {
             int32_t p = (rng.below(10) < 3) ? (int32_t)(1 + rng.below(L)) : (int32_t)t->sites[rng.below(t->sites.size())];
             uint8_t curr = kOneHot[t->ref[p]];

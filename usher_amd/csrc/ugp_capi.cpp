@@ -214,8 +214,10 @@ struct ugp_mat {
         ugp::B3Dev b3_host = {};
         DevBuf<uint64_t> d_stats, d_trace;
         uint64_t last_words_total = 0;
+        const uint32_t *last_nitems = nullptr;   // (statistics) phase 2's item counter of the last launch sequence
         const uint32_t *last_list_n = nullptr;   // (UGP_STATS) record counts of the last packed launch, per 512-sample tile
         uint32_t last_list_tiles = 0;
+        DevBuf<uint32_t> d_dnode, d_dres, d_luniq, d_gcnt, d_gcnt_part;   // phase 2 without a walk for single-node minima (Phase2Uniq)
         DevBuf<uint32_t> d_refined, d_keys, d_keys2, d_idx, d_order, d_slot, d_bins;
         DevBuf<ugp_result> d_coarse_res, d_prev_res;
         uint64_t prev_serial = 0;   // (UGP_SEED_PREV / UGP_SEED_CHECK diagnostics) content serial of the query set d_prev_res belongs to; 0 = none
@@ -432,12 +434,36 @@ int run_place(ugp_mat *m, ugp_qset *qs, int mode, ugp_result *d_out, int32_t *d_
         // Third pruning bound (round 5): for the sorted main walk of batches of up to 256 tiles, when the tree carries its posting lists
         // and the tiles are built by the scatter kernels (they mark the tile's useful (site, allele) pairs)
         const uint32_t useful_words = (n_sites + 7) / 8;
-        const bool b3_can = use8 && !coarse_only && sorted && m->d_b3_events.p && !K.no_bound3 && K.bound3 != 0 && !K.no_prune && n_tiles512 <= 256 && K.tile_build <= 0;
+        // (what the walk will be launched with is decided here, in front of the tile build: a batch whose walk keeps its active-row
+        // bitmap in LDS -- lds_bits == 1 -- has no third-bound variant, and building the tables for it, or letting the tuner book
+        // the batch as one "with", would be cost without effect: ADVICE r5)
+        int nmi = -1;   // the query set carries N masks for this tree
+        for (int i = 0; i < 2; i++) if (qs->nmask_for[i] == m && use8 && n_sites) nmi = i;
+        const uint64_t e0 = qs->ent_off[q0], e1 = qs->ent_off[q0 + nq];
+        // many rows per sample (high-ambiguity queries): the (tile, site block)-in-LDS builder; otherwise fill + one atomic per row
+        // (only for batches in arrival order, i.e. the coarse pass: consecutive threads then read neighbouring row lists; behind
+        // the locality sort the builder's uncoalesced row reads cost more than the scatter's atomics -- measured on config 5:
+        // coarse pass 2.72 -> 2.33 ms, sorted build 1.77 -> 2.03 ms)
+        bool lds_build = use8 && n_sites && !sorted && (e1 - e0) >= (uint64_t)nq * 128;
+        if (K.tile_build >= 0) lds_build = use8 && n_sites && K.tile_build != 0;
+        uint32_t lds_bits_plan = 0;
+        if (use8) {
+            const bool stats_on = K.stats;
+            lds_bits_plan = (!stats_on && (size_t)active_words * 4 <= 4096 && n_tiles512 >= 64 && !m->sharing) ? 1u : 0u;
+            if (nmi >= 0 && !stats_on) lds_bits_plan = 2u;
+            if (K.lds_bits >= 0) lds_bits_plan = stats_on ? 0u : (K.lds_bits == 2 ? 2u : (((size_t)active_words * 4 <= 4096 && K.lds_bits != 0) ? 1u : 0u));
+        }
+        const bool b3_can = use8 && !coarse_only && sorted && m->d_b3_events.p && !K.no_bound3 && K.bound3 != 0 && !K.no_prune && n_tiles512 <= 256 && K.tile_build <= 0 &&
+                            lds_bits_plan != 1u && !(lds_build && nmi < 0);
         bool b3_want = b3_can;
-        const int b3_class = B3Tuner::class_of(qs->ent_off[q0 + nq] - qs->ent_off[q0], nq);
+        const int b3_class = B3Tuner::class_of(e1 - e0, nq);
         uint32_t b3_pos = 0;
         uint64_t b3_seq = 0;
-        if (b3_can && K.bound3 < 0) { tuner_poll(m); b3_want = m->b3_tuner.next(b3_class, &b3_pos, &b3_seq); }
+        // UGP_BOUND3 unset: decided from what is known of the tree and of the batch (ugp_tuner.hpp b3_static_choice) -- every call of a
+        // kind runs the same way from the first one on; UGP_BOUND3=auto: the handle's run-time A/B (B3Tuner); 1 / 0: pinned
+        const bool b3_tuned = b3_can && K.bound3 == -1;
+        if (b3_tuned) { tuner_poll(m); b3_want = m->b3_tuner.next(b3_class, &b3_pos, &b3_seq); }
+        else if (b3_can && K.bound3 < -1) b3_want = ugp::b3_static_choice(m->wide_descent, b3_class);
         const size_t z_dbottom = 0, z_active = z_dbottom + (size_t)n_tiles512 * 512, z_queue = z_active + (size_t)n_tiles512 * active_words,
                      z_list_n = z_queue + 8, z_nitems = z_list_n + n_tiles512, z_cnt = z_nitems + 8, z_key = z_cnt + (size_t)n_tiles512 * 512,
                      z_useful = z_key + (size_t)n_tiles512 * 512, z_end = z_useful + (b3_want ? (size_t)n_tiles512 * useful_words : 0);
@@ -464,7 +490,6 @@ int run_place(ugp_mat *m, ugp_qset *qs, int mode, ugp_result *d_out, int32_t *d_
         EventSet &es = TG.events[TG.events_used++];
         es.b3_class = -1;   // (set behind this sub-batch's last event record: until then the events still hold their previous use)
         es.b3_used = b3_want; es.b3_tiles = n_tiles512; es.b3_pos = b3_pos; es.b3_seq = b3_seq; es.b3_first = m->b3_tuner.first;
-        const uint64_t e0 = qs->ent_off[q0], e1 = qs->ent_off[q0 + nq];
 
         HIP_TRY(hipEventRecord(es.ev[0], s));
         const uint32_t *slot_of = nullptr, *order = nullptr;
@@ -480,14 +505,6 @@ int run_place(ugp_mat *m, ugp_qset *qs, int mode, ugp_result *d_out, int32_t *d_
             slot_of = W.d_slot.p; order = W.d_order.p;
         }
         HIP_TRY(hipMemsetAsync(W.d_zero.p, 0, z_end * sizeof(uint32_t), s));
-        // many rows per sample (high-ambiguity queries): the (tile, site block)-in-LDS builder; otherwise fill + one atomic per row
-        // (only for batches in arrival order, i.e. the coarse pass: consecutive threads then read neighbouring row lists; behind
-        // the locality sort the builder's uncoalesced row reads cost more than the scatter's atomics -- measured on config 5:
-        // coarse pass 2.72 -> 2.33 ms, sorted build 1.77 -> 2.03 ms)
-        bool lds_build = use8 && n_sites && !order && (e1 - e0) >= (uint64_t)nq * 128;
-        if (K.tile_build >= 0) lds_build = use8 && n_sites && K.tile_build != 0;
-        int nmi = -1;   // the query set carries N masks for this tree
-        for (int i = 0; i < 2; i++) if (qs->nmask_for[i] == m && use8 && n_sites) nmi = i;
         if (nmi >= 0) {
             HIP_TRY(ugp::launch_ntiles(W.d_table.p, d_active, active_words, n_tiles512, qs->d_nmask[nmi].p, qs->nmask_words[nmi], order, (uint32_t)q0, (uint32_t)nq,
                                        m->d_site_ref.p, n_sites, s));
@@ -505,7 +522,7 @@ int run_place(ugp_mat *m, ugp_qset *qs, int mode, ugp_result *d_out, int32_t *d_
                                     f.max_pos, n_sites, e1 - e0, (uint32_t)q0, d_active, active_words, slot_of, qs->d_err.p, d_useful, useful_words, s));
         }
         // third pruning bound: the events of every tile's useful pairs -> block tables (ugp_bound3.hip)
-        const bool b3_on = b3_want && !(lds_build && nmi < 0);
+        const bool b3_on = b3_want;
         if (b3_on) {
             const uint32_t nb = ugp::b3_blocks(m->stream8_dwords), n_l1 = ugp::b3_div64(nb), n_l2 = ugp::b3_div64(n_l1), n_l3 = ugp::b3_div64(n_l2);
             HIP_TRY(W.d_b3_pairmask.reserve((size_t)((n_tiles512 + 31) / 32) * n_sites * 4));
@@ -521,23 +538,30 @@ int run_place(ugp_mat *m, ugp_qset *qs, int mode, ugp_result *d_out, int32_t *d_
             HIP_TRY(ugp::launch_b3_tables(d_useful, useful_words, n_sites, n_tiles512, m->d_b3_group_off.p, m->d_b3_events.p, nb, W.d_b3_pairmask.p,
                                           W.d_b3_over.p, W.d_b3_under.p, W.d_b3_l1.p, W.d_b3_l2.p, W.d_b3_l3.p, s));
         }
+        // phase 2 without a walk for the samples whose minimum is attained by one node (ugp_kernels.hpp Phase2Uniq): the plain search only
+        ugp::Phase2Uniq uq{};
+        const bool uniq_ok = use8 && sorted && !coarse_only && mode == 0 && !ex && !d_tie_count && f.n_nodes < (1ull << 31) && !K.no_uniq;
         if (use8) {   // upper bounds of best(s) the pruning starts from
 #ifdef UGP_EXPERIMENTS
             if (sorted && K.seed_prev && W.d_prev_res.cap >= Q && W.prev_serial == qs->serial)   // (experiment: bounds = the previous call's exact answers)
-                HIP_TRY(ugp::launch_seed_ub(W.d_prev_res.p + q0, order, (uint32_t)nq, n_tiles512, W.d_ub.p, nullptr, nullptr, 0, nullptr, nullptr, s));
+                HIP_TRY(ugp::launch_seed_ub(W.d_prev_res.p + q0, order, (uint32_t)nq, n_tiles512, W.d_ub.p, nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr, s));
             else
 #endif
             if (sorted && !K.no_seed) {
                 // the coarse pass's best costs (real costs of real nodes), tightened by a greedy descent from the coarse best node
                 // through the full tree (k_descend; it reads the sample's alleles from the tiles just built)
                 const uint32_t *refined = nullptr;
+                uint32_t *dnode = nullptr;
                 // (the descent derives D of its start node from "cost(best_j) == best", which both forms of the pre-pass's result
                 // guarantee)
                 if (m->d_node_pair.p && m->d_coarse2bfs.p && !K.no_descent) {
                     HIP_TRY(W.d_refined.reserve(nq));
+                    // (round 6) the descent also says WHICH node has the cost it reports: phase 2 answers the samples whose minimum is
+                    // attained by one node from it, without a walk (Phase2Uniq; plain searches of trees below 2^31 nodes)
+                    if (uniq_ok) { HIP_TRY(W.d_dnode.reserve(nq)); HIP_TRY(W.d_dres.reserve((size_t)n_tiles512 * 256)); dnode = W.d_dnode.p; }
                     HIP_TRY(ugp::launch_descend(W.d_coarse_res.p + q0, order, (uint32_t)nq, m->d_coarse2bfs.p, m->d_node_pair.p,
                                                 m->d_parent.p, m->d_stream.p, W.d_table.p, n_sites, W.d_refined.p, m->wide_descent, K.descent_max, K.descent_slack,
-                                                ex_skip ? ex_skip + q0 : nullptr, s));
+                                                ex_skip ? ex_skip + q0 : nullptr, dnode, s));
                     refined = W.d_refined.p;
 #ifdef UGP_EXPERIMENTS
                     if (K.stats && K.seed_check && W.prev_serial == qs->serial && W.d_prev_res.cap >= Q) {   // debug: seeds against the previous call's answers
@@ -588,7 +612,8 @@ int run_place(ugp_mat *m, ugp_qset *qs, int mode, ugp_result *d_out, int32_t *d_
                 // (the unused slots of the last tile: far from everything, see k_seed_ub; 16-bit safe by the guard of the packed path)
                 const uint32_t pad_d = K.no_pad_fix ? 0u : (uint32_t)std::min<uint64_t>(4096, 0x7F7Eu - 2u - std::min<uint64_t>(f.max_path_muts, 0x7F00u));
                 HIP_TRY(ugp::launch_seed_ub(W.d_coarse_res.p + q0, order, (uint32_t)nq, n_tiles512, W.d_ub.p, refined,
-                                            K.no_pad_fix ? nullptr : d_dbottom, pad_d, ex_skip ? ex_skip + q0 : nullptr, m->d_coarse2bfs.p, s));
+                                            K.no_pad_fix ? nullptr : d_dbottom, pad_d, ex_skip ? ex_skip + q0 : nullptr, m->d_coarse2bfs.p, dnode, dnode ? W.d_dres.p : nullptr, s));
+                if (dnode && refined) { uq.dnode = dnode; uq.refined = refined; uq.dres = W.d_dres.p; }
             } else
                 HIP_TRY(hipMemsetAsync(W.d_ub.p, 0x7F, (size_t)n_tiles512 * 256 * sizeof(uint32_t), s));   // 0x7F7F: above every valid cost
         }
@@ -623,7 +648,12 @@ int run_place(ugp_mat *m, ugp_qset *qs, int mode, ugp_result *d_out, int32_t *d_
             b.lbest = W.d_lbest.p;
             if (coarse_only) { HIP_TRY(W.d_lpos.reserve((size_t)f.n_chunks * n_tiles512 * 256)); b.lpos = W.d_lpos.p; }
             b.list = W.d_list.p; b.list_n = d_list_n;
-            W.last_list_n = d_list_n; W.last_list_tiles = n_tiles512;
+            if (uq.dnode) {
+                HIP_TRY(W.d_luniq.reserve((size_t)f.n_chunks * n_tiles512 * 16));   // (64 bytes per record)
+                HIP_TRY(W.d_gcnt.reserve((size_t)n_tiles512 * 256)); HIP_TRY(W.d_gcnt_part.reserve((size_t)ugp::GBEST_SLICES * n_tiles512 * 256));
+                b.luniq = W.d_luniq.p; uq.luniq = W.d_luniq.p; uq.gcnt = W.d_gcnt.p; uq.gcnt_part = W.d_gcnt_part.p;
+            }
+            W.last_list_n = d_list_n; W.last_list_tiles = n_tiles512; W.last_nitems = coarse_only ? nullptr : d_nitems;
             b.queue = d_queue;
             b.ub = K.no_prune ? nullptr : W.d_ub.p;
             const uint32_t *hstart = nullptr, *hlen = nullptr;
@@ -686,7 +716,7 @@ int run_place(ugp_mat *m, ugp_qset *qs, int mode, ugp_result *d_out, int32_t *d_
                 b.units = (const uint4 *)W.d_units.p; b.unit_base = W.d_unit_info.p; b.unit_count = W.d_unit_info.p + 8;
             }
             HIP_TRY(W.d_stats.reserve(96));
-            if (q0 == 0) { HIP_TRY(hipMemsetAsync(W.d_stats.p, 0, 96 * sizeof(uint64_t), s)); W.last_words_total = 0; }
+            if (q0 == 0) { if (K.stats) HIP_TRY(hipMemsetAsync(W.d_stats.p, 0, 96 * sizeof(uint64_t), s)); W.last_words_total = 0; }   // (the counters exist only in the statistics build: no launch for them otherwise)
             b.stats = K.stats ? W.d_stats.p : nullptr;   // the counters are two contended atomics per skip: debug only
             if (b.stats && !K.trace.empty() && !coarse_only) {   // per-unit records of this launch, dumped by ugp_get_timing
                 constexpr size_t kTraceCap = 1u << 20;
@@ -707,12 +737,11 @@ int run_place(ugp_mat *m, ugp_qset *qs, int mode, ugp_result *d_out, int32_t *d_
             // at 16,384, where the tail of the launch and the number of resident waves matter more.  Hence: from 64 tiles on.
             // (not when two calls share the device: the grids are halved then, and the LDS is better spent on resident waves --
             // 65,536 samples per call, pipelined: 10.5 M/s with, 11.0 M/s without)
-            b.lds_bits = (!b.stats && (size_t)active_words * 4 <= 4096 && n_tiles512 >= 64 && !m->sharing) ? 1u : 0u;
+            b.lds_bits = lds_bits_plan;   // (decided in front of the tile build, with the third bound)
             // Batches with thousands of N cells per sample (their tiles come from the N masks: nmi >= 0): every site row of every tile is
             // live, the bitmap says "fetch the row" for every word -- the variant without a bitmap saves each restart a dependent round
             // trip and each group a load (round 5; exact for any batch: a site's own row is always right, the constant row is the shortcut)
-            if (nmi >= 0 && !b.stats) b.lds_bits = 2u;
-            if (K.lds_bits >= 0) b.lds_bits = b.stats ? 0u : (K.lds_bits == 2 ? 2u : (((size_t)active_words * 4 <= 4096 && K.lds_bits != 0) ? 1u : 0u));
+            // (nmi >= 0: lds_bits_plan == 2)
             const size_t lds_bytes = (size_t)b.lds_slots * 64 * 16 + (b.lds_bits == 1 ? (((size_t)active_words * 4 + 15) & ~(size_t)15) : 0);
             b.b3 = (b3_on && b.ub && b.lds_bits != 1) ? W.d_b3_dev.p : nullptr;
             if (b.b3) TG.last.bound3 = 1;
@@ -767,7 +796,8 @@ int run_place(ugp_mat *m, ugp_qset *qs, int mode, ugp_result *d_out, int32_t *d_
             else
                 HIP_TRY(ugp::launch_phase2(a, W.d_lbest.p, W.d_list.p, d_list_n, W.d_gbest_part.p, W.d_gbest.p, n_tiles512, W.d_items.p, d_nitems,
                                            (uint32_t)std::min<uint64_t>(pairs, 0xFFFFFFFFull), d_cnt, d_key,
-                                           m->d_rank2bfs.p, ex ? ex->rank2out : nullptr, d_out + q0, order, f.max_slots, d_tie_count != nullptr, s));
+                                           m->d_rank2bfs.p, ex ? ex->rank2out : nullptr, d_out + q0, order, f.max_slots, d_tie_count != nullptr,
+                                           uq.luniq ? &uq : nullptr, s));
                 if (d_tie_count) m->tie_lists_filled++;
         } else if (mode == 1 && !ex && !m->h_level_off.empty() && !K.scores_dfs) {
             // -p in the output's own order: level by level of the breadth-first expansion, 64 consecutive scores of one sample per
@@ -793,7 +823,7 @@ int run_place(ugp_mat *m, ugp_qset *qs, int mode, ugp_result *d_out, int32_t *d_
             W.prev_serial = (q0 + nq >= Q) ? qs->serial : 0;   // valid once every sub-batch of THIS query set has been stored
         }
         HIP_TRY(hipEventRecord(es.ev[3], s));
-        if (b3_can && K.bound3 < 0) es.b3_class = b3_class;   // (from here on the tuner may read this sub-batch's events)
+        if (b3_tuned) es.b3_class = b3_class;   // (from here on the tuner may read this sub-batch's events)
         W.last_used_best8 = use8;
         TG.last.packed_path = use8 ? 1u : 0u;
         es.used = true;
@@ -2202,6 +2232,11 @@ static int harvest_timing(ugp_mat *m, ugp_mat::Work &W, ugp_mat::Work::Gen &G) {
                 fprintf(stderr, "[ugp stats] jump lengths in words (<8 <16 <32 <64 <128 <512 <4096 more):");
                 for (int i = 0; i < 8; i++) fprintf(stderr, " %llu", (unsigned long long)v[56 + i]);
                 fprintf(stderr, "\n");
+                if (W.last_nitems) {
+                    uint32_t ni = 0;
+                    HIP_TRY(hipMemcpy(&ni, W.last_nitems, 4, hipMemcpyDeviceToHost));
+                    fprintf(stderr, "[ugp stats] phase 2: %u (chunk, 64-sample sub-tile) pairs walked by k_ties\n", ni);
+                }
                 if (W.last_list_n && W.last_list_tiles) {
                     std::vector<uint32_t> ln(W.last_list_tiles);
                     HIP_TRY(hipMemcpy(ln.data(), W.last_list_n, ln.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));

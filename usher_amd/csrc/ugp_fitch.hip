@@ -22,7 +22,10 @@
 // top-down, one launch per level; states overwrite F in place and a final pass lists the
 // (site, node) pairs whose state differs from the parent's.
 #include <hip/hip_runtime.h>
-#include <hipcub/hipcub.hpp>
+#include <cstring>
+#include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_select.hpp>
+#include <rocprim/iterator/counting_iterator.hpp>
 
 #include <algorithm>
 #include <chrono>
@@ -402,10 +405,10 @@ extern "C" int ugp_fitch_sankoff(int device, uint64_t n_nodes, const uint32_t *p
     hipLaunchKernelGGL(k_fs_heads, dim3((N + 255) / 256), dim3(256), 0, stream, d_parent.p, N, P.d_flag.p, P.d_small.p);
     {
         size_t sel_bytes = 0;
-        hipcub::CountingInputIterator<uint32_t> idx(0);
-        FS_TRY(hipcub::DeviceSelect::Flagged(nullptr, sel_bytes, idx, P.d_flag.p, P.d_heads.p, P.d_small.p + 1, (int)N, stream));
+        rocprim::counting_iterator<uint32_t> idx(0);
+        FS_TRY(rocprim::select(nullptr, sel_bytes, idx, P.d_flag.p, P.d_heads.p, P.d_small.p + 1, (size_t)N, stream));
         FS_TRY(P.d_sel_tmp.alloc(sel_bytes));
-        FS_TRY(hipcub::DeviceSelect::Flagged(P.d_sel_tmp.p, sel_bytes, idx, P.d_flag.p, P.d_heads.p, P.d_small.p + 1, (int)N, stream));
+        FS_TRY(rocprim::select(P.d_sel_tmp.p, sel_bytes, idx, P.d_flag.p, P.d_heads.p, P.d_small.p + 1, (size_t)N, stream));
     }
     hipLaunchKernelGGL(k_fs_topo, dim3((N + 255) / 256), dim3(256), 0, stream, d_parent.p, N, P.d_heads.p, P.d_small.p + 1, d_first.p, d_nchild.p, d_inodes.p);
     std::vector<uint32_t> lvl_off{0, 1};   // nodes of level L are [lvl_off[L], lvl_off[L+1])
@@ -574,9 +577,9 @@ extern "C" int ugp_fitch_sankoff(int device, uint64_t n_nodes, const uint32_t *p
         FS_TRY(d_oval.alloc(n_mut));
         // deterministic order: by site, then breadth-first node index
         size_t tmp_bytes = 0;
-        FS_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, d_okey2.p, d_okey.p, d_oval2.p, d_oval.p, (int64_t)n_mut, 0, 64, stream));
+        FS_TRY(rocprim::radix_sort_pairs(nullptr, tmp_bytes, d_okey2.p, d_okey.p, d_oval2.p, d_oval.p, (size_t)n_mut, 0u, 64u, stream));
         FS_TRY(d_tmp.alloc(tmp_bytes));
-        FS_TRY(hipcub::DeviceRadixSort::SortPairs(d_tmp.p, tmp_bytes, d_okey2.p, d_okey.p, d_oval2.p, d_oval.p, (int64_t)n_mut, 0, 64, stream));
+        FS_TRY(rocprim::radix_sort_pairs(d_tmp.p, tmp_bytes, d_okey2.p, d_okey.p, d_oval2.p, d_oval.p, (size_t)n_mut, 0u, 64u, stream));
         h_key.resize(n_mut);
         h_val.resize(n_mut);
         FS_TRY(hipMemcpyAsync(h_key.data(), d_okey.p, n_mut * sizeof(uint64_t), hipMemcpyDeviceToHost, stream));

@@ -29,7 +29,8 @@
 //   k_place   one sample per lane, 32-bit: per-node scores (-p), tie lists, and
 //             the general fallback when 16-bit counters could overflow.
 #include <hip/hip_runtime.h>
-#include <hipcub/hipcub.hpp>
+#include <cstring>
+#include <rocprim/device/device_radix_sort.hpp>
 #include <stdint.h>
 
 #include <algorithm>
@@ -57,6 +58,9 @@ __device__ __forceinline__ uint32_t pk_sub(uint32_t a, uint32_t b) {
 }
 __device__ __forceinline__ uint32_t pk_min(uint32_t a, uint32_t b) {
     return __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(us2, a), __builtin_bit_cast(us2, b)));
+}
+__device__ __forceinline__ uint32_t pk_max(uint32_t a, uint32_t b) {
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(us2, a), __builtin_bit_cast(us2, b)));
 }
 __device__ __forceinline__ uint32_t rdlane(uint32_t v, uint32_t l) {
     return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)l);
@@ -1093,8 +1097,13 @@ __global__ void __launch_bounds__(64, TIES ? 3 : 4) k_best8(Best8Args a) {
         irr.v[2] = pk_min(lb.z ^ gb.z, 0x00010001u) << 15; irr.v[3] = pk_min(lb.w ^ gb.w, 0x00010001u) << 15;
     }
     Pk4 best, dcur, dpar;
+    // (round 6) the SECOND smallest cost of the open chunk, per sample: a chunk whose minimum is attained by exactly one node has
+    // sec > best.  Phase 2 then needs no walk for a sample whose global minimum lies in one such chunk only -- the node is the one the
+    // seed descent found (k_descend records it): k_select / k_final.  Two packed instructions per node and pair of samples.
+    constexpr bool UNIQ = !ARG && !TIES;
+    Pk4 sec;
 #pragma unroll
-    for (int j = 0; j < 4; j++) { best.v[j] = 0xFFFFFFFFu; dcur.v[j] = dbot.v[j]; dpar.v[j] = 0; }   // (dcur: the root reads D(bottom) as "the previous node's D")
+    for (int j = 0; j < 4; j++) { best.v[j] = 0xFFFFFFFFu; sec.v[j] = 0xFFFFFFFFu; dcur.v[j] = dbot.v[j]; dpar.v[j] = 0; }   // (dcur: the root reads D(bottom) as "the previous node's D")
     // A node with more than 15 mutation words overflows the 4-bit counters: its header carries H_SLOW, so it is walked by slow_node
     // (outside the pipelined loop), which spills the counters into these packed carries every 15 words (M_FLUSH).  They exist only
     // there: held across the pipelined loop they cost 14 vector registers that the loop needs for rows in flight.
@@ -1120,6 +1129,7 @@ __global__ void __launch_bounds__(64, TIES ? 3 : 4) k_best8(Best8Args a) {
             return;
         }
         const uint32_t nb = pk_min(best.v[j], c);
+        if (UNIQ) sec.v[j] = pk_min(sec.v[j], pk_max(best.v[j], c));
         if (ARG) {
             const uint32_t t = pk_min(nb ^ best.v[j], 0x00010001u);   // 1 per half that changed
             const uint32_t msk = (t << 16) - t;                        // 0xFFFF per such half
@@ -1203,6 +1213,16 @@ __global__ void __launch_bounds__(64, TIES ? 3 : 4) k_best8(Best8Args a) {
             uint4 *dst = (uint4 *)(a.lbest + (((uint64_t)chunk * a.n_tiles + tile) * 64 + lane) * 4);
             *dst = make_uint4(best.v[0], best.v[1], best.v[2], best.v[3]);
             if (ARG) *(uint4 *)(a.lpos + (((uint64_t)chunk * a.n_tiles + tile) * 64 + lane) * 4) = make_uint4(bpos.v[0], bpos.v[1], bpos.v[2], bpos.v[3]);
+            if (UNIQ && a.luniq) {
+                // one byte per lane: bit j + 4h set = sample j + 4h of the lane has at least two nodes at its chunk minimum (or no candidate)
+                uint32_t nu = 0;
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const uint32_t eq = pk_min(sec.v[j] ^ best.v[j], 0x00010001u) ^ 0x00010001u;   // 1 per half whose two smallest costs are equal
+                    nu |= ((eq & 1u) << j) | ((eq >> 16) << (j + 4));
+                }
+                ((uint8_t *)a.luniq)[((uint64_t)chunk * a.n_tiles + tile) * 64 + lane] = (uint8_t)nu;
+            }
             if (lane == 0) a.list[(uint64_t)tile * a.n_chunks + atomicAdd(&a.list_n[tile], 1u)] = chunk;   // (order is irrelevant to phase 2)
         }
         if (can_prune && !a.freeze_ub) {
@@ -1214,7 +1234,7 @@ __global__ void __launch_bounds__(64, TIES ? 3 : 4) k_best8(Best8Args a) {
             }
         }
 #pragma unroll
-        for (int j = 0; j < 4; j++) best.v[j] = 0xFFFFFFFFu;
+        for (int j = 0; j < 4; j++) { best.v[j] = 0xFFFFFFFFu; if (UNIQ) sec.v[j] = 0xFFFFFFFFu; }
         chunk++;
     };
     // The chunks that lie wholly in front of relative position `to` (none of them walked, so none holds a candidate) are
@@ -1854,35 +1874,67 @@ __global__ void k_coarse_result(const uint32_t *__restrict__ lbest, const uint32
 // gridDim.y slices (partial minima in `part`), then k_gbest2 folds the slices.  Block = (tile, slice), thread =
 // one dword of the tile's 1 KB record.
 __global__ void k_gbest(const uint32_t *__restrict__ lbest, const uint32_t *__restrict__ list, const uint32_t *__restrict__ list_n,
-                        uint32_t n_chunks, uint32_t n_tiles, uint32_t *__restrict__ part /* [gridDim.y][n_tiles*256] */) {
+                        uint32_t n_chunks, uint32_t n_tiles, uint32_t *__restrict__ part /* [gridDim.y][n_tiles*256] */,
+                        uint32_t *__restrict__ part_cnt /* or null: in how many chunks of the slice the slice minimum is attained, per half, capped at 3 */) {
     // (one-wave blocks, four per tile: see k_descend -- a CU next to the other batches' walks has room for one more wave)
     const uint32_t tile = blockIdx.x >> 2, i = blockIdx.x * 64 + threadIdx.x;
     const uint32_t per_chunk = n_tiles * 256;
     const uint32_t n = list_n[tile];
     const uint32_t e0 = (uint32_t)((uint64_t)blockIdx.y * n / gridDim.y), e1 = (uint32_t)((uint64_t)(blockIdx.y + 1) * n / gridDim.y);
     const uint32_t *l = list + (uint64_t)tile * n_chunks;
-    uint32_t m = 0xFFFFFFFFu;
-    for (uint32_t e = e0; e < e1; e++) m = pk_min(m, lbest[(uint64_t)l[e] * per_chunk + i]);
-    part[(uint64_t)blockIdx.y * per_chunk + i] = m;
+    if (!part_cnt) {
+        uint32_t m = 0xFFFFFFFFu;
+        for (uint32_t e = e0; e < e1; e++) m = pk_min(m, lbest[(uint64_t)l[e] * per_chunk + i]);
+        part[(uint64_t)blockIdx.y * per_chunk + i] = m;
+        return;
+    }
+    uint32_t ml = 0xFFFFu, mh = 0xFFFFu, cl = 0, ch = 0;
+    for (uint32_t e = e0; e < e1; e++) {
+        const uint32_t x = lbest[(uint64_t)l[e] * per_chunk + i], xl = x & 0xFFFFu, xh = x >> 16;
+        cl = xl < ml ? 1u : (xl == ml ? min(cl + 1u, 3u) : cl); ml = min(ml, xl);
+        ch = xh < mh ? 1u : (xh == mh ? min(ch + 1u, 3u) : ch); mh = min(mh, xh);
+    }
+    part[(uint64_t)blockIdx.y * per_chunk + i] = ml | (mh << 16);
+    part_cnt[(uint64_t)blockIdx.y * per_chunk + i] = cl | (ch << 16);
 }
 __global__ void k_gbest2(const uint32_t *__restrict__ part, uint32_t n_slices, uint32_t per_chunk,
-                         uint32_t *__restrict__ gbest /* [n_tiles][64][4] packed */) {
+                         uint32_t *__restrict__ gbest /* [n_tiles][64][4] packed */, const uint32_t *__restrict__ part_cnt, uint32_t *__restrict__ gcnt /* both or neither */) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= per_chunk) return;
     // (eight independent loads in flight per thread: one after the other the 64 slices were 64 round trips, 21 us of a batch's chain)
-    uint32_t m8[8];
+    if (!gcnt) {
+        uint32_t m8[8];
 #pragma unroll
-    for (int j = 0; j < 8; j++) m8[j] = 0xFFFFFFFFu;
+        for (int j = 0; j < 8; j++) m8[j] = 0xFFFFFFFFu;
+        uint32_t k = 0;
+        for (; k + 8 <= n_slices; k += 8) {
+#pragma unroll
+            for (int j = 0; j < 8; j++) m8[j] = pk_min(m8[j], part[(uint64_t)(k + j) * per_chunk + i]);
+        }
+        uint32_t m = 0xFFFFFFFFu;
+        for (; k < n_slices; k++) m = pk_min(m, part[(uint64_t)k * per_chunk + i]);
+#pragma unroll
+        for (int j = 0; j < 8; j++) m = pk_min(m, m8[j]);
+        gbest[i] = m;
+        return;
+    }
+    uint32_t ml = 0xFFFFu, mh = 0xFFFFu, cl = 0, ch = 0;
+    auto fold = [&](uint32_t x, uint32_t c) {
+        const uint32_t xl = x & 0xFFFFu, xh = x >> 16, kl = c & 0xFFFFu, kh = c >> 16;
+        cl = xl < ml ? kl : (xl == ml ? min(cl + kl, 3u) : cl); ml = min(ml, xl);
+        ch = xh < mh ? kh : (xh == mh ? min(ch + kh, 3u) : ch); mh = min(mh, xh);
+    };
     uint32_t k = 0;
     for (; k + 8 <= n_slices; k += 8) {
+        uint32_t x8[8], c8[8];
 #pragma unroll
-        for (int j = 0; j < 8; j++) m8[j] = pk_min(m8[j], part[(uint64_t)(k + j) * per_chunk + i]);
+        for (int j = 0; j < 8; j++) { x8[j] = part[(uint64_t)(k + j) * per_chunk + i]; c8[j] = part_cnt[(uint64_t)(k + j) * per_chunk + i]; }
+#pragma unroll
+        for (int j = 0; j < 8; j++) fold(x8[j], c8[j]);
     }
-    uint32_t m = 0xFFFFFFFFu;
-    for (; k < n_slices; k++) m = pk_min(m, part[(uint64_t)k * per_chunk + i]);
-#pragma unroll
-    for (int j = 0; j < 8; j++) m = pk_min(m, m8[j]);
-    gbest[i] = m;
+    for (; k < n_slices; k++) fold(part[(uint64_t)k * per_chunk + i], part_cnt[(uint64_t)k * per_chunk + i]);
+    gbest[i] = ml | (mh << 16);
+    gcnt[i] = cl | (ch << 16);
 }
 
 __device__ __forceinline__ uint32_t pk_lookup(const uint32_t *packed, uint32_t tile512, uint32_t within) {
@@ -1897,7 +1949,11 @@ __device__ __forceinline__ uint32_t pk_lookup(const uint32_t *packed, uint32_t t
 // global minimum in this chunk?  If so the pair becomes a phase-2 work item.
 __global__ void k_select(const uint32_t *__restrict__ lbest, const uint32_t *__restrict__ list, const uint32_t *__restrict__ list_n,
                          const uint32_t *__restrict__ gbest, uint32_t n_chunks, uint32_t n_tiles, uint32_t n_queries,
-                         uint32_t *__restrict__ items, uint32_t *__restrict__ n_items, uint32_t cap) {
+                         uint32_t *__restrict__ items, uint32_t *__restrict__ n_items, uint32_t cap,
+                         // (round 6; all three or none) A sample needs no walk of this chunk when its global minimum is attained in this ONE
+                         // chunk (gcnt == 1), by ONE node of it (its bit in luniq clear: k_best8's second-smallest cost), and the seed descent
+                         // names a node of exactly that cost (dres == gbest): that node is then the only optimal placement (k_final).
+                         const uint32_t *__restrict__ gcnt, const uint32_t *__restrict__ luniq, const uint32_t *__restrict__ dres) {
     // blocks (tile, 0..gridDim.y-1) share one tile; their threads stride over its (recorded chunk, 64-sample sub-tile) pairs
     const uint32_t tile = blockIdx.x;
     const uint32_t n = list_n[tile], n_t64 = n_tiles * 8;
@@ -1910,10 +1966,31 @@ __global__ void k_select(const uint32_t *__restrict__ lbest, const uint32_t *__r
         const uint64_t off = ((uint64_t)tile * 64 + t8 * 8) * 4;
         const uint4 *lb = (const uint4 *)(lbest + (uint64_t)c * n_tiles * 256 + off);   // (16-byte loads, all sixteen in flight together)
         const uint4 *gb = (const uint4 *)(gbest + off);
+        bool hit = false;
+        if (gcnt) {
+            // the sub-tile's eight lanes' bytes of the record's "more than one node at the chunk minimum" flags (bit j + 4h: sample j + 4h of the lane)
+            const uint2 nu2 = *(const uint2 *)((const uint8_t *)luniq + ((uint64_t)c * n_tiles + tile) * 64 + t8 * 8u);
+            const uint4 *gc = (const uint4 *)(gcnt + off), *dr = (const uint4 *)(dres + off);
+#pragma unroll 4
+            for (int v = 0; v < 8; v++) {   // v = lane within the sub-tile; dword w = samples w (low half) and w + 4 (high half) of that lane (four lanes' loads in flight together)
+                const uint4 l4 = lb[v], g4 = gb[v], c4 = gc[v], d4 = dr[v];
+                const uint32_t nu = ((v < 4 ? nu2.x : nu2.y) >> (8 * (v & 3))) & 0xFFu;
+                const uint32_t ls[4] = {l4.x, l4.y, l4.z, l4.w}, gs[4] = {g4.x, g4.y, g4.z, g4.w};
+                const uint32_t cs[4] = {c4.x, c4.y, c4.z, c4.w}, ds[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+                for (int w = 0; w < 4; w++) {
+                    const uint32_t q0 = t64 * 64 + (uint32_t)v * 8 + (uint32_t)w;
+                    const uint32_t x = ls[w] ^ gs[w];
+                    const bool res_lo = (cs[w] & 0xFFFFu) == 1u && !((nu >> w) & 1u) && ((ds[w] ^ gs[w]) & 0xFFFFu) == 0;
+                    const bool res_hi = (cs[w] >> 16) == 1u && !((nu >> (w + 4)) & 1u) && ((ds[w] ^ gs[w]) >> 16) == 0;
+                    if ((x & 0xFFFFu) == 0 && q0 < n_queries && !res_lo) hit = true;
+                    if ((x >> 16) == 0 && q0 + 4 < n_queries && !res_hi) hit = true;
+                }
+            }
+        } else {
         uint4 xl[8], xg[8];
 #pragma unroll
         for (int v = 0; v < 8; v++) { xl[v] = lb[v]; xg[v] = gb[v]; }
-        bool hit = false;
 #pragma unroll
         for (int v = 0; v < 8; v++) {
             const uint32_t xs[4] = {xl[v].x ^ xg[v].x, xl[v].y ^ xg[v].y, xl[v].z ^ xg[v].z, xl[v].w ^ xg[v].w};
@@ -1924,6 +2001,7 @@ __global__ void k_select(const uint32_t *__restrict__ lbest, const uint32_t *__r
                 if ((x & 0xFFFFu) == 0 && q0 < n_queries) hit = true;
                 if ((x >> 16) == 0 && q0 + 4 < n_queries) hit = true;
             }
+        }
         }
         if (hit) {
             const uint32_t idx = atomicAdd(n_items, 1u);
@@ -2017,12 +2095,22 @@ __global__ void __launch_bounds__(64) k_fix_skip(PlaceArgs a, uint32_t *__restri
 
 __global__ void k_final(const uint32_t *__restrict__ gbest, const uint32_t *__restrict__ cnt, const uint32_t *__restrict__ key,
                         const uint32_t *__restrict__ rank2bfs, uint32_t n_queries, ugp_result *__restrict__ out,
-                        const uint32_t *__restrict__ order /* slot -> sample, or nullptr */) {
+                        const uint32_t *__restrict__ order /* slot -> sample, or nullptr */,
+                        const uint32_t *__restrict__ dnode, const uint32_t *__restrict__ refined /* both or neither: the seed descent's node and its cost, by slot */) {
     const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
     if (q >= n_queries) return;
     ugp_result r;
     r.best_set_difference = (int32_t)pk_lookup(gbest, q >> 9, q & 511u);
     r.num_best = cnt[q];
+    if (dnode && r.num_best == 0) {
+        // no chunk was walked for this sample: k_select found its minimum attained once, by one node, at the cost of the descent's node.
+        // (The condition is checked again here; a sample that fails it keeps num_best = 0, which no caller can mistake for an answer.)
+        const uint32_t dn = dnode[q];
+        if (dn != 0xFFFFFFFFu && refined[q] == (uint32_t)r.best_set_difference) { r.num_best = 1u; r.best_j = dn >> 1; r.best_has_unique = dn & 1u; }
+        else { r.best_j = 0xFFFFFFFFu; r.best_has_unique = 0u; }
+        out[order ? order[q] : q] = r;
+        return;
+    }
     r.best_j = rank2bfs[key[q] >> 1];
     r.best_has_unique = key[q] & 1u;
     out[order ? order[q] : q] = r;
@@ -2053,10 +2141,15 @@ __global__ void k_invert(const uint32_t *__restrict__ order, uint32_t n, uint32_
 // then holds for them everywhere.  Their results are never read.
 __global__ void k_seed_ub(const ugp_result *__restrict__ coarse_res, const uint32_t *__restrict__ order, uint32_t n_queries,
                           uint32_t n_words, uint32_t *__restrict__ ub, const uint32_t *__restrict__ refined, uint32_t *__restrict__ dbottom,
-                          uint32_t pad_d, const uint32_t *__restrict__ skip, const uint32_t *__restrict__ coarse2bfs) {
+                          uint32_t pad_d, const uint32_t *__restrict__ skip, const uint32_t *__restrict__ coarse2bfs,
+                          const uint32_t *__restrict__ dnode, uint32_t *__restrict__ dres /* both or neither: packed like ub -- refined[slot] where the descent names a node of that cost, else 0xFFFF */) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;   // word (tile*64 + lane)*4 + jj holds samples jj and jj+4 of the lane
     if (i >= n_words) return;
     const uint32_t slot = (i >> 2) * 8 + (i & 3u);
+    if (dres) {
+        auto dv = [&](uint32_t q) -> uint32_t { return (q < n_queries && refined && dnode[q] != 0xFFFFFFFFu) ? min(refined[q], 0xFFFFu) : 0xFFFFu; };
+        dres[i] = dv(slot) | (dv(slot + 4) << 16);
+    }
     auto val = [&](uint32_t q) -> uint32_t {
         if (q >= n_queries) { if (dbottom) dbottom[q] = pad_d; return dbottom ? 0u : 0x7F7Fu; }
         const int32_t b = coarse_res[order[q]].best_set_difference;
@@ -2103,7 +2196,8 @@ template <uint32_t G>
 __global__ void __launch_bounds__(DESC_BLOCK) k_descend(const ugp_result *__restrict__ coarse_res, const uint32_t *__restrict__ order, uint32_t n_queries,
                           const uint32_t *__restrict__ coarse2bfs, const uint2 *__restrict__ node_pair,
                           const uint32_t *__restrict__ parent, const uint32_t *__restrict__ stream, const uint32_t *__restrict__ table, uint32_t n_sites,
-                          uint32_t *__restrict__ refined, uint32_t max_expansions, int slack, const uint32_t *__restrict__ skip) {
+                          uint32_t *__restrict__ refined, uint32_t max_expansions, int slack, const uint32_t *__restrict__ skip,
+                          uint32_t *__restrict__ dnode /* or null: [n_queries] by slot -- (BFS index << 1 | has_unique) of a node whose cost is refined[slot], UINT32_MAX: none */) {
     constexpr uint32_t NG = DESC_BLOCK / G;   // samples per block
     __shared__ uint32_t f_node[NG][DESC_FRONTIER], f_cb[NG][DESC_FRONTIER], f_ce[NG][DESC_FRONTIER];
     __shared__ int f_d[NG][DESC_FRONTIER];
@@ -2139,6 +2233,9 @@ __global__ void __launch_bounds__(DESC_BLOCK) k_descend(const ugp_result *__rest
         }
     };
     int best = alive ? r.best_set_difference : 0x7F7F;
+    // (round 6) which node attains `best`: cost << 34 | BFS index << 1 | has_unique, smallest first -- for phase 2's samples whose minimum
+    // is attained by one node only (k_select): that node is then this one, and no chunk is walked for it
+    unsigned long long bkey = ~0ull;
     // one node left out for this sample (ugp_place_opts::skip_node): its cost is never a bound; the search still passes through it
     const uint32_t skipn = (skip && slot < n_queries) ? skip[order ? order[slot] : slot] : 0xFFFFFFFFu;
     uint32_t n_f = 0;   // uniform within the group: frontier entries
@@ -2155,6 +2252,12 @@ __global__ void __launch_bounds__(DESC_BLOCK) k_descend(const ugp_result *__rest
         // cost(node) = D(parent) + neg = best  ->  D(parent) = best - neg, D(node) = D(parent) + dsum;  the root's cost is its D
         int D = (w0 & F_ROOT) ? best : best - neg + dsum;
         if (node == skipn) best = 0x7F7F;   // (D above is derived from the node's true cost; as a bound it does not count)
+        else {
+            // the coarse winner is a node of the full tree with the same mutations, the same cost and eligible (k_seed_ub); has_unique as
+            // walk_ties computes it: a masked mutation, or a mutation the sample does not share; the root never
+            const uint32_t hu0 = (w0 & F_ROOT) ? 0u : (((w0 & F_MASKED) || common != (w0 & 0xFFFFu)) ? 1u : 0u);
+            if (!excl) bkey = ((unsigned long long)(uint32_t)best << 34) | ((unsigned long long)node << 1) | hu0;
+        }
         if (gl == 0) { f_node[g][0] = node; f_d[g][0] = D; f_cb[g][0] = pr.x + 1u; f_ce[g][0] = ce + 1u; }
         n_f = 1;
         for (uint32_t up = 0; up < DESC_UP && node != 0; up++) {   // D(ancestor) = D(child) - (sum of the child's deltas)
@@ -2193,6 +2296,7 @@ __global__ void __launch_bounds__(DESC_BLOCK) k_descend(const ugp_result *__rest
             if (__builtin_amdgcn_ballot_w64(more) == 0) break;
             const uint32_t c = c0 + gl;
             int cost = 0x7FFFFFFF, dc = 0;
+            unsigned long long ck = ~0ull;
             bool push = false;
             uint32_t ccb = 0, cce = 0;
             if (more && c < ce) {
@@ -2202,7 +2306,10 @@ __global__ void __launch_bounds__(DESC_BLOCK) k_descend(const ugp_result *__rest
                 int dsum, neg; uint32_t common, w0; bool excl;
                 eval(pr.y, dsum, neg, common, w0, excl);
                 const bool leaf = (w0 & F_LEAF) != 0, masked = (w0 & F_MASKED) != 0;
-                if (!masked && !excl && c != skipn && (common > 0 || (!leaf && (w0 & 0xFFFFu) == 0))) cost = D + neg;
+                if (!masked && !excl && c != skipn && (common > 0 || (!leaf && (w0 & 0xFFFFu) == 0))) {
+                    cost = D + neg;
+                    ck = ((unsigned long long)(uint32_t)cost << 34) | ((unsigned long long)c << 1) | (common != (w0 & 0xFFFFu) ? 1u : 0u);
+                }
                 dc = D + dsum;
                 // follow a child whose D does not grow -- or grows by one while it shares a mutation with the sample (the sample's
                 // lineage passing a node of which it lacks one mutation; a sibling branch shares one only by homoplasy)
@@ -2212,6 +2319,11 @@ __global__ void __launch_bounds__(DESC_BLOCK) k_descend(const ugp_result *__rest
             }
 #pragma unroll
             for (int o = (int)G / 2; o > 0; o >>= 1) cost = min(cost, __shfl_xor(cost, o, (int)G));
+            if (dnode) {
+#pragma unroll
+                for (int o = (int)G / 2; o > 0; o >>= 1) { const unsigned long long other = __shfl_xor(ck, o, (int)G); ck = other < ck ? other : ck; }
+                bkey = ck < bkey ? ck : bkey;
+            }
             best = min(best, cost);
             const unsigned long long pm = (__builtin_amdgcn_ballot_w64(push) >> gsh) & (G == 64 ? ~0ull : ((1ull << (G & 63u)) - 1ull));
             if (push) {
@@ -2221,7 +2333,11 @@ __global__ void __launch_bounds__(DESC_BLOCK) k_descend(const ugp_result *__rest
             n_f = min(n_f + (uint32_t)__builtin_popcountll(pm), DESC_FRONTIER);
         }
     }
-    if (slot < n_queries && gl == 0) refined[slot] = alive ? (uint32_t)max(0, min(best, 0x7F7F)) : 0x7F7Fu;
+    if (slot < n_queries && gl == 0) {
+        refined[slot] = alive ? (uint32_t)max(0, min(best, 0x7F7F)) : 0x7F7Fu;
+        // (valid only when the key's cost IS the value stored above: a cost outside [0, 0x7F7F) is clamped there and names no node)
+        if (dnode) dnode[slot] = (alive && bkey != ~0ull && (int)(bkey >> 34) == best && best >= 0 && best < 0x7F7F) ? (uint32_t)(bkey & 0xFFFFFFFFull) : 0xFFFFFFFFu;
+    }
 }
 
 // Where in the chunk order do a tile's own samples sit?  keys_sorted[q] = DFS rank of the coarse best node of
@@ -2377,25 +2493,26 @@ hipError_t launch_build_units(const uint32_t *hstart, const uint32_t *hlen, uint
 }
 
 hipError_t launch_seed_ub(const ugp_result *coarse_res, const uint32_t *order, uint32_t n_queries, uint32_t n_tiles512, uint32_t *ub,
-                          const uint32_t *refined, uint32_t *dbottom, uint32_t pad_d, const uint32_t *skip, const uint32_t *coarse2bfs, hipStream_t s) {
+                          const uint32_t *refined, uint32_t *dbottom, uint32_t pad_d, const uint32_t *skip, const uint32_t *coarse2bfs,
+                          const uint32_t *dnode, uint32_t *dres, hipStream_t s) {
     const uint32_t n_words = n_tiles512 * 256;
     hipLaunchKernelGGL(k_seed_ub, dim3((n_words + 63) / 64), dim3(64), 0, s, coarse_res, order, n_queries, n_words, ub, refined, dbottom, pad_d,
-                       skip, coarse2bfs);
+                       skip, coarse2bfs, dnode, (dnode && refined) ? dres : nullptr);
     return hipGetLastError();
 }
 
 hipError_t launch_descend(const ugp_result *coarse_res, const uint32_t *order, uint32_t n_queries, const uint32_t *coarse2bfs,
                           const uint32_t *node_pair, const uint32_t *parent, const uint32_t *stream, const uint32_t *table,
-                          uint32_t n_sites, uint32_t *refined, bool wide, uint32_t max_expansions, int slack, const uint32_t *skip, hipStream_t s) {
+                          uint32_t n_sites, uint32_t *refined, bool wide, uint32_t max_expansions, int slack, const uint32_t *skip, uint32_t *dnode, hipStream_t s) {
     if (!n_queries) return hipSuccess;
     const uint32_t max_exp = max_expansions ? max_expansions : DESC_MAX_EXPANSIONS;   // (tuning)
     // (slack, measured at 10M nodes: 0 costs the main walk 60 %, 1..5 are alike, none is 8 % more descent)
     if (wide)
         hipLaunchKernelGGL(k_descend<64>, dim3((n_queries + DESC_BLOCK / 64 - 1) / (DESC_BLOCK / 64)), dim3(DESC_BLOCK), 0, s, coarse_res, order, n_queries, coarse2bfs, (const uint2 *)node_pair, parent,
-                           stream, table, n_sites, refined, max_exp, slack, skip);
+                           stream, table, n_sites, refined, max_exp, slack, skip, dnode);
     else
         hipLaunchKernelGGL(k_descend<16>, dim3((n_queries + DESC_BLOCK / 16 - 1) / (DESC_BLOCK / 16)), dim3(DESC_BLOCK), 0, s, coarse_res, order, n_queries, coarse2bfs, (const uint2 *)node_pair, parent,
-                           stream, table, n_sites, refined, max_exp, slack, skip);
+                           stream, table, n_sites, refined, max_exp, slack, skip, dnode);
     return hipGetLastError();
 }
 
@@ -2452,10 +2569,10 @@ hipError_t launch_locality_sort(const ugp_result *coarse_res, const uint32_t *co
         return hipGetLastError();
     }
     if (!temp) {   // size query
-        return hipcub::DeviceRadixSort::SortPairs(nullptr, *temp_bytes, keys, keys_sorted, idx, order, (int)n, 0, 32, s);
+        return rocprim::radix_sort_pairs(nullptr, *temp_bytes, keys, keys_sorted, idx, order, (size_t)n, 0u, 32u, s);
     }
     hipLaunchKernelGGL(k_sort_keys, dim3((n + 63) / 64), dim3(64), 0, s, coarse_res, coarse2dfs, n, keys, idx);
-    hipError_t e = hipcub::DeviceRadixSort::SortPairs(temp, *temp_bytes, keys, keys_sorted, idx, order, (int)n, 0, 32, s);
+    hipError_t e = rocprim::radix_sort_pairs(temp, *temp_bytes, keys, keys_sorted, idx, order, (size_t)n, 0u, 32u, s);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k_invert, dim3((n + 63) / 64), dim3(64), 0, s, order, n, slot_of);
     return hipGetLastError();
@@ -2614,8 +2731,8 @@ hipError_t launch_phase2_packed(const Best8Args &b1, const uint32_t *list, const
                                 uint32_t blocks, hipStream_t s) {
     const uint32_t per_chunk = n_tiles512 * 256;
     const uint32_t slices = std::min<uint32_t>(GBEST_SLICES, b1.n_chunks);
-    hipLaunchKernelGGL(k_gbest, dim3(n_tiles512 * 4, slices), dim3(64), 0, s, b1.lbest, list, list_n, b1.n_chunks, n_tiles512, gbest_part);
-    hipLaunchKernelGGL(k_gbest2, dim3((per_chunk + 255) / 256), dim3(256), 0, s, gbest_part, slices, per_chunk, gbest);
+    hipLaunchKernelGGL(k_gbest, dim3(n_tiles512 * 4, slices), dim3(64), 0, s, b1.lbest, list, list_n, b1.n_chunks, n_tiles512, gbest_part, (uint32_t *)nullptr);
+    hipLaunchKernelGGL(k_gbest2, dim3((per_chunk + 255) / 256), dim3(256), 0, s, gbest_part, slices, per_chunk, gbest, (const uint32_t *)nullptr, (uint32_t *)nullptr);
     hipError_t e = hipMemsetAsync(info, 0, 128 * sizeof(uint32_t), s);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k_select8, dim3(n_tiles512, n_tiles512 < 256 ? 8 : 1), dim3(256), 0, s, b1.lbest, list, list_n, gbest, b1.n_chunks, n_tiles512,
@@ -2628,7 +2745,7 @@ hipError_t launch_phase2_packed(const Best8Args &b1, const uint32_t *list, const
     b.tie_cnt = cnt; b.tie_key = key; b.node_pos8 = node_pos8; b.rank_dfs = rank_dfs; b.chunk_node_off = chunk_node_off; b.n_queries = n_queries;
     e = launch_best8(b, blocks, s);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_final, dim3((n_queries + 255) / 256), dim3(256), 0, s, gbest, cnt, key, rank2bfs, n_queries, out, order);
+    hipLaunchKernelGGL(k_final, dim3((n_queries + 255) / 256), dim3(256), 0, s, gbest, cnt, key, rank2bfs, n_queries, out, order, (const uint32_t *)nullptr, (const uint32_t *)nullptr);
     return hipGetLastError();
 }
 #endif
@@ -2643,14 +2760,16 @@ hipError_t launch_fix_skip(const PlaceArgs &a, uint32_t *lbest, const uint32_t *
 hipError_t launch_phase2(const PlaceArgs &a, const uint32_t *lbest, const uint32_t *list, const uint32_t *list_n, uint32_t *gbest_part,
                          uint32_t *gbest, uint32_t n_tiles512,
                          uint32_t *items, uint32_t *n_items, uint32_t cap, uint32_t *cnt, uint32_t *key,
-                         const uint32_t *rank2bfs, const uint32_t *rank2out, ugp_result *out, const uint32_t *order, uint32_t max_slots, bool lists, hipStream_t s) {
+                         const uint32_t *rank2bfs, const uint32_t *rank2out, ugp_result *out, const uint32_t *order, uint32_t max_slots, bool lists,
+                         const Phase2Uniq *u, hipStream_t s) {
     const uint32_t per_chunk = n_tiles512 * 256;
     const uint32_t slices = std::min<uint32_t>(GBEST_SLICES, a.n_chunks);
-    hipLaunchKernelGGL(k_gbest, dim3(n_tiles512 * 4, slices), dim3(64), 0, s, lbest, list, list_n, a.n_chunks, n_tiles512, gbest_part);
-    hipLaunchKernelGGL(k_gbest2, dim3((per_chunk + 63) / 64), dim3(64), 0, s, gbest_part, slices, per_chunk, gbest);
+    const bool uq = u && u->luniq && u->dnode && u->refined && u->dres && u->gcnt && u->gcnt_part && !lists && !rank2out;
+    hipLaunchKernelGGL(k_gbest, dim3(n_tiles512 * 4, slices), dim3(64), 0, s, lbest, list, list_n, a.n_chunks, n_tiles512, gbest_part, uq ? u->gcnt_part : nullptr);
+    hipLaunchKernelGGL(k_gbest2, dim3((per_chunk + 63) / 64), dim3(64), 0, s, gbest_part, slices, per_chunk, gbest, uq ? u->gcnt_part : nullptr, uq ? u->gcnt : nullptr);
     const uint64_t pairs = (uint64_t)a.n_chunks * n_tiles512 * 8;
     hipLaunchKernelGGL(k_select, dim3(n_tiles512, n_tiles512 < 256 ? 32 : 4), dim3(64), 0, s, lbest, list, list_n, gbest, a.n_chunks, n_tiles512, a.n_queries, items,
-                       n_items, cap);
+                       n_items, cap, uq ? u->gcnt : nullptr, uq ? u->luniq : nullptr, uq ? u->dres : nullptr);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     const size_t lds = (size_t)max_slots * 64 * sizeof(uint32_t);
@@ -2658,7 +2777,8 @@ hipError_t launch_phase2(const PlaceArgs &a, const uint32_t *lbest, const uint32
     if ((uint64_t)blocks > pairs) blocks = (uint32_t)pairs;
     if (lists) hipLaunchKernelGGL(k_ties<true>, dim3(blocks), dim3(64), lds, s, a, lbest, gbest, items, n_items, cap, n_tiles512 * 8, cnt, key, rank2bfs, order);
     else hipLaunchKernelGGL(k_ties<false>, dim3(blocks), dim3(64), lds, s, a, lbest, gbest, items, n_items, cap, n_tiles512 * 8, cnt, key, rank2bfs, order);
-    hipLaunchKernelGGL(k_final, dim3((a.n_queries + 63) / 64), dim3(64), 0, s, gbest, cnt, key, rank2out ? rank2out : rank2bfs, a.n_queries, out, order);
+    hipLaunchKernelGGL(k_final, dim3((a.n_queries + 63) / 64), dim3(64), 0, s, gbest, cnt, key, rank2out ? rank2out : rank2bfs, a.n_queries, out, order,
+                       uq ? u->dnode : nullptr, uq ? u->refined : nullptr);
     return hipGetLastError();
 }
 

@@ -47,6 +47,8 @@ struct Best8Args {
     const uint32_t *active;    // [n_tiles][active_words] bit per site: some sample of the tile is not reference there
     uint32_t active_words;
     uint32_t *lbest;           // [n_chunks][n_tiles][64][4] packed u16 pairs; a record exists only for the chunks in `list`
+    uint32_t *luniq;           // (main walk, round 6) or null: [n_chunks][n_tiles][64] BYTES beside every lbest record -- byte l, bit j + 4h set: sample j + 4h of lane l
+                               // has MORE than one node at its chunk minimum (or no candidate); clear = the minimum is attained by exactly one node
     uint32_t *lpos;            // (coarse pass) or null: same layout as lbest -- low 16 bits of the stream position of the node that set each chunk minimum
     uint32_t *list, *list_n;   // [n_tiles][n_chunks] chunks of each tile that left a record, [n_tiles] their number (zeroed before the launch)
     uint32_t *queue;           // [8] work-queue heads, one per XCD, zeroed before the launch
@@ -99,11 +101,20 @@ hipError_t launch_phase2_packed(const Best8Args &b1, const uint32_t *list, const
                                 void *units, uint32_t *info, uint32_t *cnt, uint32_t *key, const uint32_t *node_pos8, const uint32_t *rank_dfs,
                                 const uint32_t *chunk_node_off, const uint32_t *rank2bfs, uint32_t n_queries, ugp_result *out, const uint32_t *order,
                                 uint32_t blocks, hipStream_t s);
+// Phase 2 without a walk for the samples whose minimum is attained by ONE node (round 6): pass 2 of the reference visits the tied nodes
+// only (usher_common.cpp:416-449); a sample whose global minimum lies in one recorded chunk (gcnt), at one node of it (luniq, written by
+// k_best8), at the cost of the node the seed descent found (dnode / refined by sorted slot; dres = the same cost packed like gbest), is
+// answered from that node -- k_select leaves it out of the (chunk, sub-tile) pairs k_ties walks, k_final takes the node.
+struct Phase2Uniq {
+    const uint32_t *luniq, *dnode, *refined, *dres;
+    uint32_t *gcnt /* [n_tiles512 * 256] */, *gcnt_part /* [GBEST_SLICES][n_tiles512 * 256] */;
+};
 hipError_t launch_phase2(const PlaceArgs &a, const uint32_t *lbest, const uint32_t *list, const uint32_t *list_n, uint32_t *gbest_part,
                          uint32_t *gbest, uint32_t n_tiles512,
                          uint32_t *items, uint32_t *n_items, uint32_t cap, uint32_t *cnt, uint32_t *key,
                          const uint32_t *rank2bfs, const uint32_t *rank2out /* tie key -> index reported (extended searches), or null = rank2bfs */,
-                         ugp_result *out, const uint32_t *order, uint32_t max_slots, bool lists /* also a.tie_* */, hipStream_t s);
+                         ugp_result *out, const uint32_t *order, uint32_t max_slots, bool lists /* also a.tie_* */,
+                         const Phase2Uniq *uniq /* or null */, hipStream_t s);
 
 // row checks of k_rows_prepare: *err = (row << 3) | kind of the first offending row, ~0 when clean
 enum { ROWS_UNSORTED = 1, ROWS_BAD_REF = 2, ROWS_BAD_MASK = 3, ROWS_REF_MISMATCH = 4 };
@@ -140,11 +151,14 @@ hipError_t launch_descend(const ugp_result *coarse_res, const uint32_t *order, u
                           const uint32_t *node_pair /* [n_nodes + 1][2]: child_begin, rec_off */, const uint32_t *parent, const uint32_t *stream,
                           const uint32_t *table, uint32_t n_sites, uint32_t *refined, bool wide /* a whole wave per sample: trees with large polytomies */,
                           uint32_t max_expansions /* 0: default */, int slack, const uint32_t *skip /* [n_queries] by sample, or null: BFS index of a node whose cost is no bound for that sample */,
+                          uint32_t *dnode /* or null: [n_queries] by sorted slot, (BFS index << 1 | has_unique) of a node whose cost is refined[slot]; UINT32_MAX: none.  Trees of < 2^31 nodes */,
                           hipStream_t s);
 hipError_t launch_seed_ub(const ugp_result *coarse_res, const uint32_t *order, uint32_t n_queries, uint32_t n_tiles512, uint32_t *ub,
                           const uint32_t *refined /* [n_queries] by sorted slot, or null */,
                           uint32_t *dbottom /* or null: D(bottom) of the unused slots of the last tile is set to pad_d, their bound to 0 */, uint32_t pad_d,
-                          const uint32_t *skip /* as launch_descend */, const uint32_t *coarse2bfs, hipStream_t s);
+                          const uint32_t *skip /* as launch_descend */, const uint32_t *coarse2bfs,
+                          const uint32_t *dnode /* as launch_descend, or null */, uint32_t *dres /* [n_tiles512 * 256] packed like ub: the descent's cost where it names a node, else 0xFFFF */,
+                          hipStream_t s);
 // skip_node on the packed path: recompute, without the sample's excluded node, the minimum of the chunk that holds it (k_fix_skip)
 hipError_t launch_fix_skip(const PlaceArgs &a, uint32_t *lbest, const uint32_t *skip_chunk /* [n_queries] by sample */, uint32_t n_tiles512, const uint32_t *rank2bfs,
                            const uint32_t *order, uint32_t max_slots, hipStream_t s);

@@ -14,9 +14,10 @@ namespace ugp {
 struct Knobs {
     // switches
     bool force_v1 = false, no_sort = false, no_prune = false, coarse_phase2 = false, no_seed = false, no_descent = false, no_pad_fix = false,
-         no_lpt = false, radix_sort = false, refill_all = false, scores_dfs = false, ties_dfs = false, debug_sharing = false, no_graph = false, ex_slow = false, no_bound3 = false;
+         no_lpt = false, radix_sort = false, refill_all = false, scores_dfs = false, ties_dfs = false, debug_sharing = false, no_graph = false, ex_slow = false, no_bound3 = false, no_uniq = false;
     // -1 = the library's own choice
-    int bound3 = -1, tile_build = -1, nmask = -1, lds_bits = -1, light_order = -1, unit_grow = -1, split_cycles = -1, split_heavy = -1, split_dense = -1,
+    int bound3 = -2,   // third pruning bound: -2 = decided from the tree and the batch (b3_static_choice), -1 = UGP_BOUND3=auto: the run-time tuner, 0 / 1 pinned
+        tile_build = -1, nmask = -1, lds_bits = -1, light_order = -1, unit_grow = -1, split_cycles = -1, split_heavy = -1, split_dense = -1,
         descent_slack = 2;
     // 0 = the library's own choice
     uint32_t target_waves = 0, groups = 0, unit_chunks = 0, heavy_chunks = 0, unit_max = 0, shared_waves = 0, waves_per_cu = 0, ub_every = 0,
@@ -39,8 +40,9 @@ struct Knobs {
         k.coarse_phase2 = flag("UGP_COARSE_PHASE2"); k.no_seed = flag("UGP_NO_SEED"); k.no_descent = flag("UGP_NO_DESCENT");
         k.no_pad_fix = flag("UGP_NO_PAD_FIX"); k.no_lpt = flag("UGP_NO_LPT"); k.refill_all = flag("UGP_REFILL_ALL"); k.radix_sort = flag("UGP_RADIX_SORT");
         k.scores_dfs = flag("UGP_SCORES_DFS"); k.ties_dfs = flag("UGP_TIES_DFS"); k.debug_sharing = flag("UGP_DEBUG_SHARING");
-        k.no_graph = flag("UGP_NO_GRAPH"); k.ex_slow = flag("UGP_EX_SLOW"); k.no_bound3 = flag("UGP_NO_BOUND3");
-        k.bound3 = num("UGP_BOUND3", -1); k.tile_build = num("UGP_TILE_BUILD", -1); k.nmask = num("UGP_NMASK", -1); k.lds_bits = num("UGP_LDS_BITS", -1);
+        k.no_graph = flag("UGP_NO_GRAPH"); k.ex_slow = flag("UGP_EX_SLOW"); k.no_bound3 = flag("UGP_NO_BOUND3"); k.no_uniq = flag("UGP_NO_UNIQ");
+        if (const char *e = getenv("UGP_BOUND3")) k.bound3 = (e[0] == 'a' || e[0] == 'A') ? -1 : (atoi(e) != 0 ? 1 : 0);
+        k.tile_build = num("UGP_TILE_BUILD", -1); k.nmask = num("UGP_NMASK", -1); k.lds_bits = num("UGP_LDS_BITS", -1);
         k.light_order = num("UGP_LIGHT_ORDER", -1);
         if (getenv("UGP_UNIT_GROW")) k.unit_grow = num("UGP_UNIT_GROW", 0) < 0 ? 0 : num("UGP_UNIT_GROW", 0);
         if (getenv("UGP_SPLIT_CYCLES")) k.split_cycles = k.split_heavy = num("UGP_SPLIT_CYCLES", 0) < 0 ? 0 : num("UGP_SPLIT_CYCLES", 0);

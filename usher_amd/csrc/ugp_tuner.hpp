@@ -17,6 +17,16 @@ namespace ugp {
 // the other mode to keep its figure fresh.
 // UGP_BOUND3=1 / 0 (or UGP_NO_BOUND3) pins the choice.  (First version: each sub-batch's own first-to-last-kernel time -- with
 // three calls in flight that mostly measures the neighbours, and the choice flipped at random.)
+// The default (round 6): no A/B inside the caller's steps.  Whether the tables pay is decided from two things known
+// before the batch runs -- the shape of the tree (fixed at ugp_mat_create: `polytomy_tree` = more than 5 % of the nodes hang off a node
+// with more than 16 children, the SARS-CoV-2 shape: short branches, hsub is small already, the walk's cost is sibling runs that no
+// subtree test removes) and the batch's class by rows per sample (B3Tuner::class_of).  The measured cases (tools/b3_static_probe.sh,
+// profiles/r06_b3_static_probe.txt) separate on exactly these; B3Tuner stays available as UGP_BOUND3=auto.
+inline bool b3_static_choice(bool polytomy_tree, int row_class) {
+    if (!polytomy_tree) return true;          // random-attachment shape: +3-5 % on plain batches, +70-100 % on ambiguous ones
+    return row_class >= 2;                    // polytomy-dominated shape: only for batches of hundreds of rows per sample
+}
+
 struct B3Tuner {
     static constexpr int kClasses = 3;
     static constexpr uint32_t kBlock = 6, kSkip = 2;
@@ -39,7 +49,8 @@ struct B3Tuner {
             const uint32_t k = blocks[c]++;
             first = k == 0;
             if (k < 4) mode = (k & 1u) == 0;                // (with, without, with, without; the very first block -- allocations, cold caches -- is not counted)
-            else if (!n[c][0] || !n[c][1]) mode = true;     // (their figures still on the way)
+            else if (!n[c][0] || !n[c][1]) mode = (k & 1u) == 0;   // (no figure for one of the modes yet -- still on the way, or the blocks of this class keep
+                                                                   //  being interrupted by another class and never complete: keep alternating, never pin a mode unmeasured)
             else {
                 const double a = ema[c][1], b = ema[c][0];
                 const bool best = a <= b;

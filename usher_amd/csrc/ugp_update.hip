@@ -3,7 +3,8 @@
 // See ugp_update.hpp.  Integer work, lanes = samples, record data wave-uniform.
 #include "ugp_update.hpp"
 
-#include <hipcub/hipcub.hpp>
+#include <cstring>
+#include <rocprim/device/device_radix_sort.hpp>
 
 #include <climits>
 
@@ -29,9 +30,9 @@ __global__ void k_rank_scatter(const uint32_t *__restrict__ rank2out, const uint
 }
 hipError_t launch_rank_sort(void *temp, size_t *temp_bytes, const uint64_t *keys, uint64_t *keys_out, uint32_t *iota, uint32_t *rank2out, uint32_t n,
                             const uint32_t *to_bfs, uint32_t *rank_bfs, hipStream_t s) {
-    if (!temp) return hipcub::DeviceRadixSort::SortPairs(nullptr, *temp_bytes, keys, keys_out, iota, rank2out, (int)n, 0, 64, s);
+    if (!temp) return rocprim::radix_sort_pairs(nullptr, *temp_bytes, keys, keys_out, iota, rank2out, (size_t)n, 0u, 64u, s);
     hipLaunchKernelGGL(k_iota, dim3((n + 255) / 256), dim3(256), 0, s, iota, n);
-    hipError_t e = hipcub::DeviceRadixSort::SortPairs(temp, *temp_bytes, keys, keys_out, iota, rank2out, (int)n, 0, 64, s);
+    hipError_t e = rocprim::radix_sort_pairs(temp, *temp_bytes, keys, keys_out, iota, rank2out, (size_t)n, 0u, 64u, s);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k_rank_scatter, dim3((n + 255) / 256), dim3(256), 0, s, rank2out, to_bfs, n, rank_bfs);
     return hipGetLastError();

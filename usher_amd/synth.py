@@ -89,11 +89,14 @@ class SynthTree:
         self.genome_len = genome_len
 
     def queries(self, n_queries: int, seed: int = 1, max_subst: int = 3, n_lo: int = 0, n_hi: int = 0, iupac_hi: int = 0, recent: bool = False,
-                iupac_true: bool = False):
+                iupac_true: bool = False, min_subst: int = 0, ref_every_8th: bool = False):
         """CSR query arrays: (ent_off, pos, ref, nuc, is_missing, source_node).  iupac_true: every ambiguity code holds the
-        sample's own base (default: any set of 2-3 bases, i.e. most such cells are mismatches)."""
+        sample's own base (default: any set of 2-3 bases, i.e. most such cells are mismatches).  min_subst .. max_subst
+        substitutions per sample (uniform); ref_every_8th: every 8th sample is the all-reference sample (no rows) -- together the
+        "far" queries: samples that are not in the neighbourhood of any node."""
         L = _L()
-        q = L.ugs_queries_create2(self._h, n_queries, seed, max_subst, n_lo, n_hi, iupac_hi, (1 if recent else 0) | (2 if iupac_true else 0))
+        q = L.ugs_queries_create2(self._h, n_queries, seed, max_subst, n_lo, n_hi, iupac_hi,
+                                  (1 if recent else 0) | (2 if iupac_true else 0) | (4 if ref_every_8th else 0) | (int(min_subst) << 8))
         if not q:
             raise MemoryError("ugs_queries_create failed")
         try:
