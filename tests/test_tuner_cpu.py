@@ -92,7 +92,7 @@ STATIC_DRIVER = r"""
 #include "ugp_knobs.hpp"
 int main(int argc, char **argv) {
     // the static rule for every (tree shape, batch class), then what the knob parser makes of UGP_BOUND3
-    for (int poly = 0; poly < 2; poly++) { for (int c = 0; c < 3; c++) putchar(ugp::b3_static_choice(poly != 0, c) ? '1' : '0'); putchar(' '); }
+    for (int big = 0; big < 2; big++) for (int poly = 0; poly < 2; poly++) { for (int c = 0; c < 3; c++) putchar(ugp::b3_static_choice(poly != 0, c, big ? 10000000ull : 1000000ull) ? '1' : '0'); putchar(' '); }
     printf("%d\n", ugp::Knobs::from_env().bound3);
     // two classes taking turns: no block of either ever completes, nothing is ever recorded
     ugp::B3Tuner T;
@@ -119,11 +119,12 @@ def test_static_choice_and_the_knob(tmp_path):
     the caller's steps: every call of a kind runs the same way from the first one on.  UGP_BOUND3=auto keeps the run-time tuner,
     1 / 0 pin it."""
     out = _static(tmp_path, None)
-    rule, knob = out[0].split()[:2], out[0].split()[2]
-    assert rule == ["111", "001"]        # random-attachment shape: always; polytomy-dominated shape: only for hundreds of rows per sample
+    rule, knob = out[0].split()[:4], out[0].split()[4]
+    # (1 M nodes: random shape, polytomy shape; 10 M nodes: the same) x (few rows, tens of rows, hundreds of rows per sample)
+    assert rule == ["001", "001", "111", "001"]
     assert knob == "-2"
-    assert _static(tmp_path, "auto")[0].split()[2] == "-1"
-    assert _static(tmp_path, "1")[0].split()[2] == "1" and _static(tmp_path, "0")[0].split()[2] == "0"
+    assert _static(tmp_path, "auto")[0].split()[4] == "-1"
+    assert _static(tmp_path, "1")[0].split()[4] == "1" and _static(tmp_path, "0")[0].split()[4] == "0"
 
 
 def test_tuner_never_pins_a_mode_it_has_no_figure_for(tmp_path):

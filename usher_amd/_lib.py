@@ -97,6 +97,7 @@ SYMBOLS = {
     "ugp_fitch_count": (C.c_uint64, [P]),
     "ugp_fitch_get": (C.c_int, [P, P, P, P, P]),
     "ugp_fitch_destroy": (None, [P]),
+    "ugp_fitch_release": (None, [C.c_int]),
     "ugp_mat_create_chunked": (C.c_int, [C.POINTER(ugp_tree_desc), C.c_int, C.c_uint32, C.POINTER(P)]),
     "ugp_flat_create": (C.c_int, [C.POINTER(ugp_tree_desc), C.c_uint32, C.POINTER(P)]),
     "ugp_flat_destroy": (None, [P]),

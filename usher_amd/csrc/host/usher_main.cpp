@@ -25,6 +25,7 @@ struct GpuCtx {
     std::vector<int> devices{0};
     std::vector<ugp_mat *> mats;
     ugp_fitch *fitch = nullptr;
+    bool fitch_pool = false;   // ugp_fitch_sankoff has run: its pooled device buffers are handed back before the first tree goes to the device
     uint64_t version = 0;
     std::string err;
     std::thread warm_th;   // Backend::warm: the device runtime comes up while the inputs are read
@@ -39,6 +40,7 @@ int ensure(GpuCtx *c, const ugp_tree_desc *t, uint64_t version) {
     if (c->warm_th.joinable()) c->warm_th.join();
     if (!c->mats.empty() && c->version == version) return UGP_OK;
     drop_mats(c);
+    if (c->fitch_pool) { ugp_fitch_release(c->devices[0]); c->fitch_pool = false; }   // (the MAT is built: up to 4 GiB of row storage back to the placement handles)
     c->mats.assign(c->devices.size(), nullptr);
     int rc = ugp_mat_create_multi(t, c->devices.data(), (int)c->devices.size(), c->mats.data());
     if (rc != UGP_OK) { c->err = ugp_last_error(); c->mats.clear(); return rc; }
@@ -138,6 +140,7 @@ int gpu_prepare(void *ctx, const ugp_tree_desc *t, uint64_t v) { return ensure((
 int gpu_fitch(void *ctx, uint64_t n_nodes, const uint32_t *parent, const ugp_sites *sites, uint64_t *n_out) {
     GpuCtx *c = (GpuCtx *)ctx;
     if (c->fitch) { ugp_fitch_destroy(c->fitch); c->fitch = nullptr; }
+    c->fitch_pool = true;
     if (int rc = ugp_fitch_sankoff(c->devices[0], n_nodes, parent, sites, &c->fitch)) { c->err = ugp_last_error(); return rc; }
     *n_out = ugp_fitch_count(c->fitch);
     return UGP_OK;

@@ -239,6 +239,11 @@ struct ugp_mat {
         DevBuf<ugp_result> d_job_out;
         PinBuf job_in, job_out;
         bool job_busy = false;           // a job on this set has been started and not yet waited for
+        // (round 6) a side stream of the set: work of one call that does not depend on each other runs beside its main chain -- the fill of
+        // the main pass's allele tiles under the locality pre-pass, the third bound's tables beside the seed descent (fork / join events)
+        hipStream_t aux = nullptr;
+        hipEvent_t ev_fork = nullptr, ev_fill = nullptr, ev_join = nullptr;
+        bool join_pending = false;       // work on `aux` that the call's stream has not waited for yet
         hipStream_t stream = nullptr;    // the handle's own stream for this set (ugp_place_device)
         hipEvent_t done = nullptr;       // recorded behind the last call that used this set
         hipStream_t done_on = nullptr;   // ... on this stream
@@ -362,6 +367,7 @@ int run_place(ugp_mat *m, ugp_qset *qs, int mode, ugp_result *d_out, int32_t *d_
     struct Finish {   // whatever way this call ends: mark the set's last use
         ugp_mat::Work &W; hipStream_t s;
         ~Finish() {
+            if (W.join_pending) { (void)hipStreamWaitEvent(s, W.ev_join, 0); W.join_pending = false; }   // (a call that failed between fork and join)
             if (!W.done && hipEventCreateWithFlags(&W.done, hipEventDisableTiming) != hipSuccess) { W.done = nullptr; return; }
             (void)hipEventRecord(W.done, s);
             W.done_on = s;
@@ -391,6 +397,32 @@ int run_place(ugp_mat *m, ugp_qset *qs, int mode, ugp_result *d_out, int32_t *d_
     const bool packed_ok = (mode == 0) && (!ex || ex_packable) && !K.force_v1 && !f.mask_not_first && (qs->max_rows + f.max_path_muts + 2 < 0x7F7Full);
     const bool sorted = packed_ok && m->coarse && Q > 512 && !K.no_sort && !K.no_prune;
     TG.coarse_timed = false;
+    // The side stream (see Work::aux): only where there is something to put on it -- the sorted main pass.
+    // And only for a call that has the device to itself: measured with three calls in flight (six queues instead of three), the
+    // cross-queue waits cost far more than the overlap gives -- 12.9 -> 10.4 M placements/s; a lone call gains 45 us of its 1.96 ms.
+    const bool can_fork = sorted && !coarse_only && !K.no_fork && !m->sharing;
+    bool fill_ahead = false;   // the first sub-batch's table has been filled with the reference bases on the side stream, under the pre-pass
+    if (can_fork) {
+        if (!W.aux) {
+            HIP_TRY(hipStreamCreateWithFlags(&W.aux, hipStreamNonBlocking));
+            HIP_TRY(hipEventCreateWithFlags(&W.ev_fork, hipEventDisableTiming)); HIP_TRY(hipEventCreateWithFlags(&W.ev_fill, hipEventDisableTiming));
+            HIP_TRY(hipEventCreateWithFlags(&W.ev_join, hipEventDisableTiming));
+        }
+        // plain batches (fill + scatter; the other tile builders write every row themselves): the fill depends on nothing but the set
+        // being free, which `s` has just waited for
+        int nmi0 = -1;
+        for (int i = 0; i < 2; i++) if (qs->nmask_for[i] == m && n_sites) nmi0 = i;
+        const uint64_t nq0 = std::min<uint64_t>(Q, (uint64_t)kMaxTilesPerLaunch * 64);
+        if (nmi0 < 0 && K.tile_build <= 0 && f.n_sites && nq0 == Q) {
+            const uint64_t dw = (uint64_t)((nq0 + 511) / 512) * (n_sites + ugp::TABLE_CONST_ROWS) * 64;
+            HIP_TRY(W.d_table.reserve(dw));
+            HIP_TRY(hipEventRecord(W.ev_fork, s));
+            HIP_TRY(hipStreamWaitEvent(W.aux, W.ev_fork, 0));
+            HIP_TRY(ugp::launch_fill_table(W.d_table.p, m->d_site_ref.p, n_sites, dw, W.aux));
+            HIP_TRY(hipEventRecord(W.ev_fill, W.aux));
+            fill_ahead = true;
+        }
+    }
     if (sorted) {
         HIP_TRY(W.d_coarse_res.reserve(Q));
         if (!TG.ev_coarse[0]) { HIP_TRY(hipEventCreate(&TG.ev_coarse[0])); HIP_TRY(hipEventCreate(&TG.ev_coarse[1])); }
@@ -463,7 +495,7 @@ int run_place(ugp_mat *m, ugp_qset *qs, int mode, ugp_result *d_out, int32_t *d_
         // kind runs the same way from the first one on; UGP_BOUND3=auto: the handle's run-time A/B (B3Tuner); 1 / 0: pinned
         const bool b3_tuned = b3_can && K.bound3 == -1;
         if (b3_tuned) { tuner_poll(m); b3_want = m->b3_tuner.next(b3_class, &b3_pos, &b3_seq); }
-        else if (b3_can && K.bound3 < -1) b3_want = ugp::b3_static_choice(m->wide_descent, b3_class);
+        else if (b3_can && K.bound3 < -1) b3_want = ugp::b3_static_choice(m->wide_descent, b3_class, f.n_nodes);
         const size_t z_dbottom = 0, z_active = z_dbottom + (size_t)n_tiles512 * 512, z_queue = z_active + (size_t)n_tiles512 * active_words,
                      z_list_n = z_queue + 8, z_nitems = z_list_n + n_tiles512, z_cnt = z_nitems + 8, z_key = z_cnt + (size_t)n_tiles512 * 512,
                      z_useful = z_key + (size_t)n_tiles512 * 512, z_end = z_useful + (b3_want ? (size_t)n_tiles512 * useful_words : 0);
@@ -516,7 +548,8 @@ int run_place(ugp_mat *m, ugp_qset *qs, int mode, ugp_result *d_out, int32_t *d_
                                             qs->d_ref.p, qs->d_nuc.p, qs->d_missing.p, m->d_pos2site.p, m->d_site_pos.p, m->d_site_ref.p, n_sites, f.max_pos,
                                             d_dbottom, qs->d_err.p, s));
         else {
-        HIP_TRY(ugp::launch_fill_table(W.d_table.p, m->d_site_ref.p, n_sites, table_dwords, s));
+        if (fill_ahead && q0 == 0) HIP_TRY(hipStreamWaitEvent(s, W.ev_fill, 0));
+        else HIP_TRY(ugp::launch_fill_table(W.d_table.p, m->d_site_ref.p, n_sites, table_dwords, s));
         HIP_TRY(ugp::launch_scatter(W.d_table.p, d_dbottom, qs->d_pos.p + e0, qs->d_ref.p + e0,
                                     qs->d_nuc.p + e0, qs->d_missing.p + e0, qs->d_ent_q.p + e0, m->d_pos2site.p,
                                     f.max_pos, n_sites, e1 - e0, (uint32_t)q0, d_active, active_words, slot_of, qs->d_err.p, d_useful, useful_words, s));
@@ -535,8 +568,16 @@ int run_place(ugp_mat *m, ugp_qset *qs, int mode, ugp_result *d_out, int32_t *d_
                 HIP_TRY(hipMemcpy(W.d_b3_dev.p, &hd, sizeof hd, hipMemcpyHostToDevice));
                 W.b3_host = hd;
             }
+            // (beside the seed descent, which needs the tiles but not the tables: the walk's launch joins the two)
+            hipStream_t sb = s;
+            if (can_fork) {
+                HIP_TRY(hipEventRecord(W.ev_fork, s));
+                HIP_TRY(hipStreamWaitEvent(W.aux, W.ev_fork, 0));
+                sb = W.aux;
+            }
             HIP_TRY(ugp::launch_b3_tables(d_useful, useful_words, n_sites, n_tiles512, m->d_b3_group_off.p, m->d_b3_events.p, nb, W.d_b3_pairmask.p,
-                                          W.d_b3_over.p, W.d_b3_under.p, W.d_b3_l1.p, W.d_b3_l2.p, W.d_b3_l3.p, s));
+                                          W.d_b3_over.p, W.d_b3_under.p, W.d_b3_l1.p, W.d_b3_l2.p, W.d_b3_l3.p, sb));
+            if (can_fork) { HIP_TRY(hipEventRecord(W.ev_join, W.aux)); W.join_pending = true; }
         }
         // phase 2 without a walk for the samples whose minimum is attained by one node (ugp_kernels.hpp Phase2Uniq): the plain search only
         ugp::Phase2Uniq uq{};
@@ -769,6 +810,7 @@ int run_place(ugp_mat *m, ugp_qset *qs, int mode, ugp_result *d_out, int32_t *d_
             // chip; the small kernels in front of the second walk are slowed by the first and become the critical path)
             const bool exclusive = K.kbest_exclusive;
             if (exclusive && !coarse_only && m->kb_done && m->kb_done_on != s) HIP_TRY(hipStreamWaitEvent(s, m->kb_done, 0));
+            if (W.join_pending) { HIP_TRY(hipStreamWaitEvent(s, W.ev_join, 0)); W.join_pending = false; }
             HIP_TRY(ugp::launch_best8(b, (uint32_t)blocks, s));
             if (exclusive && !coarse_only) {
                 if (!m->kb_done) HIP_TRY(hipEventCreateWithFlags(&m->kb_done, hipEventDisableTiming));
@@ -1198,6 +1240,8 @@ void ugp_mat_destroy(ugp_mat *m) {
                 fprintf(stderr, "[ugp stats] third bound, batches of class %d: %u blocks; ms per tile with %.5f (%u blocks measured), without %.5f (%u)\n", c, m->b3_tuner.blocks[c],
                         m->b3_tuner.ema[c][1], m->b3_tuner.n[c][1], m->b3_tuner.ema[c][0], m->b3_tuner.n[c][0]);
     for (auto &W : m->work) {
+        if (W.aux) { (void)hipStreamSynchronize(W.aux); (void)hipStreamDestroy(W.aux); }
+        for (hipEvent_t e : {W.ev_fork, W.ev_fill, W.ev_join}) if (e) (void)hipEventDestroy(e);
         if (W.stream) { (void)hipStreamSynchronize(W.stream); (void)hipStreamDestroy(W.stream); }
         if (W.done) { (void)hipEventSynchronize(W.done); (void)hipEventDestroy(W.done); }
         for (auto &G : W.gens) {

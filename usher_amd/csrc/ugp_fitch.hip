@@ -283,6 +283,7 @@ struct Dev {
     T *p = nullptr;
     size_t cap = 0;
     ~Dev() { if (p) (void)hipFree(p); }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
     hipError_t alloc(size_t n) {
         if (n <= cap && p) return hipSuccess;
         if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
@@ -331,7 +332,7 @@ __global__ void k_fs_level_ranks(const uint32_t *__restrict__ heads, const uint3
 
 struct FsPool {   // one per device, kept until the process ends: a call allocates nothing in the steady state
     std::mutex mu;
-    Dev<uint32_t> d_parent, d_first, d_nchild, d_inodes, d_heads, d_small, d_F, d_refw, d_vnode;
+    Dev<uint32_t> d_parent, d_first, d_nchild, d_inodes, d_heads, d_small, d_levels, d_F, d_refw, d_vnode;
     Dev<uint8_t> d_flag, d_vnuc, d_oval, d_oval2, d_tmp, d_sel_tmp;
     Dev<uint64_t> d_okey, d_okey2, d_voff;
     Dev<unsigned long long> d_cnt, d_segb;
@@ -346,6 +347,20 @@ FsPool *fs_pool(int device) {
 }
 
 }  // namespace
+
+// the pool keeps up to 4 GiB of row storage and the sort buffers per device for the next call; a caller that is done
+// building (the front end behind `-t`, before it places samples on the same device) hands them back.
+extern "C" void ugp_fitch_release(int device) {
+    if (device < 0) return;
+    FsPool *p = fs_pool(device);
+    std::lock_guard<std::mutex> g(p->mu);
+    if (hipSetDevice(device) != hipSuccess) return;
+    (void)hipDeviceSynchronize();
+    for (Dev<uint32_t> *d : {&p->d_parent, &p->d_first, &p->d_nchild, &p->d_inodes, &p->d_heads, &p->d_small, &p->d_levels, &p->d_F, &p->d_refw, &p->d_vnode}) d->release();
+    for (Dev<uint8_t> *d : {&p->d_flag, &p->d_vnuc, &p->d_oval, &p->d_oval2, &p->d_tmp, &p->d_sel_tmp}) d->release();
+    for (Dev<uint64_t> *d : {&p->d_okey, &p->d_okey2, &p->d_voff}) d->release();
+    for (Dev<unsigned long long> *d : {&p->d_cnt, &p->d_segb}) d->release();
+}
 
 struct ugp_fitch {
     std::vector<uint32_t> site, node;
@@ -398,7 +413,7 @@ extern "C" int ugp_fitch_sankoff(int device, uint64_t n_nodes, const uint32_t *p
     // the nodes whose parent lies in it), meaningful once the device has confirmed the order.
     FS_TRY(d_parent.upload(parent, N, stream));
     FS_TRY(d_first.alloc(N)); FS_TRY(d_nchild.alloc(N)); FS_TRY(d_inodes.alloc(N)); FS_TRY(P.d_heads.alloc(N)); FS_TRY(P.d_flag.alloc(N));
-    FS_TRY(P.d_small.alloc(4096));   // [0] order violated, [1] run heads, [2] cell flags, [8..] level tables
+    FS_TRY(P.d_small.alloc(16));   // [0] order violated, [1] run heads, [2] cell flags
     FS_TRY(hipMemsetAsync(P.d_small.p, 0, 8 * sizeof(uint32_t), stream));
     FS_TRY(hipMemsetAsync(d_first.p, 0, (size_t)N * 4, stream));
     FS_TRY(hipMemsetAsync(d_nchild.p, 0, (size_t)N * 4, stream));
@@ -416,7 +431,7 @@ extern "C" int ugp_fitch_sankoff(int device, uint64_t n_nodes, const uint32_t *p
         // first j whose parent is not in front of the end of the last level: std::lower_bound over parent[1..N)
         const uint32_t lim = lvl_off.back();
         const uint32_t nxt = (uint32_t)(std::lower_bound(parent + 1, parent + N, lim) - parent);
-        if (nxt <= lim || lvl_off.size() > 4096 - 16) break;   // (no progress: the array is not a breadth-first expansion -- the device says so below; or a tree deeper than the level table)
+        if (nxt <= lim) break;   // (no progress: the array is not a breadth-first expansion -- the device says so below)
         lvl_off.push_back(nxt);
     }
     if (lvl_off.back() != N) {
@@ -424,15 +439,15 @@ extern "C" int ugp_fitch_sankoff(int device, uint64_t n_nodes, const uint32_t *p
         FS_TRY(hipMemcpyAsync(&bad, P.d_small.p, 4, hipMemcpyDeviceToHost, stream));
         FS_TRY(hipStreamSynchronize(stream));
         if (bad || N > 1) {
-            if (!bad && lvl_off.size() > 4096 - 16) return ugp::set_error(UGP_ERR_UNSUPPORTED, "tree deeper than 4,000 levels");
             return ugp::set_error(UGP_ERR_INVALID, "tree arrays are not in breadth-first order");
         }
     }
     const uint32_t n_levels = (uint32_t)lvl_off.size() - 1;
     std::vector<uint32_t> ilvl_off(n_levels + 1, 0);
     {
-        uint32_t *d_lvl = P.d_small.p + 8, *d_ilvl = P.d_small.p + 8 + (n_levels + 1);
-        FS_TRY(P.d_small.cap >= 8 + 2 * (size_t)(n_levels + 1) ? hipSuccess : hipErrorInvalidValue);
+        // (the level tables have a buffer of their own, sized by the tree -- a caterpillar has as many levels as nodes)
+        FS_TRY(P.d_levels.alloc(2 * (size_t)(n_levels + 1)));
+        uint32_t *d_lvl = P.d_levels.p, *d_ilvl = P.d_levels.p + (n_levels + 1);
         FS_TRY(hipMemcpyAsync(d_lvl, lvl_off.data(), (n_levels + 1) * 4, hipMemcpyHostToDevice, stream));
         hipLaunchKernelGGL(k_fs_level_ranks, dim3((n_levels + 1 + 63) / 64), dim3(64), 0, stream, P.d_heads.p, P.d_small.p + 1, d_lvl, n_levels, d_ilvl);
         uint32_t bad = 0;
@@ -497,6 +512,9 @@ extern "C" int ugp_fitch_sankoff(int device, uint64_t n_nodes, const uint32_t *p
         unsigned long long seg_cap = 0;
         for (int attempt = 0; attempt < 2; attempt++) {
             FS_TRY(hipMemcpyAsync(d_refw.p, refw.data(), (size_t)W * 4, hipMemcpyHostToDevice, stream));
+            // (round 6) the rows are initialised -- N x W words written, 2.3 ms at 10 M nodes x 2 048 sites -- while the cells cross
+            // PCIe: the init needs the reference word only, and a copy from the caller's pageable arrays keeps the host busy anyway
+            hipLaunchKernelGGL(k_fs_init, blocks((uint64_t)N * gy, FS_NB), dim3(256), 0, stream, d_F.p, d_refw.p, d_nchild.p, N, W, gy);
             FS_TRY(d_voff.upload(voff.data(), voff.size(), stream));
             FS_TRY(d_vnode.upload(cell_node, n_cells, stream));
             FS_TRY(d_vnuc.upload(cell_nuc, n_cells, stream));
@@ -508,7 +526,6 @@ extern "C" int ugp_fitch_sankoff(int device, uint64_t n_nodes, const uint32_t *p
             if (const char *e = getenv("UGP_FITCH_EMIT_CAP")) seg_cap = strtoull(e, nullptr, 10);
             FS_TRY(d_okey.alloc(seg_cap * FS_SEG));
             FS_TRY(d_oval.alloc(seg_cap * FS_SEG));
-            hipLaunchKernelGGL(k_fs_init, blocks((uint64_t)N * gy, FS_NB), dim3(256), 0, stream, d_F.p, d_refw.p, d_nchild.p, N, W, gy);
             uint32_t cell_flags = 0;
             if (n_cells) {
                 hipLaunchKernelGGL(k_fs_scatter, dim3((unsigned)((n_cells + 255) / 256)), dim3(256), 0, stream, d_F.p, d_refw.p, d_nchild.p,
@@ -576,14 +593,21 @@ extern "C" int ugp_fitch_sankoff(int device, uint64_t n_nodes, const uint32_t *p
         FS_TRY(d_okey.alloc(n_mut));
         FS_TRY(d_oval.alloc(n_mut));
         // deterministic order: by site, then breadth-first node index
-        size_t tmp_bytes = 0;
-        FS_TRY(rocprim::radix_sort_pairs(nullptr, tmp_bytes, d_okey2.p, d_okey.p, d_oval2.p, d_oval.p, (size_t)n_mut, 0u, 64u, stream));
+        // (key = site << 32 | node: a stable sort by the node's bits, then by the site's -- the radix passes over the empty bits between
+        // the two fields and above the site are not run: 35 of 64 bits at 10 M nodes x 2 048 sites)
+        auto bits_of = [](uint64_t n) { unsigned b = 1; while (b < 32 && (n >> b)) b++; return b; };
+        const unsigned nb_bits = bits_of(N), sb_bits = bits_of(s1 > 0 ? s1 - 1 : 0);
+        size_t tmp_bytes = 0, tmp2 = 0;
+        FS_TRY(rocprim::radix_sort_pairs(nullptr, tmp_bytes, d_okey2.p, d_okey.p, d_oval2.p, d_oval.p, (size_t)n_mut, 0u, nb_bits, stream));
+        FS_TRY(rocprim::radix_sort_pairs(nullptr, tmp2, d_okey.p, d_okey2.p, d_oval.p, d_oval2.p, (size_t)n_mut, 32u, 32u + sb_bits, stream));
+        tmp_bytes = std::max(tmp_bytes, tmp2);
         FS_TRY(d_tmp.alloc(tmp_bytes));
-        FS_TRY(rocprim::radix_sort_pairs(d_tmp.p, tmp_bytes, d_okey2.p, d_okey.p, d_oval2.p, d_oval.p, (size_t)n_mut, 0u, 64u, stream));
+        FS_TRY(rocprim::radix_sort_pairs(d_tmp.p, tmp_bytes, d_okey2.p, d_okey.p, d_oval2.p, d_oval.p, (size_t)n_mut, 0u, nb_bits, stream));
+        FS_TRY(rocprim::radix_sort_pairs(d_tmp.p, tmp_bytes, d_okey.p, d_okey2.p, d_oval.p, d_oval2.p, (size_t)n_mut, 32u, 32u + sb_bits, stream));
         h_key.resize(n_mut);
         h_val.resize(n_mut);
-        FS_TRY(hipMemcpyAsync(h_key.data(), d_okey.p, n_mut * sizeof(uint64_t), hipMemcpyDeviceToHost, stream));
-        FS_TRY(hipMemcpyAsync(h_val.data(), d_oval.p, n_mut, hipMemcpyDeviceToHost, stream));
+        FS_TRY(hipMemcpyAsync(h_key.data(), d_okey2.p, n_mut * sizeof(uint64_t), hipMemcpyDeviceToHost, stream));
+        FS_TRY(hipMemcpyAsync(h_val.data(), d_oval2.p, n_mut, hipMemcpyDeviceToHost, stream));
         FS_TRY(hipStreamSynchronize(stream));
         const size_t base = res->site.size();
         res->site.resize(base + n_mut); res->node.resize(base + n_mut); res->par.resize(base + n_mut); res->nuc.resize(base + n_mut);

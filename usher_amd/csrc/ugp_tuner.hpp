@@ -18,13 +18,19 @@ namespace ugp {
 // UGP_BOUND3=1 / 0 (or UGP_NO_BOUND3) pins the choice.  (First version: each sub-batch's own first-to-last-kernel time -- with
 // three calls in flight that mostly measures the neighbours, and the choice flipped at random.)
 // The default (round 6): no A/B inside the caller's steps.  Whether the tables pay is decided from two things known
-// before the batch runs -- the shape of the tree (fixed at ugp_mat_create: `polytomy_tree` = more than 5 % of the nodes hang off a node
+// before the batch runs -- the size and shape of the tree (fixed at ugp_mat_create: `polytomy_tree` = more than 5 % of the nodes hang off a node
 // with more than 16 children, the SARS-CoV-2 shape: short branches, hsub is small already, the walk's cost is sibling runs that no
 // subtree test removes) and the batch's class by rows per sample (B3Tuner::class_of).  The measured cases (tools/b3_static_probe.sh,
 // profiles/r06_b3_static_probe.txt) separate on exactly these; B3Tuner stays available as UGP_BOUND3=auto.
-inline bool b3_static_choice(bool polytomy_tree, int row_class) {
-    if (!polytomy_tree) return true;          // random-attachment shape: +3-5 % on plain batches, +70-100 % on ambiguous ones
-    return row_class >= 2;                    // polytomy-dominated shape: only for batches of hundreds of rows per sample
+inline bool b3_static_choice(bool polytomy_tree, int row_class, uint64_t n_nodes) {
+    // measured on one MI355X, 16 384 samples per call, M placements/s without / with (profiles/r06_b3_static_probe.txt):
+    //   random-attachment 10 M nodes, plain queries     12.06 / 12.97        the same tree, ambiguous queries   3.69 / 6.94
+    //   random-attachment  1 M nodes, plain queries     23.65 / 22.45        (the tables cost per block of the stream, the walk of a small tree is short)
+    //   SARS-CoV-2 shape  10 M nodes, plain queries     11.53 / 10.59        the same tree, ambiguous queries   4.87 / 6.38
+    //   SARS-CoV-2 shape  15 M x 10 000                  6.65 /  6.59        SARS-CoV-2 shape 1 M nodes        22.60 / 21.84
+    if (row_class >= 2) return true;          // hundreds of rows per sample (runs of N, IUPAC cells): large bounds, weak first test -- the third decides
+    if (polytomy_tree) return false;          // short branches: hsub is small already; what the walk costs there is sibling runs
+    return n_nodes >= 3000000ull;             // plain batches: from a few million nodes on the walk saves more than the tables cost
 }
 
 struct B3Tuner {

@@ -45,3 +45,8 @@ def fitch_sankoff(parent, ref, var_off, var_node, var_nuc, device: int = 0):
     finally:
         L.ugp_fitch_destroy(h)
     return site, node, mpar, mnuc
+
+
+def release_pool(device: int = 0) -> None:
+    """ugp_fitch_release: hand the pooled device buffers of fitch_sankoff (up to 4 GiB of row storage) back."""
+    _lib.lib().ugp_fitch_release(device)
