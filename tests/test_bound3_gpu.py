@@ -27,6 +27,7 @@ def _tables(placer, tile):
 @pytest.mark.parametrize("seed,n_leaves,ambig", [(11, 3000, (0, 0, 2, 6)), (12, 9000, (0, 0, 0, 0)), (13, 9000, (3, 8, 0, 3))])
 def test_device_tables_equal_the_restatement(seed, n_leaves, ambig, monkeypatch):
     monkeypatch.setenv("UGP_COARSE_MIN_NODES", "0")   # (the bound serves the sorted main walk: needs the locality pre-pass)
+    monkeypatch.setenv("UGP_BOUND3", "1")             # (pinned on: by itself the library leaves it off for plain batches on trees this small)
     monkeypatch.delenv("UGP_NO_BOUND3", raising=False)
     arrays, queries = synth.make_case(seed, n_leaves=n_leaves, n_queries=12, n_sites=400, n_ambig=ambig, p_masked=0.01)
     flat = FlatTreeView(arrays)

@@ -136,5 +136,6 @@ def lib(experiments: bool = False):
             _lib_exp = _load(EXP_LIB_PATH)
         return _lib_exp
     if _lib is None:
-        _lib = _load(LIB_PATH)
+        # (tuning hook: USHER_AMD_LIB names another build of the same sources -- e.g. one compiled with -DUGP_GRP=8 -- for an A/B on one box)
+        _lib = _load(os.environ.get("USHER_AMD_LIB") or LIB_PATH)
     return _lib
