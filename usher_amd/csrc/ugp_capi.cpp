@@ -16,6 +16,8 @@
 #include <mutex>
 #include <vector>
 
+#include <unistd.h>
+
 #include "ugp_bound3.hpp"
 #include "ugp_tuner.hpp"
 #include "ugp_flatten.hpp"
@@ -1153,7 +1155,11 @@ constexpr uint64_t kFlatMagic = 0x3154414C46504755ull;   // "UGPFLAT1"
 uint64_t flat_signature() {
     uint64_t h = 1469598103934665603ull;
     auto mix = [&](const char *p) { for (; p && *p; p++) { h ^= (uint8_t)*p; h *= 1099511628211ull; } h ^= 0xFF; h *= 1099511628211ull; };
-    mix(__DATE__ " " __TIME__);
+    mix(__DATE__ " " __TIME__);   // (this translation unit's build ...
+    // ... and the format itself: an explicit version of the flattening's layouts plus the constants they are built from)
+    const uint64_t fmt[] = {ugp::FLAT_FORMAT_VERSION, ugp::B3_BLOCK_SHIFT, ugp::B3_GROUP_SHIFT, ugp::T_PRUNE_MIN_DWORDS, ugp::PRUNE_MIN_WORDS, ugp::LDS_SLOTS, ugp::MAX_HOT_SLOTS,
+                            ugp::INFO_JUMP_MASK, sizeof(ugp::FlatMat), sizeof(HostFlat), sizeof(ugp_result)};
+    for (uint64_t v : fmt) { h ^= v; h *= 1099511628211ull; }
     for (const char *k : {"UGP_CHUNK_NODES", "UGP_PRUNE_MIN_WORDS", "UGP_NO_SIB", "UGP_NO_BOUND2", "UGP_LDS_SLOTS", "UGP_PRE_WEIGHT", "UGP_NO_UPDATE_MAPS",
                           "UGP_COARSE_MIN_NODES", "UGP_NO_SORT", "UGP_COARSE_DIV", "UGP_COARSE_FLOOR", "UGP_COARSE_CHUNK_NODES", "UGP_NO_BOUND3"}) { mix(k); mix(getenv(k)); }
     return h;
@@ -1191,16 +1197,18 @@ int ugp_flat_save(const ugp_tree_desc *tree, const char *path) {
     if (!tree || !path) return fail(UGP_ERR_INVALID, "null argument");
     HostFlat hf;
     if (int rc = host_flatten(tree, default_options(), true, hf)) return rc;
-    FILE *fp = fopen(path, "wb");
-    if (!fp) return fail(UGP_ERR_INVALID, std::string("cannot write ") + path);
+    // (written under a temporary name and renamed: a reader never sees half a file)
+    const std::string tmp = std::string(path) + ".tmp." + std::to_string((unsigned long long)getpid());
+    FILE *fp = fopen(tmp.c_str(), "wb");
+    if (!fp) return fail(UGP_ERR_INVALID, std::string("cannot write ") + tmp);
     FlatWriter w{fp};
     w.pod(kFlatMagic); const uint64_t sig = flat_signature(); w.pod(sig);
     const uint8_t has_coarse = hf.coarse ? 1 : 0;
     w.pod(has_coarse);
     flat_io(w, hf);
     if (hf.coarse) flat_io(w, *hf.coarse);
-    const bool ok = w.ok && fclose(fp) == 0;
-    if (!ok) return fail(UGP_ERR_INVALID, std::string("short write to ") + path);
+    const bool ok = (fclose(fp) == 0) && w.ok;
+    if (!ok || rename(tmp.c_str(), path) != 0) { (void)remove(tmp.c_str()); return fail(UGP_ERR_INVALID, std::string("short write to ") + path); }
     return UGP_OK;
 }
 
@@ -1227,6 +1235,15 @@ int ugp_mat_create_from_flat(const char *path, int device, ugp_mat **out) {
         flat_io(r, hf);
         if (has_coarse) { hf.coarse = new HostFlat(); flat_io(r, *hf.coarse); }
         if (!r.ok || r.p != r.e) return fail(UGP_ERR_INVALID, "truncated or oversized flattening file");
+        // (the file's contents index device tables: what the kernels trust is checked here)
+        for (const HostFlat *x : {(const HostFlat *)&hf, (const HostFlat *)hf.coarse}) {
+            if (!x) continue;
+            const auto &g = x->f;
+            if (g.site_ref.size() != g.n_sites || g.pos2site.size() != (size_t)g.max_pos + 1 || g.chunk8_body_off.size() != (size_t)g.n_chunks + 1 ||
+                g.chunk_body_off.size() != (size_t)g.n_chunks + 1 || g.rank2bfs.size() != g.n_nodes || g.dfs2bfs.size() != g.n_nodes)
+                return fail(UGP_ERR_INVALID, "inconsistent flattening file (array sizes)");
+            for (int32_t v : g.pos2site) if (v >= (int64_t)g.n_sites) return fail(UGP_ERR_INVALID, "inconsistent flattening file (site index out of range)");
+        }
         return upload_flat(hf, device, out);
     } catch (const std::bad_alloc &) { return fail(UGP_ERR_NOMEM, "out of host memory"); }
 }

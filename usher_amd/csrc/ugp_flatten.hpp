@@ -141,6 +141,10 @@ constexpr uint32_t B3_GROUP_SHIFT = 8, B3_GROUP_BLOCKS = 1u << B3_GROUP_SHIFT;
 // blocks per tile row of the tables (whole groups; one block more than the stream has words for)
 inline uint32_t b3_blocks(uint64_t stream8_words) { return (uint32_t)((((stream8_words + B3_BLOCK_WORDS - 1) >> B3_BLOCK_SHIFT) + 1u + B3_GROUP_BLOCKS - 1u) & ~(uint64_t)(B3_GROUP_BLOCKS - 1u)); }
 constexpr uint32_t MAX_SITES = 1u << 22;
+// Version of everything flatten() produces (stream encodings, record fields, event lists): BUMP IT with every change of a layout.
+// ugp_flat_save stamps its files with it (next to the flattening switches), ugp_mat_create_from_flat refuses any other -- a build
+// time stamp of one translation unit cannot see a change made in another.  6: events listed under their own word's block.
+constexpr uint32_t FLAT_FORMAT_VERSION = 6;
 constexpr uint32_t MAX_NODE_MUTS = 65534;   // 0xFFFF marks a pruning pseudo-record of the tie stream
 
 struct Options {
