@@ -117,6 +117,8 @@ def stored_profile(info, Q, packed):
             m = re.match(r"r(\d+)([a-z]*)_", os.path.basename(fn))
             return (int(m.group(1)), m.group(2) == "", m.group(2)) if m else (-1, False, "")
         for fn in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.json")), key=round_key, reverse=True):
+            if not re.fullmatch(r"r\d+[a-z]*_pmc_summary\.json", os.path.basename(fn)):
+                continue   # (rNN_dense_ / rNN_sars2_ / rNN_config5_: profiles of other workloads on the same tree)
             with open(fn) as f:
                 ps = json.load(f)
             cfg = ps.get("bench", {}).get("config", {})
