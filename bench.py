@@ -40,7 +40,7 @@ def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=30)   # (covers the handle's own trial of the third pruning bound: four blocks of six calls)
+    ap.add_argument("--warmup", type=int, default=5)    # (since round 6 nothing is tried out inside the caller's steps: the third bound is decided before the batch runs)
     ap.add_argument("--nodes", type=int, default=10_000_000)
     ap.add_argument("--sites", type=int, default=0, help="variable sites (default 25000 at >=1M nodes, else 1500)")
     ap.add_argument("--queries", type=int, default=16384, help="query samples per GPU per step (total samples with --strong)")
@@ -584,8 +584,7 @@ def main():
             extra["config4_1m_queries_one_gpu"] = {"error": repr(ex)[:300]}
         # config 5's workload on one device: high-ambiguity queries (100-5,000 N cells + 0-30 IUPAC cells of any 2-3 bases each) and tie lists
         try:
-            # (24 warm-up calls: this class of batches is new to the handle -- its trial of the third pruning bound, four blocks of six calls, is over when the clock starts)
-            c5 = timed_config(pl, st, 16384, 12, 24, ties_cap=64, n_lo=100, n_hi=5000, iupac_hi=30)
+            c5 = timed_config(pl, st, 16384, 12, 6, ties_cap=64, n_lo=100, n_hi=5000, iupac_hi=30)
             c5["workload"] = "BASELINE config 5 on one device: 16,384 queries with 100-5,000 N cells and 0-30 IUPAC cells each on the %d-node MAT, tie lists of up to 64 nodes" % info["n_nodes"]
             extra["config5_high_ambiguity_one_gpu"] = c5
         except Exception as ex:
@@ -801,7 +800,7 @@ def main():
             pl3 = Placer(st3.arrays, device=dev_index)
             t_flat3 = time.time() - t0
             free_b, total_b = torch.cuda.mem_get_info(dev)
-            c3 = timed_config(pl3, st3, 10_000, 12, 24, recent=True)   # (24 warm-up calls: a new handle, its trial of the third bound first)
+            c3 = timed_config(pl3, st3, 10_000, 12, 6, recent=True)
             i3 = pl3.info()
             c3.update({"workload": "BASELINE config 3's size: synthetic sars2-shaped MAT %d nodes / %d mutations, 10,000 queries per step" % (i3["n_nodes"], i3["n_muts"]),
                        "gen_s": round(t_gen3, 2), "flatten_upload_s": round(t_flat3, 2), "device_bytes_in_use": int(total_b - free_b)})

@@ -192,3 +192,42 @@ def test_extended_searches_at_10m_nodes(big, monkeypatch):
         assert int(tc[i]) == w["num_best"], (name, i)
         if w["num_best"] <= 64:
             assert tj[i].tolist() == w["ties"].tolist() and th[i].tolist() == w["ties_has_unique"].tolist(), (name, i)
+
+
+def test_far_queries_at_10m_nodes(big, monkeypatch):
+    """Round 6: queries that are NOT near any node -- a random node's genotype + 50-200 substitutions, every 8th the
+    all-reference sample (no rows at all) -- the batch bench.py's `far_queries` key times: bounds decide little, the seeds are loose,
+    whole tiles sit at the root.  512 samples against the C closed form (incl. every all-reference one among them), 16 against the
+    literal oracle; with and without the phase-2 shortcut and the third bound the same answers."""
+    st, ot = big
+    for k in KNOBS:
+        monkeypatch.delenv(k, raising=False)
+    q = st.queries(16384, seed=9001, max_subst=200, min_subst=50, ref_every_8th=True)      # (bench.py far_pruned_frac draws seed 9001 too)
+    rows = np.diff(q["ent_off"].astype(np.int64))
+    assert (rows[7::8] == 0).all() and rows[rows > 0].min() >= 20
+    batch = _batch(q)
+    pl = Placer(st.arrays)
+    res = pl.place(batch)
+    assert pl.timing()["packed_path"] == 1
+    for knobs in ({"UGP_NO_UNIQ": "1"}, {"UGP_BOUND3": "0"}, {"UGP_BOUND3": "1", "UGP_NO_FORK": "1"}):
+        for k, v in knobs.items():
+            monkeypatch.setenv(k, v)
+        pl.reload_knobs()
+        again = pl.place(batch)
+        for k in knobs:
+            monkeypatch.delenv(k)
+        assert (_rows(again) == _rows(res)).all(), knobs
+    pl.reload_knobs()
+    pl.close()
+    n_cf, base = 512, 4096
+    e0, e1 = int(q["ent_off"][base]), int(q["ent_off"][base + n_cf])
+    cf = capi.ClosedFormC(ot).place_csr(q["ent_off"][base:base + n_cf + 1] - q["ent_off"][base], q["pos"][e0:e1], q["ref"][e0:e1], q["nuc"][e0:e1],
+                                        q["is_missing"][e0:e1])
+    got = _rows(res)[base:base + n_cf]
+    want = np.stack([cf["best"].astype(np.int64), cf["num_best"].astype(np.int64), cf["best_j"].astype(np.int64), cf["has_unique"].astype(np.int64)], 1)
+    assert (got == want).all(), np.flatnonzero((got != want).any(axis=1))[:10]
+    picks = list(range(3, 16384, 1024)) + [7, 8199]          # (7, 8199: all-reference samples)
+    lit = _pool(lambda i: ot.place(gsynth.csr_sample(q, i)), picks)
+    for i, w in zip(picks, lit):
+        assert (int(res["best_set_difference"][i]), int(res["num_best"][i]), int(res["best_j"][i]), bool(res["best_has_unique"][i])) == \
+               (w["best"], w["num_best"], w["best_j"], w["has_unique"]), i
