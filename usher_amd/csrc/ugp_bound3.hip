@@ -45,7 +45,11 @@ __global__ void __launch_bounds__(256) k_b3_pairmask(const uint32_t *__restrict_
 // words) and range ends (31:16; at most the mutation words of one root path, < 0x7F7F where the lists exist: ugp_flatten.cpp); thread (tile, sixteenth of the group) then turns 16
 // of them into cum_over | cum_under << 16 in place, and the block writes the rows out four bytes (two blocks) at a time.
 constexpr uint32_t B3_ROW = B3_GROUP_BLOCKS + 1;   // (padded: a wave's 32 rows fall into 32 different LDS banks)
-constexpr uint32_t B3_TB = 512, B3_CH = B3_TB / 32, B3_CB = B3_GROUP_BLOCKS / B3_CH;   // threads; scan pieces per tile row; blocks per piece
+#ifndef UGP_B3_TB
+#define UGP_B3_TB 512
+#endif
+constexpr uint32_t B3_TB = UGP_B3_TB, B3_CH = B3_TB / 32, B3_CB = B3_GROUP_BLOCKS / B3_CH;   // threads (128, 256 or 512); scan pieces per tile row; blocks per piece
+static_assert(B3_TB == 128 || B3_TB == 256 || B3_TB == 512, "k_b3_group_tables: 128, 256 or 512 threads");
 __global__ void __launch_bounds__(B3_TB) k_b3_group_tables(const uint32_t *__restrict__ pairmask, uint32_t n_pairs, uint32_t n_tiles, const uint32_t *__restrict__ group_off,
                                                            const uint32_t *__restrict__ events, uint32_t n_groups, uint32_t n_blocks,
                                                            uint16_t *__restrict__ over, uint16_t *__restrict__ under, uint16_t *__restrict__ l1, uint32_t n_l1) {

@@ -802,6 +802,11 @@ int run_place(ugp_mat *m, ugp_qset *qs, int mode, ugp_result *d_out, int32_t *d_
             // waves to exit -- measured at 16,384 samples per call: 2.71 -> 2.29 ms per call (6.05 -> 7.2 M placements/s), best at
             // 8 of the 17 waves per CU of that time (7: 2.32, 9: 2.39, 12: 2.51); with 16 resident since the B halves moved into registers, 8 again (6: 1.85, 8: 1.75, 10: 1.86 ms).  A call that finds the device to itself keeps the full grid.
             if (m->sharing) waves_cu = std::max(1, K.shared_waves ? (int)K.shared_waves : waves_cu / std::max(2, m->share_n));
+            // (round 6) A lone call of a short, plain batch fills three quarters of the slots: with every slot taken more waves wait for
+            // work at the end of the launch, every waiting wave makes a running one cut its unit, and every piece replays a preamble --
+            // measured alone (profiles/r06_sweep_lone_waves.txt), 16 -> 12 waves per CU: 0.98 -> 0.89 ms at 16 384 x 10 M, 0.92 -> 0.77 at
+            // 4 096, 0.76 -> 0.67 at 1 M nodes; batches of hundreds of rows per sample, 65 536 samples and the polytomy shape gain nothing or lose.
+            else if (!coarse_only && sorted && b3_class == 0 && n_tiles512 <= 32 && !m->wide_descent && waves_cu >= 16) waves_cu = waves_cu * 3 / 4;
             if (K.waves_per_cu) waves_cu = std::max(1, std::min(std::max(m->occ_per_cu, 1), (int)K.waves_per_cu));   // tuning
             uint64_t blocks = (uint64_t)waves_cu * std::max(m->n_cu, 1);
             blocks = std::min<uint64_t>(blocks, (uint64_t)n_tiles512 * G);
