@@ -584,7 +584,7 @@ def main():
             extra["config4_1m_queries_one_gpu"] = {"error": repr(ex)[:300]}
         # config 5's workload on one device: high-ambiguity queries (100-5,000 N cells + 0-30 IUPAC cells of any 2-3 bases each) and tie lists
         try:
-            c5 = timed_config(pl, st, 16384, 12, 6, ties_cap=64, n_lo=100, n_hi=5000, iupac_hi=30)
+            c5 = timed_config(pl, st, 16384, 12, 12, ties_cap=64, n_lo=100, n_hi=5000, iupac_hi=30)
             c5["workload"] = "BASELINE config 5 on one device: 16,384 queries with 100-5,000 N cells and 0-30 IUPAC cells each on the %d-node MAT, tie lists of up to 64 nodes" % info["n_nodes"]
             extra["config5_high_ambiguity_one_gpu"] = c5
         except Exception as ex:
@@ -595,7 +595,7 @@ def main():
         except Exception as ex:
             extra["dense_walk"] = {"error": repr(ex)[:300]}
         try:
-            fq = timed_config(pl, st, 16384, 12, 6, n_rot=3, max_subst=200, min_subst=50, ref_every_8th=True)
+            fq = timed_config(pl, st, 16384, 12, 12, n_rot=3, max_subst=200, min_subst=50, ref_every_8th=True)
             fq["workload"] = ("16,384 queries per step that are NOT near any node: a random node's genotype + 50-200 substitutions (70 %% at the tree's variable sites), "
                               "every 8th the all-reference sample; %d-node MAT" % info["n_nodes"])
             fq["pruned_frac"] = far_pruned_frac(st, dev_index)
@@ -800,7 +800,7 @@ def main():
             pl3 = Placer(st3.arrays, device=dev_index)
             t_flat3 = time.time() - t0
             free_b, total_b = torch.cuda.mem_get_info(dev)
-            c3 = timed_config(pl3, st3, 10_000, 12, 6, recent=True)
+            c3 = timed_config(pl3, st3, 10_000, 12, 24, recent=True)   # (24 warm-up calls: a new handle -- its workspace sets are allocated and first touched in the first calls)
             i3 = pl3.info()
             c3.update({"workload": "BASELINE config 3's size: synthetic sars2-shaped MAT %d nodes / %d mutations, 10,000 queries per step" % (i3["n_nodes"], i3["n_muts"]),
                        "gen_s": round(t_gen3, 2), "flatten_upload_s": round(t_flat3, 2), "device_bytes_in_use": int(total_b - free_b)})
