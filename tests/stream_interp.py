@@ -189,6 +189,8 @@ def b3_hu(b3, P, J):
     q0, q1 = (P + 1) >> B3_BLOCK_SHIFT, (P + J) >> B3_BLOCK_SHIFT
     m = int(b3["over"][q0:q1 + 1].max())
     u = int(b3["under"][P >> B3_BLOCK_SHIFT])
+    if m >= 255:              # (the device keeps one byte per block since round 6: 255 = "255 or more" = no bound)
+        return 1 << 20
     return max(0, m - u)
 
 

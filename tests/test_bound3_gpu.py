@@ -46,8 +46,8 @@ def test_device_tables_equal_the_restatement(seed, n_leaves, ambig, monkeypatch)
                 assert over is not None, "the call did not build the tables"
                 n = len(b3["over"])
                 assert len(over) == n
-                np.testing.assert_array_equal(over, np.minimum(b3["over"], 65535))
-                np.testing.assert_array_equal(under, np.minimum(b3["under"], 65535))
+                np.testing.assert_array_equal(over, np.minimum(b3["over"], 255))       # (one byte per block on the device: 255 = "255 or more")
+                np.testing.assert_array_equal(under, np.minimum(b3["under"], 255))
         # (b) a mixed batch: each tile's tables lie between those of its least useful sample and those of the whole batch
         mixed = [dict(queries[i % len(queries)], name="m%d" % i) for i in range(1500)]
         res = placer.place(QueryBatch(mixed))
@@ -59,7 +59,7 @@ def test_device_tables_equal_the_restatement(seed, n_leaves, ambig, monkeypatch)
         least = np.min([stream_interp.b3_tables(flat, [n])["over"] for n in nibs], axis=0)
         for tile in range(3):
             over, under = _tables(placer, tile)
-            assert (over <= whole["over"]).all() and (over >= least).all()
+            assert (over <= np.minimum(whole["over"], 255)).all() and (over >= np.minimum(least, 255)).all()
     finally:
         placer.close()
         del orc
@@ -90,9 +90,10 @@ def test_long_branches_shared_by_the_queries(seed, monkeypatch):
             b3 = stream_interp.b3_tables(flat, [stream_interp.sample_site_alleles(flat, q)[0]])
             over, under = _tables(placer, 0)
             assert over is not None, "the call did not build the tables"
-            np.testing.assert_array_equal(over, b3["over"])
-            np.testing.assert_array_equal(under, b3["under"])
-            assert under.max() < 65535
+            # (counts of 255 and more are saturated on the device: "no bound" there -- what the 8-bit counters of round 5 turned into a wrong one)
+            np.testing.assert_array_equal(over, np.minimum(b3["over"], 255))
+            np.testing.assert_array_equal(under, np.minimum(b3["under"], 255))
+            assert (under <= over).all()
         mixed = [dict(queries[i % len(queries)], name="m%d" % i) for i in range(2000)]
         res = placer.place(QueryBatch(mixed))
         for i in range(len(queries)):

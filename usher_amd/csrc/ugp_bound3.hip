@@ -43,7 +43,7 @@ __global__ void __launch_bounds__(256) k_b3_pairmask(const uint32_t *__restrict_
 // the tables of one group of B3_GROUP_BLOCKS blocks for 32 tiles: per (tile, block) one LDS word counts range starts (bits 7:0), events
 // inside the block (15:8; both at most B3_BLOCK_WORDS: an event is listed under the block of its own mutation word, and a block has 16
 // words) and range ends (31:16; at most the mutation words of one root path, < 0x7F7F where the lists exist: ugp_flatten.cpp); thread (tile, sixteenth of the group) then turns 16
-// of them into cum_over | cum_under << 16 in place, and the block writes the rows out four bytes (two blocks) at a time.
+// of them into cum_over | cum_under << 16 in place (each saturated at 255), and the block writes the rows out four bytes (four blocks) at a time.
 constexpr uint32_t B3_ROW = B3_GROUP_BLOCKS + 1;   // (padded: a wave's 32 rows fall into 32 different LDS banks)
 #ifndef UGP_B3_TB
 #define UGP_B3_TB 512
@@ -52,7 +52,7 @@ constexpr uint32_t B3_TB = UGP_B3_TB, B3_CH = B3_TB / 32, B3_CB = B3_GROUP_BLOCK
 static_assert(B3_TB == 128 || B3_TB == 256 || B3_TB == 512, "k_b3_group_tables: 128, 256 or 512 threads");
 __global__ void __launch_bounds__(B3_TB) k_b3_group_tables(const uint32_t *__restrict__ pairmask, uint32_t n_pairs, uint32_t n_tiles, const uint32_t *__restrict__ group_off,
                                                            const uint32_t *__restrict__ events, uint32_t n_groups, uint32_t n_blocks,
-                                                           uint16_t *__restrict__ over, uint16_t *__restrict__ under, uint16_t *__restrict__ l1, uint32_t n_l1) {
+                                                           uint8_t *__restrict__ over, uint8_t *__restrict__ under, uint8_t *__restrict__ l1, uint32_t n_l1) {
     __shared__ uint32_t cnt[32 * B3_ROW];
     __shared__ uint32_t pa[B3_TB], pb[B3_TB], mx[B3_TB], open0[32];
     const uint32_t g = blockIdx.x, y = blockIdx.y, tid = threadIdx.x;
@@ -108,8 +108,9 @@ __global__ void __launch_bounds__(B3_TB) k_b3_group_tables(const uint32_t *__res
     for (int k = 0; k < (int)B3_CB; k++) {
         const uint32_t w = row[k];
         const uint32_t st = w & 0xFFu, same = (w >> 8) & 0xFFu, en = w >> 16;
-        const uint32_t ov = min(S + st - E + same, 65535u);   // S(b) - E(b - 1) + same(b)   (65535: "no bound" for the walk -- cannot be reached on the packed path)
-        const uint32_t un = min(S - (E + en), 65535u);        // S(b - 1) - E(b)   (never negative: an event ends where or behind it starts)
+        const uint32_t ov = min(S + st - E + same, 255u);   // S(b) - E(b - 1) + same(b)   (255: "no bound" for the walk)
+        const uint32_t un = min(S - (E + en), 255u);        // S(b - 1) - E(b)   (never negative: an event ends where or behind it starts; saturated like ov: a node whose
+                                                            //  count is 255 or more has only descendants whose blocks read 255 -- no bound, the safe answer)
         S += st; E += en;
         row[k] = ov | (un << 16);
         m = max(m, ov);
@@ -117,13 +118,14 @@ __global__ void __launch_bounds__(B3_TB) k_b3_group_tables(const uint32_t *__res
     mx[t * B3_CH + c] = m;
     __syncthreads();
     const uint64_t g0 = (uint64_t)g * B3_GROUP_BLOCKS;
-    for (uint32_t it = 0; it < 32u / (B3_TB / 128u); it++) {   // B3_TB / 128 tile rows per pass: 128 threads x two blocks each
-        const uint32_t tt = it * (B3_TB / 128u) + (tid >> 7), i = tid & 127u, tl = y * 32u + tt;
+    for (uint32_t it = 0; it < 32u / (B3_TB / 64u); it++) {   // B3_TB / 64 tile rows per pass: 64 threads x four blocks (one dword of bytes) each
+        const uint32_t tt = it * (B3_TB / 64u) + (tid >> 6), i = tid & 63u, tl = y * 32u + tt;
         if (tl >= n_tiles) continue;
-        const uint32_t r0 = cnt[tt * B3_ROW + 2u * i], r1 = cnt[tt * B3_ROW + 2u * i + 1u];
-        const uint64_t at = (uint64_t)tl * n_blocks + g0 + 2u * i;
-        *(uint32_t *)(over + at) = (r0 & 0xFFFFu) | (r1 << 16);
-        *(uint32_t *)(under + at) = (r0 >> 16) | (r1 & 0xFFFF0000u);
+        const uint32_t *r = cnt + tt * B3_ROW + 4u * i;
+        const uint32_t r0 = r[0], r1 = r[1], r2 = r[2], r3 = r[3];
+        const uint64_t at = (uint64_t)tl * n_blocks + g0 + 4u * i;
+        *(uint32_t *)(over + at) = (r0 & 0xFFu) | ((r1 & 0xFFu) << 8) | ((r2 & 0xFFu) << 16) | ((r3 & 0xFFu) << 24);
+        *(uint32_t *)(under + at) = ((r0 >> 16) & 0xFFu) | (((r1 >> 16) & 0xFFu) << 8) | (((r2 >> 16) & 0xFFu) << 16) | (((r3 >> 16) & 0xFFu) << 24);
     }
     if (tid < 128u) {   // level 1: 64 blocks = 64 / B3_CB pieces
         constexpr uint32_t PER = 64u / B3_CB;
@@ -131,17 +133,17 @@ __global__ void __launch_bounds__(B3_TB) k_b3_group_tables(const uint32_t *__res
         uint32_t v = 0;
 #pragma unroll
         for (uint32_t k = 0; k < PER; k++) v = max(v, mx[tt * B3_CH + PER * q + k]);
-        if (tl < n_tiles && i < n_l1) l1[(uint64_t)tl * n_l1 + i] = (uint16_t)v;
+        if (tl < n_tiles && i < n_l1) l1[(uint64_t)tl * n_l1 + i] = (uint8_t)v;
     }
 }
 
 // levels 2 and 3 in one launch: block (i, tile) owns level-3 entry i = 64 level-2 entries = 4096 level-1 entries; a wave reduces 64
 // level-1 entries at a time (one per lane) to a level-2 entry, the block's maximum is the level-3 entry
-__global__ void __launch_bounds__(256) k_b3_levels(const uint16_t *__restrict__ l1, uint32_t n_l1, uint16_t *__restrict__ l2, uint32_t n_l2, uint16_t *__restrict__ l3,
+__global__ void __launch_bounds__(256) k_b3_levels(const uint8_t *__restrict__ l1, uint32_t n_l1, uint8_t *__restrict__ l2, uint32_t n_l2, uint8_t *__restrict__ l3,
                                                    uint32_t n_l3) {
     __shared__ uint32_t wm[4];
     const uint32_t i3 = blockIdx.x, tile = blockIdx.y, lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
-    const uint16_t *A = l1 + (uint64_t)tile * n_l1;
+    const uint8_t *A = l1 + (uint64_t)tile * n_l1;
     uint32_t m3 = 0;
     for (uint32_t e = wv; e < 64u; e += 4u) {
         const uint32_t i2 = i3 * 64u + e;
@@ -150,16 +152,16 @@ __global__ void __launch_bounds__(256) k_b3_levels(const uint16_t *__restrict__ 
         uint32_t v = at < n_l1 ? (uint32_t)A[at] : 0u;
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) v = max(v, (uint32_t)__shfl_xor((int)v, o));
-        if (lane == 0) l2[(uint64_t)tile * n_l2 + i2] = (uint16_t)v;
+        if (lane == 0) l2[(uint64_t)tile * n_l2 + i2] = (uint8_t)v;
         m3 = max(m3, v);
     }
     if (lane == 0) wm[wv] = m3;
     __syncthreads();
-    if (threadIdx.x == 0 && i3 < n_l3) l3[(uint64_t)tile * n_l3 + i3] = (uint16_t)max(max(wm[0], wm[1]), max(wm[2], wm[3]));
+    if (threadIdx.x == 0 && i3 < n_l3) l3[(uint64_t)tile * n_l3 + i3] = (uint8_t)max(max(wm[0], wm[1]), max(wm[2], wm[3]));
 }
 
 hipError_t launch_b3_tables(const uint32_t *useful, uint32_t useful_words, uint32_t n_sites, uint32_t n_tiles, const uint32_t *group_off, const uint32_t *events,
-                            uint32_t n_blocks, uint32_t *pairmask, uint16_t *over, uint16_t *under, uint16_t *l1, uint16_t *l2, uint16_t *l3, hipStream_t s) {
+                            uint32_t n_blocks, uint32_t *pairmask, uint8_t *over, uint8_t *under, uint8_t *l1, uint8_t *l2, uint8_t *l3, hipStream_t s) {
     if (!n_sites || !n_tiles || !n_blocks) return hipSuccess;
     const uint32_t ng = n_blocks >> B3_GROUP_SHIFT, ty = (n_tiles + 31u) / 32u, n_pairs = n_sites * 4u;
     const uint32_t n_l1 = b3_div64(n_blocks), n_l2 = b3_div64(n_l1), n_l3 = b3_div64(n_l2);

@@ -211,7 +211,7 @@ struct ugp_mat {
         uint32_t dyn_epoch = 0;
         // third pruning bound: per-batch block tables of every tile (ugp_bound3.hpp)
         DevBuf<uint32_t> d_b3_pairmask;
-        DevBuf<uint16_t> d_b3_over, d_b3_under, d_b3_l1, d_b3_l2, d_b3_l3;
+        DevBuf<uint8_t> d_b3_over, d_b3_under, d_b3_l1, d_b3_l2, d_b3_l3;
         DevBuf<ugp::B3Dev> d_b3_dev;
         ugp::B3Dev b3_host = {};
         DevBuf<uint64_t> d_stats, d_trace;
@@ -2374,8 +2374,13 @@ int ugp_debug_bound3_tables(ugp_mat *m, uint32_t tile, uint16_t *over, uint16_t 
     if (!over || !under) return UGP_OK;
     if (cap < W.b3_host.n_blocks) return fail(UGP_ERR_INVALID, "buffer too small");
     HIP_TRY(hipDeviceSynchronize());
-    HIP_TRY(hipMemcpy(over, W.b3_host.over + (uint64_t)tile * W.b3_host.n_blocks, (size_t)W.b3_host.n_blocks * 2, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(under, W.b3_host.under + (uint64_t)tile * W.b3_host.n_blocks, (size_t)W.b3_host.n_blocks * 2, hipMemcpyDeviceToHost));
+    // (the device keeps one byte per block since round 6, 255 = "255 or more"; the hook's arrays stayed 16 bits wide)
+    const size_t nb = W.b3_host.n_blocks;
+    std::vector<uint8_t> tmp(nb);
+    HIP_TRY(hipMemcpy(tmp.data(), W.b3_host.over + (uint64_t)tile * nb, nb, hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < nb; i++) over[i] = tmp[i];
+    HIP_TRY(hipMemcpy(tmp.data(), W.b3_host.under + (uint64_t)tile * nb, nb, hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < nb; i++) under[i] = tmp[i];
     return UGP_OK;
 }
 

@@ -662,8 +662,8 @@ int flatten(const ugp_tree_desc &t, const Options &opt, FlatMat &out, std::strin
     // number of mutations of that (site, allele) on the root path -- i.e. over the word range [header of the node, end of its
     // descendants), here as a range of blocks of B3_BLOCK_WORDS words.  Listed in depth-first order (deterministic).
     out.b3_group_off.clear(); out.b3_events.clear();
-    // (max_path_muts: the tables are 16-bit, 65535 = "no bound", and the kernel's per-block end counter is 16 bits wide; both are bounded
-    // by the mutation words of one root path + 16.  The packed walk -- the only reader -- needs max_path_muts < 0x7F7F anyway.)
+    // (max_path_muts: the table kernel's per-block end counter is 16 bits wide, bounded by the mutation words of one root path + 16; the tables
+    // themselves saturate at 255 = "no bound".  The packed walk -- the only reader -- needs max_path_muts < 0x7F7F anyway.)
     if (opt.keep_b3_events && out.n_sites && total8 > 0 && total8 < (1ull << 32) - 2 * B3_GROUP_BLOCKS * B3_BLOCK_WORDS && out.max_path_muts < 0x7F7Fu) {
         const uint32_t ng = b3_blocks(total8) >> B3_GROUP_SHIFT;
         out.b3_group_off.assign((size_t)4 * (ng + 1), 0);

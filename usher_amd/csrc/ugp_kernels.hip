@@ -1693,7 +1693,7 @@ __global__ void __launch_bounds__(64, TIES ? 3 : 4) k_best8(Best8Args a) {
                 // themselves one level up -- at most seven loads per lane, all in flight together
                 uint32_t mv = 0;
                 {
-                    const uint16_t *arr = b3->over + (uint64_t)tile * nb;
+                    const uint8_t *arr = b3->over + (uint64_t)tile * nb;
 #pragma unroll
                     for (int lv = 0; lv < 4; lv++) {
                         if (lv == 3 || q1 - q0 < 64u) { for (uint32_t i = q0 + lane; i <= q1; i += 64u) mv = max(mv, (uint32_t)arr[i]); break; }
@@ -1716,7 +1716,7 @@ __global__ void __launch_bounds__(64, TIES ? 3 : 4) k_best8(Best8Args a) {
                 const uint32_t gb = STATS ? min(hs3 - hr3, 4u) - 1u : 0u;   // (hsub - hsec of the record: 1, 2, 3, 4 and more)
                 if (STATS) { n_b3[0]++; if (lane == 0) { atomicAdd((unsigned long long *)a.stats + 72 + jb, 1ull); atomicAdd((unsigned long long *)a.stats + 88 + gb, 1ull); } }
                 pre_off = p + 1u; pre_w0 = sa0; pre_w1 = sa1; pre_w2 = sa2;
-                if (M != 65535u && hu + hr3 < hs3) {
+                if (M != 255u && hu + hr3 < hs3) {   // (255: some block's count is saturated -- no bound)
                     const uint32_t rec3 = (info & ~(0x7Fu << INFO_HS_SHIFT)) | ((hu + hr3) << INFO_HS_SHIFT);
                     if (all_far(dcur, bcur, rec3)) {
                         skip_to = p + 1u + J;
