@@ -1350,7 +1350,11 @@ __global__ void __launch_bounds__(64, TIES ? 3 : 4) k_best8(Best8Args a) {
 #pragma unroll
                 for (int i = 0; i < 2; i++) bcur[i] = bpar[i] + ex8(accPB, i) - ex8(accCB, i);
             }
-            if (!(hdr & H_NOSCORE)) {
+            // (round 6) A node with which NO sample of the tile shares a mutation (accC == 0 in every lane) is eligible for none of them
+            // (usher_mapper.cpp:454-455: common > 0, unless the node is "free") -- its costs would all carry the penalty and lose against
+            // any real candidate: one compare and a branch instead of ~40 vector instructions.  That is nearly every node a tile evaluates
+            // away from its samples' lineages: the walk without pruning went 5.5 -> ?? ms per 2 048 samples.
+            if (!(hdr & H_NOSCORE) && (TIES || (hdr & H_FREE) || __builtin_amdgcn_ballot_w64(accC != 0) != 0)) {
                 uint32_t z = accC | (accC >> 1);
                 z |= z >> 2;
                 z = ~z & ((hdr & H_FREE) ? 0u : 0x11111111u);   // bit 4j: sample j shares no mutation with this branch
