@@ -209,7 +209,7 @@ def test_far_queries_at_10m_nodes(big, monkeypatch):
     pl = Placer(st.arrays)
     res = pl.place(batch)
     assert pl.timing()["packed_path"] == 1
-    for knobs in ({"UGP_NO_UNIQ": "1"}, {"UGP_BOUND3": "0"}, {"UGP_BOUND3": "1", "UGP_NO_FORK": "1"}):
+    for knobs in ({"UGP_NO_UNIQ": "1"}, {"UGP_BOUND3": "0"}, {"UGP_BOUND3": "1", "UGP_FORK": "1"}):
         for k, v in knobs.items():
             monkeypatch.setenv(k, v)
         pl.reload_knobs()

@@ -14,7 +14,7 @@ sys.path.insert(0, ROOT)
 from oracle import capi  # noqa: E402
 from usher_amd import Placer, QueryBatch, synth  # noqa: E402
 
-KNOBS = ("UGP_UNIT_CHUNKS", "UGP_HEAVY_CHUNKS", "UGP_UB_EVERY", "UGP_NO_LPT", "UGP_NO_DESCENT", "UGP_NO_BOUND2", "UGP_SPLIT_CYCLES", "UGP_UNIT_GROW", "UGP_UNIT_MAX", "UGP_LDS_BITS", "UGP_BOUND3", "UGP_NO_UNIQ", "UGP_NO_FORK", "UGP_LIGHT_ORDER",
+KNOBS = ("UGP_UNIT_CHUNKS", "UGP_HEAVY_CHUNKS", "UGP_UB_EVERY", "UGP_NO_LPT", "UGP_NO_DESCENT", "UGP_NO_BOUND2", "UGP_SPLIT_CYCLES", "UGP_UNIT_GROW", "UGP_UNIT_MAX", "UGP_LDS_BITS", "UGP_BOUND3", "UGP_NO_UNIQ", "UGP_FORK", "UGP_LIGHT_ORDER",
          "UGP_DESCENT_LANES", "UGP_LDS_SLOTS", "UGP_NO_PAD_FIX", "UGP_COARSE_DIV", "UGP_COARSE_PHASE2", "UGP_NMASK", "UGP_PHASE2_PACKED", "UGP_RADIX_SORT", "UGP_SPLIT_MANY")
 
 
@@ -34,7 +34,7 @@ def main():
         if rng.random() < 0.3:
             knobs["UGP_HEAVY_CHUNKS"] = str(int(rng.choice([4, 16, 32])))
         for k, p, v in (("UGP_UB_EVERY", 0.3, "4"), ("UGP_NO_LPT", 0.2, "1"), ("UGP_NO_DESCENT", 0.2, "1"), ("UGP_NO_BOUND2", 0.15, "1"),
-                        ("UGP_SPLIT_CYCLES", 0.5, str(int(rng.choice([0, 1, 5000, 100000])))), ("UGP_UNIT_GROW", 0.4, str(int(rng.choice([0, 1, 8])))), ("UGP_UNIT_MAX", 0.3, str(int(rng.choice([32, 100000])))), ("UGP_LDS_BITS", 0.5, str(int(rng.integers(0, 3)))), ("UGP_BOUND3", 0.7, str(int(rng.integers(0, 2)))), ("UGP_NO_UNIQ", 0.25, "1"), ("UGP_NO_FORK", 0.3, "1"), ("UGP_LIGHT_ORDER", 0.4, str(int(rng.integers(0, 2)))), ("UGP_DESCENT_LANES", 0.4, str(int(rng.choice([16, 64])))),
+                        ("UGP_SPLIT_CYCLES", 0.5, str(int(rng.choice([0, 1, 5000, 100000])))), ("UGP_UNIT_GROW", 0.4, str(int(rng.choice([0, 1, 8])))), ("UGP_UNIT_MAX", 0.3, str(int(rng.choice([32, 100000])))), ("UGP_LDS_BITS", 0.5, str(int(rng.integers(0, 3)))), ("UGP_BOUND3", 0.7, str(int(rng.integers(0, 2)))), ("UGP_NO_UNIQ", 0.25, "1"), ("UGP_FORK", 0.3, "1"), ("UGP_LIGHT_ORDER", 0.4, str(int(rng.integers(0, 2)))), ("UGP_DESCENT_LANES", 0.4, str(int(rng.choice([16, 64])))),
                         ("UGP_LDS_SLOTS", 0.3, str(int(rng.integers(3, 12)))), ("UGP_NO_PAD_FIX", 0.15, "1"), ("UGP_COARSE_DIV", 0.3, str(int(rng.choice([256, 4096])))), ("UGP_COARSE_PHASE2", 0.2, "1"), ("UGP_NMASK", 0.3, str(int(rng.integers(0, 2)))), ("UGP_PHASE2_PACKED", 0.25, "1"), ("UGP_RADIX_SORT", 0.3, "1"),
                         ("UGP_SPLIT_MANY", 0.3, str(int(rng.choice([0, 1, 8]))))):
             if rng.random() < p:

@@ -13,7 +13,7 @@ from tests import synth  # noqa: E402
 from usher_amd import Placer, QueryBatch  # noqa: E402
 
 KNOBS = ("UGP_COARSE_MIN_NODES", "UGP_UNIT_CHUNKS", "UGP_HEAVY_CHUNKS", "UGP_UB_EVERY", "UGP_PRUNE_MIN_WORDS", "UGP_NO_LPT", "UGP_NO_SEED",
-         "UGP_LDS_SLOTS", "UGP_NO_SIB", "UGP_NO_SORT", "UGP_NO_DESCENT", "UGP_NO_BOUND2", "UGP_SPLIT_CYCLES", "UGP_UNIT_GROW", "UGP_UNIT_MAX", "UGP_LDS_BITS", "UGP_BOUND3", "UGP_NO_UNIQ", "UGP_NO_FORK", "UGP_PRE_WEIGHT", "UGP_COARSE_PHASE2", "UGP_NMASK", "UGP_PHASE2_PACKED", "UGP_RADIX_SORT", "UGP_SPLIT_MANY")
+         "UGP_LDS_SLOTS", "UGP_NO_SIB", "UGP_NO_SORT", "UGP_NO_DESCENT", "UGP_NO_BOUND2", "UGP_SPLIT_CYCLES", "UGP_UNIT_GROW", "UGP_UNIT_MAX", "UGP_LDS_BITS", "UGP_BOUND3", "UGP_NO_UNIQ", "UGP_FORK", "UGP_PRE_WEIGHT", "UGP_COARSE_PHASE2", "UGP_NMASK", "UGP_PHASE2_PACKED", "UGP_RADIX_SORT", "UGP_SPLIT_MANY")
 
 
 def main():
@@ -49,7 +49,7 @@ def main():
         if rng.random() < 0.7:
             knobs["UGP_BOUND3"] = str(int(rng.integers(0, 2)))     # (third pruning bound pinned on / off; otherwise the library's static rule: off on trees this small)
         for k, p in (("UGP_NO_LPT", 0.3), ("UGP_NO_SEED", 0.2), ("UGP_NO_SIB", 0.2), ("UGP_NO_SORT", 0.1), ("UGP_NO_DESCENT", 0.3), ("UGP_NO_BOUND2", 0.2),
-                     ("UGP_PRE_WEIGHT", 0.2), ("UGP_COARSE_PHASE2", 0.2), ("UGP_NMASK", 0.3), ("UGP_PHASE2_PACKED", 0.25), ("UGP_RADIX_SORT", 0.3), ("UGP_NO_UNIQ", 0.25), ("UGP_NO_FORK", 0.3)):
+                     ("UGP_PRE_WEIGHT", 0.2), ("UGP_COARSE_PHASE2", 0.2), ("UGP_NMASK", 0.3), ("UGP_PHASE2_PACKED", 0.25), ("UGP_RADIX_SORT", 0.3), ("UGP_NO_UNIQ", 0.25), ("UGP_FORK", 0.3)):
             if rng.random() < p:
                 knobs[k] = "1"
         os.environ.update(knobs)

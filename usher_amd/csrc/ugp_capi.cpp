@@ -404,6 +404,10 @@ int run_place(ugp_mat *m, ugp_qset *qs, int mode, ugp_result *d_out, int32_t *d_
     // The side stream (see Work::aux): only where there is something to put on it -- the sorted main pass.
     // And only for a call that has the device to itself: measured with three calls in flight (six queues instead of three), the
     // cross-queue waits cost far more than the overlap gives -- 12.9 -> 10.4 M placements/s; a lone call gains 45 us of its 1.96 ms.
+    // OPT-IN (UGP_FORK=1) since the end of round 6: a process has four hardware queues by default, a handle's three streams plus
+    // their side streams oversubscribe them, and which streams then share a queue -- and serialise -- depends on what the process
+    // created before: the SECOND handle of a process ran its overlapped calls one after the other (tools/probe_context.py: config 3's
+    // size 7.7 -> 4.7 M/s, the headline workload 13.9 -> 9.6) for a gain of 45 us on the first.
     const bool can_fork = sorted && !coarse_only && !K.no_fork && !m->sharing;
     bool fill_ahead = false;   // the first sub-batch's table has been filled with the reference bases on the side stream, under the pre-pass
     if (can_fork) {

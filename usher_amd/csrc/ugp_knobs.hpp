@@ -14,7 +14,7 @@ namespace ugp {
 struct Knobs {
     // switches
     bool force_v1 = false, no_sort = false, no_prune = false, coarse_phase2 = false, no_seed = false, no_descent = false, no_pad_fix = false,
-         no_lpt = false, radix_sort = false, refill_all = false, scores_dfs = false, ties_dfs = false, debug_sharing = false, no_graph = false, ex_slow = false, no_bound3 = false, no_uniq = false, no_fork = false;
+         no_lpt = false, radix_sort = false, refill_all = false, scores_dfs = false, ties_dfs = false, debug_sharing = false, no_graph = false, ex_slow = false, no_bound3 = false, no_uniq = false, no_fork = true;   // (no_fork: the side stream of a lone call is opt-in, UGP_FORK=1 -- see ugp_capi.cpp)
     // -1 = the library's own choice
     int bound3 = -2,   // third pruning bound: -2 = decided from the tree and the batch (b3_static_choice), -1 = UGP_BOUND3=auto: the run-time tuner, 0 / 1 pinned
         tile_build = -1, nmask = -1, lds_bits = -1, light_order = -1, unit_grow = -1, split_cycles = -1, split_heavy = -1, split_dense = -1,
@@ -40,7 +40,7 @@ struct Knobs {
         k.coarse_phase2 = flag("UGP_COARSE_PHASE2"); k.no_seed = flag("UGP_NO_SEED"); k.no_descent = flag("UGP_NO_DESCENT");
         k.no_pad_fix = flag("UGP_NO_PAD_FIX"); k.no_lpt = flag("UGP_NO_LPT"); k.refill_all = flag("UGP_REFILL_ALL"); k.radix_sort = flag("UGP_RADIX_SORT");
         k.scores_dfs = flag("UGP_SCORES_DFS"); k.ties_dfs = flag("UGP_TIES_DFS"); k.debug_sharing = flag("UGP_DEBUG_SHARING");
-        k.no_graph = flag("UGP_NO_GRAPH"); k.ex_slow = flag("UGP_EX_SLOW"); k.no_bound3 = flag("UGP_NO_BOUND3"); k.no_uniq = flag("UGP_NO_UNIQ"); k.no_fork = flag("UGP_NO_FORK");
+        k.no_graph = flag("UGP_NO_GRAPH"); k.ex_slow = flag("UGP_EX_SLOW"); k.no_bound3 = flag("UGP_NO_BOUND3"); k.no_uniq = flag("UGP_NO_UNIQ"); k.no_fork = !flag("UGP_FORK") || flag("UGP_NO_FORK");
         if (const char *e = getenv("UGP_BOUND3")) k.bound3 = (e[0] == 'a' || e[0] == 'A') ? -1 : (atoi(e) != 0 ? 1 : 0);
         k.tile_build = num("UGP_TILE_BUILD", -1); k.nmask = num("UGP_NMASK", -1); k.lds_bits = num("UGP_LDS_BITS", -1);
         k.light_order = num("UGP_LIGHT_ORDER", -1);
