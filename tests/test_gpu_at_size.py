@@ -231,3 +231,39 @@ def test_far_queries_at_10m_nodes(big, monkeypatch):
     for i, w in zip(picks, lit):
         assert (int(res["best_set_difference"][i]), int(res["num_best"][i]), int(res["best_j"][i]), bool(res["best_has_unique"][i])) == \
                (w["best"], w["num_best"], w["best_j"], w["has_unique"]), i
+
+
+def test_second_handle_of_a_process_keeps_its_overlap(big, monkeypatch):
+    """Round 6: a process has four hardware queues by default; a handle's three streams and the caller's use them up.  With one more
+    stream per workspace set (the side stream of a lone call, now opt-in: UGP_FORK=1) the SECOND handle of a process ran its overlapped
+    calls one after the other -- 13.9 -> 9.6 M placements/s on this very workload (tools/probe_context.py).  Two handles, one after the
+    other, the same batches through ugp_place_device_overlapped: the second must not be much slower than the first (and both exact)."""
+    import time
+    import torch
+    st, _ = big
+    for k in KNOBS + ("UGP_FORK",):
+        monkeypatch.delenv(k, raising=False)
+    dev = torch.device("cuda", torch.cuda.current_device())
+    stream = torch.cuda.current_stream().cuda_stream
+    sets = [st.queries(16384, seed=4242 + r) for r in range(3)]
+    rates, answers = [], []
+    for which in range(2):
+        pl = Placer(st.arrays)
+        hq = [pl.upload(_batch(q)) for q in sets]
+        dd = pl.pipeline_depth()
+        out = [torch.zeros((16384, 4), dtype=torch.int32, device=dev) for _ in range(dd)]
+        for k in range(9):
+            pl.place_device_overlapped(hq[k % 3], out[k % dd].data_ptr(), stream)
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        n = 30
+        for k in range(n):
+            pl.place_device_overlapped(hq[k % 3], out[k % dd].data_ptr(), stream)
+        torch.cuda.synchronize()
+        rates.append(16384 * n / (time.perf_counter() - t))
+        answers.append(out[(n - 1) % dd].cpu().numpy().copy())
+        for h in hq:
+            pl.free_qset(h)
+        pl.close()
+    assert (answers[0] == answers[1]).all()
+    assert rates[1] > 0.8 * rates[0], rates
