@@ -19,6 +19,13 @@ rank places its own `--queries` samples); `--strong` shards a fixed total of
 `--queries` samples (BASELINE config 4: `--strong --queries 1000000`).
 Rank 0 prints ONE JSON line.
 """
+import os as _os
+# A process has four hardware queues by default (ROCm: GPU_MAX_HW_QUEUES), and streams that share one run their work one after the other.
+# The handle's three streams and the caller's use them up; with N > 1 the RCCL stream of torch.distributed is a fifth, and which two then
+# share a queue is the runtime's choice (DESIGN.md 4 "A side stream", tools/probe_context.py: a fifth stream cost a third of the rate).
+# Eight queues for every N, so that the N = 1 and N > 1 lines are measured under the same setting (at N = 1 it changes nothing: 13.4 M/s
+# either way, profiles/r06_sweep_hwq.txt).  Read by the HIP runtime when it initialises: set before torch is imported; a caller's value wins.
+_os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 import argparse
 import glob
 import re
