@@ -258,6 +258,7 @@ struct ugp_mat {
     int next_job = 0;        // set the next ugp_place_batch_async job takes (sets 0 .. pipeline depth - 1)
     uint64_t n_overlapped = 0;                  // calls of ugp_place_device_overlapped so far
     hipEvent_t entry_ring[kMaxSets] = {};       // the caller's stream at the moment of the last kMaxSets such calls
+    int share_sets = 2;      // (during a call) workspace sets the caller cycles through (ugp_place_device_overlapped: 2 for long calls, else the pipeline depth)
     int share_n = 1;         // (during a call) tree walks expected on the device at a time: this call's grid is its share of the resident wave slots
     uint32_t tie_lists_filled = 0, tie_sub_batches = 0;   // sub-batches of the current call whose tie lists phase 2 has filled / all of them (ugp_tied_nodes)
     bool sharing = false;    // (during a call) another set's call was still running when this one, or the one before it, was queued
@@ -438,7 +439,7 @@ int run_place(ugp_mat *m, ugp_qset *qs, int mode, ugp_result *d_out, int32_t *d_
         // The pre-pass has no phase 2: its walk records which node set every chunk minimum (k_best8<ARG>, k_coarse_result) -- any
         // node of minimal cost serves the sort and the descent.  (UGP_COARSE_PHASE2=1: the full phase 2 instead, i.e. the
         // reference's tie-break winner: 0.2 ms more per 16,384 samples, the same answers.)
-        m->coarse->sharing = m->sharing; m->coarse->share_n = m->share_n;
+        m->coarse->sharing = m->sharing; m->coarse->share_n = m->share_n; m->coarse->share_sets = m->share_sets;
         const bool coarse_arg = m->coarse->d_node_pos8.p && m->coarse->flat.max_chunk8_words < 65536u && !K.coarse_phase2;
         if (int rc = run_place(m->coarse, qs, 0, W.d_coarse_res.p, nullptr, nullptr, nullptr, nullptr, nullptr, 0, s, coarse_arg, nullptr, wi)) return rc;
         HIP_TRY(hipSetDevice(m->device));
@@ -805,7 +806,12 @@ int run_place(ugp_mat *m, ugp_qset *qs, int mode, ugp_result *d_out, int32_t *d_
             // takes half of what the device keeps resident, so that both grids ARE resident instead of one waiting for the other's
             // waves to exit -- measured at 16,384 samples per call: 2.71 -> 2.29 ms per call (6.05 -> 7.2 M placements/s), best at
             // 8 of the 17 waves per CU of that time (7: 2.32, 9: 2.39, 12: 2.51); with 16 resident since the B halves moved into registers, 8 again (6: 1.85, 8: 1.75, 10: 1.86 ms).  A call that finds the device to itself keeps the full grid.
-            if (m->sharing) waves_cu = std::max(1, K.shared_waves ? (int)K.shared_waves : waves_cu / std::max(2, m->share_n));
+            // (end of round 6, measured again with the smaller helpers, interleaved A/Bs in profiles/r06_ab_shared*.txt: a caller that keeps
+            // THREE short calls in flight does best with 5 of the 16 slots per walk whatever the number of walks found running at the
+            // moment -- 14.1-14.5 M/s against 13.6 with the share recomputed per call (5 or 8), 13.9 with 6, 13.8 with 4 or 7; the
+            // SARS-CoV-2 shape 12.6 against 12.3.  Callers of long calls -- two sets: 65 536 samples, hundreds of rows per sample -- keep
+            // half of the slots: 6.8 M/s against 5.8 with 5 on config 5.)
+            if (m->sharing) waves_cu = std::max(1, K.shared_waves ? (int)K.shared_waves : (m->share_sets >= 3 ? waves_cu * 5 / 16 : waves_cu / 2));
             // (round 6) A lone call of a short, plain batch fills three quarters of the slots: with every slot taken more waves wait for
             // work at the end of the launch, every waiting wave makes a running one cut its unit, and every piece replays a preamble --
             // measured alone (profiles/r06_sweep_lone_waves.txt), 16 -> 12 waves per CU: 0.98 -> 0.89 ms at 16 384 x 10 M, 0.92 -> 0.77 at
@@ -1431,6 +1437,7 @@ static void note_sharing(ugp_mat *m, int wi, int depth) {
     // a caller that keeps `depth` calls in flight has depth - 1 others on the device when the pipeline is full; while it fills
     // (or drains) the calls found running, or found by the previous call, say how many walks share the chip
     m->share_n = std::max(n_busy + 1, m->was_busy ? m->was_n : 1);
+    m->share_sets = depth;   // the sets this caller cycles through: 3 for short calls, 2 for long ones
     m->was_busy = busy;
     m->was_n = n_busy + 1;
     if (m->knobs.debug_sharing) fprintf(stderr, "[ugp] call on set %d: sharing=%d among %d\n", wi, (int)m->sharing, m->share_n);
