@@ -34,7 +34,7 @@ def random_bfs_tree(rng, n, kind):
     return par.astype(np.int64)
 
 
-def random_sites(rng, parent, n_sites, p_var=0.3, p_internal=0.05):
+def random_sites(rng, parent, n_sites, p_var=0.3, p_internal=0.05, p_dense=0.9):
     n = len(parent)
     is_leaf = np.ones(n, bool)
     is_leaf[parent[1:]] = False
@@ -42,7 +42,7 @@ def random_sites(rng, parent, n_sites, p_var=0.3, p_internal=0.05):
     ref = (1 << rng.integers(0, 4, n_sites)).astype(np.uint8)
     off, nodes, nucs = [0], [], []
     for s in range(n_sites):
-        pick = leaves[rng.random(len(leaves)) < (p_var if s % 5 else 0.9)]
+        pick = leaves[rng.random(len(leaves)) < (p_var if s % 5 else p_dense)]
         extra = internal[rng.random(len(internal)) < p_internal] if s % 3 == 0 else np.zeros(0, np.int64)
         for nd in np.concatenate([pick, extra]):
             r = rng.random()
@@ -118,6 +118,31 @@ def test_gpu_fitch_sankoff_equals_oracle(kind, n, n_sites, seed, monkeypatch):
     want = oracle_mutations(parent, ref, off, nodes, nucs)
     # one pass; several passes of 24 sites; and the exact listing pass used when the first buffer is too small
     for budget, cap in ((None, None), (str(n * 4 * 3), None), (None, "3")):
+        monkeypatch.delenv("UGP_FITCH_BYTES", raising=False)
+        monkeypatch.delenv("UGP_FITCH_EMIT_CAP", raising=False)
+        if budget:
+            monkeypatch.setenv("UGP_FITCH_BYTES", budget)
+        if cap:
+            monkeypatch.setenv("UGP_FITCH_EMIT_CAP", cap)
+        site, node, mpar, mnuc = fitch_sankoff(parent, ref, off, nodes, nucs)
+        got = list(zip(site.tolist(), node.tolist(), mpar.tolist(), mnuc.tolist()))
+        assert got == want
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,n,n_sites,p_var,p_internal,seed", [("random", 3000, 1100, 0.001, 0.0, 21), ("bushy", 4000, 1600, 0.0006, 0.002, 22),
+                                                                  ("star", 2000, 600, 0.002, 0.0, 23), ("chain", 300, 1030, 0.002, 0.01, 24),
+                                                                  ("random", 2500, 520, 0.0, 0.0, 25)])
+def test_gpu_fitch_rows_that_are_never_stored(kind, n, n_sites, p_var, p_internal, seed, monkeypatch):
+    """Few cells per 512-site tile: most (leaf, tile) items have none and get no row on the device (ugp_fitch.hip, round 6) -- with and
+    without cells on internal nodes, tiles that end inside a word row, a tree without any cell; one pass, passes of 520 sites, and the
+    exact listing pass."""
+    from usher_amd.fitch import fitch_sankoff
+    rng = np.random.default_rng(seed)
+    parent = random_bfs_tree(rng, n, kind)
+    ref, off, nodes, nucs = random_sites(rng, parent, n_sites, p_var=p_var, p_internal=p_internal, p_dense=2 * p_var)
+    want = oracle_mutations(parent, ref, off, nodes, nucs)
+    for budget, cap in ((None, None), (str(n * 4 * 65), None), (None, "3")):
         monkeypatch.delenv("UGP_FITCH_BYTES", raising=False)
         monkeypatch.delenv("UGP_FITCH_EMIT_CAP", raising=False)
         if budget:

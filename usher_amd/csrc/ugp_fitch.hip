@@ -21,6 +21,13 @@
 // per child and the argmin is a bit-sliced tournament.  Levels are processed bottom-up then
 // top-down, one launch per level; states overwrite F in place and a final pass lists the
 // (site, node) pairs whose state differs from the parent's.
+//
+// Rows that are never stored (round 6).  A leaf without a genotype cell among the 512 sites of a tile is {REF} there, and an
+// internal node without one allows all four bases: neither needs a row in HBM.  Two bitmaps over the (node, tile) items, bit
+// index node * gy + tile -- `mark` (the item holds a cell of the VCF) and `stored` (mark, or the node is internal: the forward
+// pass writes its row) -- tell every kernel which rows exist; the others are the reference word / all-ones in registers.  On the
+// 10 M-node bench tree 70 % of the leaf items have no cell: the initialisation writes 1.7 GB instead of 10.2, and the two passes
+// read the leaves' rows that exist.
 #include <hip/hip_runtime.h>
 #include <cstring>
 #include <rocprim/device/device_radix_sort.hpp>
@@ -58,25 +65,75 @@ __device__ __forceinline__ uint32_t nib_lowbit(uint32_t f) {   // lowest set bit
     return f & ~up;
 }
 
-// Work items are (node, 64-word tile) pairs in node-major order, so consecutive items of a wave
-// walk contiguous memory.  FS_NB items per wave amortise the wave launch and put FS_NB independent
-// loads in flight.
+// Work items are (node, 64-word tile) pairs.  A block of four waves takes one tile of 4 x FS_* consecutive nodes (or internal
+// nodes, in the forward sweep) and the next block the next tile of the same nodes: block b -> tile b % gy, node group b / gy,
+// so neighbouring blocks read neighbouring 256-byte pieces of the same rows.  FS_* items per wave put that many independent
+// row loads in flight behind ONE round of scalar look-ups.
 constexpr int FS_NB = 8;
 
-// leaves start as {REF}, internal nodes as "any base"
-__global__ __launch_bounds__(256) void k_fs_init(uint32_t *__restrict__ F, const uint32_t *__restrict__ refw,
-                                                 const uint32_t *__restrict__ n_children, uint32_t n_nodes, uint32_t W, uint32_t gy) {
-    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    const uint64_t total = (uint64_t)n_nodes * gy;
-    uint64_t T = ((uint64_t)blockIdx.x * 4 + wave) * FS_NB;
-    if (T >= total) return;
-    uint32_t n = (uint32_t)(T / gy), wt = (uint32_t)(T % gy);
-#pragma unroll
-    for (int u = 0; u < FS_NB; u++) {
-        const uint32_t w = wt * 64 + lane;
-        if (T + u < total && w < W) F[(uint64_t)n * W + w] = n_children[n] ? 0xFFFFFFFFu : refw[w];
-        if (++wt == gy) { wt = 0; n++; }
+// the two bitmaps are tile-major: bit tile * npad + node (npad = the node count rounded up to 64), so the items of a wave --
+// consecutive nodes of one tile -- are consecutive bits
+__device__ __forceinline__ bool fs_bit(const uint32_t *__restrict__ bm, uint64_t b) { return (bm[b >> 5] >> (b & 31)) & 1u; }
+__device__ __forceinline__ uint32_t fs_bits32(const uint32_t *__restrict__ bm, uint64_t b) {   // bits b .. b+31 (the bitmaps end in two spare words)
+    const uint64_t two = (uint64_t)bm[b >> 5] | ((uint64_t)bm[(b >> 5) + 1] << 32);
+    return (uint32_t)(two >> (b & 31));
+}
+
+// which (node, tile) items hold a cell: one BYTE per item (`mark8`, zeroed by the caller), set with a plain store -- 13.7 M
+// atomicOr on a bitmap ran at 17 per nanosecond (0.8 ms of the call); k_fs_init folds the bytes into the `stored` bitmap.
+// Cells are grouped by site; v_off[s] is the first cell of site s of this pass.
+__global__ void k_fs_mark(const uint64_t *__restrict__ v_off, uint32_t n_sites, const uint32_t *__restrict__ v_node, uint64_t n_var, uint64_t npad,
+                          uint32_t n_nodes, uint8_t *__restrict__ mark8) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_var) return;
+    uint32_t lo = 0, hi = n_sites;   // last s with v_off[s] <= i
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (v_off[mid] <= i) lo = mid; else hi = mid;
     }
+    const uint32_t n = v_node[i];
+    if (n >= n_nodes) return;   // (k_fs_scatter reports it)
+    mark8[(uint64_t)(lo >> 9) * npad + n] = 1;
+}
+
+// rows of the marked items start as {REF} (leaves) or "any base" (internal nodes); `stored` = marked | internal.  A wave takes 64
+// consecutive nodes of one tile -- one 64-bit word of the bitmap: every lane looks up whether its node is marked / internal, then
+// the wave writes the rows of the marked ones, one row per step.
+__global__ __launch_bounds__(256) void k_fs_init(uint32_t *__restrict__ F, const uint32_t *__restrict__ refw,
+                                                 const uint32_t *__restrict__ n_children, uint32_t n_nodes, uint32_t W, uint32_t gy, uint64_t npad,
+                                                 const uint8_t *__restrict__ mark8, uint32_t *__restrict__ stored) {
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const uint32_t y = blockIdx.x % gy, n0 = ((blockIdx.x / gy) * 4 + wave) * 64;
+    if (n0 >= n_nodes) return;
+    const bool mine = n0 + lane < n_nodes;
+    uint64_t mb = __builtin_amdgcn_ballot_w64(mine && mark8[(uint64_t)y * npad + n0 + lane] != 0);
+    const uint64_t ib = __builtin_amdgcn_ballot_w64(mine && n_children[n0 + lane] != 0);
+    if (lane == 0) ((uint64_t *)stored)[((uint64_t)y * npad + n0) >> 6] = mb | ib;
+    const uint32_t w = y * 64 + lane;
+    if (w >= W) return;
+    const uint32_t r = refw[w];
+    uint32_t *row = F + (uint64_t)n0 * W + w;
+    while (mb) {
+        const uint32_t u = __builtin_ctzll(mb);
+        mb &= mb - 1;
+        row[(uint64_t)u * W] = ((ib >> u) & 1) ? 0xFFFFFFFFu : r;
+    }
+}
+
+// what the forward sweep needs to know about an item before it can ask for rows, in one byte per (tile, internal node): bit 0 the
+// node's own row exists (it holds a cell), bits 1 / 2 / 3 the rows of its first / second / third child exist
+__global__ void k_fs_desc(const uint32_t *__restrict__ inodes, const uint32_t *__restrict__ ifirst, const uint32_t *__restrict__ inch, uint32_t n_internal,
+                          uint32_t gy, uint64_t npad, const uint8_t *__restrict__ mark8, const uint32_t *__restrict__ stored, uint8_t *__restrict__ desc) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (uint64_t)n_internal * gy) return;
+    const uint32_t y = (uint32_t)(i / n_internal), k = (uint32_t)(i % n_internal);
+    const uint64_t base = (uint64_t)y * npad;
+    const uint32_t c0 = ifirst[k], nc = inch[k];
+    uint32_t d = mark8[base + inodes[k]] ? 1u : 0u;
+    if (fs_bit(stored, base + c0)) d |= 2u;
+    if (nc > 1 && fs_bit(stored, base + c0 + 1)) d |= 4u;
+    if (nc > 2 && fs_bit(stored, base + c0 + 2)) d |= 8u;
+    desc[i] = (uint8_t)d;
 }
 
 // genotype cells of tree nodes: replace the initial nibble by the allele mask (:47-62).
@@ -104,77 +161,95 @@ __global__ void k_fs_scatter(uint32_t *__restrict__ F, const uint32_t *__restric
     if (x) atomicXor(&F[(uint64_t)n * W + w], x);
 }
 
-// forward pass for the internal nodes of one level (:86-111).  A wave takes FS_FN (node, tile) items; the
-// node's own row and its first two child rows of every item are requested before any is used.
-constexpr int FS_FN = 4;
+// forward pass for the internal nodes of one level (:86-111).  A wave takes one tile of FS_FN internal nodes in a row; what it
+// has to know about them -- node, first child, child count, which rows exist -- is FS_FN independent scalar loads from arrays
+// indexed by the node's rank among the internal nodes, and then the node's own row and its first three child rows of every item
+// are requested before any is used.  A row that does not exist is read from the reference word instead (no branch around a
+// load; every wave keeps that row hot).  Nodes with up to three children -- two counter planes -- are finished in straight-line
+// code; the others (polytomies) take the general bit-sliced path, one copy of it, afterwards.
+constexpr int FS_FN = 8;
 
-__global__ __launch_bounds__(256) void k_fs_forward(uint32_t *__restrict__ F, const uint32_t *__restrict__ nodes, uint32_t n_level,
-                                                    const uint32_t *__restrict__ first_child,
-                                                    const uint32_t *__restrict__ n_children, uint32_t W, uint32_t gy) {
+__device__ __forceinline__ uint32_t fs_pick(uint32_t cand, uint32_t plane) {   // keep the candidates whose counter has a 0 in this plane, if any
+    const uint32_t z = cand & ~plane;
+    const uint32_t m = nib_any(z);
+    return (z & m) | (cand & ~m);
+}
+
+__global__ __launch_bounds__(256) void k_fs_forward(uint32_t *__restrict__ F, const uint32_t *__restrict__ nodes, const uint32_t *__restrict__ ifirst,
+                                                    const uint32_t *__restrict__ inch, const uint8_t *__restrict__ desc, uint32_t n_internal,
+                                                    uint32_t n_level, uint32_t W, uint32_t gy, uint64_t npad, const uint32_t *__restrict__ refw,
+                                                    const uint32_t *__restrict__ stored) {
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    const uint64_t total = (uint64_t)n_level * gy;
-    const uint64_t T = ((uint64_t)blockIdx.x * 4 + wave) * FS_FN;
-    if (T >= total) return;
-    uint32_t idx = (uint32_t)(T / gy), wt = (uint32_t)(T % gy);
-    uint32_t own[FS_FN], ch0[FS_FN], ch1[FS_FN], pp[FS_FN], cc0[FS_FN], ncs[FS_FN], ww[FS_FN];
-    bool ok[FS_FN];
+    const uint32_t y = blockIdx.x % gy, idx0 = ((blockIdx.x / gy) * 4 + wave) * FS_FN;
+    if (idx0 >= n_level) return;
+    const uint32_t w = y * 64 + lane;
+    if (w >= W) return;
+    desc += (uint64_t)y * n_internal;
+    const uint32_t *rref = refw + w;
+    uint32_t own[FS_FN], ch0[FS_FN], ch1[FS_FN], ch2[FS_FN], pp[FS_FN], ncs[FS_FN];
+    bool wide = false;
 #pragma unroll
     for (int u = 0; u < FS_FN; u++) {
-        const uint32_t w = wt * 64 + lane;
-        ok[u] = T + u < total;
-        ww[u] = w;
-        pp[u] = 0; cc0[u] = 0; ncs[u] = 0; own[u] = 0; ch0[u] = 0xFFFFFFFFu; ch1[u] = 0xFFFFFFFFu;
-        if (ok[u]) {
-            const uint32_t p = nodes[idx];
-            pp[u] = p; cc0[u] = first_child[p]; ncs[u] = n_children[p];
-            if (w < W) {
-                own[u] = F[(uint64_t)p * W + w];
-                ch0[u] = F[(uint64_t)cc0[u] * W + w];
-                if (ncs[u] > 1) ch1[u] = F[(uint64_t)(cc0[u] + 1) * W + w];
-            }
+        const bool ok = idx0 + u < n_level;
+        pp[u] = ok ? nodes[idx0 + u] : 0u;
+        const uint32_t c0 = ok ? ifirst[idx0 + u] : 0u;
+        ncs[u] = ok ? inch[idx0 + u] : 0u;
+        const uint32_t d = ok ? (uint32_t)desc[idx0 + u] : 0u;
+        own[u] = 0xFFFFFFFFu; ch0[u] = 0xFFFFFFFFu; ch1[u] = 0xFFFFFFFFu; ch2[u] = 0xFFFFFFFFu;
+        wide = wide || ncs[u] > 3;
+        if (ok && ncs[u] <= 3) {
+            const uint32_t *row = F + (uint64_t)c0 * W + w;
+            if (d & 1u) own[u] = F[(uint64_t)pp[u] * W + w];
+            ch0[u] = *((d & 2u) ? row : rref);
+            if (ncs[u] > 1) ch1[u] = *((d & 4u) ? row + W : rref);
+            if (ncs[u] > 2) ch2[u] = *((d & 8u) ? row + (uint64_t)2 * W : rref);
         }
-        if (++wt == gy) { wt = 0; idx++; }
     }
 #pragma unroll
     for (int u = 0; u < FS_FN; u++) {
-        if (!ok[u] || ww[u] >= W) continue;
-        const uint32_t nc = ncs[u];
+        if (ncs[u] == 0 || ncs[u] > 3) continue;   // (past the end of the level / left to the general path)
+        // count, per (site, base), the children whose set lacks the base: two planes hold 0..3 (an absent child's word is all-ones)
+        uint32_t c = ~ch1[u];
+        uint32_t p0 = ~ch0[u], p1 = p0 & c;
+        p0 ^= c;
+        c = ~ch2[u];
+        p1 |= p0 & c;
+        p0 ^= c;
+        F[(uint64_t)pp[u] * W + w] = fs_pick(fs_pick(own[u], p1), p0);
+    }
+    if (!wide) return;
+#pragma nounroll
+    for (uint32_t u = 0; u < FS_FN; u++) {
+        if (idx0 + u >= n_level) break;
+        const uint32_t nc = inch[idx0 + u];
+        if (nc <= 3) continue;
+        const uint32_t p = nodes[idx0 + u], c0 = ifirst[idx0 + u];
         const int K = 32 - __builtin_clz(nc);   // planes needed to count to nc
         uint32_t plane[FS_PLANES];
 #pragma unroll
         for (int k = 0; k < FS_PLANES; k++) plane[k] = 0;
-        // +1 for every (site, base) with base not in F_c; the first two children by hand, the rest rippled
-        plane[0] = ~ch0[u];
-        if (nc > 1) {
-            const uint32_t c = ~ch1[u];
-            plane[1] = plane[0] & c;
-            plane[0] ^= c;
-        }
-        if (nc > 2) {
-            const uint32_t *row = F + (uint64_t)cc0[u] * W + ww[u];
-            uint32_t nxt = row[(uint64_t)2 * W];
-            for (uint32_t c = 2; c < nc; c++) {
-                const uint32_t x = nxt;
-                if (c + 1 < nc) nxt = row[(uint64_t)(c + 1) * W];
-                uint32_t carry = ~x;
+        const uint32_t *row = F + (uint64_t)c0 * W + w;
+        const uint64_t b0 = (uint64_t)y * npad + c0;
+        uint32_t nxt = *(fs_bit(stored, b0) ? row : rref);
+        for (uint32_t c = 0; c < nc; c++) {
+            const uint32_t x = nxt;
+            if (c + 1 < nc) nxt = *(fs_bit(stored, b0 + c + 1) ? row + (uint64_t)(c + 1) * W : rref);
+            uint32_t carry = ~x;   // +1 for every (site, base) with base not in F_c
 #pragma unroll
-                for (int k = 0; k < FS_PLANES; k++) {
-                    if (k >= K) break;
-                    const uint32_t t = plane[k] & carry;
-                    plane[k] ^= carry;
-                    carry = t;
-                }
+            for (int k = 0; k < FS_PLANES; k++) {
+                if (k >= K) break;
+                const uint32_t t = plane[k] & carry;
+                plane[k] ^= carry;
+                carry = t;
             }
         }
-        uint32_t cand = own[u];   // allowed bases (all four, or the node's own genotype mask)
+        uint32_t cand = (desc[idx0 + u] & 1u) ? F[(uint64_t)p * W + w] : 0xFFFFFFFFu;   // allowed bases (all four, or the node's own genotype mask)
 #pragma unroll
         for (int k = FS_PLANES - 1; k >= 0; k--) {
             if (k >= K) continue;
-            const uint32_t z = cand & ~plane[k];   // candidates whose counter has a 0 here
-            const uint32_t m = nib_any(z);
-            cand = (z & m) | (cand & ~m);
+            cand = fs_pick(cand, plane[k]);
         }
-        F[(uint64_t)pp[u] * W + ww[u]] = cand;
+        F[(uint64_t)p * W + w] = cand;
     }
 }
 
@@ -204,41 +279,43 @@ __device__ __forceinline__ void fs_emit(uint32_t d, uint32_t s, uint32_t sp, uin
 // the segment; entries beyond `seg_cap` are dropped and the caller falls back to k_fs_emit.
 __global__ __launch_bounds__(256) void k_fs_backward(uint32_t *__restrict__ F, const uint32_t *__restrict__ refw,
                                                      const uint32_t *__restrict__ parent, const uint32_t *__restrict__ n_children,
-                                                     uint32_t lvl_begin, uint32_t lvl_end, uint32_t W, uint32_t gy, uint32_t site_base,
+                                                     uint32_t lvl_begin, uint32_t lvl_end, uint32_t W, uint32_t gy, uint64_t npad, uint32_t site_base,
                                                      unsigned long long *__restrict__ cursor, unsigned long long seg_cap,
-                                                     uint64_t *__restrict__ out_key, uint8_t *__restrict__ out_val) {
+                                                     uint64_t *__restrict__ out_key, uint8_t *__restrict__ out_val,
+                                                     const uint32_t *__restrict__ stored) {
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const uint32_t seg = (blockIdx.x * 4 + wave) & (FS_SEG - 1);
     cursor += seg * 8;
     out_key += seg * seg_cap;
     out_val += seg * seg_cap;
-    const uint64_t total = (uint64_t)(lvl_end - lvl_begin) * gy;
-    const uint64_t T = ((uint64_t)blockIdx.x * 4 + wave) * FS_NB;
-    if (T >= total) return;
-    uint32_t n = lvl_begin + (uint32_t)(T / gy), wt = (uint32_t)(T % gy);
-    uint32_t f[FS_NB], sp[FS_NB], nn[FS_NB], ww[FS_NB];
-    bool ok[FS_NB];
+    const uint32_t y = blockIdx.x % gy, n0 = lvl_begin + ((blockIdx.x / gy) * 4 + wave) * FS_NB;
+    if (n0 >= lvl_end) return;
+    const uint32_t w = y * 64 + lane;
+    if (w >= W) return;
+    const uint32_t have = fs_bits32(stored, (uint64_t)y * npad + n0);   // (a leaf without a cell in the tile has no row: it is {REF})
+    const uint32_t r = refw[w];
+    uint32_t f[FS_NB], sp[FS_NB];
+    bool ok[FS_NB], keep_row[FS_NB];
 #pragma unroll
     for (int u = 0; u < FS_NB; u++) {
-        const uint32_t w = wt * 64 + lane;
-        ok[u] = T + u < total && w < W;
-        nn[u] = n; ww[u] = w;
-        f[u] = 0; sp[u] = 0;
+        const uint32_t n = n0 + u;
+        ok[u] = n < lvl_end;
+        f[u] = 0; sp[u] = 0; keep_row[u] = false;
         if (ok[u]) {
             const uint32_t par = parent[n];
-            sp[u] = par == 0xFFFFFFFFu ? refw[w] : F[(uint64_t)par * W + w];
-            f[u] = F[(uint64_t)n * W + w];
+            keep_row[u] = n_children[n] != 0;
+            sp[u] = par == 0xFFFFFFFFu ? r : F[(uint64_t)par * W + w];
+            f[u] = *(((have >> u) & 1u) ? F + (uint64_t)n * W + w : refw + w);
         }
-        if (++wt == gy) { wt = 0; n++; }
     }
 #pragma unroll
     for (int u = 0; u < FS_NB; u++) {
         if (!ok[u]) continue;
         const uint32_t keep = nib_any(f[u] & sp[u]);
         const uint32_t s = (sp[u] & keep) | (nib_lowbit(f[u]) & ~keep);
-        if (n_children[nn[u]]) F[(uint64_t)nn[u] * W + ww[u]] = s;
+        if (keep_row[u]) F[(uint64_t)(n0 + u) * W + w] = s;
         const uint32_t d = nib_any(s ^ sp[u]) & 0x11111111u;
-        if (d) fs_emit(d, s, sp[u], nn[u], site_base + ww[u] * 8, cursor, seg_cap, out_key, out_val);
+        if (d) fs_emit(d, s, sp[u], n0 + u, site_base + w * 8, cursor, seg_cap, out_key, out_val);
     }
 }
 
@@ -246,17 +323,17 @@ __global__ __launch_bounds__(256) void k_fs_backward(uint32_t *__restrict__ F, c
 // states, leaf rows still hold their sets, so a leaf's state is derived again.
 __global__ __launch_bounds__(256) void k_fs_emit(const uint32_t *__restrict__ F, const uint32_t *__restrict__ refw,
                                                  const uint32_t *__restrict__ parent, const uint32_t *__restrict__ n_children,
-                                                 uint32_t n_nodes, uint32_t W, uint32_t gy, uint32_t site_base,
+                                                 uint32_t n_nodes, uint32_t W, uint32_t gy, uint64_t npad, uint32_t site_base,
                                                  unsigned long long *__restrict__ cursor, unsigned long long cap,
-                                                 uint64_t *__restrict__ out_key, uint8_t *__restrict__ out_val) {
+                                                 uint64_t *__restrict__ out_key, uint8_t *__restrict__ out_val,
+                                                 const uint32_t *__restrict__ stored) {
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    const uint64_t T = (uint64_t)blockIdx.x * 4 + wave;
-    const uint32_t n = (uint32_t)(T / gy);
-    const uint32_t w = (uint32_t)(T % gy) * 64 + lane;
+    const uint32_t y = blockIdx.x % gy, n = (blockIdx.x / gy) * 4 + wave;
+    const uint32_t w = y * 64 + lane;
     if (n >= n_nodes || w >= W) return;
     const uint32_t par = parent[n];
     const uint32_t sp = par == 0xFFFFFFFFu ? refw[w] : F[(uint64_t)par * W + w];
-    uint32_t s = F[(uint64_t)n * W + w];
+    uint32_t s = fs_bit(stored, (uint64_t)y * npad + n) ? F[(uint64_t)n * W + w] : refw[w];
     if (!n_children[n]) {
         const uint32_t keep = nib_any(s & sp);
         s = (sp & keep) | (nib_lowbit(s) & ~keep);
@@ -275,6 +352,16 @@ __global__ void k_fs_compact(const uint64_t *__restrict__ seg_key, const uint8_t
         out_key[b + i] = seg_key[seg * seg_cap + i];
         out_val[b + i] = seg_val[seg * seg_cap + i];
     }
+}
+
+// the sorted list as the four arrays the caller gets
+__global__ void k_fs_split(const uint64_t *__restrict__ key, const uint8_t *__restrict__ val, uint64_t n, uint32_t *__restrict__ site,
+                           uint32_t *__restrict__ node, uint8_t *__restrict__ par, uint8_t *__restrict__ nuc) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t k = key[i];
+    const uint8_t v = val[i];
+    site[i] = (uint32_t)(k >> 32); node[i] = (uint32_t)k; par[i] = v >> 4; nuc[i] = v & 0xF;
 }
 
 // Device buffers are kept from call to call (a pool per device, below): alloc() only ever grows them.
@@ -311,11 +398,13 @@ __global__ void k_fs_heads(const uint32_t *__restrict__ parent, uint32_t n, uint
     flag[j] = (j == 1 || p != q) ? 1 : 0;
 }
 __global__ void k_fs_topo(const uint32_t *__restrict__ parent, uint32_t n, const uint32_t *__restrict__ heads, const uint32_t *__restrict__ n_heads_p,
-                          uint32_t *__restrict__ first_child, uint32_t *__restrict__ n_children, uint32_t *__restrict__ inodes) {
+                          uint32_t *__restrict__ first_child, uint32_t *__restrict__ n_children, uint32_t *__restrict__ inodes,
+                          uint32_t *__restrict__ ifirst, uint32_t *__restrict__ inch) {
     const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x, nh = *n_heads_p;
     if (k >= nh) return;
     const uint32_t j = heads[k], e = k + 1 < nh ? heads[k + 1] : n, p = parent[j];
     first_child[p] = j; n_children[p] = e - j; inodes[k] = p;
+    ifirst[k] = j; inch[k] = e - j;   // (the same by the node's rank among the internal nodes: what the forward sweep indexes)
 }
 // ilvl_off[L] = internal nodes in front of level L = run heads among the nodes in front of level L + 1 (their children)
 __global__ void k_fs_level_ranks(const uint32_t *__restrict__ heads, const uint32_t *__restrict__ n_heads_p, const uint32_t *__restrict__ lvl_off, uint32_t n_levels,
@@ -332,8 +421,8 @@ __global__ void k_fs_level_ranks(const uint32_t *__restrict__ heads, const uint3
 
 struct FsPool {   // one per device, kept until the process ends: a call allocates nothing in the steady state
     std::mutex mu;
-    Dev<uint32_t> d_parent, d_first, d_nchild, d_inodes, d_heads, d_small, d_levels, d_F, d_refw, d_vnode;
-    Dev<uint8_t> d_flag, d_vnuc, d_oval, d_oval2, d_tmp, d_sel_tmp;
+    Dev<uint32_t> d_parent, d_first, d_nchild, d_inodes, d_heads, d_small, d_levels, d_F, d_refw, d_vnode, d_stored, d_osite, d_onode, d_ifirst, d_inch;
+    Dev<uint8_t> d_flag, d_vnuc, d_oval, d_oval2, d_tmp, d_sel_tmp, d_opar, d_onuc, d_desc, d_mark8;
     Dev<uint64_t> d_okey, d_okey2, d_voff;
     Dev<unsigned long long> d_cnt, d_segb;
 };
@@ -356,8 +445,9 @@ extern "C" void ugp_fitch_release(int device) {
     std::lock_guard<std::mutex> g(p->mu);
     if (hipSetDevice(device) != hipSuccess) return;
     (void)hipDeviceSynchronize();
-    for (Dev<uint32_t> *d : {&p->d_parent, &p->d_first, &p->d_nchild, &p->d_inodes, &p->d_heads, &p->d_small, &p->d_levels, &p->d_F, &p->d_refw, &p->d_vnode}) d->release();
-    for (Dev<uint8_t> *d : {&p->d_flag, &p->d_vnuc, &p->d_oval, &p->d_oval2, &p->d_tmp, &p->d_sel_tmp}) d->release();
+    for (Dev<uint32_t> *d : {&p->d_parent, &p->d_first, &p->d_nchild, &p->d_inodes, &p->d_heads, &p->d_small, &p->d_levels, &p->d_F, &p->d_refw, &p->d_vnode,
+                            &p->d_stored, &p->d_osite, &p->d_onode, &p->d_ifirst, &p->d_inch}) d->release();
+    for (Dev<uint8_t> *d : {&p->d_flag, &p->d_vnuc, &p->d_oval, &p->d_oval2, &p->d_tmp, &p->d_sel_tmp, &p->d_opar, &p->d_onuc, &p->d_desc, &p->d_mark8}) d->release();
     for (Dev<uint64_t> *d : {&p->d_okey, &p->d_okey2, &p->d_voff}) d->release();
     for (Dev<unsigned long long> *d : {&p->d_cnt, &p->d_segb}) d->release();
 }
@@ -413,6 +503,7 @@ extern "C" int ugp_fitch_sankoff(int device, uint64_t n_nodes, const uint32_t *p
     // the nodes whose parent lies in it), meaningful once the device has confirmed the order.
     FS_TRY(d_parent.upload(parent, N, stream));
     FS_TRY(d_first.alloc(N)); FS_TRY(d_nchild.alloc(N)); FS_TRY(d_inodes.alloc(N)); FS_TRY(P.d_heads.alloc(N)); FS_TRY(P.d_flag.alloc(N));
+    FS_TRY(P.d_ifirst.alloc(N)); FS_TRY(P.d_inch.alloc(N));
     FS_TRY(P.d_small.alloc(16));   // [0] order violated, [1] run heads, [2] cell flags
     FS_TRY(hipMemsetAsync(P.d_small.p, 0, 8 * sizeof(uint32_t), stream));
     FS_TRY(hipMemsetAsync(d_first.p, 0, (size_t)N * 4, stream));
@@ -425,7 +516,8 @@ extern "C" int ugp_fitch_sankoff(int device, uint64_t n_nodes, const uint32_t *p
         FS_TRY(P.d_sel_tmp.alloc(sel_bytes));
         FS_TRY(rocprim::select(P.d_sel_tmp.p, sel_bytes, idx, P.d_flag.p, P.d_heads.p, P.d_small.p + 1, (size_t)N, stream));
     }
-    hipLaunchKernelGGL(k_fs_topo, dim3((N + 255) / 256), dim3(256), 0, stream, d_parent.p, N, P.d_heads.p, P.d_small.p + 1, d_first.p, d_nchild.p, d_inodes.p);
+    hipLaunchKernelGGL(k_fs_topo, dim3((N + 255) / 256), dim3(256), 0, stream, d_parent.p, N, P.d_heads.p, P.d_small.p + 1, d_first.p, d_nchild.p, d_inodes.p,
+                       P.d_ifirst.p, P.d_inch.p);
     std::vector<uint32_t> lvl_off{0, 1};   // nodes of level L are [lvl_off[L], lvl_off[L+1])
     while (lvl_off.back() < N) {
         // first j whose parent is not in front of the end of the last level: std::lower_bound over parent[1..N)
@@ -459,12 +551,13 @@ extern "C" int ugp_fitch_sankoff(int device, uint64_t n_nodes, const uint32_t *p
     if (S == 0) { guard.r = nullptr; *out = res; return UGP_OK; }
     t_topo = lap();
 
-    // sites per pass: F takes N * W * 4 bytes.  Passes of up to 4 GiB (or half of the free HBM if that is
-    // less; UGP_FITCH_BYTES overrides): larger buffers only add allocation time, the kernels are
-    // already at full width with 512-site rows.
+    // sites per pass: F takes N * W * 4 bytes.  Passes of up to 16 GiB (or half of the free HBM if that is less; UGP_FITCH_BYTES
+    // overrides): 10 M nodes x 2 048 sites go in one -- one upload, one sweep of 2 x 46 launches, one sort, one download instead of
+    // four of each (18.9 -> 15.0 ms per call, round 6) -- and the buffer is pooled, and mostly untouched: rows that are never
+    // stored (below) are never written either.
     size_t free_b = 0, total_b = 0;
     FS_TRY(hipMemGetInfo(&free_b, &total_b));
-    uint64_t budget = std::min<uint64_t>((free_b + P.d_F.cap * 4) / 2, 4ull << 30);
+    uint64_t budget = std::min<uint64_t>((free_b + P.d_F.cap * 4) / 2, 16ull << 30);
     if (const char *e = getenv("UGP_FITCH_BYTES")) budget = strtoull(e, nullptr, 10);
     uint64_t W_max = std::max<uint64_t>(budget / ((uint64_t)N * 4), 1);
     if (W_max >= 64) W_max &= ~63ull;   // whole 512-site wave rows
@@ -480,8 +573,7 @@ extern "C" int ugp_fitch_sankoff(int device, uint64_t n_nodes, const uint32_t *p
     FS_TRY(d_segb.alloc(FS_SEG + 1));
     std::vector<uint32_t> refw(W_pass), vnode;
     std::vector<uint8_t> vnuc;
-    std::vector<uint64_t> voff, h_key;
-    std::vector<uint8_t> h_val;
+    std::vector<uint64_t> voff;
     std::vector<unsigned long long> h_cnt((size_t)FS_SEG * 8), h_segb(FS_SEG + 1);
     std::vector<uint32_t> seen_site;   // (slow path) last site, 1-based, a node had a cell at -- and where
     std::vector<uint64_t> seen_at;
@@ -508,16 +600,28 @@ extern "C" int ugp_fitch_sankoff(int device, uint64_t n_nodes, const uint32_t *p
         voff.resize(n_s + 1);
         for (uint32_t k = 0; k <= n_s; k++) voff[k] = sites->var_off[s0 + k] - v0;
         const uint32_t gy = (W + 63) / 64;
-        auto blocks = [&](uint64_t items, int per_wave) { return dim3((unsigned)((items + 4ull * per_wave - 1) / (4ull * per_wave))); };
         unsigned long long seg_cap = 0;
+        const uint64_t npad = ((uint64_t)N + 63) & ~63ull;
+        const size_t bm_words = (size_t)(npad / 32 * gy) + 2;   // (tile-major, whole 64-bit words per tile: k_fs_init takes one per wave)
+        const uint32_t n_internal = ilvl_off[n_levels];
+        FS_TRY(P.d_mark8.alloc((size_t)npad * gy));
+        FS_TRY(P.d_stored.alloc(bm_words));
+        FS_TRY(P.d_desc.alloc((size_t)n_internal * gy));
+        auto grid = [&](uint64_t nodes, int per_wave) { return dim3((unsigned)((nodes + 4ull * per_wave - 1) / (4ull * per_wave) * gy)); };
         for (int attempt = 0; attempt < 2; attempt++) {
             FS_TRY(hipMemcpyAsync(d_refw.p, refw.data(), (size_t)W * 4, hipMemcpyHostToDevice, stream));
-            // (round 6) the rows are initialised -- N x W words written, 2.3 ms at 10 M nodes x 2 048 sites -- while the cells cross
-            // PCIe: the init needs the reference word only, and a copy from the caller's pageable arrays keeps the host busy anyway
-            hipLaunchKernelGGL(k_fs_init, blocks((uint64_t)N * gy, FS_NB), dim3(256), 0, stream, d_F.p, d_refw.p, d_nchild.p, N, W, gy);
             FS_TRY(d_voff.upload(voff.data(), voff.size(), stream));
             FS_TRY(d_vnode.upload(cell_node, n_cells, stream));
             FS_TRY(d_vnuc.upload(cell_nuc, n_cells, stream));
+            // (round 6) only the (node, tile) items that hold a cell get a row: mark them, initialise those, then drop the cells in
+            FS_TRY(hipMemsetAsync(P.d_mark8.p, 0, (size_t)npad * gy, stream));
+            if (n_cells)
+                hipLaunchKernelGGL(k_fs_mark, dim3((unsigned)((n_cells + 255) / 256)), dim3(256), 0, stream, d_voff.p, n_s, d_vnode.p, n_cells, npad, N,
+                                   P.d_mark8.p);
+            hipLaunchKernelGGL(k_fs_init, grid(N, 64), dim3(256), 0, stream, d_F.p, d_refw.p, d_nchild.p, N, W, gy, npad, P.d_mark8.p, P.d_stored.p);
+            if (n_internal)
+                hipLaunchKernelGGL(k_fs_desc, dim3((unsigned)(((uint64_t)n_internal * gy + 255) / 256)), dim3(256), 0, stream, d_inodes.p, P.d_ifirst.p,
+                                   P.d_inch.p, n_internal, gy, npad, P.d_mark8.p, P.d_stored.p, P.d_desc.p);
             FS_TRY(hipMemsetAsync(d_cnt.p, 0, ((size_t)FS_SEG * 8 + 8) * sizeof(unsigned long long), stream));
             FS_TRY(hipMemsetAsync(P.d_small.p + 2, 0, 4, stream));
             // room for the listed changes: without cells on internal nodes a site has at most (cells + 1) of
@@ -558,13 +662,13 @@ extern "C" int ugp_fitch_sankoff(int device, uint64_t n_nodes, const uint32_t *p
         for (uint32_t L = n_levels; L-- > 0;) {
             const uint32_t cnt = ilvl_off[L + 1] - ilvl_off[L];
             if (cnt)
-                hipLaunchKernelGGL(k_fs_forward, blocks((uint64_t)cnt * gy, FS_FN), dim3(256), 0, stream, d_F.p, d_inodes.p + ilvl_off[L], cnt,
-                                   d_first.p, d_nchild.p, W, gy);
+                hipLaunchKernelGGL(k_fs_forward, grid(cnt, FS_FN), dim3(256), 0, stream, d_F.p, d_inodes.p + ilvl_off[L], P.d_ifirst.p + ilvl_off[L],
+                                   P.d_inch.p + ilvl_off[L], P.d_desc.p + ilvl_off[L], n_internal, cnt, W, gy, npad, d_refw.p, P.d_stored.p);
         }
         for (uint32_t L = 0; L < n_levels; L++) {
             const uint32_t cnt = lvl_off[L + 1] - lvl_off[L];
-            hipLaunchKernelGGL(k_fs_backward, blocks((uint64_t)cnt * gy, FS_NB), dim3(256), 0, stream, d_F.p, d_refw.p, d_parent.p,
-                               d_nchild.p, lvl_off[L], lvl_off[L + 1], W, gy, (uint32_t)s0, d_cnt.p, seg_cap, d_okey.p, d_oval.p);
+            hipLaunchKernelGGL(k_fs_backward, grid(cnt, FS_NB), dim3(256), 0, stream, d_F.p, d_refw.p, d_parent.p, d_nchild.p, lvl_off[L], lvl_off[L + 1],
+                               W, gy, npad, (uint32_t)s0, d_cnt.p, seg_cap, d_okey.p, d_oval.p, P.d_stored.p);
         }
         FS_TRY(hipGetLastError());
         FS_TRY(hipMemcpyAsync(h_cnt.data(), d_cnt.p, h_cnt.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
@@ -582,8 +686,8 @@ extern "C" int ugp_fitch_sankoff(int device, uint64_t n_nodes, const uint32_t *p
         FS_TRY(d_okey2.alloc(n_mut));
         FS_TRY(d_oval2.alloc(n_mut));
         if (overflow) {   // the guess was too small for some segment: list again, exactly
-            hipLaunchKernelGGL(k_fs_emit, blocks((uint64_t)N * gy, 1), dim3(256), 0, stream, d_F.p, d_refw.p, d_parent.p, d_nchild.p, N, W,
-                               gy, (uint32_t)s0, d_cnt.p + (size_t)FS_SEG * 8, n_mut, d_okey2.p, d_oval2.p);
+            hipLaunchKernelGGL(k_fs_emit, grid(N, 1), dim3(256), 0, stream, d_F.p, d_refw.p, d_parent.p, d_nchild.p, N, W, gy, npad, (uint32_t)s0,
+                               d_cnt.p + (size_t)FS_SEG * 8, n_mut, d_okey2.p, d_oval2.p, P.d_stored.p);
         } else {
             FS_TRY(hipMemcpyAsync(d_segb.p, h_segb.data(), h_segb.size() * sizeof(unsigned long long), hipMemcpyHostToDevice, stream));
             hipLaunchKernelGGL(k_fs_compact, dim3(FS_SEG), dim3(256), 0, stream, d_okey.p, d_oval.p, d_segb.p, seg_cap, d_okey2.p, d_oval2.p);
@@ -604,19 +708,17 @@ extern "C" int ugp_fitch_sankoff(int device, uint64_t n_nodes, const uint32_t *p
         FS_TRY(d_tmp.alloc(tmp_bytes));
         FS_TRY(rocprim::radix_sort_pairs(d_tmp.p, tmp_bytes, d_okey2.p, d_okey.p, d_oval2.p, d_oval.p, (size_t)n_mut, 0u, nb_bits, stream));
         FS_TRY(rocprim::radix_sort_pairs(d_tmp.p, tmp_bytes, d_okey.p, d_okey2.p, d_oval.p, d_oval2.p, (size_t)n_mut, 32u, 32u + sb_bits, stream));
-        h_key.resize(n_mut);
-        h_val.resize(n_mut);
-        FS_TRY(hipMemcpyAsync(h_key.data(), d_okey2.p, n_mut * sizeof(uint64_t), hipMemcpyDeviceToHost, stream));
-        FS_TRY(hipMemcpyAsync(h_val.data(), d_oval2.p, n_mut, hipMemcpyDeviceToHost, stream));
-        FS_TRY(hipStreamSynchronize(stream));
+        // the four arrays of the result are made on the device and land in the handle's vectors directly
+        FS_TRY(P.d_osite.alloc(n_mut)); FS_TRY(P.d_onode.alloc(n_mut)); FS_TRY(P.d_opar.alloc(n_mut)); FS_TRY(P.d_onuc.alloc(n_mut));
+        hipLaunchKernelGGL(k_fs_split, dim3((unsigned)((n_mut + 255) / 256)), dim3(256), 0, stream, d_okey2.p, d_oval2.p, (uint64_t)n_mut, P.d_osite.p,
+                           P.d_onode.p, P.d_opar.p, P.d_onuc.p);
         const size_t base = res->site.size();
         res->site.resize(base + n_mut); res->node.resize(base + n_mut); res->par.resize(base + n_mut); res->nuc.resize(base + n_mut);
-        for (unsigned long long i = 0; i < n_mut; i++) {
-            res->site[base + i] = (uint32_t)(h_key[i] >> 32);
-            res->node[base + i] = (uint32_t)h_key[i];
-            res->par[base + i] = h_val[i] >> 4;
-            res->nuc[base + i] = h_val[i] & 0xF;
-        }
+        FS_TRY(hipMemcpyAsync(res->site.data() + base, P.d_osite.p, n_mut * 4, hipMemcpyDeviceToHost, stream));
+        FS_TRY(hipMemcpyAsync(res->node.data() + base, P.d_onode.p, n_mut * 4, hipMemcpyDeviceToHost, stream));
+        FS_TRY(hipMemcpyAsync(res->par.data() + base, P.d_opar.p, n_mut, hipMemcpyDeviceToHost, stream));
+        FS_TRY(hipMemcpyAsync(res->nuc.data() + base, P.d_onuc.p, n_mut, hipMemcpyDeviceToHost, stream));
+        FS_TRY(hipStreamSynchronize(stream));
         t_out += lap();
     }
     if (getenv("UGP_FITCH_VERBOSE"))
