@@ -120,20 +120,38 @@ __global__ __launch_bounds__(256) void k_fs_init(uint32_t *__restrict__ F, const
     }
 }
 
-// what the forward sweep needs to know about an item before it can ask for rows, in one byte per (tile, internal node): bit 0 the
-// node's own row exists (it holds a cell), bits 1 / 2 / 3 the rows of its first / second / third child exist
-__global__ void k_fs_desc(const uint32_t *__restrict__ inodes, const uint32_t *__restrict__ ifirst, const uint32_t *__restrict__ inch, uint32_t n_internal,
-                          uint32_t gy, uint64_t npad, const uint8_t *__restrict__ mark8, const uint32_t *__restrict__ stored, uint8_t *__restrict__ desc) {
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (uint64_t)n_internal * gy) return;
-    const uint32_t y = (uint32_t)(i / n_internal), k = (uint32_t)(i % n_internal);
-    const uint64_t base = (uint64_t)y * npad;
-    const uint32_t c0 = ifirst[k], nc = inch[k];
-    uint32_t d = mark8[base + inodes[k]] ? 1u : 0u;
-    if (fs_bit(stored, base + c0)) d |= 2u;
-    if (nc > 1 && fs_bit(stored, base + c0 + 1)) d |= 4u;
-    if (nc > 2 && fs_bit(stored, base + c0 + 2)) d |= 8u;
-    desc[i] = (uint8_t)d;
+// what the forward sweep needs to know about its items before it can ask for rows, in one dword per wave -- (tile, group of FS_FN
+// internal nodes of a level; `goff` = the first group of every level): four bits per node, bit 0 the node's own row exists (it
+// holds a cell), bits 1 / 2 / 3 the rows of its first / second / third child exist
+constexpr int FS_FN = 8;
+__global__ void k_fs_desc(const uint32_t *__restrict__ inodes, const uint32_t *__restrict__ ifirst, const uint32_t *__restrict__ inch,
+                          const uint32_t *__restrict__ ilvl_off, const uint32_t *__restrict__ goff, uint32_t n_levels, uint32_t n_groups, uint32_t gy,
+                          uint64_t npad, const uint8_t *__restrict__ mark8, const uint32_t *__restrict__ stored, uint32_t *__restrict__ desc) {
+    static_assert(FS_FN == 8, "eight lanes fill one descriptor");
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;   // lane = (tile, group, node of the group)
+    const uint64_t ig = i >> 3;
+    const uint32_t u = (uint32_t)i & 7;
+    uint32_t x = 0;
+    if (ig < (uint64_t)n_groups * gy) {
+        const uint32_t y = (uint32_t)(ig / n_groups), g = (uint32_t)(ig % n_groups);
+        uint32_t lo = 0, hi = n_levels;   // last level L with goff[L] <= g
+        while (hi - lo > 1) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (goff[mid] <= g) lo = mid; else hi = mid;
+        }
+        const uint32_t k = ilvl_off[lo] + (g - goff[lo]) * FS_FN + u;
+        if (k < ilvl_off[lo + 1]) {
+            const uint64_t base = (uint64_t)y * npad;
+            const uint32_t c0 = ifirst[k], nc = inch[k];
+            x = mark8[base + inodes[k]] ? 1u : 0u;
+            if (fs_bit(stored, base + c0)) x |= 2u;
+            if (nc > 1 && fs_bit(stored, base + c0 + 1)) x |= 4u;
+            if (nc > 2 && fs_bit(stored, base + c0 + 2)) x |= 8u;
+            x <<= 4 * u;
+        }
+    }
+    x |= __shfl_xor(x, 1); x |= __shfl_xor(x, 2); x |= __shfl_xor(x, 4);
+    if (u == 0 && ig < (uint64_t)n_groups * gy) desc[ig] = x;
 }
 
 // genotype cells of tree nodes: replace the initial nibble by the allele mask (:47-62).
@@ -162,13 +180,14 @@ __global__ void k_fs_scatter(uint32_t *__restrict__ F, const uint32_t *__restric
 }
 
 // forward pass for the internal nodes of one level (:86-111).  A wave takes one tile of FS_FN internal nodes in a row; what it
-// has to know about them -- node, first child, child count, which rows exist -- is FS_FN independent scalar loads from arrays
-// indexed by the node's rank among the internal nodes, and then the node's own row and its first three child rows of every item
-// are requested before any is used.  A row that does not exist is read from the reference word instead (no branch around a
-// load; every wave keeps that row hot).  Nodes with up to three children -- two counter planes -- are finished in straight-line
-// code; the others (polytomies) take the general bit-sliced path, one copy of it, afterwards.
-constexpr int FS_FN = 8;
-
+// has to know about them -- node, first child, child count, which rows exist -- is independent SCALAR loads (arrays indexed by
+// the node's rank among the internal nodes; one descriptor dword for the wave), and then the node's own row and its first three
+// child rows of every item are requested, 4 x FS_FN loads without a branch or a wait between them, before any is used.  A row
+// that does not exist -- or a child that does not -- is read from the reference word instead, which every wave keeps hot, and
+// replaced afterwards.  (The first version looked the descriptor up with a byte load per item: a vector load, whose wait drained
+// the rows already requested -- the items of a wave ran one after the other, 15 us per wave.)  Nodes with up to three children --
+// two counter planes -- are finished in straight-line code; the others (polytomies) take the general bit-sliced path, one copy of
+// it, afterwards.
 __device__ __forceinline__ uint32_t fs_pick(uint32_t cand, uint32_t plane) {   // keep the candidates whose counter has a 0 in this plane, if any
     const uint32_t z = cand & ~plane;
     const uint32_t m = nib_any(z);
@@ -176,34 +195,49 @@ __device__ __forceinline__ uint32_t fs_pick(uint32_t cand, uint32_t plane) {   /
 }
 
 __global__ __launch_bounds__(256) void k_fs_forward(uint32_t *__restrict__ F, const uint32_t *__restrict__ nodes, const uint32_t *__restrict__ ifirst,
-                                                    const uint32_t *__restrict__ inch, const uint8_t *__restrict__ desc, uint32_t n_internal,
+                                                    const uint32_t *__restrict__ inch, const uint32_t *__restrict__ desc, uint32_t n_groups,
                                                     uint32_t n_level, uint32_t W, uint32_t gy, uint64_t npad, const uint32_t *__restrict__ refw,
-                                                    const uint32_t *__restrict__ stored) {
+                                                    const uint32_t *__restrict__ stored, uint32_t n_nodes) {
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    const uint32_t y = blockIdx.x % gy, idx0 = ((blockIdx.x / gy) * 4 + wave) * FS_FN;
+    const uint32_t y = blockIdx.x % gy, grp = (blockIdx.x / gy) * 4 + wave, idx0 = grp * FS_FN;
     if (idx0 >= n_level) return;
     const uint32_t w = y * 64 + lane;
     if (w >= W) return;
-    desc += (uint64_t)y * n_internal;
-    const uint32_t *rref = refw + w;
+    const uint32_t dd = desc[(uint64_t)y * n_groups + grp];
     uint32_t own[FS_FN], ch0[FS_FN], ch1[FS_FN], ch2[FS_FN], pp[FS_FN], ncs[FS_FN];
+#pragma unroll
+    for (int u = 0; u < FS_FN; u++) {   // (past the end of a level lie the next level's entries, and eight spare ones at the very end)
+        pp[u] = nodes[idx0 + u];
+        ncs[u] = inch[idx0 + u];
+        own[u] = ifirst[idx0 + u];   // (the first child, until the rows are asked for)
+    }
+    // (all 3 x FS_FN scalar loads -- three s_load_dwordx8 -- are on their way before the first is waited for: without the empty asm
+    // the compiler sinks most of them into the blocks that use them, one round trip per item)
+#pragma unroll
+    for (int u = 0; u < FS_FN; u++) {
+        asm volatile("" : "+s"(pp[u]), "+s"(ncs[u]), "+s"(own[u]));
+        if (idx0 + u >= n_level) ncs[u] = 0;
+    }
+    // Row addresses in 32-bit arithmetic: the caller keeps (n_nodes + 1) * W below 2^32 words, and row n_nodes of F is a copy of
+    // the reference word -- "the row does not exist" is a select between two row INDICES, one scalar instruction, instead of one
+    // between two 64-bit pointers (the scalar unit, one per CU, was this kernel's bound: 835 scalar instructions per wave).
     bool wide = false;
 #pragma unroll
     for (int u = 0; u < FS_FN; u++) {
-        const bool ok = idx0 + u < n_level;
-        pp[u] = ok ? nodes[idx0 + u] : 0u;
-        const uint32_t c0 = ok ? ifirst[idx0 + u] : 0u;
-        ncs[u] = ok ? inch[idx0 + u] : 0u;
-        const uint32_t d = ok ? (uint32_t)desc[idx0 + u] : 0u;
-        own[u] = 0xFFFFFFFFu; ch0[u] = 0xFFFFFFFFu; ch1[u] = 0xFFFFFFFFu; ch2[u] = 0xFFFFFFFFu;
-        wide = wide || ncs[u] > 3;
-        if (ok && ncs[u] <= 3) {
-            const uint32_t *row = F + (uint64_t)c0 * W + w;
-            if (d & 1u) own[u] = F[(uint64_t)pp[u] * W + w];
-            ch0[u] = *((d & 2u) ? row : rref);
-            if (ncs[u] > 1) ch1[u] = *((d & 4u) ? row + W : rref);
-            if (ncs[u] > 2) ch2[u] = *((d & 8u) ? row + (uint64_t)2 * W : rref);
-        }
+        const uint32_t d = dd >> (4 * u), nc = ncs[u], c0 = own[u];
+        wide = wide || nc > 3;
+        const uint32_t r0 = (d & 1u) ? pp[u] : n_nodes;
+        const uint32_t r1 = (d & 2u) ? c0 : n_nodes;
+        const uint32_t r2 = (nc > 1 && (d & 4u)) ? c0 + 1 : n_nodes;
+        const uint32_t r3 = (nc > 2 && (d & 8u)) ? c0 + 2 : n_nodes;
+        own[u] = F[r0 * W + w]; ch0[u] = F[r1 * W + w]; ch1[u] = F[r2 * W + w]; ch2[u] = F[r3 * W + w];
+    }
+#pragma unroll
+    for (int u = 0; u < FS_FN; u++) {   // what was read in place of a row that does not exist
+        const uint32_t d = dd >> (4 * u), nc = ncs[u];
+        if (!(d & 1u)) own[u] = 0xFFFFFFFFu;
+        if (nc < 2) ch1[u] = 0xFFFFFFFFu;
+        if (nc < 3) ch2[u] = 0xFFFFFFFFu;
     }
 #pragma unroll
     for (int u = 0; u < FS_FN; u++) {
@@ -215,7 +249,7 @@ __global__ __launch_bounds__(256) void k_fs_forward(uint32_t *__restrict__ F, co
         c = ~ch2[u];
         p1 |= p0 & c;
         p0 ^= c;
-        F[(uint64_t)pp[u] * W + w] = fs_pick(fs_pick(own[u], p1), p0);
+        F[pp[u] * W + w] = fs_pick(fs_pick(own[u], p1), p0);
     }
     if (!wide) return;
 #pragma nounroll
@@ -228,7 +262,7 @@ __global__ __launch_bounds__(256) void k_fs_forward(uint32_t *__restrict__ F, co
         uint32_t plane[FS_PLANES];
 #pragma unroll
         for (int k = 0; k < FS_PLANES; k++) plane[k] = 0;
-        const uint32_t *row = F + (uint64_t)c0 * W + w;
+        const uint32_t *row = F + (uint64_t)c0 * W + w, *rref = refw + w;
         const uint64_t b0 = (uint64_t)y * npad + c0;
         uint32_t nxt = *(fs_bit(stored, b0) ? row : rref);
         for (uint32_t c = 0; c < nc; c++) {
@@ -243,7 +277,7 @@ __global__ __launch_bounds__(256) void k_fs_forward(uint32_t *__restrict__ F, co
                 carry = t;
             }
         }
-        uint32_t cand = (desc[idx0 + u] & 1u) ? F[(uint64_t)p * W + w] : 0xFFFFFFFFu;   // allowed bases (all four, or the node's own genotype mask)
+        uint32_t cand = ((dd >> (4 * u)) & 1u) ? F[(uint64_t)p * W + w] : 0xFFFFFFFFu;   // allowed bases (all four, or the node's own genotype mask)
 #pragma unroll
         for (int k = FS_PLANES - 1; k >= 0; k--) {
             if (k >= K) continue;
@@ -421,8 +455,8 @@ __global__ void k_fs_level_ranks(const uint32_t *__restrict__ heads, const uint3
 
 struct FsPool {   // one per device, kept until the process ends: a call allocates nothing in the steady state
     std::mutex mu;
-    Dev<uint32_t> d_parent, d_first, d_nchild, d_inodes, d_heads, d_small, d_levels, d_F, d_refw, d_vnode, d_stored, d_osite, d_onode, d_ifirst, d_inch;
-    Dev<uint8_t> d_flag, d_vnuc, d_oval, d_oval2, d_tmp, d_sel_tmp, d_opar, d_onuc, d_desc, d_mark8;
+    Dev<uint32_t> d_parent, d_first, d_nchild, d_inodes, d_heads, d_small, d_levels, d_F, d_refw, d_vnode, d_stored, d_osite, d_onode, d_ifirst, d_inch, d_desc;
+    Dev<uint8_t> d_flag, d_vnuc, d_oval, d_oval2, d_tmp, d_sel_tmp, d_opar, d_onuc, d_mark8;
     Dev<uint64_t> d_okey, d_okey2, d_voff;
     Dev<unsigned long long> d_cnt, d_segb;
 };
@@ -446,8 +480,8 @@ extern "C" void ugp_fitch_release(int device) {
     if (hipSetDevice(device) != hipSuccess) return;
     (void)hipDeviceSynchronize();
     for (Dev<uint32_t> *d : {&p->d_parent, &p->d_first, &p->d_nchild, &p->d_inodes, &p->d_heads, &p->d_small, &p->d_levels, &p->d_F, &p->d_refw, &p->d_vnode,
-                            &p->d_stored, &p->d_osite, &p->d_onode, &p->d_ifirst, &p->d_inch}) d->release();
-    for (Dev<uint8_t> *d : {&p->d_flag, &p->d_vnuc, &p->d_oval, &p->d_oval2, &p->d_tmp, &p->d_sel_tmp, &p->d_opar, &p->d_onuc, &p->d_desc, &p->d_mark8}) d->release();
+                            &p->d_stored, &p->d_osite, &p->d_onode, &p->d_ifirst, &p->d_inch, &p->d_desc}) d->release();
+    for (Dev<uint8_t> *d : {&p->d_flag, &p->d_vnuc, &p->d_oval, &p->d_oval2, &p->d_tmp, &p->d_sel_tmp, &p->d_opar, &p->d_onuc, &p->d_mark8}) d->release();
     for (Dev<uint64_t> *d : {&p->d_okey, &p->d_okey2, &p->d_voff}) d->release();
     for (Dev<unsigned long long> *d : {&p->d_cnt, &p->d_segb}) d->release();
 }
@@ -502,8 +536,8 @@ extern "C" int ugp_fitch_sankoff(int device, uint64_t n_nodes, const uint32_t *p
     // boundaries themselves are a handful of binary searches in the caller's array (a level is an index range; its children are
     // the nodes whose parent lies in it), meaningful once the device has confirmed the order.
     FS_TRY(d_parent.upload(parent, N, stream));
-    FS_TRY(d_first.alloc(N)); FS_TRY(d_nchild.alloc(N)); FS_TRY(d_inodes.alloc(N)); FS_TRY(P.d_heads.alloc(N)); FS_TRY(P.d_flag.alloc(N));
-    FS_TRY(P.d_ifirst.alloc(N)); FS_TRY(P.d_inch.alloc(N));
+    FS_TRY(d_first.alloc(N)); FS_TRY(d_nchild.alloc(N)); FS_TRY(d_inodes.alloc((size_t)N + 8)); FS_TRY(P.d_heads.alloc(N)); FS_TRY(P.d_flag.alloc(N));
+    FS_TRY(P.d_ifirst.alloc((size_t)N + 8)); FS_TRY(P.d_inch.alloc((size_t)N + 8));   // (+8: the forward sweep reads whole groups)
     FS_TRY(P.d_small.alloc(16));   // [0] order violated, [1] run heads, [2] cell flags
     FS_TRY(hipMemsetAsync(P.d_small.p, 0, 8 * sizeof(uint32_t), stream));
     FS_TRY(hipMemsetAsync(d_first.p, 0, (size_t)N * 4, stream));
@@ -538,7 +572,7 @@ extern "C" int ugp_fitch_sankoff(int device, uint64_t n_nodes, const uint32_t *p
     std::vector<uint32_t> ilvl_off(n_levels + 1, 0);
     {
         // (the level tables have a buffer of their own, sized by the tree -- a caterpillar has as many levels as nodes)
-        FS_TRY(P.d_levels.alloc(2 * (size_t)(n_levels + 1)));
+        FS_TRY(P.d_levels.alloc(3 * (size_t)(n_levels + 1)));   // (level begins, internal-node ranks, and -- below -- the forward sweep's groups)
         uint32_t *d_lvl = P.d_levels.p, *d_ilvl = P.d_levels.p + (n_levels + 1);
         FS_TRY(hipMemcpyAsync(d_lvl, lvl_off.data(), (n_levels + 1) * 4, hipMemcpyHostToDevice, stream));
         hipLaunchKernelGGL(k_fs_level_ranks, dim3((n_levels + 1 + 63) / 64), dim3(64), 0, stream, P.d_heads.p, P.d_small.p + 1, d_lvl, n_levels, d_ilvl);
@@ -549,6 +583,12 @@ extern "C" int ugp_fitch_sankoff(int device, uint64_t n_nodes, const uint32_t *p
         if (bad) return ugp::set_error(UGP_ERR_INVALID, "tree arrays are not in breadth-first order");
     }
     if (S == 0) { guard.r = nullptr; *out = res; return UGP_OK; }
+    // the forward sweep's waves take FS_FN internal nodes of a level each: goff[L] = the first such group of level L
+    std::vector<uint32_t> goff(n_levels + 1, 0);
+    for (uint32_t L = 0; L < n_levels; L++) goff[L + 1] = goff[L] + (ilvl_off[L + 1] - ilvl_off[L] + FS_FN - 1) / FS_FN;
+    const uint32_t n_groups = goff[n_levels];
+    const uint32_t *d_ilvl = P.d_levels.p + (n_levels + 1), *d_goff = P.d_levels.p + 2 * (size_t)(n_levels + 1);
+    FS_TRY(hipMemcpyAsync(P.d_levels.p + 2 * (size_t)(n_levels + 1), goff.data(), (n_levels + 1) * 4, hipMemcpyHostToDevice, stream));
     t_topo = lap();
 
     // sites per pass: F takes N * W * 4 bytes.  Passes of up to 16 GiB (or half of the free HBM if that is less; UGP_FITCH_BYTES
@@ -559,7 +599,8 @@ extern "C" int ugp_fitch_sankoff(int device, uint64_t n_nodes, const uint32_t *p
     FS_TRY(hipMemGetInfo(&free_b, &total_b));
     uint64_t budget = std::min<uint64_t>((free_b + P.d_F.cap * 4) / 2, 16ull << 30);
     if (const char *e = getenv("UGP_FITCH_BYTES")) budget = strtoull(e, nullptr, 10);
-    uint64_t W_max = std::max<uint64_t>(budget / ((uint64_t)N * 4), 1);
+    budget = std::min<uint64_t>(budget, 16ull << 30);   // (k_fs_forward addresses F in 32-bit words)
+    uint64_t W_max = std::max<uint64_t>(budget / (((uint64_t)N + 1) * 4), 1);   // (+1: the reference word's own row, behind the nodes')
     if (W_max >= 64) W_max &= ~63ull;   // whole 512-site wave rows
     const uint64_t W_all = (S + 7) / 8;
     const uint32_t W_pass = (uint32_t)std::min<uint64_t>(W_max, W_all);
@@ -567,7 +608,7 @@ extern "C" int ugp_fitch_sankoff(int device, uint64_t n_nodes, const uint32_t *p
     auto &d_vnuc = P.d_vnuc; auto &d_oval = P.d_oval; auto &d_oval2 = P.d_oval2; auto &d_tmp = P.d_tmp;
     auto &d_okey = P.d_okey; auto &d_okey2 = P.d_okey2; auto &d_voff = P.d_voff;
     auto &d_cnt = P.d_cnt; auto &d_segb = P.d_segb;
-    FS_TRY(d_F.alloc((size_t)N * W_pass));
+    FS_TRY(d_F.alloc(((size_t)N + 1) * W_pass));
     FS_TRY(d_refw.alloc(W_pass));
     FS_TRY(d_cnt.alloc((size_t)FS_SEG * 8 + 8));
     FS_TRY(d_segb.alloc(FS_SEG + 1));
@@ -603,13 +644,13 @@ extern "C" int ugp_fitch_sankoff(int device, uint64_t n_nodes, const uint32_t *p
         unsigned long long seg_cap = 0;
         const uint64_t npad = ((uint64_t)N + 63) & ~63ull;
         const size_t bm_words = (size_t)(npad / 32 * gy) + 2;   // (tile-major, whole 64-bit words per tile: k_fs_init takes one per wave)
-        const uint32_t n_internal = ilvl_off[n_levels];
         FS_TRY(P.d_mark8.alloc((size_t)npad * gy));
         FS_TRY(P.d_stored.alloc(bm_words));
-        FS_TRY(P.d_desc.alloc((size_t)n_internal * gy));
+        FS_TRY(P.d_desc.alloc((size_t)n_groups * gy));
         auto grid = [&](uint64_t nodes, int per_wave) { return dim3((unsigned)((nodes + 4ull * per_wave - 1) / (4ull * per_wave) * gy)); };
         for (int attempt = 0; attempt < 2; attempt++) {
             FS_TRY(hipMemcpyAsync(d_refw.p, refw.data(), (size_t)W * 4, hipMemcpyHostToDevice, stream));
+            FS_TRY(hipMemcpyAsync(d_F.p + (size_t)N * W, refw.data(), (size_t)W * 4, hipMemcpyHostToDevice, stream));   // (row N: what a missing row reads as)
             FS_TRY(d_voff.upload(voff.data(), voff.size(), stream));
             FS_TRY(d_vnode.upload(cell_node, n_cells, stream));
             FS_TRY(d_vnuc.upload(cell_nuc, n_cells, stream));
@@ -619,9 +660,9 @@ extern "C" int ugp_fitch_sankoff(int device, uint64_t n_nodes, const uint32_t *p
                 hipLaunchKernelGGL(k_fs_mark, dim3((unsigned)((n_cells + 255) / 256)), dim3(256), 0, stream, d_voff.p, n_s, d_vnode.p, n_cells, npad, N,
                                    P.d_mark8.p);
             hipLaunchKernelGGL(k_fs_init, grid(N, 64), dim3(256), 0, stream, d_F.p, d_refw.p, d_nchild.p, N, W, gy, npad, P.d_mark8.p, P.d_stored.p);
-            if (n_internal)
-                hipLaunchKernelGGL(k_fs_desc, dim3((unsigned)(((uint64_t)n_internal * gy + 255) / 256)), dim3(256), 0, stream, d_inodes.p, P.d_ifirst.p,
-                                   P.d_inch.p, n_internal, gy, npad, P.d_mark8.p, P.d_stored.p, P.d_desc.p);
+            if (n_groups)
+                hipLaunchKernelGGL(k_fs_desc, dim3((unsigned)(((uint64_t)n_groups * gy * FS_FN + 255) / 256)), dim3(256), 0, stream, d_inodes.p, P.d_ifirst.p,
+                                   P.d_inch.p, d_ilvl, d_goff, n_levels, n_groups, gy, npad, P.d_mark8.p, P.d_stored.p, P.d_desc.p);
             FS_TRY(hipMemsetAsync(d_cnt.p, 0, ((size_t)FS_SEG * 8 + 8) * sizeof(unsigned long long), stream));
             FS_TRY(hipMemsetAsync(P.d_small.p + 2, 0, 4, stream));
             // room for the listed changes: without cells on internal nodes a site has at most (cells + 1) of
@@ -663,7 +704,7 @@ extern "C" int ugp_fitch_sankoff(int device, uint64_t n_nodes, const uint32_t *p
             const uint32_t cnt = ilvl_off[L + 1] - ilvl_off[L];
             if (cnt)
                 hipLaunchKernelGGL(k_fs_forward, grid(cnt, FS_FN), dim3(256), 0, stream, d_F.p, d_inodes.p + ilvl_off[L], P.d_ifirst.p + ilvl_off[L],
-                                   P.d_inch.p + ilvl_off[L], P.d_desc.p + ilvl_off[L], n_internal, cnt, W, gy, npad, d_refw.p, P.d_stored.p);
+                                   P.d_inch.p + ilvl_off[L], P.d_desc.p + goff[L], n_groups, cnt, W, gy, npad, d_refw.p, P.d_stored.p, N);
         }
         for (uint32_t L = 0; L < n_levels; L++) {
             const uint32_t cnt = lvl_off[L + 1] - lvl_off[L];
