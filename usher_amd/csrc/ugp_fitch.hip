@@ -53,8 +53,6 @@ int set_error(int code, const std::string &msg);   // ugp_capi.cpp
 
 namespace {
 
-constexpr int FS_PLANES = 32;   // counters of up to 2^32 - 1 children
-
 __device__ __forceinline__ uint32_t nib_any(uint32_t x) {   // 0xF in every nibble of x that is non-zero
     uint32_t t = (x | (x >> 1) | (x >> 2) | (x >> 3)) & 0x11111111u;
     return t * 15u;
@@ -179,112 +177,115 @@ __global__ void k_fs_scatter(uint32_t *__restrict__ F, const uint32_t *__restric
     if (x) atomicXor(&F[(uint64_t)n * W + w], x);
 }
 
-// forward pass for the internal nodes of one level (:86-111).  A wave takes one tile of FS_FN internal nodes in a row; what it
-// has to know about them -- node, first child, child count, which rows exist -- is independent SCALAR loads (arrays indexed by
-// the node's rank among the internal nodes; one descriptor dword for the wave), and then the node's own row and its first three
-// child rows of every item are requested, 4 x FS_FN loads without a branch or a wait between them, before any is used.  A row
-// that does not exist -- or a child that does not -- is read from the reference word instead, which every wave keeps hot, and
-// replaced afterwards.  (The first version looked the descriptor up with a byte load per item: a vector load, whose wait drained
-// the rows already requested -- the items of a wave ran one after the other, 15 us per wave.)  Nodes with up to three children --
-// two counter planes -- are finished in straight-line code; the others (polytomies) take the general bit-sliced path, one copy of
-// it, afterwards.
+// forward pass for the internal nodes of one level (:86-111).  A wave takes one tile of a GROUP of FS_FN internal nodes in a row.
+// In breadth-first order the children of consecutive internal nodes are consecutive rows, so the group's children are ONE run of
+// rows: the wave streams it, eight row loads per batch with the next batch requested before the current one is counted, and the
+// nodes are segments of the stream -- a node is finished (the argmin over its allowed bases, one store) when its last child has
+// been counted.  Nodes with 2 children and polytomies of hundreds go through the same code at the same depth of loads in flight.
+// What the wave has to know first is independent SCALAR loads -- three s_load_dwordx8 from arrays indexed by the node's rank among
+// the internal nodes, one descriptor dword -- and a row that does not exist is read from row n_nodes of the table, a copy of the
+// reference word, in 32-bit address arithmetic (the caller keeps (n_nodes + 1) * W below 2^32): "no row" is a select between two
+// row indices.  (History of this kernel, round 6: items with a byte-load descriptor each ran one after the other, 15 us per wave
+// -- a vector load's wait drains the rows already requested; then up to three children per node in straight-line code and a
+// one-row-ahead loop for the rest -- which is a fifth of the nodes and a third of the rows of the bench tree, half / three
+// quarters of a SARS-CoV-2-shaped one.)
+//
+// Child counts are bit-sliced (plane k = bit k of the lane's 32 (site, base) counters); KP planes count to 2^KP - 1, and a group is
+// run with 3, 5 or 32 of them by its largest node.
 __device__ __forceinline__ uint32_t fs_pick(uint32_t cand, uint32_t plane) {   // keep the candidates whose counter has a 0 in this plane, if any
     const uint32_t z = cand & ~plane;
     const uint32_t m = nib_any(z);
     return (z & m) | (cand & ~m);
 }
 
+template <int KP>
+__device__ __forceinline__ void fs_forward_group(uint32_t *__restrict__ F, uint32_t w, uint32_t W, uint32_t ref_row, uint32_t (&pp)[FS_FN],
+                                                 uint32_t (&ncs)[FS_FN], uint32_t dd, uint32_t c_first, uint32_t n_rows,
+                                                 const uint32_t *__restrict__ stored, uint64_t bbase) {
+    uint32_t plane[KP];
+#pragma unroll
+    for (int k = 0; k < KP; k++) plane[k] = 0;
+    uint32_t xa[8], xb[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    uint32_t rem = ncs[0];
+    uint32_t have = fs_bits32(stored, bbase), have_next = fs_bits32(stored, bbase + 8);
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        const uint32_t r = ((uint32_t)j < n_rows && ((have >> j) & 1u)) ? c_first + j : ref_row;
+        xa[j] = F[r * W + w];
+    }
+#pragma nounroll
+    for (uint32_t i = 0; i < n_rows; i += 8) {
+        const uint32_t have_after = fs_bits32(stored, bbase + i + 16);   // (for the batch after the next: a round trip ahead of its use)
+        if (i + 8 < n_rows) {
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const uint32_t r = (i + 8 + j < n_rows && ((have_next >> j) & 1u)) ? c_first + i + 8 + j : ref_row;
+                xb[j] = F[r * W + w];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            if (i + j >= n_rows) break;
+            uint32_t carry = ~xa[j];   // +1 for every (site, base) with base not in F_c
+            const int K = KP == 32 ? 32 - __builtin_clz(ncs[0]) : KP;
+#pragma unroll
+            for (int k = 0; k < KP; k++) {
+                if (KP == 32 && k >= K) break;
+                const uint32_t t = plane[k] & carry;
+                plane[k] ^= carry;
+                carry = t;
+            }
+            if (--rem == 0) {   // the node's last child: argmin over the allowed bases (all four, or the node's own genotype mask)
+                uint32_t cand = 0xFFFFFFFFu;
+                if (dd & 1u) cand = F[pp[0] * W + w];
+#pragma unroll
+                for (int k = KP - 1; k >= 0; k--) {
+                    if (KP == 32 && k >= K) continue;
+                    cand = fs_pick(cand, plane[k]);
+                    plane[k] = 0;
+                }
+                F[pp[0] * W + w] = cand;
+#pragma unroll
+                for (int q = 0; q + 1 < FS_FN; q++) { pp[q] = pp[q + 1]; ncs[q] = ncs[q + 1]; }
+                ncs[FS_FN - 1] = 0;
+                dd >>= 4;
+                rem = ncs[0];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 8; j++) xa[j] = xb[j];
+        have_next = have_after;
+    }
+}
+
 __global__ __launch_bounds__(256) void k_fs_forward(uint32_t *__restrict__ F, const uint32_t *__restrict__ nodes, const uint32_t *__restrict__ ifirst,
                                                     const uint32_t *__restrict__ inch, const uint32_t *__restrict__ desc, uint32_t n_groups,
-                                                    uint32_t n_level, uint32_t W, uint32_t gy, uint64_t npad, const uint32_t *__restrict__ refw,
-                                                    const uint32_t *__restrict__ stored, uint32_t n_nodes) {
+                                                    uint32_t n_level, uint32_t W, uint32_t gy, uint64_t npad, const uint32_t *__restrict__ stored,
+                                                    uint32_t n_nodes) {
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const uint32_t y = blockIdx.x % gy, grp = (blockIdx.x / gy) * 4 + wave, idx0 = grp * FS_FN;
     if (idx0 >= n_level) return;
     const uint32_t w = y * 64 + lane;
     if (w >= W) return;
     const uint32_t dd = desc[(uint64_t)y * n_groups + grp];
-    uint32_t own[FS_FN], ch0[FS_FN], ch1[FS_FN], ch2[FS_FN], pp[FS_FN], ncs[FS_FN];
+    const uint32_t c_first = ifirst[idx0];
+    uint32_t pp[FS_FN], ncs[FS_FN];
 #pragma unroll
     for (int u = 0; u < FS_FN; u++) {   // (past the end of a level lie the next level's entries, and eight spare ones at the very end)
         pp[u] = nodes[idx0 + u];
         ncs[u] = inch[idx0 + u];
-        own[u] = ifirst[idx0 + u];   // (the first child, until the rows are asked for)
     }
-    // (all 3 x FS_FN scalar loads -- three s_load_dwordx8 -- are on their way before the first is waited for: without the empty asm
-    // the compiler sinks most of them into the blocks that use them, one round trip per item)
+    uint32_t n_rows = 0, widest = 0;
 #pragma unroll
     for (int u = 0; u < FS_FN; u++) {
-        asm volatile("" : "+s"(pp[u]), "+s"(ncs[u]), "+s"(own[u]));
         if (idx0 + u >= n_level) ncs[u] = 0;
+        n_rows += ncs[u];
+        widest = max(widest, ncs[u]);
     }
-    // Row addresses in 32-bit arithmetic: the caller keeps (n_nodes + 1) * W below 2^32 words, and row n_nodes of F is a copy of
-    // the reference word -- "the row does not exist" is a select between two row INDICES, one scalar instruction, instead of one
-    // between two 64-bit pointers (the scalar unit, one per CU, was this kernel's bound: 835 scalar instructions per wave).
-    bool wide = false;
-#pragma unroll
-    for (int u = 0; u < FS_FN; u++) {
-        const uint32_t d = dd >> (4 * u), nc = ncs[u], c0 = own[u];
-        wide = wide || nc > 3;
-        const uint32_t r0 = (d & 1u) ? pp[u] : n_nodes;
-        const uint32_t r1 = (d & 2u) ? c0 : n_nodes;
-        const uint32_t r2 = (nc > 1 && (d & 4u)) ? c0 + 1 : n_nodes;
-        const uint32_t r3 = (nc > 2 && (d & 8u)) ? c0 + 2 : n_nodes;
-        own[u] = F[r0 * W + w]; ch0[u] = F[r1 * W + w]; ch1[u] = F[r2 * W + w]; ch2[u] = F[r3 * W + w];
-    }
-#pragma unroll
-    for (int u = 0; u < FS_FN; u++) {   // what was read in place of a row that does not exist
-        const uint32_t d = dd >> (4 * u), nc = ncs[u];
-        if (!(d & 1u)) own[u] = 0xFFFFFFFFu;
-        if (nc < 2) ch1[u] = 0xFFFFFFFFu;
-        if (nc < 3) ch2[u] = 0xFFFFFFFFu;
-    }
-#pragma unroll
-    for (int u = 0; u < FS_FN; u++) {
-        if (ncs[u] == 0 || ncs[u] > 3) continue;   // (past the end of the level / left to the general path)
-        // count, per (site, base), the children whose set lacks the base: two planes hold 0..3 (an absent child's word is all-ones)
-        uint32_t c = ~ch1[u];
-        uint32_t p0 = ~ch0[u], p1 = p0 & c;
-        p0 ^= c;
-        c = ~ch2[u];
-        p1 |= p0 & c;
-        p0 ^= c;
-        F[pp[u] * W + w] = fs_pick(fs_pick(own[u], p1), p0);
-    }
-    if (!wide) return;
-#pragma nounroll
-    for (uint32_t u = 0; u < FS_FN; u++) {
-        if (idx0 + u >= n_level) break;
-        const uint32_t nc = inch[idx0 + u];
-        if (nc <= 3) continue;
-        const uint32_t p = nodes[idx0 + u], c0 = ifirst[idx0 + u];
-        const int K = 32 - __builtin_clz(nc);   // planes needed to count to nc
-        uint32_t plane[FS_PLANES];
-#pragma unroll
-        for (int k = 0; k < FS_PLANES; k++) plane[k] = 0;
-        const uint32_t *row = F + (uint64_t)c0 * W + w, *rref = refw + w;
-        const uint64_t b0 = (uint64_t)y * npad + c0;
-        uint32_t nxt = *(fs_bit(stored, b0) ? row : rref);
-        for (uint32_t c = 0; c < nc; c++) {
-            const uint32_t x = nxt;
-            if (c + 1 < nc) nxt = *(fs_bit(stored, b0 + c + 1) ? row + (uint64_t)(c + 1) * W : rref);
-            uint32_t carry = ~x;   // +1 for every (site, base) with base not in F_c
-#pragma unroll
-            for (int k = 0; k < FS_PLANES; k++) {
-                if (k >= K) break;
-                const uint32_t t = plane[k] & carry;
-                plane[k] ^= carry;
-                carry = t;
-            }
-        }
-        uint32_t cand = ((dd >> (4 * u)) & 1u) ? F[(uint64_t)p * W + w] : 0xFFFFFFFFu;   // allowed bases (all four, or the node's own genotype mask)
-#pragma unroll
-        for (int k = FS_PLANES - 1; k >= 0; k--) {
-            if (k >= K) continue;
-            cand = fs_pick(cand, plane[k]);
-        }
-        F[(uint64_t)p * W + w] = cand;
-    }
+    const uint64_t bbase = (uint64_t)y * npad + c_first;
+    if (widest <= 7) fs_forward_group<3>(F, w, W, n_nodes, pp, ncs, dd, c_first, n_rows, stored, bbase);
+    else if (widest <= 31) fs_forward_group<5>(F, w, W, n_nodes, pp, ncs, dd, c_first, n_rows, stored, bbase);
+    else fs_forward_group<32>(F, w, W, n_nodes, pp, ncs, dd, c_first, n_rows, stored, bbase);
 }
 
 // Listed changes go to FS_SEG independent segments of the output buffer (cursor + base per segment):
@@ -643,7 +644,7 @@ extern "C" int ugp_fitch_sankoff(int device, uint64_t n_nodes, const uint32_t *p
         const uint32_t gy = (W + 63) / 64;
         unsigned long long seg_cap = 0;
         const uint64_t npad = ((uint64_t)N + 63) & ~63ull;
-        const size_t bm_words = (size_t)(npad / 32 * gy) + 2;   // (tile-major, whole 64-bit words per tile: k_fs_init takes one per wave)
+        const size_t bm_words = (size_t)(npad / 32 * gy) + 4;   // (tile-major, whole 64-bit words per tile: k_fs_init takes one per wave)
         FS_TRY(P.d_mark8.alloc((size_t)npad * gy));
         FS_TRY(P.d_stored.alloc(bm_words));
         FS_TRY(P.d_desc.alloc((size_t)n_groups * gy));
@@ -704,7 +705,7 @@ extern "C" int ugp_fitch_sankoff(int device, uint64_t n_nodes, const uint32_t *p
             const uint32_t cnt = ilvl_off[L + 1] - ilvl_off[L];
             if (cnt)
                 hipLaunchKernelGGL(k_fs_forward, grid(cnt, FS_FN), dim3(256), 0, stream, d_F.p, d_inodes.p + ilvl_off[L], P.d_ifirst.p + ilvl_off[L],
-                                   P.d_inch.p + ilvl_off[L], P.d_desc.p + goff[L], n_groups, cnt, W, gy, npad, d_refw.p, P.d_stored.p, N);
+                                   P.d_inch.p + ilvl_off[L], P.d_desc.p + goff[L], n_groups, cnt, W, gy, npad, P.d_stored.p, N);
         }
         for (uint32_t L = 0; L < n_levels; L++) {
             const uint32_t cnt = lvl_off[L + 1] - lvl_off[L];
