@@ -14,20 +14,25 @@
 // smaller score in the j = 0..3 scan).
 //
 // Layout.  F[node][W] u32, eight sites per word (one nibble each), nodes in breadth-first
-// order so the children of a node are W-word rows that lie back to back.  One wave owns
-// one node x 64 words (512 sites); lanes read consecutive words, so every child row is one
-// 256 B coalesced load.  Child counts are kept bit-sliced (plane k = bit k of all 32
-// (site, base) counters of the lane), so a node with c children costs ~3*log2(c) VALU ops
-// per child and the argmin is a bit-sliced tournament.  Levels are processed bottom-up then
-// top-down, one launch per level; states overwrite F in place and a final pass lists the
-// (site, node) pairs whose state differs from the parent's.
+// order so the children of a node -- and of the next internal node, and the next -- are W-word
+// rows that lie back to back.  The unit of work is a (node, tile) item, a tile = 64 words = 512
+// sites: lanes read consecutive words, so a row of a tile is one 256 B coalesced load.  Child
+// counts are kept bit-sliced (plane k = bit k of all 32 (site, base) counters of the lane), so
+// a child costs ~3*log2(c) VALU ops at a node with c children and the argmin is a bit-sliced
+// tournament.  Levels are processed bottom-up then top-down, one launch per level; states
+// overwrite F in place and the top-down sweep lists the (site, node) pairs whose state differs
+// from the parent's.
 //
 // Rows that are never stored (round 6).  A leaf without a genotype cell among the 512 sites of a tile is {REF} there, and an
-// internal node without one allows all four bases: neither needs a row in HBM.  Two bitmaps over the (node, tile) items, bit
-// index node * gy + tile -- `mark` (the item holds a cell of the VCF) and `stored` (mark, or the node is internal: the forward
-// pass writes its row) -- tell every kernel which rows exist; the others are the reference word / all-ones in registers.  On the
-// 10 M-node bench tree 70 % of the leaf items have no cell: the initialisation writes 1.7 GB instead of 10.2, and the two passes
-// read the leaves' rows that exist.
+// internal node without one allows all four bases: neither needs a row of its own.  A byte map `mark8` (the item holds a cell of
+// the VCF; plain stores) and a bitmap `stored` (marked, or the node is internal: the forward sweep writes its row), both
+// tile-major, tell every kernel which rows exist; the others are read from row N of the table -- a copy of the reference word --
+// or are all-ones in registers.  On the 10 M-node bench tree 55 % of the leaf items have no cell: the initialisation writes
+// 2.8 GB instead of 10.2, the two sweeps read 7 of 10.2 GB of child rows.  HBM traffic of a call by the counters: 48 -> 29 GB.
+//
+// Where the time of a call goes at 10 M nodes x 2 048 sites x 13.7 M cells (round 6, profiles/r06_fitch_*): 10.9 ms = the
+// caller's parent array and cells over PCIe 2.3 (pageable memory: the boundary), mark / initialise / scatter the cells 1.7,
+// forward sweep 2.9 (3.9 TB/s on the wide levels), backward sweep 3.2 (4.8 TB/s), sorted result back to the host 0.7.
 #include <hip/hip_runtime.h>
 #include <cstring>
 #include <rocprim/device/device_radix_sort.hpp>
@@ -118,13 +123,11 @@ __global__ __launch_bounds__(256) void k_fs_init(uint32_t *__restrict__ F, const
     }
 }
 
-// what the forward sweep needs to know about its items before it can ask for rows, in one dword per wave -- (tile, group of FS_FN
-// internal nodes of a level; `goff` = the first group of every level): four bits per node, bit 0 the node's own row exists (it
-// holds a cell), bits 1 / 2 / 3 the rows of its first / second / third child exist
+// which of the forward sweep's nodes hold a cell of their own (their row exists and restricts the bases they may take): one dword
+// per wave -- (tile, group of FS_FN internal nodes of a level; `goff` = the first group of every level), bit 4 * u for node u
 constexpr int FS_FN = 8;
-__global__ void k_fs_desc(const uint32_t *__restrict__ inodes, const uint32_t *__restrict__ ifirst, const uint32_t *__restrict__ inch,
-                          const uint32_t *__restrict__ ilvl_off, const uint32_t *__restrict__ goff, uint32_t n_levels, uint32_t n_groups, uint32_t gy,
-                          uint64_t npad, const uint8_t *__restrict__ mark8, const uint32_t *__restrict__ stored, uint32_t *__restrict__ desc) {
+__global__ void k_fs_desc(const uint32_t *__restrict__ inodes, const uint32_t *__restrict__ ilvl_off, const uint32_t *__restrict__ goff, uint32_t n_levels,
+                          uint32_t n_groups, uint32_t gy, uint64_t npad, const uint8_t *__restrict__ mark8, uint32_t *__restrict__ desc) {
     static_assert(FS_FN == 8, "eight lanes fill one descriptor");
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;   // lane = (tile, group, node of the group)
     const uint64_t ig = i >> 3;
@@ -138,15 +141,7 @@ __global__ void k_fs_desc(const uint32_t *__restrict__ inodes, const uint32_t *_
             if (goff[mid] <= g) lo = mid; else hi = mid;
         }
         const uint32_t k = ilvl_off[lo] + (g - goff[lo]) * FS_FN + u;
-        if (k < ilvl_off[lo + 1]) {
-            const uint64_t base = (uint64_t)y * npad;
-            const uint32_t c0 = ifirst[k], nc = inch[k];
-            x = mark8[base + inodes[k]] ? 1u : 0u;
-            if (fs_bit(stored, base + c0)) x |= 2u;
-            if (nc > 1 && fs_bit(stored, base + c0 + 1)) x |= 4u;
-            if (nc > 2 && fs_bit(stored, base + c0 + 2)) x |= 8u;
-            x <<= 4 * u;
-        }
+        if (k < ilvl_off[lo + 1] && mark8[(uint64_t)y * npad + inodes[k]]) x = 1u << (4 * u);
     }
     x |= __shfl_xor(x, 1); x |= __shfl_xor(x, 2); x |= __shfl_xor(x, 4);
     if (u == 0 && ig < (uint64_t)n_groups * gy) desc[ig] = x;
@@ -662,8 +657,8 @@ extern "C" int ugp_fitch_sankoff(int device, uint64_t n_nodes, const uint32_t *p
                                    P.d_mark8.p);
             hipLaunchKernelGGL(k_fs_init, grid(N, 64), dim3(256), 0, stream, d_F.p, d_refw.p, d_nchild.p, N, W, gy, npad, P.d_mark8.p, P.d_stored.p);
             if (n_groups)
-                hipLaunchKernelGGL(k_fs_desc, dim3((unsigned)(((uint64_t)n_groups * gy * FS_FN + 255) / 256)), dim3(256), 0, stream, d_inodes.p, P.d_ifirst.p,
-                                   P.d_inch.p, d_ilvl, d_goff, n_levels, n_groups, gy, npad, P.d_mark8.p, P.d_stored.p, P.d_desc.p);
+                hipLaunchKernelGGL(k_fs_desc, dim3((unsigned)(((uint64_t)n_groups * gy * FS_FN + 255) / 256)), dim3(256), 0, stream, d_inodes.p, d_ilvl,
+                                   d_goff, n_levels, n_groups, gy, npad, P.d_mark8.p, P.d_desc.p);
             FS_TRY(hipMemsetAsync(d_cnt.p, 0, ((size_t)FS_SEG * 8 + 8) * sizeof(unsigned long long), stream));
             FS_TRY(hipMemsetAsync(P.d_small.p + 2, 0, 4, stream));
             // room for the listed changes: without cells on internal nodes a site has at most (cells + 1) of
