@@ -132,7 +132,8 @@ def test_gpu_fitch_sankoff_equals_oracle(kind, n, n_sites, seed, monkeypatch):
 @pytest.mark.gpu
 @pytest.mark.parametrize("kind,n,n_sites,p_var,p_internal,seed", [("random", 3000, 1100, 0.001, 0.0, 21), ("bushy", 4000, 1600, 0.0006, 0.002, 22),
                                                                   ("star", 2000, 600, 0.002, 0.0, 23), ("chain", 300, 1030, 0.002, 0.01, 24),
-                                                                  ("random", 2500, 520, 0.0, 0.0, 25)])
+                                                                  ("random", 2500, 520, 0.0, 0.0, 25), ("random", 6, 33000, 0.02, 0.3, 26),
+                                                                  ("bushy", 900, 1500, 0.003, 0.0, 27)])
 def test_gpu_fitch_rows_that_are_never_stored(kind, n, n_sites, p_var, p_internal, seed, monkeypatch):
     """Few cells per 512-site tile: most (leaf, tile) items have none and get no row on the device (ugp_fitch.hip, round 6) -- with and
     without cells on internal nodes, tiles that end inside a word row, a tree without any cell; one pass, passes of 520 sites, and the
