@@ -193,10 +193,19 @@ __device__ __forceinline__ uint32_t fs_pick(uint32_t cand, uint32_t plane) {   /
     return (z & m) | (cand & ~m);
 }
 
+// Polytomies.  A node with more than FS_WIDE children is not part of any stream -- one wave counting 10 000 rows eight at a time
+// was the whole duration of the upper levels of a SARS-CoV-2-shaped tree (the seven topmost launches 2.5 of the sweep's 6.2 ms) --
+// its children are cut into chunks of FS_WIDE rows, k_fs_wide_count counts each chunk in a wave of its own (8 planes to a scratch
+// buffer), k_fs_wide_final adds the chunks' counters bit-sliced and finishes the node.  The list of such nodes is made by
+// k_fs_topo, the chunk tables by the host (they are few).
+constexpr uint32_t FS_WIDE = 255;
+
+// one run of rows [row0, row0 + n_rows) = the children of the nodes at the head of the queue (pp / ncs / dd: node, child count,
+// own-row bit; a node is popped when its last child has been counted)
 template <int KP>
-__device__ __forceinline__ void fs_forward_group(uint32_t *__restrict__ F, uint32_t w, uint32_t W, uint32_t ref_row, uint32_t (&pp)[FS_FN],
-                                                 uint32_t (&ncs)[FS_FN], uint32_t dd, uint32_t c_first, uint32_t n_rows,
-                                                 const uint32_t *__restrict__ stored, uint64_t bbase) {
+__device__ __forceinline__ void fs_stream(uint32_t *__restrict__ F, uint32_t w, uint32_t W, uint32_t ref_row, uint32_t (&pp)[FS_FN],
+                                          uint32_t (&ncs)[FS_FN], uint32_t &dd, uint32_t row0, uint32_t n_rows,
+                                          const uint32_t *__restrict__ stored, uint64_t bbase) {
     uint32_t plane[KP];
 #pragma unroll
     for (int k = 0; k < KP; k++) plane[k] = 0;
@@ -205,7 +214,7 @@ __device__ __forceinline__ void fs_forward_group(uint32_t *__restrict__ F, uint3
     uint32_t have = fs_bits32(stored, bbase), have_next = fs_bits32(stored, bbase + 8);
 #pragma unroll
     for (int j = 0; j < 8; j++) {
-        const uint32_t r = ((uint32_t)j < n_rows && ((have >> j) & 1u)) ? c_first + j : ref_row;
+        const uint32_t r = ((uint32_t)j < n_rows && ((have >> j) & 1u)) ? row0 + j : ref_row;
         xa[j] = F[r * W + w];
     }
 #pragma nounroll
@@ -214,7 +223,7 @@ __device__ __forceinline__ void fs_forward_group(uint32_t *__restrict__ F, uint3
         if (i + 8 < n_rows) {
 #pragma unroll
             for (int j = 0; j < 8; j++) {
-                const uint32_t r = (i + 8 + j < n_rows && ((have_next >> j) & 1u)) ? c_first + i + 8 + j : ref_row;
+                const uint32_t r = (i + 8 + j < n_rows && ((have_next >> j) & 1u)) ? row0 + i + 8 + j : ref_row;
                 xb[j] = F[r * W + w];
             }
         }
@@ -222,10 +231,8 @@ __device__ __forceinline__ void fs_forward_group(uint32_t *__restrict__ F, uint3
         for (int j = 0; j < 8; j++) {
             if (i + j >= n_rows) break;
             uint32_t carry = ~xa[j];   // +1 for every (site, base) with base not in F_c
-            const int K = KP == 32 ? 32 - __builtin_clz(ncs[0]) : KP;
 #pragma unroll
             for (int k = 0; k < KP; k++) {
-                if (KP == 32 && k >= K) break;
                 const uint32_t t = plane[k] & carry;
                 plane[k] ^= carry;
                 carry = t;
@@ -235,7 +242,6 @@ __device__ __forceinline__ void fs_forward_group(uint32_t *__restrict__ F, uint3
                 if (dd & 1u) cand = F[pp[0] * W + w];
 #pragma unroll
                 for (int k = KP - 1; k >= 0; k--) {
-                    if (KP == 32 && k >= K) continue;
                     cand = fs_pick(cand, plane[k]);
                     plane[k] = 0;
                 }
@@ -262,25 +268,135 @@ __global__ __launch_bounds__(256) void k_fs_forward(uint32_t *__restrict__ F, co
     if (idx0 >= n_level) return;
     const uint32_t w = y * 64 + lane;
     if (w >= W) return;
-    const uint32_t dd = desc[(uint64_t)y * n_groups + grp];
-    const uint32_t c_first = ifirst[idx0];
+    uint32_t dd = desc[(uint64_t)y * n_groups + grp];
+    uint32_t row0 = ifirst[idx0];
     uint32_t pp[FS_FN], ncs[FS_FN];
 #pragma unroll
     for (int u = 0; u < FS_FN; u++) {   // (past the end of a level lie the next level's entries, and eight spare ones at the very end)
         pp[u] = nodes[idx0 + u];
         ncs[u] = inch[idx0 + u];
     }
-    uint32_t n_rows = 0, widest = 0;
 #pragma unroll
-    for (int u = 0; u < FS_FN; u++) {
+    for (int u = 0; u < FS_FN; u++)
         if (idx0 + u >= n_level) ncs[u] = 0;
-        n_rows += ncs[u];
-        widest = max(widest, ncs[u]);
+    // the group's children are one run of rows; a polytomy cuts it (its rows belong to k_fs_wide_*): usually one turn of this loop
+#pragma nounroll
+    while (ncs[0] != 0) {
+        if (ncs[0] > FS_WIDE) {
+            row0 += ncs[0];
+#pragma unroll
+            for (int q = 0; q + 1 < FS_FN; q++) { pp[q] = pp[q + 1]; ncs[q] = ncs[q + 1]; }
+            ncs[FS_FN - 1] = 0;
+            dd >>= 4;
+            continue;
+        }
+        uint32_t n_rows = 0, widest = 0;
+        bool open = true;
+#pragma unroll
+        for (int u = 0; u < FS_FN; u++) {
+            open = open && ncs[u] != 0 && ncs[u] <= FS_WIDE;
+            if (open) { n_rows += ncs[u]; widest = max(widest, ncs[u]); }
+        }
+        const uint64_t bbase = (uint64_t)y * npad + row0;
+        if (widest <= 7) fs_stream<3>(F, w, W, n_nodes, pp, ncs, dd, row0, n_rows, stored, bbase);
+        else if (widest <= 31) fs_stream<5>(F, w, W, n_nodes, pp, ncs, dd, row0, n_rows, stored, bbase);
+        else fs_stream<8>(F, w, W, n_nodes, pp, ncs, dd, row0, n_rows, stored, bbase);
+        row0 += n_rows;
     }
-    const uint64_t bbase = (uint64_t)y * npad + c_first;
-    if (widest <= 7) fs_forward_group<3>(F, w, W, n_nodes, pp, ncs, dd, c_first, n_rows, stored, bbase);
-    else if (widest <= 31) fs_forward_group<5>(F, w, W, n_nodes, pp, ncs, dd, c_first, n_rows, stored, bbase);
-    else fs_forward_group<32>(F, w, W, n_nodes, pp, ncs, dd, c_first, n_rows, stored, bbase);
+}
+
+// one chunk of a polytomy's children (at most FS_WIDE rows) for one tile: counts in 8 planes -> part[(chunk, tile)][plane][lane]
+__global__ __launch_bounds__(256) void k_fs_wide_count(const uint32_t *__restrict__ F, const uint32_t *__restrict__ chunk_first, const uint32_t *__restrict__ chunk_rows,
+                                                       uint32_t n_chunks, uint32_t W, uint32_t gy, uint64_t npad, const uint32_t *__restrict__ stored,
+                                                       uint32_t n_nodes, uint32_t *__restrict__ part) {
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const uint32_t y = blockIdx.x % gy, ch = (blockIdx.x / gy) * 4 + wave;
+    if (ch >= n_chunks) return;
+    const uint32_t w = y * 64 + lane;
+    if (w >= W) return;
+    const uint32_t row0 = chunk_first[ch], n_rows = chunk_rows[ch];
+    const uint64_t bbase = (uint64_t)y * npad + row0;
+    uint32_t plane[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) plane[k] = 0;
+    uint32_t xa[8], xb[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    uint32_t have = fs_bits32(stored, bbase), have_next = fs_bits32(stored, bbase + 8);
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        const uint32_t r = ((uint32_t)j < n_rows && ((have >> j) & 1u)) ? row0 + j : n_nodes;
+        xa[j] = F[r * W + w];
+    }
+#pragma nounroll
+    for (uint32_t i = 0; i < n_rows; i += 8) {
+        const uint32_t have_after = fs_bits32(stored, bbase + i + 16);
+        if (i + 8 < n_rows) {
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const uint32_t r = (i + 8 + j < n_rows && ((have_next >> j) & 1u)) ? row0 + i + 8 + j : n_nodes;
+                xb[j] = F[r * W + w];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            uint32_t carry = i + j < n_rows ? ~xa[j] : 0u;
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const uint32_t t = plane[k] & carry;
+                plane[k] ^= carry;
+                carry = t;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 8; j++) xa[j] = xb[j];
+        have_next = have_after;
+    }
+    uint32_t *out = part + ((uint64_t)ch * gy + y) * 8 * 64 + lane;
+#pragma unroll
+    for (int k = 0; k < 8; k++) out[k * 64] = plane[k];
+}
+
+// a polytomy for one tile: the sum of its chunks' counters (bit-sliced addition, 8 planes into 32), then the argmin as everywhere
+__global__ __launch_bounds__(256) void k_fs_wide_final(uint32_t *__restrict__ F, const uint32_t *__restrict__ wide_node, const uint32_t *__restrict__ wide_nc,
+                                                       const uint32_t *__restrict__ wide_chunk0, uint32_t n_wide, uint32_t W, uint32_t gy, uint64_t npad,
+                                                       const uint8_t *__restrict__ mark8, const uint32_t *__restrict__ part) {
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const uint32_t y = blockIdx.x % gy, i = (blockIdx.x / gy) * 4 + wave;
+    if (i >= n_wide) return;
+    const uint32_t w = y * 64 + lane;
+    if (w >= W) return;
+    const uint32_t p = wide_node[i], nc = wide_nc[i], c0 = wide_chunk0[i], n_ch = (nc + FS_WIDE - 1) / FS_WIDE;
+    const int K = 32 - __builtin_clz(nc);
+    uint32_t acc[32];
+#pragma unroll
+    for (int k = 0; k < 32; k++) acc[k] = 0;
+    for (uint32_t c = 0; c < n_ch; c++) {
+        const uint32_t *in = part + ((uint64_t)(c0 + c) * gy + y) * 8 * 64 + lane;
+        uint32_t x[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) x[k] = in[k * 64];
+        uint32_t carry = 0;
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const uint32_t h = acc[k] ^ x[k];
+            const uint32_t cy = (acc[k] & x[k]) | (carry & h);
+            acc[k] = h ^ carry;
+            carry = cy;
+        }
+#pragma unroll
+        for (int k = 8; k < 32; k++) {
+            if (k >= K) break;
+            const uint32_t t = acc[k] & carry;
+            acc[k] ^= carry;
+            carry = t;
+        }
+    }
+    uint32_t cand = mark8[(uint64_t)y * npad + p] ? F[(uint64_t)p * W + w] : 0xFFFFFFFFu;
+#pragma unroll
+    for (int k = 31; k >= 0; k--) {
+        if (k >= K) continue;
+        cand = fs_pick(cand, acc[k]);
+    }
+    F[(uint64_t)p * W + w] = cand;
 }
 
 // Listed changes go to FS_SEG independent segments of the output buffer (cursor + base per segment):
@@ -429,12 +545,16 @@ __global__ void k_fs_heads(const uint32_t *__restrict__ parent, uint32_t n, uint
 }
 __global__ void k_fs_topo(const uint32_t *__restrict__ parent, uint32_t n, const uint32_t *__restrict__ heads, const uint32_t *__restrict__ n_heads_p,
                           uint32_t *__restrict__ first_child, uint32_t *__restrict__ n_children, uint32_t *__restrict__ inodes,
-                          uint32_t *__restrict__ ifirst, uint32_t *__restrict__ inch) {
+                          uint32_t *__restrict__ ifirst, uint32_t *__restrict__ inch, uint32_t *__restrict__ n_wide_p, uint32_t *__restrict__ wide, uint32_t wide_cap) {
     const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x, nh = *n_heads_p;
     if (k >= nh) return;
     const uint32_t j = heads[k], e = k + 1 < nh ? heads[k + 1] : n, p = parent[j];
     first_child[p] = j; n_children[p] = e - j; inodes[k] = p;
     ifirst[k] = j; inch[k] = e - j;   // (the same by the node's rank among the internal nodes: what the forward sweep indexes)
+    if (e - j > FS_WIDE) {   // a polytomy: listed for k_fs_wide_* (any order; the host sorts the few there are)
+        const uint32_t at = atomicAdd(n_wide_p, 1u);
+        if (at < wide_cap) { wide[3 * (uint64_t)at] = p; wide[3 * (uint64_t)at + 1] = j; wide[3 * (uint64_t)at + 2] = e - j; }
+    }
 }
 // ilvl_off[L] = internal nodes in front of level L = run heads among the nodes in front of level L + 1 (their children)
 __global__ void k_fs_level_ranks(const uint32_t *__restrict__ heads, const uint32_t *__restrict__ n_heads_p, const uint32_t *__restrict__ lvl_off, uint32_t n_levels,
@@ -451,7 +571,7 @@ __global__ void k_fs_level_ranks(const uint32_t *__restrict__ heads, const uint3
 
 struct FsPool {   // one per device, kept until the process ends: a call allocates nothing in the steady state
     std::mutex mu;
-    Dev<uint32_t> d_parent, d_first, d_nchild, d_inodes, d_heads, d_small, d_levels, d_F, d_refw, d_vnode, d_stored, d_osite, d_onode, d_ifirst, d_inch, d_desc;
+    Dev<uint32_t> d_parent, d_first, d_nchild, d_inodes, d_heads, d_small, d_levels, d_F, d_refw, d_vnode, d_stored, d_osite, d_onode, d_ifirst, d_inch, d_desc, d_wide, d_wtab, d_part;
     Dev<uint8_t> d_flag, d_vnuc, d_oval, d_oval2, d_tmp, d_sel_tmp, d_opar, d_onuc, d_mark8;
     Dev<uint64_t> d_okey, d_okey2, d_voff;
     Dev<unsigned long long> d_cnt, d_segb;
@@ -476,7 +596,7 @@ extern "C" void ugp_fitch_release(int device) {
     if (hipSetDevice(device) != hipSuccess) return;
     (void)hipDeviceSynchronize();
     for (Dev<uint32_t> *d : {&p->d_parent, &p->d_first, &p->d_nchild, &p->d_inodes, &p->d_heads, &p->d_small, &p->d_levels, &p->d_F, &p->d_refw, &p->d_vnode,
-                            &p->d_stored, &p->d_osite, &p->d_onode, &p->d_ifirst, &p->d_inch, &p->d_desc}) d->release();
+                            &p->d_stored, &p->d_osite, &p->d_onode, &p->d_ifirst, &p->d_inch, &p->d_desc, &p->d_wide, &p->d_wtab, &p->d_part}) d->release();
     for (Dev<uint8_t> *d : {&p->d_flag, &p->d_vnuc, &p->d_oval, &p->d_oval2, &p->d_tmp, &p->d_sel_tmp, &p->d_opar, &p->d_onuc, &p->d_mark8}) d->release();
     for (Dev<uint64_t> *d : {&p->d_okey, &p->d_okey2, &p->d_voff}) d->release();
     for (Dev<unsigned long long> *d : {&p->d_cnt, &p->d_segb}) d->release();
@@ -534,7 +654,9 @@ extern "C" int ugp_fitch_sankoff(int device, uint64_t n_nodes, const uint32_t *p
     FS_TRY(d_parent.upload(parent, N, stream));
     FS_TRY(d_first.alloc(N)); FS_TRY(d_nchild.alloc(N)); FS_TRY(d_inodes.alloc((size_t)N + 8)); FS_TRY(P.d_heads.alloc(N)); FS_TRY(P.d_flag.alloc(N));
     FS_TRY(P.d_ifirst.alloc((size_t)N + 8)); FS_TRY(P.d_inch.alloc((size_t)N + 8));   // (+8: the forward sweep reads whole groups)
-    FS_TRY(P.d_small.alloc(16));   // [0] order violated, [1] run heads, [2] cell flags
+    FS_TRY(P.d_small.alloc(16));   // [0] order violated, [1] run heads, [2] cell flags, [3] polytomies
+    const uint32_t wide_cap = N / (FS_WIDE + 1) + 1;   // (more nodes with more than FS_WIDE children each do not fit in N)
+    FS_TRY(P.d_wide.alloc(3 * (size_t)wide_cap));
     FS_TRY(hipMemsetAsync(P.d_small.p, 0, 8 * sizeof(uint32_t), stream));
     FS_TRY(hipMemsetAsync(d_first.p, 0, (size_t)N * 4, stream));
     FS_TRY(hipMemsetAsync(d_nchild.p, 0, (size_t)N * 4, stream));
@@ -547,7 +669,7 @@ extern "C" int ugp_fitch_sankoff(int device, uint64_t n_nodes, const uint32_t *p
         FS_TRY(rocprim::select(P.d_sel_tmp.p, sel_bytes, idx, P.d_flag.p, P.d_heads.p, P.d_small.p + 1, (size_t)N, stream));
     }
     hipLaunchKernelGGL(k_fs_topo, dim3((N + 255) / 256), dim3(256), 0, stream, d_parent.p, N, P.d_heads.p, P.d_small.p + 1, d_first.p, d_nchild.p, d_inodes.p,
-                       P.d_ifirst.p, P.d_inch.p);
+                       P.d_ifirst.p, P.d_inch.p, P.d_small.p + 3, P.d_wide.p, wide_cap);
     std::vector<uint32_t> lvl_off{0, 1};   // nodes of level L are [lvl_off[L], lvl_off[L+1])
     while (lvl_off.back() < N) {
         // first j whose parent is not in front of the end of the last level: std::lower_bound over parent[1..N)
@@ -566,6 +688,7 @@ extern "C" int ugp_fitch_sankoff(int device, uint64_t n_nodes, const uint32_t *p
     }
     const uint32_t n_levels = (uint32_t)lvl_off.size() - 1;
     std::vector<uint32_t> ilvl_off(n_levels + 1, 0);
+    uint32_t n_wide = 0;
     {
         // (the level tables have a buffer of their own, sized by the tree -- a caterpillar has as many levels as nodes)
         FS_TRY(P.d_levels.alloc(3 * (size_t)(n_levels + 1)));   // (level begins, internal-node ranks, and -- below -- the forward sweep's groups)
@@ -575,8 +698,40 @@ extern "C" int ugp_fitch_sankoff(int device, uint64_t n_nodes, const uint32_t *p
         uint32_t bad = 0;
         FS_TRY(hipMemcpyAsync(ilvl_off.data(), d_ilvl, (n_levels + 1) * 4, hipMemcpyDeviceToHost, stream));
         FS_TRY(hipMemcpyAsync(&bad, P.d_small.p, 4, hipMemcpyDeviceToHost, stream));
+        FS_TRY(hipMemcpyAsync(&n_wide, P.d_small.p + 3, 4, hipMemcpyDeviceToHost, stream));
         FS_TRY(hipStreamSynchronize(stream));
         if (bad) return ugp::set_error(UGP_ERR_INVALID, "tree arrays are not in breadth-first order");
+    }
+    // Polytomies (more than FS_WIDE children): sorted by node = by level, their children cut into chunks of FS_WIDE rows.  One table
+    // on the device: [chunk first rows | chunk row counts | nodes | child counts | first chunk (within the level)].
+    std::vector<uint32_t> wl_off(n_levels + 1, 0), cl_off(n_levels + 1, 0);   // polytomies / chunks in front of level L
+    uint32_t n_chunks = 0, max_level_chunks = 0;
+    const uint32_t *d_chunk_first = nullptr, *d_chunk_rows = nullptr, *d_wide_node = nullptr, *d_wide_nc = nullptr, *d_wide_chunk0 = nullptr;
+    if (n_wide) {
+        if (n_wide > wide_cap) return ugp::set_error(UGP_ERR_INVALID, "tree arrays are not in breadth-first order");
+        std::vector<uint32_t> raw(3 * (size_t)n_wide);
+        FS_TRY(hipMemcpyAsync(raw.data(), P.d_wide.p, raw.size() * 4, hipMemcpyDeviceToHost, stream));
+        FS_TRY(hipStreamSynchronize(stream));
+        std::vector<uint32_t> ord(n_wide);
+        for (uint32_t i = 0; i < n_wide; i++) ord[i] = i;
+        std::sort(ord.begin(), ord.end(), [&](uint32_t a, uint32_t b) { return raw[3 * (size_t)a] < raw[3 * (size_t)b]; });
+        for (uint32_t i = 0; i < n_wide; i++) n_chunks += (raw[3 * (size_t)i + 2] + FS_WIDE - 1) / FS_WIDE;
+        std::vector<uint32_t> tab(2 * (size_t)n_chunks + 3 * (size_t)n_wide);
+        uint32_t *c_first = tab.data(), *c_rows = c_first + n_chunks, *w_node = c_rows + n_chunks, *w_nc = w_node + n_wide, *w_c0 = w_nc + n_wide;
+        uint32_t ci = 0, L = 0;
+        for (uint32_t i = 0; i < n_wide; i++) {
+            const uint32_t nd = raw[3 * (size_t)ord[i]], first = raw[3 * (size_t)ord[i] + 1], nc = raw[3 * (size_t)ord[i] + 2];
+            while (nd >= lvl_off[L + 1]) { L++; wl_off[L] = i; cl_off[L] = ci; }
+            w_node[i] = nd; w_nc[i] = nc; w_c0[i] = ci - cl_off[L];
+            for (uint32_t at = 0; at < nc; at += FS_WIDE) { c_first[ci] = first + at; c_rows[ci] = std::min(FS_WIDE, nc - at); ci++; }
+        }
+        while (L < n_levels) { L++; wl_off[L] = n_wide; cl_off[L] = ci; }
+        for (uint32_t l = 0; l < n_levels; l++) max_level_chunks = std::max(max_level_chunks, cl_off[l + 1] - cl_off[l]);
+        FS_TRY(P.d_wtab.alloc(tab.size()));
+        FS_TRY(hipMemcpyAsync(P.d_wtab.p, tab.data(), tab.size() * 4, hipMemcpyHostToDevice, stream));
+        FS_TRY(hipStreamSynchronize(stream));   // (`tab` goes out of scope)
+        d_chunk_first = P.d_wtab.p; d_chunk_rows = d_chunk_first + n_chunks; d_wide_node = d_chunk_rows + n_chunks;
+        d_wide_nc = d_wide_node + n_wide; d_wide_chunk0 = d_wide_nc + n_wide;
     }
     if (S == 0) { guard.r = nullptr; *out = res; return UGP_OK; }
     // the forward sweep's waves take FS_FN internal nodes of a level each: goff[L] = the first such group of level L
@@ -643,6 +798,7 @@ extern "C" int ugp_fitch_sankoff(int device, uint64_t n_nodes, const uint32_t *p
         FS_TRY(P.d_mark8.alloc((size_t)npad * gy));
         FS_TRY(P.d_stored.alloc(bm_words));
         FS_TRY(P.d_desc.alloc((size_t)n_groups * gy));
+        if (max_level_chunks) FS_TRY(P.d_part.alloc((size_t)max_level_chunks * gy * 8 * 64));
         auto grid = [&](uint64_t nodes, int per_wave) { return dim3((unsigned)((nodes + 4ull * per_wave - 1) / (4ull * per_wave) * gy)); };
         for (int attempt = 0; attempt < 2; attempt++) {
             FS_TRY(hipMemcpyAsync(d_refw.p, refw.data(), (size_t)W * 4, hipMemcpyHostToDevice, stream));
@@ -701,6 +857,13 @@ extern "C" int ugp_fitch_sankoff(int device, uint64_t n_nodes, const uint32_t *p
             if (cnt)
                 hipLaunchKernelGGL(k_fs_forward, grid(cnt, FS_FN), dim3(256), 0, stream, d_F.p, d_inodes.p + ilvl_off[L], P.d_ifirst.p + ilvl_off[L],
                                    P.d_inch.p + ilvl_off[L], P.d_desc.p + goff[L], n_groups, cnt, W, gy, npad, P.d_stored.p, N);
+            if (const uint32_t nw = wl_off[L + 1] - wl_off[L]) {   // the level's polytomies: chunks counted in parallel, then summed
+                const uint32_t nc = cl_off[L + 1] - cl_off[L];
+                hipLaunchKernelGGL(k_fs_wide_count, grid(nc, 1), dim3(256), 0, stream, d_F.p, d_chunk_first + cl_off[L], d_chunk_rows + cl_off[L], nc, W, gy,
+                                   npad, P.d_stored.p, N, P.d_part.p);
+                hipLaunchKernelGGL(k_fs_wide_final, grid(nw, 1), dim3(256), 0, stream, d_F.p, d_wide_node + wl_off[L], d_wide_nc + wl_off[L],
+                                   d_wide_chunk0 + wl_off[L], nw, W, gy, npad, P.d_mark8.p, P.d_part.p);
+            }
         }
         for (uint32_t L = 0; L < n_levels; L++) {
             const uint32_t cnt = lvl_off[L + 1] - lvl_off[L];
