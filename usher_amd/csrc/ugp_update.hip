@@ -3,6 +3,8 @@
 // See ugp_update.hpp.  Integer work, lanes = samples, record data wave-uniform.
 #include "ugp_update.hpp"
 
+#include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <rocprim/device/device_radix_sort.hpp>
 
@@ -99,9 +101,8 @@ hipError_t launch_dense_scatter(uint8_t *dense, uint32_t n_pos, uint32_t qpad, i
 //   eligible  = common > 0 or (internal and no mutations);   has_unique = masked or common != #mutations
 // The entries of a record are read through scalar loads (the record index is wave-uniform); a lane's share is one byte of the
 // dense table per entry -- 64 consecutive bytes per wave.
-constexpr uint32_t T_RECS_PER_BLOCK = 16;
 template <int PASS>
-__global__ void __launch_bounds__(64) k_touched(TouchedArgs a) {
+__global__ void __launch_bounds__(64) k_touched(TouchedArgs a, uint32_t T_RECS_PER_BLOCK) {
     const uint32_t lane = threadIdx.x;
     const uint32_t q = a.q0 + blockIdx.y * 64u + lane;
     const bool in = q < a.q1;
@@ -165,10 +166,14 @@ __global__ void k_touched_reset(const int32_t *__restrict__ best, int32_t *__res
 
 hipError_t launch_touched(const TouchedArgs &a, int32_t *list_best, hipStream_t s) {
     if (a.id1 <= a.id0 || a.q1 <= a.q0) return hipSuccess;
+    // Records per wave.  The driver WAITS for these kernels once per round of insertions, and a wave takes its records one after the
+    // other (five rounds of loads each): 16 per wave were 0.3 ms per round; the few hundred records of a round spread over more waves
+    // cost more atomics on best[] and nothing else.  (UGP_TOUCHED_RECS: 1..64, for measurements.)
+    static const uint32_t T_RECS_PER_BLOCK = [] { const char *e = getenv("UGP_TOUCHED_RECS"); const int v = e ? atoi(e) : 2; return (uint32_t)std::min(64, std::max(1, v)); }();
     const dim3 grid((a.id1 - a.id0 + T_RECS_PER_BLOCK - 1) / T_RECS_PER_BLOCK, (a.q1 - a.q0 + 63) / 64);
-    hipLaunchKernelGGL(k_touched<1>, grid, dim3(64), 0, s, a);
+    hipLaunchKernelGGL(k_touched<1>, grid, dim3(64), 0, s, a, T_RECS_PER_BLOCK);
     hipLaunchKernelGGL(k_touched_reset, dim3((a.q1 - a.q0 + 255) / 256), dim3(256), 0, s, a.best, list_best, a.cnt, a.q0, a.q1);
-    hipLaunchKernelGGL(k_touched<2>, grid, dim3(64), 0, s, a);
+    hipLaunchKernelGGL(k_touched<2>, grid, dim3(64), 0, s, a, T_RECS_PER_BLOCK);
     return hipGetLastError();
 }
 
