@@ -195,10 +195,10 @@ __device__ __forceinline__ uint32_t fs_pick(uint32_t cand, uint32_t plane) {   /
 
 // Polytomies.  A node with more than FS_WIDE children is not part of any stream -- one wave counting 10 000 rows eight at a time
 // was the whole duration of the upper levels of a SARS-CoV-2-shaped tree (the seven topmost launches 2.5 of the sweep's 6.2 ms) --
-// its children are cut into chunks of FS_WIDE rows, k_fs_wide_count counts each chunk in a wave of its own (8 planes to a scratch
+// its children are cut into chunks of FS_CHUNK rows, k_fs_wide_count counts each chunk in a wave of its own (8 planes to a scratch
 // buffer), k_fs_wide_final adds the chunks' counters bit-sliced and finishes the node.  The list of such nodes is made by
 // k_fs_topo, the chunk tables by the host (they are few).
-constexpr uint32_t FS_WIDE = 255;
+constexpr uint32_t FS_WIDE = 255, FS_CHUNK = 64;   // (a chunk: 8 batches of loads, ~12 us of one wave)
 
 // one run of rows [row0, row0 + n_rows) = the children of the nodes at the head of the queue (pp / ncs / dd: node, child count,
 // own-row bit; a node is popped when its last child has been counted)
@@ -305,7 +305,7 @@ __global__ __launch_bounds__(256) void k_fs_forward(uint32_t *__restrict__ F, co
     }
 }
 
-// one chunk of a polytomy's children (at most FS_WIDE rows) for one tile: counts in 8 planes -> part[(chunk, tile)][plane][lane]
+// one chunk of a polytomy's children (at most FS_CHUNK rows) for one tile: counts in 8 planes -> part[(chunk, tile)][plane][lane]
 __global__ __launch_bounds__(256) void k_fs_wide_count(const uint32_t *__restrict__ F, const uint32_t *__restrict__ chunk_first, const uint32_t *__restrict__ chunk_rows,
                                                        uint32_t n_chunks, uint32_t W, uint32_t gy, uint64_t npad, const uint32_t *__restrict__ stored,
                                                        uint32_t n_nodes, uint32_t *__restrict__ part) {
@@ -364,16 +364,12 @@ __global__ __launch_bounds__(256) void k_fs_wide_final(uint32_t *__restrict__ F,
     if (i >= n_wide) return;
     const uint32_t w = y * 64 + lane;
     if (w >= W) return;
-    const uint32_t p = wide_node[i], nc = wide_nc[i], c0 = wide_chunk0[i], n_ch = (nc + FS_WIDE - 1) / FS_WIDE;
+    const uint32_t p = wide_node[i], nc = wide_nc[i], c0 = wide_chunk0[i], n_ch = (nc + FS_CHUNK - 1) / FS_CHUNK;
     const int K = 32 - __builtin_clz(nc);
     uint32_t acc[32];
 #pragma unroll
     for (int k = 0; k < 32; k++) acc[k] = 0;
-    for (uint32_t c = 0; c < n_ch; c++) {
-        const uint32_t *in = part + ((uint64_t)(c0 + c) * gy + y) * 8 * 64 + lane;
-        uint32_t x[8];
-#pragma unroll
-        for (int k = 0; k < 8; k++) x[k] = in[k * 64];
+    auto add = [&](const uint32_t (&x)[8]) {
         uint32_t carry = 0;
 #pragma unroll
         for (int k = 0; k < 8; k++) {
@@ -389,6 +385,16 @@ __global__ __launch_bounds__(256) void k_fs_wide_final(uint32_t *__restrict__ F,
             acc[k] ^= carry;
             carry = t;
         }
+    };
+    for (uint32_t c = 0; c < n_ch; c += 2) {   // two chunks' planes in flight
+        const bool two = c + 1 < n_ch;
+        const uint32_t *in = part + ((uint64_t)(c0 + c) * gy + y) * 8 * 64 + lane;
+        const uint32_t *in2 = part + ((uint64_t)(c0 + c + (two ? 1u : 0u)) * gy + y) * 8 * 64 + lane;
+        uint32_t x[8], z[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) { x[k] = in[k * 64]; z[k] = in2[k * 64]; }
+        add(x);
+        if (two) add(z);
     }
     uint32_t cand = mark8[(uint64_t)y * npad + p] ? F[(uint64_t)p * W + w] : 0xFFFFFFFFu;
 #pragma unroll
@@ -702,7 +708,7 @@ extern "C" int ugp_fitch_sankoff(int device, uint64_t n_nodes, const uint32_t *p
         FS_TRY(hipStreamSynchronize(stream));
         if (bad) return ugp::set_error(UGP_ERR_INVALID, "tree arrays are not in breadth-first order");
     }
-    // Polytomies (more than FS_WIDE children): sorted by node = by level, their children cut into chunks of FS_WIDE rows.  One table
+    // Polytomies (more than FS_WIDE children): sorted by node = by level, their children cut into chunks of FS_CHUNK rows.  One table
     // on the device: [chunk first rows | chunk row counts | nodes | child counts | first chunk (within the level)].
     std::vector<uint32_t> wl_off(n_levels + 1, 0), cl_off(n_levels + 1, 0);   // polytomies / chunks in front of level L
     uint32_t n_chunks = 0, max_level_chunks = 0;
@@ -715,7 +721,7 @@ extern "C" int ugp_fitch_sankoff(int device, uint64_t n_nodes, const uint32_t *p
         std::vector<uint32_t> ord(n_wide);
         for (uint32_t i = 0; i < n_wide; i++) ord[i] = i;
         std::sort(ord.begin(), ord.end(), [&](uint32_t a, uint32_t b) { return raw[3 * (size_t)a] < raw[3 * (size_t)b]; });
-        for (uint32_t i = 0; i < n_wide; i++) n_chunks += (raw[3 * (size_t)i + 2] + FS_WIDE - 1) / FS_WIDE;
+        for (uint32_t i = 0; i < n_wide; i++) n_chunks += (raw[3 * (size_t)i + 2] + FS_CHUNK - 1) / FS_CHUNK;
         std::vector<uint32_t> tab(2 * (size_t)n_chunks + 3 * (size_t)n_wide);
         uint32_t *c_first = tab.data(), *c_rows = c_first + n_chunks, *w_node = c_rows + n_chunks, *w_nc = w_node + n_wide, *w_c0 = w_nc + n_wide;
         uint32_t ci = 0, L = 0;
@@ -723,7 +729,7 @@ extern "C" int ugp_fitch_sankoff(int device, uint64_t n_nodes, const uint32_t *p
             const uint32_t nd = raw[3 * (size_t)ord[i]], first = raw[3 * (size_t)ord[i] + 1], nc = raw[3 * (size_t)ord[i] + 2];
             while (nd >= lvl_off[L + 1]) { L++; wl_off[L] = i; cl_off[L] = ci; }
             w_node[i] = nd; w_nc[i] = nc; w_c0[i] = ci - cl_off[L];
-            for (uint32_t at = 0; at < nc; at += FS_WIDE) { c_first[ci] = first + at; c_rows[ci] = std::min(FS_WIDE, nc - at); ci++; }
+            for (uint32_t at = 0; at < nc; at += FS_CHUNK) { c_first[ci] = first + at; c_rows[ci] = std::min(FS_CHUNK, nc - at); ci++; }
         }
         while (L < n_levels) { L++; wl_off[L] = n_wide; cl_off[L] = ci; }
         for (uint32_t l = 0; l < n_levels; l++) max_level_chunks = std::max(max_level_chunks, cl_off[l + 1] - cl_off[l]);
