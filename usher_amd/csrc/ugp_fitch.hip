@@ -539,7 +539,7 @@ struct Dev {
 
 // ---- topology on the device (round 5): the caller's breadth-first parent array is non-decreasing, so the children of a node are
 // one run of it.  k_fs_heads checks the order and flags the run heads; a stream compaction lists them (heads[k] = first child of
-// the k-th internal node); k_fs_topo turns the list into first_child / n_children / the internal nodes in index (= level) order.
+// the k-th internal node); k_fs_topo turns the list into n_children and, by the node's rank among the internal nodes (index = level order), node / first child / child count.
 // The host used to do this in three sequential passes over the 10M-entry array: 90 ms of a call whose kernels take 14.
 __global__ void k_fs_heads(const uint32_t *__restrict__ parent, uint32_t n, uint8_t *__restrict__ flag, uint32_t *__restrict__ bad) {
     const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
@@ -550,12 +550,12 @@ __global__ void k_fs_heads(const uint32_t *__restrict__ parent, uint32_t n, uint
     flag[j] = (j == 1 || p != q) ? 1 : 0;
 }
 __global__ void k_fs_topo(const uint32_t *__restrict__ parent, uint32_t n, const uint32_t *__restrict__ heads, const uint32_t *__restrict__ n_heads_p,
-                          uint32_t *__restrict__ first_child, uint32_t *__restrict__ n_children, uint32_t *__restrict__ inodes,
+                          uint32_t *__restrict__ n_children, uint32_t *__restrict__ inodes,
                           uint32_t *__restrict__ ifirst, uint32_t *__restrict__ inch, uint32_t *__restrict__ n_wide_p, uint32_t *__restrict__ wide, uint32_t wide_cap) {
     const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x, nh = *n_heads_p;
     if (k >= nh) return;
     const uint32_t j = heads[k], e = k + 1 < nh ? heads[k + 1] : n, p = parent[j];
-    first_child[p] = j; n_children[p] = e - j; inodes[k] = p;
+    n_children[p] = e - j; inodes[k] = p;
     ifirst[k] = j; inch[k] = e - j;   // (the same by the node's rank among the internal nodes: what the forward sweep indexes)
     if (e - j > FS_WIDE) {   // a polytomy: listed for k_fs_wide_* (any order; the host sorts the few there are)
         const uint32_t at = atomicAdd(n_wide_p, 1u);
@@ -577,7 +577,7 @@ __global__ void k_fs_level_ranks(const uint32_t *__restrict__ heads, const uint3
 
 struct FsPool {   // one per device, kept until the process ends: a call allocates nothing in the steady state
     std::mutex mu;
-    Dev<uint32_t> d_parent, d_first, d_nchild, d_inodes, d_heads, d_small, d_levels, d_F, d_refw, d_vnode, d_stored, d_osite, d_onode, d_ifirst, d_inch, d_desc, d_wide, d_wtab, d_part;
+    Dev<uint32_t> d_parent, d_nchild, d_inodes, d_heads, d_small, d_levels, d_F, d_refw, d_vnode, d_stored, d_osite, d_onode, d_ifirst, d_inch, d_desc, d_wide, d_wtab, d_part;
     Dev<uint8_t> d_flag, d_vnuc, d_oval, d_oval2, d_tmp, d_sel_tmp, d_opar, d_onuc, d_mark8;
     Dev<uint64_t> d_okey, d_okey2, d_voff;
     Dev<unsigned long long> d_cnt, d_segb;
@@ -601,7 +601,7 @@ extern "C" void ugp_fitch_release(int device) {
     std::lock_guard<std::mutex> g(p->mu);
     if (hipSetDevice(device) != hipSuccess) return;
     (void)hipDeviceSynchronize();
-    for (Dev<uint32_t> *d : {&p->d_parent, &p->d_first, &p->d_nchild, &p->d_inodes, &p->d_heads, &p->d_small, &p->d_levels, &p->d_F, &p->d_refw, &p->d_vnode,
+    for (Dev<uint32_t> *d : {&p->d_parent, &p->d_nchild, &p->d_inodes, &p->d_heads, &p->d_small, &p->d_levels, &p->d_F, &p->d_refw, &p->d_vnode,
                             &p->d_stored, &p->d_osite, &p->d_onode, &p->d_ifirst, &p->d_inch, &p->d_desc, &p->d_wide, &p->d_wtab, &p->d_part}) d->release();
     for (Dev<uint8_t> *d : {&p->d_flag, &p->d_vnuc, &p->d_oval, &p->d_oval2, &p->d_tmp, &p->d_sel_tmp, &p->d_opar, &p->d_onuc, &p->d_mark8}) d->release();
     for (Dev<uint64_t> *d : {&p->d_okey, &p->d_okey2, &p->d_voff}) d->release();
@@ -653,18 +653,17 @@ extern "C" int ugp_fitch_sankoff(int device, uint64_t n_nodes, const uint32_t *p
     hipStream_t stream = nullptr;
     FsPool &P = *fs_pool(device);
     std::lock_guard<std::mutex> pool_lock(P.mu);   // (calls on one device take turns: they share the pooled buffers)
-    auto &d_parent = P.d_parent; auto &d_first = P.d_first; auto &d_nchild = P.d_nchild; auto &d_inodes = P.d_inodes;
+    auto &d_parent = P.d_parent; auto &d_nchild = P.d_nchild; auto &d_inodes = P.d_inodes;
     // ---- topology, on the device: run heads of parent[] -> first child / child count / internal nodes in level order.  The level
     // boundaries themselves are a handful of binary searches in the caller's array (a level is an index range; its children are
     // the nodes whose parent lies in it), meaningful once the device has confirmed the order.
     FS_TRY(d_parent.upload(parent, N, stream));
-    FS_TRY(d_first.alloc(N)); FS_TRY(d_nchild.alloc(N)); FS_TRY(d_inodes.alloc((size_t)N + 8)); FS_TRY(P.d_heads.alloc(N)); FS_TRY(P.d_flag.alloc(N));
+    FS_TRY(d_nchild.alloc(N)); FS_TRY(d_inodes.alloc((size_t)N + 8)); FS_TRY(P.d_heads.alloc(N)); FS_TRY(P.d_flag.alloc(N));
     FS_TRY(P.d_ifirst.alloc((size_t)N + 8)); FS_TRY(P.d_inch.alloc((size_t)N + 8));   // (+8: the forward sweep reads whole groups)
     FS_TRY(P.d_small.alloc(16));   // [0] order violated, [1] run heads, [2] cell flags, [3] polytomies
     const uint32_t wide_cap = N / (FS_WIDE + 1) + 1;   // (more nodes with more than FS_WIDE children each do not fit in N)
     FS_TRY(P.d_wide.alloc(3 * (size_t)wide_cap));
     FS_TRY(hipMemsetAsync(P.d_small.p, 0, 8 * sizeof(uint32_t), stream));
-    FS_TRY(hipMemsetAsync(d_first.p, 0, (size_t)N * 4, stream));
     FS_TRY(hipMemsetAsync(d_nchild.p, 0, (size_t)N * 4, stream));
     hipLaunchKernelGGL(k_fs_heads, dim3((N + 255) / 256), dim3(256), 0, stream, d_parent.p, N, P.d_flag.p, P.d_small.p);
     {
@@ -674,7 +673,7 @@ extern "C" int ugp_fitch_sankoff(int device, uint64_t n_nodes, const uint32_t *p
         FS_TRY(P.d_sel_tmp.alloc(sel_bytes));
         FS_TRY(rocprim::select(P.d_sel_tmp.p, sel_bytes, idx, P.d_flag.p, P.d_heads.p, P.d_small.p + 1, (size_t)N, stream));
     }
-    hipLaunchKernelGGL(k_fs_topo, dim3((N + 255) / 256), dim3(256), 0, stream, d_parent.p, N, P.d_heads.p, P.d_small.p + 1, d_first.p, d_nchild.p, d_inodes.p,
+    hipLaunchKernelGGL(k_fs_topo, dim3((N + 255) / 256), dim3(256), 0, stream, d_parent.p, N, P.d_heads.p, P.d_small.p + 1, d_nchild.p, d_inodes.p,
                        P.d_ifirst.p, P.d_inch.p, P.d_small.p + 3, P.d_wide.p, wide_cap);
     std::vector<uint32_t> lvl_off{0, 1};   // nodes of level L are [lvl_off[L], lvl_off[L+1])
     while (lvl_off.back() < N) {
