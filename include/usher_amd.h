@@ -342,7 +342,7 @@ int ugp_fitch_sankoff(int device, uint64_t n_nodes, const uint32_t *parent, cons
 uint64_t ugp_fitch_count(const ugp_fitch *f);
 int ugp_fitch_get(const ugp_fitch *f, uint32_t *site, uint32_t *node, uint8_t *par_nuc /* one-hot */, uint8_t *mut_nuc /* one-hot */);
 void ugp_fitch_destroy(ugp_fitch *f);
-/* ugp_fitch_sankoff keeps its device buffers (row storage of up to 4 GiB, sort and output buffers) in a per-device pool for the next
+/* ugp_fitch_sankoff keeps its device buffers (row storage of up to 16 GiB -- half of the free HBM if that is less --, sort and output buffers) in a per-device pool for the next
  * call; ugp_fitch_release(device) frees them -- e.g. when the MAT has been built and the same device goes on to place samples. */
 void ugp_fitch_release(int device);
 
