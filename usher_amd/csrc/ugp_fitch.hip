@@ -176,7 +176,7 @@ __global__ void k_fs_scatter(uint32_t *__restrict__ F, const uint32_t *__restric
 // In breadth-first order the children of consecutive internal nodes are consecutive rows, so the group's children are ONE run of
 // rows: the wave streams it, eight row loads per batch with the next batch requested before the current one is counted, and the
 // nodes are segments of the stream -- a node is finished (the argmin over its allowed bases, one store) when its last child has
-// been counted.  Nodes with 2 children and polytomies of hundreds go through the same code at the same depth of loads in flight.
+// been counted.  Nodes with 2 children and nodes with 200 go through the same code at the same depth of loads in flight.
 // What the wave has to know first is independent SCALAR loads -- three s_load_dwordx8 from arrays indexed by the node's rank among
 // the internal nodes, one descriptor dword -- and a row that does not exist is read from row n_nodes of the table, a copy of the
 // reference word, in 32-bit address arithmetic (the caller keeps (n_nodes + 1) * W below 2^32): "no row" is a select between two
@@ -186,7 +186,7 @@ __global__ void k_fs_scatter(uint32_t *__restrict__ F, const uint32_t *__restric
 // quarters of a SARS-CoV-2-shaped one.)
 //
 // Child counts are bit-sliced (plane k = bit k of the lane's 32 (site, base) counters); KP planes count to 2^KP - 1, and a group is
-// run with 3, 5 or 32 of them by its largest node.
+// run with 3, 5 or 8 of them by its largest node (up to FS_WIDE = 255 children; larger nodes: "Polytomies" below).
 __device__ __forceinline__ uint32_t fs_pick(uint32_t cand, uint32_t plane) {   // keep the candidates whose counter has a 0 in this plane, if any
     const uint32_t z = cand & ~plane;
     const uint32_t m = nib_any(z);
