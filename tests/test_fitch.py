@@ -143,13 +143,17 @@ def test_gpu_fitch_rows_that_are_never_stored(kind, n, n_sites, p_var, p_interna
     parent = random_bfs_tree(rng, n, kind)
     ref, off, nodes, nucs = random_sites(rng, parent, n_sites, p_var=p_var, p_internal=p_internal, p_dense=2 * p_var)
     want = oracle_mutations(parent, ref, off, nodes, nucs)
-    for budget, cap in ((None, None), (str(n * 4 * 65), None), (None, "3")):
+    # one pass; passes of 512 sites; the exact listing pass; the cells uploaded in pieces of whole tiles (as large inputs are)
+    for budget, cap, pieces in ((None, None, None), (str(n * 4 * 65), None, None), (None, "3", None), (None, None, "4"), (None, None, "2")):
         monkeypatch.delenv("UGP_FITCH_BYTES", raising=False)
         monkeypatch.delenv("UGP_FITCH_EMIT_CAP", raising=False)
+        monkeypatch.delenv("UGP_FITCH_PIECES", raising=False)
         if budget:
             monkeypatch.setenv("UGP_FITCH_BYTES", budget)
         if cap:
             monkeypatch.setenv("UGP_FITCH_EMIT_CAP", cap)
+        if pieces:
+            monkeypatch.setenv("UGP_FITCH_PIECES", pieces)
         site, node, mpar, mnuc = fitch_sankoff(parent, ref, off, nodes, nucs)
         got = list(zip(site.tolist(), node.tolist(), mpar.tolist(), mnuc.tolist()))
         assert got == want

@@ -41,6 +41,9 @@ def main():
         mode = int(rng.integers(0, 4))
         os.environ.pop("UGP_FITCH_BYTES", None)
         os.environ.pop("UGP_FITCH_EMIT_CAP", None)
+        os.environ.pop("UGP_FITCH_PIECES", None)
+        if rng.random() < 0.5:
+            os.environ["UGP_FITCH_PIECES"] = str(int(rng.integers(2, 5)))   # (the upload in pieces of whole tiles, as for large inputs)
         if mode == 1:
             os.environ["UGP_FITCH_BYTES"] = str((n + 1) * 4 * int(rng.choice([1, 3, 64, 65, 130])))
         elif mode == 2:

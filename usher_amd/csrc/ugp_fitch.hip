@@ -85,10 +85,10 @@ __device__ __forceinline__ uint32_t fs_bits32(const uint32_t *__restrict__ bm, u
 // which (node, tile) items hold a cell: one BYTE per item (`mark8`, zeroed by the caller), set with a plain store -- 13.7 M
 // atomicOr on a bitmap ran at 17 per nanosecond (0.8 ms of the call); k_fs_init folds the bytes into the `stored` bitmap.
 // Cells are grouped by site; v_off[s] is the first cell of site s of this pass.
-__global__ void k_fs_mark(const uint64_t *__restrict__ v_off, uint32_t n_sites, const uint32_t *__restrict__ v_node, uint64_t n_var, uint64_t npad,
+__global__ void k_fs_mark(const uint64_t *__restrict__ v_off, uint32_t n_sites, const uint32_t *__restrict__ v_node, uint64_t c0, uint64_t c1, uint64_t npad,
                           uint32_t n_nodes, uint8_t *__restrict__ mark8) {
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_var) return;
+    const uint64_t i = c0 + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;   // (cells [c0, c1): one piece of the upload)
+    if (i >= c1) return;
     uint32_t lo = 0, hi = n_sites;   // last s with v_off[s] <= i
     while (hi - lo > 1) {
         const uint32_t mid = (lo + hi) >> 1;
@@ -103,10 +103,10 @@ __global__ void k_fs_mark(const uint64_t *__restrict__ v_off, uint32_t n_sites, 
 // consecutive nodes of one tile -- one 64-bit word of the bitmap: every lane looks up whether its node is marked / internal, then
 // the wave writes the rows of the marked ones, one row per step.
 __global__ __launch_bounds__(256) void k_fs_init(uint32_t *__restrict__ F, const uint32_t *__restrict__ refw,
-                                                 const uint32_t *__restrict__ n_children, uint32_t n_nodes, uint32_t W, uint32_t gy, uint64_t npad,
+                                                 const uint32_t *__restrict__ n_children, uint32_t n_nodes, uint32_t W, uint32_t y0, uint32_t ny, uint64_t npad,
                                                  const uint8_t *__restrict__ mark8, uint32_t *__restrict__ stored) {
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    const uint32_t y = blockIdx.x % gy, n0 = ((blockIdx.x / gy) * 4 + wave) * 64;
+    const uint32_t y = y0 + blockIdx.x % ny, n0 = ((blockIdx.x / ny) * 4 + wave) * 64;   // (tiles [y0, y0 + ny): one piece of the upload)
     if (n0 >= n_nodes) return;
     const bool mine = n0 + lane < n_nodes;
     uint64_t mb = __builtin_amdgcn_ballot_w64(mine && mark8[(uint64_t)y * npad + n0 + lane] != 0);
@@ -127,14 +127,14 @@ __global__ __launch_bounds__(256) void k_fs_init(uint32_t *__restrict__ F, const
 // per wave -- (tile, group of FS_FN internal nodes of a level; `goff` = the first group of every level), bit 4 * u for node u
 constexpr int FS_FN = 8;
 __global__ void k_fs_desc(const uint32_t *__restrict__ inodes, const uint32_t *__restrict__ ilvl_off, const uint32_t *__restrict__ goff, uint32_t n_levels,
-                          uint32_t n_groups, uint32_t gy, uint64_t npad, const uint8_t *__restrict__ mark8, uint32_t *__restrict__ desc) {
+                          uint32_t n_groups, uint32_t y0, uint32_t ny, uint64_t npad, const uint8_t *__restrict__ mark8, uint32_t *__restrict__ desc) {
     static_assert(FS_FN == 8, "eight lanes fill one descriptor");
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;   // lane = (tile, group, node of the group)
     const uint64_t ig = i >> 3;
     const uint32_t u = (uint32_t)i & 7;
     uint32_t x = 0;
-    if (ig < (uint64_t)n_groups * gy) {
-        const uint32_t y = (uint32_t)(ig / n_groups), g = (uint32_t)(ig % n_groups);
+    if (ig < (uint64_t)n_groups * ny) {
+        const uint32_t y = y0 + (uint32_t)(ig / n_groups), g = (uint32_t)(ig % n_groups);
         uint32_t lo = 0, hi = n_levels;   // last level L with goff[L] <= g
         while (hi - lo > 1) {
             const uint32_t mid = (lo + hi) >> 1;
@@ -144,16 +144,16 @@ __global__ void k_fs_desc(const uint32_t *__restrict__ inodes, const uint32_t *_
         if (k < ilvl_off[lo + 1] && mark8[(uint64_t)y * npad + inodes[k]]) x = 1u << (4 * u);
     }
     x |= __shfl_xor(x, 1); x |= __shfl_xor(x, 2); x |= __shfl_xor(x, 4);
-    if (u == 0 && ig < (uint64_t)n_groups * gy) desc[ig] = x;
+    if (u == 0 && ig < (uint64_t)n_groups * ny) desc[(uint64_t)y0 * n_groups + ig] = x;
 }
 
 // genotype cells of tree nodes: replace the initial nibble by the allele mask (:47-62).
 // Cells are grouped by site; v_off[s] is the first cell of site s of this pass.
 __global__ void k_fs_scatter(uint32_t *__restrict__ F, const uint32_t *__restrict__ refw, const uint32_t *__restrict__ n_children,
                              const uint64_t *__restrict__ v_off, uint32_t n_sites, const uint32_t *__restrict__ v_node,
-                             const uint8_t *__restrict__ v_nuc, uint64_t n_var, uint32_t W, uint32_t n_nodes, uint32_t *__restrict__ flags) {
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_var) return;
+                             const uint8_t *__restrict__ v_nuc, uint64_t c0, uint64_t c1, uint32_t W, uint32_t n_nodes, uint32_t *__restrict__ flags) {
+    const uint64_t i = c0 + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= c1) return;
     uint32_t lo = 0, hi = n_sites;   // last s with v_off[s] <= i
     while (hi - lo > 1) {
         const uint32_t mid = (lo + hi) >> 1;
@@ -575,8 +575,11 @@ __global__ void k_fs_level_ranks(const uint32_t *__restrict__ heads, const uint3
     ilvl_off[L] = lo;
 }
 
+constexpr int FS_PIECES = 4;
 struct FsPool {   // one per device, kept until the process ends: a call allocates nothing in the steady state
     std::mutex mu;
+    hipStream_t copy = nullptr;          // the caller's cells go up on a stream of their own, in pieces (see the per-pass preparation)
+    hipEvent_t up[FS_PIECES] = {};
     Dev<uint32_t> d_parent, d_nchild, d_inodes, d_heads, d_small, d_levels, d_F, d_refw, d_vnode, d_stored, d_osite, d_onode, d_ifirst, d_inch, d_desc, d_wide, d_wtab, d_part;
     Dev<uint8_t> d_flag, d_vnuc, d_oval, d_oval2, d_tmp, d_sel_tmp, d_opar, d_onuc, d_mark8;
     Dev<uint64_t> d_okey, d_okey2, d_voff;
@@ -809,19 +812,39 @@ extern "C" int ugp_fitch_sankoff(int device, uint64_t n_nodes, const uint32_t *p
             FS_TRY(hipMemcpyAsync(d_refw.p, refw.data(), (size_t)W * 4, hipMemcpyHostToDevice, stream));
             FS_TRY(hipMemcpyAsync(d_F.p + (size_t)N * W, refw.data(), (size_t)W * 4, hipMemcpyHostToDevice, stream));   // (row N: what a missing row reads as)
             FS_TRY(d_voff.upload(voff.data(), voff.size(), stream));
-            FS_TRY(d_vnode.upload(cell_node, n_cells, stream));
-            FS_TRY(d_vnuc.upload(cell_nuc, n_cells, stream));
-            // (round 6) only the (node, tile) items that hold a cell get a row: mark them, initialise those, then drop the cells in
+            FS_TRY(d_vnode.alloc(n_cells)); FS_TRY(d_vnuc.alloc(n_cells));
             FS_TRY(hipMemsetAsync(P.d_mark8.p, 0, (size_t)npad * gy, stream));
-            if (n_cells)
-                hipLaunchKernelGGL(k_fs_mark, dim3((unsigned)((n_cells + 255) / 256)), dim3(256), 0, stream, d_voff.p, n_s, d_vnode.p, n_cells, npad, N,
-                                   P.d_mark8.p);
-            hipLaunchKernelGGL(k_fs_init, grid(N, 64), dim3(256), 0, stream, d_F.p, d_refw.p, d_nchild.p, N, W, gy, npad, P.d_mark8.p, P.d_stored.p);
-            if (n_groups)
-                hipLaunchKernelGGL(k_fs_desc, dim3((unsigned)(((uint64_t)n_groups * gy * FS_FN + 255) / 256)), dim3(256), 0, stream, d_inodes.p, d_ilvl,
-                                   d_goff, n_levels, n_groups, gy, npad, P.d_mark8.p, P.d_desc.p);
-            FS_TRY(hipMemsetAsync(d_cnt.p, 0, ((size_t)FS_SEG * 8 + 8) * sizeof(unsigned long long), stream));
             FS_TRY(hipMemsetAsync(P.d_small.p + 2, 0, 4, stream));
+            // (round 6) Only the (node, tile) items that hold a cell get a row: mark them, initialise those, then drop the cells in.  The
+            // cells are grouped by site, i.e. by tile: they go up in pieces of whole tiles on a stream of their own, and the kernels of a
+            // piece run while the next piece crosses PCIe (68 MB from pageable memory are 1.3 ms, the kernels 1.7).
+            if (!P.copy) {
+                FS_TRY(hipStreamCreateWithFlags(&P.copy, hipStreamNonBlocking));
+                for (int k = 0; k < FS_PIECES; k++) FS_TRY(hipEventCreateWithFlags(&P.up[k], hipEventDisableTiming));
+            }
+            uint32_t n_piece = (n_cells >= (1u << 20) && gy >= 2) ? std::min<uint32_t>(gy, FS_PIECES) : 1u;
+            if (const char *e = getenv("UGP_FITCH_PIECES")) n_piece = (uint32_t)std::max(1, std::min<int>(atoi(e), (int)std::min<uint32_t>(gy, FS_PIECES)));   // (tests: small inputs in pieces)
+            for (uint32_t k = 0; k < n_piece; k++) {
+                const uint32_t y0 = (uint32_t)((uint64_t)gy * k / n_piece), y1 = (uint32_t)((uint64_t)gy * (k + 1) / n_piece), ny = y1 - y0;
+                const uint64_t c0 = voff[std::min<uint64_t>((uint64_t)y0 * 512, n_s)], c1 = voff[std::min<uint64_t>((uint64_t)y1 * 512, n_s)];
+                if (c1 > c0) {
+                    FS_TRY(hipMemcpyAsync(d_vnode.p + c0, cell_node + c0, (c1 - c0) * 4, hipMemcpyHostToDevice, P.copy));
+                    FS_TRY(hipMemcpyAsync(d_vnuc.p + c0, cell_nuc + c0, c1 - c0, hipMemcpyHostToDevice, P.copy));
+                    FS_TRY(hipEventRecord(P.up[k], P.copy));
+                    FS_TRY(hipStreamWaitEvent(stream, P.up[k], 0));
+                    hipLaunchKernelGGL(k_fs_mark, dim3((unsigned)((c1 - c0 + 255) / 256)), dim3(256), 0, stream, d_voff.p, n_s, d_vnode.p, c0, c1, npad, N,
+                                       P.d_mark8.p);
+                }
+                hipLaunchKernelGGL(k_fs_init, dim3((unsigned)(((uint64_t)N + 255) / 256 * ny)), dim3(256), 0, stream, d_F.p, d_refw.p, d_nchild.p, N, W, y0, ny,
+                                   npad, P.d_mark8.p, P.d_stored.p);
+                if (n_groups)
+                    hipLaunchKernelGGL(k_fs_desc, dim3((unsigned)(((uint64_t)n_groups * ny * FS_FN + 255) / 256)), dim3(256), 0, stream, d_inodes.p, d_ilvl,
+                                       d_goff, n_levels, n_groups, y0, ny, npad, P.d_mark8.p, P.d_desc.p);
+                if (c1 > c0)
+                    hipLaunchKernelGGL(k_fs_scatter, dim3((unsigned)((c1 - c0 + 255) / 256)), dim3(256), 0, stream, d_F.p, d_refw.p, d_nchild.p, d_voff.p, n_s,
+                                       d_vnode.p, d_vnuc.p, c0, c1, W, N, P.d_small.p + 2);
+            }
+            FS_TRY(hipMemsetAsync(d_cnt.p, 0, ((size_t)FS_SEG * 8 + 8) * sizeof(unsigned long long), stream));
             // room for the listed changes: without cells on internal nodes a site has at most (cells + 1) of
             // them, and usually far fewer; anything beyond the guess is handled by the exact pass below
             seg_cap = (n_cells + n_s) / FS_SEG * 3 / 2 + 256;
@@ -830,8 +853,6 @@ extern "C" int ugp_fitch_sankoff(int device, uint64_t n_nodes, const uint32_t *p
             FS_TRY(d_oval.alloc(seg_cap * FS_SEG));
             uint32_t cell_flags = 0;
             if (n_cells) {
-                hipLaunchKernelGGL(k_fs_scatter, dim3((unsigned)((n_cells + 255) / 256)), dim3(256), 0, stream, d_F.p, d_refw.p, d_nchild.p,
-                                   d_voff.p, n_s, d_vnode.p, d_vnuc.p, n_cells, W, N, P.d_small.p + 2);
                 FS_TRY(hipMemcpyAsync(&cell_flags, P.d_small.p + 2, 4, hipMemcpyDeviceToHost, stream));
                 FS_TRY(hipStreamSynchronize(stream));   // (the upload buffers of the caller may be reused / the verdict is needed)
             }
