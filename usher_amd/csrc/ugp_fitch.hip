@@ -202,6 +202,10 @@ constexpr uint32_t FS_WIDE = 255, FS_CHUNK = 64;   // (a chunk: 8 batches of loa
 
 // one run of rows [row0, row0 + n_rows) = the children of the nodes at the head of the queue (pp / ncs / dd: node, child count,
 // own-row bit; a node is popped when its last child has been counted)
+#ifndef UGP_FS_B
+#define UGP_FS_B 8
+#endif
+constexpr int FS_B = UGP_FS_B;   // rows per batch of the forward stream (8 or 16: the bitmap window is 32 bits; 16 measured: both sweeps' kernels 6.0 -> 6.5 ms)
 template <int KP>
 __device__ __forceinline__ void fs_stream(uint32_t *__restrict__ F, uint32_t w, uint32_t W, uint32_t ref_row, uint32_t (&pp)[FS_FN],
                                           uint32_t (&ncs)[FS_FN], uint32_t &dd, uint32_t row0, uint32_t n_rows,
@@ -209,26 +213,28 @@ __device__ __forceinline__ void fs_stream(uint32_t *__restrict__ F, uint32_t w, 
     uint32_t plane[KP];
 #pragma unroll
     for (int k = 0; k < KP; k++) plane[k] = 0;
-    uint32_t xa[8], xb[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    uint32_t rem = ncs[0];
-    uint32_t have = fs_bits32(stored, bbase), have_next = fs_bits32(stored, bbase + 8);
+    uint32_t xa[FS_B], xb[FS_B];
 #pragma unroll
-    for (int j = 0; j < 8; j++) {
+    for (int j = 0; j < FS_B; j++) xb[j] = 0;
+    uint32_t rem = ncs[0];
+    uint32_t have = fs_bits32(stored, bbase), have_next = fs_bits32(stored, bbase + FS_B);
+#pragma unroll
+    for (int j = 0; j < FS_B; j++) {
         const uint32_t r = ((uint32_t)j < n_rows && ((have >> j) & 1u)) ? row0 + j : ref_row;
         xa[j] = F[r * W + w];
     }
 #pragma nounroll
-    for (uint32_t i = 0; i < n_rows; i += 8) {
-        const uint32_t have_after = fs_bits32(stored, bbase + i + 16);   // (for the batch after the next: a round trip ahead of its use)
-        if (i + 8 < n_rows) {
+    for (uint32_t i = 0; i < n_rows; i += FS_B) {
+        const uint32_t have_after = fs_bits32(stored, bbase + i + 2 * FS_B);   // (for the batch after the next: a round trip ahead of its use)
+        if (i + FS_B < n_rows) {
 #pragma unroll
-            for (int j = 0; j < 8; j++) {
-                const uint32_t r = (i + 8 + j < n_rows && ((have_next >> j) & 1u)) ? row0 + i + 8 + j : ref_row;
+            for (int j = 0; j < FS_B; j++) {
+                const uint32_t r = (i + FS_B + j < n_rows && ((have_next >> j) & 1u)) ? row0 + i + FS_B + j : ref_row;
                 xb[j] = F[r * W + w];
             }
         }
 #pragma unroll
-        for (int j = 0; j < 8; j++) {
+        for (int j = 0; j < FS_B; j++) {
             if (i + j >= n_rows) break;
             uint32_t carry = ~xa[j];   // +1 for every (site, base) with base not in F_c
 #pragma unroll
@@ -254,7 +260,7 @@ __device__ __forceinline__ void fs_stream(uint32_t *__restrict__ F, uint32_t w, 
             }
         }
 #pragma unroll
-        for (int j = 0; j < 8; j++) xa[j] = xb[j];
+        for (int j = 0; j < FS_B; j++) xa[j] = xb[j];
         have_next = have_after;
     }
 }
