@@ -584,8 +584,18 @@ __global__ void k_fs_level_ranks(const uint32_t *__restrict__ heads, const uint3
 constexpr int FS_PIECES = 4;
 struct FsPool {   // one per device, kept until the process ends: a call allocates nothing in the steady state
     std::mutex mu;
-    hipStream_t copy = nullptr;          // the caller's cells go up on a stream of their own, in pieces (see the per-pass preparation)
+    // The caller's cells go up on a stream of their own, in pieces (see the per-pass preparation).  The stream lives for ONE call: a
+    // process has four hardware queues by default, and an idle stream that stays around shifts the queues of every stream made after
+    // it -- a placement handle's third set would share one with the caller's stream ("side stream").
+    hipStream_t copy = nullptr;
     hipEvent_t up[FS_PIECES] = {};
+    void drop_copy_stream() {
+        if (!copy) return;
+        (void)hipStreamSynchronize(copy);
+        for (int k = 0; k < FS_PIECES; k++) if (up[k]) { (void)hipEventDestroy(up[k]); up[k] = nullptr; }
+        (void)hipStreamDestroy(copy);
+        copy = nullptr;
+    }
     Dev<uint32_t> d_parent, d_nchild, d_inodes, d_heads, d_small, d_levels, d_F, d_refw, d_vnode, d_stored, d_osite, d_onode, d_ifirst, d_inch, d_desc, d_wide, d_wtab, d_part;
     Dev<uint8_t> d_flag, d_vnuc, d_oval, d_oval2, d_tmp, d_sel_tmp, d_opar, d_onuc, d_mark8;
     Dev<uint64_t> d_okey, d_okey2, d_voff;
@@ -662,6 +672,7 @@ extern "C" int ugp_fitch_sankoff(int device, uint64_t n_nodes, const uint32_t *p
     hipStream_t stream = nullptr;
     FsPool &P = *fs_pool(device);
     std::lock_guard<std::mutex> pool_lock(P.mu);   // (calls on one device take turns: they share the pooled buffers)
+    struct CopyGuard { FsPool &p; ~CopyGuard() { p.drop_copy_stream(); } } copy_guard{P};
     auto &d_parent = P.d_parent; auto &d_nchild = P.d_nchild; auto &d_inodes = P.d_inodes;
     // ---- topology, on the device: run heads of parent[] -> first child / child count / internal nodes in level order.  The level
     // boundaries themselves are a handful of binary searches in the caller's array (a level is an index range; its children are
@@ -824,20 +835,23 @@ extern "C" int ugp_fitch_sankoff(int device, uint64_t n_nodes, const uint32_t *p
             // (round 6) Only the (node, tile) items that hold a cell get a row: mark them, initialise those, then drop the cells in.  The
             // cells are grouped by site, i.e. by tile: they go up in pieces of whole tiles on a stream of their own, and the kernels of a
             // piece run while the next piece crosses PCIe (68 MB from pageable memory are 1.3 ms, the kernels 1.7).
-            if (!P.copy) {
+            uint32_t n_piece = (n_cells >= (1u << 20) && gy >= 2) ? std::min<uint32_t>(gy, FS_PIECES) : 1u;
+            if (const char *e = getenv("UGP_FITCH_PIECES")) n_piece = (uint32_t)std::max(1, std::min<int>(atoi(e), (int)std::min<uint32_t>(gy, FS_PIECES)));   // (tests: small inputs in pieces)
+            if (n_piece > 1 && !P.copy) {
                 FS_TRY(hipStreamCreateWithFlags(&P.copy, hipStreamNonBlocking));
                 for (int k = 0; k < FS_PIECES; k++) FS_TRY(hipEventCreateWithFlags(&P.up[k], hipEventDisableTiming));
             }
-            uint32_t n_piece = (n_cells >= (1u << 20) && gy >= 2) ? std::min<uint32_t>(gy, FS_PIECES) : 1u;
-            if (const char *e = getenv("UGP_FITCH_PIECES")) n_piece = (uint32_t)std::max(1, std::min<int>(atoi(e), (int)std::min<uint32_t>(gy, FS_PIECES)));   // (tests: small inputs in pieces)
             for (uint32_t k = 0; k < n_piece; k++) {
                 const uint32_t y0 = (uint32_t)((uint64_t)gy * k / n_piece), y1 = (uint32_t)((uint64_t)gy * (k + 1) / n_piece), ny = y1 - y0;
                 const uint64_t c0 = voff[std::min<uint64_t>((uint64_t)y0 * 512, n_s)], c1 = voff[std::min<uint64_t>((uint64_t)y1 * 512, n_s)];
                 if (c1 > c0) {
-                    FS_TRY(hipMemcpyAsync(d_vnode.p + c0, cell_node + c0, (c1 - c0) * 4, hipMemcpyHostToDevice, P.copy));
-                    FS_TRY(hipMemcpyAsync(d_vnuc.p + c0, cell_nuc + c0, c1 - c0, hipMemcpyHostToDevice, P.copy));
-                    FS_TRY(hipEventRecord(P.up[k], P.copy));
-                    FS_TRY(hipStreamWaitEvent(stream, P.up[k], 0));
+                    hipStream_t up_on = n_piece > 1 ? P.copy : stream;
+                    FS_TRY(hipMemcpyAsync(d_vnode.p + c0, cell_node + c0, (c1 - c0) * 4, hipMemcpyHostToDevice, up_on));
+                    FS_TRY(hipMemcpyAsync(d_vnuc.p + c0, cell_nuc + c0, c1 - c0, hipMemcpyHostToDevice, up_on));
+                    if (n_piece > 1) {
+                        FS_TRY(hipEventRecord(P.up[k], P.copy));
+                        FS_TRY(hipStreamWaitEvent(stream, P.up[k], 0));
+                    }
                     hipLaunchKernelGGL(k_fs_mark, dim3((unsigned)((c1 - c0 + 255) / 256)), dim3(256), 0, stream, d_voff.p, n_s, d_vnode.p, c0, c1, npad, N,
                                        P.d_mark8.p);
                 }
