@@ -250,6 +250,18 @@ def test_second_handle_of_a_process_keeps_its_overlap(big, monkeypatch):
     sets = [st.queries(16384, seed=4242 + r) for r in range(3)]
     rates, answers = [], []
     for which in range(2):
+        if which == 1:
+            # ... and a Fitch-Sankoff call in between, whose upload stream (cells in pieces) is pooled: the library drops it when the next
+            # handle is about to make its streams (ugp::fitch_drop_streams) -- an idle stream would shift their hardware queues
+            from usher_amd.fitch import fitch_sankoff
+            monkeypatch.setenv("UGP_FITCH_PIECES", "2")
+            par = np.concatenate([[-1], (np.arange(1, 600) - 1) // 2]).astype(np.int64)
+            leaves = np.arange(300, 600, dtype=np.uint32)
+            off = np.arange(0, 1201).astype(np.uint64) * 2   # (1 200 sites = three tiles, two cells each)
+            cells = np.tile(leaves[:2], 1200)
+            site, node, _, _ = fitch_sankoff(par, np.full(1200, 1, np.uint8), off, cells, np.full(len(cells), 2, np.uint8))
+            assert len(site) > 0
+            monkeypatch.delenv("UGP_FITCH_PIECES")
         pl = Placer(st.arrays)
         hq = [pl.upload(_batch(q)) for q in sets]
         dd = pl.pipeline_depth()

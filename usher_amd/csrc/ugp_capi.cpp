@@ -306,6 +306,7 @@ struct ugp_qset {
     std::vector<uint64_t> ent_off;   // host copy, for sub-batching
 };
 
+namespace ugp { void fitch_drop_streams(int device); }   // ugp_fitch.hip
 namespace {
 
 uint32_t pick_groups(const ugp_mat *m, uint32_t n_tiles, uint32_t target_waves = 4096) {
@@ -1463,7 +1464,7 @@ int ugp_place_device_overlapped(ugp_mat *m, ugp_qset *qs, void *d_out, void *str
     const int wi = m->next_work % use;
     m->next_work = (wi + 1) % use;
     ugp_mat::Work &W = m->work[wi];
-    if (!W.stream) HIP_TRY(hipStreamCreateWithFlags(&W.stream, hipStreamNonBlocking));
+    if (!W.stream) { ugp::fitch_drop_streams(m->device); HIP_TRY(hipStreamCreateWithFlags(&W.stream, hipStreamNonBlocking)); }   // (the Fitch-Sankoff pool's idle upload stream would shift this one's hardware queue)
     note_sharing(m, wi, use);
     struct Unshare { ugp_mat *m; ~Unshare() { m->sharing = false; m->share_n = 1; } } unshare{m};
     // What was on the caller's stream when this call was made (a ring of events by call number) is waited for by the call
@@ -1506,7 +1507,7 @@ int ugp_place_batch_async(ugp_mat *m, const ugp_queries *q, ugp_result *out, ugp
     if (wi < 0) return fail(UGP_ERR_INVALID, "as many jobs as the handle keeps in flight (ugp_pipeline_depth; two for long batches) are outstanding: ugp_job_wait the oldest first");
     ugp_mat::Work &W = m->work[wi];
     if (W.job_busy) return fail(UGP_ERR_INVALID, "as many jobs as the handle keeps in flight (ugp_pipeline_depth) are outstanding: ugp_job_wait the oldest first");
-    if (!W.stream) HIP_TRY(hipStreamCreateWithFlags(&W.stream, hipStreamNonBlocking));
+    if (!W.stream) { ugp::fitch_drop_streams(m->device); HIP_TRY(hipStreamCreateWithFlags(&W.stream, hipStreamNonBlocking)); }   // (the Fitch-Sankoff pool's idle upload stream would shift this one's hardware queue)
     if (!W.job_qs) { W.job_qs = new (std::nothrow) ugp_qset(); if (!W.job_qs) return fail(UGP_ERR_NOMEM, "out of host memory"); }
     // the previous use of this set (a job two calls ago, or any other entry point) has to be over before its staging is overwritten
     if (W.done) HIP_TRY(hipEventSynchronize(W.done));

@@ -584,9 +584,10 @@ __global__ void k_fs_level_ranks(const uint32_t *__restrict__ heads, const uint3
 constexpr int FS_PIECES = 4;
 struct FsPool {   // one per device, kept until the process ends: a call allocates nothing in the steady state
     std::mutex mu;
-    // The caller's cells go up on a stream of their own, in pieces (see the per-pass preparation).  The stream lives for ONE call: a
-    // process has four hardware queues by default, and an idle stream that stays around shifts the queues of every stream made after
-    // it -- a placement handle's third set would share one with the caller's stream ("side stream").
+    // The caller's cells go up on a stream of their own, in pieces (see the per-pass preparation).  A process has four hardware queues
+    // by default, and a stream that stays around shifts the queues of every stream made after it ("side stream"): this one
+    // is kept from call to call (making and destroying it costs 0.35 ms of a 10 ms call) but dropped by ugp_fitch_release and whenever
+    // a placement handle of the device is about to make its own streams (ugp::fitch_drop_streams, from ugp_capi.cpp).
     hipStream_t copy = nullptr;
     hipEvent_t up[FS_PIECES] = {};
     void drop_copy_stream() {
@@ -614,12 +615,22 @@ FsPool *fs_pool(int device) {
 
 // the pool keeps up to 4 GiB of row storage and the sort buffers per device for the next call; a caller that is done
 // building (the front end behind `-t`, before it places samples on the same device) hands them back.
+namespace ugp {
+void fitch_drop_streams(int device) {
+    if (device < 0) return;
+    FsPool *p = fs_pool(device);
+    std::lock_guard<std::mutex> g(p->mu);
+    if (p->copy && hipSetDevice(device) == hipSuccess) p->drop_copy_stream();
+}
+}  // namespace ugp
+
 extern "C" void ugp_fitch_release(int device) {
     if (device < 0) return;
     FsPool *p = fs_pool(device);
     std::lock_guard<std::mutex> g(p->mu);
     if (hipSetDevice(device) != hipSuccess) return;
     (void)hipDeviceSynchronize();
+    p->drop_copy_stream();
     for (Dev<uint32_t> *d : {&p->d_parent, &p->d_nchild, &p->d_inodes, &p->d_heads, &p->d_small, &p->d_levels, &p->d_F, &p->d_refw, &p->d_vnode,
                             &p->d_stored, &p->d_osite, &p->d_onode, &p->d_ifirst, &p->d_inch, &p->d_desc, &p->d_wide, &p->d_wtab, &p->d_part}) d->release();
     for (Dev<uint8_t> *d : {&p->d_flag, &p->d_vnuc, &p->d_oval, &p->d_oval2, &p->d_tmp, &p->d_sel_tmp, &p->d_opar, &p->d_onuc, &p->d_mark8}) d->release();
@@ -672,7 +683,6 @@ extern "C" int ugp_fitch_sankoff(int device, uint64_t n_nodes, const uint32_t *p
     hipStream_t stream = nullptr;
     FsPool &P = *fs_pool(device);
     std::lock_guard<std::mutex> pool_lock(P.mu);   // (calls on one device take turns: they share the pooled buffers)
-    struct CopyGuard { FsPool &p; ~CopyGuard() { p.drop_copy_stream(); } } copy_guard{P};
     auto &d_parent = P.d_parent; auto &d_nchild = P.d_nchild; auto &d_inodes = P.d_inodes;
     // ---- topology, on the device: run heads of parent[] -> first child / child count / internal nodes in level order.  The level
     // boundaries themselves are a handful of binary searches in the caller's array (a level is an index range; its children are
